@@ -1,0 +1,140 @@
+"""Pin the CPU oracle against golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU only.
+
+Tolerances: quantities that go through the reference's bmm-form squared distance
+(contact.py:27-42) carry ~1e-7*|x|^2 of BLAS-order noise -> absolute 1e-6; everything
+else is float32 round-off of identical formulas -> 1e-5 absolute / 1e-5 relative.
+"""
+import numpy as np
+import pytest
+
+import golden_io as gio
+from helpers import assert_close, golden, golden_mask, oracle_segments, region_pair_lists
+from oracle import contact as oc
+
+TAGS = ['small', 'medium']
+
+
+def test_pairwise_dense():
+    g = golden('small')
+    p = oc.pairwise_sq(g['verts'][0], g['verts'][0])
+    assert_close(p, g['pairwise_b0'], 0, 1e-6, 'pairwise')
+    assert np.all(np.diag(p) == 0)
+
+
+@pytest.mark.parametrize('tag', TAGS + ['full'])
+def test_v2v_min_masked(tag):
+    g, gm = golden(tag), golden_mask(tag)
+    for b in range(g['verts'].shape[0]):
+        mn, arg = oc.v2v_min_masked(g['verts'][b], gm)
+        assert_close(mn, g['v2v_min'][b], 0, 1e-6, 'v2v min')
+        same = arg == g['v2v_argmin'][b]
+        assert same.mean() > 0.99
+        # where the argmin differs the two candidates must be tied within bmm noise
+        v = g['verts'][b].astype(np.float64)
+        d_ours = ((v - v[arg]) ** 2).sum(1)
+        d_ref = ((v - v[g['v2v_argmin'][b]]) ** 2).sum(1)
+        assert np.all(np.abs(d_ours - d_ref)[~same] < 2e-6)
+
+
+def test_solid_angles_dense():
+    g = golden('small')
+    sa = oc.solid_angles(g['verts'][0], oc.gather_tris(g['verts'][0], g['faces']))
+    assert_close(sa, g['solid_angles_b0'], 1e-5, 1e-5, 'solid angles')
+
+
+@pytest.mark.parametrize('tag', TAGS + ['full'])
+def test_winding(tag):
+    g = golden(tag)
+    for b in range(g['verts'].shape[0]):
+        w = oc.winding_numbers(g['verts'][b], oc.gather_tris(g['verts'][b], g['faces']))
+        # float32 round-off of identical formulas; an ill-conditioned (query almost in the
+        # plane of a nearby triangle) term may move a single vertex by a few 1e-5
+        err = np.abs(w - g['winding'][b])
+        assert np.percentile(err, 99.9) < 5e-6
+        assert_close(w, g['winding'][b], 0, 2e-4, 'winding')
+        clear = np.abs(g['winding'][b] - 0.99) > 1e-4
+        assert np.array_equal((w <= 0.99)[clear], (g['winding'][b] <= 0.99)[clear])
+
+
+@pytest.mark.parametrize('tag', TAGS + ['full'])
+def test_segments(tag):
+    g = golden(tag)
+    segs = oracle_segments(g)
+    if 'segment_faces_flat' in g:
+        for s, f in zip(segs, gio.unpack_ragged('segment_faces', g)):
+            assert np.array_equal(s.faces.ravel(), f)
+    for b in range(g['verts'].shape[0]):
+        ext = np.concatenate([s.exterior(g['verts'][b]) for s in segs])
+        want = g['segment_exterior'][b].astype(bool)
+        assert (ext != want).sum() <= 1   # a flag may sit within 1e-6 of the 0.99 threshold
+
+
+def _smplify_total(g, gm, segs, eucl):
+    b_count, v_count = g['verts'].shape[:2]
+    clw = float(g['contact_loss_weight'])
+    has_dc = g['has_discrete_contact'] if 'has_discrete_contact' in g else np.ones(b_count, bool)
+    total, grad = 0.0, np.zeros((b_count, v_count, 3))
+    for b in range(b_count):
+        rp = region_pair_lists(g, b) if has_dc[b] else None
+        r = oc.smplify_contact_body(g['verts'][b], g['faces'], gm, eucl, segs, rp)
+        total += 10 * r['contact'] + clw * r['r2r']            # losses.py:120
+        grad[b] = 10 * r['grad_contact'] + clw * r['grad_r2r']
+    return total, grad
+
+
+@pytest.mark.parametrize('tag', TAGS)
+@pytest.mark.parametrize('eu', ['e0', 'e2'])
+@pytest.mark.parametrize('sg', ['nos', 'seg'])
+def test_smplify_contact_loss(tag, eu, sg):
+    g, gm = golden(tag), golden_mask(tag)
+    eucl = 0.0 if eu == 'e0' else float(g['euclthres'])
+    total, grad = _smplify_total(g, gm, oracle_segments(g) if sg == 'seg' else None, eucl)
+    key = 'smplify_%s_%s_contact' % (eu, sg)
+    assert_close(total, g[key + '_loss'], 1e-5, 0, key)
+    scale = np.abs(g[key + '_grad_verts']).max()
+    assert_close(grad, g[key + '_grad_verts'], 1e-4, 1e-6 * scale, key + ' grad')
+
+
+@pytest.mark.parametrize('eu', ['e0', 'e2'])
+def test_smplify_contact_loss_fullsize(eu):
+    g, gm = golden('full'), golden_mask('full')
+    eucl = 0.0 if eu == 'e0' else float(g['euclthres'])
+    total, grad = _smplify_total(g, gm, oracle_segments(g), eucl)
+    key = 'smplify_%s_seg_contact' % eu
+    assert_close(total, g[key + '_loss'], 1e-5, 0, key)
+    scale = np.abs(g[key + '_grad_verts']).max()
+    assert_close(grad, g[key + '_grad_verts'], 1e-4, 1e-6 * scale, key + ' grad')
+
+
+@pytest.mark.parametrize('tag', TAGS)
+@pytest.mark.parametrize('use_hd', [False, True])
+def test_train_contact_loss(tag, use_hd):
+    g, gm = golden(tag), golden_mask(tag)
+    loss, grad, _ = oc.train_contact_loss(
+        g['verts'], g['valid_fit'], g['faces'], gm, float(g['euclthres']), oracle_segments(g),
+        use_hd, hd_idx=g['hd_idx'], hd_w=g['hd_w'], hd_face=g['hd_face'])
+    key = 'train_hd' if use_hd else 'train_plain'
+    assert_close(loss, g[key + '_loss'], 1e-5, 0, key)
+    scale = np.abs(g[key + '_grad_verts']).max()
+    assert_close(grad, g[key + '_grad_verts'], 1e-4, 2e-6 * scale, key + ' grad')
+
+
+@pytest.mark.parametrize('tag', TAGS)
+def test_contact_from_verts(tag):
+    g = golden(tag)
+    regions, pairs = gio.unpack_regions(g)
+    pc = oc.contact_from_verts(g['verts'], regions, pairs)
+    assert_close(pc, g['contact_from_verts'], 0, 1e-6, 'contact_from_verts')
+
+
+def test_known_answers_tetrahedron():
+    """Math KAT: winding number of a closed mesh is 1 inside, 0 outside."""
+    v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32)
+    f = np.array([[0, 2, 1], [0, 1, 3], [0, 3, 2], [1, 2, 3]], np.int64)
+    pts = np.array([[0.1, 0.1, 0.1], [2, 2, 2], [0.2, 0.3, 0.1]], np.float32)
+    w = oc.winding_numbers(pts, oc.gather_tris(v, f))
+    assert_close(w, [1, 0, 1], 0, 1e-6, 'tetra')
+    # on a vertex: incident faces contribute atan2(0,0)=0
+    w0 = oc.winding_numbers(v[:1], oc.gather_tris(v, f))
+    assert np.isfinite(w0).all()
