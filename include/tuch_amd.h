@@ -1,0 +1,127 @@
+/*
+ * libtuch_amd -- MI355X (gfx950) implementation of TUCH's self-contact path.
+ *
+ * C ABI: plain device pointers and sizes, one HIP stream per call, no torch types.
+ * The reference (muelea/tuch) is pure Python with no FFI layer; every entry point
+ * below replaces the reference function(s) cited next to it and is what a binding
+ * for that function would call (INTEGRATION.md shows the ctypes stubs).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless marked "host"; float = IEEE binary32;
+ *     tensors are dense row-major with the shape given in the comment
+ *   - return 0 on success, negative on failure; tuch_last_error() describes the last
+ *     failure on the calling thread; nothing is thrown across the ABI
+ *   - hot calls never allocate, never synchronise and are hipGraph-capturable; scratch
+ *     memory is passed in by the caller (size from the matching *_workspace_bytes)
+ *   - `stream` is a hipStream_t (NULL = default stream)
+ *   - results are deterministic (fixed reduction order); only gradient scatters use
+ *     float atomics
+ */
+#ifndef TUCH_AMD_H
+#define TUCH_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* tuch_last_error(void);
+int tuch_abi_version(void);
+
+/* ---- tuch/utils/contact.py ------------------------------------------------------- */
+
+/* batch_pairwise_dist(x, y, use_cuda, squared), contact.py:23-47.
+ * x [B,Nx,3], y [B,Ny,3] -> P [B,Nx,Ny] = |x|^2 + |y|^2 - 2 x.y (sqrt of it if !squared).
+ * Materialising form kept for API parity; the hot path uses tuch_v2v_min_masked. */
+int tuch_batch_pairwise_dist(const float* x, const float* y, int B, int Nx, int Ny, int squared,
+                             float* P, void* stream);
+
+/* solid_angles(points, triangles, thresh), contact.py:49-109.
+ * points [B,Q,3], triangles [B,F,3,3] -> out [B,Q,F] = 2*atan2(num, den). */
+int tuch_solid_angles(const float* points, const float* triangles, int B, int Q, int F, float* out,
+                      void* stream);
+
+/* winding_numbers(points, triangles, thresh), contact.py:112-147, fused with the callers'
+ * `.le(0.99)` (losses.py:82, loss.py:262,297).  w [B,Q] and/or exterior [B,Q] (1 = w <= thresh);
+ * either output may be NULL.  Never materialises anything of size QxF. */
+size_t tuch_winding_workspace_bytes(int B, int Q, int F);
+int tuch_winding_numbers(const float* points, const float* triangles, int B, int Q, int F, float* w,
+                         uint8_t* exterior, float exterior_thresh, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
+/* triangles = verts[b][face_tensor[0]], losses.py:81 / loss.py:260.
+ * verts [B,V,3], faces [F,3] int32 -> triangles [B,F,3,3]. */
+int tuch_gather_triangles(const float* verts, const int32_t* faces, int B, int V, int F,
+                          float* triangles, void* stream);
+
+/* ---- masked nearest vertex: losses.py:76-78,92-93 / loss.py:255-257,269-270 -------- */
+
+/* geomask (geod > geothres, smplifydc.py:65 / loss.py:71) as bits: word [w][j] holds
+ * columns 64w..64w+63 of row j; tuch_geomask_words(V) words per row set (even, zero padded). */
+int tuch_geomask_words(int V);
+size_t tuch_geomask_bits_bytes(int V);
+int tuch_pack_geomask(const uint8_t* geomask /* [V,V] bytes */, int V, uint64_t* bits, void* stream);
+
+/* For every column i: min / argmin over rows j with geomask[j][i] of |v_i - v_j|^2
+ * (first index on ties, all-masked -> (inf, 0), as torch.min / torch.argmin).
+ * points [B,N,3], bits from tuch_pack_geomask or a model -> min_d2 [B,N], argmin [B,N] int32. */
+size_t tuch_v2v_workspace_bytes(int B, int N);
+int tuch_v2v_min_masked(const float* points, const uint64_t* geomask_bits, int B, int N, float* min_d2,
+                        int32_t* argmin, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- pull/push terms: losses.py:96-105 (mode 0) / loss.py:303-315 (mode 1) ---------- */
+
+/* terms [B,2] = (sum over interior, sum over exterior) of weight*tanh(d/scale)^2 with
+ * d_i = |x_i - x_partner(i)|; body_valid [B] bytes or NULL (invalid bodies give 0). */
+int tuch_contact_terms_fwd(const float* points, const int32_t* partner, const uint8_t* exterior,
+                           const uint8_t* body_valid, int B, int N, int mode, float euclthres,
+                           float* terms, void* stream);
+/* grad_points [B,N,3] += d(terms)/d(points) . grad_scale [B,2]; grad_points zeroed by the caller. */
+int tuch_contact_terms_bwd(const float* points, const int32_t* partner, const uint8_t* exterior,
+                           const float* grad_scale, int B, int N, int mode, float euclthres,
+                           float* grad_points, void* stream);
+
+/* ---- per-model constants -------------------------------------------------------------
+ * Host tables in, device copies kept by the handle.  Segments follow
+ * tuch/utils/segmentation.py:29-99: seg_q = segment_vidx lists; seg_faces = faces of the
+ * closed segment where cap vertex c (global numbering over all segments) has index V + c;
+ * cap_* = the ordered boundary loops whose mean is the cap vertex.  Regions follow
+ * ContactSigSMPL / classes (train_module.py:64-66): CSR vertex lists and [P,2] pairs. */
+typedef struct tuch_contact_model tuch_contact_model;
+
+int tuch_contact_model_create(tuch_contact_model** out, int V, int F, const int32_t* faces /* host [F,3] */,
+                              const uint8_t* geomask /* host [V,V] bytes or NULL */,
+                              int num_segments, const int32_t* seg_q_off, const int32_t* seg_q_vidx,
+                              const int32_t* seg_f_off, const int32_t* seg_faces,
+                              int num_caps, const int32_t* cap_off, const int32_t* cap_vidx,
+                              int num_regions, const int32_t* region_off, const int32_t* region_vidx,
+                              int num_pairs, const int32_t* pairs);
+void tuch_contact_model_destroy(tuch_contact_model* model);
+const uint64_t* tuch_contact_model_mask_bits(const tuch_contact_model* model);
+const int32_t* tuch_contact_model_faces(const tuch_contact_model* model);
+int tuch_contact_model_info(const tuch_contact_model* model, int* V, int* F, int* num_segments,
+                            int* seg_q_total, int* num_pairs);
+
+/* exterior flags of losses.py:79-89 / loss.py:259-266: winding_numbers(verts, verts[faces]).le(thresh),
+ * then BatchBodySegment.batch_has_self_isec (segmentation.py:117-124) and the re-marking of
+ * vertices interior to their own segment.  verts [B,V,3] -> exterior [B,V] bytes;
+ * optional: w [B,V], seg_w / seg_exterior [B, seg_q_total]. */
+size_t tuch_exterior_workspace_bytes(const tuch_contact_model* model, int B);
+int tuch_exterior_flags(const tuch_contact_model* model, const float* verts, int B, int apply_segments,
+                        float thresh, float* w, uint8_t* exterior, float* seg_w, uint8_t* seg_exterior,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* region-pair minima: TUCH.contact_from_verts, train_module.py:69-91 (select NULL, unmasked)
+ * and the region-to-region term, losses.py:107-117 (select = gt_contact & has_discrete_contact,
+ * geodesically masked).  out_min [B,P] (0 where not selected), out_ij [B,P,2] arg-min vertices. */
+int tuch_region_pair_min(const tuch_contact_model* model, const float* verts, int B, const uint8_t* select,
+                         int use_geomask, float* out_min, int32_t* out_ij, void* stream);
+int tuch_region_pair_min_bwd(const tuch_contact_model* model, const float* verts, int B, const int32_t* ij,
+                             const float* grad_out, float* grad_verts, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TUCH_AMD_H */

@@ -1,0 +1,96 @@
+"""ctypes binding of the C ABI in include/tuch_amd.h (libtuch_amd.so).
+
+There is no fallback: if the library is missing or a call fails, this raises.
+torch only supplies device memory and the current stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_size_t, c_void_p
+
+import torch  # noqa: F401  (must be imported first so the HIP runtime it ships is the one in the process)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libtuch_amd.so')
+_lib = None
+
+# name -> (restype, argtypes); mirrors include/tuch_amd.h
+_SIGNATURES = {
+    'tuch_last_error': (c_char_p, []),
+    'tuch_abi_version': (c_int, []),
+    'tuch_batch_pairwise_dist': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'tuch_solid_angles': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'tuch_gather_triangles': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'tuch_winding_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'tuch_winding_numbers': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
+                                     c_void_p, c_size_t, c_void_p]),
+    'tuch_geomask_words': (c_int, [c_int]),
+    'tuch_geomask_bits_bytes': (c_size_t, [c_int]),
+    'tuch_pack_geomask': (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    'tuch_v2v_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'tuch_v2v_min_masked': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
+                                    c_void_p]),
+    'tuch_contact_terms_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
+                                       c_void_p, c_void_p]),
+    'tuch_contact_terms_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
+                                       c_void_p, c_void_p]),
+    'tuch_contact_model_create': (c_int, [POINTER(c_void_p), c_int, c_int, c_void_p, c_void_p,
+                                          c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_int, c_void_p, c_void_p,
+                                          c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    'tuch_contact_model_destroy': (None, [c_void_p]),
+    'tuch_contact_model_mask_bits': (c_void_p, [c_void_p]),
+    'tuch_contact_model_faces': (c_void_p, [c_void_p]),
+    'tuch_contact_model_info': (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int),
+                                        POINTER(c_int), POINTER(c_int)]),
+    'tuch_exterior_workspace_bytes': (c_size_t, [c_void_p, c_int]),
+    'tuch_exterior_flags': (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_size_t, c_void_p]),
+    'tuch_region_pair_min': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    'tuch_region_pair_min_bwd': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'libtuch_amd.so is not built (%s). Run `python -m tuch_amd._build` (needs hipcc); '
+                'there is no CPU fallback.' % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)   # AttributeError if the ABI and the binding drift apart
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class TuchError(RuntimeError):
+    pass
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise TuchError('libtuch_amd error %d: %s' % (rc, lib().tuch_last_error().decode()))
+
+
+def ptr(t) -> c_void_p:
+    """Device pointer of a contiguous CUDA/HIP tensor (None -> NULL)."""
+    if t is None:
+        return c_void_p(0)
+    if not t.is_cuda:
+        raise TuchError('tuch_amd kernels need tensors on a HIP device, got %s' % t.device)
+    if not t.is_contiguous():
+        raise TuchError('tuch_amd kernels need contiguous tensors')
+    return c_void_p(t.data_ptr())
+
+
+def stream() -> c_void_p:
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

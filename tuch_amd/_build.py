@@ -1,0 +1,58 @@
+"""Build libtuch_amd.so (hand-written HIP for gfx950 + the C ABI) in-tree with hipcc.
+
+    python -m tuch_amd._build            # build if stale
+    python -m tuch_amd._build --force
+
+The library links only the HIP runtime: no torch types cross the ABI
+(include/tuch_amd.h).  hipcc cross-compiles without a GPU.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libtuch_amd.so')
+ARCH = 'gfx950'
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    objs = []
+    os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
+    for src in sources():
+        obj = os.path.join(HERE, 'build', os.path.basename(src)[:-4] + '.o')
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
+                os.path.getmtime(src), *[os.path.getmtime(os.path.join(CSRC, h))
+                                         for h in os.listdir(CSRC) if h.endswith('.h')]):
+            cmd = [hipcc, '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-I', CSRC,
+                   '-Wall', '-Wno-unused-function', '-c', src, '-o', obj]
+            if verbose:
+                print(' '.join(cmd))
+            subprocess.run(cmd, check=True)
+        objs.append(obj)
+    cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

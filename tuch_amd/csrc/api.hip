@@ -1,0 +1,27 @@
+// Error reporting and version for the C ABI declared in include/tuch_amd.h.
+#include "common.h"
+#include <stdarg.h>
+#include <stdio.h>
+
+static thread_local char g_error[512] = "";
+
+void tuch_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+}
+
+int tuch_check_launch(const char* what)
+{
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        tuch_set_error("%s: %s", what, hipGetErrorString(e));
+        return TUCH_ERR_HIP;
+    }
+    return TUCH_OK;
+}
+
+extern "C" const char* tuch_last_error(void) { return g_error; }
+extern "C" int tuch_abi_version(void) { return 1; }

@@ -1,0 +1,28 @@
+// Device-resident constants of one body model (faces, packed geodesic mask,
+// segment and region tables).  Created once, read-only in the hot calls.
+#pragma once
+#include "common.h"
+
+struct tuch_contact_model {
+    int device;
+    int V, F;
+    int32_t* faces;            // [F,3]
+    uint64_t* mask_bits;       // [W][V] or nullptr
+    // segments (tuch/utils/segmentation.py): CSR over segments
+    int num_segments, num_caps, seg_q_total, seg_f_total;
+    int32_t* seg_q_off;        // [S+1] into seg_q_vidx
+    int32_t* seg_q_vidx;       // segment_vidx lists, concatenated
+    int32_t* seg_f_off;        // [S+1] into seg_faces (in faces)
+    int32_t* seg_faces;        // [seg_f_total,3], cap vertex c is index V + c
+    int32_t* cap_off;          // [K+1] into cap_vidx
+    int32_t* cap_vidx;         // ordered boundary loops, concatenated
+    int* seg_q_off_host;       // host copies for grid sizing
+    int* seg_f_off_host;
+    int seg_q_max;
+    // contact regions (ContactSigSMPL / classes): CSR over regions
+    int num_regions, num_pairs, region_max;
+    int32_t* region_off;       // [R+1]
+    int32_t* region_vidx;
+    int32_t* pairs;            // [P,2]
+    int* region_off_host;
+};

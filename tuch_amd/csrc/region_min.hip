@@ -1,0 +1,147 @@
+// Minimum squared distance between two contact regions (K5 of SURVEY.md §2.2).
+//
+// Replaces (a) the region-to-region term of tuch/smplify/losses.py:107-117, which slices
+// the geodesically masked [1,V,V] matrix per annotated region pair, and (b)
+// TUCH.contact_from_verts, tuch/train/train_module.py:69-91, which runs three bmm's
+// per region pair in a Python loop over all P pairs ("Speed up this function will
+// speed up training loop!", :74).
+//
+// One block per (pair, body).  The second region's vertices are staged in LDS once
+// and read by all lanes at the same address (broadcast, conflict-free); every
+// lane walks its share of the first region; the block minimum and its (i, j)
+// are found with a wavefront shuffle reduction on (d2, flat index) keys so that
+// ties resolve to the first flat index like torch.min / argmin.
+// Distances are direct differences (DESIGN.md "Parity").
+#include "common.h"
+#include "model.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kTile = 1024;   // second-region vertices staged per pass (12 KB of LDS)
+
+struct Best {
+    float d;
+    int idx;   // flat index a * n2 + bb in region-list order
+};
+
+__device__ __forceinline__ Best better(Best x, Best y)
+{
+    return (y.d < x.d || (y.d == x.d && y.idx < x.idx)) ? y : x;
+}
+
+__global__ __launch_bounds__(kBlock) void region_pair_min_kernel(
+    const float* __restrict__ verts, const int32_t* __restrict__ region_off,
+    const int32_t* __restrict__ region_vidx, const int32_t* __restrict__ pairs,
+    const uint8_t* __restrict__ select,        // [B,P] or nullptr (= all)
+    const uint64_t* __restrict__ mask_bits,    // [W][V] or nullptr (= unmasked)
+    int V, int P, float* __restrict__ out_min, int32_t* __restrict__ out_ij)
+{
+    __shared__ float sx[kTile], sy[kTile], sz[kTile];
+    __shared__ int sv[kTile];
+    __shared__ Best swave[kBlock / 64];
+    const int p = blockIdx.x, b = blockIdx.y;
+    const size_t o = (size_t)b * P + p;
+    if (select && !select[o]) {
+        if (threadIdx.x == 0) {
+            out_min[o] = 0.0f;
+            if (out_ij) { out_ij[2 * o] = -1; out_ij[2 * o + 1] = -1; }
+        }
+        return;
+    }
+    const int r1 = pairs[2 * p], r2 = pairs[2 * p + 1];
+    const int a_beg = region_off[r1], n1 = region_off[r1 + 1] - a_beg;
+    const int b_beg = region_off[r2], n2 = region_off[r2 + 1] - b_beg;
+    const float* vb = verts + (size_t)b * V * 3;
+    Best best = {__builtin_inff(), 0x7fffffff};
+    for (int t0 = 0; t0 < n2; t0 += kTile) {
+        const int tn = min(kTile, n2 - t0);
+        __syncthreads();
+        for (int k = threadIdx.x; k < tn; k += kBlock) {
+            const int v = region_vidx[b_beg + t0 + k];
+            sv[k] = v;
+            sx[k] = vb[3 * v]; sy[k] = vb[3 * v + 1]; sz[k] = vb[3 * v + 2];
+        }
+        __syncthreads();
+        for (int a = threadIdx.x; a < n1; a += kBlock) {
+            const int i = region_vidx[a_beg + a];
+            const float px = vb[3 * i], py = vb[3 * i + 1], pz = vb[3 * i + 2];
+            const uint64_t* mrow = mask_bits ? mask_bits + (size_t)(i >> 6) * V : nullptr;
+            for (int k = 0; k < tn; ++k) {
+                const float dx = px - sx[k], dy = py - sy[k], dz = pz - sz[k];
+                float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                if (mrow && !((mrow[sv[k]] >> (i & 63)) & 1)) d = __builtin_inff();
+                const int flat = a * n2 + t0 + k;
+                if (d < best.d || (d == best.d && flat < best.idx)) { best.d = d; best.idx = flat; }
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        Best other = {__shfl_down(best.d, s, 64), __shfl_down(best.idx, s, 64)};
+        best = better(best, other);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) swave[wave] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Best r = swave[0];
+        for (int w = 1; w < kBlock / 64; ++w) r = better(r, swave[w]);
+        out_min[o] = r.d;
+        if (out_ij) {
+            const bool ok = r.idx != 0x7fffffff && n2 > 0;
+            out_ij[2 * o] = ok ? region_vidx[a_beg + r.idx / n2] : -1;
+            out_ij[2 * o + 1] = ok ? region_vidx[b_beg + r.idx % n2] : -1;
+        }
+    }
+}
+
+// d(min d2)/dv: +2 g (v_i - v_j) to i, the negative to j
+__global__ __launch_bounds__(kBlock) void region_pair_min_bwd_kernel(
+    const float* __restrict__ verts, const int32_t* __restrict__ ij, const float* __restrict__ gout,
+    int V, int P, float* __restrict__ grad)
+{
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= P) return;
+    const size_t o = (size_t)b * P + p;
+    const int i = ij[2 * o], j = ij[2 * o + 1];
+    const float g = gout[o];
+    if (i < 0 || j < 0 || g == 0.0f) return;
+    const float* vb = verts + (size_t)b * V * 3;
+    float* gb = grad + (size_t)b * V * 3;
+    for (int c = 0; c < 3; ++c) {
+        const float d = 2.0f * g * (vb[3 * i + c] - vb[3 * j + c]);
+        atomicAdd(gb + 3 * i + c, d);
+        atomicAdd(gb + 3 * j + c, -d);
+    }
+}
+
+}  // namespace
+
+extern "C" int tuch_region_pair_min(const tuch_contact_model* m, const float* verts, int B,
+                                    const uint8_t* select, int use_geomask, float* out_min,
+                                    int32_t* out_ij, void* stream)
+{
+    TUCH_REQUIRE(m && verts && out_min, "tuch_region_pair_min: null pointer");
+    TUCH_REQUIRE(B > 0 && B <= 65535, "tuch_region_pair_min: bad batch %d", B);
+    TUCH_REQUIRE(m->num_pairs > 0, "tuch_region_pair_min: model has no region pairs");
+    TUCH_REQUIRE(!use_geomask || m->mask_bits, "tuch_region_pair_min: model has no geodesic mask");
+    hipLaunchKernelGGL(region_pair_min_kernel, dim3(m->num_pairs, B), dim3(kBlock), 0, (hipStream_t)stream,
+                       verts, (const int32_t*)m->region_off, (const int32_t*)m->region_vidx,
+                       (const int32_t*)m->pairs, select,
+                       use_geomask ? (const uint64_t*)m->mask_bits : (const uint64_t*)nullptr, m->V,
+                       m->num_pairs, out_min, out_ij);
+    return tuch_check_launch("tuch_region_pair_min");
+}
+
+extern "C" int tuch_region_pair_min_bwd(const tuch_contact_model* m, const float* verts, int B,
+                                        const int32_t* ij, const float* grad_out, float* grad_verts,
+                                        void* stream)
+{
+    TUCH_REQUIRE(m && verts && ij && grad_out && grad_verts, "tuch_region_pair_min_bwd: null pointer");
+    TUCH_REQUIRE(B > 0 && B <= 65535 && m->num_pairs > 0, "tuch_region_pair_min_bwd: bad arguments");
+    hipLaunchKernelGGL(region_pair_min_bwd_kernel, dim3(ceil_div(m->num_pairs, kBlock), B), dim3(kBlock), 0,
+                       (hipStream_t)stream, verts, ij, grad_out, m->V, m->num_pairs, grad_verts);
+    return tuch_check_launch("tuch_region_pair_min_bwd");
+}

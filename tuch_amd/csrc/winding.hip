@@ -1,0 +1,373 @@
+// Generalized winding numbers on gfx950 (K2/K3 of SURVEY.md §2.2).
+//
+// Replaces tuch/utils/contact.py:49-147 (solid_angles + winding_numbers): for every
+// query point q and triangle (a,b,c), with A=a-q, B=b-q, C=c-q,
+//     omega = 2*atan2(A.(BxC), |A||B||C| + (A.B)|C| + (A.C)|B| + (B.C)|A|)
+//     w(q)  = 1/(4 pi) * sum_f omega
+// The reference materialises a [1,Q,F,3,3] tensor (3.4 GB at SMPL size); here
+// nothing of size QxF exists.  Design (VALU-bound):
+//   * one lane owns TWO queries held as float2 so that the ~50 add/mul/fma per
+//     (query, triangle) issue as v_pk_*_f32 (the packed-FP32 rate is what the
+//     157 TFLOP/s vector peak is quoted on);
+//   * the triangle is wave-uniform: its nine floats are read with scalar loads
+//     (SGPR broadcast), so the inner loop touches neither LDS nor the vector
+//     memory path;
+//   * F is split across blocks (grid.y) so that small batches still fill 256 CUs;
+//     the per-split partial sums are reduced in fixed order by a second tiny
+//     kernel => bit-reproducible results, no float atomics.
+#include "common.h"
+#include "model.h"
+
+namespace {
+
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kHalfPi = 1.57079632679489661923f;
+constexpr int kBlock = 256;
+constexpr int kQueriesPerLane = 2;
+constexpr int kQueriesPerBlock = kBlock * kQueriesPerLane;
+
+// atan on [0,1]: t * P(t^2), minimax, max abs error 9.6e-8 in float32.
+__device__ __forceinline__ v2f atan_poly(v2f t)
+{
+    const v2f s = t * t;
+    v2f p = splat2(0.0024567253421992064f);
+    p = fma2(p, s, splat2(-0.014401361346244812f));
+    p = fma2(p, s, splat2(0.03978123143315315f));
+    p = fma2(p, s, splat2(-0.07234857976436615f));
+    p = fma2(p, s, splat2(0.10498946160078049f));
+    p = fma2(p, s, splat2(-0.14161229133605957f));
+    p = fma2(p, s, splat2(0.19985906779766083f));
+    p = fma2(p, s, splat2(-0.33332598209381104f));
+    p = fma2(p, s, splat2(0.9999998807907104f));
+    return p * t;
+}
+
+// atan2(y, x) for a pair.  atan2(0,0) = 0 as torch.atan2 returns (contact.py:105:
+// a query that is a corner of the triangle has a zero vector => num = den = 0).
+__device__ __forceinline__ v2f atan2_pair(v2f y, v2f x)
+{
+    v2f r;
+    float t[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float ax = __builtin_fabsf(x[k]), ay = __builtin_fabsf(y[k]);
+        const float mx = __builtin_fmaxf(__builtin_fmaxf(ax, ay), 1e-37f);
+        const float mn = __builtin_fminf(ax, ay);
+        t[k] = mn * __builtin_amdgcn_rcpf(mx);
+    }
+    const v2f p = atan_poly((v2f){t[0], t[1]});
+    const v2f swapped = splat2(kHalfPi) - p;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        float v = (__builtin_fabsf(y[k]) > __builtin_fabsf(x[k])) ? swapped[k] : p[k];
+        v = (x[k] < 0.0f) ? (kPi - v) : v;
+        r[k] = __builtin_copysignf(v, y[k]);
+    }
+    return r;
+}
+
+__device__ __forceinline__ v2f sqrt2(v2f a)
+{
+    return (v2f){__builtin_amdgcn_sqrtf(a[0]), __builtin_amdgcn_sqrtf(a[1])};
+}
+
+// Half solid angle atan2(num, den) of one (wave-uniform) triangle for a pair of queries.
+__device__ __forceinline__ v2f half_solid_angle(const float* __restrict__ t, v2f qx, v2f qy, v2f qz)
+{
+    const v2f Ax = splat2(t[0]) - qx, Ay = splat2(t[1]) - qy, Az = splat2(t[2]) - qz;
+    const v2f Bx = splat2(t[3]) - qx, By = splat2(t[4]) - qy, Bz = splat2(t[5]) - qz;
+    const v2f Cx = splat2(t[6]) - qx, Cy = splat2(t[7]) - qy, Cz = splat2(t[8]) - qz;
+    const v2f nA = sqrt2(fma2(Az, Az, fma2(Ay, Ay, Ax * Ax)));
+    const v2f nB = sqrt2(fma2(Bz, Bz, fma2(By, By, Bx * Bx)));
+    const v2f nC = sqrt2(fma2(Cz, Cz, fma2(Cy, Cy, Cx * Cx)));
+    const v2f cx = fma2(By, Cz, -(Bz * Cy));
+    const v2f cy = fma2(Bz, Cx, -(Bx * Cz));
+    const v2f cz = fma2(Bx, Cy, -(By * Cx));
+    const v2f num = fma2(Az, cz, fma2(Ay, cy, Ax * cx));
+    const v2f dAB = fma2(Az, Bz, fma2(Ay, By, Ax * Bx));
+    const v2f dBC = fma2(Bz, Cz, fma2(By, Cy, Bx * Cx));
+    const v2f dAC = fma2(Az, Cz, fma2(Ay, Cy, Ax * Cx));
+    v2f den = nA * nB * nC;
+    den = fma2(dAB, nC, den);
+    den = fma2(dAC, nB, den);
+    den = fma2(dBC, nA, den);
+    return atan2_pair(num, den);
+}
+
+// partial[b][split][q] = sum over the split's triangles of atan2(num, den)
+__global__ __launch_bounds__(kBlock) void winding_partial_kernel(
+    const float* __restrict__ points,   // [B,Q,3]
+    const float* __restrict__ tris,     // [B,F,9]
+    int Q, int F, int tris_per_split,
+    float* __restrict__ partial)        // [B,S,Q]
+{
+    const int b = blockIdx.z, split = blockIdx.y, nsplit = gridDim.y;
+    const int q0 = blockIdx.x * kQueriesPerBlock + threadIdx.x;
+    const int q1 = q0 + kBlock;
+    const float* pts = points + (size_t)b * Q * 3;
+    // out-of-range lanes recompute query Q-1; their result is not stored
+    const int c0 = q0 < Q ? q0 : Q - 1, c1 = q1 < Q ? q1 : Q - 1;
+    const v2f qx = {pts[3 * c0 + 0], pts[3 * c1 + 0]};
+    const v2f qy = {pts[3 * c0 + 1], pts[3 * c1 + 1]};
+    const v2f qz = {pts[3 * c0 + 2], pts[3 * c1 + 2]};
+
+    const int f_begin = split * tris_per_split;
+    const int f_end = min(F, f_begin + tris_per_split);
+    const float* t = tris + ((size_t)b * F + f_begin) * 9;
+    v2f acc = splat2(0.0f);
+    for (int f = f_begin; f < f_end; ++f, t += 9)
+        acc += half_solid_angle(t, qx, qy, qz);
+
+    float* out = partial + ((size_t)b * nsplit + split) * Q;
+    if (q0 < Q) out[q0] = acc[0];
+    if (q1 < Q) out[q1] = acc[1];
+}
+
+// w = (2 / 4pi) * sum_s partial, exterior = w <= thresh (losses.py:82, loss.py:262)
+__global__ __launch_bounds__(kBlock) void winding_finalize_kernel(
+    const float* __restrict__ partial, int Q, int nsplit, float thresh,
+    float* __restrict__ w, uint8_t* __restrict__ exterior)
+{
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * kBlock + threadIdx.x;
+    if (q >= Q) return;
+    const float* p = partial + (size_t)b * nsplit * Q + q;
+    float acc = 0.0f;
+    for (int s = 0; s < nsplit; ++s) acc += p[(size_t)s * Q];
+    const float val = acc * (0.5f / kPi);
+    if (w) w[(size_t)b * Q + q] = val;
+    if (exterior) exterior[(size_t)b * Q + q] = val <= thresh ? 1 : 0;
+}
+
+// contact.py:49-109 materialised (API parity; small inputs): out[b][q][f] = 2*atan2(...)
+__global__ __launch_bounds__(kBlock) void solid_angles_kernel(
+    const float* __restrict__ points, const float* __restrict__ tris, int Q, int F,
+    float* __restrict__ out)
+{
+    const int b = blockIdx.z;
+    const int f = blockIdx.y;
+    const int q = blockIdx.x * kBlock + threadIdx.x;
+    if (q >= Q) return;
+    const float* pt = points + ((size_t)b * Q + q) * 3;
+    const float* t = tris + ((size_t)b * F + f) * 9;
+    const v2f h = half_solid_angle(t, splat2(pt[0]), splat2(pt[1]), splat2(pt[2]));
+    out[((size_t)b * Q + q) * F + f] = 2.0f * h[0];
+}
+
+// triangles[b][f] = verts[b][faces[f]]  (losses.py:81, loss.py:260)
+__global__ __launch_bounds__(kBlock) void gather_triangles_kernel(
+    const float* __restrict__ verts, const int32_t* __restrict__ faces, int V, int F,
+    float* __restrict__ tris)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * kBlock + threadIdx.x;   // one (face, corner) per thread
+    if (i >= F * 3) return;
+    const int v = faces[i];
+    const float* src = verts + ((size_t)b * V + v) * 3;
+    float* dst = tris + ((size_t)b * F * 3 + i) * 3;
+    dst[0] = src[0];
+    dst[1] = src[1];
+    dst[2] = src[2];
+}
+
+// ---- body segments (tuch/utils/segmentation.py) ---------------------------------
+// cap vertex of band c = mean of the band's boundary-loop vertices (segmentation.py:74-76)
+__global__ __launch_bounds__(kBlock) void cap_centroid_kernel(
+    const float* __restrict__ verts, const int32_t* __restrict__ cap_off,
+    const int32_t* __restrict__ cap_vidx, int V, int K, float* __restrict__ caps)   // [B,K,3]
+{
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= K) return;
+    const float* vb = verts + (size_t)b * V * 3;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    const int beg = cap_off[c], end = cap_off[c + 1];
+    for (int k = beg; k < end; ++k) {
+        const float* p = vb + 3 * cap_vidx[k];
+        sx += p[0]; sy += p[1]; sz += p[2];
+    }
+    const float inv = 1.0f / (float)(end - beg);
+    float* o = caps + ((size_t)b * K + c) * 3;
+    o[0] = sx * inv; o[1] = sy * inv; o[2] = sz * inv;
+}
+
+// closed-segment triangles: index < V -> body vertex, else cap vertex (segmentation.py:77)
+__global__ __launch_bounds__(kBlock) void gather_segment_triangles_kernel(
+    const float* __restrict__ verts, const float* __restrict__ caps,
+    const int32_t* __restrict__ seg_faces, int V, int K, int Fs, float* __restrict__ tris)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= Fs * 3) return;
+    const int v = seg_faces[i];
+    const float* src = v < V ? verts + ((size_t)b * V + v) * 3 : caps + ((size_t)b * K + (v - V)) * 3;
+    float* dst = tris + ((size_t)b * Fs * 3 + i) * 3;
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+}
+
+// winding number of every segment vertex w.r.t. its own closed segment
+// (segmentation.py:81-99); vertices that are NOT exterior to their own segment
+// are re-marked exterior in the body flags (losses.py:87-89, loss.py:265-266).
+__global__ __launch_bounds__(kBlock) void segment_winding_kernel(
+    const float* __restrict__ verts, const float* __restrict__ seg_tris,
+    const int32_t* __restrict__ seg_q_off, const int32_t* __restrict__ seg_q_vidx,
+    const int32_t* __restrict__ seg_f_off, int V, int Fs_total, int Qs_total, float thresh,
+    float* __restrict__ seg_w,          // [B,Qs_total] or nullptr
+    uint8_t* __restrict__ seg_ext,      // [B,Qs_total] or nullptr: w <= thresh
+    uint8_t* __restrict__ exterior)     // [B,V] or nullptr: set to 1 where w > thresh
+{
+    const int b = blockIdx.z, s = blockIdx.y;
+    const int q_beg = seg_q_off[s], q_cnt = seg_q_off[s + 1] - q_beg;
+    const int l0 = blockIdx.x * kQueriesPerBlock + threadIdx.x, l1 = l0 + kBlock;
+    if (blockIdx.x * kQueriesPerBlock >= q_cnt) return;
+    const int c0 = min(l0, q_cnt - 1), c1 = min(l1, q_cnt - 1);
+    const int v0 = seg_q_vidx[q_beg + c0], v1 = seg_q_vidx[q_beg + c1];
+    const float* vb = verts + (size_t)b * V * 3;
+    const v2f qx = {vb[3 * v0 + 0], vb[3 * v1 + 0]};
+    const v2f qy = {vb[3 * v0 + 1], vb[3 * v1 + 1]};
+    const v2f qz = {vb[3 * v0 + 2], vb[3 * v1 + 2]};
+    const int f_beg = seg_f_off[s], f_end = seg_f_off[s + 1];
+    const float* t = seg_tris + ((size_t)b * Fs_total + f_beg) * 9;
+    v2f acc = splat2(0.0f);
+    for (int f = f_beg; f < f_end; ++f, t += 9)
+        acc += half_solid_angle(t, qx, qy, qz);
+    const float w0 = acc[0] * (0.5f / kPi), w1 = acc[1] * (0.5f / kPi);
+    const size_t o = (size_t)b * Qs_total + q_beg;
+    if (l0 < q_cnt) {
+        if (seg_w) seg_w[o + l0] = w0;
+        if (seg_ext) seg_ext[o + l0] = w0 <= thresh;
+        if (exterior && !(w0 <= thresh)) exterior[(size_t)b * V + v0] = 1;
+    }
+    if (l1 < q_cnt) {
+        if (seg_w) seg_w[o + l1] = w1;
+        if (seg_ext) seg_ext[o + l1] = w1 <= thresh;
+        if (exterior && !(w1 <= thresh)) exterior[(size_t)b * V + v1] = 1;
+    }
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct ExteriorLayout {
+    size_t tris, partial, caps, seg_tris, total;
+};
+
+int choose_splits(int B, int Q, int F);
+
+ExteriorLayout exterior_layout(const tuch_contact_model* m, int B)
+{
+    ExteriorLayout l;
+    size_t o = 0;
+    l.tris = o;     o += align256((size_t)B * m->F * 9 * sizeof(float));
+    l.partial = o;  o += align256((size_t)B * choose_splits(B, m->V, m->F) * m->V * sizeof(float));
+    l.caps = o;     o += align256((size_t)B * (m->num_caps > 0 ? m->num_caps : 1) * 3 * sizeof(float));
+    l.seg_tris = o; o += align256((size_t)B * (m->seg_f_total > 0 ? m->seg_f_total : 1) * 9 * sizeof(float));
+    l.total = o;
+    return l;
+}
+
+int choose_splits(int B, int Q, int F)
+{
+    // enough blocks for >= ~8 waves per SIMD over 256 CUs, at least ~512 triangles per split
+    const int qblocks = ceil_div(Q, kQueriesPerBlock);
+    int s = 1;
+    while (s < 16 && (long)B * qblocks * s < 2048 && F / (s * 2) >= 512) s *= 2;
+    return s;
+}
+
+}  // namespace
+
+extern "C" size_t tuch_winding_workspace_bytes(int B, int Q, int F)
+{
+    if (B <= 0 || Q <= 0 || F <= 0) return 0;
+    return (size_t)B * choose_splits(B, Q, F) * Q * sizeof(float);
+}
+
+extern "C" int tuch_winding_numbers(const float* points, const float* triangles, int B, int Q, int F,
+                                    float* w, uint8_t* exterior, float exterior_thresh,
+                                    void* workspace, size_t workspace_bytes, void* stream)
+{
+    TUCH_REQUIRE(points && triangles && (w || exterior), "tuch_winding_numbers: null pointer");
+    TUCH_REQUIRE(B > 0 && Q > 0 && F > 0, "tuch_winding_numbers: bad sizes B=%d Q=%d F=%d", B, Q, F);
+    const int nsplit = choose_splits(B, Q, F);
+    const size_t need = (size_t)B * nsplit * Q * sizeof(float);
+    if (!workspace || workspace_bytes < need) {
+        tuch_set_error("tuch_winding_numbers: workspace %zu < %zu bytes", workspace_bytes, need);
+        return TUCH_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int per_split = ceil_div(F, nsplit);
+    dim3 grid(ceil_div(Q, kQueriesPerBlock), nsplit, B);
+    hipLaunchKernelGGL(winding_partial_kernel, grid, dim3(kBlock), 0, s, points, triangles, Q, F,
+                       per_split, (float*)workspace);
+    hipLaunchKernelGGL(winding_finalize_kernel, dim3(ceil_div(Q, kBlock), B), dim3(kBlock), 0, s,
+                       (const float*)workspace, Q, nsplit, exterior_thresh, w, exterior);
+    return tuch_check_launch("tuch_winding_numbers");
+}
+
+extern "C" int tuch_solid_angles(const float* points, const float* triangles, int B, int Q, int F,
+                                 float* out, void* stream)
+{
+    TUCH_REQUIRE(points && triangles && out, "tuch_solid_angles: null pointer");
+    TUCH_REQUIRE(B > 0 && Q > 0 && F > 0 && F <= 65535 && B <= 65535, "tuch_solid_angles: bad sizes");
+    hipLaunchKernelGGL(solid_angles_kernel, dim3(ceil_div(Q, kBlock), F, B), dim3(kBlock), 0,
+                       (hipStream_t)stream, points, triangles, Q, F, out);
+    return tuch_check_launch("tuch_solid_angles");
+}
+
+extern "C" int tuch_gather_triangles(const float* verts, const int32_t* faces, int B, int V, int F,
+                                     float* triangles, void* stream)
+{
+    TUCH_REQUIRE(verts && faces && triangles, "tuch_gather_triangles: null pointer");
+    TUCH_REQUIRE(B > 0 && V > 0 && F > 0, "tuch_gather_triangles: bad sizes");
+    hipLaunchKernelGGL(gather_triangles_kernel, dim3(ceil_div(F * 3, kBlock), B), dim3(kBlock), 0,
+                       (hipStream_t)stream, verts, faces, V, F, triangles);
+    return tuch_check_launch("tuch_gather_triangles");
+}
+
+// ---- model-level entry points ------------------------------------------------------
+extern "C" size_t tuch_exterior_workspace_bytes(const tuch_contact_model* m, int B)
+{
+    if (!m || B <= 0) return 0;
+    return exterior_layout(m, B).total;
+}
+
+// exterior flags of tuch/smplify/losses.py:81-89 and tuch/train/loss.py:260-266:
+//   exterior = winding_numbers(verts, verts[faces]).le(thresh), then every vertex that is
+//   interior to its own closed body segment is re-marked exterior.
+extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* verts, int B,
+                                   int apply_segments, float thresh, float* w, uint8_t* exterior,
+                                   float* seg_w, uint8_t* seg_exterior,
+                                   void* workspace, size_t workspace_bytes, void* stream)
+{
+    TUCH_REQUIRE(m && verts && exterior, "tuch_exterior_flags: null pointer");
+    TUCH_REQUIRE(B > 0, "tuch_exterior_flags: bad batch %d", B);
+    const ExteriorLayout l = exterior_layout(m, B);
+    if (!workspace || workspace_bytes < l.total) {
+        tuch_set_error("tuch_exterior_flags: workspace %zu < %zu bytes", workspace_bytes, l.total);
+        return TUCH_ERR_WORKSPACE;
+    }
+    char* ws = (char*)workspace;
+    float* tris = (float*)(ws + l.tris);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gather_triangles_kernel, dim3(ceil_div(m->F * 3, kBlock), B), dim3(kBlock), 0, s,
+                       verts, (const int32_t*)m->faces, m->V, m->F, tris);
+    int rc = tuch_winding_numbers(verts, tris, B, m->V, m->F, w, exterior, thresh, ws + l.partial,
+                                  l.caps - l.partial, stream);
+    if (rc != TUCH_OK) return rc;
+    if (apply_segments && m->num_segments > 0) {
+        float* caps = (float*)(ws + l.caps);
+        float* seg_tris = (float*)(ws + l.seg_tris);
+        hipLaunchKernelGGL(cap_centroid_kernel, dim3(ceil_div(m->num_caps, kBlock), B), dim3(kBlock), 0, s,
+                           verts, (const int32_t*)m->cap_off, (const int32_t*)m->cap_vidx, m->V,
+                           m->num_caps, caps);
+        hipLaunchKernelGGL(gather_segment_triangles_kernel, dim3(ceil_div(m->seg_f_total * 3, kBlock), B),
+                           dim3(kBlock), 0, s, verts, (const float*)caps, (const int32_t*)m->seg_faces,
+                           m->V, m->num_caps, m->seg_f_total, seg_tris);
+        hipLaunchKernelGGL(segment_winding_kernel,
+                           dim3(ceil_div(m->seg_q_max, kQueriesPerBlock), m->num_segments, B), dim3(kBlock),
+                           0, s, verts, (const float*)seg_tris, (const int32_t*)m->seg_q_off,
+                           (const int32_t*)m->seg_q_vidx, (const int32_t*)m->seg_f_off, m->V,
+                           m->seg_f_total, m->seg_q_total, thresh, seg_w, seg_exterior, exterior);
+    }
+    return tuch_check_launch("tuch_exterior_flags");
+}

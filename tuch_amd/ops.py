@@ -1,0 +1,276 @@
+"""torch-facing wrappers over the C ABI: device tensors in, device tensors out.
+
+Everything here runs the hand-written HIP kernels of libtuch_amd.so; there is no
+eager/CPU fallback.  Index outputs are int64 like the reference's torch ops.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _C
+
+MODE_SMPLIFY = 0   # tuch/smplify/losses.py:96-105
+MODE_TRAIN = 1     # tuch/train/loss.py:303-315
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------- raw functions
+def batch_pairwise_dist(x: torch.Tensor, y: torch.Tensor, squared: bool = True) -> torch.Tensor:
+    x, y = _f32(x), _f32(y)
+    b, nx, _ = x.shape
+    ny = y.shape[1]
+    out = torch.empty(b, nx, ny, dtype=torch.float32, device=x.device)
+    _C.check(_C.lib().tuch_batch_pairwise_dist(_C.ptr(x), _C.ptr(y), b, nx, ny, int(squared), _C.ptr(out),
+                                               _C.stream()))
+    return out
+
+
+def solid_angles(points: torch.Tensor, triangles: torch.Tensor) -> torch.Tensor:
+    points, triangles = _f32(points), _f32(triangles)
+    b, q, _ = points.shape
+    f = triangles.shape[1]
+    out = torch.empty(b, q, f, dtype=torch.float32, device=points.device)
+    _C.check(_C.lib().tuch_solid_angles(_C.ptr(points), _C.ptr(triangles), b, q, f, _C.ptr(out), _C.stream()))
+    return out
+
+
+def winding_numbers(points: torch.Tensor, triangles: torch.Tensor, thresh: Optional[float] = None):
+    """[B,Q,3], [B,F,3,3] -> w [B,Q] (and exterior = w <= thresh if thresh is given)."""
+    points, triangles = _f32(points), _f32(triangles)
+    b, q, _ = points.shape
+    f = triangles.shape[1]
+    L = _C.lib()
+    w = torch.empty(b, q, dtype=torch.float32, device=points.device)
+    ext = torch.empty(b, q, dtype=torch.uint8, device=points.device) if thresh is not None else None
+    nbytes = L.tuch_winding_workspace_bytes(b, q, f)
+    ws = _workspace(nbytes, points.device)
+    _C.check(L.tuch_winding_numbers(_C.ptr(points), _C.ptr(triangles), b, q, f, _C.ptr(w), _C.ptr(ext),
+                                    float(thresh if thresh is not None else 0.0), _C.ptr(ws), nbytes,
+                                    _C.stream()))
+    return (w, ext.bool()) if thresh is not None else w
+
+
+def gather_triangles(verts: torch.Tensor, faces_i32: torch.Tensor) -> torch.Tensor:
+    verts = _f32(verts)
+    b, v, _ = verts.shape
+    f = faces_i32.shape[0]
+    out = torch.empty(b, f, 3, 3, dtype=torch.float32, device=verts.device)
+    _C.check(_C.lib().tuch_gather_triangles(_C.ptr(verts), _C.ptr(faces_i32), b, v, f, _C.ptr(out),
+                                            _C.stream()))
+    return out
+
+
+def pack_geomask(geomask: torch.Tensor) -> torch.Tensor:
+    """[V,V] bool on device -> bit-packed words int64 [W,V] (layout of v2v.hip)."""
+    gm = geomask.to(torch.uint8).contiguous()
+    v = gm.shape[0]
+    L = _C.lib()
+    bits = torch.empty(L.tuch_geomask_words(v), v, dtype=torch.int64, device=gm.device)
+    _C.check(L.tuch_pack_geomask(_C.ptr(gm), v, _C.ptr(bits), _C.stream()))
+    return bits
+
+
+def v2v_min_masked(points: torch.Tensor, mask_bits_ptr, num_points: Optional[int] = None):
+    """Masked nearest neighbour: [B,N,3] + packed mask -> (min_d2 [B,N] f32, argmin [B,N] int32)."""
+    points = _f32(points)
+    b, n, _ = points.shape
+    L = _C.lib()
+    mn = torch.empty(b, n, dtype=torch.float32, device=points.device)
+    arg = torch.empty(b, n, dtype=torch.int32, device=points.device)
+    nbytes = L.tuch_v2v_workspace_bytes(b, n)
+    ws = _workspace(nbytes, points.device)
+    mptr = _C.ptr(mask_bits_ptr) if isinstance(mask_bits_ptr, torch.Tensor) else mask_bits_ptr
+    _C.check(L.tuch_v2v_min_masked(_C.ptr(points), mptr, b, n, _C.ptr(mn), _C.ptr(arg), _C.ptr(ws), nbytes,
+                                   _C.stream()))
+    return mn, arg
+
+
+class _ContactTerms(torch.autograd.Function):
+    """terms[b] = (interior sum, exterior sum); gradient flows to the points only."""
+
+    @staticmethod
+    def forward(ctx, points, partner, exterior, valid, mode, euclthres):
+        pts = _f32(points)
+        b, n, _ = pts.shape
+        terms = torch.empty(b, 2, dtype=torch.float32, device=pts.device)
+        _C.check(_C.lib().tuch_contact_terms_fwd(_C.ptr(pts), _C.ptr(partner), _C.ptr(exterior), _C.ptr(valid),
+                                                 b, n, int(mode), float(euclthres), _C.ptr(terms), _C.stream()))
+        ctx.save_for_backward(pts, partner, exterior, valid)
+        ctx.mode, ctx.euclthres = int(mode), float(euclthres)
+        return terms
+
+    @staticmethod
+    def backward(ctx, grad_terms):
+        pts, partner, exterior, valid = ctx.saved_tensors
+        b, n, _ = pts.shape
+        grad = torch.zeros_like(pts)
+        g = grad_terms.to(torch.float32)
+        if valid is not None:
+            g = g * valid.to(g.dtype)[:, None]
+        g = g.contiguous()   # [B,2]: upstream gradient of the interior and of the exterior sum
+        _C.check(_C.lib().tuch_contact_terms_bwd(_C.ptr(pts), _C.ptr(partner), _C.ptr(exterior), _C.ptr(g),
+                                                 b, n, ctx.mode, ctx.euclthres, _C.ptr(grad), _C.stream()))
+        return grad, None, None, None, None, None
+
+
+def contact_terms(points, partner_i32, exterior_u8, valid_u8, mode, euclthres):
+    """Sum of pull/push terms per body: [B] = interior + exterior (differentiable wrt points)."""
+    terms = _ContactTerms.apply(points, partner_i32, exterior_u8, valid_u8, mode, euclthres)
+    return terms.sum(dim=1), terms
+
+
+# ------------------------------------------------------------------------- model
+def _i32(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a), dtype=np.int32)
+
+
+def segment_faces(body_faces: np.ndarray, vidx: np.ndarray, bands: Sequence[np.ndarray], first_cap: int,
+                  num_verts: Optional[int] = None) -> np.ndarray:
+    """Closed-segment face list of tuch/utils/segmentation.py:48-66: body faces whose three
+    vertices are all in ``vidx`` followed by the cap fans [b[i+1], b[i], cap_k]; cap k of this
+    segment is stored at global vertex index ``first_cap + k``."""
+    body_faces = np.asarray(body_faces, np.int64)
+    inside = np.isin(body_faces, np.asarray(vidx)).sum(1) == 3
+    fans = []
+    for k, band in enumerate(bands):
+        band = np.asarray(band, np.int64)
+        fans.append(np.stack([band[1:], band[:-1], np.full(len(band) - 1, first_cap + k, np.int64)], 1))
+    return np.concatenate([body_faces[inside]] + fans, 0) if fans else body_faces[inside]
+
+
+class ContactModel:
+    """Device-side constants of one body model; wraps tuch_contact_model.
+
+    faces      [F,3] ints                       (smpl.faces, train.py:62)
+    geomask    [V,V] bool, geod > geothres      (smplifydc.py:65, loss.py:71), optional
+    segments   list of (vidx, [band loops])     (segmentation.py), optional
+    regions    ordered list of vertex-id lists; pairs [P,2] region indices, optional
+    """
+
+    def __init__(self, faces, geomask=None, segments=None, regions=None, pairs=None,
+                 device: Optional[torch.device] = None):
+        self.device = torch.device(device if device is not None else 'cuda')
+        faces = np.asarray(faces.detach().cpu() if isinstance(faces, torch.Tensor) else faces)
+        self.faces_np = faces.astype(np.int64)
+        self.num_verts = int(faces.max()) + 1
+        self.num_faces = int(faces.shape[0])
+        gm = None
+        if geomask is not None:
+            gm = geomask.detach().cpu().numpy() if isinstance(geomask, torch.Tensor) else np.asarray(geomask)
+            self.num_verts = max(self.num_verts, gm.shape[0])
+            gm = np.ascontiguousarray(gm.astype(np.uint8))
+            assert gm.shape == (self.num_verts, self.num_verts)
+        self.has_mask = gm is not None
+        v = self.num_verts
+        # segment tables
+        segments = list(segments or [])
+        seg_q_off, seg_q, seg_f_off, seg_f, cap_off, cap_v = [0], [], [0], [], [0], []
+        for vidx, bands in segments:
+            first_cap = v + len(cap_off) - 1
+            seg_f.append(segment_faces(self.faces_np, vidx, bands, first_cap))
+            seg_f_off.append(seg_f_off[-1] + len(seg_f[-1]))
+            seg_q.append(np.asarray(vidx, np.int64))
+            seg_q_off.append(seg_q_off[-1] + len(vidx))
+            for band in bands:
+                cap_v.append(np.asarray(band, np.int64))
+                cap_off.append(cap_off[-1] + len(band))
+        self.num_segments = len(segments)
+        self.seg_q_total = seg_q_off[-1]
+        self.seg_q_off = seg_q_off
+        self.seg_vidx = [np.asarray(s[0], np.int64) for s in segments]
+        # region tables
+        regions = list(regions or [])
+        reg_off = np.cumsum([0] + [len(r) for r in regions])
+        self.num_pairs = 0 if pairs is None else len(pairs)
+        cat = lambda lst, width=None: (np.concatenate(lst) if lst else np.zeros(0, np.int64))
+        keep = dict(
+            faces=_i32(faces), seg_q_off=_i32(seg_q_off), seg_q=_i32(cat(seg_q)), seg_f_off=_i32(seg_f_off),
+            seg_f=_i32(cat(seg_f).reshape(-1, 3)), cap_off=_i32(cap_off), cap_v=_i32(cat(cap_v)),
+            reg_off=_i32(reg_off), reg_v=_i32(cat([np.asarray(r) for r in regions])),
+            pairs=_i32(pairs if pairs is not None else np.zeros((0, 2))))
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a.size else ctypes.c_void_p(0)
+        handle = ctypes.c_void_p(0)
+        with torch.cuda.device(self.device):
+            _C.check(_C.lib().tuch_contact_model_create(
+                ctypes.byref(handle), v, self.num_faces, p(keep['faces']),
+                gm.ctypes.data_as(ctypes.c_void_p) if gm is not None else ctypes.c_void_p(0),
+                self.num_segments, p(keep['seg_q_off']), p(keep['seg_q']), p(keep['seg_f_off']), p(keep['seg_f']),
+                len(cap_off) - 1, p(keep['cap_off']), p(keep['cap_v']),
+                len(regions), p(keep['reg_off']), p(keep['reg_v']), self.num_pairs, p(keep['pairs'])))
+        self._handle = handle
+        self.faces_i32 = torch.as_tensor(keep['faces'], device=self.device)
+
+    def __del__(self):
+        h = getattr(self, '_handle', None)
+        if h:
+            try:
+                _C.lib().tuch_contact_model_destroy(h)
+            except Exception:
+                pass
+            self._handle = None
+
+    # K2 + K3
+    def exterior_flags(self, verts: torch.Tensor, apply_segments: bool = True, thresh: float = 0.99,
+                       return_details: bool = False):
+        verts = _f32(verts)
+        b = verts.shape[0]
+        assert verts.shape[1] == self.num_verts
+        L = _C.lib()
+        ext = torch.empty(b, self.num_verts, dtype=torch.uint8, device=verts.device)
+        w = torch.empty(b, self.num_verts, dtype=torch.float32, device=verts.device) if return_details else None
+        seg_w = seg_e = None
+        if return_details and self.num_segments:
+            seg_w = torch.empty(b, self.seg_q_total, dtype=torch.float32, device=verts.device)
+            seg_e = torch.empty(b, self.seg_q_total, dtype=torch.uint8, device=verts.device)
+        nbytes = L.tuch_exterior_workspace_bytes(self._handle, b)
+        ws = _workspace(nbytes, verts.device)
+        _C.check(L.tuch_exterior_flags(self._handle, _C.ptr(verts), b, int(apply_segments), float(thresh),
+                                       _C.ptr(w), _C.ptr(ext), _C.ptr(seg_w), _C.ptr(seg_e), _C.ptr(ws), nbytes,
+                                       _C.stream()))
+        return (ext, w, seg_w, seg_e) if return_details else ext
+
+    # K1
+    def v2v_min(self, verts: torch.Tensor):
+        if not self.has_mask:
+            raise _C.TuchError('ContactModel was created without a geodesic mask')
+        return v2v_min_masked(verts, ctypes.c_void_p(_C.lib().tuch_contact_model_mask_bits(self._handle)))
+
+    # K5
+    def region_pair_min(self, verts: torch.Tensor, select: Optional[torch.Tensor] = None, masked: bool = False):
+        return _RegionPairMin.apply(verts, self, select, masked)
+
+
+class _RegionPairMin(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, verts, model: ContactModel, select, masked):
+        v = _f32(verts)
+        b = v.shape[0]
+        out = torch.empty(b, model.num_pairs, dtype=torch.float32, device=v.device)
+        ij = torch.empty(b, model.num_pairs, 2, dtype=torch.int32, device=v.device)
+        sel = select.to(torch.uint8).contiguous() if select is not None else None
+        _C.check(_C.lib().tuch_region_pair_min(model._handle, _C.ptr(v), b, _C.ptr(sel), int(masked),
+                                               _C.ptr(out), _C.ptr(ij), _C.stream()))
+        ctx.save_for_backward(v, ij)
+        ctx.model = model
+        ctx.mark_non_differentiable(ij)
+        return out, ij
+
+    @staticmethod
+    def backward(ctx, grad_out, _grad_ij):
+        v, ij = ctx.saved_tensors
+        grad = torch.zeros_like(v)
+        _C.check(_C.lib().tuch_region_pair_min_bwd(ctx.model._handle, _C.ptr(v), v.shape[0], _C.ptr(ij),
+                                                   _C.ptr(grad_out.to(torch.float32).contiguous()),
+                                                   _C.ptr(grad), _C.stream()))
+        return grad, None, None, None
