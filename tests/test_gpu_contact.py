@@ -2,7 +2,7 @@
 vectors from the reference and against the CPU oracle.  Run with `-m gpu` on MI355X.
 
 Tolerances (see DESIGN.md "Parity"):
-  * winding numbers: 99.9 % of the vertices within 1e-5 absolute, all within 2e-4
+  * winding numbers: 99 % of the vertices within 5e-6 absolute, 99.5 % within 1e-5, all within 2e-4
     (one ill-conditioned term can move a vertex by a few 1e-5 in the reference itself),
     exterior flags identical wherever |w - 0.99| > 1e-4;
   * squared distances taken by value: 1e-6 absolute (the reference's bmm form carries that
@@ -38,7 +38,8 @@ def make_model(g, gm, with_segments=True, with_regions=True):
 
 def check_winding(w, w_ref):
     err = np.abs(w - w_ref)
-    assert np.percentile(err, 99.9) < 1e-5, np.percentile(err, 99.9)
+    assert np.percentile(err, 99) < 5e-6, np.percentile(err, 99)
+    assert (err > 1e-5).mean() < 5e-3, (err > 1e-5).mean()
     assert err.max() < 2e-4, err.max()
     clear = np.abs(w_ref - 0.99) > 1e-4
     assert np.array_equal((w <= 0.99)[clear], (w_ref <= 0.99)[clear])
