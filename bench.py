@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SMPLify-DC stage-2 fit iterations per second at batch 64 per GPU.
+
+One *step* = one pass of the reference's stage-2 loop body (tuch/smplify/smplifydc.py:155-183)
+over one batch: SMPL forward -> contact_fitting_loss (reprojection + GMM prior + self-contact
+push/pull terms with winding-number inside test and segment filter + region-to-region term)
+-> backward -> Adam step, on SMPL-sized synthetic bodies (V=6890, F=13776).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+The batch dimension shards across ranks (64 bodies per GPU, weak scaling); the only
+collective is a 2-float all-reduce of [sum of losses, body count] per step (RCCL).
+Rank 0 prints ONE JSON line (contract in the task description) including
+  roofline     -- dominant kernel (winding numbers), achieved FLOP/s measured here with HIP events
+  roofline_v2v -- the vertex-distance kernel, physical and reference-layout-equivalent figures
+  cpu_baseline -- the CPU oracle (test infrastructure) timed on this box's host cores, rank 0, N=1
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+BATCH_PER_GPU = 64
+FLOP_PER_WINDING_PAIR = 67        # 63 arithmetic + 3 sqrt + 1 atan2
+FLOP_PER_V2V_PAIR = 8
+PEAK_FP32_VECTOR_TFLOPS = 157.3   # MI355X_MICROARCH.md (packed FP32 FMA rate)
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='bodies per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    return ap.parse_args()
+
+
+def build_problem(batch, device, seed):
+    from tuch_amd.models.smpl import SMPL
+    from tuch_amd.smplify.prior import MaxMixturePrior
+    from tuch_amd.synthetic import make_body, random_poses
+    from tuch_amd.utils.geometry import perspective_projection
+    from tuch_amd.utils.segmentation import BatchBodySegment
+    body = make_body(84, 82, seed=1234)
+    smpl = SMPL(model_data=body, batch_size=batch).to(device)
+    prior = MaxMixturePrior(num_gaussians=8, gmm=body.gmm).to(device)
+    face_tensor = torch.tensor(body.faces, dtype=torch.long, device=device)[None].repeat(batch, 1, 1)
+    geomask = torch.tensor(body.geodesics > 0.3, device=device)
+    segments = BatchBodySegment(list(body.segments.keys()), face_tensor[0], body.segments)
+    cdict = {'classes': [list(p) for p in body.region_pairs], 'csig': dict(body.regions)}
+    rng = np.random.Generator(np.random.PCG64(seed))
+    bp, go, be = random_poses(batch, seed)
+    t = lambda a: torch.tensor(a, device=device)
+    body_pose, global_orient, betas = t(bp), t(go), t(be)
+    cam_t = torch.tensor([[0.0, 0.0, 20.0]], device=device).repeat(batch, 1)
+    cam_c = torch.zeros(batch, 2, device=device)
+    with torch.no_grad():
+        tgt = smpl(global_orient=global_orient, body_pose=body_pose + 0.05 * torch.randn_like(body_pose),
+                   betas=betas)
+        j2d = perspective_projection(tgt.joints, torch.eye(3, device=device)[None].expand(batch, -1, -1),
+                                     cam_t, 5000., cam_c)
+    j2d = j2d + 2.0 * t(rng.standard_normal((batch, 49, 2)).astype(np.float32))
+    conf = t((0.5 + 0.5 * rng.random((batch, 49))).astype(np.float32))
+    conf[:, [1, 9, 12, 27, 28]] = 0.0                                   # smplifydc.py:153
+    gt = t((rng.random((batch, len(body.region_pairs))) < 0.03).astype(np.float32))
+    return dict(body=body, smpl=smpl, prior=prior, face_tensor=face_tensor, geomask=geomask,
+                segments=segments, cdict=cdict, body_pose=body_pose, global_orient=global_orient,
+                betas=betas, cam_t=cam_t, cam_c=cam_c, j2d=j2d, conf=conf, gt=gt,
+                ignore=torch.zeros(batch, dtype=torch.bool, device=device),
+                has_dc=torch.ones(batch, dtype=torch.bool, device=device))
+
+
+def make_step(p, world):
+    """The stage-2 loop body of SMPLifyDC.__call__ (smplifydc.py:155-183)."""
+    from tuch_amd.smplify.losses import contact_fitting_loss
+    body_pose = p['body_pose'].clone().requires_grad_(True)
+    global_orient = p['global_orient'].clone().requires_grad_(True)
+    opt = torch.optim.Adam([body_pose, global_orient], lr=1e-2)
+    stats = torch.zeros(2, device=body_pose.device)
+
+    def step():
+        out = p['smpl'](global_orient=global_orient, body_pose=body_pose, betas=p['betas'])
+        loss = contact_fitting_loss(body_pose, global_orient, None, None, p['betas'], out.joints,
+                                    p['geomask'], 0.02, p['cam_t'], p['cam_c'], p['j2d'], p['conf'],
+                                    p['prior'], cdict=p['cdict'], gt_contact=[p['gt'], None],
+                                    ignore_idxs=p['ignore'], has_discrete_contact=p['has_dc'],
+                                    verts=out.vertices, face_tensor=p['face_tensor'],
+                                    focal_length=5000., contact_loss_weight=2000.0,
+                                    segments=p['segments'])
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        stats[0] = loss.detach()
+        stats[1] = float(body_pose.shape[0])
+        if world > 1:
+            torch.distributed.all_reduce(stats)          # 2 floats over RCCL / xGMI
+        return stats
+    return step, (body_pose, global_orient)
+
+
+def time_kernel(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3      # seconds per launch
+
+
+def rooflines(p, batch):
+    """Dominant-kernel figures measured live (HIP events on the launch stream)."""
+    from tuch_amd import ops
+    from tuch_amd.smplify.losses import contact_model_for
+    body = p['body']
+    v, f = body.num_verts, body.num_faces
+    model = contact_model_for(p['geomask'], p['face_tensor'], p['segments'], p['cdict'])
+    with torch.no_grad():
+        verts = p['smpl'](global_orient=p['global_orient'], body_pose=p['body_pose'], betas=p['betas']).vertices
+    tris = ops.gather_triangles(verts, model.faces_i32)
+    t_w = time_kernel(lambda: ops.winding_numbers(verts, tris), 10)
+    flops = FLOP_PER_WINDING_PAIR * batch * v * f
+    ach = flops / t_w / 1e12
+    roof = {'kernel': 'winding_partial_kernel', 'bound': 'valu', 'achieved': round(ach, 2),
+            'peak': PEAK_FP32_VECTOR_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_VECTOR_TFLOPS, 4),
+            'traffic': None, 'launch_ms': round(t_w * 1e3, 4),
+            'algorithmic_flop_per_launch': flops,
+            'algorithmic_bytes_per_launch': batch * (v * 12 + f * 36 + v * 4)}
+    t_v = time_kernel(lambda: model.v2v_min(verts), 10)
+    ref_layout_bytes = batch * (12 * v + v * v + 8 * v)           # SURVEY.md §8(d) layout (i)
+    compact_bytes = batch * (12 * v + 8 * v) + v * v // 8         # layout (ii): bit-packed mask read once
+    v2v = {'kernel': 'v2v_partial_kernel', 'bound': 'valu', 'launch_ms': round(t_v * 1e3, 4),
+           'achieved': round(FLOP_PER_V2V_PAIR * batch * v * v / t_v / 1e12, 2), 'unit': 'TFLOP/s',
+           'peak': PEAK_FP32_VECTOR_TFLOPS,
+           'frac': round(FLOP_PER_V2V_PAIR * batch * v * v / t_v / 1e12 / PEAK_FP32_VECTOR_TFLOPS, 4),
+           'compact_layout_GBs': round(compact_bytes / t_v / 1e9, 1),
+           'reference_layout_equivalent_GBs': round(ref_layout_bytes / t_v / 1e9, 1),
+           'reference_layout_equivalent_frac_of_hbm': round(ref_layout_bytes / t_v / 1e9 / PEAK_HBM_GBS, 3),
+           'note': 'mask is bit-packed and L2-resident: the equivalent figure is NOT physical bandwidth'}
+    return roof, v2v
+
+
+def cpu_baseline(p, seconds):
+    """The CPU oracle (a port of the reference's arithmetic, test infrastructure) timed on the host:
+    contact loss forward + gradient for whole bodies, until ~`seconds` have elapsed."""
+    from oracle import contact as oc
+    body = p['body']
+    with torch.no_grad():
+        verts = p['smpl'](global_orient=p['global_orient'], body_pose=p['body_pose'],
+                          betas=p['betas']).vertices.cpu().numpy()
+    gm = body.geodesics > 0.3
+    segs = [oc.Segment(n, body.faces, s['vidx'], list(s['bands'].values())) for n, s in body.segments.items()]
+    cores = oc.max_threads()
+    oc.smplify_contact_body(verts[0], body.faces, gm, 0.02, segs, None)      # warm-up
+    t0, n = time.time(), 0
+    while time.time() - t0 < seconds and n < verts.shape[0]:
+        oc.smplify_contact_body(verts[n], body.faces, gm, 0.02, segs, None)
+        n += 1
+    dt = time.time() - t0
+    return {'value': round(n / dt, 3), 'unit': 'body-fit iterations/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d bodies (V=6890,F=13776): contact term forward+gradient (winding, segments, '
+                      'masked v2v, push/pull) with the C/OpenMP oracle, %.1f s; SMPL forward, '
+                      'reprojection and Adam are excluded (negligible on CPU)' % (n, dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local)
+        torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
+    device = torch.device('cuda', local)
+    torch.manual_seed(1000 + rank)
+    p = build_problem(args.batch, device, seed=1002 + rank)
+    step, _ = make_step(p, world)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stats = step()
+    fence()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+    roof, v2v = rooflines(p, args.batch)
+    if rank == 0:
+        bodies = args.batch * world
+        line = {
+            'metric': 'SMPLify-DC fit iters/sec at batch 64', 'value': round(bodies * args.steps / dt, 2),
+            'unit': 'body-fit iterations/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'configs[1] extended to the full stage-2 step: batch=%d/GPU SMPL forward + '
+                                   'contact_fitting_loss (L_P/L_C push/pull, winding inside test, segment '
+                                   'filter, r2r) + backward + Adam, V=6890 F=13776, float32' % args.batch,
+                       'bodies_per_gpu': args.batch, 'global_batch': bodies, 'euclthres': 0.02,
+                       'geothres': 0.3, 'parallelism': 'dp%d (bodies sharded, 2-float all-reduce)' % world,
+                       'batch_iterations_per_s': round(args.steps / dt, 3),
+                       'contact_loss_ms_per_body': round(dt / args.steps * 1e3 / args.batch, 4),
+                       'loss_sum': float(stats[0].item()), 'bodies': float(stats[1].item())},
+            'roofline': roof, 'roofline_v2v': v2v,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(p, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

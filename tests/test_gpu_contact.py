@@ -181,3 +181,56 @@ def test_region_pair_min(tag):
         r = oc.smplify_contact_body(g['verts'][b], g['faces'], gm, 0.0, None, rp)
         assert_close(out_m[b].sum().item(), r['r2r'], 1e-4, 1e-6, 'r2r')
         assert_close(grad[b], r['grad_r2r'], 1e-4, 1e-6, 'r2r grad')
+
+
+def _fitting_inputs(g, full):
+    from tuch_amd.smplify.prior import MaxMixturePrior
+    d = dev()
+    t = lambda a: torch.tensor(a, device=d)
+    if full:
+        prior = MaxMixturePrior(num_gaussians=8, gmm={k: g['gmm_' + k] for k in ('means', 'covars', 'weights')}).to(d)
+        conf = t(g['joints_conf'])
+    else:
+        prior = lambda pose, betas: torch.zeros(pose.shape[0], device=d)
+        conf = torch.zeros_like(t(g['joints_conf']))
+    return t, prior, conf
+
+
+@pytest.mark.parametrize('tag', ['small', 'medium'])
+@pytest.mark.parametrize('eu', ['e0', 'e2'])
+@pytest.mark.parametrize('sg', ['nos', 'seg'])
+@pytest.mark.parametrize('full', [False, True])
+def test_contact_fitting_loss_vs_reference(tag, eu, sg, full):
+    """a6 of SURVEY.md §8a through the reference's own call signature (losses.py:34-123)."""
+    from tuch_amd.smplify.losses import contact_fitting_loss
+    from tuch_amd.utils.segmentation import BatchBodySegment
+    g, gm = golden(tag), golden_mask(tag)
+    t, prior, conf = _fitting_inputs(g, full)
+    batch = g['verts'].shape[0]
+    regions, pairs = gio.unpack_regions(g)
+    cdict = {'classes': [list(p) for p in pairs], 'csig': regions}
+    face_tensor = t(g['faces'])[None].repeat(batch, 1, 1)
+    segs = gio.unpack_segments(g)
+    segments = BatchBodySegment(list(segs.keys()), face_tensor[0], segs) if sg == 'seg' else None
+    verts = t(g['verts']).requires_grad_(True)
+    mj = t(g['model_joints']).requires_grad_(True)
+    pose = t(g['body_pose']).requires_grad_(True)
+    loss = contact_fitting_loss(
+        pose, t(g['global_orient']), None, None, t(g['betas']), mj, t(gm),
+        0.0 if eu == 'e0' else float(g['euclthres']), t(g['camera_t']), t(g['camera_center']),
+        t(g['joints_2d']), conf, prior, cdict, [t(g['gt_contact']), None], t(g['ignore_idxs']),
+        t(g['has_discrete_contact']), verts, face_tensor=face_tensor, focal_length=5000.,
+        contact_loss_weight=float(g['contact_loss_weight']), segments=segments)
+    loss.backward()
+    key = 'smplify_%s_%s_%s' % (eu, sg, 'full' if full else 'contact')
+    # the r2r term enters by value with weight 2000: its bmm-form reference value carries ~1e-6
+    # absolute noise per selected pair (DESIGN.md "Parity")
+    n_sel = float(((g['gt_contact'] == 1) & g['has_discrete_contact'][:, None]).sum())
+    assert_close(loss.item(), g[key + '_loss'], 1e-4, 2000 * 1e-6 * n_sel, key)
+    gv = g[key + '_grad_verts']
+    assert_close(verts.grad.cpu().numpy(), gv, 1e-3, 2e-6 * np.abs(gv).max(), key + ' grad verts')
+    if full:
+        gj = g[key + '_grad_joints']
+        assert_close(mj.grad.cpu().numpy(), gj, 1e-3, 1e-5 * np.abs(gj).max(), key + ' grad joints')
+        gp = g[key + '_grad_pose']
+        assert_close(pose.grad.cpu().numpy(), gp, 1e-3, 1e-5 * np.abs(gp).max(), key + ' grad pose')

@@ -1,0 +1,131 @@
+"""Drop-in for the reference's ``tuch/smplify/losses.py`` (same function names and argument
+lists).  The contact part of ``contact_fitting_loss`` -- the per-body Python loop of
+losses.py:74-117 -- is one batched pass over the HIP kernels; reprojection, GMoF and the
+priors are [B,49]-sized torch ops (K8).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..utils.geometry import perspective_projection
+
+_MODEL_CACHE: Dict[tuple, ops.ContactModel] = {}
+
+
+def gmof(x, sigma):
+    """Geman-McClure robustifier sigma^2 x^2 / (sigma^2 + x^2) (reference: losses.py:25-32)."""
+    x2, s2 = x ** 2, sigma ** 2
+    return (s2 * x2) / (s2 + x2)
+
+
+def contact_model_for(geomask, face_tensor, segments=None, cdict=None, device=None) -> ops.ContactModel:
+    """The device-side constants for one (geomask, faces, segments, regions) combination, built
+    on first use and cached: the reference passes these objects on every call
+    (smplifydc.py:162-179) and keeps them alive for the whole run."""
+    faces = face_tensor[0] if face_tensor.dim() == 3 else face_tensor
+    key = (geomask.data_ptr() if torch.is_tensor(geomask) else id(geomask), faces.data_ptr(),
+           id(segments), id(cdict))
+    model = _MODEL_CACHE.get(key)
+    if model is None:
+        seg_tables = segments.tables() if segments is not None else None
+        regions = pairs = None
+        if cdict is not None and len(cdict.get('classes', [])) > 0:
+            names = list(cdict['csig'].keys())
+            index = {n: i for i, n in enumerate(names)}
+            regions = [np.asarray(cdict['csig'][n], dtype=np.int64) for n in names]
+            pairs = np.asarray([[index[str(p[0])], index[str(p[1])]] for p in cdict['classes']], np.int64)
+        model = ops.ContactModel(faces, geomask, seg_tables, regions, pairs,
+                                 device=device if device is not None else faces.device)
+        _MODEL_CACHE[key] = model
+    return model
+
+
+def _reprojection(model_joints, camera_t, camera_center, joints_2d, joints_conf, focal_length, sigma):
+    batch = model_joints.shape[0]
+    eye = torch.eye(3, device=model_joints.device).unsqueeze(0).expand(batch, -1, -1)
+    proj = perspective_projection(model_joints, eye, camera_t, focal_length, camera_center)
+    return (joints_conf ** 2) * gmof(proj - joints_2d, sigma).sum(dim=-1)
+
+
+def contact_fitting_loss(body_pose, global_orient, body_pose_loop1, opt_global_orient_smplifyloop1,
+                         betas, model_joints, geomask, euclthres,
+                         camera_t, camera_center,
+                         joints_2d, joints_conf, pose_prior,
+                         cdict, gt_contact,
+                         ignore_idxs,
+                         has_discrete_contact,
+                         verts, face_tensor=None,
+                         device=None,
+                         focal_length=5000, sigma=100, pose_prior_weight=1.0,
+                         shape_prior_weight=1.0, angle_prior_weight=1.0,
+                         contact_loss_weight=1000, output='sum',
+                         segments=None):
+    """SMPLify-DC stage-2 objective (reference: losses.py:34-123):
+
+        sum_b [ sum_j conf^2 gmof(proj - j2d) + 10 * contact_b + ppw^2 prior_b + clw * r2r_b ]
+
+    contact_b = sum_{interior} tanh^2(d/0.04) + sum_{exterior, d<euclthres} 0.005 tanh^2(d/0.005)
+    with d_i the distance to the nearest geodesically-far vertex; r2r_b = sum over the annotated
+    region pairs of the (geodesically masked) minimum squared distance between the regions.
+    Bodies in ``ignore_idxs`` get neither contact term.  ``device`` is accepted for signature
+    compatibility; the computation runs where ``verts`` lives.
+    """
+    reprojection_loss = _reprojection(model_joints, camera_t, camera_center, joints_2d, joints_conf,
+                                      focal_length, sigma)
+    pose_prior_loss = (pose_prior_weight ** 2) * pose_prior(body_pose, betas)
+
+    model = contact_model_for(geomask, face_tensor, segments, cdict, device=verts.device)
+    valid = (~ignore_idxs).to(torch.uint8).contiguous()
+    exterior = model.exterior_flags(verts, apply_segments=segments is not None)     # losses.py:79-89
+    _, partner = model.v2v_min(verts)                                               # losses.py:76-78,92-93
+    contact_loss, _ = ops.contact_terms(verts, partner, exterior, valid, ops.MODE_SMPLIFY, euclthres)
+
+    if model.num_pairs > 0 and gt_contact is not None and gt_contact[0] is not None:
+        select = (gt_contact[0] == 1) & has_discrete_contact.bool()[:, None] & (~ignore_idxs)[:, None]
+        r2r, _ = model.region_pair_min(verts, select=select, masked=True)           # losses.py:107-117
+        r2r_loss = r2r.sum(dim=1)
+    else:
+        r2r_loss = torch.zeros_like(contact_loss)
+
+    total_loss = reprojection_loss.sum(dim=-1) + 10 * contact_loss \
+        + pose_prior_loss + contact_loss_weight * r2r_loss
+    return total_loss.sum()
+
+
+def camera_fitting_loss(smpl_output, camera_t, camera_t_est, camera_center, joints_2d, joints_conf,
+                        focal_length=5000, depth_loss_weight=100, sigma=100, shape_prior_weight=0.0):
+    """Stage-1 objective for camera translation / betas (reference: losses.py:125-152)."""
+    reprojection_loss = _reprojection(smpl_output.joints, camera_t, camera_center, joints_2d, joints_conf,
+                                      focal_length, sigma)
+    depth_loss = (depth_loss_weight ** 2) * (camera_t[:, 2] - camera_t_est[:, 2]) ** 2
+    shape_prior_loss = (shape_prior_weight ** 2) * (smpl_output.betas ** 2).sum(dim=-1)
+    return (reprojection_loss.sum(dim=-1) + depth_loss + shape_prior_loss).sum()
+
+
+def angle_prior(pose):
+    """Exponential penalty on unnatural knee / elbow bending (reference: losses.py:155-162;
+    indices are into the 69-D body pose, hence the -3)."""
+    signs = torch.tensor([1., -1., -1., -1.], device=pose.device)
+    return torch.exp(pose[:, [55 - 3, 58 - 3, 12 - 3, 15 - 3]] * signs) ** 2
+
+
+def body_fitting_loss(body_pose, betas, model_joints, camera_t, camera_center,
+                      joints_2d, joints_conf, pose_prior,
+                      focal_length=5000, sigma=100, pose_prior_weight=4.78,
+                      shape_prior_weight=5, angle_prior_weight=15.2,
+                      output='sum'):
+    """SPIN's SMPLify objective, kept for the no-contact branch and for the final
+    per-joint reprojection report (reference: losses.py:164-198)."""
+    reprojection_loss = _reprojection(model_joints, camera_t, camera_center, joints_2d, joints_conf,
+                                      focal_length, sigma)
+    if output == 'reprojection':
+        return reprojection_loss
+    total = reprojection_loss.sum(dim=-1) \
+        + (pose_prior_weight ** 2) * pose_prior(body_pose, betas) \
+        + (angle_prior_weight ** 2) * angle_prior(body_pose).sum(dim=-1) \
+        + (shape_prior_weight ** 2) * (betas ** 2).sum(dim=-1)
+    return total.sum()

@@ -1,0 +1,161 @@
+"""Drop-in for the reference's ``tuch/smplify/smplifydc.py``: the SMPLify-DC optimiser.
+
+Same constructor and ``__call__`` signature / 7-tuple return as the reference
+(smplifydc.py:27-276).  Differences, all behind the interface:
+  * the assets the reference loads from disk inside ``__init__`` (SMPL .pkl, GMM prior,
+    constants.JOINT_IDS) may be injected (``smpl=``, ``pose_prior=``, ``ign_joints=``) because
+    they do not ship; with the licensed files present the reference's paths are used;
+  * the device follows the inputs (the reference hard-codes 'cuda');
+  * the contact term of every iteration is one batched pass over the HIP kernels.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .losses import body_fitting_loss, camera_fitting_loss, contact_fitting_loss
+from .prior import MaxMixturePrior
+
+# indices of ['OP Neck','OP RHip','OP LHip','Right Hip','Left Hip'] in SPIN's 49-joint layout
+# (constants.JOINT_IDS is not shipped)
+DEFAULT_IGNORED_JOINTS = [1, 9, 12, 27, 28]
+
+
+class SMPLifyDC():
+    """SMPLify with discrete self-contact: stage 1 fits camera translation (+ betas when contact is
+    used), stage 2 fits pose and global orientation against the contact objective."""
+
+    def __init__(self,
+                 step_size=1e-2,
+                 batch_size=66,
+                 num_iters=100,
+                 focal_length=5000,
+                 geodistssmpl=None,
+                 geothres=0.0,
+                 euclthres=0.0,
+                 device=torch.device('cuda'),
+                 smpl=None, pose_prior=None, ign_joints=None,
+                 smpl_model_dir=None, prior_folder=None):
+        self.device = device
+        self.focal_length = focal_length
+        self.step_size = step_size
+        self.ign_joints = list(DEFAULT_IGNORED_JOINTS if ign_joints is None else ign_joints)
+        self.num_iters = num_iters
+        if pose_prior is None:
+            pose_prior = MaxMixturePrior(prior_folder=prior_folder or 'data/essentials/spin',
+                                         num_gaussians=8, dtype=torch.float32)
+        self.pose_prior = pose_prior.to(device)
+        if smpl is None:
+            from ..models.smpl import SMPL
+            smpl = SMPL(smpl_model_dir or 'data/models/smpl', batch_size=batch_size, create_transl=False)
+        self.smpl = smpl.to(self.device)
+        self.face_tensor = torch.tensor(self.smpl.faces.astype(np.int64), dtype=torch.long,
+                                        device=self.device).unsqueeze_(0).repeat([batch_size, 1, 1])
+        self.geodistssmpl = geodistssmpl
+        self.geothres = geothres
+        self.geomask = self.geodistssmpl > self.geothres            # smplifydc.py:65 (strict >)
+        self.euclthres = euclthres
+
+    def __call__(self, init_pose, init_betas, init_cam_t,
+                 camera_center, keypoints_2d, use_contact=False,
+                 contactlist=[], gt_contact=None,
+                 ignore_idxs=None, has_discrete_contact=None,
+                 has_gt_keypoints=None, contact_loss_weight=1,
+                 contact_loss_return='sum', segments=None):
+        """Fit a batch of bodies.  Returns (vertices, joints, pose, betas, camera_translation,
+        reprojection_loss, optiverts) exactly like the reference (smplifydc.py:231-236)."""
+        camera_translation = init_cam_t.clone()
+        joints_2d = keypoints_2d[:, :, :2]
+        joints_conf = keypoints_2d[:, :, -1].clone()
+        body_pose = init_pose[:, 3:].detach().clone()
+        global_orient = init_pose[:, :3].detach().clone()
+        betas = init_betas.detach().clone()
+
+        # ---- stage 1: camera translation (+ shape with contact, + orientation without)
+        body_pose.requires_grad = False
+        camera_translation.requires_grad = True
+        global_orient.requires_grad = not use_contact
+        betas.requires_grad = bool(use_contact)
+        stage1 = [betas, camera_translation] if use_contact else [global_orient, camera_translation]
+        optimizer = torch.optim.Adam(stage1, lr=self.step_size, betas=(0.9, 0.999))
+        shape_prior_weight = 1.0 if use_contact else 0.0
+        for _ in range(self.num_iters):
+            out = self.smpl(global_orient=global_orient, body_pose=body_pose, betas=betas)
+            loss = camera_fitting_loss(out, camera_translation, init_cam_t, camera_center, joints_2d,
+                                       joints_conf, focal_length=self.focal_length,
+                                       shape_prior_weight=shape_prior_weight)
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
+
+        # ---- stage 2: pose + global orientation
+        optiverts = []
+        joints_conf[:, self.ign_joints] = 0.0                        # smplifydc.py:153,198
+        camera_translation.requires_grad = False
+        body_pose.requires_grad = True
+        global_orient.requires_grad = True
+        if use_contact:
+            pose_stage1 = body_pose.clone()
+            orient_stage1 = global_orient.clone()
+            betas.requires_grad = False
+            optimizer = torch.optim.Adam([body_pose, global_orient], lr=self.step_size)
+            for _ in range(self.num_iters):
+                out = self.smpl(global_orient=global_orient, body_pose=body_pose, betas=betas)
+                optiverts += [out.vertices]
+                loss = contact_fitting_loss(body_pose, global_orient, pose_stage1, orient_stage1,
+                                            betas, out.joints, self.geomask, self.euclthres,
+                                            camera_translation, camera_center, joints_2d, joints_conf,
+                                            self.pose_prior, cdict=contactlist, gt_contact=gt_contact,
+                                            ignore_idxs=ignore_idxs,
+                                            has_discrete_contact=has_discrete_contact,
+                                            verts=out.vertices, face_tensor=self.face_tensor,
+                                            focal_length=self.focal_length,
+                                            contact_loss_weight=contact_loss_weight,
+                                            output=contact_loss_return, segments=segments)
+                optimizer.zero_grad()
+                loss.backward()
+                optimizer.step()
+        else:
+            betas.requires_grad = True
+            optimizer = torch.optim.Adam([body_pose, betas, global_orient], lr=self.step_size,
+                                         betas=(0.9, 0.999))
+            for _ in range(self.num_iters):
+                out = self.smpl(global_orient=global_orient, body_pose=body_pose, betas=betas)
+                optiverts += [out.vertices]
+                loss = body_fitting_loss(body_pose, betas, out.joints, camera_translation, camera_center,
+                                         joints_2d, joints_conf, self.pose_prior,
+                                         focal_length=self.focal_length)
+                optimizer.zero_grad()
+                loss.backward()
+                optimizer.step()
+        if len(optiverts) == 0:
+            optiverts = None
+
+        # ---- final evaluation
+        with torch.no_grad():
+            out = self.smpl(global_orient=global_orient, body_pose=body_pose, betas=betas,
+                            return_full_pose=True)
+            if has_gt_keypoints is not None:
+                joints_conf[has_gt_keypoints, :25] = 0
+            reprojection_loss = body_fitting_loss(body_pose, betas, out.joints, camera_translation,
+                                                  camera_center, joints_2d, joints_conf, self.pose_prior,
+                                                  focal_length=self.focal_length, output='reprojection')
+        pose = torch.cat([global_orient, body_pose], dim=-1).detach()
+        return (out.vertices.detach(), out.joints.detach(), pose, betas.detach(), camera_translation,
+                reprojection_loss, optiverts)
+
+    def get_fitting_loss(self, pose, betas, cam_t, camera_center, keypoints_2d, has_gt_keypoints=None):
+        """Per-joint reprojection loss of given parameters (reference: smplifydc.py:238-276;
+        like the reference, zeroing the ignored joints writes through into ``keypoints_2d``)."""
+        joints_2d = keypoints_2d[:, :, :2]
+        joints_conf = keypoints_2d[:, :, -1]
+        joints_conf[:, self.ign_joints] = 0.
+        if has_gt_keypoints is not None:
+            joints_conf = joints_conf.clone()
+            joints_conf[has_gt_keypoints, :25] = 0
+        with torch.no_grad():
+            out = self.smpl(global_orient=pose[:, :3], body_pose=pose[:, 3:], betas=betas,
+                            return_full_pose=True)
+            return body_fitting_loss(pose[:, 3:], betas, out.joints, cam_t, camera_center, joints_2d,
+                                     joints_conf, self.pose_prior, focal_length=self.focal_length,
+                                     output='reprojection')
