@@ -121,6 +121,33 @@ int tuch_region_pair_min(const tuch_contact_model* model, const float* verts, in
 int tuch_region_pair_min_bwd(const tuch_contact_model* model, const float* verts, int B, const int32_t* ij,
                              const float* grad_out, float* grad_verts, void* stream);
 
+/* ---- SMPL forward / backward: tuch/models/smpl.py:34-56 over smplx 0.1.13 lbs() -------------
+ * Model arrays are HOST pointers in the layouts smplx registers them: v_template [V,3],
+ * shapedirs [V,3,10], posedirs [207,3V], J_regressor [24,V], lbs_weights [V,24], parents [24],
+ * extra_vertex_ids [21] (smplx VertexJointSelector), J_regressor_extra [9,V] and joint_map [49]
+ * (models/smpl.py:39-42). */
+typedef struct tuch_smpl_model tuch_smpl_model;
+
+int tuch_smpl_model_create(tuch_smpl_model** out, int V, const float* v_template, const float* shapedirs,
+                           const float* posedirs, const float* J_regressor, const float* lbs_weights,
+                           const int32_t* parents, const int32_t* extra_vertex_ids,
+                           const float* J_regressor_extra, const int32_t* joint_map);
+void tuch_smpl_model_destroy(tuch_smpl_model* model);
+int tuch_smpl_model_info(const tuch_smpl_model* model, int* V);
+
+/* SMPL.forward(betas, body_pose, global_orient, pose2rot): betas [B,10]; pose [B,72] axis-angle
+ * (pose2rot != 0) or [B,24,3,3] rotation matrices -> vertices [B,V,3], joints [B,49,3].
+ * The forward workspace keeps the intermediates tuch_smpl_backward needs. */
+size_t tuch_smpl_forward_workspace_bytes(const tuch_smpl_model* model, int B);
+int tuch_smpl_forward(const tuch_smpl_model* model, const float* betas, const float* pose, int pose2rot, int B,
+                      float* verts, float* joints, void* workspace, size_t workspace_bytes, void* stream);
+/* Adjoint: g_verts [B,V,3] / g_joints [B,49,3] (either may be NULL) -> g_betas [B,10],
+ * g_pose [B,72] or [B,24,3,3]. */
+size_t tuch_smpl_backward_workspace_bytes(const tuch_smpl_model* model, int B);
+int tuch_smpl_backward(const tuch_smpl_model* model, const float* pose, int pose2rot, int B,
+                       const void* fwd_workspace, const float* g_verts, const float* g_joints, float* g_betas,
+                       float* g_pose, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

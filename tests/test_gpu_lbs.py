@@ -1,0 +1,89 @@
+"""GPU: the HIP SMPL forward/backward (csrc/smpl_lbs.hip, through the C ABI) against the CPU
+oracle (float32 restatement of smplx lbs + fp64 truth of the same formulas).
+Tolerance: 1e-4 relative on vertices (north_star); observed ~1e-6."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close
+from oracle import lbs as ol
+from tuch_amd.synthetic import make_body, random_poses
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def bodies():
+    return {'tiny': make_body(10, 12, with_geodesics=False), 'full': make_body(84, 82, with_geodesics=False)}
+
+
+def _smpl(body):
+    from tuch_amd.models.smpl import SMPL
+    return SMPL(model_data=body).to(DEV)
+
+
+@pytest.mark.parametrize('size,batch', [('tiny', 1), ('tiny', 3), ('tiny', 17), ('full', 2), ('full', 64)])
+def test_forward_matches_oracle(bodies, size, batch):
+    body = bodies[size]
+    bp, go, be = random_poses(batch, 21 + batch)
+    t = lambda a: torch.tensor(a, device=DEV)
+    out = _smpl(body)(betas=t(be), body_pose=t(bp), global_orient=t(go))
+    t64 = lambda a: torch.tensor(a, dtype=torch.float64)
+    v64, j64 = ol.smpl_forward(ol.model_tensors(body, torch.float64), t64(be), t64(bp), t64(go))
+    assert out.vertices.shape == (batch, body.num_verts, 3) and out.joints.shape == (batch, 49, 3)
+    assert_close(out.vertices.cpu().numpy(), v64.numpy(), 1e-4, 5e-6, 'verts vs fp64')
+    assert_close(out.joints.cpu().numpy(), j64.numpy(), 1e-4, 5e-6, 'joints vs fp64')
+    v32, j32 = ol.smpl_forward(ol.model_tensors(body), torch.tensor(be), torch.tensor(bp), torch.tensor(go))
+    assert_close(out.vertices.cpu().numpy(), v32.numpy(), 1e-5, 5e-6, 'verts vs f32 oracle')
+
+
+@pytest.mark.parametrize('size,batch', [('tiny', 3), ('full', 5)])
+@pytest.mark.parametrize('pose2rot', [True, False])
+def test_backward_matches_oracle_autograd(bodies, size, batch, pose2rot):
+    body = bodies[size]
+    bp, go, be = random_poses(batch, 33)
+    rng = np.random.default_rng(5)
+    gv = rng.standard_normal((batch, body.num_verts, 3)).astype(np.float32)
+    gj = rng.standard_normal((batch, 49, 3)).astype(np.float32)
+    m64 = ol.model_tensors(body, torch.float64)
+    t64 = lambda a: torch.tensor(a, dtype=torch.float64)
+    be64 = t64(be).requires_grad_(True)
+    full64 = torch.cat([t64(go), t64(bp)], 1)
+    if pose2rot:
+        pose64 = full64.clone().requires_grad_(True)
+    else:
+        pose64 = ol.rodrigues(full64.reshape(-1, 3)).reshape(batch, 24, 3, 3).clone().requires_grad_(True)
+    v, j = ol.lbs(be64, pose64, m64, pose2rot=pose2rot)
+    picked = v[:, m64['extra_vertex_ids']]
+    extra = torch.einsum('bvk,jv->bjk', v, m64['J_regressor_extra'])
+    joints = torch.cat([j, picked, extra], 1)[:, m64['joint_map']]
+    ((v * t64(gv)).sum() + (joints * t64(gj)).sum()).backward()
+
+    smpl = _smpl(body)
+    t = lambda a: torch.tensor(a, device=DEV)
+    be_d = t(be).requires_grad_(True)
+    if pose2rot:
+        go_d, bp_d = t(go).requires_grad_(True), t(bp).requires_grad_(True)
+        out = smpl(betas=be_d, body_pose=bp_d, global_orient=go_d)
+    else:
+        rot = pose64.detach().to(torch.float32).to(DEV)
+        go_d, bp_d = rot[:, :1].clone().requires_grad_(True), rot[:, 1:].clone().requires_grad_(True)
+        out = smpl(betas=be_d, body_pose=bp_d, global_orient=go_d, pose2rot=False)
+    ((out.vertices * t(gv)).sum() + (out.joints * t(gj)).sum()).backward()
+    got_pose = torch.cat([go_d.grad.reshape(batch, -1), bp_d.grad.reshape(batch, -1)], 1).cpu().numpy()
+    want_pose = pose64.grad.reshape(batch, -1).numpy()
+    assert_close(got_pose, want_pose, 1e-3, 2e-4 * np.abs(want_pose).max(), 'grad pose')
+    want_b = be64.grad.numpy()
+    assert_close(be_d.grad.cpu().numpy(), want_b, 1e-3, 2e-4 * np.abs(want_b).max(), 'grad betas')
+
+
+def test_joints_only_and_verts_only_gradients(bodies):
+    body = bodies['tiny']
+    smpl = _smpl(body)
+    bp, go, be = [torch.tensor(a, device=DEV) for a in random_poses(2, 3)]
+    for which in ('joints', 'vertices'):
+        bp_ = bp.clone().requires_grad_(True)
+        out = smpl(betas=be, body_pose=bp_, global_orient=go)
+        getattr(out, which).sum().backward()
+        assert torch.isfinite(bp_.grad).all() and bp_.grad.abs().sum() > 0

@@ -69,16 +69,3 @@ def test_segment_face_tables_match_reference(tag):
     for name, w in zip(segs.keys(), want):
         assert np.array_equal(bbs.segmentation[name].segment_faces.numpy().ravel(), w)
         assert bbs.segmentation[name].append_idx == gg['faces'].max()
-
-
-def test_temporary_lbs_matches_oracle():
-    from oracle import lbs as ol
-    from tuch_amd.models.smpl import SMPL
-    from tuch_amd.synthetic import make_body, random_poses
-    body = make_body(12, 14, with_geodesics=False)
-    bp, go, be = random_poses(3, 5)
-    out = SMPL(model_data=body)(betas=torch.tensor(be), body_pose=torch.tensor(bp), global_orient=torch.tensor(go))
-    v, j = ol.smpl_forward(ol.model_tensors(body), torch.tensor(be), torch.tensor(bp), torch.tensor(go))
-    assert_close(out.vertices.numpy(), v.numpy(), 1e-5, 1e-6, 'verts')
-    assert_close(out.joints.numpy(), j.numpy(), 1e-5, 1e-6, 'joints')
-    assert out.joints.shape == (3, 49, 3)

@@ -48,6 +48,15 @@ _SIGNATURES = {
     'tuch_exterior_flags': (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_size_t, c_void_p]),
     'tuch_region_pair_min': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    'tuch_smpl_model_create': (c_int, [POINTER(c_void_p), c_int] + [c_void_p] * 9),
+    'tuch_smpl_model_destroy': (None, [c_void_p]),
+    'tuch_smpl_model_info': (c_int, [c_void_p, POINTER(c_int)]),
+    'tuch_smpl_forward_workspace_bytes': (c_size_t, [c_void_p, c_int]),
+    'tuch_smpl_backward_workspace_bytes': (c_size_t, [c_void_p, c_int]),
+    'tuch_smpl_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                  c_size_t, c_void_p]),
+    'tuch_smpl_backward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_size_t, c_void_p]),
     'tuch_region_pair_min_bwd': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 

@@ -1,0 +1,748 @@
+// SMPL linear blend skinning forward + backward on gfx950 (K7 of SURVEY.md §2.2).
+//
+// Replaces tuch/models/smpl.py:44-56, i.e. smplx 0.1.13 SMPL.forward -> lbs() (third-party,
+// SURVEY.md §3.3) + the 9 extra regressed joints and the 49-joint re-map:
+//   v_shaped = v_template + shapedirs.beta          J = J_regressor.v_shaped
+//   R = rodrigues(pose)   v_posed = v_shaped + posedirs^T.(R[1:] - I)
+//   (posed joints, A) = rigid chain(R, J)            verts = (sum_j W_vj A_j) [v_posed; 1]
+//   joints = cat(posed joints, verts[picked 21], J_regressor_extra.verts)[joint_map]
+//
+// Kernels (f32 throughout; MFMA = v_mfma_f32_16x16x4_f32, exact f32 FMA chains):
+//   pose_kernel        per body: Rodrigues, J = J_template + J_shapedirs.beta (the joint regressor
+//                      folded through the shape basis once at model creation), kinematic chain,
+//                      blend-feature row [R[1:]-I | beta | 1].
+//   blend_kernel       MFMA GEMM  v_posed[B, 3V] = feat[B,220] x [posedirs; shapedirs^T; v_template]
+//   skin_kernel        per (body, vertex): T = sum_j W_vj A_j (A wave-uniform, scalar loads), verts
+//   extra_joints_kernel MFMA split-K GEMM  J_regressor_extra[9,V] x verts[B][V,3]
+//   assemble_kernel    joints[49] via joint_map
+// Backward mirrors it: joints scatter, skinning adjoint (g_v_posed = T_R^T g_v and
+// g_A = W^T (g_v (x) [v_posed;1]) on MFMA), blend adjoint (MFMA split-K GEMM against the same
+// matrix), chain + Rodrigues adjoint per body.
+#include "common.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct tuch_smpl_model {
+    int V, N3;                 // vertices, 3V
+    float* blend;              // [kFeat][N3]: posedirs (207) | shapedirs^T (10) | v_template | 0 0
+    float* J_template;         // [24*3]
+    float* J_shapedirs;        // [24*3][10]
+    float* weights;            // [V][24]
+    float* Jrx;                // [9][V]  J_regressor_extra
+    int32_t* parents;          // [24]
+    int32_t* extra_ids;        // [21]
+    int32_t* joint_map;        // [49]
+    int parents_host[24];
+};
+
+namespace {
+
+constexpr int kJoints = 24;
+constexpr int kBetas = 10;
+constexpr int kPoseFeat = 207;
+constexpr int kFeat = 220;            // 207 + 10 + 1, padded to a multiple of 4
+constexpr int kPicked = 21;
+constexpr int kExtra = 9;
+constexpr int kAllJoints = kJoints + kPicked + kExtra;   // 54
+constexpr int kOutJoints = 49;
+constexpr int kXChunks = 32;          // split-K chunks of the extra-joint regression
+constexpr int kBlendBwdChunk = 256;   // columns of 3V per split-K chunk in the blend adjoint
+constexpr int kSkinBlock = 256;
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// ---------------------------------------------------------------------------------- 3x3 helpers
+struct M3 { float m[9]; };
+__device__ __forceinline__ M3 mul(const M3& a, const M3& b)
+{
+    M3 r;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            r.m[3 * i + j] = a.m[3 * i] * b.m[j] + a.m[3 * i + 1] * b.m[3 + j] + a.m[3 * i + 2] * b.m[6 + j];
+    return r;
+}
+__device__ __forceinline__ M3 mul_nt(const M3& a, const M3& b)   // a * b^T
+{
+    M3 r;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            r.m[3 * i + j] = a.m[3 * i] * b.m[3 * j] + a.m[3 * i + 1] * b.m[3 * j + 1] + a.m[3 * i + 2] * b.m[3 * j + 2];
+    return r;
+}
+__device__ __forceinline__ M3 mul_tn(const M3& a, const M3& b)   // a^T * b
+{
+    M3 r;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            r.m[3 * i + j] = a.m[i] * b.m[j] + a.m[3 + i] * b.m[3 + j] + a.m[6 + i] * b.m[6 + j];
+    return r;
+}
+__device__ __forceinline__ void mulv(const M3& a, const float* v, float* o)
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[i] = a.m[3 * i] * v[0] + a.m[3 * i + 1] * v[1] + a.m[3 * i + 2] * v[2];
+}
+__device__ __forceinline__ void mulv_t(const M3& a, const float* v, float* o)   // a^T v
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[i] = a.m[i] * v[0] + a.m[3 + i] * v[1] + a.m[6 + i] * v[2];
+}
+
+// smplx batch_rodrigues: angle = |aa + 1e-8|, d = aa/angle, R = I + sin K + (1-cos) K^2
+__device__ __forceinline__ M3 rodrigues(const float* aa)
+{
+    const float ex = aa[0] + 1e-8f, ey = aa[1] + 1e-8f, ez = aa[2] + 1e-8f;
+    const float th = sqrtf(ex * ex + ey * ey + ez * ez);
+    const float x = aa[0] / th, y = aa[1] / th, z = aa[2] / th;
+    const float s = sinf(th), c1 = 1.0f - cosf(th);
+    // K^2 = d d^T - |d|^2 I
+    const float dd = x * x + y * y + z * z;
+    M3 r;
+    r.m[0] = 1.0f + c1 * (x * x - dd); r.m[1] = -s * z + c1 * x * y;      r.m[2] = s * y + c1 * x * z;
+    r.m[3] = s * z + c1 * x * y;       r.m[4] = 1.0f + c1 * (y * y - dd); r.m[5] = -s * x + c1 * y * z;
+    r.m[6] = -s * y + c1 * x * z;      r.m[7] = s * x + c1 * y * z;       r.m[8] = 1.0f + c1 * (z * z - dd);
+    return r;
+}
+
+// adjoint of rodrigues(): gR -> g_aa
+__device__ __forceinline__ void rodrigues_bwd(const float* aa, const M3& g, float* g_aa)
+{
+    const float ex = aa[0] + 1e-8f, ey = aa[1] + 1e-8f, ez = aa[2] + 1e-8f;
+    const float th = sqrtf(ex * ex + ey * ey + ez * ez);
+    const float d[3] = {aa[0] / th, aa[1] / th, aa[2] / th};
+    const float s = sinf(th), c = cosf(th), c1 = 1.0f - c;
+    const M3 K = {{0.f, -d[2], d[1], d[2], 0.f, -d[0], -d[1], d[0], 0.f}};
+    const M3 K2 = mul(K, K);
+    float g_th = 0.f;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) g_th += g.m[e] * (c * K.m[e] + s * K2.m[e]);
+    // gK = s G + (1-c) (G K^T + K^T G)
+    const M3 gkt = mul_nt(g, K), ktg = mul_tn(K, g);
+    M3 gK;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) gK.m[e] = s * g.m[e] + c1 * (gkt.m[e] + ktg.m[e]);
+    const float gd[3] = {gK.m[7] - gK.m[5], gK.m[2] - gK.m[6], gK.m[3] - gK.m[1]};
+    g_th += -(gd[0] * aa[0] + gd[1] * aa[1] + gd[2] * aa[2]) / (th * th);
+    g_aa[0] = gd[0] / th + g_th * ex / th;
+    g_aa[1] = gd[1] / th + g_th * ey / th;
+    g_aa[2] = gd[2] / th + g_th * ez / th;
+}
+
+// ------------------------------------------------------------------------------------ forward
+// One block (64 threads) per body.
+__global__ __launch_bounds__(64) void pose_kernel(
+    const float* __restrict__ betas, const float* __restrict__ pose, int pose2rot,
+    const float* __restrict__ J_template, const float* __restrict__ J_shapedirs,
+    const int32_t* __restrict__ parents,
+    float* __restrict__ R_out,      // [B,24,9]
+    float* __restrict__ J_out,      // [B,24,3]
+    float* __restrict__ world_out,  // [B,24,12] world rotation | world translation (= posed joint)
+    float* __restrict__ A_out,      // [B,24,12] rotation | translation relative to the rest pose
+    float* __restrict__ feat)       // [Bpad,220]
+{
+    __shared__ float sR[kJoints][9];
+    __shared__ float sJ[kJoints][3];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float* be = betas + (size_t)b * kBetas;
+    if (t < kJoints) {
+        M3 r;
+        if (pose2rot) r = rodrigues(pose + ((size_t)b * kJoints + t) * 3);
+        else {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) r.m[e] = pose[((size_t)b * kJoints + t) * 9 + e];
+        }
+#pragma unroll
+        for (int e = 0; e < 9; ++e) {
+            sR[t][e] = r.m[e];
+            R_out[((size_t)b * kJoints + t) * 9 + e] = r.m[e];
+            if (t > 0) feat[(size_t)b * kFeat + (t - 1) * 9 + e] = r.m[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
+        }
+    }
+    for (int i = t; i < kJoints * 3; i += 64) {
+        float acc = J_template[i];
+#pragma unroll
+        for (int l = 0; l < kBetas; ++l) acc += J_shapedirs[i * kBetas + l] * be[l];
+        sJ[i / 3][i % 3] = acc;
+        J_out[(size_t)b * kJoints * 3 + i] = acc;
+    }
+    if (t < kBetas) feat[(size_t)b * kFeat + kPoseFeat + t] = be[t];
+    if (t == 0) {
+        feat[(size_t)b * kFeat + 217] = 1.0f;
+        feat[(size_t)b * kFeat + 218] = 0.0f;
+        feat[(size_t)b * kFeat + 219] = 0.0f;
+    }
+    __syncthreads();
+    if (t == 0) {
+        float* W = world_out + (size_t)b * kJoints * 12;
+        float* A = A_out + (size_t)b * kJoints * 12;
+        for (int k = 0; k < kJoints; ++k) {
+            M3 rk;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) rk.m[e] = sR[k][e];
+            M3 rw;
+            float tw[3];
+            if (k == 0) {
+                rw = rk;
+                tw[0] = sJ[0][0]; tw[1] = sJ[0][1]; tw[2] = sJ[0][2];
+            } else {
+                const int p = parents[k];
+                M3 rp;
+#pragma unroll
+                for (int e = 0; e < 9; ++e) rp.m[e] = W[p * 12 + e];
+                rw = mul(rp, rk);
+                const float rel[3] = {sJ[k][0] - sJ[p][0], sJ[k][1] - sJ[p][1], sJ[k][2] - sJ[p][2]};
+                mulv(rp, rel, tw);
+                tw[0] += W[p * 12 + 9]; tw[1] += W[p * 12 + 10]; tw[2] += W[p * 12 + 11];
+            }
+            float rj[3];
+            mulv(rw, sJ[k], rj);
+#pragma unroll
+            for (int e = 0; e < 9; ++e) { W[k * 12 + e] = rw.m[e]; A[k * 12 + e] = rw.m[e]; }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { W[k * 12 + 9 + c] = tw[c]; A[k * 12 + 9 + c] = tw[c] - rj[c]; }
+        }
+    }
+}
+
+// v_posed[b][n] = sum_k feat[b][k] * blend[k][n].  One wave per (16 bodies, 64 columns).
+__global__ __launch_bounds__(256) void blend_kernel(
+    const float* __restrict__ feat, const float* __restrict__ blend, int B, int N3,
+    float* __restrict__ v_posed)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int strip = blockIdx.x * 4 + wave;
+    const int n0 = strip * 64;
+    if (n0 >= N3) return;
+    const int m0 = blockIdx.y * 16;
+    const int lm = lane & 15, lq = lane >> 4;
+    const int row = min(m0 + lm, B - 1);
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int col[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) col[j] = min(n0 + j * 16 + lm, N3 - 1);
+    for (int k0 = 0; k0 < kFeat; k0 += 4) {
+        const float a = feat[(size_t)row * kFeat + k0 + lq];
+        const float* brow = blend + (size_t)(k0 + lq) * N3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, brow[col[j]], acc[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + j * 16 + lm;
+        if (n >= N3) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + lq * 4 + r;
+            if (m < B) v_posed[(size_t)m * N3 + n] = acc[j][r];
+        }
+    }
+}
+
+// verts[b][v] = (sum_j W[v][j] A[b][j]) [v_posed[b][v]; 1]
+__global__ __launch_bounds__(kSkinBlock) void skin_kernel(
+    const float* __restrict__ v_posed, const float* __restrict__ A, const float* __restrict__ weights,
+    int V, float* __restrict__ verts)
+{
+    const int b = blockIdx.y;
+    const int v = blockIdx.x * kSkinBlock + threadIdx.x;
+    if (v >= V) return;
+    const float* Ab = A + (size_t)b * kJoints * 12;   // wave-uniform -> scalar loads
+    const float* w = weights + (size_t)v * kJoints;
+    float T[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) T[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < kJoints; ++j) {
+        const float wj = w[j];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) T[e] = __builtin_fmaf(wj, Ab[j * 12 + e], T[e]);
+    }
+    const float* p = v_posed + ((size_t)b * V + v) * 3;
+    float* o = verts + ((size_t)b * V + v) * 3;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[i] = T[3 * i] * p[0] + T[3 * i + 1] * p[1] + T[3 * i + 2] * p[2] + T[9 + i];
+}
+
+// partial[chunk][m][n] = sum_{v in chunk} Jrx[m][v] * verts[b(n)][v][c(n)],  n = 3 b + c.
+// One wave per (16-column block of n, K chunk).
+__global__ __launch_bounds__(64) void extra_joints_kernel(
+    const float* __restrict__ Jrx, const float* __restrict__ verts, int B, int V, int v_per_chunk,
+    float* __restrict__ partial)   // [kXChunks][16][Npad], Npad = 16 * gridDim.x
+{
+    const int lane = threadIdx.x, lm = lane & 15, lq = lane >> 4;
+    const int n = blockIdx.x * 16 + lm;
+    const int chunk = blockIdx.y;
+    const int nb = min(n / 3, B - 1), nc = n % 3;
+    const bool n_ok = n < 3 * B;
+    const int v_beg = chunk * v_per_chunk, v_end = min(V, v_beg + v_per_chunk);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int v0 = v_beg; v0 < v_end; v0 += 4) {
+        const int v = v0 + lq;
+        const bool ok = v < v_end;
+        const float a = (ok && lm < kExtra) ? Jrx[(size_t)lm * V + v] : 0.f;
+        const float bb = (ok && n_ok) ? verts[((size_t)nb * V + v) * 3 + nc] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb, acc, 0, 0, 0);
+    }
+    const int npad = 16 * gridDim.x;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        partial[((size_t)chunk * 16 + lq * 4 + r) * npad + n] = acc[r];
+}
+
+__global__ __launch_bounds__(64) void assemble_joints_kernel(
+    const float* __restrict__ world, const float* __restrict__ verts, const float* __restrict__ partial,
+    const int32_t* __restrict__ extra_ids, const int32_t* __restrict__ joint_map, int V, int npad,
+    float* __restrict__ joints)   // [B,49,3]
+{
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < kOutJoints * 3; i += 64) {
+        const int src = joint_map[i / 3], c = i % 3;
+        float val;
+        if (src < kJoints) val = world[((size_t)b * kJoints + src) * 12 + 9 + c];
+        else if (src < kJoints + kPicked) val = verts[((size_t)b * V + extra_ids[src - kJoints]) * 3 + c];
+        else {
+            val = 0.f;
+            const int m = src - kJoints - kPicked;
+            for (int ch = 0; ch < kXChunks; ++ch) val += partial[((size_t)ch * 16 + m) * npad + 3 * b + c];
+        }
+        joints[(size_t)b * kOutJoints * 3 + i] = val;
+    }
+}
+
+// ----------------------------------------------------------------------------------- backward
+// g_all[b][54][3] = scatter of g_joints through joint_map (deterministic gather form)
+__global__ __launch_bounds__(64) void joints_bwd_kernel(
+    const float* __restrict__ g_joints, const int32_t* __restrict__ joint_map, float* __restrict__ g_all)
+{
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < kAllJoints * 3; i += 64) {
+        const int src = i / 3, c = i % 3;
+        float acc = 0.f;
+        if (g_joints)
+            for (int o = 0; o < kOutJoints; ++o)
+                if (joint_map[o] == src) acc += g_joints[((size_t)b * kOutJoints + o) * 3 + c];
+        g_all[(size_t)b * kAllJoints * 3 + i] = acc;
+    }
+}
+
+// Skinning adjoint.  Per (body, 256-vertex block):
+//   g_v      = g_verts + Jrx^T g_extra + picked-vertex gradients
+//   g_vposed = T_R^T g_v
+//   gA_part[b][block][j][n] = sum_v W[v][j] * (g_v (x) [v_posed; 1])[n]      (MFMA, K = vertices)
+__global__ __launch_bounds__(kSkinBlock) void skin_bwd_kernel(
+    const float* __restrict__ g_verts, const float* __restrict__ g_all, const float* __restrict__ Jrx,
+    const int32_t* __restrict__ extra_ids, const float* __restrict__ v_posed, const float* __restrict__ A,
+    const float* __restrict__ weights, int V, float* __restrict__ g_vposed, float* __restrict__ gA_part)
+{
+    __shared__ float sG[kSkinBlock][16];      // per vertex: g_v (x) [v_posed;1], 12 used
+    const int b = blockIdx.y;
+    const int v = blockIdx.x * kSkinBlock + threadIdx.x;
+    const bool ok = v < V;
+    const int vc = ok ? v : V - 1;
+    const float* ga = g_all + (size_t)b * kAllJoints * 3;
+    float g[3] = {0.f, 0.f, 0.f};
+    if (g_verts) {
+        const float* gp = g_verts + ((size_t)b * V + vc) * 3;
+        g[0] = gp[0]; g[1] = gp[1]; g[2] = gp[2];
+    }
+#pragma unroll
+    for (int j = 0; j < kExtra; ++j) {
+        const float w = Jrx[(size_t)j * V + vc];
+        const float* gj = ga + (kJoints + kPicked + j) * 3;
+        g[0] = __builtin_fmaf(w, gj[0], g[0]); g[1] = __builtin_fmaf(w, gj[1], g[1]); g[2] = __builtin_fmaf(w, gj[2], g[2]);
+    }
+    for (int e = 0; e < kPicked; ++e)
+        if (extra_ids[e] == vc) {
+            const float* gj = ga + (kJoints + e) * 3;
+            g[0] += gj[0]; g[1] += gj[1]; g[2] += gj[2];
+        }
+    if (!ok) { g[0] = 0.f; g[1] = 0.f; g[2] = 0.f; }
+    const float* Ab = A + (size_t)b * kJoints * 12;
+    const float* w = weights + (size_t)vc * kJoints;
+    float T[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) T[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < kJoints; ++j) {
+        const float wj = w[j];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) T[e] = __builtin_fmaf(wj, Ab[j * 12 + e], T[e]);
+    }
+    const float* p = v_posed + ((size_t)b * V + vc) * 3;
+    const float ph[4] = {p[0], p[1], p[2], 1.0f};
+    if (ok) {
+        float* o = g_vposed + ((size_t)b * V + v) * 3;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) o[i] = T[i] * g[0] + T[3 + i] * g[1] + T[6 + i] * g[2];
+    }
+    // G[n]: n = 3*i + c for the rotation part (i row of A, c column), 9 + i for the translation
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sG[threadIdx.x][3 * i + c] = g[i] * ph[c];
+        sG[threadIdx.x][9 + i] = g[i];
+    }
+#pragma unroll
+    for (int n = 12; n < 16; ++n) sG[threadIdx.x][n] = 0.f;
+    __syncthreads();
+    // waves 0,1 reduce joints 0-15 / 16-31 over the block's 256 vertices
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lm = lane & 15, lq = lane >> 4;
+    if (wave < 2) {
+        const int j = wave * 16 + lm;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int vbase = blockIdx.x * kSkinBlock;
+        for (int k0 = 0; k0 < kSkinBlock; k0 += 4) {
+            const int vv = vbase + k0 + lq;
+            const float a = (j < kJoints && vv < V) ? weights[(size_t)vv * kJoints + j] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, sG[k0 + lq][lm], acc, 0, 0, 0);
+        }
+        float* out = gA_part + (((size_t)b * gridDim.x + blockIdx.x) * 32 + wave * 16) * 16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(lq * 4 + r) * 16 + lm] = acc[r];
+    }
+}
+
+// g_feat partial: [chunk][m][n] = sum_{k in chunk} g_vposed[m][k] * blend[n][k];  n < 224.
+// One wave per (16 bodies, K chunk); K index permuted so that every lane reads float4s.
+__global__ __launch_bounds__(64) void blend_bwd_kernel(
+    const float* __restrict__ g_vposed, const float* __restrict__ blend, int B, int N3,
+    float* __restrict__ part)   // [chunks][Bpad][224]
+{
+    const int lane = threadIdx.x, lm = lane & 15, lq = lane >> 4;
+    const int chunk = blockIdx.x, m0 = blockIdx.y * 16;
+    const int k_beg = chunk * kBlendBwdChunk, k_end = min(N3, k_beg + kBlendBwdChunk);
+    const int row = min(m0 + lm, B - 1);
+    const bool row_ok = m0 + lm < B;
+    f32x4 acc[14];
+#pragma unroll
+    for (int j = 0; j < 14; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = k_beg; k0 < k_end; k0 += 16) {
+        // lane group q covers k0 + 4q .. k0 + 4q + 3 over the four MFMA steps
+        const int kk = k0 + 4 * lq;
+        float a4[4], b4[14][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = kk + s;
+            const bool k_ok = k < k_end;
+            a4[s] = (row_ok && k_ok) ? g_vposed[(size_t)row * N3 + k] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 14; ++j) {
+                const int n = j * 16 + lm;
+                b4[j][s] = (k_ok && n < kFeat) ? blend[(size_t)n * N3 + k] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < 14; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s], b4[j][s], acc[j], 0, 0, 0);
+    }
+    const int bpad = gridDim.y * 16;
+#pragma unroll
+    for (int j = 0; j < 14; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            part[((size_t)chunk * bpad + m0 + lq * 4 + r) * 224 + j * 16 + lm] = acc[j][r];
+}
+
+// Per body: reduce the partials, chain adjoint, Rodrigues adjoint, shape gradient.
+__global__ __launch_bounds__(64) void pose_bwd_kernel(
+    const float* __restrict__ gA_part, int skin_blocks, const float* __restrict__ feat_part, int feat_chunks,
+    int bpad, const float* __restrict__ g_all, const float* __restrict__ R, const float* __restrict__ J,
+    const float* __restrict__ world, const float* __restrict__ pose, int pose2rot,
+    const float* __restrict__ J_shapedirs, const int32_t* __restrict__ parents,
+    float* __restrict__ g_pose, float* __restrict__ g_betas)
+{
+    __shared__ float sGA[kJoints][12];
+    __shared__ float sGF[224];
+    __shared__ float sGR[kJoints][9];
+    __shared__ float sGJ[kJoints][3];
+    const int b = blockIdx.x, t = threadIdx.x;
+    for (int i = t; i < kJoints * 12; i += 64) {
+        const int j = i / 12, n = i % 12;
+        float acc = 0.f;
+        for (int s = 0; s < skin_blocks; ++s) acc += gA_part[(((size_t)b * skin_blocks + s) * 32 + j) * 16 + n];
+        sGA[j][n] = acc;
+    }
+    for (int i = t; i < 224; i += 64) {
+        float acc = 0.f;
+        for (int c = 0; c < feat_chunks; ++c) acc += feat_part[((size_t)c * bpad + b) * 224 + i];
+        sGF[i] = acc;
+    }
+    __syncthreads();
+    if (t == 0) {
+        const float* Jb = J + (size_t)b * kJoints * 3;
+        const float* Wb = world + (size_t)b * kJoints * 12;
+        const float* Rb = R + (size_t)b * kJoints * 9;
+        const float* gtw_in = g_all + (size_t)b * kAllJoints * 3;
+        float gRw[kJoints][9], gtw[kJoints][3], gJ[kJoints][3];
+        for (int k = 0; k < kJoints; ++k) {
+            // A_k = [Rw | tw - Rw J]
+            const float* ga = sGA[k];
+            const float gt[3] = {ga[9], ga[10], ga[11]};
+            for (int i = 0; i < 3; ++i) {
+                gtw[k][i] = gtw_in[k * 3 + i] + gt[i];
+                for (int c = 0; c < 3; ++c) gRw[k][3 * i + c] = ga[3 * i + c] - gt[i] * Jb[k * 3 + c];
+            }
+            M3 rw;
+            for (int e = 0; e < 9; ++e) rw.m[e] = Wb[k * 12 + e];
+            float tmp[3];
+            mulv_t(rw, gt, tmp);
+            for (int c = 0; c < 3; ++c) gJ[k][c] = -tmp[c];
+        }
+        for (int k = kJoints - 1; k >= 1; --k) {
+            const int p = parents[k];
+            M3 rp, rk, g;
+            for (int e = 0; e < 9; ++e) { rp.m[e] = Wb[p * 12 + e]; rk.m[e] = Rb[k * 9 + e]; g.m[e] = gRw[k][e]; }
+            const float rel[3] = {Jb[k * 3] - Jb[p * 3], Jb[k * 3 + 1] - Jb[p * 3 + 1], Jb[k * 3 + 2] - Jb[p * 3 + 2]};
+            const M3 up = mul_nt(g, rk);                 // gRw_k R_k^T
+            for (int i = 0; i < 3; ++i)
+                for (int c = 0; c < 3; ++c) gRw[p][3 * i + c] += up.m[3 * i + c] + gtw[k][i] * rel[c];
+            const M3 gr = mul_tn(rp, g);                 // Rw_p^T gRw_k
+            for (int e = 0; e < 9; ++e) sGR[k][e] = gr.m[e];
+            float grel[3];
+            mulv_t(rp, gtw[k], grel);
+            for (int c = 0; c < 3; ++c) { gJ[k][c] += grel[c]; gJ[p][c] -= grel[c]; gtw[p][c] += gtw[k][c]; }
+        }
+        for (int e = 0; e < 9; ++e) sGR[0][e] = gRw[0][e];
+        for (int c = 0; c < 3; ++c) gJ[0][c] += gtw[0][c];
+        for (int k = 0; k < kJoints; ++k)
+            for (int c = 0; c < 3; ++c) sGJ[k][c] = gJ[k][c];
+    }
+    __syncthreads();
+    if (t < kJoints) {
+        M3 g;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) g.m[e] = sGR[t][e] + (t > 0 ? sGF[(t - 1) * 9 + e] : 0.f);
+        if (pose2rot) {
+            float ga[3];
+            rodrigues_bwd(pose + ((size_t)b * kJoints + t) * 3, g, ga);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g_pose[((size_t)b * kJoints + t) * 3 + c] = ga[c];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) g_pose[((size_t)b * kJoints + t) * 9 + e] = g.m[e];
+        }
+    }
+    if (t >= 32 && t < 32 + kBetas) {
+        const int l = t - 32;
+        float acc = sGF[kPoseFeat + l];
+        for (int i = 0; i < kJoints * 3; ++i) acc += J_shapedirs[i * kBetas + l] * sGJ[i / 3][i % 3];
+        g_betas[(size_t)b * kBetas + l] = acc;
+    }
+}
+
+struct FwdLayout { size_t R, J, world, A, feat, v_posed, partial, total; int bpad, npad; };
+
+FwdLayout fwd_layout(const tuch_smpl_model* m, int B)
+{
+    FwdLayout l;
+    l.bpad = ceil_div(B, 16) * 16;
+    l.npad = ceil_div(3 * B, 16) * 16;
+    size_t o = 0;
+    l.R = o;       o += align256((size_t)B * kJoints * 9 * 4);
+    l.J = o;       o += align256((size_t)B * kJoints * 3 * 4);
+    l.world = o;   o += align256((size_t)B * kJoints * 12 * 4);
+    l.A = o;       o += align256((size_t)B * kJoints * 12 * 4);
+    l.feat = o;    o += align256((size_t)l.bpad * kFeat * 4);
+    l.v_posed = o; o += align256((size_t)B * m->N3 * 4);
+    l.partial = o; o += align256((size_t)kXChunks * 16 * l.npad * 4);
+    l.total = o;
+    return l;
+}
+
+struct BwdLayout { size_t g_all, g_vposed, gA_part, feat_part, total; int skin_blocks, feat_chunks, bpad; };
+
+BwdLayout bwd_layout(const tuch_smpl_model* m, int B)
+{
+    BwdLayout l;
+    l.skin_blocks = ceil_div(m->V, kSkinBlock);
+    l.feat_chunks = ceil_div(m->N3, kBlendBwdChunk);
+    l.bpad = ceil_div(B, 16) * 16;
+    size_t o = 0;
+    l.g_all = o;     o += align256((size_t)B * kAllJoints * 3 * 4);
+    l.g_vposed = o;  o += align256((size_t)B * m->N3 * 4);
+    l.gA_part = o;   o += align256((size_t)B * l.skin_blocks * 32 * 16 * 4);
+    l.feat_part = o; o += align256((size_t)l.feat_chunks * l.bpad * 224 * 4);
+    l.total = o;
+    return l;
+}
+
+template <typename T>
+int upload(T** dst, const T* src, size_t count)
+{
+    *dst = nullptr;
+    if (hipMalloc((void**)dst, count * sizeof(T)) != hipSuccess ||
+        hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) {
+        tuch_set_error("tuch_smpl_model_create: device upload of %zu bytes failed", count * sizeof(T));
+        return TUCH_ERR_HIP;
+    }
+    return TUCH_OK;
+}
+
+}  // namespace
+
+extern "C" void tuch_smpl_model_destroy(tuch_smpl_model* m)
+{
+    if (!m) return;
+    void* dev[] = {m->blend, m->J_template, m->J_shapedirs, m->weights, m->Jrx, m->parents, m->extra_ids, m->joint_map};
+    for (void* p : dev)
+        if (p) (void)hipFree(p);
+    free(m);
+}
+
+// All arrays are HOST pointers in the layouts smplx registers them:
+// v_template [V,3], shapedirs [V,3,10], posedirs [207, 3V], J_regressor [24,V], lbs_weights [V,24],
+// parents [24] (parents[0] ignored), extra_vertex_ids [21], J_regressor_extra [9,V], joint_map [49].
+extern "C" int tuch_smpl_model_create(tuch_smpl_model** out, int V, const float* v_template,
+                                      const float* shapedirs, const float* posedirs, const float* J_regressor,
+                                      const float* lbs_weights, const int32_t* parents,
+                                      const int32_t* extra_vertex_ids, const float* J_regressor_extra,
+                                      const int32_t* joint_map)
+{
+    TUCH_REQUIRE(out && V > 0 && v_template && shapedirs && posedirs && J_regressor && lbs_weights && parents &&
+                     extra_vertex_ids && J_regressor_extra && joint_map, "tuch_smpl_model_create: null argument");
+    for (int k = 1; k < kJoints; ++k)
+        TUCH_REQUIRE(parents[k] >= 0 && parents[k] < k, "tuch_smpl_model_create: parents[%d]=%d is not a tree order", k, parents[k]);
+    for (int e = 0; e < kPicked; ++e)
+        TUCH_REQUIRE(extra_vertex_ids[e] >= 0 && extra_vertex_ids[e] < V, "tuch_smpl_model_create: bad picked vertex");
+    for (int o = 0; o < kOutJoints; ++o)
+        TUCH_REQUIRE(joint_map[o] >= 0 && joint_map[o] < kAllJoints, "tuch_smpl_model_create: bad joint_map entry");
+    tuch_smpl_model* m = (tuch_smpl_model*)calloc(1, sizeof(tuch_smpl_model));
+    m->V = V;
+    m->N3 = 3 * V;
+    const size_t n3 = (size_t)m->N3;
+    std::vector<float> blend((size_t)kFeat * n3, 0.f);
+    memcpy(blend.data(), posedirs, sizeof(float) * kPoseFeat * n3);
+    for (size_t n = 0; n < n3; ++n) {
+        for (int l = 0; l < kBetas; ++l) blend[(size_t)(kPoseFeat + l) * n3 + n] = shapedirs[n * kBetas + l];
+        blend[(size_t)217 * n3 + n] = v_template[n];
+    }
+    // joint regressor folded through the shape basis (double accumulation, rounded once)
+    std::vector<float> jt(kJoints * 3), js((size_t)kJoints * 3 * kBetas);
+    for (int j = 0; j < kJoints; ++j)
+        for (int c = 0; c < 3; ++c) {
+            double a = 0.0, s[kBetas] = {0};
+            for (int v = 0; v < V; ++v) {
+                const double w = J_regressor[(size_t)j * V + v];
+                a += w * v_template[(size_t)v * 3 + c];
+                for (int l = 0; l < kBetas; ++l) s[l] += w * shapedirs[((size_t)v * 3 + c) * kBetas + l];
+            }
+            jt[j * 3 + c] = (float)a;
+            for (int l = 0; l < kBetas; ++l) js[(size_t)(j * 3 + c) * kBetas + l] = (float)s[l];
+        }
+    int32_t par[kJoints];
+    memcpy(par, parents, sizeof(par));
+    par[0] = -1;
+    memcpy(m->parents_host, par, sizeof(par));
+    int rc = upload(&m->blend, blend.data(), blend.size());
+    if (rc == TUCH_OK) rc = upload(&m->J_template, jt.data(), jt.size());
+    if (rc == TUCH_OK) rc = upload(&m->J_shapedirs, js.data(), js.size());
+    if (rc == TUCH_OK) rc = upload(&m->weights, lbs_weights, (size_t)V * kJoints);
+    if (rc == TUCH_OK) rc = upload(&m->Jrx, J_regressor_extra, (size_t)kExtra * V);
+    if (rc == TUCH_OK) rc = upload(&m->parents, par, kJoints);
+    if (rc == TUCH_OK) rc = upload(&m->extra_ids, extra_vertex_ids, kPicked);
+    if (rc == TUCH_OK) rc = upload(&m->joint_map, joint_map, kOutJoints);
+    if (rc != TUCH_OK) {
+        tuch_smpl_model_destroy(m);
+        *out = nullptr;
+        return rc;
+    }
+    *out = m;
+    return TUCH_OK;
+}
+
+extern "C" size_t tuch_smpl_forward_workspace_bytes(const tuch_smpl_model* m, int B)
+{
+    return (m && B > 0) ? fwd_layout(m, B).total : 0;
+}
+
+extern "C" size_t tuch_smpl_backward_workspace_bytes(const tuch_smpl_model* m, int B)
+{
+    return (m && B > 0) ? bwd_layout(m, B).total : 0;
+}
+
+// pose: [B,72] axis-angle (pose2rot) or [B,24,3,3] rotation matrices.  The forward workspace
+// holds the intermediates the backward pass needs and must be kept alive until then.
+extern "C" int tuch_smpl_forward(const tuch_smpl_model* m, const float* betas, const float* pose, int pose2rot,
+                                 int B, float* verts, float* joints, void* workspace, size_t workspace_bytes,
+                                 void* stream)
+{
+    TUCH_REQUIRE(m && betas && pose && verts && joints, "tuch_smpl_forward: null pointer");
+    TUCH_REQUIRE(B > 0 && B <= 65535, "tuch_smpl_forward: bad batch %d", B);
+    const FwdLayout l = fwd_layout(m, B);
+    if (!workspace || workspace_bytes < l.total) {
+        tuch_set_error("tuch_smpl_forward: workspace %zu < %zu bytes", workspace_bytes, l.total);
+        return TUCH_ERR_WORKSPACE;
+    }
+    char* ws = (char*)workspace;
+    float *R = (float*)(ws + l.R), *J = (float*)(ws + l.J), *world = (float*)(ws + l.world), *A = (float*)(ws + l.A),
+          *feat = (float*)(ws + l.feat), *v_posed = (float*)(ws + l.v_posed), *partial = (float*)(ws + l.partial);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(pose_kernel, dim3(B), dim3(64), 0, s, betas, pose, pose2rot, (const float*)m->J_template,
+                       (const float*)m->J_shapedirs, (const int32_t*)m->parents, R, J, world, A, feat);
+    hipLaunchKernelGGL(blend_kernel, dim3(ceil_div(ceil_div(m->N3, 64), 4), l.bpad / 16), dim3(256), 0, s,
+                       (const float*)feat, (const float*)m->blend, B, m->N3, v_posed);
+    hipLaunchKernelGGL(skin_kernel, dim3(ceil_div(m->V, kSkinBlock), B), dim3(kSkinBlock), 0, s,
+                       (const float*)v_posed, (const float*)A, (const float*)m->weights, m->V, verts);
+    hipLaunchKernelGGL(extra_joints_kernel, dim3(l.npad / 16, kXChunks), dim3(64), 0, s, (const float*)m->Jrx,
+                       (const float*)verts, B, m->V, ceil_div(ceil_div(m->V, kXChunks), 4) * 4, partial);
+    hipLaunchKernelGGL(assemble_joints_kernel, dim3(B), dim3(64), 0, s, (const float*)world, (const float*)verts,
+                       (const float*)partial, (const int32_t*)m->extra_ids, (const int32_t*)m->joint_map, m->V,
+                       l.npad, joints);
+    return tuch_check_launch("tuch_smpl_forward");
+}
+
+// g_verts [B,V,3] and/or g_joints [B,49,3] (either may be NULL) -> g_betas [B,10] and
+// g_pose ([B,72] or [B,24,3,3]).
+extern "C" int tuch_smpl_backward(const tuch_smpl_model* m, const float* pose, int pose2rot, int B,
+                                  const void* fwd_workspace, const float* g_verts, const float* g_joints,
+                                  float* g_betas, float* g_pose, void* workspace, size_t workspace_bytes,
+                                  void* stream)
+{
+    TUCH_REQUIRE(m && pose && fwd_workspace && g_betas && g_pose, "tuch_smpl_backward: null pointer");
+    TUCH_REQUIRE(B > 0 && B <= 65535, "tuch_smpl_backward: bad batch %d", B);
+    const FwdLayout f = fwd_layout(m, B);
+    const BwdLayout l = bwd_layout(m, B);
+    if (!workspace || workspace_bytes < l.total) {
+        tuch_set_error("tuch_smpl_backward: workspace %zu < %zu bytes", workspace_bytes, l.total);
+        return TUCH_ERR_WORKSPACE;
+    }
+    const char* fw = (const char*)fwd_workspace;
+    const float *R = (const float*)(fw + f.R), *J = (const float*)(fw + f.J), *world = (const float*)(fw + f.world),
+                *A = (const float*)(fw + f.A), *v_posed = (const float*)(fw + f.v_posed);
+    char* ws = (char*)workspace;
+    float *g_all = (float*)(ws + l.g_all), *g_vposed = (float*)(ws + l.g_vposed), *gA_part = (float*)(ws + l.gA_part),
+          *feat_part = (float*)(ws + l.feat_part);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(joints_bwd_kernel, dim3(B), dim3(64), 0, s, g_joints, (const int32_t*)m->joint_map, g_all);
+    hipLaunchKernelGGL(skin_bwd_kernel, dim3(l.skin_blocks, B), dim3(kSkinBlock), 0, s, g_verts, (const float*)g_all,
+                       (const float*)m->Jrx, (const int32_t*)m->extra_ids, v_posed, A, (const float*)m->weights, m->V,
+                       g_vposed, gA_part);
+    hipLaunchKernelGGL(blend_bwd_kernel, dim3(l.feat_chunks, l.bpad / 16), dim3(64), 0, s, (const float*)g_vposed,
+                       (const float*)m->blend, B, m->N3, feat_part);
+    hipLaunchKernelGGL(pose_bwd_kernel, dim3(B), dim3(64), 0, s, (const float*)gA_part, l.skin_blocks,
+                       (const float*)feat_part, l.feat_chunks, l.bpad, (const float*)g_all, R, J, world, pose, pose2rot,
+                       (const float*)m->J_shapedirs, (const int32_t*)m->parents, g_pose, g_betas);
+    return tuch_check_launch("tuch_smpl_backward");
+}
+
+extern "C" int tuch_smpl_model_info(const tuch_smpl_model* m, int* V)
+{
+    TUCH_REQUIRE(m, "tuch_smpl_model_info: null model");
+    if (V) *V = m->V;
+    return TUCH_OK;
+}
