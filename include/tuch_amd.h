@@ -103,6 +103,10 @@ const uint64_t* tuch_contact_model_mask_bits(const tuch_contact_model* model);
 const int32_t* tuch_contact_model_faces(const tuch_contact_model* model);
 int tuch_contact_model_info(const tuch_contact_model* model, int* V, int* F, int* num_segments,
                             int* seg_q_total, int* num_pairs);
+/* The triangle-strip walk of the faces used by the winding kernel (inspection / tests):
+ * stream_len vertex ids with sign 0 (prime) or +-1 (emit triangle of the last three ids). */
+int tuch_contact_model_strips(const tuch_contact_model* model, int* stream_len, int* num_strips,
+                              int32_t* vidx_host, float* sign_host);
 
 /* exterior flags of losses.py:79-89 / loss.py:259-266: winding_numbers(verts, verts[faces]).le(thresh),
  * then BatchBodySegment.batch_has_self_isec (segmentation.py:117-124) and the re-marking of

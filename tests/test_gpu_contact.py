@@ -234,3 +234,26 @@ def test_contact_fitting_loss_vs_reference(tag, eu, sg, full):
         assert_close(mj.grad.cpu().numpy(), gj, 1e-3, 1e-5 * np.abs(gj).max(), key + ' grad joints')
         gp = g[key + '_grad_pose']
         assert_close(pose.grad.cpu().numpy(), gp, 1e-3, 1e-5 * np.abs(gp).max(), key + ' grad pose')
+
+
+@pytest.mark.parametrize('tag', TAGS)
+def test_triangle_strips_cover_every_face_once(tag):
+    g = golden(tag)
+    model = make_model(g, None, False, False)
+    vidx, sign, nstrips = model.strips()
+    faces = g['faces']
+    emitted = {}
+    for p in range(len(vidx)):
+        if sign[p] == 0:
+            continue
+        tri = (int(vidx[p - 2]), int(vidx[p - 1]), int(vidx[p]))
+        key = tuple(sorted(tri))
+        assert key not in emitted
+        emitted[key] = (tri, sign[p])
+    assert len(emitted) == len(faces)
+    for f in faces:
+        tri, sg = emitted[tuple(sorted(int(x) for x in f))]
+        rots = [tuple(int(x) for x in np.roll(f, k)) for k in range(3)]
+        assert (tri in rots) == (sg > 0)
+    assert (sign[:2] == 0).all() and nstrips >= 1
+    print(tag, 'faces', len(faces), 'stream', len(vidx), 'strips', nstrips)

@@ -8,6 +8,12 @@ struct tuch_contact_model {
     int V, F;
     int32_t* faces;            // [F,3]
     uint64_t* mask_bits;       // [W][V] or nullptr
+    // triangle strips over `faces` (built at create): stream of vertex ids with a per-element
+    // sign: 0 = priming vertex (no triangle), +1/-1 = emit triangle (p-2, p-1, p) with that
+    // orientation sign relative to the original face
+    int strip_len, num_strips;
+    int32_t* strip_vidx;       // [strip_len]
+    float* strip_sign;         // [strip_len]
     // segments (tuch/utils/segmentation.py): CSR over segments
     int num_segments, num_caps, seg_q_total, seg_f_total;
     int32_t* seg_q_off;        // [S+1] into seg_q_vidx

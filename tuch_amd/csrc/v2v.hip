@@ -29,7 +29,7 @@ constexpr int kColsPerBlock = kColsPerWave * kWaves;
 __device__ __forceinline__ float select_by_lane_mask(float if_clear, float if_set, uint64_t lane_mask)
 {
     float r;
-    asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(lane_mask));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(lane_mask));
     return r;
 }
 
@@ -67,7 +67,9 @@ __global__ __launch_bounds__(kBlock) void v2v_partial_kernel(
 {
     const int b = blockIdx.z, split = blockIdx.y, nsplit = gridDim.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int w0 = (blockIdx.x * kWaves + wave) * 2;          // first 64-column block of this wave
+    // first 64-column block of this wave; readfirstlane tells the compiler it is wave-uniform so
+    // that the mask words come in through scalar loads (otherwise: one VMEM round trip per row)
+    const int w0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * kWaves + wave) * 2);
     if (w0 * 64 >= V) return;                                  // wave-uniform: no columns left
     const int i0 = w0 * 64 + lane, i1 = i0 + 64;
     const float* vb = verts + (size_t)b * V * 3;
@@ -83,17 +85,26 @@ __global__ __launch_bounds__(kBlock) void v2v_partial_kernel(
     const float inf = __builtin_inff();
     float best0 = inf, best1 = inf;
     int arg0 = 0, arg1 = 0;
-    for (int j = j_begin; j < j_end; ++j) {
-        const uint64_t k0 = uniform64(m0[j]), k1 = uniform64(m1[j]);
-        if ((k0 | k1) == 0) continue;                          // wave-uniform: row fully masked
-        const float* vj = vb + 3 * j;
-        const v2f dx = px - splat2(vj[0]), dy = py - splat2(vj[1]), dz = pz - splat2(vj[2]);
+    auto row = [&](int j, uint64_t k0, uint64_t k1, float vx, float vy, float vz) {
+        const v2f dx = px - splat2(vx), dy = py - splat2(vy), dz = pz - splat2(vz);
         const v2f d = fma2(dz, dz, fma2(dy, dy, dx * dx));
         const float d0 = select_by_lane_mask(inf, d[0], k0);
         const float d1 = select_by_lane_mask(inf, d[1], k1);
         if (d0 < best0) { best0 = d0; arg0 = j; }
         if (d1 < best1) { best1 = d1; arg1 = j; }
+    };
+    int j = j_begin;
+    for (; j + 4 <= j_end; j += 4) {      // four rows per trip: the scalar loads are issued together
+        uint64_t k0[4], k1[4];
+        float c[12];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { k0[u] = m0[j + u]; k1[u] = m1[j + u]; }
+#pragma unroll
+        for (int u = 0; u < 12; ++u) c[u] = vb[3 * j + u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) row(j + u, k0[u], k1[u], c[3 * u], c[3 * u + 1], c[3 * u + 2]);
     }
+    for (; j < j_end; ++j) row(j, m0[j], m1[j], vb[3 * j], vb[3 * j + 1], vb[3 * j + 2]);
     const size_t o = ((size_t)b * nsplit + split) * V;
     if (i0 < V) { part_min[o + i0] = best0; part_arg[o + i0] = arg0; }
     if (i1 < V) { part_min[o + i1] = best1; part_arg[o + i1] = arg1; }

@@ -17,6 +17,7 @@
 //     kernel => bit-reproducible results, no float atomics.
 #include "common.h"
 #include "model.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -66,6 +67,23 @@ __device__ __forceinline__ v2f atan2_pair(v2f y, v2f x)
     return r;
 }
 
+// atan2(num, den) when every lane of the wave has |num| < den/8 for both of its queries
+// (far triangles, the overwhelming majority): atan(t) = t - t^3/3 + t^5/5 - t^7/7, truncation
+// error < 1e-9.  Otherwise the whole wave takes the general path; the choice is wave-uniform.
+__device__ __forceinline__ v2f half_angle(v2f num, v2f den)
+{
+    const bool big = !(__builtin_fabsf(num[0]) < 0.125f * den[0]) || !(__builtin_fabsf(num[1]) < 0.125f * den[1]);
+    if (__builtin_amdgcn_ballot_w64(big) == 0) {
+        const v2f t = num * (v2f){__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+        const v2f s = t * t;
+        v2f p = fma2(s, splat2(-1.0f / 7.0f), splat2(0.2f));
+        p = fma2(p, s, splat2(-1.0f / 3.0f));
+        p = fma2(p, s, splat2(1.0f));
+        return p * t;
+    }
+    return atan2_pair(num, den);
+}
+
 __device__ __forceinline__ v2f sqrt2(v2f a)
 {
     return (v2f){__builtin_amdgcn_sqrtf(a[0]), __builtin_amdgcn_sqrtf(a[1])};
@@ -91,7 +109,7 @@ __device__ __forceinline__ v2f half_solid_angle(const float* __restrict__ t, v2f
     den = fma2(dAB, nC, den);
     den = fma2(dAC, nB, den);
     den = fma2(dBC, nA, den);
-    return atan2_pair(num, den);
+    return half_angle(num, den);
 }
 
 // partial[b][split][q] = sum over the split's triangles of atan2(num, den)
@@ -168,6 +186,101 @@ __global__ __launch_bounds__(kBlock) void gather_triangles_kernel(
     dst[0] = src[0];
     dst[1] = src[1];
     dst[2] = src[2];
+}
+
+
+// ---- triangle-strip form ------------------------------------------------------------------
+// The model's faces are walked as triangle strips (model.hip build_strips): consecutive
+// triangles share two vertices, so per emitted triangle only ONE new vertex needs its
+// difference vector and norm (1 sqrt instead of 3) and only two of the three dot products
+// are new.  Stream element = (x, y, z, sign): sign 0 primes a strip, +-1 emits the triangle
+// of the last three elements with that orientation.  Three register slots are rotated by
+// position modulo 3 (loop unrolled by 3, no register moves).
+struct StreamElem { float x, y, z, sign; };
+
+__global__ __launch_bounds__(kBlock) void gather_stream_kernel(
+    const float* __restrict__ verts, const int32_t* __restrict__ vidx, const float* __restrict__ sign,
+    int V, int L, int Lpad, StreamElem* __restrict__ out)
+{
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= Lpad) return;
+    StreamElem e = {0.f, 0.f, 0.f, 0.f};
+    if (p < L) {
+        const float* src = verts + ((size_t)b * V + vidx[p]) * 3;
+        e.x = src[0]; e.y = src[1]; e.z = src[2]; e.sign = sign[p];
+    }
+    out[(size_t)b * Lpad + p] = e;
+}
+
+struct Slot { v2f x, y, z, n; };
+
+template <int A>
+__device__ __forceinline__ void strip_step(const StreamElem e, bool emit, Slot (&s)[3], v2f (&d)[3],
+                                           v2f qx, v2f qy, v2f qz, v2f& acc)
+{
+    constexpr int Bq = (A + 1) % 3, Cq = (A + 2) % 3;      // slots of stream positions p-2 and p-1
+    s[A].x = splat2(e.x) - qx;
+    s[A].y = splat2(e.y) - qy;
+    s[A].z = splat2(e.z) - qz;
+    s[A].n = sqrt2(fma2(s[A].z, s[A].z, fma2(s[A].y, s[A].y, s[A].x * s[A].x)));
+    // d[k] = dot of the two slots other than k
+    d[Cq] = fma2(s[A].z, s[Bq].z, fma2(s[A].y, s[Bq].y, s[A].x * s[Bq].x));
+    d[Bq] = fma2(s[A].z, s[Cq].z, fma2(s[A].y, s[Cq].y, s[A].x * s[Cq].x));
+    if (emit && e.sign != 0.0f) {                            // wave-uniform
+        const v2f cx = fma2(s[Bq].y, s[Cq].z, -(s[Bq].z * s[Cq].y));
+        const v2f cy = fma2(s[Bq].z, s[Cq].x, -(s[Bq].x * s[Cq].z));
+        const v2f cz = fma2(s[Bq].x, s[Cq].y, -(s[Bq].y * s[Cq].x));
+        const v2f num = fma2(s[A].z, cz, fma2(s[A].y, cy, s[A].x * cx));
+        v2f den = s[0].n * s[1].n * s[2].n;
+        den = fma2(d[0], s[0].n, den);
+        den = fma2(d[1], s[1].n, den);
+        den = fma2(d[2], s[2].n, den);
+        acc = fma2(splat2(e.sign), half_angle(num, den), acc);
+    }
+}
+
+constexpr int kStripBlock = 128;
+constexpr int kStripQueries = kStripBlock * kQueriesPerLane;
+
+__global__ __launch_bounds__(kStripBlock) void winding_strip_kernel(
+    const float* __restrict__ points,            // [B,Q,3]
+    const StreamElem* __restrict__ stream,       // [B,Lpad]
+    int Q, int Lpad, int elems_per_split,        // elems_per_split % 3 == 0
+    float* __restrict__ partial)                 // [B,S,Q]
+{
+    const int b = blockIdx.z, split = blockIdx.y, nsplit = gridDim.y;
+    const int q0 = blockIdx.x * kStripQueries + threadIdx.x, q1 = q0 + kStripBlock;
+    const float* pts = points + (size_t)b * Q * 3;
+    const int c0 = q0 < Q ? q0 : Q - 1, c1 = q1 < Q ? q1 : Q - 1;
+    const v2f qx = {pts[3 * c0 + 0], pts[3 * c1 + 0]};
+    const v2f qy = {pts[3 * c0 + 1], pts[3 * c1 + 1]};
+    const v2f qz = {pts[3 * c0 + 2], pts[3 * c1 + 2]};
+    const int p_first = split * elems_per_split;
+    const int p_end = min(Lpad - 3, p_first + elems_per_split);   // the prefetch reads up to p_end + 2
+    const StreamElem* st = stream + (size_t)b * Lpad;
+    Slot s[3];
+    v2f d[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        s[k].x = s[k].y = s[k].z = s[k].n = splat2(0.0f);
+        d[k] = splat2(0.0f);
+    }
+    v2f acc = splat2(0.0f);
+    // the triple before the chunk only primes the slots (a strip may straddle the boundary)
+    int p = max(p_first - 3, 0);
+    StreamElem n0 = st[p], n1 = st[p + 1], n2 = st[p + 2];     // Lpad has a spare triple at the end
+    for (; p < p_end; p += 3) {
+        const bool emit = p >= p_first;
+        const StreamElem e0 = n0, e1 = n1, e2 = n2;
+        n0 = st[p + 3]; n1 = st[p + 4]; n2 = st[p + 5];        // next triple in flight during the math
+        strip_step<0>(e0, emit, s, d, qx, qy, qz, acc);
+        strip_step<1>(e1, emit, s, d, qx, qy, qz, acc);
+        strip_step<2>(e2, emit, s, d, qx, qy, qz, acc);
+    }
+    float* out = partial + ((size_t)b * nsplit + split) * Q;
+    if (q0 < Q) out[q0] = acc[0];
+    if (q1 < Q) out[q1] = acc[1];
 }
 
 // ---- body segments (tuch/utils/segmentation.py) ---------------------------------
@@ -247,9 +360,36 @@ __global__ __launch_bounds__(kBlock) void segment_winding_kernel(
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// TUCH_WINDING_STRIPS=0 selects the plain per-triangle kernel (A/B measurements)
+bool use_strips()
+{
+    static const int v = [] { const char* e = getenv("TUCH_WINDING_STRIPS"); return e ? atoi(e) : 1; }();
+    return v != 0;
+}
+
+// Number of stream chunks for the strip kernel: fill the 256 CUs x 4 SIMDs x 8 resident waves an
+// integral number of times (tail effect), keep chunks long enough to amortise the priming triple.
+int choose_strip_splits(int B, int Q, int L)
+{
+    const long slots = 256L * 4 * 8;
+    const long base = (long)B * ceil_div(Q, kStripQueries) * (kStripBlock / 64);
+    int best = 1;
+    double best_eff = 0.0;
+    for (int s = 1; s <= 32; ++s) {
+        if (s > 1 && L / s < 384) break;
+        const double rounds = (double)(base * s) / slots;
+        const double eff = rounds / (double)((long)((base * s + slots - 1) / slots));
+        if (eff > best_eff + 0.02) { best_eff = eff; best = s; }
+    }
+    return best;
+}
+
 struct ExteriorLayout {
     size_t tris, partial, caps, seg_tris, total;
+    int lpad;
 };
+
+inline int strip_lpad(int L) { return ceil_div(L, 3) * 3 + 6; }
 
 int choose_splits(int B, int Q, int F);
 
@@ -257,8 +397,14 @@ ExteriorLayout exterior_layout(const tuch_contact_model* m, int B)
 {
     ExteriorLayout l;
     size_t o = 0;
-    l.tris = o;     o += align256((size_t)B * m->F * 9 * sizeof(float));
-    l.partial = o;  o += align256((size_t)B * choose_splits(B, m->V, m->F) * m->V * sizeof(float));
+    l.lpad = strip_lpad(m->strip_len);
+    // triangle buffer or strip stream, whichever is larger (both forms are supported)
+    const size_t tri_bytes = (size_t)B * m->F * 9 * sizeof(float);
+    const size_t strip_bytes = (size_t)B * l.lpad * sizeof(StreamElem);
+    l.tris = o;     o += align256(tri_bytes > strip_bytes ? tri_bytes : strip_bytes);
+    const int max_splits = choose_splits(B, m->V, m->F) > choose_strip_splits(B, m->V, strip_lpad(m->strip_len))
+                               ? choose_splits(B, m->V, m->F) : choose_strip_splits(B, m->V, strip_lpad(m->strip_len));
+    l.partial = o;  o += align256((size_t)B * max_splits * m->V * sizeof(float));
     l.caps = o;     o += align256((size_t)B * (m->num_caps > 0 ? m->num_caps : 1) * 3 * sizeof(float));
     l.seg_tris = o; o += align256((size_t)B * (m->seg_f_total > 0 ? m->seg_f_total : 1) * 9 * sizeof(float));
     l.total = o;
@@ -349,11 +495,25 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
     char* ws = (char*)workspace;
     float* tris = (float*)(ws + l.tris);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(gather_triangles_kernel, dim3(ceil_div(m->F * 3, kBlock), B), dim3(kBlock), 0, s,
-                       verts, (const int32_t*)m->faces, m->V, m->F, tris);
-    int rc = tuch_winding_numbers(verts, tris, B, m->V, m->F, w, exterior, thresh, ws + l.partial,
+    int rc = TUCH_OK;
+    if (use_strips() && m->strip_len > 0) {
+        StreamElem* st = (StreamElem*)tris;
+        hipLaunchKernelGGL(gather_stream_kernel, dim3(ceil_div(l.lpad, kBlock), B), dim3(kBlock), 0, s, verts,
+                           (const int32_t*)m->strip_vidx, (const float*)m->strip_sign, m->V, m->strip_len,
+                           l.lpad, st);
+        const int nsplit = choose_strip_splits(B, m->V, l.lpad);
+        const int per_split = ceil_div(ceil_div(l.lpad - 6, nsplit), 3) * 3;
+        hipLaunchKernelGGL(winding_strip_kernel, dim3(ceil_div(m->V, kStripQueries), nsplit, B), dim3(kStripBlock),
+                           0, s, verts, (const StreamElem*)st, m->V, l.lpad, per_split, (float*)(ws + l.partial));
+        hipLaunchKernelGGL(winding_finalize_kernel, dim3(ceil_div(m->V, kBlock), B), dim3(kBlock), 0, s,
+                           (const float*)(ws + l.partial), m->V, nsplit, thresh, w, exterior);
+    } else {
+        hipLaunchKernelGGL(gather_triangles_kernel, dim3(ceil_div(m->F * 3, kBlock), B), dim3(kBlock), 0, s,
+                           verts, (const int32_t*)m->faces, m->V, m->F, tris);
+        rc = tuch_winding_numbers(verts, tris, B, m->V, m->F, w, exterior, thresh, ws + l.partial,
                                   l.caps - l.partial, stream);
-    if (rc != TUCH_OK) return rc;
+        if (rc != TUCH_OK) return rc;
+    }
     if (apply_segments && m->num_segments > 0) {
         float* caps = (float*)(ws + l.caps);
         float* seg_tris = (float*)(ws + l.seg_tris);

@@ -220,6 +220,17 @@ class ContactModel:
                 pass
             self._handle = None
 
+    def strips(self):
+        """(vertex ids, signs, number of strips) of the triangle-strip walk used by the winding kernel."""
+        n, k = ctypes.c_int(0), ctypes.c_int(0)
+        L = _C.lib()
+        _C.check(L.tuch_contact_model_strips(self._handle, ctypes.byref(n), ctypes.byref(k), None, None))
+        vidx = np.zeros(n.value, np.int32)
+        sign = np.zeros(n.value, np.float32)
+        _C.check(L.tuch_contact_model_strips(self._handle, None, None, vidx.ctypes.data_as(ctypes.c_void_p),
+                                             sign.ctypes.data_as(ctypes.c_void_p)))
+        return vidx, sign, k.value
+
     # K2 + K3
     def exterior_flags(self, verts: torch.Tensor, apply_segments: bool = True, thresh: float = 0.99,
                        return_details: bool = False):
