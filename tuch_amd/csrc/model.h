@@ -22,6 +22,8 @@ struct tuch_contact_model {
     int32_t* seg_faces;        // [seg_f_total,3], cap vertex c is index V + c
     int32_t* cap_off;          // [K+1] into cap_vidx
     int32_t* cap_vidx;         // ordered boundary loops, concatenated
+    int num_seg_blocks;        // 256-query blocks over all segments
+    int32_t* seg_blocks;       // [num_seg_blocks][2] = (segment, first query within the segment)
     int* seg_q_off_host;       // host copies for grid sizing
     int* seg_f_off_host;
     int seg_q_max;
@@ -30,5 +32,9 @@ struct tuch_contact_model {
     int32_t* region_off;       // [R+1]
     int32_t* region_vidx;
     int32_t* pairs;            // [P,2]
+    // geodesic mask restricted to every region pair: rows = vertices of the first region,
+    // bit k of a row = geomask[row vertex][k-th vertex of the second region]
+    uint32_t* pair_mask;       // concatenated [n1][ceil(n2/32)] blocks, or nullptr
+    int64_t* pair_mask_off;    // [P+1] word offsets
     int* region_off_host;
 };

@@ -110,8 +110,8 @@ void build_strips(const int32_t* faces, int F, std::vector<int32_t>& vidx, std::
 extern "C" void tuch_contact_model_destroy(tuch_contact_model* m)
 {
     if (!m) return;
-    void* dev[] = {m->faces, m->mask_bits, m->strip_vidx, m->strip_sign, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces,
-                   m->cap_off, m->cap_vidx, m->region_off, m->region_vidx, m->pairs};
+    void* dev[] = {m->faces, m->mask_bits, m->strip_vidx, m->strip_sign, m->seg_blocks, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces,
+                   m->cap_off, m->cap_vidx, m->region_off, m->region_vidx, m->pairs, m->pair_mask, m->pair_mask_off};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     free(m->seg_q_off_host);
@@ -180,6 +180,11 @@ extern "C" int tuch_contact_model_create(
                 tuch_set_error("tuch_contact_model_create: segment face index %d out of range", seg_faces[i]);
                 rc = TUCH_ERR_ARG;
             }
+        std::vector<int32_t> blocks;
+        for (int s = 0; s < num_segments; ++s)
+            for (int q = 0; q < seg_q_off[s + 1] - seg_q_off[s]; q += 256) { blocks.push_back(s); blocks.push_back(q); }
+        m->num_seg_blocks = (int)blocks.size() / 2;
+        if (rc == TUCH_OK) rc = upload(&m->seg_blocks, blocks.data(), blocks.size());
         if (rc == TUCH_OK) rc = upload(&m->seg_q_off, seg_q_off, (size_t)num_segments + 1);
         if (rc == TUCH_OK) rc = upload(&m->seg_q_vidx, seg_q_vidx, (size_t)m->seg_q_total);
         if (rc == TUCH_OK) rc = upload(&m->seg_f_off, seg_f_off, (size_t)num_segments + 1);
@@ -200,6 +205,28 @@ extern "C" int tuch_contact_model_create(
         rc = upload(&m->region_off, region_off, (size_t)num_regions + 1);
         if (rc == TUCH_OK) rc = upload(&m->region_vidx, region_vidx, (size_t)region_off[num_regions]);
         if (rc == TUCH_OK && num_pairs > 0) rc = upload(&m->pairs, pairs, (size_t)num_pairs * 2);
+        if (rc == TUCH_OK && num_pairs > 0 && geomask) {
+            std::vector<int64_t> off(num_pairs + 1, 0);
+            for (int p = 0; p < num_pairs; ++p) {
+                const int n1 = region_off[pairs[2 * p] + 1] - region_off[pairs[2 * p]];
+                const int n2 = region_off[pairs[2 * p + 1] + 1] - region_off[pairs[2 * p + 1]];
+                off[p + 1] = off[p] + (int64_t)n1 * ((n2 + 31) / 32);
+            }
+            std::vector<uint32_t> words((size_t)off[num_pairs], 0u);
+            for (int p = 0; p < num_pairs; ++p) {
+                const int32_t* r1 = region_vidx + region_off[pairs[2 * p]];
+                const int32_t* r2 = region_vidx + region_off[pairs[2 * p + 1]];
+                const int n1 = region_off[pairs[2 * p] + 1] - region_off[pairs[2 * p]];
+                const int n2 = region_off[pairs[2 * p + 1] + 1] - region_off[pairs[2 * p + 1]];
+                const int wpr = (n2 + 31) / 32;
+                for (int a = 0; a < n1; ++a)
+                    for (int k = 0; k < n2; ++k)
+                        if (geomask[(size_t)r1[a] * V + r2[k]])
+                            words[(size_t)off[p] + (size_t)a * wpr + (k >> 5)] |= 1u << (k & 31);
+            }
+            rc = upload(&m->pair_mask, words.data(), words.size());
+            if (rc == TUCH_OK) rc = upload(&m->pair_mask_off, off.data(), off.size());
+        }
     }
     if (rc != TUCH_OK) {
         tuch_contact_model_destroy(m);

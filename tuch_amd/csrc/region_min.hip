@@ -34,11 +34,11 @@ __global__ __launch_bounds__(kBlock) void region_pair_min_kernel(
     const float* __restrict__ verts, const int32_t* __restrict__ region_off,
     const int32_t* __restrict__ region_vidx, const int32_t* __restrict__ pairs,
     const uint8_t* __restrict__ select,        // [B,P] or nullptr (= all)
-    const uint64_t* __restrict__ mask_bits,    // [W][V] or nullptr (= unmasked)
+    const uint32_t* __restrict__ pair_mask,    // per-pair geomask blocks or nullptr (= unmasked)
+    const int64_t* __restrict__ pair_mask_off,
     int V, int P, float* __restrict__ out_min, int32_t* __restrict__ out_ij)
 {
     __shared__ float sx[kTile], sy[kTile], sz[kTile];
-    __shared__ int sv[kTile];
     __shared__ Best swave[kBlock / 64];
     const int p = blockIdx.x, b = blockIdx.y;
     const size_t o = (size_t)b * P + p;
@@ -59,20 +59,25 @@ __global__ __launch_bounds__(kBlock) void region_pair_min_kernel(
         __syncthreads();
         for (int k = threadIdx.x; k < tn; k += kBlock) {
             const int v = region_vidx[b_beg + t0 + k];
-            sv[k] = v;
             sx[k] = vb[3 * v]; sy[k] = vb[3 * v + 1]; sz[k] = vb[3 * v + 2];
         }
         __syncthreads();
         for (int a = threadIdx.x; a < n1; a += kBlock) {
             const int i = region_vidx[a_beg + a];
             const float px = vb[3 * i], py = vb[3 * i + 1], pz = vb[3 * i + 2];
-            const uint64_t* mrow = mask_bits ? mask_bits + (size_t)(i >> 6) * V : nullptr;
-            for (int k = 0; k < tn; ++k) {
-                const float dx = px - sx[k], dy = py - sy[k], dz = pz - sz[k];
-                float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                if (mrow && !((mrow[sv[k]] >> (i & 63)) & 1)) d = __builtin_inff();
-                const int flat = a * n2 + t0 + k;
-                if (d < best.d || (d == best.d && flat < best.idx)) { best.d = d; best.idx = flat; }
+            const uint32_t* mrow = pair_mask ? pair_mask + pair_mask_off[p] + (size_t)a * ((n2 + 31) / 32) + (t0 >> 5)
+                                             : nullptr;
+            for (int g = 0; g < tn; g += 32) {
+                const uint32_t word = mrow ? mrow[g >> 5] : 0xffffffffu;
+                const int gn = min(32, tn - g);
+                for (int kk = 0; kk < gn; ++kk) {
+                    const int k = g + kk;
+                    const float dx = px - sx[k], dy = py - sy[k], dz = pz - sz[k];
+                    float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                    if (!((word >> kk) & 1)) d = __builtin_inff();
+                    const int flat = a * n2 + k + t0;
+                    if (d < best.d || (d == best.d && flat < best.idx)) { best.d = d; best.idx = flat; }
+                }
             }
         }
     }
@@ -126,12 +131,12 @@ extern "C" int tuch_region_pair_min(const tuch_contact_model* m, const float* ve
     TUCH_REQUIRE(m && verts && out_min, "tuch_region_pair_min: null pointer");
     TUCH_REQUIRE(B > 0 && B <= 65535, "tuch_region_pair_min: bad batch %d", B);
     TUCH_REQUIRE(m->num_pairs > 0, "tuch_region_pair_min: model has no region pairs");
-    TUCH_REQUIRE(!use_geomask || m->mask_bits, "tuch_region_pair_min: model has no geodesic mask");
+    TUCH_REQUIRE(!use_geomask || m->pair_mask, "tuch_region_pair_min: model has no geodesic mask");
     hipLaunchKernelGGL(region_pair_min_kernel, dim3(m->num_pairs, B), dim3(kBlock), 0, (hipStream_t)stream,
                        verts, (const int32_t*)m->region_off, (const int32_t*)m->region_vidx,
                        (const int32_t*)m->pairs, select,
-                       use_geomask ? (const uint64_t*)m->mask_bits : (const uint64_t*)nullptr, m->V,
-                       m->num_pairs, out_min, out_ij);
+                       use_geomask ? (const uint32_t*)m->pair_mask : (const uint32_t*)nullptr,
+                       (const int64_t*)m->pair_mask_off, m->V, m->num_pairs, out_min, out_ij);
     return tuch_check_launch("tuch_region_pair_min");
 }
 

@@ -26,6 +26,8 @@ constexpr float kHalfPi = 1.57079632679489661923f;
 constexpr int kBlock = 256;
 constexpr int kQueriesPerLane = 2;
 constexpr int kQueriesPerBlock = kBlock * kQueriesPerLane;
+constexpr int kStripBlock = 128;                              // strip / segment kernels
+constexpr int kStripQueries = kStripBlock * kQueriesPerLane;
 
 // atan on [0,1]: t * P(t^2), minimax, max abs error 9.6e-8 in float32.
 __device__ __forceinline__ v2f atan_poly(v2f t)
@@ -240,9 +242,6 @@ __device__ __forceinline__ void strip_step(const StreamElem e, bool emit, Slot (
     }
 }
 
-constexpr int kStripBlock = 128;
-constexpr int kStripQueries = kStripBlock * kQueriesPerLane;
-
 __global__ __launch_bounds__(kStripBlock) void winding_strip_kernel(
     const float* __restrict__ points,            // [B,Q,3]
     const StreamElem* __restrict__ stream,       // [B,Lpad]
@@ -319,43 +318,55 @@ __global__ __launch_bounds__(kBlock) void gather_segment_triangles_kernel(
 }
 
 // winding number of every segment vertex w.r.t. its own closed segment
-// (segmentation.py:81-99); vertices that are NOT exterior to their own segment
-// are re-marked exterior in the body flags (losses.py:87-89, loss.py:265-266).
-__global__ __launch_bounds__(kBlock) void segment_winding_kernel(
+// (segmentation.py:81-99).  Blocks come from a host-built table (segment, first query) so
+// that segments of very different sizes fill the chip evenly; the segment's faces are split
+// over grid.y and reduced in fixed order by segment_finalize_kernel.
+constexpr int kSegSplits = 4;
+
+__global__ __launch_bounds__(kStripBlock) void segment_winding_kernel(
     const float* __restrict__ verts, const float* __restrict__ seg_tris,
-    const int32_t* __restrict__ seg_q_off, const int32_t* __restrict__ seg_q_vidx,
-    const int32_t* __restrict__ seg_f_off, int V, int Fs_total, int Qs_total, float thresh,
-    float* __restrict__ seg_w,          // [B,Qs_total] or nullptr
-    uint8_t* __restrict__ seg_ext,      // [B,Qs_total] or nullptr: w <= thresh
-    uint8_t* __restrict__ exterior)     // [B,V] or nullptr: set to 1 where w > thresh
+    const int32_t* __restrict__ seg_blocks, const int32_t* __restrict__ seg_q_off,
+    const int32_t* __restrict__ seg_q_vidx, const int32_t* __restrict__ seg_f_off, int V, int Fs_total,
+    int Qs_total, float* __restrict__ partial)     // [B,kSegSplits,Qs_total]
 {
-    const int b = blockIdx.z, s = blockIdx.y;
+    const int b = blockIdx.z, split = blockIdx.y;
+    const int s = seg_blocks[2 * blockIdx.x], q_start = seg_blocks[2 * blockIdx.x + 1];
     const int q_beg = seg_q_off[s], q_cnt = seg_q_off[s + 1] - q_beg;
-    const int l0 = blockIdx.x * kQueriesPerBlock + threadIdx.x, l1 = l0 + kBlock;
-    if (blockIdx.x * kQueriesPerBlock >= q_cnt) return;
+    const int l0 = q_start + threadIdx.x, l1 = l0 + kStripBlock;
     const int c0 = min(l0, q_cnt - 1), c1 = min(l1, q_cnt - 1);
     const int v0 = seg_q_vidx[q_beg + c0], v1 = seg_q_vidx[q_beg + c1];
     const float* vb = verts + (size_t)b * V * 3;
     const v2f qx = {vb[3 * v0 + 0], vb[3 * v1 + 0]};
     const v2f qy = {vb[3 * v0 + 1], vb[3 * v1 + 1]};
     const v2f qz = {vb[3 * v0 + 2], vb[3 * v1 + 2]};
-    const int f_beg = seg_f_off[s], f_end = seg_f_off[s + 1];
+    const int f_seg = seg_f_off[s], f_cnt = seg_f_off[s + 1] - f_seg;
+    const int per = (f_cnt + kSegSplits - 1) / kSegSplits;
+    const int f_beg = f_seg + split * per, f_end = min(f_seg + f_cnt, f_beg + per);
     const float* t = seg_tris + ((size_t)b * Fs_total + f_beg) * 9;
     v2f acc = splat2(0.0f);
     for (int f = f_beg; f < f_end; ++f, t += 9)
         acc += half_solid_angle(t, qx, qy, qz);
-    const float w0 = acc[0] * (0.5f / kPi), w1 = acc[1] * (0.5f / kPi);
-    const size_t o = (size_t)b * Qs_total + q_beg;
-    if (l0 < q_cnt) {
-        if (seg_w) seg_w[o + l0] = w0;
-        if (seg_ext) seg_ext[o + l0] = w0 <= thresh;
-        if (exterior && !(w0 <= thresh)) exterior[(size_t)b * V + v0] = 1;
-    }
-    if (l1 < q_cnt) {
-        if (seg_w) seg_w[o + l1] = w1;
-        if (seg_ext) seg_ext[o + l1] = w1 <= thresh;
-        if (exterior && !(w1 <= thresh)) exterior[(size_t)b * V + v1] = 1;
-    }
+    float* out = partial + ((size_t)b * kSegSplits + split) * Qs_total + q_beg;
+    if (l0 < q_cnt) out[l0] = acc[0];
+    if (l1 < q_cnt) out[l1] = acc[1];
+}
+
+// vertices that are NOT exterior to their own segment are re-marked exterior in the body
+// flags (losses.py:87-89, loss.py:265-266)
+__global__ __launch_bounds__(kBlock) void segment_finalize_kernel(
+    const float* __restrict__ partial, const int32_t* __restrict__ seg_q_vidx, int V, int Qs_total,
+    float thresh, float* __restrict__ seg_w, uint8_t* __restrict__ seg_ext, uint8_t* __restrict__ exterior)
+{
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * kBlock + threadIdx.x;
+    if (q >= Qs_total) return;
+    float acc = 0.0f;
+    for (int sp = 0; sp < kSegSplits; ++sp) acc += partial[((size_t)b * kSegSplits + sp) * Qs_total + q];
+    const float w = acc * (0.5f / kPi);
+    const size_t o = (size_t)b * Qs_total + q;
+    if (seg_w) seg_w[o] = w;
+    if (seg_ext) seg_ext[o] = w <= thresh;
+    if (exterior && !(w <= thresh)) exterior[(size_t)b * V + seg_q_vidx[q]] = 1;
 }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -385,7 +396,7 @@ int choose_strip_splits(int B, int Q, int L)
 }
 
 struct ExteriorLayout {
-    size_t tris, partial, caps, seg_tris, total;
+    size_t tris, partial, caps, seg_tris, seg_partial, total;
     int lpad;
 };
 
@@ -407,6 +418,7 @@ ExteriorLayout exterior_layout(const tuch_contact_model* m, int B)
     l.partial = o;  o += align256((size_t)B * max_splits * m->V * sizeof(float));
     l.caps = o;     o += align256((size_t)B * (m->num_caps > 0 ? m->num_caps : 1) * 3 * sizeof(float));
     l.seg_tris = o; o += align256((size_t)B * (m->seg_f_total > 0 ? m->seg_f_total : 1) * 9 * sizeof(float));
+    l.seg_partial = o; o += align256((size_t)B * kSegSplits * (m->seg_q_total > 0 ? m->seg_q_total : 1) * sizeof(float));
     l.total = o;
     return l;
 }
@@ -523,11 +535,14 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
         hipLaunchKernelGGL(gather_segment_triangles_kernel, dim3(ceil_div(m->seg_f_total * 3, kBlock), B),
                            dim3(kBlock), 0, s, verts, (const float*)caps, (const int32_t*)m->seg_faces,
                            m->V, m->num_caps, m->seg_f_total, seg_tris);
-        hipLaunchKernelGGL(segment_winding_kernel,
-                           dim3(ceil_div(m->seg_q_max, kQueriesPerBlock), m->num_segments, B), dim3(kBlock),
-                           0, s, verts, (const float*)seg_tris, (const int32_t*)m->seg_q_off,
-                           (const int32_t*)m->seg_q_vidx, (const int32_t*)m->seg_f_off, m->V,
-                           m->seg_f_total, m->seg_q_total, thresh, seg_w, seg_exterior, exterior);
+        float* seg_partial = (float*)(ws + l.seg_partial);
+        hipLaunchKernelGGL(segment_winding_kernel, dim3(m->num_seg_blocks, kSegSplits, B), dim3(kStripBlock),
+                           0, s, verts, (const float*)seg_tris, (const int32_t*)m->seg_blocks,
+                           (const int32_t*)m->seg_q_off, (const int32_t*)m->seg_q_vidx,
+                           (const int32_t*)m->seg_f_off, m->V, m->seg_f_total, m->seg_q_total, seg_partial);
+        hipLaunchKernelGGL(segment_finalize_kernel, dim3(ceil_div(m->seg_q_total, kBlock), B), dim3(kBlock), 0, s,
+                           (const float*)seg_partial, (const int32_t*)m->seg_q_vidx, m->V, m->seg_q_total,
+                           thresh, seg_w, seg_exterior, exterior);
     }
     return tuch_check_launch("tuch_exterior_flags");
 }
