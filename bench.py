@@ -130,15 +130,15 @@ def rooflines(p, batch):
     model = contact_model_for(p['geomask'], p['face_tensor'], p['segments'], p['cdict'])
     with torch.no_grad():
         verts = p['smpl'](global_orient=p['global_orient'], body_pose=p['body_pose'], betas=p['betas']).vertices
-    tris = ops.gather_triangles(verts, model.faces_i32)
-    t_w = time_kernel(lambda: ops.winding_numbers(verts, tris), 10)
+    # the launch below = gather_stream (~9 us) + winding_strip_kernel + finalize (~5 us)
+    t_w = time_kernel(lambda: model.exterior_flags(verts, apply_segments=False), 10)
     flops = FLOP_PER_WINDING_PAIR * batch * v * f
     ach = flops / t_w / 1e12
-    roof = {'kernel': 'winding_partial_kernel', 'bound': 'valu', 'achieved': round(ach, 2),
+    roof = {'kernel': 'winding_strip_kernel', 'bound': 'valu', 'achieved': round(ach, 2),
             'peak': PEAK_FP32_VECTOR_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_VECTOR_TFLOPS, 4),
             'traffic': None, 'launch_ms': round(t_w * 1e3, 4),
             'algorithmic_flop_per_launch': flops,
-            'algorithmic_bytes_per_launch': batch * (v * 12 + f * 36 + v * 4)}
+            'algorithmic_bytes_per_launch': batch * (v * 12 + v * 4) + f * 12}
     t_v = time_kernel(lambda: model.v2v_min(verts), 10)
     ref_layout_bytes = batch * (12 * v + v * v + 8 * v)           # SURVEY.md §8(d) layout (i)
     compact_bytes = batch * (12 * v + 8 * v) + v * v // 8         # layout (ii): bit-packed mask read once

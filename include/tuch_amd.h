@@ -71,6 +71,13 @@ size_t tuch_v2v_workspace_bytes(int B, int N);
 int tuch_v2v_min_masked(const float* points, const uint64_t* geomask_bits, int B, int N, float* min_d2,
                         int32_t* argmin, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Ragged variant for the HD resampling of loss.py:284-291: body b owns points
+ * offsets[b]..offsets[b+1] (device int32 [B+1]); point a inherits the mask row/column of template
+ * vertex vertex_ids[a] (geovec_verts, loss.py:88).  argmin is relative to the body's first point. */
+int tuch_v2v_min_indexed(const float* points, const int32_t* vertex_ids, const int32_t* offsets,
+                         const uint64_t* geomask_bits, int B, int V, int max_points_per_body, float* min_d2,
+                         int32_t* argmin, void* stream);
+
 /* ---- pull/push terms: losses.py:96-105 (mode 0) / loss.py:303-315 (mode 1) ---------- */
 
 /* terms [B,2] = (sum over interior, sum over exterior) of weight*tanh(d/scale)^2 with

@@ -257,3 +257,39 @@ def test_triangle_strips_cover_every_face_once(tag):
         assert (tri in rots) == (sg > 0)
     assert (sign[:2] == 0).all() and nstrips >= 1
     print(tag, 'faces', len(faces), 'stream', len(vidx), 'strips', nstrips)
+
+
+@pytest.mark.parametrize('tag', ['small', 'medium'])
+@pytest.mark.parametrize('use_hd', [False, True])
+def test_regressor_contact_loss_vs_reference(tag, use_hd):
+    """a7 of SURVEY.md §8a: RegressorLoss.contact_loss (loss.py:240-317), both branches."""
+    import types
+    from tuch_amd.train.loss import RegressorLoss
+    from tuch_amd.utils.segmentation import BatchBodySegment
+    g, gm = golden(tag), golden_mask(tag)
+    d = dev()
+    batch = g['verts'].shape[0]
+    face_tensor = torch.tensor(g['faces'], device=d)[None].repeat(batch, 1, 1)
+    segs = gio.unpack_segments(g)
+    segments = BatchBodySegment(list(segs.keys()), face_tensor[0], segs)
+    geod = torch.tensor(np.where(gm, 1.0, 0.0).astype(np.float32), device=d)     # geod > 0.3 <=> mask
+    crit = RegressorLoss(types.SimpleNamespace(contact_loss_weight=1.0), d, g['verts'].shape[1], face_tensor,
+                         geod, geothres=0.3, euclthres=float(g['euclthres']), face_tensor=face_tensor,
+                         use_hd=use_hd, segments=segments, hd_regressor=(g['hd_idx'], g['hd_w']),
+                         hd_faces=g['hd_face'])
+    verts = torch.tensor(g['verts'], device=d, requires_grad=True)
+    loss = crit.contact_loss(verts, torch.tensor(g['valid_fit'], device=d))
+    loss.backward()
+    key = 'train_hd' if use_hd else 'train_plain'
+    assert_close(loss.item(), g[key + '_loss'], 1e-4, 0, key)
+    gv = g[key + '_grad_verts']
+    assert_close(verts.grad.cpu().numpy(), gv, 1e-3, 5e-6 * np.abs(gv).max(), key + ' grad')
+
+
+def test_contact_from_verts_class():
+    from tuch_amd.train.train_module import TUCH
+    g = golden('medium')
+    regions, pairs = gio.unpack_regions(g)
+    t = TUCH({'classes': [list(p) for p in pairs], 'csig': regions}, g['faces'], device=dev())
+    out = t.contact_from_verts(torch.tensor(g['verts'], device=dev()))
+    assert_close(out.cpu().numpy(), g['contact_from_verts'], 0, 1e-6, 'contact_from_verts')

@@ -31,6 +31,8 @@ _SIGNATURES = {
     'tuch_v2v_workspace_bytes': (c_size_t, [c_int, c_int]),
     'tuch_v2v_min_masked': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
                                     c_void_p]),
+    'tuch_v2v_min_indexed': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                     c_void_p]),
     'tuch_contact_terms_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                        c_void_p, c_void_p]),
     'tuch_contact_terms_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,

@@ -147,6 +147,36 @@ __global__ __launch_bounds__(kBlock) void pairwise_kernel(
     out[((size_t)b * nx + i) * ny + j] = p;
 }
 
+// Ragged variant for resampled (HD) point sets, tuch/train/loss.py:288-291: body b owns points
+// off[b]..off[b+1]; point a carries the template vertex vid[a] whose geodesic-mask row/column
+// it inherits (geovec_verts, loss.py:88).  Column a: min over the body's rows r with
+// geomask[vid[r]][vid[a]].  argmin is the row index relative to the body's first point.
+__global__ __launch_bounds__(kBlock) void v2v_indexed_kernel(
+    const float* __restrict__ pts, const int32_t* __restrict__ vid, const int32_t* __restrict__ off,
+    const uint64_t* __restrict__ bits, int V, float* __restrict__ out_min, int32_t* __restrict__ out_arg)
+{
+    const int b = blockIdx.y;
+    const int beg = off[b], n = off[b + 1] - beg;
+    const int a = blockIdx.x * kBlock + threadIdx.x;
+    if (blockIdx.x * kBlock >= n) return;
+    const int ac = min(a, n - 1);
+    const float px = pts[3 * (size_t)(beg + ac)], py = pts[3 * (size_t)(beg + ac) + 1], pz = pts[3 * (size_t)(beg + ac) + 2];
+    const int va = vid[beg + ac];
+    const uint64_t* col = bits + (size_t)(va >> 6) * V;
+    const int sh = va & 63;
+    float best = __builtin_inff();
+    int arg = 0;
+    for (int r = 0; r < n; ++r) {
+        const float* q = pts + 3 * (size_t)(beg + r);       // wave-uniform
+        const int vr = vid[beg + r];
+        const float dx = px - q[0], dy = py - q[1], dz = pz - q[2];
+        float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        if (!((col[vr] >> sh) & 1)) d = __builtin_inff();
+        if (d < best) { best = d; arg = r; }
+    }
+    if (a < n) { out_min[beg + a] = best; out_arg[beg + a] = arg; }
+}
+
 int choose_row_splits(int B, int V)
 {
     const int cblocks = ceil_div(V, kColsPerBlock);
@@ -211,4 +241,17 @@ extern "C" int tuch_batch_pairwise_dist(const float* x, const float* y, int B, i
     hipLaunchKernelGGL(pairwise_kernel, dim3(ceil_div(Ny, kBlock), Nx, B), dim3(kBlock), 0,
                        (hipStream_t)stream, x, y, Nx, Ny, squared, P);
     return tuch_check_launch("tuch_batch_pairwise_dist");
+}
+
+extern "C" int tuch_v2v_min_indexed(const float* points, const int32_t* vertex_ids, const int32_t* offsets,
+                                    const uint64_t* geomask_bits, int B, int V, int max_points_per_body,
+                                    float* min_d2, int32_t* argmin, void* stream)
+{
+    TUCH_REQUIRE(points && vertex_ids && offsets && geomask_bits && min_d2 && argmin,
+                 "tuch_v2v_min_indexed: null pointer");
+    TUCH_REQUIRE(B > 0 && B <= 65535 && V > 0 && max_points_per_body >= 0, "tuch_v2v_min_indexed: bad sizes");
+    if (max_points_per_body == 0) return TUCH_OK;
+    hipLaunchKernelGGL(v2v_indexed_kernel, dim3(ceil_div(max_points_per_body, kBlock), B), dim3(kBlock), 0,
+                       (hipStream_t)stream, points, vertex_ids, offsets, geomask_bits, V, min_d2, argmin);
+    return tuch_check_launch("tuch_v2v_min_indexed");
 }

@@ -257,6 +257,23 @@ class ContactModel:
             raise _C.TuchError('ContactModel was created without a geodesic mask')
         return v2v_min_masked(verts, ctypes.c_void_p(_C.lib().tuch_contact_model_mask_bits(self._handle)))
 
+    def v2v_min_indexed(self, points: torch.Tensor, vertex_ids: torch.Tensor, offsets: torch.Tensor,
+                        max_points: int):
+        """Ragged masked nearest neighbour (HD points, loss.py:288-291).  points [N,3], vertex_ids [N]
+        int32, offsets [B+1] int32 -> (min_d2 [N], argmin [N] int32 relative to the body's first point)."""
+        if not self.has_mask:
+            raise _C.TuchError('ContactModel was created without a geodesic mask')
+        pts = _f32(points)
+        n = pts.shape[0]
+        mn = torch.empty(n, dtype=torch.float32, device=pts.device)
+        arg = torch.empty(n, dtype=torch.int32, device=pts.device)
+        L = _C.lib()
+        _C.check(L.tuch_v2v_min_indexed(_C.ptr(pts), _C.ptr(vertex_ids.contiguous()), _C.ptr(offsets.contiguous()),
+                                        ctypes.c_void_p(L.tuch_contact_model_mask_bits(self._handle)),
+                                        offsets.shape[0] - 1, self.num_verts, int(max_points), _C.ptr(mn),
+                                        _C.ptr(arg), _C.stream()))
+        return mn, arg
+
     # K5
     def region_pair_min(self, verts: torch.Tensor, select: Optional[torch.Tensor] = None, masked: bool = False):
         return _RegionPairMin.apply(verts, self, select, masked)

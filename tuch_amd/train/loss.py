@@ -1,0 +1,170 @@
+"""Drop-in for the reference's ``tuch/train/loss.py``: ``RegressorLoss`` with the L_P / L_C
+contact loss on the HIP kernels; the SPIN terms (keypoints, shape, pose/betas regression,
+camera) are small torch reductions as in the reference.
+
+Constructor differences, all optional keyword arguments (the licensed assets do not ship):
+``segments`` (a BatchBodySegment), ``hd_regressor`` = (idx [N,3], weights [N,3]) -- the three
+non-zeros of every row of smpl_neutral_hd_vert_regressor.npy -- and ``hd_faces`` =
+faces_vert_is_sampled_from.  With the asset files present they are loaded like the reference
+does (loss.py:81-91).
+"""
+from __future__ import annotations
+
+import os.path as osp
+import pickle
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..utils.geometry import batch_rodrigues
+
+
+def batch_face_normals(triangles):
+    """Unit normals of [B,F,3,3] triangles (reference: loss.py:30-41)."""
+    n = torch.cross(triangles[:, :, 1] - triangles[:, :, 0], triangles[:, :, 2] - triangles[:, :, 0], dim=2)
+    return n / torch.norm(n, 2, dim=2, keepdim=True)
+
+
+class RegressorLoss(nn.Module):
+    def __init__(self, options, device, num_verts, faces, geodistssmpl, geothres=0.2, euclthres=0.02,
+                 face_tensor=None, use_hd=True, segments=None, hd_regressor=None, hd_faces=None,
+                 hd_model_dir='data/essentials/hd_model/smpl'):
+        super().__init__()
+        self.device = device
+        self.options = options
+        self.criterion_shape = nn.L1Loss().to(self.device)
+        self.criterion_keypoints = nn.MSELoss(reduction='none').to(self.device)
+        self.criterion_regr = nn.MSELoss().to(self.device)
+        self.faces = faces
+        self.nv = num_verts
+        self.geodistssmpl = geodistssmpl
+        self.geothres = geothres
+        self.geomask = geodistssmpl > geothres                       # loss.py:71 (strict >)
+        self.euclthres = euclthres
+        self.face_tensor = face_tensor
+        self.use_hd = use_hd
+        if use_hd:
+            if hd_regressor is None:
+                dense = np.load(osp.join(hd_model_dir, 'smpl_neutral_hd_vert_regressor.npy'))
+                idx = np.argsort(-np.abs(dense), axis=1)[:, :3]
+                hd_regressor = (idx, np.take_along_axis(dense, idx, 1))
+                with open(osp.join(hd_model_dir, 'smpl_neutral_hd_sample_from_mesh_out.pkl'), 'rb') as f:
+                    hd_faces = pickle.load(f)['faces_vert_is_sampled_from']
+            dev = face_tensor.device
+            self.hd_idx = torch.as_tensor(np.asarray(hd_regressor[0]), dtype=torch.long, device=dev)
+            self.hd_w = torch.as_tensor(np.asarray(hd_regressor[1]), dtype=torch.float32, device=dev)
+            self.geovec = torch.as_tensor(np.asarray(hd_faces), dtype=torch.long, device=dev)
+            self.geovec_verts = self.face_tensor[0][self.geovec][:, 0]            # loss.py:88
+        self.segments = segments
+        seg_tables = segments.tables() if segments is not None else None
+        self._model = ops.ContactModel(face_tensor[0], self.geomask, seg_tables, device=face_tensor.device)
+
+    # ------------------------------------------------------------------ contact (loss.py:240-317)
+    def contact_loss(self, pred_vertices, valid_fit):
+        """mean over the valid bodies of  sum_exterior 0.005 tanh^2(d/0.005) + sum_interior tanh^2(d/0.04)
+        with d the distance to the nearest geodesically-far point, on the SMPL vertices
+        (use_hd=False) or on the HD points resampled around contact / interior (use_hd=True)."""
+        model = self._model
+        valid = valid_fit.bool()
+        valid_u8 = valid.to(torch.uint8).contiguous()
+        exterior = model.exterior_flags(pred_vertices, apply_segments=self.segments is not None)
+        min_d2, partner = model.v2v_min(pred_vertices)
+        n_valid = valid.sum().to(torch.float32)
+        if not self.use_hd:
+            per_body, _ = ops.contact_terms(pred_vertices, partner, exterior, valid_u8, ops.MODE_TRAIN,
+                                            self.euclthres)
+            return per_body.sum() / n_valid
+        # HD branch, loss.py:274-301
+        with torch.no_grad():
+            faces = self.face_tensor[0]
+            cand = ((min_d2 < self.euclthres ** 2) | (exterior == 0)) & valid[:, None]      # :278
+            face_sel = cand[:, faces].any(dim=2)                                          # :279-280
+            hd_sel = face_sel[:, self.geovec]                                             # :281
+            bidx, hidx = hd_sel.nonzero(as_tuple=True)
+            counts = hd_sel.sum(dim=1)
+            offsets = torch.zeros(counts.shape[0] + 1, dtype=torch.int32, device=counts.device)
+            offsets[1:] = counts.cumsum(0)
+            n_max = int(counts.max().item())
+        if bidx.numel() == 0:
+            return pred_vertices.sum() * 0.0
+        corner = self.hd_idx[hidx]                                                        # [N,3]
+        hd = (pred_vertices[bidx[:, None], corner] * self.hd_w[hidx][:, :, None]).sum(1)  # :285
+        with torch.no_grad():
+            vid = self.geovec_verts[hidx].to(torch.int32)
+            _, arg = model.v2v_min_indexed(hd, vid, offsets, n_max)                       # :288-291
+            partner_hd = (arg + offsets[:-1][bidx]).to(torch.int32)
+            tris = ops.gather_triangles(pred_vertices, model.faces_i32)
+            normals = 0.001 * batch_face_normals(tris)                                    # :295
+            offs = hd.detach() + normals[bidx, self.geovec[hidx]]                         # :296
+            batch = pred_vertices.shape[0]
+            padded = torch.full((batch, n_max, 3), 1.0e3, dtype=torch.float32, device=hd.device)
+            slot = torch.arange(bidx.numel(), device=hd.device) - offsets[:-1][bidx]
+            padded[bidx, slot] = offs
+            ext_hd = ops.winding_numbers(padded, tris, thresh=0.99)[1][bidx, slot].to(torch.uint8)  # :297
+        total, _ = ops.contact_terms(hd[None], partner_hd[None].contiguous(), ext_hd[None].contiguous(), None,
+                                     ops.MODE_TRAIN, self.euclthres)                      # :299-315
+        return total.sum() / n_valid
+
+    # ---------------------------------------------------------------------------- SPIN terms
+    def forward(self, pred_rotmat, pred_betas, opt_pose, opt_betas, pred_keypoints_2d, gt_keypoints_2d,
+                pred_joints, gt_joints, has_pose_3d, pred_vertices, opt_vertices, pred_camera, valid_fit,
+                valid_fit_shape):
+        """Reference: loss.py:94-168 -> (total_loss, loss_dict with the same 7 keys)."""
+        loss_contact = torch.tensor(0)
+        if self.options.contact_loss_weight > 0:
+            loss_contact = self.contact_loss(pred_vertices, valid_fit)
+        contact_loss = self.options.contact_loss_weight * loss_contact
+        loss_regr_pose, loss_regr_betas = self.smpl_losses(pred_rotmat, pred_betas, opt_pose, opt_betas,
+                                                           valid_fit, valid_fit_shape)
+        loss_keypoints = self.keypoint_loss(pred_keypoints_2d, gt_keypoints_2d,
+                                            self.options.openpose_train_weight, self.options.gt_train_weight,
+                                            valid_fit)
+        loss_keypoints_3d = self.keypoint_3d_loss(pred_joints, gt_joints, has_pose_3d)
+        loss_shape = self.shape_loss(pred_vertices, opt_vertices, valid_fit)
+        cam_loss = ((torch.exp(-pred_camera[:, 0] * 10)) ** 2).mean()
+        o = self.options
+        spin_loss = o.shape_loss_weight * loss_shape + o.keypoint_loss_weight * loss_keypoints + \
+            o.keypoint_loss_weight * loss_keypoints_3d + o.pose_loss_weight * loss_regr_pose + \
+            o.beta_loss_weight * loss_regr_betas + cam_loss
+        loss_dict = {'loss_shape': loss_shape, 'loss_keypoints': loss_keypoints,
+                     'loss_keypoints_3d': loss_keypoints_3d, 'loss_regr_pose': loss_regr_pose,
+                     'loss_regr_betas': loss_regr_betas, 'loss_cam': cam_loss, 'loss_contact': loss_contact}
+        return spin_loss + contact_loss, loss_dict
+
+    def _zero(self):
+        return torch.zeros(1, dtype=torch.float32, device=self.device)
+
+    def keypoint_loss(self, pred_keypoints_2d, gt_keypoints_2d, openpose_weight, gt_weight, valid_fit=None):
+        """Confidence-weighted 2D reprojection MSE (loss.py:172-183)."""
+        conf = gt_keypoints_2d[:, :, -1].unsqueeze(-1).clone()
+        conf[:, :25] *= openpose_weight
+        conf[:, 25:] *= gt_weight
+        loss = (conf * self.criterion_keypoints(pred_keypoints_2d, gt_keypoints_2d[:, :, :-1])).mean(axis=(1, 2))
+        return loss[valid_fit].mean()
+
+    def keypoint_3d_loss(self, pred_keypoints_3d, gt_keypoints_3d, has_pose_3d):
+        """Pelvis-centred 3D keypoint MSE on the 24 ground-truth joints (loss.py:185-204)."""
+        pred = pred_keypoints_3d[:, 25:, :][has_pose_3d == 1]
+        conf = gt_keypoints_3d[:, :, -1].unsqueeze(-1).clone()[has_pose_3d == 1]
+        gt = gt_keypoints_3d[:, :, :-1].clone()[has_pose_3d == 1]
+        if len(gt) == 0:
+            return self._zero()
+        gt = gt - ((gt[:, 2, :] + gt[:, 3, :]) / 2)[:, None, :]
+        pred = pred - ((pred[:, 2, :] + pred[:, 3, :]) / 2)[:, None, :]
+        return (conf * self.criterion_keypoints(pred, gt)).mean()
+
+    def shape_loss(self, pred_vertices, gt_vertices, has_smpl):
+        """Per-vertex L1 where SMPL fits exist (loss.py:206-215)."""
+        pv, gv = pred_vertices[has_smpl == 1], gt_vertices[has_smpl == 1]
+        return self.criterion_shape(pv, gv) if len(gv) > 0 else self._zero()
+
+    def smpl_losses(self, pred_rotmat, pred_betas, gt_pose, gt_betas, has_smpl_pose, has_smpl_shape):
+        """MSE on rotation matrices and betas (loss.py:217-238)."""
+        pr = pred_rotmat[has_smpl_pose == 1]
+        gr = batch_rodrigues(gt_pose.view(-1, 3)).view(-1, 24, 3, 3)[has_smpl_pose == 1]
+        loss_pose = self.criterion_regr(pr, gr) if len(pr) > 0 else self._zero()
+        pb, gb = pred_betas[has_smpl_shape == 1], gt_betas[has_smpl_shape == 1]
+        loss_betas = self.criterion_regr(pb, gb) if len(pb) > 0 else self._zero()
+        return loss_pose, loss_betas
