@@ -42,6 +42,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='bodies per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--eager', action='store_true', help='launch every step eagerly instead of replaying a hipGraph')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     return ap.parse_args()
 
@@ -86,8 +87,9 @@ def make_step(p, world):
     from tuch_amd.smplify.losses import contact_fitting_loss
     body_pose = p['body_pose'].clone().requires_grad_(True)
     global_orient = p['global_orient'].clone().requires_grad_(True)
-    opt = torch.optim.Adam([body_pose, global_orient], lr=1e-2)
+    opt = torch.optim.Adam([body_pose, global_orient], lr=1e-2, capturable=True)
     stats = torch.zeros(2, device=body_pose.device)
+    stats[1] = float(body_pose.shape[0])          # set once: a host scalar write is not graph-capturable
 
     def step():
         out = p['smpl'](global_orient=global_orient, body_pose=body_pose, betas=p['betas'])
@@ -98,15 +100,37 @@ def make_step(p, world):
                                     verts=out.vertices, face_tensor=p['face_tensor'],
                                     focal_length=5000., contact_loss_weight=2000.0,
                                     segments=p['segments'])
-        opt.zero_grad()
+        opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
-        stats[0] = loss.detach()
-        stats[1] = float(body_pose.shape[0])
-        if world > 1:
-            torch.distributed.all_reduce(stats)          # 2 floats over RCCL / xGMI
+        stats[0].copy_(loss.detach())
         return stats
-    return step, (body_pose, global_orient)
+
+    def reduce(local):
+        if world > 1:
+            local = local.clone()
+            torch.distributed.all_reduce(local)          # 2 floats over RCCL / xGMI
+        return local
+    return step, reduce
+
+
+def capture(step, warmup):
+    """Capture one whole step (forward, backward, Adam) into a hipGraph; returns the replay callable."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(max(warmup, 3)):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = step()
+
+    def replay():
+        graph.replay()
+        return out
+    return replay
 
 
 def time_kernel(fn, iters):
@@ -190,7 +214,15 @@ def main():
     device = torch.device('cuda', local)
     torch.manual_seed(1000 + rank)
     p = build_problem(args.batch, device, seed=1002 + rank)
-    step, _ = make_step(p, world)
+    step, reduce = make_step(p, world)
+    launch = 'eager'
+    if not args.eager:
+        try:
+            step = capture(step, args.warmup)
+            launch = 'hipGraph replay of the whole step'
+        except Exception as exc:       # keep the bench alive, say so in the JSON
+            print('graph capture failed, running eagerly: %r' % (exc,), file=sys.stderr)
+            step, reduce = make_step(p, world)
 
     def fence():
         torch.cuda.synchronize()
@@ -199,11 +231,11 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        reduce(step())
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        stats = step()
+        stats = reduce(step())
     fence()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -222,7 +254,7 @@ def main():
                                    'contact_fitting_loss (L_P/L_C push/pull, winding inside test, segment '
                                    'filter, r2r) + backward + Adam, V=6890 F=13776, float32' % args.batch,
                        'bodies_per_gpu': args.batch, 'global_batch': bodies, 'euclthres': 0.02,
-                       'geothres': 0.3, 'parallelism': 'dp%d (bodies sharded, 2-float all-reduce)' % world,
+                       'geothres': 0.3, 'launch': launch, 'parallelism': 'dp%d (bodies sharded, 2-float all-reduce)' % world,
                        'batch_iterations_per_s': round(args.steps / dt, 3),
                        'contact_loss_ms_per_body': round(dt / args.steps * 1e3 / args.batch, 4),
                        'loss_sum': float(stats[0].item()), 'bodies': float(stats[1].item())},

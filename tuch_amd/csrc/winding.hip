@@ -70,16 +70,15 @@ __device__ __forceinline__ v2f atan2_pair(v2f y, v2f x)
 }
 
 // atan2(num, den) when every lane of the wave has |num| < den/8 for both of its queries
-// (far triangles, the overwhelming majority): atan(t) = t - t^3/3 + t^5/5 - t^7/7, truncation
-// error < 1e-9.  Otherwise the whole wave takes the general path; the choice is wave-uniform.
+// (far triangles, the overwhelming majority): atan(t) = t - t^3/3 + t^5/5, truncation error
+// < t^7/7 <= 7e-8 at the gate and ~1e-20 for a typical far triangle (t ~ 1e-3).  Otherwise the whole wave takes the general path; the choice is wave-uniform.
 __device__ __forceinline__ v2f half_angle(v2f num, v2f den)
 {
     const bool big = !(__builtin_fabsf(num[0]) < 0.125f * den[0]) || !(__builtin_fabsf(num[1]) < 0.125f * den[1]);
     if (__builtin_amdgcn_ballot_w64(big) == 0) {
         const v2f t = num * (v2f){__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
         const v2f s = t * t;
-        v2f p = fma2(s, splat2(-1.0f / 7.0f), splat2(0.2f));
-        p = fma2(p, s, splat2(-1.0f / 3.0f));
+        v2f p = fma2(s, splat2(0.2f), splat2(-1.0f / 3.0f));
         p = fma2(p, s, splat2(1.0f));
         return p * t;
     }
@@ -217,9 +216,13 @@ __global__ __launch_bounds__(kBlock) void gather_stream_kernel(
 
 struct Slot { v2f x, y, z, n; };
 
-template <int A>
+// One stream element.  A = register slot of the new vertex (position mod 3), EVEN = position
+// parity.  With P, Q the two previous vertices and N the new one, the triple product is taken as
+// P.(QxN) on even positions and as N.(PxQ) on odd ones, where PxQ is exactly the QxN of the step
+// before -- one cross product serves two consecutive triangles.
+template <int A, bool EVEN>
 __device__ __forceinline__ void strip_step(const StreamElem e, bool emit, Slot (&s)[3], v2f (&d)[3],
-                                           v2f qx, v2f qy, v2f qz, v2f& acc)
+                                           v2f (&c)[3], v2f qx, v2f qy, v2f qz, v2f& acc)
 {
     constexpr int Bq = (A + 1) % 3, Cq = (A + 2) % 3;      // slots of stream positions p-2 and p-1
     s[A].x = splat2(e.x) - qx;
@@ -229,11 +232,14 @@ __device__ __forceinline__ void strip_step(const StreamElem e, bool emit, Slot (
     // d[k] = dot of the two slots other than k
     d[Cq] = fma2(s[A].z, s[Bq].z, fma2(s[A].y, s[Bq].y, s[A].x * s[Bq].x));
     d[Bq] = fma2(s[A].z, s[Cq].z, fma2(s[A].y, s[Cq].y, s[A].x * s[Cq].x));
+    if (EVEN) {                                              // Q x N, also used by the next position
+        c[0] = fma2(s[Cq].y, s[A].z, -(s[Cq].z * s[A].y));
+        c[1] = fma2(s[Cq].z, s[A].x, -(s[Cq].x * s[A].z));
+        c[2] = fma2(s[Cq].x, s[A].y, -(s[Cq].y * s[A].x));
+    }
     if (emit && e.sign != 0.0f) {                            // wave-uniform
-        const v2f cx = fma2(s[Bq].y, s[Cq].z, -(s[Bq].z * s[Cq].y));
-        const v2f cy = fma2(s[Bq].z, s[Cq].x, -(s[Bq].x * s[Cq].z));
-        const v2f cz = fma2(s[Bq].x, s[Cq].y, -(s[Bq].y * s[Cq].x));
-        const v2f num = fma2(s[A].z, cz, fma2(s[A].y, cy, s[A].x * cx));
+        constexpr int T = EVEN ? Bq : A;                     // the vertex not in the cross product
+        const v2f num = fma2(s[T].z, c[2], fma2(s[T].y, c[1], s[T].x * c[0]));
         v2f den = s[0].n * s[1].n * s[2].n;
         den = fma2(d[0], s[0].n, den);
         den = fma2(d[1], s[1].n, den);
@@ -245,7 +251,7 @@ __device__ __forceinline__ void strip_step(const StreamElem e, bool emit, Slot (
 __global__ __launch_bounds__(kStripBlock) void winding_strip_kernel(
     const float* __restrict__ points,            // [B,Q,3]
     const StreamElem* __restrict__ stream,       // [B,Lpad]
-    int Q, int Lpad, int elems_per_split,        // elems_per_split % 3 == 0
+    int Q, int Lpad, int elems_per_split,        // Lpad % 6 == 0, elems_per_split % 6 == 0
     float* __restrict__ partial)                 // [B,S,Q]
 {
     const int b = blockIdx.z, split = blockIdx.y, nsplit = gridDim.y;
@@ -256,26 +262,30 @@ __global__ __launch_bounds__(kStripBlock) void winding_strip_kernel(
     const v2f qy = {pts[3 * c0 + 1], pts[3 * c1 + 1]};
     const v2f qz = {pts[3 * c0 + 2], pts[3 * c1 + 2]};
     const int p_first = split * elems_per_split;
-    const int p_end = min(Lpad - 3, p_first + elems_per_split);   // the prefetch reads up to p_end + 2
+    const int p_end = min(Lpad - 6, p_first + elems_per_split);   // the prefetch reads one sextuple ahead
     const StreamElem* st = stream + (size_t)b * Lpad;
     Slot s[3];
-    v2f d[3];
+    v2f d[3], c[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         s[k].x = s[k].y = s[k].z = s[k].n = splat2(0.0f);
-        d[k] = splat2(0.0f);
+        d[k] = c[k] = splat2(0.0f);
     }
     v2f acc = splat2(0.0f);
-    // the triple before the chunk only primes the slots (a strip may straddle the boundary)
-    int p = max(p_first - 3, 0);
-    StreamElem n0 = st[p], n1 = st[p + 1], n2 = st[p + 2];     // Lpad has a spare triple at the end
-    for (; p < p_end; p += 3) {
+    // the sextuple before the chunk only primes the slots (a strip may straddle the boundary)
+    int p = max(p_first - 6, 0);
+    StreamElem n0 = st[p], n1 = st[p + 1], n2 = st[p + 2], n3 = st[p + 3], n4 = st[p + 4], n5 = st[p + 5];
+    for (; p < p_end; p += 6) {
         const bool emit = p >= p_first;
-        const StreamElem e0 = n0, e1 = n1, e2 = n2;
-        n0 = st[p + 3]; n1 = st[p + 4]; n2 = st[p + 5];        // next triple in flight during the math
-        strip_step<0>(e0, emit, s, d, qx, qy, qz, acc);
-        strip_step<1>(e1, emit, s, d, qx, qy, qz, acc);
-        strip_step<2>(e2, emit, s, d, qx, qy, qz, acc);
+        const StreamElem e0 = n0, e1 = n1, e2 = n2, e3 = n3, e4 = n4, e5 = n5;
+        n0 = st[p + 6]; n1 = st[p + 7]; n2 = st[p + 8];        // next sextuple in flight during the math
+        n3 = st[p + 9]; n4 = st[p + 10]; n5 = st[p + 11];
+        strip_step<0, true>(e0, emit, s, d, c, qx, qy, qz, acc);
+        strip_step<1, false>(e1, emit, s, d, c, qx, qy, qz, acc);
+        strip_step<2, true>(e2, emit, s, d, c, qx, qy, qz, acc);
+        strip_step<0, false>(e3, emit, s, d, c, qx, qy, qz, acc);
+        strip_step<1, true>(e4, emit, s, d, c, qx, qy, qz, acc);
+        strip_step<2, false>(e5, emit, s, d, c, qx, qy, qz, acc);
     }
     float* out = partial + ((size_t)b * nsplit + split) * Q;
     if (q0 < Q) out[q0] = acc[0];
@@ -327,7 +337,8 @@ __global__ __launch_bounds__(kStripBlock) void segment_winding_kernel(
     const float* __restrict__ verts, const float* __restrict__ seg_tris,
     const int32_t* __restrict__ seg_blocks, const int32_t* __restrict__ seg_q_off,
     const int32_t* __restrict__ seg_q_vidx, const int32_t* __restrict__ seg_f_off, int V, int Fs_total,
-    int Qs_total, float* __restrict__ partial)     // [B,kSegSplits,Qs_total]
+    int Qs_total, const uint8_t* __restrict__ skip_if_exterior,   // [B,V] body flags or nullptr
+    float* __restrict__ partial)                   // [B,kSegSplits,Qs_total]
 {
     const int b = blockIdx.z, split = blockIdx.y;
     const int s = seg_blocks[2 * blockIdx.x], q_start = seg_blocks[2 * blockIdx.x + 1];
@@ -335,6 +346,17 @@ __global__ __launch_bounds__(kStripBlock) void segment_winding_kernel(
     const int l0 = q_start + threadIdx.x, l1 = l0 + kStripBlock;
     const int c0 = min(l0, q_cnt - 1), c1 = min(l1, q_cnt - 1);
     const int v0 = seg_q_vidx[q_beg + c0], v1 = seg_q_vidx[q_beg + c1];
+    float* out = partial + ((size_t)b * kSegSplits + split) * Qs_total + q_beg;
+    if (skip_if_exterior) {
+        // the filter can only turn interior vertices exterior (losses.py:85-89): a wave whose
+        // vertices are all exterior already has nothing to decide (w = 0 leaves the flag alone)
+        const bool need = !skip_if_exterior[(size_t)b * V + v0] || !skip_if_exterior[(size_t)b * V + v1];
+        if (__builtin_amdgcn_ballot_w64(need) == 0) {
+            if (l0 < q_cnt) out[l0] = 0.0f;
+            if (l1 < q_cnt) out[l1] = 0.0f;
+            return;
+        }
+    }
     const float* vb = verts + (size_t)b * V * 3;
     const v2f qx = {vb[3 * v0 + 0], vb[3 * v1 + 0]};
     const v2f qy = {vb[3 * v0 + 1], vb[3 * v1 + 1]};
@@ -346,7 +368,6 @@ __global__ __launch_bounds__(kStripBlock) void segment_winding_kernel(
     v2f acc = splat2(0.0f);
     for (int f = f_beg; f < f_end; ++f, t += 9)
         acc += half_solid_angle(t, qx, qy, qz);
-    float* out = partial + ((size_t)b * kSegSplits + split) * Qs_total + q_beg;
     if (l0 < q_cnt) out[l0] = acc[0];
     if (l1 < q_cnt) out[l1] = acc[1];
 }
@@ -400,7 +421,7 @@ struct ExteriorLayout {
     int lpad;
 };
 
-inline int strip_lpad(int L) { return ceil_div(L, 3) * 3 + 6; }
+inline int strip_lpad(int L) { return ceil_div(L, 6) * 6 + 12; }
 
 int choose_splits(int B, int Q, int F);
 
@@ -514,7 +535,7 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
                            (const int32_t*)m->strip_vidx, (const float*)m->strip_sign, m->V, m->strip_len,
                            l.lpad, st);
         const int nsplit = choose_strip_splits(B, m->V, l.lpad);
-        const int per_split = ceil_div(ceil_div(l.lpad - 6, nsplit), 3) * 3;
+        const int per_split = ceil_div(ceil_div(l.lpad - 12, nsplit), 6) * 6;
         hipLaunchKernelGGL(winding_strip_kernel, dim3(ceil_div(m->V, kStripQueries), nsplit, B), dim3(kStripBlock),
                            0, s, verts, (const StreamElem*)st, m->V, l.lpad, per_split, (float*)(ws + l.partial));
         hipLaunchKernelGGL(winding_finalize_kernel, dim3(ceil_div(m->V, kBlock), B), dim3(kBlock), 0, s,
@@ -539,7 +560,8 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
         hipLaunchKernelGGL(segment_winding_kernel, dim3(m->num_seg_blocks, kSegSplits, B), dim3(kStripBlock),
                            0, s, verts, (const float*)seg_tris, (const int32_t*)m->seg_blocks,
                            (const int32_t*)m->seg_q_off, (const int32_t*)m->seg_q_vidx,
-                           (const int32_t*)m->seg_f_off, m->V, m->seg_f_total, m->seg_q_total, seg_partial);
+                           (const int32_t*)m->seg_f_off, m->V, m->seg_f_total, m->seg_q_total,
+                           (seg_w || seg_exterior) ? (const uint8_t*)nullptr : (const uint8_t*)exterior, seg_partial);
         hipLaunchKernelGGL(segment_finalize_kernel, dim3(ceil_div(m->seg_q_total, kBlock), B), dim3(kBlock), 0, s,
                            (const float*)seg_partial, (const int32_t*)m->seg_q_vidx, m->V, m->seg_q_total,
                            thresh, seg_w, seg_exterior, exterior);

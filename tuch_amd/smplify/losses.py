@@ -14,6 +14,7 @@ from .. import ops
 from ..utils.geometry import perspective_projection
 
 _MODEL_CACHE: Dict[tuple, ops.ContactModel] = {}
+_ANGLE_SIGNS: Dict[tuple, tuple] = {}
 
 
 def gmof(x, sigma):
@@ -109,8 +110,12 @@ def camera_fitting_loss(smpl_output, camera_t, camera_t_est, camera_center, join
 def angle_prior(pose):
     """Exponential penalty on unnatural knee / elbow bending (reference: losses.py:155-162;
     indices are into the 69-D body pose, hence the -3)."""
-    signs = torch.tensor([1., -1., -1., -1.], device=pose.device)
-    return torch.exp(pose[:, [55 - 3, 58 - 3, 12 - 3, 15 - 3]] * signs) ** 2
+    key = (pose.device, pose.dtype)
+    if key not in _ANGLE_SIGNS:       # built once per device: a host->device copy cannot be graph-captured
+        _ANGLE_SIGNS[key] = (torch.tensor([1., -1., -1., -1.], device=pose.device, dtype=pose.dtype),
+                             torch.tensor([55 - 3, 58 - 3, 12 - 3, 15 - 3], device=pose.device))
+    signs, idx = _ANGLE_SIGNS[key]
+    return torch.exp(pose.index_select(1, idx) * signs) ** 2
 
 
 def body_fitting_loss(body_pose, betas, model_joints, camera_t, camera_center,
