@@ -24,6 +24,7 @@ struct tuch_contact_model {
     int32_t* cap_vidx;         // ordered boundary loops, concatenated
     int num_seg_blocks;        // 256-query blocks over all segments
     int32_t* seg_blocks;       // [num_seg_blocks][2] = (segment, first query within the segment)
+    int32_t* seg_of_q;         // [seg_q_total] segment of every entry of seg_q_vidx
     int* seg_q_off_host;       // host copies for grid sizing
     int* seg_f_off_host;
     int seg_q_max;

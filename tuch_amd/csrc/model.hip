@@ -110,7 +110,7 @@ void build_strips(const int32_t* faces, int F, std::vector<int32_t>& vidx, std::
 extern "C" void tuch_contact_model_destroy(tuch_contact_model* m)
 {
     if (!m) return;
-    void* dev[] = {m->faces, m->mask_bits, m->strip_vidx, m->strip_sign, m->seg_blocks, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces,
+    void* dev[] = {m->faces, m->mask_bits, m->strip_vidx, m->strip_sign, m->seg_blocks, m->seg_of_q, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces,
                    m->cap_off, m->cap_vidx, m->region_off, m->region_vidx, m->pairs, m->pair_mask, m->pair_mask_off};
     for (void* p : dev)
         if (p) (void)hipFree(p);
@@ -184,6 +184,10 @@ extern "C" int tuch_contact_model_create(
         for (int s = 0; s < num_segments; ++s)
             for (int q = 0; q < seg_q_off[s + 1] - seg_q_off[s]; q += 256) { blocks.push_back(s); blocks.push_back(q); }
         m->num_seg_blocks = (int)blocks.size() / 2;
+        std::vector<int32_t> seg_of_q((size_t)m->seg_q_total);
+        for (int s = 0; s < num_segments; ++s)
+            for (int q = seg_q_off[s]; q < seg_q_off[s + 1]; ++q) seg_of_q[q] = s;
+        if (rc == TUCH_OK) rc = upload(&m->seg_of_q, seg_of_q.data(), seg_of_q.size());
         if (rc == TUCH_OK) rc = upload(&m->seg_blocks, blocks.data(), blocks.size());
         if (rc == TUCH_OK) rc = upload(&m->seg_q_off, seg_q_off, (size_t)num_segments + 1);
         if (rc == TUCH_OK) rc = upload(&m->seg_q_vidx, seg_q_vidx, (size_t)m->seg_q_total);

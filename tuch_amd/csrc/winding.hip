@@ -327,67 +327,113 @@ __global__ __launch_bounds__(kBlock) void gather_segment_triangles_kernel(
     dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
 }
 
-// winding number of every segment vertex w.r.t. its own closed segment
-// (segmentation.py:81-99).  Blocks come from a host-built table (segment, first query) so
-// that segments of very different sizes fill the chip evenly; the segment's faces are split
-// over grid.y and reduced in fixed order by segment_finalize_kernel.
-constexpr int kSegSplits = 4;
+// winding number of segment vertices w.r.t. their own closed segment (segmentation.py:81-99).
+// The filter can only turn INTERIOR vertices exterior (losses.py:85-89, loss.py:264-266), so
+// only those are tested: segment_compact_kernel builds, per (body, segment), the list of the
+// segment's interior vertices; the winding kernel walks dense lists.  Blocks come from a
+// host-built table (segment, first list position); the segment's faces are split over grid.y
+// and reduced in fixed order by segment_finalize_kernel.  (List order comes from an atomic
+// counter and may vary between runs; every entry's result does not.)
+constexpr int kSegSplits = 16;   // maximum; few (compacted) queries per segment: parallelism comes from the faces
+int seg_splits()
+{
+    static const int v = [] { const char* e = getenv("TUCH_SEG_SPLITS"); int x = e ? atoi(e) : 16; return x < 1 ? 1 : (x > kSegSplits ? kSegSplits : x); }();
+    return v;
+}
+
+// list[b][seg_q_off[s] + k] = position (within the segment) of its k-th vertex that needs the test
+__global__ __launch_bounds__(kBlock) void segment_compact_kernel(
+    const uint8_t* __restrict__ exterior,      // [B,V] or nullptr (= test every segment vertex)
+    const int32_t* __restrict__ seg_of_q, const int32_t* __restrict__ seg_q_off,
+    const int32_t* __restrict__ seg_q_vidx, int V, int Qs_total, int S,
+    int32_t* __restrict__ count,               // [B,S], zeroed by the caller
+    int32_t* __restrict__ list)                // [B,Qs_total]
+{
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * kBlock + threadIdx.x;
+    if (q >= Qs_total) return;
+    const int s = seg_of_q[q];
+    const int local = q - seg_q_off[s];
+    if (!exterior) {
+        list[(size_t)b * Qs_total + q] = local;
+        if (local == 0) count[b * S + s] = seg_q_off[s + 1] - seg_q_off[s];
+        return;
+    }
+    if (exterior[(size_t)b * V + seg_q_vidx[q]]) return;
+    const int pos = atomicAdd(&count[b * S + s], 1);
+    list[(size_t)b * Qs_total + seg_q_off[s] + pos] = local;
+}
 
 __global__ __launch_bounds__(kStripBlock) void segment_winding_kernel(
     const float* __restrict__ verts, const float* __restrict__ seg_tris,
     const int32_t* __restrict__ seg_blocks, const int32_t* __restrict__ seg_q_off,
-    const int32_t* __restrict__ seg_q_vidx, const int32_t* __restrict__ seg_f_off, int V, int Fs_total,
-    int Qs_total, const uint8_t* __restrict__ skip_if_exterior,   // [B,V] body flags or nullptr
-    float* __restrict__ partial)                   // [B,kSegSplits,Qs_total]
+    const int32_t* __restrict__ seg_q_vidx, const int32_t* __restrict__ seg_f_off,
+    const int32_t* __restrict__ count, const int32_t* __restrict__ list, int V, int Fs_total,
+    int Qs_total, int S, float* __restrict__ partial)     // [B,kSegSplits,Qs_total] by list position
 {
-    const int b = blockIdx.z, split = blockIdx.y;
-    const int s = seg_blocks[2 * blockIdx.x], q_start = seg_blocks[2 * blockIdx.x + 1];
-    const int q_beg = seg_q_off[s], q_cnt = seg_q_off[s + 1] - q_beg;
-    const int l0 = q_start + threadIdx.x, l1 = l0 + kStripBlock;
-    const int c0 = min(l0, q_cnt - 1), c1 = min(l1, q_cnt - 1);
-    const int v0 = seg_q_vidx[q_beg + c0], v1 = seg_q_vidx[q_beg + c1];
-    float* out = partial + ((size_t)b * kSegSplits + split) * Qs_total + q_beg;
-    if (skip_if_exterior) {
-        // the filter can only turn interior vertices exterior (losses.py:85-89): a wave whose
-        // vertices are all exterior already has nothing to decide (w = 0 leaves the flag alone)
-        const bool need = !skip_if_exterior[(size_t)b * V + v0] || !skip_if_exterior[(size_t)b * V + v1];
-        if (__builtin_amdgcn_ballot_w64(need) == 0) {
-            if (l0 < q_cnt) out[l0] = 0.0f;
-            if (l1 < q_cnt) out[l1] = 0.0f;
-            return;
-        }
-    }
+    // bodies vary fastest in the launch order: consecutive workgroups go to consecutive XCDs, and
+    // the heavy table entries (big segments) would otherwise all land on the same one or two XCDs
+    const int b = blockIdx.x, split = blockIdx.y;
+    const int s = seg_blocks[2 * blockIdx.z], k_start = seg_blocks[2 * blockIdx.z + 1];
+    const int n = count[b * S + s];
+    if (k_start >= n) return;
+    const int q_beg = seg_q_off[s];
+    const int32_t* mine = list + (size_t)b * Qs_total + q_beg;
+    const int k0 = k_start + threadIdx.x, k1 = k0 + kStripBlock;
+    const int v0 = seg_q_vidx[q_beg + mine[min(k0, n - 1)]], v1 = seg_q_vidx[q_beg + mine[min(k1, n - 1)]];
     const float* vb = verts + (size_t)b * V * 3;
     const v2f qx = {vb[3 * v0 + 0], vb[3 * v1 + 0]};
     const v2f qy = {vb[3 * v0 + 1], vb[3 * v1 + 1]};
     const v2f qz = {vb[3 * v0 + 2], vb[3 * v1 + 2]};
     const int f_seg = seg_f_off[s], f_cnt = seg_f_off[s + 1] - f_seg;
-    const int per = (f_cnt + kSegSplits - 1) / kSegSplits;
+    const int nsplit = gridDim.y;
+    const int per = (f_cnt + nsplit - 1) / nsplit;
     const int f_beg = f_seg + split * per, f_end = min(f_seg + f_cnt, f_beg + per);
-    const float* t = seg_tris + ((size_t)b * Fs_total + f_beg) * 9;
+    // Few waves are alive here (compacted queries), so a per-triangle scalar load would expose its
+    // full memory latency every iteration.  Stage the chunk's triangles in LDS with coalesced
+    // vector loads (many in flight), then read them back as broadcasts.
+    __shared__ float sT[kStripBlock * 9];
     v2f acc = splat2(0.0f);
-    for (int f = f_beg; f < f_end; ++f, t += 9)
-        acc += half_solid_angle(t, qx, qy, qz);
-    if (l0 < q_cnt) out[l0] = acc[0];
-    if (l1 < q_cnt) out[l1] = acc[1];
+    for (int chunk = f_beg; chunk < f_end; chunk += kStripBlock) {
+        const int cn = min(kStripBlock, f_end - chunk);
+        const float* src = seg_tris + ((size_t)b * Fs_total + chunk) * 9;
+        __syncthreads();
+        for (int i = threadIdx.x; i < cn * 9; i += kStripBlock) sT[i] = src[i];
+        __syncthreads();
+        for (int f = 0; f < cn; ++f) {
+            float tri[9];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) tri[e] = sT[f * 9 + e];
+            acc += half_solid_angle(tri, qx, qy, qz);
+        }
+    }
+    float* out = partial + ((size_t)b * nsplit + split) * Qs_total + q_beg;
+    if (k0 < n) out[k0] = acc[0];
+    if (k1 < n) out[k1] = acc[1];
 }
 
 // vertices that are NOT exterior to their own segment are re-marked exterior in the body
 // flags (losses.py:87-89, loss.py:265-266)
 __global__ __launch_bounds__(kBlock) void segment_finalize_kernel(
-    const float* __restrict__ partial, const int32_t* __restrict__ seg_q_vidx, int V, int Qs_total,
-    float thresh, float* __restrict__ seg_w, uint8_t* __restrict__ seg_ext, uint8_t* __restrict__ exterior)
+    const float* __restrict__ partial, const int32_t* __restrict__ seg_of_q,
+    const int32_t* __restrict__ seg_q_off, const int32_t* __restrict__ seg_q_vidx,
+    const int32_t* __restrict__ count, const int32_t* __restrict__ list, int V, int Qs_total, int S,
+    int nsplit, float thresh, float* __restrict__ seg_w, uint8_t* __restrict__ seg_ext, uint8_t* __restrict__ exterior)
 {
     const int b = blockIdx.y;
-    const int q = blockIdx.x * kBlock + threadIdx.x;
+    const int q = blockIdx.x * kBlock + threadIdx.x;       // a list position
     if (q >= Qs_total) return;
+    const int s = seg_of_q[q];
+    const int k = q - seg_q_off[s];
+    if (k >= count[b * S + s]) return;
     float acc = 0.0f;
-    for (int sp = 0; sp < kSegSplits; ++sp) acc += partial[((size_t)b * kSegSplits + sp) * Qs_total + q];
+    for (int sp = 0; sp < nsplit; ++sp) acc += partial[((size_t)b * nsplit + sp) * Qs_total + q];
     const float w = acc * (0.5f / kPi);
-    const size_t o = (size_t)b * Qs_total + q;
+    const int qq = seg_q_off[s] + list[(size_t)b * Qs_total + q];   // the vertex's slot in the segment tables
+    const size_t o = (size_t)b * Qs_total + qq;
     if (seg_w) seg_w[o] = w;
     if (seg_ext) seg_ext[o] = w <= thresh;
-    if (exterior && !(w <= thresh)) exterior[(size_t)b * V + seg_q_vidx[q]] = 1;
+    if (exterior && !(w <= thresh)) exterior[(size_t)b * V + seg_q_vidx[qq]] = 1;
 }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -417,7 +463,7 @@ int choose_strip_splits(int B, int Q, int L)
 }
 
 struct ExteriorLayout {
-    size_t tris, partial, caps, seg_tris, seg_partial, total;
+    size_t tris, partial, caps, seg_tris, seg_partial, seg_count, seg_list, total;
     int lpad;
 };
 
@@ -438,8 +484,10 @@ ExteriorLayout exterior_layout(const tuch_contact_model* m, int B)
                                ? choose_splits(B, m->V, m->F) : choose_strip_splits(B, m->V, strip_lpad(m->strip_len));
     l.partial = o;  o += align256((size_t)B * max_splits * m->V * sizeof(float));
     l.caps = o;     o += align256((size_t)B * (m->num_caps > 0 ? m->num_caps : 1) * 3 * sizeof(float));
-    l.seg_tris = o; o += align256((size_t)B * (m->seg_f_total > 0 ? m->seg_f_total : 1) * 9 * sizeof(float));
+    l.seg_tris = o; o += align256(((size_t)B * (m->seg_f_total > 0 ? m->seg_f_total : 1) + 1) * 9 * sizeof(float));
     l.seg_partial = o; o += align256((size_t)B * kSegSplits * (m->seg_q_total > 0 ? m->seg_q_total : 1) * sizeof(float));
+    l.seg_count = o; o += align256((size_t)B * (m->num_segments > 0 ? m->num_segments : 1) * sizeof(int32_t));
+    l.seg_list = o; o += align256((size_t)B * (m->seg_q_total > 0 ? m->seg_q_total : 1) * sizeof(int32_t));
     l.total = o;
     return l;
 }
@@ -557,14 +605,26 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
                            dim3(kBlock), 0, s, verts, (const float*)caps, (const int32_t*)m->seg_faces,
                            m->V, m->num_caps, m->seg_f_total, seg_tris);
         float* seg_partial = (float*)(ws + l.seg_partial);
-        hipLaunchKernelGGL(segment_winding_kernel, dim3(m->num_seg_blocks, kSegSplits, B), dim3(kStripBlock),
+        int32_t* seg_count = (int32_t*)(ws + l.seg_count);
+        int32_t* seg_list = (int32_t*)(ws + l.seg_list);
+        const bool all = seg_w || seg_exterior;     // the detailed outputs want every segment vertex
+        if (hipMemsetAsync(seg_count, 0, (size_t)B * m->num_segments * sizeof(int32_t), s) != hipSuccess) {
+            tuch_set_error("tuch_exterior_flags: hipMemsetAsync failed");
+            return TUCH_ERR_HIP;
+        }
+        hipLaunchKernelGGL(segment_compact_kernel, dim3(ceil_div(m->seg_q_total, kBlock), B), dim3(kBlock), 0, s,
+                           all ? (const uint8_t*)nullptr : (const uint8_t*)exterior, (const int32_t*)m->seg_of_q,
+                           (const int32_t*)m->seg_q_off, (const int32_t*)m->seg_q_vidx, m->V, m->seg_q_total,
+                           m->num_segments, seg_count, seg_list);
+        hipLaunchKernelGGL(segment_winding_kernel, dim3(B, seg_splits(), m->num_seg_blocks), dim3(kStripBlock),
                            0, s, verts, (const float*)seg_tris, (const int32_t*)m->seg_blocks,
                            (const int32_t*)m->seg_q_off, (const int32_t*)m->seg_q_vidx,
-                           (const int32_t*)m->seg_f_off, m->V, m->seg_f_total, m->seg_q_total,
-                           (seg_w || seg_exterior) ? (const uint8_t*)nullptr : (const uint8_t*)exterior, seg_partial);
+                           (const int32_t*)m->seg_f_off, (const int32_t*)seg_count, (const int32_t*)seg_list,
+                           m->V, m->seg_f_total, m->seg_q_total, m->num_segments, seg_partial);
         hipLaunchKernelGGL(segment_finalize_kernel, dim3(ceil_div(m->seg_q_total, kBlock), B), dim3(kBlock), 0, s,
-                           (const float*)seg_partial, (const int32_t*)m->seg_q_vidx, m->V, m->seg_q_total,
-                           thresh, seg_w, seg_exterior, exterior);
+                           (const float*)seg_partial, (const int32_t*)m->seg_of_q, (const int32_t*)m->seg_q_off,
+                           (const int32_t*)m->seg_q_vidx, (const int32_t*)seg_count, (const int32_t*)seg_list,
+                           m->V, m->seg_q_total, m->num_segments, seg_splits(), thresh, seg_w, seg_exterior, exterior);
     }
     return tuch_check_launch("tuch_exterior_flags");
 }
