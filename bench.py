@@ -33,6 +33,9 @@ FLOP_PER_WINDING_PAIR = 67        # 63 arithmetic + 3 sqrt + 1
 FLOP_PER_V2V_PAIR = 8
 PEAK_FP32_VECTOR_TFLOPS = 157.3   # MI355X_MICROARCH.md (packed FP32 FMA rate)
 PEAK_HBM_GBS = 8000.0
+# HBM-side bytes per launch of winding_strip_kernel at batch 64 from the PMC passes committed under
+# profiles/ (FETCH_SIZE 18607.5 KB + WRITE_SIZE 12470.2 KB); algorithmic: 19.9 MB in + 12.3 MB out
+WINDING_TRAFFIC_BYTES = int((18607.5 + 12470.2) * 1024)
 
 
 def parse():
@@ -160,7 +163,10 @@ def rooflines(p, batch):
     ach = flops / t_w / 1e12
     roof = {'kernel': 'winding_strip_kernel', 'bound': 'valu', 'achieved': round(ach, 2),
             'peak': PEAK_FP32_VECTOR_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_VECTOR_TFLOPS, 4),
-            'traffic': None, 'launch_ms': round(t_w * 1e3, 4),
+            'traffic': WINDING_TRAFFIC_BYTES if batch == BATCH_PER_GPU else None,
+            'traffic_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, KB x 1024 '
+                              '(profiles/r01_d_pmc_*_xcd_order.txt); narrow loads: counter uncalibrated',
+            'launch_ms': round(t_w * 1e3, 4),
             'algorithmic_flop_per_launch': flops,
             'algorithmic_bytes_per_launch': batch * (v * 12 + v * 4) + f * 12}
     t_v = time_kernel(lambda: model.v2v_min(verts), 10)

@@ -65,11 +65,12 @@ __global__ __launch_bounds__(kBlock) void v2v_partial_kernel(
     float* __restrict__ part_min,         // [B,S,V]
     int* __restrict__ part_arg)           // [B,S,V]
 {
-    const int b = blockIdx.z, split = blockIdx.y, nsplit = gridDim.y;
+    // body index fastest in the launch order (XCD b % 8 keeps body b's vertices in one L2)
+    const int b = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // first 64-column block of this wave; readfirstlane tells the compiler it is wave-uniform so
     // that the mask words come in through scalar loads (otherwise: one VMEM round trip per row)
-    const int w0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * kWaves + wave) * 2);
+    const int w0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.z * kWaves + wave) * 2);
     if (w0 * 64 >= V) return;                                  // wave-uniform: no columns left
     const int i0 = w0 * 64 + lane, i1 = i0 + 64;
     const float* vb = verts + (size_t)b * V * 3;
@@ -214,7 +215,7 @@ extern "C" int tuch_v2v_min_masked(const float* verts, const uint64_t* geomask_b
                                    size_t workspace_bytes, void* stream)
 {
     TUCH_REQUIRE(verts && geomask_bits && (min_d2 || argmin), "tuch_v2v_min_masked: null pointer");
-    TUCH_REQUIRE(B > 0 && V > 0, "tuch_v2v_min_masked: bad sizes B=%d V=%d", B, V);
+    TUCH_REQUIRE(B > 0 && B <= 65535 && V > 0, "tuch_v2v_min_masked: bad sizes B=%d V=%d", B, V);
     const int nsplit = choose_row_splits(B, V);
     const size_t n = (size_t)B * nsplit * V;
     if (!workspace || workspace_bytes < n * (sizeof(float) + sizeof(int))) {
@@ -225,7 +226,7 @@ extern "C" int tuch_v2v_min_masked(const float* verts, const uint64_t* geomask_b
     float* pmin = (float*)workspace;
     int* parg = (int*)(pmin + n);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(v2v_partial_kernel, dim3(ceil_div(V, kColsPerBlock), nsplit, B), dim3(kBlock), 0, s,
+    hipLaunchKernelGGL(v2v_partial_kernel, dim3(B, nsplit, ceil_div(V, kColsPerBlock)), dim3(kBlock), 0, s,
                        verts, geomask_bits, V, ceil_div(V, nsplit), pmin, parg);
     hipLaunchKernelGGL(v2v_merge_kernel, dim3(ceil_div(V, kBlock), B), dim3(kBlock), 0, s,
                        (const float*)pmin, (const int*)parg, V, nsplit, min_d2, argmin);
