@@ -1,0 +1,134 @@
+"""GPU: size-independent properties at BASELINE.json's full size (batch 64, V=6890, F=13776) and
+edge cases (ragged sizes, empty tables, fully masked columns, ignored bodies)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close
+from oracle import contact as oc
+from oracle import lbs as ol
+from tuch_amd.synthetic import make_body, random_poses
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def full():
+    body = make_body(84, 82, with_geodesics=False)
+    bp, go, be = random_poses(64, 4242)
+    v, _ = ol.smpl_forward(ol.model_tensors(body), torch.tensor(be), torch.tensor(bp), torch.tensor(go))
+    idx = np.arange(body.num_verts)
+    mask = np.abs(idx[:, None] - idx[None, :]) > 300          # any symmetric mask will do here
+    return body, v.numpy().astype(np.float32), mask
+
+
+def test_full_batch_winding_is_deterministic_and_rigid_invariant(full):
+    from tuch_amd.ops import ContactModel
+    body, verts_np, _ = full
+    model = ContactModel(body.faces, None, None, device=DEV)
+    verts = torch.tensor(verts_np, device=DEV)
+    e1, w1, _, _ = model.exterior_flags(verts, apply_segments=False, return_details=True)
+    e2, w2, _, _ = model.exterior_flags(verts, apply_segments=False, return_details=True)
+    assert torch.equal(w1, w2) and torch.equal(e1, e2)                      # bit-reproducible
+    # rigid motion leaves winding numbers unchanged (up to rounding of the moved coordinates)
+    rot = ol.rodrigues(torch.tensor([[0.4, -0.7, 0.2]])).to(DEV)[0]
+    moved = verts @ rot.T + torch.tensor([0.3, -0.2, 0.5], device=DEV)
+    _, w3, _, _ = model.exterior_flags(moved.contiguous(), apply_segments=False, return_details=True)
+    err = (w3 - w1).abs()
+    assert err.median() < 1e-6 and torch.quantile(err.flatten()[::7], 0.999) < 5e-5
+    # spot check against the CPU oracle
+    for b in (0, 37, 63):
+        wo = oc.winding_numbers(verts_np[b], oc.gather_tris(verts_np[b], body.faces))
+        d = np.abs(w1[b].cpu().numpy() - wo)
+        assert np.percentile(d, 99) < 5e-6 and d.max() < 2e-4
+
+
+def test_full_batch_v2v_matches_oracle_and_is_deterministic(full):
+    from tuch_amd.ops import ContactModel
+    body, verts_np, mask = full
+    model = ContactModel(body.faces, mask, None, device=DEV)
+    verts = torch.tensor(verts_np, device=DEV)
+    mn1, a1 = model.v2v_min(verts)
+    mn2, a2 = model.v2v_min(verts)
+    assert torch.equal(mn1, mn2) and torch.equal(a1, a2)
+    a1n, mn1n = a1.cpu().numpy().astype(np.int64), mn1.cpu().numpy()
+    assert mask[a1n, np.arange(mask.shape[0])[None, :]].all()              # partners respect the mask
+    for b in (0, 31, 63):
+        v = verts_np[b].astype(np.float64)
+        d_true = ((v - v[a1n[b]]) ** 2).sum(1)
+        assert_close(mn1n[b], d_true, 1e-5, 1e-9, 'min = distance to the returned partner')
+        mo, ao = oc.v2v_min_masked(verts_np[b], mask)
+        same = ao == a1n[b]
+        assert same.mean() > 0.99
+        d_ref = ((v - v[ao]) ** 2).sum(1)
+        assert np.all(d_true <= d_ref + 1e-9)                              # never worse than the bmm-form pick
+
+
+def test_closed_mesh_inside_outside_points(full):
+    from tuch_amd import ops
+    body, _, _ = full
+    v = torch.tensor(body.v_template, device=DEV)[None]
+    tris = ops.gather_triangles(v, torch.tensor(body.faces.astype(np.int32), device=DEV))
+    pts = torch.tensor([[[0.0, 0.0, 0.0], [0.0, 0.3, 0.0], [3.0, 3.0, 3.0], [0.0, -2.0, 0.5]]], device=DEV)
+    w = ops.winding_numbers(pts, tris)[0].cpu().numpy()
+    assert_close(w, [1.0, 1.0, 0.0, 0.0], 0, 2e-5, 'inside/outside')
+
+
+@pytest.mark.parametrize('rings,segs,batch', [(5, 13, 1), (9, 7, 3), (12, 14, 5)])
+def test_ragged_sizes_match_oracle(rings, segs, batch):
+    """V = rings*segs+2 is not a multiple of 64 (or of anything convenient)."""
+    from tuch_amd.ops import ContactModel, contact_terms, MODE_TRAIN
+    body = make_body(rings, segs, relax_iters=20)
+    bp, go, be = random_poses(batch, 77)
+    verts_np = ol.smpl_forward(ol.model_tensors(body), torch.tensor(be), torch.tensor(bp),
+                               torch.tensor(go))[0].numpy().astype(np.float32)
+    gm = body.geodesics > 0.3
+    segs_t = [(s['vidx'], list(s['bands'].values())) for s in body.segments.values()]
+    model = ContactModel(body.faces, gm, segs_t or None, device=DEV)
+    verts = torch.tensor(verts_np, device=DEV, requires_grad=True)
+    ext = model.exterior_flags(verts, apply_segments=bool(segs_t))
+    mn, arg = model.v2v_min(verts)
+    per_body, _ = contact_terms(verts, arg, ext, None, MODE_TRAIN, 0.02)
+    per_body.sum().backward()
+    osegs = [oc.Segment(n, body.faces, s['vidx'], list(s['bands'].values())) for n, s in body.segments.items()]
+    for b in range(batch):
+        r = oc.train_contact_body(verts_np[b], body.faces, gm, 0.02, osegs, False)
+        flips = (ext[b].cpu().numpy().astype(bool) != r['exterior_verts'])
+        near = np.abs(r['winding'] - 0.99) < 1e-4
+        assert not (flips & ~near).any()
+        if not flips.any():
+            assert_close(per_body[b].item(), r['loss'], 1e-4, 1e-6, 'loss')
+            assert_close(verts.grad[b].cpu().numpy(), r['grad'], 1e-3, 1e-5 * max(np.abs(r['grad']).max(), 1e-3), 'grad')
+
+
+def test_fully_masked_columns_and_ignored_bodies():
+    from tuch_amd.ops import ContactModel, contact_terms, MODE_SMPLIFY
+    body = make_body(10, 12)
+    gm = body.geodesics > 0.3
+    gm[:, 5] = False
+    gm[5, :] = False                                   # vertex 5 has no admissible partner
+    verts = torch.tensor(body.v_template, device=DEV)[None].repeat(2, 1, 1).contiguous()
+    model = ContactModel(body.faces, gm, None, device=DEV)
+    mn, arg = model.v2v_min(verts)
+    assert torch.isinf(mn[:, 5]).all() and (arg[:, 5] == 0).all()          # torch.min/argmin of an all-inf column
+    ext = model.exterior_flags(verts, apply_segments=False)
+    assert ext.all()                                                        # rest pose: nothing is inside
+    valid = torch.tensor([1, 0], dtype=torch.uint8, device=DEV)
+    per_body, _ = contact_terms(verts, arg, ext, valid, MODE_SMPLIFY, 0.02)
+    assert per_body[1].item() == 0.0                                        # ignored body contributes nothing
+
+
+def test_model_without_optional_tables():
+    from tuch_amd import _C
+    from tuch_amd.ops import ContactModel
+    body = make_body(10, 12, with_geodesics=False)
+    model = ContactModel(body.faces, None, None, None, None, device=DEV)
+    verts = torch.tensor(body.v_template, device=DEV)[None]
+    assert model.exterior_flags(verts, apply_segments=True).shape == (1, body.num_verts)
+    with pytest.raises(_C.TuchError):
+        model.v2v_min(verts)
+    with pytest.raises(_C.TuchError):
+        model.region_pair_min(verts)
+    with pytest.raises(_C.TuchError):
+        model.exterior_flags(verts.cpu())

@@ -1,0 +1,111 @@
+"""GPU: the SMPLify-DC loop (a9 of SURVEY.md §8a).  The stage-2 gradient with respect to the
+optimised parameters is checked against a gradient composed from the CPU oracle pieces
+(oracle LBS autograd fed with the oracle's analytic contact gradient), and the optimiser is run
+end to end on a small model."""
+import numpy as np
+import pytest
+import torch
+
+import golden_io as gio
+from helpers import assert_close, golden, golden_mask, oracle_segments, region_pair_lists
+from oracle import contact as oc
+from oracle import lbs as ol
+from tuch_amd.synthetic import make_body, random_poses
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _setup(batch, seed):
+    from tuch_amd.models.smpl import SMPL
+    from tuch_amd.smplify.prior import MaxMixturePrior
+    from tuch_amd.utils.segmentation import BatchBodySegment
+    body = make_body(14, 16, relax_iters=40)
+    smpl = SMPL(model_data=body, batch_size=batch).to(DEV)
+    prior = MaxMixturePrior(num_gaussians=8, gmm=body.gmm).to(DEV)
+    bp, go, be = random_poses(batch, seed)
+    rng = np.random.default_rng(seed)
+    t = lambda a: torch.tensor(a, device=DEV)
+    faces = t(body.faces)
+    segments = BatchBodySegment(list(body.segments.keys()), faces, body.segments) if body.segments else None
+    cdict = {'classes': [list(p) for p in body.region_pairs], 'csig': dict(body.regions)}
+    gt = (rng.random((batch, len(body.region_pairs))) < 0.05).astype(np.float32)
+    kp = np.concatenate([rng.standard_normal((batch, 49, 2)).astype(np.float32) * 30,
+                         (0.5 + 0.5 * rng.random((batch, 49, 1))).astype(np.float32)], 2)
+    return dict(body=body, smpl=smpl, prior=prior, bp=bp, go=go, be=be, segments=segments, cdict=cdict, gt=gt,
+                kp=kp, cam_t=np.tile([[0., 0., 20.]], (batch, 1)).astype(np.float32), t=t)
+
+
+def test_stage2_gradient_matches_oracle_composition():
+    from tuch_amd.smplify.losses import contact_fitting_loss
+    batch = 3
+    s = _setup(batch, 11)
+    body, t = s['body'], s['t']
+    gm = body.geodesics > 0.3
+    bp = t(s['bp']).requires_grad_(True)
+    go = t(s['go']).requires_grad_(True)
+    out = s['smpl'](global_orient=go, body_pose=bp, betas=t(s['be']))
+    zero_prior = lambda pose, betas: torch.zeros(pose.shape[0], device=DEV)
+    face_tensor = t(body.faces)[None].repeat(batch, 1, 1)
+    loss = contact_fitting_loss(bp, go, None, None, t(s['be']), out.joints, t(gm), 0.02, t(s['cam_t']),
+                                torch.zeros(batch, 2, device=DEV), t(s['kp'][:, :, :2]),
+                                torch.zeros(batch, 49, device=DEV), zero_prior, s['cdict'],
+                                [t(s['gt']), None], torch.zeros(batch, dtype=torch.bool, device=DEV),
+                                torch.ones(batch, dtype=torch.bool, device=DEV), out.vertices,
+                                face_tensor=face_tensor, contact_loss_weight=2000.0, segments=s['segments'])
+    loss.backward()
+    # oracle: forward LBS (fp64 autograd), contact gradient from the analytic oracle
+    m64 = ol.model_tensors(body, torch.float64)
+    t64 = lambda a: torch.tensor(a, dtype=torch.float64)
+    bp64, go64 = t64(s['bp']).requires_grad_(True), t64(s['go']).requires_grad_(True)
+    v64, _ = ol.smpl_forward(m64, t64(s['be']), bp64, go64)
+    osegs = [oc.Segment(n, body.faces, sg['vidx'], list(sg['bands'].values())) for n, sg in body.segments.items()]
+    names = list(body.regions.keys())
+    total, gv = 0.0, np.zeros((batch, body.num_verts, 3))
+    v32 = out.vertices.detach().cpu().numpy()
+    for b in range(batch):
+        rp = [(body.regions[a], body.regions[c]) for k, (a, c) in enumerate(body.region_pairs) if s['gt'][b, k] == 1]
+        r = oc.smplify_contact_body(v32[b], body.faces, gm, 0.02, osegs or None, rp)
+        total += 10 * r['contact'] + 2000.0 * r['r2r']
+        gv[b] = 10 * r['grad_contact'] + 2000.0 * r['grad_r2r']
+    (v64 * torch.tensor(gv)).sum().backward()
+    assert_close(loss.item(), total, 1e-4, 2000 * 1e-6 * max(float(s['gt'].sum()), 1.0), 'stage-2 loss')
+    # the contact terms are invariant under a rigid rotation about the root, so d/d(global_orient) is
+    # analytically zero: both sides hold cancellation noise there -> one absolute scale for both
+    scale = float(bp64.grad.abs().max())
+    for got, want, name in ((bp.grad, bp64.grad, 'body_pose'), (go.grad, go64.grad, 'global_orient')):
+        assert_close(got.cpu().numpy(), want.numpy(), 2e-3, 2e-4 * scale, 'grad ' + name)
+
+
+@pytest.mark.parametrize('use_contact', [True, False])
+def test_smplifydc_runs_and_reduces_the_objective(use_contact):
+    from tuch_amd.smplify.smplifydc import SMPLifyDC
+    batch = 4
+    s = _setup(batch, 5)
+    body, t = s['body'], s['t']
+    geod = t(body.geodesics)
+    fitter = SMPLifyDC(step_size=1e-2, batch_size=batch, num_iters=6, focal_length=5000., geodistssmpl=geod,
+                       geothres=0.3, euclthres=0.02, device=torch.device(DEV), smpl=s['smpl'],
+                       pose_prior=s['prior'])
+    # keypoints = projection of a perturbed pose, so that there is something to fit
+    from tuch_amd.utils.geometry import perspective_projection
+    with torch.no_grad():
+        tgt = s['smpl'](global_orient=t(s['go']), body_pose=t(s['bp']) + 0.1, betas=t(s['be']))
+        j2d = perspective_projection(tgt.joints, torch.eye(3, device=DEV)[None].expand(batch, -1, -1),
+                                     t(s['cam_t']), 5000., torch.zeros(batch, 2, device=DEV))
+    kp = torch.cat([j2d, torch.ones(batch, 49, 1, device=DEV)], 2)
+    init_pose = torch.cat([t(s['go']), t(s['bp'])], 1)
+    before = fitter.get_fitting_loss(init_pose, t(s['be']), t(s['cam_t']), torch.zeros(batch, 2, device=DEV),
+                                     kp.clone()).sum().item()
+    res = fitter(init_pose, t(s['be']), t(s['cam_t']), torch.zeros(batch, 2, device=DEV), kp.clone(),
+                 use_contact=use_contact, contactlist=s['cdict'], gt_contact=[t(s['gt']), None],
+                 ignore_idxs=torch.zeros(batch, dtype=torch.bool, device=DEV),
+                 has_discrete_contact=torch.ones(batch, dtype=torch.bool, device=DEV),
+                 contact_loss_weight=1.0, segments=s['segments'])
+    verts, joints, pose, betas, cam, reproj, optiverts = res
+    assert verts.shape == (batch, body.num_verts, 3) and joints.shape == (batch, 49, 3)
+    assert pose.shape == (batch, 72) and betas.shape == (batch, 10) and cam.shape == (batch, 3)
+    assert reproj.shape == (batch, 49) and len(optiverts) == 6
+    assert torch.isfinite(verts).all() and torch.isfinite(reproj).all()
+    assert reproj.sum().item() < before                       # the fit moved toward the keypoints
+    assert not torch.equal(pose, init_pose)
