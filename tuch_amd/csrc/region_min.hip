@@ -36,19 +36,13 @@ __global__ __launch_bounds__(kBlock) void region_pair_min_kernel(
     const uint8_t* __restrict__ select,        // [B,P] or nullptr (= all)
     const uint32_t* __restrict__ pair_mask,    // per-pair geomask blocks or nullptr (= unmasked)
     const int64_t* __restrict__ pair_mask_off,
-    int V, int P, float* __restrict__ out_min, int32_t* __restrict__ out_ij)
+    int V, int P, unsigned long long* __restrict__ keys)   // [B,P], preset to all ones
 {
     __shared__ float sx[kTile], sy[kTile], sz[kTile];
     __shared__ Best swave[kBlock / 64];
     const int p = blockIdx.x, b = blockIdx.y;
     const size_t o = (size_t)b * P + p;
-    if (select && !select[o]) {
-        if (threadIdx.x == 0) {
-            out_min[o] = 0.0f;
-            if (out_ij) { out_ij[2 * o] = -1; out_ij[2 * o + 1] = -1; }
-        }
-        return;
-    }
+    if (select && !select[o]) return;
     const int r1 = pairs[2 * p], r2 = pairs[2 * p + 1];
     const int a_beg = region_off[r1], n1 = region_off[r1 + 1] - a_beg;
     const int b_beg = region_off[r2], n2 = region_off[r2 + 1] - b_beg;
@@ -62,7 +56,10 @@ __global__ __launch_bounds__(kBlock) void region_pair_min_kernel(
             sx[k] = vb[3 * v]; sy[k] = vb[3 * v + 1]; sz[k] = vb[3 * v + 2];
         }
         __syncthreads();
-        for (int a = threadIdx.x; a < n1; a += kBlock) {
+        // rows of the first region are split over blockIdx.z (more workgroups per selected pair)
+        const int rows = (n1 + gridDim.z - 1) / gridDim.z;
+        const int a_lo = blockIdx.z * rows, a_hi = min(n1, a_lo + rows);
+        for (int a = a_lo + threadIdx.x; a < a_hi; a += kBlock) {
             const int i = region_vidx[a_beg + a];
             const float px = vb[3 * i], py = vb[3 * i + 1], pz = vb[3 * i + 2];
             const uint32_t* mrow = pair_mask ? pair_mask + pair_mask_off[p] + (size_t)a * ((n2 + 31) / 32) + (t0 >> 5)
@@ -92,13 +89,36 @@ __global__ __launch_bounds__(kBlock) void region_pair_min_kernel(
     if (threadIdx.x == 0) {
         Best r = swave[0];
         for (int w = 1; w < kBlock / 64; ++w) r = better(r, swave[w]);
-        out_min[o] = r.d;
-        if (out_ij) {
-            const bool ok = r.idx != 0x7fffffff && n2 > 0;
-            out_ij[2 * o] = ok ? region_vidx[a_beg + r.idx / n2] : -1;
-            out_ij[2 * o + 1] = ok ? region_vidx[b_beg + r.idx % n2] : -1;
-        }
+        // d >= 0, so the float's bit pattern orders like the value: (d, flat index) packs into one
+        // 64-bit key whose minimum is independent of the arrival order -> deterministic
+        if (r.idx != 0x7fffffff)
+            atomicMin(&keys[o], ((unsigned long long)__float_as_uint(r.d) << 32) | (unsigned int)r.idx);
     }
+}
+
+// keys -> (min d2, arg-min vertex ids); unselected / empty pairs give 0 and (-1, -1).  The keys
+// live in the storage of out_ij and are overwritten in place.
+__global__ __launch_bounds__(kBlock) void region_pair_finalize_kernel(
+    const int32_t* __restrict__ region_off, const int32_t* __restrict__ region_vidx,
+    const int32_t* __restrict__ pairs, int P, float* __restrict__ out_min, int32_t* __restrict__ out_ij)
+{
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= P) return;
+    const size_t o = (size_t)b * P + p;
+    const unsigned long long key = ((const unsigned long long*)out_ij)[o];
+    if (key == ~0ull) {
+        out_min[o] = 0.0f;
+        out_ij[2 * o] = -1;
+        out_ij[2 * o + 1] = -1;
+        return;
+    }
+    const int r1 = pairs[2 * p], r2 = pairs[2 * p + 1];
+    const int n2 = region_off[r2 + 1] - region_off[r2];
+    const int idx = (int)(unsigned int)key;
+    out_min[o] = __uint_as_float((unsigned int)(key >> 32));
+    out_ij[2 * o] = region_vidx[region_off[r1] + idx / n2];
+    out_ij[2 * o + 1] = region_vidx[region_off[r2] + idx % n2];
 }
 
 // d(min d2)/dv: +2 g (v_i - v_j) to i, the negative to j
@@ -128,15 +148,25 @@ extern "C" int tuch_region_pair_min(const tuch_contact_model* m, const float* ve
                                     const uint8_t* select, int use_geomask, float* out_min,
                                     int32_t* out_ij, void* stream)
 {
-    TUCH_REQUIRE(m && verts && out_min, "tuch_region_pair_min: null pointer");
+    TUCH_REQUIRE(m && verts && out_min && out_ij, "tuch_region_pair_min: null pointer");
     TUCH_REQUIRE(B > 0 && B <= 65535, "tuch_region_pair_min: bad batch %d", B);
     TUCH_REQUIRE(m->num_pairs > 0, "tuch_region_pair_min: model has no region pairs");
     TUCH_REQUIRE(!use_geomask || m->pair_mask, "tuch_region_pair_min: model has no geodesic mask");
-    hipLaunchKernelGGL(region_pair_min_kernel, dim3(m->num_pairs, B), dim3(kBlock), 0, (hipStream_t)stream,
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(out_ij, 0xFF, (size_t)B * m->num_pairs * 2 * sizeof(int32_t), s) != hipSuccess) {
+        tuch_set_error("tuch_region_pair_min: hipMemsetAsync failed");
+        return TUCH_ERR_HIP;
+    }
+    // few pairs selected (SMPLify r2r): split their rows over 4 workgroups; all pairs: 1 is enough
+    const int row_splits = select ? 4 : 1;
+    hipLaunchKernelGGL(region_pair_min_kernel, dim3(m->num_pairs, B, row_splits), dim3(kBlock), 0, s,
                        verts, (const int32_t*)m->region_off, (const int32_t*)m->region_vidx,
                        (const int32_t*)m->pairs, select,
                        use_geomask ? (const uint32_t*)m->pair_mask : (const uint32_t*)nullptr,
-                       (const int64_t*)m->pair_mask_off, m->V, m->num_pairs, out_min, out_ij);
+                       (const int64_t*)m->pair_mask_off, m->V, m->num_pairs, (unsigned long long*)out_ij);
+    hipLaunchKernelGGL(region_pair_finalize_kernel, dim3(ceil_div(m->num_pairs, kBlock), B), dim3(kBlock), 0, s,
+                       (const int32_t*)m->region_off, (const int32_t*)m->region_vidx, (const int32_t*)m->pairs,
+                       m->num_pairs, out_min, out_ij);
     return tuch_check_launch("tuch_region_pair_min");
 }
 

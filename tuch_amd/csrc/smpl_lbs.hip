@@ -459,7 +459,7 @@ __global__ __launch_bounds__(64) void blend_bwd_kernel(
 }
 
 // Per body: reduce the partials, chain adjoint, Rodrigues adjoint, shape gradient.
-__global__ __launch_bounds__(64) void pose_bwd_kernel(
+__global__ __launch_bounds__(256) void pose_bwd_kernel(
     const float* __restrict__ gA_part, int skin_blocks, const float* __restrict__ feat_part, int feat_chunks,
     int bpad, const float* __restrict__ g_all, const float* __restrict__ R, const float* __restrict__ J,
     const float* __restrict__ world, const float* __restrict__ pose, int pose2rot,
@@ -471,56 +471,70 @@ __global__ __launch_bounds__(64) void pose_bwd_kernel(
     __shared__ float sGR[kJoints][9];
     __shared__ float sGJ[kJoints][3];
     const int b = blockIdx.x, t = threadIdx.x;
-    for (int i = t; i < kJoints * 12; i += 64) {
+    for (int i = t; i < kJoints * 12; i += 256) {
         const int j = i / 12, n = i % 12;
         float acc = 0.f;
         for (int s = 0; s < skin_blocks; ++s) acc += gA_part[(((size_t)b * skin_blocks + s) * 32 + j) * 16 + n];
         sGA[j][n] = acc;
     }
-    for (int i = t; i < 224; i += 64) {
+    for (int i = t; i < 224; i += 256) {
         float acc = 0.f;
         for (int c = 0; c < feat_chunks; ++c) acc += feat_part[((size_t)c * bpad + b) * 224 + i];
         sGF[i] = acc;
     }
     __syncthreads();
-    if (t == 0) {
-        const float* Jb = J + (size_t)b * kJoints * 3;
-        const float* Wb = world + (size_t)b * kJoints * 12;
-        const float* Rb = R + (size_t)b * kJoints * 9;
+    // Chain adjoint.  Phase A (one thread per joint): contributions of A_k and of the posed joint.
+    // Phase B (thread 0, LDS-resident state): propagate from the leaves to the root.
+    __shared__ float sRw[kJoints][9];      // gradient w.r.t. the world rotations
+    __shared__ float sTw[kJoints][3];      // ... world translations
+    const float* Jb = J + (size_t)b * kJoints * 3;
+    const float* Wb = world + (size_t)b * kJoints * 12;
+    const float* Rb = R + (size_t)b * kJoints * 9;
+    if (t < kJoints) {
+        const int k = t;
+        const float* ga = sGA[k];                      // A_k = [Rw | tw - Rw J]
+        const float gt[3] = {ga[9], ga[10], ga[11]};
         const float* gtw_in = g_all + (size_t)b * kAllJoints * 3;
-        float gRw[kJoints][9], gtw[kJoints][3], gJ[kJoints][3];
-        for (int k = 0; k < kJoints; ++k) {
-            // A_k = [Rw | tw - Rw J]
-            const float* ga = sGA[k];
-            const float gt[3] = {ga[9], ga[10], ga[11]};
-            for (int i = 0; i < 3; ++i) {
-                gtw[k][i] = gtw_in[k * 3 + i] + gt[i];
-                for (int c = 0; c < 3; ++c) gRw[k][3 * i + c] = ga[3 * i + c] - gt[i] * Jb[k * 3 + c];
-            }
-            M3 rw;
-            for (int e = 0; e < 9; ++e) rw.m[e] = Wb[k * 12 + e];
-            float tmp[3];
-            mulv_t(rw, gt, tmp);
-            for (int c = 0; c < 3; ++c) gJ[k][c] = -tmp[c];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            sTw[k][i] = gtw_in[k * 3 + i] + gt[i];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sRw[k][3 * i + c] = ga[3 * i + c] - gt[i] * Jb[k * 3 + c];
         }
+        M3 rw;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) rw.m[e] = Wb[k * 12 + e];
+        float tmp[3];
+        mulv_t(rw, gt, tmp);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sGJ[k][c] = -tmp[c];
+    }
+    __syncthreads();
+    if (t == 0) {
         for (int k = kJoints - 1; k >= 1; --k) {
             const int p = parents[k];
             M3 rp, rk, g;
-            for (int e = 0; e < 9; ++e) { rp.m[e] = Wb[p * 12 + e]; rk.m[e] = Rb[k * 9 + e]; g.m[e] = gRw[k][e]; }
+#pragma unroll
+            for (int e = 0; e < 9; ++e) { rp.m[e] = Wb[p * 12 + e]; rk.m[e] = Rb[k * 9 + e]; g.m[e] = sRw[k][e]; }
             const float rel[3] = {Jb[k * 3] - Jb[p * 3], Jb[k * 3 + 1] - Jb[p * 3 + 1], Jb[k * 3 + 2] - Jb[p * 3 + 2]};
+            const float gk[3] = {sTw[k][0], sTw[k][1], sTw[k][2]};
             const M3 up = mul_nt(g, rk);                 // gRw_k R_k^T
+#pragma unroll
             for (int i = 0; i < 3; ++i)
-                for (int c = 0; c < 3; ++c) gRw[p][3 * i + c] += up.m[3 * i + c] + gtw[k][i] * rel[c];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) sRw[p][3 * i + c] += up.m[3 * i + c] + gk[i] * rel[c];
             const M3 gr = mul_tn(rp, g);                 // Rw_p^T gRw_k
+#pragma unroll
             for (int e = 0; e < 9; ++e) sGR[k][e] = gr.m[e];
             float grel[3];
-            mulv_t(rp, gtw[k], grel);
-            for (int c = 0; c < 3; ++c) { gJ[k][c] += grel[c]; gJ[p][c] -= grel[c]; gtw[p][c] += gtw[k][c]; }
+            mulv_t(rp, gk, grel);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { sGJ[k][c] += grel[c]; sGJ[p][c] -= grel[c]; sTw[p][c] += gk[c]; }
         }
-        for (int e = 0; e < 9; ++e) sGR[0][e] = gRw[0][e];
-        for (int c = 0; c < 3; ++c) gJ[0][c] += gtw[0][c];
-        for (int k = 0; k < kJoints; ++k)
-            for (int c = 0; c < 3; ++c) sGJ[k][c] = gJ[k][c];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) sGR[0][e] = sRw[0][e];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sGJ[0][c] += sTw[0][c];
     }
     __syncthreads();
     if (t < kJoints) {
@@ -734,7 +748,7 @@ extern "C" int tuch_smpl_backward(const tuch_smpl_model* m, const float* pose, i
                        g_vposed, gA_part);
     hipLaunchKernelGGL(blend_bwd_kernel, dim3(l.feat_chunks, l.bpad / 16), dim3(64), 0, s, (const float*)g_vposed,
                        (const float*)m->blend, B, m->N3, feat_part);
-    hipLaunchKernelGGL(pose_bwd_kernel, dim3(B), dim3(64), 0, s, (const float*)gA_part, l.skin_blocks,
+    hipLaunchKernelGGL(pose_bwd_kernel, dim3(B), dim3(256), 0, s, (const float*)gA_part, l.skin_blocks,
                        (const float*)feat_part, l.feat_chunks, l.bpad, (const float*)g_all, R, J, world, pose, pose2rot,
                        (const float*)m->J_shapedirs, (const int32_t*)m->parents, g_pose, g_betas);
     return tuch_check_launch("tuch_smpl_backward");
