@@ -90,7 +90,10 @@ def make_step(p, world):
     from tuch_amd.smplify.losses import contact_fitting_loss
     body_pose = p['body_pose'].clone().requires_grad_(True)
     global_orient = p['global_orient'].clone().requires_grad_(True)
-    opt = torch.optim.Adam([body_pose, global_orient], lr=1e-2, capturable=True)
+    try:      # one multi-tensor kernel for the update; same arithmetic as the reference's torch.optim.Adam
+        opt = torch.optim.Adam([body_pose, global_orient], lr=1e-2, capturable=True, fused=True)
+    except (RuntimeError, TypeError):
+        opt = torch.optim.Adam([body_pose, global_orient], lr=1e-2, capturable=True)
     stats = torch.zeros(2, device=body_pose.device)
     stats[1] = float(body_pose.shape[0])          # set once: a host scalar write is not graph-capturable
 

@@ -90,6 +90,17 @@ int tuch_contact_terms_bwd(const float* points, const int32_t* partner, const ui
                            const float* grad_scale, int B, int N, int mode, float euclthres,
                            float* grad_points, void* stream);
 
+/* Reprojection + pose-prior part of the SMPLify-DC objective, losses.py:56-64 (projection
+ * geometry.py:83-111 with identity rotation, gmof losses.py:25-32, max-mixture prior
+ * prior.py:117-132).  out [B,2] = (sum_j conf^2 gmof, prior_scale * prior); gradients for a unit
+ * upstream gradient.  body_pose may be NULL (no prior). */
+int tuch_smplify_small_terms(const float* joints, const float* camera_t, const float* camera_center,
+                             const float* joints_2d, const float* joints_conf, const float* body_pose,
+                             const float* gmm_means, const float* gmm_precisions, const float* gmm_log_weights,
+                             int B, int num_joints, int num_gaussians, float focal_length, float sigma,
+                             float prior_scale, float* out, float* grad_joints, float* grad_camera_t,
+                             float* grad_body_pose, void* stream);
+
 /* ---- per-model constants -------------------------------------------------------------
  * Host tables in, device copies kept by the handle.  Segments follow
  * tuch/utils/segmentation.py:29-99: seg_q = segment_vidx lists; seg_faces = faces of the

@@ -1,0 +1,133 @@
+// The O(B x 49) part of the SMPLify-DC objective in one kernel (K8 of SURVEY.md §2.2):
+//   reprojection: pinhole projection with identity rotation (tuch/utils/geometry.py:83-111),
+//                 Geman-McClure robustifier (tuch/smplify/losses.py:25-32), confidence^2 weights
+//                 (losses.py:56-61)
+//   pose prior:   max-mixture GMM, min_m [ 0.5 (p-mu_m)^T P_m (p-mu_m) - log w'_m ]
+//                 (tuch/smplify/prior.py:117-132)
+// Forward value per body and the gradients w.r.t. joints, camera translation and body pose for a
+// unit upstream gradient (the caller scales them).  Replaces ~75 tiny torch kernels per step.
+#include "common.h"
+
+namespace {
+
+constexpr int kBlock = 128;
+constexpr int kPoseDim = 69;
+constexpr int kMaxGauss = 16;
+
+__global__ __launch_bounds__(kBlock) void small_terms_kernel(
+    const float* __restrict__ joints,     // [B,J,3]
+    const float* __restrict__ cam_t,      // [B,3]
+    const float* __restrict__ cam_c,      // [B,2]
+    const float* __restrict__ j2d,        // [B,J,2]
+    const float* __restrict__ conf,       // [B,J]
+    const float* __restrict__ pose,       // [B,69] or nullptr (no prior)
+    const float* __restrict__ means,      // [M,69]
+    const float* __restrict__ prec,       // [M,69,69]
+    const float* __restrict__ log_w,      // [M] log(nll_weights)
+    int J, int M, float focal, float sigma, float prior_scale,
+    float* __restrict__ out,              // [B,2]: reprojection sum, prior_scale * prior
+    float* __restrict__ g_joints,         // [B,J,3]
+    float* __restrict__ g_cam,            // [B,3]
+    float* __restrict__ g_pose)           // [B,69]
+{
+    __shared__ float red[kBlock];
+    __shared__ float sdiff[kPoseDim];
+    __shared__ float sq[kMaxGauss];
+    __shared__ float sgc[3][kBlock];
+    const int b = blockIdx.x, t = threadIdx.x;
+    // ---- reprojection
+    float loss = 0.f, gcx = 0.f, gcy = 0.f, gcz = 0.f;
+    const float s2 = sigma * sigma;
+    for (int j = t; j < J; j += kBlock) {
+        const float* X = joints + ((size_t)b * J + j) * 3;
+        const float x = X[0] + cam_t[3 * b], y = X[1] + cam_t[3 * b + 1], z = X[2] + cam_t[3 * b + 2];
+        const float iz = 1.0f / z;
+        const float rx = focal * (x * iz) + cam_c[2 * b] - j2d[((size_t)b * J + j) * 2];
+        const float ry = focal * (y * iz) + cam_c[2 * b + 1] - j2d[((size_t)b * J + j) * 2 + 1];
+        const float c2 = conf[(size_t)b * J + j] * conf[(size_t)b * J + j];
+        const float dx = s2 + rx * rx, dy = s2 + ry * ry;
+        loss += c2 * (s2 * rx * rx / dx + s2 * ry * ry / dy);
+        const float gx = c2 * 2.0f * s2 * s2 * rx / (dx * dx), gy = c2 * 2.0f * s2 * s2 * ry / (dy * dy);
+        const float a = gx * focal * iz, c = gy * focal * iz;
+        const float e = -(gx * focal * x + gy * focal * y) * iz * iz;
+        float* g = g_joints + ((size_t)b * J + j) * 3;
+        g[0] = a; g[1] = c; g[2] = e;
+        gcx += a; gcy += c; gcz += e;
+    }
+    red[t] = loss; sgc[0][t] = gcx; sgc[1][t] = gcy; sgc[2][t] = gcz;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if (t < s) {
+            red[t] += red[t + s];
+            sgc[0][t] += sgc[0][t + s]; sgc[1][t] += sgc[1][t + s]; sgc[2][t] += sgc[2][t + s];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        out[2 * b] = red[0];
+        g_cam[3 * b] = sgc[0][0]; g_cam[3 * b + 1] = sgc[1][0]; g_cam[3 * b + 2] = sgc[2][0];
+    }
+    // ---- pose prior
+    if (!pose) {
+        if (t == 0) out[2 * b + 1] = 0.f;
+        return;
+    }
+    int best = 0;
+    float best_ll = 0.f;
+    for (int m = 0; m < M; ++m) {
+        __syncthreads();
+        if (t < kPoseDim) sdiff[t] = pose[(size_t)b * kPoseDim + t] - means[m * kPoseDim + t];
+        __syncthreads();
+        float part = 0.f;
+        if (t < kPoseDim) {
+            const float* row = prec + ((size_t)m * kPoseDim + t) * kPoseDim;
+            float acc = 0.f;
+            for (int k = 0; k < kPoseDim; ++k) acc += row[k] * sdiff[k];
+            part = acc * sdiff[t];
+        }
+        red[t] = part;
+        __syncthreads();
+        for (int s = kBlock / 2; s > 0; s >>= 1) {
+            if (t < s) red[t] += red[t + s];
+            __syncthreads();
+        }
+        if (t == 0) sq[m] = 0.5f * red[0] - log_w[m];
+    }
+    __syncthreads();
+    best_ll = sq[0];
+    for (int m = 1; m < M; ++m)
+        if (sq[m] < best_ll) { best_ll = sq[m]; best = m; }       // first minimum, as torch.min
+    if (t == 0) out[2 * b + 1] = prior_scale * best_ll;
+    if (t < kPoseDim) sdiff[t] = pose[(size_t)b * kPoseDim + t] - means[best * kPoseDim + t];
+    __syncthreads();
+    if (t < kPoseDim) {
+        // d/dp [0.5 d^T P d] = 0.5 (P + P^T) d
+        const float* P = prec + (size_t)best * kPoseDim * kPoseDim;
+        float acc = 0.f;
+        for (int k = 0; k < kPoseDim; ++k) acc += (P[t * kPoseDim + k] + P[k * kPoseDim + t]) * sdiff[k];
+        g_pose[(size_t)b * kPoseDim + t] = prior_scale * 0.5f * acc;
+    }
+}
+
+}  // namespace
+
+extern "C" int tuch_smplify_small_terms(const float* joints, const float* camera_t, const float* camera_center,
+                                        const float* joints_2d, const float* joints_conf, const float* body_pose,
+                                        const float* gmm_means, const float* gmm_precisions,
+                                        const float* gmm_log_weights, int B, int num_joints, int num_gaussians,
+                                        float focal_length, float sigma, float prior_scale, float* out,
+                                        float* grad_joints, float* grad_camera_t, float* grad_body_pose,
+                                        void* stream)
+{
+    TUCH_REQUIRE(joints && camera_t && camera_center && joints_2d && joints_conf && out && grad_joints &&
+                     grad_camera_t, "tuch_smplify_small_terms: null pointer");
+    TUCH_REQUIRE(B > 0 && num_joints > 0, "tuch_smplify_small_terms: bad sizes");
+    TUCH_REQUIRE(!body_pose || (gmm_means && gmm_precisions && gmm_log_weights && grad_body_pose &&
+                                num_gaussians > 0 && num_gaussians <= kMaxGauss),
+                 "tuch_smplify_small_terms: bad prior arguments");
+    hipLaunchKernelGGL(small_terms_kernel, dim3(B), dim3(kBlock), 0, (hipStream_t)stream, joints, camera_t,
+                       camera_center, joints_2d, joints_conf, body_pose, gmm_means, gmm_precisions,
+                       gmm_log_weights, num_joints, num_gaussians, focal_length, sigma, prior_scale, out,
+                       grad_joints, grad_camera_t, grad_body_pose);
+    return tuch_check_launch("tuch_smplify_small_terms");
+}

@@ -130,6 +130,41 @@ def contact_terms(points, partner_i32, exterior_u8, valid_u8, mode, euclthres):
     return terms.sum(dim=1), terms
 
 
+class _SmallTerms(torch.autograd.Function):
+    """Reprojection + max-mixture prior of the SMPLify-DC objective in one kernel; returns [B,2]."""
+
+    @staticmethod
+    def forward(ctx, joints, camera_t, body_pose, camera_center, joints_2d, joints_conf, means, precisions,
+                log_weights, focal, sigma, prior_scale):
+        j = _f32(joints)
+        b, nj, _ = j.shape
+        out = torch.empty(b, 2, dtype=torch.float32, device=j.device)
+        gj = torch.empty_like(j)
+        gc = torch.empty(b, 3, dtype=torch.float32, device=j.device)
+        gp = torch.empty(b, 69, dtype=torch.float32, device=j.device) if body_pose is not None else None
+        _C.check(_C.lib().tuch_smplify_small_terms(
+            _C.ptr(j), _C.ptr(_f32(camera_t)), _C.ptr(_f32(camera_center)), _C.ptr(_f32(joints_2d)),
+            _C.ptr(_f32(joints_conf)), _C.ptr(_f32(body_pose) if body_pose is not None else None),
+            _C.ptr(means), _C.ptr(precisions), _C.ptr(log_weights), b, nj,
+            means.shape[0] if means is not None else 0, float(focal), float(sigma), float(prior_scale),
+            _C.ptr(out), _C.ptr(gj), _C.ptr(gc), _C.ptr(gp), _C.stream()))
+        ctx.save_for_backward(gj, gc, gp)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        gj, gc, gp = ctx.saved_tensors
+        g_rep, g_pri = g[:, 0].contiguous(), g[:, 1].contiguous()
+        return (gj * g_rep[:, None, None], gc * g_rep[:, None],
+                gp * g_pri[:, None] if gp is not None else None) + (None,) * 9
+
+
+def smplify_small_terms(joints, camera_t, body_pose, camera_center, joints_2d, joints_conf, means, precisions,
+                        log_weights, focal, sigma, prior_scale):
+    return _SmallTerms.apply(joints, camera_t, body_pose, camera_center, joints_2d, joints_conf, means,
+                             precisions, log_weights, focal, sigma, prior_scale)
+
+
 # ------------------------------------------------------------------------- model
 def _i32(a) -> np.ndarray:
     return np.ascontiguousarray(np.asarray(a), dtype=np.int32)

@@ -75,9 +75,18 @@ def contact_fitting_loss(body_pose, global_orient, body_pose_loop1, opt_global_o
     Bodies in ``ignore_idxs`` get neither contact term.  ``device`` is accepted for signature
     compatibility; the computation runs where ``verts`` lives.
     """
-    reprojection_loss = _reprojection(model_joints, camera_t, camera_center, joints_2d, joints_conf,
-                                      focal_length, sigma)
-    pose_prior_loss = (pose_prior_weight ** 2) * pose_prior(body_pose, betas)
+    from .prior import MaxMixturePrior
+    fused = (isinstance(pose_prior, MaxMixturePrior) and pose_prior.use_merged and verts.is_cuda
+             and not torch.is_tensor(focal_length) and body_pose.shape[1] == 69)
+    if fused:      # projection + gmof + GMM prior in one kernel (K8)
+        small = ops.smplify_small_terms(model_joints, camera_t, body_pose, camera_center, joints_2d, joints_conf,
+                                        pose_prior.means, pose_prior.precisions, pose_prior.log_nll_weights,
+                                        focal_length, sigma, pose_prior_weight ** 2)
+        reprojection_sum, pose_prior_loss = small[:, 0], small[:, 1]
+    else:
+        reprojection_sum = _reprojection(model_joints, camera_t, camera_center, joints_2d, joints_conf,
+                                         focal_length, sigma).sum(dim=-1)
+        pose_prior_loss = (pose_prior_weight ** 2) * pose_prior(body_pose, betas)
 
     model = contact_model_for(geomask, face_tensor, segments, cdict, device=verts.device)
     valid = (~ignore_idxs).to(torch.uint8).contiguous()
@@ -92,7 +101,7 @@ def contact_fitting_loss(body_pose, global_orient, body_pose_loop1, opt_global_o
     else:
         r2r_loss = torch.zeros_like(contact_loss)
 
-    total_loss = reprojection_loss.sum(dim=-1) + 10 * contact_loss \
+    total_loss = reprojection_sum + 10 * contact_loss \
         + pose_prior_loss + contact_loss_weight * r2r_loss
     return total_loss.sum()
 

@@ -44,6 +44,7 @@ class MaxMixturePrior(nn.Module):
         const = (2 * np.pi) ** (69 / 2.)
         nll_weights = np.asarray(weights / (const * (sqrdets / sqrdets.min())))
         self.register_buffer('nll_weights', torch.tensor(nll_weights, dtype=dtype).unsqueeze(0))
+        self.register_buffer('log_nll_weights', torch.log(torch.tensor(nll_weights, dtype=dtype)).contiguous())
         self.register_buffer('weights', torch.tensor(weights, dtype=dtype).unsqueeze(0))
         self.register_buffer('pi_term', torch.log(torch.tensor(2 * np.pi, dtype=dtype)))
         cov_dets = [np.log(np.linalg.det(c.astype(np_dtype)) + epsilon) for c in covs]
