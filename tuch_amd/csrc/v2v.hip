@@ -91,8 +91,13 @@ __global__ __launch_bounds__(kBlock) void v2v_partial_kernel(
         const v2f d = fma2(dz, dz, fma2(dy, dy, dx * dx));
         const float d0 = select_by_lane_mask(inf, d[0], k0);
         const float d1 = select_by_lane_mask(inf, d[1], k1);
-        if (d0 < best0) { best0 = d0; arg0 = j; }
-        if (d1 < best1) { best1 = d1; arg1 = j; }
+        // running minima improve O(log V) times per column: skip the four selects unless some lane
+        // of the wave improves (wave-uniform branch; results unchanged)
+        const bool up0 = d0 < best0, up1 = d1 < best1;
+        if (__builtin_amdgcn_ballot_w64(up0 || up1)) {
+            if (up0) { best0 = d0; arg0 = j; }
+            if (up1) { best1 = d1; arg1 = j; }
+        }
     };
     int j = j_begin;
     for (; j + 4 <= j_end; j += 4) {      // four rows per trip: the scalar loads are issued together
