@@ -18,6 +18,7 @@
 namespace {
 
 constexpr int kBlock = 256;
+constexpr int kPairsPerBlock = 8;
 constexpr int kTile = 1024;   // second-region vertices staged per pass (12 KB of LDS)
 
 struct Best {
@@ -40,9 +41,14 @@ __global__ __launch_bounds__(kBlock) void region_pair_min_kernel(
 {
     __shared__ float sx[kTile], sy[kTile], sz[kTile];
     __shared__ Best swave[kBlock / 64];
-    const int p = blockIdx.x, b = blockIdx.y;
+    // few pairs are selected in the SMPLify use: one workgroup walks kPairsPerBlock pairs so that
+    // the launch does not consist of tens of thousands of empty workgroups
+    const int b = blockIdx.y;
+    const int per_block = select ? kPairsPerBlock : 1;
+    for (int p = blockIdx.x * per_block; p < min(P, (int)(blockIdx.x + 1) * per_block); ++p) {
     const size_t o = (size_t)b * P + p;
-    if (select && !select[o]) return;
+    if (select && !select[o]) continue;
+    __syncthreads();
     const int r1 = pairs[2 * p], r2 = pairs[2 * p + 1];
     const int a_beg = region_off[r1], n1 = region_off[r1 + 1] - a_beg;
     const int b_beg = region_off[r2], n2 = region_off[r2 + 1] - b_beg;
@@ -93,6 +99,7 @@ __global__ __launch_bounds__(kBlock) void region_pair_min_kernel(
         // 64-bit key whose minimum is independent of the arrival order -> deterministic
         if (r.idx != 0x7fffffff)
             atomicMin(&keys[o], ((unsigned long long)__float_as_uint(r.d) << 32) | (unsigned int)r.idx);
+    }
     }
 }
 
@@ -159,7 +166,7 @@ extern "C" int tuch_region_pair_min(const tuch_contact_model* m, const float* ve
     }
     // few pairs selected (SMPLify r2r): split their rows over 4 workgroups; all pairs: 1 is enough
     const int row_splits = select ? 4 : 1;
-    hipLaunchKernelGGL(region_pair_min_kernel, dim3(m->num_pairs, B, row_splits), dim3(kBlock), 0, s,
+    hipLaunchKernelGGL(region_pair_min_kernel, dim3(ceil_div(m->num_pairs, select ? kPairsPerBlock : 1), B, row_splits), dim3(kBlock), 0, s,
                        verts, (const int32_t*)m->region_off, (const int32_t*)m->region_vidx,
                        (const int32_t*)m->pairs, select,
                        use_geomask ? (const uint32_t*)m->pair_mask : (const uint32_t*)nullptr,

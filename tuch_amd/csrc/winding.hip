@@ -297,23 +297,28 @@ __global__ __launch_bounds__(kStripBlock) void winding_strip_kernel(
 
 // ---- body segments (tuch/utils/segmentation.py) ---------------------------------
 // cap vertex of band c = mean of the band's boundary-loop vertices (segmentation.py:74-76)
-__global__ __launch_bounds__(kBlock) void cap_centroid_kernel(
+__global__ __launch_bounds__(64) void cap_centroid_kernel(
     const float* __restrict__ verts, const int32_t* __restrict__ cap_off,
     const int32_t* __restrict__ cap_vidx, int V, int K, float* __restrict__ caps)   // [B,K,3]
 {
-    const int b = blockIdx.y;
-    const int c = blockIdx.x * kBlock + threadIdx.x;
-    if (c >= K) return;
+    // one wave per (cap, body): lanes stride over the loop, shuffle-reduce
+    const int c = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     const float* vb = verts + (size_t)b * V * 3;
     float sx = 0.f, sy = 0.f, sz = 0.f;
     const int beg = cap_off[c], end = cap_off[c + 1];
-    for (int k = beg; k < end; ++k) {
+    for (int k = beg + lane; k < end; k += 64) {
         const float* p = vb + 3 * cap_vidx[k];
         sx += p[0]; sy += p[1]; sz += p[2];
     }
-    const float inv = 1.0f / (float)(end - beg);
-    float* o = caps + ((size_t)b * K + c) * 3;
-    o[0] = sx * inv; o[1] = sy * inv; o[2] = sz * inv;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sx += __shfl_down(sx, o, 64); sy += __shfl_down(sy, o, 64); sz += __shfl_down(sz, o, 64);
+    }
+    if (lane == 0) {
+        const float inv = 1.0f / (float)(end - beg);
+        float* o = caps + ((size_t)b * K + c) * 3;
+        o[0] = sx * inv; o[1] = sy * inv; o[2] = sz * inv;
+    }
 }
 
 // closed-segment triangles: index < V -> body vertex, else cap vertex (segmentation.py:77)
@@ -601,7 +606,7 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
     if (apply_segments && m->num_segments > 0) {
         float* caps = (float*)(ws + l.caps);
         float* seg_tris = (float*)(ws + l.seg_tris);
-        hipLaunchKernelGGL(cap_centroid_kernel, dim3(ceil_div(m->num_caps, kBlock), B), dim3(kBlock), 0, s,
+        hipLaunchKernelGGL(cap_centroid_kernel, dim3(m->num_caps, B), dim3(64), 0, s,
                            verts, (const int32_t*)m->cap_off, (const int32_t*)m->cap_vidx, m->V,
                            m->num_caps, caps);
         hipLaunchKernelGGL(gather_segment_triangles_kernel, dim3(ceil_div(m->seg_f_total * 3, kBlock), B),
