@@ -47,6 +47,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager', action='store_true', help='launch every step eagerly instead of replaying a hipGraph')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--no-torch-chain', action='store_true',
+                    help='skip the torch-CPU op-chain baseline (one body, ~8 GB of host memory, ~30 s)')
     return ap.parse_args()
 
 
@@ -209,6 +211,30 @@ def cpu_baseline(p, seconds):
                       'reprojection and Adam are excluded (negligible on CPU)' % (n, dt)}
 
 
+def cpu_torch_chain(p):
+    """One body through the reference's stock-op formulation on CPU (materialises the 3.4 GB
+    [1,Q,F,3,3] tensor like tuch/utils/contact.py:79): first call and warm call, all host threads."""
+    import psutil
+    from oracle import torch_chain as tc
+    if psutil.virtual_memory().available < 24 * 2 ** 30:
+        return {'skipped': 'less than 24 GiB of free host memory'}
+    body = p['body']
+    with torch.no_grad():
+        verts = p['smpl'](global_orient=p['global_orient'][:1], body_pose=p['body_pose'][:1],
+                          betas=p['betas'][:1]).vertices[0].cpu()
+        faces = torch.tensor(body.faces)
+        gm = torch.tensor(body.geodesics > 0.3)
+        times = []
+        for _ in range(2):
+            t0 = time.time()
+            tc.contact_forward_one_body(verts, faces, gm, 0.02)
+            times.append(time.time() - t0)
+    return {'value': round(1.0 / times[1], 4), 'unit': 'body contact-loss forwards/s', 'cores': torch.get_num_threads(),
+            'kind': 'port', 'first_call_s': round(times[0], 2), 'warm_call_s': round(times[1], 2),
+            'sample': '1 body (V=6890,F=13776), contact forward only (pairwise + winding + argmin + terms), '
+                      'torch CPU ops materialising the reference intermediates; no segments, no backward'}
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -271,6 +297,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(p, args.cpu_seconds)
+            if not args.no_torch_chain:
+                line['cpu_baseline_torch_chain'] = cpu_torch_chain(p)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

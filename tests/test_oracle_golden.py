@@ -138,3 +138,23 @@ def test_known_answers_tetrahedron():
     # on a vertex: incident faces contribute atan2(0,0)=0
     w0 = oc.winding_numbers(v[:1], oc.gather_tris(v, f))
     assert np.isfinite(w0).all()
+
+
+def test_torch_chain_matches_reference_goldens():
+    """The torch op-chain used as the CPU baseline computes what the reference computes."""
+    import torch
+    from oracle import torch_chain as tc
+    g, gm = golden('medium'), golden_mask('medium')
+    faces = torch.tensor(g['faces'])
+    for b in range(g['verts'].shape[0]):
+        v = torch.tensor(g['verts'][b])
+        w = tc.winding(v[None], v[faces][None])[0].numpy()
+        assert_close(w, g['winding'][b], 0, 2e-6, 'torch chain winding')
+    p = tc.pairwise_sq(torch.tensor(g['verts'][:1]), torch.tensor(g['verts'][:1]))
+    p[:, ~torch.tensor(gm)] = float('inf')
+    mn, arg = torch.min(p, dim=1)
+    assert_close(mn[0].numpy(), g['v2v_min'][0], 0, 1e-6, 'torch chain v2v')
+    assert (arg[0].numpy() == g['v2v_argmin'][0]).mean() > 0.99
+    val = tc.contact_forward_one_body(torch.tensor(g['verts'][0]), faces, torch.tensor(gm), 0.02)
+    r = oc.smplify_contact_body(g['verts'][0], g['faces'], gm, 0.02, None, None)
+    assert_close(val.item(), r['contact'], 1e-4, 1e-6, 'torch chain contact term')
