@@ -323,3 +323,18 @@ def contact_from_verts(verts, regions: Dict[str, np.ndarray], pairs) -> np.ndarr
         for b in range(verts.shape[0]):
             out[b, k] = pairwise_sq(verts[b][i1], verts[b][i2]).min()
     return out
+
+
+def eft_contact_body(verts, faces, geomask, segments, region_pairs):
+    """One trip of the per-body loop of EFTLoss.contact_loss, tuch/eft/loss.py:140-179: means instead
+    of sums, no distance gate on the exterior term; the caller applies 100 * (contact + 0.5 * r2r)."""
+    r = smplify_contact_body(verts, faces, geomask, np.inf, segments, region_pairs)
+    verts = _c32(verts)
+    ext = exterior_flags(verts, faces, segments, always_filter=True)[0]      # eft/loss.py:149-152 (always)
+    diff, d = _pair_distance(verts, r['argmin'])
+    n_in, n_out = int((~ext).sum()), int(ext.sum())
+    vin, dd_in = _tanh2_terms(d, ~ext, 1.0, 0.04)
+    vout, dd_out = _tanh2_terms(d, ext, 0.005, 0.005)
+    contact = vin / max(n_in, 1) + vout / max(n_out, 1)
+    grad = _scatter_pair_grad(diff, d, dd_in / max(n_in, 1) + dd_out / max(n_out, 1), r['argmin'], verts.shape[0])
+    return dict(contact=contact, r2r=r['r2r'], grad_contact=grad, grad_r2r=r['grad_r2r'])

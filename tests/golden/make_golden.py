@@ -250,6 +250,23 @@ def contact_case(tag, rings, segs, batch, seed, store_dense):
             out[key + '_loss'] = np.float64(loss.item())
             out[key + '_grad_verts'] = v.grad.numpy()
 
+    # --- f1: EFT variant, EFTLoss.contact_loss (tuch/eft/loss.py:129-181); the reference tests the
+    # segments with the whole batch (:150), which only works for batch 1 -> one call per body
+    from tuch.eft import loss as ref_eft
+    eft = ref_eft.EFTLoss.__new__(ref_eft.EFTLoss)
+    torch.nn.Module.__init__(eft)
+    eft.device, eft.options = 'cpu', types.SimpleNamespace(batch_size=1)
+    eft.face_tensor, eft.geomask, eft.cdict, eft.segments = face_tensor[:1], geomask, cdict, segments
+    eft_loss, eft_grad = [], []
+    for b in range(batch):
+        v = torch.tensor(verts_np[b:b + 1], requires_grad=True)
+        l = eft.contact_loss(torch.tensor(gt[b:b + 1]), v)
+        l.backward()
+        eft_loss.append(l.item())
+        eft_grad.append(v.grad.numpy()[0])
+    out['eft_loss'] = np.asarray(eft_loss, np.float64)
+    out['eft_grad_verts'] = np.stack(eft_grad)
+
     # --- a8: contact_from_verts (train_module.py:83-90 loop around the reference's own op)
     pc = np.zeros((batch, num_pairs), np.float32)
     for k, (ra, rb) in enumerate(body.region_pairs):

@@ -293,3 +293,28 @@ def test_contact_from_verts_class():
     t = TUCH({'classes': [list(p) for p in pairs], 'csig': regions}, g['faces'], device=dev())
     out = t.contact_from_verts(torch.tensor(g['verts'], device=dev()))
     assert_close(out.cpu().numpy(), g['contact_from_verts'], 0, 1e-6, 'contact_from_verts')
+
+
+@pytest.mark.parametrize('tag', ['small', 'medium'])
+def test_eft_contact_loss_vs_reference(tag):
+    """EFTLoss.contact_loss (tuch/eft/loss.py:129-181) on the kernels, whole batch at once."""
+    import types
+    from tuch_amd.eft.loss import EFTLoss
+    from tuch_amd.utils.segmentation import BatchBodySegment
+    g, gm = golden(tag), golden_mask(tag)
+    d = dev()
+    batch = g['verts'].shape[0]
+    face_tensor = torch.tensor(g['faces'], device=d)[None].repeat(batch, 1, 1)
+    segs = gio.unpack_segments(g)
+    regions, pairs = gio.unpack_regions(g)
+    crit = EFTLoss(types.SimpleNamespace(batch_size=batch, img_res=224), d, None, g['verts'].shape[1], None,
+                   torch.tensor(np.where(gm, 1.0, 0.0).astype(np.float32), device=d), 0.3, face_tensor=face_tensor,
+                   cdict={'classes': [list(p) for p in pairs], 'csig': regions},
+                   segments=BatchBodySegment(list(segs.keys()), face_tensor[0], segs))
+    verts = torch.tensor(g['verts'], device=d, requires_grad=True)
+    loss = crit.contact_loss(torch.tensor(g['gt_contact'], device=d), verts)
+    loss.backward()
+    n_sel = float((g['gt_contact'] == 1).sum())
+    assert_close(loss.item(), g['eft_loss'].sum(), 1e-4, 50 * 1e-6 * n_sel, 'eft loss')
+    gv = g['eft_grad_verts']
+    assert_close(verts.grad.cpu().numpy(), gv, 1e-3, 5e-6 * np.abs(gv).max(), 'eft grad')

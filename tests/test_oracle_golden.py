@@ -158,3 +158,17 @@ def test_torch_chain_matches_reference_goldens():
     val = tc.contact_forward_one_body(torch.tensor(g['verts'][0]), faces, torch.tensor(gm), 0.02)
     r = oc.smplify_contact_body(g['verts'][0], g['faces'], gm, 0.02, None, None)
     assert_close(val.item(), r['contact'], 1e-4, 1e-6, 'torch chain contact term')
+
+
+@pytest.mark.parametrize('tag', TAGS)
+def test_eft_contact_loss(tag):
+    """EFT variant (tuch/eft/loss.py:129-181): means instead of sums, 100 * (contact + 0.5 r2r)."""
+    g, gm = golden(tag), golden_mask(tag)
+    segs = oracle_segments(g)
+    for b in range(g['verts'].shape[0]):
+        r = oc.eft_contact_body(g['verts'][b], g['faces'], gm, segs, region_pair_lists(g, b))
+        total = 100 * (r['contact'] + 0.5 * r['r2r'])
+        grad = 100 * (r['grad_contact'] + 0.5 * r['grad_r2r'])
+        assert_close(total, g['eft_loss'][b], 1e-5, 1e-6, 'eft loss')
+        scale = np.abs(g['eft_grad_verts'][b]).max()
+        assert_close(grad, g['eft_grad_verts'][b], 1e-4, 2e-6 * scale, 'eft grad')

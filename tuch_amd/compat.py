@@ -23,12 +23,13 @@ _MAP = {
     'tuch.smplify.smplifydc': 'tuch_amd.smplify.smplifydc',
     'tuch.models.smpl': 'tuch_amd.models.smpl',
     'tuch.train.loss': 'tuch_amd.train.loss',
+    'tuch.eft.loss': 'tuch_amd.eft.loss',
 }
 
 
 def install(overwrite: bool = True):
     """Register the tuch_amd modules in sys.modules under the reference's names."""
-    for pkg in ('tuch', 'tuch.utils', 'tuch.smplify', 'tuch.models', 'tuch.train'):
+    for pkg in ('tuch', 'tuch.utils', 'tuch.smplify', 'tuch.models', 'tuch.train', 'tuch.eft'):
         if pkg not in sys.modules:
             mod = types.ModuleType(pkg)
             mod.__path__ = []          # namespace-like: lets the reference's other submodules resolve
