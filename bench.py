@@ -132,7 +132,9 @@ def capture(step, warmup):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    # thread_local: with a process group alive the RCCL watchdog thread queries events; that must not
+    # invalidate this thread's capture
+    with torch.cuda.graph(graph, capture_error_mode='thread_local'):
         out = step()
 
     def replay():

@@ -1,0 +1,97 @@
+"""Loaders for the reference's asset files, so that ``train.py`` /
+``demo_smplify_dc.py`` can run against this package on a machine that has the licensed data.
+None of these files ship; the loaders are exercised on synthetic files of the same formats.
+
+    configs/config.py:74-87   SMPL_MODEL_DIR, GEODESICS_SMPL, SEGMENT_DIR, HD_MODEL_DIR, DSC_ROOT
+"""
+from __future__ import annotations
+
+import os
+import pickle
+import struct
+from typing import Dict, Tuple
+
+import numpy as np
+
+
+def load_geodesic_mask(path: str, geothres: float) -> np.ndarray:
+    """smpl_neutral_geodesic_dist.npy [V,V] -> bool mask geod > geothres (smplifydc.py:65, loss.py:71)."""
+    geod = np.load(path)
+    return geod > geothres
+
+
+def load_contact_regions(dsc_root: str) -> Dict[str, object]:
+    """classes.pkl + ContactSigSMPL.pkl -> {'classes': [...], 'csig': {...}} (train_module.py:64-66)."""
+    with open(os.path.join(dsc_root, 'classes.pkl'), 'rb') as f:
+        classes = pickle.load(f)
+    with open(os.path.join(dsc_root, 'ContactSigSMPL.pkl'), 'rb') as f:
+        csig = pickle.load(f)
+    return {'classes': classes, 'csig': csig}
+
+
+def load_hd_regressor(hd_model_dir: str) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """smpl_neutral_hd_vert_regressor.npy (dense [N,V], barycentric: <= 3 non-zeros per row) and
+    smpl_neutral_hd_sample_from_mesh_out.pkl -> (corner ids [N,3], weights [N,3], face ids [N])
+    (loss.py:81-88)."""
+    dense = np.load(os.path.join(hd_model_dir, 'smpl_neutral_hd_vert_regressor.npy'))
+    idx = np.argsort(-np.abs(dense), axis=1)[:, :3]
+    wgt = np.take_along_axis(dense, idx, 1).astype(np.float32)
+    rest = np.abs(dense).sum(1) - np.abs(wgt).sum(1)
+    if rest.max() > 1e-6:
+        raise ValueError('HD regressor rows have more than three non-zeros (max residual %g)' % rest.max())
+    with open(os.path.join(hd_model_dir, 'smpl_neutral_hd_sample_from_mesh_out.pkl'), 'rb') as f:
+        faces = np.asarray(pickle.load(f)['faces_vert_is_sampled_from'])
+    return idx.astype(np.int64), wgt, faces.astype(np.int64)
+
+
+_PLY_TYPES = {'char': 'b', 'int8': 'b', 'uchar': 'B', 'uint8': 'B', 'short': 'h', 'int16': 'h',
+              'ushort': 'H', 'uint16': 'H', 'int': 'i', 'int32': 'i', 'uint': 'I', 'uint32': 'I',
+              'float': 'f', 'float32': 'f', 'double': 'd', 'float64': 'd'}
+
+
+def read_ply_vertex_red(path: str) -> np.ndarray:
+    """The red channel of every vertex of an ascii or binary PLY file -- all the reference needs from
+    the segment meshes (segmentation.py:40-42, `visual.vertex_colors[:, 0] == 255`), without trimesh."""
+    with open(path, 'rb') as f:
+        if f.readline().strip() != b'ply':
+            raise ValueError('%s is not a PLY file' % path)
+        fmt, n_vert, props, in_vertex = None, 0, [], False
+        while True:
+            line = f.readline().decode('ascii', 'replace').strip()
+            tok = line.split()
+            if not tok:
+                continue
+            if tok[0] == 'format':
+                fmt = tok[1]
+            elif tok[0] == 'element':
+                in_vertex = tok[1] == 'vertex'
+                if in_vertex:
+                    n_vert = int(tok[2])
+            elif tok[0] == 'property' and in_vertex:
+                if tok[1] == 'list':
+                    raise ValueError('list property on vertices is not supported')
+                props.append((tok[2], _PLY_TYPES[tok[1]]))
+            elif tok[0] == 'end_header':
+                break
+        names = [p[0] for p in props]
+        if 'red' not in names:
+            raise ValueError('%s has no per-vertex colours' % path)
+        red_i = names.index('red')
+        if fmt == 'ascii':
+            rows = [f.readline().split() for _ in range(n_vert)]
+            return np.asarray([float(r[red_i]) for r in rows]).astype(np.int64)
+        endian = '<' if fmt == 'binary_little_endian' else '>'
+        rec = struct.Struct(endian + ''.join(p[1] for p in props))
+        data = f.read(rec.size * n_vert)
+        return np.asarray([rec.unpack_from(data, i * rec.size)[red_i] for i in range(n_vert)]).astype(np.int64)
+
+
+def load_segments(segment_dir: str, segm_utils_segments: Dict[str, Dict[str, list]]) -> Dict[str, dict]:
+    """smpl_segment_{name}.ply + segm_utils.segments -> {name: {'vidx', 'bands'}}, the form
+    tuch_amd.utils.segmentation.BatchBodySegment takes (segmentation.py:40-46)."""
+    out = {}
+    for name, bands in segm_utils_segments.items():
+        red = read_ply_vertex_red(os.path.join(segment_dir, 'smpl_segment_{}.ply'.format(name)))
+        out[name] = {'vidx': np.where(red == 255)[0].astype(np.int64),
+                     'bands': {k: np.asarray(v, np.int64) for k, v in bands.items()}}
+    return out
