@@ -1,6 +1,10 @@
-"""Max-mixture GMM pose prior used inside the SMPLify-DC loop (reference:
-tuch/smplify/prior.py:36-167, 8 Gaussians over the 69-D body pose).  [B,69] -> [B]; tiny,
-stays on torch ops on the parameters' device (K8)."""
+"""Max-mixture GMM pose prior used inside the SMPLify-DC loop.
+
+Drop-in for ``tuch/smplify/prior.py`` (class name, constructor arguments, buffer names and
+``forward(pose, betas)`` as in the reference, :36-167): 8 Gaussians over the 69-D body pose,
+[B,69] -> [B].  Inside ``contact_fitting_loss`` the merged form is evaluated by the fused HIP kernel
+(csrc/small_terms.hip); the torch expressions below serve every other caller.
+"""
 from __future__ import annotations
 
 import os
@@ -11,66 +15,74 @@ import torch
 import torch.nn as nn
 
 
+def _read_mixture(prior_folder, num_gaussians):
+    """means [M,D], covariances [M,D,D], weights [M] from gmm_{M:02d}.pkl (dict or sklearn GMM)."""
+    path = os.path.join(prior_folder, 'gmm_{:02d}.pkl'.format(num_gaussians))
+    if not os.path.exists(path):
+        raise FileNotFoundError('The path to the mixture prior "{}" does not exist'.format(path))
+    with open(path, 'rb') as handle:
+        stored = pickle.load(handle, encoding='latin1')
+    if isinstance(stored, dict):
+        return stored['means'], stored['covars'], stored['weights']
+    return stored.means_, stored.covars_, stored.weights_
+
+
 class MaxMixturePrior(nn.Module):
     def __init__(self, prior_folder='prior', num_gaussians=6, dtype=torch.float32, epsilon=1e-16,
                  use_merged=True, gmm=None, **kwargs):
-        """``gmm``: optional dict with 'means' [M,D], 'covars' [M,D,D], 'weights' [M]; otherwise
-        ``prior_folder/gmm_{num_gaussians:02d}.pkl`` is read like the reference does (:56-76)."""
+        """``gmm``: optional dict {'means', 'covars', 'weights'} instead of the pickle in ``prior_folder``."""
         super().__init__()
         if dtype not in (torch.float32, torch.float64):
             raise ValueError('Unknown float type {}'.format(dtype))
-        self.num_gaussians = num_gaussians
-        self.epsilon = epsilon
-        self.use_merged = use_merged
-        if gmm is None:
-            path = os.path.join(prior_folder, 'gmm_{:02d}.pkl'.format(num_gaussians))
-            if not os.path.exists(path):
-                raise FileNotFoundError('The path to the mixture prior "{}" does not exist'.format(path))
-            with open(path, 'rb') as f:
-                gmm = pickle.load(f, encoding='latin1')
-            if not isinstance(gmm, dict):
-                gmm = {'means': gmm.means_, 'covars': gmm.covars_, 'weights': gmm.weights_}
         np_dtype = np.float32 if dtype == torch.float32 else np.float64
-        means = np.asarray(gmm['means']).astype(np_dtype)
-        covs = np.asarray(gmm['covars']).astype(np_dtype)
-        weights = np.asarray(gmm['weights'])
-        self.register_buffer('means', torch.tensor(means, dtype=dtype))
-        self.register_buffer('covs', torch.tensor(covs, dtype=dtype))
-        precisions = np.stack([np.linalg.inv(c) for c in covs]).astype(np_dtype)
-        self.register_buffer('precisions', torch.tensor(precisions, dtype=dtype))
-        # mixture weights folded with the Gaussian normalisers, relative to the tightest
-        # component (reference :88-96)
-        sqrdets = np.array([np.sqrt(np.linalg.det(c)) for c in np.asarray(gmm['covars'])])
-        const = (2 * np.pi) ** (69 / 2.)
-        nll_weights = np.asarray(weights / (const * (sqrdets / sqrdets.min())))
-        self.register_buffer('nll_weights', torch.tensor(nll_weights, dtype=dtype).unsqueeze(0))
-        self.register_buffer('log_nll_weights', torch.log(torch.tensor(nll_weights, dtype=dtype)).contiguous())
-        self.register_buffer('weights', torch.tensor(weights, dtype=dtype).unsqueeze(0))
+        self.num_gaussians, self.epsilon, self.use_merged = num_gaussians, epsilon, use_merged
+        if gmm is not None:
+            mu, sigma, pi = gmm['means'], gmm['covars'], gmm['weights']
+        else:
+            mu, sigma, pi = _read_mixture(prior_folder, num_gaussians)
+        mu64, sigma64, pi64 = np.asarray(mu), np.asarray(sigma), np.asarray(pi)
+        sigma_t = sigma64.astype(np_dtype)
+
+        def buf(name, array):
+            self.register_buffer(name, torch.tensor(array, dtype=dtype))
+
+        buf('means', mu64.astype(np_dtype))
+        buf('covs', sigma_t)
+        buf('precisions', np.stack([np.linalg.inv(c) for c in sigma_t]).astype(np_dtype))
+        # mixture weights folded with each Gaussian's normaliser, relative to the tightest
+        # component (reference :88-96): w_m / ((2 pi)^(69/2) * sqrt|S_m| / min_k sqrt|S_k|)
+        root_det = np.sqrt(np.array([np.linalg.det(c) for c in sigma64]))
+        folded = pi64 / ((2 * np.pi) ** (69 / 2.) * (root_det / root_det.min()))
+        buf('nll_weights', np.asarray(folded)[None])
+        self.register_buffer('log_nll_weights', torch.log(self.nll_weights[0]).contiguous())
+        buf('weights', pi64[None])
         self.register_buffer('pi_term', torch.log(torch.tensor(2 * np.pi, dtype=dtype)))
-        cov_dets = [np.log(np.linalg.det(c.astype(np_dtype)) + epsilon) for c in covs]
-        self.register_buffer('cov_dets', torch.tensor(cov_dets, dtype=dtype))
+        buf('cov_dets', [np.log(np.linalg.det(c) + epsilon) for c in sigma_t])
         self.random_var_dim = self.means.shape[1]
 
     def get_mean(self):
-        return torch.matmul(self.weights, self.means)
+        """Mixture mean, [1,D]."""
+        return self.weights @ self.means
 
     def merged_log_likelihood(self, pose, betas):
         """min_m [ 0.5 (p-mu_m)^T P_m (p-mu_m) - log w'_m ]  (reference :117-132)."""
-        diff = pose.unsqueeze(1) - self.means
-        quad = (torch.einsum('mij,bmj->bmi', self.precisions, diff) * diff).sum(-1)
-        return (0.5 * quad - torch.log(self.nll_weights)).min(dim=1)[0]
+        centred = pose[:, None, :] - self.means[None]
+        mahalanobis = torch.einsum('bmi,mij,bmj->bm', centred, self.precisions, centred)
+        return torch.min(0.5 * mahalanobis - torch.log(self.nll_weights), dim=1)[0]
 
     def log_likelihood(self, pose, betas, *args, **kwargs):
-        """Per-component negative log-likelihood, then the arg-min component (reference :134-161)."""
-        vals = []
+        """Per-component negative log-likelihood and the selected component's weight (reference :134-161)."""
+        per_component = []
         for m in range(self.num_gaussians):
-            diff = pose - self.means[m]
-            quad = torch.einsum('bi,bi->b', torch.einsum('bj,ji->bi', diff, self.precisions[m]), diff)
-            cov_term = torch.log(torch.det(self.covs[m]) + self.epsilon)
-            vals.append(quad + 0.5 * (cov_term + self.random_var_dim * self.pi_term))
-        ll = torch.stack(vals, dim=1)
-        idx = torch.argmin(ll, dim=1)
-        return -torch.log(self.nll_weights[:, idx]) + ll[:, idx]
+            centred = pose - self.means[m]
+            mahalanobis = torch.einsum('bi,ij,bj->b', centred, self.precisions[m], centred)
+            log_det = torch.log(torch.det(self.covs[m]) + self.epsilon)
+            per_component.append(mahalanobis + 0.5 * (log_det + self.random_var_dim * self.pi_term))
+        table = torch.stack(per_component, dim=1)
+        chosen = torch.argmin(table, dim=1)
+        return table[:, chosen] - torch.log(self.nll_weights[:, chosen])
 
     def forward(self, pose, betas):
-        return self.merged_log_likelihood(pose, betas) if self.use_merged else self.log_likelihood(pose, betas)
+        if self.use_merged:
+            return self.merged_log_likelihood(pose, betas)
+        return self.log_likelihood(pose, betas)

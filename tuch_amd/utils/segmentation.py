@@ -41,10 +41,9 @@ class BodySegment(nn.Module):
 
     @classmethod
     def from_reference_assets(cls, name, faces, segment_dir, segm_utils_segments, append_idx=None):
-        import trimesh  # only needed for the licensed assets
-        mesh = trimesh.load(os.path.join(segment_dir, 'smpl_segment_{}.ply'.format(name)), process=False)
-        vidx = np.where(np.array(mesh.visual.vertex_colors[:, 0]) == 255)[0]
-        return cls(name, faces, append_idx, vidx, segm_utils_segments[name])
+        from ..assets import read_ply_vertex_red      # no trimesh needed: only the red channel is used
+        red = read_ply_vertex_red(os.path.join(segment_dir, 'smpl_segment_{}.ply'.format(name)))
+        return cls(name, faces, append_idx, np.where(red == 255)[0], segm_utils_segments[name])
 
     def get_closed_segment(self, vertices):
         """[B,V,3] -> triangles [B,Fs,3,3] of the closed segment (segmentation.py:68-79)."""
