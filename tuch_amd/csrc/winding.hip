@@ -194,10 +194,15 @@ __global__ __launch_bounds__(kBlock) void gather_triangles_kernel(
 // The model's faces are walked as triangle strips (model.hip build_strips): consecutive
 // triangles share two vertices, so per emitted triangle only ONE new vertex needs its
 // difference vector and norm (1 sqrt instead of 3) and only two of the three dot products
-// are new.  Stream element = (x, y, z, sign): sign 0 primes a strip, +-1 emits the triangle
-// of the last three elements with that orientation.  Three register slots are rotated by
-// position modulo 3 (loop unrolled by 3, no register moves).
-struct StreamElem { float x, y, z, sign; };
+// are new.  The triple product A.(BxC) equals X.n for ANY corner X of the triangle, with
+// n = (b-a)x(c-a) independent of the query: n is computed once per (body, triangle) by
+// gather_stream_kernel and arrives as wave-uniform scalars, so the numerator costs one dot
+// product.  (n is built from edge vectors, which avoids the cancellation inside BxC for far
+// triangles.)  Stream element = (x, y, z, sign, nx, ny, nz, -): sign 0 primes a strip, +-1
+// emits the triangle of the last three elements with that orientation; n is already
+// multiplied by the sign.  Three register slots are rotated by position modulo 3 (loop unrolled
+// by 3, no register moves).
+struct StreamElem { float x, y, z, sign, nx, ny, nz, pad; };
 
 __global__ __launch_bounds__(kBlock) void gather_stream_kernel(
     const float* __restrict__ verts, const int32_t* __restrict__ vidx, const float* __restrict__ sign,
@@ -206,23 +211,49 @@ __global__ __launch_bounds__(kBlock) void gather_stream_kernel(
     const int b = blockIdx.y;
     const int p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= Lpad) return;
-    StreamElem e = {0.f, 0.f, 0.f, 0.f};
+    StreamElem e = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (p < L) {
-        const float* src = verts + ((size_t)b * V + vidx[p]) * 3;
-        e.x = src[0]; e.y = src[1]; e.z = src[2]; e.sign = sign[p];
+        const float* vb = verts + (size_t)b * V * 3;
+        const float* c = vb + 3 * vidx[p];
+        e.x = c[0]; e.y = c[1]; e.z = c[2]; e.sign = sign[p];
+        if (e.sign != 0.0f) {
+            const float* a = vb + 3 * vidx[p - 2];
+            const float* bb = vb + 3 * vidx[p - 1];
+            const float ux = bb[0] - a[0], uy = bb[1] - a[1], uz = bb[2] - a[2];
+            const float wx = c[0] - a[0], wy = c[1] - a[1], wz = c[2] - a[2];
+            e.nx = e.sign * (uy * wz - uz * wy);
+            e.ny = e.sign * (uz * wx - ux * wz);
+            e.nz = e.sign * (ux * wy - uy * wx);
+        }
     }
     out[(size_t)b * Lpad + p] = e;
 }
 
 struct Slot { v2f x, y, z, n; };
 
-// One stream element.  A = register slot of the new vertex (position mod 3), EVEN = position
-// parity.  With P, Q the two previous vertices and N the new one, the triple product is taken as
-// P.(QxN) on even positions and as N.(PxQ) on odd ones, where PxQ is exactly the QxN of the step
-// before -- one cross product serves two consecutive triangles.
-template <int A, bool EVEN>
+// atan2(num, den) as half_angle(), plus: den == 0 exactly happens when the query IS a corner of
+// the triangle (its difference vector, hence one norm and two dot products, are exactly zero);
+// the reference then evaluates atan2(0, 0) = 0 (contact.py:105), while X.n carries rounding noise.
+__device__ __forceinline__ v2f half_angle_strip(v2f num, v2f den)
+{
+    const bool big = !(__builtin_fabsf(num[0]) < 0.125f * den[0]) || !(__builtin_fabsf(num[1]) < 0.125f * den[1]);
+    if (__builtin_amdgcn_ballot_w64(big) == 0) {
+        const v2f t = num * (v2f){__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+        const v2f s = t * t;
+        v2f p = fma2(s, splat2(0.2f), splat2(-1.0f / 3.0f));
+        p = fma2(p, s, splat2(1.0f));
+        return p * t;
+    }
+    v2f r = atan2_pair(num, den);
+    if (den[0] == 0.0f) r[0] = 0.0f;
+    if (den[1] == 0.0f) r[1] = 0.0f;
+    return r;
+}
+
+// One stream element; A = register slot of the new vertex (position mod 3).
+template <int A>
 __device__ __forceinline__ void strip_step(const StreamElem e, bool emit, Slot (&s)[3], v2f (&d)[3],
-                                           v2f (&c)[3], v2f qx, v2f qy, v2f qz, v2f& acc)
+                                           v2f qx, v2f qy, v2f qz, v2f& acc)
 {
     constexpr int Bq = (A + 1) % 3, Cq = (A + 2) % 3;      // slots of stream positions p-2 and p-1
     s[A].x = splat2(e.x) - qx;
@@ -232,31 +263,25 @@ __device__ __forceinline__ void strip_step(const StreamElem e, bool emit, Slot (
     // d[k] = dot of the two slots other than k
     d[Cq] = fma2(s[A].z, s[Bq].z, fma2(s[A].y, s[Bq].y, s[A].x * s[Bq].x));
     d[Bq] = fma2(s[A].z, s[Cq].z, fma2(s[A].y, s[Cq].y, s[A].x * s[Cq].x));
-    if (EVEN) {                                              // Q x N, also used by the next position
-        c[0] = fma2(s[Cq].y, s[A].z, -(s[Cq].z * s[A].y));
-        c[1] = fma2(s[Cq].z, s[A].x, -(s[Cq].x * s[A].z));
-        c[2] = fma2(s[Cq].x, s[A].y, -(s[Cq].y * s[A].x));
-    }
     if (emit && e.sign != 0.0f) {                            // wave-uniform
-        constexpr int T = EVEN ? Bq : A;                     // the vertex not in the cross product
-        const v2f num = fma2(s[T].z, c[2], fma2(s[T].y, c[1], s[T].x * c[0]));
+        const v2f num = fma2(s[A].z, splat2(e.nz), fma2(s[A].y, splat2(e.ny), s[A].x * splat2(e.nx)));
         v2f den = s[0].n * s[1].n * s[2].n;
         den = fma2(d[0], s[0].n, den);
         den = fma2(d[1], s[1].n, den);
         den = fma2(d[2], s[2].n, den);
-        acc = fma2(splat2(e.sign), half_angle(num, den), acc);
+        acc += half_angle_strip(num, den);
     }
 }
 
 __global__ __launch_bounds__(kStripBlock) void winding_strip_kernel(
     const float* __restrict__ points,            // [B,Q,3]
     const StreamElem* __restrict__ stream,       // [B,Lpad]
-    int Q, int Lpad, int elems_per_split,        // Lpad % 6 == 0, elems_per_split % 6 == 0
+    int Q, int Lpad, int elems_per_split,        // Lpad % 3 == 0, elems_per_split % 3 == 0
     float* __restrict__ partial)                 // [B,S,Q]
 {
     // XCD-aware launch order: the body index varies fastest, so with the observed round-robin of
-    // workgroups over the 8 XCDs all workgroups of body b run on XCD b % 8 and its 228 KB stream
-    // is fetched into ONE L2 instead of all eight (FETCH_SIZE 136 MB -> see profiles/)
+    // workgroups over the 8 XCDs all workgroups of body b run on XCD b % 8 and its stream is
+    // fetched into ONE L2 instead of all eight (FETCH_SIZE 133 MB -> 19 MB, profiles/)
     const int b = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
     const int q0 = blockIdx.z * kStripQueries + threadIdx.x, q1 = q0 + kStripBlock;
     const float* pts = points + (size_t)b * Q * 3;
@@ -265,30 +290,26 @@ __global__ __launch_bounds__(kStripBlock) void winding_strip_kernel(
     const v2f qy = {pts[3 * c0 + 1], pts[3 * c1 + 1]};
     const v2f qz = {pts[3 * c0 + 2], pts[3 * c1 + 2]};
     const int p_first = split * elems_per_split;
-    const int p_end = min(Lpad - 6, p_first + elems_per_split);   // the prefetch reads one sextuple ahead
+    const int p_end = min(Lpad - 3, p_first + elems_per_split);   // the prefetch reads one triple ahead
     const StreamElem* st = stream + (size_t)b * Lpad;
     Slot s[3];
-    v2f d[3], c[3];
+    v2f d[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         s[k].x = s[k].y = s[k].z = s[k].n = splat2(0.0f);
-        d[k] = c[k] = splat2(0.0f);
+        d[k] = splat2(0.0f);
     }
     v2f acc = splat2(0.0f);
-    // the sextuple before the chunk only primes the slots (a strip may straddle the boundary)
-    int p = max(p_first - 6, 0);
-    StreamElem n0 = st[p], n1 = st[p + 1], n2 = st[p + 2], n3 = st[p + 3], n4 = st[p + 4], n5 = st[p + 5];
-    for (; p < p_end; p += 6) {
+    // the triple before the chunk only primes the slots (a strip may straddle the boundary)
+    int p = max(p_first - 3, 0);
+    StreamElem n0 = st[p], n1 = st[p + 1], n2 = st[p + 2];
+    for (; p < p_end; p += 3) {
         const bool emit = p >= p_first;
-        const StreamElem e0 = n0, e1 = n1, e2 = n2, e3 = n3, e4 = n4, e5 = n5;
-        n0 = st[p + 6]; n1 = st[p + 7]; n2 = st[p + 8];        // next sextuple in flight during the math
-        n3 = st[p + 9]; n4 = st[p + 10]; n5 = st[p + 11];
-        strip_step<0, true>(e0, emit, s, d, c, qx, qy, qz, acc);
-        strip_step<1, false>(e1, emit, s, d, c, qx, qy, qz, acc);
-        strip_step<2, true>(e2, emit, s, d, c, qx, qy, qz, acc);
-        strip_step<0, false>(e3, emit, s, d, c, qx, qy, qz, acc);
-        strip_step<1, true>(e4, emit, s, d, c, qx, qy, qz, acc);
-        strip_step<2, false>(e5, emit, s, d, c, qx, qy, qz, acc);
+        const StreamElem e0 = n0, e1 = n1, e2 = n2;
+        n0 = st[p + 3]; n1 = st[p + 4]; n2 = st[p + 5];        // next triple in flight during the math
+        strip_step<0>(e0, emit, s, d, qx, qy, qz, acc);
+        strip_step<1>(e1, emit, s, d, qx, qy, qz, acc);
+        strip_step<2>(e2, emit, s, d, qx, qy, qz, acc);
     }
     float* out = partial + ((size_t)b * nsplit + split) * Q;
     if (q0 < Q) out[q0] = acc[0];
@@ -475,7 +496,7 @@ struct ExteriorLayout {
     int lpad;
 };
 
-inline int strip_lpad(int L) { return ceil_div(L, 6) * 6 + 12; }
+inline int strip_lpad(int L) { return ceil_div(L, 3) * 3 + 6; }
 
 int choose_splits(int B, int Q, int F);
 
@@ -591,7 +612,7 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
                            (const int32_t*)m->strip_vidx, (const float*)m->strip_sign, m->V, m->strip_len,
                            l.lpad, st);
         const int nsplit = choose_strip_splits(B, m->V, l.lpad);
-        const int per_split = ceil_div(ceil_div(l.lpad - 12, nsplit), 6) * 6;
+        const int per_split = ceil_div(ceil_div(l.lpad - 6, nsplit), 3) * 3;
         hipLaunchKernelGGL(winding_strip_kernel, dim3(B, nsplit, ceil_div(m->V, kStripQueries)), dim3(kStripBlock),
                            0, s, verts, (const StreamElem*)st, m->V, l.lpad, per_split, (float*)(ws + l.partial));
         hipLaunchKernelGGL(winding_finalize_kernel, dim3(ceil_div(m->V, kBlock), B), dim3(kBlock), 0, s,
