@@ -109,3 +109,34 @@ def test_smplifydc_runs_and_reduces_the_objective(use_contact):
     assert torch.isfinite(verts).all() and torch.isfinite(reproj).all()
     assert reproj.sum().item() < before                       # the fit moved toward the keypoints
     assert not torch.equal(pose, init_pose)
+
+
+def test_graph_replayed_loops_match_eager_loops():
+    """SMPLifyDC replays its optimisation loops as hipGraphs; the result must be the eager one
+    (up to the last-ulp order dependence of the gradient scatter atomics)."""
+    from tuch_amd.smplify.smplifydc import SMPLifyDC
+    from tuch_amd.utils.geometry import perspective_projection
+    batch = 3
+    s = _setup(batch, 23)
+    body, t = s['body'], s['t']
+    with torch.no_grad():
+        tgt = s['smpl'](global_orient=t(s['go']), body_pose=t(s['bp']) + 0.1, betas=t(s['be']))
+        j2d = perspective_projection(tgt.joints, torch.eye(3, device=DEV)[None].expand(batch, -1, -1),
+                                     t(s['cam_t']), 5000., torch.zeros(batch, 2, device=DEV))
+    kp = torch.cat([j2d, torch.ones(batch, 49, 1, device=DEV)], 2)
+    init_pose = torch.cat([t(s['go']), t(s['bp'])], 1)
+    results = []
+    for use_graph in (False, True):
+        fitter = SMPLifyDC(step_size=1e-2, batch_size=batch, num_iters=8, focal_length=5000.,
+                           geodistssmpl=t(body.geodesics), geothres=0.3, euclthres=0.02,
+                           device=torch.device(DEV), smpl=s['smpl'], pose_prior=s['prior'], use_graph=use_graph)
+        results.append(fitter(init_pose, t(s['be']), t(s['cam_t']), torch.zeros(batch, 2, device=DEV), kp.clone(),
+                              use_contact=True, contactlist=s['cdict'], gt_contact=[t(s['gt']), None],
+                              ignore_idxs=torch.zeros(batch, dtype=torch.bool, device=DEV),
+                              has_discrete_contact=torch.ones(batch, dtype=torch.bool, device=DEV),
+                              contact_loss_weight=1.0, segments=s['segments']))
+    eager, graph = results
+    assert len(eager[6]) == len(graph[6]) == 8
+    for a, b, name in zip(eager[:6], graph[:6], ('verts', 'joints', 'pose', 'betas', 'cam', 'reproj')):
+        assert_close(b.detach().cpu().numpy(), a.detach().cpu().numpy(), 2e-3, 2e-4, name)
+    assert_close(graph[6][-1].cpu().numpy(), eager[6][-1].detach().cpu().numpy(), 2e-3, 2e-4, 'last optiverts')

@@ -13,7 +13,7 @@ import torch
 from .. import ops
 from ..utils.geometry import perspective_projection
 
-_MODEL_CACHE: Dict[tuple, ops.ContactModel] = {}
+_MODEL_CACHE: Dict[tuple, tuple] = {}
 _ANGLE_SIGNS: Dict[tuple, tuple] = {}
 
 
@@ -30,7 +30,8 @@ def contact_model_for(geomask, face_tensor, segments=None, cdict=None, device=No
     faces = face_tensor[0] if face_tensor.dim() == 3 else face_tensor
     key = (geomask.data_ptr() if torch.is_tensor(geomask) else id(geomask), faces.data_ptr(),
            id(segments), id(cdict))
-    model = _MODEL_CACHE.get(key)
+    entry = _MODEL_CACHE.get(key)
+    model = entry[0] if entry is not None else None
     if model is None:
         seg_tables = segments.tables() if segments is not None else None
         regions = pairs = None
@@ -41,7 +42,11 @@ def contact_model_for(geomask, face_tensor, segments=None, cdict=None, device=No
             pairs = np.asarray([[index[str(p[0])], index[str(p[1])]] for p in cdict['classes']], np.int64)
         model = ops.ContactModel(faces, geomask, seg_tables, regions, pairs,
                                  device=device if device is not None else faces.device)
-        _MODEL_CACHE[key] = model
+        # keep the keyed objects alive with the entry: a freed tensor's address / a dead object's id can
+        # be reused, which would turn the key into a stale hit
+        while len(_MODEL_CACHE) >= 8:
+            _MODEL_CACHE.pop(next(iter(_MODEL_CACHE)))
+        _MODEL_CACHE[key] = (model, geomask, face_tensor, segments, cdict)
     return model
 
 

@@ -35,7 +35,7 @@ class SMPLifyDC():
                  euclthres=0.0,
                  device=torch.device('cuda'),
                  smpl=None, pose_prior=None, ign_joints=None,
-                 smpl_model_dir=None, prior_folder=None):
+                 smpl_model_dir=None, prior_folder=None, use_graph=True):
         self.device = device
         self.focal_length = focal_length
         self.step_size = step_size
@@ -55,6 +55,50 @@ class SMPLifyDC():
         self.geothres = geothres
         self.geomask = self.geodistssmpl > self.geothres            # smplifydc.py:65 (strict >)
         self.euclthres = euclthres
+        # replay each optimisation loop as a hipGraph after three eager iterations (same arithmetic,
+        # no per-kernel launch cost: at small batch the loop is launch-bound otherwise)
+        self.use_graph = use_graph
+
+    def _optimise(self, params, iteration, num_iters, adam_kwargs, collect=None):
+        """Run ``num_iters`` Adam iterations of ``iteration()`` (which returns (loss, vertices))."""
+        graph_ok = self.use_graph and params[0].is_cuda and num_iters > 4
+        optimizer = torch.optim.Adam(params, lr=self.step_size, capturable=graph_ok, **adam_kwargs)
+        static = {}
+
+        def one():
+            loss, verts = iteration()
+            optimizer.zero_grad(set_to_none=graph_ok)
+            loss.backward()
+            optimizer.step()
+            static['verts'] = verts
+            return verts
+
+        done = 0
+        if graph_ok:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    verts = one()
+                    if collect is not None:
+                        collect.append(verts.detach().clone())
+            torch.cuda.current_stream().wait_stream(side)
+            done = 3
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                    one()
+                for _ in range(num_iters - done):
+                    graph.replay()
+                    if collect is not None:
+                        collect.append(static['verts'].detach().clone())
+                return
+            except Exception:            # capture not possible in this environment: finish eagerly
+                torch.cuda.synchronize()
+        for _ in range(num_iters - done):
+            verts = one()
+            if collect is not None:
+                collect.append(verts)
 
     def __call__(self, init_pose, init_betas, init_cam_t,
                  camera_center, keypoints_2d, use_contact=False,
@@ -77,31 +121,32 @@ class SMPLifyDC():
         global_orient.requires_grad = not use_contact
         betas.requires_grad = bool(use_contact)
         stage1 = [betas, camera_translation] if use_contact else [global_orient, camera_translation]
-        optimizer = torch.optim.Adam(stage1, lr=self.step_size, betas=(0.9, 0.999))
         shape_prior_weight = 1.0 if use_contact else 0.0
-        for _ in range(self.num_iters):
+
+        def camera_iteration():
             out = self.smpl(global_orient=global_orient, body_pose=body_pose, betas=betas)
-            loss = camera_fitting_loss(out, camera_translation, init_cam_t, camera_center, joints_2d,
+            return camera_fitting_loss(out, camera_translation, init_cam_t, camera_center, joints_2d,
                                        joints_conf, focal_length=self.focal_length,
-                                       shape_prior_weight=shape_prior_weight)
-            optimizer.zero_grad()
-            loss.backward()
-            optimizer.step()
+                                       shape_prior_weight=shape_prior_weight), out.vertices
+
+        self._optimise(stage1, camera_iteration, self.num_iters, dict(betas=(0.9, 0.999)))
 
         # ---- stage 2: pose + global orientation
         optiverts = []
         joints_conf[:, self.ign_joints] = 0.0                        # smplifydc.py:153,198
         camera_translation.requires_grad = False
+        # snapshots of the stage-1 result (smplifydc.py:141-142), taken before gradients are switched on:
+        # a clone of a leaf that requires grad would keep its AccumulateGrad node (created on the
+        # default stream) alive and break the graph capture of the loop below
+        pose_stage1 = body_pose.detach().clone()
+        orient_stage1 = global_orient.detach().clone()
         body_pose.requires_grad = True
         global_orient.requires_grad = True
         if use_contact:
-            pose_stage1 = body_pose.clone()
-            orient_stage1 = global_orient.clone()
             betas.requires_grad = False
-            optimizer = torch.optim.Adam([body_pose, global_orient], lr=self.step_size)
-            for _ in range(self.num_iters):
+
+            def contact_iteration():
                 out = self.smpl(global_orient=global_orient, body_pose=body_pose, betas=betas)
-                optiverts += [out.vertices]
                 loss = contact_fitting_loss(body_pose, global_orient, pose_stage1, orient_stage1,
                                             betas, out.joints, self.geomask, self.euclthres,
                                             camera_translation, camera_center, joints_2d, joints_conf,
@@ -112,22 +157,20 @@ class SMPLifyDC():
                                             focal_length=self.focal_length,
                                             contact_loss_weight=contact_loss_weight,
                                             output=contact_loss_return, segments=segments)
-                optimizer.zero_grad()
-                loss.backward()
-                optimizer.step()
+                return loss, out.vertices
+
+            self._optimise([body_pose, global_orient], contact_iteration, self.num_iters, {}, optiverts)
         else:
             betas.requires_grad = True
-            optimizer = torch.optim.Adam([body_pose, betas, global_orient], lr=self.step_size,
-                                         betas=(0.9, 0.999))
-            for _ in range(self.num_iters):
+
+            def body_iteration():
                 out = self.smpl(global_orient=global_orient, body_pose=body_pose, betas=betas)
-                optiverts += [out.vertices]
-                loss = body_fitting_loss(body_pose, betas, out.joints, camera_translation, camera_center,
+                return body_fitting_loss(body_pose, betas, out.joints, camera_translation, camera_center,
                                          joints_2d, joints_conf, self.pose_prior,
-                                         focal_length=self.focal_length)
-                optimizer.zero_grad()
-                loss.backward()
-                optimizer.step()
+                                         focal_length=self.focal_length), out.vertices
+
+            self._optimise([body_pose, betas, global_orient], body_iteration, self.num_iters,
+                           dict(betas=(0.9, 0.999)), optiverts)
         if len(optiverts) == 0:
             optiverts = None
 
