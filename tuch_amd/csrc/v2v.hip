@@ -87,7 +87,6 @@ __global__ __launch_bounds__(kBlock) void v2v_partial_kernel(
     float best0 = inf, best1 = inf;
     int arg0 = 0, arg1 = 0;
     auto row = [&](int j, uint64_t k0, uint64_t k1, float vx, float vy, float vz) {
-        if ((k0 | k1) == 0) return;                            // wave-uniform: row masked for all 128 columns
         const v2f dx = px - splat2(vx), dy = py - splat2(vy), dz = pz - splat2(vz);
         const v2f d = fma2(dz, dz, fma2(dy, dy, dx * dx));
         const float d0 = select_by_lane_mask(inf, d[0], k0);
