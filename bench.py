@@ -34,8 +34,9 @@ FLOP_PER_V2V_PAIR = 8
 PEAK_FP32_VECTOR_TFLOPS = 157.3   # MI355X_MICROARCH.md (packed FP32 FMA rate)
 PEAK_HBM_GBS = 8000.0
 # HBM-side bytes per launch of winding_strip_kernel at batch 64 from the PMC passes committed under
-# profiles/ (FETCH_SIZE 18607.5 KB + WRITE_SIZE 12470.2 KB); algorithmic: 19.9 MB in + 12.3 MB out
-WINDING_TRAFFIC_BYTES = int((18607.5 + 12470.2) * 1024)
+# profiles/r01_e_pmc_{fetch,write}.txt (FETCH_SIZE 55159.2 KB + WRITE_SIZE 12920.4 KB); the kernel's own
+# layout moves 34.5 MB in (32-byte stream elements + query points) + 12.3 MB of partial sums out
+WINDING_TRAFFIC_BYTES = int((55159.2 + 12920.4) * 1024)
 
 
 def parse():
@@ -177,7 +178,7 @@ def rooflines(p, batch):
             'peak': PEAK_FP32_VECTOR_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_VECTOR_TFLOPS, 4),
             'traffic': WINDING_TRAFFIC_BYTES if batch == BATCH_PER_GPU else None,
             'traffic_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, KB x 1024 '
-                              '(profiles/r01_d_pmc_*_xcd_order.txt); narrow loads: counter uncalibrated',
+                              '(profiles/r01_e_pmc_fetch.txt, r01_e_pmc_write.txt); narrow loads: counter uncalibrated',
             'launch_ms': round(t_w * 1e3, 4),
             'algorithmic_flop_per_launch': flops,
             'algorithmic_bytes_per_launch': batch * (v * 12 + v * 4) + f * 12}
