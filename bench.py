@@ -196,6 +196,38 @@ def rooflines(p, batch):
     return roof, v2v
 
 
+def contact_loss_eval(p, batch):
+    """BASELINE metric 2, 'contact-loss eval ms/body' (SURVEY.md §8d): RegressorLoss.contact_loss
+    (tuch/train/loss.py:240-317) on the posed vertices, batch 64, forward and forward+backward,
+    plain and HD branch; HIP events on the launch stream."""
+    import types
+    from tuch_amd.train.loss import RegressorLoss
+    body = p['body']
+    with torch.no_grad():
+        verts = p['smpl'](global_orient=p['global_orient'], body_pose=p['body_pose'], betas=p['betas']).vertices
+    dev = verts.device
+    valid = torch.ones(batch, dtype=torch.bool, device=dev)
+    out = {}
+    for tag, use_hd in (('plain', False), ('hd', True)):
+        crit = RegressorLoss(types.SimpleNamespace(contact_loss_weight=1.0), dev, body.num_verts, p['face_tensor'],
+                             torch.tensor(body.geodesics, device=dev), geothres=0.3, euclthres=0.02,
+                             face_tensor=p['face_tensor'], use_hd=use_hd, segments=p['segments'],
+                             hd_regressor=(body.hd_bary_idx, body.hd_bary_w), hd_faces=body.hd_face_id)
+        v = verts.clone().requires_grad_(True)
+
+        def fwd():
+            with torch.no_grad():
+                return crit.contact_loss(v, valid)
+
+        def fwd_bwd():
+            v.grad = None
+            crit.contact_loss(v, valid).backward()
+        iters = 5 if not use_hd else 2
+        out['regressor_%s_fwd_ms_per_body' % tag] = round(time_kernel(fwd, iters) * 1e3 / batch, 5)
+        out['regressor_%s_fwd_bwd_ms_per_body' % tag] = round(time_kernel(fwd_bwd, iters) * 1e3 / batch, 5)
+    return out
+
+
 def cpu_baseline(p, seconds):
     """The CPU oracle (a port of the reference's arithmetic, test infrastructure) timed on the host:
     contact loss forward + gradient for whole bodies, until ~`seconds` have elapsed."""
@@ -297,6 +329,7 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
     roof, v2v = rooflines(p, args.batch)
+    eval_ms = contact_loss_eval(p, args.batch) if rank == 0 else None
     if rank == 0:
         bodies = args.batch * world
         line = {
@@ -312,7 +345,7 @@ def main():
                        'batch_iterations_per_s': round(args.steps / dt, 3),
                        'contact_loss_ms_per_body': round(dt / args.steps * 1e3 / args.batch, 4),
                        'loss_sum': float(stats[0].item()), 'bodies': float(stats[1].item())},
-            'roofline': roof, 'roofline_v2v': v2v,
+            'roofline': roof, 'roofline_v2v': v2v, 'contact_loss_eval': eval_ms,
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(p, args.cpu_seconds)
