@@ -85,6 +85,14 @@ int tuch_v2v_min_indexed(const float* points, const int32_t* vertex_ids, const i
 int tuch_contact_terms_fwd(const float* points, const int32_t* partner, const uint8_t* exterior,
                            const uint8_t* body_valid, int B, int N, int mode, float euclthres,
                            float* terms, void* stream);
+/* Ragged forward (HD points, loss.py:299-315): body b owns points offsets[b]..offsets[b+1] of one
+ * concatenated set [N,3]; partner holds global indices; terms [B,2]. */
+int tuch_contact_terms_ragged_fwd(const float* points, const int32_t* partner, const uint8_t* exterior,
+                                  const int32_t* offsets, int B, int mode, float euclthres, float* terms,
+                                  void* stream);
+int tuch_contact_terms_ragged_bwd(const float* points, const int32_t* partner, const uint8_t* exterior,
+                                  const int32_t* body_of_point, const float* grad_scale, int N, int mode,
+                                  float euclthres, float* grad_points, void* stream);
 /* grad_points [B,N,3] += d(terms)/d(points) . grad_scale [B,2]; grad_points zeroed by the caller. */
 int tuch_contact_terms_bwd(const float* points, const int32_t* partner, const uint8_t* exterior,
                            const float* grad_scale, int B, int N, int mode, float euclthres,
@@ -133,6 +141,14 @@ int tuch_contact_model_strips(const tuch_contact_model* model, int* stream_len, 
 size_t tuch_exterior_workspace_bytes(const tuch_contact_model* model, int B);
 int tuch_exterior_flags(const tuch_contact_model* model, const float* verts, int B, int apply_segments,
                         float thresh, float* w, uint8_t* exterior, float* seg_w, uint8_t* seg_exterior,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* Winding numbers of arbitrary points against the model's mesh posed by `verts`, loss.py:295-297
+ * (HD points offset along the face normals).  points [B,Q,3] (padded); counts [B] device ints or
+ * NULL: meaningful points per body; padded entries give w = 0, exterior = 1. */
+size_t tuch_winding_points_workspace_bytes(const tuch_contact_model* model, int B, int Q);
+int tuch_winding_points(const tuch_contact_model* model, const float* verts, const float* points,
+                        const int32_t* counts, int B, int Q, float thresh, float* w, uint8_t* exterior,
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* region-pair minima: TUCH.contact_from_verts, train_module.py:69-91 (select NULL, unmasked)

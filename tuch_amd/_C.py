@@ -51,6 +51,13 @@ _SIGNATURES = {
     'tuch_exterior_workspace_bytes': (c_size_t, [c_void_p, c_int]),
     'tuch_exterior_flags': (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_size_t, c_void_p]),
+    'tuch_winding_points_workspace_bytes': (c_size_t, [c_void_p, c_int, c_int]),
+    'tuch_winding_points': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p,
+                                    c_void_p, c_size_t, c_void_p]),
+    'tuch_contact_terms_ragged_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p,
+                                              c_void_p]),
+    'tuch_contact_terms_ragged_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
+                                              c_void_p, c_void_p]),
     'tuch_region_pair_min': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     'tuch_smpl_model_create': (c_int, [POINTER(c_void_p), c_int] + [c_void_p] * 9),
     'tuch_smpl_model_destroy': (None, [c_void_p]),

@@ -83,6 +83,30 @@ __global__ __launch_bounds__(kBlock) void contact_terms_fwd_kernel(
     if (threadIdx.x == 0) { terms[2 * b] = a; terms[2 * b + 1] = c; }
 }
 
+// Ragged form (HD points, loss.py:299-315): body b owns points off[b]..off[b+1] of ONE
+// concatenated set; partner indices are global.  terms[b] = {interior sum, exterior sum}.
+__global__ __launch_bounds__(kBlock) void contact_terms_ragged_fwd_kernel(
+    const float* __restrict__ pts, const int32_t* __restrict__ partner,
+    const uint8_t* __restrict__ exterior, const int32_t* __restrict__ off, int mode, float euclthres,
+    float* __restrict__ terms)
+{
+    __shared__ float smem[kBlock / 64];
+    const int b = blockIdx.x;
+    float in_sum = 0.0f, ex_sum = 0.0f;
+    for (int i = off[b] + threadIdx.x; i < off[b + 1]; i += kBlock) {
+        const int p = partner[i];
+        const float dx = pts[3 * (size_t)i] - pts[3 * (size_t)p], dy = pts[3 * (size_t)i + 1] - pts[3 * (size_t)p + 1],
+                    dz = pts[3 * (size_t)i + 2] - pts[3 * (size_t)p + 2];
+        const float d = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
+        const bool ext = exterior[i] != 0;
+        const Term t = contact_term(d, ext, mode, euclthres);
+        if (ext) ex_sum += t.value; else in_sum += t.value;
+    }
+    const float a = block_sum(in_sum, smem);
+    const float c = block_sum(ex_sum, smem);
+    if (threadIdx.x == 0) { terms[2 * b] = a; terms[2 * b + 1] = c; }
+}
+
 // grad[b][i] += g_b * dd * (x_i - x_p)/d ; grad[b][p] -= the same.  grad pre-zeroed by the caller.
 __global__ __launch_bounds__(256) void contact_terms_bwd_kernel(
     const float* __restrict__ pts, const int32_t* __restrict__ partner,
@@ -106,6 +130,31 @@ __global__ __launch_bounds__(256) void contact_terms_bwd_kernel(
     const float c = g * t.dd / d;
     float* gi = grad + ((size_t)b * N + i) * 3;
     float* gp = grad + ((size_t)b * N + p) * 3;
+    atomicAdd(gi + 0, c * dx); atomicAdd(gi + 1, c * dy); atomicAdd(gi + 2, c * dz);
+    atomicAdd(gp + 0, -c * dx); atomicAdd(gp + 1, -c * dy); atomicAdd(gp + 2, -c * dz);
+}
+
+// ragged backward: point i belongs to body body_of[i]; grad [N,3] pre-zeroed by the caller
+__global__ __launch_bounds__(256) void contact_terms_ragged_bwd_kernel(
+    const float* __restrict__ pts, const int32_t* __restrict__ partner, const uint8_t* __restrict__ exterior,
+    const int32_t* __restrict__ body_of, const float* __restrict__ gscale, int N, int mode, float euclthres,
+    float* __restrict__ grad)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const bool ext = exterior[i] != 0;
+    const float g = gscale[2 * body_of[i] + (ext ? 1 : 0)];
+    if (g == 0.0f) return;
+    const int p = partner[i];
+    const float dx = pts[3 * (size_t)i] - pts[3 * (size_t)p], dy = pts[3 * (size_t)i + 1] - pts[3 * (size_t)p + 1],
+                dz = pts[3 * (size_t)i + 2] - pts[3 * (size_t)p + 2];
+    const float d = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
+    if (!(d > 0.0f)) return;
+    const Term t = contact_term(d, ext, mode, euclthres);
+    if (t.dd == 0.0f) return;
+    const float c = g * t.dd / d;
+    float* gi = grad + (size_t)i * 3;
+    float* gp = grad + (size_t)p * 3;
     atomicAdd(gi + 0, c * dx); atomicAdd(gi + 1, c * dy); atomicAdd(gi + 2, c * dz);
     atomicAdd(gp + 0, -c * dx); atomicAdd(gp + 1, -c * dy); atomicAdd(gp + 2, -c * dz);
 }
@@ -134,4 +183,29 @@ extern "C" int tuch_contact_terms_bwd(const float* points, const int32_t* partne
                        (hipStream_t)stream, points, partner, exterior, grad_scale, N, mode, euclthres,
                        grad_points);
     return tuch_check_launch("tuch_contact_terms_bwd");
+}
+
+extern "C" int tuch_contact_terms_ragged_fwd(const float* points, const int32_t* partner,
+                                             const uint8_t* exterior, const int32_t* offsets, int B, int mode,
+                                             float euclthres, float* terms, void* stream)
+{
+    TUCH_REQUIRE(points && partner && exterior && offsets && terms, "tuch_contact_terms_ragged_fwd: null pointer");
+    TUCH_REQUIRE(B > 0 && (mode == 0 || mode == 1), "tuch_contact_terms_ragged_fwd: bad arguments");
+    hipLaunchKernelGGL(contact_terms_ragged_fwd_kernel, dim3(B), dim3(kBlock), 0, (hipStream_t)stream, points,
+                       partner, exterior, offsets, mode, euclthres, terms);
+    return tuch_check_launch("tuch_contact_terms_ragged_fwd");
+}
+
+extern "C" int tuch_contact_terms_ragged_bwd(const float* points, const int32_t* partner,
+                                             const uint8_t* exterior, const int32_t* body_of_point,
+                                             const float* grad_scale, int N, int mode, float euclthres,
+                                             float* grad_points, void* stream)
+{
+    TUCH_REQUIRE(points && partner && exterior && body_of_point && grad_scale && grad_points,
+                 "tuch_contact_terms_ragged_bwd: null pointer");
+    TUCH_REQUIRE(N >= 0 && (mode == 0 || mode == 1), "tuch_contact_terms_ragged_bwd: bad arguments");
+    if (N == 0) return TUCH_OK;
+    hipLaunchKernelGGL(contact_terms_ragged_bwd_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream,
+                       points, partner, exterior, body_of_point, grad_scale, N, mode, euclthres, grad_points);
+    return tuch_check_launch("tuch_contact_terms_ragged_bwd");
 }

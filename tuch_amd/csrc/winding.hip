@@ -277,6 +277,7 @@ __global__ __launch_bounds__(kStripBlock) void winding_strip_kernel(
     const float* __restrict__ points,            // [B,Q,3]
     const StreamElem* __restrict__ stream,       // [B,Lpad]
     int Q, int Lpad, int elems_per_split,        // Lpad % 3 == 0, elems_per_split % 3 == 0
+    const int32_t* __restrict__ counts,          // [B] valid queries per body, or nullptr (= Q)
     float* __restrict__ partial)                 // [B,S,Q]
 {
     // XCD-aware launch order: the body index varies fastest, so with the observed round-robin of
@@ -284,6 +285,7 @@ __global__ __launch_bounds__(kStripBlock) void winding_strip_kernel(
     // fetched into ONE L2 instead of all eight (FETCH_SIZE 133 MB -> 19 MB, profiles/)
     const int b = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
     const int q0 = blockIdx.z * kStripQueries + threadIdx.x, q1 = q0 + kStripBlock;
+    if (counts && (int)(blockIdx.z * kStripQueries) >= counts[b]) return;   // padding of a ragged point set
     const float* pts = points + (size_t)b * Q * 3;
     const int c0 = q0 < Q ? q0 : Q - 1, c1 = q1 < Q ? q1 : Q - 1;
     const v2f qx = {pts[3 * c0 + 0], pts[3 * c1 + 0]};
@@ -614,7 +616,8 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
         const int nsplit = choose_strip_splits(B, m->V, l.lpad);
         const int per_split = ceil_div(ceil_div(l.lpad - 6, nsplit), 3) * 3;
         hipLaunchKernelGGL(winding_strip_kernel, dim3(B, nsplit, ceil_div(m->V, kStripQueries)), dim3(kStripBlock),
-                           0, s, verts, (const StreamElem*)st, m->V, l.lpad, per_split, (float*)(ws + l.partial));
+                           0, s, verts, (const StreamElem*)st, m->V, l.lpad, per_split, (const int32_t*)nullptr,
+                           (float*)(ws + l.partial));
         hipLaunchKernelGGL(winding_finalize_kernel, dim3(ceil_div(m->V, kBlock), B), dim3(kBlock), 0, s,
                            (const float*)(ws + l.partial), m->V, nsplit, thresh, w, exterior);
     } else {
@@ -656,4 +659,46 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
                            m->V, m->seg_q_total, m->num_segments, seg_splits(), thresh, seg_w, seg_exterior, exterior);
     }
     return tuch_check_launch("tuch_exterior_flags");
+}
+
+// winding numbers of ARBITRARY query points against the model's mesh posed by `verts`
+// (tuch/train/loss.py:297: HD points offset along the face normals).  points [B,Q,3]; counts [B]
+// (device, optional) = number of meaningful points per body when the set is ragged and padded
+// to Q; w / exterior of padded entries are 0 / 1.
+extern "C" size_t tuch_winding_points_workspace_bytes(const tuch_contact_model* m, int B, int Q)
+{
+    if (!m || B <= 0 || Q <= 0) return 0;
+    const int lpad = strip_lpad(m->strip_len);
+    return align256((size_t)B * lpad * sizeof(StreamElem)) +
+           align256((size_t)B * choose_strip_splits(B, Q, lpad) * Q * sizeof(float));
+}
+
+extern "C" int tuch_winding_points(const tuch_contact_model* m, const float* verts, const float* points,
+                                   const int32_t* counts, int B, int Q, float thresh, float* w,
+                                   uint8_t* exterior, void* workspace, size_t workspace_bytes, void* stream)
+{
+    TUCH_REQUIRE(m && verts && points && (w || exterior), "tuch_winding_points: null pointer");
+    TUCH_REQUIRE(B > 0 && B <= 65535 && Q > 0, "tuch_winding_points: bad sizes B=%d Q=%d", B, Q);
+    const size_t need = tuch_winding_points_workspace_bytes(m, B, Q);
+    if (!workspace || workspace_bytes < need) {
+        tuch_set_error("tuch_winding_points: workspace %zu < %zu bytes", workspace_bytes, need);
+        return TUCH_ERR_WORKSPACE;
+    }
+    const int lpad = strip_lpad(m->strip_len);
+    StreamElem* st = (StreamElem*)workspace;
+    float* partial = (float*)((char*)workspace + align256((size_t)B * lpad * sizeof(StreamElem)));
+    hipStream_t s = (hipStream_t)stream;
+    const int nsplit = choose_strip_splits(B, Q, lpad);
+    if (counts && hipMemsetAsync(partial, 0, (size_t)B * nsplit * Q * sizeof(float), s) != hipSuccess) {
+        tuch_set_error("tuch_winding_points: hipMemsetAsync failed");
+        return TUCH_ERR_HIP;
+    }
+    hipLaunchKernelGGL(gather_stream_kernel, dim3(ceil_div(lpad, kBlock), B), dim3(kBlock), 0, s, verts,
+                       (const int32_t*)m->strip_vidx, (const float*)m->strip_sign, m->V, m->strip_len, lpad, st);
+    const int per_split = ceil_div(ceil_div(lpad - 6, nsplit), 3) * 3;
+    hipLaunchKernelGGL(winding_strip_kernel, dim3(B, nsplit, ceil_div(Q, kStripQueries)), dim3(kStripBlock), 0, s,
+                       points, (const StreamElem*)st, Q, lpad, per_split, counts, partial);
+    hipLaunchKernelGGL(winding_finalize_kernel, dim3(ceil_div(Q, kBlock), B), dim3(kBlock), 0, s,
+                       (const float*)partial, Q, nsplit, thresh, w, exterior);
+    return tuch_check_launch("tuch_winding_points");
 }

@@ -124,6 +124,38 @@ class _ContactTerms(torch.autograd.Function):
         return grad, None, None, None, None, None
 
 
+class _ContactTermsRagged(torch.autograd.Function):
+    """terms[b] over the ragged point set of body b (HD points): points [N,3], global partner indices."""
+
+    @staticmethod
+    def forward(ctx, points, partner, exterior, offsets, body_of_point, mode, euclthres):
+        pts = _f32(points)
+        b = offsets.shape[0] - 1
+        terms = torch.empty(b, 2, dtype=torch.float32, device=pts.device)
+        _C.check(_C.lib().tuch_contact_terms_ragged_fwd(_C.ptr(pts), _C.ptr(partner), _C.ptr(exterior),
+                                                        _C.ptr(offsets), b, int(mode), float(euclthres),
+                                                        _C.ptr(terms), _C.stream()))
+        ctx.save_for_backward(pts, partner, exterior, body_of_point)
+        ctx.mode, ctx.euclthres = int(mode), float(euclthres)
+        return terms
+
+    @staticmethod
+    def backward(ctx, grad_terms):
+        pts, partner, exterior, body_of_point = ctx.saved_tensors
+        grad = torch.zeros_like(pts)
+        g = grad_terms.to(torch.float32).contiguous()
+        _C.check(_C.lib().tuch_contact_terms_ragged_bwd(_C.ptr(pts), _C.ptr(partner), _C.ptr(exterior),
+                                                        _C.ptr(body_of_point), _C.ptr(g), pts.shape[0], ctx.mode,
+                                                        ctx.euclthres, _C.ptr(grad), _C.stream()))
+        return grad, None, None, None, None, None, None
+
+
+def contact_terms_ragged(points, partner_i32, exterior_u8, offsets_i32, body_of_point_i32, mode, euclthres):
+    """[B,2] (interior sum, exterior sum) per body over a concatenated ragged point set."""
+    return _ContactTermsRagged.apply(points, partner_i32, exterior_u8, offsets_i32, body_of_point_i32, mode,
+                                     euclthres)
+
+
 def contact_terms(points, partner_i32, exterior_u8, valid_u8, mode, euclthres):
     """Sum of pull/push terms per body: [B] = interior + exterior (differentiable wrt points)."""
     terms = _ContactTerms.apply(points, partner_i32, exterior_u8, valid_u8, mode, euclthres)
@@ -291,6 +323,21 @@ class ContactModel:
         if not self.has_mask:
             raise _C.TuchError('ContactModel was created without a geodesic mask')
         return v2v_min_masked(verts, ctypes.c_void_p(_C.lib().tuch_contact_model_mask_bits(self._handle)))
+
+    def winding_points(self, verts: torch.Tensor, points: torch.Tensor, counts: Optional[torch.Tensor] = None,
+                       thresh: float = 0.99):
+        """Winding numbers of arbitrary points [B,Q,3] against this mesh posed by verts [B,V,3]
+        (triangle-strip kernel); counts [B] int32 marks how many points per body are real."""
+        v, pts = _f32(verts), _f32(points)
+        b, q, _ = pts.shape
+        L = _C.lib()
+        w = torch.empty(b, q, dtype=torch.float32, device=pts.device)
+        ext = torch.empty(b, q, dtype=torch.uint8, device=pts.device)
+        nbytes = L.tuch_winding_points_workspace_bytes(self._handle, b, q)
+        ws = _workspace(nbytes, pts.device)
+        _C.check(L.tuch_winding_points(self._handle, _C.ptr(v), _C.ptr(pts), _C.ptr(counts), b, q, float(thresh),
+                                       _C.ptr(w), _C.ptr(ext), _C.ptr(ws), nbytes, _C.stream()))
+        return w, ext
 
     def v2v_min_indexed(self, points: torch.Tensor, vertex_ids: torch.Tensor, offsets: torch.Tensor,
                         max_points: int):

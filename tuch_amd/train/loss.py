@@ -99,13 +99,14 @@ class RegressorLoss(nn.Module):
             normals = 0.001 * batch_face_normals(tris)                                    # :295
             offs = hd.detach() + normals[bidx, self.geovec[hidx]]                         # :296
             batch = pred_vertices.shape[0]
-            padded = torch.full((batch, n_max, 3), 1.0e3, dtype=torch.float32, device=hd.device)
+            padded = torch.zeros((batch, n_max, 3), dtype=torch.float32, device=hd.device)
             slot = torch.arange(bidx.numel(), device=hd.device) - offsets[:-1][bidx]
             padded[bidx, slot] = offs
-            ext_hd = ops.winding_numbers(padded, tris, thresh=0.99)[1][bidx, slot].to(torch.uint8)  # :297
-        total, _ = ops.contact_terms(hd[None], partner_hd[None].contiguous(), ext_hd[None].contiguous(), None,
-                                     ops.MODE_TRAIN, self.euclthres)                      # :299-315
-        return total.sum() / n_valid
+            _, ext_pad = model.winding_points(pred_vertices, padded, counts.to(torch.int32))   # :297
+            ext_hd = ext_pad[bidx, slot].contiguous()
+        terms = ops.contact_terms_ragged(hd, partner_hd, ext_hd, offsets, bidx.to(torch.int32),
+                                         ops.MODE_TRAIN, self.euclthres)                  # :299-315
+        return terms.sum() / n_valid
 
     # ---------------------------------------------------------------------------- SPIN terms
     def forward(self, pred_rotmat, pred_betas, opt_pose, opt_betas, pred_keypoints_2d, gt_keypoints_2d,
