@@ -318,3 +318,50 @@ def test_eft_contact_loss_vs_reference(tag):
     assert_close(loss.item(), g['eft_loss'].sum(), 1e-4, 50 * 1e-6 * n_sel, 'eft loss')
     gv = g['eft_grad_verts']
     assert_close(verts.grad.cpu().numpy(), gv, 1e-3, 5e-6 * np.abs(gv).max(), 'eft grad')
+
+
+@pytest.mark.parametrize('tag', ['small', 'medium', 'full'])
+def test_winding_points_ragged_vs_oracle(tag):
+    """tuch_winding_points: arbitrary query points against the posed mesh (strip kernel), with a
+    ragged count per body; checked against the CPU oracle."""
+    g = golden(tag)
+    model = make_model(g, None, False, False)
+    verts_np = g['verts']
+    b_count, v_count = verts_np.shape[:2]
+    rng = np.random.default_rng(3)
+    q = min(300, v_count)
+    # points just off the surface (vertex + small random offset) and a few far away
+    pts = np.stack([verts_np[b][rng.choice(v_count, q, replace=False)] for b in range(b_count)])
+    pts = (pts + 0.003 * rng.standard_normal(pts.shape)).astype(np.float32)
+    pts[:, :5] += 3.0
+    counts = np.array([q - 7 * b for b in range(b_count)], np.int32)
+    w, ext = model.winding_points(torch.tensor(verts_np, device=dev()), torch.tensor(pts, device=dev()),
+                                  torch.tensor(counts, device=dev()))
+    w, ext = w.cpu().numpy(), ext.cpu().numpy()
+    for b in range(b_count):
+        wo = oc.winding_numbers(pts[b][:counts[b]], oc.gather_tris(verts_np[b], g['faces']))
+        err = np.abs(w[b][:counts[b]] - wo)
+        assert np.percentile(err, 99) < 5e-6 and err.max() < 2e-4
+        clear = np.abs(wo - 0.99) > 1e-4
+        assert np.array_equal(ext[b][:counts[b]][clear].astype(bool), (wo <= 0.99)[clear])
+
+
+def test_contact_terms_ragged_matches_dense():
+    from tuch_amd import ops
+    g, gm = golden('medium'), golden_mask('medium')
+    verts_np = g['verts']
+    b_count, v_count = verts_np.shape[:2]
+    partner = np.stack([oc.v2v_min_masked(verts_np[b], gm)[1] for b in range(b_count)]).astype(np.int32)
+    ext = (np.arange(b_count * v_count).reshape(b_count, v_count) % 3 != 0).astype(np.uint8)
+    d = dev()
+    vd = torch.tensor(verts_np, device=d, requires_grad=True)
+    dense = ops.contact_terms(vd, torch.tensor(partner, device=d), torch.tensor(ext, device=d), None, 1, 0.02)[1]
+    (dense * torch.tensor([[1.0, 2.0]], device=d)).sum().backward()
+    flat = torch.tensor(verts_np.reshape(-1, 3), device=d, requires_grad=True)
+    off = torch.arange(b_count + 1, dtype=torch.int32, device=d) * v_count
+    gpart = torch.tensor((partner + np.arange(b_count)[:, None] * v_count).reshape(-1).astype(np.int32), device=d)
+    body_of = torch.arange(b_count, dtype=torch.int32, device=d).repeat_interleave(v_count).contiguous()
+    ragged = ops.contact_terms_ragged(flat, gpart, torch.tensor(ext.reshape(-1), device=d), off, body_of, 1, 0.02)
+    (ragged * torch.tensor([[1.0, 2.0]], device=d)).sum().backward()
+    assert_close(ragged.detach().cpu().numpy(), dense.detach().cpu().numpy(), 1e-6, 1e-7, 'ragged terms')
+    assert_close(flat.grad.cpu().numpy().reshape(b_count, v_count, 3), vd.grad.cpu().numpy(), 1e-5, 1e-7, 'ragged grad')
