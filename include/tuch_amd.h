@@ -109,6 +109,13 @@ int tuch_smplify_small_terms(const float* joints, const float* camera_t, const f
                              float prior_scale, float* out, float* grad_joints, float* grad_camera_t,
                              float* grad_body_pose, void* stream);
 
+/* Objective assembly of losses.py:120-123 as one deterministic reduction:
+ * out[0] = sum(small_terms [B,2]) + contact_scale * sum(contact_terms [B,2]) + r2r_scale * sum(r2r [B,P]). */
+int tuch_smplify_objective(const float* small_terms, const float* contact_terms, const float* r2r, int B, int P,
+                           float contact_scale, float r2r_scale, float* out, void* stream);
+int tuch_smplify_objective_bwd(const float* grad_out, int B, int P, float contact_scale, float r2r_scale,
+                               float* grad_small, float* grad_contact, float* grad_r2r, void* stream);
+
 /* ---- per-model constants -------------------------------------------------------------
  * Host tables in, device copies kept by the handle.  Segments follow
  * tuch/utils/segmentation.py:29-99: seg_q = segment_vidx lists; seg_faces = faces of the

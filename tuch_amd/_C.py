@@ -38,6 +38,9 @@ _SIGNATURES = {
     'tuch_contact_terms_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                        c_void_p, c_void_p]),
     'tuch_smplify_small_terms': (c_int, [c_void_p] * 9 + [c_int, c_int, c_int, c_float, c_float, c_float] + [c_void_p] * 5),
+    'tuch_smplify_objective': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p]),
+    'tuch_smplify_objective_bwd': (c_int, [c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p,
+                                           c_void_p]),
     'tuch_contact_model_create': (c_int, [POINTER(c_void_p), c_int, c_int, c_void_p, c_void_p,
                                           c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_int, c_void_p, c_void_p,

@@ -131,3 +131,60 @@ extern "C" int tuch_smplify_small_terms(const float* joints, const float* camera
                        grad_joints, grad_camera_t, grad_body_pose);
     return tuch_check_launch("tuch_smplify_small_terms");
 }
+
+// ---- SMPLify-DC objective assembly, tuch/smplify/losses.py:120-123 ---------------------------
+//   total = sum_b [ reprojection_b + prior_b + 10 * (interior_b + exterior_b) + clw * sum_p r2r[b,p] ]
+// one block, fixed-order tree reduction (deterministic).
+namespace {
+__global__ __launch_bounds__(256) void objective_kernel(
+    const float* __restrict__ small, const float* __restrict__ terms, const float* __restrict__ r2r,
+    int B, int P, float contact_scale, float r2r_scale, float* __restrict__ out)
+{
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < 2 * B; i += 256) acc += small[i] + contact_scale * terms[i];
+    if (r2r)
+        for (int i = threadIdx.x; i < B * P; i += 256) acc += r2r_scale * r2r[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+// gradients of the scalar w.r.t. its three inputs: constants times the upstream gradient
+__global__ __launch_bounds__(256) void objective_bwd_kernel(
+    const float* __restrict__ gout, int B, int P, float contact_scale, float r2r_scale,
+    float* __restrict__ g_small, float* __restrict__ g_terms, float* __restrict__ g_r2r)
+{
+    const float g = gout[0];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 2 * B) { g_small[i] = g; g_terms[i] = contact_scale * g; }
+    if (g_r2r && i < B * P) g_r2r[i] = r2r_scale * g;
+}
+}  // namespace
+
+extern "C" int tuch_smplify_objective(const float* small_terms, const float* contact_terms, const float* r2r,
+                                      int B, int P, float contact_scale, float r2r_scale, float* out,
+                                      void* stream)
+{
+    TUCH_REQUIRE(small_terms && contact_terms && out && B > 0 && P >= 0, "tuch_smplify_objective: bad arguments");
+    hipLaunchKernelGGL(objective_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, small_terms, contact_terms,
+                       (P > 0 ? r2r : (const float*)nullptr), B, P, contact_scale, r2r_scale, out);
+    return tuch_check_launch("tuch_smplify_objective");
+}
+
+extern "C" int tuch_smplify_objective_bwd(const float* grad_out, int B, int P, float contact_scale,
+                                          float r2r_scale, float* grad_small, float* grad_contact,
+                                          float* grad_r2r, void* stream)
+{
+    TUCH_REQUIRE(grad_out && grad_small && grad_contact && B > 0 && P >= 0,
+                 "tuch_smplify_objective_bwd: bad arguments");
+    const int n = (2 * B > B * P ? 2 * B : B * P);
+    hipLaunchKernelGGL(objective_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, grad_out,
+                       B, P, contact_scale, r2r_scale, grad_small, grad_contact,
+                       (P > 0 ? grad_r2r : (float*)nullptr));
+    return tuch_check_launch("tuch_smplify_objective_bwd");
+}

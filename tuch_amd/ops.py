@@ -197,6 +197,54 @@ def smplify_small_terms(joints, camera_t, body_pose, camera_center, joints_2d, j
                              precisions, log_weights, focal, sigma, prior_scale)
 
 
+class _Objective(torch.autograd.Function):
+    """sum(small) + contact_scale * sum(terms) + r2r_scale * sum(r2r) as one deterministic kernel."""
+
+    @staticmethod
+    def forward(ctx, small, terms, r2r, contact_scale, r2r_scale):
+        small, terms = small.contiguous(), terms.contiguous()
+        b = small.shape[0]
+        p = r2r.shape[1] if r2r is not None else 0
+        out = torch.empty(1, dtype=torch.float32, device=small.device)
+        _C.check(_C.lib().tuch_smplify_objective(_C.ptr(small), _C.ptr(terms),
+                                                 _C.ptr(r2r.contiguous() if p else None), b, p,
+                                                 float(contact_scale), float(r2r_scale), _C.ptr(out), _C.stream()))
+        ctx.shape = (b, p, float(contact_scale), float(r2r_scale))
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        b, p, cs, rs = ctx.shape
+        g = g.reshape(1).to(torch.float32).contiguous()
+        gs = torch.empty(b, 2, dtype=torch.float32, device=g.device)
+        gt = torch.empty(b, 2, dtype=torch.float32, device=g.device)
+        gr = torch.empty(b, p, dtype=torch.float32, device=g.device) if p else None
+        _C.check(_C.lib().tuch_smplify_objective_bwd(_C.ptr(g), b, p, cs, rs, _C.ptr(gs), _C.ptr(gt), _C.ptr(gr),
+                                                     _C.stream()))
+        return gs, gt, gr, None, None
+
+
+def smplify_objective(small, terms, r2r, contact_scale, r2r_scale):
+    return _Objective.apply(small, terms, r2r, contact_scale, r2r_scale)
+
+
+_DERIVED = {}
+
+
+def cached_derived(key_tensors, build):
+    """Small per-call tensors derived from caller inputs that do not change between iterations
+    (validity / selection masks): rebuilt only when an input was modified in place or replaced.  The
+    entry holds its source tensors, so their addresses cannot be reused while it is cached."""
+    key = tuple((t.data_ptr(), t._version, tuple(t.shape)) if t is not None else None for t in key_tensors)
+    hit = _DERIVED.get(key)
+    if hit is None:
+        while len(_DERIVED) >= 16:
+            _DERIVED.pop(next(iter(_DERIVED)))
+        hit = (build(), key_tensors)
+        _DERIVED[key] = hit
+    return hit[0]
+
+
 # ------------------------------------------------------------------------- model
 def _i32(a) -> np.ndarray:
     return np.ascontiguousarray(np.asarray(a), dtype=np.int32)

@@ -81,31 +81,31 @@ def contact_fitting_loss(body_pose, global_orient, body_pose_loop1, opt_global_o
     compatibility; the computation runs where ``verts`` lives.
     """
     from .prior import MaxMixturePrior
+    model = contact_model_for(geomask, face_tensor, segments, cdict, device=verts.device)
+    valid = ops.cached_derived((ignore_idxs,), lambda: (~ignore_idxs).to(torch.uint8).contiguous())
+    exterior = model.exterior_flags(verts, apply_segments=segments is not None)     # losses.py:79-89
+    _, partner = model.v2v_min(verts)                                               # losses.py:76-78,92-93
+    contact_loss, contact_terms = ops.contact_terms(verts, partner, exterior, valid, ops.MODE_SMPLIFY, euclthres)
+
+    r2r = None
+    if model.num_pairs > 0 and gt_contact is not None and gt_contact[0] is not None:
+        select = ops.cached_derived(
+            (gt_contact[0], has_discrete_contact, ignore_idxs),
+            lambda: ((gt_contact[0] == 1) & has_discrete_contact.bool()[:, None]
+                     & (~ignore_idxs)[:, None]).to(torch.uint8).contiguous())
+        r2r, _ = model.region_pair_min(verts, select=select, masked=True)           # losses.py:107-117
+
     fused = (isinstance(pose_prior, MaxMixturePrior) and pose_prior.use_merged and verts.is_cuda
              and not torch.is_tensor(focal_length) and body_pose.shape[1] == 69)
-    if fused:      # projection + gmof + GMM prior in one kernel (K8)
+    if fused:      # projection + gmof + GMM prior in one kernel (K8), objective assembled in one reduction
         small = ops.smplify_small_terms(model_joints, camera_t, body_pose, camera_center, joints_2d, joints_conf,
                                         pose_prior.means, pose_prior.precisions, pose_prior.log_nll_weights,
                                         focal_length, sigma, pose_prior_weight ** 2)
-        reprojection_sum, pose_prior_loss = small[:, 0], small[:, 1]
-    else:
-        reprojection_sum = _reprojection(model_joints, camera_t, camera_center, joints_2d, joints_conf,
-                                         focal_length, sigma).sum(dim=-1)
-        pose_prior_loss = (pose_prior_weight ** 2) * pose_prior(body_pose, betas)
-
-    model = contact_model_for(geomask, face_tensor, segments, cdict, device=verts.device)
-    valid = (~ignore_idxs).to(torch.uint8).contiguous()
-    exterior = model.exterior_flags(verts, apply_segments=segments is not None)     # losses.py:79-89
-    _, partner = model.v2v_min(verts)                                               # losses.py:76-78,92-93
-    contact_loss, _ = ops.contact_terms(verts, partner, exterior, valid, ops.MODE_SMPLIFY, euclthres)
-
-    if model.num_pairs > 0 and gt_contact is not None and gt_contact[0] is not None:
-        select = (gt_contact[0] == 1) & has_discrete_contact.bool()[:, None] & (~ignore_idxs)[:, None]
-        r2r, _ = model.region_pair_min(verts, select=select, masked=True)           # losses.py:107-117
-        r2r_loss = r2r.sum(dim=1)
-    else:
-        r2r_loss = torch.zeros_like(contact_loss)
-
+        return ops.smplify_objective(small, contact_terms, r2r, 10.0, contact_loss_weight)   # losses.py:120-123
+    reprojection_sum = _reprojection(model_joints, camera_t, camera_center, joints_2d, joints_conf,
+                                     focal_length, sigma).sum(dim=-1)
+    pose_prior_loss = (pose_prior_weight ** 2) * pose_prior(body_pose, betas)
+    r2r_loss = r2r.sum(dim=1) if r2r is not None else torch.zeros_like(contact_loss)
     total_loss = reprojection_sum + 10 * contact_loss \
         + pose_prior_loss + contact_loss_weight * r2r_loss
     return total_loss.sum()
