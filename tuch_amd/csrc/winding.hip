@@ -365,6 +365,8 @@ __global__ __launch_bounds__(kBlock) void gather_segment_triangles_kernel(
 // host-built table (segment, first list position); the segment's faces are split over grid.y
 // and reduced in fixed order by segment_finalize_kernel.  (List order comes from an atomic
 // counter and may vary between runs; every entry's result does not.)
+constexpr int kSegBlock = 64;     // one wave = 128 compacted queries per workgroup
+constexpr int kSegChunk = 128;    // triangles staged in LDS per pass
 constexpr int kSegSplits = 16;   // maximum; few (compacted) queries per segment: parallelism comes from the faces
 int seg_splits()
 {
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(kBlock) void segment_compact_kernel(
     list[(size_t)b * Qs_total + seg_q_off[s] + pos] = local;
 }
 
-__global__ __launch_bounds__(kStripBlock) void segment_winding_kernel(
+__global__ __launch_bounds__(kSegBlock) void segment_winding_kernel(
     const float* __restrict__ verts, const float* __restrict__ seg_tris,
     const int32_t* __restrict__ seg_blocks, const int32_t* __restrict__ seg_q_off,
     const int32_t* __restrict__ seg_q_vidx, const int32_t* __restrict__ seg_f_off,
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(kStripBlock) void segment_winding_kernel(
     if (k_start >= n) return;
     const int q_beg = seg_q_off[s];
     const int32_t* mine = list + (size_t)b * Qs_total + q_beg;
-    const int k0 = k_start + threadIdx.x, k1 = k0 + kStripBlock;
+    const int k0 = k_start + threadIdx.x, k1 = k0 + kSegBlock;
     const int v0 = seg_q_vidx[q_beg + mine[min(k0, n - 1)]], v1 = seg_q_vidx[q_beg + mine[min(k1, n - 1)]];
     const float* vb = verts + (size_t)b * V * 3;
     const v2f qx = {vb[3 * v0 + 0], vb[3 * v1 + 0]};
@@ -423,13 +425,13 @@ __global__ __launch_bounds__(kStripBlock) void segment_winding_kernel(
     // Few waves are alive here (compacted queries), so a per-triangle scalar load would expose its
     // full memory latency every iteration.  Stage the chunk's triangles in LDS with coalesced
     // vector loads (many in flight), then read them back as broadcasts.
-    __shared__ float sT[kStripBlock * 9];
+    __shared__ float sT[kSegChunk * 9];
     v2f acc = splat2(0.0f);
-    for (int chunk = f_beg; chunk < f_end; chunk += kStripBlock) {
-        const int cn = min(kStripBlock, f_end - chunk);
+    for (int chunk = f_beg; chunk < f_end; chunk += kSegChunk) {
+        const int cn = min(kSegChunk, f_end - chunk);
         const float* src = seg_tris + ((size_t)b * Fs_total + chunk) * 9;
         __syncthreads();
-        for (int i = threadIdx.x; i < cn * 9; i += kStripBlock) sT[i] = src[i];
+        for (int i = threadIdx.x; i < cn * 9; i += kSegBlock) sT[i] = src[i];
         __syncthreads();
         for (int f = 0; f < cn; ++f) {
             float tri[9];
@@ -648,7 +650,7 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
                            all ? (const uint8_t*)nullptr : (const uint8_t*)exterior, (const int32_t*)m->seg_of_q,
                            (const int32_t*)m->seg_q_off, (const int32_t*)m->seg_q_vidx, m->V, m->seg_q_total,
                            m->num_segments, seg_count, seg_list);
-        hipLaunchKernelGGL(segment_winding_kernel, dim3(B, seg_splits(), m->num_seg_blocks), dim3(kStripBlock),
+        hipLaunchKernelGGL(segment_winding_kernel, dim3(B, seg_splits(), m->num_seg_blocks), dim3(kSegBlock),
                            0, s, verts, (const float*)seg_tris, (const int32_t*)m->seg_blocks,
                            (const int32_t*)m->seg_q_off, (const int32_t*)m->seg_q_vidx,
                            (const int32_t*)m->seg_f_off, (const int32_t*)seg_count, (const int32_t*)seg_list,
