@@ -141,6 +141,24 @@ int tuch_contact_model_info(const tuch_contact_model* model, int* V, int* F, int
 int tuch_contact_model_strips(const tuch_contact_model* model, int* stream_len, int* num_strips,
                               int32_t* vidx_host, float* sign_host);
 
+/* Cluster tree over the faces of a closed mesh (host only, no device needed): the structure behind the
+ * hierarchical evaluation of winding_numbers (tuch/utils/contact.py:112-147) inside tuch_exterior_flags.
+ * A set of faces far from the query is replaced by a triangulation of its boundary loops, which subtends
+ * the same solid angle for every query outside the set's bounding box (exact in real arithmetic).
+ * nodes [num_nodes][8] = {cap_off, cap_len, exact_off, exact_len, skip, child0, child1, num_faces} in
+ * preorder; vidx / sign [stream_len] = strip stream as in tuch_contact_model_strips (leaf strips in
+ * [0, exact_len), then the caps); qperm [num_qblocks*128] = query order; frontier f =
+ * frontier_nodes[frontier_off[f] .. frontier_off[f+1]) = subtrees that together cover the mesh.
+ * tuch_contact_model_create builds the same tree internally.  Fails (TUCH_ERR_ARG) for a mesh that is
+ * not a closed, consistently oriented manifold; the library then keeps the flat evaluation. */
+typedef struct tuch_cluster_tree tuch_cluster_tree;
+int tuch_cluster_tree_build(int V, int F, const int32_t* faces, int leaf_faces, tuch_cluster_tree** out);
+void tuch_cluster_tree_free(tuch_cluster_tree* tree);
+int tuch_cluster_tree_info(const tuch_cluster_tree* tree, int* num_nodes, int* exact_len, int* stream_len,
+                           int* num_qblocks, int* num_frontiers, int* frontier_total);
+int tuch_cluster_tree_export(const tuch_cluster_tree* tree, int32_t* nodes, int32_t* vidx, float* sign,
+                             int32_t* qperm, int32_t* frontier_off, int32_t* frontier_nodes);
+
 /* exterior flags of losses.py:79-89 / loss.py:259-266: winding_numbers(verts, verts[faces]).le(thresh),
  * then BatchBodySegment.batch_has_self_isec (segmentation.py:117-124) and the re-marking of
  * vertices interior to their own segment.  verts [B,V,3] -> exterior [B,V] bytes;

@@ -2,6 +2,24 @@
 // segment and region tables).  Created once, read-only in the hot calls.
 #pragma once
 #include "common.h"
+#include <vector>
+
+// Cluster tree over the faces (cluster_tree.hip): host form.  nodes[i] = {cap_off, cap_len, exact_off,
+// exact_len (0 for inner nodes), skip, child0, child1, num_faces}, preorder numbering; offsets index
+// the stream (vidx, sign): leaf strips first ([0, exact_len)), then the boundary caps of all nodes.
+struct tuch_cluster_tree {
+    int V = 0, F = 0, num_nodes = 0, exact_len = 0, stream_len = 0, num_qblocks = 0, num_heights = 0;
+    std::vector<int32_t> nodes;
+    std::vector<int32_t> vidx;
+    std::vector<float> sign;
+    std::vector<int32_t> qperm;                       // [num_qblocks * 128] vertex ids, surface-coherent
+    std::vector<int32_t> height_off, height_nodes;    // nodes grouped by height (0 = leaves)
+    std::vector<int32_t> frontier_off, frontier_nodes;
+};
+
+bool tuch_cluster_tree_build_impl(int V, int F, const int32_t* faces, int leaf_faces, tuch_cluster_tree& t);
+void tuch_build_strips(const int32_t* faces, int F, std::vector<int32_t>& vidx, std::vector<float>& sign,
+                       int* num_strips);
 
 struct tuch_contact_model {
     int device;
@@ -14,6 +32,17 @@ struct tuch_contact_model {
     int strip_len, num_strips;
     int32_t* strip_vidx;       // [strip_len]
     float* strip_sign;         // [strip_len]
+    // cluster tree for the hierarchical winding numbers (device copies; tree_nodes == 0: not available)
+    int tree_nodes, tree_stream_len, tree_qblocks, tree_heights;
+    int32_t* tree_node;        // [tree_nodes][8]
+    int32_t* tree_vidx;        // [tree_stream_len]
+    float* tree_sign;
+    int32_t* tree_qperm;       // [tree_qblocks*128]
+    int32_t* tree_height_off;  // [tree_heights+1]
+    int32_t* tree_height_nodes;
+    int32_t* tree_frontier_nodes;
+    int tree_num_frontiers;
+    int* tree_frontier_off_host;   // [tree_num_frontiers+1]
     // segments (tuch/utils/segmentation.py): CSR over segments
     int num_segments, num_caps, seg_q_total, seg_f_total;
     int32_t* seg_q_off;        // [S+1] into seg_q_vidx

@@ -34,86 +34,17 @@ int* host_copy(const int32_t* src, size_t n)
     return p;
 }
 
-// Greedy triangle strips.  Every face appears exactly once as an emitted element; the sign
-// says whether (stream[p-2], stream[p-1], stream[p]) is an even permutation of the face.
-void build_strips(const int32_t* faces, int F, std::vector<int32_t>& vidx, std::vector<float>& sign,
-                  int* num_strips)
-{
-    std::unordered_map<uint64_t, int> edge_face;      // directed edge (a -> b) -> face
-    edge_face.reserve((size_t)F * 3 * 2);
-    auto key = [](int a, int b) { return ((uint64_t)(uint32_t)a << 32) | (uint32_t)b; };
-    for (int f = 0; f < F; ++f)
-        for (int k = 0; k < 3; ++k) edge_face[key(faces[3 * f + k], faces[3 * f + (k + 1) % 3])] = f;
-    std::vector<char> used(F, 0);
-    auto third = [&](int f, int a, int b) {            // vertex of face f that is neither a nor b
-        for (int k = 0; k < 3; ++k) {
-            const int v = faces[3 * f + k];
-            if (v != a && v != b) return v;
-        }
-        return -1;
-    };
-    // walk a strip from face f starting with rotation r; returns its vertex sequence
-    auto walk = [&](int f, int r, std::vector<int>& seq, std::vector<int>& fseq, std::vector<char>& mark) {
-        seq.clear(); fseq.clear();
-        seq.push_back(faces[3 * f + r]); seq.push_back(faces[3 * f + (r + 1) % 3]);
-        seq.push_back(faces[3 * f + (r + 2) % 3]);
-        fseq.push_back(f);
-        mark[f] = 1;
-        for (;;) {
-            const int n = (int)seq.size();
-            const int y = seq[n - 2], z = seq[n - 1];
-            // triangle index i = n-3 (0-based); its face holds directed edge y->z when i is even
-            // and z->y when odd; the neighbour across holds the opposite directed edge
-            const bool even = ((n - 3) % 2) == 0;
-            auto it = even ? edge_face.find(key(z, y)) : edge_face.find(key(y, z));
-            if (it == edge_face.end()) break;
-            const int nf = it->second;
-            if (used[nf] || mark[nf]) break;
-            const int d = third(nf, y, z);
-            if (d < 0) break;
-            seq.push_back(d);
-            fseq.push_back(nf);
-            mark[nf] = 1;
-        }
-        for (int ff : fseq) mark[ff] = 0;
-    };
-    std::vector<char> mark(F, 0);
-    std::vector<int> seq, fseq, best_seq, best_f;
-    *num_strips = 0;
-    for (int f = 0; f < F; ++f) {
-        if (used[f]) continue;
-        best_seq.clear();
-        for (int r = 0; r < 3; ++r) {
-            walk(f, r, seq, fseq, mark);
-            if (seq.size() > best_seq.size()) { best_seq = seq; best_f = fseq; }
-        }
-        for (size_t i = 0; i < best_seq.size(); ++i) {
-            vidx.push_back(best_seq[i]);
-            if (i < 2) { sign.push_back(0.0f); continue; }
-            const int ff = best_f[i - 2];
-            used[ff] = 1;
-            // parity of (s[i-2], s[i-1], s[i]) relative to the face's own order
-            const int a = best_seq[i - 2], b = best_seq[i - 1];
-            int ia = -1, ib = -1;
-            for (int k = 0; k < 3; ++k) {
-                if (faces[3 * ff + k] == a) ia = k;
-                if (faces[3 * ff + k] == b) ib = k;
-            }
-            sign.push_back(((ia + 1) % 3 == ib) ? 1.0f : -1.0f);
-        }
-        ++*num_strips;
-    }
-}
-
 }  // namespace
 
 extern "C" void tuch_contact_model_destroy(tuch_contact_model* m)
 {
     if (!m) return;
-    void* dev[] = {m->faces, m->mask_bits, m->strip_vidx, m->strip_sign, m->seg_blocks, m->seg_of_q, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces,
+    void* dev[] = {m->faces, m->mask_bits, m->strip_vidx, m->strip_sign, m->tree_node, m->tree_vidx, m->tree_sign, m->tree_qperm,
+                   m->tree_height_off, m->tree_height_nodes, m->tree_frontier_nodes, m->seg_blocks, m->seg_of_q, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces,
                    m->cap_off, m->cap_vidx, m->region_off, m->region_vidx, m->pairs, m->pair_mask, m->pair_mask_off};
     for (void* p : dev)
         if (p) (void)hipFree(p);
+    free(m->tree_frontier_off_host);
     free(m->seg_q_off_host);
     free(m->seg_f_off_host);
     free(m->region_off_host);
@@ -148,10 +79,31 @@ extern "C" int tuch_contact_model_create(
     if (rc == TUCH_OK) {
         std::vector<int32_t> sv;
         std::vector<float> ss;
-        build_strips(faces, F, sv, ss, &m->num_strips);
+        tuch_build_strips(faces, F, sv, ss, &m->num_strips);
         m->strip_len = (int)sv.size();
         rc = upload(&m->strip_vidx, sv.data(), sv.size());
         if (rc == TUCH_OK) rc = upload(&m->strip_sign, ss.data(), ss.size());
+    }
+    if (rc == TUCH_OK) {
+        // cluster tree for the hierarchical winding numbers; a mesh that is not a closed manifold (or
+        // has too many clusters for the LDS-resident boxes) simply keeps the flat strip path
+        tuch_cluster_tree t;
+        const char* e = getenv("TUCH_TREE_LEAF_FACES");
+        if (tuch_cluster_tree_build_impl(V, F, faces, e ? atoi(e) : 64, t) && t.num_nodes <= 2000) {
+            m->tree_nodes = t.num_nodes;
+            m->tree_stream_len = t.stream_len;
+            m->tree_qblocks = t.num_qblocks;
+            m->tree_heights = t.num_heights;
+            m->tree_num_frontiers = (int)t.frontier_off.size() - 1;
+            m->tree_frontier_off_host = host_copy(t.frontier_off.data(), t.frontier_off.size());
+            rc = upload(&m->tree_node, t.nodes.data(), t.nodes.size());
+            if (rc == TUCH_OK) rc = upload(&m->tree_vidx, t.vidx.data(), t.vidx.size());
+            if (rc == TUCH_OK) rc = upload(&m->tree_sign, t.sign.data(), t.sign.size());
+            if (rc == TUCH_OK) rc = upload(&m->tree_qperm, t.qperm.data(), t.qperm.size());
+            if (rc == TUCH_OK) rc = upload(&m->tree_height_off, t.height_off.data(), t.height_off.size());
+            if (rc == TUCH_OK) rc = upload(&m->tree_height_nodes, t.height_nodes.data(), t.height_nodes.size());
+            if (rc == TUCH_OK) rc = upload(&m->tree_frontier_nodes, t.frontier_nodes.data(), t.frontier_nodes.size());
+        }
     }
     if (rc == TUCH_OK && geomask) {
         // bit-pack on the host: bits[w][j], bit k = geomask[j][64 w + k]

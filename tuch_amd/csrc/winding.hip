@@ -318,6 +318,131 @@ __global__ __launch_bounds__(kStripBlock) void winding_strip_kernel(
     if (q1 < Q) out[q1] = acc[1];
 }
 
+// ---- hierarchical form (cluster_tree.hip) ------------------------------------------------------
+// Posed bounding boxes of all tree nodes of one body: leaves from their strip elements, inner
+// nodes bottom-up from their children.  One workgroup per body, boxes kept in LDS.
+struct TreeNode { int cap_off, cap_len, ex_off, ex_len, skip, c0, c1, nfaces; };
+constexpr int kBoundsBlock = 256;
+constexpr int kTreeQueries = 128;          // one wavefront, two queries per lane
+
+__global__ __launch_bounds__(kBoundsBlock) void tree_bounds_kernel(
+    const StreamElem* __restrict__ stream, int T, const TreeNode* __restrict__ nodes, int N,
+    const int32_t* __restrict__ height_off, const int32_t* __restrict__ height_nodes, int num_heights,
+    float* __restrict__ bounds)                  // [B,N,8] = (min xyz, -, max xyz, -)
+{
+    extern __shared__ float sb[];
+    const int b = blockIdx.x;
+    const StreamElem* st = stream + (size_t)b * T;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = height_off[0] + wave; i < height_off[1]; i += kBoundsBlock / 64) {
+        const int node = height_nodes[i];
+        const int off = nodes[node].ex_off, len = nodes[node].ex_len;
+        float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        for (int p = lane; p < len; p += 64) {
+            const StreamElem e = st[off + p];
+            lo[0] = fminf(lo[0], e.x); lo[1] = fminf(lo[1], e.y); lo[2] = fminf(lo[2], e.z);
+            hi[0] = fmaxf(hi[0], e.x); hi[1] = fmaxf(hi[1], e.y); hi[2] = fmaxf(hi[2], e.z);
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = fminf(lo[k], __shfl_xor(lo[k], m));
+                hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m));
+            }
+        if (lane == 0) {
+            float* o = sb + node * 8;
+            o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = 0.0f;
+            o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = 0.0f;
+        }
+    }
+    __syncthreads();
+    for (int h = 1; h < num_heights; ++h) {
+        for (int i = height_off[h] + threadIdx.x; i < height_off[h + 1]; i += kBoundsBlock) {
+            const int node = height_nodes[i];
+            const float* a = sb + nodes[node].c0 * 8;
+            const float* c = sb + nodes[node].c1 * 8;
+            float* o = sb + node * 8;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                o[k] = fminf(a[k], c[k]);
+                o[4 + k] = fmaxf(a[4 + k], c[4 + k]);
+            }
+            o[3] = o[7] = 0.0f;
+        }
+        __syncthreads();
+    }
+    float* out = bounds + (size_t)b * N * 8;
+    for (int i = threadIdx.x; i < N * 8; i += kBoundsBlock) out[i] = sb[i];
+}
+
+// one run of the strip loop over stream elements [off, off+len), len % 3 == 0; the stream has
+// three readable elements past its end for the prefetch
+__device__ __forceinline__ void run_stream(const StreamElem* __restrict__ st, int off, int len, Slot (&s)[3],
+                                           v2f (&d)[3], v2f qx, v2f qy, v2f qz, v2f& acc)
+{
+    const StreamElem* p = st + off;
+    const StreamElem* end = p + len;
+    StreamElem n0 = p[0], n1 = p[1], n2 = p[2];
+    for (; p < end; p += 3) {
+        const StreamElem e0 = n0, e1 = n1, e2 = n2;
+        n0 = p[3]; n1 = p[4]; n2 = p[5];
+        strip_step<0>(e0, true, s, d, qx, qy, qz, acc);
+        strip_step<1>(e1, true, s, d, qx, qy, qz, acc);
+        strip_step<2>(e2, true, s, d, qx, qy, qz, acc);
+    }
+}
+
+// Winding numbers of the model's own vertices by walking the cluster tree: a node whose posed box
+// contains none of the wavefront's 128 queries contributes through its boundary cap (exactly the
+// same solid angle), a leaf that does is summed face by face, an inner node that does is descended.
+// All decisions are wave-uniform.  grid (B, subtrees of the frontier, query blocks).
+__global__ __launch_bounds__(64) void winding_tree_kernel(
+    const float* __restrict__ verts,             // [B,V,3]
+    const StreamElem* __restrict__ stream,       // [B,T]
+    const TreeNode* __restrict__ nodes, const float* __restrict__ bounds, int N,
+    const int32_t* __restrict__ frontier, const int32_t* __restrict__ qperm,
+    int V, int T, float* __restrict__ partial)   // [B,S,V]
+{
+    const int b = blockIdx.x, sub = blockIdx.y, nsub = gridDim.y;
+    const int i0 = qperm[blockIdx.z * kTreeQueries + threadIdx.x];
+    const int i1 = qperm[blockIdx.z * kTreeQueries + 64 + threadIdx.x];
+    const float* pts = verts + (size_t)b * V * 3;
+    const v2f qx = {pts[3 * i0 + 0], pts[3 * i1 + 0]};
+    const v2f qy = {pts[3 * i0 + 1], pts[3 * i1 + 1]};
+    const v2f qz = {pts[3 * i0 + 2], pts[3 * i1 + 2]};
+    const StreamElem* st = stream + (size_t)b * T;
+    const float* bb = bounds + (size_t)b * N * 8;
+    Slot s[3];
+    v2f d[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        s[k].x = s[k].y = s[k].z = s[k].n = splat2(0.0f);
+        d[k] = splat2(0.0f);
+    }
+    v2f acc = splat2(0.0f);
+    int node = __builtin_amdgcn_readfirstlane(frontier[sub]);
+    const int end = __builtin_amdgcn_readfirstlane(nodes[node].skip);
+    while (node < end) {
+        const TreeNode nd = nodes[node];
+        const float* box = bb + (size_t)node * 8;
+        const float lx = box[0], ly = box[1], lz = box[2], hx = box[4], hy = box[5], hz = box[6];
+        const bool in0 = qx[0] >= lx && qx[0] <= hx && qy[0] >= ly && qy[0] <= hy && qz[0] >= lz && qz[0] <= hz;
+        const bool in1 = qx[1] >= lx && qx[1] <= hx && qy[1] >= ly && qy[1] <= hy && qz[1] >= lz && qz[1] <= hz;
+        const bool near = __builtin_amdgcn_ballot_w64(in0 || in1) != 0;
+        if (near && nd.ex_len == 0) {
+            node = node + 1;
+        } else {
+            run_stream(st, near ? nd.ex_off : nd.cap_off, near ? nd.ex_len : nd.cap_len, s, d, qx, qy, qz, acc);
+            node = nd.skip;
+        }
+        node = __builtin_amdgcn_readfirstlane(node);
+    }
+    float* out = partial + ((size_t)b * nsub + sub) * V;
+    out[i0] = acc[0];
+    out[i1] = acc[1];
+}
+
 // ---- body segments (tuch/utils/segmentation.py) ---------------------------------
 // cap vertex of band c = mean of the band's boundary-loop vertices (segmentation.py:74-76)
 __global__ __launch_bounds__(64) void cap_centroid_kernel(
@@ -496,9 +621,30 @@ int choose_strip_splits(int B, int Q, int L)
 }
 
 struct ExteriorLayout {
-    size_t tris, partial, caps, seg_tris, seg_partial, seg_count, seg_list, total;
+    size_t tris, partial, bounds, caps, seg_tris, seg_partial, seg_count, seg_list, total;
     int lpad;
+    int tree_frontier;         // frontier used by the hierarchical path (-1: flat path)
+    int tree_subs;
 };
+
+// TUCH_WINDING_TREE=0 keeps the flat strip walk (A/B measurements); read per call
+bool use_tree(const tuch_contact_model* m)
+{
+    if (m->tree_nodes <= 0) return false;
+    const char* e = getenv("TUCH_WINDING_TREE");
+    return !e || atoi(e) != 0;
+}
+
+// smallest frontier (set of subtrees, one workgroup column each) that yields enough wavefronts to
+// balance the uneven subtree costs over 256 CUs
+int choose_frontier(const tuch_contact_model* m, int B)
+{
+    static const long target = [] { const char* e = getenv("TUCH_TREE_WAVES"); return e ? atol(e) : 32768L; }();
+    int f = 0;
+    while (f + 1 < m->tree_num_frontiers &&
+           (long)B * m->tree_qblocks * (m->tree_frontier_off_host[f + 1] - m->tree_frontier_off_host[f]) < target) ++f;
+    return f;
+}
 
 inline int strip_lpad(int L) { return ceil_div(L, 3) * 3 + 6; }
 
@@ -511,11 +657,21 @@ ExteriorLayout exterior_layout(const tuch_contact_model* m, int B)
     l.lpad = strip_lpad(m->strip_len);
     // triangle buffer or strip stream, whichever is larger (both forms are supported)
     const size_t tri_bytes = (size_t)B * m->F * 9 * sizeof(float);
-    const size_t strip_bytes = (size_t)B * l.lpad * sizeof(StreamElem);
+    size_t strip_bytes = (size_t)B * l.lpad * sizeof(StreamElem);
+    int max_splits = choose_splits(B, m->V, m->F) > choose_strip_splits(B, m->V, strip_lpad(m->strip_len))
+                         ? choose_splits(B, m->V, m->F) : choose_strip_splits(B, m->V, strip_lpad(m->strip_len));
+    l.tree_frontier = -1;
+    l.tree_subs = 0;
+    if (m->tree_nodes > 0) {       // sized for both paths: the switch is read per call
+        l.tree_frontier = choose_frontier(m, B);
+        l.tree_subs = m->tree_frontier_off_host[l.tree_frontier + 1] - m->tree_frontier_off_host[l.tree_frontier];
+        const size_t tree_bytes = (size_t)B * (m->tree_stream_len + 3) * sizeof(StreamElem);
+        if (tree_bytes > strip_bytes) strip_bytes = tree_bytes;
+        if (l.tree_subs > max_splits) max_splits = l.tree_subs;
+    }
     l.tris = o;     o += align256(tri_bytes > strip_bytes ? tri_bytes : strip_bytes);
-    const int max_splits = choose_splits(B, m->V, m->F) > choose_strip_splits(B, m->V, strip_lpad(m->strip_len))
-                               ? choose_splits(B, m->V, m->F) : choose_strip_splits(B, m->V, strip_lpad(m->strip_len));
     l.partial = o;  o += align256((size_t)B * max_splits * m->V * sizeof(float));
+    l.bounds = o;   o += align256((size_t)B * (m->tree_nodes > 0 ? m->tree_nodes : 1) * 8 * sizeof(float));
     l.caps = o;     o += align256((size_t)B * (m->num_caps > 0 ? m->num_caps : 1) * 3 * sizeof(float));
     l.seg_tris = o; o += align256(((size_t)B * (m->seg_f_total > 0 ? m->seg_f_total : 1) + 1) * 9 * sizeof(float));
     l.seg_partial = o; o += align256((size_t)B * kSegSplits * (m->seg_q_total > 0 ? m->seg_q_total : 1) * sizeof(float));
@@ -610,7 +766,23 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
     float* tris = (float*)(ws + l.tris);
     hipStream_t s = (hipStream_t)stream;
     int rc = TUCH_OK;
-    if (use_strips() && m->strip_len > 0) {
+    if (use_strips() && use_tree(m)) {
+        StreamElem* st = (StreamElem*)tris;
+        const int T = m->tree_stream_len + 3;
+        float* bounds = (float*)(ws + l.bounds);
+        hipLaunchKernelGGL(gather_stream_kernel, dim3(ceil_div(T, kBlock), B), dim3(kBlock), 0, s, verts,
+                           (const int32_t*)m->tree_vidx, (const float*)m->tree_sign, m->V, m->tree_stream_len, T, st);
+        hipLaunchKernelGGL(tree_bounds_kernel, dim3(B), dim3(kBoundsBlock), (size_t)m->tree_nodes * 8 * sizeof(float), s,
+                           (const StreamElem*)st, T, (const TreeNode*)m->tree_node, m->tree_nodes,
+                           (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, m->tree_heights,
+                           bounds);
+        hipLaunchKernelGGL(winding_tree_kernel, dim3(B, l.tree_subs, m->tree_qblocks), dim3(64), 0, s, verts,
+                           (const StreamElem*)st, (const TreeNode*)m->tree_node, (const float*)bounds, m->tree_nodes,
+                           (const int32_t*)m->tree_frontier_nodes + m->tree_frontier_off_host[l.tree_frontier],
+                           (const int32_t*)m->tree_qperm, m->V, T, (float*)(ws + l.partial));
+        hipLaunchKernelGGL(winding_finalize_kernel, dim3(ceil_div(m->V, kBlock), B), dim3(kBlock), 0, s,
+                           (const float*)(ws + l.partial), m->V, l.tree_subs, thresh, w, exterior);
+    } else if (use_strips() && m->strip_len > 0) {
         StreamElem* st = (StreamElem*)tris;
         hipLaunchKernelGGL(gather_stream_kernel, dim3(ceil_div(l.lpad, kBlock), B), dim3(kBlock), 0, s, verts,
                            (const int32_t*)m->strip_vidx, (const float*)m->strip_sign, m->V, m->strip_len,
@@ -626,7 +798,7 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
         hipLaunchKernelGGL(gather_triangles_kernel, dim3(ceil_div(m->F * 3, kBlock), B), dim3(kBlock), 0, s,
                            verts, (const int32_t*)m->faces, m->V, m->F, tris);
         rc = tuch_winding_numbers(verts, tris, B, m->V, m->F, w, exterior, thresh, ws + l.partial,
-                                  l.caps - l.partial, stream);
+                                  l.bounds - l.partial, stream);
         if (rc != TUCH_OK) return rc;
     }
     if (apply_segments && m->num_segments > 0) {

@@ -264,6 +264,30 @@ def segment_faces(body_faces: np.ndarray, vidx: np.ndarray, bands: Sequence[np.n
     return np.concatenate([body_faces[inside]] + fans, 0) if fans else body_faces[inside]
 
 
+def cluster_tree(faces, num_verts: int, leaf_faces: int = 64) -> dict:
+    """The face-cluster tree used by the hierarchical winding numbers (host only; see include/tuch_amd.h,
+    tuch_cluster_tree_build).  Returns numpy arrays: nodes [N,8], vidx, sign, qperm, frontier_off,
+    frontier_nodes, plus exact_len."""
+    L = _C.lib()
+    f = np.ascontiguousarray(np.asarray(faces).reshape(-1, 3), dtype=np.int32)
+    h = ctypes.c_void_p()
+    _C.check(L.tuch_cluster_tree_build(int(num_verts), f.shape[0], f.ctypes.data_as(ctypes.c_void_p), int(leaf_faces),
+                                       ctypes.byref(h)))
+    try:
+        vals = [ctypes.c_int(0) for _ in range(6)]
+        _C.check(L.tuch_cluster_tree_info(h, *[ctypes.byref(v) for v in vals]))
+        n, exact_len, stream_len, qblocks, nfr, frtot = [v.value for v in vals]
+        out = dict(nodes=np.zeros((n, 8), np.int32), vidx=np.zeros(stream_len, np.int32),
+                   sign=np.zeros(stream_len, np.float32), qperm=np.zeros(qblocks * 128, np.int32),
+                   frontier_off=np.zeros(nfr + 1, np.int32), frontier_nodes=np.zeros(frtot, np.int32))
+        _C.check(L.tuch_cluster_tree_export(h, *[out[k].ctypes.data_as(ctypes.c_void_p) for k in
+                                                 ('nodes', 'vidx', 'sign', 'qperm', 'frontier_off', 'frontier_nodes')]))
+        out['exact_len'] = exact_len
+        return out
+    finally:
+        L.tuch_cluster_tree_free(h)
+
+
 class ContactModel:
     """Device-side constants of one body model; wraps tuch_contact_model.
 
