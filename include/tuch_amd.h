@@ -148,7 +148,9 @@ int tuch_contact_model_strips(const tuch_contact_model* model, int* stream_len, 
  * nodes [num_nodes][8] = {cap_off, cap_len, exact_off, exact_len, skip, child0, child1, num_faces} in
  * preorder; vidx / sign [stream_len] = strip stream as in tuch_contact_model_strips (leaf strips in
  * [0, exact_len), then the caps); qperm [num_qblocks*128] = query order; frontier f =
- * frontier_nodes[frontier_off[f] .. frontier_off[f+1]) = subtrees that together cover the mesh.
+ * frontier_nodes[frontier_off[f] .. frontier_off[f+1]) = subtrees that together cover the mesh;
+ * launch_order [frontier_total * num_qblocks] = per frontier (at frontier_off[f] * num_qblocks) the
+ * (subtree index << 16 | query block) pairs, the long-running ones first.
  * tuch_contact_model_create builds the same tree internally.  Fails (TUCH_ERR_ARG) for a mesh that is
  * not a closed, consistently oriented manifold; the library then keeps the flat evaluation. */
 typedef struct tuch_cluster_tree tuch_cluster_tree;
@@ -157,7 +159,8 @@ void tuch_cluster_tree_free(tuch_cluster_tree* tree);
 int tuch_cluster_tree_info(const tuch_cluster_tree* tree, int* num_nodes, int* exact_len, int* stream_len,
                            int* num_qblocks, int* num_frontiers, int* frontier_total);
 int tuch_cluster_tree_export(const tuch_cluster_tree* tree, int32_t* nodes, int32_t* vidx, float* sign,
-                             int32_t* qperm, int32_t* frontier_off, int32_t* frontier_nodes);
+                             int32_t* qperm, int32_t* frontier_off, int32_t* frontier_nodes,
+                             int32_t* launch_order);
 
 /* exterior flags of losses.py:79-89 / loss.py:259-266: winding_numbers(verts, verts[faces]).le(thresh),
  * then BatchBodySegment.batch_has_self_isec (segmentation.py:117-124) and the re-marking of

@@ -430,9 +430,10 @@ bool tuch_cluster_tree_build_impl(int V, int F, const int32_t* faces, int leaf_f
     }
 
     // ---- query order
-    std::vector<int> vkey(V, 1 << 30);
+    std::vector<int> vkey(V, 1 << 30), seq_node(nleaves_seen, 0);
     for (int i = 0; i < N; ++i) {
         if (leaf_seq[i] < 0) continue;
+        seq_node[leaf_seq[i]] = i;
         for (int f : groups[order[i]].faces)
             for (int k = 0; k < 3; ++k) vkey[faces[3 * f + k]] = std::min(vkey[faces[3 * f + k]], leaf_seq[i]);
     }
@@ -458,6 +459,24 @@ bool tuch_cluster_tree_build_impl(int V, int F, const int32_t* faces, int leaf_f
             fr.push_back(t.nodes[(size_t)n * 8 + 6]);
         }
         std::sort(fr.begin(), fr.end());
+        // launch order of the (subtree, query block) pairs: pairs whose queries live inside the subtree
+        // walk it down to the leaves (long-running) and go first, far pairs (one cap) fill the tail
+        std::vector<std::pair<long, int32_t>> cost;
+        for (size_t si = 0; si < fr.size(); ++si) {
+            const int lo = fr[si], hi = t.nodes[(size_t)fr[si] * 8 + 4];
+            for (int qb = 0; qb < t.num_qblocks; ++qb) {
+                long home = 0;
+                for (int k = 0; k < 128; ++k) {
+                    const int ln = seq_node[vkey[t.qperm[(size_t)qb * 128 + k]]];
+                    home += (ln >= lo && ln < hi);
+                }
+                cost.emplace_back(-(home * 100000L + t.nodes[(size_t)fr[si] * 8 + 7]), (int32_t)((si << 16) | qb));
+            }
+        }
+        std::stable_sort(cost.begin(), cost.end(), [](const std::pair<long, int32_t>& a, const std::pair<long, int32_t>& b) {
+            return a.first < b.first;
+        });
+        for (auto& c : cost) t.launch_order.push_back(c.second);
         t.frontier_nodes.insert(t.frontier_nodes.end(), fr.begin(), fr.end());
         t.frontier_off.push_back((int)t.frontier_nodes.size());
     }
@@ -495,7 +514,8 @@ extern "C" int tuch_cluster_tree_info(const tuch_cluster_tree* t, int* num_nodes
 }
 
 extern "C" int tuch_cluster_tree_export(const tuch_cluster_tree* t, int32_t* nodes, int32_t* vidx, float* sign,
-                                        int32_t* qperm, int32_t* frontier_off, int32_t* frontier_nodes)
+                                        int32_t* qperm, int32_t* frontier_off, int32_t* frontier_nodes,
+                                        int32_t* launch_order)
 {
     TUCH_REQUIRE(t, "tuch_cluster_tree_export: null tree");
     if (nodes) memcpy(nodes, t->nodes.data(), t->nodes.size() * sizeof(int32_t));
@@ -504,5 +524,6 @@ extern "C" int tuch_cluster_tree_export(const tuch_cluster_tree* t, int32_t* nod
     if (qperm) memcpy(qperm, t->qperm.data(), t->qperm.size() * sizeof(int32_t));
     if (frontier_off) memcpy(frontier_off, t->frontier_off.data(), t->frontier_off.size() * sizeof(int32_t));
     if (frontier_nodes) memcpy(frontier_nodes, t->frontier_nodes.data(), t->frontier_nodes.size() * sizeof(int32_t));
+    if (launch_order) memcpy(launch_order, t->launch_order.data(), t->launch_order.size() * sizeof(int32_t));
     return TUCH_OK;
 }

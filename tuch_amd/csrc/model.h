@@ -15,6 +15,8 @@ struct tuch_cluster_tree {
     std::vector<int32_t> qperm;                       // [num_qblocks * 128] vertex ids, surface-coherent
     std::vector<int32_t> height_off, height_nodes;    // nodes grouped by height (0 = leaves)
     std::vector<int32_t> frontier_off, frontier_nodes;
+    // per frontier f, at frontier_off[f] * num_qblocks: (subtree index << 16 | query block), heavy first
+    std::vector<int32_t> launch_order;
 };
 
 bool tuch_cluster_tree_build_impl(int V, int F, const int32_t* faces, int leaf_faces, tuch_cluster_tree& t);
@@ -33,7 +35,7 @@ struct tuch_contact_model {
     int32_t* strip_vidx;       // [strip_len]
     float* strip_sign;         // [strip_len]
     // cluster tree for the hierarchical winding numbers (device copies; tree_nodes == 0: not available)
-    int tree_nodes, tree_stream_len, tree_qblocks, tree_heights;
+    int tree_nodes, tree_stream_len, tree_qblocks, tree_heights, tree_leaves;
     int32_t* tree_node;        // [tree_nodes][8]
     int32_t* tree_vidx;        // [tree_stream_len]
     float* tree_sign;
@@ -41,6 +43,7 @@ struct tuch_contact_model {
     int32_t* tree_height_off;  // [tree_heights+1]
     int32_t* tree_height_nodes;
     int32_t* tree_frontier_nodes;
+    int32_t* tree_launch_order;
     int tree_num_frontiers;
     int* tree_frontier_off_host;   // [tree_num_frontiers+1]
     // segments (tuch/utils/segmentation.py): CSR over segments

@@ -40,7 +40,7 @@ extern "C" void tuch_contact_model_destroy(tuch_contact_model* m)
 {
     if (!m) return;
     void* dev[] = {m->faces, m->mask_bits, m->strip_vidx, m->strip_sign, m->tree_node, m->tree_vidx, m->tree_sign, m->tree_qperm,
-                   m->tree_height_off, m->tree_height_nodes, m->tree_frontier_nodes, m->seg_blocks, m->seg_of_q, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces,
+                   m->tree_height_off, m->tree_height_nodes, m->tree_frontier_nodes, m->tree_launch_order, m->seg_blocks, m->seg_of_q, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces,
                    m->cap_off, m->cap_vidx, m->region_off, m->region_vidx, m->pairs, m->pair_mask, m->pair_mask_off};
     for (void* p : dev)
         if (p) (void)hipFree(p);
@@ -94,6 +94,7 @@ extern "C" int tuch_contact_model_create(
             m->tree_stream_len = t.stream_len;
             m->tree_qblocks = t.num_qblocks;
             m->tree_heights = t.num_heights;
+            m->tree_leaves = t.height_off[1];
             m->tree_num_frontiers = (int)t.frontier_off.size() - 1;
             m->tree_frontier_off_host = host_copy(t.frontier_off.data(), t.frontier_off.size());
             rc = upload(&m->tree_node, t.nodes.data(), t.nodes.size());
@@ -103,6 +104,7 @@ extern "C" int tuch_contact_model_create(
             if (rc == TUCH_OK) rc = upload(&m->tree_height_off, t.height_off.data(), t.height_off.size());
             if (rc == TUCH_OK) rc = upload(&m->tree_height_nodes, t.height_nodes.data(), t.height_nodes.size());
             if (rc == TUCH_OK) rc = upload(&m->tree_frontier_nodes, t.frontier_nodes.data(), t.frontier_nodes.size());
+            if (rc == TUCH_OK) rc = upload(&m->tree_launch_order, t.launch_order.data(), t.launch_order.size());
         }
     }
     if (rc == TUCH_OK && geomask) {

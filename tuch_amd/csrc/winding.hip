@@ -325,36 +325,48 @@ struct TreeNode { int cap_off, cap_len, ex_off, ex_len, skip, c0, c1, nfaces; };
 constexpr int kBoundsBlock = 256;
 constexpr int kTreeQueries = 128;          // one wavefront, two queries per lane
 
-__global__ __launch_bounds__(kBoundsBlock) void tree_bounds_kernel(
+__global__ __launch_bounds__(kBoundsBlock) void tree_leaf_bounds_kernel(
     const StreamElem* __restrict__ stream, int T, const TreeNode* __restrict__ nodes, int N,
-    const int32_t* __restrict__ height_off, const int32_t* __restrict__ height_nodes, int num_heights,
+    const int32_t* __restrict__ height_off, const int32_t* __restrict__ height_nodes,
     float* __restrict__ bounds)                  // [B,N,8] = (min xyz, -, max xyz, -)
 {
-    extern __shared__ float sb[];
-    const int b = blockIdx.x;
+    const int b = blockIdx.y;
     const StreamElem* st = stream + (size_t)b * T;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int i = height_off[0] + wave; i < height_off[1]; i += kBoundsBlock / 64) {
+    const int i = height_off[0] + blockIdx.x * (kBoundsBlock / 64) + wave;       // one leaf per wave
+    if (i >= height_off[1]) return;
+    const int node = height_nodes[i];
+    const int off = nodes[node].ex_off, len = nodes[node].ex_len;
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int p = lane; p < len; p += 64) {
+        const StreamElem e = st[off + p];
+        lo[0] = fminf(lo[0], e.x); lo[1] = fminf(lo[1], e.y); lo[2] = fminf(lo[2], e.z);
+        hi[0] = fmaxf(hi[0], e.x); hi[1] = fmaxf(hi[1], e.y); hi[2] = fmaxf(hi[2], e.z);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], m));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m));
+        }
+    if (lane == 0) {
+        float* o = bounds + ((size_t)b * N + node) * 8;
+        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = 0.0f;
+        o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(kBoundsBlock) void tree_inner_bounds_kernel(
+    const TreeNode* __restrict__ nodes, int N, const int32_t* __restrict__ height_off,
+    const int32_t* __restrict__ height_nodes, int num_heights, float* __restrict__ bounds)
+{
+    extern __shared__ float sb[];
+    float* out = bounds + (size_t)blockIdx.x * N * 8;
+    for (int i = height_off[0] + threadIdx.x; i < height_off[1]; i += kBoundsBlock) {
         const int node = height_nodes[i];
-        const int off = nodes[node].ex_off, len = nodes[node].ex_len;
-        float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-        for (int p = lane; p < len; p += 64) {
-            const StreamElem e = st[off + p];
-            lo[0] = fminf(lo[0], e.x); lo[1] = fminf(lo[1], e.y); lo[2] = fminf(lo[2], e.z);
-            hi[0] = fmaxf(hi[0], e.x); hi[1] = fmaxf(hi[1], e.y); hi[2] = fmaxf(hi[2], e.z);
-        }
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                lo[k] = fminf(lo[k], __shfl_xor(lo[k], m));
-                hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m));
-            }
-        if (lane == 0) {
-            float* o = sb + node * 8;
-            o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = 0.0f;
-            o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = 0.0f;
-        }
+        for (int k = 0; k < 8; ++k) sb[node * 8 + k] = out[node * 8 + k];
     }
     __syncthreads();
     for (int h = 1; h < num_heights; ++h) {
@@ -362,18 +374,21 @@ __global__ __launch_bounds__(kBoundsBlock) void tree_bounds_kernel(
             const int node = height_nodes[i];
             const float* a = sb + nodes[node].c0 * 8;
             const float* c = sb + nodes[node].c1 * 8;
-            float* o = sb + node * 8;
+            float o[8];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 o[k] = fminf(a[k], c[k]);
                 o[4 + k] = fmaxf(a[4 + k], c[4 + k]);
             }
             o[3] = o[7] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                sb[node * 8 + k] = o[k];
+                out[node * 8 + k] = o[k];
+            }
         }
         __syncthreads();
     }
-    float* out = bounds + (size_t)b * N * 8;
-    for (int i = threadIdx.x; i < N * 8; i += kBoundsBlock) out[i] = sb[i];
 }
 
 // one run of the strip loop over stream elements [off, off+len), len % 3 == 0; the stream has
@@ -397,16 +412,20 @@ __device__ __forceinline__ void run_stream(const StreamElem* __restrict__ st, in
 // contains none of the wavefront's 128 queries contributes through its boundary cap (exactly the
 // same solid angle), a leaf that does is summed face by face, an inner node that does is descended.
 // All decisions are wave-uniform.  grid (B, subtrees of the frontier, query blocks).
-__global__ __launch_bounds__(64) void winding_tree_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void winding_tree_kernel(
     const float* __restrict__ verts,             // [B,V,3]
     const StreamElem* __restrict__ stream,       // [B,T]
     const TreeNode* __restrict__ nodes, const float* __restrict__ bounds, int N,
-    const int32_t* __restrict__ frontier, const int32_t* __restrict__ qperm,
-    int V, int T, float* __restrict__ partial)   // [B,S,V]
+    const int32_t* __restrict__ frontier, const int32_t* __restrict__ order, const int32_t* __restrict__ qperm,
+    int V, int T, int nsub, float* __restrict__ partial)   // [B,S,V]
 {
-    const int b = blockIdx.x, sub = blockIdx.y, nsub = gridDim.y;
-    const int i0 = qperm[blockIdx.z * kTreeQueries + threadIdx.x];
-    const int i1 = qperm[blockIdx.z * kTreeQueries + 64 + threadIdx.x];
+    // grid (B, pairs): the body index varies fastest (XCD-aware, see winding_strip_kernel); the
+    // (subtree, query block) pairs come in the model's launch order, long-running first
+    const int b = blockIdx.x;
+    const int pair = __builtin_amdgcn_readfirstlane(order[blockIdx.y]);
+    const int sub = pair >> 16, qb = pair & 0xffff;
+    const int i0 = qperm[qb * kTreeQueries + threadIdx.x];
+    const int i1 = qperm[qb * kTreeQueries + 64 + threadIdx.x];
     const float* pts = verts + (size_t)b * V * 3;
     const v2f qx = {pts[3 * i0 + 0], pts[3 * i1 + 0]};
     const v2f qy = {pts[3 * i0 + 1], pts[3 * i1 + 1]};
@@ -639,7 +658,8 @@ bool use_tree(const tuch_contact_model* m)
 // balance the uneven subtree costs over 256 CUs
 int choose_frontier(const tuch_contact_model* m, int B)
 {
-    static const long target = [] { const char* e = getenv("TUCH_TREE_WAVES"); return e ? atol(e) : 32768L; }();
+    const char* e = getenv("TUCH_TREE_WAVES");
+    const long target = e ? atol(e) : 32768L;
     int f = 0;
     while (f + 1 < m->tree_num_frontiers &&
            (long)B * m->tree_qblocks * (m->tree_frontier_off_host[f + 1] - m->tree_frontier_off_host[f]) < target) ++f;
@@ -772,14 +792,19 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
         float* bounds = (float*)(ws + l.bounds);
         hipLaunchKernelGGL(gather_stream_kernel, dim3(ceil_div(T, kBlock), B), dim3(kBlock), 0, s, verts,
                            (const int32_t*)m->tree_vidx, (const float*)m->tree_sign, m->V, m->tree_stream_len, T, st);
-        hipLaunchKernelGGL(tree_bounds_kernel, dim3(B), dim3(kBoundsBlock), (size_t)m->tree_nodes * 8 * sizeof(float), s,
-                           (const StreamElem*)st, T, (const TreeNode*)m->tree_node, m->tree_nodes,
+        hipLaunchKernelGGL(tree_leaf_bounds_kernel, dim3(ceil_div(m->tree_leaves, kBoundsBlock / 64), B),
+                           dim3(kBoundsBlock), 0, s, (const StreamElem*)st, T, (const TreeNode*)m->tree_node,
+                           m->tree_nodes, (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, bounds);
+        hipLaunchKernelGGL(tree_inner_bounds_kernel, dim3(B), dim3(kBoundsBlock),
+                           (size_t)m->tree_nodes * 8 * sizeof(float), s, (const TreeNode*)m->tree_node, m->tree_nodes,
                            (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, m->tree_heights,
                            bounds);
-        hipLaunchKernelGGL(winding_tree_kernel, dim3(B, l.tree_subs, m->tree_qblocks), dim3(64), 0, s, verts,
+        const int f0 = m->tree_frontier_off_host[l.tree_frontier];
+        hipLaunchKernelGGL(winding_tree_kernel, dim3(B, l.tree_subs * m->tree_qblocks), dim3(64), 0, s, verts,
                            (const StreamElem*)st, (const TreeNode*)m->tree_node, (const float*)bounds, m->tree_nodes,
-                           (const int32_t*)m->tree_frontier_nodes + m->tree_frontier_off_host[l.tree_frontier],
-                           (const int32_t*)m->tree_qperm, m->V, T, (float*)(ws + l.partial));
+                           (const int32_t*)m->tree_frontier_nodes + f0,
+                           (const int32_t*)m->tree_launch_order + (size_t)f0 * m->tree_qblocks,
+                           (const int32_t*)m->tree_qperm, m->V, T, l.tree_subs, (float*)(ws + l.partial));
         hipLaunchKernelGGL(winding_finalize_kernel, dim3(ceil_div(m->V, kBlock), B), dim3(kBlock), 0, s,
                            (const float*)(ws + l.partial), m->V, l.tree_subs, thresh, w, exterior);
     } else if (use_strips() && m->strip_len > 0) {
