@@ -365,3 +365,46 @@ def test_contact_terms_ragged_matches_dense():
     (ragged * torch.tensor([[1.0, 2.0]], device=d)).sum().backward()
     assert_close(ragged.detach().cpu().numpy(), dense.detach().cpu().numpy(), 1e-6, 1e-7, 'ragged terms')
     assert_close(flat.grad.cpu().numpy().reshape(b_count, v_count, 3), vd.grad.cpu().numpy(), 1e-5, 1e-7, 'ragged grad')
+
+
+def _flags_and_winding(model, verts, tree, monkeypatch):
+    monkeypatch.setenv('TUCH_WINDING_TREE', '1' if tree else '0')
+    ext, w = model.exterior_flags(verts, apply_segments=False, return_details=True)[:2]
+    return ext.cpu().numpy().astype(bool), w.cpu().numpy()
+
+
+@pytest.mark.parametrize('tag', TAGS)
+@pytest.mark.parametrize('batch', [1, 3, 9])
+def test_tree_walk_matches_flat_walk(tag, batch, monkeypatch):
+    """The hierarchical evaluation (cluster tree + boundary caps) against the flat walk over every
+    face, both on the device, and both against the reference's output."""
+    g = golden(tag)
+    model = make_model(g, None, False, False)
+    base = torch.tensor(g['verts'], device=dev())
+    verts = base[torch.arange(batch, device=dev()) % base.shape[0]].contiguous()
+    if batch > base.shape[0]:        # perturb the repeats: shear + offset keeps the surface closed
+        k = (torch.arange(batch, device=dev(), dtype=torch.float32) - (base.shape[0] - 1)).clamp(min=0).view(-1, 1)
+        verts[:, :, 0] += 0.03 * k * verts[:, :, 1]
+        verts[:, :, 2] += 0.1 * k
+    ext_t, w_t = _flags_and_winding(model, verts, True, monkeypatch)
+    ext_f, w_f = _flags_and_winding(model, verts, False, monkeypatch)
+    for b in range(batch):
+        check_winding(w_t[b], w_f[b])
+        if b < base.shape[0]:
+            check_winding(w_t[b], g['winding'][b])
+    clear = np.abs(w_f - 0.99) > 1e-4
+    assert np.array_equal(ext_t[clear], ext_f[clear])
+
+
+def test_open_mesh_keeps_the_flat_walk():
+    """A mesh with a hole has no cluster tree (the cap identity needs a closed surface); the model
+    still answers, through the flat walk, and agrees with the oracle."""
+    g = golden('small')
+    from tuch_amd.ops import ContactModel
+    faces = g['faces'][:-3]
+    model = ContactModel(faces, None, None, None, None, device=dev())
+    verts = torch.tensor(g['verts'], device=dev())
+    w = model.exterior_flags(verts, apply_segments=False, return_details=True)[1].cpu().numpy()
+    for b in range(verts.shape[0]):
+        ref = oc.winding_numbers(g['verts'][b], g['verts'][b][faces])
+        assert np.abs(w[b] - ref).max() < 2e-5
