@@ -141,6 +141,14 @@ int tuch_contact_model_info(const tuch_contact_model* model, int* V, int* F, int
 int tuch_contact_model_strips(const tuch_contact_model* model, int* stream_len, int* num_strips,
                               int32_t* vidx_host, float* sign_host);
 
+/* Model-level form of tuch_v2v_min_masked: uses the model's geodesic mask and, when the model has a
+ * cluster tree, a pruned walk that gives the same minima (rows whose posed box is farther than a column's
+ * current minimum, or that the mask rules out entirely, are skipped).  Exact ties between rows are
+ * resolved deterministically (smallest row in the tree's vertex order). */
+size_t tuch_v2v_model_workspace_bytes(const tuch_contact_model* model, int B);
+int tuch_v2v_min_model(const tuch_contact_model* model, const float* verts, int B, float* min_d2,
+                       int32_t* argmin, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Cluster tree over the faces of a closed mesh (host only, no device needed): the structure behind the
  * hierarchical evaluation of winding_numbers (tuch/utils/contact.py:112-147) inside tuch_exterior_flags.
  * A set of faces far from the query is replaced by a triangulation of its boundary loops, which subtends
@@ -150,7 +158,8 @@ int tuch_contact_model_strips(const tuch_contact_model* model, int* stream_len, 
  * [0, exact_len), then the caps); qperm [num_qblocks*128] = query order; frontier f =
  * frontier_nodes[frontier_off[f] .. frontier_off[f+1]) = subtrees that together cover the mesh;
  * launch_order [frontier_total * num_qblocks] = per frontier (at frontier_off[f] * num_qblocks) the
- * (subtree index << 16 | query block) pairs, the long-running ones first.
+ * (subtree index << 16 | query block) pairs, the long-running ones first; rows [num_nodes][2] = (first
+ * position, count) in qperm of the vertices below a node (each vertex belongs to one leaf).
  * tuch_contact_model_create builds the same tree internally.  Fails (TUCH_ERR_ARG) for a mesh that is
  * not a closed, consistently oriented manifold; the library then keeps the flat evaluation. */
 typedef struct tuch_cluster_tree tuch_cluster_tree;
@@ -160,7 +169,7 @@ int tuch_cluster_tree_info(const tuch_cluster_tree* tree, int* num_nodes, int* e
                            int* num_qblocks, int* num_frontiers, int* frontier_total);
 int tuch_cluster_tree_export(const tuch_cluster_tree* tree, int32_t* nodes, int32_t* vidx, float* sign,
                              int32_t* qperm, int32_t* frontier_off, int32_t* frontier_nodes,
-                             int32_t* launch_order);
+                             int32_t* launch_order, int32_t* rows);
 
 /* exterior flags of losses.py:79-89 / loss.py:259-266: winding_numbers(verts, verts[faces]).le(thresh),
  * then BatchBodySegment.batch_has_self_isec (segmentation.py:117-124) and the re-marking of

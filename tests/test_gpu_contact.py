@@ -341,7 +341,8 @@ def test_winding_points_ragged_vs_oracle(tag):
     for b in range(b_count):
         wo = oc.winding_numbers(pts[b][:counts[b]], oc.gather_tris(verts_np[b], g['faces']))
         err = np.abs(w[b][:counts[b]] - wo)
-        assert np.percentile(err, 99) < 5e-6 and err.max() < 2e-4
+        # points inside several layers have w = 2, 3: float32 accumulation noise scales with |w|
+        assert np.percentile(err / np.maximum(1.0, np.abs(wo)), 99) < 5e-6 and err.max() < 2e-4
         clear = np.abs(wo - 0.99) > 1e-4
         assert np.array_equal(ext[b][:counts[b]][clear].astype(bool), (wo <= 0.99)[clear])
 

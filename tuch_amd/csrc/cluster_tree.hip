@@ -203,6 +203,8 @@ void pad3(std::vector<int32_t>& vidx, std::vector<float>& sign, size_t begin)
 
 // Greedy triangle strips.  Every face appears exactly once as an emitted element; the sign
 // says whether (stream[p-2], stream[p-1], stream[p]) is an even permutation of the face.
+// Seeds are the faces with the fewest unused neighbours (strip ends first); from a seed the strip
+// is grown in both directions, best of the three rotations.
 void tuch_build_strips(const int32_t* faces, int F, std::vector<int32_t>& vidx, std::vector<float>& sign,
                        int* num_strips)
 {
@@ -210,7 +212,7 @@ void tuch_build_strips(const int32_t* faces, int F, std::vector<int32_t>& vidx, 
     edge_face.reserve((size_t)F * 3 * 2);
     for (int f = 0; f < F; ++f)
         for (int k = 0; k < 3; ++k) edge_face[key2(faces[3 * f + k], faces[3 * f + (k + 1) % 3])] = f;
-    std::vector<char> used(F, 0);
+    std::vector<char> used(F, 0), mark(F, 0);
     auto third = [&](int f, int a, int b) {            // vertex of face f that is neither a nor b
         for (int k = 0; k < 3; ++k) {
             const int v = faces[3 * f + k];
@@ -218,39 +220,61 @@ void tuch_build_strips(const int32_t* faces, int F, std::vector<int32_t>& vidx, 
         }
         return -1;
     };
-    // walk a strip from face f starting with rotation r; returns its vertex sequence
-    auto walk = [&](int f, int r, std::vector<int>& seq, std::vector<int>& fseq, std::vector<char>& mark) {
-        seq.clear(); fseq.clear();
-        seq.push_back(faces[3 * f + r]); seq.push_back(faces[3 * f + (r + 1) % 3]);
-        seq.push_back(faces[3 * f + (r + 2) % 3]);
-        fseq.push_back(f);
+    auto across = [&](int f, int y, int z) {           // the other face on the edge {y, z}
+        auto it = edge_face.find(key2(y, z));
+        if (it != edge_face.end() && it->second != f) return it->second;
+        it = edge_face.find(key2(z, y));
+        if (it != edge_face.end() && it->second != f) return it->second;
+        return -1;
+    };
+    // grow from face f entered with the vertex order (a, b, c); faces taken are marked
+    auto walk = [&](int f, int a, int b, int c, std::vector<int>& seq, std::vector<int>& fseq) {
+        seq.assign({a, b, c});
+        fseq.assign(1, f);
         mark[f] = 1;
+        int cur = f;
         for (;;) {
             const int n = (int)seq.size();
             const int y = seq[n - 2], z = seq[n - 1];
-            // triangle index i = n-3 (0-based); its face holds directed edge y->z when i is even
-            // and z->y when odd; the neighbour across holds the opposite directed edge
-            const bool even = ((n - 3) % 2) == 0;
-            auto it = even ? edge_face.find(key2(z, y)) : edge_face.find(key2(y, z));
-            if (it == edge_face.end()) break;
-            const int nf = it->second;
-            if (used[nf] || mark[nf]) break;
+            const int nf = across(cur, y, z);
+            if (nf < 0 || used[nf] || mark[nf]) break;
             const int d = third(nf, y, z);
             if (d < 0) break;
             seq.push_back(d);
             fseq.push_back(nf);
             mark[nf] = 1;
+            cur = nf;
         }
-        for (int ff : fseq) mark[ff] = 0;
     };
-    std::vector<char> mark(F, 0);
-    std::vector<int> seq, fseq, best_seq, best_f;
+    auto free_neighbours = [&](int f) {
+        int n = 0;
+        for (int k = 0; k < 3; ++k) {
+            const int g = across(f, faces[3 * f + k], faces[3 * f + (k + 1) % 3]);
+            n += (g >= 0 && !used[g]);
+        }
+        return n;
+    };
+    std::vector<int> fwd, ffwd, bwd, fbwd, seq, fseq, best_seq, best_f;
     if (num_strips) *num_strips = 0;
-    for (int f = 0; f < F; ++f) {
-        if (used[f]) continue;
+    int remaining = F;
+    while (remaining > 0) {
+        int seed = -1, seed_free = 4;
+        for (int f = 0; f < F && seed_free > 0; ++f) {
+            if (used[f]) continue;
+            const int n = free_neighbours(f);
+            if (n < seed_free) { seed = f; seed_free = n; }
+        }
         best_seq.clear();
         for (int r = 0; r < 3; ++r) {
-            walk(f, r, seq, fseq, mark);
+            const int a = faces[3 * seed + r], b = faces[3 * seed + (r + 1) % 3], c = faces[3 * seed + (r + 2) % 3];
+            walk(seed, a, b, c, fwd, ffwd);
+            walk(seed, c, b, a, bwd, fbwd);            // the other direction, around the faces just taken
+            seq.assign(bwd.rbegin(), bwd.rend() - 3);
+            seq.insert(seq.end(), fwd.begin(), fwd.end());
+            fseq.assign(fbwd.rbegin(), fbwd.rend() - 1);
+            fseq.insert(fseq.end(), ffwd.begin(), ffwd.end());
+            for (int ff : ffwd) mark[ff] = 0;
+            for (int ff : fbwd) mark[ff] = 0;
             if (seq.size() > best_seq.size()) { best_seq = seq; best_f = fseq; }
         }
         for (size_t i = 0; i < best_seq.size(); ++i) {
@@ -258,6 +282,7 @@ void tuch_build_strips(const int32_t* faces, int F, std::vector<int32_t>& vidx, 
             if (i < 2) { sign.push_back(0.0f); continue; }
             const int ff = best_f[i - 2];
             used[ff] = 1;
+            --remaining;
             // parity of (s[i-2], s[i-1], s[i]) relative to the face's own order
             const int a = best_seq[i - 2], b = best_seq[i - 1];
             int ia = -1, ib = -1;
@@ -443,6 +468,23 @@ bool tuch_cluster_tree_build_impl(int V, int F, const int32_t* faces, int leaf_f
     t.num_qblocks = (V + 127) / 128;
     t.qperm.assign((size_t)t.num_qblocks * 128, vorder[V - 1]);
     std::copy(vorder.begin(), vorder.end(), t.qperm.begin());
+    // the vertices keyed to a leaf are contiguous in this order: rows[leaf] = (first position, count)
+    t.rows.assign((size_t)N * 2, 0);
+    for (int pos = 0; pos < V; ++pos) {
+        const int nd = seq_node[vkey[vorder[pos]]];
+        if (t.rows[(size_t)nd * 2 + 1]++ == 0) t.rows[(size_t)nd * 2] = pos;
+    }
+    for (int i = N - 1; i >= 0; --i) {               // inner nodes: the span of their leaves
+        const int c0 = t.nodes[(size_t)i * 8 + 5], c1 = t.nodes[(size_t)i * 8 + 6];
+        if (c0 < 0) continue;
+        int lo = 1 << 30, hi = 0;
+        for (int c : {c0, c1})
+            if (t.rows[(size_t)c * 2 + 1] > 0) {
+                lo = std::min(lo, t.rows[(size_t)c * 2]);
+                hi = std::max(hi, t.rows[(size_t)c * 2] + t.rows[(size_t)c * 2 + 1]);
+            }
+        if (hi > 0) { t.rows[(size_t)i * 2] = lo; t.rows[(size_t)i * 2 + 1] = hi - lo; }
+    }
 
     // ---- frontiers: sets of subtrees that together cover the mesh, one workgroup column each
     t.frontier_off.push_back(0);
@@ -515,7 +557,7 @@ extern "C" int tuch_cluster_tree_info(const tuch_cluster_tree* t, int* num_nodes
 
 extern "C" int tuch_cluster_tree_export(const tuch_cluster_tree* t, int32_t* nodes, int32_t* vidx, float* sign,
                                         int32_t* qperm, int32_t* frontier_off, int32_t* frontier_nodes,
-                                        int32_t* launch_order)
+                                        int32_t* launch_order, int32_t* rows)
 {
     TUCH_REQUIRE(t, "tuch_cluster_tree_export: null tree");
     if (nodes) memcpy(nodes, t->nodes.data(), t->nodes.size() * sizeof(int32_t));
@@ -525,5 +567,6 @@ extern "C" int tuch_cluster_tree_export(const tuch_cluster_tree* t, int32_t* nod
     if (frontier_off) memcpy(frontier_off, t->frontier_off.data(), t->frontier_off.size() * sizeof(int32_t));
     if (frontier_nodes) memcpy(frontier_nodes, t->frontier_nodes.data(), t->frontier_nodes.size() * sizeof(int32_t));
     if (launch_order) memcpy(launch_order, t->launch_order.data(), t->launch_order.size() * sizeof(int32_t));
+    if (rows) memcpy(rows, t->rows.data(), t->rows.size() * sizeof(int32_t));
     return TUCH_OK;
 }

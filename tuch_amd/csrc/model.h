@@ -17,6 +17,9 @@ struct tuch_cluster_tree {
     std::vector<int32_t> frontier_off, frontier_nodes;
     // per frontier f, at frontier_off[f] * num_qblocks: (subtree index << 16 | query block), heavy first
     std::vector<int32_t> launch_order;
+    // rows [num_nodes][2]: the positions in qperm of the vertices below a node (first, count); every
+    // vertex belongs to exactly one leaf (the first leaf in preorder that touches it)
+    std::vector<int32_t> rows;
 };
 
 bool tuch_cluster_tree_build_impl(int V, int F, const int32_t* faces, int leaf_faces, tuch_cluster_tree& t);
@@ -44,6 +47,11 @@ struct tuch_contact_model {
     int32_t* tree_height_nodes;
     int32_t* tree_frontier_nodes;
     int32_t* tree_launch_order;
+    int32_t* tree_rows;        // [tree_nodes][2]
+    // geodesic mask in the tree's vertex order: tree_mask_bits[w][j'], bit k = geomask[qperm[j']][qperm[64 w + k]],
+    // w < 2 * tree_qblocks, j' < V; tree_masked[qb][node] != 0: no allowed pair between query block qb and the node
+    uint64_t* tree_mask_bits;
+    int32_t* tree_masked;
     int tree_num_frontiers;
     int* tree_frontier_off_host;   // [tree_num_frontiers+1]
     // segments (tuch/utils/segmentation.py): CSR over segments

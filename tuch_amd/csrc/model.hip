@@ -40,7 +40,7 @@ extern "C" void tuch_contact_model_destroy(tuch_contact_model* m)
 {
     if (!m) return;
     void* dev[] = {m->faces, m->mask_bits, m->strip_vidx, m->strip_sign, m->tree_node, m->tree_vidx, m->tree_sign, m->tree_qperm,
-                   m->tree_height_off, m->tree_height_nodes, m->tree_frontier_nodes, m->tree_launch_order, m->seg_blocks, m->seg_of_q, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces,
+                   m->tree_height_off, m->tree_height_nodes, m->tree_frontier_nodes, m->tree_launch_order, m->tree_rows, m->tree_mask_bits, m->tree_masked, m->seg_blocks, m->seg_of_q, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces,
                    m->cap_off, m->cap_vidx, m->region_off, m->region_vidx, m->pairs, m->pair_mask, m->pair_mask_off};
     for (void* p : dev)
         if (p) (void)hipFree(p);
@@ -105,6 +105,35 @@ extern "C" int tuch_contact_model_create(
             if (rc == TUCH_OK) rc = upload(&m->tree_height_nodes, t.height_nodes.data(), t.height_nodes.size());
             if (rc == TUCH_OK) rc = upload(&m->tree_frontier_nodes, t.frontier_nodes.data(), t.frontier_nodes.size());
             if (rc == TUCH_OK) rc = upload(&m->tree_launch_order, t.launch_order.data(), t.launch_order.size());
+            if (rc == TUCH_OK) rc = upload(&m->tree_rows, t.rows.data(), t.rows.size());
+            if (rc == TUCH_OK && geomask) {
+                // the mask in the tree's vertex order, and which (query block, node) pairs it rules out entirely
+                const int Wp = 2 * t.num_qblocks, N = t.num_nodes;
+                std::vector<uint64_t> bits((size_t)Wp * V, 0);
+                for (int jp = 0; jp < V; ++jp) {
+                    const uint8_t* row = geomask + (size_t)t.qperm[jp] * V;
+                    for (int ip = 0; ip < V; ++ip)
+                        if (row[t.qperm[ip]]) bits[(size_t)(ip >> 6) * V + jp] |= (uint64_t)1 << (ip & 63);
+                }
+                std::vector<int32_t> masked((size_t)t.num_qblocks * N, 0);
+                for (int qb = 0; qb < t.num_qblocks; ++qb) {
+                    const uint64_t* w0 = bits.data() + (size_t)(2 * qb) * V;
+                    const uint64_t* w1 = w0 + V;
+                    for (int i = N - 1; i >= 0; --i) {
+                        const int c0 = t.nodes[(size_t)i * 8 + 5], c1 = t.nodes[(size_t)i * 8 + 6];
+                        int32_t all = 1;
+                        if (c0 >= 0) {
+                            all = masked[(size_t)qb * N + c0] && masked[(size_t)qb * N + c1];
+                        } else {
+                            const int lo = t.rows[(size_t)i * 2], n = t.rows[(size_t)i * 2 + 1];
+                            for (int j = lo; j < lo + n && all; ++j) all = (w0[j] | w1[j]) == 0;
+                        }
+                        masked[(size_t)qb * N + i] = all;
+                    }
+                }
+                rc = upload(&m->tree_mask_bits, bits.data(), bits.size());
+                if (rc == TUCH_OK) rc = upload(&m->tree_masked, masked.data(), masked.size());
+            }
         }
     }
     if (rc == TUCH_OK && geomask) {

@@ -18,6 +18,9 @@
 //     ascending row order with a strict '<' => first-index tie rule of
 //     torch.argmin, all-masked column -> (inf, 0).
 #include "common.h"
+#include "model.h"
+#include "tree_device.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -183,6 +186,276 @@ __global__ __launch_bounds__(kBlock) void v2v_indexed_kernel(
     if (a < n) { out_min[beg + a] = best; out_arg[beg + a] = arg; }
 }
 
+// ---- tree-pruned form ----------------------------------------------------------------------
+// Same result as v2v_partial/merge, but most rows are never touched.  Vertices are renumbered in
+// the cluster tree's order (cluster_tree.hip: the vertices of a leaf are consecutive, a block of 128
+// columns is a compact patch) and the mask is packed in that numbering.  A wavefront owns 128
+// columns and walks the tree: a node is skipped when the mask rules out every (column, row) pair
+// below it (static, per model) or when no column can improve, i.e. for every lane the squared
+// distance from its column to the node's posed box exceeds that column's current minimum
+// (exact: the box distance is a lower bound of every row distance below the node).  Minima start
+// from a seed (the nearest admissible leaf by box distance) and are shared between the subtree
+// walks of a body through 64-bit (distance bits, row) keys merged with atomicMin, so the final
+// key is the lexicographic minimum over all rows attaining the minimum: deterministic, ties go
+// to the smallest row in tree order.
+constexpr int kTreeCols = 128;
+constexpr float kPruneSlack = 0.999999f;      // lower bounds are deflated by 1e-6: rounding of the two sums
+
+__device__ __forceinline__ uint64_t v2v_key(float d, int j)
+{
+    return ((uint64_t)__float_as_uint(d) << 32) | (uint32_t)j;
+}
+
+// rows in tree order + box of every leaf's rows; one wave per (leaf, body)
+__global__ __launch_bounds__(kBoundsBlock) void v2v_rows_kernel(
+    const float* __restrict__ verts, int V, int Vp, const int32_t* __restrict__ qperm,
+    const int32_t* __restrict__ rows, const int32_t* __restrict__ height_off,
+    const int32_t* __restrict__ height_nodes, int N,
+    float* __restrict__ prow,                    // [B,Vp,3]
+    float* __restrict__ bounds)                  // [B,N,8]
+{
+    const int b = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = height_off[0] + blockIdx.x * (kBoundsBlock / 64) + wave;
+    const float* vb = verts + (size_t)b * V * 3;
+    float* pb = prow + (size_t)b * Vp * 3;
+    if (blockIdx.x == 0 && wave == 0)            // padding columns repeat the last vertex
+        for (int j = V + lane; j < Vp; j += 64) {
+            const int v = qperm[j];
+            pb[3 * j] = vb[3 * v]; pb[3 * j + 1] = vb[3 * v + 1]; pb[3 * j + 2] = vb[3 * v + 2];
+        }
+    if (i >= height_off[1]) return;
+    const int node = height_nodes[i];
+    const int off = rows[2 * node], len = rows[2 * node + 1];
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int j = off + lane; j < off + len; j += 64) {
+        const int v = qperm[j];
+        const float x = vb[3 * v], y = vb[3 * v + 1], z = vb[3 * v + 2];
+        pb[3 * j] = x; pb[3 * j + 1] = y; pb[3 * j + 2] = z;
+        lo[0] = fminf(lo[0], x); lo[1] = fminf(lo[1], y); lo[2] = fminf(lo[2], z);
+        hi[0] = fmaxf(hi[0], x); hi[1] = fmaxf(hi[1], y); hi[2] = fmaxf(hi[2], z);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], m));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m));
+        }
+    if (lane == 0) {
+        float* o = bounds + ((size_t)b * N + node) * 8;
+        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = 0.0f;
+        o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = 0.0f;
+    }
+}
+
+struct ColumnPair {
+    v2f px, py, pz;
+    float best0, best1;
+    int arg0, arg1;
+};
+
+// rows [j0, j0+n) against the wave's 128 columns; ties keep the smaller row
+__device__ __forceinline__ void v2v_rows(ColumnPair& c, const float* __restrict__ pb,
+                                         const uint64_t* __restrict__ m0, const uint64_t* __restrict__ m1,
+                                         int j0, int n)
+{
+    const float inf = __builtin_inff();
+    auto row = [&](int j, uint64_t k0, uint64_t k1, float vx, float vy, float vz) {
+        const v2f dx = c.px - splat2(vx), dy = c.py - splat2(vy), dz = c.pz - splat2(vz);
+        const v2f d = fma2(dz, dz, fma2(dy, dy, dx * dx));
+        const float d0 = select_by_lane_mask(inf, d[0], k0);
+        const float d1 = select_by_lane_mask(inf, d[1], k1);
+        if (__builtin_amdgcn_ballot_w64(d0 <= c.best0 || d1 <= c.best1)) {       // rare, wave-uniform
+            if (d0 < c.best0 || (d0 == c.best0 && d0 < inf && j < c.arg0)) { c.best0 = d0; c.arg0 = j; }
+            if (d1 < c.best1 || (d1 == c.best1 && d1 < inf && j < c.arg1)) { c.best1 = d1; c.arg1 = j; }
+        }
+    };
+    int j = j0;
+    const int j_end = j0 + n;
+    for (; j + 4 <= j_end; j += 4) {
+        uint64_t k0[4], k1[4];
+        float v[12];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { k0[u] = m0[j + u]; k1[u] = m1[j + u]; }
+#pragma unroll
+        for (int u = 0; u < 12; ++u) v[u] = pb[3 * j + u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) row(j + u, k0[u], k1[u], v[3 * u], v[3 * u + 1], v[3 * u + 2]);
+    }
+    for (; j < j_end; ++j) row(j, m0[j], m1[j], pb[3 * j], pb[3 * j + 1], pb[3 * j + 2]);
+}
+
+// squared distance from each of the lane's two columns to a box
+__device__ __forceinline__ v2f box_dist2(const ColumnPair& c, const float* __restrict__ box)
+{
+    const v2f zero = splat2(0.0f);
+    const v2f ex = __builtin_elementwise_max(__builtin_elementwise_max(splat2(box[0]) - c.px, c.px - splat2(box[4])), zero);
+    const v2f ey = __builtin_elementwise_max(__builtin_elementwise_max(splat2(box[1]) - c.py, c.py - splat2(box[5])), zero);
+    const v2f ez = __builtin_elementwise_max(__builtin_elementwise_max(splat2(box[2]) - c.pz, c.pz - splat2(box[6])), zero);
+    return fma2(ez, ez, fma2(ey, ey, ex * ex));
+}
+
+__device__ __forceinline__ void load_columns(ColumnPair& c, const float* __restrict__ pb, int i0, int i1)
+{
+    c.px = (v2f){pb[3 * i0], pb[3 * i1]};
+    c.py = (v2f){pb[3 * i0 + 1], pb[3 * i1 + 1]};
+    c.pz = (v2f){pb[3 * i0 + 2], pb[3 * i1 + 2]};
+}
+
+// seed: descend to the admissible leaf nearest to the block's box, evaluate its rows
+__global__ __launch_bounds__(64) void v2v_seed_kernel(
+    const float* __restrict__ prow, int V, int Vp, const uint64_t* __restrict__ bits,
+    const TreeNode* __restrict__ nodes, const int32_t* __restrict__ rows, const float* __restrict__ bounds,
+    const int32_t* __restrict__ masked, int N, uint64_t* __restrict__ keys)       // [B,Vp]
+{
+    const int b = blockIdx.x, qb = blockIdx.y, lane = threadIdx.x;
+    const float* pb = prow + (size_t)b * Vp * 3;
+    const int i0 = qb * kTreeCols + lane, i1 = i0 + 64;
+    ColumnPair c;
+    load_columns(c, pb, i0, i1);
+    c.best0 = c.best1 = __builtin_inff();
+    c.arg0 = c.arg1 = 0;
+    float lo[3] = {fminf(c.px[0], c.px[1]), fminf(c.py[0], c.py[1]), fminf(c.pz[0], c.pz[1])};
+    float hi[3] = {fmaxf(c.px[0], c.px[1]), fmaxf(c.py[0], c.py[1]), fmaxf(c.pz[0], c.pz[1])};
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], m));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m));
+        }
+    const float* bb = bounds + (size_t)b * N * 8;
+    const int32_t* mk = masked + (size_t)qb * N;
+    auto gap2 = [&](int node) {                 // squared distance between the block's box and the node's box
+        const float* box = bb + (size_t)node * 8;
+        float g = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float e = fmaxf(fmaxf(box[k] - hi[k], lo[k] - box[4 + k]), 0.0f);
+            g = fmaf(e, e, g);
+        }
+        return g;
+    };
+    int node = 0;
+    bool ok = mk[0] == 0;
+    while (ok) {
+        const TreeNode nd = nodes[node];
+        if (nd.c0 < 0) break;
+        const bool a0 = mk[nd.c0] == 0, a1 = mk[nd.c1] == 0;
+        if (a0 && a1) {
+            const float g0 = gap2(nd.c0), g1 = gap2(nd.c1);
+            node = __builtin_amdgcn_readfirstlane(g1 < g0 ? nd.c1 : nd.c0);
+        } else if (a0 || a1) {
+            node = a0 ? nd.c0 : nd.c1;
+        } else {
+            ok = false;
+        }
+    }
+    if (ok) {
+        const uint64_t* m0 = bits + (size_t)(2 * qb) * V;
+        v2v_rows(c, pb, m0, m0 + V, rows[2 * node], rows[2 * node + 1]);
+    }
+    uint64_t* kb = keys + (size_t)b * Vp;
+    kb[i0] = v2v_key(c.best0, c.arg0);
+    kb[i1] = v2v_key(c.best1, c.arg1);
+}
+
+__global__ __launch_bounds__(64) void v2v_tree_kernel(
+    const float* __restrict__ prow, int V, int Vp, const uint64_t* __restrict__ bits,
+    const TreeNode* __restrict__ nodes, const int32_t* __restrict__ rows, const float* __restrict__ bounds,
+    const int32_t* __restrict__ masked, int N, const int32_t* __restrict__ frontier,
+    const int32_t* __restrict__ order, uint64_t* __restrict__ keys)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int pair = __builtin_amdgcn_readfirstlane(order[blockIdx.y]);
+    const int sub = pair >> 16, qb = pair & 0xffff;
+    const float* pb = prow + (size_t)b * Vp * 3;
+    const int i0 = qb * kTreeCols + lane, i1 = i0 + 64;
+    uint64_t* kb = keys + (size_t)b * Vp;
+    // any value read here is the key of a real row (seed, or another walk's improvement): a valid bound
+    const uint64_t init0 = __hip_atomic_load(kb + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t init1 = __hip_atomic_load(kb + i1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ColumnPair c;
+    load_columns(c, pb, i0, i1);
+    c.best0 = __uint_as_float((uint32_t)(init0 >> 32)); c.arg0 = (int)(uint32_t)init0;
+    c.best1 = __uint_as_float((uint32_t)(init1 >> 32)); c.arg1 = (int)(uint32_t)init1;
+    const float* bb = bounds + (size_t)b * N * 8;
+    const int32_t* mk = masked + (size_t)qb * N;
+    const uint64_t* m0 = bits + (size_t)(2 * qb) * V;
+    const uint64_t* m1 = m0 + V;
+    int node = __builtin_amdgcn_readfirstlane(frontier[sub]);
+    const int end = __builtin_amdgcn_readfirstlane(nodes[node].skip);
+    while (node < end) {
+        const TreeNode nd = nodes[node];
+        bool descend = mk[node] == 0;
+        if (descend) {
+            const v2f g = box_dist2(c, bb + (size_t)node * 8) * splat2(kPruneSlack);
+            descend = __builtin_amdgcn_ballot_w64(g[0] <= c.best0 || g[1] <= c.best1) != 0;
+        }
+        if (!descend) {
+            node = nd.skip;
+        } else if (nd.c0 < 0) {
+            v2v_rows(c, pb, m0, m1, rows[2 * node], rows[2 * node + 1]);
+            node = nd.skip;
+        } else {
+            node = node + 1;
+        }
+        node = __builtin_amdgcn_readfirstlane(node);
+    }
+    const uint64_t k0 = v2v_key(c.best0, c.arg0), k1 = v2v_key(c.best1, c.arg1);
+    if (k0 < init0) atomicMin((unsigned long long*)(kb + i0), (unsigned long long)k0);
+    if (k1 < init1) atomicMin((unsigned long long*)(kb + i1), (unsigned long long)k1);
+}
+
+// keys -> (min, argmin) in the caller's vertex numbering; all-masked column -> (inf, 0)
+__global__ __launch_bounds__(kBlock) void v2v_tree_finalize_kernel(
+    const uint64_t* __restrict__ keys, const int32_t* __restrict__ qperm, int V, int Vp,
+    float* __restrict__ out_min, int32_t* __restrict__ out_arg)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= V) return;
+    const uint64_t k = keys[(size_t)b * Vp + i];
+    const float d = __uint_as_float((uint32_t)(k >> 32));
+    const int v = qperm[i];
+    if (out_min) out_min[(size_t)b * V + v] = d;
+    if (out_arg) out_arg[(size_t)b * V + v] = d < __builtin_inff() ? qperm[(uint32_t)k] : 0;
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct TreeV2VLayout { size_t prow, bounds, keys, total; };
+
+TreeV2VLayout tree_v2v_layout(const tuch_contact_model* m, int B)
+{
+    TreeV2VLayout l;
+    size_t o = 0;
+    const int Vp = m->tree_qblocks * kTreeCols;
+    l.prow = o;   o += align256((size_t)B * Vp * 3 * sizeof(float) + 64);
+    l.bounds = o; o += align256((size_t)B * m->tree_nodes * 8 * sizeof(float));
+    l.keys = o;   o += align256((size_t)B * Vp * sizeof(uint64_t));
+    l.total = o;
+    return l;
+}
+
+bool use_v2v_tree(const tuch_contact_model* m)
+{
+    if (m->tree_nodes <= 0 || !m->tree_mask_bits) return false;
+    const char* e = getenv("TUCH_V2V_TREE");
+    return !e || atoi(e) != 0;
+}
+
+int choose_v2v_frontier(const tuch_contact_model* m, int B)
+{
+    const char* e = getenv("TUCH_V2V_WAVES");
+    const long target = e ? atol(e) : 65536L;
+    int f = 0;
+    while (f + 1 < m->tree_num_frontiers &&
+           (long)B * m->tree_qblocks * (m->tree_frontier_off_host[f + 1] - m->tree_frontier_off_host[f]) < target) ++f;
+    return f;
+}
+
 int choose_row_splits(int B, int V)
 {
     const int cblocks = ceil_div(V, kColsPerBlock);
@@ -236,6 +509,56 @@ extern "C" int tuch_v2v_min_masked(const float* verts, const uint64_t* geomask_b
     hipLaunchKernelGGL(v2v_merge_kernel, dim3(ceil_div(V, kBlock), B), dim3(kBlock), 0, s,
                        (const float*)pmin, (const int*)parg, V, nsplit, min_d2, argmin);
     return tuch_check_launch("tuch_v2v_min_masked");
+}
+
+// Model-level form of tuch_v2v_min_masked (tuch/smplify/losses.py:76-78,92-93; tuch/train/loss.py:255-257,
+// 269-270): the model's mask, and -- when the model has a cluster tree -- the tree-pruned walk.
+extern "C" size_t tuch_v2v_model_workspace_bytes(const tuch_contact_model* m, int B)
+{
+    if (!m || B <= 0) return 0;
+    const size_t flat = tuch_v2v_workspace_bytes(B, m->V);
+    if (m->tree_nodes <= 0 || !m->tree_mask_bits) return flat;
+    const size_t tree = tree_v2v_layout(m, B).total;
+    return tree > flat ? tree : flat;
+}
+
+extern "C" int tuch_v2v_min_model(const tuch_contact_model* m, const float* verts, int B, float* min_d2,
+                                  int32_t* argmin, void* workspace, size_t workspace_bytes, void* stream)
+{
+    TUCH_REQUIRE(m && verts && (min_d2 || argmin), "tuch_v2v_min_model: null pointer");
+    TUCH_REQUIRE(m->mask_bits, "tuch_v2v_min_model: the model has no geodesic mask");
+    TUCH_REQUIRE(B > 0 && B <= 65535, "tuch_v2v_min_model: bad batch %d", B);
+    if (!use_v2v_tree(m))
+        return tuch_v2v_min_masked(verts, m->mask_bits, B, m->V, min_d2, argmin, workspace, workspace_bytes, stream);
+    const TreeV2VLayout l = tree_v2v_layout(m, B);
+    if (!workspace || workspace_bytes < l.total) {
+        tuch_set_error("tuch_v2v_min_model: workspace %zu < %zu bytes", workspace_bytes, l.total);
+        return TUCH_ERR_WORKSPACE;
+    }
+    char* ws = (char*)workspace;
+    float* prow = (float*)(ws + l.prow);
+    float* bounds = (float*)(ws + l.bounds);
+    uint64_t* keys = (uint64_t*)(ws + l.keys);
+    hipStream_t s = (hipStream_t)stream;
+    const int V = m->V, Vp = m->tree_qblocks * kTreeCols, N = m->tree_nodes;
+    const TreeNode* nodes = (const TreeNode*)m->tree_node;
+    hipLaunchKernelGGL(v2v_rows_kernel, dim3(ceil_div(m->tree_leaves, kBoundsBlock / 64), B), dim3(kBoundsBlock), 0, s,
+                       verts, V, Vp, (const int32_t*)m->tree_qperm, (const int32_t*)m->tree_rows,
+                       (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, N, prow, bounds);
+    hipLaunchKernelGGL(tree_inner_bounds_kernel, dim3(B), dim3(kBoundsBlock), (size_t)N * 8 * sizeof(float), s, nodes, N,
+                       (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, m->tree_heights, bounds);
+    hipLaunchKernelGGL(v2v_seed_kernel, dim3(B, m->tree_qblocks), dim3(64), 0, s, (const float*)prow, V, Vp,
+                       (const uint64_t*)m->tree_mask_bits, nodes, (const int32_t*)m->tree_rows, (const float*)bounds,
+                       (const int32_t*)m->tree_masked, N, keys);
+    const int f = choose_v2v_frontier(m, B);
+    const int f0 = m->tree_frontier_off_host[f], nsub = m->tree_frontier_off_host[f + 1] - f0;
+    hipLaunchKernelGGL(v2v_tree_kernel, dim3(B, nsub * m->tree_qblocks), dim3(64), 0, s, (const float*)prow, V, Vp,
+                       (const uint64_t*)m->tree_mask_bits, nodes, (const int32_t*)m->tree_rows, (const float*)bounds,
+                       (const int32_t*)m->tree_masked, N, (const int32_t*)m->tree_frontier_nodes + f0,
+                       (const int32_t*)m->tree_launch_order + (size_t)f0 * m->tree_qblocks, keys);
+    hipLaunchKernelGGL(v2v_tree_finalize_kernel, dim3(ceil_div(V, kBlock), B), dim3(kBlock), 0, s,
+                       (const uint64_t*)keys, (const int32_t*)m->tree_qperm, V, Vp, min_d2, argmin);
+    return tuch_check_launch("tuch_v2v_min_model");
 }
 
 extern "C" int tuch_batch_pairwise_dist(const float* x, const float* y, int B, int Nx, int Ny,

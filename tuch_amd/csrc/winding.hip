@@ -17,6 +17,7 @@
 //     kernel => bit-reproducible results, no float atomics.
 #include "common.h"
 #include "model.h"
+#include "tree_device.h"
 #include <stdlib.h>
 
 namespace {
@@ -321,8 +322,6 @@ __global__ __launch_bounds__(kStripBlock) void winding_strip_kernel(
 // ---- hierarchical form (cluster_tree.hip) ------------------------------------------------------
 // Posed bounding boxes of all tree nodes of one body: leaves from their strip elements, inner
 // nodes bottom-up from their children.  One workgroup per body, boxes kept in LDS.
-struct TreeNode { int cap_off, cap_len, ex_off, ex_len, skip, c0, c1, nfaces; };
-constexpr int kBoundsBlock = 256;
 constexpr int kTreeQueries = 128;          // one wavefront, two queries per lane
 
 __global__ __launch_bounds__(kBoundsBlock) void tree_leaf_bounds_kernel(
@@ -354,40 +353,6 @@ __global__ __launch_bounds__(kBoundsBlock) void tree_leaf_bounds_kernel(
         float* o = bounds + ((size_t)b * N + node) * 8;
         o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = 0.0f;
         o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = 0.0f;
-    }
-}
-
-__global__ __launch_bounds__(kBoundsBlock) void tree_inner_bounds_kernel(
-    const TreeNode* __restrict__ nodes, int N, const int32_t* __restrict__ height_off,
-    const int32_t* __restrict__ height_nodes, int num_heights, float* __restrict__ bounds)
-{
-    extern __shared__ float sb[];
-    float* out = bounds + (size_t)blockIdx.x * N * 8;
-    for (int i = height_off[0] + threadIdx.x; i < height_off[1]; i += kBoundsBlock) {
-        const int node = height_nodes[i];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) sb[node * 8 + k] = out[node * 8 + k];
-    }
-    __syncthreads();
-    for (int h = 1; h < num_heights; ++h) {
-        for (int i = height_off[h] + threadIdx.x; i < height_off[h + 1]; i += kBoundsBlock) {
-            const int node = height_nodes[i];
-            const float* a = sb + nodes[node].c0 * 8;
-            const float* c = sb + nodes[node].c1 * 8;
-            float o[8];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                o[k] = fminf(a[k], c[k]);
-                o[4 + k] = fmaxf(a[4 + k], c[4 + k]);
-            }
-            o[3] = o[7] = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                sb[node * 8 + k] = o[k];
-                out[node * 8 + k] = o[k];
-            }
-        }
-        __syncthreads();
     }
 }
 

@@ -267,7 +267,7 @@ def segment_faces(body_faces: np.ndarray, vidx: np.ndarray, bands: Sequence[np.n
 def cluster_tree(faces, num_verts: int, leaf_faces: int = 64) -> dict:
     """The face-cluster tree used by the hierarchical winding numbers (host only; see include/tuch_amd.h,
     tuch_cluster_tree_build).  Returns numpy arrays: nodes [N,8], vidx, sign, qperm, frontier_off,
-    frontier_nodes, launch_order, plus exact_len."""
+    frontier_nodes, launch_order, rows, plus exact_len."""
     L = _C.lib()
     f = np.ascontiguousarray(np.asarray(faces).reshape(-1, 3), dtype=np.int32)
     h = ctypes.c_void_p()
@@ -280,10 +280,10 @@ def cluster_tree(faces, num_verts: int, leaf_faces: int = 64) -> dict:
         out = dict(nodes=np.zeros((n, 8), np.int32), vidx=np.zeros(stream_len, np.int32),
                    sign=np.zeros(stream_len, np.float32), qperm=np.zeros(qblocks * 128, np.int32),
                    frontier_off=np.zeros(nfr + 1, np.int32), frontier_nodes=np.zeros(frtot, np.int32),
-                   launch_order=np.zeros(frtot * qblocks, np.int32))
+                   launch_order=np.zeros(frtot * qblocks, np.int32), rows=np.zeros((n, 2), np.int32))
         _C.check(L.tuch_cluster_tree_export(h, *[out[k].ctypes.data_as(ctypes.c_void_p) for k in
                                                  ('nodes', 'vidx', 'sign', 'qperm', 'frontier_off', 'frontier_nodes',
-                                                  'launch_order')]))
+                                                  'launch_order', 'rows')]))
         out['exact_len'] = exact_len
         return out
     finally:
@@ -396,7 +396,17 @@ class ContactModel:
     def v2v_min(self, verts: torch.Tensor):
         if not self.has_mask:
             raise _C.TuchError('ContactModel was created without a geodesic mask')
-        return v2v_min_masked(verts, ctypes.c_void_p(_C.lib().tuch_contact_model_mask_bits(self._handle)))
+        verts = _f32(verts)
+        b = verts.shape[0]
+        assert verts.shape[1] == self.num_verts
+        L = _C.lib()
+        mn = torch.empty(b, self.num_verts, dtype=torch.float32, device=verts.device)
+        arg = torch.empty(b, self.num_verts, dtype=torch.int32, device=verts.device)
+        nbytes = L.tuch_v2v_model_workspace_bytes(self._handle, b)
+        ws = _workspace(nbytes, verts.device)
+        _C.check(L.tuch_v2v_min_model(self._handle, _C.ptr(verts), b, _C.ptr(mn), _C.ptr(arg), _C.ptr(ws), nbytes,
+                                      _C.stream()))
+        return mn, arg
 
     def winding_points(self, verts: torch.Tensor, points: torch.Tensor, counts: Optional[torch.Tensor] = None,
                        thresh: float = 0.99):
