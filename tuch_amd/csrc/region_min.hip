@@ -6,11 +6,11 @@
 // per region pair in a Python loop over all P pairs ("Speed up this function will
 // speed up training loop!", :74).
 //
-// One block per (pair, body).  The second region's vertices are staged in LDS once
-// and read by all lanes at the same address (broadcast, conflict-free); every
-// lane walks its share of the first region; the block minimum and its (i, j)
-// are found with a wavefront shuffle reduction on (d2, flat index) keys so that
-// ties resolve to the first flat index like torch.min / argmin.
+// One wavefront per (body, pair, 64 rows of the first region).  The second region's vertices
+// are staged in LDS and read by all lanes at the same address (broadcast, conflict-free); every
+// lane owns one vertex of the first region; the minimum and its (i, j) are found with a wavefront
+// shuffle reduction on (d2, flat index) keys and merged across wavefronts with a 64-bit atomicMin,
+// so that ties resolve to the first flat index like torch.min / argmin.
 // Distances are direct differences (DESIGN.md "Parity").
 #include "common.h"
 #include "model.h"
@@ -18,7 +18,6 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kPairsPerBlock = 8;
 constexpr int kTile = 1024;   // second-region vertices staged per pass (12 KB of LDS)
 
 struct Best {
@@ -31,7 +30,9 @@ __device__ __forceinline__ Best better(Best x, Best y)
     return (y.d < x.d || (y.d == x.d && y.idx < x.idx)) ? y : x;
 }
 
-__global__ __launch_bounds__(kBlock) void region_pair_min_kernel(
+// One wavefront per (body, pair, 64 rows of the first region): unselected pairs leave at once, the
+// selected ones spread over the whole chip (the SMPLify use selects ~10 of ~280 pairs per body).
+__global__ __launch_bounds__(64) void region_pair_min_kernel(
     const float* __restrict__ verts, const int32_t* __restrict__ region_off,
     const int32_t* __restrict__ region_vidx, const int32_t* __restrict__ pairs,
     const uint8_t* __restrict__ select,        // [B,P] or nullptr (= all)
@@ -40,67 +41,51 @@ __global__ __launch_bounds__(kBlock) void region_pair_min_kernel(
     int V, int P, unsigned long long* __restrict__ keys)   // [B,P], preset to all ones
 {
     __shared__ float sx[kTile], sy[kTile], sz[kTile];
-    __shared__ Best swave[kBlock / 64];
-    // few pairs are selected in the SMPLify use: one workgroup walks kPairsPerBlock pairs so that
-    // the launch does not consist of tens of thousands of empty workgroups
-    const int b = blockIdx.y;
-    const int per_block = select ? kPairsPerBlock : 1;
-    for (int p = blockIdx.x * per_block; p < min(P, (int)(blockIdx.x + 1) * per_block); ++p) {
+    const int b = blockIdx.x, p = blockIdx.y;
     const size_t o = (size_t)b * P + p;
-    if (select && !select[o]) continue;
-    __syncthreads();
+    if (select && !select[o]) return;
     const int r1 = pairs[2 * p], r2 = pairs[2 * p + 1];
     const int a_beg = region_off[r1], n1 = region_off[r1 + 1] - a_beg;
     const int b_beg = region_off[r2], n2 = region_off[r2 + 1] - b_beg;
+    const int a = blockIdx.z * 64 + threadIdx.x;               // this lane's row of the first region
+    if ((int)blockIdx.z * 64 >= n1) return;
     const float* vb = verts + (size_t)b * V * 3;
+    const int i = region_vidx[a_beg + min(a, n1 - 1)];
+    const float px = vb[3 * i], py = vb[3 * i + 1], pz = vb[3 * i + 2];
+    const int wpr = (n2 + 31) / 32;
+    const uint32_t* mrow = pair_mask ? pair_mask + pair_mask_off[p] + (size_t)min(a, n1 - 1) * wpr : nullptr;
     Best best = {__builtin_inff(), 0x7fffffff};
     for (int t0 = 0; t0 < n2; t0 += kTile) {
         const int tn = min(kTile, n2 - t0);
         __syncthreads();
-        for (int k = threadIdx.x; k < tn; k += kBlock) {
+        for (int k = threadIdx.x; k < tn; k += 64) {
             const int v = region_vidx[b_beg + t0 + k];
             sx[k] = vb[3 * v]; sy[k] = vb[3 * v + 1]; sz[k] = vb[3 * v + 2];
         }
         __syncthreads();
-        // rows of the first region are split over blockIdx.z (more workgroups per selected pair)
-        const int rows = (n1 + gridDim.z - 1) / gridDim.z;
-        const int a_lo = blockIdx.z * rows, a_hi = min(n1, a_lo + rows);
-        for (int a = a_lo + threadIdx.x; a < a_hi; a += kBlock) {
-            const int i = region_vidx[a_beg + a];
-            const float px = vb[3 * i], py = vb[3 * i + 1], pz = vb[3 * i + 2];
-            const uint32_t* mrow = pair_mask ? pair_mask + pair_mask_off[p] + (size_t)a * ((n2 + 31) / 32) + (t0 >> 5)
-                                             : nullptr;
+        if (a < n1)
             for (int g = 0; g < tn; g += 32) {
-                const uint32_t word = mrow ? mrow[g >> 5] : 0xffffffffu;
+                const uint32_t word = mrow ? mrow[(t0 + g) >> 5] : 0xffffffffu;
                 const int gn = min(32, tn - g);
                 for (int kk = 0; kk < gn; ++kk) {
                     const int k = g + kk;
                     const float dx = px - sx[k], dy = py - sy[k], dz = pz - sz[k];
                     float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
                     if (!((word >> kk) & 1)) d = __builtin_inff();
-                    const int flat = a * n2 + k + t0;
-                    if (d < best.d || (d == best.d && flat < best.idx)) { best.d = d; best.idx = flat; }
+                    // columns ascend, so within a lane the first minimum is the one with the smallest flat index
+                    if (d < best.d) { best.d = d; best.idx = a * n2 + k + t0; }
                 }
             }
-        }
     }
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) {
         Best other = {__shfl_down(best.d, s, 64), __shfl_down(best.idx, s, 64)};
         best = better(best, other);
     }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) swave[wave] = best;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        Best r = swave[0];
-        for (int w = 1; w < kBlock / 64; ++w) r = better(r, swave[w]);
-        // d >= 0, so the float's bit pattern orders like the value: (d, flat index) packs into one
-        // 64-bit key whose minimum is independent of the arrival order -> deterministic
-        if (r.idx != 0x7fffffff)
-            atomicMin(&keys[o], ((unsigned long long)__float_as_uint(r.d) << 32) | (unsigned int)r.idx);
-    }
-    }
+    // d >= 0, so the float's bit pattern orders like the value: (d, flat index) packs into one
+    // 64-bit key whose minimum is independent of the arrival order -> deterministic
+    if (threadIdx.x == 0 && best.idx != 0x7fffffff)
+        atomicMin(&keys[o], ((unsigned long long)__float_as_uint(best.d) << 32) | (unsigned int)best.idx);
 }
 
 // keys -> (min d2, arg-min vertex ids); unselected / empty pairs give 0 and (-1, -1).  The keys
@@ -164,9 +149,7 @@ extern "C" int tuch_region_pair_min(const tuch_contact_model* m, const float* ve
         tuch_set_error("tuch_region_pair_min: hipMemsetAsync failed");
         return TUCH_ERR_HIP;
     }
-    // few pairs selected (SMPLify r2r): split their rows over 4 workgroups; all pairs: 1 is enough
-    const int row_splits = select ? 4 : 1;
-    hipLaunchKernelGGL(region_pair_min_kernel, dim3(ceil_div(m->num_pairs, select ? kPairsPerBlock : 1), B, row_splits), dim3(kBlock), 0, s,
+    hipLaunchKernelGGL(region_pair_min_kernel, dim3(B, m->num_pairs, ceil_div(m->region_max, 64)), dim3(64), 0, s,
                        verts, (const int32_t*)m->region_off, (const int32_t*)m->region_vidx,
                        (const int32_t*)m->pairs, select,
                        use_geomask ? (const uint32_t*)m->pair_mask : (const uint32_t*)nullptr,
