@@ -31,6 +31,9 @@ import torch
 BATCH_PER_GPU = 64
 FLOP_PER_WINDING_PAIR = 67        # 63 arithmetic + 3 sqrt + 1 atan2
 FLOP_PER_V2V_PAIR = 8
+# executed arithmetic of the strip walk per (query, stream element): 3 sub, |.|^2 (5) + sqrt, two dot products
+# (10), numerator (5), denominator (8), small-angle atan (rcp + 8)
+FLOP_PER_STRIP_ELEMENT = 41
 PEAK_FP32_VECTOR_TFLOPS = 157.3   # MI355X_MICROARCH.md (packed FP32 FMA rate)
 PEAK_HBM_GBS = 8000.0
 # HBM-side bytes per launch of winding_strip_kernel at batch 64 from the PMC passes committed under
@@ -163,36 +166,45 @@ def time_kernel(fn, iters):
 
 def rooflines(p, batch):
     """Dominant-kernel figures measured live (HIP events on the launch stream)."""
-    from tuch_amd import ops
     from tuch_amd.smplify.losses import contact_model_for
     body = p['body']
     v, f = body.num_verts, body.num_faces
     model = contact_model_for(p['geomask'], p['face_tensor'], p['segments'], p['cdict'])
     with torch.no_grad():
         verts = p['smpl'](global_orient=p['global_orient'], body_pose=p['body_pose'], betas=p['betas']).vertices
-    # the launch below = gather_stream (~9 us) + winding_strip_kernel + finalize (~5 us)
+    # the launch below = gather_stream (~20 us) + node boxes (~18 us) + winding_tree_kernel + finalize (~7 us)
     t_w = time_kernel(lambda: model.exterior_flags(verts, apply_segments=False), 10)
-    flops = FLOP_PER_WINDING_PAIR * batch * v * f
+    work = model.winding_tree_work(verts)
+    steps = work['leaf_elements'] + work['cap_elements']          # wavefront element steps, 128 queries each
+    flops = FLOP_PER_STRIP_ELEMENT * 128 * steps
     ach = flops / t_w / 1e12
-    roof = {'kernel': 'winding_strip_kernel', 'bound': 'valu', 'achieved': round(ach, 2),
+    ref_flops = FLOP_PER_WINDING_PAIR * batch * v * f
+    roof = {'kernel': 'winding_tree_kernel', 'bound': 'valu', 'achieved': round(ach, 2),
             'peak': PEAK_FP32_VECTOR_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_VECTOR_TFLOPS, 4),
             'traffic': WINDING_TRAFFIC_BYTES if batch == BATCH_PER_GPU else None,
             'traffic_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, KB x 1024 '
-                              '(profiles/r01_e_pmc_fetch.txt, r01_e_pmc_write.txt); narrow loads: counter uncalibrated',
+                              '(profiles/r01_g_pmc_fetch.txt, r01_g_pmc_write.txt); narrow loads: counter uncalibrated',
             'launch_ms': round(t_w * 1e3, 4),
-            'algorithmic_flop_per_launch': flops,
+            'executed_flop_per_launch': flops,
+            'flop_per_query_element': FLOP_PER_STRIP_ELEMENT,
+            'element_steps_per_launch': steps, 'leaf_steps': work['leaf_elements'], 'cap_steps': work['cap_elements'],
+            'steps_fraction_of_flat_walk': round(steps / (work['query_blocks'] * work['flat_stream_elements']), 4),
+            # the reference's formulation (every query x every face, SURVEY.md 8d) priced at this launch time:
+            # above the vector peak because the cluster tree replaces ~3/4 of the pairs by boundary caps
+            'reference_formulation_flop_per_launch': ref_flops,
+            'reference_formulation_equivalent_TFLOPs': round(ref_flops / t_w / 1e12, 1),
             'algorithmic_bytes_per_launch': batch * (v * 12 + v * 4) + f * 12}
     t_v = time_kernel(lambda: model.v2v_min(verts), 10)
     ref_layout_bytes = batch * (12 * v + v * v + 8 * v)           # SURVEY.md §8(d) layout (i)
     compact_bytes = batch * (12 * v + 8 * v) + v * v // 8         # layout (ii): bit-packed mask read once
-    v2v = {'kernel': 'v2v_partial_kernel', 'bound': 'valu', 'launch_ms': round(t_v * 1e3, 4),
-           'achieved': round(FLOP_PER_V2V_PAIR * batch * v * v / t_v / 1e12, 2), 'unit': 'TFLOP/s',
-           'peak': PEAK_FP32_VECTOR_TFLOPS,
-           'frac': round(FLOP_PER_V2V_PAIR * batch * v * v / t_v / 1e12 / PEAK_FP32_VECTOR_TFLOPS, 4),
+    v2v = {'kernel': 'v2v_tree_kernel (+ rows, boxes, seed, finalize)', 'bound': 'valu', 'launch_ms': round(t_v * 1e3, 4),
+           'all_pairs_equivalent_TFLOPs': round(FLOP_PER_V2V_PAIR * batch * v * v / t_v / 1e12, 2),
+           'unit': 'TFLOP/s', 'peak': PEAK_FP32_VECTOR_TFLOPS,
            'compact_layout_GBs': round(compact_bytes / t_v / 1e9, 1),
            'reference_layout_equivalent_GBs': round(ref_layout_bytes / t_v / 1e9, 1),
            'reference_layout_equivalent_frac_of_hbm': round(ref_layout_bytes / t_v / 1e9 / PEAK_HBM_GBS, 3),
-           'note': 'mask is bit-packed and L2-resident: the equivalent figure is NOT physical bandwidth'}
+           'note': 'mask is bit-packed and L2-resident and ~60 % of the rows are pruned by box distance: the '
+                   'equivalent figures are NOT physical bandwidth or executed arithmetic'}
     return roof, v2v
 
 

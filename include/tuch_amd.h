@@ -141,6 +141,13 @@ int tuch_contact_model_info(const tuch_contact_model* model, int* V, int* F, int
 int tuch_contact_model_strips(const tuch_contact_model* model, int* stream_len, int* num_strips,
                               int32_t* vidx_host, float* sign_host);
 
+/* Measurement aid for the hierarchical winding numbers inside tuch_exterior_flags: walks the cluster tree
+ * for verts [B,V,3] and reports the stream elements the wavefronts stepped through.  out_host[4] =
+ * {leaf-strip elements, cap elements, wavefronts, elements of the flat strip stream}; one element step
+ * serves 128 queries.  Workspace as for tuch_exterior_flags.  Synchronises the stream. */
+int tuch_winding_tree_work(const tuch_contact_model* model, const float* verts, int B, void* workspace,
+                           size_t workspace_bytes, unsigned long long* out_host, void* stream);
+
 /* Model-level form of tuch_v2v_min_masked: uses the model's geodesic mask and, when the model has a
  * cluster tree, a pruned walk that gives the same minima (rows whose posed box is farther than a column's
  * current minimum, or that the mask rules out entirely, are skipped).  Exact ties between rows are

@@ -324,10 +324,22 @@ __global__ __launch_bounds__(kStripBlock) void winding_strip_kernel(
 // nodes bottom-up from their children.  One workgroup per body, boxes kept in LDS.
 constexpr int kTreeQueries = 128;          // one wavefront, two queries per lane
 
+// Bounding volume of a node = 9 slabs (a 18-DOP): the coordinate axes and the six face diagonals
+// x+-y, x+-z, y+-z (unnormalised sums: rounding is monotone, so a point of the convex hull can
+// never test as outside).  Much tighter than a box around a limb that runs diagonally.
+constexpr int kSlabs = 9;
+constexpr int kSlabStride = 10;            // floats per half (9 + pad): node = [lo[10], hi[10]]
+
+__device__ __forceinline__ void slab_project(float x, float y, float z, float (&p)[kSlabs])
+{
+    p[0] = x; p[1] = y; p[2] = z;
+    p[3] = x + y; p[4] = x - y; p[5] = x + z; p[6] = x - z; p[7] = y + z; p[8] = y - z;
+}
+
 __global__ __launch_bounds__(kBoundsBlock) void tree_leaf_bounds_kernel(
     const StreamElem* __restrict__ stream, int T, const TreeNode* __restrict__ nodes, int N,
     const int32_t* __restrict__ height_off, const int32_t* __restrict__ height_nodes,
-    float* __restrict__ bounds)                  // [B,N,8] = (min xyz, -, max xyz, -)
+    float* __restrict__ bounds)                  // [B,N,2*kSlabStride]
 {
     const int b = blockIdx.y;
     const StreamElem* st = stream + (size_t)b * T;
@@ -336,23 +348,29 @@ __global__ __launch_bounds__(kBoundsBlock) void tree_leaf_bounds_kernel(
     if (i >= height_off[1]) return;
     const int node = height_nodes[i];
     const int off = nodes[node].ex_off, len = nodes[node].ex_len;
-    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    float lo[kSlabs], hi[kSlabs];
+#pragma unroll
+    for (int k = 0; k < kSlabs; ++k) { lo[k] = 3.0e38f; hi[k] = -3.0e38f; }
     for (int p = lane; p < len; p += 64) {
         const StreamElem e = st[off + p];
-        lo[0] = fminf(lo[0], e.x); lo[1] = fminf(lo[1], e.y); lo[2] = fminf(lo[2], e.z);
-        hi[0] = fmaxf(hi[0], e.x); hi[1] = fmaxf(hi[1], e.y); hi[2] = fmaxf(hi[2], e.z);
+        float pr[kSlabs];
+        slab_project(e.x, e.y, e.z, pr);
+#pragma unroll
+        for (int k = 0; k < kSlabs; ++k) { lo[k] = fminf(lo[k], pr[k]); hi[k] = fmaxf(hi[k], pr[k]); }
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < kSlabs; ++k) {
             lo[k] = fminf(lo[k], __shfl_xor(lo[k], m));
             hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m));
         }
     if (lane == 0) {
-        float* o = bounds + ((size_t)b * N + node) * 8;
-        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = 0.0f;
-        o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = 0.0f;
+        float* o = bounds + ((size_t)b * N + node) * (2 * kSlabStride);
+#pragma unroll
+        for (int k = 0; k < kSlabs; ++k) { o[k] = lo[k]; o[kSlabStride + k] = hi[k]; }
+        o[kSlabs] = 0.0f;
+        o[kSlabStride + kSlabs] = 0.0f;
     }
 }
 
@@ -377,13 +395,18 @@ __device__ __forceinline__ void run_stream(const StreamElem* __restrict__ st, in
 // contains none of the wavefront's 128 queries contributes through its boundary cap (exactly the
 // same solid angle), a leaf that does is summed face by face, an inner node that does is descended.
 // All decisions are wave-uniform.  grid (B, subtrees of the frontier, query blocks).
+// kCount: also add the number of stream elements walked (leaf strips, caps) to stats[0], stats[1]
+// (measurement only: tuch_winding_tree_work).
+template <bool kCount>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void winding_tree_kernel(
     const float* __restrict__ verts,             // [B,V,3]
     const StreamElem* __restrict__ stream,       // [B,T]
     const TreeNode* __restrict__ nodes, const float* __restrict__ bounds, int N,
     const int32_t* __restrict__ frontier, const int32_t* __restrict__ order, const int32_t* __restrict__ qperm,
-    int V, int T, int nsub, float* __restrict__ partial)   // [B,S,V]
+    int V, int T, int nsub, float* __restrict__ partial,   // [B,S,V]
+    unsigned long long* __restrict__ stats)
 {
+    int walked_exact = 0, walked_cap = 0;
     // grid (B, pairs): the body index varies fastest (XCD-aware, see winding_strip_kernel); the
     // (subtree, query block) pairs come in the model's launch order, long-running first
     const int b = blockIdx.x;
@@ -396,7 +419,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const v2f qy = {pts[3 * i0 + 1], pts[3 * i1 + 1]};
     const v2f qz = {pts[3 * i0 + 2], pts[3 * i1 + 2]};
     const StreamElem* st = stream + (size_t)b * T;
-    const float* bb = bounds + (size_t)b * N * 8;
+    const float* bb = bounds + (size_t)b * N * (2 * kSlabStride);
     Slot s[3];
     v2f d[3];
 #pragma unroll
@@ -409,15 +432,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const int end = __builtin_amdgcn_readfirstlane(nodes[node].skip);
     while (node < end) {
         const TreeNode nd = nodes[node];
-        const float* box = bb + (size_t)node * 8;
-        const float lx = box[0], ly = box[1], lz = box[2], hx = box[4], hy = box[5], hz = box[6];
-        const bool in0 = qx[0] >= lx && qx[0] <= hx && qy[0] >= ly && qy[0] <= hy && qz[0] >= lz && qz[0] <= hz;
-        const bool in1 = qx[1] >= lx && qx[1] <= hx && qy[1] >= ly && qy[1] <= hy && qz[1] >= lz && qz[1] <= hz;
-        const bool near = __builtin_amdgcn_ballot_w64(in0 || in1) != 0;
+        const float* box = bb + (size_t)node * (2 * kSlabStride);
+        // outside = some slab separates the query from the node: max_k max(lo_k - p_k, p_k - hi_k) > 0
+        // (the six diagonal projections are recomputed per node: keeping them would cost 12 VGPRs)
+        const v2f qp[kSlabs] = {qx, qy, qz, qx + qy, qx - qy, qx + qz, qx - qz, qy + qz, qy - qz};
+        v2f out = splat2(-1.0f);
+#pragma unroll
+        for (int k = 0; k < kSlabs; ++k)
+            out = __builtin_elementwise_max(out, __builtin_elementwise_max(splat2(box[k]) - qp[k], qp[k] - splat2(box[kSlabStride + k])));
+        const bool near = __builtin_amdgcn_ballot_w64(!(out[0] > 0.0f) || !(out[1] > 0.0f)) != 0;
         if (near && nd.ex_len == 0) {
             node = node + 1;
         } else {
             run_stream(st, near ? nd.ex_off : nd.cap_off, near ? nd.ex_len : nd.cap_len, s, d, qx, qy, qz, acc);
+            if (kCount) {
+                walked_exact += near ? nd.ex_len : 0;
+                walked_cap += near ? 0 : nd.cap_len;
+            }
             node = nd.skip;
         }
         node = __builtin_amdgcn_readfirstlane(node);
@@ -425,6 +456,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     float* out = partial + ((size_t)b * nsub + sub) * V;
     out[i0] = acc[0];
     out[i1] = acc[1];
+    if (kCount && threadIdx.x == 0) {
+        atomicAdd(stats, (unsigned long long)walked_exact);
+        atomicAdd(stats + 1, (unsigned long long)walked_cap);
+    }
 }
 
 // ---- body segments (tuch/utils/segmentation.py) ---------------------------------
@@ -605,7 +640,7 @@ int choose_strip_splits(int B, int Q, int L)
 }
 
 struct ExteriorLayout {
-    size_t tris, partial, bounds, caps, seg_tris, seg_partial, seg_count, seg_list, total;
+    size_t tris, partial, bounds, stats, caps, seg_tris, seg_partial, seg_count, seg_list, total;
     int lpad;
     int tree_frontier;         // frontier used by the hierarchical path (-1: flat path)
     int tree_subs;
@@ -656,7 +691,8 @@ ExteriorLayout exterior_layout(const tuch_contact_model* m, int B)
     }
     l.tris = o;     o += align256(tri_bytes > strip_bytes ? tri_bytes : strip_bytes);
     l.partial = o;  o += align256((size_t)B * max_splits * m->V * sizeof(float));
-    l.bounds = o;   o += align256((size_t)B * (m->tree_nodes > 0 ? m->tree_nodes : 1) * 8 * sizeof(float));
+    l.bounds = o;   o += align256((size_t)B * (m->tree_nodes > 0 ? m->tree_nodes : 1) * 2 * kSlabStride * sizeof(float));
+    l.stats = o;    o += 256;
     l.caps = o;     o += align256((size_t)B * (m->num_caps > 0 ? m->num_caps : 1) * 3 * sizeof(float));
     l.seg_tris = o; o += align256(((size_t)B * (m->seg_f_total > 0 ? m->seg_f_total : 1) + 1) * 9 * sizeof(float));
     l.seg_partial = o; o += align256((size_t)B * kSegSplits * (m->seg_q_total > 0 ? m->seg_q_total : 1) * sizeof(float));
@@ -673,6 +709,36 @@ int choose_splits(int B, int Q, int F)
     int s = 1;
     while (s < 16 && (long)B * qblocks * s < 2048 && F / (s * 2) >= 512) s *= 2;
     return s;
+}
+
+// gather the posed stream, box every node, walk the tree: partial sums into ws + l.partial
+void launch_tree_walk(const tuch_contact_model* m, const ExteriorLayout& l, const float* verts, int B, char* ws,
+                      unsigned long long* stats, hipStream_t s)
+{
+    StreamElem* st = (StreamElem*)(ws + l.tris);
+    const int T = m->tree_stream_len + 3;
+    float* bounds = (float*)(ws + l.bounds);
+    hipLaunchKernelGGL(gather_stream_kernel, dim3(ceil_div(T, kBlock), B), dim3(kBlock), 0, s, verts,
+                       (const int32_t*)m->tree_vidx, (const float*)m->tree_sign, m->V, m->tree_stream_len, T, st);
+    hipLaunchKernelGGL(tree_leaf_bounds_kernel, dim3(ceil_div(m->tree_leaves, kBoundsBlock / 64), B),
+                       dim3(kBoundsBlock), 0, s, (const StreamElem*)st, T, (const TreeNode*)m->tree_node,
+                       m->tree_nodes, (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, bounds);
+    hipLaunchKernelGGL(tree_inner_bounds_kernel<kSlabStride>, dim3(B), dim3(kBoundsBlock),
+                       (size_t)m->tree_nodes * 2 * kSlabStride * sizeof(float), s, (const TreeNode*)m->tree_node, m->tree_nodes,
+                       (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, m->tree_heights,
+                       bounds);
+    const int f0 = m->tree_frontier_off_host[l.tree_frontier];
+    const dim3 grid(B, l.tree_subs * m->tree_qblocks);
+    const int32_t* frontier = (const int32_t*)m->tree_frontier_nodes + f0;
+    const int32_t* order = (const int32_t*)m->tree_launch_order + (size_t)f0 * m->tree_qblocks;
+    if (stats)
+        hipLaunchKernelGGL(winding_tree_kernel<true>, grid, dim3(64), 0, s, verts, (const StreamElem*)st,
+                           (const TreeNode*)m->tree_node, (const float*)bounds, m->tree_nodes, frontier, order,
+                           (const int32_t*)m->tree_qperm, m->V, T, l.tree_subs, (float*)(ws + l.partial), stats);
+    else
+        hipLaunchKernelGGL(winding_tree_kernel<false>, grid, dim3(64), 0, s, verts, (const StreamElem*)st,
+                           (const TreeNode*)m->tree_node, (const float*)bounds, m->tree_nodes, frontier, order,
+                           (const int32_t*)m->tree_qperm, m->V, T, l.tree_subs, (float*)(ws + l.partial), stats);
 }
 
 }  // namespace
@@ -752,24 +818,7 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
     hipStream_t s = (hipStream_t)stream;
     int rc = TUCH_OK;
     if (use_strips() && use_tree(m)) {
-        StreamElem* st = (StreamElem*)tris;
-        const int T = m->tree_stream_len + 3;
-        float* bounds = (float*)(ws + l.bounds);
-        hipLaunchKernelGGL(gather_stream_kernel, dim3(ceil_div(T, kBlock), B), dim3(kBlock), 0, s, verts,
-                           (const int32_t*)m->tree_vidx, (const float*)m->tree_sign, m->V, m->tree_stream_len, T, st);
-        hipLaunchKernelGGL(tree_leaf_bounds_kernel, dim3(ceil_div(m->tree_leaves, kBoundsBlock / 64), B),
-                           dim3(kBoundsBlock), 0, s, (const StreamElem*)st, T, (const TreeNode*)m->tree_node,
-                           m->tree_nodes, (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, bounds);
-        hipLaunchKernelGGL(tree_inner_bounds_kernel, dim3(B), dim3(kBoundsBlock),
-                           (size_t)m->tree_nodes * 8 * sizeof(float), s, (const TreeNode*)m->tree_node, m->tree_nodes,
-                           (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, m->tree_heights,
-                           bounds);
-        const int f0 = m->tree_frontier_off_host[l.tree_frontier];
-        hipLaunchKernelGGL(winding_tree_kernel, dim3(B, l.tree_subs * m->tree_qblocks), dim3(64), 0, s, verts,
-                           (const StreamElem*)st, (const TreeNode*)m->tree_node, (const float*)bounds, m->tree_nodes,
-                           (const int32_t*)m->tree_frontier_nodes + f0,
-                           (const int32_t*)m->tree_launch_order + (size_t)f0 * m->tree_qblocks,
-                           (const int32_t*)m->tree_qperm, m->V, T, l.tree_subs, (float*)(ws + l.partial));
+        launch_tree_walk(m, l, verts, B, ws, nullptr, s);
         hipLaunchKernelGGL(winding_finalize_kernel, dim3(ceil_div(m->V, kBlock), B), dim3(kBlock), 0, s,
                            (const float*)(ws + l.partial), m->V, l.tree_subs, thresh, w, exterior);
     } else if (use_strips() && m->strip_len > 0) {
@@ -823,6 +872,36 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
                            m->V, m->seg_q_total, m->num_segments, seg_splits(), thresh, seg_w, seg_exterior, exterior);
     }
     return tuch_check_launch("tuch_exterior_flags");
+}
+
+// Measurement aid: walk the tree for `verts` and report how many stream elements the wavefronts
+// actually stepped through.  out_host = {leaf-strip elements, cap elements, wavefronts, elements of
+// the flat strip stream (what every 128-query block would step through without the tree)}.
+// One element step serves 128 queries.  Synchronises the stream.
+extern "C" int tuch_winding_tree_work(const tuch_contact_model* m, const float* verts, int B,
+                                      void* workspace, size_t workspace_bytes, unsigned long long* out_host, void* stream)
+{
+    TUCH_REQUIRE(m && verts && out_host, "tuch_winding_tree_work: null pointer");
+    TUCH_REQUIRE(m->tree_nodes > 0, "tuch_winding_tree_work: the model has no cluster tree");
+    TUCH_REQUIRE(B > 0 && B <= 65535, "tuch_winding_tree_work: bad batch %d", B);
+    const ExteriorLayout l = exterior_layout(m, B);
+    if (!workspace || workspace_bytes < l.total) {
+        tuch_set_error("tuch_winding_tree_work: workspace %zu < %zu bytes", workspace_bytes, l.total);
+        return TUCH_ERR_WORKSPACE;
+    }
+    char* ws = (char*)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long* stats = (unsigned long long*)(ws + l.stats);
+    if (hipMemsetAsync(stats, 0, 2 * sizeof(unsigned long long), s) != hipSuccess) return TUCH_ERR_HIP;
+    launch_tree_walk(m, l, verts, B, ws, stats, s);
+    if (hipMemcpyAsync(out_host, stats, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) {
+        tuch_set_error("tuch_winding_tree_work: copy back failed");
+        return TUCH_ERR_HIP;
+    }
+    out_host[2] = (unsigned long long)B * l.tree_subs * m->tree_qblocks;
+    out_host[3] = (unsigned long long)m->strip_len;
+    return tuch_check_launch("tuch_winding_tree_work");
 }
 
 // winding numbers of ARBITRARY query points against the model's mesh posed by `verts`

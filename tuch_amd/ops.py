@@ -372,6 +372,18 @@ class ContactModel:
                                              sign.ctypes.data_as(ctypes.c_void_p)))
         return vidx, sign, k.value
 
+    def winding_tree_work(self, verts: torch.Tensor) -> dict:
+        """Stream elements the hierarchical winding walk steps through for these vertices (measurement aid)."""
+        verts = _f32(verts)
+        b = verts.shape[0]
+        L = _C.lib()
+        nbytes = L.tuch_exterior_workspace_bytes(self._handle, b)
+        ws = _workspace(nbytes, verts.device)
+        out = (ctypes.c_ulonglong * 4)()
+        _C.check(L.tuch_winding_tree_work(self._handle, _C.ptr(verts), b, _C.ptr(ws), nbytes, out, _C.stream()))
+        return dict(leaf_elements=int(out[0]), cap_elements=int(out[1]), wavefronts=int(out[2]),
+                    flat_stream_elements=int(out[3]), query_blocks=-(-self.num_verts // 128) * b)
+
     # K2 + K3
     def exterior_flags(self, verts: torch.Tensor, apply_segments: bool = True, thresh: float = 0.99,
                        return_details: bool = False):
