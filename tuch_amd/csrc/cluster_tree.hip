@@ -519,6 +519,13 @@ bool tuch_cluster_tree_build_impl(int V, int F, const int32_t* faces, int leaf_f
             return a.first < b.first;
         });
         for (auto& c : cost) t.launch_order.push_back(c.second);
+        // the first 8 ancestors (root first) of every frontier node; preorder: a is an ancestor of n iff a < n < skip[a]
+        for (size_t si = 0; si < fr.size(); ++si) {
+            int count = 0;
+            for (int a = 0; a < fr[si] && count < 8; ++a)
+                if (t.nodes[(size_t)a * 8 + 4] > fr[si]) { t.ancestors.push_back(a); ++count; }
+            for (; count < 8; ++count) t.ancestors.push_back(-1);
+        }
         t.frontier_nodes.insert(t.frontier_nodes.end(), fr.begin(), fr.end());
         t.frontier_off.push_back((int)t.frontier_nodes.size());
     }

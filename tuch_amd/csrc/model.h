@@ -17,6 +17,7 @@ struct tuch_cluster_tree {
     std::vector<int32_t> frontier_off, frontier_nodes;
     // per frontier f, at frontier_off[f] * num_qblocks: (subtree index << 16 | query block), heavy first
     std::vector<int32_t> launch_order;
+    std::vector<int32_t> ancestors;                   // [frontier_total][8]: ancestors of a frontier node, root first, -1 padded
     // rows [num_nodes][2]: the positions in qperm of the vertices below a node (first, count); every
     // vertex belongs to exactly one leaf (the first leaf in preorder that touches it)
     std::vector<int32_t> rows;
@@ -47,6 +48,7 @@ struct tuch_contact_model {
     int32_t* tree_height_nodes;
     int32_t* tree_frontier_nodes;
     int32_t* tree_launch_order;
+    int32_t* tree_ancestors;   // [frontier_total][8]
     int32_t* tree_rows;        // [tree_nodes][2]
     // geodesic mask in the tree's vertex order: tree_mask_bits[w][j'], bit k = geomask[qperm[j']][qperm[64 w + k]],
     // w < 2 * tree_qblocks, j' < V; tree_masked[qb][node] != 0: no allowed pair between query block qb and the node

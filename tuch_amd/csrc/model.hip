@@ -40,7 +40,7 @@ extern "C" void tuch_contact_model_destroy(tuch_contact_model* m)
 {
     if (!m) return;
     void* dev[] = {m->faces, m->mask_bits, m->strip_vidx, m->strip_sign, m->tree_node, m->tree_vidx, m->tree_sign, m->tree_qperm,
-                   m->tree_height_off, m->tree_height_nodes, m->tree_frontier_nodes, m->tree_launch_order, m->tree_rows, m->tree_mask_bits, m->tree_masked, m->seg_blocks, m->seg_of_q, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces,
+                   m->tree_height_off, m->tree_height_nodes, m->tree_frontier_nodes, m->tree_launch_order, m->tree_ancestors, m->tree_rows, m->tree_mask_bits, m->tree_masked, m->seg_blocks, m->seg_of_q, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces,
                    m->cap_off, m->cap_vidx, m->region_off, m->region_vidx, m->pairs, m->pair_mask, m->pair_mask_off};
     for (void* p : dev)
         if (p) (void)hipFree(p);
@@ -107,6 +107,7 @@ extern "C" int tuch_contact_model_create(
             if (rc == TUCH_OK) rc = upload(&m->tree_height_nodes, t.height_nodes.data(), t.height_nodes.size());
             if (rc == TUCH_OK) rc = upload(&m->tree_frontier_nodes, t.frontier_nodes.data(), t.frontier_nodes.size());
             if (rc == TUCH_OK) rc = upload(&m->tree_launch_order, t.launch_order.data(), t.launch_order.size());
+            if (rc == TUCH_OK) rc = upload(&m->tree_ancestors, t.ancestors.data(), t.ancestors.size());
             if (rc == TUCH_OK) rc = upload(&m->tree_rows, t.rows.data(), t.rows.size());
             if (rc == TUCH_OK && geomask) {
                 // the mask in the tree's vertex order, and which (query block, node) pairs it rules out entirely

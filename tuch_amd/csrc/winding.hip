@@ -159,6 +159,23 @@ __global__ __launch_bounds__(kBlock) void winding_finalize_kernel(
     if (exterior) exterior[(size_t)b * Q + q] = val <= thresh ? 1 : 0;
 }
 
+// the same for partial sums stored in the cluster tree's query order: position i holds vertex qperm[i]
+__global__ __launch_bounds__(kBlock) void winding_finalize_tree_kernel(
+    const float* __restrict__ partial, const int32_t* __restrict__ qperm, int V, int Vp, int nsplit, float thresh,
+    float* __restrict__ w, uint8_t* __restrict__ exterior)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= V) return;                              // positions >= V repeat the last vertex
+    const float* p = partial + (size_t)b * nsplit * Vp + i;
+    float acc = 0.0f;
+    for (int s = 0; s < nsplit; ++s) acc += p[(size_t)s * Vp];
+    const float val = acc * (0.5f / kPi);
+    const int q = qperm[i];
+    if (w) w[(size_t)b * V + q] = val;
+    if (exterior) exterior[(size_t)b * V + q] = val <= thresh ? 1 : 0;
+}
+
 // contact.py:49-109 materialised (API parity; small inputs): out[b][q][f] = 2*atan2(...)
 __global__ __launch_bounds__(kBlock) void solid_angles_kernel(
     const float* __restrict__ points, const float* __restrict__ tris, int Q, int F,
@@ -397,13 +414,20 @@ __device__ __forceinline__ void run_stream(const StreamElem* __restrict__ st, in
 // All decisions are wave-uniform.  grid (B, subtrees of the frontier, query blocks).
 // kCount: also add the number of stream elements walked (leaf strips, caps) to stats[0], stats[1]
 // (measurement only: tuch_winding_tree_work).
+// The nodes above the frontier are handled without a pass of their own: every wavefront first tests
+// the ancestors of its subtree top-down (a static list).  At the first ancestor that is far, the
+// wavefront of the ancestor's FIRST frontier subtree adds the ancestor's cap and all others leave,
+// so splitting the tree into many subtrees (load balance) does not cost one cap per far subtree.
+constexpr int kMaxAncestors = 8;           // deeper ancestors are simply never replaced by their caps
+
 template <bool kCount>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void winding_tree_kernel(
     const float* __restrict__ verts,             // [B,V,3]
     const StreamElem* __restrict__ stream,       // [B,T]
     const TreeNode* __restrict__ nodes, const float* __restrict__ bounds, int N,
-    const int32_t* __restrict__ frontier, const int32_t* __restrict__ order, const int32_t* __restrict__ qperm,
-    int V, int T, int nsub, float* __restrict__ partial,   // [B,S,V]
+    const int32_t* __restrict__ frontier, const int32_t* __restrict__ ancestors,   // [S], [S][kMaxAncestors]
+    const int32_t* __restrict__ order, const int32_t* __restrict__ qperm,
+    int V, int T, int nsub, float* __restrict__ partial,   // [B,S,qblocks*128]
     unsigned long long* __restrict__ stats)
 {
     int walked_exact = 0, walked_cap = 0;
@@ -428,10 +452,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         d[k] = splat2(0.0f);
     }
     v2f acc = splat2(0.0f);
-    int node = __builtin_amdgcn_readfirstlane(frontier[sub]);
-    const int end = __builtin_amdgcn_readfirstlane(nodes[node].skip);
-    while (node < end) {
-        const TreeNode nd = nodes[node];
+    // near = some query of the wavefront is inside all slabs of the node (wave-uniform)
+    auto is_near = [&](int node) {
         const float* box = bb + (size_t)node * (2 * kSlabStride);
         // outside = some slab separates the query from the node: max_k max(lo_k - p_k, p_k - hi_k) > 0
         // (the six diagonal projections are recomputed per node: keeping them would cost 12 VGPRs)
@@ -440,7 +462,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 #pragma unroll
         for (int k = 0; k < kSlabs; ++k)
             out = __builtin_elementwise_max(out, __builtin_elementwise_max(splat2(box[k]) - qp[k], qp[k] - splat2(box[kSlabStride + k])));
-        const bool near = __builtin_amdgcn_ballot_w64(!(out[0] > 0.0f) || !(out[1] > 0.0f)) != 0;
+        return __builtin_amdgcn_ballot_w64(!(out[0] > 0.0f) || !(out[1] > 0.0f)) != 0;
+    };
+    // partial sums are stored in the tree's query order (coalesced); the finalize kernel un-permutes
+    float* out = partial + ((size_t)b * nsub + sub) * (gridDim.y / nsub * kTreeQueries) + qb * kTreeQueries;
+    int node = __builtin_amdgcn_readfirstlane(frontier[sub]);
+    int end = __builtin_amdgcn_readfirstlane(nodes[node].skip);
+    const int32_t* anc = ancestors + (size_t)sub * kMaxAncestors;
+    for (int k = 0; k < kMaxAncestors; ++k) {
+        const int x = __builtin_amdgcn_readfirstlane(anc[k]);
+        if (x < 0) break;
+        if (is_near(x)) continue;
+        // far ancestor: its cap stands for all frontier subtrees below it
+        const bool first = sub == 0 || __builtin_amdgcn_readfirstlane(frontier[sub - 1]) < x;
+        if (first) {
+            const TreeNode nd = nodes[x];
+            run_stream(st, nd.cap_off, nd.cap_len, s, d, qx, qy, qz, acc);
+            if (kCount) walked_cap += nd.cap_len;
+        }
+        end = node;                                // nothing left to walk
+        break;
+    }
+    while (node < end) {
+        const TreeNode nd = nodes[node];
+        const bool near = is_near(node);
         if (near && nd.ex_len == 0) {
             node = node + 1;
         } else {
@@ -453,9 +498,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         }
         node = __builtin_amdgcn_readfirstlane(node);
     }
-    float* out = partial + ((size_t)b * nsub + sub) * V;
-    out[i0] = acc[0];
-    out[i1] = acc[1];
+    out[threadIdx.x] = acc[0];
+    out[64 + threadIdx.x] = acc[1];
     if (kCount && threadIdx.x == 0) {
         atomicAdd(stats, (unsigned long long)walked_exact);
         atomicAdd(stats + 1, (unsigned long long)walked_cap);
@@ -659,7 +703,7 @@ bool use_tree(const tuch_contact_model* m)
 int choose_frontier(const tuch_contact_model* m, int B)
 {
     const char* e = getenv("TUCH_TREE_WAVES");
-    const long target = e ? atol(e) : 32768L;
+    const long target = e ? atol(e) : 65536L;
     int f = 0;
     while (f + 1 < m->tree_num_frontiers &&
            (long)B * m->tree_qblocks * (m->tree_frontier_off_host[f + 1] - m->tree_frontier_off_host[f]) < target) ++f;
@@ -690,7 +734,7 @@ ExteriorLayout exterior_layout(const tuch_contact_model* m, int B)
         if (l.tree_subs > max_splits) max_splits = l.tree_subs;
     }
     l.tris = o;     o += align256(tri_bytes > strip_bytes ? tri_bytes : strip_bytes);
-    l.partial = o;  o += align256((size_t)B * max_splits * m->V * sizeof(float));
+    l.partial = o;  o += align256((size_t)B * max_splits * (m->V + 128) * sizeof(float));
     l.bounds = o;   o += align256((size_t)B * (m->tree_nodes > 0 ? m->tree_nodes : 1) * 2 * kSlabStride * sizeof(float));
     l.stats = o;    o += 256;
     l.caps = o;     o += align256((size_t)B * (m->num_caps > 0 ? m->num_caps : 1) * 3 * sizeof(float));
@@ -730,14 +774,15 @@ void launch_tree_walk(const tuch_contact_model* m, const ExteriorLayout& l, cons
     const int f0 = m->tree_frontier_off_host[l.tree_frontier];
     const dim3 grid(B, l.tree_subs * m->tree_qblocks);
     const int32_t* frontier = (const int32_t*)m->tree_frontier_nodes + f0;
+    const int32_t* ancestors = (const int32_t*)m->tree_ancestors + (size_t)f0 * kMaxAncestors;
     const int32_t* order = (const int32_t*)m->tree_launch_order + (size_t)f0 * m->tree_qblocks;
     if (stats)
         hipLaunchKernelGGL(winding_tree_kernel<true>, grid, dim3(64), 0, s, verts, (const StreamElem*)st,
-                           (const TreeNode*)m->tree_node, (const float*)bounds, m->tree_nodes, frontier, order,
+                           (const TreeNode*)m->tree_node, (const float*)bounds, m->tree_nodes, frontier, ancestors, order,
                            (const int32_t*)m->tree_qperm, m->V, T, l.tree_subs, (float*)(ws + l.partial), stats);
     else
         hipLaunchKernelGGL(winding_tree_kernel<false>, grid, dim3(64), 0, s, verts, (const StreamElem*)st,
-                           (const TreeNode*)m->tree_node, (const float*)bounds, m->tree_nodes, frontier, order,
+                           (const TreeNode*)m->tree_node, (const float*)bounds, m->tree_nodes, frontier, ancestors, order,
                            (const int32_t*)m->tree_qperm, m->V, T, l.tree_subs, (float*)(ws + l.partial), stats);
 }
 
@@ -819,8 +864,9 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
     int rc = TUCH_OK;
     if (use_strips() && use_tree(m)) {
         launch_tree_walk(m, l, verts, B, ws, nullptr, s);
-        hipLaunchKernelGGL(winding_finalize_kernel, dim3(ceil_div(m->V, kBlock), B), dim3(kBlock), 0, s,
-                           (const float*)(ws + l.partial), m->V, l.tree_subs, thresh, w, exterior);
+        hipLaunchKernelGGL(winding_finalize_tree_kernel, dim3(ceil_div(m->V, kBlock), B), dim3(kBlock), 0, s,
+                           (const float*)(ws + l.partial), (const int32_t*)m->tree_qperm, m->V,
+                           m->tree_qblocks * kTreeQueries, l.tree_subs, thresh, w, exterior);
     } else if (use_strips() && m->strip_len > 0) {
         StreamElem* st = (StreamElem*)tris;
         hipLaunchKernelGGL(gather_stream_kernel, dim3(ceil_div(l.lpad, kBlock), B), dim3(kBlock), 0, s, verts,
