@@ -79,8 +79,7 @@ class EFTLoss(nn.Module):
 
     def contact_loss(self, gt_contact, verts):
         model = self._model
-        exterior = model.exterior_flags(verts, apply_segments=self.segments is not None)
-        _, partner = model.v2v_min(verts)
+        exterior, _, partner, _ = model.exterior_and_partner(verts, apply_segments=self.segments is not None)
         _, terms = ops.contact_terms(verts, partner, exterior, None, ops.MODE_TRAIN, 0.0)
         n_ext = exterior.to(torch.float32).sum(dim=1)
         n_int = exterior.shape[1] - n_ext

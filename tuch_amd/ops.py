@@ -6,6 +6,7 @@ eager/CPU fallback.  Index outputs are int64 like the reference's torch ops.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -19,6 +20,16 @@ MODE_TRAIN = 1     # tuch/train/loss.py:303-315
 
 def _f32(t: torch.Tensor) -> torch.Tensor:
     return t.detach().to(torch.float32).contiguous()
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device) -> 'torch.cuda.Stream':
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
@@ -371,6 +382,28 @@ class ContactModel:
         _C.check(L.tuch_contact_model_strips(self._handle, None, None, vidx.ctypes.data_as(ctypes.c_void_p),
                                              sign.ctypes.data_as(ctypes.c_void_p)))
         return vidx, sign, k.value
+
+    def exterior_and_partner(self, verts: torch.Tensor, apply_segments: bool = True, also=None):
+        """exterior_flags + v2v_min of the same vertices -> (exterior, min_d2, partner[, also()]).
+        The two only share their input: the nearest-vertex search (and the optional callable ``also``,
+        e.g. the region pairs) runs on a second stream so that its tail fills the gaps of the long winding
+        walk (TUCH_OVERLAP=0 keeps everything on the current stream)."""
+        if not (verts.is_cuda and os.environ.get('TUCH_OVERLAP', '1') != '0'):
+            exterior = self.exterior_flags(verts, apply_segments=apply_segments)
+            mn, partner = self.v2v_min(verts)
+            return exterior, mn, partner, (also() if also is not None else None)
+        cur = torch.cuda.current_stream(verts.device)
+        side = _side_stream(verts.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            mn, partner = self.v2v_min(verts)
+            extra = also() if also is not None else None
+        exterior = self.exterior_flags(verts, apply_segments=apply_segments)
+        cur.wait_stream(side)
+        for t in (mn, partner) + (tuple(extra) if isinstance(extra, (tuple, list)) else (extra,)):
+            if torch.is_tensor(t):
+                t.record_stream(cur)
+        return exterior, mn, partner, extra
 
     def winding_tree_work(self, verts: torch.Tensor) -> dict:
         """Stream elements the hierarchical winding walk steps through for these vertices (measurement aid)."""

@@ -83,17 +83,19 @@ def contact_fitting_loss(body_pose, global_orient, body_pose_loop1, opt_global_o
     from .prior import MaxMixturePrior
     model = contact_model_for(geomask, face_tensor, segments, cdict, device=verts.device)
     valid = ops.cached_derived((ignore_idxs,), lambda: (~ignore_idxs).to(torch.uint8).contiguous())
-    exterior = model.exterior_flags(verts, apply_segments=segments is not None)     # losses.py:79-89
-    _, partner = model.v2v_min(verts)                                               # losses.py:76-78,92-93
-    contact_loss, contact_terms = ops.contact_terms(verts, partner, exterior, valid, ops.MODE_SMPLIFY, euclthres)
-
-    r2r = None
+    select = None
     if model.num_pairs > 0 and gt_contact is not None and gt_contact[0] is not None:
         select = ops.cached_derived(
             (gt_contact[0], has_discrete_contact, ignore_idxs),
             lambda: ((gt_contact[0] == 1) & has_discrete_contact.bool()[:, None]
                      & (~ignore_idxs)[:, None]).to(torch.uint8).contiguous())
-        r2r, _ = model.region_pair_min(verts, select=select, masked=True)           # losses.py:107-117
+    pairs = None
+    if select is not None:
+        pairs = lambda: model.region_pair_min(verts, select=select, masked=True)        # losses.py:107-117
+    # losses.py:79-89 (inside test) and losses.py:76-78,92-93 (nearest geodesically-far vertex)
+    exterior, _, partner, extra = model.exterior_and_partner(verts, apply_segments=segments is not None, also=pairs)
+    r2r = extra[0] if extra is not None else None
+    contact_loss, contact_terms = ops.contact_terms(verts, partner, exterior, valid, ops.MODE_SMPLIFY, euclthres)
 
     fused = (isinstance(pose_prior, MaxMixturePrior) and pose_prior.use_merged and verts.is_cuda
              and not torch.is_tensor(focal_length) and body_pose.shape[1] == 69)

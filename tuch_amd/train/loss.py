@@ -69,8 +69,8 @@ class RegressorLoss(nn.Module):
         model = self._model
         valid = valid_fit.bool()
         valid_u8 = valid.to(torch.uint8).contiguous()
-        exterior = model.exterior_flags(pred_vertices, apply_segments=self.segments is not None)
-        min_d2, partner = model.v2v_min(pred_vertices)
+        exterior, min_d2, partner, _ = model.exterior_and_partner(pred_vertices,
+                                                                  apply_segments=self.segments is not None)
         n_valid = valid.sum().to(torch.float32)
         if not self.use_hd:
             per_body, _ = ops.contact_terms(pred_vertices, partner, exterior, valid_u8, ops.MODE_TRAIN,
