@@ -230,6 +230,20 @@ int tuch_smpl_backward(const tuch_smpl_model* model, const float* pose, int pose
                        const void* fwd_workspace, const float* g_verts, const float* g_joints, float* g_betas,
                        float* g_pose, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- caller-side glue of the training step ----------------------------------------
+ * tuch_estimate_translation: tuch/utils/geometry.py:114-205 (estimate_translation + estimate_translation_np):
+ * camera translation [B,3] that best projects the model joints onto the 2D keypoints (weighted least squares,
+ * weights sqrt(conf)); joints3d [B,J,3], keypoints2d [B,J,3] = (u, v, conf), J = 49; has_anno[b] selects the
+ * ground-truth joints [25,J) else the OpenPose joints [0,25); samples whose confidences sum to 0 get zeros.
+ * float64 inside, like the reference's numpy.
+ * tuch_rotmat_to_angle_axis: torchgeometry 0.1.2 rotation_matrix_to_angle_axis as called at
+ * tuch/train/train_module.py:208-212 and demo_smplify_dc.py:128-132; rotmat [N,3,row_stride] with
+ * row_stride 3 or 4 (the callers append a homogeneous column); NaN entries propagate and
+ * are zeroed by the callers (train_module.py:212). */
+int tuch_estimate_translation(const float* joints3d, const float* keypoints2d, const uint8_t* has_anno, int B, int J,
+                              float focal_length, float img_size, float* trans, void* stream);
+int tuch_rotmat_to_angle_axis(const float* rotmat, int N, int row_stride, float* angle_axis, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

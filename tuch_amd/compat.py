@@ -43,4 +43,24 @@ def install(overwrite: bool = True):
         parent, _, leaf = ref_name.rpartition('.')
         setattr(sys.modules[parent], leaf, mod)
         installed.append(ref_name)
+    if install_torchgeometry():
+        installed.append('torchgeometry')
     return installed
+
+
+def install_torchgeometry() -> bool:
+    """The reference imports two functions from torchgeometry==0.1.2 (train_module.py:27,
+    demo_smplify_dc.py:33, fits_dict.py:25).  When that package is absent, a module of that name
+    with exactly these two is registered (our device implementations); a real installation is left alone."""
+    try:
+        importlib.import_module('torchgeometry')
+        return False
+    except ImportError:
+        pass
+    from .utils import geometry
+    mod = types.ModuleType('torchgeometry')
+    mod.rotation_matrix_to_angle_axis = geometry.rotation_matrix_to_angle_axis
+    mod.angle_axis_to_rotation_matrix = geometry.angle_axis_to_rotation_matrix
+    mod.__version__ = '0.1.2+tuch_amd'
+    sys.modules['torchgeometry'] = mod
+    return True
