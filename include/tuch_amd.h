@@ -166,7 +166,8 @@ int tuch_v2v_min_model(const tuch_contact_model* model, const float* verts, int 
  * frontier_nodes[frontier_off[f] .. frontier_off[f+1]) = subtrees that together cover the mesh;
  * launch_order [frontier_total * num_qblocks] = per frontier (at frontier_off[f] * num_qblocks) the
  * (subtree index << 16 | query block) pairs, the long-running ones first; rows [num_nodes][2] = (first
- * position, count) in qperm of the vertices below a node (each vertex belongs to one leaf).
+ * position, count) in qperm of the vertices below a node (each vertex belongs to one leaf); face_leaf [F] =
+ * sequence number of the leaf holding each face (sort query points by it to make them coherent).
  * tuch_contact_model_create builds the same tree internally.  Fails (TUCH_ERR_ARG) for a mesh that is
  * not a closed, consistently oriented manifold; the library then keeps the flat evaluation. */
 typedef struct tuch_cluster_tree tuch_cluster_tree;
@@ -176,7 +177,7 @@ int tuch_cluster_tree_info(const tuch_cluster_tree* tree, int* num_nodes, int* e
                            int* num_qblocks, int* num_frontiers, int* frontier_total);
 int tuch_cluster_tree_export(const tuch_cluster_tree* tree, int32_t* nodes, int32_t* vidx, float* sign,
                              int32_t* qperm, int32_t* frontier_off, int32_t* frontier_nodes,
-                             int32_t* launch_order, int32_t* rows);
+                             int32_t* launch_order, int32_t* rows, int32_t* face_leaf);
 
 /* exterior flags of losses.py:79-89 / loss.py:259-266: winding_numbers(verts, verts[faces]).le(thresh),
  * then BatchBodySegment.batch_has_self_isec (segmentation.py:117-124) and the re-marking of

@@ -54,7 +54,7 @@ _SIGNATURES = {
     'tuch_cluster_tree_build': (c_int, [c_int, c_int, c_void_p, c_int, POINTER(c_void_p)]),
     'tuch_cluster_tree_free': (None, [c_void_p]),
     'tuch_cluster_tree_info': (c_int, [c_void_p] + [POINTER(c_int)] * 6),
-    'tuch_cluster_tree_export': (c_int, [c_void_p] * 9),
+    'tuch_cluster_tree_export': (c_int, [c_void_p] * 10),
     'tuch_estimate_translation': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p]),
     'tuch_rotmat_to_angle_axis': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'tuch_winding_tree_work': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),

@@ -398,6 +398,7 @@ bool tuch_cluster_tree_build_impl(int V, int F, const int32_t* faces, int leaf_f
 
     // ---- exact streams of the leaves (in preorder), then the cap streams of all nodes
     t.num_nodes = N;
+    t.face_leaf.assign(F, 0);
     t.nodes.assign((size_t)N * 8, 0);
     std::vector<int32_t> sub;
     std::vector<int> leaf_seq(N, -1);
@@ -411,6 +412,7 @@ bool tuch_cluster_tree_build_impl(int V, int F, const int32_t* faces, int leaf_f
         nd[7] = (int)g.faces.size();
         if (g.c0 >= 0) continue;
         leaf_seq[i] = nleaves_seen++;
+        for (int f : g.faces) t.face_leaf[f] = leaf_seq[i];
         sub.clear();
         for (int f : g.faces) { sub.push_back(faces[3 * f]); sub.push_back(faces[3 * f + 1]); sub.push_back(faces[3 * f + 2]); }
         const size_t begin = t.vidx.size();
@@ -564,7 +566,7 @@ extern "C" int tuch_cluster_tree_info(const tuch_cluster_tree* t, int* num_nodes
 
 extern "C" int tuch_cluster_tree_export(const tuch_cluster_tree* t, int32_t* nodes, int32_t* vidx, float* sign,
                                         int32_t* qperm, int32_t* frontier_off, int32_t* frontier_nodes,
-                                        int32_t* launch_order, int32_t* rows)
+                                        int32_t* launch_order, int32_t* rows, int32_t* face_leaf)
 {
     TUCH_REQUIRE(t, "tuch_cluster_tree_export: null tree");
     if (nodes) memcpy(nodes, t->nodes.data(), t->nodes.size() * sizeof(int32_t));
@@ -575,5 +577,6 @@ extern "C" int tuch_cluster_tree_export(const tuch_cluster_tree* t, int32_t* nod
     if (frontier_nodes) memcpy(frontier_nodes, t->frontier_nodes.data(), t->frontier_nodes.size() * sizeof(int32_t));
     if (launch_order) memcpy(launch_order, t->launch_order.data(), t->launch_order.size() * sizeof(int32_t));
     if (rows) memcpy(rows, t->rows.data(), t->rows.size() * sizeof(int32_t));
+    if (face_leaf) memcpy(face_leaf, t->face_leaf.data(), t->face_leaf.size() * sizeof(int32_t));
     return TUCH_OK;
 }

@@ -21,6 +21,7 @@ struct tuch_cluster_tree {
     // rows [num_nodes][2]: the positions in qperm of the vertices below a node (first, count); every
     // vertex belongs to exactly one leaf (the first leaf in preorder that touches it)
     std::vector<int32_t> rows;
+    std::vector<int32_t> face_leaf;                   // [F]: sequence number (preorder) of the leaf that holds the face
 };
 
 bool tuch_cluster_tree_build_impl(int V, int F, const int32_t* faces, int leaf_faces, tuch_cluster_tree& t);

@@ -145,15 +145,15 @@ __global__ __launch_bounds__(kBlock) void winding_partial_kernel(
 
 // w = (2 / 4pi) * sum_s partial, exterior = w <= thresh (losses.py:82, loss.py:262)
 __global__ __launch_bounds__(kBlock) void winding_finalize_kernel(
-    const float* __restrict__ partial, int Q, int nsplit, float thresh,
+    const float* __restrict__ partial, int Q, int stride, int nsplit, float thresh,   // partial [B,S,stride]
     float* __restrict__ w, uint8_t* __restrict__ exterior)
 {
     const int b = blockIdx.y;
     const int q = blockIdx.x * kBlock + threadIdx.x;
     if (q >= Q) return;
-    const float* p = partial + (size_t)b * nsplit * Q + q;
+    const float* p = partial + (size_t)b * nsplit * stride + q;
     float acc = 0.0f;
-    for (int s = 0; s < nsplit; ++s) acc += p[(size_t)s * Q];
+    for (int s = 0; s < nsplit; ++s) acc += p[(size_t)s * stride];
     const float val = acc * (0.5f / kPi);
     if (w) w[(size_t)b * Q + q] = val;
     if (exterior) exterior[(size_t)b * Q + q] = val <= thresh ? 1 : 0;
@@ -420,13 +420,16 @@ __device__ __forceinline__ void run_stream(const StreamElem* __restrict__ st, in
 // so splitting the tree into many subtrees (load balance) does not cost one cap per far subtree.
 constexpr int kMaxAncestors = 8;           // deeper ancestors are simply never replaced by their caps
 
+// Queries: the model's own vertices in the tree's order (qperm, Q = V), or arbitrary points [B,Q,3]
+// in the caller's order (qperm == nullptr; counts[b] of them are real): any order is exact, blocks of
+// 128 consecutive points that are close in space are fast.
 template <bool kCount>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void winding_tree_kernel(
-    const float* __restrict__ verts,             // [B,V,3]
+    const float* __restrict__ verts,             // query points [B,Q,3]
     const StreamElem* __restrict__ stream,       // [B,T]
     const TreeNode* __restrict__ nodes, const float* __restrict__ bounds, int N,
     const int32_t* __restrict__ frontier, const int32_t* __restrict__ ancestors,   // [S], [S][kMaxAncestors]
-    const int32_t* __restrict__ order, const int32_t* __restrict__ qperm,
+    const int32_t* __restrict__ order, const int32_t* __restrict__ qperm, const int32_t* __restrict__ counts,
     int V, int T, int nsub, float* __restrict__ partial,   // [B,S,qblocks*128]
     unsigned long long* __restrict__ stats)
 {
@@ -434,10 +437,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     // grid (B, pairs): the body index varies fastest (XCD-aware, see winding_strip_kernel); the
     // (subtree, query block) pairs come in the model's launch order, long-running first
     const int b = blockIdx.x;
-    const int pair = __builtin_amdgcn_readfirstlane(order[blockIdx.y]);
-    const int sub = pair >> 16, qb = pair & 0xffff;
-    const int i0 = qperm[qb * kTreeQueries + threadIdx.x];
-    const int i1 = qperm[qb * kTreeQueries + 64 + threadIdx.x];
+    int sub, qb, i0, i1;
+    if (qperm) {
+        const int pair = __builtin_amdgcn_readfirstlane(order[blockIdx.y]);
+        sub = pair >> 16;
+        qb = pair & 0xffff;
+        i0 = qperm[qb * kTreeQueries + threadIdx.x];
+        i1 = qperm[qb * kTreeQueries + 64 + threadIdx.x];
+    } else {
+        sub = blockIdx.y % nsub;
+        qb = blockIdx.y / nsub;
+        const int n = counts ? counts[b] : V;
+        if (qb * kTreeQueries >= n) return;          // padding of a ragged point set (partial sums preset to 0)
+        i0 = min(qb * kTreeQueries + (int)threadIdx.x, n - 1);
+        i1 = min(qb * kTreeQueries + 64 + (int)threadIdx.x, n - 1);
+    }
     const float* pts = verts + (size_t)b * V * 3;
     const v2f qx = {pts[3 * i0 + 0], pts[3 * i1 + 0]};
     const v2f qy = {pts[3 * i0 + 1], pts[3 * i1 + 1]};
@@ -755,13 +769,10 @@ int choose_splits(int B, int Q, int F)
     return s;
 }
 
-// gather the posed stream, box every node, walk the tree: partial sums into ws + l.partial
-void launch_tree_walk(const tuch_contact_model* m, const ExteriorLayout& l, const float* verts, int B, char* ws,
-                      unsigned long long* stats, hipStream_t s)
+// the posed strip stream of the tree (leaf strips + caps) and the slabs of every node
+void launch_tree_boxes(const tuch_contact_model* m, const float* verts, int B, StreamElem* st, float* bounds, hipStream_t s)
 {
-    StreamElem* st = (StreamElem*)(ws + l.tris);
     const int T = m->tree_stream_len + 3;
-    float* bounds = (float*)(ws + l.bounds);
     hipLaunchKernelGGL(gather_stream_kernel, dim3(ceil_div(T, kBlock), B), dim3(kBlock), 0, s, verts,
                        (const int32_t*)m->tree_vidx, (const float*)m->tree_sign, m->V, m->tree_stream_len, T, st);
     hipLaunchKernelGGL(tree_leaf_bounds_kernel, dim3(ceil_div(m->tree_leaves, kBoundsBlock / 64), B),
@@ -771,6 +782,16 @@ void launch_tree_walk(const tuch_contact_model* m, const ExteriorLayout& l, cons
                        (size_t)m->tree_nodes * 2 * kSlabStride * sizeof(float), s, (const TreeNode*)m->tree_node, m->tree_nodes,
                        (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, m->tree_heights,
                        bounds);
+}
+
+// gather the posed stream, box every node, walk the tree: partial sums into ws + l.partial
+void launch_tree_walk(const tuch_contact_model* m, const ExteriorLayout& l, const float* verts, int B, char* ws,
+                      unsigned long long* stats, hipStream_t s)
+{
+    StreamElem* st = (StreamElem*)(ws + l.tris);
+    const int T = m->tree_stream_len + 3;
+    float* bounds = (float*)(ws + l.bounds);
+    launch_tree_boxes(m, verts, B, st, bounds, s);
     const int f0 = m->tree_frontier_off_host[l.tree_frontier];
     const dim3 grid(B, l.tree_subs * m->tree_qblocks);
     const int32_t* frontier = (const int32_t*)m->tree_frontier_nodes + f0;
@@ -779,11 +800,11 @@ void launch_tree_walk(const tuch_contact_model* m, const ExteriorLayout& l, cons
     if (stats)
         hipLaunchKernelGGL(winding_tree_kernel<true>, grid, dim3(64), 0, s, verts, (const StreamElem*)st,
                            (const TreeNode*)m->tree_node, (const float*)bounds, m->tree_nodes, frontier, ancestors, order,
-                           (const int32_t*)m->tree_qperm, m->V, T, l.tree_subs, (float*)(ws + l.partial), stats);
+                           (const int32_t*)m->tree_qperm, (const int32_t*)nullptr, m->V, T, l.tree_subs, (float*)(ws + l.partial), stats);
     else
         hipLaunchKernelGGL(winding_tree_kernel<false>, grid, dim3(64), 0, s, verts, (const StreamElem*)st,
                            (const TreeNode*)m->tree_node, (const float*)bounds, m->tree_nodes, frontier, ancestors, order,
-                           (const int32_t*)m->tree_qperm, m->V, T, l.tree_subs, (float*)(ws + l.partial), stats);
+                           (const int32_t*)m->tree_qperm, (const int32_t*)nullptr, m->V, T, l.tree_subs, (float*)(ws + l.partial), stats);
 }
 
 }  // namespace
@@ -812,7 +833,7 @@ extern "C" int tuch_winding_numbers(const float* points, const float* triangles,
     hipLaunchKernelGGL(winding_partial_kernel, grid, dim3(kBlock), 0, s, points, triangles, Q, F,
                        per_split, (float*)workspace);
     hipLaunchKernelGGL(winding_finalize_kernel, dim3(ceil_div(Q, kBlock), B), dim3(kBlock), 0, s,
-                       (const float*)workspace, Q, nsplit, exterior_thresh, w, exterior);
+                       (const float*)workspace, Q, Q, nsplit, exterior_thresh, w, exterior);
     return tuch_check_launch("tuch_winding_numbers");
 }
 
@@ -878,7 +899,7 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
                            0, s, verts, (const StreamElem*)st, m->V, l.lpad, per_split, (const int32_t*)nullptr,
                            (float*)(ws + l.partial));
         hipLaunchKernelGGL(winding_finalize_kernel, dim3(ceil_div(m->V, kBlock), B), dim3(kBlock), 0, s,
-                           (const float*)(ws + l.partial), m->V, nsplit, thresh, w, exterior);
+                           (const float*)(ws + l.partial), m->V, m->V, nsplit, thresh, w, exterior);
     } else {
         hipLaunchKernelGGL(gather_triangles_kernel, dim3(ceil_div(m->F * 3, kBlock), B), dim3(kBlock), 0, s,
                            verts, (const int32_t*)m->faces, m->V, m->F, tris);
@@ -954,12 +975,35 @@ extern "C" int tuch_winding_tree_work(const tuch_contact_model* m, const float* 
 // (tuch/train/loss.py:297: HD points offset along the face normals).  points [B,Q,3]; counts [B]
 // (device, optional) = number of meaningful points per body when the set is ragged and padded
 // to Q; w / exterior of padded entries are 0 / 1.
+struct PointsLayout { size_t stream, bounds, partial, total; int frontier, nsub, qblocks; };
+
+static PointsLayout points_layout(const tuch_contact_model* m, int B, int Q)
+{
+    PointsLayout l;
+    l.qblocks = ceil_div(Q, kTreeQueries);
+    // enough wavefronts to balance the uneven subtree walks (as choose_frontier, for Q points per body)
+    int f = 0;
+    while (f + 1 < m->tree_num_frontiers &&
+           (long)B * l.qblocks * (m->tree_frontier_off_host[f + 1] - m->tree_frontier_off_host[f]) < 65536L) ++f;
+    l.frontier = f;
+    l.nsub = m->tree_frontier_off_host[f + 1] - m->tree_frontier_off_host[f];
+    size_t o = 0;
+    l.stream = o;  o += align256((size_t)B * (m->tree_stream_len + 3) * sizeof(StreamElem));
+    l.bounds = o;  o += align256((size_t)B * m->tree_nodes * 2 * kSlabStride * sizeof(float));
+    l.partial = o; o += align256((size_t)B * l.nsub * l.qblocks * kTreeQueries * sizeof(float));
+    l.total = o;
+    return l;
+}
+
 extern "C" size_t tuch_winding_points_workspace_bytes(const tuch_contact_model* m, int B, int Q)
 {
     if (!m || B <= 0 || Q <= 0) return 0;
     const int lpad = strip_lpad(m->strip_len);
-    return align256((size_t)B * lpad * sizeof(StreamElem)) +
-           align256((size_t)B * choose_strip_splits(B, Q, lpad) * Q * sizeof(float));
+    const size_t flat = align256((size_t)B * lpad * sizeof(StreamElem)) +
+                        align256((size_t)B * choose_strip_splits(B, Q, lpad) * Q * sizeof(float));
+    if (m->tree_nodes <= 0) return flat;
+    const size_t tree = points_layout(m, B, Q).total;
+    return tree > flat ? tree : flat;
 }
 
 extern "C" int tuch_winding_points(const tuch_contact_model* m, const float* verts, const float* points,
@@ -973,10 +1017,33 @@ extern "C" int tuch_winding_points(const tuch_contact_model* m, const float* ver
         tuch_set_error("tuch_winding_points: workspace %zu < %zu bytes", workspace_bytes, need);
         return TUCH_ERR_WORKSPACE;
     }
+    hipStream_t s = (hipStream_t)stream;
+    if (use_strips() && use_tree(m)) {
+        // hierarchical walk (cluster tree + boundary caps) with the caller's points as queries
+        const PointsLayout l = points_layout(m, B, Q);
+        char* ws = (char*)workspace;
+        StreamElem* st = (StreamElem*)(ws + l.stream);
+        float* bounds = (float*)(ws + l.bounds);
+        float* partial = (float*)(ws + l.partial);
+        const int T = m->tree_stream_len + 3, stride = l.qblocks * kTreeQueries;
+        if (counts && hipMemsetAsync(partial, 0, (size_t)B * l.nsub * stride * sizeof(float), s) != hipSuccess) {
+            tuch_set_error("tuch_winding_points: hipMemsetAsync failed");
+            return TUCH_ERR_HIP;
+        }
+        launch_tree_boxes(m, verts, B, st, bounds, s);
+        const int f0 = m->tree_frontier_off_host[l.frontier];
+        hipLaunchKernelGGL(winding_tree_kernel<false>, dim3(B, l.nsub * l.qblocks), dim3(64), 0, s, points,
+                           (const StreamElem*)st, (const TreeNode*)m->tree_node, (const float*)bounds, m->tree_nodes,
+                           (const int32_t*)m->tree_frontier_nodes + f0,
+                           (const int32_t*)m->tree_ancestors + (size_t)f0 * kMaxAncestors, (const int32_t*)nullptr,
+                           (const int32_t*)nullptr, counts, Q, T, l.nsub, partial, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL(winding_finalize_kernel, dim3(ceil_div(Q, kBlock), B), dim3(kBlock), 0, s,
+                           (const float*)partial, Q, stride, l.nsub, thresh, w, exterior);
+        return tuch_check_launch("tuch_winding_points");
+    }
     const int lpad = strip_lpad(m->strip_len);
     StreamElem* st = (StreamElem*)workspace;
     float* partial = (float*)((char*)workspace + align256((size_t)B * lpad * sizeof(StreamElem)));
-    hipStream_t s = (hipStream_t)stream;
     const int nsplit = choose_strip_splits(B, Q, lpad);
     if (counts && hipMemsetAsync(partial, 0, (size_t)B * nsplit * Q * sizeof(float), s) != hipSuccess) {
         tuch_set_error("tuch_winding_points: hipMemsetAsync failed");
@@ -988,6 +1055,6 @@ extern "C" int tuch_winding_points(const tuch_contact_model* m, const float* ver
     hipLaunchKernelGGL(winding_strip_kernel, dim3(B, nsplit, ceil_div(Q, kStripQueries)), dim3(kStripBlock), 0, s,
                        points, (const StreamElem*)st, Q, lpad, per_split, counts, partial);
     hipLaunchKernelGGL(winding_finalize_kernel, dim3(ceil_div(Q, kBlock), B), dim3(kBlock), 0, s,
-                       (const float*)partial, Q, nsplit, thresh, w, exterior);
+                       (const float*)partial, Q, Q, nsplit, thresh, w, exterior);
     return tuch_check_launch("tuch_winding_points");
 }

@@ -278,7 +278,7 @@ def segment_faces(body_faces: np.ndarray, vidx: np.ndarray, bands: Sequence[np.n
 def cluster_tree(faces, num_verts: int, leaf_faces: int = 64) -> dict:
     """The face-cluster tree used by the hierarchical winding numbers (host only; see include/tuch_amd.h,
     tuch_cluster_tree_build).  Returns numpy arrays: nodes [N,8], vidx, sign, qperm, frontier_off,
-    frontier_nodes, launch_order, rows, plus exact_len."""
+    frontier_nodes, launch_order, rows, face_leaf, plus exact_len."""
     L = _C.lib()
     f = np.ascontiguousarray(np.asarray(faces).reshape(-1, 3), dtype=np.int32)
     h = ctypes.c_void_p()
@@ -291,10 +291,11 @@ def cluster_tree(faces, num_verts: int, leaf_faces: int = 64) -> dict:
         out = dict(nodes=np.zeros((n, 8), np.int32), vidx=np.zeros(stream_len, np.int32),
                    sign=np.zeros(stream_len, np.float32), qperm=np.zeros(qblocks * 128, np.int32),
                    frontier_off=np.zeros(nfr + 1, np.int32), frontier_nodes=np.zeros(frtot, np.int32),
-                   launch_order=np.zeros(frtot * qblocks, np.int32), rows=np.zeros((n, 2), np.int32))
+                   launch_order=np.zeros(frtot * qblocks, np.int32), rows=np.zeros((n, 2), np.int32),
+                   face_leaf=np.zeros(f.shape[0], np.int32))
         _C.check(L.tuch_cluster_tree_export(h, *[out[k].ctypes.data_as(ctypes.c_void_p) for k in
                                                  ('nodes', 'vidx', 'sign', 'qperm', 'frontier_off', 'frontier_nodes',
-                                                  'launch_order', 'rows')]))
+                                                  'launch_order', 'rows', 'face_leaf')]))
         out['exact_len'] = exact_len
         return out
     finally:

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import _C, ops
 from ..utils.geometry import batch_rodrigues
 
 
@@ -53,9 +53,19 @@ class RegressorLoss(nn.Module):
                 with open(osp.join(hd_model_dir, 'smpl_neutral_hd_sample_from_mesh_out.pkl'), 'rb') as f:
                     hd_faces = pickle.load(f)['faces_vert_is_sampled_from']
             dev = face_tensor.device
-            self.hd_idx = torch.as_tensor(np.asarray(hd_regressor[0]), dtype=torch.long, device=dev)
-            self.hd_w = torch.as_tensor(np.asarray(hd_regressor[1]), dtype=torch.float32, device=dev)
-            self.geovec = torch.as_tensor(np.asarray(hd_faces), dtype=torch.long, device=dev)
+            hd_i, hd_wt, hd_f = np.asarray(hd_regressor[0]), np.asarray(hd_regressor[1]), np.asarray(hd_faces)
+            # The HD points are a set (the loss sums over them): keep them sorted by the surface patch their
+            # face belongs to, so that consecutive selected points are neighbours in space and the inside
+            # test of loss.py:297 walks the cluster tree with coherent blocks of queries.
+            try:
+                leaf = ops.cluster_tree(face_tensor[0].detach().cpu().numpy(), num_verts)['face_leaf']
+                order = np.argsort(leaf[hd_f], kind='stable')
+                hd_i, hd_wt, hd_f = hd_i[order], hd_wt[order], hd_f[order]
+            except _C.TuchError:      # open mesh: no tree, the flat walk does not care about the order
+                pass
+            self.hd_idx = torch.as_tensor(hd_i, dtype=torch.long, device=dev)
+            self.hd_w = torch.as_tensor(hd_wt, dtype=torch.float32, device=dev)
+            self.geovec = torch.as_tensor(hd_f, dtype=torch.long, device=dev)
             self.geovec_verts = self.face_tensor[0][self.geovec][:, 0]            # loss.py:88
         self.segments = segments
         seg_tables = segments.tables() if segments is not None else None
