@@ -1,0 +1,19 @@
+import sys, types; sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
+import numpy as np, torch
+import bench
+from tuch_amd.train.loss import RegressorLoss
+dev = torch.device('cuda:0')
+p = bench.build_problem(64, dev, 1002)
+body = p['body']
+with torch.no_grad():
+    verts = p['smpl'](global_orient=p['global_orient'], body_pose=p['body_pose'], betas=p['betas']).vertices
+valid = torch.ones(64, dtype=torch.bool, device=dev)
+crit = RegressorLoss(types.SimpleNamespace(contact_loss_weight=1.0), dev, body.num_verts, p['face_tensor'],
+                     torch.tensor(body.geodesics, device=dev), geothres=0.3, euclthres=0.02,
+                     face_tensor=p['face_tensor'], use_hd=True, segments=p['segments'],
+                     hd_regressor=(body.hd_bary_idx, body.hd_bary_w), hd_faces=body.hd_face_id)
+v = verts.clone().requires_grad_(True)
+for _ in range(6):
+    v.grad = None
+    crit.contact_loss(v, valid).backward()
+torch.cuda.synchronize()

@@ -160,30 +160,72 @@ __global__ __launch_bounds__(kBlock) void pairwise_kernel(
 // off[b]..off[b+1]; point a carries the template vertex vid[a] whose geodesic-mask row/column
 // it inherits (geovec_verts, loss.py:88).  Column a: min over the body's rows r with
 // geomask[vid[r]][vid[a]].  argmin is the row index relative to the body's first point.
-__global__ __launch_bounds__(kBlock) void v2v_indexed_kernel(
+constexpr int kIndexedWaves = 8;             // wavefronts per workgroup: each takes an eighth of the rows
+__global__ __launch_bounds__(64 * kIndexedWaves) void v2v_indexed_kernel(
     const float* __restrict__ pts, const int32_t* __restrict__ vid, const int32_t* __restrict__ off,
     const uint64_t* __restrict__ bits, int V, float* __restrict__ out_min, int32_t* __restrict__ out_arg)
 {
     const int b = blockIdx.y;
-    const int beg = off[b], n = off[b + 1] - beg;
-    const int a = blockIdx.x * kBlock + threadIdx.x;
-    if (blockIdx.x * kBlock >= n) return;
+    // wave-uniform bounds (readfirstlane lets the row data below come in through scalar loads)
+    const int beg = __builtin_amdgcn_readfirstlane(off[b]);
+    const int n = __builtin_amdgcn_readfirstlane(off[b + 1]) - beg;
+    // 64 columns per workgroup, the rows split over its wavefronts (one long serial loop per wavefront
+    // would leave most of the chip idle at the few thousand points a body selects)
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int a = blockIdx.x * 64 + lane;
+    if ((int)(blockIdx.x * 64) >= n) return;
     const int ac = min(a, n - 1);
     const float px = pts[3 * (size_t)(beg + ac)], py = pts[3 * (size_t)(beg + ac) + 1], pz = pts[3 * (size_t)(beg + ac) + 2];
     const int va = vid[beg + ac];
     const uint64_t* col = bits + (size_t)(va >> 6) * V;
     const int sh = va & 63;
-    float best = __builtin_inff();
+    const float inf = __builtin_inff();
+    float best = inf;
     int arg = 0;
-    for (int r = 0; r < n; ++r) {
-        const float* q = pts + 3 * (size_t)(beg + r);       // wave-uniform
-        const int vr = vid[beg + r];
-        const float dx = px - q[0], dy = py - q[1], dz = pz - q[2];
+    int prev = -1;
+    bool allowed = false;
+    const float* rp = pts + 3 * (size_t)beg;
+    const int32_t* rv = vid + beg;
+    auto row = [&](int r, int vr, float qx, float qy, float qz) {
+        // consecutive points usually inherit the same template vertex (samples of one face): the per-lane
+        // gather of the mask word is repeated only when the row's vertex changes (wave-uniform test)
+        if (vr != prev) {
+            allowed = (col[vr] >> sh) & 1;
+            prev = vr;
+        }
+        const float dx = px - qx, dy = py - qy, dz = pz - qz;
         float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-        if (!((col[vr] >> sh) & 1)) d = __builtin_inff();
-        if (d < best) { best = d; arg = r; }
+        if (!allowed) d = inf;
+        if (__builtin_amdgcn_ballot_w64(d < best)) {
+            if (d < best) { best = d; arg = r; }
+        }
+    };
+    const int per_wave = ((n + kIndexedWaves - 1) / kIndexedWaves + 3) & ~3;
+    int r = min(n, wave * per_wave);
+    const int r_end = min(n, r + per_wave);
+    for (; r + 4 <= r_end; r += 4) {                   // four rows per trip: their scalar loads are issued together
+        float c[12];
+        int v[4];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) c[u] = rp[3 * r + u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = rv[r + u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) row(r + u, v[u], c[3 * u], c[3 * u + 1], c[3 * u + 2]);
     }
-    if (a < n) { out_min[beg + a] = best; out_arg[beg + a] = arg; }
+    for (; r < r_end; ++r) row(r, rv[r], rp[3 * r], rp[3 * r + 1], rp[3 * r + 2]);
+    // merge the wavefronts in ascending row order, strict '<': first-index rule as torch.argmin
+    __shared__ float sbest[kIndexedWaves][64];
+    __shared__ int sarg[kIndexedWaves][64];
+    sbest[wave][lane] = best;
+    sarg[wave][lane] = arg;
+    __syncthreads();
+    if (wave == 0 && a < n) {
+        for (int w = 1; w < kIndexedWaves; ++w)
+            if (sbest[w][lane] < best) { best = sbest[w][lane]; arg = sarg[w][lane]; }
+        out_min[beg + a] = best;
+        out_arg[beg + a] = arg;
+    }
 }
 
 // ---- tree-pruned form ----------------------------------------------------------------------
@@ -580,7 +622,7 @@ extern "C" int tuch_v2v_min_indexed(const float* points, const int32_t* vertex_i
                  "tuch_v2v_min_indexed: null pointer");
     TUCH_REQUIRE(B > 0 && B <= 65535 && V > 0 && max_points_per_body >= 0, "tuch_v2v_min_indexed: bad sizes");
     if (max_points_per_body == 0) return TUCH_OK;
-    hipLaunchKernelGGL(v2v_indexed_kernel, dim3(ceil_div(max_points_per_body, kBlock), B), dim3(kBlock), 0,
+    hipLaunchKernelGGL(v2v_indexed_kernel, dim3(ceil_div(max_points_per_body, 64), B), dim3(64 * kIndexedWaves), 0,
                        (hipStream_t)stream, points, vertex_ids, offsets, geomask_bits, V, min_d2, argmin);
     return tuch_check_launch("tuch_v2v_min_indexed");
 }
