@@ -409,3 +409,64 @@ def test_open_mesh_keeps_the_flat_walk():
     for b in range(verts.shape[0]):
         ref = oc.winding_numbers(g['verts'][b], g['verts'][b][faces])
         assert np.abs(w[b] - ref).max() < 2e-5
+
+
+@pytest.mark.parametrize('tag', TAGS)
+@pytest.mark.parametrize('batch', [1, 5])
+def test_v2v_tree_walk_matches_flat_search(tag, batch, monkeypatch):
+    """The pruned nearest-vertex search (cluster tree, box distances, static mask table) against the flat
+    all-rows kernel: identical minima bit for bit; the partner may differ only between exactly tied rows."""
+    g, gm = golden(tag), golden_mask(tag)
+    model = make_model(g, gm, False, False)
+    base = torch.tensor(g['verts'], device=dev())
+    verts = base[torch.arange(batch, device=dev()) % base.shape[0]].contiguous()
+    k = (torch.arange(batch, device=dev(), dtype=torch.float32) - (base.shape[0] - 1)).clamp(min=0).view(-1, 1)
+    verts[:, :, 0] += 0.05 * k * verts[:, :, 1]
+    monkeypatch.setenv('TUCH_V2V_TREE', '0')
+    mn_f, arg_f = model.v2v_min(verts)
+    monkeypatch.setenv('TUCH_V2V_TREE', '1')
+    for waves in ('1', '4096', '1000000'):               # one subtree ... as many as the model has
+        monkeypatch.setenv('TUCH_V2V_WAVES', waves)
+        mn_t, arg_t = model.v2v_min(verts)
+        assert torch.equal(mn_t, mn_f)
+        diff = (arg_t != arg_f).nonzero()
+        v = verts.double()
+        for b, i in diff.tolist():
+            d_t = ((v[b, i] - v[b, arg_t[b, i]]) ** 2).sum()
+            d_f = ((v[b, i] - v[b, arg_f[b, i]]) ** 2).sum()
+            assert abs(float(d_t - d_f)) < 1e-9 and gm[int(arg_t[b, i]), i]
+        assert len(diff) <= 2
+    # repeatable despite the atomics
+    mn_again, arg_again = model.v2v_min(verts)
+    assert torch.equal(mn_again, mn_t) and torch.equal(arg_again, arg_t)
+
+
+@pytest.mark.parametrize('tag', ['medium', 'full'])
+def test_winding_points_tree_matches_flat(tag, monkeypatch):
+    """tuch_winding_points through the cluster tree (queries in the caller's order) against the flat strips."""
+    g = golden(tag)
+    model = make_model(g, None, False, False)
+    verts_np = g['verts']
+    rng = np.random.default_rng(11)
+    b_count, v_count = verts_np.shape[:2]
+    q = 700
+    # points on / near the surface in random order (incoherent blocks: slow but exact) and sorted by vertex id
+    idx = np.stack([rng.choice(v_count, q, replace=True) for _ in range(b_count)])
+    for order in ('random', 'sorted'):
+        ids = np.sort(idx, axis=1) if order == 'sorted' else idx
+        pts = np.stack([verts_np[b][ids[b]] for b in range(b_count)]) + 0.002 * rng.standard_normal((b_count, q, 3))
+        pts = torch.tensor(pts.astype(np.float32), device=dev())
+        counts = torch.tensor([q - 37 * b for b in range(b_count)], dtype=torch.int32, device=dev())
+        verts = torch.tensor(verts_np, device=dev())
+        res = {}
+        for tree in ('0', '1'):
+            monkeypatch.setenv('TUCH_WINDING_TREE', tree)
+            w, ext = model.winding_points(verts, pts, counts)
+            res[tree] = (w.cpu().numpy(), ext.cpu().numpy())
+        for b in range(b_count):
+            n = int(counts[b])
+            err = np.abs(res['1'][0][b][:n] - res['0'][0][b][:n])
+            assert np.percentile(err / np.maximum(1.0, np.abs(res['0'][0][b][:n])), 99) < 5e-6 and err.max() < 2e-4
+            clear = np.abs(res['0'][0][b][:n] - 0.99) > 1e-4
+            assert np.array_equal(res['1'][1][b][:n][clear], res['0'][1][b][:n][clear])
+            assert (res['1'][0][b][n:] == 0).all() and (res['1'][1][b][n:] == 1).all()      # padding: w = 0, exterior

@@ -438,6 +438,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     // (subtree, query block) pairs come in the model's launch order, long-running first
     const int b = blockIdx.x;
     int sub, qb, i0, i1;
+    bool real0 = true, real1 = true;                 // padding entries of a ragged point set report w = 0
     if (qperm) {
         const int pair = __builtin_amdgcn_readfirstlane(order[blockIdx.y]);
         sub = pair >> 16;
@@ -449,6 +450,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         qb = blockIdx.y / nsub;
         const int n = counts ? counts[b] : V;
         if (qb * kTreeQueries >= n) return;          // padding of a ragged point set (partial sums preset to 0)
+        real0 = qb * kTreeQueries + (int)threadIdx.x < n;
+        real1 = qb * kTreeQueries + 64 + (int)threadIdx.x < n;
         i0 = min(qb * kTreeQueries + (int)threadIdx.x, n - 1);
         i1 = min(qb * kTreeQueries + 64 + (int)threadIdx.x, n - 1);
     }
@@ -512,8 +515,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         }
         node = __builtin_amdgcn_readfirstlane(node);
     }
-    out[threadIdx.x] = acc[0];
-    out[64 + threadIdx.x] = acc[1];
+    out[threadIdx.x] = real0 ? acc[0] : 0.0f;
+    out[64 + threadIdx.x] = real1 ? acc[1] : 0.0f;
     if (kCount && threadIdx.x == 0) {
         atomicAdd(stats, (unsigned long long)walked_exact);
         atomicAdd(stats + 1, (unsigned long long)walked_cap);
