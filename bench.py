@@ -175,8 +175,8 @@ def rooflines(p, batch):
     # the launch below = gather_stream (~20 us) + node boxes (~18 us) + winding_tree_kernel + finalize (~7 us)
     t_w = time_kernel(lambda: model.exterior_flags(verts, apply_segments=False), 10)
     work = model.winding_tree_work(verts)
-    steps = work['leaf_elements'] + work['cap_elements']          # wavefront element steps, 128 queries each
-    flops = FLOP_PER_STRIP_ELEMENT * 128 * steps
+    steps = work['leaf_elements'] + work['cap_elements']          # wavefront element steps, 64 queries each
+    flops = FLOP_PER_STRIP_ELEMENT * work['queries_per_step'] * steps
     ach = flops / t_w / 1e12
     ref_flops = FLOP_PER_WINDING_PAIR * batch * v * f
     roof = {'kernel': 'winding_tree_kernel', 'bound': 'valu', 'achieved': round(ach, 2),

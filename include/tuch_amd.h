@@ -144,7 +144,7 @@ int tuch_contact_model_strips(const tuch_contact_model* model, int* stream_len, 
 /* Measurement aid for the hierarchical winding numbers inside tuch_exterior_flags: walks the cluster tree
  * for verts [B,V,3] and reports the stream elements the wavefronts stepped through.  out_host[4] =
  * {leaf-strip elements, cap elements, wavefronts, elements of the flat strip stream}; one element step
- * serves 128 queries.  Workspace as for tuch_exterior_flags.  Synchronises the stream. */
+ * serves 64 queries (one wavefront).  Workspace as for tuch_exterior_flags.  Synchronises the stream. */
 int tuch_winding_tree_work(const tuch_contact_model* model, const float* verts, int B, void* workspace,
                            size_t workspace_bytes, unsigned long long* out_host, void* stream);
 

@@ -291,6 +291,75 @@ __device__ __forceinline__ void strip_step(const StreamElem e, bool emit, Slot (
     }
 }
 
+// ---- the same strip walk with ONE query per lane (64 queries per wavefront) ------------------------
+// Plain and packed FP32 instructions have the same per-float throughput on gfx950, so halving the
+// block costs nothing per query; the smaller block tests "near" for fewer nodes of the tree.
+struct Slot1 { float x, y, z, n; };
+
+__device__ __forceinline__ float atan2_single(float y, float x)
+{
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    const float mx = __builtin_fmaxf(__builtin_fmaxf(ax, ay), 1e-37f);
+    const float mn = __builtin_fminf(ax, ay);
+    const float t = mn * __builtin_amdgcn_rcpf(mx);
+    const v2f p2 = atan_poly((v2f){t, t});
+    float v = ay > ax ? kHalfPi - p2[0] : p2[0];
+    v = x < 0.0f ? kPi - v : v;
+    return __builtin_copysignf(v, y);
+}
+
+__device__ __forceinline__ float half_angle_strip1(float num, float den)
+{
+    const bool big = !(__builtin_fabsf(num) < 0.125f * den);
+    if (__builtin_amdgcn_ballot_w64(big) == 0) {
+        const float t = num * __builtin_amdgcn_rcpf(den);
+        const float s = t * t;
+        float p = __builtin_fmaf(s, 0.2f, -1.0f / 3.0f);
+        p = __builtin_fmaf(p, s, 1.0f);
+        return p * t;
+    }
+    const float r = atan2_single(num, den);
+    return den == 0.0f ? 0.0f : r;
+}
+
+template <int A>
+__device__ __forceinline__ void strip_step1(const StreamElem e, Slot1 (&s)[3], float (&d)[3],
+                                            float qx, float qy, float qz, float& acc)
+{
+    constexpr int Bq = (A + 1) % 3, Cq = (A + 2) % 3;
+    s[A].x = e.x - qx;
+    s[A].y = e.y - qy;
+    s[A].z = e.z - qz;
+    s[A].n = __builtin_amdgcn_sqrtf(__builtin_fmaf(s[A].z, s[A].z, __builtin_fmaf(s[A].y, s[A].y, s[A].x * s[A].x)));
+    d[Cq] = __builtin_fmaf(s[A].z, s[Bq].z, __builtin_fmaf(s[A].y, s[Bq].y, s[A].x * s[Bq].x));
+    d[Bq] = __builtin_fmaf(s[A].z, s[Cq].z, __builtin_fmaf(s[A].y, s[Cq].y, s[A].x * s[Cq].x));
+    if (e.sign != 0.0f) {                                    // wave-uniform
+        const float num = __builtin_fmaf(s[A].z, e.nz, __builtin_fmaf(s[A].y, e.ny, s[A].x * e.nx));
+        float den = s[0].n * s[1].n * s[2].n;
+        den = __builtin_fmaf(d[0], s[0].n, den);
+        den = __builtin_fmaf(d[1], s[1].n, den);
+        den = __builtin_fmaf(d[2], s[2].n, den);
+        acc += half_angle_strip1(num, den);
+    }
+}
+
+// one run of the strip loop over stream elements [off, off+len), len % 3 == 0; the stream has
+// three readable elements past its end for the prefetch
+__device__ __forceinline__ void run_stream1(const StreamElem* __restrict__ st, int off, int len, Slot1 (&s)[3],
+                                            float (&d)[3], float qx, float qy, float qz, float& acc)
+{
+    const StreamElem* p = st + off;
+    const StreamElem* end = p + len;
+    StreamElem n0 = p[0], n1 = p[1], n2 = p[2];
+    for (; p < end; p += 3) {
+        const StreamElem e0 = n0, e1 = n1, e2 = n2;
+        n0 = p[3]; n1 = p[4]; n2 = p[5];
+        strip_step1<0>(e0, s, d, qx, qy, qz, acc);
+        strip_step1<1>(e1, s, d, qx, qy, qz, acc);
+        strip_step1<2>(e2, s, d, qx, qy, qz, acc);
+    }
+}
+
 __global__ __launch_bounds__(kStripBlock) void winding_strip_kernel(
     const float* __restrict__ points,            // [B,Q,3]
     const StreamElem* __restrict__ stream,       // [B,Lpad]
@@ -339,7 +408,6 @@ __global__ __launch_bounds__(kStripBlock) void winding_strip_kernel(
 // ---- hierarchical form (cluster_tree.hip) ------------------------------------------------------
 // Posed bounding boxes of all tree nodes of one body: leaves from their strip elements, inner
 // nodes bottom-up from their children.  One workgroup per body, boxes kept in LDS.
-constexpr int kTreeQueries = 128;          // one wavefront, two queries per lane
 
 // Bounding volume of a node = 9 slabs (a 18-DOP): the coordinate axes and the six face diagonals
 // x+-y, x+-z, y+-z (unnormalised sums: rounding is monotone, so a point of the convex hull can
@@ -391,98 +459,79 @@ __global__ __launch_bounds__(kBoundsBlock) void tree_leaf_bounds_kernel(
     }
 }
 
-// one run of the strip loop over stream elements [off, off+len), len % 3 == 0; the stream has
-// three readable elements past its end for the prefetch
-__device__ __forceinline__ void run_stream(const StreamElem* __restrict__ st, int off, int len, Slot (&s)[3],
-                                           v2f (&d)[3], v2f qx, v2f qy, v2f qz, v2f& acc)
-{
-    const StreamElem* p = st + off;
-    const StreamElem* end = p + len;
-    StreamElem n0 = p[0], n1 = p[1], n2 = p[2];
-    for (; p < end; p += 3) {
-        const StreamElem e0 = n0, e1 = n1, e2 = n2;
-        n0 = p[3]; n1 = p[4]; n2 = p[5];
-        strip_step<0>(e0, true, s, d, qx, qy, qz, acc);
-        strip_step<1>(e1, true, s, d, qx, qy, qz, acc);
-        strip_step<2>(e2, true, s, d, qx, qy, qz, acc);
-    }
-}
-
-// Winding numbers of the model's own vertices by walking the cluster tree: a node whose posed box
-// contains none of the wavefront's 128 queries contributes through its boundary cap (exactly the
-// same solid angle), a leaf that does is summed face by face, an inner node that does is descended.
-// All decisions are wave-uniform.  grid (B, subtrees of the frontier, query blocks).
-// kCount: also add the number of stream elements walked (leaf strips, caps) to stats[0], stats[1]
-// (measurement only: tuch_winding_tree_work).
+// Winding numbers by walking the cluster tree: a node whose posed bounding volume contains none of
+// the wavefront's 64 queries contributes through its boundary cap (exactly the same solid angle), a
+// leaf that does is summed face by face, an inner node that does is descended.  All decisions are
+// wave-uniform.  One query per lane: plain and packed FP32 have the same per-float throughput on
+// gfx950, and a 64-query block is "near" fewer nodes than a 128-query block (-12 % run time).
 // The nodes above the frontier are handled without a pass of their own: every wavefront first tests
 // the ancestors of its subtree top-down (a static list).  At the first ancestor that is far, the
 // wavefront of the ancestor's FIRST frontier subtree adds the ancestor's cap and all others leave,
 // so splitting the tree into many subtrees (load balance) does not cost one cap per far subtree.
-constexpr int kMaxAncestors = 8;           // deeper ancestors are simply never replaced by their caps
-
 // Queries: the model's own vertices in the tree's order (qperm, Q = V), or arbitrary points [B,Q,3]
 // in the caller's order (qperm == nullptr; counts[b] of them are real): any order is exact, blocks of
-// 128 consecutive points that are close in space are fast.
+// 64 consecutive points that are close in space are fast.
+// kCount: also add the number of stream elements walked (leaf strips, caps) to stats[0], stats[1]
+// (measurement only: tuch_winding_tree_work).
+constexpr int kMaxAncestors = 8;           // deeper ancestors are simply never replaced by their caps
+constexpr int kTreeQueries = 64;           // queries per wavefront
+
 template <bool kCount>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void winding_tree_kernel(
     const float* __restrict__ verts,             // query points [B,Q,3]
     const StreamElem* __restrict__ stream,       // [B,T]
     const TreeNode* __restrict__ nodes, const float* __restrict__ bounds, int N,
     const int32_t* __restrict__ frontier, const int32_t* __restrict__ ancestors,   // [S], [S][kMaxAncestors]
-    const int32_t* __restrict__ order, const int32_t* __restrict__ qperm, const int32_t* __restrict__ counts,
-    int V, int T, int nsub, float* __restrict__ partial,   // [B,S,qblocks*128]
+    const int32_t* __restrict__ order,           // launch order over (subtree, 128-query block) pairs, or nullptr
+    const int32_t* __restrict__ qperm, const int32_t* __restrict__ counts,
+    int V, int T, int nsub, float* __restrict__ partial,   // [B,S,qblocks*64]
     unsigned long long* __restrict__ stats)
 {
     int walked_exact = 0, walked_cap = 0;
     // grid (B, pairs): the body index varies fastest (XCD-aware, see winding_strip_kernel); the
     // (subtree, query block) pairs come in the model's launch order, long-running first
     const int b = blockIdx.x;
-    int sub, qb, i0, i1;
-    bool real0 = true, real1 = true;                 // padding entries of a ragged point set report w = 0
+    int sub, qb, i0;
+    bool real = true;                                // padding entries of a ragged point set report w = 0
     if (qperm) {
-        const int pair = __builtin_amdgcn_readfirstlane(order[blockIdx.y]);
+        const int pair = __builtin_amdgcn_readfirstlane(order[blockIdx.y >> 1]);
         sub = pair >> 16;
-        qb = pair & 0xffff;
+        qb = (pair & 0xffff) * 2 + (blockIdx.y & 1);            // the two halves of the model's 128-blocks
         i0 = qperm[qb * kTreeQueries + threadIdx.x];
-        i1 = qperm[qb * kTreeQueries + 64 + threadIdx.x];
     } else {
         sub = blockIdx.y % nsub;
         qb = blockIdx.y / nsub;
         const int n = counts ? counts[b] : V;
         if (qb * kTreeQueries >= n) return;          // padding of a ragged point set (partial sums preset to 0)
-        real0 = qb * kTreeQueries + (int)threadIdx.x < n;
-        real1 = qb * kTreeQueries + 64 + (int)threadIdx.x < n;
+        real = qb * kTreeQueries + (int)threadIdx.x < n;
         i0 = min(qb * kTreeQueries + (int)threadIdx.x, n - 1);
-        i1 = min(qb * kTreeQueries + 64 + (int)threadIdx.x, n - 1);
     }
     const float* pts = verts + (size_t)b * V * 3;
-    const v2f qx = {pts[3 * i0 + 0], pts[3 * i1 + 0]};
-    const v2f qy = {pts[3 * i0 + 1], pts[3 * i1 + 1]};
-    const v2f qz = {pts[3 * i0 + 2], pts[3 * i1 + 2]};
+    const float qx = pts[3 * i0 + 0], qy = pts[3 * i0 + 1], qz = pts[3 * i0 + 2];
     const StreamElem* st = stream + (size_t)b * T;
     const float* bb = bounds + (size_t)b * N * (2 * kSlabStride);
-    Slot s[3];
-    v2f d[3];
+    Slot1 s[3];
+    float d[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        s[k].x = s[k].y = s[k].z = s[k].n = splat2(0.0f);
-        d[k] = splat2(0.0f);
+        s[k].x = s[k].y = s[k].z = s[k].n = 0.0f;
+        d[k] = 0.0f;
     }
-    v2f acc = splat2(0.0f);
-    // near = some query of the wavefront is inside all slabs of the node (wave-uniform)
+    float acc = 0.0f;
+    // near = some query of the wavefront is inside all slabs of the node (wave-uniform):
+    // outside = some slab separates the query from the node, max_k max(lo_k - p_k, p_k - hi_k) > 0
     auto is_near = [&](int node) {
         const float* box = bb + (size_t)node * (2 * kSlabStride);
-        // outside = some slab separates the query from the node: max_k max(lo_k - p_k, p_k - hi_k) > 0
-        // (the six diagonal projections are recomputed per node: keeping them would cost 12 VGPRs)
-        const v2f qp[kSlabs] = {qx, qy, qz, qx + qy, qx - qy, qx + qz, qx - qz, qy + qz, qy - qz};
-        v2f out = splat2(-1.0f);
+        const float qp[kSlabs] = {qx, qy, qz, qx + qy, qx - qy, qx + qz, qx - qz, qy + qz, qy - qz};
+        float out = -1.0f;
 #pragma unroll
         for (int k = 0; k < kSlabs; ++k)
-            out = __builtin_elementwise_max(out, __builtin_elementwise_max(splat2(box[k]) - qp[k], qp[k] - splat2(box[kSlabStride + k])));
-        return __builtin_amdgcn_ballot_w64(!(out[0] > 0.0f) || !(out[1] > 0.0f)) != 0;
+            out = __builtin_fmaxf(out, __builtin_fmaxf(box[k] - qp[k], qp[k] - box[kSlabStride + k]));
+        return __builtin_amdgcn_ballot_w64(!(out > 0.0f)) != 0;
     };
     // partial sums are stored in the tree's query order (coalesced); the finalize kernel un-permutes
-    float* out = partial + ((size_t)b * nsub + sub) * (gridDim.y / nsub * kTreeQueries) + qb * kTreeQueries;
+    const int qblocks = gridDim.y / nsub;
+    float* out = partial + ((size_t)b * nsub + sub) * ((size_t)qblocks * kTreeQueries) + qb * kTreeQueries;
     int node = __builtin_amdgcn_readfirstlane(frontier[sub]);
     int end = __builtin_amdgcn_readfirstlane(nodes[node].skip);
     const int32_t* anc = ancestors + (size_t)sub * kMaxAncestors;
@@ -494,7 +543,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         const bool first = sub == 0 || __builtin_amdgcn_readfirstlane(frontier[sub - 1]) < x;
         if (first) {
             const TreeNode nd = nodes[x];
-            run_stream(st, nd.cap_off, nd.cap_len, s, d, qx, qy, qz, acc);
+            run_stream1(st, nd.cap_off, nd.cap_len, s, d, qx, qy, qz, acc);
             if (kCount) walked_cap += nd.cap_len;
         }
         end = node;                                // nothing left to walk
@@ -506,7 +555,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         if (near && nd.ex_len == 0) {
             node = node + 1;
         } else {
-            run_stream(st, near ? nd.ex_off : nd.cap_off, near ? nd.ex_len : nd.cap_len, s, d, qx, qy, qz, acc);
+            run_stream1(st, near ? nd.ex_off : nd.cap_off, near ? nd.ex_len : nd.cap_len, s, d, qx, qy, qz, acc);
             if (kCount) {
                 walked_exact += near ? nd.ex_len : 0;
                 walked_cap += near ? 0 : nd.cap_len;
@@ -515,8 +564,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         }
         node = __builtin_amdgcn_readfirstlane(node);
     }
-    out[threadIdx.x] = real0 ? acc[0] : 0.0f;
-    out[64 + threadIdx.x] = real1 ? acc[1] : 0.0f;
+    out[threadIdx.x] = real ? acc : 0.0f;
     if (kCount && threadIdx.x == 0) {
         atomicAdd(stats, (unsigned long long)walked_exact);
         atomicAdd(stats + 1, (unsigned long long)walked_cap);
@@ -720,7 +768,7 @@ bool use_tree(const tuch_contact_model* m)
 int choose_frontier(const tuch_contact_model* m, int B)
 {
     const char* e = getenv("TUCH_TREE_WAVES");
-    const long target = e ? atol(e) : 65536L;
+    const long target = e ? atol(e) : 32768L;   // counted in 128-query blocks: two wavefronts each
     int f = 0;
     while (f + 1 < m->tree_num_frontiers &&
            (long)B * m->tree_qblocks * (m->tree_frontier_off_host[f + 1] - m->tree_frontier_off_host[f]) < target) ++f;
@@ -796,7 +844,8 @@ void launch_tree_walk(const tuch_contact_model* m, const ExteriorLayout& l, cons
     float* bounds = (float*)(ws + l.bounds);
     launch_tree_boxes(m, verts, B, st, bounds, s);
     const int f0 = m->tree_frontier_off_host[l.tree_frontier];
-    const dim3 grid(B, l.tree_subs * m->tree_qblocks);
+    // the model's query blocks hold 128 vertices (m->tree_qblocks of them): two wavefronts each
+    const dim3 grid(B, 2 * l.tree_subs * m->tree_qblocks);
     const int32_t* frontier = (const int32_t*)m->tree_frontier_nodes + f0;
     const int32_t* ancestors = (const int32_t*)m->tree_ancestors + (size_t)f0 * kMaxAncestors;
     const int32_t* order = (const int32_t*)m->tree_launch_order + (size_t)f0 * m->tree_qblocks;
@@ -890,7 +939,7 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
         launch_tree_walk(m, l, verts, B, ws, nullptr, s);
         hipLaunchKernelGGL(winding_finalize_tree_kernel, dim3(ceil_div(m->V, kBlock), B), dim3(kBlock), 0, s,
                            (const float*)(ws + l.partial), (const int32_t*)m->tree_qperm, m->V,
-                           m->tree_qblocks * kTreeQueries, l.tree_subs, thresh, w, exterior);
+                           2 * m->tree_qblocks * kTreeQueries, l.tree_subs, thresh, w, exterior);
     } else if (use_strips() && m->strip_len > 0) {
         StreamElem* st = (StreamElem*)tris;
         hipLaunchKernelGGL(gather_stream_kernel, dim3(ceil_div(l.lpad, kBlock), B), dim3(kBlock), 0, s, verts,
@@ -947,7 +996,7 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
 // Measurement aid: walk the tree for `verts` and report how many stream elements the wavefronts
 // actually stepped through.  out_host = {leaf-strip elements, cap elements, wavefronts, elements of
 // the flat strip stream (what every 128-query block would step through without the tree)}.
-// One element step serves 128 queries.  Synchronises the stream.
+// One element step serves 64 queries (one wavefront).  Synchronises the stream.
 extern "C" int tuch_winding_tree_work(const tuch_contact_model* m, const float* verts, int B,
                                       void* workspace, size_t workspace_bytes, unsigned long long* out_host, void* stream)
 {
@@ -969,7 +1018,7 @@ extern "C" int tuch_winding_tree_work(const tuch_contact_model* m, const float* 
         tuch_set_error("tuch_winding_tree_work: copy back failed");
         return TUCH_ERR_HIP;
     }
-    out_host[2] = (unsigned long long)B * l.tree_subs * m->tree_qblocks;
+    out_host[2] = (unsigned long long)B * l.tree_subs * m->tree_qblocks * 2;
     out_host[3] = (unsigned long long)m->strip_len;
     return tuch_check_launch("tuch_winding_tree_work");
 }
@@ -987,7 +1036,7 @@ static PointsLayout points_layout(const tuch_contact_model* m, int B, int Q)
     // enough wavefronts to balance the uneven subtree walks (as choose_frontier, for Q points per body)
     int f = 0;
     while (f + 1 < m->tree_num_frontiers &&
-           (long)B * l.qblocks * (m->tree_frontier_off_host[f + 1] - m->tree_frontier_off_host[f]) < 65536L) ++f;
+           (long)B * l.qblocks * (m->tree_frontier_off_host[f + 1] - m->tree_frontier_off_host[f]) < 65536L) ++f;   // wavefronts
     l.frontier = f;
     l.nsub = m->tree_frontier_off_host[f + 1] - m->tree_frontier_off_host[f];
     size_t o = 0;

@@ -416,7 +416,8 @@ class ContactModel:
         out = (ctypes.c_ulonglong * 4)()
         _C.check(L.tuch_winding_tree_work(self._handle, _C.ptr(verts), b, _C.ptr(ws), nbytes, out, _C.stream()))
         return dict(leaf_elements=int(out[0]), cap_elements=int(out[1]), wavefronts=int(out[2]),
-                    flat_stream_elements=int(out[3]), query_blocks=-(-self.num_verts // 128) * b)
+                    flat_stream_elements=int(out[3]), queries_per_step=64,
+                    query_blocks=-(-self.num_verts // 128) * 2 * b)
 
     # K2 + K3
     def exterior_flags(self, verts: torch.Tensor, apply_segments: bool = True, thresh: float = 0.99,
