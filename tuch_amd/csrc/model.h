@@ -65,7 +65,7 @@ struct tuch_contact_model {
     int32_t* seg_faces;        // [seg_f_total,3], cap vertex c is index V + c
     int32_t* cap_off;          // [K+1] into cap_vidx
     int32_t* cap_vidx;         // ordered boundary loops, concatenated
-    int num_seg_blocks;        // 128-query blocks over all segments
+    int num_seg_blocks;        // 64-query blocks over all segments
     int32_t* seg_blocks;       // [num_seg_blocks][2] = (segment, first query within the segment)
     int32_t* seg_of_q;         // [seg_q_total] segment of every entry of seg_q_vidx
     int* seg_q_off_host;       // host copies for grid sizing

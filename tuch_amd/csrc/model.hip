@@ -168,7 +168,7 @@ extern "C" int tuch_contact_model_create(
             }
         std::vector<int32_t> blocks;
         for (int s = 0; s < num_segments; ++s)
-            for (int q = 0; q < seg_q_off[s + 1] - seg_q_off[s]; q += 128) { blocks.push_back(s); blocks.push_back(q); }
+            for (int q = 0; q < seg_q_off[s + 1] - seg_q_off[s]; q += 64) { blocks.push_back(s); blocks.push_back(q); }
         m->num_seg_blocks = (int)blocks.size() / 2;
         std::vector<int32_t> seg_of_q((size_t)m->seg_q_total);
         for (int s = 0; s < num_segments; ++s)

@@ -322,6 +322,38 @@ __device__ __forceinline__ float half_angle_strip1(float num, float den)
     return den == 0.0f ? 0.0f : r;
 }
 
+// Half solid angle atan2(num, den) of one (wave-uniform) triangle for one query per lane (per-triangle form
+// of contact.py:79-105, used for the small closed segment meshes).
+__device__ __forceinline__ float half_solid_angle1(const float* __restrict__ t, float qx, float qy, float qz)
+{
+    const float Ax = t[0] - qx, Ay = t[1] - qy, Az = t[2] - qz;
+    const float Bx = t[3] - qx, By = t[4] - qy, Bz = t[5] - qz;
+    const float Cx = t[6] - qx, Cy = t[7] - qy, Cz = t[8] - qz;
+    const float nA = __builtin_amdgcn_sqrtf(__builtin_fmaf(Az, Az, __builtin_fmaf(Ay, Ay, Ax * Ax)));
+    const float nB = __builtin_amdgcn_sqrtf(__builtin_fmaf(Bz, Bz, __builtin_fmaf(By, By, Bx * Bx)));
+    const float nC = __builtin_amdgcn_sqrtf(__builtin_fmaf(Cz, Cz, __builtin_fmaf(Cy, Cy, Cx * Cx)));
+    const float cx = __builtin_fmaf(By, Cz, -(Bz * Cy));
+    const float cy = __builtin_fmaf(Bz, Cx, -(Bx * Cz));
+    const float cz = __builtin_fmaf(Bx, Cy, -(By * Cx));
+    const float num = __builtin_fmaf(Az, cz, __builtin_fmaf(Ay, cy, Ax * cx));
+    const float dAB = __builtin_fmaf(Az, Bz, __builtin_fmaf(Ay, By, Ax * Bx));
+    const float dBC = __builtin_fmaf(Bz, Cz, __builtin_fmaf(By, Cy, Bx * Cx));
+    const float dAC = __builtin_fmaf(Az, Cz, __builtin_fmaf(Ay, Cy, Ax * Cx));
+    float den = nA * nB * nC;
+    den = __builtin_fmaf(dAB, nC, den);
+    den = __builtin_fmaf(dAC, nB, den);
+    den = __builtin_fmaf(dBC, nA, den);
+    const bool big = !(__builtin_fabsf(num) < 0.125f * den);
+    if (__builtin_amdgcn_ballot_w64(big) == 0) {
+        const float tt = num * __builtin_amdgcn_rcpf(den);
+        const float s2 = tt * tt;
+        float p = __builtin_fmaf(s2, 0.2f, -1.0f / 3.0f);
+        p = __builtin_fmaf(p, s2, 1.0f);
+        return p * tt;
+    }
+    return atan2_single(num, den);
+}
+
 template <int A>
 __device__ __forceinline__ void strip_step1(const StreamElem e, Slot1 (&s)[3], float (&d)[3],
                                             float qx, float qy, float qz, float& acc)
@@ -618,7 +650,7 @@ __global__ __launch_bounds__(kBlock) void gather_segment_triangles_kernel(
 // host-built table (segment, first list position); the segment's faces are split over grid.y
 // and reduced in fixed order by segment_finalize_kernel.  (List order comes from an atomic
 // counter and may vary between runs; every entry's result does not.)
-constexpr int kSegBlock = 64;     // one wave = 128 compacted queries per workgroup
+constexpr int kSegBlock = 64;     // one wave = 64 compacted queries per workgroup
 constexpr int kSegChunk = 128;    // triangles staged in LDS per pass
 constexpr int kSegSplits = 16;   // maximum; few (compacted) queries per segment: parallelism comes from the faces
 int seg_splits()
@@ -665,12 +697,12 @@ __global__ __launch_bounds__(kSegBlock) void segment_winding_kernel(
     if (k_start >= n) return;
     const int q_beg = seg_q_off[s];
     const int32_t* mine = list + (size_t)b * Qs_total + q_beg;
-    const int k0 = k_start + threadIdx.x, k1 = k0 + kSegBlock;
-    const int v0 = seg_q_vidx[q_beg + mine[min(k0, n - 1)]], v1 = seg_q_vidx[q_beg + mine[min(k1, n - 1)]];
+    // one query per lane: the compacted lists are short (a few dozen interior vertices per body and
+    // segment), 64-query blocks waste far fewer lanes than 128-query blocks
+    const int k0 = k_start + threadIdx.x;
+    const int v0 = seg_q_vidx[q_beg + mine[min(k0, n - 1)]];
     const float* vb = verts + (size_t)b * V * 3;
-    const v2f qx = {vb[3 * v0 + 0], vb[3 * v1 + 0]};
-    const v2f qy = {vb[3 * v0 + 1], vb[3 * v1 + 1]};
-    const v2f qz = {vb[3 * v0 + 2], vb[3 * v1 + 2]};
+    const float qx = vb[3 * v0 + 0], qy = vb[3 * v0 + 1], qz = vb[3 * v0 + 2];
     const int f_seg = seg_f_off[s], f_cnt = seg_f_off[s + 1] - f_seg;
     const int nsplit = gridDim.y;
     const int per = (f_cnt + nsplit - 1) / nsplit;
@@ -679,7 +711,7 @@ __global__ __launch_bounds__(kSegBlock) void segment_winding_kernel(
     // full memory latency every iteration.  Stage the chunk's triangles in LDS with coalesced
     // vector loads (many in flight), then read them back as broadcasts.
     __shared__ float sT[kSegChunk * 9];
-    v2f acc = splat2(0.0f);
+    float acc = 0.0f;
     for (int chunk = f_beg; chunk < f_end; chunk += kSegChunk) {
         const int cn = min(kSegChunk, f_end - chunk);
         const float* src = seg_tris + ((size_t)b * Fs_total + chunk) * 9;
@@ -690,12 +722,11 @@ __global__ __launch_bounds__(kSegBlock) void segment_winding_kernel(
             float tri[9];
 #pragma unroll
             for (int e = 0; e < 9; ++e) tri[e] = sT[f * 9 + e];
-            acc += half_solid_angle(tri, qx, qy, qz);
+            acc += half_solid_angle1(tri, qx, qy, qz);
         }
     }
     float* out = partial + ((size_t)b * nsplit + split) * Qs_total + q_beg;
-    if (k0 < n) out[k0] = acc[0];
-    if (k1 < n) out[k1] = acc[1];
+    if (k0 < n) out[k0] = acc;
 }
 
 // vertices that are NOT exterior to their own segment are re-marked exterior in the body
