@@ -470,3 +470,20 @@ def test_winding_points_tree_matches_flat(tag, monkeypatch):
             clear = np.abs(res['0'][0][b][:n] - 0.99) > 1e-4
             assert np.array_equal(res['1'][1][b][:n][clear], res['0'][1][b][:n][clear])
             assert (res['1'][0][b][n:] == 0).all() and (res['1'][1][b][n:] == 1).all()      # padding: w = 0, exterior
+
+
+def test_exterior_and_partner_matches_the_separate_calls(monkeypatch):
+    """The two-stream form used by the loss functions returns exactly what the two calls return."""
+    g, gm = golden('medium'), golden_mask('medium')
+    model = make_model(g, gm, True, True)
+    verts = torch.tensor(g['verts'], device=dev())
+    ext = model.exterior_flags(verts, apply_segments=True)
+    mn, arg = model.v2v_min(verts)
+    for overlap in ('1', '0'):
+        monkeypatch.setenv('TUCH_OVERLAP', overlap)
+        e2, mn2, arg2, extra = model.exterior_and_partner(verts, apply_segments=True,
+                                                          also=lambda: model.region_pair_min(verts, masked=True))
+        torch.cuda.synchronize()
+        assert torch.equal(e2, ext) and torch.equal(mn2, mn) and torch.equal(arg2, arg)
+        r2r, _ = model.region_pair_min(verts, masked=True)
+        assert torch.equal(extra[0], r2r)
