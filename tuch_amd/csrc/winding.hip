@@ -516,13 +516,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const int32_t* __restrict__ frontier, const int32_t* __restrict__ ancestors,   // [S], [S][kMaxAncestors]
     const int32_t* __restrict__ order,           // launch order over (subtree, 128-query block) pairs, or nullptr
     const int32_t* __restrict__ qperm, const int32_t* __restrict__ counts,
-    int V, int T, int nsub, float* __restrict__ partial,   // [B,S,qblocks*64]
+    int V, int T, int nsub, int num_bodies, float* __restrict__ partial,   // [B,S,qblocks*64]
     unsigned long long* __restrict__ stats)
 {
     int walked_exact = 0, walked_cap = 0;
-    // grid (B, pairs): the body index varies fastest (XCD-aware, see winding_strip_kernel); the
-    // (subtree, query block) pairs come in the model's launch order, long-running first
-    const int b = blockIdx.x;
+    // grid (8, pairs, B/8), x fastest: workgroups go round-robin to the 8 XCDs, so XCD x works on body
+    // 8 z + x -- ONE body per XCD at a time, whose 1.1 MB posed stream stays in that XCD's 4 MB L2 (with all
+    // bodies in flight at once, 8 streams competed for each L2 and were fetched twice).  Within a body the
+    // (subtree, query block) pairs come in the model's launch order, long-running first.
+    const int b = blockIdx.z * gridDim.x + blockIdx.x;
+    if (b >= num_bodies) return;
     int sub, qb, i0;
     bool real = true;                                // padding entries of a ragged point set report w = 0
     if (qperm) {
@@ -876,18 +879,18 @@ void launch_tree_walk(const tuch_contact_model* m, const ExteriorLayout& l, cons
     launch_tree_boxes(m, verts, B, st, bounds, s);
     const int f0 = m->tree_frontier_off_host[l.tree_frontier];
     // the model's query blocks hold 128 vertices (m->tree_qblocks of them): two wavefronts each
-    const dim3 grid(B, 2 * l.tree_subs * m->tree_qblocks);
+    const dim3 grid(B < 8 ? B : 8, 2 * l.tree_subs * m->tree_qblocks, ceil_div(B, 8));
     const int32_t* frontier = (const int32_t*)m->tree_frontier_nodes + f0;
     const int32_t* ancestors = (const int32_t*)m->tree_ancestors + (size_t)f0 * kMaxAncestors;
     const int32_t* order = (const int32_t*)m->tree_launch_order + (size_t)f0 * m->tree_qblocks;
     if (stats)
         hipLaunchKernelGGL(winding_tree_kernel<true>, grid, dim3(64), 0, s, verts, (const StreamElem*)st,
                            (const TreeNode*)m->tree_node, (const float*)bounds, m->tree_nodes, frontier, ancestors, order,
-                           (const int32_t*)m->tree_qperm, (const int32_t*)nullptr, m->V, T, l.tree_subs, (float*)(ws + l.partial), stats);
+                           (const int32_t*)m->tree_qperm, (const int32_t*)nullptr, m->V, T, l.tree_subs, B, (float*)(ws + l.partial), stats);
     else
         hipLaunchKernelGGL(winding_tree_kernel<false>, grid, dim3(64), 0, s, verts, (const StreamElem*)st,
                            (const TreeNode*)m->tree_node, (const float*)bounds, m->tree_nodes, frontier, ancestors, order,
-                           (const int32_t*)m->tree_qperm, (const int32_t*)nullptr, m->V, T, l.tree_subs, (float*)(ws + l.partial), stats);
+                           (const int32_t*)m->tree_qperm, (const int32_t*)nullptr, m->V, T, l.tree_subs, B, (float*)(ws + l.partial), stats);
 }
 
 }  // namespace
@@ -1115,11 +1118,11 @@ extern "C" int tuch_winding_points(const tuch_contact_model* m, const float* ver
         }
         launch_tree_boxes(m, verts, B, st, bounds, s);
         const int f0 = m->tree_frontier_off_host[l.frontier];
-        hipLaunchKernelGGL(winding_tree_kernel<false>, dim3(B, l.nsub * l.qblocks), dim3(64), 0, s, points,
+        hipLaunchKernelGGL(winding_tree_kernel<false>, dim3(B < 8 ? B : 8, l.nsub * l.qblocks, ceil_div(B, 8)), dim3(64), 0, s, points,
                            (const StreamElem*)st, (const TreeNode*)m->tree_node, (const float*)bounds, m->tree_nodes,
                            (const int32_t*)m->tree_frontier_nodes + f0,
                            (const int32_t*)m->tree_ancestors + (size_t)f0 * kMaxAncestors, (const int32_t*)nullptr,
-                           (const int32_t*)nullptr, counts, Q, T, l.nsub, partial, (unsigned long long*)nullptr);
+                           (const int32_t*)nullptr, counts, Q, T, l.nsub, B, partial, (unsigned long long*)nullptr);
         hipLaunchKernelGGL(winding_finalize_kernel, dim3(ceil_div(Q, kBlock), B), dim3(kBlock), 0, s,
                            (const float*)partial, Q, stride, l.nsub, thresh, w, exterior);
         return tuch_check_launch("tuch_winding_points");
