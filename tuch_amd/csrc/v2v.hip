@@ -231,7 +231,7 @@ __global__ __launch_bounds__(64 * kIndexedWaves) void v2v_indexed_kernel(
 // ---- tree-pruned form ----------------------------------------------------------------------
 // Same result as v2v_partial/merge, but most rows are never touched.  Vertices are renumbered in
 // the cluster tree's order (cluster_tree.hip: the vertices of a leaf are consecutive, a block of 128
-// columns is a compact patch) and the mask is packed in that numbering.  A wavefront owns 128
+// columns is a compact patch) and the mask is packed in that numbering.  A wavefront owns 64
 // columns and walks the tree: a node is skipped when the mask rules out every (column, row) pair
 // below it (static, per model) or when no column can improve, i.e. for every lane the squared
 // distance from its column to the node's posed box exceeds that column's current minimum
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64 * kIndexedWaves) void v2v_indexed_kernel(
 // walks of a body through 64-bit (distance bits, row) keys merged with atomicMin, so the final
 // key is the lexicographic minimum over all rows attaining the minimum: deterministic, ties go
 // to the smallest row in tree order.
-constexpr int kTreeCols = 128;
+constexpr int kTreeCols = 64;
 constexpr float kPruneSlack = 0.999999f;      // lower bounds are deflated by 1e-6: rounding of the two sums
 
 __device__ __forceinline__ uint64_t v2v_key(float d, int j)
@@ -291,61 +291,51 @@ __global__ __launch_bounds__(kBoundsBlock) void v2v_rows_kernel(
     }
 }
 
-struct ColumnPair {
-    v2f px, py, pz;
-    float best0, best1;
-    int arg0, arg1;
+// One column per lane (64 columns per wavefront): plain and packed FP32 cost the same per float on
+// gfx950, and the union of the columns' search balls is smaller for 64 neighbours than for 128.
+struct Column {
+    float px, py, pz, best;
+    int arg;
 };
 
-// rows [j0, j0+n) against the wave's 128 columns; ties keep the smaller row
-__device__ __forceinline__ void v2v_rows(ColumnPair& c, const float* __restrict__ pb,
-                                         const uint64_t* __restrict__ m0, const uint64_t* __restrict__ m1,
+// rows [j0, j0+n) against the wave's 64 columns; ties keep the smaller row
+__device__ __forceinline__ void v2v_rows(Column& c, const float* __restrict__ pb, const uint64_t* __restrict__ m0,
                                          int j0, int n)
 {
     const float inf = __builtin_inff();
-    auto row = [&](int j, uint64_t k0, uint64_t k1, float vx, float vy, float vz) {
-        const v2f dx = c.px - splat2(vx), dy = c.py - splat2(vy), dz = c.pz - splat2(vz);
-        const v2f d = fma2(dz, dz, fma2(dy, dy, dx * dx));
-        const float d0 = select_by_lane_mask(inf, d[0], k0);
-        const float d1 = select_by_lane_mask(inf, d[1], k1);
-        if (__builtin_amdgcn_ballot_w64(d0 <= c.best0 || d1 <= c.best1)) {       // rare, wave-uniform
-            if (d0 < c.best0 || (d0 == c.best0 && d0 < inf && j < c.arg0)) { c.best0 = d0; c.arg0 = j; }
-            if (d1 < c.best1 || (d1 == c.best1 && d1 < inf && j < c.arg1)) { c.best1 = d1; c.arg1 = j; }
+    auto row = [&](int j, uint64_t k0, float vx, float vy, float vz) {
+        const float dx = c.px - vx, dy = c.py - vy, dz = c.pz - vz;
+        const float d = select_by_lane_mask(inf, __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)), k0);
+        if (__builtin_amdgcn_ballot_w64(d <= c.best)) {                       // rare, wave-uniform
+            if (d < c.best || (d == c.best && d < inf && j < c.arg)) { c.best = d; c.arg = j; }
         }
     };
     int j = j0;
     const int j_end = j0 + n;
     for (; j + 4 <= j_end; j += 4) {
-        uint64_t k0[4], k1[4];
+        uint64_t k0[4];
         float v[12];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { k0[u] = m0[j + u]; k1[u] = m1[j + u]; }
+        for (int u = 0; u < 4; ++u) k0[u] = m0[j + u];
 #pragma unroll
         for (int u = 0; u < 12; ++u) v[u] = pb[3 * j + u];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) row(j + u, k0[u], k1[u], v[3 * u], v[3 * u + 1], v[3 * u + 2]);
+        for (int u = 0; u < 4; ++u) row(j + u, k0[u], v[3 * u], v[3 * u + 1], v[3 * u + 2]);
     }
-    for (; j < j_end; ++j) row(j, m0[j], m1[j], pb[3 * j], pb[3 * j + 1], pb[3 * j + 2]);
+    for (; j < j_end; ++j) row(j, m0[j], pb[3 * j], pb[3 * j + 1], pb[3 * j + 2]);
 }
 
-// squared distance from each of the lane's two columns to a box
-__device__ __forceinline__ v2f box_dist2(const ColumnPair& c, const float* __restrict__ box)
+// squared distance from the lane's column to a box
+__device__ __forceinline__ float box_dist2(const Column& c, const float* __restrict__ box)
 {
-    const v2f zero = splat2(0.0f);
-    const v2f ex = __builtin_elementwise_max(__builtin_elementwise_max(splat2(box[0]) - c.px, c.px - splat2(box[4])), zero);
-    const v2f ey = __builtin_elementwise_max(__builtin_elementwise_max(splat2(box[1]) - c.py, c.py - splat2(box[5])), zero);
-    const v2f ez = __builtin_elementwise_max(__builtin_elementwise_max(splat2(box[2]) - c.pz, c.pz - splat2(box[6])), zero);
-    return fma2(ez, ez, fma2(ey, ey, ex * ex));
+    const float ex = __builtin_fmaxf(__builtin_fmaxf(box[0] - c.px, c.px - box[4]), 0.0f);
+    const float ey = __builtin_fmaxf(__builtin_fmaxf(box[1] - c.py, c.py - box[5]), 0.0f);
+    const float ez = __builtin_fmaxf(__builtin_fmaxf(box[2] - c.pz, c.pz - box[6]), 0.0f);
+    return __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
 }
 
-__device__ __forceinline__ void load_columns(ColumnPair& c, const float* __restrict__ pb, int i0, int i1)
-{
-    c.px = (v2f){pb[3 * i0], pb[3 * i1]};
-    c.py = (v2f){pb[3 * i0 + 1], pb[3 * i1 + 1]};
-    c.pz = (v2f){pb[3 * i0 + 2], pb[3 * i1 + 2]};
-}
-
-// seed: descend to the admissible leaf nearest to the block's box, evaluate its rows
+// seed: descend to the admissible leaf nearest to the block's box, evaluate its rows.
+// grid (B, 64-column blocks); the static mask table is kept per 128-column block (qb >> 1).
 __global__ __launch_bounds__(64) void v2v_seed_kernel(
     const float* __restrict__ prow, int V, int Vp, const uint64_t* __restrict__ bits,
     const TreeNode* __restrict__ nodes, const int32_t* __restrict__ rows, const float* __restrict__ bounds,
@@ -353,13 +343,12 @@ __global__ __launch_bounds__(64) void v2v_seed_kernel(
 {
     const int b = blockIdx.x, qb = blockIdx.y, lane = threadIdx.x;
     const float* pb = prow + (size_t)b * Vp * 3;
-    const int i0 = qb * kTreeCols + lane, i1 = i0 + 64;
-    ColumnPair c;
-    load_columns(c, pb, i0, i1);
-    c.best0 = c.best1 = __builtin_inff();
-    c.arg0 = c.arg1 = 0;
-    float lo[3] = {fminf(c.px[0], c.px[1]), fminf(c.py[0], c.py[1]), fminf(c.pz[0], c.pz[1])};
-    float hi[3] = {fmaxf(c.px[0], c.px[1]), fmaxf(c.py[0], c.py[1]), fmaxf(c.pz[0], c.pz[1])};
+    const int i0 = qb * kTreeCols + lane;
+    Column c;
+    c.px = pb[3 * i0]; c.py = pb[3 * i0 + 1]; c.pz = pb[3 * i0 + 2];
+    c.best = __builtin_inff();
+    c.arg = 0;
+    float lo[3] = {c.px, c.py, c.pz}, hi[3] = {c.px, c.py, c.pz};
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1)
 #pragma unroll
@@ -368,7 +357,7 @@ __global__ __launch_bounds__(64) void v2v_seed_kernel(
             hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m));
         }
     const float* bb = bounds + (size_t)b * N * 8;
-    const int32_t* mk = masked + (size_t)qb * N;
+    const int32_t* mk = masked + (size_t)(qb >> 1) * N;
     auto gap2 = [&](int node) {                 // squared distance between the block's box and the node's box
         const float* box = bb + (size_t)node * 8;
         float g = 0.0f;
@@ -394,13 +383,8 @@ __global__ __launch_bounds__(64) void v2v_seed_kernel(
             ok = false;
         }
     }
-    if (ok) {
-        const uint64_t* m0 = bits + (size_t)(2 * qb) * V;
-        v2v_rows(c, pb, m0, m0 + V, rows[2 * node], rows[2 * node + 1]);
-    }
-    uint64_t* kb = keys + (size_t)b * Vp;
-    kb[i0] = v2v_key(c.best0, c.arg0);
-    kb[i1] = v2v_key(c.best1, c.arg1);
+    if (ok) v2v_rows(c, pb, bits + (size_t)qb * V, rows[2 * node], rows[2 * node + 1]);
+    keys[(size_t)b * Vp + i0] = v2v_key(c.best, c.arg);
 }
 
 __global__ __launch_bounds__(64) void v2v_tree_kernel(
@@ -410,44 +394,41 @@ __global__ __launch_bounds__(64) void v2v_tree_kernel(
     const int32_t* __restrict__ order, uint64_t* __restrict__ keys)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
-    const int pair = __builtin_amdgcn_readfirstlane(order[blockIdx.y]);
-    const int sub = pair >> 16, qb = pair & 0xffff;
+    const int pair = __builtin_amdgcn_readfirstlane(order[blockIdx.y >> 1]);      // launch order over 128-blocks
+    const int sub = pair >> 16, qb = (pair & 0xffff) * 2 + (blockIdx.y & 1);
     const float* pb = prow + (size_t)b * Vp * 3;
-    const int i0 = qb * kTreeCols + lane, i1 = i0 + 64;
+    const int i0 = qb * kTreeCols + lane;
     uint64_t* kb = keys + (size_t)b * Vp;
     // any value read here is the key of a real row (seed, or another walk's improvement): a valid bound
-    const uint64_t init0 = __hip_atomic_load(kb + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint64_t init1 = __hip_atomic_load(kb + i1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ColumnPair c;
-    load_columns(c, pb, i0, i1);
-    c.best0 = __uint_as_float((uint32_t)(init0 >> 32)); c.arg0 = (int)(uint32_t)init0;
-    c.best1 = __uint_as_float((uint32_t)(init1 >> 32)); c.arg1 = (int)(uint32_t)init1;
+    const uint64_t init = __hip_atomic_load(kb + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    Column c;
+    c.px = pb[3 * i0]; c.py = pb[3 * i0 + 1]; c.pz = pb[3 * i0 + 2];
+    c.best = __uint_as_float((uint32_t)(init >> 32));
+    c.arg = (int)(uint32_t)init;
     const float* bb = bounds + (size_t)b * N * 8;
-    const int32_t* mk = masked + (size_t)qb * N;
-    const uint64_t* m0 = bits + (size_t)(2 * qb) * V;
-    const uint64_t* m1 = m0 + V;
+    const int32_t* mk = masked + (size_t)(qb >> 1) * N;
+    const uint64_t* m0 = bits + (size_t)qb * V;
     int node = __builtin_amdgcn_readfirstlane(frontier[sub]);
     const int end = __builtin_amdgcn_readfirstlane(nodes[node].skip);
     while (node < end) {
         const TreeNode nd = nodes[node];
         bool descend = mk[node] == 0;
         if (descend) {
-            const v2f g = box_dist2(c, bb + (size_t)node * 8) * splat2(kPruneSlack);
-            descend = __builtin_amdgcn_ballot_w64(g[0] <= c.best0 || g[1] <= c.best1) != 0;
+            const float g = box_dist2(c, bb + (size_t)node * 8) * kPruneSlack;
+            descend = __builtin_amdgcn_ballot_w64(g <= c.best) != 0;
         }
         if (!descend) {
             node = nd.skip;
         } else if (nd.c0 < 0) {
-            v2v_rows(c, pb, m0, m1, rows[2 * node], rows[2 * node + 1]);
+            v2v_rows(c, pb, m0, rows[2 * node], rows[2 * node + 1]);
             node = nd.skip;
         } else {
             node = node + 1;
         }
         node = __builtin_amdgcn_readfirstlane(node);
     }
-    const uint64_t k0 = v2v_key(c.best0, c.arg0), k1 = v2v_key(c.best1, c.arg1);
-    if (k0 < init0) atomicMin((unsigned long long*)(kb + i0), (unsigned long long)k0);
-    if (k1 < init1) atomicMin((unsigned long long*)(kb + i1), (unsigned long long)k1);
+    const uint64_t k0 = v2v_key(c.best, c.arg);
+    if (k0 < init) atomicMin((unsigned long long*)(kb + i0), (unsigned long long)k0);
 }
 
 // keys -> (min, argmin) in the caller's vertex numbering; all-masked column -> (inf, 0)
@@ -473,7 +454,7 @@ TreeV2VLayout tree_v2v_layout(const tuch_contact_model* m, int B)
 {
     TreeV2VLayout l;
     size_t o = 0;
-    const int Vp = m->tree_qblocks * kTreeCols;
+    const int Vp = m->tree_qblocks * 2 * kTreeCols;
     l.prow = o;   o += align256((size_t)B * Vp * 3 * sizeof(float) + 64);
     l.bounds = o; o += align256((size_t)B * m->tree_nodes * 8 * sizeof(float));
     l.keys = o;   o += align256((size_t)B * Vp * sizeof(uint64_t));
@@ -582,19 +563,19 @@ extern "C" int tuch_v2v_min_model(const tuch_contact_model* m, const float* vert
     float* bounds = (float*)(ws + l.bounds);
     uint64_t* keys = (uint64_t*)(ws + l.keys);
     hipStream_t s = (hipStream_t)stream;
-    const int V = m->V, Vp = m->tree_qblocks * kTreeCols, N = m->tree_nodes;
+    const int V = m->V, Vp = m->tree_qblocks * 2 * kTreeCols, N = m->tree_nodes;
     const TreeNode* nodes = (const TreeNode*)m->tree_node;
     hipLaunchKernelGGL(v2v_rows_kernel, dim3(ceil_div(m->tree_leaves, kBoundsBlock / 64), B), dim3(kBoundsBlock), 0, s,
                        verts, V, Vp, (const int32_t*)m->tree_qperm, (const int32_t*)m->tree_rows,
                        (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, N, prow, bounds);
     hipLaunchKernelGGL(tree_inner_bounds_kernel<4>, dim3(B), dim3(kBoundsBlock), (size_t)N * 8 * sizeof(float), s, nodes, N,
                        (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, m->tree_heights, bounds);
-    hipLaunchKernelGGL(v2v_seed_kernel, dim3(B, m->tree_qblocks), dim3(64), 0, s, (const float*)prow, V, Vp,
+    hipLaunchKernelGGL(v2v_seed_kernel, dim3(B, 2 * m->tree_qblocks), dim3(64), 0, s, (const float*)prow, V, Vp,
                        (const uint64_t*)m->tree_mask_bits, nodes, (const int32_t*)m->tree_rows, (const float*)bounds,
                        (const int32_t*)m->tree_masked, N, keys);
     const int f = choose_v2v_frontier(m, B);
     const int f0 = m->tree_frontier_off_host[f], nsub = m->tree_frontier_off_host[f + 1] - f0;
-    hipLaunchKernelGGL(v2v_tree_kernel, dim3(B, nsub * m->tree_qblocks), dim3(64), 0, s, (const float*)prow, V, Vp,
+    hipLaunchKernelGGL(v2v_tree_kernel, dim3(B, 2 * nsub * m->tree_qblocks), dim3(64), 0, s, (const float*)prow, V, Vp,
                        (const uint64_t*)m->tree_mask_bits, nodes, (const int32_t*)m->tree_rows, (const float*)bounds,
                        (const int32_t*)m->tree_masked, N, (const int32_t*)m->tree_frontier_nodes + f0,
                        (const int32_t*)m->tree_launch_order + (size_t)f0 * m->tree_qblocks, keys);
