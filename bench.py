@@ -154,15 +154,21 @@ def capture(step, warmup):
 
 
 def time_kernel(fn, iters):
+    """Seconds per call (HIP events on the current stream); best of two passes after two warm-up calls, so that
+    a one-off allocator growth does not land in the figure."""
+    fn()
     fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e-3      # seconds per launch
+    best = float('inf')
+    for _ in range(2):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / iters * 1e-3)
+    return best
 
 
 def rooflines(p, batch):

@@ -245,6 +245,15 @@ int tuch_estimate_translation(const float* joints3d, const float* keypoints2d, c
                               float focal_length, float img_size, float* trans, void* stream);
 int tuch_rotmat_to_angle_axis(const float* rotmat, int N, int row_stride, float* angle_axis, void* stream);
 
+/* HD points of tuch/train/loss.py:285 (hd = Vert_Regressor[selected] @ verts, a dense [N_hd,6890] matrix with three
+ * non-zeros per row): point n belongs to body body_of_point[n] and is HD point hd_of_point[n];
+ * points[n] = sum_k hd_w[h][k] * verts[body][hd_idx[h][k]].  verts [B,V,3], hd_idx / hd_w [N_hd,3], points [N,3].
+ * The adjoint ADDS into grad_verts [B,V,3] (float atomics; zero it first). */
+int tuch_hd_points_fwd(const float* verts, const int32_t* body_of_point, const int32_t* hd_of_point,
+                       const int32_t* hd_idx, const float* hd_w, int V, int N, float* points, void* stream);
+int tuch_hd_points_bwd(const float* grad_points, const int32_t* body_of_point, const int32_t* hd_of_point,
+                       const int32_t* hd_idx, const float* hd_w, int V, int N, float* grad_verts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

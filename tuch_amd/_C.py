@@ -55,6 +55,8 @@ _SIGNATURES = {
     'tuch_cluster_tree_free': (None, [c_void_p]),
     'tuch_cluster_tree_info': (c_int, [c_void_p] + [POINTER(c_int)] * 6),
     'tuch_cluster_tree_export': (c_int, [c_void_p] * 10),
+    'tuch_hd_points_fwd': (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p, c_void_p]),
+    'tuch_hd_points_bwd': (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p, c_void_p]),
     'tuch_estimate_translation': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p]),
     'tuch_rotmat_to_angle_axis': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'tuch_winding_tree_work': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),

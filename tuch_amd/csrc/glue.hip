@@ -126,3 +126,68 @@ extern "C" int tuch_rotmat_to_angle_axis(const float* rotmat, int N, int row_str
                        rotmat, N, row_stride, angle_axis);
     return tuch_check_launch("tuch_rotmat_to_angle_axis");
 }
+
+// ---- HD points (tuch/train/loss.py:285: hd = Vert_Regressor[selected] @ verts) -----------------------
+// The reference multiplies a dense [N_hd, 6890] regressor with the vertices; every row has three non-zeros
+// (barycentric weights of the face the point was sampled from).  Here: point n of body body[n] is HD point
+// hd[n]: out[n] = sum_k w[hd[n]][k] * verts[body[n]][idx[hd[n]][k]]; the adjoint scatters with atomics.
+namespace {
+
+__global__ __launch_bounds__(256) void hd_points_fwd_kernel(
+    const float* __restrict__ verts, const int32_t* __restrict__ body, const int32_t* __restrict__ hd,
+    const int32_t* __restrict__ idx, const float* __restrict__ w, int V, int N, float* __restrict__ out)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const float* vb = verts + (size_t)body[n] * V * 3;
+    const int h = hd[n];
+    float x = 0.f, y = 0.f, z = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float wk = w[3 * (size_t)h + k];
+        const float* p = vb + 3 * (size_t)idx[3 * (size_t)h + k];
+        x = __builtin_fmaf(wk, p[0], x); y = __builtin_fmaf(wk, p[1], y); z = __builtin_fmaf(wk, p[2], z);
+    }
+    out[3 * (size_t)n] = x; out[3 * (size_t)n + 1] = y; out[3 * (size_t)n + 2] = z;
+}
+
+__global__ __launch_bounds__(256) void hd_points_bwd_kernel(
+    const float* __restrict__ g, const int32_t* __restrict__ body, const int32_t* __restrict__ hd,
+    const int32_t* __restrict__ idx, const float* __restrict__ w, int V, int N, float* __restrict__ g_verts)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float* gb = g_verts + (size_t)body[n] * V * 3;
+    const int h = hd[n];
+    const float gx = g[3 * (size_t)n], gy = g[3 * (size_t)n + 1], gz = g[3 * (size_t)n + 2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float wk = w[3 * (size_t)h + k];
+        float* p = gb + 3 * (size_t)idx[3 * (size_t)h + k];
+        atomicAdd(p, wk * gx); atomicAdd(p + 1, wk * gy); atomicAdd(p + 2, wk * gz);
+    }
+}
+
+}  // namespace
+
+extern "C" int tuch_hd_points_fwd(const float* verts, const int32_t* body_of_point, const int32_t* hd_of_point,
+                                  const int32_t* hd_idx, const float* hd_w, int V, int N, float* points, void* stream)
+{
+    TUCH_REQUIRE(verts && body_of_point && hd_of_point && hd_idx && hd_w && points, "tuch_hd_points_fwd: null pointer");
+    TUCH_REQUIRE(V > 0 && N >= 0, "tuch_hd_points_fwd: bad sizes");
+    if (N == 0) return TUCH_OK;
+    hipLaunchKernelGGL(hd_points_fwd_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, verts,
+                       body_of_point, hd_of_point, hd_idx, hd_w, V, N, points);
+    return tuch_check_launch("tuch_hd_points_fwd");
+}
+
+extern "C" int tuch_hd_points_bwd(const float* grad_points, const int32_t* body_of_point, const int32_t* hd_of_point,
+                                  const int32_t* hd_idx, const float* hd_w, int V, int N, float* grad_verts, void* stream)
+{
+    TUCH_REQUIRE(grad_points && body_of_point && hd_of_point && hd_idx && hd_w && grad_verts, "tuch_hd_points_bwd: null pointer");
+    TUCH_REQUIRE(V > 0 && N >= 0, "tuch_hd_points_bwd: bad sizes");
+    if (N == 0) return TUCH_OK;
+    hipLaunchKernelGGL(hd_points_bwd_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, grad_points,
+                       body_of_point, hd_of_point, hd_idx, hd_w, V, N, grad_verts);
+    return tuch_check_launch("tuch_hd_points_bwd");
+}

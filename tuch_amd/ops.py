@@ -135,6 +135,35 @@ class _ContactTerms(torch.autograd.Function):
         return grad, None, None, None, None, None
 
 
+class _HDPoints(torch.autograd.Function):
+    """points[n] = sum_k w[hd[n],k] * verts[body[n], idx[hd[n],k]]  (loss.py:285 with the regressor's 3 non-zeros per row)."""
+
+    @staticmethod
+    def forward(ctx, verts, body, hd, idx, w):
+        v = _f32(verts)
+        n = body.shape[0]
+        out = torch.empty(n, 3, dtype=torch.float32, device=v.device)
+        _C.check(_C.lib().tuch_hd_points_fwd(_C.ptr(v), _C.ptr(body), _C.ptr(hd), _C.ptr(idx), _C.ptr(w), v.shape[1], n,
+                                             _C.ptr(out), _C.stream()))
+        ctx.save_for_backward(body, hd, idx, w)
+        ctx.shape = v.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        body, hd, idx, w = ctx.saved_tensors
+        g = grad.to(torch.float32).contiguous()
+        gv = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
+        _C.check(_C.lib().tuch_hd_points_bwd(_C.ptr(g), _C.ptr(body), _C.ptr(hd), _C.ptr(idx), _C.ptr(w), ctx.shape[1],
+                                             body.shape[0], _C.ptr(gv), _C.stream()))
+        return gv, None, None, None, None
+
+
+def hd_points(verts, body_of_point, hd_of_point, hd_idx, hd_w):
+    """Selected HD points [N,3] of posed vertices [B,V,3]; int32 indices, hd_idx / hd_w [N_hd,3]."""
+    return _HDPoints.apply(verts, body_of_point, hd_of_point, hd_idx, hd_w)
+
+
 class _ContactTermsRagged(torch.autograd.Function):
     """terms[b] over the ragged point set of body b (HD points): points [N,3], global partner indices."""
 

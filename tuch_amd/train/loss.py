@@ -64,7 +64,8 @@ class RegressorLoss(nn.Module):
             except _C.TuchError:      # open mesh: no tree, the flat walk does not care about the order
                 pass
             self.hd_idx = torch.as_tensor(hd_i, dtype=torch.long, device=dev)
-            self.hd_w = torch.as_tensor(hd_wt, dtype=torch.float32, device=dev)
+            self.hd_w = torch.as_tensor(hd_wt, dtype=torch.float32, device=dev).contiguous()
+            self.hd_idx32 = self.hd_idx.to(torch.int32).contiguous()
             self.geovec = torch.as_tensor(hd_f, dtype=torch.long, device=dev)
             self.geovec_verts = self.face_tensor[0][self.geovec][:, 0]            # loss.py:88
         self.segments = segments
@@ -99,8 +100,8 @@ class RegressorLoss(nn.Module):
             n_max = int(counts.max().item())
         if bidx.numel() == 0:
             return pred_vertices.sum() * 0.0
-        corner = self.hd_idx[hidx]                                                        # [N,3]
-        hd = (pred_vertices[bidx[:, None], corner] * self.hd_w[hidx][:, :, None]).sum(1)  # :285
+        bidx32 = bidx.to(torch.int32)
+        hd = ops.hd_points(pred_vertices, bidx32, hidx.to(torch.int32), self.hd_idx32, self.hd_w)   # :285
         with torch.no_grad():
             vid = self.geovec_verts[hidx].to(torch.int32)
             _, arg = model.v2v_min_indexed(hd, vid, offsets, n_max)                       # :288-291
@@ -114,7 +115,7 @@ class RegressorLoss(nn.Module):
             padded[bidx, slot] = offs
             _, ext_pad = model.winding_points(pred_vertices, padded, counts.to(torch.int32))   # :297
             ext_hd = ext_pad[bidx, slot].contiguous()
-        terms = ops.contact_terms_ragged(hd, partner_hd, ext_hd, offsets, bidx.to(torch.int32),
+        terms = ops.contact_terms_ragged(hd, partner_hd, ext_hd, offsets, bidx32,
                                          ops.MODE_TRAIN, self.euclthres)                  # :299-315
         return terms.sum() / n_valid
 
