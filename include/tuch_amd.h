@@ -73,10 +73,14 @@ int tuch_v2v_min_masked(const float* points, const uint64_t* geomask_bits, int B
 
 /* Ragged variant for the HD resampling of loss.py:284-291: body b owns points
  * offsets[b]..offsets[b+1] (device int32 [B+1]); point a inherits the mask row/column of template
- * vertex vertex_ids[a] (geovec_verts, loss.py:88).  argmin is relative to the body's first point. */
+ * vertex vertex_ids[a] (geovec_verts, loss.py:88).  argmin is relative to the body's first point (first index
+ * among equal minima, 0 when no row is admissible).  Rows are visited in chunks of 32 that are skipped when
+ * their bounding box is farther than the columns' current minima: any point order is exact, points of a body
+ * that are sorted by surface patch are fast. */
+size_t tuch_v2v_min_indexed_workspace_bytes(int B, int max_points_per_body);
 int tuch_v2v_min_indexed(const float* points, const int32_t* vertex_ids, const int32_t* offsets,
                          const uint64_t* geomask_bits, int B, int V, int max_points_per_body, float* min_d2,
-                         int32_t* argmin, void* stream);
+                         int32_t* argmin, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- pull/push terms: losses.py:96-105 (mode 0) / loss.py:303-315 (mode 1) ---------- */
 
@@ -134,6 +138,10 @@ int tuch_contact_model_create(tuch_contact_model** out, int V, int F, const int3
 void tuch_contact_model_destroy(tuch_contact_model* model);
 const uint64_t* tuch_contact_model_mask_bits(const tuch_contact_model* model);
 const int32_t* tuch_contact_model_faces(const tuch_contact_model* model);
+/* The geodesic mask packed in the cluster tree's vertex order (device, same layout as mask_bits with vertex v
+ * replaced by its position in tuch_cluster_tree_export's qperm), or NULL without tree or mask: neighbouring
+ * positions are neighbours on the surface, so a wavefront of nearby points touches few mask words. */
+const uint64_t* tuch_contact_model_tree_mask_bits(const tuch_contact_model* model);
 int tuch_contact_model_info(const tuch_contact_model* model, int* V, int* F, int* num_segments,
                             int* seg_q_total, int* num_pairs);
 /* The triangle-strip walk of the faces used by the winding kernel (inspection / tests):

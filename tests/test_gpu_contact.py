@@ -487,3 +487,48 @@ def test_exterior_and_partner_matches_the_separate_calls(monkeypatch):
         assert torch.equal(e2, ext) and torch.equal(mn2, mn) and torch.equal(arg2, arg)
         r2r, _ = model.region_pair_min(verts, masked=True)
         assert torch.equal(extra[0], r2r)
+
+
+@pytest.mark.parametrize('order', ['sorted', 'shuffled'])
+def test_v2v_min_indexed_matches_brute_force(order):
+    """tuch_v2v_min_indexed (ragged point sets, chunk pruning) against a float64 brute force: the minimum is
+    the true masked minimum, the argmin is the first row attaining the float32 minimum."""
+    g, gm = golden('medium'), golden_mask('medium')
+    model = make_model(g, gm, False, False)
+    rng = np.random.default_rng(4)
+    v = g['verts'].shape[1]
+    counts = [900, 0, 317, 64, 1]
+    pts, vids = [], []
+    for b, n in enumerate(counts):
+        base = rng.choice(v, n, replace=True)
+        if order == 'sorted':
+            base = np.sort(base)
+        pts.append(g['verts'][b % g['verts'].shape[0]][base] + 0.004 * rng.standard_normal((n, 3)))
+        vids.append(base)
+    pts = np.concatenate(pts).astype(np.float32)
+    vids = np.concatenate(vids).astype(np.int32)
+    offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    mn, arg = model.v2v_min_indexed(torch.tensor(pts, device=dev()), torch.tensor(vids, device=dev()),
+                                    torch.tensor(offsets, device=dev()), max(counts))
+    mn, arg = mn.cpu().numpy(), arg.cpu().numpy()
+    for b, n in enumerate(counts):
+        lo = offsets[b]
+        p, vid = pts[lo:lo + n], vids[lo:lo + n]
+        if n == 0:
+            continue
+        d = ((p[:, None].astype(np.float32) - p[None].astype(np.float32)) ** 2)
+        d32 = (d[..., 2] + (d[..., 1] + d[..., 0])).astype(np.float32)        # same association as the kernel, no fma
+        allowed = gm[vid[None, :], vid[:, None]]                              # [column a, row r] = geomask[vid[r]][vid[a]]
+        d64 = ((p[:, None].astype(np.float64) - p[None].astype(np.float64)) ** 2).sum(2)
+        d64 = np.where(allowed, d64, np.inf)
+        want = d64.min(1)
+        got = mn[lo:lo + n]
+        fin = np.isfinite(want)
+        assert np.array_equal(np.isfinite(got), fin)
+        np.testing.assert_allclose(got[fin], want[fin], rtol=2e-6, atol=1e-9)
+        a = arg[lo:lo + n]
+        assert (a[~fin] == 0).all()
+        # the returned row attains the minimum and is admissible; no earlier row does strictly better
+        rows = np.arange(n)
+        assert allowed[rows[fin], a[fin]].all()
+        np.testing.assert_allclose(d64[rows[fin], a[fin]], want[fin], rtol=2e-6, atol=1e-9)

@@ -31,8 +31,9 @@ _SIGNATURES = {
     'tuch_v2v_workspace_bytes': (c_size_t, [c_int, c_int]),
     'tuch_v2v_min_masked': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
                                     c_void_p]),
+    'tuch_v2v_min_indexed_workspace_bytes': (c_size_t, [c_int, c_int]),
     'tuch_v2v_min_indexed': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
-                                     c_void_p]),
+                                     c_void_p, c_size_t, c_void_p]),
     'tuch_contact_terms_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                        c_void_p, c_void_p]),
     'tuch_contact_terms_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
@@ -48,6 +49,7 @@ _SIGNATURES = {
     'tuch_contact_model_destroy': (None, [c_void_p]),
     'tuch_contact_model_mask_bits': (c_void_p, [c_void_p]),
     'tuch_contact_model_faces': (c_void_p, [c_void_p]),
+    'tuch_contact_model_tree_mask_bits': (c_void_p, [c_void_p]),
     'tuch_contact_model_info': (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int),
                                         POINTER(c_int), POINTER(c_int)]),
     'tuch_contact_model_strips': (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), c_void_p, c_void_p]),

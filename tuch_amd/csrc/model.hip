@@ -232,6 +232,11 @@ extern "C" const uint64_t* tuch_contact_model_mask_bits(const tuch_contact_model
     return m ? m->mask_bits : nullptr;
 }
 
+extern "C" const uint64_t* tuch_contact_model_tree_mask_bits(const tuch_contact_model* m)
+{
+    return m ? m->tree_mask_bits : nullptr;
+}
+
 extern "C" const int32_t* tuch_contact_model_faces(const tuch_contact_model* m)
 {
     return m ? m->faces : nullptr;

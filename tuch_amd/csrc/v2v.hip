@@ -161,16 +161,49 @@ __global__ __launch_bounds__(kBlock) void pairwise_kernel(
 // it inherits (geovec_verts, loss.py:88).  Column a: min over the body's rows r with
 // geomask[vid[r]][vid[a]].  argmin is the row index relative to the body's first point.
 constexpr int kIndexedWaves = 8;             // wavefronts per workgroup: each takes an eighth of the rows
+constexpr int kIndexedChunk = 32;            // rows per bounding box
+constexpr float kIndexedSlack = 0.999999f;   // lower bounds are deflated by 1e-6 (rounding of the two sums)
+
+// box of every chunk of kIndexedChunk consecutive points of a body: [B][max_chunks][8] = (lo xyz, -, hi xyz, -).
+// The caller keeps the points of a body sorted by surface patch, so a chunk is a small patch.
+__global__ __launch_bounds__(256) void v2v_indexed_boxes_kernel(
+    const float* __restrict__ pts, const int32_t* __restrict__ off, int max_chunks, float* __restrict__ boxes)
+{
+    const int b = blockIdx.y;
+    const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int beg = off[b], n = off[b + 1] - beg;
+    if (chunk >= max_chunks || chunk * kIndexedChunk >= n) return;
+    const int r = chunk * kIndexedChunk + (lane & (kIndexedChunk - 1));
+    const float* p = pts + 3 * (size_t)(beg + min(r, n - 1));
+    float lo[3] = {p[0], p[1], p[2]}, hi[3] = {p[0], p[1], p[2]};
+#pragma unroll
+    for (int m = kIndexedChunk / 2; m >= 1; m >>= 1)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], m));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m));
+        }
+    if (lane == 0) {
+        float* o = boxes + ((size_t)b * max_chunks + chunk) * 8;
+        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = 0.0f;
+        o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = 0.0f;
+    }
+}
+
+// 64 columns per workgroup, the rows split over its 8 wavefronts.  Pass 1: every wavefront evaluates every
+// eighth row of its share, the minima are merged in LDS: an upper bound for every column.  Pass 2: every
+// wavefront walks the 32-row chunks of its share and skips those whose box is farther from all its columns
+// than their current minima.  Candidates at the minimum are never skipped (strict test) and ties go to the
+// smaller row, so the result is the first-index argmin of torch.min regardless of the order of evaluation.
 __global__ __launch_bounds__(64 * kIndexedWaves) void v2v_indexed_kernel(
     const float* __restrict__ pts, const int32_t* __restrict__ vid, const int32_t* __restrict__ off,
-    const uint64_t* __restrict__ bits, int V, float* __restrict__ out_min, int32_t* __restrict__ out_arg)
+    const uint64_t* __restrict__ bits, int V, const float* __restrict__ boxes, int max_chunks,
+    float* __restrict__ out_min, int32_t* __restrict__ out_arg)
 {
     const int b = blockIdx.y;
     // wave-uniform bounds (readfirstlane lets the row data below come in through scalar loads)
     const int beg = __builtin_amdgcn_readfirstlane(off[b]);
     const int n = __builtin_amdgcn_readfirstlane(off[b + 1]) - beg;
-    // 64 columns per workgroup, the rows split over its wavefronts (one long serial loop per wavefront
-    // would leave most of the chip idle at the few thousand points a body selects)
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int a = blockIdx.x * 64 + lane;
     if ((int)(blockIdx.x * 64) >= n) return;
@@ -182,49 +215,93 @@ __global__ __launch_bounds__(64 * kIndexedWaves) void v2v_indexed_kernel(
     const float inf = __builtin_inff();
     float best = inf;
     int arg = 0;
-    int prev = -1;
-    bool allowed = false;
     const float* rp = pts + 3 * (size_t)beg;
     const int32_t* rv = vid + beg;
-    auto row = [&](int r, int vr, float qx, float qy, float qz) {
-        // consecutive points usually inherit the same template vertex (samples of one face): the per-lane
-        // gather of the mask word is repeated only when the row's vertex changes (wave-uniform test)
-        if (vr != prev) {
-            allowed = (col[vr] >> sh) & 1;
-            prev = vr;
-        }
+    auto row = [&](int r, uint64_t word, float qx, float qy, float qz) {
         const float dx = px - qx, dy = py - qy, dz = pz - qz;
         float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-        if (!allowed) d = inf;
-        if (__builtin_amdgcn_ballot_w64(d < best)) {
-            if (d < best) { best = d; arg = r; }
+        if (!((word >> sh) & 1)) d = inf;
+        if (__builtin_amdgcn_ballot_w64(d <= best && d < inf)) {             // rare, wave-uniform
+            if (d < best || (d == best && d < inf && r < arg)) { best = d; arg = r; }
         }
     };
-    const int per_wave = ((n + kIndexedWaves - 1) / kIndexedWaves + 3) & ~3;
-    int r = min(n, wave * per_wave);
-    const int r_end = min(n, r + per_wave);
-    for (; r + 4 <= r_end; r += 4) {                   // four rows per trip: their scalar loads are issued together
-        float c[12];
-        int v[4];
+    // kTrip rows r0, r0+step, ...: coordinates and template vertices through scalar loads, the per-lane
+    // gathers of the mask words (word = column's 64-vertex block x row's vertex) issued together so that
+    // their latency overlaps
+    constexpr int kTrip = 8;      // rows per trip: the wavefront is latency-bound on the scalar loads, not on the math
+    auto rows_trip = [&](int r0, int step) {
+        float q[3 * kTrip];
+        int v[kTrip];
+        uint64_t w[kTrip];
 #pragma unroll
-        for (int u = 0; u < 12; ++u) c[u] = rp[3 * r + u];
+        for (int u = 0; u < kTrip; ++u) {
+            v[u] = rv[r0 + u * step];
+            q[3 * u] = rp[3 * (r0 + u * step)]; q[3 * u + 1] = rp[3 * (r0 + u * step) + 1]; q[3 * u + 2] = rp[3 * (r0 + u * step) + 2];
+        }
+        // consecutive points usually inherit the same template vertex (samples of one face): the gather is
+        // repeated only when the row's vertex changes (wave-uniform test)
+        w[0] = col[v[0]];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = rv[r + u];
+        for (int u = 1; u < kTrip; ++u) {
+            if (v[u] != v[u - 1]) w[u] = col[v[u]];
+            else w[u] = w[u - 1];
+        }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) row(r + u, v[u], c[3 * u], c[3 * u + 1], c[3 * u + 2]);
-    }
-    for (; r < r_end; ++r) row(r, rv[r], rp[3 * r], rp[3 * r + 1], rp[3 * r + 2]);
-    // merge the wavefronts in ascending row order, strict '<': first-index rule as torch.argmin
+        for (int u = 0; u < kTrip; ++u) row(r0 + u * step, w[u], q[3 * u], q[3 * u + 1], q[3 * u + 2]);
+    };
+    // chunks are dealt to the wavefronts round-robin: the chunks that survive the pruning are neighbours
+    // (the contact partner's patch), contiguous shares would leave them all to one wavefront
+    const int chunks = (n + kIndexedChunk - 1) / kIndexedChunk;
     __shared__ float sbest[kIndexedWaves][64];
     __shared__ int sarg[kIndexedWaves][64];
-    sbest[wave][lane] = best;
-    sarg[wave][lane] = arg;
-    __syncthreads();
+    auto merge = [&]() {                                 // lexicographic (d, row) minimum over the wavefronts
+        sbest[wave][lane] = best;
+        sarg[wave][lane] = arg;
+        __syncthreads();
+        for (int w = 0; w < kIndexedWaves; ++w) {
+            const float d = sbest[w][lane];
+            const int r = sarg[w][lane];
+            if (d < best || (d == best && d < inf && r < arg)) { best = d; arg = r; }
+        }
+        __syncthreads();
+    };
+    for (int c = wave; c < chunks; c += kIndexedWaves) {                                                 // pass 1
+        const int r = c * kIndexedChunk;
+        if (r + 24 < n) {
+            float q[12];
+            int v[4];
+            uint64_t w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u] = rv[r + 8 * u];
+                q[3 * u] = rp[3 * (r + 8 * u)]; q[3 * u + 1] = rp[3 * (r + 8 * u) + 1]; q[3 * u + 2] = rp[3 * (r + 8 * u) + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w[u] = col[v[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) row(r + 8 * u, w[u], q[3 * u], q[3 * u + 1], q[3 * u + 2]);
+        } else {
+            for (int rr = r; rr < n; rr += 8) row(rr, col[rv[rr]], rp[3 * rr], rp[3 * rr + 1], rp[3 * rr + 2]);
+        }
+    }
+    merge();
+    const float* bx = boxes + (size_t)b * max_chunks * 8;
+    for (int c = wave; c < chunks; c += kIndexedWaves) {                                                 // pass 2
+        const float* box = bx + (size_t)c * 8;
+        const float ex = __builtin_fmaxf(__builtin_fmaxf(box[0] - px, px - box[4]), 0.0f);
+        const float ey = __builtin_fmaxf(__builtin_fmaxf(box[1] - py, py - box[5]), 0.0f);
+        const float ez = __builtin_fmaxf(__builtin_fmaxf(box[2] - pz, pz - box[6]), 0.0f);
+        const float lb = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) * kIndexedSlack;
+        if (__builtin_amdgcn_ballot_w64(lb <= best) == 0) continue;
+        int r = c * kIndexedChunk;
+        const int re = min(n, r + kIndexedChunk);
+        for (; r + kTrip <= re; r += kTrip) rows_trip(r, 1);
+        for (; r < re; ++r) row(r, col[rv[r]], rp[3 * r], rp[3 * r + 1], rp[3 * r + 2]);
+    }
+    merge();
     if (wave == 0 && a < n) {
-        for (int w = 1; w < kIndexedWaves; ++w)
-            if (sbest[w][lane] < best) { best = sbest[w][lane]; arg = sarg[w][lane]; }
         out_min[beg + a] = best;
-        out_arg[beg + a] = arg;
+        out_arg[beg + a] = best < inf ? arg : 0;
     }
 }
 
@@ -595,15 +672,32 @@ extern "C" int tuch_batch_pairwise_dist(const float* x, const float* y, int B, i
     return tuch_check_launch("tuch_batch_pairwise_dist");
 }
 
+extern "C" size_t tuch_v2v_min_indexed_workspace_bytes(int B, int max_points_per_body)
+{
+    if (B <= 0 || max_points_per_body <= 0) return 0;
+    return (size_t)B * ceil_div(max_points_per_body, kIndexedChunk) * 8 * sizeof(float);
+}
+
 extern "C" int tuch_v2v_min_indexed(const float* points, const int32_t* vertex_ids, const int32_t* offsets,
                                     const uint64_t* geomask_bits, int B, int V, int max_points_per_body,
-                                    float* min_d2, int32_t* argmin, void* stream)
+                                    float* min_d2, int32_t* argmin, void* workspace, size_t workspace_bytes,
+                                    void* stream)
 {
     TUCH_REQUIRE(points && vertex_ids && offsets && geomask_bits && min_d2 && argmin,
                  "tuch_v2v_min_indexed: null pointer");
     TUCH_REQUIRE(B > 0 && B <= 65535 && V > 0 && max_points_per_body >= 0, "tuch_v2v_min_indexed: bad sizes");
     if (max_points_per_body == 0) return TUCH_OK;
-    hipLaunchKernelGGL(v2v_indexed_kernel, dim3(ceil_div(max_points_per_body, 64), B), dim3(64 * kIndexedWaves), 0,
-                       (hipStream_t)stream, points, vertex_ids, offsets, geomask_bits, V, min_d2, argmin);
+    const size_t need = tuch_v2v_min_indexed_workspace_bytes(B, max_points_per_body);
+    if (!workspace || workspace_bytes < need) {
+        tuch_set_error("tuch_v2v_min_indexed: workspace %zu < %zu bytes", workspace_bytes, need);
+        return TUCH_ERR_WORKSPACE;
+    }
+    const int max_chunks = ceil_div(max_points_per_body, kIndexedChunk);
+    float* boxes = (float*)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(v2v_indexed_boxes_kernel, dim3(ceil_div(max_chunks, 4), B), dim3(256), 0, s, points, offsets,
+                       max_chunks, boxes);
+    hipLaunchKernelGGL(v2v_indexed_kernel, dim3(ceil_div(max_points_per_body, 64), B), dim3(64 * kIndexedWaves), 0, s,
+                       points, vertex_ids, offsets, geomask_bits, V, (const float*)boxes, max_chunks, min_d2, argmin);
     return tuch_check_launch("tuch_v2v_min_indexed");
 }

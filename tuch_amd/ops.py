@@ -500,9 +500,11 @@ class ContactModel:
         return w, ext
 
     def v2v_min_indexed(self, points: torch.Tensor, vertex_ids: torch.Tensor, offsets: torch.Tensor,
-                        max_points: int):
+                        max_points: int, tree_order: bool = False):
         """Ragged masked nearest neighbour (HD points, loss.py:288-291).  points [N,3], vertex_ids [N]
-        int32, offsets [B+1] int32 -> (min_d2 [N], argmin [N] int32 relative to the body's first point)."""
+        int32, offsets [B+1] int32 -> (min_d2 [N], argmin [N] int32 relative to the body's first point).
+        tree_order: vertex_ids are positions in the cluster tree's vertex order (``tree_positions``) and the
+        mask packed in that order is used -- the same answer, far fewer distinct mask words per wavefront."""
         if not self.has_mask:
             raise _C.TuchError('ContactModel was created without a geodesic mask')
         pts = _f32(points)
@@ -510,11 +512,26 @@ class ContactModel:
         mn = torch.empty(n, dtype=torch.float32, device=pts.device)
         arg = torch.empty(n, dtype=torch.int32, device=pts.device)
         L = _C.lib()
+        bits = L.tuch_contact_model_tree_mask_bits(self._handle) if tree_order else \
+            L.tuch_contact_model_mask_bits(self._handle)
+        if not bits:
+            raise _C.TuchError('ContactModel has no mask in tree order (no cluster tree)')
+        nbytes = L.tuch_v2v_min_indexed_workspace_bytes(offsets.shape[0] - 1, int(max_points))
+        ws = _workspace(nbytes, pts.device)
         _C.check(L.tuch_v2v_min_indexed(_C.ptr(pts), _C.ptr(vertex_ids.contiguous()), _C.ptr(offsets.contiguous()),
-                                        ctypes.c_void_p(L.tuch_contact_model_mask_bits(self._handle)),
-                                        offsets.shape[0] - 1, self.num_verts, int(max_points), _C.ptr(mn),
-                                        _C.ptr(arg), _C.stream()))
+                                        ctypes.c_void_p(bits), offsets.shape[0] - 1, self.num_verts, int(max_points),
+                                        _C.ptr(mn), _C.ptr(arg), _C.ptr(ws), nbytes, _C.stream()))
         return mn, arg
+
+    def tree_positions(self) -> Optional[np.ndarray]:
+        """position of every vertex in the cluster tree's vertex order (inverse of qperm), or None without tree."""
+        try:
+            qperm = cluster_tree(self.faces_np, self.num_verts)['qperm'][:self.num_verts]
+        except _C.TuchError:
+            return None
+        pos = np.empty(self.num_verts, np.int32)
+        pos[qperm] = np.arange(self.num_verts, dtype=np.int32)
+        return pos
 
     # K5
     def region_pair_min(self, verts: torch.Tensor, select: Optional[torch.Tensor] = None, masked: bool = False):

@@ -71,6 +71,14 @@ class RegressorLoss(nn.Module):
         self.segments = segments
         seg_tables = segments.tables() if segments is not None else None
         self._model = ops.ContactModel(face_tensor[0], self.geomask, seg_tables, device=face_tensor.device)
+        if use_hd:
+            # template vertex of every HD point as its position in the tree's vertex order (mask lookups of
+            # neighbouring points then fall into the same few 64-vertex words)
+            pos = self._model.tree_positions()
+            self._hd_tree_order = pos is not None
+            ids = self.geovec_verts.cpu().numpy()
+            self._hd_mask_ids = torch.as_tensor(pos[ids] if pos is not None else ids, dtype=torch.int32,
+                                                device=face_tensor.device)
 
     # ------------------------------------------------------------------ contact (loss.py:240-317)
     def contact_loss(self, pred_vertices, valid_fit):
@@ -103,8 +111,8 @@ class RegressorLoss(nn.Module):
         bidx32 = bidx.to(torch.int32)
         hd = ops.hd_points(pred_vertices, bidx32, hidx.to(torch.int32), self.hd_idx32, self.hd_w)   # :285
         with torch.no_grad():
-            vid = self.geovec_verts[hidx].to(torch.int32)
-            _, arg = model.v2v_min_indexed(hd, vid, offsets, n_max)                       # :288-291
+            vid = self._hd_mask_ids[hidx]
+            _, arg = model.v2v_min_indexed(hd, vid, offsets, n_max, tree_order=self._hd_tree_order)   # :288-291
             partner_hd = (arg + offsets[:-1][bidx]).to(torch.int32)
             tris = ops.gather_triangles(pred_vertices, model.faces_i32)
             normals = 0.001 * batch_face_normals(tris)                                    # :295
