@@ -85,3 +85,27 @@ out['options'] = np.array([opts.shape_loss_weight, opts.keypoint_loss_weight, op
 np.savez_compressed(os.path.join(HERE, 'regressor_forward.npz'), **out)
 print({k: float(v) for k, v in out.items() if k.startswith('a_') and 'in_' not in k})
 print({k: float(v) for k, v in out.items() if k.startswith('none_valid_') and 'in_' not in k})
+
+# ---- EFTLoss.forward (tuch/eft/loss.py:73-117) with contact_weight = 0: keypoint + shape terms and the x60 total
+import contextlib
+import io
+from tuch.eft import loss as ref_eft                    # noqa: E402
+
+eft = ref_eft.EFTLoss.__new__(ref_eft.EFTLoss)
+torch.nn.Module.__init__(eft)
+eft.device, eft.options = 'cpu', types.SimpleNamespace(img_res=224)
+eft.focal_length, eft.camera_center = 5000, torch.tensor([0, 0])
+eft.criterion_keypoints = torch.nn.MSELoss(reduction='none')
+eft.keypoints_weight, eft.shape_weight, eft.contact_weight = 0.7, 1.3, 0.0
+Be = 3
+joints = (0.4 * rng.standard_normal((Be, 49, 3))).astype(np.float32)
+betas = rng.standard_normal((Be, 10)).astype(np.float32)
+camera = np.stack([rng.uniform(0.6, 1.2, Be), rng.uniform(-0.1, 0.1, Be), rng.uniform(-0.1, 0.1, Be)], 1).astype(np.float32)
+kp = np.concatenate([rng.uniform(-1, 1, (Be, 49, 2)), rng.uniform(0, 1, (Be, 49, 1))], 2).astype(np.float32)
+body = types.SimpleNamespace(joints=torch.tensor(joints), betas=torch.tensor(betas), vertices=None)
+with contextlib.redirect_stdout(io.StringIO()):          # the reference prints the losses (:115)
+    loss, d = eft.forward(body, torch.tensor(camera), {'keypoints': torch.tensor(kp), 'contact': None})
+eft_out = dict(joints=joints, betas=betas, camera=camera, keypoints=kp, weights=np.array([0.7, 1.3, 0.0]),
+               total=np.float64(loss.item()), **{k: np.float64(v.item()) for k, v in d.items()})
+np.savez_compressed(os.path.join(HERE, 'eft_forward.npz'), **eft_out)
+print({k: float(v) for k, v in eft_out.items() if np.ndim(v) == 0})

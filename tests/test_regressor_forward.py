@@ -56,3 +56,21 @@ def test_forward_backward_reaches_every_prediction():
     total.backward()
     for k, t in grads.items():
         assert t.grad is not None and torch.isfinite(t.grad).all() and t.grad.abs().sum() > 0, k
+
+
+def test_eft_forward_matches_reference():
+    """EFTLoss.forward (tuch/eft/loss.py:73-117) with contact_weight = 0: keypoint and shape terms, x60 total."""
+    from tuch_amd.eft.loss import EFTLoss
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'eft_forward.npz'))
+    crit = EFTLoss.__new__(EFTLoss)
+    torch.nn.Module.__init__(crit)
+    crit.device, crit.options = torch.device('cpu'), types.SimpleNamespace(img_res=224)
+    crit.focal_length, crit.camera_center = 5000, torch.zeros(2)
+    crit.criterion_keypoints = torch.nn.MSELoss(reduction='none')
+    crit.keypoints_weight, crit.shape_weight, crit.contact_weight = [float(x) for x in g['weights']]
+    body = types.SimpleNamespace(joints=torch.tensor(g['joints']), betas=torch.tensor(g['betas']), vertices=None)
+    loss, d = crit.forward(body, torch.tensor(g['camera']), {'keypoints': torch.tensor(g['keypoints']), 'contact': None})
+    assert list(d.keys()) == ['loss_shape', 'loss_keypoints', 'loss_contact']
+    for k in d:
+        np.testing.assert_allclose(float(d[k]), float(g[k]), rtol=2e-6, atol=1e-9, err_msg=k)
+    np.testing.assert_allclose(float(loss), float(g['total']), rtol=2e-6)
