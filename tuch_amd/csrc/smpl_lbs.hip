@@ -409,9 +409,10 @@ __global__ __launch_bounds__(kSkinBlock) void skin_bwd_kernel(
             const float a = (j < kJoints && vv < V) ? weights[(size_t)vv * kJoints + j] : 0.f;
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, sG[k0 + lq][lm], acc, 0, 0, 0);
         }
-        float* out = gA_part + (((size_t)b * gridDim.x + blockIdx.x) * 32 + wave * 16) * 16;
+        // [B][32][16], zeroed by the caller: the vertex blocks accumulate with float atomics
+        float* out = gA_part + ((size_t)b * 32 + wave * 16) * 16;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[(lq * 4 + r) * 16 + lm] = acc[r];
+        for (int r = 0; r < 4; ++r) atomicAdd(&out[(lq * 4 + r) * 16 + lm], acc[r]);
     }
 }
 
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(kSkinBlock) void skin_bwd_kernel(
 constexpr int kBlendBwdTiles = 2;
 __global__ __launch_bounds__(64) void blend_bwd_kernel(
     const float* __restrict__ g_vposed, const float* __restrict__ blend, int B, int N3,
-    float* __restrict__ part)   // [chunks][Bpad][224]
+    float* __restrict__ part)   // [Bpad][224], zeroed by the caller; the K chunks accumulate with float atomics
 {
     const int lane = threadIdx.x, lm = lane & 15, lq = lane >> 4;
     const int chunk = blockIdx.x, m0 = blockIdx.y * 16, j0 = blockIdx.z * kBlendBwdTiles;
@@ -458,7 +459,8 @@ __global__ __launch_bounds__(64) void blend_bwd_kernel(
     for (int j = 0; j < kBlendBwdTiles; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            part[((size_t)chunk * bpad + m0 + lq * 4 + r) * 224 + (j0 + j) * 16 + lm] = acc[j][r];
+            atomicAdd(&part[((size_t)(m0 + lq * 4 + r)) * 224 + (j0 + j) * 16 + lm], acc[j][r]);
+    (void)bpad;
 }
 
 // Per body: reduce the partials, chain adjoint, Rodrigues adjoint, shape gradient.
@@ -745,14 +747,19 @@ extern "C" int tuch_smpl_backward(const tuch_smpl_model* m, const float* pose, i
     float *g_all = (float*)(ws + l.g_all), *g_vposed = (float*)(ws + l.g_vposed), *gA_part = (float*)(ws + l.gA_part),
           *feat_part = (float*)(ws + l.feat_part);
     hipStream_t s = (hipStream_t)stream;
+    // gA_part and feat_part are adjacent in the workspace: one memset clears both accumulators
+    if (hipMemsetAsync(gA_part, 0, (size_t)((char*)feat_part - (char*)gA_part) + (size_t)l.bpad * 224 * sizeof(float), s) != hipSuccess) {
+        tuch_set_error("tuch_smpl_backward: hipMemsetAsync failed");
+        return TUCH_ERR_HIP;
+    }
     hipLaunchKernelGGL(joints_bwd_kernel, dim3(B), dim3(64), 0, s, g_joints, (const int32_t*)m->joint_map, g_all);
     hipLaunchKernelGGL(skin_bwd_kernel, dim3(l.skin_blocks, B), dim3(kSkinBlock), 0, s, g_verts, (const float*)g_all,
                        (const float*)m->Jrx, (const int32_t*)m->extra_ids, v_posed, A, (const float*)m->weights, m->V,
                        g_vposed, gA_part);
     hipLaunchKernelGGL(blend_bwd_kernel, dim3(l.feat_chunks, l.bpad / 16, 14 / kBlendBwdTiles), dim3(64), 0, s, (const float*)g_vposed,
                        (const float*)m->blend, B, m->N3, feat_part);
-    hipLaunchKernelGGL(pose_bwd_kernel, dim3(B), dim3(256), 0, s, (const float*)gA_part, l.skin_blocks,
-                       (const float*)feat_part, l.feat_chunks, l.bpad, (const float*)g_all, R, J, world, pose, pose2rot,
+    hipLaunchKernelGGL(pose_bwd_kernel, dim3(B), dim3(256), 0, s, (const float*)gA_part, 1,
+                       (const float*)feat_part, 1, l.bpad, (const float*)g_all, R, J, world, pose, pose2rot,
                        (const float*)m->J_shapedirs, (const int32_t*)m->parents, g_pose, g_betas);
     return tuch_check_launch("tuch_smpl_backward");
 }
