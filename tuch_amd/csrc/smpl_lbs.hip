@@ -416,32 +416,37 @@ __global__ __launch_bounds__(kSkinBlock) void skin_bwd_kernel(
     }
 }
 
-// g_feat partial: [chunk][m][n] = sum_{k in chunk} g_vposed[m][k] * blend[n][k];  n < 224.
-// One wave per (K chunk, 16 bodies, group of kBlendBwdTiles 16-column tiles); K index permuted so that
-// every lane reads float4s.  The column tiles are spread over grid.z: with all 14 in one wave the launch
-// had 324 wavefronts for 256 CUs.
+// g_feat[m][n] += sum_{k in chunk} g_vposed[m][k] * blend[n][k];  n < 224.
+// One wave per (K chunk, up to kBlendBwdGroups x 16 bodies, kBlendBwdTiles 16-column tiles): the blend tile is
+// loaded once and used for all body groups of the wave; K index permuted so that every lane reads float4s.
+// The K chunks accumulate with float atomics into [Bpad][224] (zeroed by the caller).
 constexpr int kBlendBwdTiles = 2;
+constexpr int kBlendBwdGroups = 4;
 __global__ __launch_bounds__(64) void blend_bwd_kernel(
-    const float* __restrict__ g_vposed, const float* __restrict__ blend, int B, int N3,
-    float* __restrict__ part)   // [Bpad][224], zeroed by the caller; the K chunks accumulate with float atomics
+    const float* __restrict__ g_vposed, const float* __restrict__ blend, int B, int N3, int chunk_len,
+    float* __restrict__ part)
 {
     const int lane = threadIdx.x, lm = lane & 15, lq = lane >> 4;
-    const int chunk = blockIdx.x, m0 = blockIdx.y * 16, j0 = blockIdx.z * kBlendBwdTiles;
-    const int k_beg = chunk * kBlendBwdChunk, k_end = min(N3, k_beg + kBlendBwdChunk);
-    const int row = min(m0 + lm, B - 1);
-    const bool row_ok = m0 + lm < B;
-    f32x4 acc[kBlendBwdTiles];
+    const int chunk = blockIdx.x, g0 = blockIdx.y * kBlendBwdGroups, j0 = blockIdx.z * kBlendBwdTiles;
+    const int k_beg = chunk * chunk_len, k_end = min(N3, k_beg + chunk_len);
+    f32x4 acc[kBlendBwdGroups][kBlendBwdTiles];
 #pragma unroll
-    for (int j = 0; j < kBlendBwdTiles; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < kBlendBwdGroups; ++g)
+#pragma unroll
+        for (int j = 0; j < kBlendBwdTiles; ++j) acc[g][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int k0 = k_beg; k0 < k_end; k0 += 16) {
         // lane group q covers k0 + 4q .. k0 + 4q + 3 over the four MFMA steps
         const int kk = k0 + 4 * lq;
-        float a4[4], b4[kBlendBwdTiles][4];
+        float a4[kBlendBwdGroups][4], b4[kBlendBwdTiles][4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int k = kk + s;
             const bool k_ok = k < k_end;
-            a4[s] = (row_ok && k_ok) ? g_vposed[(size_t)row * N3 + k] : 0.f;
+#pragma unroll
+            for (int g = 0; g < kBlendBwdGroups; ++g) {
+                const int row = (g0 + g) * 16 + lm;
+                a4[g][s] = (row < B && k_ok) ? g_vposed[(size_t)row * N3 + k] : 0.f;
+            }
 #pragma unroll
             for (int j = 0; j < kBlendBwdTiles; ++j) {
                 const int n = (j0 + j) * 16 + lm;
@@ -451,16 +456,20 @@ __global__ __launch_bounds__(64) void blend_bwd_kernel(
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int j = 0; j < kBlendBwdTiles; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s], b4[j][s], acc[j], 0, 0, 0);
+            for (int g = 0; g < kBlendBwdGroups; ++g)
+#pragma unroll
+                for (int j = 0; j < kBlendBwdTiles; ++j)
+                    acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[g][s], b4[j][s], acc[g][j], 0, 0, 0);
     }
-    const int bpad = gridDim.y * 16;
 #pragma unroll
-    for (int j = 0; j < kBlendBwdTiles; ++j)
+    for (int g = 0; g < kBlendBwdGroups; ++g) {
+        if ((g0 + g) * 16 >= B) break;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            atomicAdd(&part[((size_t)(m0 + lq * 4 + r)) * 224 + (j0 + j) * 16 + lm], acc[j][r]);
-    (void)bpad;
+        for (int j = 0; j < kBlendBwdTiles; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                atomicAdd(&part[((size_t)((g0 + g) * 16 + lq * 4 + r)) * 224 + (j0 + j) * 16 + lm], acc[g][j][r]);
+    }
 }
 
 // Per body: reduce the partials, chain adjoint, Rodrigues adjoint, shape gradient.
@@ -756,8 +765,10 @@ extern "C" int tuch_smpl_backward(const tuch_smpl_model* m, const float* pose, i
     hipLaunchKernelGGL(skin_bwd_kernel, dim3(l.skin_blocks, B), dim3(kSkinBlock), 0, s, g_verts, (const float*)g_all,
                        (const float*)m->Jrx, (const int32_t*)m->extra_ids, v_posed, A, (const float*)m->weights, m->V,
                        g_vposed, gA_part);
-    hipLaunchKernelGGL(blend_bwd_kernel, dim3(l.feat_chunks, l.bpad / 16, 14 / kBlendBwdTiles), dim3(64), 0, s, (const float*)g_vposed,
-                       (const float*)m->blend, B, m->N3, feat_part);
+    // 81 K chunks x 7 tile pairs = 567 wavefronts, each using its blend tiles for all bodies
+    const int chunk_len = 256;
+    hipLaunchKernelGGL(blend_bwd_kernel, dim3(ceil_div(m->N3, chunk_len), ceil_div(l.bpad / 16, kBlendBwdGroups), 14 / kBlendBwdTiles),
+                       dim3(64), 0, s, (const float*)g_vposed, (const float*)m->blend, B, m->N3, chunk_len, feat_part);
     hipLaunchKernelGGL(pose_bwd_kernel, dim3(B), dim3(256), 0, s, (const float*)gA_part, 1,
                        (const float*)feat_part, 1, l.bpad, (const float*)g_all, R, J, world, pose, pose2rot,
                        (const float*)m->J_shapedirs, (const int32_t*)m->parents, g_pose, g_betas);
