@@ -89,20 +89,22 @@ def contact_fitting_loss(body_pose, global_orient, body_pose_loop1, opt_global_o
             (gt_contact[0], has_discrete_contact, ignore_idxs),
             lambda: ((gt_contact[0] == 1) & has_discrete_contact.bool()[:, None]
                      & (~ignore_idxs)[:, None]).to(torch.uint8).contiguous())
-    pairs = None
-    if select is not None:
-        pairs = lambda: model.region_pair_min(verts, select=select, masked=True)        # losses.py:107-117
-    # losses.py:79-89 (inside test) and losses.py:76-78,92-93 (nearest geodesically-far vertex)
-    exterior, _, partner, extra = model.exterior_and_partner(verts, apply_segments=segments is not None, also=pairs)
-    r2r = extra[0] if extra is not None else None
-    contact_loss, contact_terms = ops.contact_terms(verts, partner, exterior, valid, ops.MODE_SMPLIFY, euclthres)
-
     fused = (isinstance(pose_prior, MaxMixturePrior) and pose_prior.use_merged and verts.is_cuda
              and not torch.is_tensor(focal_length) and body_pose.shape[1] == 69)
-    if fused:      # projection + gmof + GMM prior in one kernel (K8), objective assembled in one reduction
-        small = ops.smplify_small_terms(model_joints, camera_t, body_pose, camera_center, joints_2d, joints_conf,
-                                        pose_prior.means, pose_prior.precisions, pose_prior.log_nll_weights,
-                                        focal_length, sigma, pose_prior_weight ** 2)
+
+    def beside_the_walk():
+        """Everything that does not need the inside test: region pairs (losses.py:107-117) and, fused into one
+        kernel (K8), projection + gmof + GMM prior (losses.py:56-64).  Runs on the second stream."""
+        r = model.region_pair_min(verts, select=select, masked=True)[0] if select is not None else None
+        sm = ops.smplify_small_terms(model_joints, camera_t, body_pose, camera_center, joints_2d, joints_conf,
+                                     pose_prior.means, pose_prior.precisions, pose_prior.log_nll_weights,
+                                     focal_length, sigma, pose_prior_weight ** 2) if fused else None
+        return r, sm
+    # losses.py:79-89 (inside test) and losses.py:76-78,92-93 (nearest geodesically-far vertex)
+    exterior, _, partner, (r2r, small) = model.exterior_and_partner(verts, apply_segments=segments is not None,
+                                                                    also=beside_the_walk)
+    contact_loss, contact_terms = ops.contact_terms(verts, partner, exterior, valid, ops.MODE_SMPLIFY, euclthres)
+    if fused:      # objective assembled in one deterministic reduction
         return ops.smplify_objective(small, contact_terms, r2r, 10.0, contact_loss_weight)   # losses.py:120-123
     reprojection_sum = _reprojection(model_joints, camera_t, camera_center, joints_2d, joints_conf,
                                      focal_length, sigma).sum(dim=-1)
