@@ -136,18 +136,28 @@ extern "C" int tuch_smplify_small_terms(const float* joints, const float* camera
 //   total = sum_b [ reprojection_b + prior_b + 10 * (interior_b + exterior_b) + clw * sum_p r2r[b,p] ]
 // one block, fixed-order tree reduction (deterministic).
 namespace {
-__global__ __launch_bounds__(256) void objective_kernel(
+constexpr int kObjBlock = 1024;
+__global__ __launch_bounds__(kObjBlock) void objective_kernel(
     const float* __restrict__ small, const float* __restrict__ terms, const float* __restrict__ r2r,
     int B, int P, float contact_scale, float r2r_scale, float* __restrict__ out)
 {
-    __shared__ float red[256];
+    __shared__ float red[kObjBlock];
     float acc = 0.f;
-    for (int i = threadIdx.x; i < 2 * B; i += 256) acc += small[i] + contact_scale * terms[i];
-    if (r2r)
-        for (int i = threadIdx.x; i < B * P; i += 256) acc += r2r_scale * r2r[i];
+    for (int i = threadIdx.x; i < 2 * B; i += kObjBlock) acc += small[i] + contact_scale * terms[i];
+    if (r2r) {
+        // four independent loads per trip (the single workgroup is latency-bound); fixed order per thread
+        const int n = B * P;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int i = threadIdx.x;
+        for (; i + 3 * kObjBlock < n; i += 4 * kObjBlock) {
+            a0 += r2r[i]; a1 += r2r[i + kObjBlock]; a2 += r2r[i + 2 * kObjBlock]; a3 += r2r[i + 3 * kObjBlock];
+        }
+        for (; i < n; i += kObjBlock) a0 += r2r[i];
+        acc += r2r_scale * ((a0 + a1) + (a2 + a3));
+    }
     red[threadIdx.x] = acc;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = kObjBlock / 2; s > 0; s >>= 1) {
         if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
@@ -171,7 +181,7 @@ extern "C" int tuch_smplify_objective(const float* small_terms, const float* con
                                       void* stream)
 {
     TUCH_REQUIRE(small_terms && contact_terms && out && B > 0 && P >= 0, "tuch_smplify_objective: bad arguments");
-    hipLaunchKernelGGL(objective_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, small_terms, contact_terms,
+    hipLaunchKernelGGL(objective_kernel, dim3(1), dim3(kObjBlock), 0, (hipStream_t)stream, small_terms, contact_terms,
                        (P > 0 ? r2r : (const float*)nullptr), B, P, contact_scale, r2r_scale, out);
     return tuch_check_launch("tuch_smplify_objective");
 }
