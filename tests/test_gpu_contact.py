@@ -532,3 +532,16 @@ def test_v2v_min_indexed_matches_brute_force(order):
         rows = np.arange(n)
         assert allowed[rows[fin], a[fin]].all()
         np.testing.assert_allclose(d64[rows[fin], a[fin]], want[fin], rtol=2e-6, atol=1e-9)
+
+
+def test_winding_tree_work_counts():
+    """The measurement aid behind bench.py's roofline: element steps walked by the tree, far below the flat walk."""
+    g = golden('full')
+    model = make_model(g, None, False, False)
+    verts = torch.tensor(g['verts'], device=dev())
+    w = model.winding_tree_work(verts)
+    steps = w['leaf_elements'] + w['cap_elements']
+    flat = w['query_blocks'] * w['flat_stream_elements']
+    assert w['leaf_elements'] > 0 and w['cap_elements'] > 0 and w['queries_per_step'] == 64
+    assert 0.05 < steps / flat < 0.5
+    assert w == model.winding_tree_work(verts)           # counts are deterministic
