@@ -37,10 +37,10 @@ FLOP_PER_STRIP_ELEMENT = 41
 PEAK_FP32_VECTOR_TFLOPS = 157.3   # MI355X_MICROARCH.md (packed FP32 FMA rate)
 PEAK_HBM_GBS = 8000.0
 # HBM-side bytes per launch of winding_tree_kernel at batch 64 from the PMC passes committed under
-# profiles/r01_j_pmc_{fetch,write}.txt (FETCH_SIZE 68778 KB + WRITE_SIZE 25540 KB).  The kernel's own layout moves
+# profiles/r01_k_pmc_{fetch,write}.txt (FETCH_SIZE 67907 KB + WRITE_SIZE 24844 KB).  The kernel's own layout moves
 # 69.5 MB of posed stream (33 948 elements x 32 B x 64 bodies, fetched once: one body per XCD at a time) + 2.2 MB of
 # node slabs in and 28 MB of partial sums out.
-WINDING_TRAFFIC_BYTES = int((68777.7 + 25539.8) * 1024)
+WINDING_TRAFFIC_BYTES = int((67906.9 + 24843.7) * 1024)
 
 
 def parse():
@@ -190,7 +190,7 @@ def rooflines(p, batch):
             'peak': PEAK_FP32_VECTOR_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_VECTOR_TFLOPS, 4),
             'traffic': WINDING_TRAFFIC_BYTES if batch == BATCH_PER_GPU else None,
             'traffic_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, KB x 1024 '
-                              '(profiles/r01_j_pmc_fetch.txt, r01_j_pmc_write.txt); scalar loads: counter uncalibrated',
+                              '(profiles/r01_k_pmc_fetch.txt, r01_k_pmc_write.txt); scalar loads: counter uncalibrated',
             'launch_ms': round(t_w * 1e3, 4),
             'executed_flop_per_launch': flops,
             'flop_per_query_element': FLOP_PER_STRIP_ELEMENT,
@@ -201,7 +201,7 @@ def rooflines(p, batch):
             'reference_formulation_flop_per_launch': ref_flops,
             'reference_formulation_equivalent_TFLOPs': round(ref_flops / t_w / 1e12, 1),
             'algorithmic_bytes_per_launch': batch * (v * 12 + v * 4) + f * 12,
-            'valu_issue_note': 'PMC (profiles/r01_j_pmc_sq.txt): 5.5e8 VALU + 1.6e8 SALU instructions per launch, '
+            'valu_issue_note': 'PMC (profiles/r01_k_pmc_sq.txt): 5.5e8 VALU + 1.6e8 SALU instructions per launch, '
                                '32 VALU instructions per 64-query element step'}
     t_v = time_kernel(lambda: model.v2v_min(verts), 10)
     ref_layout_bytes = batch * (12 * v + v * v + 8 * v)           # SURVEY.md §8(d) layout (i)
