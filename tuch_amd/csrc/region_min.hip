@@ -31,16 +31,18 @@ __device__ __forceinline__ Best better(Best x, Best y)
 }
 
 // One wavefront per (body, pair, 64 rows of the first region): unselected pairs leave at once, the
-// selected ones spread over the whole chip (the SMPLify use selects ~10 of ~280 pairs per body).
+// selected ones spread over the whole chip (the SMPLify use selects ~10 of ~280 pairs per body;
+// contact_from_verts, train_module.py:69-91, takes all pairs, unmasked).
+template <bool kMasked>
 __global__ __launch_bounds__(64) void region_pair_min_kernel(
     const float* __restrict__ verts, const int32_t* __restrict__ region_off,
     const int32_t* __restrict__ region_vidx, const int32_t* __restrict__ pairs,
     const uint8_t* __restrict__ select,        // [B,P] or nullptr (= all)
-    const uint32_t* __restrict__ pair_mask,    // per-pair geomask blocks or nullptr (= unmasked)
+    const uint32_t* __restrict__ pair_mask,    // per-pair geomask blocks (kMasked)
     const int64_t* __restrict__ pair_mask_off,
     int V, int P, unsigned long long* __restrict__ keys)   // [B,P], preset to all ones
 {
-    __shared__ float sx[kTile], sy[kTile], sz[kTile];
+    __shared__ __attribute__((aligned(16))) float sx[kTile], sy[kTile], sz[kTile];
     const int b = blockIdx.x, p = blockIdx.y;
     const size_t o = (size_t)b * P + p;
     if (select && !select[o]) return;
@@ -53,8 +55,17 @@ __global__ __launch_bounds__(64) void region_pair_min_kernel(
     const int i = region_vidx[a_beg + min(a, n1 - 1)];
     const float px = vb[3 * i], py = vb[3 * i + 1], pz = vb[3 * i + 2];
     const int wpr = (n2 + 31) / 32;
-    const uint32_t* mrow = pair_mask ? pair_mask + pair_mask_off[p] + (size_t)min(a, n1 - 1) * wpr : nullptr;
-    Best best = {__builtin_inff(), 0x7fffffff};
+    const uint32_t* mrow = kMasked ? pair_mask + pair_mask_off[p] + (size_t)min(a, n1 - 1) * wpr : nullptr;
+    const float inf = __builtin_inff();
+    float best = inf;
+    int best_k = -1;                                            // column of the second region
+    // columns ascend, so within a lane the first minimum (strict '<') is the one with the smallest flat index
+    auto column = [&](int k, float x, float y, float z, bool allowed) {
+        const float dx = px - x, dy = py - y, dz = pz - z;
+        float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        if (kMasked && !allowed) d = inf;
+        if (d < best) { best = d; best_k = k; }
+    };
     for (int t0 = 0; t0 < n2; t0 += kTile) {
         const int tn = min(kTile, n2 - t0);
         __syncthreads();
@@ -65,27 +76,31 @@ __global__ __launch_bounds__(64) void region_pair_min_kernel(
         __syncthreads();
         if (a < n1)
             for (int g = 0; g < tn; g += 32) {
-                const uint32_t word = mrow ? mrow[(t0 + g) >> 5] : 0xffffffffu;
+                const uint32_t word = kMasked ? mrow[(t0 + g) >> 5] : 0xffffffffu;
                 const int gn = min(32, tn - g);
-                for (int kk = 0; kk < gn; ++kk) {
-                    const int k = g + kk;
-                    const float dx = px - sx[k], dy = py - sy[k], dz = pz - sz[k];
-                    float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                    if (!((word >> kk) & 1)) d = __builtin_inff();
-                    // columns ascend, so within a lane the first minimum is the one with the smallest flat index
-                    if (d < best.d) { best.d = d; best.idx = a * n2 + k + t0; }
+                int kk = 0;
+                for (; kk + 4 <= gn; kk += 4) {               // four columns per LDS read (b128 broadcasts)
+                    const float4 x4 = *(const float4*)&sx[g + kk];
+                    const float4 y4 = *(const float4*)&sy[g + kk];
+                    const float4 z4 = *(const float4*)&sz[g + kk];
+                    column(t0 + g + kk + 0, x4.x, y4.x, z4.x, (word >> (kk + 0)) & 1);
+                    column(t0 + g + kk + 1, x4.y, y4.y, z4.y, (word >> (kk + 1)) & 1);
+                    column(t0 + g + kk + 2, x4.z, y4.z, z4.z, (word >> (kk + 2)) & 1);
+                    column(t0 + g + kk + 3, x4.w, y4.w, z4.w, (word >> (kk + 3)) & 1);
                 }
+                for (; kk < gn; ++kk) column(t0 + g + kk, sx[g + kk], sy[g + kk], sz[g + kk], (word >> kk) & 1);
             }
     }
+    Best r = {best, best_k >= 0 ? a * n2 + best_k : 0x7fffffff};
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) {
-        Best other = {__shfl_down(best.d, s, 64), __shfl_down(best.idx, s, 64)};
-        best = better(best, other);
+        Best other = {__shfl_down(r.d, s, 64), __shfl_down(r.idx, s, 64)};
+        r = better(r, other);
     }
     // d >= 0, so the float's bit pattern orders like the value: (d, flat index) packs into one
     // 64-bit key whose minimum is independent of the arrival order -> deterministic
-    if (threadIdx.x == 0 && best.idx != 0x7fffffff)
-        atomicMin(&keys[o], ((unsigned long long)__float_as_uint(best.d) << 32) | (unsigned int)best.idx);
+    if (threadIdx.x == 0 && r.idx != 0x7fffffff)
+        atomicMin(&keys[o], ((unsigned long long)__float_as_uint(r.d) << 32) | (unsigned int)r.idx);
 }
 
 // keys -> (min d2, arg-min vertex ids); unselected / empty pairs give 0 and (-1, -1).  The keys
@@ -149,11 +164,15 @@ extern "C" int tuch_region_pair_min(const tuch_contact_model* m, const float* ve
         tuch_set_error("tuch_region_pair_min: hipMemsetAsync failed");
         return TUCH_ERR_HIP;
     }
-    hipLaunchKernelGGL(region_pair_min_kernel, dim3(B, m->num_pairs, ceil_div(m->region_max, 64)), dim3(64), 0, s,
-                       verts, (const int32_t*)m->region_off, (const int32_t*)m->region_vidx,
-                       (const int32_t*)m->pairs, select,
-                       use_geomask ? (const uint32_t*)m->pair_mask : (const uint32_t*)nullptr,
-                       (const int64_t*)m->pair_mask_off, m->V, m->num_pairs, (unsigned long long*)out_ij);
+    const dim3 grid(B, m->num_pairs, ceil_div(m->region_max, 64));
+    if (use_geomask)
+        hipLaunchKernelGGL(region_pair_min_kernel<true>, grid, dim3(64), 0, s, verts, (const int32_t*)m->region_off,
+                           (const int32_t*)m->region_vidx, (const int32_t*)m->pairs, select, (const uint32_t*)m->pair_mask,
+                           (const int64_t*)m->pair_mask_off, m->V, m->num_pairs, (unsigned long long*)out_ij);
+    else
+        hipLaunchKernelGGL(region_pair_min_kernel<false>, grid, dim3(64), 0, s, verts, (const int32_t*)m->region_off,
+                           (const int32_t*)m->region_vidx, (const int32_t*)m->pairs, select, (const uint32_t*)nullptr,
+                           (const int64_t*)nullptr, m->V, m->num_pairs, (unsigned long long*)out_ij);
     hipLaunchKernelGGL(region_pair_finalize_kernel, dim3(ceil_div(m->num_pairs, kBlock), B), dim3(kBlock), 0, s,
                        (const int32_t*)m->region_off, (const int32_t*)m->region_vidx, (const int32_t*)m->pairs,
                        m->num_pairs, out_min, out_ij);
