@@ -229,6 +229,15 @@ def contact_loss_eval(p, batch):
     dev = verts.device
     valid = torch.ones(batch, dtype=torch.bool, device=dev)
     out = {}
+    # TUCH.contact_from_verts (tuch/train/train_module.py:69-91): minimum squared distance of ALL region pairs,
+    # unmasked; the reference calls it twice per training step
+    from tuch_amd.smplify.losses import contact_model_for
+    cmodel = contact_model_for(p['geomask'], p['face_tensor'], p['segments'], p['cdict'])
+    if cmodel.num_pairs:
+        with torch.no_grad():
+            out['contact_from_verts_ms'] = round(time_kernel(
+                lambda: cmodel.region_pair_min(verts, select=None, masked=False), 5) * 1e3, 4)
+        out['contact_from_verts_pairs'] = cmodel.num_pairs
     for tag, use_hd in (('plain', False), ('hd', True)):
         crit = RegressorLoss(types.SimpleNamespace(contact_loss_weight=1.0), dev, body.num_verts, p['face_tensor'],
                              torch.tensor(body.geodesics, device=dev), geothres=0.3, euclthres=0.02,
