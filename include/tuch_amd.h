@@ -161,8 +161,13 @@ int tuch_winding_tree_work(const tuch_contact_model* model, const float* verts, 
  * current minimum, or that the mask rules out entirely, are skipped).  Exact ties between rows are
  * resolved deterministically (smallest row in the tree's vertex order). */
 size_t tuch_v2v_model_workspace_bytes(const tuch_contact_model* model, int B);
+/* hint_inout (optional, tuch_v2v_hint_bytes bytes, device, opaque, zero-initialised by the caller): the partners found
+ * by this call are left there and seed the next call with the same buffer -- in an iterative fit the previous
+ * iteration's partner is still admissible and almost as close, so nearly every box is pruned at once.  The result
+ * does not depend on the hint (any content is safe); only the run time does.  Used only with a cluster tree. */
+size_t tuch_v2v_hint_bytes(const tuch_contact_model* model, int B);
 int tuch_v2v_min_model(const tuch_contact_model* model, const float* verts, int B, float* min_d2,
-                       int32_t* argmin, void* workspace, size_t workspace_bytes, void* stream);
+                       int32_t* argmin, void* hint_inout, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Cluster tree over the faces of a closed mesh (host only, no device needed): the structure behind the
  * hierarchical evaluation of winding_numbers (tuch/utils/contact.py:112-147) inside tuch_exterior_flags.

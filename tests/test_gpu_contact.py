@@ -545,3 +545,29 @@ def test_winding_tree_work_counts():
     assert w['leaf_elements'] > 0 and w['cap_elements'] > 0 and w['queries_per_step'] == 64
     assert 0.05 < steps / flat < 0.5
     assert w == model.winding_tree_work(verts)           # counts are deterministic
+
+
+def test_v2v_hints_never_change_the_result(monkeypatch):
+    """The partner hints kept between calls only seed the pruning: whatever the buffer holds (garbage included),
+    minima and partners are those of a call without hints."""
+    g, gm = golden('medium'), golden_mask('medium')
+    model = make_model(g, gm, False, False)
+    verts = torch.tensor(g['verts'], device=dev())
+    monkeypatch.setenv('TUCH_V2V_HINT', '0')
+    mn0, arg0 = model.v2v_min(verts)
+    monkeypatch.setenv('TUCH_V2V_HINT', '1')
+    mn1, arg1 = model.v2v_min(verts)                       # zero-initialised hints
+    mn2, arg2 = model.v2v_min(verts)                       # hints = the partners just found
+    buf = model._v2v_hint(verts.shape[0])
+    assert buf is not None
+    junk = torch.randint(-5, 3 * verts.shape[1], (buf.numel() // 4,), dtype=torch.int32, device=dev())
+    buf.view(torch.int32).copy_(junk)
+    mn3, arg3 = model.v2v_min(verts)                       # garbage, out-of-range and inadmissible rows included
+    moved = verts + 0.01 * torch.randn_like(verts)
+    monkeypatch.setenv('TUCH_V2V_HINT', '0')
+    mn4, arg4 = model.v2v_min(moved)
+    monkeypatch.setenv('TUCH_V2V_HINT', '1')
+    mn5, arg5 = model.v2v_min(moved)                       # hints from the other pose
+    for mn, arg in ((mn1, arg1), (mn2, arg2), (mn3, arg3)):
+        assert torch.equal(mn, mn0) and torch.equal(arg, arg0)
+    assert torch.equal(mn5, mn4) and torch.equal(arg5, arg4)

@@ -416,7 +416,9 @@ __device__ __forceinline__ float box_dist2(const Column& c, const float* __restr
 __global__ __launch_bounds__(64) void v2v_seed_kernel(
     const float* __restrict__ prow, int V, int Vp, const uint64_t* __restrict__ bits,
     const TreeNode* __restrict__ nodes, const int32_t* __restrict__ rows, const float* __restrict__ bounds,
-    const int32_t* __restrict__ masked, int N, uint64_t* __restrict__ keys)       // [B,Vp]
+    const int32_t* __restrict__ masked, int N,
+    const int32_t* __restrict__ hint,            // [B,Vp] a row per column (tree order) from an earlier call, or nullptr
+    uint64_t* __restrict__ keys)                 // [B,Vp]
 {
     const int b = blockIdx.x, qb = blockIdx.y, lane = threadIdx.x;
     const float* pb = prow + (size_t)b * Vp * 3;
@@ -461,6 +463,16 @@ __global__ __launch_bounds__(64) void v2v_seed_kernel(
         }
     }
     if (ok) v2v_rows(c, pb, bits + (size_t)qb * V, rows[2 * node], rows[2 * node + 1]);
+    if (hint) {
+        // the partner found for this column by an earlier call (e.g. the previous iteration of a fit): still an
+        // admissible row, so its current distance is a valid -- and usually almost final -- upper bound
+        const int j = hint[(size_t)b * Vp + i0];
+        if (j >= 0 && j < V && ((bits[(size_t)qb * V + j] >> lane) & 1)) {
+            const float dx = c.px - pb[3 * j], dy = c.py - pb[3 * j + 1], dz = c.pz - pb[3 * j + 2];
+            const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            if (d < c.best || (d == c.best && j < c.arg)) { c.best = d; c.arg = j; }
+        }
+    }
     keys[(size_t)b * Vp + i0] = v2v_key(c.best, c.arg);
 }
 
@@ -511,7 +523,7 @@ __global__ __launch_bounds__(64) void v2v_tree_kernel(
 // keys -> (min, argmin) in the caller's vertex numbering; all-masked column -> (inf, 0)
 __global__ __launch_bounds__(kBlock) void v2v_tree_finalize_kernel(
     const uint64_t* __restrict__ keys, const int32_t* __restrict__ qperm, int V, int Vp,
-    float* __restrict__ out_min, int32_t* __restrict__ out_arg)
+    float* __restrict__ out_min, int32_t* __restrict__ out_arg, int32_t* __restrict__ hint)
 {
     const int b = blockIdx.y;
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -519,6 +531,7 @@ __global__ __launch_bounds__(kBlock) void v2v_tree_finalize_kernel(
     const uint64_t k = keys[(size_t)b * Vp + i];
     const float d = __uint_as_float((uint32_t)(k >> 32));
     const int v = qperm[i];
+    if (hint) hint[(size_t)b * Vp + i] = d < __builtin_inff() ? (int)(uint32_t)k : -1;
     if (out_min) out_min[(size_t)b * V + v] = d;
     if (out_arg) out_arg[(size_t)b * V + v] = d < __builtin_inff() ? qperm[(uint32_t)k] : 0;
 }
@@ -622,8 +635,14 @@ extern "C" size_t tuch_v2v_model_workspace_bytes(const tuch_contact_model* m, in
     return tree > flat ? tree : flat;
 }
 
+extern "C" size_t tuch_v2v_hint_bytes(const tuch_contact_model* m, int B)
+{
+    if (!m || B <= 0 || m->tree_nodes <= 0 || !m->tree_mask_bits) return 0;
+    return (size_t)B * m->tree_qblocks * 2 * kTreeCols * sizeof(int32_t);
+}
+
 extern "C" int tuch_v2v_min_model(const tuch_contact_model* m, const float* verts, int B, float* min_d2,
-                                  int32_t* argmin, void* workspace, size_t workspace_bytes, void* stream)
+                                  int32_t* argmin, void* hint_inout, void* workspace, size_t workspace_bytes, void* stream)
 {
     TUCH_REQUIRE(m && verts && (min_d2 || argmin), "tuch_v2v_min_model: null pointer");
     TUCH_REQUIRE(m->mask_bits, "tuch_v2v_min_model: the model has no geodesic mask");
@@ -649,7 +668,7 @@ extern "C" int tuch_v2v_min_model(const tuch_contact_model* m, const float* vert
                        (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, m->tree_heights, bounds);
     hipLaunchKernelGGL(v2v_seed_kernel, dim3(B, 2 * m->tree_qblocks), dim3(64), 0, s, (const float*)prow, V, Vp,
                        (const uint64_t*)m->tree_mask_bits, nodes, (const int32_t*)m->tree_rows, (const float*)bounds,
-                       (const int32_t*)m->tree_masked, N, keys);
+                       (const int32_t*)m->tree_masked, N, (const int32_t*)hint_inout, keys);
     const int f = choose_v2v_frontier(m, B);
     const int f0 = m->tree_frontier_off_host[f], nsub = m->tree_frontier_off_host[f + 1] - f0;
     hipLaunchKernelGGL(v2v_tree_kernel, dim3(B, 2 * nsub * m->tree_qblocks), dim3(64), 0, s, (const float*)prow, V, Vp,
@@ -657,7 +676,7 @@ extern "C" int tuch_v2v_min_model(const tuch_contact_model* m, const float* vert
                        (const int32_t*)m->tree_masked, N, (const int32_t*)m->tree_frontier_nodes + f0,
                        (const int32_t*)m->tree_launch_order + (size_t)f0 * m->tree_qblocks, keys);
     hipLaunchKernelGGL(v2v_tree_finalize_kernel, dim3(ceil_div(V, kBlock), B), dim3(kBlock), 0, s,
-                       (const uint64_t*)keys, (const int32_t*)m->tree_qperm, V, Vp, min_d2, argmin);
+                       (const uint64_t*)keys, (const int32_t*)m->tree_qperm, V, Vp, min_d2, argmin, (int32_t*)hint_inout);
     return tuch_check_launch("tuch_v2v_min_model");
 }
 

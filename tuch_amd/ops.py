@@ -345,6 +345,7 @@ class ContactModel:
         self.device = torch.device(device if device is not None else 'cuda')
         faces = np.asarray(faces.detach().cpu() if isinstance(faces, torch.Tensor) else faces)
         self.faces_np = faces.astype(np.int64)
+        self._hints = {}
         self.num_verts = int(faces.max()) + 1
         self.num_faces = int(faces.shape[0])
         gm = None
@@ -480,9 +481,24 @@ class ContactModel:
         arg = torch.empty(b, self.num_verts, dtype=torch.int32, device=verts.device)
         nbytes = L.tuch_v2v_model_workspace_bytes(self._handle, b)
         ws = _workspace(nbytes, verts.device)
-        _C.check(L.tuch_v2v_min_model(self._handle, _C.ptr(verts), b, _C.ptr(mn), _C.ptr(arg), _C.ptr(ws), nbytes,
-                                      _C.stream()))
+        _C.check(L.tuch_v2v_min_model(self._handle, _C.ptr(verts), b, _C.ptr(mn), _C.ptr(arg), _C.ptr(self._v2v_hint(b)),
+                                      _C.ptr(ws), nbytes, _C.stream()))
         return mn, arg
+
+    def _v2v_hint(self, batch: int) -> Optional[torch.Tensor]:
+        """Persistent per-batch-size buffer in which the search leaves its partners for the next call (an iterative
+        fit re-finds almost the same partners): seeds only, the results never depend on it (TUCH_V2V_HINT=0: off).
+        Buffers are kept for the life of the model (a captured hipGraph may hold their addresses)."""
+        if os.environ.get('TUCH_V2V_HINT', '1') == '0':
+            return None
+        buf = self._hints.get(batch)
+        if buf is None:
+            n = _C.lib().tuch_v2v_hint_bytes(self._handle, batch)
+            if n == 0:
+                return None
+            buf = torch.zeros(n, dtype=torch.uint8, device=self.device)
+            self._hints[batch] = buf
+        return buf
 
     def winding_points(self, verts: torch.Tensor, points: torch.Tensor, counts: Optional[torch.Tensor] = None,
                        thresh: float = 0.99):
