@@ -26,7 +26,9 @@ _SIDE_STREAMS = {}
 
 
 def _side_stream(device) -> 'torch.cuda.Stream':
-    key = (device.type, device.index)
+    """The companion stream of the CURRENT stream (one per stream: callers that run several fits on streams of
+    their own must not be coupled through a shared side stream)."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     if key not in _SIDE_STREAMS:
         _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
     return _SIDE_STREAMS[key]
