@@ -326,11 +326,65 @@ def fullsize_case():
     print('wrote', path, '%.1f KB' % (os.path.getsize(path) / 1024))
 
 
+def fullsize_train_case():
+    """The SMPL-sized body of ``fullsize_case`` (same vertices) through the reference's
+    RegressorLoss.contact_loss, plain and HD branch with all N_hd = 3 F = 41 328 HD points
+    (tuch/train/loss.py:240-317), and through EFTLoss.contact_loss (tuch/eft/loss.py:129-181).
+    Inputs live in contact_full.npz; this file holds the expected outputs only."""
+    body = make_body(84, 82)
+    _use_body(body)
+    verts_np, _, _, _, _ = _posed_verts(body, 1, 2002)
+    assert np.array_equal(verts_np, gio.load('contact_full.npz')['verts'])
+    out = {}
+    face_tensor = torch.tensor(body.faces, dtype=torch.long)[None]
+    geomask = torch.tensor(body.geodesics) > ref_config.geothres
+    valid = torch.ones(1, dtype=torch.bool)
+    with tempfile.TemporaryDirectory() as tmp:
+        ref_config.HD_MODEL_DIR = tmp
+        np.save(os.path.join(tmp, 'smpl_neutral_hd_vert_regressor.npy'), dense_hd_regressor(body))
+        with open(os.path.join(tmp, 'smpl_neutral_hd_sample_from_mesh_out.pkl'), 'wb') as f:
+            pickle.dump({'faces_vert_is_sampled_from': body.hd_face_id}, f)
+        for use_hd in (False, True):
+            crit = ref_train_loss.RegressorLoss(
+                options=types.SimpleNamespace(contact_loss_weight=1.0), device='cpu',
+                num_verts=body.num_verts, faces=face_tensor, geodistssmpl=torch.tensor(body.geodesics),
+                geothres=ref_config.geothres, euclthres=ref_config.euclthres,
+                face_tensor=face_tensor, use_hd=use_hd)
+            v = torch.tensor(verts_np, requires_grad=True)
+            loss = crit.contact_loss(v, valid)
+            loss.backward()
+            key = 'train_hd' if use_hd else 'train_plain'
+            out[key + '_loss'] = np.float64(loss.item())
+            out[key + '_grad_verts'] = v.grad.numpy()
+            print(key, loss.item(), flush=True)
+            del crit
+    from tuch.eft import loss as ref_eft
+    names = list(body.segments.keys())
+    segments = ref_segmentation.BatchBodySegment(names, face_tensor[0])
+    cdict = {'classes': [list(p) for p in body.region_pairs], 'csig': dict(body.regions)}
+    gt = gio.load('contact_full.npz')['gt_contact']
+    eft = ref_eft.EFTLoss.__new__(ref_eft.EFTLoss)
+    torch.nn.Module.__init__(eft)
+    eft.device, eft.options = 'cpu', types.SimpleNamespace(batch_size=1)
+    eft.face_tensor, eft.geomask, eft.cdict, eft.segments = face_tensor, geomask, cdict, segments
+    v = torch.tensor(verts_np, requires_grad=True)
+    l = eft.contact_loss(torch.tensor(gt), v)
+    l.backward()
+    out['eft_loss'] = np.asarray([l.item()], np.float64)
+    out['eft_grad_verts'] = v.grad.numpy()
+    print('eft', l.item(), flush=True)
+    path = os.path.join(HERE, 'contact_full_train.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, '%.1f KB' % (os.path.getsize(path) / 1024))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['small', 'medium', 'full']
+    which = sys.argv[1:] or ['small', 'medium', 'full', 'full_train']
     if 'small' in which:
         contact_case('small', 10, 12, batch=2, seed=1001, store_dense=True)
     if 'medium' in which:
         contact_case('medium', 40, 40, batch=3, seed=1002, store_dense=False)
     if 'full' in which:
         fullsize_case()
+    if 'full_train' in which:
+        fullsize_train_case()

@@ -25,6 +25,20 @@ def dev():
     return torch.device('cuda:0')
 
 
+def report(what, count, total):
+    """Observed index/flag mismatches against the reference (allowed only between candidates tied within the
+    reference's own float32 noise): printed (-s) and appended to gpurun_out/parity_counts.txt."""
+    import os
+    line = '%-64s %6d / %d' % (what, count, total)
+    print(line)
+    try:
+        os.makedirs(os.path.join(gio.GOLDEN_DIR, '..', '..', 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(gio.GOLDEN_DIR, '..', '..', 'gpurun_out', 'parity_counts.txt'), 'a') as f:
+            f.write(line + '\n')
+    except OSError:
+        pass
+
+
 def make_model(g, gm, with_segments=True, with_regions=True):
     from tuch_amd.ops import ContactModel
     segs = gio.unpack_segments(g)
@@ -80,6 +94,7 @@ def test_v2v_min_masked_vs_reference(tag):
     for b in range(mn.shape[0]):
         assert_close(mn[b], g['v2v_min'][b], 0, 1e-6, 'v2v min')
         same = arg[b] == g['v2v_argmin'][b]
+        report('v2v argmin != reference [%s, body %d]' % (tag, b), int((~same).sum()), same.size)
         assert same.mean() > 0.99
         v = g['verts'][b].astype(np.float64)
         d_ours = ((v - v[arg[b]]) ** 2).sum(1)
@@ -116,6 +131,9 @@ def test_exterior_flags_and_segments(tag):
         check_winding(w[b], g['winding'][b])
         assert np.array_equal(ext_plain[b], w[b] <= np.float32(0.99))
         want = g['segment_exterior'][b].astype(bool)
+        report('segment flags != reference [%s, body %d]' % (tag, b), int((seg_e[b].astype(bool) != want).sum()), want.size)
+        report('exterior flags (w <= 0.99) != reference [%s, body %d]' % (tag, b),
+               int(((w[b] <= np.float32(0.99)) != (g['winding'][b] <= np.float32(0.99))).sum()), w[b].size)
         assert (seg_e[b].astype(bool) != want).sum() <= 1
         expect = ext_plain[b].copy()
         off = 0
@@ -234,6 +252,106 @@ def test_contact_fitting_loss_vs_reference(tag, eu, sg, full):
         assert_close(mj.grad.cpu().numpy(), gj, 1e-3, 1e-5 * np.abs(gj).max(), key + ' grad joints')
         gp = g[key + '_grad_pose']
         assert_close(pose.grad.cpu().numpy(), gp, 1e-3, 1e-5 * np.abs(gp).max(), key + ' grad pose')
+
+
+def _full_train():
+    data = gio.load('contact_full_train.npz')
+    return {k: data[k] for k in data.files}
+
+
+@pytest.mark.parametrize('eu', ['e0', 'e2'])
+def test_contact_fitting_loss_vs_reference_fullsize(eu):
+    """a6 at SMPL size (V=6890, F=13776): the reference's contact_fitting_loss on one body with segments and
+    three annotated region pairs (tests/golden/make_golden.py:fullsize_case) -- loss and gradient."""
+    from tuch_amd.smplify.losses import contact_fitting_loss
+    from tuch_amd.utils.segmentation import BatchBodySegment
+    g, gm = golden('full'), golden_mask('full')
+    d = dev()
+    t = lambda a: torch.tensor(a, device=d)
+    regions, pairs = gio.unpack_regions(g)
+    cdict = {'classes': [list(p) for p in pairs], 'csig': regions}
+    face_tensor = t(g['faces'])[None]
+    segs = gio.unpack_segments(g)
+    segments = BatchBodySegment(list(segs.keys()), face_tensor[0], segs)
+    verts = t(g['verts']).requires_grad_(True)
+    zero_prior = lambda pose, betas: torch.zeros(pose.shape[0], device=d)
+    loss = contact_fitting_loss(
+        torch.zeros(1, 69, device=d), torch.zeros(1, 3, device=d), None, None, torch.zeros(1, 10, device=d),
+        torch.ones(1, 49, 3, device=d), t(gm), 0.0 if eu == 'e0' else float(g['euclthres']),
+        torch.tensor([[0., 0., 20.]], device=d), torch.zeros(1, 2, device=d), torch.zeros(1, 49, 2, device=d),
+        torch.zeros(1, 49, device=d), zero_prior, cdict, [t(g['gt_contact']), None],
+        torch.zeros(1, dtype=torch.bool, device=d), torch.ones(1, dtype=torch.bool, device=d), verts,
+        face_tensor=face_tensor, contact_loss_weight=float(g['contact_loss_weight']), segments=segments)
+    loss.backward()
+    key = 'smplify_%s_seg_contact' % eu
+    n_sel = float((g['gt_contact'] == 1).sum())
+    assert_close(loss.item(), g[key + '_loss'], 1e-4, 2000 * 1e-6 * n_sel, key)
+    gv = g[key + '_grad_verts']
+    assert_close(verts.grad.cpu().numpy(), gv, 1e-3, 2e-6 * np.abs(gv).max(), key + ' grad verts')
+
+
+@pytest.mark.parametrize('use_hd', [False, True])
+def test_regressor_contact_loss_vs_reference_fullsize(use_hd):
+    """a7 at SMPL size with all N_hd = 41 328 HD points: the configuration bench.py times."""
+    import types
+    from tuch_amd.train.loss import RegressorLoss
+    from tuch_amd.utils.segmentation import BatchBodySegment
+    g, gm, gt = golden('full'), golden_mask('full'), _full_train()
+    d = dev()
+    face_tensor = torch.tensor(g['faces'], device=d)[None]
+    segs = gio.unpack_segments(g)
+    segments = BatchBodySegment(list(segs.keys()), face_tensor[0], segs)
+    geod = torch.tensor(np.where(gm, 1.0, 0.0).astype(np.float32), device=d)
+    crit = RegressorLoss(types.SimpleNamespace(contact_loss_weight=1.0), d, g['verts'].shape[1], face_tensor,
+                         geod, geothres=0.3, euclthres=float(g['euclthres']), face_tensor=face_tensor,
+                         use_hd=use_hd, segments=segments, hd_regressor=(g['hd_idx'], g['hd_w']),
+                         hd_faces=g['hd_face'])
+    assert not use_hd or crit.hd_idx.shape[0] == 41328
+    verts = torch.tensor(g['verts'], device=d, requires_grad=True)
+    loss = crit.contact_loss(verts, torch.ones(1, dtype=torch.bool, device=d))
+    loss.backward()
+    key = 'train_hd' if use_hd else 'train_plain'
+    assert_close(loss.item(), gt[key + '_loss'], 1e-4, 0, key)
+    gv = gt[key + '_grad_verts']
+    assert_close(verts.grad.cpu().numpy(), gv, 1e-3, 5e-6 * np.abs(gv).max(), key + ' grad')
+
+
+def test_eft_contact_loss_vs_reference_fullsize():
+    import types
+    from tuch_amd.eft.loss import EFTLoss
+    from tuch_amd.utils.segmentation import BatchBodySegment
+    g, gm, gt = golden('full'), golden_mask('full'), _full_train()
+    d = dev()
+    face_tensor = torch.tensor(g['faces'], device=d)[None]
+    segs = gio.unpack_segments(g)
+    regions, pairs = gio.unpack_regions(g)
+    crit = EFTLoss(types.SimpleNamespace(batch_size=1, img_res=224), d, None, g['verts'].shape[1], None,
+                   torch.tensor(np.where(gm, 1.0, 0.0).astype(np.float32), device=d), 0.3, face_tensor=face_tensor,
+                   cdict={'classes': [list(p) for p in pairs], 'csig': regions},
+                   segments=BatchBodySegment(list(segs.keys()), face_tensor[0], segs))
+    verts = torch.tensor(g['verts'], device=d, requires_grad=True)
+    loss = crit.contact_loss(torch.tensor(g['gt_contact'], device=d), verts)
+    loss.backward()
+    n_sel = float((g['gt_contact'] == 1).sum())
+    assert_close(loss.item(), gt['eft_loss'].sum(), 1e-4, 50 * 1e-6 * n_sel, 'eft loss')
+    gv = gt['eft_grad_verts']
+    assert_close(verts.grad.cpu().numpy(), gv, 1e-3, 5e-6 * np.abs(gv).max(), 'eft grad')
+
+
+def test_batch_pairwise_dist_batched_regions():
+    """a1 as contact_from_verts calls it (train_module.py:83-88): full batch, two different region subsets."""
+    from tuch_amd import ops
+    g = golden('medium')
+    regions, pairs = gio.unpack_regions(g)
+    verts = torch.tensor(g['verts'], device=dev())
+    for k in (0, len(pairs) // 2, len(pairs) - 1):
+        r1, r2 = regions[pairs[k][0]], regions[pairs[k][1]]
+        x, y = verts[:, torch.as_tensor(r1, device=dev())], verts[:, torch.as_tensor(r2, device=dev())]
+        p = ops.batch_pairwise_dist(x.contiguous(), y.contiguous()).cpu().numpy()
+        assert p.shape == (verts.shape[0], len(r1), len(r2))
+        for b in range(verts.shape[0]):
+            assert_close(p[b], oc.pairwise_sq(g['verts'][b][r1], g['verts'][b][r2]), 0, 1e-6, 'pairwise block')
+        assert_close(p.reshape(p.shape[0], -1).min(1), g['contact_from_verts'][:, k], 0, 1e-6, 'block minimum')
 
 
 @pytest.mark.parametrize('tag', TAGS)

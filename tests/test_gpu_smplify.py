@@ -140,3 +140,144 @@ def test_graph_replayed_loops_match_eager_loops():
     for a, b, name in zip(eager[:6], graph[:6], ('verts', 'joints', 'pose', 'betas', 'cam', 'reproj')):
         assert_close(b.detach().cpu().numpy(), a.detach().cpu().numpy(), 2e-3, 2e-4, name)
     assert_close(graph[6][-1].cpu().numpy(), eager[6][-1].detach().cpu().numpy(), 2e-3, 2e-4, 'last optiverts')
+
+
+def _loop_golden():
+    data = gio.load('smplify_loop.npz')
+    return {k: data[k] for k in data.files}
+
+
+@pytest.mark.parametrize('use_contact', [True, False])
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_smplifydc_matches_the_reference_loop(use_contact, use_graph, monkeypatch):
+    """a9: the 7-tuple of the REFERENCE'S OWN SMPLifyDC.__call__ (tests/golden/make_golden_smplify.py: its two Adam
+    loops, 10 + 10 iterations, ignored bodies, has_gt_keypoints, both branches) against ours, eager and replayed
+    as hipGraphs.  1e-3 on everything; the per-iteration vertices of stage 2 as well."""
+    from tuch_amd.models.smpl import SMPL
+    from tuch_amd.smplify.prior import MaxMixturePrior
+    from tuch_amd.smplify.smplifydc import SMPLifyDC
+    from tuch_amd.utils.segmentation import BatchBodySegment
+    monkeypatch.setenv('TUCH_GRAPH_STRICT', '1')
+    g = _loop_golden()
+    body = make_body(int(g['rings']), int(g['segs']), relax_iters=int(g['relax_iters']))
+    t = lambda a: torch.tensor(a, device=DEV)
+    batch = g['init_pose'].shape[0]
+    smpl = SMPL(model_data=body, batch_size=batch).to(DEV)
+    prior = MaxMixturePrior(num_gaussians=8, gmm=body.gmm).to(DEV)
+    segments = BatchBodySegment(list(body.segments.keys()), t(body.faces), body.segments)
+    cdict = {'classes': [list(p) for p in body.region_pairs], 'csig': dict(body.regions)}
+    fitter = SMPLifyDC(step_size=1e-2, batch_size=batch, num_iters=int(g['num_iters']), focal_length=5000.,
+                       geodistssmpl=t(body.geodesics), geothres=float(g['geothres']), euclthres=float(g['euclthres']),
+                       device=torch.device(DEV), smpl=smpl, pose_prior=prior, use_graph=use_graph)
+    assert fitter.ign_joints == [1, 9, 12, 27, 28]
+    kp = t(g['keypoints_2d'])
+    res = fitter(t(g['init_pose']), t(g['init_betas']), t(g['init_cam_t']), t(g['camera_center']), kp,
+                 use_contact=use_contact, contactlist=cdict, gt_contact=[t(g['gt_contact']), None],
+                 ignore_idxs=t(g['ignore_idxs']), has_discrete_contact=t(g['has_discrete_contact']),
+                 has_gt_keypoints=t(g['has_gt_keypoints']), contact_loss_weight=float(g['contact_loss_weight']),
+                 segments=segments)
+    if use_graph:
+        assert fitter.graph_replayed == {'stage1': 7, 'stage2': 7}
+    tag = 'contact' if use_contact else 'plain'
+    names = ('vertices', 'joints', 'pose', 'betas', 'camera_translation', 'reprojection_loss')
+    for name, got in zip(names, res[:6]):
+        want = g['%s_%s' % (tag, name)]
+        assert_close(got.detach().cpu().numpy(), want, 1e-3, 1e-3 * np.abs(want).max(), '%s %s' % (tag, name))
+    optiverts = torch.stack([v.detach() for v in res[6]]).cpu().numpy()
+    want = g['%s_optiverts' % tag]
+    assert optiverts.shape == want.shape
+    assert_close(optiverts, want, 1e-3, 1e-3, tag + ' optiverts')
+    assert torch.equal(kp, t(g['keypoints_2d']))                 # __call__ does not write into its input
+    # the fit actually moved: not a comparison of two untouched initial states
+    assert np.abs(g['%s_pose' % tag] - g['init_pose']).max() > 0.05
+    got = fitter.get_fitting_loss(t(g['init_pose']), t(g['init_betas']), t(g['init_cam_t']), t(g['camera_center']),
+                                  kp.clone(), t(g['has_gt_keypoints']))
+    assert_close(got.cpu().numpy(), g['get_fitting_loss'], 1e-4, 1e-3, 'get_fitting_loss')
+
+
+def test_smplifydc_default_contactlist():
+    """__call__ defaults contactlist=[] (smplifydc.py:70); with use_contact that means no region term."""
+    from tuch_amd.smplify.smplifydc import SMPLifyDC
+    batch = 2
+    s = _setup(batch, 7)
+    t = s['t']
+    fitter = SMPLifyDC(step_size=1e-2, batch_size=batch, num_iters=3, focal_length=5000.,
+                       geodistssmpl=t(s['body'].geodesics), geothres=0.3, euclthres=0.02, device=torch.device(DEV),
+                       smpl=s['smpl'], pose_prior=s['prior'])
+    init_pose = torch.cat([t(s['go']), t(s['bp'])], 1)
+    res = fitter(init_pose, t(s['be']), t(s['cam_t']), torch.zeros(batch, 2, device=DEV), t(s['kp']),
+                 use_contact=True, gt_contact=[t(s['gt']), None],
+                 ignore_idxs=torch.zeros(batch, dtype=torch.bool, device=DEV),
+                 has_discrete_contact=torch.ones(batch, dtype=torch.bool, device=DEV))
+    assert torch.isfinite(res[0]).all() and len(res[6]) == 3
+
+
+def test_config3_fit_batch32_fullsize(monkeypatch):
+    """BASELINE configs[2]: demo_smplify_dc.py-style fit, batch 32, V=6890, 100 + 100 iterations, loops replayed as
+    hipGraphs.  Checks: everything finite, the stage-2 objective decreases, and the objective the GPU reports at
+    iterations 0, 1 and 99 equals the CPU oracle's evaluated at the recorded parameters (oracle LBS -> oracle
+    contact / reprojection / prior), for a sample of the bodies at 0 and 99 and for all of them at iteration 1."""
+    import bench
+    from oracle import smplify as osm
+    from tuch_amd.smplify.smplifydc import SMPLifyDC
+    monkeypatch.setenv('TUCH_GRAPH_STRICT', '1')
+    batch, iters = 32, 100
+    dev = torch.device(DEV)
+    p = bench.build_problem(batch, dev, 1003)
+    body = p['body']
+    fitter = SMPLifyDC(step_size=1e-2, batch_size=batch, num_iters=iters, focal_length=5000.,
+                       geodistssmpl=torch.tensor(body.geodesics, device=dev), geothres=0.3, euclthres=0.02, device=dev,
+                       smpl=p['smpl'], pose_prior=p['prior'], record_history=True)
+    kp = torch.cat([p['j2d'], p['conf'][..., None]], 2)
+    init_pose = torch.cat([p['global_orient'], p['body_pose']], 1)
+    res = fitter(init_pose, p['betas'], p['cam_t'], p['cam_c'], kp, use_contact=True, contactlist=p['cdict'],
+                 gt_contact=[p['gt'], None], ignore_idxs=p['ignore'], has_discrete_contact=p['has_dc'],
+                 contact_loss_weight=2000.0, segments=p['segments'])
+    verts, joints, pose, betas, cam, reproj, optiverts = res
+    assert fitter.graph_replayed == {'stage1': iters - 3, 'stage2': iters - 3}
+    assert len(optiverts) == iters and len(fitter.history['stage2']) == iters
+    for x in (verts, joints, pose, betas, cam, reproj):
+        assert torch.isfinite(x).all()
+    losses = torch.stack([h['loss'] for h in fitter.history['stage2']]).cpu().numpy()
+    assert np.isfinite(losses).all()
+    assert losses[-1] < losses[0]
+    # Adam at lr 1e-2 is not strictly monotone step by step; averaged over windows of 10 it is
+    win = losses.reshape(10, 10).mean(1)
+    assert np.all(np.diff(win) < 0.02 * np.abs(win[:-1])), win
+    # ---- oracle evaluation at the recorded parameters
+    m = ol.model_tensors(body)
+    gm = body.geodesics > 0.3
+    osegs = [oc.Segment(n, body.faces, sg['vidx'], list(sg['bands'].values())) for n, sg in body.segments.items()]
+    gt = p['gt'].cpu().numpy()
+    conf = kp[:, :, 2].clone()
+    conf[:, fitter.ign_joints] = 0.0
+    for it, sample in ((0, [0, 13, 31]), (1, list(range(batch))), (99, [0, 13, 31])):
+        h = fitter.history['stage2'][it]
+        bp, go = h['params'][0].cpu(), h['params'][1].cpu()
+        v_o, j_o = ol.smpl_forward(m, betas.cpu(), bp, go)
+        v_gpu = optiverts[it].cpu().numpy()
+        assert_close(v_gpu, v_o.numpy(), 1e-4, 1e-5, 'vertices at iteration %d' % it)
+        idx = np.asarray(sample)
+        rp = [[(body.regions[a], body.regions[c]) for k, (a, c) in enumerate(body.region_pairs) if gt[b, k] == 1]
+              for b in idx]
+        total, per_body, parts = osm.stage2_objective(
+            v_gpu[idx], j_o.numpy()[idx], bp.numpy()[idx], body.faces, gm, 0.02, cam.cpu().numpy()[idx],
+            p['cam_c'].cpu().numpy()[idx], p['j2d'].cpu().numpy()[idx], conf.cpu().numpy()[idx], body.gmm, osegs, rp,
+            None, contact_loss_weight=2000.0)
+        if len(sample) == batch:
+            n_sel = float(gt.sum())
+            assert_close(float(losses[it]), total, 1e-4, 2000 * 1e-6 * n_sel, 'objective at iteration %d' % it)
+        else:
+            # the GPU reports the batch sum; compare the sampled bodies through a sub-batch evaluation on the GPU
+            from tuch_amd.smplify.losses import contact_fitting_loss
+            sel = torch.as_tensor(idx, device=dev)
+            with torch.no_grad():
+                out = p['smpl'](global_orient=h['params'][1][sel], body_pose=h['params'][0][sel], betas=betas[sel])
+                sub = contact_fitting_loss(h['params'][0][sel], h['params'][1][sel], None, None, betas[sel], out.joints,
+                                           fitter.geomask, 0.02, cam[sel], p['cam_c'][sel], p['j2d'][sel].contiguous(),
+                                           conf[sel], p['prior'], cdict=p['cdict'], gt_contact=[p['gt'][sel], None],
+                                           ignore_idxs=p['ignore'][sel], has_discrete_contact=p['has_dc'][sel],
+                                           verts=out.vertices, face_tensor=fitter.face_tensor[:len(idx)],
+                                           focal_length=5000., contact_loss_weight=2000.0, segments=p['segments'])
+            n_sel = float(gt[idx].sum())
+            assert_close(sub.item(), total, 1e-4, 2000 * 1e-6 * n_sel, 'objective of the sample at iteration %d' % it)

@@ -172,3 +172,52 @@ def test_eft_contact_loss(tag):
         assert_close(total, g['eft_loss'][b], 1e-5, 1e-6, 'eft loss')
         scale = np.abs(g['eft_grad_verts'][b]).max()
         assert_close(grad, g['eft_grad_verts'][b], 1e-4, 2e-6 * scale, 'eft grad')
+
+
+def _full_train():
+    data = gio.load('contact_full_train.npz')
+    return {k: data[k] for k in data.files}
+
+
+@pytest.mark.parametrize('use_hd', [False, True])
+def test_train_contact_loss_fullsize(use_hd):
+    """a7 at SMPL size (V=6890, N_hd=41328), plain and HD branch (loss.py:240-317)."""
+    g, gm, gt = golden('full'), golden_mask('full'), _full_train()
+    loss, grad, _ = oc.train_contact_loss(
+        g['verts'], np.ones(1, bool), g['faces'], gm, float(g['euclthres']), oracle_segments(g),
+        use_hd, hd_idx=g['hd_idx'], hd_w=g['hd_w'], hd_face=g['hd_face'])
+    key = 'train_hd' if use_hd else 'train_plain'
+    assert_close(loss, gt[key + '_loss'], 1e-5, 0, key)
+    scale = np.abs(gt[key + '_grad_verts']).max()
+    assert_close(grad, gt[key + '_grad_verts'], 1e-4, 2e-6 * scale, key + ' grad')
+
+
+def test_eft_contact_loss_fullsize():
+    g, gm, gt = golden('full'), golden_mask('full'), _full_train()
+    r = oc.eft_contact_body(g['verts'][0], g['faces'], gm, oracle_segments(g), region_pair_lists(g, 0))
+    assert_close(100 * (r['contact'] + 0.5 * r['r2r']), gt['eft_loss'][0], 1e-5, 1e-6, 'eft loss')
+    grad = 100 * (r['grad_contact'] + 0.5 * r['grad_r2r'])
+    scale = np.abs(gt['eft_grad_verts'][0]).max()
+    assert_close(grad, gt['eft_grad_verts'][0], 1e-4, 2e-6 * scale, 'eft grad')
+
+
+@pytest.mark.parametrize('tag', TAGS)
+def test_smplify_objective_terms(tag):
+    """oracle/smplify.py against the reference's projection, gmof, GMM prior and the full stage-2 objective."""
+    from oracle import smplify as osm
+    g, gm = golden(tag), golden_mask(tag)
+    proj = osm.perspective_projection(g['model_joints'], g['camera_t'], 5000., g['camera_center'])
+    assert_close(proj, g['projected_joints'], 1e-6, 1e-4, 'projection')
+    assert_close(osm.gmof(g['joints_2d'] - proj, 100.), g['gmof_values'], 1e-5, 1e-5, 'gmof')
+    gmm = {k: g['gmm_' + k] for k in ('means', 'covars', 'weights')}
+    assert_close(osm.merged_prior(g['body_pose'], gmm), g['prior_values'], 1e-5, 1e-4, 'prior')
+    assert_close(osm.reprojection(g['model_joints'], g['camera_t'], g['camera_center'], g['joints_2d'],
+                                  g['joints_conf']), g['body_fitting_reprojection'], 1e-5, 1e-4, 'reprojection')
+    b_count = g['verts'].shape[0]
+    rp = [region_pair_lists(g, b) if g['has_discrete_contact'][b] else None for b in range(b_count)]
+    for eu, eucl in (('e0', 0.0), ('e2', float(g['euclthres']))):
+        total, _, _ = osm.stage2_objective(
+            g['verts'], g['model_joints'], g['body_pose'], g['faces'], gm, eucl, g['camera_t'], g['camera_center'],
+            g['joints_2d'], g['joints_conf'], gmm, oracle_segments(g), rp, g['ignore_idxs'],
+            contact_loss_weight=float(g['contact_loss_weight']))
+        assert_close(total, g['smplify_%s_seg_full_loss' % eu], 1e-5, 0, 'stage-2 objective ' + eu)

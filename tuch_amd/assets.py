@@ -14,14 +14,53 @@ from typing import Dict, Tuple
 import numpy as np
 
 
+# configs/config.py:74-92 -- used when the reference checkout (and with it ``configs.config``) is not importable
+_DEFAULT_PATHS = {
+    'SMPL_MODEL_DIR': 'data/models/smpl',
+    'JOINT_REGRESSOR_TRAIN_EXTRA': 'data/essentials/spin/J_regressor_extra.npy',
+    'PRIOR_FOLDER': 'data/essentials/spin',
+    'GEODESICS_SMPL': 'data/essentials/geodesics/smpl/smpl_neutral_geodesic_dist.npy',
+    'HD_MODEL_DIR': 'data/essentials/hd_model/smpl',
+    'SEGMENT_DIR': 'data/essentials/segments/smpl',
+    'STATIC_FITS_DIR': 'data/static_fits',
+    'DSC_ROOT': '//tuch/dsc/release',
+}
+
+
+def config_path(name: str) -> str:
+    """``configs.config.<name>`` of the reference checkout when importable, else its shipped default."""
+    try:
+        import importlib
+        cfg = importlib.import_module('configs.config')
+        if hasattr(cfg, name):
+            return getattr(cfg, name)
+    except ImportError:
+        pass
+    return _DEFAULT_PATHS[name]
+
+
+def reference_segm_utils():
+    """``data.essentials.segments.smpl.segm_utils`` (segmentation.py:26: boundary loops per segment); part of the
+    licensed data folder.  Raises ImportError with a pointer when it is not importable."""
+    import importlib
+    try:
+        return importlib.import_module('data.essentials.segments.smpl.segm_utils')
+    except ImportError as exc:
+        raise ImportError('the body-segment tables (data/essentials/segments/smpl/segm_utils.py) are not importable: '
+                          'run from a directory that holds the reference\'s data/ folder, or pass the segment '
+                          'tables explicitly (segments=...)') from exc
+
+
 def load_geodesic_mask(path: str, geothres: float) -> np.ndarray:
     """smpl_neutral_geodesic_dist.npy [V,V] -> bool mask geod > geothres (smplifydc.py:65, loss.py:71)."""
     geod = np.load(path)
     return geod > geothres
 
 
-def load_contact_regions(dsc_root: str) -> Dict[str, object]:
+def load_contact_regions(dsc_root: str = None) -> Dict[str, object]:
     """classes.pkl + ContactSigSMPL.pkl -> {'classes': [...], 'csig': {...}} (train_module.py:64-66)."""
+    if dsc_root is None:
+        dsc_root = config_path('DSC_ROOT')
     with open(os.path.join(dsc_root, 'classes.pkl'), 'rb') as f:
         classes = pickle.load(f)
     with open(os.path.join(dsc_root, 'ContactSigSMPL.pkl'), 'rb') as f:
@@ -29,10 +68,12 @@ def load_contact_regions(dsc_root: str) -> Dict[str, object]:
     return {'classes': classes, 'csig': csig}
 
 
-def load_hd_regressor(hd_model_dir: str) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+def load_hd_regressor(hd_model_dir: str = None) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """smpl_neutral_hd_vert_regressor.npy (dense [N,V], barycentric: <= 3 non-zeros per row) and
     smpl_neutral_hd_sample_from_mesh_out.pkl -> (corner ids [N,3], weights [N,3], face ids [N])
     (loss.py:81-88)."""
+    if hd_model_dir is None:
+        hd_model_dir = config_path('HD_MODEL_DIR')
     dense = np.load(os.path.join(hd_model_dir, 'smpl_neutral_hd_vert_regressor.npy'))
     idx = np.argsort(-np.abs(dense), axis=1)[:, :3]
     wgt = np.take_along_axis(dense, idx, 1).astype(np.float32)
@@ -86,9 +127,13 @@ def read_ply_vertex_red(path: str) -> np.ndarray:
         return np.asarray([rec.unpack_from(data, i * rec.size)[red_i] for i in range(n_vert)]).astype(np.int64)
 
 
-def load_segments(segment_dir: str, segm_utils_segments: Dict[str, Dict[str, list]]) -> Dict[str, dict]:
+def load_segments(segment_dir: str = None, segm_utils_segments: Dict[str, Dict[str, list]] = None) -> Dict[str, dict]:
     """smpl_segment_{name}.ply + segm_utils.segments -> {name: {'vidx', 'bands'}}, the form
     tuch_amd.utils.segmentation.BatchBodySegment takes (segmentation.py:40-46)."""
+    if segment_dir is None:
+        segment_dir = config_path('SEGMENT_DIR')
+    if segm_utils_segments is None:
+        segm_utils_segments = reference_segm_utils().segments
     out = {}
     for name, bands in segm_utils_segments.items():
         red = read_ply_vertex_red(os.path.join(segment_dir, 'smpl_segment_{}.ply'.format(name)))

@@ -23,6 +23,7 @@ _MAP = {
     'tuch.smplify.smplifydc': 'tuch_amd.smplify.smplifydc',
     'tuch.models.smpl': 'tuch_amd.models.smpl',
     'tuch.train.loss': 'tuch_amd.train.loss',
+    'tuch.train.train_module': 'tuch_amd.train.train_module',
     'tuch.eft.loss': 'tuch_amd.eft.loss',
 }
 

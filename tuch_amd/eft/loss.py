@@ -10,10 +10,6 @@ i.e. the SMPLify terms with means instead of sums and no distance gate on the ex
 """
 from __future__ import annotations
 
-import os.path as osp
-import pickle
-
-import numpy as np
 import torch
 import torch.nn as nn
 
@@ -39,18 +35,17 @@ class EFTLoss(nn.Module):
         self.geodistssmpl = geodistssmpl
         self.geothres = geothres
         self.geomask = self.geodistssmpl > self.geothres
-        if cdict is None:
-            classes = pickle.load(open(osp.join(dsc_root, 'classes.pkl'), 'rb'))
-            csig = pickle.load(open(osp.join(dsc_root, 'ContactSigSMPL.pkl'), 'rb'))
-            cdict = {'classes': classes, 'csig': csig}
+        if cdict is None:                                          # eft/loss.py:63-66
+            from ..assets import load_contact_regions
+            cdict = load_contact_regions(dsc_root)
         self.cdict = cdict
-        self.segments = segments
-        names = list(cdict['csig'].keys())
-        index = {n: i for i, n in enumerate(names)}
-        pairs = np.asarray([[index[str(a)], index[str(b)]] for a, b in cdict['classes']], np.int64)
         ft = face_tensor[0] if face_tensor.dim() == 3 else face_tensor
-        self._model = ops.ContactModel(ft, self.geomask, segments.tables() if segments is not None else None,
-                                       [np.asarray(cdict['csig'][n]) for n in names], pairs, device=ft.device)
+        if segments is None:                                       # eft/loss.py:69-71: always built
+            from ..utils.segmentation import BatchBodySegment, reference_segment_names
+            segments = BatchBodySegment(reference_segment_names(), ft)
+        self.segments = segments
+        regions, pairs = ops.region_tables(cdict)
+        self._model = ops.ContactModel(ft, self.geomask, segments.tables(), regions, pairs, device=ft.device)
 
     def forward(self, body, camera, batch):
         """Reference: eft/loss.py:73-118 (the debugging print is not reproduced)."""
@@ -79,7 +74,7 @@ class EFTLoss(nn.Module):
 
     def contact_loss(self, gt_contact, verts):
         model = self._model
-        exterior, _, partner, _ = model.exterior_and_partner(verts, apply_segments=self.segments is not None)
+        exterior, _, partner, _ = model.exterior_and_partner(verts, apply_segments=True)
         _, terms = ops.contact_terms(verts, partner, exterior, None, ops.MODE_TRAIN, 0.0)
         n_ext = exterior.to(torch.float32).sum(dim=1)
         n_int = exterior.shape[1] - n_ext

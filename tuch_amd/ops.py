@@ -216,9 +216,11 @@ class _SmallTerms(torch.autograd.Function):
         gj = torch.empty_like(j)
         gc = torch.empty(b, 3, dtype=torch.float32, device=j.device)
         gp = torch.empty(b, 69, dtype=torch.float32, device=j.device) if body_pose is not None else None
+        # bound to locals: a converted copy must stay alive until the kernel has been enqueued
+        cam_t, cam_c, j2d, conf = _f32(camera_t), _f32(camera_center), _f32(joints_2d), _f32(joints_conf)
+        pose = _f32(body_pose) if body_pose is not None else None
         _C.check(_C.lib().tuch_smplify_small_terms(
-            _C.ptr(j), _C.ptr(_f32(camera_t)), _C.ptr(_f32(camera_center)), _C.ptr(_f32(joints_2d)),
-            _C.ptr(_f32(joints_conf)), _C.ptr(_f32(body_pose) if body_pose is not None else None),
+            _C.ptr(j), _C.ptr(cam_t), _C.ptr(cam_c), _C.ptr(j2d), _C.ptr(conf), _C.ptr(pose),
             _C.ptr(means), _C.ptr(precisions), _C.ptr(log_weights), b, nj,
             means.shape[0] if means is not None else 0, float(focal), float(sigma), float(prior_scale),
             _C.ptr(out), _C.ptr(gj), _C.ptr(gc), _C.ptr(gp), _C.stream()))
@@ -248,8 +250,8 @@ class _Objective(torch.autograd.Function):
         b = small.shape[0]
         p = r2r.shape[1] if r2r is not None else 0
         out = torch.empty(1, dtype=torch.float32, device=small.device)
-        _C.check(_C.lib().tuch_smplify_objective(_C.ptr(small), _C.ptr(terms),
-                                                 _C.ptr(r2r.contiguous() if p else None), b, p,
+        r2r_c = r2r.contiguous() if p else None
+        _C.check(_C.lib().tuch_smplify_objective(_C.ptr(small), _C.ptr(terms), _C.ptr(r2r_c), b, p,
                                                  float(contact_scale), float(r2r_scale), _C.ptr(out), _C.stream()))
         ctx.shape = (b, p, float(contact_scale), float(r2r_scale))
         return out[0]
@@ -288,6 +290,29 @@ def cached_derived(key_tensors, build):
 
 
 # ------------------------------------------------------------------------- model
+def region_tables(cdict):
+    """{'classes': [(regA, regB), ...], 'csig': {region: vertex ids}} (train_module.py:64-66) ->
+    (ordered vertex-id lists, pairs [P,2] of indices into that order).  Region keys are looked up as the
+    reference does (``csig[regpair[0]]``), whatever their type; numpy string scalars match their str()."""
+    csig = cdict['csig']
+    names = list(csig.keys())
+    index = {n: i for i, n in enumerate(names)}
+
+    def find(key):
+        for k in (key, str(key)):
+            try:
+                if k in index:
+                    return index[k]
+            except TypeError:
+                pass
+        if hasattr(key, 'item'):
+            return find(key.item())
+        raise KeyError('region %r of cdict[\'classes\'] is not a key of cdict[\'csig\']' % (key,))
+    regions = [np.asarray(csig[n], dtype=np.int64) for n in names]
+    pairs = np.asarray([[find(p[0]), find(p[1])] for p in cdict['classes']], np.int64).reshape(-1, 2)
+    return regions, pairs
+
+
 def _i32(a) -> np.ndarray:
     return np.ascontiguousarray(np.asarray(a), dtype=np.int32)
 
@@ -384,26 +409,45 @@ class ContactModel:
             seg_f=_i32(cat(seg_f).reshape(-1, 3)), cap_off=_i32(cap_off), cap_v=_i32(cat(cap_v)),
             reg_off=_i32(reg_off), reg_v=_i32(cat([np.asarray(r) for r in regions])),
             pairs=_i32(pairs if pairs is not None else np.zeros((0, 2))))
-        p = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a.size else ctypes.c_void_p(0)
-        handle = ctypes.c_void_p(0)
-        with torch.cuda.device(self.device):
-            _C.check(_C.lib().tuch_contact_model_create(
-                ctypes.byref(handle), v, self.num_faces, p(keep['faces']),
-                gm.ctypes.data_as(ctypes.c_void_p) if gm is not None else ctypes.c_void_p(0),
-                self.num_segments, p(keep['seg_q_off']), p(keep['seg_q']), p(keep['seg_f_off']), p(keep['seg_f']),
-                len(cap_off) - 1, p(keep['cap_off']), p(keep['cap_v']),
-                len(regions), p(keep['reg_off']), p(keep['reg_v']), self.num_pairs, p(keep['pairs'])))
-        self._handle = handle
-        self.faces_i32 = torch.as_tensor(keep['faces'], device=self.device)
+        # the device copy (tuch_contact_model_create: the library's only allocations) is made on first use, so
+        # that the callers' constructors (RegressorLoss, SMPLifyDC, ...) also run where no GPU is visible
+        self._host = (keep, gm, len(cap_off) - 1, len(regions))
+        self._h = None
+        self._faces_i32 = None
+
+    @property
+    def _handle(self):
+        if self._h is None:
+            keep, gm, num_caps, num_regions = self._host
+            if self.device.type != 'cuda':
+                raise _C.TuchError('tuch_amd kernels need a HIP device, the model was created for %s' % self.device)
+            p = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a.size else ctypes.c_void_p(0)
+            handle = ctypes.c_void_p(0)
+            with torch.cuda.device(self.device):
+                _C.check(_C.lib().tuch_contact_model_create(
+                    ctypes.byref(handle), self.num_verts, self.num_faces, p(keep['faces']),
+                    gm.ctypes.data_as(ctypes.c_void_p) if gm is not None else ctypes.c_void_p(0),
+                    self.num_segments, p(keep['seg_q_off']), p(keep['seg_q']), p(keep['seg_f_off']), p(keep['seg_f']),
+                    num_caps, p(keep['cap_off']), p(keep['cap_v']),
+                    num_regions, p(keep['reg_off']), p(keep['reg_v']), self.num_pairs, p(keep['pairs'])))
+            self._h = handle
+            self._host = None          # the 47 MB byte mask is not needed again
+        return self._h
+
+    @property
+    def faces_i32(self):
+        if self._faces_i32 is None:
+            self._faces_i32 = torch.as_tensor(_i32(self.faces_np), device=self.device)
+        return self._faces_i32
 
     def __del__(self):
-        h = getattr(self, '_handle', None)
+        h = getattr(self, '_h', None)
         if h:
             try:
                 _C.lib().tuch_contact_model_destroy(h)
             except Exception:
                 pass
-            self._handle = None
+            self._h = None
 
     def strips(self):
         """(vertex ids, signs, number of strips) of the triangle-strip walk used by the winding kernel."""
@@ -537,7 +581,8 @@ class ContactModel:
             raise _C.TuchError('ContactModel has no mask in tree order (no cluster tree)')
         nbytes = L.tuch_v2v_min_indexed_workspace_bytes(offsets.shape[0] - 1, int(max_points))
         ws = _workspace(nbytes, pts.device)
-        _C.check(L.tuch_v2v_min_indexed(_C.ptr(pts), _C.ptr(vertex_ids.contiguous()), _C.ptr(offsets.contiguous()),
+        vertex_ids, offsets = vertex_ids.contiguous(), offsets.contiguous()
+        _C.check(L.tuch_v2v_min_indexed(_C.ptr(pts), _C.ptr(vertex_ids), _C.ptr(offsets),
                                         ctypes.c_void_p(bits), offsets.shape[0] - 1, self.num_verts, int(max_points),
                                         _C.ptr(mn), _C.ptr(arg), _C.ptr(ws), nbytes, _C.stream()))
         return mn, arg
@@ -576,7 +621,7 @@ class _RegionPairMin(torch.autograd.Function):
     def backward(ctx, grad_out, _grad_ij):
         v, ij = ctx.saved_tensors
         grad = torch.zeros_like(v)
+        g_out = grad_out.to(torch.float32).contiguous()
         _C.check(_C.lib().tuch_region_pair_min_bwd(ctx.model._handle, _C.ptr(v), v.shape[0], _C.ptr(ij),
-                                                   _C.ptr(grad_out.to(torch.float32).contiguous()),
-                                                   _C.ptr(grad), _C.stream()))
+                                                   _C.ptr(g_out), _C.ptr(grad), _C.stream()))
         return grad, None, None, None

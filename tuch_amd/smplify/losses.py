@@ -35,11 +35,10 @@ def contact_model_for(geomask, face_tensor, segments=None, cdict=None, device=No
     if model is None:
         seg_tables = segments.tables() if segments is not None else None
         regions = pairs = None
-        if cdict is not None and len(cdict.get('classes', [])) > 0:
-            names = list(cdict['csig'].keys())
-            index = {n: i for i, n in enumerate(names)}
-            regions = [np.asarray(cdict['csig'][n], dtype=np.int64) for n in names]
-            pairs = np.asarray([[index[str(p[0])], index[str(p[1])]] for p in cdict['classes']], np.int64)
+        # SMPLifyDC.__call__ defaults contactlist=[] (smplifydc.py:70): anything that is not a dict with
+        # region pairs means "no region term" (the reference only reads cdict for annotated bodies)
+        if isinstance(cdict, dict) and len(cdict.get('classes', [])) > 0:
+            regions, pairs = ops.region_tables(cdict)
         model = ops.ContactModel(faces, geomask, seg_tables, regions, pairs,
                                  device=device if device is not None else faces.device)
         # keep the keyed objects alive with the entry: a freed tensor's address / a dead object's id can
@@ -90,7 +89,9 @@ def contact_fitting_loss(body_pose, global_orient, body_pose_loop1, opt_global_o
             lambda: ((gt_contact[0] == 1) & has_discrete_contact.bool()[:, None]
                      & (~ignore_idxs)[:, None]).to(torch.uint8).contiguous())
     fused = (isinstance(pose_prior, MaxMixturePrior) and pose_prior.use_merged and verts.is_cuda
-             and not torch.is_tensor(focal_length) and body_pose.shape[1] == 69)
+             and not torch.is_tensor(focal_length) and body_pose.shape[1] == 69
+             and pose_prior.means.dtype == torch.float32 and pose_prior.means.is_cuda
+             and model_joints.dtype == torch.float32 and body_pose.dtype == torch.float32)
 
     def beside_the_walk():
         """Everything that does not need the inside test: region pairs (losses.py:107-117) and, fused into one

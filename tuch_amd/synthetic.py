@@ -488,3 +488,99 @@ def random_poses(batch: int, seed: int, penetrating_fraction: float = 0.5):
         body_pose[b, 3 * 0 + 2] += 0.35 * amt      # L hip about z: legs together
         body_pose[b, 3 * 1 + 2] -= 0.35 * amt
     return (body_pose.astype(np.float32), global_orient.astype(np.float32), betas.astype(np.float32))
+
+
+# ------------------------------------------------------------------ asset files in the reference's formats
+def _write_ply_vertex_colours(path: str, verts: np.ndarray, red: np.ndarray, binary: bool = True) -> None:
+    import struct
+    header = ['ply', 'format %s 1.0' % ('binary_little_endian' if binary else 'ascii'),
+              'element vertex %d' % len(verts), 'property float x', 'property float y', 'property float z',
+              'property uchar red', 'property uchar green', 'property uchar blue', 'property uchar alpha',
+              'element face 0', 'property list uchar int vertex_indices', 'end_header']
+    with open(path, 'wb') as f:
+        f.write(('\n'.join(header) + '\n').encode())
+        for v, r in zip(verts, red):
+            if binary:
+                f.write(struct.pack('<fffBBBB', v[0], v[1], v[2], int(r), 0, 0, 255))
+            else:
+                f.write(('%f %f %f %d 0 0 255\n' % (v[0], v[1], v[2], int(r))).encode())
+
+
+def write_reference_assets(body: SyntheticBody, root: str, with_extra_vertex_ids: Optional[bool] = None) -> Dict[str, str]:
+    """Write ``body`` as the files the reference loads, under ``root`` with the reference's relative paths
+    (configs/config.py:74-92), plus a ``configs/config.py`` and the two python modules of the data folder
+    (``data/essentials/constants.py``, ``data/essentials/segments/smpl/segm_utils.py``).  With ``root`` as
+    the working directory and on sys.path, the reference's scripts' constructor calls (train.py:57-100,
+    demo_smplify_dc.py:54-87) run against synthetic data.
+
+    The SMPL pickle has the official key names and layouts (posedirs [V,3,207], sparse J_regressor,
+    kintree_table [2,24], f).  A mesh that does not have the 6890-vertex SMPL topology carries the extra key
+    ``extra_vertex_ids`` (the 21 picked vertices smplx takes from its own table), see models/smpl.py.
+    Returns the written paths by config name."""
+    import os
+    import pickle
+    from .models.smpl import SPIN_JOINT_NAMES
+    if with_extra_vertex_ids is None:
+        with_extra_vertex_ids = body.num_verts != 6890
+    j = lambda *p: os.path.join(root, *p)
+    paths = {'SMPL_MODEL_DIR': 'data/models/smpl', 'JOINT_REGRESSOR_TRAIN_EXTRA': 'data/essentials/spin/J_regressor_extra.npy',
+             'PRIOR_FOLDER': 'data/essentials/spin', 'GEODESICS_SMPL': 'data/essentials/geodesics/smpl/smpl_neutral_geodesic_dist.npy',
+             'HD_MODEL_DIR': 'data/essentials/hd_model/smpl', 'SEGMENT_DIR': 'data/essentials/segments/smpl',
+             'STATIC_FITS_DIR': 'data/static_fits', 'DSC_ROOT': 'data/dsc'}
+    for d in ('SMPL_MODEL_DIR', 'PRIOR_FOLDER', 'HD_MODEL_DIR', 'SEGMENT_DIR', 'STATIC_FITS_DIR', 'DSC_ROOT'):
+        os.makedirs(j(paths[d]), exist_ok=True)
+    os.makedirs(j(os.path.dirname(paths['GEODESICS_SMPL'])), exist_ok=True)
+    os.makedirs(j('configs'), exist_ok=True)
+    # SMPL model, official layout
+    v = body.num_verts
+    kintree = np.stack([np.where(body.parents < 0, 2 ** 32 - 1, body.parents), np.arange(24)]).astype(np.int64)
+    model = {'v_template': body.v_template.astype(np.float64), 'shapedirs': body.shapedirs.astype(np.float64),
+             'posedirs': body.posedirs.reshape(207, v, 3).transpose(1, 2, 0).astype(np.float64),
+             'J_regressor': sp.csc_matrix(body.J_regressor.astype(np.float64)), 'weights': body.lbs_weights.astype(np.float64),
+             'kintree_table': kintree, 'f': body.faces.astype(np.uint32)}
+    if with_extra_vertex_ids:
+        model['extra_vertex_ids'] = body.extra_vertex_ids
+    with open(j(paths['SMPL_MODEL_DIR'], 'SMPL_NEUTRAL.pkl'), 'wb') as f:
+        pickle.dump(model, f, protocol=2)
+    np.save(j(paths['JOINT_REGRESSOR_TRAIN_EXTRA']), body.J_regressor_extra)
+    with open(j(paths['PRIOR_FOLDER'], 'gmm_08.pkl'), 'wb') as f:
+        pickle.dump({k: np.asarray(val, np.float64) for k, val in body.gmm.items()}, f, protocol=2)
+    if body.geodesics is not None:
+        np.save(j(paths['GEODESICS_SMPL']), body.geodesics)
+    # HD regressor: the reference stores it dense [N_hd, V] float (1.1 GB at SMPL size)
+    np.save(j(paths['HD_MODEL_DIR'], 'smpl_neutral_hd_vert_regressor.npy'), dense_hd_regressor(body))
+    with open(j(paths['HD_MODEL_DIR'], 'smpl_neutral_hd_sample_from_mesh_out.pkl'), 'wb') as f:
+        pickle.dump({'faces_vert_is_sampled_from': body.hd_face_id}, f, protocol=2)
+    # segments: painted .ply + segm_utils.py
+    for i, (name, seg) in enumerate(body.segments.items()):
+        red = np.zeros(v, np.int64)
+        red[seg['vidx']] = 255
+        _write_ply_vertex_colours(j(paths['SEGMENT_DIR'], 'smpl_segment_%s.ply' % name), body.v_template, red, binary=bool(i % 2))
+    with open(j(paths['SEGMENT_DIR'], 'segm_utils.py'), 'w') as f:
+        f.write('# synthetic stand-in for the licensed segm_utils.py: ordered boundary loops per segment\nsegments = {\n')
+        for name, seg in body.segments.items():
+            f.write('    %r: {\n' % name)
+            for band, loop in seg['bands'].items():
+                f.write('        %r: %r,\n' % (band, [int(x) for x in loop]))
+            f.write('    },\n')
+        f.write('}\n')
+    # DSC region tables
+    with open(j(paths['DSC_ROOT'], 'classes.pkl'), 'wb') as f:
+        pickle.dump(np.asarray(body.region_pairs), f, protocol=2)
+    with open(j(paths['DSC_ROOT'], 'ContactSigSMPL.pkl'), 'wb') as f:
+        pickle.dump({k: [int(x) for x in val] for k, val in body.regions.items()}, f, protocol=2)
+    # constants.py: SPIN's joint names, the joint map of THIS body, flip permutation
+    flip = [0, 2, 1, 3, 5, 4, 6, 8, 7, 9, 11, 10, 12, 14, 13, 15, 17, 16, 19, 18, 21, 20, 23, 22]
+    with open(j('data/essentials/constants.py'), 'w') as f:
+        f.write('# synthetic stand-in for the licensed constants.py\nFOCAL_LENGTH = 5000.\nIMG_RES = 224\n')
+        f.write('JOINT_NAMES = %r\n' % (list(SPIN_JOINT_NAMES),))
+        f.write('JOINT_IDS = {JOINT_NAMES[i]: i for i in range(len(JOINT_NAMES))}\n')
+        f.write('JOINT_MAP = %r\n' % ({n: int(body.joint_map[i]) for i, n in enumerate(SPIN_JOINT_NAMES)},))
+        f.write('SMPL_JOINTS_FLIP_PERM = %r\n' % (flip,))
+        f.write('SMPL_POSE_FLIP_PERM = [3 * i + k for i in SMPL_JOINTS_FLIP_PERM for k in range(3)]\n')
+    with open(j('configs/config.py'), 'w') as f:
+        f.write('# synthetic stand-in for configs/config.py of the reference (same names)\n')
+        for k, val in paths.items():
+            f.write('%s = %r\n' % (k, val))
+        f.write('geothres = 0.3\neuclthres = 0.02\n')
+    return paths

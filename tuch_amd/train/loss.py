@@ -2,16 +2,19 @@
 contact loss on the HIP kernels; the SPIN terms (keypoints, shape, pose/betas regression,
 camera) are small torch reductions as in the reference.
 
-Constructor differences, all optional keyword arguments (the licensed assets do not ship):
-``segments`` (a BatchBodySegment), ``hd_regressor`` = (idx [N,3], weights [N,3]) -- the three
-non-zeros of every row of smpl_neutral_hd_vert_regressor.npy -- and ``hd_faces`` =
-faces_vert_is_sampled_from.  With the asset files present they are loaded like the reference
-does (loss.py:81-91).
+The reference's constructor call works verbatim (train.py:79-87):
+
+    RegressorLoss(options=..., device=..., num_verts=..., faces=face_tensor, geodistssmpl=...,
+                  geothres=config.geothres, face_tensor=face_tensor)
+
+and then loads what the reference loads: the HD regressor files from config.HD_MODEL_DIR
+(loss.py:81-88) and the body segments from config.SEGMENT_DIR + segm_utils (loss.py:91).  A missing
+asset raises -- the segment filter is never skipped silently.  Because the licensed assets do not
+ship, the same data may be injected instead: ``segments`` (a BatchBodySegment), ``hd_regressor`` =
+(idx [N,3], weights [N,3]) -- the three non-zeros of every row of smpl_neutral_hd_vert_regressor.npy
+-- and ``hd_faces`` = faces_vert_is_sampled_from.
 """
 from __future__ import annotations
-
-import os.path as osp
-import pickle
 
 import numpy as np
 import torch
@@ -30,7 +33,7 @@ def batch_face_normals(triangles):
 class RegressorLoss(nn.Module):
     def __init__(self, options, device, num_verts, faces, geodistssmpl, geothres=0.2, euclthres=0.02,
                  face_tensor=None, use_hd=True, segments=None, hd_regressor=None, hd_faces=None,
-                 hd_model_dir='data/essentials/hd_model/smpl'):
+                 hd_model_dir=None):
         super().__init__()
         self.device = device
         self.options = options
@@ -46,12 +49,10 @@ class RegressorLoss(nn.Module):
         self.face_tensor = face_tensor
         self.use_hd = use_hd
         if use_hd:
-            if hd_regressor is None:
-                dense = np.load(osp.join(hd_model_dir, 'smpl_neutral_hd_vert_regressor.npy'))
-                idx = np.argsort(-np.abs(dense), axis=1)[:, :3]
-                hd_regressor = (idx, np.take_along_axis(dense, idx, 1))
-                with open(osp.join(hd_model_dir, 'smpl_neutral_hd_sample_from_mesh_out.pkl'), 'rb') as f:
-                    hd_faces = pickle.load(f)['faces_vert_is_sampled_from']
+            if hd_regressor is None:                                          # loss.py:81-87
+                from ..assets import load_hd_regressor
+                hd_i, hd_wt, hd_faces = load_hd_regressor(hd_model_dir)
+                hd_regressor = (hd_i, hd_wt)
             dev = face_tensor.device
             hd_i, hd_wt, hd_f = np.asarray(hd_regressor[0]), np.asarray(hd_regressor[1]), np.asarray(hd_faces)
             # The HD points are a set (the loss sums over them): keep them sorted by the surface patch their
@@ -68,9 +69,11 @@ class RegressorLoss(nn.Module):
             self.hd_idx32 = self.hd_idx.to(torch.int32).contiguous()
             self.geovec = torch.as_tensor(hd_f, dtype=torch.long, device=dev)
             self.geovec_verts = self.face_tensor[0][self.geovec][:, 0]            # loss.py:88
+        if segments is None:                                                  # loss.py:91: always built
+            from ..utils.segmentation import BatchBodySegment, reference_segment_names
+            segments = BatchBodySegment(reference_segment_names(), self.face_tensor[0])
         self.segments = segments
-        seg_tables = segments.tables() if segments is not None else None
-        self._model = ops.ContactModel(face_tensor[0], self.geomask, seg_tables, device=face_tensor.device)
+        self._model = ops.ContactModel(face_tensor[0], self.geomask, segments.tables(), device=face_tensor.device)
         if use_hd:
             # template vertex of every HD point as its position in the tree's vertex order (mask lookups of
             # neighbouring points then fall into the same few 64-vertex words)
@@ -88,8 +91,7 @@ class RegressorLoss(nn.Module):
         model = self._model
         valid = valid_fit.bool()
         valid_u8 = valid.to(torch.uint8).contiguous()
-        exterior, min_d2, partner, _ = model.exterior_and_partner(pred_vertices,
-                                                                  apply_segments=self.segments is not None)
+        exterior, min_d2, partner, _ = model.exterior_and_partner(pred_vertices, apply_segments=True)   # :264-266
         n_valid = valid.sum().to(torch.float32)
         if not self.use_hd:
             per_body, _ = ops.contact_terms(pred_vertices, partner, exterior, valid_u8, ops.MODE_TRAIN,

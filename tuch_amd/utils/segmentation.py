@@ -3,8 +3,13 @@ sub-meshes that whitelist self-intersection inside one segment (skin folds at jo
 
 The reference reads each segment's vertex set from a painted .ply through trimesh
 (segmentation.py:40-42) and its boundary loops from data.essentials.segments.smpl.segm_utils
-(:45-46).  Neither asset ships, so the constructors here take the same information as plain
-arrays; ``BodySegment.from_reference_assets`` loads the original files when they exist.
+(:45-46).  The reference's constructor calls work verbatim --
+
+    BatchBodySegment([x for x in exn.segments.keys()], face_tensor[0])      # demo_smplify_dc.py:87, loss.py:91
+
+-- and load exactly those files (config.SEGMENT_DIR; the .ply is parsed here, no trimesh needed).
+Neither asset ships, so the same information may also be passed as plain arrays
+(``segment_vidx=`` / ``bands=``, ``segments=``).  Missing assets raise; nothing is skipped silently.
 """
 from __future__ import annotations
 
@@ -18,6 +23,12 @@ import torch.nn as nn
 from .. import ops
 
 
+def reference_segment_names() -> List[str]:
+    """``[x for x in exn.segments.keys()]`` (loss.py:91, demo_smplify_dc.py:87)."""
+    from ..assets import reference_segm_utils
+    return list(reference_segm_utils().segments.keys())
+
+
 class BodySegment(nn.Module):
     """One named segment.  Attributes match the reference: ``name``, ``segment_vidx``,
     ``bands``, ``bands_verts``, ``bands_faces``, ``segment_faces``, ``append_idx``."""
@@ -28,8 +39,13 @@ class BodySegment(nn.Module):
         self.device = faces.device
         self.name = name
         self.append_idx = int(faces.max().item()) if append_idx is None else append_idx
-        if segment_vidx is None or bands is None:
-            raise ValueError('BodySegment needs segment_vidx and bands (or use from_reference_assets)')
+        if segment_vidx is None:               # segmentation.py:40-42
+            from ..assets import config_path, read_ply_vertex_red
+            red = read_ply_vertex_red(os.path.join(config_path('SEGMENT_DIR'), 'smpl_segment_{}.ply'.format(name)))
+            segment_vidx = np.where(red == 255)[0]
+        if bands is None:                      # segmentation.py:45-46
+            from ..assets import reference_segm_utils
+            bands = reference_segm_utils().segments[name]
         self.segment_vidx = np.asarray(segment_vidx, dtype=np.int64)
         self.bands = list(bands.keys())
         self.bands_verts = [np.asarray(v, dtype=np.int64) for v in bands.values()]
@@ -64,14 +80,15 @@ class BatchBodySegment(nn.Module):
 
     def __init__(self, names, faces, segments: Optional[Dict[str, dict]] = None):
         super().__init__()
-        if segments is None:
-            raise ValueError('BatchBodySegment needs the segment tables (vidx + bands per name)')
         self.names = list(names)
         self.nv = int(faces.max().item())
         self.segmentation = {}
         for name in self.names:
-            self.segmentation[name] = BodySegment(name, faces, None, segments[name]['vidx'],
-                                                  segments[name]['bands'])
+            if segments is None:               # the reference's call: everything from the asset files
+                self.segmentation[name] = BodySegment(name, faces)
+            else:
+                self.segmentation[name] = BodySegment(name, faces, None, segments[name]['vidx'],
+                                                      segments[name]['bands'])
 
     def tables(self):
         """(vidx, [band loops]) per segment, the form ops.ContactModel consumes."""
