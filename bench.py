@@ -6,19 +6,26 @@ over one batch: SMPL forward -> contact_fitting_loss (reprojection + GMM prior +
 push/pull terms with winding-number inside test and segment filter + region-to-region term)
 -> backward -> Adam step, on SMPL-sized synthetic bodies (V=6890, F=13776).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          # N > 1: spawns N ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-The batch dimension shards across ranks (64 bodies per GPU, weak scaling); the only
-collective is a 2-float all-reduce of [sum of losses, body count] per step (RCCL).
-Rank 0 prints ONE JSON line (contract in the task description) including
+The batch dimension shards across ranks (weak scaling: 64 bodies per GPU; --global-batch G: strong
+scaling, G/N bodies per GPU); the only collective is a 2-float all-reduce of [sum of losses, body
+count] per step (RCCL).  Rank 0 prints ONE JSON line (contract in the task description) including
   roofline     -- dominant kernel (winding numbers), achieved FLOP/s measured here with HIP events
   roofline_v2v -- the vertex-distance kernel, physical and reference-layout-equivalent figures
   cpu_baseline -- the CPU oracle (test infrastructure) timed on this box's host cores, rank 0, N=1
+  repeat_ms_per_step -- the same K-step block timed --repeats times (median / min / max)
+  shard_sweep  -- the step at 8/16/32/64 bodies on one GPU (the per-GPU shards of a global batch of 64)
+  workloads    -- the per-rank workloads of BASELINE configs 3, 4 and 5
+  worst_case   -- every body self-penetrating
+--config {2,3,4-shard,5-shard} makes one of those workloads the timed step instead (its own metric name).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,43 +43,86 @@ FLOP_PER_V2V_PAIR = 8
 FLOP_PER_STRIP_ELEMENT = 41
 PEAK_FP32_VECTOR_TFLOPS = 157.3   # MI355X_MICROARCH.md (packed FP32 FMA rate)
 PEAK_HBM_GBS = 8000.0
-# HBM-side bytes per launch of winding_tree_kernel at batch 64 from the PMC passes committed under
-# profiles/r01_k_pmc_{fetch,write}.txt (FETCH_SIZE 67907 KB + WRITE_SIZE 24844 KB).  The kernel's own layout moves
-# 69.5 MB of posed stream (33 948 elements x 32 B x 64 bodies, fetched once: one body per XCD at a time) + 2.2 MB of
-# node slabs in and 28 MB of partial sums out.
-WINDING_TRAFFIC_BYTES = int((67906.9 + 24843.7) * 1024)
+# HBM-side bytes per launch of the winding walk at batch 64 and its VALU-busy fraction: PMC passes committed under
+# profiles/ (see profiles/README.md); constants from those files, NOT measured in this run.
+PROFILE = {
+    'traffic_bytes': int((67906.9 + 24843.7) * 1024),
+    'traffic_source': 'profiles/r01_k_pmc_fetch.txt + r01_k_pmc_write.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
+                      'separate passes, KB x 1024), batch 64; from profiles/, not measured in this run',
+    'valu_busy': None,
+    'valu_busy_source': None,
+}
+_BODY = {}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='bodies per GPU')
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='bodies per GPU (weak scaling)')
+    ap.add_argument('--global-batch', type=int, default=None,
+                    help='strong scaling: total bodies, split evenly over the GPUs')
+    ap.add_argument('--repeats', type=int, default=5, help='how many times the K-step block is timed')
+    ap.add_argument('--config', default='2', choices=['2', '3', '4-shard', '5-shard'],
+                    help='which BASELINE config is the timed step (default 2 = the headline)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager', action='store_true', help='launch every step eagerly instead of replaying a hipGraph')
-    ap.add_argument('--graph', action='store_true', help='replay a hipGraph also when several ranks run')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-torch-chain', action='store_true',
                     help='skip the torch-CPU op-chain baseline (one body, ~8 GB of host memory, ~30 s)')
-    return ap.parse_args()
+    ap.add_argument('--no-extras', action='store_true', help='skip shard sweep, workloads, worst case, contact-loss eval')
+    return ap.parse_args(argv)
 
 
-def build_problem(batch, device, seed):
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args):
+    """--gpus N without a launcher: re-exec under torch.distributed.run, one rank per GPU of this node."""
+    backend = os.environ.get('TUCH_BENCH_BACKEND', 'nccl')
+    if backend == 'nccl' and torch.cuda.device_count() < args.gpus:
+        raise SystemExit('bench.py --gpus %d: only %d GPU(s) visible (RCCL needs one device per rank)'
+                         % (args.gpus, torch.cuda.device_count()))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.call(cmd, env=env)
+
+
+def synthetic_body():
+    from tuch_amd.synthetic import make_body
+    if 'body' not in _BODY:
+        _BODY['body'] = make_body(84, 82, seed=1234)
+    return _BODY['body']
+
+
+def build_problem(batch, device, seed, penetrating_fraction=0.5):
     from tuch_amd.models.smpl import SMPL
     from tuch_amd.smplify.prior import MaxMixturePrior
-    from tuch_amd.synthetic import make_body, random_poses
+    from tuch_amd.synthetic import random_poses
     from tuch_amd.utils.geometry import perspective_projection
     from tuch_amd.utils.segmentation import BatchBodySegment
-    body = make_body(84, 82, seed=1234)
-    smpl = SMPL(model_data=body, batch_size=batch).to(device)
-    prior = MaxMixturePrior(num_gaussians=8, gmm=body.gmm).to(device)
-    face_tensor = torch.tensor(body.faces, dtype=torch.long, device=device)[None].repeat(batch, 1, 1)
-    geomask = torch.tensor(body.geodesics > 0.3, device=device)
-    segments = BatchBodySegment(list(body.segments.keys()), face_tensor[0], body.segments)
-    cdict = {'classes': [list(p) for p in body.region_pairs], 'csig': dict(body.regions)}
+    body = synthetic_body()
+    key = ('shared', str(device))
+    if key not in _BODY:       # model constants are shared by every problem built on this device
+        smpl = SMPL(model_data=body, batch_size=batch).to(device)
+        prior = MaxMixturePrior(num_gaussians=8, gmm=body.gmm).to(device)
+        face_row = torch.tensor(body.faces, dtype=torch.long, device=device)
+        geomask = torch.tensor(body.geodesics > 0.3, device=device)
+        segments = BatchBodySegment(list(body.segments.keys()), face_row, body.segments)
+        cdict = {'classes': [list(p) for p in body.region_pairs], 'csig': dict(body.regions)}
+        _BODY[key] = (smpl, prior, face_row, geomask, segments, cdict)
+    smpl, prior, face_row, geomask, segments, cdict = _BODY[key]
+    face_tensor = face_row[None].expand(batch, -1, -1)
     rng = np.random.Generator(np.random.PCG64(seed))
-    bp, go, be = random_poses(batch, seed)
+    bp, go, be = random_poses(batch, seed, penetrating_fraction)
     t = lambda a: torch.tensor(a, device=device)
     body_pose, global_orient, betas = t(bp), t(go), t(be)
     cam_t = torch.tensor([[0.0, 0.0, 20.0]], device=device).repeat(batch, 1)
@@ -93,8 +143,8 @@ def build_problem(batch, device, seed):
                 has_dc=torch.ones(batch, dtype=torch.bool, device=device))
 
 
-def make_step(p, world):
-    """The stage-2 loop body of SMPLifyDC.__call__ (smplifydc.py:155-183)."""
+def make_step(p):
+    """The stage-2 loop body of SMPLifyDC.__call__ (smplifydc.py:155-183); returns [loss sum, bodies]."""
     from tuch_amd.smplify.losses import contact_fitting_loss
     body_pose = p['body_pose'].clone().requires_grad_(True)
     global_orient = p['global_orient'].clone().requires_grad_(True)
@@ -119,17 +169,72 @@ def make_step(p, world):
         opt.step()
         stats[0].copy_(loss.detach())
         return stats
+    return step
 
-    def reduce(local):
-        if world > 1:
-            if torch.distributed.get_backend() == 'gloo':   # single-GPU smoke test of the N>1 path only
-                host = local.cpu()
-                torch.distributed.all_reduce(host)
-                return host.to(local.device)
-            local = local.clone()
-            torch.distributed.all_reduce(local)          # 2 floats over RCCL / xGMI
-        return local
-    return step, reduce
+
+def make_fit(p, iters):
+    """BASELINE configs[2]: one demo_smplify_dc.py-style fit = `iters` stage-1 + `iters` stage-2 iterations."""
+    from tuch_amd.smplify.smplifydc import SMPLifyDC
+    batch = p['body_pose'].shape[0]
+    dev = p['body_pose'].device
+    fitter = SMPLifyDC(step_size=1e-2, batch_size=batch, num_iters=iters, focal_length=5000.,
+                       geodistssmpl=torch.tensor(p['body'].geodesics, device=dev), geothres=0.3, euclthres=0.02,
+                       device=dev, smpl=p['smpl'], pose_prior=p['prior'])
+    kp = torch.cat([p['j2d'], p['conf'][..., None]], 2)
+    init_pose = torch.cat([p['global_orient'], p['body_pose']], 1)
+    stats = torch.zeros(2, device=dev)
+    stats[1] = float(batch)
+
+    def fit():
+        res = fitter(init_pose, p['betas'], p['cam_t'], p['cam_c'], kp, use_contact=True, contactlist=p['cdict'],
+                     gt_contact=[p['gt'], None], ignore_idxs=p['ignore'], has_discrete_contact=p['has_dc'],
+                     contact_loss_weight=2000.0, segments=p['segments'])
+        stats[0] = res[5].sum()
+        return stats
+    return fit, fitter
+
+
+def regressor_loss(p, use_hd):
+    import types
+    from tuch_amd.train.loss import RegressorLoss
+    body = p['body']
+    dev = p['body_pose'].device
+    key = ('crit', str(dev), use_hd)
+    if key not in _BODY:
+        _BODY[key] = RegressorLoss(types.SimpleNamespace(contact_loss_weight=1.0), dev, body.num_verts, p['face_tensor'],
+                                   torch.tensor(body.geodesics, device=dev), geothres=0.3, euclthres=0.02,
+                                   face_tensor=p['face_tensor'], use_hd=use_hd, segments=p['segments'],
+                                   hd_regressor=(body.hd_bary_idx, body.hd_bary_w), hd_faces=body.hd_face_id)
+    return _BODY[key]
+
+
+def make_train_step(p, use_hd, smplify_iters=0):
+    """BASELINE configs[3] / [4] per-rank step, the regressor's output replaced by synthetic rotation matrices
+    (train_module.py:202-204, 239-255, 302-317): [SMPLify-DC in the loop for `smplify_iters` + `smplify_iters`
+    iterations ->] SMPL forward with pose2rot=False -> RegressorLoss.contact_loss (mean over the valid bodies of
+    ALL ranks) -> backward to the rotation matrices and betas."""
+    from tuch_amd.utils.geometry import batch_rodrigues
+    batch = p['body_pose'].shape[0]
+    dev = p['body_pose'].device
+    crit = regressor_loss(p, use_hd)
+    full_pose = torch.cat([p['global_orient'], p['body_pose']], dim=1).detach()
+    rotmat = batch_rodrigues(full_pose.reshape(-1, 3)).view(batch, 24, 3, 3).detach().requires_grad_(True)
+    betas = p['betas'].detach().clone().requires_grad_(True)
+    valid = torch.ones(batch, dtype=torch.bool, device=dev)
+    fit = make_fit(p, smplify_iters)[0] if smplify_iters else None
+    stats = torch.zeros(2, device=dev)
+    stats[1] = float(batch)
+
+    def step():
+        if fit is not None:
+            fit()
+        rotmat.grad = betas.grad = None
+        o = p['smpl'](betas=betas, body_pose=rotmat[:, 1:], global_orient=rotmat[:, :1], pose2rot=False)
+        loss = crit.contact_loss(o.vertices, valid)
+        loss.backward()
+        stats[0] = loss.detach() * batch
+        return stats
+    return step
 
 
 def capture(step, warmup):
@@ -142,8 +247,6 @@ def capture(step, warmup):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    # thread_local: with a process group alive the RCCL watchdog thread queries events; that must not
-    # invalidate this thread's capture
     with torch.cuda.graph(graph, capture_error_mode='thread_local'):
         out = step()
 
@@ -179,7 +282,7 @@ def rooflines(p, batch):
     model = contact_model_for(p['geomask'], p['face_tensor'], p['segments'], p['cdict'])
     with torch.no_grad():
         verts = p['smpl'](global_orient=p['global_orient'], body_pose=p['body_pose'], betas=p['betas']).vertices
-    # the launch below = gather_stream (~20 us) + node boxes (~18 us) + winding_tree_kernel + finalize (~7 us)
+    # the launch below = posed stream + node slabs + winding_tree_kernel + finalize
     t_w = time_kernel(lambda: model.exterior_flags(verts, apply_segments=False), 10)
     work = model.winding_tree_work(verts)
     steps = work['leaf_elements'] + work['cap_elements']          # wavefront element steps, 64 queries each
@@ -188,9 +291,9 @@ def rooflines(p, batch):
     ref_flops = FLOP_PER_WINDING_PAIR * batch * v * f
     roof = {'kernel': 'winding_tree_kernel', 'bound': 'valu', 'achieved': round(ach, 2),
             'peak': PEAK_FP32_VECTOR_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_VECTOR_TFLOPS, 4),
-            'traffic': WINDING_TRAFFIC_BYTES if batch == BATCH_PER_GPU else None,
-            'traffic_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, KB x 1024 '
-                              '(profiles/r01_k_pmc_fetch.txt, r01_k_pmc_write.txt); scalar loads: counter uncalibrated',
+            'traffic': PROFILE['traffic_bytes'] if batch == BATCH_PER_GPU else None,
+            'traffic_source': PROFILE['traffic_source'],
+            'valu_busy': PROFILE['valu_busy'], 'valu_busy_source': PROFILE['valu_busy_source'],
             'launch_ms': round(t_w * 1e3, 4),
             'executed_flop_per_launch': flops,
             'flop_per_query_element': FLOP_PER_STRIP_ELEMENT,
@@ -200,9 +303,7 @@ def rooflines(p, batch):
             # above the vector peak because the cluster tree replaces ~3/4 of the pairs by boundary caps
             'reference_formulation_flop_per_launch': ref_flops,
             'reference_formulation_equivalent_TFLOPs': round(ref_flops / t_w / 1e12, 1),
-            'algorithmic_bytes_per_launch': batch * (v * 12 + v * 4) + f * 12,
-            'valu_issue_note': 'PMC (profiles/r01_k_pmc_sq.txt): 5.5e8 VALU + 1.6e8 SALU instructions per launch, '
-                               '32 VALU instructions per 64-query element step'}
+            'algorithmic_bytes_per_launch': batch * (v * 12 + v * 4) + f * 12}
     t_v = time_kernel(lambda: model.v2v_min(verts), 10)
     ref_layout_bytes = batch * (12 * v + v * v + 8 * v)           # SURVEY.md §8(d) layout (i)
     compact_bytes = batch * (12 * v + 8 * v) + v * v // 8         # layout (ii): bit-packed mask read once
@@ -214,35 +315,25 @@ def rooflines(p, batch):
            'reference_layout_equivalent_frac_of_hbm': round(ref_layout_bytes / t_v / 1e9 / PEAK_HBM_GBS, 3),
            'note': 'mask is bit-packed and L2-resident and ~60 % of the rows are pruned by box distance: the '
                    'equivalent figures are NOT physical bandwidth or executed arithmetic'}
-    return roof, v2v
+    return roof, v2v, verts, model
 
 
-def contact_loss_eval(p, batch):
+def contact_loss_eval(p, batch, verts, model):
     """BASELINE metric 2, 'contact-loss eval ms/body' (SURVEY.md §8d): RegressorLoss.contact_loss
     (tuch/train/loss.py:240-317) on the posed vertices, batch 64, forward and forward+backward,
     plain and HD branch; HIP events on the launch stream."""
-    import types
-    from tuch_amd.train.loss import RegressorLoss
-    body = p['body']
-    with torch.no_grad():
-        verts = p['smpl'](global_orient=p['global_orient'], body_pose=p['body_pose'], betas=p['betas']).vertices
     dev = verts.device
     valid = torch.ones(batch, dtype=torch.bool, device=dev)
     out = {}
     # TUCH.contact_from_verts (tuch/train/train_module.py:69-91): minimum squared distance of ALL region pairs,
     # unmasked; the reference calls it twice per training step
-    from tuch_amd.smplify.losses import contact_model_for
-    cmodel = contact_model_for(p['geomask'], p['face_tensor'], p['segments'], p['cdict'])
-    if cmodel.num_pairs:
+    if model.num_pairs:
         with torch.no_grad():
             out['contact_from_verts_ms'] = round(time_kernel(
-                lambda: cmodel.region_pair_min(verts, select=None, masked=False), 5) * 1e3, 4)
-        out['contact_from_verts_pairs'] = cmodel.num_pairs
+                lambda: model.region_pair_min(verts, select=None, masked=False), 5) * 1e3, 4)
+        out['contact_from_verts_pairs'] = model.num_pairs
     for tag, use_hd in (('plain', False), ('hd', True)):
-        crit = RegressorLoss(types.SimpleNamespace(contact_loss_weight=1.0), dev, body.num_verts, p['face_tensor'],
-                             torch.tensor(body.geodesics, device=dev), geothres=0.3, euclthres=0.02,
-                             face_tensor=p['face_tensor'], use_hd=use_hd, segments=p['segments'],
-                             hd_regressor=(body.hd_bary_idx, body.hd_bary_w), hd_faces=body.hd_face_id)
+        crit = regressor_loss(p, use_hd)
         v = verts.clone().requires_grad_(True)
 
         def fwd():
@@ -252,24 +343,62 @@ def contact_loss_eval(p, batch):
         def fwd_bwd():
             v.grad = None
             crit.contact_loss(v, valid).backward()
-        iters = 5 if not use_hd else 2
+        iters = 5 if not use_hd else 3
         out['regressor_%s_fwd_ms_per_body' % tag] = round(time_kernel(fwd, iters) * 1e3 / batch, 5)
         out['regressor_%s_fwd_bwd_ms_per_body' % tag] = round(time_kernel(fwd_bwd, iters) * 1e3 / batch, 5)
-
-        # BASELINE configs[3] flavour (train.py-style step, the regressor's output replaced by synthetic rotation
-        # matrices): SMPL forward with pose2rot=False (train_module.py:202-204) + contact loss + backward to the
-        # rotation matrices and betas
-        from tuch_amd.utils.geometry import batch_rodrigues
-        full_pose = torch.cat([p['global_orient'], p['body_pose']], dim=1).detach()
-        rotmat = batch_rodrigues(full_pose.reshape(-1, 3)).view(batch, 24, 3, 3).detach().requires_grad_(True)
-        betas = p['betas'].detach().clone().requires_grad_(True)
-
-        def train_step():
-            rotmat.grad = betas.grad = None
-            o = p['smpl'](betas=betas, body_pose=rotmat[:, 1:], global_orient=rotmat[:, :1], pose2rot=False)
-            crit.contact_loss(o.vertices, valid).backward()
-        out['train_style_%s_step_ms' % tag] = round(time_kernel(train_step, iters) * 1e3, 4)
+        out['train_style_%s_step_ms' % tag] = round(time_kernel(make_train_step(p, use_hd), iters) * 1e3, 4)
     return out
+
+
+def shard_sweep(device, seed):
+    """The per-GPU shards of a global batch of 64 (64 / 32 / 16 / 8 bodies per GPU at 1 / 2 / 4 / 8
+    GPUs), each timed on this one GPU: the stage-2 step replayed as a hipGraph and launched eagerly."""
+    out = {}
+    for b in (8, 16, 32, 64):
+        p = build_problem(b, device, seed)
+        eager = time_kernel(make_step(p), 10) * 1e3
+        graph = time_kernel(capture(make_step(p), 3), 20) * 1e3
+        out[str(b)] = {'graph_ms': round(graph, 4), 'eager_ms': round(eager, 4),
+                       'body_iterations_per_s_graph': round(b / graph * 1e3, 1),
+                       'implied_8gpu_global64_body_iterations_per_s': round(64 / graph * 1e3, 1) if b == 8 else None}
+    return out
+
+
+def workloads(device, seed):
+    """Per-rank workloads of BASELINE configs 3, 4, 5 on this GPU (synthetic rotation matrices stand in for the
+    frozen regressor's output)."""
+    out = {}
+    p32 = build_problem(32, device, seed + 1)
+    fit, fitter = make_fit(p32, 100)
+    t = time_kernel(fit, 1)
+    out['config3_fit_b32_100+100_iters'] = {'seconds_per_fit': round(t, 4), 'body_iterations_per_s': round(32 * 200 / t, 1),
+                                            'graph_replayed': dict(fitter.graph_replayed)}
+    out['config4_shard_b32_train_step'] = {
+        'plain_ms': round(time_kernel(make_train_step(p32, False), 5) * 1e3, 4),
+        'hd_ms': round(time_kernel(make_train_step(p32, True), 3) * 1e3, 4),
+        'what': 'SMPL fwd (pose2rot=False) + RegressorLoss.contact_loss + backward, 32 bodies per rank (256 / 8)'}
+    p64 = build_problem(64, device, seed + 2)
+    out['config5_shard_b64_in_the_loop_step'] = {
+        'hd_ms': round(time_kernel(make_train_step(p64, True, smplify_iters=10), 2) * 1e3, 4),
+        'what': 'SMPLify-DC 10 + 10 iterations in the loop, then SMPL fwd + contact_loss (HD) + backward, '
+                '64 bodies per rank (512 / 8); the bf16 ResNet regressor is stock PyTorch and not part of the path'}
+    return out
+
+
+def worst_case(device, seed, batch):
+    """All bodies self-penetrating (arm across the torso, legs together) instead of half of them."""
+    from tuch_amd.smplify.losses import contact_model_for
+    p = build_problem(batch, device, seed, penetrating_fraction=1.0)
+    ms = time_kernel(capture(make_step(p), 3), 20) * 1e3
+    model = contact_model_for(p['geomask'], p['face_tensor'], p['segments'], p['cdict'])
+    with torch.no_grad():
+        verts = p['smpl'](global_orient=p['global_orient'], body_pose=p['body_pose'], betas=p['betas']).vertices
+        work = model.winding_tree_work(verts)
+        interior = float((model.exterior_flags(verts, apply_segments=True) == 0).float().sum(1).mean())
+    return {'ms_per_step': round(ms, 4), 'body_iterations_per_s': round(batch / ms * 1e3, 1),
+            'winding_element_steps': work['leaf_elements'] + work['cap_elements'],
+            'mean_interior_vertices_per_body': round(interior, 1),
+            'what': 'batch %d, penetrating_fraction=1.0 (default mix: 0.5)' % batch}
 
 
 def cpu_baseline(p, seconds):
@@ -319,8 +448,30 @@ def cpu_torch_chain(p):
                       'torch CPU ops materialising the reference intermediates; no segments, no backward'}
 
 
+CONFIGS = {
+    '2': dict(metric='SMPLify-DC fit iters/sec at batch 64', unit='body-fit iterations/s', iters_per_step=1,
+              workload='configs[1] extended to the full stage-2 step: batch=%d/GPU SMPL forward + contact_fitting_loss '
+                       '(L_P/L_C push/pull, winding inside test, segment filter, r2r) + backward + Adam, V=6890 '
+                       'F=13776, float32'),
+    '3': dict(metric='SMPLify-DC fit iters/sec, demo-style 100+100-iteration fits', unit='body-fit iterations/s',
+              iters_per_step=200,
+              workload='configs[2]: demo_smplify_dc.py-style fit, batch=%d/GPU, 100 stage-1 + 100 stage-2 iterations per '
+                       'step (SMPLifyDC.__call__, loops replayed as hipGraphs), V=6890 F=13776, float32'),
+    '4-shard': dict(metric='train.py-style contact-loss steps/sec (bodies/s)', unit='bodies/s', iters_per_step=1,
+                    workload='configs[3] per-rank shard: batch=%d/GPU, SMPL forward (pose2rot=False) + '
+                             'RegressorLoss.contact_loss (HD branch, global valid mean) + backward; frozen regressor '
+                             'replaced by synthetic rotation matrices'),
+    '5-shard': dict(metric='SMPLify-DC in-the-loop training steps/sec (bodies/s)', unit='bodies/s', iters_per_step=1,
+                    workload='configs[4] per-rank shard: batch=%d/GPU, SMPLify-DC 10+10 iterations in the loop, then SMPL '
+                             'forward + RegressorLoss.contact_loss (HD) + backward; regressor replaced by synthetic '
+                             'rotation matrices'),
+}
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(launch_ranks(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -331,28 +482,45 @@ def main():
     backend = os.environ.get('TUCH_BENCH_BACKEND', 'nccl')
     local = local % torch.cuda.device_count() if backend == 'gloo' else local
     device = torch.device('cuda', local)
+    torch.cuda.set_device(local)
+    if args.global_batch is not None:
+        if args.global_batch % world:
+            raise SystemExit('--global-batch %d is not divisible by %d ranks' % (args.global_batch, world))
+        batch, scaling = args.global_batch // world, 'strong'
+    else:
+        batch = {'3': 32, '4-shard': 32}.get(args.config, args.batch) if args.batch == BATCH_PER_GPU else args.batch
+        scaling = 'weak'
+    torch.manual_seed(1000 + rank)
+    p = build_problem(batch, device, seed=1002 + rank)
+    launch = 'eager'
+    if args.config == '2':
+        step = make_step(p)
+        if not args.eager:
+            # the whole step replayed as one hipGraph.  Captured BEFORE the process group exists: the step holds no
+            # collective, and a capture next to RCCL's watchdog thread is the one combination that faulted in round 1
+            step = capture(step, args.warmup)
+            launch = 'hipGraph replay of the whole step'
+    elif args.config == '3':
+        step = make_fit(p, 100)[0]
+        launch = 'SMPLifyDC.__call__ (each loop replayed as a hipGraph after 3 eager iterations)'
+    else:
+        step = make_train_step(p, True, smplify_iters=10 if args.config == '5-shard' else 0)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local)
         if backend == 'nccl':
             torch.distributed.init_process_group('nccl', device_id=device)
         else:
             torch.distributed.init_process_group(backend)
-    torch.manual_seed(1000 + rank)
-    p = build_problem(args.batch, device, seed=1002 + rank)
-    step, reduce = make_step(p, world)
-    launch = 'eager'
-    # N = 1: the whole step is replayed as one hipGraph.  N > 1: eager launches by default (the step is
-    # GPU-bound, eager costs < 1 %); graph replay next to a live process group could only be smoke-tested
-    # with two ranks sharing one GPU here, where it faulted, so it stays opt-in (--graph) until it has
-    # run on a multi-GPU node.
-    if not args.eager and (world == 1 or args.graph):
-        try:
-            step = capture(step, args.warmup)
-            launch = 'hipGraph replay of the whole step'
-        except Exception as exc:       # keep the bench alive, say so in the JSON
-            print('graph capture failed, running eagerly: %r' % (exc,), file=sys.stderr)
-            step, reduce = make_step(p, world)
+
+    def reduce(local_stats):
+        if world > 1:
+            if backend == 'gloo':                        # single-GPU smoke test of the N>1 path only
+                host = local_stats.cpu()
+                torch.distributed.all_reduce(host)
+                return host.to(local_stats.device)
+            local_stats = local_stats.clone()
+            torch.distributed.all_reduce(local_stats)    # 2 floats over RCCL / xGMI
+        return local_stats
 
     def fence():
         torch.cuda.synchronize()
@@ -360,37 +528,52 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    def block(steps):
+        """EXACTLY `steps` steps between two fences; seconds, MAX over ranks."""
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            stats = reduce(step())
+        fence()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
+        if world > 1:
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        return float(tmax.item()), stats
+
     for _ in range(args.warmup):
         reduce(step())
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        stats = reduce(step())
-    fence()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
-    if world > 1:
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-    dt = float(tmax.item())
-    roof, v2v = rooflines(p, args.batch)
-    eval_ms = contact_loss_eval(p, args.batch) if rank == 0 else None
+    dt, stats = block(args.steps)                        # the contract's measurement
+    repeats = [dt] + [block(args.steps)[0] for _ in range(max(args.repeats, 1) - 1)]
     if rank == 0:
-        bodies = args.batch * world
+        cfg = CONFIGS[args.config]
+        bodies = batch * world
+        per_step = [r / args.steps * 1e3 for r in repeats]
         line = {
-            'metric': 'SMPLify-DC fit iters/sec at batch 64', 'value': round(bodies * args.steps / dt, 2),
-            'unit': 'body-fit iterations/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'metric': cfg['metric'], 'value': round(bodies * cfg['iters_per_step'] * args.steps / dt, 2),
+            'unit': cfg['unit'], 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': scaling,
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'configs[1] extended to the full stage-2 step: batch=%d/GPU SMPL forward + '
-                                   'contact_fitting_loss (L_P/L_C push/pull, winding inside test, segment '
-                                   'filter, r2r) + backward + Adam, V=6890 F=13776, float32' % args.batch,
-                       'bodies_per_gpu': args.batch, 'global_batch': bodies, 'euclthres': 0.02,
-                       'geothres': 0.3, 'launch': launch, 'parallelism': 'dp%d (bodies sharded, 2-float all-reduce)' % world,
-                       'batch_iterations_per_s': round(args.steps / dt, 3),
-                       'contact_loss_ms_per_body': round(dt / args.steps * 1e3 / args.batch, 4),
+            'config': {'workload': cfg['workload'] % batch,
+                       'bodies_per_gpu': batch, 'global_batch': bodies, 'euclthres': 0.02,
+                       'geothres': 0.3, 'launch': launch,
+                       'parallelism': 'dp%d (bodies sharded, 2-float all-reduce)' % world,
+                       'batch_iterations_per_s': round(cfg['iters_per_step'] * args.steps / dt, 3),
                        'loss_sum': float(stats[0].item()), 'bodies': float(stats[1].item())},
-            'roofline': roof, 'roofline_v2v': v2v, 'contact_loss_eval': eval_ms,
+            'repeat_ms_per_step': {'n': len(per_step), 'median': round(float(np.median(per_step)), 4),
+                                   'min': round(min(per_step), 4), 'max': round(max(per_step), 4),
+                                   'note': 'the same %d-step block timed %d times; ms_per_step/value are block 1'
+                                           % (args.steps, len(per_step))},
+            'scaling_note': 'no multi-GPU node was available to the builder: N>1 values exist only when the driver '
+                            'runs this script on one' if world == 1 else None,
         }
+        roof, v2v, verts, model = rooflines(p, batch)
+        line['roofline'], line['roofline_v2v'] = roof, v2v
+        if world == 1 and not args.no_extras:
+            line['contact_loss_eval'] = contact_loss_eval(p, batch, verts, model)
+            line['shard_sweep'] = shard_sweep(device, 1002)
+            line['workloads'] = workloads(device, 1002)
+            line['worst_case'] = worst_case(device, 1002, batch)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(p, args.cpu_seconds)
             if not args.no_torch_chain:

@@ -37,7 +37,8 @@ def _worker(rank, world, port, per_body, valid, out):
     pb = tdist.shard_batch(torch.tensor(per_body), rank, world)
     va = tdist.shard_batch(torch.tensor(valid), rank, world)
     total, count = tdist.allreduce_loss((pb * va).sum(), float(va.sum()))
-    mean = tdist.global_mean_loss(pb, va)
+    mean = tdist.global_mean_loss(pb, va).reshape(1)      # this rank's share of the global mean
+    dist.all_reduce(mean)
     if rank == 0:
         out.put((float(total), float(count), float(mean)))
     dist.barrier()
@@ -66,3 +67,91 @@ def test_two_rank_allreduce_matches_single_process():
     assert count == valid.sum()
     assert abs(total - float((per_body * valid).sum())) <= 1e-6 * abs(total)
     assert abs(mean - float(per_body[valid > 0].mean())) <= 1e-6 * abs(mean)
+
+
+def _hip_worker(rank, world, port, out):
+    """Rank r evaluates RegressorLoss.contact_loss (HIP path) on its shard of the medium golden batch."""
+    import types
+    import golden_io as gio
+    from helpers import golden, golden_mask
+    from tuch_amd.train.loss import RegressorLoss
+    from tuch_amd.utils.segmentation import BatchBodySegment
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    g, gm = golden('medium'), golden_mask('medium')
+    d = torch.device('cuda:0')                      # both ranks share the one GPU of the test box
+    lo, hi = tdist.shard_range(g['verts'].shape[0], rank, world)
+    face_tensor = torch.tensor(g['faces'], device=d)[None].repeat(hi - lo, 1, 1)
+    segs = gio.unpack_segments(g)
+    crit = RegressorLoss(types.SimpleNamespace(contact_loss_weight=1.0), d, g['verts'].shape[1], face_tensor,
+                         torch.tensor(np.where(gm, 1.0, 0.0).astype(np.float32), device=d), geothres=0.3,
+                         euclthres=float(g['euclthres']), face_tensor=face_tensor, use_hd=(rank >= 0),
+                         segments=BatchBodySegment(list(segs.keys()), face_tensor[0], segs),
+                         hd_regressor=(g['hd_idx'], g['hd_w']), hd_faces=g['hd_face'])
+    verts = torch.tensor(g['verts'][lo:hi], device=d, requires_grad=True)
+    # all_reduce of the valid count inside contact_loss: gloo needs host tensors, the product passes the device
+    # tensor (RCCL on a real multi-GPU node) -> route this test's reduction through the host
+    real = dist.all_reduce
+
+    def via_host(t, op=dist.ReduceOp.SUM):
+        h = t.cpu()
+        real(h, op=op)
+        t.copy_(h)
+    dist.all_reduce = via_host
+    share = crit.contact_loss(verts, torch.tensor(g['valid_fit'][lo:hi], device=d))
+    share.backward()
+    dist.all_reduce = real
+    total = share.detach().cpu().reshape(1)
+    dist.all_reduce(total)
+    grads = [None] * world
+    dist.all_gather_object(grads, (lo, hi, verts.grad.cpu().numpy()))
+    if rank == 0:
+        out.put((float(total), grads))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_the_hip_path_reproduce_the_reference_mean():
+    """Bodies sharded over 2 ranks (gloo, sharing the box's GPU): the sum of the per-rank shares of
+    RegressorLoss.contact_loss is the reference's mean over all valid bodies (loss.py:317), and each rank's
+    gradient is the reference's gradient for its bodies."""
+    from helpers import golden
+    g = golden('medium')
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hip_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    total, grads = q.get(timeout=300)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert abs(total - float(g['train_hd_loss'])) <= 1e-4 * abs(float(g['train_hd_loss']))
+    gv = g['train_hd_grad_verts']
+    for lo, hi, grad in grads:
+        assert np.allclose(grad, gv[lo:hi], rtol=1e-3, atol=5e-6 * np.abs(gv).max())
+
+
+@pytest.mark.gpu
+def test_bench_spawns_its_own_ranks():
+    """`bench.py --gpus 2` without a launcher re-execs under torch.distributed.run and prints one line with
+    n_gpus 2 (two gloo ranks sharing this box's GPU; RCCL needs one device per rank)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TUCH_BENCH_BACKEND='gloo')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                          '--global-batch', '8', '--repeats', '2', '--no-extras', '--no-cpu-baseline'],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['scaling'] == 'strong' and line['config']['bodies_per_gpu'] == 4
+    assert line['config']['bodies'] == 8.0 and line['config']['launch'].startswith('hipGraph')
+    assert np.isfinite(line['config']['loss_sum']) and line['value'] > 0

@@ -20,7 +20,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import _C, ops
+from .. import _C, dist as tdist, ops
 from ..utils.geometry import batch_rodrigues
 
 
@@ -92,7 +92,9 @@ class RegressorLoss(nn.Module):
         valid = valid_fit.bool()
         valid_u8 = valid.to(torch.uint8).contiguous()
         exterior, min_d2, partner, _ = model.exterior_and_partner(pred_vertices, apply_segments=True)   # :264-266
-        n_valid = valid.sum().to(torch.float32)
+        # loss.py:317 is a mean over ALL valid bodies: with the batch sharded over ranks the count is all-reduced
+        # (one float, no host sync), so that every body's gradient is the single-process one
+        n_valid = tdist.global_count(valid.sum())
         if not self.use_hd:
             per_body, _ = ops.contact_terms(pred_vertices, partner, exterior, valid_u8, ops.MODE_TRAIN,
                                             self.euclthres)
@@ -109,7 +111,7 @@ class RegressorLoss(nn.Module):
             offsets[1:] = counts.cumsum(0)
             n_max = int(counts.max().item())
         if bidx.numel() == 0:
-            return pred_vertices.sum() * 0.0
+            return pred_vertices.sum() * 0.0 / n_valid          # NaN without any valid body, like the reference
         bidx32 = bidx.to(torch.int32)
         hd = ops.hd_points(pred_vertices, bidx32, hidx.to(torch.int32), self.hd_idx32, self.hd_w)   # :285
         with torch.no_grad():
