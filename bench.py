@@ -253,6 +253,10 @@ def capture(step, warmup):
     def replay():
         graph.replay()
         return out
+    # the graph holds raw addresses of everything `step` owns (parameters, Adam state, ...): they must live as
+    # long as the graph does.  (Round 1 dropped `step` here; its tensors were then recycled by the next regular
+    # allocation -- the all-reduce's clone for N > 1 -- which is what "faulted next to a process group".)
+    replay.keep_alive = (step, graph)
     return replay
 
 
@@ -513,6 +517,8 @@ def main():
             torch.distributed.init_process_group(backend)
 
     def reduce(local_stats):
+        if os.environ.get('TUCH_BENCH_DEBUG'):
+            print('rank', rank, 'local stats', local_stats.tolist(), flush=True)
         if world > 1:
             if backend == 'gloo':                        # single-GPU smoke test of the N>1 path only
                 host = local_stats.cpu()

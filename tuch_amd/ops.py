@@ -278,11 +278,13 @@ _DERIVED = {}
 def cached_derived(key_tensors, build):
     """Small per-call tensors derived from caller inputs that do not change between iterations
     (validity / selection masks): rebuilt only when an input was modified in place or replaced.  The
-    entry holds its source tensors, so their addresses cannot be reused while it is cached."""
+    entry holds its source tensors, so their addresses cannot be reused while it is cached.  A captured
+    hipGraph holds the address of the derived tensor: entries are kept for 256 distinct inputs before the oldest
+    is dropped, far more than the graphs a process keeps alive at once."""
     key = tuple((t.data_ptr(), t._version, tuple(t.shape)) if t is not None else None for t in key_tensors)
     hit = _DERIVED.get(key)
     if hit is None:
-        while len(_DERIVED) >= 16:
+        while len(_DERIVED) >= 256:
             _DERIVED.pop(next(iter(_DERIVED)))
         hit = (build(), key_tensors)
         _DERIVED[key] = hit

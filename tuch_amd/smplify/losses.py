@@ -43,7 +43,7 @@ def contact_model_for(geomask, face_tensor, segments=None, cdict=None, device=No
                                  device=device if device is not None else faces.device)
         # keep the keyed objects alive with the entry: a freed tensor's address / a dead object's id can
         # be reused, which would turn the key into a stale hit
-        while len(_MODEL_CACHE) >= 8:
+        while len(_MODEL_CACHE) >= 32:
             _MODEL_CACHE.pop(next(iter(_MODEL_CACHE)))
         _MODEL_CACHE[key] = (model, geomask, face_tensor, segments, cdict)
     return model
