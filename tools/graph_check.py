@@ -1,5 +1,5 @@
 """Loss trajectory of the stage-2 step: eager launches vs hipGraph replay, at several batch sizes."""
-import sys; sys.path.insert(0, '.')
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 dev = torch.device('cuda:0')
