@@ -689,3 +689,98 @@ def test_v2v_hints_never_change_the_result(monkeypatch):
     for mn, arg in ((mn1, arg1), (mn2, arg2), (mn3, arg3)):
         assert torch.equal(mn, mn0) and torch.equal(arg, arg0)
     assert torch.equal(mn5, mn4) and torch.equal(arg5, arg4)
+
+
+# ---- inside test by ray crossings (csrc/ray_winding.hip) against the solid-angle sums ------------------------------
+def _posed_batch(tag, batch, seed, scale=1.0):
+    """`batch` bodies of the fixture's mesh in new poses: the golden ones followed by sheared / squeezed copies
+    (affine maps keep the surface closed; squeezing x makes limbs interpenetrate)."""
+    g = golden(tag)
+    base = torch.tensor(g['verts'], device=dev())
+    verts = base[torch.arange(batch, device=dev()) % base.shape[0]].clone()
+    rng = np.random.default_rng(seed)
+    for b in range(base.shape[0], batch):
+        a = torch.tensor(np.eye(3) + 0.25 * scale * rng.standard_normal((3, 3)), dtype=torch.float32, device=dev())
+        verts[b] = verts[b] @ a.T + torch.tensor(rng.standard_normal(3), dtype=torch.float32, device=dev())
+    return g, verts.contiguous()
+
+
+@pytest.mark.parametrize('tag', TAGS)
+@pytest.mark.parametrize('batch', [1, 7])
+def test_ray_crossing_flags_match_the_solid_angle_sums(tag, batch, monkeypatch):
+    """Vertices: w = crossings - fan angles (TUCH_WINDING_RAY=2 reports it) against the summed solid angles of the
+    tree walk and of the reference; flags identical wherever w is not within 1e-4 of the threshold."""
+    g, verts = _posed_batch(tag, batch, 5)
+    model = make_model(g, None, False, False)
+    monkeypatch.setenv('TUCH_WINDING_RAY', '0')
+    ext_s, w_s = model.exterior_flags(verts, apply_segments=False, return_details=True)[:2]
+    monkeypatch.setenv('TUCH_WINDING_RAY', '2')
+    ext_r, w_r = model.exterior_flags(verts, apply_segments=False, return_details=True)[:2]
+    monkeypatch.setenv('TUCH_WINDING_RAY', '1')
+    ext_1 = model.exterior_flags(verts, apply_segments=False)
+    w_s, w_r = w_s.cpu().numpy(), w_r.cpu().numpy()
+    ext_s, ext_r, ext_1 = ext_s.cpu().numpy(), ext_r.cpu().numpy(), ext_1.cpu().numpy()
+    assert np.array_equal(ext_r, ext_1)
+    err = np.abs(w_r - w_s)
+    report('ray vs solid-angle w: max |dw| [%s, B=%d] x1e7' % (tag, batch), int(err.max() * 1e7), w_s.size)
+    assert err.max() < 5e-5, err.max()             # an integer error would be >= 1
+    clear = np.abs(w_s - 0.99) > 1e-4
+    assert np.array_equal(ext_r[clear], ext_s[clear])
+    report('ray flags != solid-angle flags [%s, B=%d]' % (tag, batch), int((ext_r != ext_s).sum()), ext_s.size)
+    for b in range(min(batch, g['verts'].shape[0])):
+        check_winding(w_r[b], g['winding'][b])
+
+
+def test_ray_crossing_flags_at_rest_pose_and_axis_aligned():
+    """Degenerate input: the symmetric template itself, unposed and axis aligned (many exactly equal coordinates,
+    rays through edges and vertices: the tie rules decide) and a mirrored copy (orientation reversed: w = -...)."""
+    from tuch_amd.synthetic import make_body
+    import os
+    body = make_body(40, 40)
+    from tuch_amd.ops import ContactModel
+    model = ContactModel(body.faces, None, None, None, None, device=dev())
+    v = torch.tensor(body.v_template, device=dev())[None]
+    # the shear of the ray frame is fixed in space: also test the template rotated so that rays run along mesh symmetry
+    verts = torch.cat([v, v[:, :, [2, 0, 1]], v * torch.tensor([1.0, 1.0, 0.5], device=dev())]).contiguous()
+    os.environ['TUCH_WINDING_RAY'] = '0'
+    try:
+        ext_s, w_s = model.exterior_flags(verts, apply_segments=False, return_details=True)[:2]
+        os.environ['TUCH_WINDING_RAY'] = '2'
+        ext_r, w_r = model.exterior_flags(verts, apply_segments=False, return_details=True)[:2]
+    finally:
+        os.environ.pop('TUCH_WINDING_RAY', None)
+    assert float((w_r - w_s).abs().max()) < 5e-5
+    assert torch.equal(ext_r, ext_s)
+
+
+@pytest.mark.parametrize('tag', ['medium', 'full'])
+def test_ray_crossing_flags_of_points_match_the_solid_angle_sums(tag, monkeypatch):
+    """Off-surface points (HD points of loss.py:297: on a face, 1 mm along its normal; plus points well inside and
+    outside): integer crossing counts against the summed solid angles, ragged counts, both point orders."""
+    g, verts = _posed_batch(tag, 5, 9, scale=0.6)
+    model = make_model(g, None, False, False)
+    rng = np.random.default_rng(2)
+    faces = torch.tensor(g['faces'], device=dev())
+    q = 900
+    fid = torch.tensor(rng.integers(0, faces.shape[0], (5, q)), device=dev())
+    bary = torch.tensor(rng.dirichlet([1, 1, 1], (5, q)).astype(np.float32), device=dev())
+    tri = torch.stack([verts[b][faces[fid[b]]] for b in range(5)])                 # [5,q,3,3]
+    on = (tri * bary[..., None]).sum(2)
+    n = torch.cross(tri[:, :, 1] - tri[:, :, 0], tri[:, :, 2] - tri[:, :, 0], dim=2)
+    n = n / n.norm(dim=2, keepdim=True)
+    sign = torch.tensor(rng.choice([1.0, -1.0, 20.0, -20.0], (5, q, 1)).astype(np.float32), device=dev())
+    pts = (on + 0.001 * sign * n).contiguous()                                     # 1 mm / 2 cm above / below
+    counts = torch.tensor([q, q - 100, 1, 0, 517], dtype=torch.int32, device=dev())
+    monkeypatch.setenv('TUCH_WINDING_RAY', '0')
+    w_s, ext_s = model.winding_points(verts, pts, counts)
+    monkeypatch.setenv('TUCH_WINDING_RAY', '1')
+    _, ext_r = model.winding_points(verts, pts, counts, flags_only=True)
+    monkeypatch.setenv('TUCH_WINDING_RAY', '2')
+    w_r, ext_2 = model.winding_points(verts, pts, counts)
+    w_s, w_r = w_s.cpu().numpy(), w_r.cpu().numpy()
+    assert torch.equal(ext_r, ext_2)
+    assert np.array_equal(w_r, np.round(w_r))                                      # integers
+    report('ray vs solid-angle w of points: max |dw| [%s] x1e6' % tag, int(np.abs(w_r - w_s).max() * 1e6), w_s.size)
+    assert np.abs(w_r - w_s).max() < 1e-3
+    assert torch.equal(ext_r, ext_s)
+    assert len(np.unique(w_r)) >= 2                                                # inside and outside points both occur

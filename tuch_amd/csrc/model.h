@@ -28,6 +28,17 @@ bool tuch_cluster_tree_build_impl(int V, int F, const int32_t* faces, int leaf_f
 void tuch_build_strips(const int32_t* faces, int F, std::vector<int32_t>& vidx, std::vector<float>& sign,
                        int* num_strips);
 
+struct tuch_contact_model;
+
+// Inside test by signed ray crossings (ray_winding.hip): exterior flags of the model's own vertices / of arbitrary
+// points, identical to thresholding the winding-number sum wherever that sum is well separated from the threshold.
+bool tuch_ray_available(const tuch_contact_model* m);
+size_t tuch_ray_workspace_bytes(const tuch_contact_model* m, int B, int Q);
+int tuch_ray_exterior_verts(const tuch_contact_model* m, const float* verts, int B, float thresh, uint8_t* exterior,
+                            float* w, void* workspace, hipStream_t s, unsigned long long* stats_host);
+int tuch_ray_exterior_points(const tuch_contact_model* m, const float* verts, const float* points, const int32_t* counts,
+                             int B, int Q, float thresh, uint8_t* exterior, float* w, void* workspace, hipStream_t s);
+
 struct tuch_contact_model {
     int device;
     int V, F;
@@ -40,7 +51,7 @@ struct tuch_contact_model {
     int32_t* strip_vidx;       // [strip_len]
     float* strip_sign;         // [strip_len]
     // cluster tree for the hierarchical winding numbers (device copies; tree_nodes == 0: not available)
-    int tree_nodes, tree_stream_len, tree_qblocks, tree_heights, tree_leaves;
+    int tree_nodes, tree_stream_len, tree_exact_len, tree_qblocks, tree_heights, tree_leaves;
     int32_t* tree_node;        // [tree_nodes][8]
     int32_t* tree_vidx;        // [tree_stream_len]
     float* tree_sign;
@@ -57,6 +68,13 @@ struct tuch_contact_model {
     int32_t* tree_masked;
     int tree_num_frontiers;
     int* tree_frontier_off_host;   // [tree_num_frontiers+1]
+    int32_t* tree_face_leaf_host;  // [F] leaf (preorder sequence number) of every face, host copy (or nullptr)
+    int32_t* tree_qperm_host;      // [tree_qblocks*128] host copy of tree_qperm (or nullptr)
+    // ordered one-ring of every vertex (closed manifold meshes only, else nullptr): ring_vidx[ring_off[v] + j] = r_j
+    // with the faces around v being (v, r_j, r_{j+1}) in their own orientation, j cyclic (ray_winding.hip)
+    int32_t* ring_off;         // [V+1]
+    int32_t* ring_vidx;
+    int ring_max;              // largest valence
     // segments (tuch/utils/segmentation.py): CSR over segments
     int num_segments, num_caps, seg_q_total, seg_f_total;
     int32_t* seg_q_off;        // [S+1] into seg_q_vidx

@@ -39,12 +39,14 @@ int* host_copy(const int32_t* src, size_t n)
 extern "C" void tuch_contact_model_destroy(tuch_contact_model* m)
 {
     if (!m) return;
-    void* dev[] = {m->faces, m->mask_bits, m->strip_vidx, m->strip_sign, m->tree_node, m->tree_vidx, m->tree_sign, m->tree_qperm,
+    void* dev[] = {m->ring_off, m->ring_vidx, m->faces, m->mask_bits, m->strip_vidx, m->strip_sign, m->tree_node, m->tree_vidx, m->tree_sign, m->tree_qperm,
                    m->tree_height_off, m->tree_height_nodes, m->tree_frontier_nodes, m->tree_launch_order, m->tree_ancestors, m->tree_rows, m->tree_mask_bits, m->tree_masked, m->seg_blocks, m->seg_of_q, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces,
                    m->cap_off, m->cap_vidx, m->region_off, m->region_vidx, m->pairs, m->pair_mask, m->pair_mask_off};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     free(m->tree_frontier_off_host);
+    free(m->tree_face_leaf_host);
+    free(m->tree_qperm_host);
     free(m->seg_q_off_host);
     free(m->seg_f_off_host);
     free(m->region_off_host);
@@ -94,11 +96,14 @@ extern "C" int tuch_contact_model_create(
         if (tuch_cluster_tree_build_impl(V, F, faces, leaf_faces, t) && t.num_nodes <= 800) {
             m->tree_nodes = t.num_nodes;
             m->tree_stream_len = t.stream_len;
+            m->tree_exact_len = t.exact_len;
             m->tree_qblocks = t.num_qblocks;
             m->tree_heights = t.num_heights;
             m->tree_leaves = t.height_off[1];
             m->tree_num_frontiers = (int)t.frontier_off.size() - 1;
             m->tree_frontier_off_host = host_copy(t.frontier_off.data(), t.frontier_off.size());
+            m->tree_face_leaf_host = host_copy(t.face_leaf.data(), t.face_leaf.size());
+            m->tree_qperm_host = host_copy(t.qperm.data(), t.qperm.size());
             rc = upload(&m->tree_node, t.nodes.data(), t.nodes.size());
             if (rc == TUCH_OK) rc = upload(&m->tree_vidx, t.vidx.data(), t.vidx.size());
             if (rc == TUCH_OK) rc = upload(&m->tree_sign, t.sign.data(), t.sign.size());
@@ -137,6 +142,46 @@ extern "C" int tuch_contact_model_create(
                 rc = upload(&m->tree_mask_bits, bits.data(), bits.size());
                 if (rc == TUCH_OK) rc = upload(&m->tree_masked, masked.data(), masked.size());
             }
+        }
+    }
+    if (rc == TUCH_OK && m->tree_nodes > 0) {
+        // ordered one-rings (the tree exists, so the mesh is a closed manifold): face (v, a, b) in its cyclic order
+        // contributes the directed link edge a -> b; the link of v is the single cycle through them
+        std::vector<int32_t> deg(V + 1, 0);
+        for (int i = 0; i < F * 3; ++i) ++deg[faces[i] + 1];
+        for (int v = 0; v < V; ++v) deg[v + 1] += deg[v];
+        std::vector<int32_t> from((size_t)F * 3), to((size_t)F * 3), fill(deg.begin(), deg.end() - 1);
+        for (int f = 0; f < F; ++f)
+            for (int k = 0; k < 3; ++k) {
+                const int v = faces[3 * f + k], slot = fill[v]++;
+                from[slot] = faces[3 * f + (k + 1) % 3];
+                to[slot] = faces[3 * f + (k + 2) % 3];
+            }
+        std::vector<int32_t> ring((size_t)F * 3);
+        bool ok = true;
+        int ring_max = 0;
+        for (int v = 0; v < V && ok; ++v) {
+            const int lo = deg[v], n = deg[v + 1] - lo;
+            if (n < 3) { ok = false; break; }
+            if (n > ring_max) ring_max = n;
+            int cur = from[lo];
+            for (int j = 0; j < n && ok; ++j) {
+                ring[lo + j] = cur;
+                int nxt = -1;
+                for (int e = lo; e < lo + n; ++e)
+                    if (from[e] == cur) { nxt = to[e]; break; }
+                if (nxt < 0) ok = false;
+                cur = nxt;
+            }
+            if (ok && cur != from[lo]) ok = false;          // the cycle must close after exactly n steps
+            for (int j = 0; j < n && ok; ++j)               // ... and visit n distinct vertices
+                for (int i = 0; i < j; ++i)
+                    if (ring[lo + i] == ring[lo + j]) ok = false;
+        }
+        if (ok) {
+            m->ring_max = ring_max;
+            rc = upload(&m->ring_off, deg.data(), deg.size());
+            if (rc == TUCH_OK) rc = upload(&m->ring_vidx, ring.data(), ring.size());
         }
     }
     if (rc == TUCH_OK && geomask) {
@@ -240,6 +285,16 @@ extern "C" const uint64_t* tuch_contact_model_tree_mask_bits(const tuch_contact_
 extern "C" const int32_t* tuch_contact_model_faces(const tuch_contact_model* m)
 {
     return m ? m->faces : nullptr;
+}
+
+extern "C" int tuch_contact_model_tree_order(const tuch_contact_model* m, int32_t* qperm_host, int32_t* face_leaf_host)
+{
+    TUCH_REQUIRE(m, "tuch_contact_model_tree_order: null model");
+    TUCH_REQUIRE(m->tree_nodes > 0 && m->tree_qperm_host && m->tree_face_leaf_host,
+                 "tuch_contact_model_tree_order: the model has no cluster tree");
+    if (qperm_host) memcpy(qperm_host, m->tree_qperm_host, sizeof(int32_t) * m->V);
+    if (face_leaf_host) memcpy(face_leaf_host, m->tree_face_leaf_host, sizeof(int32_t) * m->F);
+    return TUCH_OK;
 }
 
 extern "C" int tuch_contact_model_strips(const tuch_contact_model* m, int* stream_len, int* num_strips,

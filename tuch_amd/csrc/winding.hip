@@ -783,11 +783,20 @@ int choose_strip_splits(int B, int Q, int L)
 }
 
 struct ExteriorLayout {
-    size_t tris, partial, bounds, stats, caps, seg_tris, seg_partial, seg_count, seg_list, total;
+    size_t tris, partial, bounds, stats, caps, seg_tris, seg_partial, seg_count, seg_list, ray, total;
     int lpad;
     int tree_frontier;         // frontier used by the hierarchical path (-1: flat path)
     int tree_subs;
 };
+
+// Inside test by ray crossings (ray_winding.hip): TUCH_WINDING_RAY=0 never, 1 (default) when only the flags are
+// wanted, 2 also when the caller asks for w (reported as crossings - fan angles); read per call
+int ray_mode(const tuch_contact_model* m)
+{
+    if (!tuch_ray_available(m)) return 0;
+    const char* e = getenv("TUCH_WINDING_RAY");
+    return e ? atoi(e) : 1;
+}
 
 // TUCH_WINDING_TREE=0 keeps the flat strip walk (A/B measurements); read per call
 bool use_tree(const tuch_contact_model* m)
@@ -841,6 +850,7 @@ ExteriorLayout exterior_layout(const tuch_contact_model* m, int B)
     l.seg_partial = o; o += align256((size_t)B * kSegSplits * (m->seg_q_total > 0 ? m->seg_q_total : 1) * sizeof(float));
     l.seg_count = o; o += align256((size_t)B * (m->num_segments > 0 ? m->num_segments : 1) * sizeof(int32_t));
     l.seg_list = o; o += align256((size_t)B * (m->seg_q_total > 0 ? m->seg_q_total : 1) * sizeof(int32_t));
+    l.ray = o;      o += align256(tuch_ray_workspace_bytes(m, B, 0));
     l.total = o;
     return l;
 }
@@ -969,7 +979,11 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
     float* tris = (float*)(ws + l.tris);
     hipStream_t s = (hipStream_t)stream;
     int rc = TUCH_OK;
-    if (use_strips() && use_tree(m)) {
+    const int ray = ray_mode(m);
+    if (ray == 2 || (ray == 1 && !w)) {
+        rc = tuch_ray_exterior_verts(m, verts, B, thresh, exterior, w, ws + l.ray, s, nullptr);
+        if (rc != TUCH_OK) return rc;
+    } else if (use_strips() && use_tree(m)) {
         launch_tree_walk(m, l, verts, B, ws, nullptr, s);
         hipLaunchKernelGGL(winding_finalize_tree_kernel, dim3(ceil_div(m->V, kBlock), B), dim3(kBlock), 0, s,
                            (const float*)(ws + l.partial), (const int32_t*)m->tree_qperm, m->V,
@@ -1088,7 +1102,9 @@ extern "C" size_t tuch_winding_points_workspace_bytes(const tuch_contact_model* 
     const size_t flat = align256((size_t)B * lpad * sizeof(StreamElem)) +
                         align256((size_t)B * choose_strip_splits(B, Q, lpad) * Q * sizeof(float));
     if (m->tree_nodes <= 0) return flat;
-    const size_t tree = points_layout(m, B, Q).total;
+    size_t tree = points_layout(m, B, Q).total;
+    const size_t ray = tuch_ray_workspace_bytes(m, B, Q);
+    if (ray > tree) tree = ray;
     return tree > flat ? tree : flat;
 }
 
@@ -1104,6 +1120,9 @@ extern "C" int tuch_winding_points(const tuch_contact_model* m, const float* ver
         return TUCH_ERR_WORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
+    const int ray = ray_mode(m);
+    if (ray == 2 || (ray == 1 && !w))     // off-surface points: the winding number is the integer crossing count
+        return tuch_ray_exterior_points(m, verts, points, counts, B, Q, thresh, exterior, w, workspace, s);
     if (use_strips() && use_tree(m)) {
         // hierarchical walk (cluster tree + boundary caps) with the caller's points as queries
         const PointsLayout l = points_layout(m, B, Q);

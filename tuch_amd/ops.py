@@ -549,14 +549,16 @@ class ContactModel:
         return buf
 
     def winding_points(self, verts: torch.Tensor, points: torch.Tensor, counts: Optional[torch.Tensor] = None,
-                       thresh: float = 0.99):
+                       thresh: float = 0.99, flags_only: bool = False):
         """Winding numbers of arbitrary points [B,Q,3] against this mesh posed by verts [B,V,3]
         (cluster-tree walk; flat triangle strips for meshes without a tree); counts [B] int32 marks how many points per
-        body are real.  Any point order is exact; blocks of 64 consecutive points that are close in space are fast."""
+        body are real.  Any point order is exact; blocks of 64 consecutive points that are close in space are fast.
+        flags_only: return (None, exterior); for points OFF the surface the winding number is an integer and the flags
+        come from signed ray crossings (csrc/ray_winding.hip) instead of the solid-angle sum."""
         v, pts = _f32(verts), _f32(points)
         b, q, _ = pts.shape
         L = _C.lib()
-        w = torch.empty(b, q, dtype=torch.float32, device=pts.device)
+        w = torch.empty(b, q, dtype=torch.float32, device=pts.device) if not flags_only else None
         ext = torch.empty(b, q, dtype=torch.uint8, device=pts.device)
         nbytes = L.tuch_winding_points_workspace_bytes(self._handle, b, q)
         ws = _workspace(nbytes, pts.device)

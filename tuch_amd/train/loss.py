@@ -125,7 +125,7 @@ class RegressorLoss(nn.Module):
             padded = torch.zeros((batch, n_max, 3), dtype=torch.float32, device=hd.device)
             slot = torch.arange(bidx.numel(), device=hd.device) - offsets[:-1][bidx]
             padded[bidx, slot] = offs
-            _, ext_pad = model.winding_points(pred_vertices, padded, counts.to(torch.int32))   # :297
+            _, ext_pad = model.winding_points(pred_vertices, padded, counts.to(torch.int32), flags_only=True)   # :297
             ext_hd = ext_pad[bidx, slot].contiguous()
         terms = ops.contact_terms_ragged(hd, partner_hd, ext_hd, offsets, bidx32,
                                          ops.MODE_TRAIN, self.euclthres)                  # :299-315
