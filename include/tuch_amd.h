@@ -156,6 +156,15 @@ int tuch_contact_model_strips(const tuch_contact_model* model, int* stream_len, 
 int tuch_winding_tree_work(const tuch_contact_model* model, const float* verts, int B, void* workspace,
                            size_t workspace_bytes, unsigned long long* out_host, void* stream);
 
+/* Measurement aid for the ray-crossing inside test (csrc/ray_winding.hip) that tuch_exterior_flags and
+ * tuch_winding_points use when only the flags are wanted: out_host[2] = {strip elements stepped through by all
+ * wavefronts (64 queries each), wavefronts}.  Workspace as for tuch_exterior_flags.  Synchronises the stream. */
+int tuch_ray_work(const tuch_contact_model* model, const float* verts, int B, void* workspace,
+                  size_t workspace_bytes, unsigned long long* out_host, void* stream);
+/* The cluster tree the model built for itself: qperm_host [V] = vertices in tree order, face_leaf_host [F] = leaf
+ * (preorder sequence number) of every face; either may be NULL.  Fails when the model has no tree. */
+int tuch_contact_model_tree_order(const tuch_contact_model* model, int32_t* qperm_host, int32_t* face_leaf_host);
+
 /* Model-level form of tuch_v2v_min_masked: uses the model's geodesic mask and, when the model has a
  * cluster tree, a pruned walk that gives the same minima (rows whose posed box is farther than a column's
  * current minimum, or that the mask rules out entirely, are skipped).  Exact ties between rows are

@@ -41,3 +41,29 @@ def assert_close(actual, expected, rtol, atol, what=''):
         k = int(np.argmax(err - tol))
         raise AssertionError('%s: max violation at flat index %d: got %r want %r (|err|=%g tol=%g)'
                              % (what, k, actual.flat[k], expected.flat[k], err.flat[k], tol.flat[k]))
+
+
+def touches_surface(verts_b, faces, vid, tol=2e-6):
+    """float64: does vertex `vid` lie within `tol` of a triangle it is not a corner of (inside its outline)?
+    There the winding number jumps by one across the triangle: the reference's float32 sum, any other summation
+    order and a crossing count may legitimately land on either side."""
+    v = np.asarray(verts_b, np.float64)
+    faces = np.asarray(faces)
+    tri = v[faces[~(faces == vid).any(1)]]
+    a, b, c = tri[:, 0], tri[:, 1], tri[:, 2]
+    n = np.cross(b - a, c - a)
+    nn = np.linalg.norm(n, axis=1)
+    ok = nn > 0
+    n = n[ok] / nn[ok, None]
+    a, b, c = a[ok], b[ok], c[ok]
+    p = v[vid]
+    dist = ((p - a) * n).sum(1)
+    near = np.abs(dist) < tol
+    if not near.any():
+        return False
+    a, b, c, n, dist = a[near], b[near], c[near], n[near], dist[near]
+    q = p - dist[:, None] * n
+    inside = np.ones(len(a), bool)
+    for s, e in ((a, b), (b, c), (c, a)):
+        inside &= (np.cross(e - s, q - s) * n).sum(1) >= -tol * np.linalg.norm(e - s, axis=1)
+    return bool(inside.any())

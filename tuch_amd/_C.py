@@ -62,6 +62,8 @@ _SIGNATURES = {
     'tuch_estimate_translation': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p]),
     'tuch_rotmat_to_angle_axis': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'tuch_winding_tree_work': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
+    'tuch_ray_work': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
+    'tuch_contact_model_tree_order': (c_int, [c_void_p, c_void_p, c_void_p]),
     'tuch_v2v_model_workspace_bytes': (c_size_t, [c_void_p, c_int]),
     'tuch_v2v_hint_bytes': (c_size_t, [c_void_p, c_int]),
     'tuch_v2v_min_model': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -140,10 +140,26 @@ __device__ __forceinline__ int crossing(const P3& a, const P3& b, const P3& c, f
     return numz < 0.0f ? -1 : 0;
 }
 
+// careful form of the crossing test for lanes with an edge function that is exactly zero (the ray passes through an
+// edge or a corner: tie rules) -- which includes every triangle that has the query itself as a corner
+template <bool kSkipIncident>
+__device__ __forceinline__ int crossing_with_ties(const P3 a, const P3 b, const P3 c, float ea, float eb, float ec)
+{
+    if (kSkipIncident) {
+        // faces around the query vertex: the reference's atan2(0,0) = 0 terms; the closing fan stands in for them
+        const bool za = (a.x == 0.0f) & (a.y == 0.0f) & (a.z == 0.0f);
+        const bool zb = (b.x == 0.0f) & (b.y == 0.0f) & (b.z == 0.0f);
+        const bool zc = (c.x == 0.0f) & (c.y == 0.0f) & (c.z == 0.0f);
+        if (za | zb | zc) return 0;
+    }
+    return crossing(a, b, c, ea, eb, ec);
+}
+
 // One leaf strip, elements [off, off+len), len % 3 == 0, three readable elements past the end.  Register slots are
 // rotated by position modulo 3 like the solid-angle walk; e[k] = edge function of the edge opposite slot k in
-// stream order (p-2 -> p-1 -> p).  kSkipIncident: triangles that have the query itself as a corner are skipped
-// (the reference's atan2(0,0) = 0 terms; they are replaced by the closing fan in the finalize kernel).
+// stream order (p-2 -> p-1 -> p).  Fast path (most elements): two new edge functions, min3 / max3, one ballot.
+// Elements whose projection holds the ray of some lane: depth test, +-1; lanes with an exact tie (and, for vertex
+// queries, the faces around the query itself) take the careful form.
 template <int A, bool kSkipIncident>
 __device__ __forceinline__ void ray_step(const RayElem el, P3 (&s)[3], float (&e)[3], float qx, float qy, float qz, int& count)
 {
@@ -157,19 +173,18 @@ __device__ __forceinline__ void ray_step(const RayElem el, P3 (&s)[3], float (&e
     if (el.sign != 0.0f) {                                        // wave-uniform
         const float mn = __builtin_fminf(__builtin_fminf(e[0], e[1]), e[2]);
         const float mx = __builtin_fmaxf(__builtin_fmaxf(e[0], e[1]), e[2]);
-        const bool cand = mn >= 0.0f || mx <= 0.0f;              // the origin may be inside the projection (ties included)
-        if (__builtin_amdgcn_ballot_w64(cand)) {                  // rare per element: a few hits per ray
-            bool take = cand;
-            if (kSkipIncident) {
-                const bool zb = s[Bq].x == 0.0f && s[Bq].y == 0.0f && s[Bq].z == 0.0f;
-                const bool zc = s[Cq].x == 0.0f && s[Cq].y == 0.0f && s[Cq].z == 0.0f;
-                const bool za = s[A].x == 0.0f && s[A].y == 0.0f && s[A].z == 0.0f;
-                take = take && !(za || zb || zc);
+        const bool cand = (mn >= 0.0f) | (mx <= 0.0f);           // the origin may be inside the projection (ties included)
+        if (__builtin_amdgcn_ballot_w64(cand)) {                  // a few hits per ray
+            // triangle (Bq, Cq, A): det = sum of (edge function opposite a corner) x (that corner's depth)
+            const float numz = e[Bq] * s[Bq].z + e[Cq] * s[Cq].z + e[A] * s[A].z;
+            // generic position: all edge functions of one sign; the hit is in front iff det has that sign, and the
+            // crossing is +1 (leaving through the front) for the positive orientation, -1 for the negative one
+            int c = ((mn > 0.0f) & (numz > 0.0f)) - ((mx < 0.0f) & (numz < 0.0f));
+            const bool tie = cand & ((mn == 0.0f) | (mx == 0.0f));
+            if (__builtin_amdgcn_ballot_w64(tie)) {
+                if (tie) c = crossing_with_ties<kSkipIncident>(s[Bq], s[Cq], s[A], e[Bq], e[Cq], e[A]);
             }
-            if (take) {
-                const int c = crossing(s[Bq], s[Cq], s[A], e[Bq], e[Cq], e[A]);
-                count += el.sign > 0.0f ? c : -c;
-            }
+            count += el.sign > 0.0f ? c : -c;
         }
     }
 }
@@ -190,76 +205,133 @@ __device__ __forceinline__ void ray_run(const RayElem* __restrict__ st, int off,
     }
 }
 
-// Crossing counts by walking the cluster tree.  Queries: the model's vertices in tree order (qperm != nullptr,
-// incident faces skipped) or arbitrary points [B,Q,3] in the caller's order (counts[b] of them real).  Grid and
-// body -> XCD mapping as winding_tree_kernel.  kCount: elements walked are added to stats[0] (measurement).
+// ---- which leaves can the rays of a 64-query block meet? -------------------------------------------------------------
+// A ray can only cross faces of a leaf whose 9-slab volume it meets.  Slabs whose functional does not change along
+// the ray (x, y, x+y, x-y in the sheared frame) bound the query from both sides, those that grow along it (z, x+z,
+// y+z) only from above, those that shrink (x-z, y-z) only from below.  One wavefront per (block, body):
+//   stage 1, lanes over LEAVES: the ranges of the block's 64 queries against every leaf's slabs (a superset);
+//   stage 2, lanes over QUERIES: the surviving leaves tested query by query (wave-uniform leaf, scalar loads).
+// Output: the strip ranges (ex_off, ex_len) of the leaves some ray of the block can meet, and how many.  No tree
+// descent: with ~215 leaves the flat test is four rounds of 64 lanes, and nothing in it waits on a parent's verdict.
+constexpr int kChunks = 8;                    // wavefronts per query block in ray_strips_kernel
+
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+
+template <bool kVerts>
+__global__ __launch_bounds__(64) void ray_near_kernel(
+    const float* __restrict__ pts, const TreeNode* __restrict__ nodes, const float* __restrict__ bounds, int N,
+    const int32_t* __restrict__ leaf_nodes, int num_leaves, const int32_t* __restrict__ qperm,
+    const int32_t* __restrict__ counts, int Q, int qblocks, int2* __restrict__ lists, int32_t* __restrict__ list_len)
+{
+    const int qb = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    int i0;
+    if (kVerts) {
+        i0 = qperm[qb * kRayQueries + lane];
+    } else {
+        const int n = counts ? counts[b] : Q;
+        if (qb * kRayQueries >= n) {
+            if (lane == 0) list_len[(size_t)b * qblocks + qb] = 0;
+            return;
+        }
+        i0 = min(qb * kRayQueries + lane, n - 1);
+    }
+    const float* q3 = pts + ((size_t)b * Q + i0) * 3;
+    const float qz = q3[2];
+    const float qx = shear_x(q3[0], qz), qy = shear_y(q3[1], qz);
+    const float q4 = qx + qy, q5 = qx - qy, q6 = qx + qz, q7 = qx - qz, q8 = qy + qz, q9 = qy - qz;
+    // ranges of the block (wave-uniform after the reductions)
+    const float bx0 = wave_min(qx), bx1 = wave_max(qx), by0 = wave_min(qy), by1 = wave_max(qy);
+    const float b40 = wave_min(q4), b41 = wave_max(q4), b50 = wave_min(q5), b51 = wave_max(q5);
+    const float bz0 = wave_min(qz), b60 = wave_min(q6), b71 = wave_max(q7), b80 = wave_min(q8), b91 = wave_max(q9);
+    const float* bb = bounds + (size_t)b * N * (2 * kSlabStride);
+    int2* list = lists + ((size_t)b * qblocks + qb) * num_leaves;
+    int cnt = 0;
+    for (int base = 0; base < num_leaves; base += 64) {
+        const int leaf = base + lane;
+        const int node = leaf_nodes[leaf < num_leaves ? leaf : num_leaves - 1];
+        const float* lo = bb + (size_t)node * (2 * kSlabStride);
+        const float* hi = lo + kSlabStride;
+        bool pass = leaf < num_leaves;
+        pass = pass && bx0 <= hi[0] && bx1 >= lo[0] && by0 <= hi[1] && by1 >= lo[1];
+        pass = pass && b40 <= hi[3] && b41 >= lo[3] && b50 <= hi[4] && b51 >= lo[4];
+        pass = pass && bz0 <= hi[2] && b60 <= hi[5] && b71 >= lo[6] && b80 <= hi[7] && b91 >= lo[8];
+        unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
+        while (mask) {
+            const int j = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const int nd = __builtin_amdgcn_readlane(node, j);
+            const float* l2 = bb + (size_t)nd * (2 * kSlabStride);
+            const float* h2 = l2 + kSlabStride;
+            float out = __builtin_fmaxf(l2[0] - qx, qx - h2[0]);
+            out = __builtin_fmaxf(out, __builtin_fmaxf(l2[1] - qy, qy - h2[1]));
+            out = __builtin_fmaxf(out, __builtin_fmaxf(l2[3] - q4, q4 - h2[3]));
+            out = __builtin_fmaxf(out, __builtin_fmaxf(l2[4] - q5, q5 - h2[4]));
+            out = __builtin_fmaxf(out, qz - h2[2]);
+            out = __builtin_fmaxf(out, q6 - h2[5]);
+            out = __builtin_fmaxf(out, l2[6] - q7);
+            out = __builtin_fmaxf(out, q8 - h2[7]);
+            out = __builtin_fmaxf(out, l2[8] - q9);
+            if (__builtin_amdgcn_ballot_w64(!(out > 0.0f))) {
+                const TreeNode t = nodes[nd];
+                if (lane == 0) list[cnt] = make_int2(t.ex_off, t.ex_len);
+                ++cnt;
+            }
+        }
+    }
+    if (lane == 0) list_len[(size_t)b * qblocks + qb] = cnt;
+}
+
+// Crossing counts: wavefront c of a query block walks the strips c, c + kChunks, ... of the block's list.  Queries:
+// the model's vertices in tree order (qperm != nullptr; faces around the query are skipped) or arbitrary points
+// [B,Q,3] in the caller's order (counts[b] of them real).  Grid (8, blocks x kChunks, B/8): workgroups go round-robin
+// to the 8 XCDs, so XCD x works on body 8 z + x (its 0.2 MB sheared stream stays in that L2).
+// kCount: elements walked are added to stats[0] (measurement).
 template <bool kVerts, bool kCount>
-__global__ __launch_bounds__(64) void ray_tree_kernel(
-    const float* __restrict__ pts, const RayElem* __restrict__ stream, const TreeNode* __restrict__ nodes,
-    const float* __restrict__ bounds, int N, const int32_t* __restrict__ frontier, const int32_t* __restrict__ order,
-    const int32_t* __restrict__ qperm, const int32_t* __restrict__ counts, int Q, int T, int nsub, int num_bodies,
-    int32_t* __restrict__ partial, unsigned long long* __restrict__ stats)
+__global__ __launch_bounds__(64) void ray_strips_kernel(
+    const float* __restrict__ pts, const RayElem* __restrict__ stream, const int2* __restrict__ lists,
+    const int32_t* __restrict__ list_len, int num_leaves, const int32_t* __restrict__ qperm,
+    const int32_t* __restrict__ counts, int Q, int T, int qblocks, int num_bodies, int32_t* __restrict__ partial,
+    unsigned long long* __restrict__ stats)
 {
     const int b = blockIdx.z * gridDim.x + blockIdx.x;
     if (b >= num_bodies) return;
-    int sub, qb, i0;
+    const int qb = blockIdx.y / kChunks, c = blockIdx.y % kChunks;
+    const int cnt = __builtin_amdgcn_readfirstlane(list_len[(size_t)b * qblocks + qb]);
+    if (c >= cnt) return;
+    int i0;
     if (kVerts) {
-        const int pair = __builtin_amdgcn_readfirstlane(order[blockIdx.y >> 1]);
-        sub = pair >> 16;
-        qb = (pair & 0xffff) * 2 + (blockIdx.y & 1);
         i0 = qperm[qb * kRayQueries + threadIdx.x];
     } else {
-        sub = blockIdx.y % nsub;
-        qb = blockIdx.y / nsub;
         const int n = counts ? counts[b] : Q;
-        if (qb * kRayQueries >= n) return;                        // padding of a ragged point set (partials preset to 0)
         i0 = min(qb * kRayQueries + (int)threadIdx.x, n - 1);
     }
     const float* q3 = pts + ((size_t)b * Q + i0) * 3;
     const float qz = q3[2];
     const float qx = shear_x(q3[0], qz), qy = shear_y(q3[1], qz);
     const RayElem* st = stream + (size_t)b * T;
-    const float* bb = bounds + (size_t)b * N * (2 * kSlabStride);
-    // can the +z ray of some query of the wavefront meet the node's volume?  Slabs whose functional does not
-    // change along the ray bound the query from both sides, those that grow (z, x+z, y+z) only from above, those
-    // that shrink (x-z, y-z) only from below.
-    const float q4 = qx + qy, q5 = qx - qy, q6 = qx + qz, q7 = qx - qz, q8 = qy + qz, q9 = qy - qz;
-    auto is_near = [&](int node) {
-        const float* lo = bb + (size_t)node * (2 * kSlabStride);
-        const float* hi = lo + kSlabStride;
-        float out = __builtin_fmaxf(lo[0] - qx, qx - hi[0]);
-        out = __builtin_fmaxf(out, __builtin_fmaxf(lo[1] - qy, qy - hi[1]));
-        out = __builtin_fmaxf(out, __builtin_fmaxf(lo[3] - q4, q4 - hi[3]));
-        out = __builtin_fmaxf(out, __builtin_fmaxf(lo[4] - q5, q5 - hi[4]));
-        out = __builtin_fmaxf(out, qz - hi[2]);
-        out = __builtin_fmaxf(out, q6 - hi[5]);
-        out = __builtin_fmaxf(out, lo[6] - q7);
-        out = __builtin_fmaxf(out, q8 - hi[7]);
-        out = __builtin_fmaxf(out, lo[8] - q9);
-        return __builtin_amdgcn_ballot_w64(!(out > 0.0f)) != 0;
-    };
+    const int2* list = lists + ((size_t)b * qblocks + qb) * num_leaves;
     P3 s[3];
     float e[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) { s[k].x = s[k].y = s[k].z = 0.0f; e[k] = 0.0f; }
     int count = 0, walked = 0;
-    int node = __builtin_amdgcn_readfirstlane(frontier[sub]);
-    const int end = __builtin_amdgcn_readfirstlane(nodes[node].skip);
-    while (node < end) {
-        const TreeNode nd = nodes[node];
-        if (!is_near(node)) {
-            node = nd.skip;
-        } else if (nd.ex_len == 0) {
-            node = node + 1;
-        } else {
-            ray_run<kVerts>(st, nd.ex_off, nd.ex_len, s, e, qx, qy, qz, count);
-            if (kCount) walked += nd.ex_len;
-            node = nd.skip;
-        }
-        node = __builtin_amdgcn_readfirstlane(node);
+    for (int j = c; j < cnt; j += kChunks) {
+        const int off = __builtin_amdgcn_readfirstlane(list[j].x), len = __builtin_amdgcn_readfirstlane(list[j].y);
+        ray_run<kVerts>(st, off, len, s, e, qx, qy, qz, count);
+        if (kCount) walked += len;
     }
-    const int qblocks = gridDim.y / nsub;
-    partial[((size_t)b * nsub + sub) * ((size_t)qblocks * kRayQueries) + qb * kRayQueries + threadIdx.x] = count;
+    partial[((size_t)b * kChunks + c) * ((size_t)qblocks * kRayQueries) + qb * kRayQueries + threadIdx.x] = count;
     if (kCount && threadIdx.x == 0) atomicAdd(stats, (unsigned long long)walked);
 }
 
@@ -281,15 +353,16 @@ __device__ __forceinline__ float half_solid_angle(const P3& a, const P3& b, cons
 // vertices: N = sum of the subtree counts + crossings of the closing fan; w = N - (sum of the fan's half angles) / (2 pi)
 __global__ __launch_bounds__(kBlock) void ray_finalize_verts_kernel(
     const float* __restrict__ verts, const int32_t* __restrict__ partial, const int32_t* __restrict__ qperm,
-    const int32_t* __restrict__ ring_off, const int32_t* __restrict__ ring_vidx, int V, int stride, int nsub,
-    float thresh, float* __restrict__ w_out, uint8_t* __restrict__ exterior)
+    const int32_t* __restrict__ ring_off, const int32_t* __restrict__ ring_vidx, const int32_t* __restrict__ list_len,
+    int V, int stride, float thresh, float* __restrict__ w_out, uint8_t* __restrict__ exterior)
 {
     const int b = blockIdx.y;
     const int i = blockIdx.x * kBlock + threadIdx.x;     // position in tree order
     if (i >= V) return;
     const int v = qperm[i];
     int n = 0;
-    for (int sp = 0; sp < nsub; ++sp) n += partial[((size_t)b * nsub + sp) * stride + i];
+    const int chunks = min(kChunks, list_len[(size_t)b * (stride / kRayQueries) + i / kRayQueries]);
+    for (int sp = 0; sp < chunks; ++sp) n += partial[((size_t)b * kChunks + sp) * stride + i];
     const float* vb = verts + (size_t)b * V * 3;
     const float vx = vb[3 * v], vy = vb[3 * v + 1], vz = vb[3 * v + 2];
     const float qx = shear_x(vx, vz), qy = shear_y(vy, vz);
@@ -319,15 +392,17 @@ __global__ __launch_bounds__(kBlock) void ray_finalize_verts_kernel(
 }
 
 __global__ __launch_bounds__(kBlock) void ray_finalize_points_kernel(
-    const int32_t* __restrict__ partial, const int32_t* __restrict__ counts, int Q, int stride, int nsub, float thresh,
-    float* __restrict__ w_out, uint8_t* __restrict__ exterior)
+    const int32_t* __restrict__ partial, const int32_t* __restrict__ counts, const int32_t* __restrict__ list_len,
+    int Q, int stride, float thresh, float* __restrict__ w_out, uint8_t* __restrict__ exterior)
 {
     const int b = blockIdx.y;
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= Q) return;
     int n = 0;
-    if (!counts || i < counts[b])
-        for (int sp = 0; sp < nsub; ++sp) n += partial[((size_t)b * nsub + sp) * stride + i];
+    if (!counts || i < counts[b]) {
+        const int chunks = min(kChunks, list_len[(size_t)b * (stride / kRayQueries) + i / kRayQueries]);
+        for (int sp = 0; sp < chunks; ++sp) n += partial[((size_t)b * kChunks + sp) * stride + i];
+    }
     const float w = (float)n;
     const size_t o = (size_t)b * Q + i;
     if (w_out) w_out[o] = w;
@@ -336,29 +411,7 @@ __global__ __launch_bounds__(kBlock) void ray_finalize_points_kernel(
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-struct RayLayout { size_t stream, bounds, partial, stats, total; int T, frontier, nsub, qblocks; };
-
-// smallest frontier (set of subtrees, one one-wave workgroup per subtree and query block) that gives enough
-// wavefronts to balance the uneven walks over 256 CUs x 32 wave slots
-int choose_frontier(const tuch_contact_model* m, int B, int qblocks)
-{
-    const char* env = getenv("TUCH_RAY_WAVES");
-    const long target = env ? atol(env) : 32768L;
-    int f = 0;
-    while (f + 1 < m->tree_num_frontiers &&
-           (long)B * qblocks * (m->tree_frontier_off_host[f + 1] - m->tree_frontier_off_host[f]) < target) ++f;
-    return f;
-}
-
-RayLayout ray_layout(const tuch_contact_model* m, int B, int Q, bool verts)
-{
-    RayLayout l;
-    l.T = 0;
-    l.qblocks = verts ? 2 * m->tree_qblocks : ceil_div(Q, kRayQueries);
-    l.frontier = choose_frontier(m, B, l.qblocks);
-    l.nsub = m->tree_frontier_off_host[l.frontier + 1] - m->tree_frontier_off_host[l.frontier];
-    return l;
-}
+struct RayLayout { size_t stream, bounds, partial, lists, list_len, stats, total; int T, qblocks; };
 
 }  // namespace
 
@@ -371,14 +424,17 @@ bool tuch_ray_available(const tuch_contact_model* m)
 
 static RayLayout full_layout(const tuch_contact_model* m, int B, int Q, bool verts)
 {
-    RayLayout l = ray_layout(m, B, Q, verts);
+    RayLayout l;
+    l.qblocks = verts ? 2 * m->tree_qblocks : ceil_div(Q, kRayQueries);
     // leaf strips are the first part of the tree stream; the caps behind them are never read
     l.T = ceil_div(m->tree_exact_len, 3) * 3 + 6;
     size_t o = 0;
-    l.stream = o;  o += align256((size_t)B * l.T * sizeof(RayElem));
-    l.bounds = o;  o += align256((size_t)B * m->tree_nodes * 2 * kSlabStride * sizeof(float));
-    l.partial = o; o += align256((size_t)B * l.nsub * l.qblocks * kRayQueries * sizeof(int32_t));
-    l.stats = o;   o += 256;
+    l.stream = o;   o += align256((size_t)B * l.T * sizeof(RayElem));
+    l.bounds = o;   o += align256((size_t)B * m->tree_nodes * 2 * kSlabStride * sizeof(float));
+    l.partial = o;  o += align256((size_t)B * kChunks * l.qblocks * kRayQueries * sizeof(int32_t));
+    l.lists = o;    o += align256((size_t)B * l.qblocks * m->tree_leaves * sizeof(int2));
+    l.list_len = o; o += align256((size_t)B * l.qblocks * sizeof(int32_t));
+    l.stats = o;    o += 256;
     l.total = o;
     return l;
 }
@@ -391,6 +447,7 @@ size_t tuch_ray_workspace_bytes(const tuch_contact_model* m, int B, int Q)
     return a > b ? a : b;
 }
 
+// sheared leaf strips and the slabs of every LEAF (inner nodes are not used by the flat near test)
 static void launch_ray_boxes(const tuch_contact_model* m, const RayLayout& l, const float* verts, int B, char* ws, hipStream_t s)
 {
     RayElem* st = (RayElem*)(ws + l.stream);
@@ -400,9 +457,6 @@ static void launch_ray_boxes(const tuch_contact_model* m, const RayLayout& l, co
     hipLaunchKernelGGL(ray_leaf_bounds_kernel, dim3(ceil_div(m->tree_leaves, kBoundsBlock / 64), B), dim3(kBoundsBlock), 0, s,
                        (const RayElem*)st, l.T, (const TreeNode*)m->tree_node, m->tree_nodes,
                        (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, bounds);
-    hipLaunchKernelGGL(tree_inner_bounds_kernel<kSlabStride>, dim3(B), dim3(kBoundsBlock),
-                       (size_t)m->tree_nodes * 2 * kSlabStride * sizeof(float), s, (const TreeNode*)m->tree_node, m->tree_nodes,
-                       (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, m->tree_heights, bounds);
 }
 
 int tuch_ray_exterior_verts(const tuch_contact_model* m, const float* verts, int B, float thresh, uint8_t* exterior,
@@ -411,30 +465,36 @@ int tuch_ray_exterior_verts(const tuch_contact_model* m, const float* verts, int
     const RayLayout l = full_layout(m, B, m->V, true);
     char* ws = (char*)workspace;
     launch_ray_boxes(m, l, verts, B, ws, s);
-    const int f0 = m->tree_frontier_off_host[l.frontier];
-    const dim3 grid(B < 8 ? B : 8, l.nsub * l.qblocks, ceil_div(B, 8));
-    const int32_t* frontier = (const int32_t*)m->tree_frontier_nodes + f0;
-    const int32_t* order = (const int32_t*)m->tree_launch_order + (size_t)f0 * m->tree_qblocks;
     int32_t* partial = (int32_t*)(ws + l.partial);
+    int2* lists = (int2*)(ws + l.lists);
+    int32_t* list_len = (int32_t*)(ws + l.list_len);
     unsigned long long* stats = (unsigned long long*)(ws + l.stats);
+    // the leaves are the height-0 entries of the tree's height table (tree_height_off_host[0] == 0)
+    const int32_t* leaf_nodes = (const int32_t*)m->tree_height_nodes;
+    hipLaunchKernelGGL(ray_near_kernel<true>, dim3(l.qblocks, B), dim3(64), 0, s, verts, (const TreeNode*)m->tree_node,
+                       (const float*)(ws + l.bounds), m->tree_nodes, leaf_nodes, m->tree_leaves, (const int32_t*)m->tree_qperm,
+                       (const int32_t*)nullptr, m->V, l.qblocks, lists, list_len);
+    const dim3 grid(B < 8 ? B : 8, l.qblocks * kChunks, ceil_div(B, 8));
     if (stats_host) {
         if (hipMemsetAsync(stats, 0, sizeof(unsigned long long), s) != hipSuccess) return TUCH_ERR_HIP;
-        hipLaunchKernelGGL((ray_tree_kernel<true, true>), grid, dim3(64), 0, s, verts, (const RayElem*)(ws + l.stream),
-                           (const TreeNode*)m->tree_node, (const float*)(ws + l.bounds), m->tree_nodes, frontier, order,
-                           (const int32_t*)m->tree_qperm, (const int32_t*)nullptr, m->V, l.T, l.nsub, B, partial, stats);
+        hipLaunchKernelGGL((ray_strips_kernel<true, true>), grid, dim3(64), 0, s, verts, (const RayElem*)(ws + l.stream),
+                           (const int2*)lists, (const int32_t*)list_len, m->tree_leaves, (const int32_t*)m->tree_qperm,
+                           (const int32_t*)nullptr, m->V, l.T, l.qblocks, B, partial, stats);
     } else {
-        hipLaunchKernelGGL((ray_tree_kernel<true, false>), grid, dim3(64), 0, s, verts, (const RayElem*)(ws + l.stream),
-                           (const TreeNode*)m->tree_node, (const float*)(ws + l.bounds), m->tree_nodes, frontier, order,
-                           (const int32_t*)m->tree_qperm, (const int32_t*)nullptr, m->V, l.T, l.nsub, B, partial, stats);
+        hipLaunchKernelGGL((ray_strips_kernel<true, false>), grid, dim3(64), 0, s, verts, (const RayElem*)(ws + l.stream),
+                           (const int2*)lists, (const int32_t*)list_len, m->tree_leaves, (const int32_t*)m->tree_qperm,
+                           (const int32_t*)nullptr, m->V, l.T, l.qblocks, B, partial, stats);
     }
-    hipLaunchKernelGGL(ray_finalize_verts_kernel, dim3(ceil_div(m->V, kBlock), B), dim3(kBlock), 0, s, verts,
-                       (const int32_t*)partial, (const int32_t*)m->tree_qperm, (const int32_t*)m->ring_off,
-                       (const int32_t*)m->ring_vidx, m->V, l.qblocks * kRayQueries, l.nsub, thresh, w, exterior);
+    if (w || exterior)
+        hipLaunchKernelGGL(ray_finalize_verts_kernel, dim3(ceil_div(m->V, kBlock), B), dim3(kBlock), 0, s, verts,
+                           (const int32_t*)partial, (const int32_t*)m->tree_qperm, (const int32_t*)m->ring_off,
+                           (const int32_t*)m->ring_vidx, (const int32_t*)list_len, m->V, l.qblocks * kRayQueries, thresh, w,
+                           exterior);
     if (stats_host) {
         if (hipMemcpyAsync(stats_host, stats, sizeof(unsigned long long), hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipStreamSynchronize(s) != hipSuccess)
             return TUCH_ERR_HIP;
-        stats_host[1] = (unsigned long long)B * l.nsub * l.qblocks;
+        stats_host[1] = (unsigned long long)B * l.qblocks * kChunks;
     }
     return tuch_check_launch("tuch_ray_exterior_verts");
 }
@@ -445,18 +505,16 @@ int tuch_ray_exterior_points(const tuch_contact_model* m, const float* verts, co
     const RayLayout l = full_layout(m, B, Q, false);
     char* ws = (char*)workspace;
     int32_t* partial = (int32_t*)(ws + l.partial);
-    const int stride = l.qblocks * kRayQueries;
-    if (counts && hipMemsetAsync(partial, 0, (size_t)B * l.nsub * stride * sizeof(int32_t), s) != hipSuccess) {
-        tuch_set_error("tuch_ray_exterior_points: hipMemsetAsync failed");
-        return TUCH_ERR_HIP;
-    }
+    int2* lists = (int2*)(ws + l.lists);
+    int32_t* list_len = (int32_t*)(ws + l.list_len);
     launch_ray_boxes(m, l, verts, B, ws, s);
-    const int f0 = m->tree_frontier_off_host[l.frontier];
-    hipLaunchKernelGGL((ray_tree_kernel<false, false>), dim3(B < 8 ? B : 8, l.nsub * l.qblocks, ceil_div(B, 8)), dim3(64), 0, s,
-                       points, (const RayElem*)(ws + l.stream), (const TreeNode*)m->tree_node, (const float*)(ws + l.bounds),
-                       m->tree_nodes, (const int32_t*)m->tree_frontier_nodes + f0, (const int32_t*)nullptr,
-                       (const int32_t*)nullptr, counts, Q, l.T, l.nsub, B, partial, (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(ray_near_kernel<false>, dim3(l.qblocks, B), dim3(64), 0, s, points, (const TreeNode*)m->tree_node,
+                       (const float*)(ws + l.bounds), m->tree_nodes, (const int32_t*)m->tree_height_nodes, m->tree_leaves,
+                       (const int32_t*)nullptr, counts, Q, l.qblocks, lists, list_len);
+    hipLaunchKernelGGL((ray_strips_kernel<false, false>), dim3(B < 8 ? B : 8, l.qblocks * kChunks, ceil_div(B, 8)), dim3(64), 0, s,
+                       points, (const RayElem*)(ws + l.stream), (const int2*)lists, (const int32_t*)list_len, m->tree_leaves,
+                       (const int32_t*)nullptr, counts, Q, l.T, l.qblocks, B, partial, (unsigned long long*)nullptr);
     hipLaunchKernelGGL(ray_finalize_points_kernel, dim3(ceil_div(Q, kBlock), B), dim3(kBlock), 0, s,
-                       (const int32_t*)partial, counts, Q, stride, l.nsub, thresh, w, exterior);
+                       (const int32_t*)partial, counts, (const int32_t*)list_len, Q, l.qblocks * kRayQueries, thresh, w, exterior);
     return tuch_check_launch("tuch_ray_exterior_points");
 }

@@ -1071,6 +1071,22 @@ extern "C" int tuch_winding_tree_work(const tuch_contact_model* m, const float* 
     return tuch_check_launch("tuch_winding_tree_work");
 }
 
+// Measurement aid for the ray-crossing inside test (ray_winding.hip): out_host = {strip elements walked by all
+// wavefronts (64 queries each), wavefronts launched}.  Synchronises the stream.
+extern "C" int tuch_ray_work(const tuch_contact_model* m, const float* verts, int B, void* workspace,
+                             size_t workspace_bytes, unsigned long long* out_host, void* stream)
+{
+    TUCH_REQUIRE(m && verts && out_host, "tuch_ray_work: null pointer");
+    TUCH_REQUIRE(tuch_ray_available(m), "tuch_ray_work: the model has no cluster tree / vertex rings");
+    TUCH_REQUIRE(B > 0 && B <= 65535, "tuch_ray_work: bad batch %d", B);
+    const ExteriorLayout l = exterior_layout(m, B);
+    if (!workspace || workspace_bytes < l.total) {
+        tuch_set_error("tuch_ray_work: workspace %zu < %zu bytes", workspace_bytes, l.total);
+        return TUCH_ERR_WORKSPACE;
+    }
+    return tuch_ray_exterior_verts(m, verts, B, 0.99f, nullptr, nullptr, (char*)workspace + l.ray, (hipStream_t)stream, out_host);
+}
+
 // winding numbers of ARBITRARY query points against the model's mesh posed by `verts`
 // (tuch/train/loss.py:297: HD points offset along the face normals).  points [B,Q,3]; counts [B]
 // (device, optional) = number of meaningful points per body when the set is ragged and padded

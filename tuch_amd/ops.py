@@ -497,6 +497,17 @@ class ContactModel:
                     flat_stream_elements=int(out[3]), queries_per_step=64,
                     query_blocks=-(-self.num_verts // 128) * 2 * b)
 
+    def ray_work(self, verts: torch.Tensor) -> dict:
+        """Strip elements the ray-crossing inside test steps through for these vertices (measurement aid)."""
+        verts = _f32(verts)
+        b = verts.shape[0]
+        L = _C.lib()
+        nbytes = L.tuch_exterior_workspace_bytes(self._handle, b)
+        ws = _workspace(nbytes, verts.device)
+        out = (ctypes.c_ulonglong * 2)()
+        _C.check(L.tuch_ray_work(self._handle, _C.ptr(verts), b, _C.ptr(ws), nbytes, out, _C.stream()))
+        return dict(elements=int(out[0]), wavefronts=int(out[1]), queries_per_step=64)
+
     # K2 + K3
     def exterior_flags(self, verts: torch.Tensor, apply_segments: bool = True, thresh: float = 0.99,
                        return_details: bool = False):
