@@ -180,7 +180,10 @@ __device__ __forceinline__ void ray_step(const RayElem el, P3 (&s)[3], float (&e
             // generic position: all edge functions of one sign; the hit is in front iff det has that sign, and the
             // crossing is +1 (leaving through the front) for the positive orientation, -1 for the negative one
             int c = ((mn > 0.0f) & (numz > 0.0f)) - ((mx < 0.0f) & (numz < 0.0f));
-            const bool tie = cand & ((mn == 0.0f) | (mx == 0.0f));
+            // exact ties.  The faces around a query vertex (two edge functions through the origin) always tie, but
+            // their det is exactly 0 (the zero corner), so the generic form already counts them as 0: the careful form
+            // is only needed where det != 0, i.e. for rays through an edge or a corner of some OTHER triangle
+            const bool tie = cand & ((mn == 0.0f) | (mx == 0.0f)) & (numz != 0.0f);
             if (__builtin_amdgcn_ballot_w64(tie)) {
                 if (tie) c = crossing_with_ties<kSkipIncident>(s[Bq], s[Cq], s[A], e[Bq], e[Cq], e[A]);
             }
@@ -213,7 +216,7 @@ __device__ __forceinline__ void ray_run(const RayElem* __restrict__ st, int off,
 //   stage 2, lanes over QUERIES: the surviving leaves tested query by query (wave-uniform leaf, scalar loads).
 // Output: the strip ranges (ex_off, ex_len) of the leaves some ray of the block can meet, and how many.  No tree
 // descent: with ~215 leaves the flat test is four rounds of 64 lanes, and nothing in it waits on a parent's verdict.
-constexpr int kChunks = 8;                    // wavefronts per query block in ray_strips_kernel
+constexpr int kMaxChunks = 16;                // most wavefronts per query block in ray_strips_kernel (TUCH_RAY_CHUNKS, default 8)
 
 __device__ __forceinline__ float wave_min(float v)
 {
@@ -301,8 +304,8 @@ template <bool kVerts, bool kCount>
 __global__ __launch_bounds__(64) void ray_strips_kernel(
     const float* __restrict__ pts, const RayElem* __restrict__ stream, const int2* __restrict__ lists,
     const int32_t* __restrict__ list_len, int num_leaves, const int32_t* __restrict__ qperm,
-    const int32_t* __restrict__ counts, int Q, int T, int qblocks, int num_bodies, int32_t* __restrict__ partial,
-    unsigned long long* __restrict__ stats)
+    const int32_t* __restrict__ counts, int Q, int T, int qblocks, int num_bodies, int kChunks,
+    int32_t* __restrict__ partial, unsigned long long* __restrict__ stats)
 {
     const int b = blockIdx.z * gridDim.x + blockIdx.x;
     if (b >= num_bodies) return;
@@ -335,7 +338,29 @@ __global__ __launch_bounds__(64) void ray_strips_kernel(
     if (kCount && threadIdx.x == 0) atomicAdd(stats, (unsigned long long)walked);
 }
 
-// half solid angle atan2(num, den) of the triangle with corner vectors a, b, c (contact.py:79-105), precise atan2
+// atan2 with a degree-8 minimax atan on [0,1] (max abs error 1e-7), octant fix-up; atan2(0,0) = 0
+__device__ __forceinline__ float fast_atan2(float y, float x)
+{
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    const float mx = __builtin_fmaxf(__builtin_fmaxf(ax, ay), 1e-37f);
+    const float t = __builtin_fminf(ax, ay) / mx;
+    const float s = t * t;
+    float p = 0.0024567253421992064f;
+    p = p * s + -0.014401361346244812f;
+    p = p * s + 0.03978123143315315f;
+    p = p * s + -0.07234857976436615f;
+    p = p * s + 0.10498946160078049f;
+    p = p * s + -0.14161229133605957f;
+    p = p * s + 0.19985906779766083f;
+    p = p * s + -0.33332598209381104f;
+    p = p * s + 0.9999998807907104f;
+    float v = p * t;
+    v = ay > ax ? 1.57079632679489661923f - v : v;
+    v = x < 0.0f ? kPi - v : v;
+    return __builtin_copysignf(v, y);
+}
+
+// half solid angle atan2(num, den) of the triangle with corner vectors a, b, c (contact.py:79-105)
 __device__ __forceinline__ float half_solid_angle(const P3& a, const P3& b, const P3& c)
 {
     const float na = __builtin_sqrtf(a.x * a.x + a.y * a.y + a.z * a.z);
@@ -347,14 +372,14 @@ __device__ __forceinline__ float half_solid_angle(const P3& a, const P3& b, cons
     const float dbc = b.x * c.x + b.y * c.y + b.z * c.z;
     const float dac = a.x * c.x + a.y * c.y + a.z * c.z;
     const float den = na * nb * nc + dab * nc + dac * nb + dbc * na;
-    return atan2f(num, den);
+    return fast_atan2(num, den);
 }
 
 // vertices: N = sum of the subtree counts + crossings of the closing fan; w = N - (sum of the fan's half angles) / (2 pi)
 __global__ __launch_bounds__(kBlock) void ray_finalize_verts_kernel(
     const float* __restrict__ verts, const int32_t* __restrict__ partial, const int32_t* __restrict__ qperm,
     const int32_t* __restrict__ ring_off, const int32_t* __restrict__ ring_vidx, const int32_t* __restrict__ list_len,
-    int V, int stride, float thresh, float* __restrict__ w_out, uint8_t* __restrict__ exterior)
+    int V, int stride, int kChunks, float thresh, float* __restrict__ w_out, uint8_t* __restrict__ exterior)
 {
     const int b = blockIdx.y;
     const int i = blockIdx.x * kBlock + threadIdx.x;     // position in tree order
@@ -393,7 +418,7 @@ __global__ __launch_bounds__(kBlock) void ray_finalize_verts_kernel(
 
 __global__ __launch_bounds__(kBlock) void ray_finalize_points_kernel(
     const int32_t* __restrict__ partial, const int32_t* __restrict__ counts, const int32_t* __restrict__ list_len,
-    int Q, int stride, float thresh, float* __restrict__ w_out, uint8_t* __restrict__ exterior)
+    int Q, int stride, int kChunks, float thresh, float* __restrict__ w_out, uint8_t* __restrict__ exterior)
 {
     const int b = blockIdx.y;
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -422,6 +447,13 @@ bool tuch_ray_available(const tuch_contact_model* m)
     return !e || atoi(e) != 0;
 }
 
+static int ray_chunks()
+{
+    const char* e = getenv("TUCH_RAY_CHUNKS");
+    const int c = e ? atoi(e) : 8;
+    return c < 1 ? 1 : (c > kMaxChunks ? kMaxChunks : c);
+}
+
 static RayLayout full_layout(const tuch_contact_model* m, int B, int Q, bool verts)
 {
     RayLayout l;
@@ -431,7 +463,7 @@ static RayLayout full_layout(const tuch_contact_model* m, int B, int Q, bool ver
     size_t o = 0;
     l.stream = o;   o += align256((size_t)B * l.T * sizeof(RayElem));
     l.bounds = o;   o += align256((size_t)B * m->tree_nodes * 2 * kSlabStride * sizeof(float));
-    l.partial = o;  o += align256((size_t)B * kChunks * l.qblocks * kRayQueries * sizeof(int32_t));
+    l.partial = o;  o += align256((size_t)B * kMaxChunks * l.qblocks * kRayQueries * sizeof(int32_t));
     l.lists = o;    o += align256((size_t)B * l.qblocks * m->tree_leaves * sizeof(int2));
     l.list_len = o; o += align256((size_t)B * l.qblocks * sizeof(int32_t));
     l.stats = o;    o += 256;
@@ -474,21 +506,22 @@ int tuch_ray_exterior_verts(const tuch_contact_model* m, const float* verts, int
     hipLaunchKernelGGL(ray_near_kernel<true>, dim3(l.qblocks, B), dim3(64), 0, s, verts, (const TreeNode*)m->tree_node,
                        (const float*)(ws + l.bounds), m->tree_nodes, leaf_nodes, m->tree_leaves, (const int32_t*)m->tree_qperm,
                        (const int32_t*)nullptr, m->V, l.qblocks, lists, list_len);
+    const int kChunks = ray_chunks();
     const dim3 grid(B < 8 ? B : 8, l.qblocks * kChunks, ceil_div(B, 8));
     if (stats_host) {
         if (hipMemsetAsync(stats, 0, sizeof(unsigned long long), s) != hipSuccess) return TUCH_ERR_HIP;
         hipLaunchKernelGGL((ray_strips_kernel<true, true>), grid, dim3(64), 0, s, verts, (const RayElem*)(ws + l.stream),
                            (const int2*)lists, (const int32_t*)list_len, m->tree_leaves, (const int32_t*)m->tree_qperm,
-                           (const int32_t*)nullptr, m->V, l.T, l.qblocks, B, partial, stats);
+                           (const int32_t*)nullptr, m->V, l.T, l.qblocks, B, kChunks, partial, stats);
     } else {
         hipLaunchKernelGGL((ray_strips_kernel<true, false>), grid, dim3(64), 0, s, verts, (const RayElem*)(ws + l.stream),
                            (const int2*)lists, (const int32_t*)list_len, m->tree_leaves, (const int32_t*)m->tree_qperm,
-                           (const int32_t*)nullptr, m->V, l.T, l.qblocks, B, partial, stats);
+                           (const int32_t*)nullptr, m->V, l.T, l.qblocks, B, kChunks, partial, stats);
     }
     if (w || exterior)
         hipLaunchKernelGGL(ray_finalize_verts_kernel, dim3(ceil_div(m->V, kBlock), B), dim3(kBlock), 0, s, verts,
                            (const int32_t*)partial, (const int32_t*)m->tree_qperm, (const int32_t*)m->ring_off,
-                           (const int32_t*)m->ring_vidx, (const int32_t*)list_len, m->V, l.qblocks * kRayQueries, thresh, w,
+                           (const int32_t*)m->ring_vidx, (const int32_t*)list_len, m->V, l.qblocks * kRayQueries, kChunks, thresh, w,
                            exterior);
     if (stats_host) {
         if (hipMemcpyAsync(stats_host, stats, sizeof(unsigned long long), hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -511,10 +544,11 @@ int tuch_ray_exterior_points(const tuch_contact_model* m, const float* verts, co
     hipLaunchKernelGGL(ray_near_kernel<false>, dim3(l.qblocks, B), dim3(64), 0, s, points, (const TreeNode*)m->tree_node,
                        (const float*)(ws + l.bounds), m->tree_nodes, (const int32_t*)m->tree_height_nodes, m->tree_leaves,
                        (const int32_t*)nullptr, counts, Q, l.qblocks, lists, list_len);
+    const int kChunks = ray_chunks();
     hipLaunchKernelGGL((ray_strips_kernel<false, false>), dim3(B < 8 ? B : 8, l.qblocks * kChunks, ceil_div(B, 8)), dim3(64), 0, s,
                        points, (const RayElem*)(ws + l.stream), (const int2*)lists, (const int32_t*)list_len, m->tree_leaves,
-                       (const int32_t*)nullptr, counts, Q, l.T, l.qblocks, B, partial, (unsigned long long*)nullptr);
+                       (const int32_t*)nullptr, counts, Q, l.T, l.qblocks, B, kChunks, partial, (unsigned long long*)nullptr);
     hipLaunchKernelGGL(ray_finalize_points_kernel, dim3(ceil_div(Q, kBlock), B), dim3(kBlock), 0, s,
-                       (const int32_t*)partial, counts, (const int32_t*)list_len, Q, l.qblocks * kRayQueries, thresh, w, exterior);
+                       (const int32_t*)partial, counts, (const int32_t*)list_len, Q, l.qblocks * kRayQueries, kChunks, thresh, w, exterior);
     return tuch_check_launch("tuch_ray_exterior_points");
 }
