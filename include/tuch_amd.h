@@ -267,6 +267,36 @@ int tuch_estimate_translation(const float* joints3d, const float* keypoints2d, c
                               float focal_length, float img_size, float* trans, void* stream);
 int tuch_rotmat_to_angle_axis(const float* rotmat, int N, int row_stride, float* angle_axis, void* stream);
 
+/* ---- the HD-mesh branch of RegressorLoss.contact_loss, tuch/train/loss.py:274-301, as one device pipeline ----
+ * (csrc/hd_contact.hip).  tuch_hd_model holds the HD vertex regressor (loss.py:81-83) as its three non-zeros per
+ * row -- hd_idx / hd_w [N,3] -- and faces_vert_is_sampled_from (loss.py:85-87) -- hd_face [N]; all host arrays, copied.
+ * It refers to the contact model (faces, geodesic mask, cluster tree), which must outlive it.  Point order is the
+ * library's business (the loss is a sum over the points): tuch_hd_model_info reports it (order_host[k] = caller's
+ * index of the k-th point). */
+typedef struct tuch_hd_model tuch_hd_model;
+int tuch_hd_model_create(tuch_hd_model** out, const tuch_contact_model* contact_model, int N, const int32_t* hd_idx,
+                         const float* hd_w, const int32_t* hd_face);
+void tuch_hd_model_destroy(tuch_hd_model* model);
+int tuch_hd_model_info(const tuch_hd_model* model, int* N, int32_t* order_host);
+/* One call = loss.py:274-315 for the whole batch: exterior [B,V] u8, min_d2 [B,V], partner [B,V] int32 are the
+ * vertex-level results for the same verts [B,V,3] (tuch_exterior_flags with the segment filter, tuch_v2v_min_model);
+ * valid [B] u8 or NULL.  terms [B,2] = (sum over interior HD points of tanh^2(d/0.04), sum over exterior ones of
+ * 0.005 tanh^2(d/0.005)); bodies with valid == 0 or without a selected point give (0, 0).  thresh = 0.99.
+ * `saved` (tuch_hd_contact_saved_bytes, caller-owned, opaque) carries the selection to tuch_hd_contact_bwd, which
+ * OVERWRITES grad_verts [B,V,3] with d(sum_b grad_terms[b,:] . terms[b,:]) / d verts.  All buffers are sized for the
+ * worst case (every HD point selected); the actual counts never leave the device: no synchronisation, no allocation. */
+size_t tuch_hd_contact_saved_bytes(const tuch_hd_model* model, int B);
+size_t tuch_hd_contact_workspace_bytes(const tuch_hd_model* model, int B);
+int tuch_hd_contact_fwd(const tuch_hd_model* model, const float* verts, const uint8_t* exterior, const float* min_d2,
+                        const int32_t* partner, const uint8_t* valid, int B, float euclthres, float thresh, float* terms,
+                        void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes, void* stream);
+int tuch_hd_contact_bwd(const tuch_hd_model* model, const void* saved, const float* grad_terms, int B,
+                        float* grad_verts, void* workspace, size_t workspace_bytes, void* stream);
+/* inspection (tests; synchronous copies): counts_host [B]; selected_host [B,N] = caller-order index of the point in
+ * every slot, -1 beyond the count (or NULL) */
+int tuch_hd_contact_selection(const tuch_hd_model* model, const void* saved, int B, int32_t* counts_host,
+                              int32_t* selected_host);
+
 /* HD points of tuch/train/loss.py:285 (hd = Vert_Regressor[selected] @ verts, a dense [N_hd,6890] matrix with three
  * non-zeros per row): point n belongs to body body_of_point[n] and is HD point hd_of_point[n];
  * points[n] = sum_k hd_w[h][k] * verts[body][hd_idx[h][k]].  verts [B,V,3], hd_idx / hd_w [N_hd,3], points [N,3].

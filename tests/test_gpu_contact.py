@@ -793,3 +793,64 @@ def test_ray_crossing_flags_of_points_match_the_solid_angle_sums(tag, monkeypatc
     assert np.abs(w_r - w_s).max() < 1e-3
     assert torch.equal(ext_r, ext_s)
     assert len(np.unique(w_r)) >= 2                                                # inside and outside points both occur
+
+
+@pytest.mark.parametrize('tag', ['small', 'medium'])
+def test_hd_branch_selection_partners_and_graph_capture(tag):
+    """The fused HD branch (csrc/hd_contact.hip): the selected HD points of every body are exactly those of the
+    restated reference (loss.py:278-281); an invalid body selects nothing; the whole contact_loss(use_hd=True) runs
+    without host synchronisation, so it can be captured in a hipGraph, and the replay reproduces loss and gradient."""
+    import types
+    from tuch_amd.train.loss import RegressorLoss
+    from tuch_amd.utils.segmentation import BatchBodySegment
+    g, gm = golden(tag), golden_mask(tag)
+    d = dev()
+    batch = g['verts'].shape[0]
+    face_tensor = torch.tensor(g['faces'], device=d)[None].repeat(batch, 1, 1)
+    segs = gio.unpack_segments(g)
+    crit = RegressorLoss(types.SimpleNamespace(contact_loss_weight=1.0), d, g['verts'].shape[1], face_tensor,
+                         torch.tensor(np.where(gm, 1.0, 0.0).astype(np.float32), device=d), geothres=0.3,
+                         euclthres=float(g['euclthres']), face_tensor=face_tensor, use_hd=True,
+                         segments=BatchBodySegment(list(segs.keys()), face_tensor[0], segs),
+                         hd_regressor=(g['hd_idx'], g['hd_w']), hd_faces=g['hd_face'])
+    verts = torch.tensor(g['verts'], device=d, requires_grad=True)
+    valid = torch.tensor(g['valid_fit'], device=d)
+    loss = crit.contact_loss(verts, valid)
+    loss.backward()
+    counts, sel = crit._hd.selection(crit._hd.last_saved, batch)
+    osegs = oracle_segments(g)
+    for b in range(batch):
+        if not g['valid_fit'][b]:
+            assert counts[b] == 0
+            continue
+        r = oc.train_contact_body(g['verts'][b], g['faces'], gm, float(g['euclthres']), osegs, True,
+                                  hd_idx=g['hd_idx'], hd_w=g['hd_w'], hd_face=g['hd_face'])
+        want = np.where(r['hd_sel'])[0]
+        got = np.sort(sel[b, :counts[b]])
+        assert (sel[b, counts[b]:] == -1).all()
+        assert np.array_equal(got, want), (b, len(got), len(want))
+    # hipGraph capture of forward + backward
+    static_v = torch.tensor(g['verts'], device=d, requires_grad=True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            static_v.grad = None
+            crit.contact_loss(static_v, valid).backward()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    static_v.grad = None
+    with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+        out = crit.contact_loss(static_v, valid)
+        out.backward()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert abs(out.item() - loss.item()) <= 1e-6 * abs(loss.item())
+    assert torch.allclose(static_v.grad, verts.grad, rtol=1e-4, atol=1e-6 * float(verts.grad.abs().max()))
+    # new vertices through the same graph
+    with torch.no_grad():
+        static_v.copy_(torch.tensor(g['verts'], device=d).flip(0))
+    graph.replay()
+    flipped = torch.tensor(g['verts'], device=d).flip(0).requires_grad_(True)
+    want2 = crit.contact_loss(flipped, valid)
+    assert abs(out.item() - want2.item()) <= 1e-5 * abs(want2.item()) + 1e-7

@@ -62,6 +62,15 @@ _SIGNATURES = {
     'tuch_estimate_translation': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p]),
     'tuch_rotmat_to_angle_axis': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'tuch_winding_tree_work': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
+    'tuch_hd_model_create': (c_int, [POINTER(c_void_p), c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    'tuch_hd_model_destroy': (None, [c_void_p]),
+    'tuch_hd_model_info': (c_int, [c_void_p, POINTER(c_int), c_void_p]),
+    'tuch_hd_contact_saved_bytes': (c_size_t, [c_void_p, c_int]),
+    'tuch_hd_contact_workspace_bytes': (c_size_t, [c_void_p, c_int]),
+    'tuch_hd_contact_fwd': (c_int, [c_void_p] * 6 + [c_int, c_float, c_float, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t,
+                                    c_void_p]),
+    'tuch_hd_contact_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'tuch_hd_contact_selection': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     'tuch_ray_work': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     'tuch_contact_model_tree_order': (c_int, [c_void_p, c_void_p, c_void_p]),
     'tuch_v2v_model_workspace_bytes': (c_size_t, [c_void_p, c_int]),

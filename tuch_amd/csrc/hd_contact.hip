@@ -1,0 +1,526 @@
+// The HD-mesh branch of RegressorLoss.contact_loss (tuch/train/loss.py:274-301) as one device pipeline.
+//
+// Reference, per valid body: vertices in contact or inside (:278) -> faces touching them (:279-280, a
+// [3F x n_c] boolean broadcast) -> HD points sampled from those faces (:281, an [N_hd x n_f] broadcast) ->
+// positions = dense regressor rows x vertices (:285) -> masked nearest HD point (:288-291, n x n) -> inside test
+// of the points moved 1 mm along their face normals (:295-297, n x F x 3 x 3) -> pull / push terms (:299-315).
+//
+// Here: a persistent tuch_hd_model holds the regressor as its three non-zeros per row, the points sorted by the
+// surface patch (cluster-tree leaf) of their face, and two CSR tables (vertex -> the HD points it supports, for the
+// adjoint; template vertex -> its HD points, for the search seeds).  Every call is a fixed sequence of kernels over
+// buffers of the worst-case size (every HD point selected), the actual counts stay on the device: no host
+// synchronisation, no allocation, capturable in a hipGraph.
+//   hd_select   flags per face (LDS) -> selected points of each body compacted in order (block scan) + slot table
+//   hd_points   positions, positions + 1 mm normal, mask ids of the selected points
+//   hd_seed     a first admissible partner: the HD points that hang on the vertex-level partner of the point's
+//               template vertex -- near-final bounds for the search (any real admissible row is a valid seed)
+//   search      v2v_indexed_kernel (v2v.hip) with counts + seeds
+//   inside      tuch_winding_points: integer ray-crossing counts (ray_winding.hip), or the solid-angle walk
+//   hd_terms    pull / push sums per body, fixed-order reduction
+// Adjoint: point gradients (the partner side through float atomics on the points, low contention) and then a
+// GATHER per vertex over the CSR table -- no atomics on the vertices, where ~18 point corners meet.
+#include "common.h"
+#include "model.h"
+#include <algorithm>
+#include <numeric>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+struct tuch_hd_model {
+    const tuch_contact_model* cm;
+    int N, V, F;
+    int32_t* idx;        // [N,3] supporting vertices (sorted order)
+    float* w;            // [N,3] barycentric weights
+    int32_t* face;       // [N] face the point was sampled from (loss.py:87 faces_vert_is_sampled_from)
+    int32_t* tv;         // [N] template vertex = first vertex of that face (loss.py:88 geovec_verts)
+    int32_t* mask_id;    // [N] row / column of the geodesic mask the point inherits: tv, or its position in tree order
+    int32_t* orig;       // [N] index of the point in the caller's order
+    int32_t* v_off;      // [V+1] CSR: vertex -> entries (point * 4 + corner)
+    int32_t* v_ent;
+    int32_t* tv_off;     // [V+1] CSR: template vertex -> points
+    int32_t* tv_pts;
+    int32_t* offsets;    // [B_max+1] = b * N (device), grown on demand? fixed: built for kMaxBatch
+    int tree_order;      // mask ids are tree positions (the model's mask in tree order is used)
+    std::vector<int32_t>* order_host;   // sorted -> original index
+};
+
+namespace {
+
+constexpr int kMaxBatch = 4096;
+constexpr int kSel = 1024;
+
+template <typename T>
+int upload(T** dst, const T* src, size_t count)
+{
+    *dst = nullptr;
+    if (count == 0) return TUCH_OK;
+    if (hipMalloc((void**)dst, count * sizeof(T)) != hipSuccess ||
+        hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) {
+        tuch_set_error("tuch_hd_model_create: device allocation / copy of %zu bytes failed", count * sizeof(T));
+        return TUCH_ERR_HIP;
+    }
+    return TUCH_OK;
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// ---- selection (loss.py:278-281) -------------------------------------------------------------------------------
+// one workgroup per body: candidate vertices -> face flags in LDS -> selected HD points compacted in their order
+__global__ __launch_bounds__(kSel) void hd_select_kernel(
+    const uint8_t* __restrict__ exterior, const float* __restrict__ min_d2, const uint8_t* __restrict__ valid,
+    const int32_t* __restrict__ faces, const int32_t* __restrict__ hd_face, const int32_t* __restrict__ hd_orig,
+    int V, int F, int N, float eucl2, int32_t* __restrict__ sel, int32_t* __restrict__ slot,
+    int32_t* __restrict__ counts, int32_t* __restrict__ first_slot)
+{
+    extern __shared__ uint8_t face_flag[];           // [F]
+    __shared__ int wave_sum[kSel / 64];
+    __shared__ int base_s;
+    __shared__ unsigned long long first_key;          // (original index << 32 | slot) of the selected point that is first in the caller's order
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool body_ok = !valid || valid[b];
+    const uint8_t* ext = exterior + (size_t)b * V;
+    const float* md = min_d2 + (size_t)b * V;
+    for (int f = tid; f < F; f += kSel) {
+        bool any = false;
+        if (body_ok) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int v = faces[3 * f + k];
+                any = any || (md[v] < eucl2) || (ext[v] == 0);           // :278
+            }
+        }
+        face_flag[f] = any;
+    }
+    if (tid == 0) { base_s = 0; first_key = ~0ull; }
+    __syncthreads();
+    int32_t* sel_b = sel + (size_t)b * N;
+    int32_t* slot_b = slot + (size_t)b * N;
+    for (int n0 = 0; n0 < N; n0 += kSel) {
+        const int n = n0 + tid;
+        const bool take = n < N && face_flag[hd_face[n]];                 // :281
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(take);
+        const int before = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_sum[wave] = __builtin_popcountll(m);
+        __syncthreads();
+        int wbase = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < kSel / 64; ++k) {
+            const int c = wave_sum[k];
+            wbase += k < wave ? c : 0;
+            total += c;
+        }
+        const int base = base_s;
+        if (n < N) {
+            const int s = take ? base + wbase + before : -1;
+            slot_b[n] = s;
+            if (take) {
+                sel_b[s] = n;
+                atomicMin(&first_key, ((unsigned long long)(uint32_t)hd_orig[n] << 32) | (uint32_t)s);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) base_s = base + total;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        counts[b] = base_s;
+        first_slot[b] = base_s > 0 ? (int32_t)(first_key & 0xffffffffu) : 0;
+    }
+}
+
+// ---- positions (loss.py:285, :295-296) ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hd_points_kernel(
+    const float* __restrict__ verts, const int32_t* __restrict__ sel, const int32_t* __restrict__ counts,
+    const int32_t* __restrict__ idx, const float* __restrict__ w, const int32_t* __restrict__ hd_face,
+    const int32_t* __restrict__ faces, const int32_t* __restrict__ mask_id, int V, int N,
+    float* __restrict__ pts, float* __restrict__ offs, int32_t* __restrict__ vid)
+{
+    const int b = blockIdx.y;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= counts[b]) return;
+    const size_t o = (size_t)b * N + k;
+    const int n = sel[o];
+    const float* vb = verts + (size_t)b * V * 3;
+    float x = 0.f, y = 0.f, z = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float wc = w[3 * (size_t)n + c];
+        const float* p = vb + 3 * (size_t)idx[3 * (size_t)n + c];
+        x = __builtin_fmaf(wc, p[0], x); y = __builtin_fmaf(wc, p[1], y); z = __builtin_fmaf(wc, p[2], z);
+    }
+    pts[3 * o] = x; pts[3 * o + 1] = y; pts[3 * o + 2] = z;
+    // unit face normal of the posed face the point was sampled from (loss.py:30-41)
+    const int f = hd_face[n];
+    const float* a = vb + 3 * (size_t)faces[3 * f];
+    const float* c1 = vb + 3 * (size_t)faces[3 * f + 1];
+    const float* c2 = vb + 3 * (size_t)faces[3 * f + 2];
+    const float ux = c1[0] - a[0], uy = c1[1] - a[1], uz = c1[2] - a[2];
+    const float vx = c2[0] - a[0], vy = c2[1] - a[1], vz = c2[2] - a[2];
+    const float nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
+    const float inv = 0.001f / __builtin_sqrtf(nx * nx + ny * ny + nz * nz);
+    offs[3 * o] = x + inv * nx; offs[3 * o + 1] = y + inv * ny; offs[3 * o + 2] = z + inv * nz;
+    vid[o] = mask_id[n];
+}
+
+// ---- search seeds ---------------------------------------------------------------------------------------------------
+// partner_v = vertex-level partner (loss.py:269-270) of the point's template vertex: admissible for it by
+// construction, so every selected HD point hanging on partner_v is an admissible row for this column
+__global__ __launch_bounds__(256) void hd_seed_kernel(
+    const float* __restrict__ pts, const int32_t* __restrict__ sel, const int32_t* __restrict__ slot,
+    const int32_t* __restrict__ counts, const int32_t* __restrict__ tv, const int32_t* __restrict__ partner_v,
+    const int32_t* __restrict__ tv_off, const int32_t* __restrict__ tv_pts, int V, int N,
+    float* __restrict__ seed_best, int32_t* __restrict__ seed_arg)
+{
+    const int b = blockIdx.y;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= counts[b]) return;
+    const size_t o = (size_t)b * N + k;
+    const int n = sel[o];
+    const int pv = partner_v[(size_t)b * V + tv[n]];
+    const float* pb = pts + (size_t)b * N * 3;
+    const float px = pb[3 * k], py = pb[3 * k + 1], pz = pb[3 * k + 2];
+    float best = __builtin_inff();
+    int arg = 0;
+    for (int e = tv_off[pv]; e < tv_off[pv + 1]; ++e) {
+        const int s = slot[(size_t)b * N + tv_pts[e]];
+        if (s < 0) continue;
+        const float dx = px - pb[3 * s], dy = py - pb[3 * s + 1], dz = pz - pb[3 * s + 2];
+        const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));     // as v2v_indexed_kernel
+        if (d < best || (d == best && s < arg)) { best = d; arg = s; }
+    }
+    seed_best[o] = best;
+    seed_arg[o] = arg;
+}
+
+// ---- terms (loss.py:299-315) and their adjoint -------------------------------------------------------------------
+struct Term { float value, dd; };
+
+__device__ __forceinline__ Term contact_term(float d, bool exterior)
+{
+    const float weight = exterior ? 0.005f : 1.0f, scale = exterior ? 0.005f : 0.04f;
+    const float th = tanhf(d / scale);
+    Term t = {weight * th * th, 2.0f * weight * th * (1.0f - th * th) / scale};
+    return t;
+}
+
+__global__ __launch_bounds__(1024) void hd_terms_kernel(
+    const float* __restrict__ pts, const int32_t* __restrict__ partner, const uint8_t* __restrict__ ext,
+    const int32_t* __restrict__ counts, int N, float* __restrict__ terms)
+{
+    __shared__ float smem[2][16];
+    const int b = blockIdx.x;
+    const float* pb = pts + (size_t)b * N * 3;
+    float in_sum = 0.0f, ex_sum = 0.0f;
+    const int n = counts[b];
+    for (int k = threadIdx.x; k < n; k += 1024) {
+        const int p = partner[(size_t)b * N + k];
+        const float dx = pb[3 * k] - pb[3 * p], dy = pb[3 * k + 1] - pb[3 * p + 1], dz = pb[3 * k + 2] - pb[3 * p + 2];
+        const float d = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
+        const bool e = ext[(size_t)b * N + k] != 0;
+        const Term t = contact_term(d, e);
+        if (e) ex_sum += t.value; else in_sum += t.value;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { in_sum += __shfl_down(in_sum, o, 64); ex_sum += __shfl_down(ex_sum, o, 64); }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { smem[0][wave] = in_sum; smem[1][wave] = ex_sum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.0f, c = 0.0f;
+        for (int k = 0; k < 16; ++k) { a += smem[0][k]; c += smem[1][k]; }
+        terms[2 * b] = a; terms[2 * b + 1] = c;
+    }
+}
+
+// gradient on the points: own side written, partner side scattered with atomics (G pre-zeroed)
+__global__ __launch_bounds__(256) void hd_grad_points_kernel(
+    const float* __restrict__ pts, const int32_t* __restrict__ partner, const uint8_t* __restrict__ ext,
+    const int32_t* __restrict__ counts, const float* __restrict__ gscale, int N, float* __restrict__ G)
+{
+    const int b = blockIdx.y;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= counts[b]) return;
+    const size_t o = (size_t)b * N + k;
+    const bool e = ext[o] != 0;
+    const float g = gscale[2 * b + (e ? 1 : 0)];
+    if (g == 0.0f) return;
+    const float* pb = pts + (size_t)b * N * 3;
+    const int p = partner[o];
+    const float dx = pb[3 * k] - pb[3 * p], dy = pb[3 * k + 1] - pb[3 * p + 1], dz = pb[3 * k + 2] - pb[3 * p + 2];
+    const float d = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
+    if (!(d > 0.0f)) return;                      // torch.norm's backward at 0 is 0
+    const Term t = contact_term(d, e);
+    const float c = g * t.dd / d;
+    float* gk = G + 3 * o;
+    float* gp = G + 3 * ((size_t)b * N + p);
+    atomicAdd(gk, c * dx); atomicAdd(gk + 1, c * dy); atomicAdd(gk + 2, c * dz);
+    atomicAdd(gp, -c * dx); atomicAdd(gp + 1, -c * dy); atomicAdd(gp + 2, -c * dz);
+}
+
+// adjoint of the regressor rows: a gather per vertex over the points it supports
+__global__ __launch_bounds__(256) void hd_grad_verts_kernel(
+    const float* __restrict__ G, const int32_t* __restrict__ slot, const int32_t* __restrict__ v_off,
+    const int32_t* __restrict__ v_ent, const float* __restrict__ w, int V, int N, float* __restrict__ grad_verts)
+{
+    const int b = blockIdx.y;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    float x = 0.f, y = 0.f, z = 0.f;
+    for (int e = v_off[v]; e < v_off[v + 1]; ++e) {
+        const int ent = v_ent[e], n = ent >> 2, c = ent & 3;
+        const int s = slot[(size_t)b * N + n];
+        if (s < 0) continue;
+        const float wc = w[3 * (size_t)n + c];
+        const float* g = G + 3 * ((size_t)b * N + s);
+        x = __builtin_fmaf(wc, g[0], x); y = __builtin_fmaf(wc, g[1], y); z = __builtin_fmaf(wc, g[2], z);
+    }
+    float* o = grad_verts + 3 * ((size_t)b * V + v);
+    o[0] = x; o[1] = y; o[2] = z;
+}
+
+struct Saved { size_t counts, first, sel, slot, pts, partner, ext, total; };
+Saved saved_layout(int B, int N)
+{
+    Saved l;
+    size_t o = 0;
+    l.counts = o;  o += align256((size_t)B * sizeof(int32_t));
+    l.first = o;   o += align256((size_t)B * sizeof(int32_t));
+    l.sel = o;     o += align256((size_t)B * N * sizeof(int32_t));
+    l.slot = o;    o += align256((size_t)B * N * sizeof(int32_t));
+    l.pts = o;     o += align256((size_t)B * N * 3 * sizeof(float));
+    l.partner = o; o += align256((size_t)B * N * sizeof(int32_t));
+    l.ext = o;     o += align256((size_t)B * N);
+    l.total = o;
+    return l;
+}
+
+struct Work { size_t offs, vid, seed_best, seed_arg, min_d2, search, winding, total; };
+Work work_layout(const tuch_hd_model* hm, int B)
+{
+    Work l;
+    const int N = hm->N;
+    size_t o = 0;
+    l.offs = o;      o += align256((size_t)B * N * 3 * sizeof(float));
+    l.vid = o;       o += align256((size_t)B * N * sizeof(int32_t));
+    l.seed_best = o; o += align256((size_t)B * N * sizeof(float));
+    l.seed_arg = o;  o += align256((size_t)B * N * sizeof(int32_t));
+    l.min_d2 = o;    o += align256((size_t)B * N * sizeof(float));
+    l.search = o;    o += align256(tuch_v2v_min_indexed_workspace_bytes(B, N));
+    l.winding = o;   o += align256(tuch_winding_points_workspace_bytes(hm->cm, B, N));
+    l.total = o;
+    return l;
+}
+
+}  // namespace
+
+extern "C" void tuch_hd_model_destroy(tuch_hd_model* hm)
+{
+    if (!hm) return;
+    void* dev[] = {hm->idx, hm->w, hm->face, hm->tv, hm->mask_id, hm->orig, hm->v_off, hm->v_ent, hm->tv_off, hm->tv_pts, hm->offsets};
+    for (void* p : dev)
+        if (p) (void)hipFree(p);
+    delete hm->order_host;
+    free(hm);
+}
+
+// hd_idx / hd_w [N,3]: the three non-zeros of every row of the HD vertex regressor; hd_face [N]: the face each point
+// was sampled from.  The contact model must outlive the HD model.
+extern "C" int tuch_hd_model_create(tuch_hd_model** out, const tuch_contact_model* cm, int N, const int32_t* hd_idx,
+                                    const float* hd_w, const int32_t* hd_face)
+{
+    TUCH_REQUIRE(out && cm && hd_idx && hd_w && hd_face && N > 0, "tuch_hd_model_create: bad arguments");
+    TUCH_REQUIRE(cm->mask_bits, "tuch_hd_model_create: the contact model has no geodesic mask");
+    const int V = cm->V, F = cm->F;
+    std::vector<int32_t> faces((size_t)F * 3);
+    if (hipMemcpy(faces.data(), cm->faces, faces.size() * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) {
+        tuch_set_error("tuch_hd_model_create: cannot read the model's faces");
+        return TUCH_ERR_HIP;
+    }
+    for (int n = 0; n < N; ++n) {
+        TUCH_REQUIRE(hd_face[n] >= 0 && hd_face[n] < F, "tuch_hd_model_create: face id %d out of range", hd_face[n]);
+        for (int c = 0; c < 3; ++c)
+            TUCH_REQUIRE(hd_idx[3 * n + c] >= 0 && hd_idx[3 * n + c] < V, "tuch_hd_model_create: vertex id out of range");
+    }
+    // The HD points are a set (the loss sums over them): keep them sorted by the surface patch of their face, so that
+    // consecutive selected points are neighbours in space (coherent query blocks for the inside test, tight row boxes
+    // for the search).  The model's own tree decides (not a rebuilt one).
+    std::vector<int32_t> order(N);
+    std::iota(order.begin(), order.end(), 0);
+    const bool tree = cm->tree_nodes > 0 && cm->tree_face_leaf_host;
+    if (tree)
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+            return cm->tree_face_leaf_host[hd_face[a]] < cm->tree_face_leaf_host[hd_face[b]];
+        });
+    std::vector<int32_t> pos(V);
+    const bool tree_mask = tree && cm->tree_mask_bits && cm->tree_qperm_host;
+    if (tree_mask)
+        for (int i = 0; i < V; ++i) pos[cm->tree_qperm_host[i]] = i;
+    std::vector<int32_t> idx((size_t)N * 3), face(N), tv(N), mask_id(N);
+    std::vector<float> w((size_t)N * 3);
+    for (int k = 0; k < N; ++k) {
+        const int n = order[k];
+        for (int c = 0; c < 3; ++c) { idx[3 * k + c] = hd_idx[3 * n + c]; w[3 * k + c] = hd_w[3 * n + c]; }
+        face[k] = hd_face[n];
+        tv[k] = faces[3 * (size_t)hd_face[n]];                       // loss.py:88: first vertex of the face
+        mask_id[k] = tree_mask ? pos[tv[k]] : tv[k];
+    }
+    // CSR tables
+    std::vector<int32_t> v_off(V + 1, 0), tv_off(V + 1, 0);
+    for (int k = 0; k < N; ++k) {
+        for (int c = 0; c < 3; ++c) ++v_off[idx[3 * k + c] + 1];
+        ++tv_off[tv[k] + 1];
+    }
+    for (int v = 0; v < V; ++v) { v_off[v + 1] += v_off[v]; tv_off[v + 1] += tv_off[v]; }
+    std::vector<int32_t> v_ent((size_t)N * 3), tv_pts(N), vf(v_off.begin(), v_off.end() - 1), tf(tv_off.begin(), tv_off.end() - 1);
+    for (int k = 0; k < N; ++k) {
+        for (int c = 0; c < 3; ++c) v_ent[vf[idx[3 * k + c]]++] = k * 4 + c;
+        tv_pts[tf[tv[k]]++] = k;
+    }
+    std::vector<int32_t> offsets(kMaxBatch + 1);
+    for (int b = 0; b <= kMaxBatch; ++b) offsets[b] = (int32_t)((long)b * N < 0x7fffffffL ? (long)b * N : 0x7fffffffL);
+    tuch_hd_model* hm = (tuch_hd_model*)calloc(1, sizeof(tuch_hd_model));
+    hm->cm = cm; hm->N = N; hm->V = V; hm->F = F; hm->tree_order = tree_mask ? 1 : 0;
+    hm->order_host = new std::vector<int32_t>(order);
+    int rc = upload(&hm->idx, idx.data(), idx.size());
+    if (rc == TUCH_OK) rc = upload(&hm->w, w.data(), w.size());
+    if (rc == TUCH_OK) rc = upload(&hm->face, face.data(), face.size());
+    if (rc == TUCH_OK) rc = upload(&hm->tv, tv.data(), tv.size());
+    if (rc == TUCH_OK) rc = upload(&hm->mask_id, mask_id.data(), mask_id.size());
+    if (rc == TUCH_OK) rc = upload(&hm->orig, order.data(), order.size());
+    if (rc == TUCH_OK) rc = upload(&hm->v_off, v_off.data(), v_off.size());
+    if (rc == TUCH_OK) rc = upload(&hm->v_ent, v_ent.data(), v_ent.size());
+    if (rc == TUCH_OK) rc = upload(&hm->tv_off, tv_off.data(), tv_off.size());
+    if (rc == TUCH_OK) rc = upload(&hm->tv_pts, tv_pts.data(), tv_pts.size());
+    if (rc == TUCH_OK) rc = upload(&hm->offsets, offsets.data(), offsets.size());
+    if (rc != TUCH_OK) {
+        tuch_hd_model_destroy(hm);
+        *out = nullptr;
+        return rc;
+    }
+    *out = hm;
+    return TUCH_OK;
+}
+
+extern "C" int tuch_hd_model_info(const tuch_hd_model* hm, int* N, int32_t* order_host)
+{
+    TUCH_REQUIRE(hm, "tuch_hd_model_info: null model");
+    if (N) *N = hm->N;
+    if (order_host) memcpy(order_host, hm->order_host->data(), sizeof(int32_t) * hm->N);
+    return TUCH_OK;
+}
+
+extern "C" size_t tuch_hd_contact_saved_bytes(const tuch_hd_model* hm, int B)
+{
+    return hm && B > 0 ? saved_layout(B, hm->N).total : 0;
+}
+
+extern "C" size_t tuch_hd_contact_workspace_bytes(const tuch_hd_model* hm, int B)
+{
+    if (!hm || B <= 0) return 0;
+    const size_t f = work_layout(hm, B).total;
+    const size_t g = align256((size_t)B * hm->N * 3 * sizeof(float));       // adjoint: point gradients
+    return f > g ? f : g;
+}
+
+// terms[b] = {sum over interior HD points of tanh^2(d/0.04), sum over exterior ones of 0.005 tanh^2(d/0.005)} for
+// every body with valid[b] != 0 (others 0, 0); inputs are the vertex-level results of the same vertices
+// (tuch_exterior_flags with the segment filter, tuch_v2v_min_model).  `saved` is kept by the caller for the adjoint.
+extern "C" int tuch_hd_contact_fwd(const tuch_hd_model* hm, const float* verts, const uint8_t* exterior, const float* min_d2,
+                                   const int32_t* partner, const uint8_t* valid, int B, float euclthres, float thresh,
+                                   float* terms, void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes,
+                                   void* stream)
+{
+    TUCH_REQUIRE(hm && verts && exterior && min_d2 && partner && terms && saved && workspace, "tuch_hd_contact_fwd: null pointer");
+    TUCH_REQUIRE(B > 0 && B <= kMaxBatch && (long)B * hm->N < 0x7fffffffL, "tuch_hd_contact_fwd: bad batch %d", B);
+    const int N = hm->N, V = hm->V;
+    const Saved sl = saved_layout(B, N);
+    const Work wl = work_layout(hm, B);
+    if (saved_bytes < sl.total || workspace_bytes < wl.total) {
+        tuch_set_error("tuch_hd_contact_fwd: saved %zu < %zu or workspace %zu < %zu bytes", saved_bytes, sl.total,
+                       workspace_bytes, wl.total);
+        return TUCH_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    char* sv = (char*)saved;
+    char* ws = (char*)workspace;
+    int32_t* counts = (int32_t*)(sv + sl.counts);
+    int32_t* first = (int32_t*)(sv + sl.first);
+    int32_t* sel = (int32_t*)(sv + sl.sel);
+    int32_t* slot = (int32_t*)(sv + sl.slot);
+    float* pts = (float*)(sv + sl.pts);
+    int32_t* part = (int32_t*)(sv + sl.partner);
+    uint8_t* ext = (uint8_t*)(sv + sl.ext);
+    float* offs = (float*)(ws + wl.offs);
+    int32_t* vid = (int32_t*)(ws + wl.vid);
+    float* seed_best = (float*)(ws + wl.seed_best);
+    int32_t* seed_arg = (int32_t*)(ws + wl.seed_arg);
+    hipLaunchKernelGGL(hd_select_kernel, dim3(B), dim3(kSel), (size_t)hm->F, s, exterior, min_d2, valid,
+                       (const int32_t*)hm->cm->faces, (const int32_t*)hm->face, (const int32_t*)hm->orig, V, hm->F, N,
+                       euclthres * euclthres, sel, slot, counts, first);
+    const dim3 pgrid(ceil_div(N, 256), B);
+    hipLaunchKernelGGL(hd_points_kernel, pgrid, dim3(256), 0, s, verts, (const int32_t*)sel, (const int32_t*)counts,
+                       (const int32_t*)hm->idx, (const float*)hm->w, (const int32_t*)hm->face,
+                       (const int32_t*)hm->cm->faces, (const int32_t*)hm->mask_id, V, N, pts, offs, vid);
+    hipLaunchKernelGGL(hd_seed_kernel, pgrid, dim3(256), 0, s, (const float*)pts, (const int32_t*)sel, (const int32_t*)slot,
+                       (const int32_t*)counts, (const int32_t*)hm->tv, partner, (const int32_t*)hm->tv_off,
+                       (const int32_t*)hm->tv_pts, V, N, seed_best, seed_arg);
+    const uint64_t* bits = hm->tree_order ? hm->cm->tree_mask_bits : hm->cm->mask_bits;
+    int rc = tuch_v2v_min_indexed_seeded(pts, vid, hm->offsets, counts, seed_best, seed_arg, first, bits, B, V, N,
+                                         (float*)(ws + wl.min_d2), part, ws + wl.search, s);
+    if (rc != TUCH_OK) return rc;
+    rc = tuch_winding_points(hm->cm, verts, offs, counts, B, N, thresh, nullptr, ext, ws + wl.winding,
+                             wl.total - wl.winding, stream);
+    if (rc != TUCH_OK) return rc;
+    hipLaunchKernelGGL(hd_terms_kernel, dim3(B), dim3(1024), 0, s, (const float*)pts, (const int32_t*)part,
+                       (const uint8_t*)ext, (const int32_t*)counts, N, terms);
+    return tuch_check_launch("tuch_hd_contact_fwd");
+}
+
+// grad_verts [B,V,3] (overwritten) = d (sum_b grad_terms[b,0] * terms[b,0] + grad_terms[b,1] * terms[b,1]) / d verts
+extern "C" int tuch_hd_contact_bwd(const tuch_hd_model* hm, const void* saved, const float* grad_terms, int B,
+                                   float* grad_verts, void* workspace, size_t workspace_bytes, void* stream)
+{
+    TUCH_REQUIRE(hm && saved && grad_terms && grad_verts && workspace, "tuch_hd_contact_bwd: null pointer");
+    TUCH_REQUIRE(B > 0 && B <= kMaxBatch, "tuch_hd_contact_bwd: bad batch %d", B);
+    const int N = hm->N, V = hm->V;
+    const Saved sl = saved_layout(B, N);
+    const size_t gbytes = (size_t)B * N * 3 * sizeof(float);
+    if (workspace_bytes < gbytes) {
+        tuch_set_error("tuch_hd_contact_bwd: workspace %zu < %zu bytes", workspace_bytes, gbytes);
+        return TUCH_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const char* sv = (const char*)saved;
+    float* G = (float*)workspace;
+    if (hipMemsetAsync(G, 0, gbytes, s) != hipSuccess) {
+        tuch_set_error("tuch_hd_contact_bwd: hipMemsetAsync failed");
+        return TUCH_ERR_HIP;
+    }
+    hipLaunchKernelGGL(hd_grad_points_kernel, dim3(ceil_div(N, 256), B), dim3(256), 0, s, (const float*)(sv + sl.pts),
+                       (const int32_t*)(sv + sl.partner), (const uint8_t*)(sv + sl.ext), (const int32_t*)(sv + sl.counts),
+                       grad_terms, N, G);
+    hipLaunchKernelGGL(hd_grad_verts_kernel, dim3(ceil_div(V, 256), B), dim3(256), 0, s, (const float*)G,
+                       (const int32_t*)(sv + sl.slot), (const int32_t*)hm->v_off, (const int32_t*)hm->v_ent,
+                       (const float*)hm->w, V, N, grad_verts);
+    return tuch_check_launch("tuch_hd_contact_bwd");
+}
+
+// inspection (tests): counts [B] and, per body, the caller-order indices of the selected points in slot order
+extern "C" int tuch_hd_contact_selection(const tuch_hd_model* hm, const void* saved, int B, int32_t* counts_host,
+                                         int32_t* selected_host /* [B,N] caller-order index per slot, -1 padded */)
+{
+    TUCH_REQUIRE(hm && saved && counts_host, "tuch_hd_contact_selection: null pointer");
+    const int N = hm->N;
+    const Saved sl = saved_layout(B, N);
+    const char* sv = (const char*)saved;
+    if (hipMemcpy(counts_host, sv + sl.counts, sizeof(int32_t) * B, hipMemcpyDeviceToHost) != hipSuccess) return TUCH_ERR_HIP;
+    if (selected_host) {
+        std::vector<int32_t> sel((size_t)B * N);
+        if (hipMemcpy(sel.data(), sv + sl.sel, sel.size() * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return TUCH_ERR_HIP;
+        for (int b = 0; b < B; ++b)
+            for (int k = 0; k < N; ++k)
+                selected_host[(size_t)b * N + k] = k < counts_host[b] ? (*hm->order_host)[sel[(size_t)b * N + k]] : -1;
+    }
+    return TUCH_OK;
+}

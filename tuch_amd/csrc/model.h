@@ -39,6 +39,17 @@ int tuch_ray_exterior_verts(const tuch_contact_model* m, const float* verts, int
 int tuch_ray_exterior_points(const tuch_contact_model* m, const float* verts, const float* points, const int32_t* counts,
                              int B, int Q, float thresh, uint8_t* exterior, float* w, void* workspace, hipStream_t s);
 
+// nearest admissible point within ragged point sets (v2v.hip), options of the fused HD branch
+int tuch_v2v_min_indexed_seeded(const float* points, const int32_t* vertex_ids, const int32_t* offsets,
+                                const int32_t* counts, const float* seed_best, const int32_t* seed_arg,
+                                const int32_t* all_masked_arg, const uint64_t* geomask_bits, int B, int V,
+                                int max_points_per_body, float* min_d2, int32_t* argmin, void* workspace, hipStream_t s);
+extern "C" size_t tuch_v2v_min_indexed_workspace_bytes(int B, int max_points_per_body);
+extern "C" size_t tuch_winding_points_workspace_bytes(const tuch_contact_model* m, int B, int Q);
+extern "C" int tuch_winding_points(const tuch_contact_model* m, const float* verts, const float* points,
+                                   const int32_t* counts, int B, int Q, float thresh, float* w,
+                                   uint8_t* exterior, void* workspace, size_t workspace_bytes, void* stream);
+
 struct tuch_contact_model {
     int device;
     int V, F;

@@ -167,11 +167,12 @@ constexpr float kIndexedSlack = 0.999999f;   // lower bounds are deflated by 1e-
 // box of every chunk of kIndexedChunk consecutive points of a body: [B][max_chunks][8] = (lo xyz, -, hi xyz, -).
 // The caller keeps the points of a body sorted by surface patch, so a chunk is a small patch.
 __global__ __launch_bounds__(256) void v2v_indexed_boxes_kernel(
-    const float* __restrict__ pts, const int32_t* __restrict__ off, int max_chunks, float* __restrict__ boxes)
+    const float* __restrict__ pts, const int32_t* __restrict__ off, const int32_t* __restrict__ counts, int max_chunks,
+    float* __restrict__ boxes)
 {
     const int b = blockIdx.y;
     const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int beg = off[b], n = off[b + 1] - beg;
+    const int beg = off[b], n = counts ? counts[b] : off[b + 1] - beg;
     if (chunk >= max_chunks || chunk * kIndexedChunk >= n) return;
     const int r = chunk * kIndexedChunk + (lane & (kIndexedChunk - 1));
     const float* p = pts + 3 * (size_t)(beg + min(r, n - 1));
@@ -197,13 +198,15 @@ __global__ __launch_bounds__(256) void v2v_indexed_boxes_kernel(
 // smaller row, so the result is the first-index argmin of torch.min regardless of the order of evaluation.
 __global__ __launch_bounds__(64 * kIndexedWaves) void v2v_indexed_kernel(
     const float* __restrict__ pts, const int32_t* __restrict__ vid, const int32_t* __restrict__ off,
+    const int32_t* __restrict__ counts, const float* __restrict__ seed_best, const int32_t* __restrict__ seed_arg,
+    const int32_t* __restrict__ all_masked_arg,
     const uint64_t* __restrict__ bits, int V, const float* __restrict__ boxes, int max_chunks,
     float* __restrict__ out_min, int32_t* __restrict__ out_arg)
 {
     const int b = blockIdx.y;
     // wave-uniform bounds (readfirstlane lets the row data below come in through scalar loads)
     const int beg = __builtin_amdgcn_readfirstlane(off[b]);
-    const int n = __builtin_amdgcn_readfirstlane(off[b + 1]) - beg;
+    const int n = counts ? __builtin_amdgcn_readfirstlane(counts[b]) : __builtin_amdgcn_readfirstlane(off[b + 1]) - beg;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int a = blockIdx.x * 64 + lane;
     if ((int)(blockIdx.x * 64) >= n) return;
@@ -215,6 +218,14 @@ __global__ __launch_bounds__(64 * kIndexedWaves) void v2v_indexed_kernel(
     const float inf = __builtin_inff();
     float best = inf;
     int arg = 0;
+    // optional seeds: the distance to some admissible row (any real row works: the result is the lexicographic
+    // (distance, row) minimum whatever the search starts from) -- with near-final bounds pass 1 is not needed
+    bool sample = true;
+    if (seed_best) {
+        best = seed_best[beg + ac];
+        arg = seed_arg[beg + ac];
+        sample = __builtin_amdgcn_ballot_w64(!(best < inf)) != 0;     // some column without a seed: sample after all
+    }
     const float* rp = pts + 3 * (size_t)beg;
     const int32_t* rv = vid + beg;
     auto row = [&](int r, uint64_t word, float qx, float qy, float qz) {
@@ -265,7 +276,7 @@ __global__ __launch_bounds__(64 * kIndexedWaves) void v2v_indexed_kernel(
         }
         __syncthreads();
     };
-    for (int c = wave; c < chunks; c += kIndexedWaves) {                                                 // pass 1
+    for (int c = wave; sample && c < chunks; c += kIndexedWaves) {                                       // pass 1
         const int r = c * kIndexedChunk;
         if (r + 24 < n) {
             float q[12];
@@ -301,7 +312,9 @@ __global__ __launch_bounds__(64 * kIndexedWaves) void v2v_indexed_kernel(
     merge();
     if (wave == 0 && a < n) {
         out_min[beg + a] = best;
-        out_arg[beg + a] = best < inf ? arg : 0;
+        // every row masked: torch.min of an all-inf column returns index 0 (of the caller's ORIGINAL order, which the
+        // caller may pass as all_masked_arg[b] when it keeps the points in another order)
+        out_arg[beg + a] = best < inf ? arg : (all_masked_arg ? all_masked_arg[b] : 0);
     }
 }
 
@@ -697,6 +710,23 @@ extern "C" size_t tuch_v2v_min_indexed_workspace_bytes(int B, int max_points_per
     return (size_t)B * ceil_div(max_points_per_body, kIndexedChunk) * 8 * sizeof(float);
 }
 
+// internal form with the options of the fused HD branch (hd_contact.hip): counts[b] rows per body at offsets[b],
+// seeds (best, arg) per column, the row to report for columns whose rows are all masked
+int tuch_v2v_min_indexed_seeded(const float* points, const int32_t* vertex_ids, const int32_t* offsets,
+                                const int32_t* counts, const float* seed_best, const int32_t* seed_arg,
+                                const int32_t* all_masked_arg, const uint64_t* geomask_bits, int B, int V,
+                                int max_points_per_body, float* min_d2, int32_t* argmin, void* workspace, hipStream_t s)
+{
+    const int max_chunks = ceil_div(max_points_per_body, kIndexedChunk);
+    float* boxes = (float*)workspace;
+    hipLaunchKernelGGL(v2v_indexed_boxes_kernel, dim3(ceil_div(max_chunks, 4), B), dim3(256), 0, s, points, offsets, counts,
+                       max_chunks, boxes);
+    hipLaunchKernelGGL(v2v_indexed_kernel, dim3(ceil_div(max_points_per_body, 64), B), dim3(64 * kIndexedWaves), 0, s,
+                       points, vertex_ids, offsets, counts, seed_best, seed_arg, all_masked_arg, geomask_bits, V,
+                       (const float*)boxes, max_chunks, min_d2, argmin);
+    return tuch_check_launch("tuch_v2v_min_indexed");
+}
+
 extern "C" int tuch_v2v_min_indexed(const float* points, const int32_t* vertex_ids, const int32_t* offsets,
                                     const uint64_t* geomask_bits, int B, int V, int max_points_per_body,
                                     float* min_d2, int32_t* argmin, void* workspace, size_t workspace_bytes,
@@ -711,12 +741,6 @@ extern "C" int tuch_v2v_min_indexed(const float* points, const int32_t* vertex_i
         tuch_set_error("tuch_v2v_min_indexed: workspace %zu < %zu bytes", workspace_bytes, need);
         return TUCH_ERR_WORKSPACE;
     }
-    const int max_chunks = ceil_div(max_points_per_body, kIndexedChunk);
-    float* boxes = (float*)workspace;
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(v2v_indexed_boxes_kernel, dim3(ceil_div(max_chunks, 4), B), dim3(256), 0, s, points, offsets,
-                       max_chunks, boxes);
-    hipLaunchKernelGGL(v2v_indexed_kernel, dim3(ceil_div(max_points_per_body, 64), B), dim3(64 * kIndexedWaves), 0, s,
-                       points, vertex_ids, offsets, geomask_bits, V, (const float*)boxes, max_chunks, min_d2, argmin);
-    return tuch_check_launch("tuch_v2v_min_indexed");
+    return tuch_v2v_min_indexed_seeded(points, vertex_ids, offsets, nullptr, nullptr, nullptr, nullptr, geomask_bits, B, V,
+                                       max_points_per_body, min_d2, argmin, workspace, (hipStream_t)stream);
 }

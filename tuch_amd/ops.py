@@ -617,6 +617,86 @@ class ContactModel:
         return _RegionPairMin.apply(verts, self, select, masked)
 
 
+class HDModel:
+    """Device tables of the HD vertex regressor for the fused HD branch (wraps tuch_hd_model; csrc/hd_contact.hip).
+    hd_idx / hd_w [N,3]: the three non-zeros of every regressor row; hd_face [N]: faces_vert_is_sampled_from."""
+
+    def __init__(self, contact_model: ContactModel, hd_idx, hd_w, hd_face):
+        self.contact_model = contact_model
+        self.num_points = int(np.asarray(hd_face).shape[0])
+        self._host = (_i32(np.asarray(hd_idx).reshape(-1, 3)), np.ascontiguousarray(np.asarray(hd_w).reshape(-1, 3), np.float32),
+                      _i32(hd_face))
+        self._h = None
+
+    @property
+    def _handle(self):
+        if self._h is None:
+            idx, w, face = self._host
+            handle = ctypes.c_void_p(0)
+            cm = self.contact_model._handle
+            with torch.cuda.device(self.contact_model.device):
+                _C.check(_C.lib().tuch_hd_model_create(ctypes.byref(handle), cm, self.num_points,
+                                                       idx.ctypes.data_as(ctypes.c_void_p), w.ctypes.data_as(ctypes.c_void_p),
+                                                       face.ctypes.data_as(ctypes.c_void_p)))
+            self._h = handle
+        return self._h
+
+    def __del__(self):
+        h = getattr(self, '_h', None)
+        if h:
+            try:
+                _C.lib().tuch_hd_model_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def contact_terms(self, verts, exterior, min_d2, partner, valid_u8, euclthres, thresh=0.99):
+        """[B,2] (interior sum, exterior sum) over the HD points of loss.py:274-315, differentiable w.r.t. verts."""
+        return _HDContact.apply(verts, exterior, min_d2, partner, valid_u8, self, float(euclthres), float(thresh))
+
+    def selection(self, saved, batch):
+        """(counts [B], selected [B,N] caller-order ids per slot, -1 padded) of a forward call (tests)."""
+        counts = np.zeros(batch, np.int32)
+        sel = np.zeros((batch, self.num_points), np.int32)
+        _C.check(_C.lib().tuch_hd_contact_selection(self._handle, _C.ptr(saved), batch, counts.ctypes.data_as(ctypes.c_void_p),
+                                                    sel.ctypes.data_as(ctypes.c_void_p)))
+        return counts, sel
+
+
+class _HDContact(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, verts, exterior, min_d2, partner, valid, hm: HDModel, euclthres, thresh):
+        v = _f32(verts)
+        b = v.shape[0]
+        L = _C.lib()
+        h = hm._handle
+        terms = torch.empty(b, 2, dtype=torch.float32, device=v.device)
+        nsaved = L.tuch_hd_contact_saved_bytes(h, b)
+        nws = L.tuch_hd_contact_workspace_bytes(h, b)
+        saved = torch.empty(nsaved, dtype=torch.uint8, device=v.device)
+        ws = _workspace(nws, v.device)
+        ext, md, part = exterior.contiguous(), _f32(min_d2), partner.contiguous()
+        _C.check(L.tuch_hd_contact_fwd(h, _C.ptr(v), _C.ptr(ext), _C.ptr(md), _C.ptr(part), _C.ptr(valid), b, euclthres, thresh,
+                                       _C.ptr(terms), _C.ptr(saved), nsaved, _C.ptr(ws), nws, _C.stream()))
+        ctx.save_for_backward(saved)
+        ctx.hm, ctx.shape = hm, tuple(v.shape)
+        hm.last_saved = saved           # inspection only
+        return terms
+
+    @staticmethod
+    def backward(ctx, grad_terms):
+        saved, = ctx.saved_tensors
+        hm = ctx.hm
+        b = ctx.shape[0]
+        L = _C.lib()
+        g = grad_terms.to(torch.float32).contiguous()
+        grad = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        nws = L.tuch_hd_contact_workspace_bytes(hm._handle, b)
+        ws = _workspace(nws, g.device)
+        _C.check(L.tuch_hd_contact_bwd(hm._handle, _C.ptr(saved), _C.ptr(g), b, _C.ptr(grad), _C.ptr(ws), nws, _C.stream()))
+        return grad, None, None, None, None, None, None, None
+
+
 class _RegionPairMin(torch.autograd.Function):
     @staticmethod
     def forward(ctx, verts, model: ContactModel, select, masked):

@@ -20,7 +20,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import _C, dist as tdist, ops
+from .. import dist as tdist, ops
 from ..utils.geometry import batch_rodrigues
 
 
@@ -55,18 +55,9 @@ class RegressorLoss(nn.Module):
                 hd_regressor = (hd_i, hd_wt)
             dev = face_tensor.device
             hd_i, hd_wt, hd_f = np.asarray(hd_regressor[0]), np.asarray(hd_regressor[1]), np.asarray(hd_faces)
-            # The HD points are a set (the loss sums over them): keep them sorted by the surface patch their
-            # face belongs to, so that consecutive selected points are neighbours in space and the inside
-            # test of loss.py:297 walks the cluster tree with coherent blocks of queries.
-            try:
-                leaf = ops.cluster_tree(face_tensor[0].detach().cpu().numpy(), num_verts)['face_leaf']
-                order = np.argsort(leaf[hd_f], kind='stable')
-                hd_i, hd_wt, hd_f = hd_i[order], hd_wt[order], hd_f[order]
-            except _C.TuchError:      # open mesh: no tree, the flat walk does not care about the order
-                pass
+            # attributes of the reference (loss.py:83-88), in the reference's point order
             self.hd_idx = torch.as_tensor(hd_i, dtype=torch.long, device=dev)
             self.hd_w = torch.as_tensor(hd_wt, dtype=torch.float32, device=dev).contiguous()
-            self.hd_idx32 = self.hd_idx.to(torch.int32).contiguous()
             self.geovec = torch.as_tensor(hd_f, dtype=torch.long, device=dev)
             self.geovec_verts = self.face_tensor[0][self.geovec][:, 0]            # loss.py:88
         if segments is None:                                                  # loss.py:91: always built
@@ -75,13 +66,9 @@ class RegressorLoss(nn.Module):
         self.segments = segments
         self._model = ops.ContactModel(face_tensor[0], self.geomask, segments.tables(), device=face_tensor.device)
         if use_hd:
-            # template vertex of every HD point as its position in the tree's vertex order (mask lookups of
-            # neighbouring points then fall into the same few 64-vertex words)
-            pos = self._model.tree_positions()
-            self._hd_tree_order = pos is not None
-            ids = self.geovec_verts.cpu().numpy()
-            self._hd_mask_ids = torch.as_tensor(pos[ids] if pos is not None else ids, dtype=torch.int32,
-                                                device=face_tensor.device)
+            # device tables of the fused HD branch (csrc/hd_contact.hip); the library keeps the points sorted by the
+            # surface patch of their face (the loss is a sum over them, their order is free)
+            self._hd = ops.HDModel(self._model, hd_i, hd_wt, hd_f)
 
     # ------------------------------------------------------------------ contact (loss.py:240-317)
     def contact_loss(self, pred_vertices, valid_fit):
@@ -99,36 +86,8 @@ class RegressorLoss(nn.Module):
             per_body, _ = ops.contact_terms(pred_vertices, partner, exterior, valid_u8, ops.MODE_TRAIN,
                                             self.euclthres)
             return per_body.sum() / n_valid
-        # HD branch, loss.py:274-301
-        with torch.no_grad():
-            faces = self.face_tensor[0]
-            cand = ((min_d2 < self.euclthres ** 2) | (exterior == 0)) & valid[:, None]      # :278
-            face_sel = cand[:, faces].any(dim=2)                                          # :279-280
-            hd_sel = face_sel[:, self.geovec]                                             # :281
-            bidx, hidx = hd_sel.nonzero(as_tuple=True)
-            counts = hd_sel.sum(dim=1)
-            offsets = torch.zeros(counts.shape[0] + 1, dtype=torch.int32, device=counts.device)
-            offsets[1:] = counts.cumsum(0)
-            n_max = int(counts.max().item())
-        if bidx.numel() == 0:
-            return pred_vertices.sum() * 0.0 / n_valid          # NaN without any valid body, like the reference
-        bidx32 = bidx.to(torch.int32)
-        hd = ops.hd_points(pred_vertices, bidx32, hidx.to(torch.int32), self.hd_idx32, self.hd_w)   # :285
-        with torch.no_grad():
-            vid = self._hd_mask_ids[hidx]
-            _, arg = model.v2v_min_indexed(hd, vid, offsets, n_max, tree_order=self._hd_tree_order)   # :288-291
-            partner_hd = (arg + offsets[:-1][bidx]).to(torch.int32)
-            tris = ops.gather_triangles(pred_vertices, model.faces_i32)
-            normals = 0.001 * batch_face_normals(tris)                                    # :295
-            offs = hd.detach() + normals[bidx, self.geovec[hidx]]                         # :296
-            batch = pred_vertices.shape[0]
-            padded = torch.zeros((batch, n_max, 3), dtype=torch.float32, device=hd.device)
-            slot = torch.arange(bidx.numel(), device=hd.device) - offsets[:-1][bidx]
-            padded[bidx, slot] = offs
-            _, ext_pad = model.winding_points(pred_vertices, padded, counts.to(torch.int32), flags_only=True)   # :297
-            ext_hd = ext_pad[bidx, slot].contiguous()
-        terms = ops.contact_terms_ragged(hd, partner_hd, ext_hd, offsets, bidx32,
-                                         ops.MODE_TRAIN, self.euclthres)                  # :299-315
+        # HD branch, loss.py:274-315: one fixed sequence of kernels, no host synchronisation (hipGraph-capturable)
+        terms = self._hd.contact_terms(pred_vertices, exterior, min_d2, partner, valid_u8, self.euclthres)
         return terms.sum() / n_valid
 
     # ---------------------------------------------------------------------------- SPIN terms
