@@ -41,6 +41,9 @@ FLOP_PER_V2V_PAIR = 8
 # executed arithmetic of the strip walk per (query, stream element): 3 sub, |.|^2 (5) + sqrt, two dot products
 # (10), numerator (5), denominator (8), small-angle atan (rcp + 8)
 FLOP_PER_STRIP_ELEMENT = 41
+# executed arithmetic of the ray-crossing walk per (query, strip element): 3 sub, 2 edge functions (4 mul + 2 sub), min3,
+# max3, 1 mul -- plain FP32 operations, no FMA (the edge functions must not be contracted), no sqrt / atan
+OPS_PER_RAY_ELEMENT = 12
 PEAK_FP32_VECTOR_TFLOPS = 157.3   # MI355X_MICROARCH.md (packed FP32 FMA rate)
 PEAK_HBM_GBS = 8000.0
 # HBM-side bytes per launch of the winding walk at batch 64 and its VALU-busy fraction: PMC passes committed under
@@ -279,35 +282,45 @@ def time_kernel(fn, iters):
 
 
 def rooflines(p, batch):
-    """Dominant-kernel figures measured live (HIP events on the launch stream)."""
+    """Dominant-kernel figures measured live (HIP events on the launch stream).
+
+    The inside test (exterior flags) is the dominant part of the step.  Since round 2 it counts signed ray crossings
+    (csrc/ray_winding.hip) instead of summing solid angles: per (query, strip element) 12 plain FP32 operations (3
+    subtractions, two edge functions = 4 mul + 2 sub, min3, max3, one mul) -- none of them an FMA, no sqrt, no atan --
+    against 41 for a step of the solid-angle walk, and 30 % fewer steps.  `roofline` prices those executed operations
+    against the FP32 vector peak (which counts FMAs: a stream of plain add/mul can reach half of it at most)."""
     from tuch_amd.smplify.losses import contact_model_for
     body = p['body']
     v, f = body.num_verts, body.num_faces
     model = contact_model_for(p['geomask'], p['face_tensor'], p['segments'], p['cdict'])
     with torch.no_grad():
         verts = p['smpl'](global_orient=p['global_orient'], body_pose=p['body_pose'], betas=p['betas']).vertices
-    # the launch below = posed stream + node slabs + winding_tree_kernel + finalize
+    # the launch below = sheared strips + leaf slabs + near-leaf lists + ray_strips_kernel + fan finalize
     t_w = time_kernel(lambda: model.exterior_flags(verts, apply_segments=False), 10)
-    work = model.winding_tree_work(verts)
-    steps = work['leaf_elements'] + work['cap_elements']          # wavefront element steps, 64 queries each
-    flops = FLOP_PER_STRIP_ELEMENT * work['queries_per_step'] * steps
-    ach = flops / t_w / 1e12
+    work = model.ray_work(verts)
+    steps = work['elements']                                     # wavefront element steps, 64 queries each
+    ops = OPS_PER_RAY_ELEMENT * work['queries_per_step'] * steps
+    ach = ops / t_w / 1e12
     ref_flops = FLOP_PER_WINDING_PAIR * batch * v * f
-    roof = {'kernel': 'winding_tree_kernel', 'bound': 'valu', 'achieved': round(ach, 2),
-            'peak': PEAK_FP32_VECTOR_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_VECTOR_TFLOPS, 4),
+    tree = model.winding_tree_work(verts)
+    tree_steps = tree['leaf_elements'] + tree['cap_elements']
+    roof = {'kernel': 'ray_strips_kernel (+ ray_stream, ray_leaf_bounds, ray_near, ray_finalize_verts)', 'bound': 'valu',
+            'achieved': round(ach, 2), 'peak': PEAK_FP32_VECTOR_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(ach / PEAK_FP32_VECTOR_TFLOPS, 4),
+            'frac_of_non_fma_peak': round(ach / (PEAK_FP32_VECTOR_TFLOPS / 2), 4),
             'traffic': PROFILE['traffic_bytes'] if batch == BATCH_PER_GPU else None,
             'traffic_source': PROFILE['traffic_source'],
             'valu_busy': PROFILE['valu_busy'], 'valu_busy_source': PROFILE['valu_busy_source'],
             'launch_ms': round(t_w * 1e3, 4),
-            'executed_flop_per_launch': flops,
-            'flop_per_query_element': FLOP_PER_STRIP_ELEMENT,
-            'element_steps_per_launch': steps, 'leaf_steps': work['leaf_elements'], 'cap_steps': work['cap_elements'],
-            'steps_fraction_of_flat_walk': round(steps / (work['query_blocks'] * work['flat_stream_elements']), 4),
-            # the reference's formulation (every query x every face, SURVEY.md 8d) priced at this launch time:
-            # above the vector peak because the cluster tree replaces ~3/4 of the pairs by boundary caps
+            'executed_op_per_launch': ops, 'op_per_query_element': OPS_PER_RAY_ELEMENT,
+            'element_steps_per_launch': steps,
+            # the same vertices through last round's kernel (exact solid angles over the cluster tree), for scale
+            'solid_angle_tree_walk_steps': tree_steps, 'solid_angle_tree_walk_flop': FLOP_PER_STRIP_ELEMENT * 64 * tree_steps,
+            # the reference's formulation (every query x every face, SURVEY.md 8d) priced at this launch time: far
+            # above the vector peak because crossings are counted, not solid angles summed
             'reference_formulation_flop_per_launch': ref_flops,
             'reference_formulation_equivalent_TFLOPs': round(ref_flops / t_w / 1e12, 1),
-            'algorithmic_bytes_per_launch': batch * (v * 12 + v * 4) + f * 12}
+            'algorithmic_bytes_per_launch': batch * (v * 12 + v) + f * 12}
     t_v = time_kernel(lambda: model.v2v_min(verts), 10)
     ref_layout_bytes = batch * (12 * v + v * v + 8 * v)           # SURVEY.md §8(d) layout (i)
     compact_bytes = batch * (12 * v + 8 * v) + v * v // 8         # layout (ii): bit-packed mask read once
@@ -400,7 +413,8 @@ def worst_case(device, seed, batch):
         work = model.winding_tree_work(verts)
         interior = float((model.exterior_flags(verts, apply_segments=True) == 0).float().sum(1).mean())
     return {'ms_per_step': round(ms, 4), 'body_iterations_per_s': round(batch / ms * 1e3, 1),
-            'winding_element_steps': work['leaf_elements'] + work['cap_elements'],
+            'ray_element_steps': model.ray_work(verts)['elements'],
+            'solid_angle_tree_walk_steps': work['leaf_elements'] + work['cap_elements'],
             'mean_interior_vertices_per_body': round(interior, 1),
             'what': 'batch %d, penetrating_fraction=1.0 (default mix: 0.5)' % batch}
 
