@@ -408,7 +408,7 @@ def test_contact_from_verts_class():
     from tuch_amd.train.train_module import TUCH
     g = golden('medium')
     regions, pairs = gio.unpack_regions(g)
-    t = TUCH({'classes': [list(p) for p in pairs], 'csig': regions}, g['faces'], device=dev())
+    t = TUCH(contactlists={'classes': [list(p) for p in pairs], 'csig': regions}, faces=g['faces'], device=dev())
     out = t.contact_from_verts(torch.tensor(g['verts'], device=dev()))
     assert_close(out.cpu().numpy(), g['contact_from_verts'], 0, 1e-6, 'contact_from_verts')
 

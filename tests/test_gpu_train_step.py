@@ -1,0 +1,113 @@
+"""GPU: the callers of the hot path (BASELINE configs 4/5) against goldens produced by the REFERENCE'S OWN
+``TUCH.forward_train_step`` and ``FitsDict`` (tests/golden/make_golden_train.py): one training step with SMPLify-DC in
+the loop, the dictionary of best fits on the device, the valid-fit logic and RegressorLoss (HD branch)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import golden_io as gio
+from helpers import assert_close
+from tuch_amd.synthetic import make_body, make_regressor
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda:0')
+
+
+def _golden():
+    data = gio.load('train_step.npz')
+    return {k: data[k] for k in data.files}
+
+
+def _options(g, tmp):
+    o = types.SimpleNamespace(checkpoint_dir=str(tmp))
+    for k in g:
+        if k.startswith('opt_'):
+            v = g[k]
+            setattr(o, k[4:], v.item() if v.shape == () else v)
+    return o
+
+
+def _datasets(g):
+    names = [k[len('static_fits_'):] for k in g if k.startswith('static_fits_')]
+    return types.SimpleNamespace(dataset_dict={n: i for i, n in enumerate(names)},
+                                 datasets=[list(range(len(g['static_fits_' + n]))) for n in names]), names
+
+
+def _batch(g):
+    out = {}
+    for k in g:
+        if k.startswith('batch_'):
+            v = g[k]
+            out[k[6:]] = [str(x) for x in v] if v.dtype.kind in 'US' else torch.tensor(v, device=DEV)
+    return out
+
+
+def test_fits_dict_gather_and_scatter_match_the_reference(tmp_path):
+    from tuch_amd.train.fits_dict import FitsDict
+    g = _golden()
+    train_ds, names = _datasets(g)
+    for n in names:
+        np.save(tmp_path / (n + '_fits.npy'), g['static_fits_' + n])
+    fd = FitsDict(_options(g, tmp_path), train_ds, device=DEV)
+    b = _batch(g)
+    key = (b['dataset_name'], b['sample_index'], b['rot_angle'], b['is_flipped'])
+    pose, betas = fd[key]
+    assert pose.device.type == 'cuda'
+    assert_close(pose.cpu().numpy(), g['fits_get_pose'], 1e-5, 2e-5, 'fits[...] pose')
+    assert_close(betas.cpu().numpy(), g['fits_get_betas'], 0, 0, 'fits[...] betas')
+    fd[key + (torch.tensor(g['fits_set_update'], device=DEV),)] = (torch.tensor(g['fits_set_pose'], device=DEV), betas + 0.1)
+    for n in names:
+        assert_close(fd.fits_dict[n].cpu().numpy(), g['fits_after_set_' + n], 1e-5, 2e-5, 'table ' + n)
+    fd.save()
+    assert np.allclose(np.load(tmp_path / (names[0] + '_fits.npy')), fd.fits_dict[names[0]].cpu().numpy())
+
+
+def test_forward_train_step_matches_the_reference(tmp_path):
+    """run_smplify + use_contact_in_the_loop: regressor -> SMPL (pose2rot=False) -> rotation matrices to axis-angle ->
+    SMPLify-DC (5 + 5 iterations) -> better-fit bookkeeping + dictionary update -> RegressorLoss with the HD contact
+    term -> backward into the regressor."""
+    from tuch_amd.models.smpl import SMPL
+    from tuch_amd.smplify.prior import MaxMixturePrior
+    from tuch_amd.smplify.smplifydc import SMPLifyDC
+    from tuch_amd.train.loss import RegressorLoss
+    from tuch_amd.train.train_module import TUCH
+    from tuch_amd.utils.segmentation import BatchBodySegment
+    g = _golden()
+    batch = int(g['batch'])
+    body = make_body(int(g['rings']), int(g['segs']), relax_iters=int(g['relax_iters']))
+    train_ds, names = _datasets(g)
+    for n in names:
+        np.save(tmp_path / (n + '_fits.npy'), g['static_fits_' + n])
+    options = _options(g, tmp_path)
+    smpl = SMPL(model_data=body, batch_size=batch).to(DEV)
+    face_tensor = torch.tensor(body.faces.astype(np.int64), device=DEV)[None].repeat(batch, 1, 1)
+    geod = torch.tensor(body.geodesics, device=DEV)
+    smplify = SMPLifyDC(step_size=1e-2, batch_size=batch, num_iters=int(options.num_smplify_iters), focal_length=5000.,
+                        geodistssmpl=geod, geothres=0.3, euclthres=0.02, device=DEV, smpl=smpl,
+                        pose_prior=MaxMixturePrior(num_gaussians=8, gmm=body.gmm).to(DEV))
+    criterion = RegressorLoss(options=options, device=DEV, num_verts=body.num_verts, faces=face_tensor, geodistssmpl=geod,
+                              geothres=0.3, face_tensor=face_tensor,
+                              segments=BatchBodySegment(list(body.segments.keys()), face_tensor[0], body.segments),
+                              hd_regressor=(body.hd_bary_idx, body.hd_bary_w), hd_faces=body.hd_face_id)
+    module = TUCH(options=options, device=DEV, datasets=(train_ds, None), bodymodel=smpl, spin_model=make_regressor(11).to(DEV),
+                  regressor=make_regressor(12).to(DEV), optimization=smplify, criterion=criterion, geodistssmpl=geod,
+                  contactlists={'classes': [list(p) for p in body.region_pairs], 'csig': dict(body.regions)})
+    loss, losses, output = module.forward_train_step(_batch(g))
+    loss.backward()
+    assert_close(loss.item(), g['loss'], 1e-3, 1e-5, 'loss')
+    for k, v in losses.items():
+        assert_close(v.cpu().numpy(), g['losses_' + k], 1e-3, 1e-6, 'losses[%s]' % k)
+    assert np.array_equal(output['valid_kpts_anno'].cpu().numpy(), g['output_valid_kpts_anno'])
+    for k in ('pred_vertices', 'opt_vertices', 'pred_cam_t', 'opt_cam_t', 'spin_vertices', 'spin_cam_t', 'gt_keypoints'):
+        want = g['output_' + k]
+        assert_close(output[k].cpu().numpy(), want, 1e-3, 1e-3 * max(np.abs(want).max(), 1e-3), 'output[%s]' % k)
+    assert_close(output['smplifyoptiverts'][-1].cpu().numpy(), g['output_smplifyoptiverts_last'], 1e-3, 1e-3, 'optiverts')
+    for n in names:
+        want = g['fits_after_step_' + n]
+        got = module.fits_dict.fits_dict[n].cpu().numpy()
+        assert np.array_equal((got != g['static_fits_' + n]).any(1), (want != g['static_fits_' + n]).any(1)), 'updated rows ' + n
+        assert_close(got, want, 1e-3, 2e-3, 'fits table ' + n)
+    gw = g['grad_fc_weight']
+    assert_close(module.model.fc.weight.grad.cpu().numpy(), gw, 2e-3, 2e-4 * np.abs(gw).max(), 'regressor gradient')

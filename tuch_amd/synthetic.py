@@ -584,3 +584,63 @@ def write_reference_assets(body: SyntheticBody, root: str, with_extra_vertex_ids
             f.write('%s = %r\n' % (k, val))
         f.write('geothres = 0.3\neuclthres = 0.02\n')
     return paths
+
+
+# ------------------------------------------------------------------ stand-ins for the caller's side of a training step
+def make_regressor(seed: int, img: int = 8):
+    """A deterministic stand-in for the HMR regressor (``hmr(...)`` in train.py): images [B,3,img,img] ->
+    (pred_rotmat [B,24,3,3], pred_betas [B,10], pred_camera [B,3]).  One linear layer (weights from NumPy PCG64, so the
+    same on every device and torch version) followed by the 6D -> rotation-matrix map; the outputs are small
+    perturbations of a mean pose, which is what a trained regressor hands to the losses."""
+    import torch
+    import torch.nn as nn
+
+    class Regressor(nn.Module):
+        def __init__(self):
+            super().__init__()
+            rng = np.random.Generator(np.random.PCG64(seed))
+            self.fc = nn.Linear(3 * img * img, 24 * 6 + 13)
+            with torch.no_grad():
+                self.fc.weight.copy_(torch.tensor(0.02 * rng.standard_normal((24 * 6 + 13, 3 * img * img)), dtype=torch.float32))
+                self.fc.bias.copy_(torch.tensor(0.05 * rng.standard_normal(24 * 6 + 13), dtype=torch.float32))
+            base = np.tile(np.array([1.0, 0.0, 0.0, 1.0, 0.0, 0.0], np.float32), 24)       # identity in 6D form
+            self.register_buffer('mean6d', torch.tensor(base))
+
+        def forward(self, images):
+            x = self.fc(images.flatten(1))
+            r6 = (self.mean6d + x[:, :144]).view(-1, 3, 2)
+            a1, a2 = r6[:, :, 0], r6[:, :, 1]
+            b1 = torch.nn.functional.normalize(a1)
+            b2 = torch.nn.functional.normalize(a2 - (b1 * a2).sum(-1, keepdim=True) * b1)
+            rotmat = torch.stack((b1, b2, torch.cross(b1, b2, dim=1)), dim=-1).view(-1, 24, 3, 3)
+            betas = x[:, 144:154]
+            camera = torch.stack([0.9 + 0.1 * torch.tanh(x[:, 154]), 0.1 * torch.tanh(x[:, 155]), 0.1 * torch.tanh(x[:, 156])], 1)
+            return rotmat, betas, camera
+    return Regressor()
+
+
+def make_train_batch(body: SyntheticBody, batch: int, seed: int, datasets=(('dsA', 50), ('dsB', 30)), img: int = 8) -> dict:
+    """One ``input_batch`` of the reference's training step (train_module.py:105-134) as NumPy arrays + lists."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    bp, go, be = random_poses(batch, seed)
+    names = [datasets[int(i)][0] for i in rng.integers(0, len(datasets), batch)]
+    sizes = dict(datasets)
+    kp = np.concatenate([rng.uniform(-0.8, 0.8, (batch, 49, 2)), rng.uniform(0.3, 1.0, (batch, 49, 1))], 2).astype(np.float32)
+    has_smpl = rng.random(batch) < 0.25
+    return {
+        'img': rng.standard_normal((batch, 3, img, img)).astype(np.float32),
+        'sample_index': np.asarray([rng.integers(0, sizes[n]) for n in names], np.int64),
+        'is_flipped': (rng.random(batch) < 0.5).astype(np.int64),
+        'rot_angle': (rng.uniform(-30, 30, batch) * (rng.random(batch) < 0.6)).astype(np.float32),
+        'dataset_name': names,
+        'has_pose_3d': (rng.random(batch) < 0.5).astype(np.uint8),
+        'has_disc_contact': (rng.random(batch) < 0.6).astype(np.uint8),
+        'has_gt_kpts': (rng.random(batch) < 0.4).astype(np.uint8),
+        'has_smpl': has_smpl.astype(np.uint8),
+        'has_pgt_smpl': (rng.random(batch) < 0.1).astype(np.uint8),
+        'keypoints': kp,
+        'pose_3d': np.concatenate([0.3 * rng.standard_normal((batch, 24, 3)), rng.uniform(0.5, 1.0, (batch, 24, 1))], 2).astype(np.float32),
+        'pose': np.concatenate([go, bp], 1).astype(np.float32),
+        'betas': be,
+        'contact_vec': (rng.random((batch, len(body.region_pairs))) < 0.05).astype(np.float32),
+    }
