@@ -212,10 +212,9 @@ def regressor_loss(p, use_hd):
 
 
 def make_train_step(p, use_hd, smplify_iters=0):
-    """BASELINE configs[3] / [4] per-rank step, the regressor's output replaced by synthetic rotation matrices
-    (train_module.py:202-204, 239-255, 302-317): [SMPLify-DC in the loop for `smplify_iters` + `smplify_iters`
-    iterations ->] SMPL forward with pose2rot=False -> RegressorLoss.contact_loss (mean over the valid bodies of
-    ALL ranks) -> backward to the rotation matrices and betas."""
+    """The contact part of a train.py-style step in isolation (used for the HD / plain comparison): SMPL forward with
+    pose2rot=False (train_module.py:202-204) -> RegressorLoss.contact_loss (mean over the valid bodies of ALL ranks)
+    -> backward to the rotation matrices and betas."""
     from tuch_amd.utils.geometry import batch_rodrigues
     batch = p['body_pose'].shape[0]
     dev = p['body_pose'].device
@@ -224,16 +223,58 @@ def make_train_step(p, use_hd, smplify_iters=0):
     rotmat = batch_rodrigues(full_pose.reshape(-1, 3)).view(batch, 24, 3, 3).detach().requires_grad_(True)
     betas = p['betas'].detach().clone().requires_grad_(True)
     valid = torch.ones(batch, dtype=torch.bool, device=dev)
-    fit = make_fit(p, smplify_iters)[0] if smplify_iters else None
     stats = torch.zeros(2, device=dev)
     stats[1] = float(batch)
 
     def step():
-        if fit is not None:
-            fit()
         rotmat.grad = betas.grad = None
         o = p['smpl'](betas=betas, body_pose=rotmat[:, 1:], global_orient=rotmat[:, :1], pose2rot=False)
         loss = crit.contact_loss(o.vertices, valid)
+        loss.backward()
+        stats[0] = loss.detach() * batch
+        return stats
+    return step
+
+
+def make_tuch_step(p, run_smplify, smplify_iters=10, seed=77):
+    """BASELINE configs[3] / [4] per-rank step: the whole TUCH.forward_train_step (tuch/train/train_module.py:105-335,
+    restated in tuch_amd/train/train_module.py and pinned to the reference's own output by tests/test_gpu_train_step.py)
+    + backward.  The HMR / SPIN regressors are small deterministic stand-ins (tuch_amd.synthetic.make_regressor): the
+    ResNet-50 is stock PyTorch and not part of the path; everything downstream of its output is the real step --
+    SMPL with rotation matrices, rotation matrix -> axis-angle, estimate_translation, the dictionary of best fits,
+    contact_from_verts, [SMPLify-DC in the loop with contact], RegressorLoss with the HD contact term."""
+    import tempfile
+    import types
+    from tuch_amd.smplify.smplifydc import SMPLifyDC
+    from tuch_amd.synthetic import make_regressor, make_train_batch
+    from tuch_amd.train.train_module import TUCH
+    batch = p['body_pose'].shape[0]
+    dev = p['body_pose'].device
+    body = p['body']
+    options = types.SimpleNamespace(
+        batch_size=batch, img_res=224, run_smplify=run_smplify, use_contact_in_the_loop=True,
+        contact_in_the_loop_loss_weight=2000.0, smplify_threshold=100.0, num_smplify_iters=smplify_iters,
+        contact_loss_weight=1.0, shape_loss_weight=0.5, keypoint_loss_weight=5.0, pose_loss_weight=1.0, beta_loss_weight=0.001,
+        openpose_train_weight=0.0, gt_train_weight=1.0, checkpoint_dir=tempfile.mkdtemp(prefix='tuch_bench_'))
+    datasets = (('dsA', 4096), ('dsB', 4096))
+    train_ds = types.SimpleNamespace(dataset_dict={n: i for i, (n, _) in enumerate(datasets)},
+                                     datasets=[range(k) for _, k in datasets])
+    smplify = SMPLifyDC(step_size=1e-2, batch_size=batch, num_iters=smplify_iters, focal_length=5000.,
+                        geodistssmpl=torch.tensor(body.geodesics, device=dev), geothres=0.3, euclthres=0.02, device=dev,
+                        smpl=p['smpl'], pose_prior=p['prior'])
+    module = TUCH(options=options, device=dev, datasets=(train_ds, None), bodymodel=p['smpl'],
+                  spin_model=make_regressor(11).to(dev), regressor=make_regressor(12).to(dev), optimization=smplify,
+                  criterion=regressor_loss(p, True), geodistssmpl=None, contactlists=p['cdict'])
+    raw = make_train_batch(body, batch, seed, datasets)
+    input_batch = {k: (torch.tensor(v, device=dev) if not isinstance(v, list) else v) for k, v in raw.items()}
+    params = [q for q in module.model.parameters()]
+    stats = torch.zeros(2, device=dev)
+    stats[1] = float(batch)
+
+    def step():
+        for q in params:
+            q.grad = None
+        loss, _, _ = module.forward_train_step(input_batch)
         loss.backward()
         stats[0] = loss.detach() * batch
         return stats
@@ -391,14 +432,16 @@ def workloads(device, seed):
     out['config3_fit_b32_100+100_iters'] = {'seconds_per_fit': round(t, 4), 'body_iterations_per_s': round(32 * 200 / t, 1),
                                             'graph_replayed': dict(fitter.graph_replayed)}
     out['config4_shard_b32_train_step'] = {
-        'plain_ms': round(time_kernel(make_train_step(p32, False), 5) * 1e3, 4),
-        'hd_ms': round(time_kernel(make_train_step(p32, True), 3) * 1e3, 4),
-        'what': 'SMPL fwd (pose2rot=False) + RegressorLoss.contact_loss + backward, 32 bodies per rank (256 / 8)'}
+        'ms': round(time_kernel(make_tuch_step(p32, run_smplify=False), 5) * 1e3, 4),
+        'contact_only_plain_ms': round(time_kernel(make_train_step(p32, False), 5) * 1e3, 4),
+        'contact_only_hd_ms': round(time_kernel(make_train_step(p32, True), 3) * 1e3, 4),
+        'what': 'TUCH.forward_train_step (no SMPLify in the loop) + backward, 32 bodies per rank (256 / 8), stand-in '
+                'regressors; contact_only_* = SMPL fwd (pose2rot=False) + RegressorLoss.contact_loss + backward alone'}
     p64 = build_problem(64, device, seed + 2)
     out['config5_shard_b64_in_the_loop_step'] = {
-        'hd_ms': round(time_kernel(make_train_step(p64, True, smplify_iters=10), 2) * 1e3, 4),
-        'what': 'SMPLify-DC 10 + 10 iterations in the loop, then SMPL fwd + contact_loss (HD) + backward, '
-                '64 bodies per rank (512 / 8); the bf16 ResNet regressor is stock PyTorch and not part of the path'}
+        'ms': round(time_kernel(make_tuch_step(p64, run_smplify=True, smplify_iters=10), 2) * 1e3, 4),
+        'what': 'TUCH.forward_train_step with --run_smplify (SMPLify-DC 10 + 10 iterations with contact in the loop) + '
+                'backward, 64 bodies per rank (512 / 8); the bf16 ResNet regressor is stock PyTorch and not part of the path'}
     return out
 
 
@@ -476,13 +519,13 @@ CONFIGS = {
               workload='configs[2]: demo_smplify_dc.py-style fit, batch=%d/GPU, 100 stage-1 + 100 stage-2 iterations per '
                        'step (SMPLifyDC.__call__, loops replayed as hipGraphs), V=6890 F=13776, float32'),
     '4-shard': dict(metric='train.py-style contact-loss steps/sec (bodies/s)', unit='bodies/s', iters_per_step=1,
-                    workload='configs[3] per-rank shard: batch=%d/GPU, SMPL forward (pose2rot=False) + '
-                             'RegressorLoss.contact_loss (HD branch, global valid mean) + backward; frozen regressor '
-                             'replaced by synthetic rotation matrices'),
+                    workload='configs[3] per-rank shard: batch=%d/GPU, TUCH.forward_train_step (regressor stand-in -> SMPL '
+                             'with rotation matrices -> fits dictionary -> RegressorLoss incl. the HD contact term, global '
+                             'valid mean) + backward'),
     '5-shard': dict(metric='SMPLify-DC in-the-loop training steps/sec (bodies/s)', unit='bodies/s', iters_per_step=1,
-                    workload='configs[4] per-rank shard: batch=%d/GPU, SMPLify-DC 10+10 iterations in the loop, then SMPL '
-                             'forward + RegressorLoss.contact_loss (HD) + backward; regressor replaced by synthetic '
-                             'rotation matrices'),
+                    workload='configs[4] per-rank shard: batch=%d/GPU, TUCH.forward_train_step with --run_smplify (SMPLify-DC '
+                             '10+10 iterations with contact in the loop) + RegressorLoss (HD contact term) + backward; '
+                             'regressor stand-in'),
 }
 
 
@@ -522,7 +565,7 @@ def main():
         step = make_fit(p, 100)[0]
         launch = 'SMPLifyDC.__call__ (each loop replayed as a hipGraph after 3 eager iterations)'
     else:
-        step = make_train_step(p, True, smplify_iters=10 if args.config == '5-shard' else 0)
+        step = make_tuch_step(p, run_smplify=args.config == '5-shard', smplify_iters=10)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend == 'nccl':
