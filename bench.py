@@ -204,7 +204,9 @@ def regressor_loss(p, use_hd):
     dev = p['body_pose'].device
     key = ('crit', str(dev), use_hd)
     if key not in _BODY:
-        _BODY[key] = RegressorLoss(types.SimpleNamespace(contact_loss_weight=1.0), dev, body.num_verts, p['face_tensor'],
+        opts = types.SimpleNamespace(contact_loss_weight=1.0, shape_loss_weight=0.5, keypoint_loss_weight=5.0, pose_loss_weight=1.0,
+                                     beta_loss_weight=0.001, openpose_train_weight=0.0, gt_train_weight=1.0)
+        _BODY[key] = RegressorLoss(opts, dev, body.num_verts, p['face_tensor'],
                                    torch.tensor(body.geodesics, device=dev), geothres=0.3, euclthres=0.02,
                                    face_tensor=p['face_tensor'], use_hd=use_hd, segments=p['segments'],
                                    hd_regressor=(body.hd_bary_idx, body.hd_bary_w), hd_faces=body.hd_face_id)
