@@ -12,7 +12,8 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_size_t, c_void_p
 import torch  # noqa: F401  (must be imported first so the HIP runtime it ships is the one in the process)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libtuch_amd.so')
+# TUCH_AMD_LIB: another build of the same library (A/B measurements of kernel variants)
+LIB_PATH = os.environ.get('TUCH_AMD_LIB') or os.path.join(_HERE, 'libtuch_amd.so')
 _lib = None
 
 # name -> (restype, argtypes); mirrors include/tuch_amd.h
