@@ -49,11 +49,13 @@ PEAK_HBM_GBS = 8000.0
 # HBM-side bytes per launch of the winding walk at batch 64 and its VALU-busy fraction: PMC passes committed under
 # profiles/ (see profiles/README.md); constants from those files, NOT measured in this run.
 PROFILE = {
-    'traffic_bytes': int((67906.9 + 24843.7) * 1024),
-    'traffic_source': 'profiles/r01_k_pmc_fetch.txt + r01_k_pmc_write.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
-                      'separate passes, KB x 1024), batch 64; from profiles/, not measured in this run',
-    'valu_busy': None,
-    'valu_busy_source': None,
+    'traffic_bytes': int((21882.8 + 13807.8) * 1024),
+    'traffic_source': 'ray_strips_kernel: profiles/r02_h_pmc_fetch.txt + r02_h_pmc_write.txt (rocprofv3 --pmc FETCH_SIZE / '
+                      'WRITE_SIZE, separate passes, KB x 1024), batch 64; from profiles/, not measured in this run',
+    'valu_busy': 1.03,
+    'valu_busy_source': 'SQ_ACTIVE_INST_VALU x 4 / (1024 x GRBM_GUI_ACTIVE / 8) from profiles/r02_h_pmc_sq.txt (2.065e8, 6.288e6); the '
+                        'counter charges one quad-cycle per VALU instruction; at the 2.2-2.7 cycles per plain FP32 op measured by '
+                        'tools/ubench/valu_rate.hip the issue slots are ~0.6 used; from profiles/, not measured in this run',
 }
 _BODY = {}
 
