@@ -281,3 +281,52 @@ def test_config3_fit_batch32_fullsize(monkeypatch):
                                            focal_length=5000., contact_loss_weight=2000.0, segments=p['segments'])
             n_sel = float(gt[idx].sum())
             assert_close(sub.item(), total, 1e-4, 2000 * 1e-6 * n_sel, 'objective of the sample at iteration %d' % it)
+
+
+def test_loops_kept_between_calls_reproduce_fresh_fits(monkeypatch):
+    """SMPLifyDC keeps its captured loops between calls (a training step runs 10 + 10 iterations per call): a second
+    call with other inputs must give what a fitter without that cache gives, and calls must not disturb each other's
+    returned tensors."""
+    from tuch_amd.smplify.smplifydc import SMPLifyDC
+    from tuch_amd.utils.geometry import perspective_projection
+    monkeypatch.setenv('TUCH_GRAPH_STRICT', '1')
+    batch = 3
+    s = _setup(batch, 31)
+    body, t = s['body'], s['t']
+
+    def inputs(seed):
+        rng = np.random.default_rng(seed)
+        bp, go = s['bp'] + 0.05 * rng.standard_normal(s['bp'].shape).astype(np.float32), s['go']
+        with torch.no_grad():
+            tgt = s['smpl'](global_orient=t(go), body_pose=t(bp) + 0.1, betas=t(s['be']))
+            j2d = perspective_projection(tgt.joints, torch.eye(3, device=DEV)[None].expand(batch, -1, -1),
+                                         t(s['cam_t']), 5000., torch.zeros(batch, 2, device=DEV))
+        kp = torch.cat([j2d, torch.tensor(rng.uniform(0.5, 1, (batch, 49, 1)).astype(np.float32), device=DEV)], 2)
+        gt = t((rng.random((batch, len(body.region_pairs))) < 0.05).astype(np.float32))
+        return torch.cat([t(go), t(bp)], 1), kp, gt
+
+    def fit(fitter, pose, kp, gt):
+        return fitter(pose, t(s['be']), t(s['cam_t']), torch.zeros(batch, 2, device=DEV), kp, use_contact=True,
+                      contactlist=s['cdict'], gt_contact=[gt, None],
+                      ignore_idxs=torch.tensor([False, True, False], device=DEV),
+                      has_discrete_contact=torch.ones(batch, dtype=torch.bool, device=DEV),
+                      has_gt_keypoints=torch.tensor([True, False, False], device=DEV),
+                      contact_loss_weight=2000.0, segments=s['segments'])
+
+    mk = lambda: SMPLifyDC(step_size=1e-2, batch_size=batch, num_iters=8, focal_length=5000., geodistssmpl=t(body.geodesics),
+                           geothres=0.3, euclthres=0.02, device=torch.device(DEV), smpl=s['smpl'], pose_prior=s['prior'])
+    cached = mk()
+    a1 = fit(cached, *inputs(1))
+    keep = [x.clone() for x in a1[:6]]
+    a2 = fit(cached, *inputs(2))
+    assert len(cached._sessions) == 1 and cached.graph_replayed == {'stage1': 8, 'stage2': 8}
+    for x, k in zip(a1[:6], keep):
+        assert torch.equal(x, k)                         # the first call's results were not overwritten by the second
+    monkeypatch.setenv('TUCH_SMPLIFY_SESSIONS', '0')
+    fresh = mk()
+    b2 = fit(fresh, *inputs(2))
+    assert len(fresh._sessions) == 0
+    for a, b, name in zip(a2[:6], b2[:6], ('verts', 'joints', 'pose', 'betas', 'cam', 'reproj')):
+        assert_close(a.cpu().numpy(), b.detach().cpu().numpy(), 2e-3, 2e-4, name)
+    assert len(a2[6]) == len(b2[6]) == 8
+    assert_close(a2[6][-1].cpu().numpy(), b2[6][-1].detach().cpu().numpy(), 2e-3, 2e-4, 'last optiverts')

@@ -79,7 +79,6 @@ def contact_fitting_loss(body_pose, global_orient, body_pose_loop1, opt_global_o
     Bodies in ``ignore_idxs`` get neither contact term.  ``device`` is accepted for signature
     compatibility; the computation runs where ``verts`` lives.
     """
-    from .prior import MaxMixturePrior
     model = contact_model_for(geomask, face_tensor, segments, cdict, device=verts.device)
     valid = ops.cached_derived((ignore_idxs,), lambda: (~ignore_idxs).to(torch.uint8).contiguous())
     select = None
@@ -88,6 +87,18 @@ def contact_fitting_loss(body_pose, global_orient, body_pose_loop1, opt_global_o
             (gt_contact[0], has_discrete_contact, ignore_idxs),
             lambda: ((gt_contact[0] == 1) & has_discrete_contact.bool()[:, None]
                      & (~ignore_idxs)[:, None]).to(torch.uint8).contiguous())
+    return stage2_objective(model, valid, select, body_pose, betas, model_joints, euclthres, camera_t, camera_center,
+                            joints_2d, joints_conf, pose_prior, verts, focal_length, sigma, pose_prior_weight,
+                            contact_loss_weight, apply_segments=segments is not None)
+
+
+def stage2_objective(model, valid, select, body_pose, betas, model_joints, euclthres, camera_t, camera_center, joints_2d,
+                     joints_conf, pose_prior, verts, focal_length=5000, sigma=100, pose_prior_weight=1.0,
+                     contact_loss_weight=1000, apply_segments=True):
+    """The body of contact_fitting_loss on prepared constants: ``model`` (ops.ContactModel), ``valid`` [B] u8 = bodies
+    that get contact terms (~ignore_idxs), ``select`` [B,P] u8 = annotated region pairs of the bodies with discrete
+    contact (or None)."""
+    from .prior import MaxMixturePrior
     fused = (isinstance(pose_prior, MaxMixturePrior) and pose_prior.use_merged and verts.is_cuda
              and not torch.is_tensor(focal_length) and body_pose.shape[1] == 69
              and pose_prior.means.dtype == torch.float32 and pose_prior.means.is_cuda
@@ -102,7 +113,7 @@ def contact_fitting_loss(body_pose, global_orient, body_pose_loop1, opt_global_o
                                      focal_length, sigma, pose_prior_weight ** 2) if fused else None
         return r, sm
     # losses.py:79-89 (inside test) and losses.py:76-78,92-93 (nearest geodesically-far vertex)
-    exterior, _, partner, (r2r, small) = model.exterior_and_partner(verts, apply_segments=segments is not None,
+    exterior, _, partner, (r2r, small) = model.exterior_and_partner(verts, apply_segments=apply_segments,
                                                                     also=beside_the_walk)
     contact_loss, contact_terms = ops.contact_terms(verts, partner, exterior, valid, ops.MODE_SMPLIFY, euclthres)
     if fused:      # objective assembled in one deterministic reduction

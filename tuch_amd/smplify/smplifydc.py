@@ -16,7 +16,8 @@ import os
 import numpy as np
 import torch
 
-from .losses import body_fitting_loss, camera_fitting_loss, contact_fitting_loss
+from .losses import (body_fitting_loss, camera_fitting_loss, contact_fitting_loss, contact_model_for,
+                     stage2_objective)
 from .prior import MaxMixturePrior
 
 log = logging.getLogger(__name__)
@@ -76,6 +77,9 @@ class SMPLifyDC():
         self.record_history = record_history
         self.history = None
         self.graph_replayed = {}
+        # captured loops are kept between calls (keyed by batch size and the constant arguments): a training step
+        # with SMPLify-DC in the loop runs 10 + 10 iterations per call, far too few to pay for two captures each time
+        self._sessions = {}
 
     def _optimise(self, params, iteration, num_iters, adam_kwargs, collect=None, stage=''):
         """Run ``num_iters`` Adam iterations of ``iteration()`` (which returns (loss, vertices))."""
@@ -138,6 +142,137 @@ class SMPLifyDC():
             if collect is not None:
                 collect.append(verts)
 
+    # ------------------------------------------------------------------ loops kept between calls
+    class _Stage:
+        """One Adam loop on static tensors: three eager iterations + capture the first time, replays afterwards."""
+
+        def __init__(self, owner, name, params, iteration, adam_kwargs):
+            self.owner, self.name, self.params, self.iteration = owner, name, params, iteration
+            self.optimizer = torch.optim.Adam(params, lr=owner.step_size, capturable=True, **adam_kwargs)
+            self.graph, self.verts, self.loss = None, None, None
+
+        def _one(self):
+            loss, verts = self.iteration()
+            self.optimizer.zero_grad(set_to_none=True)
+            loss.backward()
+            self.optimizer.step()
+            self.verts, self.loss = verts, loss.detach()
+
+        def run(self, num_iters, collect):
+            for state in self.optimizer.state.values():            # a fresh optimiser per call (smplifydc.py:117,150)
+                for v in state.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+            done = 0
+            if self.graph is None:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(min(3, num_iters)):
+                        self._one()
+                        if collect is not None:
+                            collect.append(self.verts.detach().clone())
+                torch.cuda.current_stream().wait_stream(side)
+                done = min(3, num_iters)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                    self._one()
+                self.graph = graph
+            for _ in range(num_iters - done):
+                self.graph.replay()
+                if collect is not None:
+                    collect.append(self.verts.detach().clone())
+            self.owner.graph_replayed[self.name] = num_iters - done
+
+    def _session(self, batch, use_contact, contactlist, segments, contact_loss_weight, with_pairs, like):
+        key = (batch, bool(use_contact), id(contactlist), id(segments), float(contact_loss_weight), bool(with_pairs))
+        sess = self._sessions.get(key)
+        if sess is not None:
+            return sess
+        dev, f32 = like.device, torch.float32
+        z = lambda *shape, dtype=f32: torch.zeros(*shape, dtype=dtype, device=dev)
+        t = dict(body_pose=z(batch, 69), global_orient=z(batch, 3), betas=z(batch, 10), cam=z(batch, 3), init_cam=z(batch, 3),
+                 centre=z(batch, 2), j2d=z(batch, 49, 2), conf1=z(batch, 49), conf2=z(batch, 49),
+                 valid=z(batch, dtype=torch.uint8))
+        model = None
+        if use_contact:
+            model = contact_model_for(self.geomask, self.face_tensor, segments, contactlist, device=dev)
+            t['select'] = z(batch, model.num_pairs, dtype=torch.uint8) if (with_pairs and model.num_pairs > 0) else None
+        body_pose, global_orient, betas, cam = t['body_pose'], t['global_orient'], t['betas'], t['cam']
+        spw = 1.0 if use_contact else 0.0
+
+        def camera_iteration():
+            out = self.smpl(global_orient=global_orient, body_pose=body_pose, betas=betas)
+            return camera_fitting_loss(out, cam, t['init_cam'], t['centre'], t['j2d'], t['conf1'],
+                                       focal_length=self.focal_length, shape_prior_weight=spw), out.vertices
+
+        def contact_iteration():
+            out = self.smpl(global_orient=global_orient, body_pose=body_pose, betas=betas)
+            loss = stage2_objective(model, t['valid'], t['select'], body_pose, betas, out.joints, self.euclthres, cam,
+                                    t['centre'], t['j2d'], t['conf2'], self.pose_prior, out.vertices,
+                                    focal_length=self.focal_length, contact_loss_weight=contact_loss_weight,
+                                    apply_segments=segments is not None)
+            return loss, out.vertices
+
+        def body_iteration():
+            out = self.smpl(global_orient=global_orient, body_pose=body_pose, betas=betas)
+            return body_fitting_loss(body_pose, betas, out.joints, cam, t['centre'], t['j2d'], t['conf2'], self.pose_prior,
+                                     focal_length=self.focal_length), out.vertices
+
+        def flags(bp, go, be, ct):
+            body_pose.requires_grad, global_orient.requires_grad, betas.requires_grad, cam.requires_grad = bp, go, be, ct
+        sess = dict(t=t, flags=flags, use_contact=use_contact)
+        # stage 1 optimises [betas, cam] with contact, [global_orient, cam] without (smplifydc.py:104-117)
+        flags(False, not use_contact, bool(use_contact), True)
+        sess['stage1'] = self._Stage(self, 'stage1', [betas, cam] if use_contact else [global_orient, cam], camera_iteration,
+                                     dict(betas=(0.9, 0.999)))
+        if use_contact:
+            sess['stage2'] = (lambda: flags(True, True, False, False),
+                              lambda: self._Stage(self, 'stage2', [body_pose, global_orient], contact_iteration, {}))
+        else:
+            sess['stage2'] = (lambda: flags(True, True, True, False),
+                              lambda: self._Stage(self, 'stage2', [body_pose, betas, global_orient], body_iteration,
+                                                  dict(betas=(0.9, 0.999))))
+        while len(self._sessions) >= 4:
+            self._sessions.pop(next(iter(self._sessions)))
+        self._sessions[key] = sess
+        return sess
+
+    def _call_cached(self, init_pose, init_betas, init_cam_t, camera_center, keypoints_2d, use_contact, contactlist,
+                     gt_contact, ignore_idxs, has_discrete_contact, has_gt_keypoints, contact_loss_weight, segments):
+        batch = init_pose.shape[0]
+        with_pairs = gt_contact is not None and gt_contact[0] is not None
+        sess = self._session(batch, use_contact, contactlist, segments, contact_loss_weight, with_pairs, init_pose)
+        t = sess['t']
+        with torch.no_grad():
+            t['body_pose'].copy_(init_pose[:, 3:]); t['global_orient'].copy_(init_pose[:, :3]); t['betas'].copy_(init_betas)
+            t['cam'].copy_(init_cam_t); t['init_cam'].copy_(init_cam_t); t['centre'].copy_(camera_center)
+            t['j2d'].copy_(keypoints_2d[:, :, :2]); t['conf1'].copy_(keypoints_2d[:, :, -1])
+            t['conf2'].copy_(keypoints_2d[:, :, -1])
+            t['conf2'][:, self.ign_joints] = 0.0                                         # smplifydc.py:153,198
+            if use_contact:
+                t['valid'].copy_(~ignore_idxs)
+                if t.get('select') is not None:
+                    t['select'].copy_((gt_contact[0] == 1) & has_discrete_contact.bool()[:, None] & (~ignore_idxs)[:, None])
+        sess['flags'](False, not use_contact, bool(use_contact), True)
+        sess['stage1'].run(self.num_iters, None)
+        set_flags, make_stage = sess['stage2']
+        set_flags()
+        if not isinstance(sess.get('stage2_obj'), self._Stage):
+            sess['stage2_obj'] = make_stage()
+        optiverts = []
+        sess['stage2_obj'].run(self.num_iters, optiverts)
+        with torch.no_grad():
+            out = self.smpl(global_orient=t['global_orient'], body_pose=t['body_pose'], betas=t['betas'], return_full_pose=True)
+            conf = t['conf2'].clone()
+            if has_gt_keypoints is not None:                                             # smplifydc.py:219-220, no host sync
+                conf[:, :25] = torch.where(has_gt_keypoints.bool()[:, None], torch.zeros_like(conf[:, :25]), conf[:, :25])
+            reprojection_loss = body_fitting_loss(t['body_pose'], t['betas'], out.joints, t['cam'], t['centre'], t['j2d'], conf,
+                                                  self.pose_prior, focal_length=self.focal_length, output='reprojection')
+        pose = torch.cat([t['global_orient'], t['body_pose']], dim=-1).detach().clone()
+        return (out.vertices.detach(), out.joints.detach(), pose, t['betas'].detach().clone(), t['cam'].detach().clone(),
+                reprojection_loss, optiverts if optiverts else None)
+
     def __call__(self, init_pose, init_betas, init_cam_t,
                  camera_center, keypoints_2d, use_contact=False,
                  contactlist=[], gt_contact=None,
@@ -146,6 +281,19 @@ class SMPLifyDC():
                  contact_loss_return='sum', segments=None):
         """Fit a batch of bodies.  Returns (vertices, joints, pose, betas, camera_translation,
         reprojection_loss, optiverts) exactly like the reference (smplifydc.py:231-236)."""
+        if (self.use_graph and init_pose.is_cuda and self.num_iters > 4 and not self.record_history
+                and os.environ.get('TUCH_SMPLIFY_SESSIONS', '1') != '0'
+                and (not use_contact or (ignore_idxs is not None and isinstance(contactlist, (dict, list))))):
+            try:
+                return self._call_cached(init_pose, init_betas, init_cam_t, camera_center, keypoints_2d, use_contact,
+                                         contactlist, gt_contact, ignore_idxs, has_discrete_contact, has_gt_keypoints,
+                                         contact_loss_weight, segments)
+            except Exception as exc:
+                if os.environ.get('TUCH_GRAPH_STRICT', '0') == '1':
+                    raise
+                log.warning('SMPLifyDC: the cached hipGraph loops failed (%r); running this call without them', exc)
+                self._sessions.clear()
+                torch.cuda.synchronize()
         if self.record_history:
             self.history = {'stage1': [], 'stage2': []}
         camera_translation = init_cam_t.clone()
