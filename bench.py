@@ -548,6 +548,9 @@ def main():
     local = local % torch.cuda.device_count() if backend == 'gloo' else local
     device = torch.device('cuda', local)
     torch.cuda.set_device(local)
+    # everything below runs on a created stream: hipGraph replays on the legacy NULL stream are not reliably ordered
+    # against the work around them (tuch_amd/ops.py:off_default_stream)
+    torch.cuda.set_stream(torch.cuda.Stream(device=device))
     if args.global_batch is not None:
         if args.global_batch % world:
             raise SystemExit('--global-batch %d is not divisible by %d ranks' % (args.global_batch, world))

@@ -829,28 +829,30 @@ def test_hd_branch_selection_partners_and_graph_capture(tag):
         got = np.sort(sel[b, :counts[b]])
         assert (sel[b, counts[b]:] == -1).all()
         assert np.array_equal(got, want), (b, len(got), len(want))
-    # hipGraph capture of forward + backward
+    # hipGraph capture of forward + backward (replays never on the NULL stream: tuch_amd/ops.py:off_default_stream)
+    from tuch_amd.ops import off_default_stream
     static_v = torch.tensor(g['verts'], device=d, requires_grad=True)
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(2):
-            static_v.grad = None
-            crit.contact_loss(static_v, valid).backward()
-    torch.cuda.current_stream().wait_stream(side)
-    graph = torch.cuda.CUDAGraph()
-    static_v.grad = None
-    with torch.cuda.graph(graph, capture_error_mode='thread_local'):
-        out = crit.contact_loss(static_v, valid)
-        out.backward()
-    graph.replay()
-    torch.cuda.synchronize()
-    assert abs(out.item() - loss.item()) <= 1e-6 * abs(loss.item())
-    assert torch.allclose(static_v.grad, verts.grad, rtol=1e-4, atol=1e-6 * float(verts.grad.abs().max()))
-    # new vertices through the same graph
-    with torch.no_grad():
-        static_v.copy_(torch.tensor(g['verts'], device=d).flip(0))
-    graph.replay()
+    with off_default_stream(d):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                static_v.grad = None
+                crit.contact_loss(static_v, valid).backward()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        static_v.grad = None
+        with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+            out = crit.contact_loss(static_v, valid)
+            out.backward()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert abs(out.item() - loss.item()) <= 1e-6 * abs(loss.item())
+        assert torch.allclose(static_v.grad, verts.grad, rtol=1e-4, atol=1e-6 * float(verts.grad.abs().max()))
+        # new vertices through the same graph
+        with torch.no_grad():
+            static_v.copy_(torch.tensor(g['verts'], device=d).flip(0))
+        graph.replay()
     flipped = torch.tensor(g['verts'], device=d).flip(0).requires_grad_(True)
     want2 = crit.contact_loss(flipped, valid)
     assert abs(out.item() - want2.item()) <= 1e-5 * abs(want2.item()) + 1e-7

@@ -5,6 +5,7 @@ eager/CPU fallback.  Index outputs are int64 like the reference's torch ops.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -32,6 +33,34 @@ def _side_stream(device) -> 'torch.cuda.Stream':
     if key not in _SIDE_STREAMS:
         _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
     return _SIDE_STREAMS[key]
+
+
+_GRAPH_STREAMS = {}
+
+
+@contextlib.contextmanager
+def off_default_stream(device):
+    """Run the body on a non-default stream when the current stream is the legacy default (NULL) stream.
+
+    hipGraph replays on the NULL stream are not reliably ordered against the kernels, copies and memsets enqueued
+    around them (ROCm 7.2, graphs with forked branches: observed as stale inputs / un-reset optimiser state in about
+    every second call, never on a created stream).  Every place in this package that replays a captured graph does it
+    inside this context; the two streams are joined with events on entry and exit, so callers see stream semantics."""
+    device = torch.device(device)
+    cur = torch.cuda.current_stream(device)
+    if cur != torch.cuda.default_stream(device):
+        yield cur
+        return
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    s = _GRAPH_STREAMS.get(key)
+    if s is None:
+        s = _GRAPH_STREAMS[key] = torch.cuda.Stream(device=device)
+    s.wait_stream(cur)
+    try:
+        with torch.cuda.stream(s):
+            yield s
+    finally:
+        cur.wait_stream(s)
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:

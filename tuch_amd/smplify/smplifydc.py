@@ -245,15 +245,16 @@ class SMPLifyDC():
         sess = self._session(batch, use_contact, contactlist, segments, contact_loss_weight, with_pairs, init_pose)
         t = sess['t']
         with torch.no_grad():
-            t['body_pose'].copy_(init_pose[:, 3:]); t['global_orient'].copy_(init_pose[:, :3]); t['betas'].copy_(init_betas)
-            t['cam'].copy_(init_cam_t); t['init_cam'].copy_(init_cam_t); t['centre'].copy_(camera_center)
-            t['j2d'].copy_(keypoints_2d[:, :, :2]); t['conf1'].copy_(keypoints_2d[:, :, -1])
-            t['conf2'].copy_(keypoints_2d[:, :, -1])
+            put = lambda dst, src: dst.copy_(src)
+            put(t['body_pose'], init_pose[:, 3:]); put(t['global_orient'], init_pose[:, :3]); put(t['betas'], init_betas)
+            put(t['cam'], init_cam_t); put(t['init_cam'], init_cam_t); put(t['centre'], camera_center)
+            put(t['j2d'], keypoints_2d[:, :, :2]); put(t['conf1'], keypoints_2d[:, :, -1])
+            put(t['conf2'], keypoints_2d[:, :, -1])
             t['conf2'][:, self.ign_joints] = 0.0                                         # smplifydc.py:153,198
             if use_contact:
-                t['valid'].copy_(~ignore_idxs)
+                put(t['valid'], ~ignore_idxs)
                 if t.get('select') is not None:
-                    t['select'].copy_((gt_contact[0] == 1) & has_discrete_contact.bool()[:, None] & (~ignore_idxs)[:, None])
+                    put(t['select'], (gt_contact[0] == 1) & has_discrete_contact.bool()[:, None] & (~ignore_idxs)[:, None])
         sess['flags'](False, not use_contact, bool(use_contact), True)
         sess['stage1'].run(self.num_iters, None)
         set_flags, make_stage = sess['stage2']
@@ -281,6 +282,18 @@ class SMPLifyDC():
                  contact_loss_return='sum', segments=None):
         """Fit a batch of bodies.  Returns (vertices, joints, pose, betas, camera_translation,
         reprojection_loss, optiverts) exactly like the reference (smplifydc.py:231-236)."""
+        if not (self.use_graph and init_pose.is_cuda):
+            return self._fit(init_pose, init_betas, init_cam_t, camera_center, keypoints_2d, use_contact, contactlist,
+                             gt_contact, ignore_idxs, has_discrete_contact, has_gt_keypoints, contact_loss_weight,
+                             contact_loss_return, segments)
+        from ..ops import off_default_stream
+        with off_default_stream(init_pose.device):       # graph replays never run on the NULL stream (ops.py)
+            return self._fit(init_pose, init_betas, init_cam_t, camera_center, keypoints_2d, use_contact, contactlist,
+                             gt_contact, ignore_idxs, has_discrete_contact, has_gt_keypoints, contact_loss_weight,
+                             contact_loss_return, segments)
+
+    def _fit(self, init_pose, init_betas, init_cam_t, camera_center, keypoints_2d, use_contact, contactlist, gt_contact,
+             ignore_idxs, has_discrete_contact, has_gt_keypoints, contact_loss_weight, contact_loss_return, segments):
         if (self.use_graph and init_pose.is_cuda and self.num_iters > 4 and not self.record_history
                 and os.environ.get('TUCH_SMPLIFY_SESSIONS', '1') != '0'
                 and (not use_contact or (ignore_idxs is not None and isinstance(contactlist, (dict, list))))):
