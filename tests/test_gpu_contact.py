@@ -404,6 +404,37 @@ def test_regressor_contact_loss_vs_reference(tag, use_hd):
     assert_close(verts.grad.cpu().numpy(), gv, 1e-3, 5e-6 * np.abs(gv).max(), key + ' grad')
 
 
+@pytest.mark.parametrize('tag', ['small', 'medium'])
+def test_regressor_contact_loss_hd_asymmetric_mask(tag):
+    """A geodesic mask is symmetric, but nothing in loss.py:288-291 needs it to be: with pairs dropped one way only,
+    row and column of geomask[vid_row][vid_col] must not be mixed up anywhere in the HD branch -- same loss and gradient
+    as the restated reference on that mask."""
+    import types
+    from tuch_amd.train.loss import RegressorLoss
+    from tuch_amd.utils.segmentation import BatchBodySegment
+    g, gm = golden(tag), golden_mask(tag)
+    rng = np.random.default_rng(5)
+    asym = gm & (rng.random(gm.shape) < 0.6)
+    assert (asym != asym.T).any()
+    d = dev()
+    batch = g['verts'].shape[0]
+    face_tensor = torch.tensor(g['faces'], device=d)[None].repeat(batch, 1, 1)
+    segs = gio.unpack_segments(g)
+    segments = BatchBodySegment(list(segs.keys()), face_tensor[0], segs)
+    geod = torch.tensor(np.where(asym, 1.0, 0.0).astype(np.float32), device=d)
+    crit = RegressorLoss(types.SimpleNamespace(contact_loss_weight=1.0), d, g['verts'].shape[1], face_tensor,
+                         geod, geothres=0.3, euclthres=float(g['euclthres']), face_tensor=face_tensor,
+                         use_hd=True, segments=segments, hd_regressor=(g['hd_idx'], g['hd_w']), hd_faces=g['hd_face'])
+    verts = torch.tensor(g['verts'], device=d, requires_grad=True)
+    loss = crit.contact_loss(verts, torch.tensor(g['valid_fit'], device=d))
+    loss.backward()
+    ref_loss, ref_grad, _ = oc.train_contact_loss(g['verts'], g['valid_fit'], g['faces'], asym, float(g['euclthres']),
+                                                  oracle_segments(g), True, hd_idx=g['hd_idx'], hd_w=g['hd_w'],
+                                                  hd_face=g['hd_face'])
+    assert_close(loss.item(), ref_loss, 1e-4, 0, 'hd loss, asymmetric mask')
+    assert_close(verts.grad.cpu().numpy(), ref_grad, 1e-3, 5e-6 * np.abs(ref_grad).max(), 'hd grad, asymmetric mask')
+
+
 def test_contact_from_verts_class():
     from tuch_amd.train.train_module import TUCH
     g = golden('medium')

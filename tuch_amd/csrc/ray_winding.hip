@@ -170,10 +170,15 @@ __device__ __forceinline__ void ray_step(const RayElem el, P3 (&s)[3], float (&e
     // e[A] = e(Bq -> Cq) is carried over from the previous triangle; the two edges at the new vertex:
     e[Bq] = edge_fn(s[Cq], s[A]);
     e[Cq] = edge_fn(s[A], s[Bq]);
-    if (el.sign != 0.0f) {                                        // wave-uniform
+    // The origin may be inside the projection (ties included) iff all edge functions are >= 0 or all <= 0, i.e. iff
+    // mn * mx >= 0: ONE compare + ballot branch per element.  (Measured on gfx950, tools/ubench/valu_rate2.hip: the
+    // two-compare form `mn >= 0 | mx <= 0` costs ~22 cycles per element in compare -> mask -> scalar OR -> branch, the
+    // product form ~11; a plain FP32 op 2.3.)  The element is wave-uniform (scalar loads), so skipping the two priming
+    // vertices of a strip is a scalar branch.
+    if (el.sign != 0.0f) {
         const float mn = __builtin_fminf(__builtin_fminf(e[0], e[1]), e[2]);
         const float mx = __builtin_fmaxf(__builtin_fmaxf(e[0], e[1]), e[2]);
-        const bool cand = (mn >= 0.0f) | (mx <= 0.0f);           // the origin may be inside the projection (ties included)
+        const bool cand = mn * mx >= 0.0f;
         if (__builtin_amdgcn_ballot_w64(cand)) {                  // a few hits per ray
             // triangle (Bq, Cq, A): det = sum of (edge function opposite a corner) x (that corner's depth)
             const float numz = e[Bq] * s[Bq].z + e[Cq] * s[Cq].z + e[A] * s[A].z;
@@ -181,8 +186,8 @@ __device__ __forceinline__ void ray_step(const RayElem el, P3 (&s)[3], float (&e
             // crossing is +1 (leaving through the front) for the positive orientation, -1 for the negative one
             int c = ((mn > 0.0f) & (numz > 0.0f)) - ((mx < 0.0f) & (numz < 0.0f));
             // exact ties.  The faces around a query vertex (two edge functions through the origin) always tie, but
-            // their det is exactly 0 (the zero corner), so the generic form already counts them as 0: the careful form
-            // is only needed where det != 0, i.e. for rays through an edge or a corner of some OTHER triangle
+            // their det is exactly 0 (the zero corner), so the generic form already counts them as 0: the careful
+            // form is only needed where det != 0, i.e. for rays through an edge or a corner of some OTHER triangle
             const bool tie = cand & ((mn == 0.0f) | (mx == 0.0f)) & (numz != 0.0f);
             if (__builtin_amdgcn_ballot_w64(tie)) {
                 if (tie) c = crossing_with_ties<kSkipIncident>(s[Bq], s[Cq], s[A], e[Bq], e[Cq], e[A]);

@@ -213,8 +213,9 @@ __global__ __launch_bounds__(64 * kIndexedWaves) void v2v_indexed_kernel(
     const int ac = min(a, n - 1);
     const float px = pts[3 * (size_t)(beg + ac)], py = pts[3 * (size_t)(beg + ac) + 1], pz = pts[3 * (size_t)(beg + ac) + 2];
     const int va = vid[beg + ac];
-    const uint64_t* col = bits + (size_t)(va >> 6) * V;
-    const int sh = va & 63;
+    // the column's bit of a row's mask word sits in one 32-bit half of it: only that half is gathered
+    const uint32_t* col = reinterpret_cast<const uint32_t*>(bits + (size_t)(va >> 6) * V) + ((va >> 5) & 1);
+    const uint32_t bit = 1u << (va & 31);
     const float inf = __builtin_inff();
     float best = inf;
     int arg = 0;
@@ -228,37 +229,53 @@ __global__ __launch_bounds__(64 * kIndexedWaves) void v2v_indexed_kernel(
     }
     const float* rp = pts + 3 * (size_t)beg;
     const int32_t* rv = vid + beg;
-    auto row = [&](int r, uint64_t word, float qx, float qy, float qz) {
+    auto dist = [&](uint32_t word, float qx, float qy, float qz) {
         const float dx = px - qx, dy = py - qy, dz = pz - qz;
-        float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-        if (!((word >> sh) & 1)) d = inf;
-        if (__builtin_amdgcn_ballot_w64(d <= best && d < inf)) {             // rare, wave-uniform
-            if (d < best || (d == best && d < inf && r < arg)) { best = d; arg = r; }
-        }
+        const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        return (word & bit) ? d : inf;
+    };
+    auto take = [&](int r, float d) {
+        if (d < best || (d == best && d < inf && r < arg)) { best = d; arg = r; }
+    };
+    auto row = [&](int r, int v, float qx, float qy, float qz) {
+        const float d = dist(col[2 * (size_t)v], qx, qy, qz);
+        if (__builtin_amdgcn_ballot_w64(d <= best)) take(r, d);              // wave-uniform
     };
     // kTrip rows r0, r0+step, ...: coordinates and template vertices through scalar loads, the per-lane
-    // gathers of the mask words (word = column's 64-vertex block x row's vertex) issued together so that
-    // their latency overlaps
-    constexpr int kTrip = 8;      // rows per trip: the wavefront is latency-bound on the scalar loads, not on the math
+    // gathers of the mask words (word = column's 32-vertex block x row's vertex) issued together so that
+    // their latency overlaps.  ONE compare + ballot branch per trip: on gfx950 a compare -> mask -> branch costs as
+    // much as four FP32 ops (tools/ubench/valu_rate2.hip), and improvements are rare once the bounds have settled.
+    constexpr int kTrip = 8;
     auto rows_trip = [&](int r0, int step) {
         float q[3 * kTrip];
         int v[kTrip];
-        uint64_t w[kTrip];
+        uint32_t w[kTrip];
+        // one base address per trip: the 8 ids and 24 coordinates then come in as a few wide scalar loads
+        const int32_t* vp = rv + (size_t)r0;
+        const float* qp = rp + 3 * (size_t)r0;
 #pragma unroll
         for (int u = 0; u < kTrip; ++u) {
-            v[u] = rv[r0 + u * step];
-            q[3 * u] = rp[3 * (r0 + u * step)]; q[3 * u + 1] = rp[3 * (r0 + u * step) + 1]; q[3 * u + 2] = rp[3 * (r0 + u * step) + 2];
+            v[u] = vp[u * step];
+            q[3 * u] = qp[3 * u * step]; q[3 * u + 1] = qp[3 * u * step + 1]; q[3 * u + 2] = qp[3 * u * step + 2];
         }
         // consecutive points usually inherit the same template vertex (samples of one face): the gather is
         // repeated only when the row's vertex changes (wave-uniform test)
-        w[0] = col[v[0]];
+        w[0] = col[2 * (size_t)v[0]];
 #pragma unroll
         for (int u = 1; u < kTrip; ++u) {
-            if (v[u] != v[u - 1]) w[u] = col[v[u]];
+            if (v[u] != v[u - 1]) w[u] = col[2 * (size_t)v[u]];
             else w[u] = w[u - 1];
         }
+        float d[kTrip];
 #pragma unroll
-        for (int u = 0; u < kTrip; ++u) row(r0 + u * step, w[u], q[3 * u], q[3 * u + 1], q[3 * u + 2]);
+        for (int u = 0; u < kTrip; ++u) d[u] = dist(w[u], q[3 * u], q[3 * u + 1], q[3 * u + 2]);
+        float m = d[0];
+#pragma unroll
+        for (int u = 1; u < kTrip; ++u) m = __builtin_fminf(m, d[u]);
+        if (__builtin_amdgcn_ballot_w64(m <= best)) {
+#pragma unroll
+            for (int u = 0; u < kTrip; ++u) take(r0 + u * step, d[u]);      // in row order: ties go to the smaller row
+        }
     };
     // chunks are dealt to the wavefronts round-robin: the chunks that survive the pruning are neighbours
     // (the contact partner's patch), contiguous shares would leave them all to one wavefront
@@ -281,18 +298,23 @@ __global__ __launch_bounds__(64 * kIndexedWaves) void v2v_indexed_kernel(
         if (r + 24 < n) {
             float q[12];
             int v[4];
-            uint64_t w[4];
+            uint32_t w[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 v[u] = rv[r + 8 * u];
                 q[3 * u] = rp[3 * (r + 8 * u)]; q[3 * u + 1] = rp[3 * (r + 8 * u) + 1]; q[3 * u + 2] = rp[3 * (r + 8 * u) + 2];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) w[u] = col[v[u]];
+            for (int u = 0; u < 4; ++u) w[u] = col[2 * (size_t)v[u]];
+            float d[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) row(r + 8 * u, w[u], q[3 * u], q[3 * u + 1], q[3 * u + 2]);
+            for (int u = 0; u < 4; ++u) d[u] = dist(w[u], q[3 * u], q[3 * u + 1], q[3 * u + 2]);
+            if (__builtin_amdgcn_ballot_w64(__builtin_fminf(__builtin_fminf(d[0], d[1]), __builtin_fminf(d[2], d[3])) <= best)) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) take(r + 8 * u, d[u]);
+            }
         } else {
-            for (int rr = r; rr < n; rr += 8) row(rr, col[rv[rr]], rp[3 * rr], rp[3 * rr + 1], rp[3 * rr + 2]);
+            for (int rr = r; rr < n; rr += 8) row(rr, rv[rr], rp[3 * rr], rp[3 * rr + 1], rp[3 * rr + 2]);
         }
     }
     merge();
@@ -307,7 +329,7 @@ __global__ __launch_bounds__(64 * kIndexedWaves) void v2v_indexed_kernel(
         int r = c * kIndexedChunk;
         const int re = min(n, r + kIndexedChunk);
         for (; r + kTrip <= re; r += kTrip) rows_trip(r, 1);
-        for (; r < re; ++r) row(r, col[rv[r]], rp[3 * r], rp[3 * r + 1], rp[3 * r + 2]);
+        for (; r < re; ++r) row(r, rv[r], rp[3 * r], rp[3 * r + 1], rp[3 * r + 2]);
     }
     merge();
     if (wave == 0 && a < n) {
@@ -393,12 +415,16 @@ __device__ __forceinline__ void v2v_rows(Column& c, const float* __restrict__ pb
                                          int j0, int n)
 {
     const float inf = __builtin_inff();
-    auto row = [&](int j, uint64_t k0, float vx, float vy, float vz) {
+    auto dist = [&](uint64_t k0, float vx, float vy, float vz) {
         const float dx = c.px - vx, dy = c.py - vy, dz = c.pz - vz;
-        const float d = select_by_lane_mask(inf, __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)), k0);
-        if (__builtin_amdgcn_ballot_w64(d <= c.best)) {                       // rare, wave-uniform
-            if (d < c.best || (d == c.best && d < inf && j < c.arg)) { c.best = d; c.arg = j; }
-        }
+        return select_by_lane_mask(inf, __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)), k0);
+    };
+    auto take = [&](int j, float d) {
+        if (d < c.best || (d == c.best && d < inf && j < c.arg)) { c.best = d; c.arg = j; }
+    };
+    auto row = [&](int j, uint64_t k0, float vx, float vy, float vz) {
+        const float d = dist(k0, vx, vy, vz);
+        if (__builtin_amdgcn_ballot_w64(d <= c.best)) take(j, d);              // rare, wave-uniform
     };
     int j = j0;
     const int j_end = j0 + n;
@@ -409,8 +435,16 @@ __device__ __forceinline__ void v2v_rows(Column& c, const float* __restrict__ pb
         for (int u = 0; u < 4; ++u) k0[u] = m0[j + u];
 #pragma unroll
         for (int u = 0; u < 12; ++u) v[u] = pb[3 * j + u];
+        float d[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) row(j + u, k0[u], v[3 * u], v[3 * u + 1], v[3 * u + 2]);
+        for (int u = 0; u < 4; ++u) d[u] = dist(k0[u], v[3 * u], v[3 * u + 1], v[3 * u + 2]);
+        // ONE compare + ballot branch per four rows (a compare -> mask -> branch costs as much as four FP32 ops on
+        // gfx950, tools/ubench/valu_rate2.hip); improvements are rare once the bounds have settled
+        const float m = __builtin_fminf(__builtin_fminf(__builtin_fminf(d[0], d[1]), d[2]), d[3]);
+        if (__builtin_amdgcn_ballot_w64(m <= c.best)) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) take(j + u, d[u]);                     // in row order: ties go to the smaller row
+        }
     }
     for (; j < j_end; ++j) row(j, m0[j], pb[3 * j], pb[3 * j + 1], pb[3 * j + 2]);
 }
