@@ -157,8 +157,9 @@ int tuch_winding_tree_work(const tuch_contact_model* model, const float* verts, 
                            size_t workspace_bytes, unsigned long long* out_host, void* stream);
 
 /* Measurement aid for the ray-crossing inside test (csrc/ray_winding.hip) that tuch_exterior_flags and
- * tuch_winding_points use when only the flags are wanted: out_host[2] = {strip elements stepped through by all
- * wavefronts (64 queries each), wavefronts}.  Workspace as for tuch_exterior_flags.  Synchronises the stream. */
+ * tuch_winding_points use when only the flags are wanted: out_host[4] = {strip elements stepped through by all
+ * wavefronts (64 queries each), (ray, element) pairs whose ray passes the slabs of the element's leaf, 64 x elements
+ * listed, wavefronts}: [1] / [2] is the share of lanes that can have a crossing at all.  Workspace as for tuch_exterior_flags.  Synchronises the stream. */
 int tuch_ray_work(const tuch_contact_model* model, const float* verts, int B, void* workspace,
                   size_t workspace_bytes, unsigned long long* out_host, void* stream);
 /* The cluster tree the model built for itself: qperm_host [V] = vertices in tree order, face_leaf_host [F] = leaf

@@ -157,9 +157,9 @@ __device__ __forceinline__ int crossing_with_ties(const P3 a, const P3 b, const 
 
 // One leaf strip, elements [off, off+len), len % 3 == 0, three readable elements past the end.  Register slots are
 // rotated by position modulo 3 like the solid-angle walk; e[k] = edge function of the edge opposite slot k in
-// stream order (p-2 -> p-1 -> p).  Fast path (most elements): two new edge functions, min3 / max3, one ballot.
-// Elements whose projection holds the ray of some lane: depth test, +-1; lanes with an exact tie (and, for vertex
-// queries, the faces around the query itself) take the careful form.
+// stream order (p-2 -> p-1 -> p).  Per element: two new edge functions, the depth determinant, and a branch-free
+// +-1 (the rays of a wavefront all pass the leaf's slabs, so most elements are hit by SOME lane: a "does any lane
+// hit" branch would almost always be taken).  Lanes with an exact tie take the careful form.
 template <int A, bool kSkipIncident>
 __device__ __forceinline__ void ray_step(const RayElem el, P3 (&s)[3], float (&e)[3], float qx, float qy, float qz, int& count)
 {
@@ -170,30 +170,26 @@ __device__ __forceinline__ void ray_step(const RayElem el, P3 (&s)[3], float (&e
     // e[A] = e(Bq -> Cq) is carried over from the previous triangle; the two edges at the new vertex:
     e[Bq] = edge_fn(s[Cq], s[A]);
     e[Cq] = edge_fn(s[A], s[Bq]);
-    // The origin may be inside the projection (ties included) iff all edge functions are >= 0 or all <= 0, i.e. iff
-    // mn * mx >= 0: ONE compare + ballot branch per element.  (Measured on gfx950, tools/ubench/valu_rate2.hip: the
-    // two-compare form `mn >= 0 | mx <= 0` costs ~22 cycles per element in compare -> mask -> scalar OR -> branch, the
-    // product form ~11; a plain FP32 op 2.3.)  The element is wave-uniform (scalar loads), so skipping the two priming
-    // vertices of a strip is a scalar branch.
-    if (el.sign != 0.0f) {
+    if (el.sign != 0.0f) {                                        // wave-uniform: the two priming vertices of a strip
+        // triangle (Bq, Cq, A): det = sum of (edge function opposite a corner) x (that corner's depth)
+        const float numz = e[Bq] * s[Bq].z + e[Cq] * s[Cq].z + e[A] * s[A].z;
         const float mn = __builtin_fminf(__builtin_fminf(e[0], e[1]), e[2]);
         const float mx = __builtin_fmaxf(__builtin_fmaxf(e[0], e[1]), e[2]);
-        const bool cand = mn * mx >= 0.0f;
-        if (__builtin_amdgcn_ballot_w64(cand)) {                  // a few hits per ray
-            // triangle (Bq, Cq, A): det = sum of (edge function opposite a corner) x (that corner's depth)
-            const float numz = e[Bq] * s[Bq].z + e[Cq] * s[Cq].z + e[A] * s[A].z;
-            // generic position: all edge functions of one sign; the hit is in front iff det has that sign, and the
-            // crossing is +1 (leaving through the front) for the positive orientation, -1 for the negative one
-            int c = ((mn > 0.0f) & (numz > 0.0f)) - ((mx < 0.0f) & (numz < 0.0f));
-            // exact ties.  The faces around a query vertex (two edge functions through the origin) always tie, but
-            // their det is exactly 0 (the zero corner), so the generic form already counts them as 0: the careful
-            // form is only needed where det != 0, i.e. for rays through an edge or a corner of some OTHER triangle
-            const bool tie = cand & ((mn == 0.0f) | (mx == 0.0f)) & (numz != 0.0f);
+        // generic position: the origin is inside the projection iff the edge functions have one sign, the hit is in
+        // front iff det has that sign too; +1 (leaving through the front) for the positive orientation, -1 for the
+        // negative one.  The faces around a query vertex (two edge functions through the origin, det exactly 0)
+        // count 0 here, as they must.
+        int c = (int)(__builtin_fminf(mn, numz) > 0.0f) - (int)(__builtin_fmaxf(mx, numz) < 0.0f);
+        // exact ties: some edge function is zero (mn * mx == 0: all are >= 0 or all <= 0 then) and det is not, i.e. the
+        // ray passes through an edge or a corner of a triangle that does not contain the query
+        const bool edge_zero = mn * mx == 0.0f;
+        if (__builtin_amdgcn_ballot_w64(edge_zero)) {             // the wavefronts of a query's own leaf; else rare
+            const bool tie = edge_zero & (numz != 0.0f);
             if (__builtin_amdgcn_ballot_w64(tie)) {
                 if (tie) c = crossing_with_ties<kSkipIncident>(s[Bq], s[Cq], s[A], e[Bq], e[Cq], e[A]);
             }
-            count += el.sign > 0.0f ? c : -c;
         }
+        count += el.sign > 0.0f ? c : -c;
     }
 }
 
@@ -221,7 +217,7 @@ __device__ __forceinline__ void ray_run(const RayElem* __restrict__ st, int off,
 //   stage 2, lanes over QUERIES: the surviving leaves tested query by query (wave-uniform leaf, scalar loads).
 // Output: the strip ranges (ex_off, ex_len) of the leaves some ray of the block can meet, and how many.  No tree
 // descent: with ~215 leaves the flat test is four rounds of 64 lanes, and nothing in it waits on a parent's verdict.
-constexpr int kMaxChunks = 16;                // most wavefronts per query block in ray_strips_kernel (TUCH_RAY_CHUNKS, default 8)
+constexpr int kFallbackChunks = 8;            // wavefronts per query block when a body falls back to block-major order
 
 __device__ __forceinline__ float wave_min(float v)
 {
@@ -236,16 +232,28 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
+// One (query block, leaf) the block has to visit: which of its 64 rays pass the leaf's slabs.
+struct RayEntry { int32_t leaf, node; uint32_t mask_lo, mask_hi; };
+// One unit of work of ray_leaf_kernel: up to 64 rays (pairs[first .. first + n)) against one leaf's strip run.
+struct RayTile { int32_t ex_off, ex_len, first, n; };
+// per body: number of tiles, whether the pair list overflowed (the body is then walked block-major)
+struct RayBody { int32_t tiles, overflow; };
+
 template <bool kVerts>
 __global__ __launch_bounds__(64) void ray_near_kernel(
     const float* __restrict__ pts, const TreeNode* __restrict__ nodes, const float* __restrict__ bounds, int N,
     const int32_t* __restrict__ leaf_nodes, int num_leaves, const int32_t* __restrict__ qperm,
-    const int32_t* __restrict__ counts, int Q, int qblocks, int2* __restrict__ lists, int32_t* __restrict__ list_len)
-{
+    const int32_t* __restrict__ counts, int Q, int qblocks, RayEntry* __restrict__ lists, int32_t* __restrict__ list_len,
+    int32_t* __restrict__ leaf_cnt,             // [B][num_leaves], zeroed: rays per leaf
+    unsigned long long* __restrict__ stats)     // measurement (or nullptr): [1] += (ray, element) pairs inside a listed
+{                                               // leaf's slabs, [2] += 64 x elements listed
     const int qb = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    unsigned long long useful = 0, listed = 0;
     int i0;
+    bool real;                                  // padding lanes repeat a query; they are left out of the masks
     if (kVerts) {
         i0 = qperm[qb * kRayQueries + lane];
+        real = qb * kRayQueries + lane < Q;
     } else {
         const int n = counts ? counts[b] : Q;
         if (qb * kRayQueries >= n) {
@@ -253,6 +261,7 @@ __global__ __launch_bounds__(64) void ray_near_kernel(
             return;
         }
         i0 = min(qb * kRayQueries + lane, n - 1);
+        real = qb * kRayQueries + lane < n;
     }
     const float* q3 = pts + ((size_t)b * Q + i0) * 3;
     const float qz = q3[2];
@@ -263,7 +272,7 @@ __global__ __launch_bounds__(64) void ray_near_kernel(
     const float b40 = wave_min(q4), b41 = wave_max(q4), b50 = wave_min(q5), b51 = wave_max(q5);
     const float bz0 = wave_min(qz), b60 = wave_min(q6), b71 = wave_max(q7), b80 = wave_min(q8), b91 = wave_max(q9);
     const float* bb = bounds + (size_t)b * N * (2 * kSlabStride);
-    int2* list = lists + ((size_t)b * qblocks + qb) * num_leaves;
+    RayEntry* list = lists + ((size_t)b * qblocks + qb) * num_leaves;
     int cnt = 0;
     for (int base = 0; base < num_leaves; base += 64) {
         const int leaf = base + lane;
@@ -290,57 +299,186 @@ __global__ __launch_bounds__(64) void ray_near_kernel(
             out = __builtin_fmaxf(out, l2[6] - q7);
             out = __builtin_fmaxf(out, q8 - h2[7]);
             out = __builtin_fmaxf(out, l2[8] - q9);
-            if (__builtin_amdgcn_ballot_w64(!(out > 0.0f))) {
-                const TreeNode t = nodes[nd];
-                if (lane == 0) list[cnt] = make_int2(t.ex_off, t.ex_len);
+            const unsigned long long hit = __builtin_amdgcn_ballot_w64(real && !(out > 0.0f));
+            if (hit) {
+                if (lane == 0) {
+                    list[cnt] = RayEntry{base + j, nd, (uint32_t)hit, (uint32_t)(hit >> 32)};
+                    atomicAdd(&leaf_cnt[(size_t)b * num_leaves + base + j], __builtin_popcountll(hit));
+                }
                 ++cnt;
+                if (stats) {
+                    const int len = nodes[nd].ex_len;
+                    useful += (unsigned long long)__builtin_popcountll(hit) * len;
+                    listed += 64ull * len;
+                }
             }
         }
     }
     if (lane == 0) list_len[(size_t)b * qblocks + qb] = cnt;
+    if (stats && lane == 0) { atomicAdd(stats + 1, useful); atomicAdd(stats + 2, listed); }
 }
 
-// Crossing counts: wavefront c of a query block walks the strips c, c + kChunks, ... of the block's list.  Queries:
-// the model's vertices in tree order (qperm != nullptr; faces around the query are skipped) or arbitrary points
-// [B,Q,3] in the caller's order (counts[b] of them real).  Grid (8, blocks x kChunks, B/8): workgroups go round-robin
-// to the 8 XCDs, so XCD x works on body 8 z + x (its 0.2 MB sheared stream stays in that L2).
+// Per body: where every leaf's rays start in the pair list (exclusive scan of the counts) and the table of tiles
+// (leaf, 64 of its rays).  A body whose pairs do not fit `cap` is marked: it is walked block-major instead.
+constexpr int kTilesBlock = 256;
+__global__ __launch_bounds__(kTilesBlock) void ray_tiles_kernel(
+    const int32_t* __restrict__ leaf_cnt, const TreeNode* __restrict__ nodes, const int32_t* __restrict__ leaf_nodes,
+    int num_leaves, int cap, int max_tiles, int fallback_tiles, int32_t* __restrict__ leaf_off,
+    RayTile* __restrict__ tiles, RayBody* __restrict__ body)
+{
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int per = (num_leaves + kTilesBlock - 1) / kTilesBlock;
+    const int l0 = min(t * per, num_leaves), l1 = min(l0 + per, num_leaves);
+    const int32_t* cnt = leaf_cnt + (size_t)b * num_leaves;
+    int pairs = 0, ntile = 0;
+    for (int l = l0; l < l1; ++l) { pairs += cnt[l]; ntile += (cnt[l] + 63) >> 6; }
+    __shared__ int sp[kTilesBlock], st[kTilesBlock];
+    sp[t] = pairs;
+    st[t] = ntile;
+    __syncthreads();
+    for (int d = 1; d < kTilesBlock; d <<= 1) {          // inclusive scans
+        const int ap = t >= d ? sp[t - d] : 0, at = t >= d ? st[t - d] : 0;
+        __syncthreads();
+        sp[t] += ap;
+        st[t] += at;
+        __syncthreads();
+    }
+    const int total_pairs = sp[kTilesBlock - 1], total_tiles = st[kTilesBlock - 1];
+    const bool overflow = total_pairs > cap || total_tiles > max_tiles;
+    if (t == 0) body[b] = RayBody{overflow ? fallback_tiles : total_tiles, overflow ? 1 : 0};
+    if (overflow) return;
+    int off = sp[t] - pairs, tile = st[t] - ntile;
+    RayTile* out = tiles + (size_t)b * max_tiles;
+    for (int l = l0; l < l1; ++l) {
+        leaf_off[(size_t)b * num_leaves + l] = off;
+        const TreeNode nd = nodes[leaf_nodes[l]];
+        for (int k = 0; k < cnt[l]; k += 64) out[tile++] = RayTile{nd.ex_off, nd.ex_len, off + k, min(64, cnt[l] - k)};
+        off += cnt[l];
+    }
+}
+
+// The rays of every leaf: slot (= position of the query in its body's order) of each set bit of every entry.
+// The order within a leaf's range comes from an atomic counter and may vary between runs; the crossing counts
+// are integer sums and do not depend on it.
+__global__ __launch_bounds__(64) void ray_fill_kernel(
+    const RayEntry* __restrict__ lists, const int32_t* __restrict__ list_len, const RayBody* __restrict__ body,
+    const int32_t* __restrict__ leaf_off, int num_leaves, int qblocks, int cap, int32_t* __restrict__ leaf_fill,
+    int32_t* __restrict__ pairs)
+{
+    const int qb = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    if (body[b].overflow) return;
+    const int cnt = list_len[(size_t)b * qblocks + qb];
+    const RayEntry* list = lists + ((size_t)b * qblocks + qb) * num_leaves;
+    int32_t* out = pairs + (size_t)b * cap;
+    for (int base = 0; base < cnt; base += 64) {
+        // lanes over entries: reserve the entry's range in its leaf (64 atomics in flight)
+        const int j = base + lane;
+        RayEntry e = RayEntry{0, 0, 0u, 0u};
+        int dst = 0;
+        if (j < cnt) {
+            e = list[j];
+            const int n = __builtin_popcount(e.mask_lo) + __builtin_popcount(e.mask_hi);
+            dst = leaf_off[(size_t)b * num_leaves + e.leaf] + atomicAdd(&leaf_fill[(size_t)b * num_leaves + e.leaf], n);
+        }
+        // lanes over rays: entry by entry, the set lanes write their slot
+        const int m = min(64, cnt - base);
+        for (int k = 0; k < m; ++k) {
+            const uint32_t lo = __builtin_amdgcn_readlane(e.mask_lo, k), hi = __builtin_amdgcn_readlane(e.mask_hi, k);
+            const int d = __builtin_amdgcn_readlane(dst, k);
+            const unsigned long long mask = ((unsigned long long)hi << 32) | lo;
+            if ((mask >> lane) & 1ull)
+                out[d + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = qb * kRayQueries + lane;
+        }
+    }
+}
+
+// Crossing counts, leaf-major: a wavefront takes a tile -- one leaf and up to 64 of the rays that pass its slabs,
+// whichever query blocks they come from -- walks the leaf's strip run and adds each ray's crossings to its query's
+// count.  (Block-major, 64 neighbouring queries against every leaf any of them meets, only ~22 % of the lanes
+// can have a crossing at all: measured, tuch_ray_work.)  Queries: the model's vertices in tree order (qperm != nullptr;
+// faces around the query are skipped) or arbitrary points [B,Q,3] in the caller's order.
+// Grid (G = min(B, 8), workers): workgroups go round-robin to the 8 XCDs, so the wavefronts of column x all sit on one
+// XCD; together they work through bodies x, x + G, x + 2 G, ... one after the other (a body's 0.2 MB sheared stream
+// stays in that XCD's L2, and a body with many tiles is shared by all the column's wavefronts).
+// The next tile (record, ray slot, query coordinates: a chain of dependent loads) is fetched while the current one is
+// walked.  A body marked overflow is walked block-major: tile t = (query block t / 8, every 8th leaf of the block's
+// list from t % 8).
 // kCount: elements walked are added to stats[0] (measurement).
 template <bool kVerts, bool kCount>
-__global__ __launch_bounds__(64) void ray_strips_kernel(
-    const float* __restrict__ pts, const RayElem* __restrict__ stream, const int2* __restrict__ lists,
-    const int32_t* __restrict__ list_len, int num_leaves, const int32_t* __restrict__ qperm,
-    const int32_t* __restrict__ counts, int Q, int T, int qblocks, int num_bodies, int kChunks,
-    int32_t* __restrict__ partial, unsigned long long* __restrict__ stats)
+__global__ __launch_bounds__(64) void ray_leaf_kernel(
+    const float* __restrict__ pts, const RayElem* __restrict__ stream, const RayTile* __restrict__ tiles,
+    const RayBody* __restrict__ body, const int32_t* __restrict__ pairs, const RayEntry* __restrict__ lists,
+    const int32_t* __restrict__ list_len, const TreeNode* __restrict__ nodes, int num_leaves,
+    const int32_t* __restrict__ qperm, const int32_t* __restrict__ counts, int Q, int T, int qblocks, int num_bodies,
+    int cap, int max_tiles, int32_t* __restrict__ count, unsigned long long* __restrict__ stats)
 {
-    const int b = blockIdx.z * gridDim.x + blockIdx.x;
-    if (b >= num_bodies) return;
-    const int qb = blockIdx.y / kChunks, c = blockIdx.y % kChunks;
-    const int cnt = __builtin_amdgcn_readfirstlane(list_len[(size_t)b * qblocks + qb]);
-    if (c >= cnt) return;
-    int i0;
-    if (kVerts) {
-        i0 = qperm[qb * kRayQueries + threadIdx.x];
-    } else {
-        const int n = counts ? counts[b] : Q;
-        i0 = min(qb * kRayQueries + (int)threadIdx.x, n - 1);
-    }
-    const float* q3 = pts + ((size_t)b * Q + i0) * 3;
-    const float qz = q3[2];
-    const float qx = shear_x(q3[0], qz), qy = shear_y(q3[1], qz);
-    const RayElem* st = stream + (size_t)b * T;
-    const int2* list = lists + ((size_t)b * qblocks + qb) * num_leaves;
-    P3 s[3];
-    float e[3];
+    const int lane = threadIdx.x;
+    struct Work { int b, off, len, slot; bool active; float qx, qy, qz; };     // b < 0: nothing left; len < 0: block-major tile `off`
+    // The tiles of the column's bodies x, x + G, ... form one sequence; wavefront y takes every gridDim.y-th of it (a
+    // work counter instead serialises: ~100 ns per atomic on one address, measured).
+    int b_cur = blockIdx.x, base = 0, g = blockIdx.y;       // current body, tiles before it, next position in the sequence
+    auto fetch = [&]() {
+        Work w;
+        w.b = -1; w.off = w.len = w.slot = 0; w.active = false; w.qx = w.qy = w.qz = 0.0f;
+        while (b_cur < num_bodies) {
+            const int b = b_cur;
+            const int nt = __builtin_amdgcn_readfirstlane(body[b].tiles);
+            if (g >= base + nt) { base += nt; b_cur += gridDim.x; continue; }
+            const int t = g - base;
+            g += gridDim.y;
+            const float* pb = pts + (size_t)b * Q * 3;
+            w.b = b;
+            int i0;
+            if (!__builtin_amdgcn_readfirstlane(body[b].overflow)) {
+                const RayTile tile = tiles[(size_t)b * max_tiles + t];
+                const int n = __builtin_amdgcn_readfirstlane(tile.n), first = __builtin_amdgcn_readfirstlane(tile.first);
+                w.active = lane < n;
+                w.slot = pairs[(size_t)b * cap + first + (w.active ? lane : 0)];
+                i0 = kVerts ? qperm[w.slot] : w.slot;
+                w.off = __builtin_amdgcn_readfirstlane(tile.ex_off);
+                w.len = __builtin_amdgcn_readfirstlane(tile.ex_len);
+            } else {
+                const int nq = kVerts ? Q : (counts ? counts[b] : Q);
+                w.slot = (t / kFallbackChunks) * kRayQueries + lane;
+                w.active = w.slot < nq;
+                i0 = kVerts ? qperm[w.slot] : min(w.slot, nq - 1);
+                w.off = t;                     // block-major tile: (query block, chunk) packed, marked by len < 0
+                w.len = -1;
+            }
+            w.qz = pb[3 * i0 + 2];
+            w.qx = shear_x(pb[3 * i0], w.qz);
+            w.qy = shear_y(pb[3 * i0 + 1], w.qz);
+            break;
+        }
+        return w;
+    };
+    int walked = 0;
+    Work next = fetch();
+    while (next.b >= 0) {
+        const Work w = next;
+        next = fetch();
+        P3 s[3];
+        float e[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { s[k].x = s[k].y = s[k].z = 0.0f; e[k] = 0.0f; }
-    int count = 0, walked = 0;
-    for (int j = c; j < cnt; j += kChunks) {
-        const int off = __builtin_amdgcn_readfirstlane(list[j].x), len = __builtin_amdgcn_readfirstlane(list[j].y);
-        ray_run<kVerts>(st, off, len, s, e, qx, qy, qz, count);
-        if (kCount) walked += len;
+        for (int k = 0; k < 3; ++k) { s[k].x = s[k].y = s[k].z = 0.0f; e[k] = 0.0f; }
+        int crossings = 0;
+        const RayElem* st = stream + (size_t)w.b * T;
+        if (w.len >= 0) {
+            ray_run<kVerts>(st, w.off, w.len, s, e, w.qx, w.qy, w.qz, crossings);
+            if (kCount) walked += w.len;
+        } else {
+            const int qb = w.off / kFallbackChunks, c = w.off % kFallbackChunks;
+            const int cnt = __builtin_amdgcn_readfirstlane(list_len[(size_t)w.b * qblocks + qb]);
+            const RayEntry* list = lists + ((size_t)w.b * qblocks + qb) * num_leaves;
+            for (int j = c; j < cnt; j += kFallbackChunks) {
+                const TreeNode nd = nodes[__builtin_amdgcn_readfirstlane(list[j].node)];
+                ray_run<kVerts>(st, nd.ex_off, nd.ex_len, s, e, w.qx, w.qy, w.qz, crossings);
+                if (kCount) walked += nd.ex_len;
+            }
+        }
+        if (w.active && crossings != 0) atomicAdd(&count[((size_t)w.b * qblocks) * kRayQueries + w.slot], crossings);
     }
-    partial[((size_t)b * kChunks + c) * ((size_t)qblocks * kRayQueries) + qb * kRayQueries + threadIdx.x] = count;
-    if (kCount && threadIdx.x == 0) atomicAdd(stats, (unsigned long long)walked);
+    if (kCount && lane == 0) atomicAdd(stats, (unsigned long long)walked);
 }
 
 // atan2 with a degree-8 minimax atan on [0,1] (max abs error 1e-7), octant fix-up; atan2(0,0) = 0
@@ -382,17 +520,15 @@ __device__ __forceinline__ float half_solid_angle(const P3& a, const P3& b, cons
 
 // vertices: N = sum of the subtree counts + crossings of the closing fan; w = N - (sum of the fan's half angles) / (2 pi)
 __global__ __launch_bounds__(kBlock) void ray_finalize_verts_kernel(
-    const float* __restrict__ verts, const int32_t* __restrict__ partial, const int32_t* __restrict__ qperm,
-    const int32_t* __restrict__ ring_off, const int32_t* __restrict__ ring_vidx, const int32_t* __restrict__ list_len,
-    int V, int stride, int kChunks, float thresh, float* __restrict__ w_out, uint8_t* __restrict__ exterior)
+    const float* __restrict__ verts, const int32_t* __restrict__ count, const int32_t* __restrict__ qperm,
+    const int32_t* __restrict__ ring_off, const int32_t* __restrict__ ring_vidx,
+    int V, int stride, float thresh, float* __restrict__ w_out, uint8_t* __restrict__ exterior)
 {
     const int b = blockIdx.y;
     const int i = blockIdx.x * kBlock + threadIdx.x;     // position in tree order
     if (i >= V) return;
     const int v = qperm[i];
-    int n = 0;
-    const int chunks = min(kChunks, list_len[(size_t)b * (stride / kRayQueries) + i / kRayQueries]);
-    for (int sp = 0; sp < chunks; ++sp) n += partial[((size_t)b * kChunks + sp) * stride + i];
+    int n = count[(size_t)b * stride + i];
     const float* vb = verts + (size_t)b * V * 3;
     const float vx = vb[3 * v], vy = vb[3 * v + 1], vz = vb[3 * v + 2];
     const float qx = shear_x(vx, vz), qy = shear_y(vy, vz);
@@ -422,17 +558,13 @@ __global__ __launch_bounds__(kBlock) void ray_finalize_verts_kernel(
 }
 
 __global__ __launch_bounds__(kBlock) void ray_finalize_points_kernel(
-    const int32_t* __restrict__ partial, const int32_t* __restrict__ counts, const int32_t* __restrict__ list_len,
-    int Q, int stride, int kChunks, float thresh, float* __restrict__ w_out, uint8_t* __restrict__ exterior)
+    const int32_t* __restrict__ count, const int32_t* __restrict__ counts,
+    int Q, int stride, float thresh, float* __restrict__ w_out, uint8_t* __restrict__ exterior)
 {
     const int b = blockIdx.y;
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= Q) return;
-    int n = 0;
-    if (!counts || i < counts[b]) {
-        const int chunks = min(kChunks, list_len[(size_t)b * (stride / kRayQueries) + i / kRayQueries]);
-        for (int sp = 0; sp < chunks; ++sp) n += partial[((size_t)b * kChunks + sp) * stride + i];
-    }
+    const int n = (!counts || i < counts[b]) ? count[(size_t)b * stride + i] : 0;
     const float w = (float)n;
     const size_t o = (size_t)b * Q + i;
     if (w_out) w_out[o] = w;
@@ -441,7 +573,11 @@ __global__ __launch_bounds__(kBlock) void ray_finalize_points_kernel(
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-struct RayLayout { size_t stream, bounds, partial, lists, list_len, stats, total; int T, qblocks; };
+struct RayLayout {
+    size_t stream, bounds, lists, list_len, zeroed, zeroed_bytes, leaf_cnt, leaf_fill, count, leaf_off, tiles, body, pairs,
+        stats, total;
+    int T, qblocks, cap, max_tiles, workers, columns;
+};
 
 }  // namespace
 
@@ -452,11 +588,12 @@ bool tuch_ray_available(const tuch_contact_model* m)
     return !e || atoi(e) != 0;
 }
 
-static int ray_chunks()
+// room in the pair list, in (ray, leaf) pairs per query (a ray passes the slabs of ~4-5 leaves; TUCH_RAY_PAIR_CAP)
+static int ray_pair_cap()
 {
-    const char* e = getenv("TUCH_RAY_CHUNKS");
-    const int c = e ? atoi(e) : 8;
-    return c < 1 ? 1 : (c > kMaxChunks ? kMaxChunks : c);
+    const char* e = getenv("TUCH_RAY_PAIR_CAP");
+    const int c = e ? atoi(e) : 16;
+    return c < 1 ? 1 : c;
 }
 
 static RayLayout full_layout(const tuch_contact_model* m, int B, int Q, bool verts)
@@ -465,13 +602,33 @@ static RayLayout full_layout(const tuch_contact_model* m, int B, int Q, bool ver
     l.qblocks = verts ? 2 * m->tree_qblocks : ceil_div(Q, kRayQueries);
     // leaf strips are the first part of the tree stream; the caps behind them are never read
     l.T = ceil_div(m->tree_exact_len, 3) * 3 + 6;
+    const int L = m->tree_leaves;
+    const long cap = (long)ray_pair_cap() * Q;
+    l.cap = (int)(cap < 0x3fffffffL ? cap : 0x3fffffffL);
+    // tiles of a body: its pairs in 64s + one ragged tile per leaf; never fewer than the block-major fallback needs
+    l.max_tiles = l.cap / 64 + L;
+    if (l.max_tiles < l.qblocks * kFallbackChunks) l.max_tiles = l.qblocks * kFallbackChunks;
+    // one column of wavefronts per XCD; four times what the chip holds at once (256 CUs x 4 SIMDs x 8), so that a
+    // wavefront's share is about one tile and the hardware balances the rest (TUCH_RAY_WAVES)
+    l.columns = B < 8 ? B : 8;
+    const char* e = getenv("TUCH_RAY_WAVES");
+    const int waves = e && atoi(e) > 0 ? atoi(e) : 32768;
+    l.workers = waves / l.columns > 0 ? waves / l.columns : 1;
     size_t o = 0;
-    l.stream = o;   o += align256((size_t)B * l.T * sizeof(RayElem));
-    l.bounds = o;   o += align256((size_t)B * m->tree_nodes * 2 * kSlabStride * sizeof(float));
-    l.partial = o;  o += align256((size_t)B * kMaxChunks * l.qblocks * kRayQueries * sizeof(int32_t));
-    l.lists = o;    o += align256((size_t)B * l.qblocks * m->tree_leaves * sizeof(int2));
-    l.list_len = o; o += align256((size_t)B * l.qblocks * sizeof(int32_t));
-    l.stats = o;    o += 256;
+    l.stream = o;    o += align256((size_t)B * l.T * sizeof(RayElem));
+    l.bounds = o;    o += align256((size_t)B * m->tree_nodes * 2 * kSlabStride * sizeof(float));
+    l.lists = o;     o += align256((size_t)B * l.qblocks * L * sizeof(RayEntry));
+    l.list_len = o;  o += align256((size_t)B * l.qblocks * sizeof(int32_t));
+    l.zeroed = o;                                                  // one memset: rays per leaf, fill cursors, crossing counts
+    l.leaf_cnt = o;  o += align256((size_t)B * L * sizeof(int32_t));
+    l.leaf_fill = o; o += align256((size_t)B * L * sizeof(int32_t));
+    l.count = o;     o += align256((size_t)B * l.qblocks * kRayQueries * sizeof(int32_t));
+    l.zeroed_bytes = o - l.zeroed;
+    l.leaf_off = o;  o += align256((size_t)B * L * sizeof(int32_t));
+    l.tiles = o;     o += align256((size_t)B * l.max_tiles * sizeof(RayTile));
+    l.body = o;      o += align256((size_t)B * sizeof(RayBody));
+    l.pairs = o;     o += align256((size_t)B * l.cap * sizeof(int32_t));
+    l.stats = o;     o += 256;
     l.total = o;
     return l;
 }
@@ -496,43 +653,69 @@ static void launch_ray_boxes(const tuch_contact_model* m, const RayLayout& l, co
                        (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, bounds);
 }
 
+// near leaves -> rays per leaf -> tiles -> crossing counts (count[b][slot])
+template <bool kVerts>
+static int launch_ray_counts(const tuch_contact_model* m, const RayLayout& l, const float* verts, const float* queries,
+                             const int32_t* counts, int B, int Q, char* ws, hipStream_t s, unsigned long long* stats)
+{
+    launch_ray_boxes(m, l, verts, B, ws, s);
+    if (hipMemsetAsync(ws + l.zeroed, 0, l.zeroed_bytes, s) != hipSuccess) return TUCH_ERR_HIP;
+    const int L = m->tree_leaves;
+    const TreeNode* nodes = (const TreeNode*)m->tree_node;
+    // the leaves are the height-0 entries of the tree's height table (tree_height_off_host[0] == 0)
+    const int32_t* leaf_nodes = (const int32_t*)m->tree_height_nodes;
+    const int32_t* qperm = kVerts ? (const int32_t*)m->tree_qperm : nullptr;
+    RayEntry* lists = (RayEntry*)(ws + l.lists);
+    int32_t* list_len = (int32_t*)(ws + l.list_len);
+    int32_t* leaf_cnt = (int32_t*)(ws + l.leaf_cnt);
+    int32_t* leaf_off = (int32_t*)(ws + l.leaf_off);
+    RayTile* tiles = (RayTile*)(ws + l.tiles);
+    RayBody* body = (RayBody*)(ws + l.body);
+    int32_t* pairs = (int32_t*)(ws + l.pairs);
+    hipLaunchKernelGGL(ray_near_kernel<kVerts>, dim3(l.qblocks, B), dim3(64), 0, s, queries, nodes,
+                       (const float*)(ws + l.bounds), m->tree_nodes, leaf_nodes, L, qperm, counts, Q, l.qblocks, lists, list_len,
+                       leaf_cnt, stats);
+    hipLaunchKernelGGL(ray_tiles_kernel, dim3(B), dim3(kTilesBlock), 0, s, (const int32_t*)leaf_cnt, nodes, leaf_nodes, L, l.cap,
+                       l.max_tiles, l.qblocks * kFallbackChunks, leaf_off, tiles, body);
+    hipLaunchKernelGGL(ray_fill_kernel, dim3(l.qblocks, B), dim3(64), 0, s, (const RayEntry*)lists, (const int32_t*)list_len,
+                       (const RayBody*)body, (const int32_t*)leaf_off, L, l.qblocks, l.cap, (int32_t*)(ws + l.leaf_fill), pairs);
+    const dim3 grid(l.columns, l.workers);
+    if (stats)
+        hipLaunchKernelGGL((ray_leaf_kernel<kVerts, true>), grid, dim3(64), 0, s, queries, (const RayElem*)(ws + l.stream),
+                           (const RayTile*)tiles, (const RayBody*)body, (const int32_t*)pairs, (const RayEntry*)lists,
+                           (const int32_t*)list_len, nodes, L, qperm, counts, Q, l.T, l.qblocks, B, l.cap, l.max_tiles,
+                           (int32_t*)(ws + l.count), stats);
+    else
+        hipLaunchKernelGGL((ray_leaf_kernel<kVerts, false>), grid, dim3(64), 0, s, queries, (const RayElem*)(ws + l.stream),
+                           (const RayTile*)tiles, (const RayBody*)body, (const int32_t*)pairs, (const RayEntry*)lists,
+                           (const int32_t*)list_len, nodes, L, qperm, counts, Q, l.T, l.qblocks, B, l.cap, l.max_tiles,
+                           (int32_t*)(ws + l.count), stats);
+    return TUCH_OK;
+}
+
 int tuch_ray_exterior_verts(const tuch_contact_model* m, const float* verts, int B, float thresh, uint8_t* exterior,
                             float* w, void* workspace, hipStream_t s, unsigned long long* stats_host)
 {
     const RayLayout l = full_layout(m, B, m->V, true);
     char* ws = (char*)workspace;
-    launch_ray_boxes(m, l, verts, B, ws, s);
-    int32_t* partial = (int32_t*)(ws + l.partial);
-    int2* lists = (int2*)(ws + l.lists);
-    int32_t* list_len = (int32_t*)(ws + l.list_len);
-    unsigned long long* stats = (unsigned long long*)(ws + l.stats);
-    // the leaves are the height-0 entries of the tree's height table (tree_height_off_host[0] == 0)
-    const int32_t* leaf_nodes = (const int32_t*)m->tree_height_nodes;
-    hipLaunchKernelGGL(ray_near_kernel<true>, dim3(l.qblocks, B), dim3(64), 0, s, verts, (const TreeNode*)m->tree_node,
-                       (const float*)(ws + l.bounds), m->tree_nodes, leaf_nodes, m->tree_leaves, (const int32_t*)m->tree_qperm,
-                       (const int32_t*)nullptr, m->V, l.qblocks, lists, list_len);
-    const int kChunks = ray_chunks();
-    const dim3 grid(B < 8 ? B : 8, l.qblocks * kChunks, ceil_div(B, 8));
-    if (stats_host) {
-        if (hipMemsetAsync(stats, 0, sizeof(unsigned long long), s) != hipSuccess) return TUCH_ERR_HIP;
-        hipLaunchKernelGGL((ray_strips_kernel<true, true>), grid, dim3(64), 0, s, verts, (const RayElem*)(ws + l.stream),
-                           (const int2*)lists, (const int32_t*)list_len, m->tree_leaves, (const int32_t*)m->tree_qperm,
-                           (const int32_t*)nullptr, m->V, l.T, l.qblocks, B, kChunks, partial, stats);
-    } else {
-        hipLaunchKernelGGL((ray_strips_kernel<true, false>), grid, dim3(64), 0, s, verts, (const RayElem*)(ws + l.stream),
-                           (const int2*)lists, (const int32_t*)list_len, m->tree_leaves, (const int32_t*)m->tree_qperm,
-                           (const int32_t*)nullptr, m->V, l.T, l.qblocks, B, kChunks, partial, stats);
-    }
+    unsigned long long* stats = stats_host ? (unsigned long long*)(ws + l.stats) : nullptr;
+    if (stats && hipMemsetAsync(stats, 0, 4 * sizeof(unsigned long long), s) != hipSuccess) return TUCH_ERR_HIP;
+    const int rc = launch_ray_counts<true>(m, l, verts, verts, nullptr, B, m->V, ws, s, stats);
+    if (rc != TUCH_OK) return rc;
     if (w || exterior)
         hipLaunchKernelGGL(ray_finalize_verts_kernel, dim3(ceil_div(m->V, kBlock), B), dim3(kBlock), 0, s, verts,
-                           (const int32_t*)partial, (const int32_t*)m->tree_qperm, (const int32_t*)m->ring_off,
-                           (const int32_t*)m->ring_vidx, (const int32_t*)list_len, m->V, l.qblocks * kRayQueries, kChunks, thresh, w,
-                           exterior);
+                           (const int32_t*)(ws + l.count), (const int32_t*)m->tree_qperm, (const int32_t*)m->ring_off,
+                           (const int32_t*)m->ring_vidx, m->V, l.qblocks * kRayQueries, thresh, w, exterior);
     if (stats_host) {
-        if (hipMemcpyAsync(stats_host, stats, sizeof(unsigned long long), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        RayBody bodies[8];
+        const int nb = B < 8 ? B : 8;
+        if (hipMemcpyAsync(stats_host, stats, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipMemcpyAsync(bodies, ws + l.body, nb * sizeof(RayBody), hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipStreamSynchronize(s) != hipSuccess)
             return TUCH_ERR_HIP;
-        stats_host[1] = (unsigned long long)B * l.qblocks * kChunks;
+        unsigned long long tiles = 0;
+        for (int b = 0; b < nb; ++b) tiles += bodies[b].tiles;
+        stats_host[3] = tiles * B / nb;            // wavefront tiles (extrapolated from the first bodies)
     }
     return tuch_check_launch("tuch_ray_exterior_verts");
 }
@@ -542,18 +725,9 @@ int tuch_ray_exterior_points(const tuch_contact_model* m, const float* verts, co
 {
     const RayLayout l = full_layout(m, B, Q, false);
     char* ws = (char*)workspace;
-    int32_t* partial = (int32_t*)(ws + l.partial);
-    int2* lists = (int2*)(ws + l.lists);
-    int32_t* list_len = (int32_t*)(ws + l.list_len);
-    launch_ray_boxes(m, l, verts, B, ws, s);
-    hipLaunchKernelGGL(ray_near_kernel<false>, dim3(l.qblocks, B), dim3(64), 0, s, points, (const TreeNode*)m->tree_node,
-                       (const float*)(ws + l.bounds), m->tree_nodes, (const int32_t*)m->tree_height_nodes, m->tree_leaves,
-                       (const int32_t*)nullptr, counts, Q, l.qblocks, lists, list_len);
-    const int kChunks = ray_chunks();
-    hipLaunchKernelGGL((ray_strips_kernel<false, false>), dim3(B < 8 ? B : 8, l.qblocks * kChunks, ceil_div(B, 8)), dim3(64), 0, s,
-                       points, (const RayElem*)(ws + l.stream), (const int2*)lists, (const int32_t*)list_len, m->tree_leaves,
-                       (const int32_t*)nullptr, counts, Q, l.T, l.qblocks, B, kChunks, partial, (unsigned long long*)nullptr);
+    const int rc = launch_ray_counts<false>(m, l, verts, points, counts, B, Q, ws, s, nullptr);
+    if (rc != TUCH_OK) return rc;
     hipLaunchKernelGGL(ray_finalize_points_kernel, dim3(ceil_div(Q, kBlock), B), dim3(kBlock), 0, s,
-                       (const int32_t*)partial, counts, (const int32_t*)list_len, Q, l.qblocks * kRayQueries, kChunks, thresh, w, exterior);
+                       (const int32_t*)(ws + l.count), counts, Q, l.qblocks * kRayQueries, thresh, w, exterior);
     return tuch_check_launch("tuch_ray_exterior_points");
 }

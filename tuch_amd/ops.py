@@ -533,9 +533,10 @@ class ContactModel:
         L = _C.lib()
         nbytes = L.tuch_exterior_workspace_bytes(self._handle, b)
         ws = _workspace(nbytes, verts.device)
-        out = (ctypes.c_ulonglong * 2)()
+        out = (ctypes.c_ulonglong * 4)()
         _C.check(L.tuch_ray_work(self._handle, _C.ptr(verts), b, _C.ptr(ws), nbytes, out, _C.stream()))
-        return dict(elements=int(out[0]), wavefronts=int(out[1]), queries_per_step=64)
+        return dict(elements=int(out[0]), wavefronts=int(out[3]), queries_per_step=64,
+                    lanes_inside_leaf_slabs=int(out[1]) / max(int(out[2]), 1))
 
     # K2 + K3
     def exterior_flags(self, verts: torch.Tensor, apply_segments: bool = True, thresh: float = 0.99,
