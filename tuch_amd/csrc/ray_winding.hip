@@ -172,7 +172,7 @@ __device__ __forceinline__ void ray_step(const RayElem el, P3 (&s)[3], float (&e
     e[Cq] = edge_fn(s[A], s[Bq]);
     if (el.sign != 0.0f) {                                        // wave-uniform: the two priming vertices of a strip
         // triangle (Bq, Cq, A): det = sum of (edge function opposite a corner) x (that corner's depth)
-        const float numz = e[Bq] * s[Bq].z + e[Cq] * s[Cq].z + e[A] * s[A].z;
+        const float numz = __builtin_fmaf(e[A], s[A].z, __builtin_fmaf(e[Cq], s[Cq].z, e[Bq] * s[Bq].z));
         const float mn = __builtin_fminf(__builtin_fminf(e[0], e[1]), e[2]);
         const float mx = __builtin_fmaxf(__builtin_fmaxf(e[0], e[1]), e[2]);
         // generic position: the origin is inside the projection iff the edge functions have one sign, the hit is in
