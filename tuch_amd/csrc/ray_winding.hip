@@ -140,6 +140,19 @@ __device__ __forceinline__ int crossing(const P3& a, const P3& b, const P3& c, f
     return numz < 0.0f ? -1 : 0;
 }
 
+// the same through the branch-free generic form, the careful one only for lanes with an exact tie (wave-uniform test)
+__device__ __forceinline__ int crossing_mostly_generic(const P3& a, const P3& b, const P3& c, float ea, float eb, float ec)
+{
+    const float numz = ea * a.z + eb * b.z + ec * c.z;
+    const float mn = __builtin_fminf(__builtin_fminf(ea, eb), ec), mx = __builtin_fmaxf(__builtin_fmaxf(ea, eb), ec);
+    int n = (int)(__builtin_fminf(mn, numz) > 0.0f) - (int)(__builtin_fmaxf(mx, numz) < 0.0f);
+    const bool tie = (mn * mx == 0.0f) & (numz != 0.0f);
+    if (__builtin_amdgcn_ballot_w64(tie)) {
+        if (tie) n = crossing(a, b, c, ea, eb, ec);
+    }
+    return n;
+}
+
 // careful form of the crossing test for lanes with an edge function that is exactly zero (the ray passes through an
 // edge or a corner: tie rules) -- which includes every triangle that has the query itself as a corner
 template <bool kSkipIncident>
@@ -533,23 +546,63 @@ __global__ __launch_bounds__(kBlock) void ray_finalize_verts_kernel(
     const float vx = vb[3 * v], vy = vb[3 * v + 1], vz = vb[3 * v + 2];
     const float qx = shear_x(vx, vz), qy = shear_y(vy, vz);
     // the apex direction of the fan, in space and sheared (ray frame)
-    const P3 u = {kFanX, kFanY, kFanZ};
+    const P3 u_dir = {kFanX, kFanY, kFanZ};
     const P3 us = {shear_x(kFanX, kFanZ), shear_y(kFanY, kFanZ), kFanZ};
     const int lo = ring_off[v], cnt = ring_off[v + 1] - lo;
     float half_sum = 0.0f;
-    // previous ring vertex (j = cnt-1) to start the cycle
-    int r = ring_vidx[lo + cnt - 1];
-    P3 pb = {vb[3 * r] - vx, vb[3 * r + 1] - vy, vb[3 * r + 2] - vz};                                 // space, for the angle
-    P3 sb = {shear_x(vb[3 * r], vb[3 * r + 2]) - qx, shear_y(vb[3 * r + 1], vb[3 * r + 2]) - qy, vb[3 * r + 2] - vz};
-    for (int j = 0; j < cnt; ++j) {
-        r = ring_vidx[lo + j];
-        const P3 pc = {vb[3 * r] - vx, vb[3 * r + 1] - vy, vb[3 * r + 2] - vz};
-        const P3 sc = {shear_x(vb[3 * r], vb[3 * r + 2]) - qx, shear_y(vb[3 * r + 1], vb[3 * r + 2]) - qy, vb[3 * r + 2] - vz};
-        // fan triangle (u, previous, current) replaces the face (v, previous, current)
-        half_sum += half_solid_angle(u, pb, pc);
-        n += crossing(us, sb, sc, edge_fn(sb, sc), edge_fn(sc, us), edge_fn(us, sb));
-        pb = pc;
-        sb = sc;
+    constexpr int kLongRing = 16;
+    if (cnt <= kLongRing) {
+        // previous ring vertex (j = cnt-1) to start the cycle
+        int r = ring_vidx[lo + cnt - 1];
+        P3 pb = {vb[3 * r] - vx, vb[3 * r + 1] - vy, vb[3 * r + 2] - vz};
+        P3 sb = {shear_x(vb[3 * r], vb[3 * r + 2]) - qx, shear_y(vb[3 * r + 1], vb[3 * r + 2]) - qy, vb[3 * r + 2] - vz};
+        // four ring vertices at a time: their ids, then their coordinates, are fetched together (the loop is
+        // otherwise a chain of dependent gathers: id -> coordinates -> next id ...)
+        for (int j0 = 0; j0 < cnt; j0 += 4) {
+            int rr[4];
+            float cc[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rr[u] = ring_vidx[lo + min(j0 + u, cnt - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { cc[u][0] = vb[3 * rr[u]]; cc[u][1] = vb[3 * rr[u] + 1]; cc[u][2] = vb[3 * rr[u] + 2]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (j0 + u < cnt) {
+                    const P3 pc = {cc[u][0] - vx, cc[u][1] - vy, cc[u][2] - vz};
+                    const P3 sc = {shear_x(cc[u][0], cc[u][2]) - qx, shear_y(cc[u][1], cc[u][2]) - qy, cc[u][2] - vz};
+                    half_sum += half_solid_angle(u_dir, pb, pc);
+                    n += crossing_mostly_generic(us, sb, sc, edge_fn(sb, sc), edge_fn(sc, us), edge_fn(us, sb));
+                    pb = pc;
+                    sb = sc;
+                }
+            }
+        }
+    }
+    // long rings (the poles of a lat-long sphere; SMPL has none above 16) are shared out over the wavefront: one fan
+    // triangle per lane, sums by butterfly -- one lane walking 80 triangles would hold up the whole launch
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(cnt > kLongRing);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int lv = __builtin_amdgcn_readlane(v, src), llo = __builtin_amdgcn_readlane(lo, src), lcnt = __builtin_amdgcn_readlane(cnt, src);
+        const float lvx = __shfl(vx, src), lvy = __shfl(vy, src), lvz = __shfl(vz, src);
+        (void)lv;
+        float h = 0.0f;
+        int cr = 0;
+        for (int j = lane; j < lcnt; j += 64) {
+            const int r_prev = ring_vidx[llo + (j == 0 ? lcnt - 1 : j - 1)], r_cur = ring_vidx[llo + j];
+            const float bx = vb[3 * r_prev], by = vb[3 * r_prev + 1], bz = vb[3 * r_prev + 2];
+            const float cx = vb[3 * r_cur], cy = vb[3 * r_cur + 1], cz = vb[3 * r_cur + 2];
+            const float lqx = shear_x(lvx, lvz), lqy = shear_y(lvy, lvz);
+            const P3 pb = {bx - lvx, by - lvy, bz - lvz}, pc = {cx - lvx, cy - lvy, cz - lvz};
+            const P3 sb = {shear_x(bx, bz) - lqx, shear_y(by, bz) - lqy, bz - lvz}, sc = {shear_x(cx, cz) - lqx, shear_y(cy, cz) - lqy, cz - lvz};
+            h += half_solid_angle(u_dir, pb, pc);
+            cr += crossing(us, sb, sc, edge_fn(sb, sc), edge_fn(sc, us), edge_fn(us, sb));
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { h += __shfl_xor(h, m); cr += __shfl_xor(cr, m); }
+        if (lane == src) { half_sum = h; n += cr; }
     }
     const float w = (float)n - half_sum * (0.5f / kPi);
     const size_t o = (size_t)b * V + v;

@@ -403,8 +403,11 @@ __global__ __launch_bounds__(kBoundsBlock) void v2v_rows_kernel(
     }
 }
 
-// One column per lane (64 columns per wavefront): plain and packed FP32 cost the same per float on
-// gfx950, and the union of the columns' search balls is smaller for 64 neighbours than for 128.
+// One column per lane (64 columns per wavefront): the union of the columns' search balls is smaller for 64
+// neighbours than for 128.  (Packed FP32 over pairs of ROWS was tried -- rows in groups of four, SoA, so that
+// (x_j, x_j+1) sit in even-aligned scalar pairs: 22 % fewer VALU instructions, but the handling of ranges that do
+// not start on a group boundary costs scalar instructions, and the CU's one scalar unit is this kernel's second
+// bottleneck: 1.35e8 SALU + 0.21e8 SMEM per launch = 0.61 M cycles per CU; 289-311 us instead of 257.)
 struct Column {
     float px, py, pz, best;
     int arg;
