@@ -260,16 +260,52 @@ __global__ __launch_bounds__(256) void hd_grad_verts_kernel(
 {
     const int b = blockIdx.y;
     const int v = blockIdx.x * 256 + threadIdx.x;
-    if (v >= V) return;
+    const bool real = v < V;                          // all lanes stay: the long lists below need the whole wavefront
+    const int e0 = real ? v_off[v] : 0, e1 = real ? v_off[v + 1] : 0;
+    const int32_t* sb = slot + (size_t)b * N;
+    const float* gb = G + 3 * (size_t)b * N;
     float x = 0.f, y = 0.f, z = 0.f;
-    for (int e = v_off[v]; e < v_off[v + 1]; ++e) {
-        const int ent = v_ent[e], n = ent >> 2, c = ent & 3;
-        const int s = slot[(size_t)b * N + n];
-        if (s < 0) continue;
-        const float wc = w[3 * (size_t)n + c];
-        const float* g = G + 3 * ((size_t)b * N + s);
+    auto add = [&](int ent, int s) {                 // entry = point * 4 + corner; s = the point's slot in this body
+        if (s < 0) return;
+        const float wc = w[3 * (size_t)(ent >> 2) + (ent & 3)];
+        const float* g = gb + 3 * (size_t)s;
         x = __builtin_fmaf(wc, g[0], x); y = __builtin_fmaf(wc, g[1], y); z = __builtin_fmaf(wc, g[2], z);
+    };
+    constexpr int kLong = 64;
+    if (e1 - e0 <= kLong) {
+        // four entries at a time: entries, then slots, are fetched together (otherwise a chain of dependent gathers)
+        for (int e = e0; e < e1; e += 4) {
+            int ent[4], s[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ent[u] = v_ent[min(e + u, e1 - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] = e + u < e1 ? sb[ent[u] >> 2] : -1;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) add(ent[u], s[u]);
+        }
     }
+    // vertices with very many HD points (the poles of a lat-long sphere) are shared out over the wavefront: one lane
+    // walking hundreds of entries would hold up the whole launch.  Lane-strided partial sums, then a butterfly:
+    // a fixed order.
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(e1 - e0 > kLong);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int le0 = __builtin_amdgcn_readlane(e0, src), le1 = __builtin_amdgcn_readlane(e1, src);
+        float px = 0.f, py = 0.f, pz = 0.f;
+        for (int e = le0 + lane; e < le1; e += 64) {
+            const int ent = v_ent[e], s = sb[ent >> 2];
+            if (s < 0) continue;
+            const float wc = w[3 * (size_t)(ent >> 2) + (ent & 3)];
+            const float* g = gb + 3 * (size_t)s;
+            px = __builtin_fmaf(wc, g[0], px); py = __builtin_fmaf(wc, g[1], py); pz = __builtin_fmaf(wc, g[2], pz);
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { px += __shfl_xor(px, m); py += __shfl_xor(py, m); pz += __shfl_xor(pz, m); }
+        if (lane == src) { x = px; y = py; z = pz; }
+    }
+    if (!real) return;
     float* o = grad_verts + 3 * ((size_t)b * V + v);
     o[0] = x; o[1] = y; o[2] = z;
 }

@@ -539,19 +539,19 @@ __global__ __launch_bounds__(kBlock) void ray_finalize_verts_kernel(
 {
     const int b = blockIdx.y;
     const int i = blockIdx.x * kBlock + threadIdx.x;     // position in tree order
-    if (i >= V) return;
-    const int v = qperm[i];
-    int n = count[(size_t)b * stride + i];
+    const bool real = i < V;                             // all lanes stay: long rings below need the whole wavefront
+    const int v = qperm[real ? i : V - 1];
+    int n = count[(size_t)b * stride + (real ? i : V - 1)];
     const float* vb = verts + (size_t)b * V * 3;
     const float vx = vb[3 * v], vy = vb[3 * v + 1], vz = vb[3 * v + 2];
     const float qx = shear_x(vx, vz), qy = shear_y(vy, vz);
     // the apex direction of the fan, in space and sheared (ray frame)
     const P3 u_dir = {kFanX, kFanY, kFanZ};
     const P3 us = {shear_x(kFanX, kFanZ), shear_y(kFanY, kFanZ), kFanZ};
-    const int lo = ring_off[v], cnt = ring_off[v + 1] - lo;
+    const int lo = ring_off[v], cnt = real ? ring_off[v + 1] - lo : 0;
     float half_sum = 0.0f;
     constexpr int kLongRing = 16;
-    if (cnt <= kLongRing) {
+    if (cnt > 0 && cnt <= kLongRing) {
         // previous ring vertex (j = cnt-1) to start the cycle
         int r = ring_vidx[lo + cnt - 1];
         P3 pb = {vb[3 * r] - vx, vb[3 * r + 1] - vy, vb[3 * r + 2] - vz};
@@ -604,6 +604,7 @@ __global__ __launch_bounds__(kBlock) void ray_finalize_verts_kernel(
         for (int m = 32; m >= 1; m >>= 1) { h += __shfl_xor(h, m); cr += __shfl_xor(cr, m); }
         if (lane == src) { half_sum = h; n += cr; }
     }
+    if (!real) return;
     const float w = (float)n - half_sum * (0.5f / kPi);
     const size_t o = (size_t)b * V + v;
     if (w_out) w_out[o] = w;
