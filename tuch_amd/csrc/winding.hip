@@ -680,9 +680,21 @@ __global__ __launch_bounds__(kBlock) void segment_compact_kernel(
         if (local == 0) count[b * S + s] = seg_q_off[s + 1] - seg_q_off[s];
         return;
     }
-    if (exterior[(size_t)b * V + seg_q_vidx[q]]) return;
-    const int pos = atomicAdd(&count[b * S + s], 1);
-    list[(size_t)b * Qs_total + seg_q_off[s] + pos] = local;
+    // one atomic per (wavefront, segment) instead of one per vertex: the counters are few (B x S) and atomics on one
+    // address serialise (~100 ns each); the lanes of a wavefront mostly belong to one segment
+    bool mine = !exterior[(size_t)b * V + seg_q_vidx[q]];
+    const int lane = threadIdx.x & 63;
+    while (unsigned long long todo = __builtin_amdgcn_ballot_w64(mine)) {
+        const int s0 = __builtin_amdgcn_readlane(s, __builtin_ctzll(todo));
+        const unsigned long long group = __builtin_amdgcn_ballot_w64(mine && s == s0);
+        int base = 0;
+        if (lane == __builtin_ctzll(group)) base = atomicAdd(&count[b * S + s0], __builtin_popcountll(group));
+        base = __builtin_amdgcn_readlane(base, __builtin_ctzll(group));
+        if (mine && s == s0) {
+            list[(size_t)b * Qs_total + seg_q_off[s] + base + __builtin_popcountll(group & ((1ull << lane) - 1ull))] = local;
+            mine = false;
+        }
+    }
 }
 
 __global__ __launch_bounds__(kSegBlock) void segment_winding_kernel(
