@@ -771,6 +771,34 @@ def test_ray_crossing_flags_match_the_solid_angle_sums(tag, batch, monkeypatch):
         check_winding(w_r[b], g['winding'][b])
 
 
+@pytest.mark.parametrize('tag', TAGS)
+def test_segment_filter_by_ray_crossings_matches_the_solid_angle_sums(tag, monkeypatch):
+    """The segment test (segmentation.py:81-99) by ray crossings: w of EVERY segment vertex w.r.t. its "closed" segment
+    = crossings + cone terms of the closing chain (links of the vertex's star - the boundary of the segment mesh; the
+    synthetic caps leave boundary edges on the arm segments, so the chain is not just a ring) against the summed solid
+    angles; flags identical wherever w is not within 1e-4 of the threshold, body flags after the filter identical."""
+    g, verts = _posed_batch(tag, 4, 11)
+    model = make_model(g, None, True, False)
+    monkeypatch.setenv('TUCH_WINDING_RAY', '0')
+    ext_s, _, segw_s, sege_s = model.exterior_flags(verts, apply_segments=True, return_details=True)
+    monkeypatch.setenv('TUCH_WINDING_RAY', '2')
+    ext_r, _, segw_r, sege_r = model.exterior_flags(verts, apply_segments=True, return_details=True)
+    monkeypatch.setenv('TUCH_WINDING_RAY', '1')
+    ext_1 = model.exterior_flags(verts, apply_segments=True)
+    segw_s, segw_r = segw_s.cpu().numpy(), segw_r.cpu().numpy()
+    err = np.abs(segw_r - segw_s)
+    jump = err > 0.5                       # a vertex touching another triangle of its segment: either side is legitimate
+    report('segment w, ray vs solid angle: vertices on a jump [%s]' % tag, int(jump.sum()), err.size)
+    assert jump.sum() <= 4
+    report('segment w, ray vs solid angle: max |dw| [%s] x1e7' % tag, int(err[~jump].max() * 1e7), err.size)
+    assert err[~jump].max() < 2e-4
+    clear = (np.abs(segw_s - 0.99) > 1e-4) & ~jump
+    assert np.array_equal(sege_r.cpu().numpy()[clear], sege_s.cpu().numpy()[clear])
+    if not jump.any():
+        assert torch.equal(ext_r, ext_s) and torch.equal(ext_1, ext_s)
+    assert len(np.unique(np.round(segw_s))) >= 2          # vertices inside their own segment do occur
+
+
 def test_ray_crossing_flags_at_rest_pose_and_axis_aligned():
     """Degenerate input: the symmetric template itself, unposed and axis aligned (many exactly equal coordinates,
     rays through edges and vertices: the tie rules decide) and a mirrored copy (orientation reversed: w = -...)."""

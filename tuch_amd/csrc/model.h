@@ -36,6 +36,9 @@ bool tuch_ray_available(const tuch_contact_model* m);
 size_t tuch_ray_workspace_bytes(const tuch_contact_model* m, int B, int Q);
 int tuch_ray_exterior_verts(const tuch_contact_model* m, const float* verts, int B, float thresh, uint8_t* exterior,
                             float* w, void* workspace, hipStream_t s, unsigned long long* stats_host);
+int tuch_ray_segment_flags(const tuch_contact_model* m, const float* verts, const float* caps, const int32_t* seg_count,
+                           const int32_t* seg_list, int B, int nsplit, float thresh, float* seg_tris, int32_t* seg_partial,
+                           float* seg_w, uint8_t* seg_ext, uint8_t* exterior, hipStream_t s);
 int tuch_ray_exterior_points(const tuch_contact_model* m, const float* verts, const float* points, const int32_t* counts,
                              int B, int Q, float thresh, uint8_t* exterior, float* w, void* workspace, hipStream_t s);
 
@@ -94,6 +97,16 @@ struct tuch_contact_model {
     int32_t* seg_faces;        // [seg_f_total,3], cap vertex c is index V + c
     int32_t* cap_off;          // [K+1] into cap_vidx
     int32_t* cap_vidx;         // ordered boundary loops, concatenated
+    // For the ray-crossing form of the segment test (ray_winding.hip), ids as in seg_faces (cap vertex c is V + c):
+    // the links (x -> y) of the faces (v, x, y) around every segment vertex v within its segment, and the boundary
+    // chain of every "closed" segment -- the directed edges whose reverse is missing, with their net multiplicity
+    // (empty when the caps really close the segment; the reference's construction does not guarantee that).
+    int32_t* seg_link_off;     // [seg_q_total+1] into seg_link (pairs)
+    int32_t* seg_link;         // [.][2]
+    // the segment's faces followed by its boundary edges as entries (x, y, -multiplicity): what the crossing kernel walks
+    int32_t* seg_ray_off;      // [S+1] into seg_ray_ent (triples)
+    int32_t* seg_ray_ent;      // [seg_ray_total][3]
+    int seg_ray_total;
     int num_seg_blocks;        // 64-query blocks over all segments
     int32_t* seg_blocks;       // [num_seg_blocks][2] = (segment, first query within the segment)
     int32_t* seg_of_q;         // [seg_q_total] segment of every entry of seg_q_vidx

@@ -4,6 +4,7 @@
 #include "model.h"
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <vector>
 #include <unordered_map>
 
@@ -40,7 +41,7 @@ extern "C" void tuch_contact_model_destroy(tuch_contact_model* m)
 {
     if (!m) return;
     void* dev[] = {m->ring_off, m->ring_vidx, m->faces, m->mask_bits, m->strip_vidx, m->strip_sign, m->tree_node, m->tree_vidx, m->tree_sign, m->tree_qperm,
-                   m->tree_height_off, m->tree_height_nodes, m->tree_frontier_nodes, m->tree_launch_order, m->tree_ancestors, m->tree_rows, m->tree_mask_bits, m->tree_masked, m->seg_blocks, m->seg_of_q, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces,
+                   m->tree_height_off, m->tree_height_nodes, m->tree_frontier_nodes, m->tree_launch_order, m->tree_ancestors, m->tree_rows, m->tree_mask_bits, m->tree_masked, m->seg_blocks, m->seg_of_q, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces, m->seg_link_off, m->seg_link, m->seg_ray_off, m->seg_ray_ent,
                    m->cap_off, m->cap_vidx, m->region_off, m->region_vidx, m->pairs, m->pair_mask, m->pair_mask_off};
     for (void* p : dev)
         if (p) (void)hipFree(p);
@@ -227,6 +228,48 @@ extern "C" int tuch_contact_model_create(
         if (rc == TUCH_OK && num_caps > 0) {
             rc = upload(&m->cap_off, cap_off, (size_t)num_caps + 1);
             if (rc == TUCH_OK) rc = upload(&m->cap_vidx, cap_vidx, (size_t)cap_off[num_caps]);
+        }
+        // Tables for the ray-crossing form of the segment test: the star of every segment vertex as links, and the
+        // boundary chain of every segment mesh (model.h).
+        if (rc == TUCH_OK) {
+            std::vector<int32_t> loff(1, 0), links, eoff(1, 0), ent;
+            for (int sg = 0; sg < num_segments; ++sg) {
+                const int32_t* fs = seg_faces + 3 * (size_t)seg_f_off[sg];
+                const int nf = seg_f_off[sg + 1] - seg_f_off[sg];
+                auto key = [](int a, int b) { return ((uint64_t)(uint32_t)a << 32) | (uint32_t)b; };
+                std::unordered_map<uint64_t, int> net;                // directed edge -> occurrences - occurrences reversed
+                std::unordered_map<int, std::vector<int32_t>> star;   // vertex -> (x, y) of its faces (v, x, y)
+                for (int f = 0; f < nf; ++f)
+                    for (int k = 0; k < 3; ++k) {
+                        const int v = fs[3 * f + k], x = fs[3 * f + (k + 1) % 3], y = fs[3 * f + (k + 2) % 3];
+                        if (v < x) ++net[key(v, x)]; else --net[key(x, v)];
+                        star[v].push_back(x);
+                        star[v].push_back(y);
+                    }
+                ent.insert(ent.end(), fs, fs + 3 * (size_t)nf);
+                std::vector<uint64_t> open_edges;
+                for (const auto& e : net)
+                    if (e.second != 0) open_edges.push_back(e.first);
+                std::sort(open_edges.begin(), open_edges.end());      // a fixed order of the sums
+                for (uint64_t e : open_edges) {
+                    const int a = (int)(e >> 32), b2 = (int)(uint32_t)e, mlt = net[e];
+                    // closing chain = links - boundary: the boundary edge x -> y enters with -multiplicity
+                    if (mlt > 0) { ent.push_back(a); ent.push_back(b2); ent.push_back(-mlt); }
+                    else { ent.push_back(b2); ent.push_back(a); ent.push_back(mlt); }
+                }
+                eoff.push_back((int32_t)(ent.size() / 3));
+                for (int q = seg_q_off[sg]; q < seg_q_off[sg + 1]; ++q) {
+                    const auto it = star.find(seg_q_vidx[q]);
+                    if (it != star.end()) links.insert(links.end(), it->second.begin(), it->second.end());
+                    loff.push_back((int32_t)(links.size() / 2));
+                }
+            }
+            if (links.empty()) links.assign(2, 0);
+            m->seg_ray_total = (int)(ent.size() / 3);
+            rc = upload(&m->seg_link_off, loff.data(), loff.size());
+            if (rc == TUCH_OK) rc = upload(&m->seg_link, links.data(), links.size());
+            if (rc == TUCH_OK) rc = upload(&m->seg_ray_off, eoff.data(), eoff.size());
+            if (rc == TUCH_OK) rc = upload(&m->seg_ray_ent, ent.data(), ent.size());
         }
     }
     if (rc == TUCH_OK && num_regions > 0) {

@@ -625,6 +625,213 @@ __global__ __launch_bounds__(kBlock) void ray_finalize_points_kernel(
     if (exterior) exterior[o] = w <= thresh;
 }
 
+// ---- the segment filter by ray crossings ------------------------------------------------------------------------
+// has_self_isect (segmentation.py:81-99): winding number of a segment's vertices w.r.t. its own "closed" mesh T
+// (segment faces + cap fans).  The reference sums the solid angles of the faces that do not contain the query v
+// (the others are atan2(0,0) = 0): of the chain T' = T minus star(v).  Close T' with cones from its boundary to an
+// apex v + delta u: the result is a 2-cycle, its winding number around v is the signed number of ray crossings, so
+//     w_ref(v) = crossings(T') + sum over the closing chain C of [crossing - half angle / 2 pi] of the cone triangle,
+//     C = -boundary(T') = links of star(v) - boundary(T),
+// exactly the fan of the body test when T is a closed manifold (boundary(T) = 0, the links form the ring) -- but with no
+// such assumption: the reference's caps need not close the segment consistently (segmentation.py:56-66 takes the loops
+// as the asset lists them), and the synthetic segments do leave a few dozen boundary edges.  As for the fan, the cone
+// terms depend on the direction u only.  A segment vertex on no face of its segment has no links: w = crossings - the
+// boundary terms.
+// The segment meshes are small (hundreds of faces) and the queries few (the segment's interior vertices, compacted
+// by winding.hip), so the layout is that of the solid-angle kernel it replaces: one wavefront per 64 queries and
+// face split, triangles staged through LDS; ~30 plain operations per (query, triangle) instead of ~90.
+constexpr int kSegRayChunk = 128;     // triangles staged in LDS per pass
+
+// The entries a segment's crossing kernel walks, posed and sheared, 9 floats each: a face (three corners; index < V ->
+// body vertex, else cap vertex, segmentation.py:77) or a boundary edge x -> y of the segment mesh with its (negative)
+// multiplicity: [x', y', multiplicity, marker, 0].
+constexpr float kConeMarker = 3.0e38f;
+__global__ __launch_bounds__(kBlock) void segment_shear_entries_kernel(
+    const float* __restrict__ verts, const float* __restrict__ caps,
+    const int32_t* __restrict__ ent, int V, int K, int E, float* __restrict__ out)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= E) return;
+    const int id[3] = {ent[3 * i], ent[3 * i + 1], ent[3 * i + 2]};
+    float* dst = out + ((size_t)b * E + i) * 9;
+    const int corners = id[2] < 0 ? 2 : 3;
+    for (int k = 0; k < corners; ++k) {
+        const float* src = id[k] < V ? verts + ((size_t)b * V + id[k]) * 3 : caps + ((size_t)b * K + (id[k] - V)) * 3;
+        dst[3 * k] = shear_x(src[0], src[2]); dst[3 * k + 1] = shear_y(src[1], src[2]); dst[3 * k + 2] = src[2];
+    }
+    if (corners == 2) { dst[6] = (float)id[2]; dst[7] = kConeMarker; dst[8] = 0.0f; }
+}
+
+// Work items of the crossing kernel: (body, segment, block of 64 compacted queries), only those that exist -- a grid
+// over the worst case (every segment vertex interior) is ten times larger and costs more in dispatch than in work.
+// One workgroup; items[i] = (body * S + segment, first query), items_total[0] = how many.
+constexpr int kItemsBlock = 256;
+__global__ __launch_bounds__(kItemsBlock) void segment_items_kernel(
+    const int32_t* __restrict__ count, int BS, int2* __restrict__ items, int32_t* __restrict__ items_total)
+{
+    __shared__ int sc[kItemsBlock];
+    __shared__ int base;
+    const int t = threadIdx.x;
+    if (t == 0) base = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < BS; c0 += kItemsBlock) {
+        const int e = c0 + t;
+        const int nb = e < BS ? (count[e] + 63) >> 6 : 0;
+        sc[t] = nb;
+        __syncthreads();
+        for (int d = 1; d < kItemsBlock; d <<= 1) {          // inclusive scan
+            const int add = t >= d ? sc[t - d] : 0;
+            __syncthreads();
+            sc[t] += add;
+            __syncthreads();
+        }
+        const int off = base + sc[t] - nb;
+        for (int k = 0; k < nb; ++k) items[off + k] = make_int2(e, 64 * k);
+        __syncthreads();
+        if (t == kItemsBlock - 1) base += sc[t];
+        __syncthreads();
+    }
+    if (t == 0) items_total[0] = base;
+}
+
+__global__ __launch_bounds__(64) void segment_ray_kernel(
+    const float* __restrict__ verts, const float* __restrict__ entries,
+    const int2* __restrict__ items, const int32_t* __restrict__ items_total, const int32_t* __restrict__ seg_q_off,
+    const int32_t* __restrict__ seg_q_vidx, const int32_t* __restrict__ ent_off,
+    const int32_t* __restrict__ count, const int32_t* __restrict__ list, int V, int E,
+    int Qs_total, int S, int nsplit, int32_t* __restrict__ partial,     // [B,nsplit,Qs_total] by list position: crossings
+    float* __restrict__ partial_half)                                   // same shape: half angles of the boundary cones
+{
+    const P3 u_dir = {kFanX, kFanY, kFanZ};
+    const P3 us = {shear_x(kFanX, kFanZ), shear_y(kFanY, kFanZ), kFanZ};
+    __shared__ float sT[kSegRayChunk * 9];
+    const int units = items_total[0] * nsplit;                          // (item, face split)
+    for (int unit = blockIdx.x; unit < units; unit += gridDim.x) {
+        const int2 item = items[unit / nsplit];
+        const int split = unit % nsplit;
+        const int b = item.x / S, s = item.x % S, k_start = item.y;
+        const int n = count[item.x];
+        const int q_beg = seg_q_off[s];
+        const int32_t* mine = list + (size_t)b * Qs_total + q_beg;
+        const int k0 = k_start + threadIdx.x;
+        const int v0 = seg_q_vidx[q_beg + mine[min(k0, n - 1)]];
+        const float* vb = verts + (size_t)b * V * 3;
+        const float qz = vb[3 * v0 + 2];
+        const float qx = shear_x(vb[3 * v0], qz), qy = shear_y(vb[3 * v0 + 1], qz);
+        const int f_seg = ent_off[s], f_cnt = ent_off[s + 1] - f_seg;
+        const int per = (f_cnt + nsplit - 1) / nsplit;
+        const int f_beg = f_seg + split * per, f_end = min(f_seg + f_cnt, f_beg + per);
+        int crossings = 0;
+        float half_sum = 0.0f;
+        for (int chunk = f_beg; chunk < f_end; chunk += kSegRayChunk) {
+            const int cn = min(kSegRayChunk, f_end - chunk);
+            const float* src = entries + ((size_t)b * E + chunk) * 9;
+            __syncthreads();
+            for (int i = threadIdx.x; i < cn * 9; i += 64) sT[i] = src[i];
+            __syncthreads();
+            for (int f = 0; f < cn; ++f) {
+                const float* t = sT + f * 9;
+                if (t[7] != kConeMarker) {                              // a face (wave-uniform: LDS broadcast)
+                    const P3 a = {t[0] - qx, t[1] - qy, t[2] - qz}, bb = {t[3] - qx, t[4] - qy, t[5] - qz}, c = {t[6] - qx, t[7] - qy, t[8] - qz};
+                    const float ea = edge_fn(bb, c), eb = edge_fn(c, a), ec = edge_fn(a, bb);
+                    const float numz = ea * a.z + eb * bb.z + ec * c.z;
+                    const float mn = __builtin_fminf(__builtin_fminf(ea, eb), ec), mx = __builtin_fmaxf(__builtin_fmaxf(ea, eb), ec);
+                    int n1 = (int)(__builtin_fminf(mn, numz) > 0.0f) - (int)(__builtin_fmaxf(mx, numz) < 0.0f);
+                    // exact ties with a definite depth; the faces around the query (det exactly 0) count 0 above
+                    const bool edge_zero = mn * mx == 0.0f;
+                    if (__builtin_amdgcn_ballot_w64(edge_zero)) {
+                        const bool tie = edge_zero & (numz != 0.0f);
+                        if (__builtin_amdgcn_ballot_w64(tie)) {
+                            if (tie) n1 = crossing_with_ties<true>(a, bb, c, ea, eb, ec);
+                        }
+                    }
+                    crossings += n1;
+                } else {
+                    // a boundary edge x -> y: the cone triangle (u, x, y), its apex a direction; edges at the query
+                    // itself cancel against the spokes of its star and are left out
+                    const P3 bb = {t[0] - qx, t[1] - qy, t[2] - qz}, c = {t[3] - qx, t[4] - qy, t[5] - qz};
+                    const bool at_query = ((bb.x == 0.0f) & (bb.y == 0.0f) & (bb.z == 0.0f)) | ((c.x == 0.0f) & (c.y == 0.0f) & (c.z == 0.0f));
+                    if (!at_query) {
+                        const int mult = (int)t[6];
+                        crossings += mult * crossing(us, bb, c, edge_fn(bb, c), edge_fn(c, us), edge_fn(us, bb));
+                        // back from the sheared frame for the angle
+                        const P3 pb = {__builtin_fmaf(kShearX, bb.z, bb.x), __builtin_fmaf(kShearY, bb.z, bb.y), bb.z};
+                        const P3 pc = {__builtin_fmaf(kShearX, c.z, c.x), __builtin_fmaf(kShearY, c.z, c.y), c.z};
+                        half_sum += (float)mult * half_solid_angle(u_dir, pb, pc);
+                    }
+                }
+            }
+        }
+        const size_t o = ((size_t)b * nsplit + split) * Qs_total + q_beg;
+        if (k0 < n) { partial[o + k0] = crossings; partial_half[o + k0] = half_sum; }
+    }
+}
+
+// vertices that are NOT exterior to their own segment are re-marked exterior in the body flags
+// (losses.py:87-89, loss.py:265-266)
+__global__ __launch_bounds__(kBlock) void segment_ray_finalize_kernel(
+    const float* __restrict__ verts, const float* __restrict__ caps, const int32_t* __restrict__ partial,
+    const float* __restrict__ partial_half,
+    const int32_t* __restrict__ seg_of_q, const int32_t* __restrict__ seg_q_off, const int32_t* __restrict__ seg_q_vidx,
+    const int32_t* __restrict__ link_off, const int32_t* __restrict__ link,
+    const int32_t* __restrict__ count, const int32_t* __restrict__ list, int V, int K,
+    int Qs_total, int S, int nsplit, float thresh, float* __restrict__ seg_w, uint8_t* __restrict__ seg_ext,
+    uint8_t* __restrict__ exterior)
+{
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * kBlock + threadIdx.x;       // a list position
+    if (q >= Qs_total) return;
+    const int s = seg_of_q[q];
+    const int k = q - seg_q_off[s];
+    if (k >= count[b * S + s]) return;
+    int n = 0;
+    float half_sum = 0.0f;
+    for (int sp = 0; sp < nsplit; ++sp) {
+        n += partial[((size_t)b * nsplit + sp) * Qs_total + q];
+        half_sum += partial_half[((size_t)b * nsplit + sp) * Qs_total + q];
+    }
+    const int qq = seg_q_off[s] + list[(size_t)b * Qs_total + q];   // the vertex's slot in the segment tables
+    const int v = seg_q_vidx[qq];
+    const float* vb = verts + (size_t)b * V * 3;
+    const float* cb = caps + (size_t)b * K * 3;
+    const float vx = vb[3 * v], vy = vb[3 * v + 1], vz = vb[3 * v + 2];
+    const float qx = shear_x(vx, vz), qy = shear_y(vy, vz);
+    const P3 u_dir = {kFanX, kFanY, kFanZ};
+    const P3 us = {shear_x(kFanX, kFanZ), shear_y(kFanY, kFanZ), kFanZ};
+    // cone triangles (apex direction u, x, y) of the links x -> y of the vertex's star, two at a time (their four
+    // corner positions are fetched together)
+    const int e0 = link_off[qq], e1 = link_off[qq + 1];
+    for (int e = e0; e < e1; e += 2) {
+        int id[4];
+        float pp[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) id[u] = link[2 * min(e + (u >> 1), e1 - 1) + (u & 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float* p = id[u] < V ? vb + 3 * (size_t)id[u] : cb + 3 * (size_t)(id[u] - V);
+            pp[u][0] = p[0]; pp[u][1] = p[1]; pp[u][2] = p[2];
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (e + h < e1) {
+                const float* p0 = pp[2 * h];
+                const float* p1 = pp[2 * h + 1];
+                const P3 pb = {p0[0] - vx, p0[1] - vy, p0[2] - vz}, pc = {p1[0] - vx, p1[1] - vy, p1[2] - vz};
+                const P3 sb = {shear_x(p0[0], p0[2]) - qx, shear_y(p0[1], p0[2]) - qy, p0[2] - vz};
+                const P3 sc = {shear_x(p1[0], p1[2]) - qx, shear_y(p1[1], p1[2]) - qy, p1[2] - vz};
+                half_sum += half_solid_angle(u_dir, pb, pc);
+                n += crossing_mostly_generic(us, sb, sc, edge_fn(sb, sc), edge_fn(sc, us), edge_fn(us, sb));
+            }
+        }
+    }
+    const float w = (float)n - half_sum * (0.5f / kPi);
+    const size_t o = (size_t)b * Qs_total + qq;
+    if (seg_w) seg_w[o] = w;
+    if (seg_ext) seg_ext[o] = w <= thresh;
+    if (exterior && !(w <= thresh)) exterior[(size_t)b * V + v] = 1;
+}
+
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct RayLayout {
@@ -784,4 +991,30 @@ int tuch_ray_exterior_points(const tuch_contact_model* m, const float* verts, co
     hipLaunchKernelGGL(ray_finalize_points_kernel, dim3(ceil_div(Q, kBlock), B), dim3(kBlock), 0, s,
                        (const int32_t*)(ws + l.count), counts, Q, l.qblocks * kRayQueries, thresh, w, exterior);
     return tuch_check_launch("tuch_ray_exterior_points");
+}
+
+// The segment filter (winding.hip: caps, compacted interior vertices per (body, segment) in seg_count / seg_list) by
+// ray crossings.  Scratch of the caller: seg_entries [B,seg_ray_total,9] floats, seg_partial [2][B,nsplit,Qs_total] words.
+int tuch_ray_segment_flags(const tuch_contact_model* m, const float* verts, const float* caps, const int32_t* seg_count,
+                           const int32_t* seg_list, int B, int nsplit, float thresh, float* seg_entries, int32_t* seg_partial,
+                           float* seg_w, uint8_t* seg_ext, uint8_t* exterior, hipStream_t s)
+{
+    float* partial_half = (float*)(seg_partial + (size_t)B * nsplit * m->seg_q_total);
+    hipLaunchKernelGGL(segment_shear_entries_kernel, dim3(ceil_div(m->seg_ray_total, kBlock), B), dim3(kBlock), 0, s,
+                       verts, caps, (const int32_t*)m->seg_ray_ent, m->V, m->num_caps, m->seg_ray_total, seg_entries);
+    // work items behind the two partial arrays (B * num_seg_blocks int2 + 1 counter; the caller sizes seg_partial for it)
+    int2* items = (int2*)(partial_half + (size_t)B * nsplit * m->seg_q_total);
+    int32_t* items_total = (int32_t*)(items + (size_t)B * m->num_seg_blocks);
+    hipLaunchKernelGGL(segment_items_kernel, dim3(1), dim3(kItemsBlock), 0, s, seg_count, B * m->num_segments, items, items_total);
+    const long worst = (long)B * m->num_seg_blocks * nsplit;
+    hipLaunchKernelGGL(segment_ray_kernel, dim3((unsigned)(worst < 8192 ? worst : 8192)), dim3(64), 0, s, verts,
+                       (const float*)seg_entries, (const int2*)items, (const int32_t*)items_total, (const int32_t*)m->seg_q_off,
+                       (const int32_t*)m->seg_q_vidx, (const int32_t*)m->seg_ray_off, seg_count, seg_list, m->V, m->seg_ray_total,
+                       m->seg_q_total, m->num_segments, nsplit, seg_partial, partial_half);
+    hipLaunchKernelGGL(segment_ray_finalize_kernel, dim3(ceil_div(m->seg_q_total, kBlock), B), dim3(kBlock), 0, s, verts, caps,
+                       (const int32_t*)seg_partial, (const float*)partial_half, (const int32_t*)m->seg_of_q,
+                       (const int32_t*)m->seg_q_off, (const int32_t*)m->seg_q_vidx, (const int32_t*)m->seg_link_off,
+                       (const int32_t*)m->seg_link, seg_count, seg_list, m->V, m->num_caps, m->seg_q_total, m->num_segments,
+                       nsplit, thresh, seg_w, seg_ext, exterior);
+    return tuch_check_launch("tuch_ray_segment_flags");
 }

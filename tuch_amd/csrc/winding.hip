@@ -858,8 +858,11 @@ ExteriorLayout exterior_layout(const tuch_contact_model* m, int B)
     l.bounds = o;   o += align256((size_t)B * (m->tree_nodes > 0 ? m->tree_nodes : 1) * 2 * kSlabStride * sizeof(float));
     l.stats = o;    o += 256;
     l.caps = o;     o += align256((size_t)B * (m->num_caps > 0 ? m->num_caps : 1) * 3 * sizeof(float));
-    l.seg_tris = o; o += align256(((size_t)B * (m->seg_f_total > 0 ? m->seg_f_total : 1) + 1) * 9 * sizeof(float));
-    l.seg_partial = o; o += align256((size_t)B * kSegSplits * (m->seg_q_total > 0 ? m->seg_q_total : 1) * sizeof(float));
+    // triangles of the closed segments, or (ray form) faces + boundary entries; partial sums, two arrays in the ray form
+    const int seg_entries = m->seg_ray_total > m->seg_f_total ? m->seg_ray_total : m->seg_f_total;
+    l.seg_tris = o; o += align256(((size_t)B * (seg_entries > 0 ? seg_entries : 1) + 1) * 9 * sizeof(float));
+    l.seg_partial = o; o += align256(2 * (size_t)B * kSegSplits * (m->seg_q_total > 0 ? m->seg_q_total : 1) * sizeof(float) +
+                                      ((size_t)B * (m->num_seg_blocks > 0 ? m->num_seg_blocks : 1) * 2 + 4) * sizeof(int32_t));
     l.seg_count = o; o += align256((size_t)B * (m->num_segments > 0 ? m->num_segments : 1) * sizeof(int32_t));
     l.seg_list = o; o += align256((size_t)B * (m->seg_q_total > 0 ? m->seg_q_total : 1) * sizeof(int32_t));
     l.ray = o;      o += align256(tuch_ray_workspace_bytes(m, B, 0));
@@ -1025,9 +1028,6 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
         hipLaunchKernelGGL(cap_centroid_kernel, dim3(m->num_caps, B), dim3(64), 0, s,
                            verts, (const int32_t*)m->cap_off, (const int32_t*)m->cap_vidx, m->V,
                            m->num_caps, caps);
-        hipLaunchKernelGGL(gather_segment_triangles_kernel, dim3(ceil_div(m->seg_f_total * 3, kBlock), B),
-                           dim3(kBlock), 0, s, verts, (const float*)caps, (const int32_t*)m->seg_faces,
-                           m->V, m->num_caps, m->seg_f_total, seg_tris);
         float* seg_partial = (float*)(ws + l.seg_partial);
         int32_t* seg_count = (int32_t*)(ws + l.seg_count);
         int32_t* seg_list = (int32_t*)(ws + l.seg_list);
@@ -1040,6 +1040,17 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
                            all ? (const uint8_t*)nullptr : (const uint8_t*)exterior, (const int32_t*)m->seg_of_q,
                            (const int32_t*)m->seg_q_off, (const int32_t*)m->seg_q_vidx, m->V, m->seg_q_total,
                            m->num_segments, seg_count, seg_list);
+        // by ray crossings under the same rule as the body test (ray_mode: when only flags are wanted, or always with
+        // TUCH_WINDING_RAY=2)
+        if (m->seg_link_off && (ray == 2 || (ray == 1 && !seg_w))) {
+            rc = tuch_ray_segment_flags(m, verts, caps, seg_count, seg_list, B, seg_splits(), thresh, seg_tris,
+                                        (int32_t*)seg_partial, seg_w, seg_exterior, exterior, s);
+            if (rc != TUCH_OK) return rc;
+            return tuch_check_launch("tuch_exterior_flags");
+        }
+        hipLaunchKernelGGL(gather_segment_triangles_kernel, dim3(ceil_div(m->seg_f_total * 3, kBlock), B),
+                           dim3(kBlock), 0, s, verts, (const float*)caps, (const int32_t*)m->seg_faces,
+                           m->V, m->num_caps, m->seg_f_total, seg_tris);
         hipLaunchKernelGGL(segment_winding_kernel, dim3(B, seg_splits(), m->num_seg_blocks), dim3(kSegBlock),
                            0, s, verts, (const float*)seg_tris, (const int32_t*)m->seg_blocks,
                            (const int32_t*)m->seg_q_off, (const int32_t*)m->seg_q_vidx,
