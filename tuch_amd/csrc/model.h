@@ -36,9 +36,12 @@ bool tuch_ray_available(const tuch_contact_model* m);
 size_t tuch_ray_workspace_bytes(const tuch_contact_model* m, int B, int Q);
 int tuch_ray_exterior_verts(const tuch_contact_model* m, const float* verts, int B, float thresh, uint8_t* exterior,
                             float* w, void* workspace, hipStream_t s, unsigned long long* stats_host);
+// crossings of every vertex with the body faces of each of its segments, [B][tree_qblocks*128][8], left in the
+// workspace of tuch_ray_exterior_verts by a model with seg_elem_mask
+const int32_t* tuch_ray_segment_counts(const tuch_contact_model* m, int B, const void* workspace);
 int tuch_ray_segment_flags(const tuch_contact_model* m, const float* verts, const float* caps, const int32_t* seg_count,
-                           const int32_t* seg_list, int B, int nsplit, float thresh, float* seg_tris, int32_t* seg_partial,
-                           float* seg_w, uint8_t* seg_ext, uint8_t* exterior, hipStream_t s);
+                           const int32_t* seg_list, const int32_t* leaf_counts, int B, int nsplit, float thresh, float* seg_tris,
+                           int32_t* seg_partial, float* seg_w, uint8_t* seg_ext, uint8_t* exterior, hipStream_t s);
 int tuch_ray_exterior_points(const tuch_contact_model* m, const float* verts, const float* points, const int32_t* counts,
                              int B, int Q, float thresh, uint8_t* exterior, float* w, void* workspace, hipStream_t s);
 
@@ -107,6 +110,16 @@ struct tuch_contact_model {
     int32_t* seg_ray_off;      // [S+1] into seg_ray_ent (triples)
     int32_t* seg_ray_ent;      // [seg_ray_total][3]
     int seg_ray_total;
+    // Leaf-assisted form: the crossings of a segment vertex with the BODY faces of its segment are counted by the body's
+    // own inside test (ray_leaf_kernel walks those faces for that vertex anyway), the segment pass keeps the cap faces
+    // and the boundary edges.  Available when the model has a cluster tree, every body face of a segment is a face of
+    // the model in the same orientation, and there are at most eight segments; else nullptr.
+    int32_t* seg_elem_mask;    // [tree_exact_len] per strip element: bit s = its triangle is a face of segment s
+    int32_t* seg_vmask;        // [tree_qblocks*128] by tree position: bit s = the vertex is a vertex of segment s
+    int32_t* seg_vpos;         // [V] tree position of every vertex
+    int32_t* seg_cap_off;      // [S+1] into seg_cap_ent: as seg_ray_* without the body faces
+    int32_t* seg_cap_ent;
+    int seg_cap_total;
     int num_seg_blocks;        // 64-query blocks over all segments
     int32_t* seg_blocks;       // [num_seg_blocks][2] = (segment, first query within the segment)
     int32_t* seg_of_q;         // [seg_q_total] segment of every entry of seg_q_vidx

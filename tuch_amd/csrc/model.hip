@@ -2,6 +2,7 @@
 // geodesic mask, segment tables, region tables).  The only place the library
 // allocates device memory; the hot calls never do.
 #include "model.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
@@ -41,7 +42,7 @@ extern "C" void tuch_contact_model_destroy(tuch_contact_model* m)
 {
     if (!m) return;
     void* dev[] = {m->ring_off, m->ring_vidx, m->faces, m->mask_bits, m->strip_vidx, m->strip_sign, m->tree_node, m->tree_vidx, m->tree_sign, m->tree_qperm,
-                   m->tree_height_off, m->tree_height_nodes, m->tree_frontier_nodes, m->tree_launch_order, m->tree_ancestors, m->tree_rows, m->tree_mask_bits, m->tree_masked, m->seg_blocks, m->seg_of_q, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces, m->seg_link_off, m->seg_link, m->seg_ray_off, m->seg_ray_ent,
+                   m->tree_height_off, m->tree_height_nodes, m->tree_frontier_nodes, m->tree_launch_order, m->tree_ancestors, m->tree_rows, m->tree_mask_bits, m->tree_masked, m->seg_blocks, m->seg_of_q, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces, m->seg_link_off, m->seg_link, m->seg_ray_off, m->seg_ray_ent, m->seg_elem_mask, m->seg_vmask, m->seg_vpos, m->seg_cap_off, m->seg_cap_ent,
                    m->cap_off, m->cap_vidx, m->region_off, m->region_vidx, m->pairs, m->pair_mask, m->pair_mask_off};
     for (void* p : dev)
         if (p) (void)hipFree(p);
@@ -87,6 +88,9 @@ extern "C" int tuch_contact_model_create(
         rc = upload(&m->strip_vidx, sv.data(), sv.size());
         if (rc == TUCH_OK) rc = upload(&m->strip_sign, ss.data(), ss.size());
     }
+    std::vector<int32_t> tree_vidx_host, tree_qperm_host;     // for the segment tables further down
+    std::vector<float> tree_sign_host;
+    int tree_exact_host = 0;
     if (rc == TUCH_OK) {
         // cluster tree for the hierarchical winding numbers; a mesh that is not a closed manifold (or
         // has too many clusters for the LDS-resident boxes) simply keeps the flat strip path
@@ -105,6 +109,7 @@ extern "C" int tuch_contact_model_create(
             m->tree_frontier_off_host = host_copy(t.frontier_off.data(), t.frontier_off.size());
             m->tree_face_leaf_host = host_copy(t.face_leaf.data(), t.face_leaf.size());
             m->tree_qperm_host = host_copy(t.qperm.data(), t.qperm.size());
+            tree_vidx_host = t.vidx; tree_sign_host = t.sign; tree_qperm_host = t.qperm; tree_exact_host = t.exact_len;
             rc = upload(&m->tree_node, t.nodes.data(), t.nodes.size());
             if (rc == TUCH_OK) rc = upload(&m->tree_vidx, t.vidx.data(), t.vidx.size());
             if (rc == TUCH_OK) rc = upload(&m->tree_sign, t.sign.data(), t.sign.size());
@@ -270,6 +275,58 @@ extern "C" int tuch_contact_model_create(
             if (rc == TUCH_OK) rc = upload(&m->seg_link, links.data(), links.size());
             if (rc == TUCH_OK) rc = upload(&m->seg_ray_off, eoff.data(), eoff.size());
             if (rc == TUCH_OK) rc = upload(&m->seg_ray_ent, ent.data(), ent.size());
+            // leaf-assisted form (model.h)
+            bool assist = rc == TUCH_OK && m->tree_nodes > 0 && tree_exact_host > 0 && num_segments <= 8;
+            if (assist) {
+                auto key3 = [](int a, int b, int c) {          // rotation with the smallest id first: orientation kept
+                    if (b < a && b < c) { const int t2 = a; a = b; b = c; c = t2; }
+                    else if (c < a && c < b) { const int t2 = c; c = b; b = a; a = t2; }
+                    return ((uint64_t)(uint32_t)a << 42) ^ ((uint64_t)(uint32_t)b << 21) ^ (uint64_t)(uint32_t)c;
+                };
+                assist = V < (1 << 21);
+                std::unordered_map<uint64_t, int32_t> face_mask;      // body face -> segments that list it
+                for (int f = 0; f < F && assist; ++f) face_mask[key3(faces[3 * f], faces[3 * f + 1], faces[3 * f + 2])] = 0;
+                std::vector<int32_t> coff(1, 0), cent;
+                for (int sg = 0; sg < num_segments && assist; ++sg) {
+                    for (int e = eoff[sg]; e < eoff[sg + 1]; ++e) {
+                        const int32_t* t3 = &ent[3 * (size_t)e];
+                        if (t3[2] >= 0 && t3[0] < V && t3[1] < V && t3[2] < V) {       // a body face of the segment
+                            const auto it = face_mask.find(key3(t3[0], t3[1], t3[2]));
+                            if (it == face_mask.end() || (it->second >> sg) & 1) { if (getenv("TUCH_DEBUG")) fprintf(stderr, "assist: seg %d face (%d %d %d) %s\n", sg, t3[0], t3[1], t3[2], it == face_mask.end() ? "not a body face" : "listed twice"); assist = false; break; }
+                            it->second |= 1 << sg;
+                        } else {                                                        // cap face or boundary edge
+                            cent.insert(cent.end(), t3, t3 + 3);
+                        }
+                    }
+                    coff.push_back((int32_t)(cent.size() / 3));
+                }
+                std::vector<int32_t> vseg((size_t)V, 0);
+                for (int sg = 0; sg < num_segments && assist; ++sg)
+                    for (int q = seg_q_off[sg]; q < seg_q_off[sg + 1]; ++q) vseg[seg_q_vidx[q]] |= 1 << sg;
+                if (assist) {
+                    std::vector<int32_t> emask((size_t)(tree_exact_host + 2) / 3 * 3 + 6, 0),    // padded like the posed stream
+                                          vmask(tree_qperm_host.size(), 0), vpos(V, 0);
+                    for (int p2 = 2; p2 < tree_exact_host; ++p2) {
+                        if (tree_sign_host[p2] == 0.0f) continue;
+                        int a = tree_vidx_host[p2 - 2], b2 = tree_vidx_host[p2 - 1], c = tree_vidx_host[p2];
+                        if (tree_sign_host[p2] < 0.0f) { const int t2 = a; a = b2; b2 = t2; }     // odd permutation of the face
+                        const auto it = face_mask.find(key3(a, b2, c));
+                        if (it == face_mask.end()) { if (getenv("TUCH_DEBUG")) fprintf(stderr, "assist: stream element %d not a face\n", p2); assist = false; break; }
+                        emask[p2] = it->second;
+                    }
+                    for (size_t i = 0; i < tree_qperm_host.size(); ++i) vmask[i] = vseg[tree_qperm_host[i]];
+                    for (int i = V - 1; i >= 0; --i) vpos[tree_qperm_host[i]] = i;
+                    if (cent.empty()) cent.assign(3, 0);
+                    if (assist) {
+                        m->seg_cap_total = coff.back();
+                        rc = upload(&m->seg_elem_mask, emask.data(), emask.size());
+                        if (rc == TUCH_OK) rc = upload(&m->seg_vmask, vmask.data(), vmask.size());
+                        if (rc == TUCH_OK) rc = upload(&m->seg_vpos, vpos.data(), vpos.size());
+                        if (rc == TUCH_OK) rc = upload(&m->seg_cap_off, coff.data(), coff.size());
+                        if (rc == TUCH_OK) rc = upload(&m->seg_cap_ent, cent.data(), cent.size());
+                    }
+                }
+            }
         }
     }
     if (rc == TUCH_OK && num_regions > 0) {

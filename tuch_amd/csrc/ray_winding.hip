@@ -173,8 +173,14 @@ __device__ __forceinline__ int crossing_with_ties(const P3 a, const P3 b, const 
 // stream order (p-2 -> p-1 -> p).  Per element: two new edge functions, the depth determinant, and a branch-free
 // +-1 (the rays of a wavefront all pass the leaf's slabs, so most elements are hit by SOME lane: a "does any lane
 // hit" branch would almost always be taken).  Lanes with an exact tie take the careful form.
-template <int A, bool kSkipIncident>
-__device__ __forceinline__ void ray_step(const RayElem el, P3 (&s)[3], float (&e)[3], float qx, float qy, float qz, int& count)
+// kSeg: `em` = the segments that list the element's triangle as a face (bit s, s < 8); qmask = the segments the lane's
+// query vertex belongs to: the crossing also goes into per-segment counts (the segment test of winding.hip needs, for
+// every segment vertex, its crossings with the faces of its own segments only).  Eight counters as biased bytes of two
+// words: bits 0-3 of (em & qmask) are spread to the byte positions by one multiplication.
+constexpr uint32_t kSegBias = 0x80808080u;
+template <int A, bool kSkipIncident, bool kSeg>
+__device__ __forceinline__ void ray_step(const RayElem el, int em, P3 (&s)[3], float (&e)[3], float qx, float qy, float qz, int& count,
+                                         int qmask, uint32_t& pa, uint32_t& pb)
 {
     constexpr int Bq = (A + 1) % 3, Cq = (A + 2) % 3;            // slots of stream positions p-2 and p-1
     s[A].x = el.x - qx;
@@ -202,23 +208,34 @@ __device__ __forceinline__ void ray_step(const RayElem el, P3 (&s)[3], float (&e
                 if (tie) c = crossing_with_ties<kSkipIncident>(s[Bq], s[Cq], s[A], e[Bq], e[Cq], e[A]);
             }
         }
-        count += el.sign > 0.0f ? c : -c;
+        const int cs = el.sign > 0.0f ? c : -c;
+        count += cs;
+        if (kSeg && em != 0) {                                        // wave-uniform
+            const uint32_t t = (uint32_t)(em & qmask);
+            pa += (uint32_t)cs * (((t & 15u) * 0x00204081u) & 0x01010101u);
+            pb += (uint32_t)cs * (((t >> 4) * 0x00204081u) & 0x01010101u);
+        }
     }
 }
 
-template <bool kSkipIncident>
-__device__ __forceinline__ void ray_run(const RayElem* __restrict__ st, int off, int len, P3 (&s)[3], float (&e)[3],
-                                        float qx, float qy, float qz, int& count)
+template <bool kSkipIncident, bool kSeg>
+__device__ __forceinline__ void ray_run(const RayElem* __restrict__ st, const int32_t* __restrict__ emask, int off, int len,
+                                        P3 (&s)[3], float (&e)[3], float qx, float qy, float qz, int& count,
+                                        int qmask, uint32_t& pa, uint32_t& pb)
 {
     const RayElem* p = st + off;
     const RayElem* end = p + len;
+    const int32_t* m = kSeg ? emask + off : nullptr;
     RayElem n0 = p[0], n1 = p[1], n2 = p[2];
+    int m0 = kSeg ? m[0] : 0, m1 = kSeg ? m[1] : 0, m2 = kSeg ? m[2] : 0;
     for (; p < end; p += 3) {
         const RayElem e0 = n0, e1 = n1, e2 = n2;
+        const int k0 = m0, k1 = m1, k2 = m2;
         n0 = p[3]; n1 = p[4]; n2 = p[5];
-        ray_step<0, kSkipIncident>(e0, s, e, qx, qy, qz, count);
-        ray_step<1, kSkipIncident>(e1, s, e, qx, qy, qz, count);
-        ray_step<2, kSkipIncident>(e2, s, e, qx, qy, qz, count);
+        if (kSeg) { m += 3; m0 = m[0]; m1 = m[1]; m2 = m[2]; }
+        ray_step<0, kSkipIncident, kSeg>(e0, k0, s, e, qx, qy, qz, count, qmask, pa, pb);
+        ray_step<1, kSkipIncident, kSeg>(e1, k1, s, e, qx, qy, qz, count, qmask, pa, pb);
+        ray_step<2, kSkipIncident, kSeg>(e2, k2, s, e, qx, qy, qz, count, qmask, pa, pb);
     }
 }
 
@@ -417,22 +434,25 @@ __global__ __launch_bounds__(64) void ray_fill_kernel(
 // walked.  A body marked overflow is walked block-major: tile t = (query block t / 8, every 8th leaf of the block's
 // list from t % 8).
 // kCount: elements walked are added to stats[0] (measurement).
-template <bool kVerts, bool kCount>
+// kSeg (vertex queries of a model with segments): the crossings with the faces of the lane's own segments are counted
+// as well (seg_count[b][slot][8]; seg_elem_mask / seg_vmask of the model).
+template <bool kVerts, bool kCount, bool kSeg>
 __global__ __launch_bounds__(64) void ray_leaf_kernel(
     const float* __restrict__ pts, const RayElem* __restrict__ stream, const RayTile* __restrict__ tiles,
     const RayBody* __restrict__ body, const int32_t* __restrict__ pairs, const RayEntry* __restrict__ lists,
     const int32_t* __restrict__ list_len, const TreeNode* __restrict__ nodes, int num_leaves,
     const int32_t* __restrict__ qperm, const int32_t* __restrict__ counts, int Q, int T, int qblocks, int num_bodies,
-    int cap, int max_tiles, int32_t* __restrict__ count, unsigned long long* __restrict__ stats)
+    int cap, int max_tiles, int32_t* __restrict__ count, unsigned long long* __restrict__ stats,
+    const int32_t* __restrict__ elem_mask, const int32_t* __restrict__ vmask, int32_t* __restrict__ seg_count)
 {
     const int lane = threadIdx.x;
-    struct Work { int b, off, len, slot; bool active; float qx, qy, qz; };     // b < 0: nothing left; len < 0: block-major tile `off`
+    struct Work { int b, off, len, slot, qmask; bool active; float qx, qy, qz; };     // b < 0: nothing left; len < 0: block-major tile `off`
     // The tiles of the column's bodies x, x + G, ... form one sequence; wavefront y takes every gridDim.y-th of it (a
     // work counter instead serialises: ~100 ns per atomic on one address, measured).
     int b_cur = blockIdx.x, base = 0, g = blockIdx.y;       // current body, tiles before it, next position in the sequence
     auto fetch = [&]() {
         Work w;
-        w.b = -1; w.off = w.len = w.slot = 0; w.active = false; w.qx = w.qy = w.qz = 0.0f;
+        w.b = -1; w.off = w.len = w.slot = 0; w.qmask = 0; w.active = false; w.qx = w.qy = w.qz = 0.0f;
         while (b_cur < num_bodies) {
             const int b = b_cur;
             const int nt = __builtin_amdgcn_readfirstlane(body[b].tiles);
@@ -461,6 +481,7 @@ __global__ __launch_bounds__(64) void ray_leaf_kernel(
             w.qz = pb[3 * i0 + 2];
             w.qx = shear_x(pb[3 * i0], w.qz);
             w.qy = shear_y(pb[3 * i0 + 1], w.qz);
+            if (kSeg) w.qmask = vmask[w.slot];
             break;
         }
         return w;
@@ -475,9 +496,10 @@ __global__ __launch_bounds__(64) void ray_leaf_kernel(
 #pragma unroll
         for (int k = 0; k < 3; ++k) { s[k].x = s[k].y = s[k].z = 0.0f; e[k] = 0.0f; }
         int crossings = 0;
+        uint32_t pa = kSegBias, pb = kSegBias;
         const RayElem* st = stream + (size_t)w.b * T;
         if (w.len >= 0) {
-            ray_run<kVerts>(st, w.off, w.len, s, e, w.qx, w.qy, w.qz, crossings);
+            ray_run<kVerts, kSeg>(st, elem_mask, w.off, w.len, s, e, w.qx, w.qy, w.qz, crossings, w.qmask, pa, pb);
             if (kCount) walked += w.len;
         } else {
             const int qb = w.off / kFallbackChunks, c = w.off % kFallbackChunks;
@@ -485,11 +507,20 @@ __global__ __launch_bounds__(64) void ray_leaf_kernel(
             const RayEntry* list = lists + ((size_t)w.b * qblocks + qb) * num_leaves;
             for (int j = c; j < cnt; j += kFallbackChunks) {
                 const TreeNode nd = nodes[__builtin_amdgcn_readfirstlane(list[j].node)];
-                ray_run<kVerts>(st, nd.ex_off, nd.ex_len, s, e, w.qx, w.qy, w.qz, crossings);
+                ray_run<kVerts, kSeg>(st, elem_mask, nd.ex_off, nd.ex_len, s, e, w.qx, w.qy, w.qz, crossings, w.qmask, pa, pb);
                 if (kCount) walked += nd.ex_len;
             }
         }
         if (w.active && crossings != 0) atomicAdd(&count[((size_t)w.b * qblocks) * kRayQueries + w.slot], crossings);
+        if (kSeg && w.active && (pa != kSegBias || pb != kSegBias)) {             // few lanes
+            int32_t* sc = seg_count + 8 * (((size_t)w.b * qblocks) * kRayQueries + w.slot);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ca = (int)((pa >> (8 * k)) & 255u) - 128, cb = (int)((pb >> (8 * k)) & 255u) - 128;
+                if (ca != 0) atomicAdd(sc + k, ca);
+                if (cb != 0) atomicAdd(sc + 4 + k, cb);
+            }
+        }
     }
     if (kCount && lane == 0) atomicAdd(stats, (unsigned long long)walked);
 }
@@ -775,7 +806,9 @@ __global__ __launch_bounds__(kBlock) void segment_ray_finalize_kernel(
     const float* __restrict__ partial_half,
     const int32_t* __restrict__ seg_of_q, const int32_t* __restrict__ seg_q_off, const int32_t* __restrict__ seg_q_vidx,
     const int32_t* __restrict__ link_off, const int32_t* __restrict__ link,
-    const int32_t* __restrict__ count, const int32_t* __restrict__ list, int V, int K,
+    const int32_t* __restrict__ count, const int32_t* __restrict__ list,
+    const int32_t* __restrict__ leaf_counts,      // [B][slots][8] crossings with the segments' body faces, or nullptr
+    const int32_t* __restrict__ vpos, int slots, int V, int K,
     int Qs_total, int S, int nsplit, float thresh, float* __restrict__ seg_w, uint8_t* __restrict__ seg_ext,
     uint8_t* __restrict__ exterior)
 {
@@ -793,6 +826,9 @@ __global__ __launch_bounds__(kBlock) void segment_ray_finalize_kernel(
     }
     const int qq = seg_q_off[s] + list[(size_t)b * Qs_total + q];   // the vertex's slot in the segment tables
     const int v = seg_q_vidx[qq];
+    if (leaf_counts) {
+        n += leaf_counts[8 * ((size_t)b * slots + vpos[v]) + s];
+    }
     const float* vb = verts + (size_t)b * V * 3;
     const float* cb = caps + (size_t)b * K * 3;
     const float vx = vb[3 * v], vy = vb[3 * v + 1], vz = vb[3 * v + 2];
@@ -838,6 +874,7 @@ struct RayLayout {
     size_t stream, bounds, lists, list_len, zeroed, zeroed_bytes, leaf_cnt, leaf_fill, count, leaf_off, tiles, body, pairs,
         stats, total;
     int T, qblocks, cap, max_tiles, workers, columns;
+    size_t seg_count;        // per-segment crossing counts of the vertices (models with seg_elem_mask), zeroed with `count`
 };
 
 }  // namespace
@@ -884,6 +921,8 @@ static RayLayout full_layout(const tuch_contact_model* m, int B, int Q, bool ver
     l.leaf_cnt = o;  o += align256((size_t)B * L * sizeof(int32_t));
     l.leaf_fill = o; o += align256((size_t)B * L * sizeof(int32_t));
     l.count = o;     o += align256((size_t)B * l.qblocks * kRayQueries * sizeof(int32_t));
+    l.seg_count = o;
+    if (verts && m->seg_elem_mask) o += align256(8 * (size_t)B * l.qblocks * kRayQueries * sizeof(int32_t));
     l.zeroed_bytes = o - l.zeroed;
     l.leaf_off = o;  o += align256((size_t)B * L * sizeof(int32_t));
     l.tiles = o;     o += align256((size_t)B * l.max_tiles * sizeof(RayTile));
@@ -941,16 +980,21 @@ static int launch_ray_counts(const tuch_contact_model* m, const RayLayout& l, co
     hipLaunchKernelGGL(ray_fill_kernel, dim3(l.qblocks, B), dim3(64), 0, s, (const RayEntry*)lists, (const int32_t*)list_len,
                        (const RayBody*)body, (const int32_t*)leaf_off, L, l.qblocks, l.cap, (int32_t*)(ws + l.leaf_fill), pairs);
     const dim3 grid(l.columns, l.workers);
-    if (stats)
-        hipLaunchKernelGGL((ray_leaf_kernel<kVerts, true>), grid, dim3(64), 0, s, queries, (const RayElem*)(ws + l.stream),
-                           (const RayTile*)tiles, (const RayBody*)body, (const int32_t*)pairs, (const RayEntry*)lists,
-                           (const int32_t*)list_len, nodes, L, qperm, counts, Q, l.T, l.qblocks, B, l.cap, l.max_tiles,
-                           (int32_t*)(ws + l.count), stats);
-    else
-        hipLaunchKernelGGL((ray_leaf_kernel<kVerts, false>), grid, dim3(64), 0, s, queries, (const RayElem*)(ws + l.stream),
-                           (const RayTile*)tiles, (const RayBody*)body, (const int32_t*)pairs, (const RayEntry*)lists,
-                           (const int32_t*)list_len, nodes, L, qperm, counts, Q, l.T, l.qblocks, B, l.cap, l.max_tiles,
-                           (int32_t*)(ws + l.count), stats);
+    const bool seg = kVerts && m->seg_elem_mask;
+    const int32_t* emask = (const int32_t*)m->seg_elem_mask;
+    const int32_t* vmask = (const int32_t*)m->seg_vmask;
+    int32_t* seg_count = (int32_t*)(ws + l.seg_count);
+#define TUCH_LAUNCH_RAY_LEAF(COUNT, SEG)                                                                                      \
+    hipLaunchKernelGGL((ray_leaf_kernel<kVerts, COUNT, SEG>), grid, dim3(64), 0, s, queries, (const RayElem*)(ws + l.stream),  \
+                       (const RayTile*)tiles, (const RayBody*)body, (const int32_t*)pairs, (const RayEntry*)lists,            \
+                       (const int32_t*)list_len, nodes, L, qperm, counts, Q, l.T, l.qblocks, B, l.cap, l.max_tiles,           \
+                       (int32_t*)(ws + l.count), stats, emask, vmask, seg_count)
+    if (stats) {
+        if (seg) TUCH_LAUNCH_RAY_LEAF(true, kVerts); else TUCH_LAUNCH_RAY_LEAF(true, false);
+    } else {
+        if (seg) TUCH_LAUNCH_RAY_LEAF(false, kVerts); else TUCH_LAUNCH_RAY_LEAF(false, false);
+    }
+#undef TUCH_LAUNCH_RAY_LEAF
     return TUCH_OK;
 }
 
@@ -981,6 +1025,12 @@ int tuch_ray_exterior_verts(const tuch_contact_model* m, const float* verts, int
     return tuch_check_launch("tuch_ray_exterior_verts");
 }
 
+const int32_t* tuch_ray_segment_counts(const tuch_contact_model* m, int B, const void* workspace)
+{
+    if (!m->seg_elem_mask) return nullptr;
+    return (const int32_t*)((const char*)workspace + full_layout(m, B, m->V, true).seg_count);
+}
+
 int tuch_ray_exterior_points(const tuch_contact_model* m, const float* verts, const float* points, const int32_t* counts,
                              int B, int Q, float thresh, uint8_t* exterior, float* w, void* workspace, hipStream_t s)
 {
@@ -994,14 +1044,21 @@ int tuch_ray_exterior_points(const tuch_contact_model* m, const float* verts, co
 }
 
 // The segment filter (winding.hip: caps, compacted interior vertices per (body, segment) in seg_count / seg_list) by
-// ray crossings.  Scratch of the caller: seg_entries [B,seg_ray_total,9] floats, seg_partial [2][B,nsplit,Qs_total] words.
+// ray crossings.  leaf_counts (tuch_ray_segment_counts of the SAME verts, or nullptr): the crossings with the body faces
+// of the segments are taken from there and only cap faces and boundary edges are walked here.
+// Scratch of the caller: seg_entries [B,seg_ray_total,9] floats, seg_partial (two partial arrays + the work items).
 int tuch_ray_segment_flags(const tuch_contact_model* m, const float* verts, const float* caps, const int32_t* seg_count,
-                           const int32_t* seg_list, int B, int nsplit, float thresh, float* seg_entries, int32_t* seg_partial,
-                           float* seg_w, uint8_t* seg_ext, uint8_t* exterior, hipStream_t s)
+                           const int32_t* seg_list, const int32_t* leaf_counts, int B, int nsplit, float thresh,
+                           float* seg_entries, int32_t* seg_partial, float* seg_w, uint8_t* seg_ext, uint8_t* exterior,
+                           hipStream_t s)
 {
+    const bool assisted = leaf_counts && m->seg_cap_off;
+    const int E = assisted ? m->seg_cap_total : m->seg_ray_total;
+    const int32_t* ent = (const int32_t*)(assisted ? m->seg_cap_ent : m->seg_ray_ent);
+    const int32_t* ent_off = (const int32_t*)(assisted ? m->seg_cap_off : m->seg_ray_off);
     float* partial_half = (float*)(seg_partial + (size_t)B * nsplit * m->seg_q_total);
-    hipLaunchKernelGGL(segment_shear_entries_kernel, dim3(ceil_div(m->seg_ray_total, kBlock), B), dim3(kBlock), 0, s,
-                       verts, caps, (const int32_t*)m->seg_ray_ent, m->V, m->num_caps, m->seg_ray_total, seg_entries);
+    hipLaunchKernelGGL(segment_shear_entries_kernel, dim3(ceil_div(E > 0 ? E : 1, kBlock), B), dim3(kBlock), 0, s,
+                       verts, caps, ent, m->V, m->num_caps, E, seg_entries);
     // work items behind the two partial arrays (B * num_seg_blocks int2 + 1 counter; the caller sizes seg_partial for it)
     int2* items = (int2*)(partial_half + (size_t)B * nsplit * m->seg_q_total);
     int32_t* items_total = (int32_t*)(items + (size_t)B * m->num_seg_blocks);
@@ -1009,12 +1066,13 @@ int tuch_ray_segment_flags(const tuch_contact_model* m, const float* verts, cons
     const long worst = (long)B * m->num_seg_blocks * nsplit;
     hipLaunchKernelGGL(segment_ray_kernel, dim3((unsigned)(worst < 8192 ? worst : 8192)), dim3(64), 0, s, verts,
                        (const float*)seg_entries, (const int2*)items, (const int32_t*)items_total, (const int32_t*)m->seg_q_off,
-                       (const int32_t*)m->seg_q_vidx, (const int32_t*)m->seg_ray_off, seg_count, seg_list, m->V, m->seg_ray_total,
+                       (const int32_t*)m->seg_q_vidx, ent_off, seg_count, seg_list, m->V, E,
                        m->seg_q_total, m->num_segments, nsplit, seg_partial, partial_half);
     hipLaunchKernelGGL(segment_ray_finalize_kernel, dim3(ceil_div(m->seg_q_total, kBlock), B), dim3(kBlock), 0, s, verts, caps,
                        (const int32_t*)seg_partial, (const float*)partial_half, (const int32_t*)m->seg_of_q,
                        (const int32_t*)m->seg_q_off, (const int32_t*)m->seg_q_vidx, (const int32_t*)m->seg_link_off,
-                       (const int32_t*)m->seg_link, seg_count, seg_list, m->V, m->num_caps, m->seg_q_total, m->num_segments,
-                       nsplit, thresh, seg_w, seg_ext, exterior);
+                       (const int32_t*)m->seg_link, seg_count, seg_list, assisted ? leaf_counts : nullptr,
+                       (const int32_t*)m->seg_vpos, 2 * m->tree_qblocks * kRayQueries, m->V,
+                       m->num_caps, m->seg_q_total, m->num_segments, nsplit, thresh, seg_w, seg_ext, exterior);
     return tuch_check_launch("tuch_ray_segment_flags");
 }

@@ -1043,8 +1043,12 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
         // by ray crossings under the same rule as the body test (ray_mode: when only flags are wanted, or always with
         // TUCH_WINDING_RAY=2)
         if (m->seg_link_off && (ray == 2 || (ray == 1 && !seg_w))) {
-            rc = tuch_ray_segment_flags(m, verts, caps, seg_count, seg_list, B, seg_splits(), thresh, seg_tris,
-                                        (int32_t*)seg_partial, seg_w, seg_exterior, exterior, s);
+            // the body's inside test, when it ran by ray crossings just above, has left the crossings of every vertex
+            // with the body faces of its segments
+            const bool body_by_rays = ray == 2 || (ray == 1 && !w);
+            rc = tuch_ray_segment_flags(m, verts, caps, seg_count, seg_list,
+                                        body_by_rays ? tuch_ray_segment_counts(m, B, ws + l.ray) : nullptr, B, seg_splits(),
+                                        thresh, seg_tris, (int32_t*)seg_partial, seg_w, seg_exterior, exterior, s);
             if (rc != TUCH_OK) return rc;
             return tuch_check_launch("tuch_exterior_flags");
         }
