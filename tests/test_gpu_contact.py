@@ -797,6 +797,14 @@ def test_segment_filter_by_ray_crossings_matches_the_solid_angle_sums(tag, monke
     if not jump.any():
         assert torch.equal(ext_r, ext_s) and torch.equal(ext_1, ext_s)
     assert len(np.unique(np.round(segw_s))) >= 2          # vertices inside their own segment do occur
+    # the default model takes the crossings with the segments' body faces from the body's own inside test; a model
+    # built with TUCH_SEG_ASSIST=0 walks every face of the segment in the segment pass: same answers
+    monkeypatch.setenv('TUCH_SEG_ASSIST', '0')
+    plain = make_model(g, None, True, False)
+    monkeypatch.setenv('TUCH_WINDING_RAY', '2')
+    ext_p, _, segw_p, sege_p = plain.exterior_flags(verts, apply_segments=True, return_details=True)
+    assert torch.equal(sege_p, sege_r) and torch.equal(ext_p, ext_r)
+    assert float((segw_p - torch.tensor(segw_r, device=segw_p.device)).abs().max()) < 2e-6
 
 
 def test_ray_crossing_flags_at_rest_pose_and_axis_aligned():

@@ -276,7 +276,8 @@ extern "C" int tuch_contact_model_create(
             if (rc == TUCH_OK) rc = upload(&m->seg_ray_off, eoff.data(), eoff.size());
             if (rc == TUCH_OK) rc = upload(&m->seg_ray_ent, ent.data(), ent.size());
             // leaf-assisted form (model.h)
-            bool assist = rc == TUCH_OK && m->tree_nodes > 0 && tree_exact_host > 0 && num_segments <= 8;
+            const char* ea = getenv("TUCH_SEG_ASSIST");              // 0: keep the segment pass self-contained (A/B, tests)
+            bool assist = rc == TUCH_OK && m->tree_nodes > 0 && tree_exact_host > 0 && num_segments <= 8 && !(ea && atoi(ea) == 0);
             if (assist) {
                 auto key3 = [](int a, int b, int c) {          // rotation with the smallest id first: orientation kept
                     if (b < a && b < c) { const int t2 = a; a = b; b = c; c = t2; }
