@@ -12,8 +12,9 @@ push/pull terms with winding-number inside test and segment filter + region-to-r
 The batch dimension shards across ranks (weak scaling: 64 bodies per GPU; --global-batch G: strong
 scaling, G/N bodies per GPU); the only collective is a 2-float all-reduce of [sum of losses, body
 count] per step (RCCL).  Rank 0 prints ONE JSON line (contract in the task description) including
-  roofline     -- dominant kernel (winding numbers), achieved FLOP/s measured here with HIP events
-  roofline_v2v -- the vertex-distance kernel, physical and reference-layout-equivalent figures
+  roofline     -- dominant kernel of the step (the masked vertex-distance search, v2v_tree_kernel: 260 of ~1150 us of
+                  kernel time), achieved FLOP/s in SURVEY 8(d)'s unit measured here with HIP events
+  roofline_inside_test -- the second kernel group (inside test by ray crossings): executed operations per launch
   cpu_baseline -- the CPU oracle (test infrastructure) timed on this box's host cores, rank 0, N=1
   repeat_ms_per_step -- the same K-step block timed --repeats times (median / min / max)
   shard_sweep  -- the step at 8/16/32/64 bodies on one GPU (the per-GPU shards of a global batch of 64)
@@ -41,21 +42,30 @@ FLOP_PER_V2V_PAIR = 8
 # executed arithmetic of the strip walk per (query, stream element): 3 sub, |.|^2 (5) + sqrt, two dot products
 # (10), numerator (5), denominator (8), small-angle atan (rcp + 8)
 FLOP_PER_STRIP_ELEMENT = 41
-# executed arithmetic of the ray-crossing walk per (query, strip element): 3 sub, 2 edge functions (4 mul + 2 sub), min3,
-# max3, 1 mul -- plain FP32 operations, no FMA (the edge functions must not be contracted), no sqrt / atan
-OPS_PER_RAY_ELEMENT = 12
-PEAK_FP32_VECTOR_TFLOPS = 157.3   # MI355X_MICROARCH.md (packed FP32 FMA rate)
+# executed arithmetic of the ray-crossing walk per (ray, strip element): 3 sub, 2 edge functions (4 mul + 2 sub, never
+# contracted), depth determinant (1 mul + 2 fma = 5), min3 + max3 (2 + 2), min, max, 1 mul for the tie test = 21 FP32
+# operations in 26 VALU instructions (29 with the per-segment counters; SQ_INSTS_VALU / element, profiles/r02_m_pmc_sq.txt)
+OPS_PER_RAY_ELEMENT = 21
+VALU_INSTR_PER_RAY_ELEMENT = 29
+PEAK_FP32_VECTOR_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs x 16 lanes x 2 (FMA) x 2 (packed) x 2.4 GHz
+# what a stream of plain (non-packed) wave64 instructions can issue: 256 x 4 SIMDs x 16 lanes x 2.4 GHz lane-instructions/s
+# (one wave64 VALU instruction occupies its SIMD for 4 cycles: 4.1-4.5 measured, tools/ubench/valu_rate.hip -fno-slp-vectorize)
+PEAK_PLAIN_ISSUE_TLANEOPS = 39.3
 PEAK_HBM_GBS = 8000.0
-# HBM-side bytes per launch of the winding walk at batch 64 and its VALU-busy fraction: PMC passes committed under
-# profiles/ (see profiles/README.md); constants from those files, NOT measured in this run.
+# HBM-side bytes per launch at batch 64 and VALU-busy fractions: PMC passes committed under profiles/ (see
+# profiles/README.md); constants from those files, NOT measured in this run.
 PROFILE = {
-    'traffic_bytes': int((21882.8 + 13807.8) * 1024),
-    'traffic_source': 'ray_strips_kernel: profiles/r02_h_pmc_fetch.txt + r02_h_pmc_write.txt (rocprofv3 --pmc FETCH_SIZE / '
-                      'WRITE_SIZE, separate passes, KB x 1024), batch 64; from profiles/, not measured in this run',
-    'valu_busy': 1.03,
-    'valu_busy_source': 'SQ_ACTIVE_INST_VALU x 4 / (1024 x GRBM_GUI_ACTIVE / 8) from profiles/r02_h_pmc_sq.txt (2.065e8, 6.288e6); the '
-                        'counter charges one quad-cycle per VALU instruction; at the 2.2-2.7 cycles per plain FP32 op measured by '
-                        'tools/ubench/valu_rate.hip the issue slots are ~0.6 used; from profiles/, not measured in this run',
+    'v2v_tree_kernel': {
+        'traffic_bytes': int((29979.4 + 3598.5) * 1024),
+        'valu_busy': 0.86,
+        'source': 'profiles/r02_m_pmc_fetch.txt + r02_m_pmc_write.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, '
+                  'KB x 1024) and r02_m_pmc_sq.txt (SQ_ACTIVE_INST_VALU x 4 / (1024 x GRBM_GUI_ACTIVE / 8) = 1.372e8 x 4 / '
+                  '(1024 x 5.003e6 / 8)), batch 64; from profiles/, not measured in this run'},
+    'ray_leaf_kernel': {
+        'traffic_bytes': int((25335.8 + 14202.6) * 1024),
+        'valu_busy': 0.89,
+        'source': 'profiles/r02_m_pmc_fetch.txt + r02_m_pmc_write.txt and r02_m_pmc_sq.txt (9.361e7 x 4 / (1024 x 3.304e6 / 8)), '
+                  'batch 64; from profiles/, not measured in this run'},
 }
 _BODY = {}
 
@@ -327,57 +337,76 @@ def time_kernel(fn, iters):
 
 
 def rooflines(p, batch):
-    """Dominant-kernel figures measured live (HIP events on the launch stream).
+    """The two kernel groups that dominate the step, measured live (HIP events on the launch stream).
 
-    The inside test (exterior flags) is the dominant part of the step.  Since round 2 it counts signed ray crossings
-    (csrc/ray_winding.hip) instead of summing solid angles: per (query, strip element) 12 plain FP32 operations (3
-    subtractions, two edge functions = 4 mul + 2 sub, min3, max3, one mul) -- none of them an FMA, no sqrt, no atan --
-    against 41 for a step of the solid-angle walk, and 30 % fewer steps.  `roofline` prices those executed operations
-    against the FP32 vector peak (which counts FMAs: a stream of plain add/mul can reach half of it at most)."""
+    roofline: the masked vertex-to-vertex search (v2v_tree_kernel + its row / box / seed / finalize helpers), since the
+    inside test went to ray crossings the largest kernel of the step.  `achieved` is SURVEY.md 8(d)'s algorithmic work
+    (8 FLOP per ordered vertex pair, V^2 pairs per body) over the launch time; the kernel prunes ~60 % of the rows by
+    box distance, so the executed arithmetic is lower -- VALU-busy from the committed PMC pass says how full the
+    vector units are.
+    roofline_inside_test: exterior flags by signed ray crossings (csrc/ray_winding.hip), priced on EXECUTED operations:
+    21 plain FP32 operations per (ray, strip element), none of them packed, two of them FMAs."""
     from tuch_amd.smplify.losses import contact_model_for
     body = p['body']
     v, f = body.num_verts, body.num_faces
     model = contact_model_for(p['geomask'], p['face_tensor'], p['segments'], p['cdict'])
     with torch.no_grad():
         verts = p['smpl'](global_orient=p['global_orient'], body_pose=p['body_pose'], betas=p['betas']).vertices
-    # the launch below = sheared strips + leaf slabs + near-leaf lists + ray_strips_kernel + fan finalize
+    # ---- the search
+    t_v = time_kernel(lambda: model.v2v_min(verts), 10)
+    alg_flop = FLOP_PER_V2V_PAIR * batch * v * v
+    ach_v = alg_flop / t_v / 1e12
+    ref_layout_bytes = batch * (12 * v + v * v + 8 * v)           # SURVEY.md 8(d) layout (i)
+    compact_bytes = batch * (12 * v + 8 * v) + v * v // 8         # layout (ii): bit-packed mask read once
+    prof_v = PROFILE['v2v_tree_kernel']
+    roof = {'kernel': 'v2v_tree_kernel (+ v2v_rows, tree_inner_bounds, v2v_seed, v2v_tree_finalize)', 'bound': 'valu',
+            'achieved': round(ach_v, 2), 'peak': PEAK_FP32_VECTOR_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(ach_v / PEAK_FP32_VECTOR_TFLOPS, 4),
+            'traffic': prof_v['traffic_bytes'] if batch == BATCH_PER_GPU else None,
+            'valu_busy': prof_v['valu_busy'], 'profile_source': prof_v['source'],
+            'launch_ms': round(t_v * 1e3, 4),
+            'algorithmic_flop_per_launch': alg_flop, 'flop_per_pair': FLOP_PER_V2V_PAIR,
+            'algorithmic_bytes_per_launch': compact_bytes,
+            'compact_layout_GBs': round(compact_bytes / t_v / 1e9, 1),
+            'reference_layout_equivalent_GBs': round(ref_layout_bytes / t_v / 1e9, 1),
+            'reference_layout_equivalent_frac_of_hbm': round(ref_layout_bytes / t_v / 1e9 / PEAK_HBM_GBS, 3),
+            'note': 'achieved = 8 FLOP x V^2 x B / launch time (SURVEY 8d); ~60 % of the rows are pruned by box distance and '
+                    'never evaluated, the mask is bit-packed and L2-resident: the equivalent-bandwidth figures are NOT '
+                    'physical bandwidth.  The vector units are ~0.86 busy; the CU scalar unit (1.15e8 scalar instructions '
+                    'per launch, one per cycle per CU = 0.19 ms) is the second limit'}
+    # ---- the inside test: sheared strips + leaf slabs + near-leaf lists + tiles + ray_leaf_kernel + fan finalize
     t_w = time_kernel(lambda: model.exterior_flags(verts, apply_segments=False), 10)
     work = model.ray_work(verts)
-    steps = work['elements']                                     # wavefront element steps, 64 queries each
+    steps = work['elements']                                     # wavefront element steps, 64 rays each
     ops = OPS_PER_RAY_ELEMENT * work['queries_per_step'] * steps
     ach = ops / t_w / 1e12
+    lane_instr = VALU_INSTR_PER_RAY_ELEMENT * work['queries_per_step'] * steps / t_w / 1e12
     ref_flops = FLOP_PER_WINDING_PAIR * batch * v * f
     tree = model.winding_tree_work(verts)
     tree_steps = tree['leaf_elements'] + tree['cap_elements']
-    roof = {'kernel': 'ray_strips_kernel (+ ray_stream, ray_leaf_bounds, ray_near, ray_finalize_verts)', 'bound': 'valu',
-            'achieved': round(ach, 2), 'peak': PEAK_FP32_VECTOR_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(ach / PEAK_FP32_VECTOR_TFLOPS, 4),
-            'frac_of_non_fma_peak': round(ach / (PEAK_FP32_VECTOR_TFLOPS / 2), 4),
-            'traffic': PROFILE['traffic_bytes'] if batch == BATCH_PER_GPU else None,
-            'traffic_source': PROFILE['traffic_source'],
-            'valu_busy': PROFILE['valu_busy'], 'valu_busy_source': PROFILE['valu_busy_source'],
-            'launch_ms': round(t_w * 1e3, 4),
-            'executed_op_per_launch': ops, 'op_per_query_element': OPS_PER_RAY_ELEMENT,
-            'element_steps_per_launch': steps,
-            # the same vertices through last round's kernel (exact solid angles over the cluster tree), for scale
-            'solid_angle_tree_walk_steps': tree_steps, 'solid_angle_tree_walk_flop': FLOP_PER_STRIP_ELEMENT * 64 * tree_steps,
-            # the reference's formulation (every query x every face, SURVEY.md 8d) priced at this launch time: far
-            # above the vector peak because crossings are counted, not solid angles summed
-            'reference_formulation_flop_per_launch': ref_flops,
-            'reference_formulation_equivalent_TFLOPs': round(ref_flops / t_w / 1e12, 1),
-            'algorithmic_bytes_per_launch': batch * (v * 12 + v) + f * 12}
-    t_v = time_kernel(lambda: model.v2v_min(verts), 10)
-    ref_layout_bytes = batch * (12 * v + v * v + 8 * v)           # SURVEY.md §8(d) layout (i)
-    compact_bytes = batch * (12 * v + 8 * v) + v * v // 8         # layout (ii): bit-packed mask read once
-    v2v = {'kernel': 'v2v_tree_kernel (+ rows, boxes, seed, finalize)', 'bound': 'valu', 'launch_ms': round(t_v * 1e3, 4),
-           'all_pairs_equivalent_TFLOPs': round(FLOP_PER_V2V_PAIR * batch * v * v / t_v / 1e12, 2),
-           'unit': 'TFLOP/s', 'peak': PEAK_FP32_VECTOR_TFLOPS,
-           'compact_layout_GBs': round(compact_bytes / t_v / 1e9, 1),
-           'reference_layout_equivalent_GBs': round(ref_layout_bytes / t_v / 1e9, 1),
-           'reference_layout_equivalent_frac_of_hbm': round(ref_layout_bytes / t_v / 1e9 / PEAK_HBM_GBS, 3),
-           'note': 'mask is bit-packed and L2-resident and ~60 % of the rows are pruned by box distance: the '
-                   'equivalent figures are NOT physical bandwidth or executed arithmetic'}
-    return roof, v2v, verts, model
+    prof_r = PROFILE['ray_leaf_kernel']
+    inside = {'kernel': 'ray_leaf_kernel (+ ray_stream, ray_leaf_bounds, ray_near, ray_tiles, ray_fill, ray_finalize_verts)',
+              'bound': 'valu', 'achieved': round(ach, 2), 'peak': PEAK_FP32_VECTOR_TFLOPS, 'unit': 'TFLOP/s',
+              'frac': round(ach / PEAK_FP32_VECTOR_TFLOPS, 4),
+              'plain_issue_T_lane_instr_per_s': round(lane_instr, 2), 'plain_issue_peak': PEAK_PLAIN_ISSUE_TLANEOPS,
+              'frac_of_plain_issue_peak': round(lane_instr / PEAK_PLAIN_ISSUE_TLANEOPS, 4),
+              'traffic': prof_r['traffic_bytes'] if batch == BATCH_PER_GPU else None,
+              'valu_busy': prof_r['valu_busy'], 'profile_source': prof_r['source'],
+              'launch_ms': round(t_w * 1e3, 4),
+              'executed_op_per_launch': ops, 'op_per_ray_element': OPS_PER_RAY_ELEMENT,
+              'element_steps_per_launch': steps, 'wavefront_tiles': work['wavefronts'],
+              'rays_inside_leaf_slabs_when_block_major': round(work['lanes_inside_leaf_slabs'], 3),
+              # the same vertices through last round's kernel (exact solid angles over the cluster tree), for scale
+              'solid_angle_tree_walk_steps': tree_steps, 'solid_angle_tree_walk_flop': FLOP_PER_STRIP_ELEMENT * 64 * tree_steps,
+              # the reference's formulation (every query x every face, SURVEY.md 8d) priced at this launch time: far
+              # above the vector peak because crossings are counted, not solid angles summed
+              'reference_formulation_flop_per_launch': ref_flops,
+              'reference_formulation_equivalent_TFLOPs': round(ref_flops / t_w / 1e12, 1),
+              'algorithmic_bytes_per_launch': batch * (v * 12 + v) + f * 12,
+              'note': 'the whole launch group is timed; ray_leaf_kernel alone is ~0.6 of it and runs at ~0.8 of the plain '
+                      'issue peak (profiles/r02_m_*): packed FP32 would double that peak but the edge functions do not '
+                      'pair up without register moves'}
+    return roof, inside, verts, model
 
 
 def contact_loss_eval(p, batch, verts, model):
@@ -637,8 +666,8 @@ def main():
             'scaling_note': 'no multi-GPU node was available to the builder: N>1 values exist only when the driver '
                             'runs this script on one' if world == 1 else None,
         }
-        roof, v2v, verts, model = rooflines(p, batch)
-        line['roofline'], line['roofline_v2v'] = roof, v2v
+        roof, inside, verts, model = rooflines(p, batch)
+        line['roofline'], line['roofline_inside_test'] = roof, inside
         if world == 1 and not args.no_extras:
             line['contact_loss_eval'] = contact_loss_eval(p, batch, verts, model)
             line['shard_sweep'] = shard_sweep(device, 1002)
