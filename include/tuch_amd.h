@@ -120,6 +120,13 @@ int tuch_smplify_objective(const float* small_terms, const float* contact_terms,
 int tuch_smplify_objective_bwd(const float* grad_out, int B, int P, float contact_scale, float r2r_scale,
                                float* grad_small, float* grad_contact, float* grad_r2r, void* stream);
 
+/* Backward of the tail of the stage-2 objective (small terms + contact sums + region minima -> scalar) in one launch:
+ * grad_contact [B,2] = contact_scale * g (0 for bodies with valid == 0), grad_r2r [B,P] = r2r_scale * g, and the unit
+ * gradients left by tuch_smplify_small_terms (gj [B,NJ,3], gc [B,3], gp [B,69] or NULL) scaled by g = grad_out[0]. */
+int tuch_smplify_tail_bwd(const float* grad_out, const uint8_t* valid, const float* gj, const float* gc, const float* gp,
+                          int B, int NJ, int P, float contact_scale, float r2r_scale, float* grad_contact, float* grad_r2r,
+                          float* gj_out, float* gc_out, float* gp_out, void* stream);
+
 /* ---- per-model constants -------------------------------------------------------------
  * Host tables in, device copies kept by the handle.  Segments follow
  * tuch/utils/segmentation.py:29-99: seg_q = segment_vidx lists; seg_faces = faces of the

@@ -43,6 +43,7 @@ _SIGNATURES = {
     'tuch_smplify_objective': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p]),
     'tuch_smplify_objective_bwd': (c_int, [c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p,
                                            c_void_p]),
+    'tuch_smplify_tail_bwd': (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_float, c_float] + [c_void_p] * 6),
     'tuch_contact_model_create': (c_int, [POINTER(c_void_p), c_int, c_int, c_void_p, c_void_p,
                                           c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_int, c_void_p, c_void_p,

@@ -174,7 +174,41 @@ __global__ __launch_bounds__(256) void objective_bwd_kernel(
     if (i < 2 * B) { g_small[i] = g; g_terms[i] = contact_scale * g; }
     if (g_r2r && i < B * P) g_r2r[i] = r2r_scale * g;
 }
+
+// Backward of the whole tail of the stage-2 objective in one launch: the upstream scalar times the objective's constants
+// -> weights of the contact sums (zero for bodies without contact terms) and of the region minima, and the unit gradients
+// the forward of small_terms_kernel left (joints, camera, pose) scaled by it.
+__global__ __launch_bounds__(256) void tail_bwd_kernel(
+    const float* __restrict__ gout, const uint8_t* __restrict__ valid, const float* __restrict__ gj,
+    const float* __restrict__ gc, const float* __restrict__ gp, int B, int NJ, int P, float contact_scale,
+    float r2r_scale, float* __restrict__ g_terms, float* __restrict__ g_r2r, float* __restrict__ gj_out,
+    float* __restrict__ gc_out, float* __restrict__ gp_out)
+{
+    const float g = gout[0];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 2 * B) g_terms[i] = (!valid || valid[i >> 1]) ? contact_scale * g : 0.0f;
+    if (g_r2r && i < B * P) g_r2r[i] = r2r_scale * g;
+    if (i < B * NJ * 3) gj_out[i] = g * gj[i];
+    if (i < B * 3) gc_out[i] = g * gc[i];
+    if (gp && i < B * 69) gp_out[i] = g * gp[i];
+}
 }  // namespace
+
+extern "C" int tuch_smplify_tail_bwd(const float* grad_out, const uint8_t* valid, const float* gj, const float* gc,
+                                     const float* gp, int B, int NJ, int P, float contact_scale, float r2r_scale,
+                                     float* grad_contact, float* grad_r2r, float* gj_out, float* gc_out, float* gp_out,
+                                     void* stream)
+{
+    TUCH_REQUIRE(grad_out && gj && gc && grad_contact && gj_out && gc_out && B > 0 && NJ > 0 && P >= 0 && (!gp || gp_out),
+                 "tuch_smplify_tail_bwd: bad arguments");
+    int n = B * NJ * 3;
+    if (B * 69 > n) n = B * 69;
+    if (B * P > n) n = B * P;
+    hipLaunchKernelGGL(tail_bwd_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, grad_out, valid, gj, gc,
+                       gp, B, NJ, P, contact_scale, r2r_scale, grad_contact, (P > 0 ? grad_r2r : (float*)nullptr), gj_out,
+                       gc_out, gp_out);
+    return tuch_check_launch("tuch_smplify_tail_bwd");
+}
 
 extern "C" int tuch_smplify_objective(const float* small_terms, const float* contact_terms, const float* r2r,
                                       int B, int P, float contact_scale, float r2r_scale, float* out,

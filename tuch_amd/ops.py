@@ -301,6 +301,81 @@ def smplify_objective(small, terms, r2r, contact_scale, r2r_scale):
     return _Objective.apply(small, terms, r2r, contact_scale, r2r_scale)
 
 
+class _Stage2Tail(torch.autograd.Function):
+    """Everything of the stage-2 objective behind the body model as ONE autograd node (tuch/smplify/losses.py:56-123):
+    inside test + nearest admissible vertex (no gradient), contact sums, region minima, reprojection + prior, the
+    weighted total.  The same kernels as the separate nodes (_SmallTerms, _ContactTerms, _RegionPairMin, _Objective);
+    what goes away is the torch glue between them -- in the backward pass ~10 small launches per step (scalings by the
+    upstream gradient, dtype / layout copies, a zero fill and an add per gradient path into the vertices).  Backward:
+    one kernel turns the upstream scalar into the weights of every term, then the contact and region kernels
+    accumulate into one vertex gradient."""
+
+    @staticmethod
+    def forward(ctx, verts, joints, camera_t, body_pose, model, valid, select, const):
+        v, j = _f32(verts), _f32(joints)
+        cam_t, pose = _f32(camera_t), _f32(body_pose)
+        b, nj, _ = j.shape
+        L = _C.lib()
+        cam_c, j2d, conf = _f32(const['camera_center']), _f32(const['joints_2d']), _f32(const['joints_conf'])
+        means, precisions, logw = const['means'], const['precisions'], const['log_weights']
+        small = torch.empty(b, 2, dtype=torch.float32, device=v.device)
+        gj = torch.empty_like(j)
+        gc = torch.empty(b, 3, dtype=torch.float32, device=v.device)
+        gp = torch.empty(b, 69, dtype=torch.float32, device=v.device)
+        p = model.num_pairs if select is not None else 0
+        r2r = torch.empty(b, p, dtype=torch.float32, device=v.device) if p else None
+        ij = torch.empty(b, p, 2, dtype=torch.int32, device=v.device) if p else None
+
+        def beside_the_walk():          # on the second stream (ContactModel.exterior_and_partner)
+            if p:
+                _C.check(L.tuch_region_pair_min(model._handle, _C.ptr(v), b, _C.ptr(select), 1, _C.ptr(r2r), _C.ptr(ij),
+                                                _C.stream()))
+            _C.check(L.tuch_smplify_small_terms(
+                _C.ptr(j), _C.ptr(cam_t), _C.ptr(cam_c), _C.ptr(j2d), _C.ptr(conf), _C.ptr(pose), _C.ptr(means),
+                _C.ptr(precisions), _C.ptr(logw), b, nj, means.shape[0], float(const['focal']), float(const['sigma']),
+                float(const['prior_scale']), _C.ptr(small), _C.ptr(gj), _C.ptr(gc), _C.ptr(gp), _C.stream()))
+            return (r2r, ij, small, gj, gc, gp)
+        exterior, _, partner, _extra = model.exterior_and_partner(v, apply_segments=const['apply_segments'],
+                                                                  also=beside_the_walk)
+        terms = torch.empty(b, 2, dtype=torch.float32, device=v.device)
+        _C.check(L.tuch_contact_terms_fwd(_C.ptr(v), _C.ptr(partner), _C.ptr(exterior), _C.ptr(valid), b, v.shape[1],
+                                          MODE_SMPLIFY, float(const['euclthres']), _C.ptr(terms), _C.stream()))
+        out = torch.empty(1, dtype=torch.float32, device=v.device)
+        _C.check(L.tuch_smplify_objective(_C.ptr(small), _C.ptr(terms), _C.ptr(r2r), b, p, float(const['contact_scale']),
+                                          float(const['r2r_scale']), _C.ptr(out), _C.stream()))
+        ctx.save_for_backward(v, partner, exterior, valid, ij, gj, gc, gp)
+        ctx.model, ctx.const, ctx.dims = model, const, (b, nj, p)
+        ctx.in_dtypes = (verts.dtype, joints.dtype, camera_t.dtype, body_pose.dtype)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        v, partner, exterior, valid, ij, gj, gc, gp = ctx.saved_tensors
+        b, nj, p = ctx.dims
+        const, L = ctx.const, _C.lib()
+        g = g.reshape(1).to(torch.float32).contiguous()
+        gt = torch.empty(b, 2, dtype=torch.float32, device=v.device)
+        gr = torch.empty(b, p, dtype=torch.float32, device=v.device) if p else None
+        gj_o, gc_o, gp_o = torch.empty_like(gj), torch.empty_like(gc), torch.empty_like(gp)
+        _C.check(L.tuch_smplify_tail_bwd(_C.ptr(g), _C.ptr(valid), _C.ptr(gj), _C.ptr(gc), _C.ptr(gp), b, nj, p,
+                                         float(const['contact_scale']), float(const['r2r_scale']), _C.ptr(gt), _C.ptr(gr),
+                                         _C.ptr(gj_o), _C.ptr(gc_o), _C.ptr(gp_o), _C.stream()))
+        gv = torch.zeros_like(v)
+        _C.check(L.tuch_contact_terms_bwd(_C.ptr(v), _C.ptr(partner), _C.ptr(exterior), _C.ptr(gt), b, v.shape[1],
+                                          MODE_SMPLIFY, float(const['euclthres']), _C.ptr(gv), _C.stream()))
+        if p:
+            _C.check(L.tuch_region_pair_min_bwd(ctx.model._handle, _C.ptr(v), b, _C.ptr(ij), _C.ptr(gr), _C.ptr(gv),
+                                                _C.stream()))
+        dv, dj, dc, dp = ctx.in_dtypes
+        return gv.to(dv), gj_o.to(dj), gc_o.to(dc), gp_o.to(dp), None, None, None, None
+
+
+def smplify_stage2_tail(verts, joints, camera_t, body_pose, model, valid_u8, select_u8, **const):
+    """Scalar stage-2 objective behind the body model (see _Stage2Tail); const: camera_center, joints_2d, joints_conf,
+    means, precisions, log_weights, focal, sigma, prior_scale, euclthres, contact_scale, r2r_scale, apply_segments."""
+    return _Stage2Tail.apply(verts, joints, camera_t, body_pose, model, valid_u8, select_u8, const)
+
+
 _DERIVED = {}
 
 

@@ -5,6 +5,8 @@ priors are [B,49]-sized torch ops (K8).
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, Optional
 
 import numpy as np
@@ -103,6 +105,16 @@ def stage2_objective(model, valid, select, body_pose, betas, model_joints, euclt
              and not torch.is_tensor(focal_length) and body_pose.shape[1] == 69
              and pose_prior.means.dtype == torch.float32 and pose_prior.means.is_cuda
              and model_joints.dtype == torch.float32 and body_pose.dtype == torch.float32)
+
+    if fused and camera_t.shape == (body_pose.shape[0], 3) and os.environ.get('TUCH_FUSED_TAIL', '1') != '0':
+        # one autograd node for everything behind the body model (ops._Stage2Tail): the same kernels, less glue
+        return ops.smplify_stage2_tail(
+            verts, model_joints, camera_t, body_pose, model, valid,
+            select.to(torch.uint8).contiguous() if select is not None else None,
+            camera_center=camera_center, joints_2d=joints_2d, joints_conf=joints_conf, means=pose_prior.means,
+            precisions=pose_prior.precisions, log_weights=pose_prior.log_nll_weights, focal=focal_length, sigma=sigma,
+            prior_scale=pose_prior_weight ** 2, euclthres=euclthres, contact_scale=10.0, r2r_scale=contact_loss_weight,
+            apply_segments=apply_segments)
 
     def beside_the_walk():
         """Everything that does not need the inside test: region pairs (losses.py:107-117) and, fused into one
