@@ -119,35 +119,47 @@ class RegressorLoss(nn.Module):
     def _zero(self):
         return torch.zeros(1, dtype=torch.float32, device=self.device)
 
+    # The SPIN terms below select samples with boolean masks (loss.py:172-238: ``x[mask]``).  Boolean indexing costs a
+    # device -> host synchronisation per use (nonzero): 15 per training step.  They are written as masked reductions
+    # instead -- the same means (sum over the selected samples / their element count; 0 where the reference returns 0
+    # for an empty selection, NaN where it takes the mean of nothing), no host round trip.
+    @staticmethod
+    def _selected_mean(per_sample, mask, elems_per_sample, empty_is_zero):
+        """mean over the elements of the selected samples; per_sample [B] = sum over a sample's elements."""
+        m = mask.reshape(-1).bool()
+        n = m.sum().to(per_sample.dtype)
+        total = torch.where(m, per_sample, torch.zeros_like(per_sample)).sum()
+        mean = total / (n * elems_per_sample)
+        return torch.where(n > 0, mean, torch.zeros_like(mean)) if empty_is_zero else mean
+
     def keypoint_loss(self, pred_keypoints_2d, gt_keypoints_2d, openpose_weight, gt_weight, valid_fit=None):
         """Confidence-weighted 2D reprojection MSE (loss.py:172-183)."""
         conf = gt_keypoints_2d[:, :, -1].unsqueeze(-1).clone()
         conf[:, :25] *= openpose_weight
         conf[:, 25:] *= gt_weight
         loss = (conf * self.criterion_keypoints(pred_keypoints_2d, gt_keypoints_2d[:, :, :-1])).mean(axis=(1, 2))
-        return loss[valid_fit].mean()
+        return self._selected_mean(loss, valid_fit, 1, empty_is_zero=False)
 
     def keypoint_3d_loss(self, pred_keypoints_3d, gt_keypoints_3d, has_pose_3d):
         """Pelvis-centred 3D keypoint MSE on the 24 ground-truth joints (loss.py:185-204)."""
-        pred = pred_keypoints_3d[:, 25:, :][has_pose_3d == 1]
-        conf = gt_keypoints_3d[:, :, -1].unsqueeze(-1).clone()[has_pose_3d == 1]
-        gt = gt_keypoints_3d[:, :, :-1].clone()[has_pose_3d == 1]
-        if len(gt) == 0:
-            return self._zero()
+        pred = pred_keypoints_3d[:, 25:, :]
+        conf = gt_keypoints_3d[:, :, -1].unsqueeze(-1)
+        gt = gt_keypoints_3d[:, :, :-1]
         gt = gt - ((gt[:, 2, :] + gt[:, 3, :]) / 2)[:, None, :]
         pred = pred - ((pred[:, 2, :] + pred[:, 3, :]) / 2)[:, None, :]
-        return (conf * self.criterion_keypoints(pred, gt)).mean()
+        per = (conf * self.criterion_keypoints(pred, gt)).sum(dim=(1, 2))
+        return self._selected_mean(per, has_pose_3d == 1, gt.shape[1] * gt.shape[2], empty_is_zero=True)
 
     def shape_loss(self, pred_vertices, gt_vertices, has_smpl):
         """Per-vertex L1 where SMPL fits exist (loss.py:206-215)."""
-        pv, gv = pred_vertices[has_smpl == 1], gt_vertices[has_smpl == 1]
-        return self.criterion_shape(pv, gv) if len(gv) > 0 else self._zero()
+        per = (pred_vertices - gt_vertices).abs().sum(dim=(1, 2))
+        return self._selected_mean(per, has_smpl == 1, pred_vertices.shape[1] * pred_vertices.shape[2], empty_is_zero=True)
 
     def smpl_losses(self, pred_rotmat, pred_betas, gt_pose, gt_betas, has_smpl_pose, has_smpl_shape):
         """MSE on rotation matrices and betas (loss.py:217-238)."""
-        pr = pred_rotmat[has_smpl_pose == 1]
-        gr = batch_rodrigues(gt_pose.view(-1, 3)).view(-1, 24, 3, 3)[has_smpl_pose == 1]
-        loss_pose = self.criterion_regr(pr, gr) if len(pr) > 0 else self._zero()
-        pb, gb = pred_betas[has_smpl_shape == 1], gt_betas[has_smpl_shape == 1]
-        loss_betas = self.criterion_regr(pb, gb) if len(pb) > 0 else self._zero()
+        gr = batch_rodrigues(gt_pose.view(-1, 3)).view(-1, 24, 3, 3)
+        per_pose = ((pred_rotmat - gr) ** 2).sum(dim=(1, 2, 3))
+        loss_pose = self._selected_mean(per_pose, has_smpl_pose == 1, 24 * 9, empty_is_zero=True)
+        per_betas = ((pred_betas - gt_betas) ** 2).sum(dim=1)
+        loss_betas = self._selected_mean(per_betas, has_smpl_shape == 1, pred_betas.shape[1], empty_is_zero=True)
         return loss_pose, loss_betas
