@@ -228,10 +228,12 @@ __global__ __launch_bounds__(1024) void hd_terms_kernel(
     }
 }
 
-// gradient on the points: own side written, partner side scattered with atomics (G pre-zeroed)
+// gradient on the points: the point's own side is a plain store (Gown), the partner's side is scattered with atomics
+// (G pre-zeroed); the vertex gather adds the two
 __global__ __launch_bounds__(256) void hd_grad_points_kernel(
     const float* __restrict__ pts, const int32_t* __restrict__ partner, const uint8_t* __restrict__ ext,
-    const int32_t* __restrict__ counts, const float* __restrict__ gscale, int N, float* __restrict__ G)
+    const int32_t* __restrict__ counts, const float* __restrict__ gscale, int N, float* __restrict__ G,
+    float* __restrict__ Gown)
 {
     const int b = blockIdx.y;
     const int k = blockIdx.x * 256 + threadIdx.x;
@@ -239,24 +241,29 @@ __global__ __launch_bounds__(256) void hd_grad_points_kernel(
     const size_t o = (size_t)b * N + k;
     const bool e = ext[o] != 0;
     const float g = gscale[2 * b + (e ? 1 : 0)];
-    if (g == 0.0f) return;
-    const float* pb = pts + (size_t)b * N * 3;
-    const int p = partner[o];
-    const float dx = pb[3 * k] - pb[3 * p], dy = pb[3 * k + 1] - pb[3 * p + 1], dz = pb[3 * k + 2] - pb[3 * p + 2];
-    const float d = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
-    if (!(d > 0.0f)) return;                      // torch.norm's backward at 0 is 0
-    const Term t = contact_term(d, e);
-    const float c = g * t.dd / d;
-    float* gk = G + 3 * o;
-    float* gp = G + 3 * ((size_t)b * N + p);
-    atomicAdd(gk, c * dx); atomicAdd(gk + 1, c * dy); atomicAdd(gk + 2, c * dz);
-    atomicAdd(gp, -c * dx); atomicAdd(gp + 1, -c * dy); atomicAdd(gp + 2, -c * dz);
+    float ox = 0.0f, oy = 0.0f, oz = 0.0f;
+    if (g != 0.0f) {
+        const float* pb = pts + (size_t)b * N * 3;
+        const int p = partner[o];
+        const float dx = pb[3 * k] - pb[3 * p], dy = pb[3 * k + 1] - pb[3 * p + 1], dz = pb[3 * k + 2] - pb[3 * p + 2];
+        const float d = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
+        if (d > 0.0f) {                               // torch.norm's backward at 0 is 0
+            const Term t = contact_term(d, e);
+            const float c = g * t.dd / d;
+            ox = c * dx; oy = c * dy; oz = c * dz;
+            float* gp = G + 3 * ((size_t)b * N + p);
+            atomicAdd(gp, -ox); atomicAdd(gp + 1, -oy); atomicAdd(gp + 2, -oz);
+        }
+    }
+    float* gk = Gown + 3 * o;
+    gk[0] = ox; gk[1] = oy; gk[2] = oz;
 }
 
 // adjoint of the regressor rows: a gather per vertex over the points it supports
 __global__ __launch_bounds__(256) void hd_grad_verts_kernel(
-    const float* __restrict__ G, const int32_t* __restrict__ slot, const int32_t* __restrict__ v_off,
-    const int32_t* __restrict__ v_ent, const float* __restrict__ w, int V, int N, float* __restrict__ grad_verts)
+    const float* __restrict__ G, const float* __restrict__ Gown, const int32_t* __restrict__ slot,
+    const int32_t* __restrict__ v_off, const int32_t* __restrict__ v_ent, const float* __restrict__ w, int V, int N,
+    float* __restrict__ grad_verts)
 {
     const int b = blockIdx.y;
     const int v = blockIdx.x * 256 + threadIdx.x;
@@ -264,12 +271,14 @@ __global__ __launch_bounds__(256) void hd_grad_verts_kernel(
     const int e0 = real ? v_off[v] : 0, e1 = real ? v_off[v + 1] : 0;
     const int32_t* sb = slot + (size_t)b * N;
     const float* gb = G + 3 * (size_t)b * N;
+    const float* go = Gown + 3 * (size_t)b * N;
     float x = 0.f, y = 0.f, z = 0.f;
     auto add = [&](int ent, int s) {                 // entry = point * 4 + corner; s = the point's slot in this body
         if (s < 0) return;
         const float wc = w[3 * (size_t)(ent >> 2) + (ent & 3)];
         const float* g = gb + 3 * (size_t)s;
-        x = __builtin_fmaf(wc, g[0], x); y = __builtin_fmaf(wc, g[1], y); z = __builtin_fmaf(wc, g[2], z);
+        const float* o = go + 3 * (size_t)s;
+        x = __builtin_fmaf(wc, g[0] + o[0], x); y = __builtin_fmaf(wc, g[1] + o[1], y); z = __builtin_fmaf(wc, g[2] + o[2], z);
     };
     constexpr int kLong = 64;
     if (e1 - e0 <= kLong) {
@@ -299,7 +308,8 @@ __global__ __launch_bounds__(256) void hd_grad_verts_kernel(
             if (s < 0) continue;
             const float wc = w[3 * (size_t)(ent >> 2) + (ent & 3)];
             const float* g = gb + 3 * (size_t)s;
-            px = __builtin_fmaf(wc, g[0], px); py = __builtin_fmaf(wc, g[1], py); pz = __builtin_fmaf(wc, g[2], pz);
+            const float* o = go + 3 * (size_t)s;
+            px = __builtin_fmaf(wc, g[0] + o[0], px); py = __builtin_fmaf(wc, g[1] + o[1], py); pz = __builtin_fmaf(wc, g[2] + o[2], pz);
         }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) { px += __shfl_xor(px, m); py += __shfl_xor(py, m); pz += __shfl_xor(pz, m); }
@@ -447,7 +457,7 @@ extern "C" size_t tuch_hd_contact_workspace_bytes(const tuch_hd_model* hm, int B
 {
     if (!hm || B <= 0) return 0;
     const size_t f = work_layout(hm, B).total;
-    const size_t g = align256((size_t)B * hm->N * 3 * sizeof(float));       // adjoint: point gradients
+    const size_t g = 2 * align256((size_t)B * hm->N * 3 * sizeof(float));   // adjoint: point gradients, own + partner side
     return f > g ? f : g;
 }
 
@@ -520,21 +530,22 @@ extern "C" int tuch_hd_contact_bwd(const tuch_hd_model* hm, const void* saved, c
     const int N = hm->N, V = hm->V;
     const Saved sl = saved_layout(B, N);
     const size_t gbytes = (size_t)B * N * 3 * sizeof(float);
-    if (workspace_bytes < gbytes) {
-        tuch_set_error("tuch_hd_contact_bwd: workspace %zu < %zu bytes", workspace_bytes, gbytes);
+    if (workspace_bytes < 2 * align256(gbytes)) {
+        tuch_set_error("tuch_hd_contact_bwd: workspace %zu < %zu bytes", workspace_bytes, 2 * align256(gbytes));
         return TUCH_ERR_WORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
     const char* sv = (const char*)saved;
     float* G = (float*)workspace;
+    float* Gown = (float*)((char*)workspace + align256(gbytes));
     if (hipMemsetAsync(G, 0, gbytes, s) != hipSuccess) {
         tuch_set_error("tuch_hd_contact_bwd: hipMemsetAsync failed");
         return TUCH_ERR_HIP;
     }
     hipLaunchKernelGGL(hd_grad_points_kernel, dim3(ceil_div(N, 256), B), dim3(256), 0, s, (const float*)(sv + sl.pts),
                        (const int32_t*)(sv + sl.partner), (const uint8_t*)(sv + sl.ext), (const int32_t*)(sv + sl.counts),
-                       grad_terms, N, G);
-    hipLaunchKernelGGL(hd_grad_verts_kernel, dim3(ceil_div(V, 256), B), dim3(256), 0, s, (const float*)G,
+                       grad_terms, N, G, Gown);
+    hipLaunchKernelGGL(hd_grad_verts_kernel, dim3(ceil_div(V, 256), B), dim3(256), 0, s, (const float*)G, (const float*)Gown,
                        (const int32_t*)(sv + sl.slot), (const int32_t*)hm->v_off, (const int32_t*)hm->v_ent,
                        (const float*)hm->w, V, N, grad_verts);
     return tuch_check_launch("tuch_hd_contact_bwd");
