@@ -218,8 +218,13 @@ def _fitting_inputs(g, full):
 @pytest.mark.parametrize('eu', ['e0', 'e2'])
 @pytest.mark.parametrize('sg', ['nos', 'seg'])
 @pytest.mark.parametrize('full', [False, True])
-def test_contact_fitting_loss_vs_reference(tag, eu, sg, full):
-    """a6 of SURVEY.md §8a through the reference's own call signature (losses.py:34-123)."""
+@pytest.mark.parametrize('fused_tail', ['1', '0'])
+def test_contact_fitting_loss_vs_reference(tag, eu, sg, full, fused_tail, monkeypatch):
+    """a6 of SURVEY.md §8a through the reference's own call signature (losses.py:34-123); with the prior of the full
+    objective the part behind the body model runs as one autograd node (TUCH_FUSED_TAIL=1, default) or as separate ones."""
+    if fused_tail == '0' and not full:
+        pytest.skip('the switch only matters for the full objective')
+    monkeypatch.setenv('TUCH_FUSED_TAIL', fused_tail)
     from tuch_amd.smplify.losses import contact_fitting_loss
     from tuch_amd.utils.segmentation import BatchBodySegment
     g, gm = golden(tag), golden_mask(tag)
