@@ -185,6 +185,12 @@ size_t tuch_v2v_model_workspace_bytes(const tuch_contact_model* model, int B);
 size_t tuch_v2v_hint_bytes(const tuch_contact_model* model, int B);
 int tuch_v2v_min_model(const tuch_contact_model* model, const float* verts, int B, float* min_d2,
                        int32_t* argmin, void* hint_inout, void* workspace, size_t workspace_bytes, void* stream);
+/* The same search for callers that run other kernels beside it on another stream (as ops.ContactModel.exterior_and_partner
+ * does with the inside test): leave_room != 0 caps the walk's occupancy so that the neighbours' small kernels are not
+ * starved of wave slots.  Same results. */
+int tuch_v2v_min_model_shared(const tuch_contact_model* model, const float* verts, int B, float* min_d2,
+                              int32_t* argmin, void* hint_inout, void* workspace, size_t workspace_bytes, int leave_room,
+                              void* stream);
 
 /* Cluster tree over the faces of a closed mesh (host only, no device needed): the structure behind the
  * hierarchical evaluation of winding_numbers (tuch/utils/contact.py:112-147) inside tuch_exterior_flags.

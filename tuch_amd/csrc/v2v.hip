@@ -694,8 +694,19 @@ extern "C" size_t tuch_v2v_hint_bytes(const tuch_contact_model* m, int B)
     return (size_t)B * m->tree_qblocks * 2 * kTreeCols * sizeof(int32_t);
 }
 
+extern "C" int tuch_v2v_min_model_shared(const tuch_contact_model* m, const float* verts, int B, float* min_d2,
+                                         int32_t* argmin, void* hint_inout, void* workspace, size_t workspace_bytes,
+                                         int leave_room, void* stream);
+
 extern "C" int tuch_v2v_min_model(const tuch_contact_model* m, const float* verts, int B, float* min_d2,
                                   int32_t* argmin, void* hint_inout, void* workspace, size_t workspace_bytes, void* stream)
+{
+    return tuch_v2v_min_model_shared(m, verts, B, min_d2, argmin, hint_inout, workspace, workspace_bytes, 0, stream);
+}
+
+extern "C" int tuch_v2v_min_model_shared(const tuch_contact_model* m, const float* verts, int B, float* min_d2,
+                                         int32_t* argmin, void* hint_inout, void* workspace, size_t workspace_bytes,
+                                         int leave_room, void* stream)
 {
     TUCH_REQUIRE(m && verts && (min_d2 || argmin), "tuch_v2v_min_model: null pointer");
     TUCH_REQUIRE(m->mask_bits, "tuch_v2v_min_model: the model has no geodesic mask");
@@ -724,7 +735,14 @@ extern "C" int tuch_v2v_min_model(const tuch_contact_model* m, const float* vert
                        (const int32_t*)m->tree_masked, N, (const int32_t*)hint_inout, keys);
     const int f = choose_v2v_frontier(m, B);
     const int f0 = m->tree_frontier_off_host[f], nsub = m->tree_frontier_off_host[f + 1] - f0;
-    hipLaunchKernelGGL(v2v_tree_kernel, dim3(B, 2 * nsub * m->tree_qblocks), dim3(64), 0, s, (const float*)prow, V, Vp,
+    // leave_room: an unused LDS allocation caps the walk at 25 of a CU's 32 wave slots.  The walk is one grid of 220 k
+    // short one-wave workgroups; when the inside test runs beside it on another stream -- a chain of mostly small
+    // kernels -- every slot is taken and those (and a 16 MB memset) queue behind the walk's workgroups: the chain only
+    // got going when the walk was done (tools/graph_timeline.py: the memset took 236 us).  -2.5 % step time; alone the
+    // walk is 10 % slower with the cap (0.28 -> 0.31 ms), hence a flag (TUCH_V2V_LDS: bytes, to compare).
+    static const int lds_env = [] { const char* e = getenv("TUCH_V2V_LDS"); return e ? atoi(e) : 6400; }();
+    const int lds_pad = leave_room ? lds_env : 0;
+    hipLaunchKernelGGL(v2v_tree_kernel, dim3(B, 2 * nsub * m->tree_qblocks), dim3(64), (size_t)lds_pad, s, (const float*)prow, V, Vp,
                        (const uint64_t*)m->tree_mask_bits, nodes, (const int32_t*)m->tree_rows, (const float*)bounds,
                        (const int32_t*)m->tree_masked, N, (const int32_t*)m->tree_frontier_nodes + f0,
                        (const int32_t*)m->tree_launch_order + (size_t)f0 * m->tree_qblocks, keys);

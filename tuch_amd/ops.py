@@ -579,7 +579,7 @@ class ContactModel:
         side = _side_stream(verts.device)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            mn, partner = self.v2v_min(verts)
+            mn, partner = self.v2v_min(verts, leave_room=True)
             extra = also() if also is not None else None
         exterior = self.exterior_flags(verts, apply_segments=apply_segments)
         cur.wait_stream(side)
@@ -634,7 +634,8 @@ class ContactModel:
         return (ext, w, seg_w, seg_e) if return_details else ext
 
     # K1
-    def v2v_min(self, verts: torch.Tensor):
+    def v2v_min(self, verts: torch.Tensor, leave_room: bool = False):
+        """leave_room: other kernels run beside the search on another stream (tuch_v2v_min_model_shared)."""
         if not self.has_mask:
             raise _C.TuchError('ContactModel was created without a geodesic mask')
         verts = _f32(verts)
@@ -645,8 +646,8 @@ class ContactModel:
         arg = torch.empty(b, self.num_verts, dtype=torch.int32, device=verts.device)
         nbytes = L.tuch_v2v_model_workspace_bytes(self._handle, b)
         ws = _workspace(nbytes, verts.device)
-        _C.check(L.tuch_v2v_min_model(self._handle, _C.ptr(verts), b, _C.ptr(mn), _C.ptr(arg), _C.ptr(self._v2v_hint(b)),
-                                      _C.ptr(ws), nbytes, _C.stream()))
+        _C.check(L.tuch_v2v_min_model_shared(self._handle, _C.ptr(verts), b, _C.ptr(mn), _C.ptr(arg),
+                                             _C.ptr(self._v2v_hint(b)), _C.ptr(ws), nbytes, int(leave_room), _C.stream()))
         return mn, arg
 
     def _v2v_hint(self, batch: int) -> Optional[torch.Tensor]:
