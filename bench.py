@@ -464,12 +464,19 @@ def workloads(device, seed):
     t = time_kernel(fit, 1)
     out['config3_fit_b32_100+100_iters'] = {'seconds_per_fit': round(t, 4), 'body_iterations_per_s': round(32 * 200 / t, 1),
                                             'graph_replayed': dict(fitter.graph_replayed)}
+    tuch_step = make_tuch_step(p32, run_smplify=False)
+    eager_ms = time_kernel(tuch_step, 5) * 1e3
+    try:        # our part of the step has no host synchronisation: the whole step replays as one hipGraph
+        graph_ms = round(time_kernel(capture(tuch_step, 3), 10) * 1e3, 4)
+    except RuntimeError as e:
+        graph_ms = 'capture failed: %s' % str(e).splitlines()[0]
     out['config4_shard_b32_train_step'] = {
-        'ms': round(time_kernel(make_tuch_step(p32, run_smplify=False), 5) * 1e3, 4),
+        'ms': round(eager_ms, 4), 'graph_ms': graph_ms,
         'contact_only_plain_ms': round(time_kernel(make_train_step(p32, False), 5) * 1e3, 4),
         'contact_only_hd_ms': round(time_kernel(make_train_step(p32, True), 3) * 1e3, 4),
         'what': 'TUCH.forward_train_step (no SMPLify in the loop) + backward, 32 bodies per rank (256 / 8), stand-in '
-                'regressors; contact_only_* = SMPL fwd (pose2rot=False) + RegressorLoss.contact_loss + backward alone'}
+                'regressors; ms = eager (CPU-launch-bound: ~580 small launches), graph_ms = the same step captured once and '
+                'replayed; contact_only_* = SMPL fwd (pose2rot=False) + RegressorLoss.contact_loss + backward alone'}
     p64 = build_problem(64, device, seed + 2)
     out['config5_shard_b64_in_the_loop_step'] = {
         'ms': round(time_kernel(make_tuch_step(p64, run_smplify=True, smplify_iters=10), 2) * 1e3, 4),

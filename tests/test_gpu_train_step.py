@@ -111,3 +111,70 @@ def test_forward_train_step_matches_the_reference(tmp_path):
         assert_close(got, want, 1e-3, 2e-3, 'fits table ' + n)
     gw = g['grad_fc_weight']
     assert_close(module.model.fc.weight.grad.cpu().numpy(), gw, 2e-3, 2e-4 * np.abs(gw).max(), 'regressor gradient')
+
+
+def test_forward_train_step_replays_as_a_hip_graph(tmp_path):
+    """Without SMPLify in the loop (BASELINE config 4) our part of the training step has no host synchronisation: the
+    whole ``forward_train_step`` + backward is captured once and replayed -- same loss and regressor gradient as the
+    eager step, and new input values (written in place) are picked up by the replay."""
+    from tuch_amd.models.smpl import SMPL
+    from tuch_amd.smplify.prior import MaxMixturePrior
+    from tuch_amd.smplify.smplifydc import SMPLifyDC
+    from tuch_amd.train.loss import RegressorLoss
+    from tuch_amd.train.train_module import TUCH
+    from tuch_amd.utils.segmentation import BatchBodySegment
+    g = _golden()
+    batch = int(g['batch'])
+    body = make_body(int(g['rings']), int(g['segs']), relax_iters=int(g['relax_iters']))
+    train_ds, names = _datasets(g)
+    for n in names:
+        np.save(tmp_path / (n + '_fits.npy'), g['static_fits_' + n])
+    options = _options(g, tmp_path)
+    options.run_smplify = False
+    smpl = SMPL(model_data=body, batch_size=batch).to(DEV)
+    face_tensor = torch.tensor(body.faces.astype(np.int64), device=DEV)[None].repeat(batch, 1, 1)
+    geod = torch.tensor(body.geodesics, device=DEV)
+    smplify = SMPLifyDC(step_size=1e-2, batch_size=batch, num_iters=2, focal_length=5000., geodistssmpl=geod, geothres=0.3,
+                        euclthres=0.02, device=DEV, smpl=smpl, pose_prior=MaxMixturePrior(num_gaussians=8, gmm=body.gmm).to(DEV))
+    criterion = RegressorLoss(options=options, device=DEV, num_verts=body.num_verts, faces=face_tensor, geodistssmpl=geod,
+                              geothres=0.3, face_tensor=face_tensor,
+                              segments=BatchBodySegment(list(body.segments.keys()), face_tensor[0], body.segments),
+                              hd_regressor=(body.hd_bary_idx, body.hd_bary_w), hd_faces=body.hd_face_id)
+    module = TUCH(options=options, device=DEV, datasets=(train_ds, None), bodymodel=smpl, spin_model=make_regressor(11).to(DEV),
+                  regressor=make_regressor(12).to(DEV), optimization=smplify, criterion=criterion, geodistssmpl=geod,
+                  contactlists={'classes': [list(p) for p in body.region_pairs], 'csig': dict(body.regions)})
+    inputs = _batch(g)
+    params = list(module.model.parameters())
+    out = torch.zeros(1, device=DEV)
+
+    def step():
+        for q in params:
+            q.grad = None
+        loss, _, _ = module.forward_train_step(inputs)
+        loss.backward()
+        out.copy_(loss.detach().reshape(1))
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    eager_loss, eager_grad = out.item(), module.model.fc.weight.grad.clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+        step()
+    captured_grad = module.model.fc.weight.grad           # static tensor of the graph
+    graph.replay()
+    torch.cuda.synchronize()
+    assert_close(out.item(), eager_loss, 1e-5, 1e-7, 'replayed loss')
+    assert_close(captured_grad.cpu().numpy(), eager_grad.cpu().numpy(), 1e-4, 1e-6 * float(eager_grad.abs().max()), 'replayed gradient')
+    inputs['img'].mul_(0.5)                                # new data, same storage
+    graph.replay()
+    torch.cuda.synchronize()
+    replay_loss = out.item()
+    step()
+    torch.cuda.synchronize()
+    assert replay_loss != eager_loss
+    assert_close(replay_loss, out.item(), 1e-5, 1e-7, 'replay with new inputs')

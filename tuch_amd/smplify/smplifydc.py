@@ -53,6 +53,7 @@ class SMPLifyDC():
         self.focal_length = focal_length
         self.step_size = step_size
         self.ign_joints = list(default_ignored_joints() if ign_joints is None else ign_joints)
+        self._ign_index = {}          # device -> index tensor (a Python list index is re-uploaded on every use)
         self.num_iters = num_iters
         if pose_prior is None:             # smplifydc.py:50-52
             pose_prior = MaxMixturePrior(prior_folder=prior_folder or config_path('PRIOR_FOLDER'),
@@ -250,7 +251,7 @@ class SMPLifyDC():
             put(t['cam'], init_cam_t); put(t['init_cam'], init_cam_t); put(t['centre'], camera_center)
             put(t['j2d'], keypoints_2d[:, :, :2]); put(t['conf1'], keypoints_2d[:, :, -1])
             put(t['conf2'], keypoints_2d[:, :, -1])
-            t['conf2'][:, self.ign_joints] = 0.0                                         # smplifydc.py:153,198
+            t['conf2'].index_fill_(1, self._ignored(t['conf2'].device), 0.0)                                         # smplifydc.py:153,198
             if use_contact:
                 put(t['valid'], ~ignore_idxs)
                 if t.get('select') is not None:
@@ -334,7 +335,7 @@ class SMPLifyDC():
 
         # ---- stage 2: pose + global orientation
         optiverts = []
-        joints_conf[:, self.ign_joints] = 0.0                        # smplifydc.py:153,198
+        joints_conf.index_fill_(1, self._ignored(joints_conf.device), 0.0)                        # smplifydc.py:153,198
         camera_translation.requires_grad = False
         # snapshots of the stage-1 result (smplifydc.py:141-142), taken before gradients are switched on:
         # a clone of a leaf that requires grad would keep its AccumulateGrad node (created on the
@@ -388,12 +389,19 @@ class SMPLifyDC():
         return (out.vertices.detach(), out.joints.detach(), pose, betas.detach(), camera_translation,
                 reprojection_loss, optiverts)
 
+    def _ignored(self, device):
+        """ign_joints as an index tensor on `device`."""
+        idx = self._ign_index.get(device)
+        if idx is None:
+            idx = self._ign_index[device] = torch.tensor(self.ign_joints, dtype=torch.int64, device=device)
+        return idx
+
     def get_fitting_loss(self, pose, betas, cam_t, camera_center, keypoints_2d, has_gt_keypoints=None):
         """Per-joint reprojection loss of given parameters (reference: smplifydc.py:238-276;
         like the reference, zeroing the ignored joints writes through into ``keypoints_2d``)."""
         joints_2d = keypoints_2d[:, :, :2]
         joints_conf = keypoints_2d[:, :, -1]
-        joints_conf[:, self.ign_joints] = 0.
+        joints_conf.index_fill_(1, self._ignored(joints_conf.device), 0.0)
         if has_gt_keypoints is not None:
             joints_conf = joints_conf.clone()
             joints_conf[has_gt_keypoints, :25] = 0

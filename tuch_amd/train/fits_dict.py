@@ -42,6 +42,7 @@ class FitsDict():
         self.fits_dict = {}
         self.flipped_parts = torch.tensor(_flip_perm(), dtype=torch.int64, device=self.device)
         self._ds_index = {}
+        self._group_cache = {}
         for ds_name, ds in train_dataset.dataset_dict.items():             # fits_dict.py:38-52
             dict_file = os.path.join(options.checkpoint_dir, ds_name + '_fits.npy')
             if not os.path.isfile(dict_file):
@@ -61,9 +62,15 @@ class FitsDict():
     def _groups(self, dataset_name, ind):
         """(dataset, positions in the batch, rows of its table) per dataset present in the batch."""
         ind = torch.as_tensor(ind).to(self.device, torch.int64)
-        names = list(dataset_name)
-        for ds in dict.fromkeys(names):
-            pos = torch.tensor([n for n, d in enumerate(names) if d == ds], dtype=torch.int64, device=self.device)
+        names = tuple(dataset_name)
+        groups = self._group_cache.get(names)
+        if groups is None:            # batch positions per dataset: uploaded once per distinct composition of a batch
+            groups = [(ds, torch.tensor([n for n, d in enumerate(names) if d == ds], dtype=torch.int64, device=self.device))
+                      for ds in dict.fromkeys(names)]
+            if len(self._group_cache) >= 64:
+                self._group_cache.pop(next(iter(self._group_cache)))
+            self._group_cache[names] = groups
+        for ds, pos in groups:
             yield ds, pos, ind[pos]
 
     def __getitem__(self, x):
