@@ -192,17 +192,6 @@ int tuch_v2v_min_model_shared(const tuch_contact_model* model, const float* vert
                               int32_t* argmin, void* hint_inout, void* workspace, size_t workspace_bytes, int leave_room,
                               void* stream);
 
-/* The search as the losses use it.  capped [B,V] u8 (device): a column with capped[b][i] != 0 only matters to its caller
- * if its partner is closer than sqrt(cap_d2) -- an exterior vertex of the SMPLify-DC term counts only inside `euclthres`
- * (losses.py:100-105), and the training term 0.005 tanh^2(d / 0.005) of an exterior vertex (loss.py:307-308) is its
- * saturated value, with zero gradient, in float32 beyond a few centimetres.  For those columns: (min_d2, argmin) exactly as
- * tuch_v2v_min_model if min_d2 < cap_d2, else (+inf, -1); cap_d2 <= 0: always (+inf, -1).  All other columns: exact.
- * The consumers (tuch_contact_terms_*) read argmin -1 as "infinitely far".  Models without a cluster tree answer with
- * the exact search for every column. */
-int tuch_v2v_min_model_capped(const tuch_contact_model* model, const float* verts, int B, const uint8_t* capped,
-                              float cap_d2, float* min_d2, int32_t* argmin, void* hint_inout, void* workspace,
-                              size_t workspace_bytes, void* stream);
-
 /* Cluster tree over the faces of a closed mesh (host only, no device needed): the structure behind the
  * hierarchical evaluation of winding_numbers (tuch/utils/contact.py:112-147) inside tuch_exterior_flags.
  * A set of faces far from the query is replaced by a triangulation of its boundary loops, which subtends

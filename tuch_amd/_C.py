@@ -78,8 +78,6 @@ _SIGNATURES = {
     'tuch_v2v_model_workspace_bytes': (c_size_t, [c_void_p, c_int]),
     'tuch_v2v_hint_bytes': (c_size_t, [c_void_p, c_int]),
     'tuch_v2v_min_model': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    'tuch_v2v_min_model_capped': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
-                                          c_size_t, c_void_p]),
     'tuch_v2v_min_model_shared': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int,
                                           c_void_p]),
     'tuch_exterior_workspace_bytes': (c_size_t, [c_void_p, c_int]),

@@ -34,7 +34,7 @@ __device__ __forceinline__ Term contact_term(float d, bool exterior, int mode, f
     } else {
         weight = 1.0f; scale = 0.04f;
     }
-    const float th = d < 3.0e38f ? tanhf(d / scale) : 1.0f;
+    const float th = tanhf(d / scale);
     t.value = weight * th * th;
     t.dd = 2.0f * weight * th * (1.0f - th * th) / scale;
     return t;
@@ -69,11 +69,10 @@ __global__ __launch_bounds__(kBlock) void contact_terms_fwd_kernel(
     if (!body_valid || body_valid[b]) {
         const float* pb = pts + (size_t)b * N * 3;
         for (int i = threadIdx.x; i < N; i += kBlock) {
-            const int pr = partner[(size_t)b * N + i];
-            const int p = pr < 0 ? i : pr;         // -1 (tuch_v2v_min_model_capped): no partner within the cap = infinitely far
+            const int p = partner[(size_t)b * N + i];
             const float dx = pb[3 * i] - pb[3 * p], dy = pb[3 * i + 1] - pb[3 * p + 1],
                         dz = pb[3 * i + 2] - pb[3 * p + 2];
-            const float d = pr < 0 ? __builtin_inff() : __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
+            const float d = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
             const bool ext = exterior[(size_t)b * N + i] != 0;
             const Term t = contact_term(d, ext, mode, euclthres);
             if (ext) ex_sum += t.value; else in_sum += t.value;
@@ -122,7 +121,6 @@ __global__ __launch_bounds__(256) void contact_terms_bwd_kernel(
     if (g == 0.0f) return;
     const float* pb = pts + (size_t)b * N * 3;
     const int p = partner[(size_t)b * N + i];
-    if (p < 0) return;                             // no partner within the cap: the term is saturated or zero, no gradient
     const float dx = pb[3 * i] - pb[3 * p], dy = pb[3 * i + 1] - pb[3 * p + 1],
                 dz = pb[3 * i + 2] - pb[3 * p + 2];
     const float d = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);

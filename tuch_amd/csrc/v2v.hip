@@ -464,44 +464,14 @@ __device__ __forceinline__ float box_dist2(const Column& c, const float* __restr
     return __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
 }
 
-// the walk of one subtree (nodes [node, end) in preorder) for the wave's 64 columns
-__device__ __forceinline__ void v2v_walk(Column& c, const float* __restrict__ pb, const uint64_t* __restrict__ m0,
-                                         const int32_t* __restrict__ mk, const float* __restrict__ bb,
-                                         const TreeNode* __restrict__ nodes, const int32_t* __restrict__ rows, int node, int end)
-{
-    while (node < end) {
-        const TreeNode nd = nodes[node];
-        bool descend = mk[node] == 0;
-        if (descend) {
-            const float g = box_dist2(c, bb + (size_t)node * 8) * kPruneSlack;
-            descend = __builtin_amdgcn_ballot_w64(g <= c.best) != 0;
-        }
-        if (!descend) {
-            node = nd.skip;
-        } else if (nd.c0 < 0) {
-            v2v_rows(c, pb, m0, rows[2 * node], rows[2 * node + 1]);
-            node = nd.skip;
-        } else {
-            node = node + 1;
-        }
-        node = __builtin_amdgcn_readfirstlane(node);
-    }
-}
-
 // seed: descend to the admissible leaf nearest to the block's box, evaluate its rows.
 // grid (B, 64-column blocks); the static mask table is kept per 128-column block (qb >> 1).
-// Capped form (capped != nullptr: tuch_v2v_min_model_capped): a column with capped[b][vertex] != 0 only wants partners
-// closer than sqrt(cap_d2) -- its bound starts there, with no row (key row 0xffffffff).  A block whose columns are all
-// capped is finished here, by one walk of the whole tree under those small bounds (almost everything is pruned at the
-// top); the others are seeded as usual and appended to the list of blocks the subtree walks still have to visit.
 __global__ __launch_bounds__(64) void v2v_seed_kernel(
     const float* __restrict__ prow, int V, int Vp, const uint64_t* __restrict__ bits,
     const TreeNode* __restrict__ nodes, const int32_t* __restrict__ rows, const float* __restrict__ bounds,
     const int32_t* __restrict__ masked, int N,
     const int32_t* __restrict__ hint,            // [B,Vp] a row per column (tree order) from an earlier call, or nullptr
-    uint64_t* __restrict__ keys,                 // [B,Vp]
-    const uint8_t* __restrict__ capped, const int32_t* __restrict__ qperm, float cap_d2,
-    int32_t* __restrict__ full_blocks, int32_t* __restrict__ n_full)
+    uint64_t* __restrict__ keys)                 // [B,Vp]
 {
     const int b = blockIdx.x, qb = blockIdx.y, lane = threadIdx.x;
     const float* pb = prow + (size_t)b * Vp * 3;
@@ -510,18 +480,6 @@ __global__ __launch_bounds__(64) void v2v_seed_kernel(
     c.px = pb[3 * i0]; c.py = pb[3 * i0 + 1]; c.pz = pb[3 * i0 + 2];
     c.best = __builtin_inff();
     c.arg = 0;
-    const float* bb = bounds + (size_t)b * N * 8;
-    const int32_t* mk = masked + (size_t)(qb >> 1) * N;
-    // padding columns (i0 >= V) repeat a vertex and are never read back: nothing to find for them
-    const bool is_capped = capped && (i0 >= V || capped[(size_t)b * V + qperm[i0]] != 0);
-    const float capv = i0 < V ? __builtin_fmaxf(cap_d2, 0.0f) : 0.0f;
-    if (capped && __builtin_amdgcn_ballot_w64(!is_capped) == 0) {
-        c.best = capv;
-        c.arg = -1;
-        if (cap_d2 > 0.0f) v2v_walk(c, pb, bits + (size_t)qb * V, mk, bb, nodes, rows, 0, N);
-        keys[(size_t)b * Vp + i0] = v2v_key(c.best, c.arg);
-        return;
-    }
     float lo[3] = {c.px, c.py, c.pz}, hi[3] = {c.px, c.py, c.pz};
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1)
@@ -530,6 +488,8 @@ __global__ __launch_bounds__(64) void v2v_seed_kernel(
             lo[k] = fminf(lo[k], __shfl_xor(lo[k], m));
             hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m));
         }
+    const float* bb = bounds + (size_t)b * N * 8;
+    const int32_t* mk = masked + (size_t)(qb >> 1) * N;
     auto gap2 = [&](int node) {                 // squared distance between the block's box and the node's box
         const float* box = bb + (size_t)node * 8;
         float g = 0.0f;
@@ -566,9 +526,7 @@ __global__ __launch_bounds__(64) void v2v_seed_kernel(
             if (d < c.best || (d == c.best && j < c.arg)) { c.best = d; c.arg = j; }
         }
     }
-    if (is_capped && !(c.best < capv)) { c.best = capv; c.arg = -1; }
     keys[(size_t)b * Vp + i0] = v2v_key(c.best, c.arg);
-    if (capped && lane == 0) full_blocks[atomicAdd(n_full, 1)] = b * (int)gridDim.y + qb;
 }
 
 __global__ __launch_bounds__(64) void v2v_tree_kernel(
@@ -589,41 +547,30 @@ __global__ __launch_bounds__(64) void v2v_tree_kernel(
     c.px = pb[3 * i0]; c.py = pb[3 * i0 + 1]; c.pz = pb[3 * i0 + 2];
     c.best = __uint_as_float((uint32_t)(init >> 32));
     c.arg = (int)(uint32_t)init;
-    const int node = __builtin_amdgcn_readfirstlane(frontier[sub]);
-    v2v_walk(c, pb, bits + (size_t)qb * V, masked + (size_t)(qb >> 1) * N, bounds + (size_t)b * N * 8, nodes, rows, node,
-             __builtin_amdgcn_readfirstlane(nodes[node].skip));
+    const float* bb = bounds + (size_t)b * N * 8;
+    const int32_t* mk = masked + (size_t)(qb >> 1) * N;
+    const uint64_t* m0 = bits + (size_t)qb * V;
+    int node = __builtin_amdgcn_readfirstlane(frontier[sub]);
+    const int end = __builtin_amdgcn_readfirstlane(nodes[node].skip);
+    while (node < end) {
+        const TreeNode nd = nodes[node];
+        bool descend = mk[node] == 0;
+        if (descend) {
+            const float g = box_dist2(c, bb + (size_t)node * 8) * kPruneSlack;
+            descend = __builtin_amdgcn_ballot_w64(g <= c.best) != 0;
+        }
+        if (!descend) {
+            node = nd.skip;
+        } else if (nd.c0 < 0) {
+            v2v_rows(c, pb, m0, rows[2 * node], rows[2 * node + 1]);
+            node = nd.skip;
+        } else {
+            node = node + 1;
+        }
+        node = __builtin_amdgcn_readfirstlane(node);
+    }
     const uint64_t k0 = v2v_key(c.best, c.arg);
     if (k0 < init) atomicMin((unsigned long long*)(kb + i0), (unsigned long long)k0);
-}
-
-// The same walks for the blocks on a device-built list (capped form: only the blocks with a column that wants the
-// unrestricted search): wavefronts loop over (listed block, subtree) items -- a grid over all blocks would be mostly
-// workgroups that leave at once, and dispatching those costs more than the walks that remain.
-__global__ __launch_bounds__(64) void v2v_tree_list_kernel(
-    const float* __restrict__ prow, int V, int Vp, const uint64_t* __restrict__ bits,
-    const TreeNode* __restrict__ nodes, const int32_t* __restrict__ rows, const float* __restrict__ bounds,
-    const int32_t* __restrict__ masked, int N, const int32_t* __restrict__ frontier, int nsub, int qblocks64,
-    const int32_t* __restrict__ full_blocks, const int32_t* __restrict__ n_full, uint64_t* __restrict__ keys)
-{
-    const int lane = threadIdx.x;
-    const int items = __builtin_amdgcn_readfirstlane(n_full[0]) * nsub;
-    for (int item = blockIdx.x; item < items; item += gridDim.x) {
-        const int blk = __builtin_amdgcn_readfirstlane(full_blocks[item / nsub]), sub = item % nsub;
-        const int b = blk / qblocks64, qb = blk % qblocks64;
-        const float* pb = prow + (size_t)b * Vp * 3;
-        const int i0 = qb * kTreeCols + lane;
-        uint64_t* kb = keys + (size_t)b * Vp;
-        const uint64_t init = __hip_atomic_load(kb + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        Column c;
-        c.px = pb[3 * i0]; c.py = pb[3 * i0 + 1]; c.pz = pb[3 * i0 + 2];
-        c.best = __uint_as_float((uint32_t)(init >> 32));
-        c.arg = (int)(uint32_t)init;
-        const int node = __builtin_amdgcn_readfirstlane(frontier[sub]);
-        v2v_walk(c, pb, bits + (size_t)qb * V, masked + (size_t)(qb >> 1) * N, bounds + (size_t)b * N * 8, nodes, rows, node,
-                 __builtin_amdgcn_readfirstlane(nodes[node].skip));
-        const uint64_t k0 = v2v_key(c.best, c.arg);
-        if (k0 < init) atomicMin((unsigned long long*)(kb + i0), (unsigned long long)k0);
-    }
 }
 
 // keys -> (min, argmin) in the caller's vertex numbering; all-masked column -> (inf, 0)
@@ -637,16 +584,14 @@ __global__ __launch_bounds__(kBlock) void v2v_tree_finalize_kernel(
     const uint64_t k = keys[(size_t)b * Vp + i];
     const float d = __uint_as_float((uint32_t)(k >> 32));
     const int v = qperm[i];
-    // capped columns that found nothing closer than their cap keep the row 0xffffffff: (inf, -1)
-    const bool none = (uint32_t)k == 0xffffffffu;
-    if (hint) hint[(size_t)b * Vp + i] = (d < __builtin_inff() && !none) ? (int)(uint32_t)k : -1;
-    if (out_min) out_min[(size_t)b * V + v] = none ? __builtin_inff() : d;
-    if (out_arg) out_arg[(size_t)b * V + v] = none ? -1 : (d < __builtin_inff() ? qperm[(uint32_t)k] : 0);
+    if (hint) hint[(size_t)b * Vp + i] = d < __builtin_inff() ? (int)(uint32_t)k : -1;
+    if (out_min) out_min[(size_t)b * V + v] = d;
+    if (out_arg) out_arg[(size_t)b * V + v] = d < __builtin_inff() ? qperm[(uint32_t)k] : 0;
 }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-struct TreeV2VLayout { size_t prow, bounds, keys, full, total; };
+struct TreeV2VLayout { size_t prow, bounds, keys, total; };
 
 TreeV2VLayout tree_v2v_layout(const tuch_contact_model* m, int B)
 {
@@ -656,7 +601,6 @@ TreeV2VLayout tree_v2v_layout(const tuch_contact_model* m, int B)
     l.prow = o;   o += align256((size_t)B * Vp * 3 * sizeof(float) + 64);
     l.bounds = o; o += align256((size_t)B * m->tree_nodes * 8 * sizeof(float));
     l.keys = o;   o += align256((size_t)B * Vp * sizeof(uint64_t));
-    l.full = o;   o += align256(((size_t)B * m->tree_qblocks * 2 + 1) * sizeof(int32_t));   // [0] = count, then the blocks
     l.total = o;
     return l;
 }
@@ -750,14 +694,24 @@ extern "C" size_t tuch_v2v_hint_bytes(const tuch_contact_model* m, int B)
     return (size_t)B * m->tree_qblocks * 2 * kTreeCols * sizeof(int32_t);
 }
 
-static int v2v_min_model_impl(const tuch_contact_model* m, const float* verts, int B, const uint8_t* capped, float cap_d2,
-                              float* min_d2, int32_t* argmin, void* hint_inout, void* workspace, size_t workspace_bytes,
-                              int leave_room, void* stream)
+extern "C" int tuch_v2v_min_model_shared(const tuch_contact_model* m, const float* verts, int B, float* min_d2,
+                                         int32_t* argmin, void* hint_inout, void* workspace, size_t workspace_bytes,
+                                         int leave_room, void* stream);
+
+extern "C" int tuch_v2v_min_model(const tuch_contact_model* m, const float* verts, int B, float* min_d2,
+                                  int32_t* argmin, void* hint_inout, void* workspace, size_t workspace_bytes, void* stream)
+{
+    return tuch_v2v_min_model_shared(m, verts, B, min_d2, argmin, hint_inout, workspace, workspace_bytes, 0, stream);
+}
+
+extern "C" int tuch_v2v_min_model_shared(const tuch_contact_model* m, const float* verts, int B, float* min_d2,
+                                         int32_t* argmin, void* hint_inout, void* workspace, size_t workspace_bytes,
+                                         int leave_room, void* stream)
 {
     TUCH_REQUIRE(m && verts && (min_d2 || argmin), "tuch_v2v_min_model: null pointer");
     TUCH_REQUIRE(m->mask_bits, "tuch_v2v_min_model: the model has no geodesic mask");
     TUCH_REQUIRE(B > 0 && B <= 65535, "tuch_v2v_min_model: bad batch %d", B);
-    if (!use_v2v_tree(m))       // no tree: the exact search for every column (a valid answer to the capped question too)
+    if (!use_v2v_tree(m))
         return tuch_v2v_min_masked(verts, m->mask_bits, B, m->V, min_d2, argmin, workspace, workspace_bytes, stream);
     const TreeV2VLayout l = tree_v2v_layout(m, B);
     if (!workspace || workspace_bytes < l.total) {
@@ -768,15 +722,9 @@ static int v2v_min_model_impl(const tuch_contact_model* m, const float* verts, i
     float* prow = (float*)(ws + l.prow);
     float* bounds = (float*)(ws + l.bounds);
     uint64_t* keys = (uint64_t*)(ws + l.keys);
-    int32_t* n_full = (int32_t*)(ws + l.full);
-    int32_t* full_blocks = n_full + 1;
     hipStream_t s = (hipStream_t)stream;
     const int V = m->V, Vp = m->tree_qblocks * 2 * kTreeCols, N = m->tree_nodes;
     const TreeNode* nodes = (const TreeNode*)m->tree_node;
-    if (capped && hipMemsetAsync(n_full, 0, sizeof(int32_t), s) != hipSuccess) {
-        tuch_set_error("tuch_v2v_min_model_capped: hipMemsetAsync failed");
-        return TUCH_ERR_HIP;
-    }
     hipLaunchKernelGGL(v2v_rows_kernel, dim3(ceil_div(m->tree_leaves, kBoundsBlock / 64), B), dim3(kBoundsBlock), 0, s,
                        verts, V, Vp, (const int32_t*)m->tree_qperm, (const int32_t*)m->tree_rows,
                        (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, N, prow, bounds);
@@ -784,8 +732,7 @@ static int v2v_min_model_impl(const tuch_contact_model* m, const float* verts, i
                        (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, m->tree_heights, bounds);
     hipLaunchKernelGGL(v2v_seed_kernel, dim3(B, 2 * m->tree_qblocks), dim3(64), 0, s, (const float*)prow, V, Vp,
                        (const uint64_t*)m->tree_mask_bits, nodes, (const int32_t*)m->tree_rows, (const float*)bounds,
-                       (const int32_t*)m->tree_masked, N, (const int32_t*)hint_inout, keys, capped,
-                       (const int32_t*)m->tree_qperm, cap_d2, full_blocks, n_full);
+                       (const int32_t*)m->tree_masked, N, (const int32_t*)hint_inout, keys);
     const int f = choose_v2v_frontier(m, B);
     const int f0 = m->tree_frontier_off_host[f], nsub = m->tree_frontier_off_host[f + 1] - f0;
     // leave_room: an unused LDS allocation caps the walk at 25 of a CU's 32 wave slots.  The walk is one grid of 220 k
@@ -795,43 +742,13 @@ static int v2v_min_model_impl(const tuch_contact_model* m, const float* verts, i
     // walk is 10 % slower with the cap (0.28 -> 0.31 ms), hence a flag (TUCH_V2V_LDS: bytes, to compare).
     static const int lds_env = [] { const char* e = getenv("TUCH_V2V_LDS"); return e ? atoi(e) : 6400; }();
     const int lds_pad = leave_room ? lds_env : 0;
-    if (capped) {
-        const long worst = (long)B * 2 * m->tree_qblocks * nsub;
-        hipLaunchKernelGGL(v2v_tree_list_kernel, dim3((unsigned)(worst < 32768 ? worst : 32768)), dim3(64), (size_t)lds_pad, s,
-                           (const float*)prow, V, Vp, (const uint64_t*)m->tree_mask_bits, nodes, (const int32_t*)m->tree_rows,
-                           (const float*)bounds, (const int32_t*)m->tree_masked, N, (const int32_t*)m->tree_frontier_nodes + f0,
-                           nsub, 2 * m->tree_qblocks, (const int32_t*)full_blocks, (const int32_t*)n_full, keys);
-    } else {
-        hipLaunchKernelGGL(v2v_tree_kernel, dim3(B, 2 * nsub * m->tree_qblocks), dim3(64), (size_t)lds_pad, s, (const float*)prow,
-                           V, Vp, (const uint64_t*)m->tree_mask_bits, nodes, (const int32_t*)m->tree_rows, (const float*)bounds,
-                           (const int32_t*)m->tree_masked, N, (const int32_t*)m->tree_frontier_nodes + f0,
-                           (const int32_t*)m->tree_launch_order + (size_t)f0 * m->tree_qblocks, keys);
-    }
+    hipLaunchKernelGGL(v2v_tree_kernel, dim3(B, 2 * nsub * m->tree_qblocks), dim3(64), (size_t)lds_pad, s, (const float*)prow, V, Vp,
+                       (const uint64_t*)m->tree_mask_bits, nodes, (const int32_t*)m->tree_rows, (const float*)bounds,
+                       (const int32_t*)m->tree_masked, N, (const int32_t*)m->tree_frontier_nodes + f0,
+                       (const int32_t*)m->tree_launch_order + (size_t)f0 * m->tree_qblocks, keys);
     hipLaunchKernelGGL(v2v_tree_finalize_kernel, dim3(ceil_div(V, kBlock), B), dim3(kBlock), 0, s,
                        (const uint64_t*)keys, (const int32_t*)m->tree_qperm, V, Vp, min_d2, argmin, (int32_t*)hint_inout);
     return tuch_check_launch("tuch_v2v_min_model");
-}
-
-extern "C" int tuch_v2v_min_model(const tuch_contact_model* m, const float* verts, int B, float* min_d2,
-                                  int32_t* argmin, void* hint_inout, void* workspace, size_t workspace_bytes, void* stream)
-{
-    return v2v_min_model_impl(m, verts, B, nullptr, 0.0f, min_d2, argmin, hint_inout, workspace, workspace_bytes, 0, stream);
-}
-
-extern "C" int tuch_v2v_min_model_shared(const tuch_contact_model* m, const float* verts, int B, float* min_d2,
-                                         int32_t* argmin, void* hint_inout, void* workspace, size_t workspace_bytes,
-                                         int leave_room, void* stream)
-{
-    return v2v_min_model_impl(m, verts, B, nullptr, 0.0f, min_d2, argmin, hint_inout, workspace, workspace_bytes, leave_room,
-                              stream);
-}
-
-extern "C" int tuch_v2v_min_model_capped(const tuch_contact_model* m, const float* verts, int B, const uint8_t* capped,
-                                         float cap_d2, float* min_d2, int32_t* argmin, void* hint_inout, void* workspace,
-                                         size_t workspace_bytes, void* stream)
-{
-    TUCH_REQUIRE(capped, "tuch_v2v_min_model_capped: null pointer");
-    return v2v_min_model_impl(m, verts, B, capped, cap_d2, min_d2, argmin, hint_inout, workspace, workspace_bytes, 0, stream);
 }
 
 extern "C" int tuch_batch_pairwise_dist(const float* x, const float* y, int B, int Nx, int Ny,

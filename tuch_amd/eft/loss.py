@@ -74,7 +74,7 @@ class EFTLoss(nn.Module):
 
     def contact_loss(self, gt_contact, verts):
         model = self._model
-        exterior, _, partner, _ = model.exterior_and_partner(verts, apply_segments=True, cap_d2=ops.TRAIN_CAP_D2)
+        exterior, _, partner, _ = model.exterior_and_partner(verts, apply_segments=True)
         _, terms = ops.contact_terms(verts, partner, exterior, None, ops.MODE_TRAIN, 0.0)
         n_ext = exterior.to(torch.float32).sum(dim=1)
         n_int = exterior.shape[1] - n_ext

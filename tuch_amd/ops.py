@@ -19,18 +19,6 @@ MODE_SMPLIFY = 0   # tuch/smplify/losses.py:96-105
 MODE_TRAIN = 1     # tuch/train/loss.py:303-315
 
 
-def smplify_cap_d2(euclthres) -> float:
-    """How far the SMPLify-DC term needs the partner of an EXTERIOR vertex: it only counts if d < euclthres
-    (losses.py:100-105); a hair more so that sqrt / square roundings cannot lose a vertex right at the threshold."""
-    e = float(euclthres)
-    return (1.001 * e) ** 2 if e > 0.0 else 0.0
-
-
-# How far the training term 0.005 tanh^2(d / 0.005) of an exterior vertex (loss.py:307-308, eft/loss.py:150-160) needs
-# its partner: at d = 6 cm tanh(12) = 1 - 7.6e-11 is 1.0f and the gradient's factor 1 - tanh^2 is 3e-10 of its peak.
-TRAIN_CAP_D2 = 0.06 ** 2
-
-
 def _f32(t: torch.Tensor) -> torch.Tensor:
     return t.detach().to(torch.float32).contiguous()
 
@@ -348,7 +336,7 @@ class _Stage2Tail(torch.autograd.Function):
                 float(const['prior_scale']), _C.ptr(small), _C.ptr(gj), _C.ptr(gc), _C.ptr(gp), _C.stream()))
             return (r2r, ij, small, gj, gc, gp)
         exterior, _, partner, _extra = model.exterior_and_partner(v, apply_segments=const['apply_segments'],
-                                                                  also=beside_the_walk, cap_d2=smplify_cap_d2(const['euclthres']))
+                                                                  also=beside_the_walk)
         terms = torch.empty(b, 2, dtype=torch.float32, device=v.device)
         _C.check(L.tuch_contact_terms_fwd(_C.ptr(v), _C.ptr(partner), _C.ptr(exterior), _C.ptr(valid), b, v.shape[1],
                                           MODE_SMPLIFY, float(const['euclthres']), _C.ptr(terms), _C.stream()))
@@ -578,39 +566,12 @@ class ContactModel:
                                              sign.ctypes.data_as(ctypes.c_void_p)))
         return vidx, sign, k.value
 
-    def exterior_and_partner(self, verts: torch.Tensor, apply_segments: bool = True, also=None,
-                             cap_d2: Optional[float] = None):
+    def exterior_and_partner(self, verts: torch.Tensor, apply_segments: bool = True, also=None):
         """exterior_flags + v2v_min of the same vertices -> (exterior, min_d2, partner[, also()]).
-        cap_d2 is None: the two only share their input, the exact nearest-vertex search (and the optional callable
-        ``also``, e.g. the region pairs) runs on a second stream beside the inside test (TUCH_OVERLAP=0 keeps everything
-        on the current stream).
-        cap_d2 given (what the losses do; TUCH_V2V_CAPPED=0: off): the search runs AFTER the inside test and only looks
-        within sqrt(cap_d2) for the vertices flagged exterior -- their term is zero (SMPLify-DC: not in contact) or
-        saturated (training) beyond that; exterior vertices without a partner that close get partner -1.  Nine in ten
-        column blocks are finished by one heavily pruned walk; ``also`` still runs beside the inside test."""
-        capped_search = cap_d2 is not None and os.environ.get('TUCH_V2V_CAPPED', '1') != '0'
-        overlap = verts.is_cuda and os.environ.get('TUCH_OVERLAP', '1') != '0'
-        if capped_search:
-            if not overlap:
-                exterior = self.exterior_flags(verts, apply_segments=apply_segments)
-                mn, partner = self.v2v_min(verts, capped=exterior, cap_d2=cap_d2)
-                return exterior, mn, partner, (also() if also is not None else None)
-            cur = torch.cuda.current_stream(verts.device)
-            extra = None
-            if also is not None:
-                side = _side_stream(verts.device)
-                side.wait_stream(cur)
-                with torch.cuda.stream(side):
-                    extra = also()
-            exterior = self.exterior_flags(verts, apply_segments=apply_segments)
-            mn, partner = self.v2v_min(verts, capped=exterior, cap_d2=cap_d2)
-            if also is not None:
-                cur.wait_stream(side)
-                for t in (tuple(extra) if isinstance(extra, (tuple, list)) else (extra,)):
-                    if torch.is_tensor(t):
-                        t.record_stream(cur)
-            return exterior, mn, partner, extra
-        if not overlap:
+        The two only share their input: the nearest-vertex search (and the optional callable ``also``,
+        e.g. the region pairs) runs on a second stream so that its tail fills the gaps of the long winding
+        walk (TUCH_OVERLAP=0 keeps everything on the current stream)."""
+        if not (verts.is_cuda and os.environ.get('TUCH_OVERLAP', '1') != '0'):
             exterior = self.exterior_flags(verts, apply_segments=apply_segments)
             mn, partner = self.v2v_min(verts)
             return exterior, mn, partner, (also() if also is not None else None)
@@ -673,11 +634,8 @@ class ContactModel:
         return (ext, w, seg_w, seg_e) if return_details else ext
 
     # K1
-    def v2v_min(self, verts: torch.Tensor, leave_room: bool = False, capped: Optional[torch.Tensor] = None,
-                cap_d2: float = 0.0):
-        """leave_room: other kernels run beside the search on another stream (tuch_v2v_min_model_shared).
-        capped [B,V] u8 + cap_d2: the search as the losses need it (tuch_v2v_min_model_capped): columns with capped != 0
-        report (min_d2, partner) only if closer than sqrt(cap_d2), else (inf, -1)."""
+    def v2v_min(self, verts: torch.Tensor, leave_room: bool = False):
+        """leave_room: other kernels run beside the search on another stream (tuch_v2v_min_model_shared)."""
         if not self.has_mask:
             raise _C.TuchError('ContactModel was created without a geodesic mask')
         verts = _f32(verts)
@@ -688,12 +646,6 @@ class ContactModel:
         arg = torch.empty(b, self.num_verts, dtype=torch.int32, device=verts.device)
         nbytes = L.tuch_v2v_model_workspace_bytes(self._handle, b)
         ws = _workspace(nbytes, verts.device)
-        if capped is not None:
-            cap = capped.contiguous()
-            assert cap.dtype == torch.uint8 and tuple(cap.shape) == (b, self.num_verts)
-            _C.check(L.tuch_v2v_min_model_capped(self._handle, _C.ptr(verts), b, _C.ptr(cap), float(cap_d2), _C.ptr(mn),
-                                                 _C.ptr(arg), _C.ptr(self._v2v_hint(b)), _C.ptr(ws), nbytes, _C.stream()))
-            return mn, arg
         _C.check(L.tuch_v2v_min_model_shared(self._handle, _C.ptr(verts), b, _C.ptr(mn), _C.ptr(arg),
                                              _C.ptr(self._v2v_hint(b)), _C.ptr(ws), nbytes, int(leave_room), _C.stream()))
         return mn, arg

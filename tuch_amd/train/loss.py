@@ -78,9 +78,7 @@ class RegressorLoss(nn.Module):
         model = self._model
         valid = valid_fit.bool()
         valid_u8 = valid.to(torch.uint8).contiguous()
-        # exterior vertices: the plain term is saturated beyond 6 cm; the HD branch only asks whether min_d2 < euclthres^2
-        cap_d2 = (1.001 * self.euclthres) ** 2 if self.use_hd else max(ops.TRAIN_CAP_D2, (1.001 * self.euclthres) ** 2)
-        exterior, min_d2, partner, _ = model.exterior_and_partner(pred_vertices, apply_segments=True, cap_d2=cap_d2)   # :264-266
+        exterior, min_d2, partner, _ = model.exterior_and_partner(pred_vertices, apply_segments=True)   # :264-266
         # loss.py:317 is a mean over ALL valid bodies: with the batch sharded over ranks the count is all-reduced
         # (one float, no host sync), so that every body's gradient is the single-process one
         n_valid = tdist.global_count(valid.sum())
