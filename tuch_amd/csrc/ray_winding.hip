@@ -1046,7 +1046,19 @@ int tuch_ray_exterior_points(const tuch_contact_model* m, const float* verts, co
 // The segment filter (winding.hip: caps, compacted interior vertices per (body, segment) in seg_count / seg_list) by
 // ray crossings.  leaf_counts (tuch_ray_segment_counts of the SAME verts, or nullptr): the crossings with the body faces
 // of the segments are taken from there and only cap faces and boundary edges are walked here.
-// Scratch of the caller: seg_entries [B,seg_ray_total,9] floats, seg_partial (two partial arrays + the work items).
+// Scratch of the caller: seg_entries [B,seg_ray_total,9] floats filled by tuch_ray_segment_prepare (same `assisted`), seg_partial
+// (two partial arrays + the work items).
+// the part that needs only the vertices and the cap centroids (the caller runs it ahead of the body's inside test, off the
+// critical chain): the posed, sheared entries.  assisted as in tuch_ray_segment_flags (leaf counts will be available).
+void tuch_ray_segment_prepare(const tuch_contact_model* m, const float* verts, const float* caps, int assisted, int B,
+                              float* seg_entries, hipStream_t s)
+{
+    const bool as = assisted && m->seg_cap_off;
+    const int E = as ? m->seg_cap_total : m->seg_ray_total;
+    hipLaunchKernelGGL(segment_shear_entries_kernel, dim3(ceil_div(E > 0 ? E : 1, kBlock), B), dim3(kBlock), 0, s,
+                       verts, caps, (const int32_t*)(as ? m->seg_cap_ent : m->seg_ray_ent), m->V, m->num_caps, E, seg_entries);
+}
+
 int tuch_ray_segment_flags(const tuch_contact_model* m, const float* verts, const float* caps, const int32_t* seg_count,
                            const int32_t* seg_list, const int32_t* leaf_counts, int B, int nsplit, float thresh,
                            float* seg_entries, int32_t* seg_partial, float* seg_w, uint8_t* seg_ext, uint8_t* exterior,
@@ -1054,11 +1066,8 @@ int tuch_ray_segment_flags(const tuch_contact_model* m, const float* verts, cons
 {
     const bool assisted = leaf_counts && m->seg_cap_off;
     const int E = assisted ? m->seg_cap_total : m->seg_ray_total;
-    const int32_t* ent = (const int32_t*)(assisted ? m->seg_cap_ent : m->seg_ray_ent);
     const int32_t* ent_off = (const int32_t*)(assisted ? m->seg_cap_off : m->seg_ray_off);
     float* partial_half = (float*)(seg_partial + (size_t)B * nsplit * m->seg_q_total);
-    hipLaunchKernelGGL(segment_shear_entries_kernel, dim3(ceil_div(E > 0 ? E : 1, kBlock), B), dim3(kBlock), 0, s,
-                       verts, caps, ent, m->V, m->num_caps, E, seg_entries);
     // work items behind the two partial arrays (B * num_seg_blocks int2 + 1 counter; the caller sizes seg_partial for it)
     int2* items = (int2*)(partial_half + (size_t)B * nsplit * m->seg_q_total);
     int32_t* items_total = (int32_t*)(items + (size_t)B * m->num_seg_blocks);

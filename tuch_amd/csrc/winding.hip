@@ -995,7 +995,23 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
     hipStream_t s = (hipStream_t)stream;
     int rc = TUCH_OK;
     const int ray = ray_mode(m);
-    if (ray == 2 || (ray == 1 && !w)) {
+    const bool segments = apply_segments && m->num_segments > 0;
+    const bool body_by_rays = ray == 2 || (ray == 1 && !w);
+    const bool segments_by_rays = segments && m->seg_link_off && (ray == 2 || (ray == 1 && !seg_w));
+    if (segments) {
+        // what the segment pass needs of the vertices alone goes first, off the critical chain behind the body test
+        hipLaunchKernelGGL(cap_centroid_kernel, dim3(m->num_caps, B), dim3(64), 0, s,
+                           verts, (const int32_t*)m->cap_off, (const int32_t*)m->cap_vidx, m->V,
+                           m->num_caps, (float*)(ws + l.caps));
+        if (hipMemsetAsync(ws + l.seg_count, 0, (size_t)B * m->num_segments * sizeof(int32_t), s) != hipSuccess) {
+            tuch_set_error("tuch_exterior_flags: hipMemsetAsync failed");
+            return TUCH_ERR_HIP;
+        }
+        if (segments_by_rays)
+            tuch_ray_segment_prepare(m, verts, (const float*)(ws + l.caps), body_by_rays && m->seg_elem_mask, B,
+                                     (float*)(ws + l.seg_tris), s);
+    }
+    if (body_by_rays) {
         rc = tuch_ray_exterior_verts(m, verts, B, thresh, exterior, w, ws + l.ray, s, nullptr);
         if (rc != TUCH_OK) return rc;
     } else if (use_strips() && use_tree(m)) {
@@ -1022,30 +1038,22 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
                                   l.bounds - l.partial, stream);
         if (rc != TUCH_OK) return rc;
     }
-    if (apply_segments && m->num_segments > 0) {
+    if (segments) {
         float* caps = (float*)(ws + l.caps);
         float* seg_tris = (float*)(ws + l.seg_tris);
-        hipLaunchKernelGGL(cap_centroid_kernel, dim3(m->num_caps, B), dim3(64), 0, s,
-                           verts, (const int32_t*)m->cap_off, (const int32_t*)m->cap_vidx, m->V,
-                           m->num_caps, caps);
         float* seg_partial = (float*)(ws + l.seg_partial);
         int32_t* seg_count = (int32_t*)(ws + l.seg_count);
         int32_t* seg_list = (int32_t*)(ws + l.seg_list);
         const bool all = seg_w || seg_exterior;     // the detailed outputs want every segment vertex
-        if (hipMemsetAsync(seg_count, 0, (size_t)B * m->num_segments * sizeof(int32_t), s) != hipSuccess) {
-            tuch_set_error("tuch_exterior_flags: hipMemsetAsync failed");
-            return TUCH_ERR_HIP;
-        }
         hipLaunchKernelGGL(segment_compact_kernel, dim3(ceil_div(m->seg_q_total, kBlock), B), dim3(kBlock), 0, s,
                            all ? (const uint8_t*)nullptr : (const uint8_t*)exterior, (const int32_t*)m->seg_of_q,
                            (const int32_t*)m->seg_q_off, (const int32_t*)m->seg_q_vidx, m->V, m->seg_q_total,
                            m->num_segments, seg_count, seg_list);
         // by ray crossings under the same rule as the body test (ray_mode: when only flags are wanted, or always with
         // TUCH_WINDING_RAY=2)
-        if (m->seg_link_off && (ray == 2 || (ray == 1 && !seg_w))) {
+        if (segments_by_rays) {
             // the body's inside test, when it ran by ray crossings just above, has left the crossings of every vertex
             // with the body faces of its segments
-            const bool body_by_rays = ray == 2 || (ray == 1 && !w);
             rc = tuch_ray_segment_flags(m, verts, caps, seg_count, seg_list,
                                         body_by_rays ? tuch_ray_segment_counts(m, B, ws + l.ray) : nullptr, B, seg_splits(),
                                         thresh, seg_tris, (int32_t*)seg_partial, seg_w, seg_exterior, exterior, s);
