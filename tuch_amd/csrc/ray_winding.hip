@@ -958,8 +958,8 @@ template <bool kVerts>
 static int launch_ray_counts(const tuch_contact_model* m, const RayLayout& l, const float* verts, const float* queries,
                              const int32_t* counts, int B, int Q, char* ws, hipStream_t s, unsigned long long* stats)
 {
-    launch_ray_boxes(m, l, verts, B, ws, s);
     if (hipMemsetAsync(ws + l.zeroed, 0, l.zeroed_bytes, s) != hipSuccess) return TUCH_ERR_HIP;
+    launch_ray_boxes(m, l, verts, B, ws, s);
     const int L = m->tree_leaves;
     const TreeNode* nodes = (const TreeNode*)m->tree_node;
     // the leaves are the height-0 entries of the tree's height table (tree_height_off_host[0] == 0)
