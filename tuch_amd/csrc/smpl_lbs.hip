@@ -13,7 +13,7 @@
 //                      blend-feature row [R[1:]-I | beta | 1].
 //   blend_kernel       MFMA GEMM  v_posed[B, 3V] = feat[B,220] x [posedirs; shapedirs^T; v_template]
 //   skin_kernel        per (body, vertex): T = sum_j W_vj A_j (A wave-uniform, scalar loads), verts
-//   extra_joints_kernel MFMA split-K GEMM  J_regressor_extra[9,V] x verts[B][V,3]
+//                      + per-workgroup partial sums of the extra-joint regression J_regressor_extra[9,V] x verts
 //   assemble_kernel    joints[49] via joint_map
 // Backward mirrors it: joints scatter, skinning adjoint (g_v_posed = T_R^T g_v and
 // g_A = W^T (g_v (x) [v_posed;1]) on MFMA), blend adjoint (MFMA split-K GEMM against the same
@@ -49,7 +49,6 @@ constexpr int kPicked = 21;
 constexpr int kExtra = 9;
 constexpr int kAllJoints = kJoints + kPicked + kExtra;   // 54
 constexpr int kOutJoints = 49;
-constexpr int kXChunks = 32;          // split-K chunks of the extra-joint regression
 constexpr int kBlendBwdChunk = 256;   // columns of 3V per split-K chunk in the blend adjoint
 constexpr int kSkinBlock = 256;
 
@@ -252,15 +251,20 @@ __global__ __launch_bounds__(256) void blend_kernel(
 }
 
 // verts[b][v] = (sum_j W[v][j] A[b][j]) [v_posed[b][v]; 1]
+// Also the extra-joint regression J_regressor_extra[9,V] x verts (models/smpl.py:47-48): every workgroup leaves the
+// contribution of its 256 vertices, xpart[b][block][9][3] (wave shuffles, then the four wavefronts through LDS: a fixed
+// order); assemble_joints_kernel adds the blocks up.  As a kernel of its own (MFMA split-K over the finished vertices)
+// the regression was 21 us of pure latency in front of everything that waits for the joints.
 __global__ __launch_bounds__(kSkinBlock) void skin_kernel(
     const float* __restrict__ v_posed, const float* __restrict__ A, const float* __restrict__ weights,
-    int V, float* __restrict__ verts)
+    const float* __restrict__ Jrx, int V, float* __restrict__ verts, float* __restrict__ xpart)
 {
     const int b = blockIdx.y;
     const int v = blockIdx.x * kSkinBlock + threadIdx.x;
-    if (v >= V) return;
+    const bool real = v < V;
+    const int vc = real ? v : V - 1;
     const float* Ab = A + (size_t)b * kJoints * 12;   // wave-uniform -> scalar loads
-    const float* w = weights + (size_t)v * kJoints;
+    const float* w = weights + (size_t)vc * kJoints;
     float T[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) T[e] = 0.f;
@@ -270,41 +274,39 @@ __global__ __launch_bounds__(kSkinBlock) void skin_kernel(
 #pragma unroll
         for (int e = 0; e < 12; ++e) T[e] = __builtin_fmaf(wj, Ab[j * 12 + e], T[e]);
     }
-    const float* p = v_posed + ((size_t)b * V + v) * 3;
-    float* o = verts + ((size_t)b * V + v) * 3;
+    const float* p = v_posed + ((size_t)b * V + vc) * 3;
+    float o[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) o[i] = T[3 * i] * p[0] + T[3 * i + 1] * p[1] + T[3 * i + 2] * p[2] + T[9 + i];
-}
-
-// partial[chunk][m][n] = sum_{v in chunk} Jrx[m][v] * verts[b(n)][v][c(n)],  n = 3 b + c.
-// One wave per (16-column block of n, K chunk).
-__global__ __launch_bounds__(64) void extra_joints_kernel(
-    const float* __restrict__ Jrx, const float* __restrict__ verts, int B, int V, int v_per_chunk,
-    float* __restrict__ partial)   // [kXChunks][16][Npad], Npad = 16 * gridDim.x
-{
-    const int lane = threadIdx.x, lm = lane & 15, lq = lane >> 4;
-    const int n = blockIdx.x * 16 + lm;
-    const int chunk = blockIdx.y;
-    const int nb = min(n / 3, B - 1), nc = n % 3;
-    const bool n_ok = n < 3 * B;
-    const int v_beg = chunk * v_per_chunk, v_end = min(V, v_beg + v_per_chunk);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int v0 = v_beg; v0 < v_end; v0 += 4) {
-        const int v = v0 + lq;
-        const bool ok = v < v_end;
-        const float a = (ok && lm < kExtra) ? Jrx[(size_t)lm * V + v] : 0.f;
-        const float bb = (ok && n_ok) ? verts[((size_t)nb * V + v) * 3 + nc] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb, acc, 0, 0, 0);
+    if (real) {
+        float* dst = verts + ((size_t)b * V + v) * 3;
+        dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
     }
-    const int npad = 16 * gridDim.x;
+    __shared__ float red[kSkinBlock / 64][kExtra * 3];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-        partial[((size_t)chunk * 16 + lq * 4 + r) * npad + n] = acc[r];
+    for (int m = 0; m < kExtra; ++m) {
+        const float jr = real ? Jrx[(size_t)m * V + v] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float t = jr * o[c];
+#pragma unroll
+            for (int k = 32; k >= 1; k >>= 1) t += __shfl_xor(t, k);
+            if (lane == 0) red[wave][m * 3 + c] = t;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kExtra * 3) {
+        float t = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < kSkinBlock / 64; ++wv) t += red[wv][threadIdx.x];
+        xpart[((size_t)b * gridDim.x + blockIdx.x) * (kExtra * 3) + threadIdx.x] = t;
+    }
 }
 
 __global__ __launch_bounds__(64) void assemble_joints_kernel(
-    const float* __restrict__ world, const float* __restrict__ verts, const float* __restrict__ partial,
-    const int32_t* __restrict__ extra_ids, const int32_t* __restrict__ joint_map, int V, int npad,
+    const float* __restrict__ world, const float* __restrict__ verts, const float* __restrict__ xpart,
+    const int32_t* __restrict__ extra_ids, const int32_t* __restrict__ joint_map, int V, int skin_blocks,
     float* __restrict__ joints)   // [B,49,3]
 {
     const int b = blockIdx.x;
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(64) void assemble_joints_kernel(
         else {
             val = 0.f;
             const int m = src - kJoints - kPicked;
-            for (int ch = 0; ch < kXChunks; ++ch) val += partial[((size_t)ch * 16 + m) * npad + 3 * b + c];
+            for (int blk = 0; blk < skin_blocks; ++blk) val += xpart[((size_t)b * skin_blocks + blk) * (kExtra * 3) + 3 * m + c];
         }
         joints[(size_t)b * kOutJoints * 3 + i] = val;
     }
@@ -587,7 +589,7 @@ FwdLayout fwd_layout(const tuch_smpl_model* m, int B)
     l.A = o;       o += align256((size_t)B * kJoints * 12 * 4);
     l.feat = o;    o += align256((size_t)l.bpad * kFeat * 4);
     l.v_posed = o; o += align256((size_t)B * m->N3 * 4);
-    l.partial = o; o += align256((size_t)kXChunks * 16 * l.npad * 4);
+    l.partial = o; o += align256((size_t)B * ceil_div(m->V, kSkinBlock) * kExtra * 3 * 4);   // xpart of skin_kernel
     l.total = o;
     return l;
 }
@@ -725,12 +727,10 @@ extern "C" int tuch_smpl_forward(const tuch_smpl_model* m, const float* betas, c
     hipLaunchKernelGGL(blend_kernel, dim3(ceil_div(ceil_div(m->N3, 64), 4), l.bpad / 16), dim3(256), 0, s,
                        (const float*)feat, (const float*)m->blend, B, m->N3, v_posed);
     hipLaunchKernelGGL(skin_kernel, dim3(ceil_div(m->V, kSkinBlock), B), dim3(kSkinBlock), 0, s,
-                       (const float*)v_posed, (const float*)A, (const float*)m->weights, m->V, verts);
-    hipLaunchKernelGGL(extra_joints_kernel, dim3(l.npad / 16, kXChunks), dim3(64), 0, s, (const float*)m->Jrx,
-                       (const float*)verts, B, m->V, ceil_div(ceil_div(m->V, kXChunks), 4) * 4, partial);
+                       (const float*)v_posed, (const float*)A, (const float*)m->weights, (const float*)m->Jrx, m->V, verts, partial);
     hipLaunchKernelGGL(assemble_joints_kernel, dim3(B), dim3(64), 0, s, (const float*)world, (const float*)verts,
                        (const float*)partial, (const int32_t*)m->extra_ids, (const int32_t*)m->joint_map, m->V,
-                       l.npad, joints);
+                       ceil_div(m->V, kSkinBlock), joints);
     return tuch_check_launch("tuch_smpl_forward");
 }
 
