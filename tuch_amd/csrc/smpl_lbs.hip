@@ -250,10 +250,24 @@ __global__ __launch_bounds__(256) void blend_kernel(
     }
 }
 
+// One level of the transposing wavefront reduction: lanes whose bit `2*kHalf` differs swap halves of their value set.
+template <int kHalf>
+__device__ __forceinline__ void butterfly_level(float (&val)[32], int lane)
+{
+    constexpr int bit = 2 * kHalf;
+    const bool upper = (lane & bit) != 0;
+#pragma unroll
+    for (int k = 0; k < kHalf; ++k) {
+        const float send = upper ? val[k] : val[k + kHalf];
+        const float keep = upper ? val[k + kHalf] : val[k];
+        val[k] = keep + __shfl_xor(send, bit);
+    }
+}
+
 // verts[b][v] = (sum_j W[v][j] A[b][j]) [v_posed[b][v]; 1]
 // Also the extra-joint regression J_regressor_extra[9,V] x verts (models/smpl.py:47-48): every workgroup leaves the
-// contribution of its 256 vertices, xpart[b][block][9][3] (wave shuffles, then the four wavefronts through LDS: a fixed
-// order); assemble_joints_kernel adds the blocks up.  As a kernel of its own (MFMA split-K over the finished vertices)
+// contribution of its 256 vertices, xpart[b][block][9][3] (a transposing butterfly over the wavefront, then the four
+// wavefronts through LDS: a fixed order); assemble_joints_kernel adds the blocks up.  As a kernel of its own (MFMA split-K over the finished vertices)
 // the regression was 21 us of pure latency in front of everything that waits for the joints.
 __global__ __launch_bounds__(kSkinBlock) void skin_kernel(
     const float* __restrict__ v_posed, const float* __restrict__ A, const float* __restrict__ weights,
@@ -282,19 +296,26 @@ __global__ __launch_bounds__(kSkinBlock) void skin_kernel(
         float* dst = verts + ((size_t)b * V + v) * 3;
         dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
     }
-    __shared__ float red[kSkinBlock / 64][kExtra * 3];
+    __shared__ float red[kSkinBlock / 64][32];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // 27 sums over the wavefront by a transposing butterfly: at every level a lane hands half of its values to its
+    // partner and adds the partner's other half -- 16 + 8 + 4 + 2 + 1 (+ 1) shuffles instead of 27 x 6
+    float val[32];
 #pragma unroll
     for (int m = 0; m < kExtra; ++m) {
         const float jr = real ? Jrx[(size_t)m * V + v] : 0.f;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float t = jr * o[c];
-#pragma unroll
-            for (int k = 32; k >= 1; k >>= 1) t += __shfl_xor(t, k);
-            if (lane == 0) red[wave][m * 3 + c] = t;
-        }
+        for (int c = 0; c < 3; ++c) val[m * 3 + c] = jr * o[c];
     }
+#pragma unroll
+    for (int k = kExtra * 3; k < 32; ++k) val[k] = 0.f;
+    butterfly_level<16>(val, lane);
+    butterfly_level<8>(val, lane);
+    butterfly_level<4>(val, lane);
+    butterfly_level<2>(val, lane);
+    butterfly_level<1>(val, lane);
+    val[0] += __shfl_xor(val[0], 1);
+    if ((lane & 1) == 0) red[wave][lane >> 1] = val[0];        // value index = bits 5..1 of the lane
     __syncthreads();
     if (threadIdx.x < kExtra * 3) {
         float t = 0.f;
