@@ -260,12 +260,22 @@ int tuch_smpl_model_info(const tuch_smpl_model* model, int* V);
 size_t tuch_smpl_forward_workspace_bytes(const tuch_smpl_model* model, int B);
 int tuch_smpl_forward(const tuch_smpl_model* model, const float* betas, const float* pose, int pose2rot, int B,
                       float* verts, float* joints, void* workspace, size_t workspace_bytes, void* stream);
+/* The same with the pose as SMPL.forward's caller holds it (tuch/models/smpl.py:44-47: global_orient [B,3] / [B,1,3,3]
+ * and body_pose [B,69] / [B,23,3,3], two tensors): no concatenated copy; row strides in floats, so views work too. */
+int tuch_smpl_forward_split(const tuch_smpl_model* model, const float* betas, const float* global_orient,
+                            int global_orient_stride, const float* body_pose, int body_pose_stride, int pose2rot, int B,
+                            float* verts, float* joints, void* workspace, size_t workspace_bytes, void* stream);
 /* Adjoint: g_verts [B,V,3] / g_joints [B,49,3] (either may be NULL) -> g_betas [B,10],
  * g_pose [B,72] or [B,24,3,3]. */
 size_t tuch_smpl_backward_workspace_bytes(const tuch_smpl_model* model, int B);
 int tuch_smpl_backward(const tuch_smpl_model* model, const float* pose, int pose2rot, int B,
                        const void* fwd_workspace, const float* g_verts, const float* g_joints, float* g_betas,
                        float* g_pose, void* workspace, size_t workspace_bytes, void* stream);
+int tuch_smpl_backward_split(const tuch_smpl_model* model, const float* global_orient, int global_orient_stride,
+                             const float* body_pose, int body_pose_stride, int pose2rot, int B,
+                             const void* fwd_workspace, const float* g_verts, const float* g_joints, float* g_betas,
+                             float* g_global_orient, int g_global_orient_stride, float* g_body_pose,
+                             int g_body_pose_stride, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- caller-side glue of the training step ----------------------------------------
  * tuch_estimate_translation: tuch/utils/geometry.py:114-205 (estimate_translation + estimate_translation_np):

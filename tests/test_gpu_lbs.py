@@ -87,3 +87,26 @@ def test_joints_only_and_verts_only_gradients(bodies):
         out = smpl(betas=be, body_pose=bp_, global_orient=go)
         getattr(out, which).sum().backward()
         assert torch.isfinite(bp_.grad).all() and bp_.grad.abs().sum() > 0
+
+
+@pytest.mark.parametrize('pose2rot', [True, False])
+def test_concatenated_pose_and_the_two_pose_tensors_agree(bodies, pose2rot):
+    """tuch/models/smpl.py:44-47 concatenates global_orient and body_pose; the kernels read the two tensors directly.
+    Row views of ONE [B,72] / [B,24,9] pose (strided rows) must give the same bits, and the same gradient."""
+    from tuch_amd import lbs
+    body = bodies['tiny']
+    smpl = _smpl(body)
+    bp, go, be = [torch.tensor(a, device=DEV) for a in random_poses(5, 11)]
+    if not pose2rot:
+        rot = ol.rodrigues(torch.cat([go, bp], 1).reshape(-1, 3).cpu()).reshape(5, 24, 9).to(DEV)
+        go, bp = rot[:, :1].reshape(5, 9).contiguous(), rot[:, 1:].reshape(5, 207).contiguous()
+    full = torch.cat([go, bp], 1).requires_grad_(True)
+    go_, bp_ = go.clone().requires_grad_(True), bp.clone().requires_grad_(True)
+    v1, j1 = lbs.smpl_forward(smpl, be, full, pose2rot)
+    out = smpl(betas=be, body_pose=bp_, global_orient=go_, pose2rot=pose2rot, return_full_pose=True)
+    assert torch.equal(v1, out.vertices) and torch.equal(j1, out.joints)
+    assert torch.equal(out.full_pose.reshape(5, -1), full.detach())
+    w = torch.linspace(0.5, 1.5, v1.numel(), device=DEV).reshape(v1.shape)
+    ((v1 * w).sum() + j1.sum()).backward()
+    ((out.vertices * w).sum() + out.joints.sum()).backward()
+    assert torch.equal(full.grad, torch.cat([go_.grad, bp_.grad], 1))

@@ -100,6 +100,11 @@ _SIGNATURES = {
                                   c_size_t, c_void_p]),
     'tuch_smpl_backward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_size_t, c_void_p]),
+    'tuch_smpl_forward_split': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
+                                        c_void_p, c_void_p, c_size_t, c_void_p]),
+    'tuch_smpl_backward_split': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t,
+                                         c_void_p]),
     'tuch_region_pair_min_bwd': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
@@ -141,6 +146,15 @@ def ptr(t) -> c_void_p:
         raise TuchError('tuch_amd kernels need tensors on a HIP device, got %s' % t.device)
     if not t.is_contiguous():
         raise TuchError('tuch_amd kernels need contiguous tensors')
+    return c_void_p(t.data_ptr())
+
+
+def row_ptr(t) -> c_void_p:
+    """Device pointer of a 2-D tensor whose rows are contiguous (the row stride goes to the kernel separately)."""
+    if not t.is_cuda:
+        raise TuchError('tuch_amd kernels need tensors on a HIP device, got %s' % t.device)
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise TuchError('tuch_amd kernels need contiguous rows')
     return c_void_p(t.data_ptr())
 
 

@@ -137,10 +137,24 @@ __device__ __forceinline__ void rodrigues_bwd(const float* aa, const M3& g, floa
     g_aa[2] = gd[2] / th + g_th * ez / th;
 }
 
+// The pose as the callers hold it: the root rotation (global_orient) and the 23 body rotations (body_pose) are two
+// tensors in the reference's API (models/smpl.py:44-47 concatenates them); joint t of body b is read from / its gradient
+// written to the right one directly.  w = 3 (axis-angle) or 9 (rotation matrix) floats per joint; strides in floats.
+struct PoseRef { const float* root; const float* body; int root_stride, body_stride; };
+struct PoseGrad { float* root; float* body; int root_stride, body_stride; };
+__device__ __forceinline__ const float* pose_joint(const PoseRef& p, int b, int t, int w)
+{
+    return t == 0 ? p.root + (size_t)b * p.root_stride : p.body + (size_t)b * p.body_stride + (size_t)(t - 1) * w;
+}
+__device__ __forceinline__ float* pose_joint(const PoseGrad& p, int b, int t, int w)
+{
+    return t == 0 ? p.root + (size_t)b * p.root_stride : p.body + (size_t)b * p.body_stride + (size_t)(t - 1) * w;
+}
+
 // ------------------------------------------------------------------------------------ forward
 // One block (64 threads) per body.
 __global__ __launch_bounds__(64) void pose_kernel(
-    const float* __restrict__ betas, const float* __restrict__ pose, int pose2rot,
+    const float* __restrict__ betas, PoseRef pose, int pose2rot,
     const float* __restrict__ J_template, const float* __restrict__ J_shapedirs,
     const int32_t* __restrict__ parents,
     float* __restrict__ R_out,      // [B,24,9]
@@ -155,10 +169,11 @@ __global__ __launch_bounds__(64) void pose_kernel(
     const float* be = betas + (size_t)b * kBetas;
     if (t < kJoints) {
         M3 r;
-        if (pose2rot) r = rodrigues(pose + ((size_t)b * kJoints + t) * 3);
+        if (pose2rot) r = rodrigues(pose_joint(pose, b, t, 3));
         else {
+            const float* src = pose_joint(pose, b, t, 9);
 #pragma unroll
-            for (int e = 0; e < 9; ++e) r.m[e] = pose[((size_t)b * kJoints + t) * 9 + e];
+            for (int e = 0; e < 9; ++e) r.m[e] = src[e];
         }
 #pragma unroll
         for (int e = 0; e < 9; ++e) {
@@ -499,9 +514,9 @@ __global__ __launch_bounds__(64) void blend_bwd_kernel(
 __global__ __launch_bounds__(256) void pose_bwd_kernel(
     const float* __restrict__ gA_part, int skin_blocks, const float* __restrict__ feat_part, int feat_chunks,
     int bpad, const float* __restrict__ g_all, const float* __restrict__ R, const float* __restrict__ J,
-    const float* __restrict__ world, const float* __restrict__ pose, int pose2rot,
+    const float* __restrict__ world, PoseRef pose, int pose2rot,
     const float* __restrict__ J_shapedirs, const int32_t* __restrict__ parents,
-    float* __restrict__ g_pose, float* __restrict__ g_betas)
+    PoseGrad g_pose, float* __restrict__ g_betas)
 {
     __shared__ float sGA[kJoints][12];
     __shared__ float sGF[224];
@@ -580,12 +595,14 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(
         for (int e = 0; e < 9; ++e) g.m[e] = sGR[t][e] + (t > 0 ? sGF[(t - 1) * 9 + e] : 0.f);
         if (pose2rot) {
             float ga[3];
-            rodrigues_bwd(pose + ((size_t)b * kJoints + t) * 3, g, ga);
+            rodrigues_bwd(pose_joint(pose, b, t, 3), g, ga);
+            float* dst = pose_joint(g_pose, b, t, 3);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) g_pose[((size_t)b * kJoints + t) * 3 + c] = ga[c];
+            for (int c = 0; c < 3; ++c) dst[c] = ga[c];
         } else {
+            float* dst = pose_joint(g_pose, b, t, 9);
 #pragma unroll
-            for (int e = 0; e < 9; ++e) g_pose[((size_t)b * kJoints + t) * 9 + e] = g.m[e];
+            for (int e = 0; e < 9; ++e) dst[e] = g.m[e];
         }
     }
     if (t >= 32 && t < 32 + kBetas) {
@@ -726,14 +743,19 @@ extern "C" size_t tuch_smpl_backward_workspace_bytes(const tuch_smpl_model* m, i
     return (m && B > 0) ? bwd_layout(m, B).total : 0;
 }
 
-// pose: [B,72] axis-angle (pose2rot) or [B,24,3,3] rotation matrices.  The forward workspace
-// holds the intermediates the backward pass needs and must be kept alive until then.
-extern "C" int tuch_smpl_forward(const tuch_smpl_model* m, const float* betas, const float* pose, int pose2rot,
-                                 int B, float* verts, float* joints, void* workspace, size_t workspace_bytes,
-                                 void* stream)
+// global_orient: [B,3] axis-angle (pose2rot) or [B,1,3,3]; body_pose: [B,69] or [B,23,3,3] -- the two tensors of
+// SMPL.forward (models/smpl.py:44-47), with row strides in floats so that views of one [B,72] pose work as well.
+// The forward workspace holds the intermediates the backward pass needs and must be kept alive until then.
+extern "C" int tuch_smpl_forward_split(const tuch_smpl_model* m, const float* betas, const float* global_orient,
+                                       int global_orient_stride, const float* body_pose, int body_pose_stride,
+                                       int pose2rot, int B, float* verts, float* joints, void* workspace,
+                                       size_t workspace_bytes, void* stream)
 {
-    TUCH_REQUIRE(m && betas && pose && verts && joints, "tuch_smpl_forward: null pointer");
+    TUCH_REQUIRE(m && betas && global_orient && body_pose && verts && joints, "tuch_smpl_forward: null pointer");
     TUCH_REQUIRE(B > 0 && B <= 65535, "tuch_smpl_forward: bad batch %d", B);
+    const int w = pose2rot ? 3 : 9;
+    TUCH_REQUIRE(global_orient_stride >= w && body_pose_stride >= 23 * w, "tuch_smpl_forward: bad pose strides %d, %d",
+                 global_orient_stride, body_pose_stride);
     const FwdLayout l = fwd_layout(m, B);
     if (!workspace || workspace_bytes < l.total) {
         tuch_set_error("tuch_smpl_forward: workspace %zu < %zu bytes", workspace_bytes, l.total);
@@ -743,6 +765,7 @@ extern "C" int tuch_smpl_forward(const tuch_smpl_model* m, const float* betas, c
     float *R = (float*)(ws + l.R), *J = (float*)(ws + l.J), *world = (float*)(ws + l.world), *A = (float*)(ws + l.A),
           *feat = (float*)(ws + l.feat), *v_posed = (float*)(ws + l.v_posed), *partial = (float*)(ws + l.partial);
     hipStream_t s = (hipStream_t)stream;
+    const PoseRef pose{global_orient, body_pose, global_orient_stride, body_pose_stride};
     hipLaunchKernelGGL(pose_kernel, dim3(B), dim3(64), 0, s, betas, pose, pose2rot, (const float*)m->J_template,
                        (const float*)m->J_shapedirs, (const int32_t*)m->parents, R, J, world, A, feat);
     hipLaunchKernelGGL(blend_kernel, dim3(ceil_div(ceil_div(m->N3, 64), 4), l.bpad / 16), dim3(256), 0, s,
@@ -755,15 +778,34 @@ extern "C" int tuch_smpl_forward(const tuch_smpl_model* m, const float* betas, c
     return tuch_check_launch("tuch_smpl_forward");
 }
 
-// g_verts [B,V,3] and/or g_joints [B,49,3] (either may be NULL) -> g_betas [B,10] and
-// g_pose ([B,72] or [B,24,3,3]).
-extern "C" int tuch_smpl_backward(const tuch_smpl_model* m, const float* pose, int pose2rot, int B,
-                                  const void* fwd_workspace, const float* g_verts, const float* g_joints,
-                                  float* g_betas, float* g_pose, void* workspace, size_t workspace_bytes,
-                                  void* stream)
+// pose: [B,72] axis-angle (pose2rot) or [B,24,3,3] rotation matrices: the concatenated form of the above.
+extern "C" int tuch_smpl_forward(const tuch_smpl_model* m, const float* betas, const float* pose, int pose2rot,
+                                 int B, float* verts, float* joints, void* workspace, size_t workspace_bytes,
+                                 void* stream)
 {
-    TUCH_REQUIRE(m && pose && fwd_workspace && g_betas && g_pose, "tuch_smpl_backward: null pointer");
+    TUCH_REQUIRE(pose, "tuch_smpl_forward: null pointer");
+    const int w = pose2rot ? 3 : 9;
+    return tuch_smpl_forward_split(m, betas, pose, kJoints * w, pose + w, kJoints * w, pose2rot, B, verts, joints,
+                                   workspace, workspace_bytes, stream);
+}
+
+// g_verts [B,V,3] and/or g_joints [B,49,3] (either may be NULL) -> g_betas [B,10] and
+// the pose gradient, written as the two tensors of tuch_smpl_forward_split (same shapes, strides in floats).
+extern "C" int tuch_smpl_backward_split(const tuch_smpl_model* m, const float* global_orient, int global_orient_stride,
+                                        const float* body_pose, int body_pose_stride, int pose2rot, int B,
+                                        const void* fwd_workspace, const float* g_verts, const float* g_joints,
+                                        float* g_betas, float* g_global_orient, int g_global_orient_stride,
+                                        float* g_body_pose, int g_body_pose_stride, void* workspace,
+                                        size_t workspace_bytes, void* stream)
+{
+    TUCH_REQUIRE(m && global_orient && body_pose && fwd_workspace && g_betas && g_global_orient && g_body_pose,
+                 "tuch_smpl_backward: null pointer");
     TUCH_REQUIRE(B > 0 && B <= 65535, "tuch_smpl_backward: bad batch %d", B);
+    const int w = pose2rot ? 3 : 9;
+    TUCH_REQUIRE(global_orient_stride >= w && body_pose_stride >= 23 * w && g_global_orient_stride >= w &&
+                 g_body_pose_stride >= 23 * w, "tuch_smpl_backward: bad pose strides");
+    const PoseRef pose{global_orient, body_pose, global_orient_stride, body_pose_stride};
+    const PoseGrad g_pose{g_global_orient, g_body_pose, g_global_orient_stride, g_body_pose_stride};
     const FwdLayout f = fwd_layout(m, B);
     const BwdLayout l = bwd_layout(m, B);
     if (!workspace || workspace_bytes < l.total) {
@@ -794,6 +836,19 @@ extern "C" int tuch_smpl_backward(const tuch_smpl_model* m, const float* pose, i
                        (const float*)feat_part, 1, l.bpad, (const float*)g_all, R, J, world, pose, pose2rot,
                        (const float*)m->J_shapedirs, (const int32_t*)m->parents, g_pose, g_betas);
     return tuch_check_launch("tuch_smpl_backward");
+}
+
+// pose / g_pose: [B,72] or [B,24,3,3], the concatenated form.
+extern "C" int tuch_smpl_backward(const tuch_smpl_model* m, const float* pose, int pose2rot, int B,
+                                  const void* fwd_workspace, const float* g_verts, const float* g_joints,
+                                  float* g_betas, float* g_pose, void* workspace, size_t workspace_bytes,
+                                  void* stream)
+{
+    TUCH_REQUIRE(pose && g_pose, "tuch_smpl_backward: null pointer");
+    const int w = pose2rot ? 3 : 9;
+    return tuch_smpl_backward_split(m, pose, kJoints * w, pose + w, kJoints * w, pose2rot, B, fwd_workspace, g_verts,
+                                    g_joints, g_betas, g_pose, kJoints * w, g_pose + w, kJoints * w, workspace,
+                                    workspace_bytes, stream);
 }
 
 extern "C" int tuch_smpl_model_info(const tuch_smpl_model* m, int* V)

@@ -41,44 +41,71 @@ class SmplDeviceModel:
             self._handle = None
 
 
+def _pose_rows(t, n):
+    """[B,n] float32 rows of a pose tensor; row views of one concatenated [B,72] pose pass as they are (row stride)."""
+    r = t.detach().to(torch.float32).reshape(-1, n)
+    return r if r.stride(1) == 1 and r.stride(0) >= n else r.contiguous()
+
+
 class _SmplLBS(torch.autograd.Function):
+    """betas [B,10], global_orient [B,3] / [B,1,3,3], body_pose [B,69] / [B,23,3,3] -> vertices, joints.  The two pose
+    tensors go to the kernels as they are (no concatenated copy, and the gradient comes back as two tensors)."""
+
     @staticmethod
-    def forward(ctx, betas, pose, dm: SmplDeviceModel, pose2rot: bool):
+    def forward(ctx, betas, global_orient, body_pose, dm: SmplDeviceModel, pose2rot: bool):
         L = _C.lib()
+        w = 3 if pose2rot else 9
         be = betas.detach().to(torch.float32).contiguous()
-        po = pose.detach().to(torch.float32).contiguous()
-        b = po.shape[0]
+        go, bp = _pose_rows(global_orient, w), _pose_rows(body_pose, 23 * w)
+        b = go.shape[0]
+        if bp.shape[0] != b or be.shape[0] != b:
+            raise ValueError(f'SMPL: batch sizes differ (betas {be.shape[0]}, global_orient {b}, body_pose {bp.shape[0]})')
         verts = torch.empty(b, dm.num_verts, 3, dtype=torch.float32, device=be.device)
         joints = torch.empty(b, 49, 3, dtype=torch.float32, device=be.device)
         nbytes = L.tuch_smpl_forward_workspace_bytes(dm._handle, b)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=be.device)
-        _C.check(L.tuch_smpl_forward(dm._handle, _C.ptr(be), _C.ptr(po), int(pose2rot), b, _C.ptr(verts),
-                                     _C.ptr(joints), _C.ptr(ws), nbytes, _C.stream()))
-        ctx.dm, ctx.pose2rot, ctx.pose_shape = dm, bool(pose2rot), pose.shape
-        ctx.save_for_backward(po, ws)
+        _C.check(L.tuch_smpl_forward_split(dm._handle, _C.ptr(be), _C.row_ptr(go), go.stride(0), _C.row_ptr(bp), bp.stride(0),
+                                           int(pose2rot), b, _C.ptr(verts), _C.ptr(joints), _C.ptr(ws), nbytes, _C.stream()))
+        ctx.dm, ctx.pose2rot = dm, bool(pose2rot)
+        ctx.shapes = (global_orient.shape, body_pose.shape)
+        ctx.save_for_backward(go, bp, ws)
         return verts, joints
 
     @staticmethod
     def backward(ctx, g_verts, g_joints):
         L = _C.lib()
-        po, ws = ctx.saved_tensors
-        b = po.shape[0]
+        go, bp, ws = ctx.saved_tensors
+        b = go.shape[0]
+        w = go.shape[1]
         gv = g_verts.to(torch.float32).contiguous() if g_verts is not None else None
         gj = g_joints.to(torch.float32).contiguous() if g_joints is not None else None
-        g_betas = torch.empty(b, 10, dtype=torch.float32, device=po.device)
-        g_pose = torch.empty(po.shape, dtype=torch.float32, device=po.device)
+        g_betas = torch.empty(b, 10, dtype=torch.float32, device=go.device)
+        g_go = torch.empty(go.shape, dtype=torch.float32, device=go.device)
+        g_bp = torch.empty(bp.shape, dtype=torch.float32, device=go.device)
         nbytes = L.tuch_smpl_backward_workspace_bytes(ctx.dm._handle, b)
-        ws2 = torch.empty(nbytes, dtype=torch.uint8, device=po.device)
-        _C.check(L.tuch_smpl_backward(ctx.dm._handle, _C.ptr(po), int(ctx.pose2rot), b, _C.ptr(ws), _C.ptr(gv),
-                                      _C.ptr(gj), _C.ptr(g_betas), _C.ptr(g_pose), _C.ptr(ws2), nbytes,
-                                      _C.stream()))
-        return g_betas, g_pose.view(ctx.pose_shape), None, None
+        ws2 = torch.empty(nbytes, dtype=torch.uint8, device=go.device)
+        _C.check(L.tuch_smpl_backward_split(ctx.dm._handle, _C.row_ptr(go), go.stride(0), _C.row_ptr(bp), bp.stride(0),
+                                            int(ctx.pose2rot), b, _C.ptr(ws), _C.ptr(gv), _C.ptr(gj),
+                                            _C.ptr(g_betas), _C.ptr(g_go), w, _C.ptr(g_bp), 23 * w, _C.ptr(ws2),
+                                            nbytes, _C.stream()))
+        return g_betas, g_go.view(ctx.shapes[0]), g_bp.view(ctx.shapes[1]), None, None
+
+
+def _device_model(smpl_module, device):
+    dm = getattr(smpl_module, '_device_model', None)
+    if dm is None or dm.device != device:
+        dm = SmplDeviceModel(smpl_module, device)
+        object.__setattr__(smpl_module, '_device_model', dm)
+    return dm
+
+
+def smpl_forward_split(smpl_module, betas, global_orient, body_pose, pose2rot=True):
+    """(vertices [B,V,3], joints [B,49,3]) from the two pose tensors of SMPL.forward (tuch/models/smpl.py:44-47)."""
+    return _SmplLBS.apply(betas, global_orient, body_pose, _device_model(smpl_module, betas.device), pose2rot)
 
 
 def smpl_forward(smpl_module, betas, full_pose, pose2rot=True):
     """(vertices [B,V,3], joints [B,49,3]) for betas [B,10] and full_pose [B,72] / [B,24,3,3]."""
-    dm = getattr(smpl_module, '_device_model', None)
-    if dm is None or dm.device != betas.device:
-        dm = SmplDeviceModel(smpl_module, betas.device)
-        object.__setattr__(smpl_module, '_device_model', dm)
-    return _SmplLBS.apply(betas, full_pose, dm, pose2rot)
+    w = 3 if pose2rot else 9
+    flat = full_pose.reshape(full_pose.shape[0], 24 * w)
+    return smpl_forward_split(smpl_module, betas, flat[:, :w], flat[:, w:], pose2rot)

@@ -204,12 +204,18 @@ class SMPL(nn.Module):
                 return_full_pose=False, **kwargs):
         """Reference: tuch/models/smpl.py:44-56 over smplx SMPL.forward."""
         from .. import lbs
-        if pose2rot:
-            full_pose = torch.cat([global_orient.reshape(-1, 3), body_pose.reshape(-1, 69)], dim=1)
-        else:
-            full_pose = torch.cat([global_orient.reshape(-1, 1, 3, 3), body_pose.reshape(-1, 23, 3, 3)], dim=1)
-        if betas.shape[0] != full_pose.shape[0]:
-            betas = betas.expand(full_pose.shape[0], -1)
-        vertices, joints = lbs.smpl_forward(self, betas, full_pose, pose2rot)
+        w = 3 if pose2rot else 9
+        global_orient_rows = global_orient.reshape(-1, w)
+        body_pose_rows = body_pose.reshape(-1, 23 * w)
+        if betas.shape[0] != body_pose_rows.shape[0]:
+            betas = betas.expand(body_pose_rows.shape[0], -1)
+        # the kernels read the two pose tensors where they are; the concatenation of models/smpl.py:44-47 only on request
+        vertices, joints = lbs.smpl_forward_split(self, betas, global_orient_rows, body_pose_rows, pose2rot)
+        full_pose = None
+        if return_full_pose:
+            if pose2rot:
+                full_pose = torch.cat([global_orient_rows, body_pose_rows], dim=1)
+            else:
+                full_pose = torch.cat([global_orient.reshape(-1, 1, 3, 3), body_pose.reshape(-1, 23, 3, 3)], dim=1)
         return ModelOutput(vertices=vertices, joints=joints, betas=betas, global_orient=global_orient,
-                           body_pose=body_pose, full_pose=full_pose if return_full_pose else None)
+                           body_pose=body_pose, full_pose=full_pose)
