@@ -49,7 +49,6 @@ constexpr int kPicked = 21;
 constexpr int kExtra = 9;
 constexpr int kAllJoints = kJoints + kPicked + kExtra;   // 54
 constexpr int kOutJoints = 49;
-constexpr int kBlendBwdChunk = 256;   // columns of 3V per split-K chunk in the blend adjoint
 constexpr int kSkinBlock = 256;
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -161,7 +160,7 @@ __global__ __launch_bounds__(64) void pose_kernel(
     float* __restrict__ J_out,      // [B,24,3]
     float* __restrict__ world_out,  // [B,24,12] world rotation | world translation (= posed joint)
     float* __restrict__ A_out,      // [B,24,12] rotation | translation relative to the rest pose
-    float* __restrict__ feat)       // [Bpad,220]
+    float* __restrict__ feat, int fpad)       // [220][fpad]: feature-major, bodies contiguous (blend_kernel)
 {
     __shared__ float sR[kJoints][9];
     __shared__ float sJ[kJoints][3];
@@ -179,7 +178,7 @@ __global__ __launch_bounds__(64) void pose_kernel(
         for (int e = 0; e < 9; ++e) {
             sR[t][e] = r.m[e];
             R_out[((size_t)b * kJoints + t) * 9 + e] = r.m[e];
-            if (t > 0) feat[(size_t)b * kFeat + (t - 1) * 9 + e] = r.m[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
+            if (t > 0) feat[(size_t)((t - 1) * 9 + e) * fpad + b] = r.m[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
         }
     }
     for (int i = t; i < kJoints * 3; i += 64) {
@@ -189,11 +188,11 @@ __global__ __launch_bounds__(64) void pose_kernel(
         sJ[i / 3][i % 3] = acc;
         J_out[(size_t)b * kJoints * 3 + i] = acc;
     }
-    if (t < kBetas) feat[(size_t)b * kFeat + kPoseFeat + t] = be[t];
+    if (t < kBetas) feat[(size_t)(kPoseFeat + t) * fpad + b] = be[t];
     if (t == 0) {
-        feat[(size_t)b * kFeat + 217] = 1.0f;
-        feat[(size_t)b * kFeat + 218] = 0.0f;
-        feat[(size_t)b * kFeat + 219] = 0.0f;
+        feat[(size_t)217 * fpad + b] = 1.0f;
+        feat[(size_t)218 * fpad + b] = 0.0f;
+        feat[(size_t)219 * fpad + b] = 0.0f;
     }
     __syncthreads();
     if (t == 0) {
@@ -228,39 +227,76 @@ __global__ __launch_bounds__(64) void pose_kernel(
     }
 }
 
-// v_posed[b][n] = sum_k feat[b][k] * blend[k][n].  One wave per (16 bodies, 64 columns).
+// v_posed[b][n] = sum_k feat[k][b] * blend[k][n]   (features stored feature-major by pose_kernel).
+// One workgroup per (64 bodies, 32 columns); its four wavefronts take a quarter of K each (14 MFMA k-steps) and hold
+// all four 16-body tiles, so the matrix is read once per 64 bodies.  The MFMA rows / columns are dealt out so that a
+// lane's operands are contiguous in memory: A row i of body tile t is body 4 i + t, B column c of tile j is column
+// 2 c + j -- one 16-byte load brings a lane's A values of a k-step for all four tiles, one 8-byte load its B values
+// (blend rows start on 4-byte boundaries only: the loads are typed so).  All 28 loads of the quarter are issued before
+// the first MFMA waits: with one wavefront walking 55 k-steps of scalar gathers this kernel was a chain of load
+// latencies, 28 us for a 17 MB matrix.  The partial tiles meet in LDS: wavefront w finishes and stores body tile w
+// (fixed order of addition).
+constexpr int kBlendSteps = kFeat / 4;                  // MFMA k-steps (K = 4 each)
+constexpr int kBlendWaveSteps = (kBlendSteps + 3) / 4;  // per wavefront
+constexpr int kBlendJ = 2;                              // 16-column tiles per workgroup
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 __global__ __launch_bounds__(256) void blend_kernel(
-    const float* __restrict__ feat, const float* __restrict__ blend, int B, int N3,
+    const float* __restrict__ feat, int fpad, const float* __restrict__ blend, int B, int N3,
     float* __restrict__ v_posed)
 {
+    __shared__ float red[4][3][kBlendJ * 4][64];     // [body tile][sender slot][j * 4 + r][lane]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int strip = blockIdx.x * 4 + wave;
-    const int n0 = strip * 64;
-    if (n0 >= N3) return;
-    const int m0 = blockIdx.y * 16;
     const int lm = lane & 15, lq = lane >> 4;
-    const int row = min(m0 + lm, B - 1);
-    f32x4 acc[4];
+    const int m_base = blockIdx.y * 64;
+    const int cbase = blockIdx.x * (16 * kBlendJ) + lm * kBlendJ;      // this lane's columns: cbase + j
+    const float* a_ptr = feat + m_base + lm * 4;
+    const float* b_ptr = blend + (cbase < N3 ? cbase : 0);             // the matrix has 4 floats of slack behind it
+    f32x4 a[kBlendWaveSteps];
+    f32x2u bv[kBlendWaveSteps];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    int col[4];
+    for (int i = 0; i < kBlendWaveSteps; ++i) {
+        const int k = min(wave * kBlendWaveSteps + i, kBlendSteps - 1) * 4 + lq;
+        a[i] = *(const f32x4*)(a_ptr + (size_t)k * fpad);
+        bv[i] = *(const f32x2u*)(b_ptr + (size_t)k * N3);
+    }
+    __builtin_amdgcn_sched_barrier(0);          // the whole quarter is in flight before the first MFMA waits
+    f32x4 acc[4][kBlendJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) col[j] = min(n0 + j * 16 + lm, N3 - 1);
-    for (int k0 = 0; k0 < kFeat; k0 += 4) {
-        const float a = feat[(size_t)row * kFeat + k0 + lq];
-        const float* brow = blend + (size_t)(k0 + lq) * N3;
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, brow[col[j]], acc[j], 0, 0, 0);
+        for (int j = 0; j < kBlendJ; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < kBlendWaveSteps; ++i) {
+        const bool live = wave * kBlendWaveSteps + i < kBlendSteps;   // the last wavefront has one step less
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float av = (i < kBlendSteps - 3 * kBlendWaveSteps || live) ? a[i][t] : 0.f;
+#pragma unroll
+            for (int j = 0; j < kBlendJ; ++j)
+                acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[i][j], acc[t][j], 0, 0, 0);
+        }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = n0 + j * 16 + lm;
-        if (n >= N3) continue;
+    for (int t = 0; t < 4; ++t) {
+        if (t == wave) continue;
+        const int slot = wave < t ? wave : wave - 1;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + lq * 4 + r;
-            if (m < B) v_posed[(size_t)m * N3 + n] = acc[j][r];
+        for (int j = 0; j < kBlendJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[t][slot][j * 4 + r][lane] = acc[t][j][r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m_base + (lq * 4 + r) * 4 + wave;              // output row lq * 4 + r of body tile `wave`
+#pragma unroll
+        for (int j = 0; j < kBlendJ; ++j) {
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) sum = (t == wave) ? acc[t][j][r] : sum;     // own partial, no dynamic index
+#pragma unroll
+            for (int slot = 0; slot < 3; ++slot) sum += red[wave][slot][j * 4 + r][lane];
+            if (m < B && cbase + j < N3) v_posed[(size_t)m * N3 + cbase + j] = sum;
         }
     }
 }
@@ -454,59 +490,80 @@ __global__ __launch_bounds__(kSkinBlock) void skin_bwd_kernel(
     }
 }
 
-// g_feat[m][n] += sum_{k in chunk} g_vposed[m][k] * blend[n][k];  n < 224.
-// One wave per (K chunk, up to kBlendBwdGroups x 16 bodies, kBlendBwdTiles 16-column tiles): the blend tile is
-// loaded once and used for all body groups of the wave; K index permuted so that every lane reads float4s.
-// The K chunks accumulate with float atomics into [Bpad][224] (zeroed by the caller).
+// part[block][m][n] = sum_{k in the block's 512 columns} g_vposed[m][k] * blend[n][k];  n < 224.
+// One workgroup per (512-wide K block, up to kBlendBwdGroups x 16 bodies, kBlendBwdTiles 16-column tiles), one
+// wavefront per 64 of its columns: the blend tile is loaded once and used for all body groups of the wave; K index
+// permuted so that every lane reads 4 consecutive floats (rows start on 8-byte boundaries only -- 3V is even, not a
+// multiple of 4 -- so the loads are typed 4-byte aligned); all 24 loads of a wavefront are issued before its first MFMA
+// waits.  The eight partial results meet in LDS, wavefront w adds up and stores accumulator w: plain stores into the
+// block's own [Bpad][224] slice (no atomics, nothing to clear); pose_bwd_kernel adds the ~41 slices up.
 constexpr int kBlendBwdTiles = 2;
 constexpr int kBlendBwdGroups = 4;
-__global__ __launch_bounds__(64) void blend_bwd_kernel(
-    const float* __restrict__ g_vposed, const float* __restrict__ blend, int B, int N3, int chunk_len,
+constexpr int kBlendBwdChunk = 64;          // K per wavefront
+constexpr int kBlendBwdWaves = kBlendBwdTiles * kBlendBwdGroups;
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+__global__ __launch_bounds__(64 * kBlendBwdWaves) void blend_bwd_kernel(
+    const float* __restrict__ g_vposed, const float* __restrict__ blend, int B, int N3, int bpad,
     float* __restrict__ part)
 {
-    const int lane = threadIdx.x, lm = lane & 15, lq = lane >> 4;
-    const int chunk = blockIdx.x, g0 = blockIdx.y * kBlendBwdGroups, j0 = blockIdx.z * kBlendBwdTiles;
-    const int k_beg = chunk * chunk_len, k_end = min(N3, k_beg + chunk_len);
+    __shared__ float red[kBlendBwdWaves][kBlendBwdWaves * 4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lm = lane & 15, lq = lane >> 4;
+    const int g0 = blockIdx.y * kBlendBwdGroups, j0 = blockIdx.z * kBlendBwdTiles;
+    const int k_beg = (blockIdx.x * kBlendBwdWaves + wave) * kBlendBwdChunk;
+    constexpr int kIters = kBlendBwdChunk / 16;
+    // lane group q covers k0 + 4q .. k0 + 4q + 3 over the four MFMA steps: one 4-float load per row and step
+    f32x4 a4[kIters][kBlendBwdGroups], b4[kIters][kBlendBwdTiles];
+#pragma unroll
+    for (int it = 0; it < kIters; ++it) {
+        const int kk = k_beg + it * 16 + 4 * lq;
+        const int kc = kk < N3 ? kk : 0;
+#pragma unroll
+        for (int g = 0; g < kBlendBwdGroups; ++g)
+            a4[it][g] = *(const f32x4u*)(g_vposed + (size_t)min((g0 + g) * 16 + lm, B - 1) * N3 + kc);
+#pragma unroll
+        for (int j = 0; j < kBlendBwdTiles; ++j)
+            b4[it][j] = *(const f32x4u*)(blend + (size_t)min((j0 + j) * 16 + lm, kFeat - 1) * N3 + kc);
+    }
+    __builtin_amdgcn_sched_barrier(0);          // every load of the wavefront is in flight before the first MFMA waits
     f32x4 acc[kBlendBwdGroups][kBlendBwdTiles];
 #pragma unroll
     for (int g = 0; g < kBlendBwdGroups; ++g)
 #pragma unroll
         for (int j = 0; j < kBlendBwdTiles; ++j) acc[g][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int k0 = k_beg; k0 < k_end; k0 += 16) {
-        // lane group q covers k0 + 4q .. k0 + 4q + 3 over the four MFMA steps
-        const int kk = k0 + 4 * lq;
-        float a4[kBlendBwdGroups][4], b4[kBlendBwdTiles][4];
+#pragma unroll
+    for (int it = 0; it < kIters; ++it) {
+        const int kk = k_beg + it * 16 + 4 * lq;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int k = kk + s;
-            const bool k_ok = k < k_end;
+            const bool k_ok = kk + s < N3;
+            float av[kBlendBwdGroups], bv[kBlendBwdTiles];
 #pragma unroll
-            for (int g = 0; g < kBlendBwdGroups; ++g) {
-                const int row = (g0 + g) * 16 + lm;
-                a4[g][s] = (row < B && k_ok) ? g_vposed[(size_t)row * N3 + k] : 0.f;
-            }
+            for (int g = 0; g < kBlendBwdGroups; ++g) av[g] = ((g0 + g) * 16 + lm < B && k_ok) ? a4[it][g][s] : 0.f;
 #pragma unroll
-            for (int j = 0; j < kBlendBwdTiles; ++j) {
-                const int n = (j0 + j) * 16 + lm;
-                b4[j][s] = (k_ok && n < kFeat) ? blend[(size_t)n * N3 + k] : 0.f;
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
+            for (int j = 0; j < kBlendBwdTiles; ++j) bv[j] = ((j0 + j) * 16 + lm < kFeat && k_ok) ? b4[it][j][s] : 0.f;
 #pragma unroll
             for (int g = 0; g < kBlendBwdGroups; ++g)
 #pragma unroll
                 for (int j = 0; j < kBlendBwdTiles; ++j)
-                    acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[g][s], b4[j][s], acc[g][j], 0, 0, 0);
+                    acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g], bv[j], acc[g][j], 0, 0, 0);
+        }
     }
 #pragma unroll
-    for (int g = 0; g < kBlendBwdGroups; ++g) {
-        if ((g0 + g) * 16 >= B) break;
+    for (int g = 0; g < kBlendBwdGroups; ++g)
 #pragma unroll
         for (int j = 0; j < kBlendBwdTiles; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                atomicAdd(&part[((size_t)((g0 + g) * 16 + lq * 4 + r)) * 224 + (j0 + j) * 16 + lm], acc[g][j][r]);
+            for (int r = 0; r < 4; ++r) red[wave][(g * kBlendBwdTiles + j) * 4 + r][lane] = acc[g][j][r];
+    __syncthreads();
+    const int g = wave / kBlendBwdTiles, j = wave % kBlendBwdTiles;      // the accumulator this wavefront finishes
+    if ((g0 + g) * 16 >= B) return;
+    part += (size_t)blockIdx.x * bpad * 224;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < kBlendBwdWaves; ++w) sum += red[w][wave * 4 + r][lane];
+        part[((size_t)((g0 + g) * 16 + lq * 4 + r)) * 224 + (j0 + j) * 16 + lm] = sum;
     }
 }
 
@@ -530,9 +587,19 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(
         sGA[j][n] = acc;
     }
     for (int i = t; i < 224; i += 256) {
-        float acc = 0.f;
-        for (int c = 0; c < feat_chunks; ++c) acc += feat_part[((size_t)c * bpad + b) * 224 + i];
-        sGF[i] = acc;
+        // four running sums: the loads of a round are independent of each other (fixed order all the same)
+        const float* src = feat_part + (size_t)b * 224 + i;
+        const size_t slice = (size_t)bpad * 224;
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+        int c = 0;
+        for (; c + 3 < feat_chunks; c += 4) {
+            p0 += src[(size_t)c * slice];
+            p1 += src[(size_t)(c + 1) * slice];
+            p2 += src[(size_t)(c + 2) * slice];
+            p3 += src[(size_t)(c + 3) * slice];
+        }
+        for (; c < feat_chunks; ++c) p0 += src[(size_t)c * slice];
+        sGF[i] = (p0 + p1) + (p2 + p3);
     }
     __syncthreads();
     // Chain adjoint.  Phase A (one thread per joint): contributions of A_k and of the posed joint.
@@ -613,7 +680,7 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(
     }
 }
 
-struct FwdLayout { size_t R, J, world, A, feat, v_posed, partial, total; int bpad, npad; };
+struct FwdLayout { size_t R, J, world, A, feat, v_posed, partial, total; int bpad, npad, fpad; };
 
 FwdLayout fwd_layout(const tuch_smpl_model* m, int B)
 {
@@ -625,7 +692,8 @@ FwdLayout fwd_layout(const tuch_smpl_model* m, int B)
     l.J = o;       o += align256((size_t)B * kJoints * 3 * 4);
     l.world = o;   o += align256((size_t)B * kJoints * 12 * 4);
     l.A = o;       o += align256((size_t)B * kJoints * 12 * 4);
-    l.feat = o;    o += align256((size_t)l.bpad * kFeat * 4);
+    l.fpad = ceil_div(B, 64) * 64;
+    l.feat = o;    o += align256((size_t)l.fpad * kFeat * 4);
     l.v_posed = o; o += align256((size_t)B * m->N3 * 4);
     l.partial = o; o += align256((size_t)B * ceil_div(m->V, kSkinBlock) * kExtra * 3 * 4);   // xpart of skin_kernel
     l.total = o;
@@ -638,12 +706,12 @@ BwdLayout bwd_layout(const tuch_smpl_model* m, int B)
 {
     BwdLayout l;
     l.skin_blocks = ceil_div(m->V, kSkinBlock);
-    l.feat_chunks = ceil_div(m->N3, kBlendBwdChunk);
+    l.feat_chunks = ceil_div(m->N3, kBlendBwdChunk * kBlendBwdWaves);
     l.bpad = ceil_div(B, 16) * 16;
     size_t o = 0;
     l.g_all = o;     o += align256((size_t)B * kAllJoints * 3 * 4);
     l.g_vposed = o;  o += align256((size_t)B * m->N3 * 4);
-    l.gA_part = o;   o += align256((size_t)B * l.skin_blocks * 32 * 16 * 4);
+    l.gA_part = o;   o += align256((size_t)B * 32 * 16 * 4);          // one accumulator per body (atomics over the blocks)
     l.feat_part = o; o += align256((size_t)l.feat_chunks * l.bpad * 224 * 4);
     l.total = o;
     return l;
@@ -693,7 +761,7 @@ extern "C" int tuch_smpl_model_create(tuch_smpl_model** out, int V, const float*
     m->V = V;
     m->N3 = 3 * V;
     const size_t n3 = (size_t)m->N3;
-    std::vector<float> blend((size_t)kFeat * n3, 0.f);
+    std::vector<float> blend((size_t)kFeat * n3 + 4, 0.f);      // + 4: the adjoint reads whole 4-float groups of a row
     memcpy(blend.data(), posedirs, sizeof(float) * kPoseFeat * n3);
     for (size_t n = 0; n < n3; ++n) {
         for (int l = 0; l < kBetas; ++l) blend[(size_t)(kPoseFeat + l) * n3 + n] = shapedirs[n * kBetas + l];
@@ -767,9 +835,9 @@ extern "C" int tuch_smpl_forward_split(const tuch_smpl_model* m, const float* be
     hipStream_t s = (hipStream_t)stream;
     const PoseRef pose{global_orient, body_pose, global_orient_stride, body_pose_stride};
     hipLaunchKernelGGL(pose_kernel, dim3(B), dim3(64), 0, s, betas, pose, pose2rot, (const float*)m->J_template,
-                       (const float*)m->J_shapedirs, (const int32_t*)m->parents, R, J, world, A, feat);
-    hipLaunchKernelGGL(blend_kernel, dim3(ceil_div(ceil_div(m->N3, 64), 4), l.bpad / 16), dim3(256), 0, s,
-                       (const float*)feat, (const float*)m->blend, B, m->N3, v_posed);
+                       (const float*)m->J_shapedirs, (const int32_t*)m->parents, R, J, world, A, feat, l.fpad);
+    hipLaunchKernelGGL(blend_kernel, dim3(ceil_div(m->N3, 16 * kBlendJ), l.fpad / 64), dim3(256), 0, s,
+                       (const float*)feat, l.fpad, (const float*)m->blend, B, m->N3, v_posed);
     hipLaunchKernelGGL(skin_kernel, dim3(ceil_div(m->V, kSkinBlock), B), dim3(kSkinBlock), 0, s,
                        (const float*)v_posed, (const float*)A, (const float*)m->weights, (const float*)m->Jrx, m->V, verts, partial);
     hipLaunchKernelGGL(assemble_joints_kernel, dim3(B), dim3(64), 0, s, (const float*)world, (const float*)verts,
@@ -819,8 +887,7 @@ extern "C" int tuch_smpl_backward_split(const tuch_smpl_model* m, const float* g
     float *g_all = (float*)(ws + l.g_all), *g_vposed = (float*)(ws + l.g_vposed), *gA_part = (float*)(ws + l.gA_part),
           *feat_part = (float*)(ws + l.feat_part);
     hipStream_t s = (hipStream_t)stream;
-    // gA_part and feat_part are adjacent in the workspace: one memset clears both accumulators
-    if (hipMemsetAsync(gA_part, 0, (size_t)((char*)feat_part - (char*)gA_part) + (size_t)l.bpad * 224 * sizeof(float), s) != hipSuccess) {
+    if (hipMemsetAsync(gA_part, 0, (size_t)B * 32 * 16 * sizeof(float), s) != hipSuccess) {
         tuch_set_error("tuch_smpl_backward: hipMemsetAsync failed");
         return TUCH_ERR_HIP;
     }
@@ -828,12 +895,10 @@ extern "C" int tuch_smpl_backward_split(const tuch_smpl_model* m, const float* g
     hipLaunchKernelGGL(skin_bwd_kernel, dim3(l.skin_blocks, B), dim3(kSkinBlock), 0, s, g_verts, (const float*)g_all,
                        (const float*)m->Jrx, (const int32_t*)m->extra_ids, v_posed, A, (const float*)m->weights, m->V,
                        g_vposed, gA_part);
-    // 81 K chunks x 7 tile pairs = 567 wavefronts, each using its blend tiles for all bodies
-    const int chunk_len = 256;
-    hipLaunchKernelGGL(blend_bwd_kernel, dim3(ceil_div(m->N3, chunk_len), ceil_div(l.bpad / 16, kBlendBwdGroups), 14 / kBlendBwdTiles),
-                       dim3(64), 0, s, (const float*)g_vposed, (const float*)m->blend, B, m->N3, chunk_len, feat_part);
+    hipLaunchKernelGGL(blend_bwd_kernel, dim3(l.feat_chunks, ceil_div(l.bpad / 16, kBlendBwdGroups), 14 / kBlendBwdTiles),
+                       dim3(64 * kBlendBwdWaves), 0, s, (const float*)g_vposed, (const float*)m->blend, B, m->N3, l.bpad, feat_part);
     hipLaunchKernelGGL(pose_bwd_kernel, dim3(B), dim3(256), 0, s, (const float*)gA_part, 1,
-                       (const float*)feat_part, 1, l.bpad, (const float*)g_all, R, J, world, pose, pose2rot,
+                       (const float*)feat_part, l.feat_chunks, l.bpad, (const float*)g_all, R, J, world, pose, pose2rot,
                        (const float*)m->J_shapedirs, (const int32_t*)m->parents, g_pose, g_betas);
     return tuch_check_launch("tuch_smpl_backward");
 }
