@@ -33,7 +33,8 @@ struct tuch_smpl_model {
     float* J_shapedirs;        // [24*3][10]
     float* weights;            // [V][24]
     float* Jrx;                // [9][V]  J_regressor_extra
-    int32_t* parents;          // [24]
+    int32_t* parents;          // [48]: parent of joint k (-1 for the root) | depth of joint k in the tree
+    int max_depth;
     int32_t* extra_ids;        // [21]
     int32_t* joint_map;        // [49]
     int parents_host[24];
@@ -155,7 +156,7 @@ __device__ __forceinline__ float* pose_joint(const PoseGrad& p, int b, int t, in
 __global__ __launch_bounds__(64) void pose_kernel(
     const float* __restrict__ betas, PoseRef pose, int pose2rot,
     const float* __restrict__ J_template, const float* __restrict__ J_shapedirs,
-    const int32_t* __restrict__ parents,
+    const int32_t* __restrict__ parents, int max_depth,      // parents [24] | depths [24]
     float* __restrict__ R_out,      // [B,24,9]
     float* __restrict__ J_out,      // [B,24,3]
     float* __restrict__ world_out,  // [B,24,12] world rotation | world translation (= posed joint)
@@ -194,11 +195,14 @@ __global__ __launch_bounds__(64) void pose_kernel(
         feat[(size_t)218 * fpad + b] = 0.0f;
         feat[(size_t)219 * fpad + b] = 0.0f;
     }
+    // Kinematic chain, one tree level at a time (SMPL: 9 levels), every joint of a level on its own lane, the world
+    // transforms in LDS.  (One lane walking all 24 joints through global memory was 23 store -> load round trips.)
+    __shared__ float sW[kJoints][12];
+    const int parent = t < kJoints ? parents[t] : -1, depth = t < kJoints ? parents[kJoints + t] : -1;
     __syncthreads();
-    if (t == 0) {
-        float* W = world_out + (size_t)b * kJoints * 12;
-        float* A = A_out + (size_t)b * kJoints * 12;
-        for (int k = 0; k < kJoints; ++k) {
+    for (int level = 0; level <= max_depth; ++level) {
+        if (t < kJoints && depth == level) {
+            const int k = t;
             M3 rk;
 #pragma unroll
             for (int e = 0; e < 9; ++e) rk.m[e] = sR[k][e];
@@ -208,22 +212,35 @@ __global__ __launch_bounds__(64) void pose_kernel(
                 rw = rk;
                 tw[0] = sJ[0][0]; tw[1] = sJ[0][1]; tw[2] = sJ[0][2];
             } else {
-                const int p = parents[k];
+                const int p = parent;
                 M3 rp;
 #pragma unroll
-                for (int e = 0; e < 9; ++e) rp.m[e] = W[p * 12 + e];
+                for (int e = 0; e < 9; ++e) rp.m[e] = sW[p][e];
                 rw = mul(rp, rk);
                 const float rel[3] = {sJ[k][0] - sJ[p][0], sJ[k][1] - sJ[p][1], sJ[k][2] - sJ[p][2]};
                 mulv(rp, rel, tw);
-                tw[0] += W[p * 12 + 9]; tw[1] += W[p * 12 + 10]; tw[2] += W[p * 12 + 11];
+                tw[0] += sW[p][9]; tw[1] += sW[p][10]; tw[2] += sW[p][11];
             }
-            float rj[3];
-            mulv(rw, sJ[k], rj);
 #pragma unroll
-            for (int e = 0; e < 9; ++e) { W[k * 12 + e] = rw.m[e]; A[k * 12 + e] = rw.m[e]; }
+            for (int e = 0; e < 9; ++e) sW[k][e] = rw.m[e];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) { W[k * 12 + 9 + c] = tw[c]; A[k * 12 + 9 + c] = tw[c] - rj[c]; }
+            for (int c = 0; c < 3; ++c) sW[k][9 + c] = tw[c];
         }
+        __syncthreads();
+    }
+    if (t < kJoints) {
+        const int k = t;
+        float* W = world_out + ((size_t)b * kJoints + k) * 12;
+        float* A = A_out + ((size_t)b * kJoints + k) * 12;
+        M3 rw;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) rw.m[e] = sW[k][e];
+        float rj[3];
+        mulv(rw, sJ[k], rj);
+#pragma unroll
+        for (int e = 0; e < 9; ++e) { W[e] = rw.m[e]; A[e] = rw.m[e]; }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { W[9 + c] = sW[k][9 + c]; A[9 + c] = sW[k][9 + c] - rj[c]; }
     }
 }
 
@@ -376,23 +393,37 @@ __global__ __launch_bounds__(kSkinBlock) void skin_kernel(
     }
 }
 
-__global__ __launch_bounds__(64) void assemble_joints_kernel(
+__global__ __launch_bounds__(256) void assemble_joints_kernel(
     const float* __restrict__ world, const float* __restrict__ verts, const float* __restrict__ xpart,
     const int32_t* __restrict__ extra_ids, const int32_t* __restrict__ joint_map, int V, int skin_blocks,
     float* __restrict__ joints)   // [B,49,3]
 {
-    const int b = blockIdx.x;
-    for (int i = threadIdx.x; i < kOutJoints * 3; i += 64) {
-        const int src = joint_map[i / 3], c = i % 3;
+    // regressed joints: 9 thread groups add every 9th block partial of the 27 values, then 27 threads add the groups
+    // (one thread adding 27 partials in turn was 27 load latencies in front of everything that waits for the joints)
+    constexpr int kVals = kExtra * 3, kGroups = 9;
+    __shared__ float sPart[kGroups][kVals], sExtra[kVals];
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (t < kVals * kGroups) {
+        const int g = t / kVals, q = t % kVals;
+        float acc = 0.f;
+        for (int blk = g; blk < skin_blocks; blk += kGroups) acc += xpart[((size_t)b * skin_blocks + blk) * kVals + q];
+        sPart[g][q] = acc;
+    }
+    __syncthreads();
+    if (t < kVals) {
+        float acc = 0.f;
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) acc += sPart[g][t];
+        sExtra[t] = acc;
+    }
+    __syncthreads();
+    if (t < kOutJoints * 3) {
+        const int src = joint_map[t / 3], c = t % 3;
         float val;
         if (src < kJoints) val = world[((size_t)b * kJoints + src) * 12 + 9 + c];
         else if (src < kJoints + kPicked) val = verts[((size_t)b * V + extra_ids[src - kJoints]) * 3 + c];
-        else {
-            val = 0.f;
-            const int m = src - kJoints - kPicked;
-            for (int blk = 0; blk < skin_blocks; ++blk) val += xpart[((size_t)b * skin_blocks + blk) * (kExtra * 3) + 3 * m + c];
-        }
-        joints[(size_t)b * kOutJoints * 3 + i] = val;
+        else val = sExtra[3 * (src - kJoints - kPicked) + c];
+        joints[(size_t)b * kOutJoints * 3 + t] = val;
     }
 }
 
@@ -401,13 +432,18 @@ __global__ __launch_bounds__(64) void assemble_joints_kernel(
 __global__ __launch_bounds__(64) void joints_bwd_kernel(
     const float* __restrict__ g_joints, const int32_t* __restrict__ joint_map, float* __restrict__ g_all)
 {
+    // the map and the body's 49 x 3 gradients go to LDS in one round of loads; the 49-way match runs from there
+    __shared__ int sMap[kOutJoints];
+    __shared__ float sG[kOutJoints * 3];
     const int b = blockIdx.x;
+    if (threadIdx.x < kOutJoints) sMap[threadIdx.x] = joint_map[threadIdx.x];
+    for (int i = threadIdx.x; i < kOutJoints * 3; i += 64)
+        sG[i] = g_joints ? g_joints[(size_t)b * kOutJoints * 3 + i] : 0.f;
+    __syncthreads();
     for (int i = threadIdx.x; i < kAllJoints * 3; i += 64) {
         const int src = i / 3, c = i % 3;
         float acc = 0.f;
-        if (g_joints)
-            for (int o = 0; o < kOutJoints; ++o)
-                if (joint_map[o] == src) acc += g_joints[((size_t)b * kOutJoints + o) * 3 + c];
+        for (int o = 0; o < kOutJoints; ++o) acc += sMap[o] == src ? sG[o * 3 + c] : 0.f;
         g_all[(size_t)b * kAllJoints * 3 + i] = acc;
     }
 }
@@ -422,6 +458,8 @@ __global__ __launch_bounds__(kSkinBlock) void skin_bwd_kernel(
     const float* __restrict__ weights, int V, float* __restrict__ g_vposed, float* __restrict__ gA_part)
 {
     __shared__ float sG[kSkinBlock][16];      // per vertex: g_v (x) [v_posed;1], 12 used
+    __shared__ int sIds[kPicked];
+    if (threadIdx.x < kPicked) sIds[threadIdx.x] = extra_ids[threadIdx.x];
     const int b = blockIdx.y;
     const int v = blockIdx.x * kSkinBlock + threadIdx.x;
     const bool ok = v < V;
@@ -438,8 +476,10 @@ __global__ __launch_bounds__(kSkinBlock) void skin_bwd_kernel(
         const float* gj = ga + (kJoints + kPicked + j) * 3;
         g[0] = __builtin_fmaf(w, gj[0], g[0]); g[1] = __builtin_fmaf(w, gj[1], g[1]); g[2] = __builtin_fmaf(w, gj[2], g[2]);
     }
+    __syncthreads();
+#pragma unroll
     for (int e = 0; e < kPicked; ++e)
-        if (extra_ids[e] == vc) {
+        if (sIds[e] == vc) {
             const float* gj = ga + (kJoints + e) * 3;
             g[0] += gj[0]; g[1] += gj[1]; g[2] += gj[2];
         }
@@ -472,22 +512,27 @@ __global__ __launch_bounds__(kSkinBlock) void skin_bwd_kernel(
 #pragma unroll
     for (int n = 12; n < 16; ++n) sG[threadIdx.x][n] = 0.f;
     __syncthreads();
-    // waves 0,1 reduce joints 0-15 / 16-31 over the block's 256 vertices
+    // gA[j][n] += sum_v W[v][j] G[v][n]: the four wavefronts take (joints 0-15 | 16-31) x (first | second half of the
+    // block's vertices).  The weights of the half (just read for T: cache hits) are all requested before the first MFMA
+    // waits -- fetched one by one inside the loop they made it a chain of 64 load latencies.
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lm = lane & 15, lq = lane >> 4;
-    if (wave < 2) {
-        const int j = wave * 16 + lm;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const int vbase = blockIdx.x * kSkinBlock;
-        for (int k0 = 0; k0 < kSkinBlock; k0 += 4) {
-            const int vv = vbase + k0 + lq;
-            const float a = (j < kJoints && vv < V) ? weights[(size_t)vv * kJoints + j] : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, sG[k0 + lq][lm], acc, 0, 0, 0);
-        }
-        // [B][32][16], zeroed by the caller: the vertex blocks accumulate with float atomics
-        float* out = gA_part + ((size_t)b * 32 + wave * 16) * 16;
+    const int j = (wave & 1) * 16 + lm, k_beg = (wave >> 1) * (kSkinBlock / 2);
+    constexpr int kSteps = kSkinBlock / 2 / 4;
+    float a[kSteps];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(&out[(lq * 4 + r) * 16 + lm], acc[r]);
+    for (int i = 0; i < kSteps; ++i) {
+        const int vv = min(blockIdx.x * kSkinBlock + k_beg + i * 4 + lq, V - 1);      // rows past V: G is zero there
+        a[i] = weights[(size_t)vv * kJoints + min(j, kJoints - 1)];
     }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < kSteps; ++i)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(j < kJoints ? a[i] : 0.f, sG[k_beg + i * 4 + lq][lm], acc, 0, 0, 0);
+    // [B][32][16], zeroed by the caller: the vertex blocks accumulate with float atomics
+    float* out = gA_part + ((size_t)b * 32 + (wave & 1) * 16) * 16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(&out[(lq * 4 + r) * 16 + lm], acc[r]);
 }
 
 // part[block][m][n] = sum_{k in the block's 512 columns} g_vposed[m][k] * blend[n][k];  n < 224.
@@ -569,87 +614,146 @@ __global__ __launch_bounds__(64 * kBlendBwdWaves) void blend_bwd_kernel(
 
 // Per body: reduce the partials, chain adjoint, Rodrigues adjoint, shape gradient.
 __global__ __launch_bounds__(256) void pose_bwd_kernel(
-    const float* __restrict__ gA_part, int skin_blocks, const float* __restrict__ feat_part, int feat_chunks,
+    const float* __restrict__ gA_part, const float* __restrict__ feat_part, int feat_chunks,
     int bpad, const float* __restrict__ g_all, const float* __restrict__ R, const float* __restrict__ J,
     const float* __restrict__ world, PoseRef pose, int pose2rot,
-    const float* __restrict__ J_shapedirs, const int32_t* __restrict__ parents,
+    const float* __restrict__ J_shapedirs, const int32_t* __restrict__ parents, int max_depth,
     PoseGrad g_pose, float* __restrict__ g_betas)
 {
     __shared__ float sGA[kJoints][12];
     __shared__ float sGF[224];
     __shared__ float sGR[kJoints][9];
     __shared__ float sGJ[kJoints][3];
-    const int b = blockIdx.x, t = threadIdx.x;
-    for (int i = t; i < kJoints * 12; i += 256) {
-        const int j = i / 12, n = i % 12;
-        float acc = 0.f;
-        for (int s = 0; s < skin_blocks; ++s) acc += gA_part[(((size_t)b * skin_blocks + s) * 32 + j) * 16 + n];
-        sGA[j][n] = acc;
-    }
-    for (int i = t; i < 224; i += 256) {
-        // four running sums: the loads of a round are independent of each other (fixed order all the same)
-        const float* src = feat_part + (size_t)b * 224 + i;
-        const size_t slice = (size_t)bpad * 224;
-        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
-        int c = 0;
-        for (; c + 3 < feat_chunks; c += 4) {
-            p0 += src[(size_t)c * slice];
-            p1 += src[(size_t)(c + 1) * slice];
-            p2 += src[(size_t)(c + 2) * slice];
-            p3 += src[(size_t)(c + 3) * slice];
-        }
-        for (; c < feat_chunks; ++c) p0 += src[(size_t)c * slice];
-        sGF[i] = (p0 + p1) + (p2 + p3);
-    }
-    __syncthreads();
-    // Chain adjoint.  Phase A (one thread per joint): contributions of A_k and of the posed joint.
-    // Phase B (thread 0, LDS-resident state): propagate from the leaves to the root.
     __shared__ float sRw[kJoints][9];      // gradient w.r.t. the world rotations
     __shared__ float sTw[kJoints][3];      // ... world translations
-    const float* Jb = J + (size_t)b * kJoints * 3;
-    const float* Wb = world + (size_t)b * kJoints * 12;
-    const float* Rb = R + (size_t)b * kJoints * 9;
+    __shared__ float sW[kJoints][9], sRl[kJoints][9], sJb[kJoints][3];   // world / local rotations, rest joints
+    __shared__ float sUp[kJoints][9], sGrel[kJoints][3];
+    __shared__ float sGall[kJoints][3], sAA[kJoints][3];
+    __shared__ int sParent[kJoints], sDepth[kJoints];
+    constexpr int kGroups = 8, kPer = 6;             // slices of the blend adjoint: 48 per pass
+    __shared__ float sPart[kGroups][224];
+    const int b = blockIdx.x, t = threadIdx.x;
+    // Everything the block reads from global memory is requested here, in one go: the kernel is a handful of threads
+    // of arithmetic behind its loads, and every separate round of loads costs a full memory latency.
+    // (gA: one [32][16] accumulator per body, the skinning adjoint adds its blocks with atomics.)
+    float ga0 = 0.f, ga1 = 0.f, w_v = 0.f, r_v = 0.f, j_v = 0.f, gall_v = 0.f, aa_v = 0.f, jsd[3] = {0.f, 0.f, 0.f};
+    int par_v = -1, dep_v = -1;
+    ga0 = gA_part[((size_t)b * 32 + t / 12) * 16 + t % 12];
+    if (t + 256 < kJoints * 12) ga1 = gA_part[((size_t)b * 32 + (t + 256) / 12) * 16 + (t + 256) % 12];
+    if (t < kJoints * 9) {
+        w_v = world[((size_t)b * kJoints + t / 9) * 12 + t % 9];
+        r_v = R[(size_t)b * kJoints * 9 + t];
+    }
+    if (t < kJoints * 3) {
+        j_v = J[(size_t)b * kJoints * 3 + t];
+        gall_v = g_all[(size_t)b * kAllJoints * 3 + t];
+        if (pose2rot) aa_v = pose_joint(pose, b, t / 3, 3)[t % 3];
+    }
+    if (t < kJoints) { par_v = parents[t]; dep_v = parents[kJoints + t]; }
+    if (t < kBetas * kJoints) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) jsd[c] = J_shapedirs[((t % kJoints) * 3 + c) * kBetas + t / kJoints];
+    }
+    // Sum of the blend adjoint's K-block slices: 8 thread groups take every 8th slice for 32 columns at a time
+    // (one thread per column adding 41 slices in turn was 41 load latencies).
+    {
+        const int cg = t >> 5, il = t & 31;
+        const size_t slice = (size_t)bpad * 224;
+        float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int c0 = 0; c0 < feat_chunks; c0 += kGroups * kPer) {
+            float v[7][kPer];
+#pragma unroll
+            for (int ii = 0; ii < 7; ++ii)
+#pragma unroll
+                for (int u = 0; u < kPer; ++u) {
+                    const int c = c0 + u * kGroups + cg;
+                    v[ii][u] = c < feat_chunks ? feat_part[(size_t)c * slice + (size_t)b * 224 + ii * 32 + il] : 0.f;
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ii = 0; ii < 7; ++ii)
+#pragma unroll
+                for (int u = 0; u < kPer; ++u) acc[ii] += v[ii][u];
+        }
+#pragma unroll
+        for (int ii = 0; ii < 7; ++ii) sPart[cg][ii * 32 + il] = acc[ii];
+    }
+    sGA[t / 12][t % 12] = ga0;                                   // 256 < 288: always a valid slot
+    if (t + 256 < kJoints * 12) sGA[(t + 256) / 12][(t + 256) % 12] = ga1;
+    if (t < kJoints * 9) { sW[t / 9][t % 9] = w_v; sRl[t / 9][t % 9] = r_v; }
+    if (t < kJoints * 3) { sJb[t / 3][t % 3] = j_v; sGall[t / 3][t % 3] = gall_v; sAA[t / 3][t % 3] = aa_v; }
+    if (t < kJoints) { sParent[t] = par_v; sDepth[t] = dep_v; }
+    __syncthreads();
+    if (t < 224) {
+        float sum = 0.f;
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) sum += sPart[g][t];
+        sGF[t] = sum;
+    }
+    // Chain adjoint.  Phase A (one thread per joint): contributions of A_k and of the posed joint.
+    // Phase B: from the leaves to the root one tree level at a time, the state in LDS: the joints of a level turn their
+    // finished gradients into what their parent receives, then every parent adds its children up in a fixed order.
+    // (One lane walking all 23 joints with the world transforms in global memory was 23 dependent load rounds.)
     if (t < kJoints) {
         const int k = t;
         const float* ga = sGA[k];                      // A_k = [Rw | tw - Rw J]
         const float gt[3] = {ga[9], ga[10], ga[11]};
-        const float* gtw_in = g_all + (size_t)b * kAllJoints * 3;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            sTw[k][i] = gtw_in[k * 3 + i] + gt[i];
+            sTw[k][i] = sGall[k][i] + gt[i];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) sRw[k][3 * i + c] = ga[3 * i + c] - gt[i] * Jb[k * 3 + c];
+            for (int c = 0; c < 3; ++c) sRw[k][3 * i + c] = ga[3 * i + c] - gt[i] * sJb[k][c];
         }
         M3 rw;
 #pragma unroll
-        for (int e = 0; e < 9; ++e) rw.m[e] = Wb[k * 12 + e];
+        for (int e = 0; e < 9; ++e) rw.m[e] = sW[k][e];
         float tmp[3];
         mulv_t(rw, gt, tmp);
 #pragma unroll
         for (int c = 0; c < 3; ++c) sGJ[k][c] = -tmp[c];
     }
     __syncthreads();
-    if (t == 0) {
-        for (int k = kJoints - 1; k >= 1; --k) {
-            const int p = parents[k];
-            M3 rp, rk, g;
-#pragma unroll
-            for (int e = 0; e < 9; ++e) { rp.m[e] = Wb[p * 12 + e]; rk.m[e] = Rb[k * 9 + e]; g.m[e] = sRw[k][e]; }
-            const float rel[3] = {Jb[k * 3] - Jb[p * 3], Jb[k * 3 + 1] - Jb[p * 3 + 1], Jb[k * 3 + 2] - Jb[p * 3 + 2]};
+    // one thread per (joint, matrix element): a level is two short steps instead of 24 lanes doing 3x3 products alone
+    const int ek = t / 9, ee = t % 9, ei = ee / 3, ec = ee % 3;
+    const bool elem = t < kJoints * 9;
+    const int edepth = elem ? sDepth[ek] : -1, eparent = elem ? sParent[ek] : 0;
+    unsigned kids = 0;                           // children of joint ek
+    if (elem)
+        for (int k = 1; k < kJoints; ++k) kids |= sParent[k] == ek ? 1u << k : 0u;
+    for (int level = max_depth; level >= 1; --level) {
+        if (edepth == level) {                   // this joint's gradients are complete
+            const int k = ek, p = eparent;
+            const float* g = sRw[k];
+            const float* rk = sRl[k];
+            const float* rp = sW[p];
             const float gk[3] = {sTw[k][0], sTw[k][1], sTw[k][2]};
-            const M3 up = mul_nt(g, rk);                 // gRw_k R_k^T
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) sRw[p][3 * i + c] += up.m[3 * i + c] + gk[i] * rel[c];
-            const M3 gr = mul_tn(rp, g);                 // Rw_p^T gRw_k
-#pragma unroll
-            for (int e = 0; e < 9; ++e) sGR[k][e] = gr.m[e];
-            float grel[3];
-            mulv_t(rp, gk, grel);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { sGJ[k][c] += grel[c]; sGJ[p][c] -= grel[c]; sTw[p][c] += gk[c]; }
+            // (gRw_k R_k^T)[i][c] + gk[i] rel[c]  ->  what the parent's world rotation receives
+            sUp[k][ee] = g[3 * ei] * rk[3 * ec] + g[3 * ei + 1] * rk[3 * ec + 1] + g[3 * ei + 2] * rk[3 * ec + 2] +
+                         gk[ei] * (sJb[k][ec] - sJb[p][ec]);
+            // (Rw_p^T gRw_k)[i][c]  ->  gradient of the local rotation
+            sGR[k][ee] = rp[ei] * g[ec] + rp[3 + ei] * g[3 + ec] + rp[6 + ei] * g[6 + ec];
+            if (ee < 3) {                        // Rw_p^T gk: the rest-joint offset
+                const float grel = rp[ee] * gk[0] + rp[3 + ee] * gk[1] + rp[6 + ee] * gk[2];
+                sGJ[k][ee] += grel;
+                sGrel[k][ee] = grel;
+            }
         }
+        __syncthreads();
+        if (edepth == level - 1) {               // parents of that level: children in descending order
+            const int p = ek;
+            float rw = sRw[p][ee], gj = ee < 3 ? sGJ[p][ee] : 0.f, tw = ee < 3 ? sTw[p][ee] : 0.f;
+            for (unsigned rest = kids; rest != 0;) {
+                const int k = 31 - __clz(rest);
+                rest &= ~(1u << k);
+                rw += sUp[k][ee];
+                if (ee < 3) { gj -= sGrel[k][ee]; tw += sTw[k][ee]; }
+            }
+            sRw[p][ee] = rw;
+            if (ee < 3) { sGJ[p][ee] = gj; sTw[p][ee] = tw; }
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
 #pragma unroll
         for (int e = 0; e < 9; ++e) sGR[0][e] = sRw[0][e];
 #pragma unroll
@@ -662,7 +766,7 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(
         for (int e = 0; e < 9; ++e) g.m[e] = sGR[t][e] + (t > 0 ? sGF[(t - 1) * 9 + e] : 0.f);
         if (pose2rot) {
             float ga[3];
-            rodrigues_bwd(pose_joint(pose, b, t, 3), g, ga);
+            rodrigues_bwd(sAA[t], g, ga);
             float* dst = pose_joint(g_pose, b, t, 3);
 #pragma unroll
             for (int c = 0; c < 3; ++c) dst[c] = ga[c];
@@ -672,11 +776,20 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(
             for (int e = 0; e < 9; ++e) dst[e] = g.m[e];
         }
     }
-    if (t >= 32 && t < 32 + kBetas) {
-        const int l = t - 32;
-        float acc = sGF[kPoseFeat + l];
-        for (int i = 0; i < kJoints * 3; ++i) acc += J_shapedirs[i * kBetas + l] * sGJ[i / 3][i % 3];
-        g_betas[(size_t)b * kBetas + l] = acc;
+    // shape gradient: 10 x 24 threads take one joint each, then ten add the joints up
+    __shared__ float sShape[kBetas][kJoints];
+    if (t < kBetas * kJoints) {
+        const int l = t / kJoints, q = t % kJoints;
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc += jsd[c] * sGJ[q][c];
+        sShape[l][q] = acc;
+    }
+    __syncthreads();
+    if (t < kBetas) {
+        float acc = sGF[kPoseFeat + t];
+        for (int q = 0; q < kJoints; ++q) acc += sShape[t][q];
+        g_betas[(size_t)b * kBetas + t] = acc;
     }
 }
 
@@ -780,16 +893,22 @@ extern "C" int tuch_smpl_model_create(tuch_smpl_model** out, int V, const float*
             jt[j * 3 + c] = (float)a;
             for (int l = 0; l < kBetas; ++l) js[(size_t)(j * 3 + c) * kBetas + l] = (float)s[l];
         }
-    int32_t par[kJoints];
-    memcpy(par, parents, sizeof(par));
+    int32_t par[2 * kJoints];
+    memcpy(par, parents, sizeof(int32_t) * kJoints);
     par[0] = -1;
-    memcpy(m->parents_host, par, sizeof(par));
+    par[kJoints] = 0;
+    m->max_depth = 0;
+    for (int k = 1; k < kJoints; ++k) {               // parents come first: one pass
+        par[kJoints + k] = par[kJoints + par[k]] + 1;
+        m->max_depth = std::max(m->max_depth, (int)par[kJoints + k]);
+    }
+    memcpy(m->parents_host, par, sizeof(int32_t) * kJoints);
     int rc = upload(&m->blend, blend.data(), blend.size());
     if (rc == TUCH_OK) rc = upload(&m->J_template, jt.data(), jt.size());
     if (rc == TUCH_OK) rc = upload(&m->J_shapedirs, js.data(), js.size());
     if (rc == TUCH_OK) rc = upload(&m->weights, lbs_weights, (size_t)V * kJoints);
     if (rc == TUCH_OK) rc = upload(&m->Jrx, J_regressor_extra, (size_t)kExtra * V);
-    if (rc == TUCH_OK) rc = upload(&m->parents, par, kJoints);
+    if (rc == TUCH_OK) rc = upload(&m->parents, par, 2 * kJoints);
     if (rc == TUCH_OK) rc = upload(&m->extra_ids, extra_vertex_ids, kPicked);
     if (rc == TUCH_OK) rc = upload(&m->joint_map, joint_map, kOutJoints);
     if (rc != TUCH_OK) {
@@ -835,12 +954,12 @@ extern "C" int tuch_smpl_forward_split(const tuch_smpl_model* m, const float* be
     hipStream_t s = (hipStream_t)stream;
     const PoseRef pose{global_orient, body_pose, global_orient_stride, body_pose_stride};
     hipLaunchKernelGGL(pose_kernel, dim3(B), dim3(64), 0, s, betas, pose, pose2rot, (const float*)m->J_template,
-                       (const float*)m->J_shapedirs, (const int32_t*)m->parents, R, J, world, A, feat, l.fpad);
+                       (const float*)m->J_shapedirs, (const int32_t*)m->parents, m->max_depth, R, J, world, A, feat, l.fpad);
     hipLaunchKernelGGL(blend_kernel, dim3(ceil_div(m->N3, 16 * kBlendJ), l.fpad / 64), dim3(256), 0, s,
                        (const float*)feat, l.fpad, (const float*)m->blend, B, m->N3, v_posed);
     hipLaunchKernelGGL(skin_kernel, dim3(ceil_div(m->V, kSkinBlock), B), dim3(kSkinBlock), 0, s,
                        (const float*)v_posed, (const float*)A, (const float*)m->weights, (const float*)m->Jrx, m->V, verts, partial);
-    hipLaunchKernelGGL(assemble_joints_kernel, dim3(B), dim3(64), 0, s, (const float*)world, (const float*)verts,
+    hipLaunchKernelGGL(assemble_joints_kernel, dim3(B), dim3(256), 0, s, (const float*)world, (const float*)verts,
                        (const float*)partial, (const int32_t*)m->extra_ids, (const int32_t*)m->joint_map, m->V,
                        ceil_div(m->V, kSkinBlock), joints);
     return tuch_check_launch("tuch_smpl_forward");
@@ -897,9 +1016,9 @@ extern "C" int tuch_smpl_backward_split(const tuch_smpl_model* m, const float* g
                        g_vposed, gA_part);
     hipLaunchKernelGGL(blend_bwd_kernel, dim3(l.feat_chunks, ceil_div(l.bpad / 16, kBlendBwdGroups), 14 / kBlendBwdTiles),
                        dim3(64 * kBlendBwdWaves), 0, s, (const float*)g_vposed, (const float*)m->blend, B, m->N3, l.bpad, feat_part);
-    hipLaunchKernelGGL(pose_bwd_kernel, dim3(B), dim3(256), 0, s, (const float*)gA_part, 1,
+    hipLaunchKernelGGL(pose_bwd_kernel, dim3(B), dim3(256), 0, s, (const float*)gA_part,
                        (const float*)feat_part, l.feat_chunks, l.bpad, (const float*)g_all, R, J, world, pose, pose2rot,
-                       (const float*)m->J_shapedirs, (const int32_t*)m->parents, g_pose, g_betas);
+                       (const float*)m->J_shapedirs, (const int32_t*)m->parents, m->max_depth, g_pose, g_betas);
     return tuch_check_launch("tuch_smpl_backward");
 }
 
