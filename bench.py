@@ -161,6 +161,7 @@ def build_problem(batch, device, seed, penetrating_fraction=0.5):
 
 def make_step(p):
     """The stage-2 loop body of SMPLifyDC.__call__ (smplifydc.py:155-183); returns [loss sum, bodies]."""
+    from tuch_amd import ops
     from tuch_amd.smplify.losses import contact_fitting_loss
     body_pose = p['body_pose'].clone().requires_grad_(True)
     global_orient = p['global_orient'].clone().requires_grad_(True)
@@ -181,7 +182,7 @@ def make_step(p):
                                     focal_length=5000., contact_loss_weight=2000.0,
                                     segments=p['segments'])
         opt.zero_grad(set_to_none=True)
-        loss.backward()
+        ops.backward_scalar(loss)                 # as SMPLifyDC._Stage._one does
         opt.step()
         stats[0].copy_(loss.detach())
         return stats

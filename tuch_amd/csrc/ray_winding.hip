@@ -53,10 +53,14 @@ __device__ __forceinline__ float shear_y(float y, float z) { return __builtin_fm
 // ---- per call: sheared leaf strips + node slabs ------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void ray_stream_kernel(
     const float* __restrict__ verts, const int32_t* __restrict__ vidx, const float* __restrict__ sign,
-    int V, int L, int Lpad, RayElem* __restrict__ out)
+    int V, int L, int Lpad, RayElem* __restrict__ out, uint4* __restrict__ zeroed, size_t zeroed_n)
 {
     const int b = blockIdx.y;
     const int p = blockIdx.x * kBlock + threadIdx.x;
+    // also clears the counters of the kernels that follow (a separate 6 MB fill in front of the chain was 12 us)
+    for (size_t g = ((size_t)b * gridDim.x + blockIdx.x) * kBlock + threadIdx.x; g < zeroed_n;
+         g += (size_t)gridDim.x * gridDim.y * kBlock)
+        zeroed[g] = make_uint4(0u, 0u, 0u, 0u);
     if (p >= Lpad) return;
     RayElem e = {0.f, 0.f, 0.f, 0.f};
     if (p < L) {
@@ -435,7 +439,7 @@ __global__ __launch_bounds__(64) void ray_fill_kernel(
 // list from t % 8).
 // kCount: elements walked are added to stats[0] (measurement).
 // kSeg (vertex queries of a model with segments): the crossings with the faces of the lane's own segments are counted
-// as well (seg_count[b][slot][8]; seg_elem_mask / seg_vmask of the model).
+// as well (seg_count[b][slot][2], four signed byte counters per word; seg_elem_mask / seg_vmask of the model).
 template <bool kVerts, bool kCount, bool kSeg>
 __global__ __launch_bounds__(64) void ray_leaf_kernel(
     const float* __restrict__ pts, const RayElem* __restrict__ stream, const RayTile* __restrict__ tiles,
@@ -513,13 +517,11 @@ __global__ __launch_bounds__(64) void ray_leaf_kernel(
         }
         if (w.active && crossings != 0) atomicAdd(&count[((size_t)w.b * qblocks) * kRayQueries + w.slot], crossings);
         if (kSeg && w.active && (pa != kSegBias || pb != kSegBias)) {             // few lanes
-            int32_t* sc = seg_count + 8 * (((size_t)w.b * qblocks) * kRayQueries + w.slot);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int ca = (int)((pa >> (8 * k)) & 255u) - 128, cb = (int)((pb >> (8 * k)) & 255u) - 128;
-                if (ca != 0) atomicAdd(sc + k, ca);
-                if (cb != 0) atomicAdd(sc + 4 + k, cb);
-            }
+            // two words of four byte-wide counters per ray; a tile's (biased) byte sums are added as ONE integer: the
+            // running word may borrow across its bytes, the final word is the exact sum all the same (seg_leaf_count)
+            int32_t* sc = seg_count + 2 * (((size_t)w.b * qblocks) * kRayQueries + w.slot);
+            if (pa != kSegBias) atomicAdd(sc, (int32_t)(pa - kSegBias));
+            if (pb != kSegBias) atomicAdd(sc + 1, (int32_t)(pb - kSegBias));
         }
     }
     if (kCount && lane == 0) atomicAdd(stats, (unsigned long long)walked);
@@ -799,6 +801,19 @@ __global__ __launch_bounds__(64) void segment_ray_kernel(
     }
 }
 
+// counter s (0..7) of a ray's two packed words: the words are sums of signed per-byte contributions (|total| < 128 per
+// byte), so the bytes are peeled off from the low end, each one's sign carried into the rest
+__device__ __forceinline__ int seg_leaf_count(const int32_t* words, int s)
+{
+    int32_t x = words[s >> 2];
+    int c = 0;
+    for (int k = 0; k <= (s & 3); ++k) {
+        c = (int)(int8_t)(x & 255);
+        x = (x - c) >> 8;
+    }
+    return c;
+}
+
 // vertices that are NOT exterior to their own segment are re-marked exterior in the body flags
 // (losses.py:87-89, loss.py:265-266)
 __global__ __launch_bounds__(kBlock) void segment_ray_finalize_kernel(
@@ -807,7 +822,7 @@ __global__ __launch_bounds__(kBlock) void segment_ray_finalize_kernel(
     const int32_t* __restrict__ seg_of_q, const int32_t* __restrict__ seg_q_off, const int32_t* __restrict__ seg_q_vidx,
     const int32_t* __restrict__ link_off, const int32_t* __restrict__ link,
     const int32_t* __restrict__ count, const int32_t* __restrict__ list,
-    const int32_t* __restrict__ leaf_counts,      // [B][slots][8] crossings with the segments' body faces, or nullptr
+    const int32_t* __restrict__ leaf_counts,      // [B][slots][2] crossings with the segments' body faces, or nullptr
     const int32_t* __restrict__ vpos, int slots, int V, int K,
     int Qs_total, int S, int nsplit, float thresh, float* __restrict__ seg_w, uint8_t* __restrict__ seg_ext,
     uint8_t* __restrict__ exterior)
@@ -827,7 +842,7 @@ __global__ __launch_bounds__(kBlock) void segment_ray_finalize_kernel(
     const int qq = seg_q_off[s] + list[(size_t)b * Qs_total + q];   // the vertex's slot in the segment tables
     const int v = seg_q_vidx[qq];
     if (leaf_counts) {
-        n += leaf_counts[8 * ((size_t)b * slots + vpos[v]) + s];
+        n += seg_leaf_count(leaf_counts + 2 * ((size_t)b * slots + vpos[v]), s);
     }
     const float* vb = verts + (size_t)b * V * 3;
     const float* cb = caps + (size_t)b * K * 3;
@@ -922,7 +937,7 @@ static RayLayout full_layout(const tuch_contact_model* m, int B, int Q, bool ver
     l.leaf_fill = o; o += align256((size_t)B * L * sizeof(int32_t));
     l.count = o;     o += align256((size_t)B * l.qblocks * kRayQueries * sizeof(int32_t));
     l.seg_count = o;
-    if (verts && m->seg_elem_mask) o += align256(8 * (size_t)B * l.qblocks * kRayQueries * sizeof(int32_t));
+    if (verts && m->seg_elem_mask) o += align256(2 * (size_t)B * l.qblocks * kRayQueries * sizeof(int32_t));
     l.zeroed_bytes = o - l.zeroed;
     l.leaf_off = o;  o += align256((size_t)B * L * sizeof(int32_t));
     l.tiles = o;     o += align256((size_t)B * l.max_tiles * sizeof(RayTile));
@@ -947,7 +962,8 @@ static void launch_ray_boxes(const tuch_contact_model* m, const RayLayout& l, co
     RayElem* st = (RayElem*)(ws + l.stream);
     float* bounds = (float*)(ws + l.bounds);
     hipLaunchKernelGGL(ray_stream_kernel, dim3(ceil_div(l.T, kBlock), B), dim3(kBlock), 0, s, verts,
-                       (const int32_t*)m->tree_vidx, (const float*)m->tree_sign, m->V, m->tree_exact_len, l.T, st);
+                       (const int32_t*)m->tree_vidx, (const float*)m->tree_sign, m->V, m->tree_exact_len, l.T, st,
+                       (uint4*)(ws + l.zeroed), l.zeroed_bytes / sizeof(uint4));
     hipLaunchKernelGGL(ray_leaf_bounds_kernel, dim3(ceil_div(m->tree_leaves, kBoundsBlock / 64), B), dim3(kBoundsBlock), 0, s,
                        (const RayElem*)st, l.T, (const TreeNode*)m->tree_node, m->tree_nodes,
                        (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, bounds);
@@ -958,8 +974,7 @@ template <bool kVerts>
 static int launch_ray_counts(const tuch_contact_model* m, const RayLayout& l, const float* verts, const float* queries,
                              const int32_t* counts, int B, int Q, char* ws, hipStream_t s, unsigned long long* stats)
 {
-    if (hipMemsetAsync(ws + l.zeroed, 0, l.zeroed_bytes, s) != hipSuccess) return TUCH_ERR_HIP;
-    launch_ray_boxes(m, l, verts, B, ws, s);
+    launch_ray_boxes(m, l, verts, B, ws, s);          // clears the counters (l.zeroed) as well
     const int L = m->tree_leaves;
     const TreeNode* nodes = (const TreeNode*)m->tree_node;
     // the leaves are the height-0 entries of the tree's height table (tree_height_off_host[0] == 0)

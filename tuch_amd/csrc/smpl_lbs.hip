@@ -430,8 +430,11 @@ __global__ __launch_bounds__(256) void assemble_joints_kernel(
 // ----------------------------------------------------------------------------------- backward
 // g_all[b][54][3] = scatter of g_joints through joint_map (deterministic gather form)
 __global__ __launch_bounds__(64) void joints_bwd_kernel(
-    const float* __restrict__ g_joints, const int32_t* __restrict__ joint_map, float* __restrict__ g_all)
+    const float* __restrict__ g_joints, const int32_t* __restrict__ joint_map, float* __restrict__ g_all,
+    float* __restrict__ gA_clear)
 {
+    // also clears the body's [32][16] accumulator of the skinning adjoint, which runs next (no memset node in between)
+    for (int i = threadIdx.x; i < 32 * 16; i += 64) gA_clear[(size_t)blockIdx.x * 32 * 16 + i] = 0.f;
     // the map and the body's 49 x 3 gradients go to LDS in one round of loads; the 49-way match runs from there
     __shared__ int sMap[kOutJoints];
     __shared__ float sG[kOutJoints * 3];
@@ -1006,11 +1009,7 @@ extern "C" int tuch_smpl_backward_split(const tuch_smpl_model* m, const float* g
     float *g_all = (float*)(ws + l.g_all), *g_vposed = (float*)(ws + l.g_vposed), *gA_part = (float*)(ws + l.gA_part),
           *feat_part = (float*)(ws + l.feat_part);
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(gA_part, 0, (size_t)B * 32 * 16 * sizeof(float), s) != hipSuccess) {
-        tuch_set_error("tuch_smpl_backward: hipMemsetAsync failed");
-        return TUCH_ERR_HIP;
-    }
-    hipLaunchKernelGGL(joints_bwd_kernel, dim3(B), dim3(64), 0, s, g_joints, (const int32_t*)m->joint_map, g_all);
+    hipLaunchKernelGGL(joints_bwd_kernel, dim3(B), dim3(64), 0, s, g_joints, (const int32_t*)m->joint_map, g_all, gA_part);
     hipLaunchKernelGGL(skin_bwd_kernel, dim3(l.skin_blocks, B), dim3(kSkinBlock), 0, s, g_verts, (const float*)g_all,
                        (const float*)m->Jrx, (const int32_t*)m->extra_ids, v_posed, A, (const float*)m->weights, m->V,
                        g_vposed, gA_part);

@@ -63,6 +63,19 @@ def off_default_stream(device):
         cur.wait_stream(s)
 
 
+_ONES = {}
+
+
+def backward_scalar(loss: torch.Tensor) -> None:
+    """``loss.backward()`` for a scalar loss with the seed gradient (ones) taken from a cache: autograd otherwise fills a
+    fresh one per call, a launch of its own at the head of every backward chain."""
+    key = (loss.device, loss.dtype, tuple(loss.shape))
+    seed = _ONES.get(key)
+    if seed is None:
+        seed = _ONES[key] = torch.ones(loss.shape, dtype=loss.dtype, device=loss.device)
+    loss.backward(gradient=seed)
+
+
 def _workspace(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
 
@@ -334,7 +347,9 @@ class _Stage2Tail(torch.autograd.Function):
                 _C.ptr(j), _C.ptr(cam_t), _C.ptr(cam_c), _C.ptr(j2d), _C.ptr(conf), _C.ptr(pose), _C.ptr(means),
                 _C.ptr(precisions), _C.ptr(logw), b, nj, means.shape[0], float(const['focal']), float(const['sigma']),
                 float(const['prior_scale']), _C.ptr(small), _C.ptr(gj), _C.ptr(gc), _C.ptr(gp), _C.stream()))
-            return (r2r, ij, small, gj, gc, gp)
+            # the cleared vertex gradient the backward pass accumulates into: filled here, beside the walk, instead of
+            # between two kernels of the backward chain
+            return (r2r, ij, small, gj, gc, gp, torch.zeros_like(v))
         exterior, _, partner, _extra = model.exterior_and_partner(v, apply_segments=const['apply_segments'],
                                                                   also=beside_the_walk)
         terms = torch.empty(b, 2, dtype=torch.float32, device=v.device)
@@ -346,6 +361,7 @@ class _Stage2Tail(torch.autograd.Function):
         ctx.save_for_backward(v, partner, exterior, valid, ij, gj, gc, gp)
         ctx.model, ctx.const, ctx.dims = model, const, (b, nj, p)
         ctx.in_dtypes = (verts.dtype, joints.dtype, camera_t.dtype, body_pose.dtype)
+        ctx.gv_cleared = _extra[6]
         return out[0]
 
     @staticmethod
@@ -360,7 +376,9 @@ class _Stage2Tail(torch.autograd.Function):
         _C.check(L.tuch_smplify_tail_bwd(_C.ptr(g), _C.ptr(valid), _C.ptr(gj), _C.ptr(gc), _C.ptr(gp), b, nj, p,
                                          float(const['contact_scale']), float(const['r2r_scale']), _C.ptr(gt), _C.ptr(gr),
                                          _C.ptr(gj_o), _C.ptr(gc_o), _C.ptr(gp_o), _C.stream()))
-        gv = torch.zeros_like(v)
+        gv, ctx.gv_cleared = ctx.gv_cleared, None
+        if gv is None:                           # a second backward pass through the same node
+            gv = torch.zeros_like(v)
         _C.check(L.tuch_contact_terms_bwd(_C.ptr(v), _C.ptr(partner), _C.ptr(exterior), _C.ptr(gt), b, v.shape[1],
                                           MODE_SMPLIFY, float(const['euclthres']), _C.ptr(gv), _C.stream()))
         if p:

@@ -19,6 +19,7 @@ import torch
 from .losses import (body_fitting_loss, camera_fitting_loss, contact_fitting_loss, contact_model_for,
                      stage2_objective)
 from .prior import MaxMixturePrior
+from .. import ops
 
 log = logging.getLogger(__name__)
 
@@ -94,7 +95,7 @@ class SMPLifyDC():
                 static['params'] = [p.detach().clone() for p in params]
             loss, verts = iteration()
             optimizer.zero_grad(set_to_none=graph_ok)
-            loss.backward()
+            ops.backward_scalar(loss)
             optimizer.step()
             static['verts'] = verts
             static['loss'] = loss.detach()
@@ -155,7 +156,7 @@ class SMPLifyDC():
         def _one(self):
             loss, verts = self.iteration()
             self.optimizer.zero_grad(set_to_none=True)
-            loss.backward()
+            ops.backward_scalar(loss)
             self.optimizer.step()
             self.verts, self.loss = verts, loss.detach()
 
