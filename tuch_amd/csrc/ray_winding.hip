@@ -76,43 +76,56 @@ __device__ __forceinline__ void slab_project(float x, float y, float z, float (&
     p[3] = x + y; p[4] = x - y; p[5] = x + z; p[6] = x - z; p[7] = y + z; p[8] = y - z;
 }
 
-// slabs of every leaf in sheared coordinates, one wave per (leaf, body); widened by a few ulps so that a ray
-// decided by the float edge functions to pass on the leaf's side of a shared edge can never test as missing it
+// minimum over the 16 lanes of a DPP row, left in every lane: quad swaps, then the two mirror controls -- single VALU
+// instructions, no LDS crossbar (a 64-lane shuffle reduction of the 18 slab values was ~200 instructions per leaf)
+template <int kCtrl>
+__device__ __forceinline__ float dpp_move(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), kCtrl, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row_min(float v)
+{
+    v = fminf(v, dpp_move<0xB1>(v));        // quad_perm [1,0,3,2]
+    v = fminf(v, dpp_move<0x4E>(v));        // quad_perm [2,3,0,1]
+    v = fminf(v, dpp_move<0x141>(v));       // row_half_mirror
+    v = fminf(v, dpp_move<0x140>(v));       // row_mirror
+    return v;
+}
+
+// slabs of every leaf in sheared coordinates, 16 lanes per (leaf, body): a leaf strip is a few dozen elements, so a
+// whole wavefront per leaf was mostly idle lanes behind four dependent rounds of loads; widened by a few ulps so that
+// a ray decided by the float edge functions to pass on the leaf's side of a shared edge can never test as missing it
 __global__ __launch_bounds__(kBoundsBlock) void ray_leaf_bounds_kernel(
     const RayElem* __restrict__ stream, int T, const TreeNode* __restrict__ nodes, int N,
     const int32_t* __restrict__ height_off, const int32_t* __restrict__ height_nodes, float* __restrict__ bounds)
 {
     const int b = blockIdx.y;
     const RayElem* st = stream + (size_t)b * T;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int i = height_off[0] + blockIdx.x * (kBoundsBlock / 64) + wave;
-    if (i >= height_off[1]) return;
-    const int node = height_nodes[i];
-    const int off = nodes[node].ex_off, len = nodes[node].ex_len;
-    float lo[kSlabs], hi[kSlabs];
+    const int group = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    const int i = height_off[0] + blockIdx.x * (kBoundsBlock / 16) + group;
+    const bool real = i < height_off[1];                // all lanes stay: the DPP rows need them
+    const int node = height_nodes[real ? i : height_off[0]];
+    const int off = nodes[node].ex_off, len = real ? nodes[node].ex_len : 0;
+    float lo[kSlabs], nhi[kSlabs];                      // minima of the projections and of their negatives
 #pragma unroll
-    for (int k = 0; k < kSlabs; ++k) { lo[k] = 3.0e38f; hi[k] = -3.0e38f; }
-    for (int p = lane; p < len; p += 64) {
+    for (int k = 0; k < kSlabs; ++k) { lo[k] = 3.0e38f; nhi[k] = 3.0e38f; }
+    for (int p = sub; p < len; p += 16) {
         const RayElem e = st[off + p];
         float pr[kSlabs];
         slab_project(e.x, e.y, e.z, pr);
 #pragma unroll
-        for (int k = 0; k < kSlabs; ++k) { lo[k] = fminf(lo[k], pr[k]); hi[k] = fmaxf(hi[k], pr[k]); }
+        for (int k = 0; k < kSlabs; ++k) { lo[k] = fminf(lo[k], pr[k]); nhi[k] = fminf(nhi[k], -pr[k]); }
     }
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1)
-#pragma unroll
-        for (int k = 0; k < kSlabs; ++k) {
-            lo[k] = fminf(lo[k], __shfl_xor(lo[k], m));
-            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m));
-        }
-    if (lane == 0) {
+    for (int k = 0; k < kSlabs; ++k) { lo[k] = row_min(lo[k]); nhi[k] = row_min(nhi[k]); }
+    if (real && sub == 0) {
         float* o = bounds + ((size_t)b * N + node) * (2 * kSlabStride);
 #pragma unroll
         for (int k = 0; k < kSlabs; ++k) {
-            const float pad = 4e-7f * fmaxf(fabsf(lo[k]), fabsf(hi[k])) + 1e-9f;
+            const float hi = -nhi[k];
+            const float pad = 4e-7f * fmaxf(fabsf(lo[k]), fabsf(hi)) + 1e-9f;
             o[k] = lo[k] - pad;
-            o[kSlabStride + k] = hi[k] + pad;
+            o[kSlabStride + k] = hi + pad;
         }
         o[kSlabs] = 0.0f;
         o[kSlabStride + kSlabs] = 0.0f;
@@ -964,7 +977,7 @@ static void launch_ray_boxes(const tuch_contact_model* m, const RayLayout& l, co
     hipLaunchKernelGGL(ray_stream_kernel, dim3(ceil_div(l.T, kBlock), B), dim3(kBlock), 0, s, verts,
                        (const int32_t*)m->tree_vidx, (const float*)m->tree_sign, m->V, m->tree_exact_len, l.T, st,
                        (uint4*)(ws + l.zeroed), l.zeroed_bytes / sizeof(uint4));
-    hipLaunchKernelGGL(ray_leaf_bounds_kernel, dim3(ceil_div(m->tree_leaves, kBoundsBlock / 64), B), dim3(kBoundsBlock), 0, s,
+    hipLaunchKernelGGL(ray_leaf_bounds_kernel, dim3(ceil_div(m->tree_leaves, kBoundsBlock / 16), B), dim3(kBoundsBlock), 0, s,
                        (const RayElem*)st, l.T, (const TreeNode*)m->tree_node, m->tree_nodes,
                        (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, bounds);
 }

@@ -538,23 +538,24 @@ __global__ __launch_bounds__(kSkinBlock) void skin_bwd_kernel(
     for (int r = 0; r < 4; ++r) atomicAdd(&out[(lq * 4 + r) * 16 + lm], acc[r]);
 }
 
-// part[block][m][n] = sum_{k in the block's 512 columns} g_vposed[m][k] * blend[n][k];  n < 224.
-// One workgroup per (512-wide K block, up to kBlendBwdGroups x 16 bodies, kBlendBwdTiles 16-column tiles), one
+// part[block][m][n] = sum_{k in the block's 256 columns} g_vposed[m][k] * blend[n][k];  n < 224.
+// One workgroup per (256-wide K block, up to kBlendBwdGroups x 16 bodies, kBlendBwdTiles 16-column tiles), one
 // wavefront per 64 of its columns: the blend tile is loaded once and used for all body groups of the wave; K index
 // permuted so that every lane reads 4 consecutive floats (rows start on 8-byte boundaries only -- 3V is even, not a
 // multiple of 4 -- so the loads are typed 4-byte aligned); all 24 loads of a wavefront are issued before its first MFMA
-// waits.  The eight partial results meet in LDS, wavefront w adds up and stores accumulator w: plain stores into the
-// block's own [Bpad][224] slice (no atomics, nothing to clear); pose_bwd_kernel adds the ~41 slices up.
+// waits.  The four partial results meet in LDS, wavefront w adds up and stores accumulators w and w + 4: plain stores
+// into the block's own [Bpad][224] slice (no atomics, nothing to clear); pose_bwd_kernel adds the ~81 slices up.
 constexpr int kBlendBwdTiles = 2;
 constexpr int kBlendBwdGroups = 4;
 constexpr int kBlendBwdChunk = 64;          // K per wavefront
-constexpr int kBlendBwdWaves = kBlendBwdTiles * kBlendBwdGroups;
+constexpr int kBlendBwdWaves = 4;           // 3 workgroups fit a CU: all 81 x 7 of them run at once at batch 64
+constexpr int kBlendBwdAccs = kBlendBwdTiles * kBlendBwdGroups;
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 __global__ __launch_bounds__(64 * kBlendBwdWaves) void blend_bwd_kernel(
     const float* __restrict__ g_vposed, const float* __restrict__ blend, int B, int N3, int bpad,
     float* __restrict__ part)
 {
-    __shared__ float red[kBlendBwdWaves][kBlendBwdWaves * 4][64];
+    __shared__ float red[kBlendBwdWaves][kBlendBwdAccs * 4][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lm = lane & 15, lq = lane >> 4;
     const int g0 = blockIdx.y * kBlendBwdGroups, j0 = blockIdx.z * kBlendBwdTiles;
     const int k_beg = (blockIdx.x * kBlendBwdWaves + wave) * kBlendBwdChunk;
@@ -603,15 +604,18 @@ __global__ __launch_bounds__(64 * kBlendBwdWaves) void blend_bwd_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[wave][(g * kBlendBwdTiles + j) * 4 + r][lane] = acc[g][j][r];
     __syncthreads();
-    const int g = wave / kBlendBwdTiles, j = wave % kBlendBwdTiles;      // the accumulator this wavefront finishes
-    if ((g0 + g) * 16 >= B) return;
     part += (size_t)blockIdx.x * bpad * 224;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float sum = 0.f;
+    for (int a = wave; a < kBlendBwdAccs; a += kBlendBwdWaves) {         // the accumulators this wavefront finishes
+        const int g = a / kBlendBwdTiles, j = a % kBlendBwdTiles;
+        if ((g0 + g) * 16 >= B) continue;
 #pragma unroll
-        for (int w = 0; w < kBlendBwdWaves; ++w) sum += red[w][wave * 4 + r][lane];
-        part[((size_t)((g0 + g) * 16 + lq * 4 + r)) * 224 + (j0 + j) * 16 + lm] = sum;
+        for (int r = 0; r < 4; ++r) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < kBlendBwdWaves; ++w) sum += red[w][a * 4 + r][lane];
+            part[((size_t)((g0 + g) * 16 + lq * 4 + r)) * 224 + (j0 + j) * 16 + lm] = sum;
+        }
     }
 }
 
@@ -633,7 +637,7 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(
     __shared__ float sUp[kJoints][9], sGrel[kJoints][3];
     __shared__ float sGall[kJoints][3], sAA[kJoints][3];
     __shared__ int sParent[kJoints], sDepth[kJoints];
-    constexpr int kGroups = 8, kPer = 6;             // slices of the blend adjoint: 48 per pass
+    constexpr int kGroups = 8, kPer = 11;            // slices of the blend adjoint: 88 per pass
     __shared__ float sPart[kGroups][224];
     const int b = blockIdx.x, t = threadIdx.x;
     // Everything the block reads from global memory is requested here, in one go: the kernel is a handful of threads
