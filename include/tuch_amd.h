@@ -127,6 +127,19 @@ int tuch_smplify_tail_bwd(const float* grad_out, const uint8_t* valid, const flo
                           int B, int NJ, int P, float contact_scale, float r2r_scale, float* grad_contact, float* grad_r2r,
                           float* gj_out, float* gc_out, float* gp_out, void* stream);
 
+/* The same tail (tuch/smplify/losses.py:96-123) in one launch per direction: contact sums + the row of region minima per
+ * body and the objective's total (the block that finishes last adds the bodies up); backward: upstream scalar -> vertex
+ * gradient (contact terms and region minima, grad_points pre-zeroed) and the scaled unit gradients of the small terms.
+ * share: [B] floats of scratch; ticket: one int, zero before the first call, left zero by every call. */
+int tuch_smplify_stage2_finish(const float* points, const int32_t* partner, const uint8_t* exterior,
+                               const uint8_t* body_valid, int B, int N, int mode, float euclthres,
+                               const float* small_terms, const float* r2r, int P, float contact_scale, float r2r_scale,
+                               float* share, int* ticket, float* terms, float* out, void* stream);
+int tuch_smplify_stage2_bwd(const float* grad_out, const uint8_t* body_valid, const float* points, const int32_t* partner,
+                            const uint8_t* exterior, int B, int N, int mode, float euclthres, float contact_scale,
+                            const int32_t* ij, int P, float r2r_scale, const float* gj, const float* gc, const float* gp,
+                            int NJ, float* grad_points, float* gj_out, float* gc_out, float* gp_out, void* stream);
+
 /* ---- per-model constants -------------------------------------------------------------
  * Host tables in, device copies kept by the handle.  Segments follow
  * tuch/utils/segmentation.py:29-99: seg_q = segment_vidx lists; seg_faces = faces of the
@@ -145,6 +158,8 @@ int tuch_contact_model_create(tuch_contact_model** out, int V, int F, const int3
 void tuch_contact_model_destroy(tuch_contact_model* model);
 const uint64_t* tuch_contact_model_mask_bits(const tuch_contact_model* model);
 const int32_t* tuch_contact_model_faces(const tuch_contact_model* model);
+/* eight device ints, zero between calls: arrival counters for tuch_smplify_stage2_finish (one per stream in flight) */
+int32_t* tuch_contact_model_tickets(const tuch_contact_model* model);
 /* The geodesic mask packed in the cluster tree's vertex order (device, same layout as mask_bits with vertex v
  * replaced by its position in tuch_cluster_tree_export's qperm), or NULL without tree or mask: neighbouring
  * positions are neighbours on the surface, so a wavefront of nearby points touches few mask words. */

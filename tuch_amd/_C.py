@@ -51,6 +51,7 @@ _SIGNATURES = {
     'tuch_contact_model_destroy': (None, [c_void_p]),
     'tuch_contact_model_mask_bits': (c_void_p, [c_void_p]),
     'tuch_contact_model_faces': (c_void_p, [c_void_p]),
+    'tuch_contact_model_tickets': (c_void_p, [c_void_p]),
     'tuch_contact_model_tree_mask_bits': (c_void_p, [c_void_p]),
     'tuch_contact_model_info': (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int),
                                         POINTER(c_int), POINTER(c_int)]),
@@ -100,6 +101,12 @@ _SIGNATURES = {
                                   c_size_t, c_void_p]),
     'tuch_smpl_backward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_size_t, c_void_p]),
+    'tuch_smplify_stage2_finish': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
+                                           c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p]),
+    'tuch_smplify_stage2_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
+                                        c_float, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_void_p]),
     'tuch_smpl_forward_split': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
                                         c_void_p, c_void_p, c_size_t, c_void_p]),
     'tuch_smpl_backward_split': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,

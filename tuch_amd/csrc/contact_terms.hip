@@ -159,6 +159,108 @@ __global__ __launch_bounds__(256) void contact_terms_ragged_bwd_kernel(
     atomicAdd(gp + 0, -c * dx); atomicAdd(gp + 1, -c * dy); atomicAdd(gp + 2, -c * dz);
 }
 
+
+// ---- the tail of the SMPLify-DC stage-2 objective in two launches (tuch/smplify/losses.py:96-123) -------------------
+// Forward: one block per body adds up its contact terms (as contact_terms_fwd_kernel) and its row of region minima and
+// leaves the body's share of the objective; the block that finishes last adds the shares up in a fixed order
+//   total = sum_b [ reprojection_b + prior_b + contact_scale (interior_b + exterior_b) + r2r_scale sum_p r2r[b,p] ]
+// (objective_kernel's sum; a launch of its own for one block of additions cost 5 us of the serial tail).
+__global__ __launch_bounds__(kBlock) void stage2_finish_kernel(
+    const float* __restrict__ pts, const int32_t* __restrict__ partner, const uint8_t* __restrict__ exterior,
+    const uint8_t* __restrict__ body_valid, int N, int mode, float euclthres, const float* __restrict__ small,
+    const float* __restrict__ r2r, int P, float contact_scale, float r2r_scale, float* __restrict__ share,
+    int* __restrict__ ticket, float* __restrict__ terms, float* __restrict__ out)
+{
+    __shared__ float smem[kBlock / 64];
+    __shared__ bool last;
+    const int b = blockIdx.x;
+    float in_sum = 0.0f, ex_sum = 0.0f, r_sum = 0.0f;
+    if (!body_valid || body_valid[b]) {
+        const float* pb = pts + (size_t)b * N * 3;
+        for (int i = threadIdx.x; i < N; i += kBlock) {
+            const int p = partner[(size_t)b * N + i];
+            const float dx = pb[3 * i] - pb[3 * p], dy = pb[3 * i + 1] - pb[3 * p + 1],
+                        dz = pb[3 * i + 2] - pb[3 * p + 2];
+            const float d = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
+            const bool ext = exterior[(size_t)b * N + i] != 0;
+            const Term t = contact_term(d, ext, mode, euclthres);
+            if (ext) ex_sum += t.value; else in_sum += t.value;
+        }
+    }
+    if (r2r)
+        for (int p = threadIdx.x; p < P; p += kBlock) r_sum += r2r[(size_t)b * P + p];
+    const float a = block_sum(in_sum, smem);
+    const float c = block_sum(ex_sum, smem);
+    const float r = block_sum(r_sum, smem);
+    if (threadIdx.x == 0) {
+        if (terms) { terms[2 * b] = a; terms[2 * b + 1] = c; }
+        const float mine = (small[2 * b] + small[2 * b + 1]) + contact_scale * (a + c) + r2r_scale * r;
+        __hip_atomic_store(share + b, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    float acc = 0.0f;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += kBlock)
+        acc += __hip_atomic_load(share + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float total = block_sum(acc, smem);
+    if (threadIdx.x == 0) {
+        out[0] = total;
+        __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next call
+    }
+}
+
+// Backward: the upstream scalar g times the objective's constants, straight into the vertex gradient (pre-zeroed):
+// contact terms (contact_terms_bwd_kernel with the weight g contact_scale [body valid]) in the vertex blocks; the last
+// block of every body scatters the region minima (region_pair_min_bwd_kernel with weight g r2r_scale) and scales the
+// unit gradients small_terms_kernel left for the joints, the camera and the pose.  Three launches before.
+__global__ __launch_bounds__(256) void stage2_bwd_kernel(
+    const float* __restrict__ gout, const uint8_t* __restrict__ body_valid, const float* __restrict__ pts,
+    const int32_t* __restrict__ partner, const uint8_t* __restrict__ exterior, int N, int mode, float euclthres,
+    float contact_scale, const int32_t* __restrict__ ij, int P, float r2r_scale, const float* __restrict__ gj,
+    const float* __restrict__ gc, const float* __restrict__ gp, int NJ, float* __restrict__ grad,
+    float* __restrict__ gj_out, float* __restrict__ gc_out, float* __restrict__ gp_out)
+{
+    const int b = blockIdx.y;
+    const float g = gout[0];
+    const float* pb = pts + (size_t)b * N * 3;
+    float* gb = grad + (size_t)b * N * 3;
+    if (blockIdx.x == gridDim.x - 1) {
+        const float gr = r2r_scale * g;
+        if (ij && gr != 0.0f)
+            for (int p = threadIdx.x; p < P; p += 256) {
+                const size_t o = (size_t)b * P + p;
+                const int i = ij[2 * o], j = ij[2 * o + 1];
+                if (i < 0 || j < 0) continue;
+                for (int c = 0; c < 3; ++c) {
+                    const float d = 2.0f * gr * (pb[3 * i + c] - pb[3 * j + c]);
+                    atomicAdd(gb + 3 * i + c, d);
+                    atomicAdd(gb + 3 * j + c, -d);
+                }
+            }
+        for (int i = threadIdx.x; i < NJ * 3; i += 256) gj_out[(size_t)b * NJ * 3 + i] = g * gj[(size_t)b * NJ * 3 + i];
+        if (threadIdx.x < 3) gc_out[b * 3 + threadIdx.x] = g * gc[b * 3 + threadIdx.x];
+        if (gp && threadIdx.x < 69) gp_out[b * 69 + threadIdx.x] = g * gp[b * 69 + threadIdx.x];
+        return;
+    }
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float gs = (!body_valid || body_valid[b]) ? contact_scale * g : 0.0f;
+    if (gs == 0.0f) return;
+    const bool ext = exterior[(size_t)b * N + i] != 0;
+    const int p = partner[(size_t)b * N + i];
+    const float dx = pb[3 * i] - pb[3 * p], dy = pb[3 * i + 1] - pb[3 * p + 1], dz = pb[3 * i + 2] - pb[3 * p + 2];
+    const float d = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
+    if (!(d > 0.0f)) return;
+    const Term t = contact_term(d, ext, mode, euclthres);
+    if (t.dd == 0.0f) return;
+    const float c = gs * t.dd / d;
+    float* gi = gb + 3 * (size_t)i;
+    float* gq = gb + 3 * (size_t)p;
+    atomicAdd(gi + 0, c * dx); atomicAdd(gi + 1, c * dy); atomicAdd(gi + 2, c * dz);
+    atomicAdd(gq + 0, -c * dx); atomicAdd(gq + 1, -c * dy); atomicAdd(gq + 2, -c * dz);
+}
+
 }  // namespace
 
 extern "C" int tuch_contact_terms_fwd(const float* points, const int32_t* partner,
@@ -208,4 +310,39 @@ extern "C" int tuch_contact_terms_ragged_bwd(const float* points, const int32_t*
     hipLaunchKernelGGL(contact_terms_ragged_bwd_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream,
                        points, partner, exterior, body_of_point, grad_scale, N, mode, euclthres, grad_points);
     return tuch_check_launch("tuch_contact_terms_ragged_bwd");
+}
+
+// The stage-2 objective behind the inside test and the nearest-vertex search, and its backward pass, as one launch
+// each (see stage2_finish_kernel / stage2_bwd_kernel).  share: [B] floats of scratch; ticket: one int, zero before the
+// first call and left zero by every call (one per stream in flight); terms: [B,2] or NULL.
+extern "C" int tuch_smplify_stage2_finish(const float* points, const int32_t* partner, const uint8_t* exterior,
+                                          const uint8_t* body_valid, int B, int N, int mode, float euclthres,
+                                          const float* small_terms, const float* r2r, int P, float contact_scale,
+                                          float r2r_scale, float* share, int* ticket, float* terms, float* out,
+                                          void* stream)
+{
+    TUCH_REQUIRE(points && partner && exterior && small_terms && share && ticket && out,
+                 "tuch_smplify_stage2_finish: null pointer");
+    TUCH_REQUIRE(B > 0 && N > 0 && P >= 0 && (mode == 0 || mode == 1), "tuch_smplify_stage2_finish: bad arguments");
+    hipLaunchKernelGGL(stage2_finish_kernel, dim3(B), dim3(kBlock), 0, (hipStream_t)stream, points, partner, exterior,
+                       body_valid, N, mode, euclthres, small_terms, (P > 0 ? r2r : (const float*)nullptr), P,
+                       contact_scale, r2r_scale, share, ticket, terms, out);
+    return tuch_check_launch("tuch_smplify_stage2_finish");
+}
+
+extern "C" int tuch_smplify_stage2_bwd(const float* grad_out, const uint8_t* body_valid, const float* points,
+                                       const int32_t* partner, const uint8_t* exterior, int B, int N, int mode,
+                                       float euclthres, float contact_scale, const int32_t* ij, int P, float r2r_scale,
+                                       const float* gj, const float* gc, const float* gp, int NJ, float* grad_points,
+                                       float* gj_out, float* gc_out, float* gp_out, void* stream)
+{
+    TUCH_REQUIRE(grad_out && points && partner && exterior && gj && gc && grad_points && gj_out && gc_out &&
+                 (!gp || gp_out), "tuch_smplify_stage2_bwd: null pointer");
+    TUCH_REQUIRE(B > 0 && B <= 65535 && N > 0 && NJ > 0 && P >= 0 && (mode == 0 || mode == 1),
+                 "tuch_smplify_stage2_bwd: bad arguments");
+    hipLaunchKernelGGL(stage2_bwd_kernel, dim3(ceil_div(N, 256) + 1, B), dim3(256), 0, (hipStream_t)stream, grad_out,
+                       body_valid, points, partner, exterior, N, mode, euclthres, contact_scale,
+                       (P > 0 ? ij : (const int32_t*)nullptr), P, r2r_scale, gj, gc, gp, NJ, grad_points, gj_out, gc_out,
+                       gp_out);
+    return tuch_check_launch("tuch_smplify_stage2_bwd");
 }

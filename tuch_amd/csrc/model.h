@@ -62,6 +62,7 @@ struct tuch_contact_model {
     int device;
     int V, F;
     int32_t* faces;            // [F,3]
+    int32_t* tickets;          // [8] arrival counters of "the last block adds up" kernels, zero between calls
     uint64_t* mask_bits;       // [W][V] or nullptr
     // triangle strips over `faces` (built at create): stream of vertex ids with a per-element
     // sign: 0 = priming vertex (no triangle), +1/-1 = emit triangle (p-2, p-1, p) with that

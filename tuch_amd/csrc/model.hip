@@ -43,7 +43,7 @@ extern "C" void tuch_contact_model_destroy(tuch_contact_model* m)
     if (!m) return;
     void* dev[] = {m->ring_off, m->ring_vidx, m->faces, m->mask_bits, m->strip_vidx, m->strip_sign, m->tree_node, m->tree_vidx, m->tree_sign, m->tree_qperm,
                    m->tree_height_off, m->tree_height_nodes, m->tree_frontier_nodes, m->tree_launch_order, m->tree_ancestors, m->tree_rows, m->tree_mask_bits, m->tree_masked, m->seg_blocks, m->seg_of_q, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces, m->seg_link_off, m->seg_link, m->seg_ray_off, m->seg_ray_ent, m->seg_elem_mask, m->seg_vmask, m->seg_vpos, m->seg_cap_off, m->seg_cap_ent,
-                   m->cap_off, m->cap_vidx, m->region_off, m->region_vidx, m->pairs, m->pair_mask, m->pair_mask_off};
+                   m->cap_off, m->cap_vidx, m->region_off, m->region_vidx, m->pairs, m->pair_mask, m->pair_mask_off, m->tickets};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     free(m->tree_frontier_off_host);
@@ -80,6 +80,10 @@ extern "C" int tuch_contact_model_create(
     m->F = F;
     (void)hipGetDevice(&m->device);
     int rc = upload(&m->faces, faces, (size_t)F * 3);
+    if (rc == TUCH_OK) {
+        const int32_t zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        rc = upload(&m->tickets, zeros, 8);
+    }
     if (rc == TUCH_OK) {
         std::vector<int32_t> sv;
         std::vector<float> ss;
@@ -381,6 +385,11 @@ extern "C" const uint64_t* tuch_contact_model_mask_bits(const tuch_contact_model
 extern "C" const uint64_t* tuch_contact_model_tree_mask_bits(const tuch_contact_model* m)
 {
     return m ? m->tree_mask_bits : nullptr;
+}
+
+extern "C" int32_t* tuch_contact_model_tickets(const tuch_contact_model* m)
+{
+    return m ? m->tickets : nullptr;
 }
 
 extern "C" const int32_t* tuch_contact_model_faces(const tuch_contact_model* m)

@@ -64,8 +64,6 @@ def off_default_stream(device):
 
 
 _ONES = {}
-
-
 def backward_scalar(loss: torch.Tensor) -> None:
     """``loss.backward()`` for a scalar loss with the seed gradient (ones) taken from a cache: autograd otherwise fills a
     fresh one per call, a launch of its own at the head of every backward chain."""
@@ -352,12 +350,12 @@ class _Stage2Tail(torch.autograd.Function):
             return (r2r, ij, small, gj, gc, gp, torch.zeros_like(v))
         exterior, _, partner, _extra = model.exterior_and_partner(v, apply_segments=const['apply_segments'],
                                                                   also=beside_the_walk)
-        terms = torch.empty(b, 2, dtype=torch.float32, device=v.device)
-        _C.check(L.tuch_contact_terms_fwd(_C.ptr(v), _C.ptr(partner), _C.ptr(exterior), _C.ptr(valid), b, v.shape[1],
-                                          MODE_SMPLIFY, float(const['euclthres']), _C.ptr(terms), _C.stream()))
         out = torch.empty(1, dtype=torch.float32, device=v.device)
-        _C.check(L.tuch_smplify_objective(_C.ptr(small), _C.ptr(terms), _C.ptr(r2r), b, p, float(const['contact_scale']),
-                                          float(const['r2r_scale']), _C.ptr(out), _C.stream()))
+        share = torch.empty(b, dtype=torch.float32, device=v.device)
+        _C.check(L.tuch_smplify_stage2_finish(_C.ptr(v), _C.ptr(partner), _C.ptr(exterior), _C.ptr(valid), b, v.shape[1],
+                                              MODE_SMPLIFY, float(const['euclthres']), _C.ptr(small), _C.ptr(r2r), p,
+                                              float(const['contact_scale']), float(const['r2r_scale']), _C.ptr(share),
+                                              model.ticket(), None, _C.ptr(out), _C.stream()))
         ctx.save_for_backward(v, partner, exterior, valid, ij, gj, gc, gp)
         ctx.model, ctx.const, ctx.dims = model, const, (b, nj, p)
         ctx.in_dtypes = (verts.dtype, joints.dtype, camera_t.dtype, body_pose.dtype)
@@ -370,20 +368,15 @@ class _Stage2Tail(torch.autograd.Function):
         b, nj, p = ctx.dims
         const, L = ctx.const, _C.lib()
         g = g.reshape(1).to(torch.float32).contiguous()
-        gt = torch.empty(b, 2, dtype=torch.float32, device=v.device)
-        gr = torch.empty(b, p, dtype=torch.float32, device=v.device) if p else None
         gj_o, gc_o, gp_o = torch.empty_like(gj), torch.empty_like(gc), torch.empty_like(gp)
-        _C.check(L.tuch_smplify_tail_bwd(_C.ptr(g), _C.ptr(valid), _C.ptr(gj), _C.ptr(gc), _C.ptr(gp), b, nj, p,
-                                         float(const['contact_scale']), float(const['r2r_scale']), _C.ptr(gt), _C.ptr(gr),
-                                         _C.ptr(gj_o), _C.ptr(gc_o), _C.ptr(gp_o), _C.stream()))
         gv, ctx.gv_cleared = ctx.gv_cleared, None
         if gv is None:                           # a second backward pass through the same node
             gv = torch.zeros_like(v)
-        _C.check(L.tuch_contact_terms_bwd(_C.ptr(v), _C.ptr(partner), _C.ptr(exterior), _C.ptr(gt), b, v.shape[1],
-                                          MODE_SMPLIFY, float(const['euclthres']), _C.ptr(gv), _C.stream()))
-        if p:
-            _C.check(L.tuch_region_pair_min_bwd(ctx.model._handle, _C.ptr(v), b, _C.ptr(ij), _C.ptr(gr), _C.ptr(gv),
-                                                _C.stream()))
+        _C.check(L.tuch_smplify_stage2_bwd(_C.ptr(g), _C.ptr(valid), _C.ptr(v), _C.ptr(partner), _C.ptr(exterior), b,
+                                           v.shape[1], MODE_SMPLIFY, float(const['euclthres']),
+                                           float(const['contact_scale']), _C.ptr(ij), p, float(const['r2r_scale']),
+                                           _C.ptr(gj), _C.ptr(gc), _C.ptr(gp), nj, _C.ptr(gv), _C.ptr(gj_o), _C.ptr(gc_o),
+                                           _C.ptr(gp_o), _C.stream()))
         dv, dj, dc, dp = ctx.in_dtypes
         return gv.to(dv), gj_o.to(dj), gc_o.to(dc), gp_o.to(dp), None, None, None, None
 
@@ -583,6 +576,17 @@ class ContactModel:
         _C.check(L.tuch_contact_model_strips(self._handle, None, None, vidx.ctypes.data_as(ctypes.c_void_p),
                                              sign.ctypes.data_as(ctypes.c_void_p)))
         return vidx, sign, k.value
+
+    def ticket(self) -> ctypes.c_void_p:
+        """Arrival counter (device int, zero between calls) of the "last block adds up" kernels for the CURRENT stream:
+        the model owns eight, dealt out round-robin to the streams that ask, so that up to eight calls in flight on
+        different streams do not share one (a counter is busy only while its kernel runs)."""
+        key = torch.cuda.current_stream().cuda_stream
+        slots = self.__dict__.setdefault('_ticket_slots', {})
+        if key not in slots:
+            slots[key] = len(slots) % 8
+        base = _C.lib().tuch_contact_model_tickets(self._handle)
+        return ctypes.c_void_p(base + 4 * slots[key])
 
     def exterior_and_partner(self, verts: torch.Tensor, apply_segments: bool = True, also=None):
         """exterior_flags + v2v_min of the same vertices -> (exterior, min_d2, partner[, also()]).
