@@ -83,7 +83,7 @@ struct tuch_contact_model {
     int32_t* tree_ancestors;   // [frontier_total][8]
     int32_t* tree_rows;        // [tree_nodes][2]
     // geodesic mask in the tree's vertex order: tree_mask_bits[w][j'], bit k = geomask[qperm[j']][qperm[64 w + k]],
-    // w < 2 * tree_qblocks, j' < V; tree_masked[qb][node] != 0: no allowed pair between query block qb and the node
+    // w < 2 * tree_qblocks, j' < V; tree_masked[w][node] != 0: no allowed pair between the 64 columns of word w and the node
     uint64_t* tree_mask_bits;
     int32_t* tree_masked;
     int tree_num_frontiers;

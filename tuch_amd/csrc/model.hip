@@ -133,10 +133,9 @@ extern "C" int tuch_contact_model_create(
                     for (int ip = 0; ip < V; ++ip)
                         if (row[t.qperm[ip]]) bits[(size_t)(ip >> 6) * V + jp] |= (uint64_t)1 << (ip & 63);
                 }
-                std::vector<int32_t> masked((size_t)t.num_qblocks * N, 0);
-                for (int qb = 0; qb < t.num_qblocks; ++qb) {
-                    const uint64_t* w0 = bits.data() + (size_t)(2 * qb) * V;
-                    const uint64_t* w1 = w0 + V;
+                std::vector<int32_t> masked((size_t)Wp * N, 0);          // per 64-column block (one wavefront's columns)
+                for (int qb = 0; qb < Wp; ++qb) {
+                    const uint64_t* w0 = bits.data() + (size_t)qb * V;
                     for (int i = N - 1; i >= 0; --i) {
                         const int c0 = t.nodes[(size_t)i * 8 + 5], c1 = t.nodes[(size_t)i * 8 + 6];
                         int32_t all = 1;
@@ -144,7 +143,7 @@ extern "C" int tuch_contact_model_create(
                             all = masked[(size_t)qb * N + c0] && masked[(size_t)qb * N + c1];
                         } else {
                             const int lo = t.rows[(size_t)i * 2], n = t.rows[(size_t)i * 2 + 1];
-                            for (int j = lo; j < lo + n && all; ++j) all = (w0[j] | w1[j]) == 0;
+                            for (int j = lo; j < lo + n && all; ++j) all = w0[j] == 0;
                         }
                         masked[(size_t)qb * N + i] = all;
                     }

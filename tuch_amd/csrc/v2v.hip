@@ -465,7 +465,7 @@ __device__ __forceinline__ float box_dist2(const Column& c, const float* __restr
 }
 
 // seed: descend to the admissible leaf nearest to the block's box, evaluate its rows.
-// grid (B, 64-column blocks); the static mask table is kept per 128-column block (qb >> 1).
+// grid (B, 64-column blocks); the static mask table is kept per 64-column block.
 __global__ __launch_bounds__(64) void v2v_seed_kernel(
     const float* __restrict__ prow, int V, int Vp, const uint64_t* __restrict__ bits,
     const TreeNode* __restrict__ nodes, const int32_t* __restrict__ rows, const float* __restrict__ bounds,
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(64) void v2v_seed_kernel(
             hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m));
         }
     const float* bb = bounds + (size_t)b * N * 8;
-    const int32_t* mk = masked + (size_t)(qb >> 1) * N;
+    const int32_t* mk = masked + (size_t)qb * N;
     auto gap2 = [&](int node) {                 // squared distance between the block's box and the node's box
         const float* box = bb + (size_t)node * 8;
         float g = 0.0f;
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(64) void v2v_tree_kernel(
     c.best = __uint_as_float((uint32_t)(init >> 32));
     c.arg = (int)(uint32_t)init;
     const float* bb = bounds + (size_t)b * N * 8;
-    const int32_t* mk = masked + (size_t)(qb >> 1) * N;
+    const int32_t* mk = masked + (size_t)qb * N;
     const uint64_t* m0 = bits + (size_t)qb * V;
     int node = __builtin_amdgcn_readfirstlane(frontier[sub]);
     const int end = __builtin_amdgcn_readfirstlane(nodes[node].skip);
