@@ -83,9 +83,10 @@ struct tuch_contact_model {
     int32_t* tree_ancestors;   // [frontier_total][8]
     int32_t* tree_rows;        // [tree_nodes][2]
     // geodesic mask in the tree's vertex order: tree_mask_bits[w][j'], bit k = geomask[qperm[j']][qperm[64 w + k]],
-    // w < 2 * tree_qblocks, j' < V; tree_masked[w][node] != 0: no allowed pair between the 64 columns of word w and the node
+    // w < 2 * tree_qblocks, j' < V; tree_masked[w][node] bit k: column 64 w + k has an allowed row below the node
+    // (0: the mask rules the whole node out for the wavefront that owns these columns)
     uint64_t* tree_mask_bits;
-    int32_t* tree_masked;
+    uint64_t* tree_masked;
     int tree_num_frontiers;
     int* tree_frontier_off_host;   // [tree_num_frontiers+1]
     int32_t* tree_face_leaf_host;  // [F] leaf (preorder sequence number) of every face, host copy (or nullptr)

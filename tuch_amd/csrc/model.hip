@@ -133,23 +133,24 @@ extern "C" int tuch_contact_model_create(
                     for (int ip = 0; ip < V; ++ip)
                         if (row[t.qperm[ip]]) bits[(size_t)(ip >> 6) * V + jp] |= (uint64_t)1 << (ip & 63);
                 }
-                std::vector<int32_t> masked((size_t)Wp * N, 0);          // per 64-column block (one wavefront's columns)
+                // per 64-column block (one wavefront's columns) and node: the columns with ANY allowed row below the node
+                std::vector<uint64_t> lanes((size_t)Wp * N, 0);
                 for (int qb = 0; qb < Wp; ++qb) {
                     const uint64_t* w0 = bits.data() + (size_t)qb * V;
                     for (int i = N - 1; i >= 0; --i) {
                         const int c0 = t.nodes[(size_t)i * 8 + 5], c1 = t.nodes[(size_t)i * 8 + 6];
-                        int32_t all = 1;
+                        uint64_t any = 0;
                         if (c0 >= 0) {
-                            all = masked[(size_t)qb * N + c0] && masked[(size_t)qb * N + c1];
+                            any = lanes[(size_t)qb * N + c0] | lanes[(size_t)qb * N + c1];
                         } else {
                             const int lo = t.rows[(size_t)i * 2], n = t.rows[(size_t)i * 2 + 1];
-                            for (int j = lo; j < lo + n && all; ++j) all = w0[j] == 0;
+                            for (int j = lo; j < lo + n; ++j) any |= w0[j];
                         }
-                        masked[(size_t)qb * N + i] = all;
+                        lanes[(size_t)qb * N + i] = any;
                     }
                 }
                 rc = upload(&m->tree_mask_bits, bits.data(), bits.size());
-                if (rc == TUCH_OK) rc = upload(&m->tree_masked, masked.data(), masked.size());
+                if (rc == TUCH_OK) rc = upload(&m->tree_masked, lanes.data(), lanes.size());
             }
         }
     }

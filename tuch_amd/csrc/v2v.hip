@@ -469,7 +469,7 @@ __device__ __forceinline__ float box_dist2(const Column& c, const float* __restr
 __global__ __launch_bounds__(64) void v2v_seed_kernel(
     const float* __restrict__ prow, int V, int Vp, const uint64_t* __restrict__ bits,
     const TreeNode* __restrict__ nodes, const int32_t* __restrict__ rows, const float* __restrict__ bounds,
-    const int32_t* __restrict__ masked, int N,
+    const uint64_t* __restrict__ masked, int N,
     const int32_t* __restrict__ hint,            // [B,Vp] a row per column (tree order) from an earlier call, or nullptr
     uint64_t* __restrict__ keys)                 // [B,Vp]
 {
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(64) void v2v_seed_kernel(
             hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m));
         }
     const float* bb = bounds + (size_t)b * N * 8;
-    const int32_t* mk = masked + (size_t)qb * N;
+    const uint64_t* mk = masked + (size_t)qb * N;     // per node: the lanes with an allowed row below it
     auto gap2 = [&](int node) {                 // squared distance between the block's box and the node's box
         const float* box = bb + (size_t)node * 8;
         float g = 0.0f;
@@ -501,11 +501,11 @@ __global__ __launch_bounds__(64) void v2v_seed_kernel(
         return g;
     };
     int node = 0;
-    bool ok = mk[0] == 0;
+    bool ok = mk[0] != 0;
     while (ok) {
         const TreeNode nd = nodes[node];
         if (nd.c0 < 0) break;
-        const bool a0 = mk[nd.c0] == 0, a1 = mk[nd.c1] == 0;
+        const bool a0 = mk[nd.c0] != 0, a1 = mk[nd.c1] != 0;
         if (a0 && a1) {
             const float g0 = gap2(nd.c0), g1 = gap2(nd.c1);
             node = __builtin_amdgcn_readfirstlane(g1 < g0 ? nd.c1 : nd.c0);
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(64) void v2v_seed_kernel(
 __global__ __launch_bounds__(64) void v2v_tree_kernel(
     const float* __restrict__ prow, int V, int Vp, const uint64_t* __restrict__ bits,
     const TreeNode* __restrict__ nodes, const int32_t* __restrict__ rows, const float* __restrict__ bounds,
-    const int32_t* __restrict__ masked, int N, const int32_t* __restrict__ frontier,
+    const uint64_t* __restrict__ masked, int N, const int32_t* __restrict__ frontier,
     const int32_t* __restrict__ order, uint64_t* __restrict__ keys)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
@@ -548,16 +548,18 @@ __global__ __launch_bounds__(64) void v2v_tree_kernel(
     c.best = __uint_as_float((uint32_t)(init >> 32));
     c.arg = (int)(uint32_t)init;
     const float* bb = bounds + (size_t)b * N * 8;
-    const int32_t* mk = masked + (size_t)qb * N;
+    const uint64_t* mk = masked + (size_t)qb * N;     // per node: the lanes with an allowed row below it
     const uint64_t* m0 = bits + (size_t)qb * V;
     int node = __builtin_amdgcn_readfirstlane(frontier[sub]);
     const int end = __builtin_amdgcn_readfirstlane(nodes[node].skip);
     while (node < end) {
         const TreeNode nd = nodes[node];
-        bool descend = mk[node] == 0;
+        // only a lane that has an allowed row below the node AND is within reach of its box can improve
+        const uint64_t lanes = mk[node];
+        bool descend = lanes != 0;
         if (descend) {
             const float g = box_dist2(c, bb + (size_t)node * 8) * kPruneSlack;
-            descend = __builtin_amdgcn_ballot_w64(g <= c.best) != 0;
+            descend = (__builtin_amdgcn_ballot_w64(g <= c.best) & lanes) != 0;
         }
         if (!descend) {
             node = nd.skip;
@@ -732,7 +734,7 @@ extern "C" int tuch_v2v_min_model_shared(const tuch_contact_model* m, const floa
                        (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, m->tree_heights, bounds);
     hipLaunchKernelGGL(v2v_seed_kernel, dim3(B, 2 * m->tree_qblocks), dim3(64), 0, s, (const float*)prow, V, Vp,
                        (const uint64_t*)m->tree_mask_bits, nodes, (const int32_t*)m->tree_rows, (const float*)bounds,
-                       (const int32_t*)m->tree_masked, N, (const int32_t*)hint_inout, keys);
+                       (const uint64_t*)m->tree_masked, N, (const int32_t*)hint_inout, keys);
     const int f = choose_v2v_frontier(m, B);
     const int f0 = m->tree_frontier_off_host[f], nsub = m->tree_frontier_off_host[f + 1] - f0;
     // leave_room: an unused LDS allocation caps the walk at 25 of a CU's 32 wave slots.  The walk is one grid of 220 k
@@ -744,7 +746,7 @@ extern "C" int tuch_v2v_min_model_shared(const tuch_contact_model* m, const floa
     const int lds_pad = leave_room ? lds_env : 0;
     hipLaunchKernelGGL(v2v_tree_kernel, dim3(B, 2 * nsub * m->tree_qblocks), dim3(64), (size_t)lds_pad, s, (const float*)prow, V, Vp,
                        (const uint64_t*)m->tree_mask_bits, nodes, (const int32_t*)m->tree_rows, (const float*)bounds,
-                       (const int32_t*)m->tree_masked, N, (const int32_t*)m->tree_frontier_nodes + f0,
+                       (const uint64_t*)m->tree_masked, N, (const int32_t*)m->tree_frontier_nodes + f0,
                        (const int32_t*)m->tree_launch_order + (size_t)f0 * m->tree_qblocks, keys);
     hipLaunchKernelGGL(v2v_tree_finalize_kernel, dim3(ceil_div(V, kBlock), B), dim3(kBlock), 0, s,
                        (const uint64_t*)keys, (const int32_t*)m->tree_qperm, V, Vp, min_d2, argmin, (int32_t*)hint_inout);
