@@ -417,8 +417,10 @@ struct Column {
 };
 
 // rows [j0, j0+n) against the wave's 64 columns; ties keep the smaller row
+// reach: the lanes that can still improve in this range (within reach of its box); a group of four rows none of
+// which is allowed for any of them is skipped on the scalar unit
 __device__ __forceinline__ void v2v_rows(Column& c, const float* __restrict__ pb, const uint64_t* __restrict__ m0,
-                                         int j0, int n)
+                                         int j0, int n, uint64_t reach = ~0ull)
 {
     const float inf = __builtin_inff();
     auto dist = [&](uint64_t k0, float vx, float vy, float vz) {
@@ -439,6 +441,7 @@ __device__ __forceinline__ void v2v_rows(Column& c, const float* __restrict__ pb
         float v[12];
 #pragma unroll
         for (int u = 0; u < 4; ++u) k0[u] = m0[j + u];
+        if (((k0[0] | k0[1] | k0[2] | k0[3]) & reach) == 0) continue;
 #pragma unroll
         for (int u = 0; u < 12; ++u) v[u] = pb[3 * j + u];
         float d[4];
@@ -557,14 +560,16 @@ __global__ __launch_bounds__(64) void v2v_tree_kernel(
         // only a lane that has an allowed row below the node AND is within reach of its box can improve
         const uint64_t lanes = mk[node];
         bool descend = lanes != 0;
+        uint64_t reach = 0;
         if (descend) {
             const float g = box_dist2(c, bb + (size_t)node * 8) * kPruneSlack;
-            descend = (__builtin_amdgcn_ballot_w64(g <= c.best) & lanes) != 0;
+            reach = __builtin_amdgcn_ballot_w64(g <= c.best) & lanes;
+            descend = reach != 0;
         }
         if (!descend) {
             node = nd.skip;
         } else if (nd.c0 < 0) {
-            v2v_rows(c, pb, m0, rows[2 * node], rows[2 * node + 1]);
+            v2v_rows(c, pb, m0, rows[2 * node], rows[2 * node + 1], reach);
             node = nd.skip;
         } else {
             node = node + 1;
