@@ -36,6 +36,15 @@ __device__ __forceinline__ float select_by_lane_mask(float if_clear, float if_se
     return r;
 }
 
+// minimum of four distances: the operands come out of select_by_lane_mask (opaque to the compiler, which would put a
+// canonicalising v_max in front of every fminf of them); none is a NaN
+__device__ __forceinline__ float min4_raw(float a, float b, float c, float d)
+{
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3\n\tv_min_f32_e32 %0, %0, %4" : "=&v"(r) : "v"(a), "v"(b), "v"(c), "v"(d));
+    return r;
+}
+
 __device__ __forceinline__ uint64_t uniform64(uint64_t x)
 {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x);
@@ -436,20 +445,27 @@ __device__ __forceinline__ void v2v_rows(Column& c, const float* __restrict__ pb
     };
     int j = j0;
     const int j_end = j0 + n;
-    for (; j + 4 <= j_end; j += 4) {
+    // running pointers: the scalar unit is this kernel's second bottleneck, and re-deriving two 64-bit addresses from
+    // the row index costs it eight instructions per trip
+    const uint64_t* mp = m0 + j0;
+    const float* cp = pb + 3 * (size_t)j0;
+    for (; j + 4 <= j_end; j += 4, mp += 4, cp += 12) {
         uint64_t k0[4];
         float v[12];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) k0[u] = m0[j + u];
-        if (((k0[0] | k0[1] | k0[2] | k0[3]) & reach) == 0) continue;
+        for (int u = 0; u < 4; ++u) k0[u] = mp[u];
 #pragma unroll
-        for (int u = 0; u < 12; ++u) v[u] = pb[3 * j + u];
+        for (int u = 0; u < 12; ++u) v[u] = cp[u];
+        // both loads are in flight before the test waits: one scalar-memory latency per trip, not two (the empty asm
+        // keeps the compiler from sinking the coordinate loads behind the branch)
+        asm volatile("" :: "s"(v[0]), "s"(v[4]), "s"(v[8]));
+        if (((k0[0] | k0[1] | k0[2] | k0[3]) & reach) == 0) continue;
         float d[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) d[u] = dist(k0[u], v[3 * u], v[3 * u + 1], v[3 * u + 2]);
         // ONE compare + ballot branch per four rows (a compare -> mask -> branch costs as much as four FP32 ops on
         // gfx950, tools/ubench/valu_rate2.hip); improvements are rare once the bounds have settled
-        const float m = __builtin_fminf(__builtin_fminf(__builtin_fminf(d[0], d[1]), d[2]), d[3]);
+        const float m = min4_raw(d[0], d[1], d[2], d[3]);
         if (__builtin_amdgcn_ballot_w64(m <= c.best)) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) take(j + u, d[u]);                     // in row order: ties go to the smaller row
