@@ -82,6 +82,7 @@ struct tuch_contact_model {
     int32_t* tree_launch_order;
     int32_t* tree_ancestors;   // [frontier_total][8]
     int32_t* tree_rows;        // [tree_nodes][2]
+    int32_t* tree_v2v_info;    // [tree_nodes][2]: skip pointer | leaf: first row + (rows << 20), inner node: -1; or nullptr
     // geodesic mask in the tree's vertex order: tree_mask_bits[w][j'], bit k = geomask[qperm[j']][qperm[64 w + k]],
     // w < 2 * tree_qblocks, j' < V; tree_masked[w][node] bit k: column 64 w + k has an allowed row below the node
     // (0: the mask rules the whole node out for the wavefront that owns these columns)

@@ -42,7 +42,7 @@ extern "C" void tuch_contact_model_destroy(tuch_contact_model* m)
 {
     if (!m) return;
     void* dev[] = {m->ring_off, m->ring_vidx, m->faces, m->mask_bits, m->strip_vidx, m->strip_sign, m->tree_node, m->tree_vidx, m->tree_sign, m->tree_qperm,
-                   m->tree_height_off, m->tree_height_nodes, m->tree_frontier_nodes, m->tree_launch_order, m->tree_ancestors, m->tree_rows, m->tree_mask_bits, m->tree_masked, m->seg_blocks, m->seg_of_q, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces, m->seg_link_off, m->seg_link, m->seg_ray_off, m->seg_ray_ent, m->seg_elem_mask, m->seg_vmask, m->seg_vpos, m->seg_cap_off, m->seg_cap_ent,
+                   m->tree_height_off, m->tree_height_nodes, m->tree_frontier_nodes, m->tree_launch_order, m->tree_ancestors, m->tree_rows, m->tree_v2v_info, m->tree_mask_bits, m->tree_masked, m->seg_blocks, m->seg_of_q, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces, m->seg_link_off, m->seg_link, m->seg_ray_off, m->seg_ray_ent, m->seg_elem_mask, m->seg_vmask, m->seg_vpos, m->seg_cap_off, m->seg_cap_ent,
                    m->cap_off, m->cap_vidx, m->region_off, m->region_vidx, m->pairs, m->pair_mask, m->pair_mask_off, m->tickets};
     for (void* p : dev)
         if (p) (void)hipFree(p);
@@ -124,6 +124,19 @@ extern "C" int tuch_contact_model_create(
             if (rc == TUCH_OK) rc = upload(&m->tree_launch_order, t.launch_order.data(), t.launch_order.size());
             if (rc == TUCH_OK) rc = upload(&m->tree_ancestors, t.ancestors.data(), t.ancestors.size());
             if (rc == TUCH_OK) rc = upload(&m->tree_rows, t.rows.data(), t.rows.size());
+            if (rc == TUCH_OK) {
+                // what the nearest-vertex walk needs of a node besides its box (rides in the box's padding, v2v.hip)
+                std::vector<int32_t> info((size_t)t.num_nodes * 2);
+                bool fits = V < (1 << 20);
+                for (int i = 0; i < t.num_nodes; ++i) {
+                    const bool leaf = t.nodes[(size_t)i * 8 + 5] < 0;
+                    const int off = t.rows[(size_t)i * 2], n = t.rows[(size_t)i * 2 + 1];
+                    fits = fits && (!leaf || n < (1 << 11));
+                    info[2 * i] = t.nodes[(size_t)i * 8 + 4];
+                    info[2 * i + 1] = leaf ? (off | (n << 20)) : -1;
+                }
+                if (fits) rc = upload(&m->tree_v2v_info, info.data(), info.size());
+            }
             if (rc == TUCH_OK && geomask) {
                 // the mask in the tree's vertex order, and which (query block, node) pairs it rules out entirely
                 const int Wp = 2 * t.num_qblocks, N = t.num_nodes;

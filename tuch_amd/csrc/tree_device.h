@@ -11,7 +11,8 @@ constexpr int kBoundsBlock = 256;
 template <int K>
 static __global__ __launch_bounds__(kBoundsBlock) void tree_inner_bounds_kernel(
     const TreeNode* __restrict__ nodes, int N, const int32_t* __restrict__ height_off,
-    const int32_t* __restrict__ height_nodes, int num_heights, float* __restrict__ bounds)
+    const int32_t* __restrict__ height_nodes, int num_heights, float* __restrict__ bounds,
+    const int32_t* __restrict__ info = nullptr)      // [N][2] or nullptr: see below
 {
     extern __shared__ float sb[];
     constexpr int S = 2 * K;
@@ -41,4 +42,11 @@ static __global__ __launch_bounds__(kBoundsBlock) void tree_inner_bounds_kernel(
         }
         __syncthreads();
     }
+    // K = 4 (boxes): the two padding floats of every node carry two words of the caller's static node table, so that a
+    // walk fetches a node's box and what it needs to know about the node in one load
+    if (K == 4 && info)
+        for (int node = threadIdx.x; node < N; node += kBoundsBlock) {
+            out[node * S + 3] = __int_as_float(info[2 * node]);
+            out[node * S + 7] = __int_as_float(info[2 * node + 1]);
+        }
 }

@@ -574,21 +574,24 @@ __global__ __launch_bounds__(64) void v2v_tree_kernel(
     int node = __builtin_amdgcn_readfirstlane(frontier[sub]);
     const int end = __builtin_amdgcn_readfirstlane(nodes[node].skip);
     while (node < end) {
-        const TreeNode nd = nodes[node];
-        // only a lane that has an allowed row below the node AND is within reach of its box can improve
+        // one round of scalar loads per node: its box, with the skip pointer and the leaf's row range in the two padding
+        // words (tree_inner_bounds_kernel), and the lanes that have an allowed row below it
+        const float* box = bb + (size_t)node * 8;
         const uint64_t lanes = mk[node];
-        bool descend = lanes != 0;
-        uint64_t reach = 0;
-        if (descend) {
-            const float g = box_dist2(c, bb + (size_t)node * 8) * kPruneSlack;
-            reach = __builtin_amdgcn_ballot_w64(g <= c.best) & lanes;
-            descend = reach != 0;
-        }
-        if (!descend) {
-            node = nd.skip;
-        } else if (nd.c0 < 0) {
-            v2v_rows(c, pb, m0, rows[2 * node], rows[2 * node + 1], reach);
-            node = nd.skip;
+        const float lx = box[0], ly = box[1], lz = box[2], hx = box[4], hy = box[5], hz = box[6];
+        const int skip = __float_as_int(box[3]), leaf = __float_as_int(box[7]);
+        // only a lane that has an allowed row below the node AND is within reach of its box can improve; the distance
+        // to the box through the nearest point of it (median of three), bit for bit box_dist2()
+        const float dx = c.px - __builtin_amdgcn_fmed3f(c.px, lx, hx);
+        const float dy = c.py - __builtin_amdgcn_fmed3f(c.py, ly, hy);
+        const float dz = c.pz - __builtin_amdgcn_fmed3f(c.pz, lz, hz);
+        const float g = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) * kPruneSlack;
+        const uint64_t reach = __builtin_amdgcn_ballot_w64(g <= c.best) & lanes;
+        if (reach == 0) {
+            node = skip;
+        } else if (leaf >= 0) {
+            v2v_rows(c, pb, m0, leaf & 0xfffff, leaf >> 20, reach);
+            node = skip;
         } else {
             node = node + 1;
         }
@@ -632,7 +635,7 @@ TreeV2VLayout tree_v2v_layout(const tuch_contact_model* m, int B)
 
 bool use_v2v_tree(const tuch_contact_model* m)
 {
-    if (m->tree_nodes <= 0 || !m->tree_mask_bits) return false;
+    if (m->tree_nodes <= 0 || !m->tree_mask_bits || !m->tree_v2v_info) return false;
     const char* e = getenv("TUCH_V2V_TREE");
     return !e || atoi(e) != 0;
 }
@@ -754,7 +757,8 @@ extern "C" int tuch_v2v_min_model_shared(const tuch_contact_model* m, const floa
                        verts, V, Vp, (const int32_t*)m->tree_qperm, (const int32_t*)m->tree_rows,
                        (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, N, prow, bounds);
     hipLaunchKernelGGL(tree_inner_bounds_kernel<4>, dim3(B), dim3(kBoundsBlock), (size_t)N * 8 * sizeof(float), s, nodes, N,
-                       (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, m->tree_heights, bounds);
+                       (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, m->tree_heights, bounds,
+                       (const int32_t*)m->tree_v2v_info);
     hipLaunchKernelGGL(v2v_seed_kernel, dim3(B, 2 * m->tree_qblocks), dim3(64), 0, s, (const float*)prow, V, Vp,
                        (const uint64_t*)m->tree_mask_bits, nodes, (const int32_t*)m->tree_rows, (const float*)bounds,
                        (const uint64_t*)m->tree_masked, N, (const int32_t*)hint_inout, keys);
