@@ -326,26 +326,30 @@ __global__ __launch_bounds__(64) void ray_near_kernel(
         const int node = leaf_nodes[leaf < num_leaves ? leaf : num_leaves - 1];
         const float* lo = bb + (size_t)node * (2 * kSlabStride);
         const float* hi = lo + kSlabStride;
+        // the 13 slab values the tests use, one leaf per lane; the per-ray test below takes a passing leaf's values from
+        // its lane (v_readlane) instead of fetching them again through the scalar cache: the loop over the passing
+        // leaves was a chain of scalar-memory latencies
+        const float lo0 = lo[0], lo1 = lo[1], lo3 = lo[3], lo4 = lo[4], lo6 = lo[6], lo8 = lo[8];
+        const float hi0 = hi[0], hi1 = hi[1], hi2 = hi[2], hi3 = hi[3], hi4 = hi[4], hi5 = hi[5], hi7 = hi[7];
         bool pass = leaf < num_leaves;
-        pass = pass && bx0 <= hi[0] && bx1 >= lo[0] && by0 <= hi[1] && by1 >= lo[1];
-        pass = pass && b40 <= hi[3] && b41 >= lo[3] && b50 <= hi[4] && b51 >= lo[4];
-        pass = pass && bz0 <= hi[2] && b60 <= hi[5] && b71 >= lo[6] && b80 <= hi[7] && b91 >= lo[8];
+        pass = pass && bx0 <= hi0 && bx1 >= lo0 && by0 <= hi1 && by1 >= lo1;
+        pass = pass && b40 <= hi3 && b41 >= lo3 && b50 <= hi4 && b51 >= lo4;
+        pass = pass && bz0 <= hi2 && b60 <= hi5 && b71 >= lo6 && b80 <= hi7 && b91 >= lo8;
         unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
+        auto from = [](float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
         while (mask) {
             const int j = __builtin_ctzll(mask);
             mask &= mask - 1;
             const int nd = __builtin_amdgcn_readlane(node, j);
-            const float* l2 = bb + (size_t)nd * (2 * kSlabStride);
-            const float* h2 = l2 + kSlabStride;
-            float out = __builtin_fmaxf(l2[0] - qx, qx - h2[0]);
-            out = __builtin_fmaxf(out, __builtin_fmaxf(l2[1] - qy, qy - h2[1]));
-            out = __builtin_fmaxf(out, __builtin_fmaxf(l2[3] - q4, q4 - h2[3]));
-            out = __builtin_fmaxf(out, __builtin_fmaxf(l2[4] - q5, q5 - h2[4]));
-            out = __builtin_fmaxf(out, qz - h2[2]);
-            out = __builtin_fmaxf(out, q6 - h2[5]);
-            out = __builtin_fmaxf(out, l2[6] - q7);
-            out = __builtin_fmaxf(out, q8 - h2[7]);
-            out = __builtin_fmaxf(out, l2[8] - q9);
+            float out = __builtin_fmaxf(from(lo0, j) - qx, qx - from(hi0, j));
+            out = __builtin_fmaxf(out, __builtin_fmaxf(from(lo1, j) - qy, qy - from(hi1, j)));
+            out = __builtin_fmaxf(out, __builtin_fmaxf(from(lo3, j) - q4, q4 - from(hi3, j)));
+            out = __builtin_fmaxf(out, __builtin_fmaxf(from(lo4, j) - q5, q5 - from(hi4, j)));
+            out = __builtin_fmaxf(out, qz - from(hi2, j));
+            out = __builtin_fmaxf(out, q6 - from(hi5, j));
+            out = __builtin_fmaxf(out, from(lo6, j) - q7);
+            out = __builtin_fmaxf(out, q8 - from(hi7, j));
+            out = __builtin_fmaxf(out, from(lo8, j) - q9);
             const unsigned long long hit = __builtin_amdgcn_ballot_w64(real && !(out > 0.0f));
             if (hit) {
                 if (lane == 0) {
