@@ -846,20 +846,22 @@ __global__ __launch_bounds__(kBlock) void segment_ray_finalize_kernel(
 {
     const int b = blockIdx.y;
     const int q = blockIdx.x * kBlock + threadIdx.x;       // a list position
-    if (q >= Qs_total) return;
-    const int s = seg_of_q[q];
+    // all lanes stay to the end: long link lists below are shared out over the wavefront
+    bool active = q < Qs_total;
+    const int s = active ? seg_of_q[q] : 0;
     const int k = q - seg_q_off[s];
-    if (k >= count[b * S + s]) return;
+    active = active && k < count[b * S + s];
     int n = 0;
     float half_sum = 0.0f;
-    for (int sp = 0; sp < nsplit; ++sp) {
-        n += partial[((size_t)b * nsplit + sp) * Qs_total + q];
-        half_sum += partial_half[((size_t)b * nsplit + sp) * Qs_total + q];
-    }
-    const int qq = seg_q_off[s] + list[(size_t)b * Qs_total + q];   // the vertex's slot in the segment tables
-    const int v = seg_q_vidx[qq];
-    if (leaf_counts) {
-        n += seg_leaf_count(leaf_counts + 2 * ((size_t)b * slots + vpos[v]), s);
+    int qq = 0, v = 0;
+    if (active) {
+        for (int sp = 0; sp < nsplit; ++sp) {
+            n += partial[((size_t)b * nsplit + sp) * Qs_total + q];
+            half_sum += partial_half[((size_t)b * nsplit + sp) * Qs_total + q];
+        }
+        qq = seg_q_off[s] + list[(size_t)b * Qs_total + q];   // the vertex's slot in the segment tables
+        v = seg_q_vidx[qq];
+        if (leaf_counts) n += seg_leaf_count(leaf_counts + 2 * ((size_t)b * slots + vpos[v]), s);
     }
     const float* vb = verts + (size_t)b * V * 3;
     const float* cb = caps + (size_t)b * K * 3;
@@ -867,32 +869,58 @@ __global__ __launch_bounds__(kBlock) void segment_ray_finalize_kernel(
     const float qx = shear_x(vx, vz), qy = shear_y(vy, vz);
     const P3 u_dir = {kFanX, kFanY, kFanZ};
     const P3 us = {shear_x(kFanX, kFanZ), shear_y(kFanY, kFanZ), kFanZ};
-    // cone triangles (apex direction u, x, y) of the links x -> y of the vertex's star, two at a time (their four
-    // corner positions are fetched together)
-    const int e0 = link_off[qq], e1 = link_off[qq + 1];
-    for (int e = e0; e < e1; e += 2) {
-        int id[4];
-        float pp[4][3];
+    // cone triangle (apex direction u, x, y) of one link x -> y of a vertex's star
+    auto cone = [&](const float* p0, const float* p1, float ax, float ay, float az, float sx, float sy, float& h, int& c) {
+        const P3 pb = {p0[0] - ax, p0[1] - ay, p0[2] - az}, pc = {p1[0] - ax, p1[1] - ay, p1[2] - az};
+        const P3 sb = {shear_x(p0[0], p0[2]) - sx, shear_y(p0[1], p0[2]) - sy, p0[2] - az};
+        const P3 sc = {shear_x(p1[0], p1[2]) - sx, shear_y(p1[1], p1[2]) - sy, p1[2] - az};
+        h += half_solid_angle(u_dir, pb, pc);
+        c += crossing_mostly_generic(us, sb, sc, edge_fn(sb, sc), edge_fn(sc, us), edge_fn(us, sb));
+    };
+    const int e0 = active ? link_off[qq] : 0, e1 = active ? link_off[qq + 1] : 0;
+    constexpr int kLongLinks = 16;
+    if (e1 - e0 <= kLongLinks) {
+        // two links at a time (their four corner positions are fetched together)
+        for (int e = e0; e < e1; e += 2) {
+            int id[4];
+            float pp[4][3];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) id[u] = link[2 * min(e + (u >> 1), e1 - 1) + (u & 1)];
+            for (int u = 0; u < 4; ++u) id[u] = link[2 * min(e + (u >> 1), e1 - 1) + (u & 1)];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float* p = id[u] < V ? vb + 3 * (size_t)id[u] : cb + 3 * (size_t)(id[u] - V);
-            pp[u][0] = p[0]; pp[u][1] = p[1]; pp[u][2] = p[2];
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (e + h < e1) {
-                const float* p0 = pp[2 * h];
-                const float* p1 = pp[2 * h + 1];
-                const P3 pb = {p0[0] - vx, p0[1] - vy, p0[2] - vz}, pc = {p1[0] - vx, p1[1] - vy, p1[2] - vz};
-                const P3 sb = {shear_x(p0[0], p0[2]) - qx, shear_y(p0[1], p0[2]) - qy, p0[2] - vz};
-                const P3 sc = {shear_x(p1[0], p1[2]) - qx, shear_y(p1[1], p1[2]) - qy, p1[2] - vz};
-                half_sum += half_solid_angle(u_dir, pb, pc);
-                n += crossing_mostly_generic(us, sb, sc, edge_fn(sb, sc), edge_fn(sc, us), edge_fn(us, sb));
+            for (int u = 0; u < 4; ++u) {
+                const float* p = id[u] < V ? vb + 3 * (size_t)id[u] : cb + 3 * (size_t)(id[u] - V);
+                pp[u][0] = p[0]; pp[u][1] = p[1]; pp[u][2] = p[2];
             }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                if (e + h < e1) cone(pp[2 * h], pp[2 * h + 1], vx, vy, vz, qx, qy, half_sum, n);
         }
     }
+    // long stars (the poles of a lat-long sphere have 80 links; SMPL has none above 16): one link per lane, sums by
+    // butterfly -- one lane walking 80 cones alone held the whole launch up (14 us or 50, depending on whether a pole
+    // was interior in that iteration)
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(e1 - e0 > kLongLinks);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int le0 = __builtin_amdgcn_readlane(e0, src), le1 = __builtin_amdgcn_readlane(e1, src);
+        const float lvx = __shfl(vx, src), lvy = __shfl(vy, src), lvz = __shfl(vz, src);
+        const float lqx = __shfl(qx, src), lqy = __shfl(qy, src);
+        float h = 0.0f;
+        int cr = 0;
+        for (int e = le0 + lane; e < le1; e += 64) {
+            const int i0 = link[2 * e], i1 = link[2 * e + 1];
+            const float* p0 = i0 < V ? vb + 3 * (size_t)i0 : cb + 3 * (size_t)(i0 - V);
+            const float* p1 = i1 < V ? vb + 3 * (size_t)i1 : cb + 3 * (size_t)(i1 - V);
+            const float a0[3] = {p0[0], p0[1], p0[2]}, a1[3] = {p1[0], p1[1], p1[2]};
+            cone(a0, a1, lvx, lvy, lvz, lqx, lqy, h, cr);
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { h += __shfl_xor(h, m); cr += __shfl_xor(cr, m); }
+        if (lane == src) { half_sum += h; n += cr; }
+    }
+    if (!active) return;
     const float w = (float)n - half_sum * (0.5f / kPi);
     const size_t o = (size_t)b * Qs_total + qq;
     if (seg_w) seg_w[o] = w;
