@@ -56,16 +56,16 @@ PEAK_HBM_GBS = 8000.0
 # profiles/README.md); constants from those files, NOT measured in this run.
 PROFILE = {
     'v2v_tree_kernel': {
-        'traffic_bytes': int((29913.2 + 3483.6) * 1024),
-        'valu_busy': 0.76,
-        'source': 'profiles/r02_m_pmc_fetch.txt + r02_m_pmc_write.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, '
-                  'KB x 1024) and r02_m_pmc_sq.txt (SQ_ACTIVE_INST_VALU x 4 / (1024 x GRBM_GUI_ACTIVE / 8) = 1.368e8 x 4 / '
-                  '(1024 x 5.636e6 / 8)), batch 64, inside the step, where the walk runs with its occupancy cap beside the '
-                  'inside test (0.86 without the cap); from profiles/, not measured in this run'},
+        'traffic_bytes': int((31188.8 + 3492.9) * 1024),
+        'valu_busy': 0.66,
+        'source': 'profiles/r02_n_pmc_fetch.txt + r02_n_pmc_write.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, '
+                  'KB x 1024) and r02_n_pmc_sq.txt (SQ_ACTIVE_INST_VALU x 4 / (1024 x GRBM_GUI_ACTIVE / 8) = 9.161e7 x 4 / '
+                  '(1024 x 4.334e6 / 8)), batch 64, inside the step, where the walk runs with its occupancy cap beside the '
+                  'inside test; from profiles/, not measured in this run'},
     'ray_leaf_kernel': {
-        'traffic_bytes': int((25341.5 + 14128.4) * 1024),
+        'traffic_bytes': int((25558.5 + 11717.1) * 1024),
         'valu_busy': 0.89,
-        'source': 'profiles/r02_m_pmc_fetch.txt + r02_m_pmc_write.txt and r02_m_pmc_sq.txt (9.331e7 x 4 / (1024 x 3.282e6 / 8)), '
+        'source': 'profiles/r02_n_pmc_fetch.txt + r02_n_pmc_write.txt and r02_n_pmc_sq.txt (9.322e7 x 4 / (1024 x 3.272e6 / 8)), '
                   'batch 64; from profiles/, not measured in this run'},
 }
 _BODY = {}
@@ -372,10 +372,11 @@ def rooflines(p, batch):
             'compact_layout_GBs': round(compact_bytes / t_v / 1e9, 1),
             'reference_layout_equivalent_GBs': round(ref_layout_bytes / t_v / 1e9, 1),
             'reference_layout_equivalent_frac_of_hbm': round(ref_layout_bytes / t_v / 1e9 / PEAK_HBM_GBS, 3),
-            'note': 'achieved = 8 FLOP x V^2 x B / launch time (SURVEY 8d); ~60 % of the rows are pruned by box distance and '
-                    'never evaluated, the mask is bit-packed and L2-resident: the equivalent-bandwidth figures are NOT '
-                    'physical bandwidth.  The vector units are ~0.86 busy (0.76 with the occupancy cap it runs under in the step); the CU scalar unit (1.15e8 scalar instructions '
-                    'per launch, one per cycle per CU = 0.19 ms) is the second limit'}
+            'note': 'achieved = 8 FLOP x V^2 x B / launch time (SURVEY 8d); most (column, row) pairs are never evaluated -- pruned '
+                    'by box distance, by the lanes the mask leaves a row for below a node, and in groups of four rows no '
+                    'reachable lane may use; the mask is bit-packed and L2-resident: the equivalent-bandwidth figures are NOT '
+                    'physical bandwidth.  Per launch 9.2e7 VALU and 9.0e7 scalar instructions (one scalar instruction per cycle '
+                    'per CU = 0.15 ms of the 0.23): vector units 0.66 busy under the occupancy cap it runs with in the step'}
     # ---- the inside test: sheared strips + leaf slabs + near-leaf lists + tiles + ray_leaf_kernel + fan finalize
     t_w = time_kernel(lambda: model.exterior_flags(verts, apply_segments=False), 10)
     work = model.ray_work(verts)
