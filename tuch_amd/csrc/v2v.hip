@@ -501,51 +501,57 @@ __global__ __launch_bounds__(64) void v2v_seed_kernel(
     c.px = pb[3 * i0]; c.py = pb[3 * i0 + 1]; c.pz = pb[3 * i0 + 2];
     c.best = __builtin_inff();
     c.arg = 0;
-    float lo[3] = {c.px, c.py, c.pz}, hi[3] = {c.px, c.py, c.pz};
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            lo[k] = fminf(lo[k], __shfl_xor(lo[k], m));
-            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m));
-        }
-    const float* bb = bounds + (size_t)b * N * 8;
     const uint64_t* mk = masked + (size_t)qb * N;     // per node: the lanes with an allowed row below it
-    auto gap2 = [&](int node) {                 // squared distance between the block's box and the node's box
-        const float* box = bb + (size_t)node * 8;
-        float g = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float e = fmaxf(fmaxf(box[k] - hi[k], lo[k] - box[4 + k]), 0.0f);
-            g = fmaf(e, e, g);
-        }
-        return g;
-    };
-    int node = 0;
-    bool ok = mk[0] != 0;
-    while (ok) {
-        const TreeNode nd = nodes[node];
-        if (nd.c0 < 0) break;
-        const bool a0 = mk[nd.c0] != 0, a1 = mk[nd.c1] != 0;
-        if (a0 && a1) {
-            const float g0 = gap2(nd.c0), g1 = gap2(nd.c1);
-            node = __builtin_amdgcn_readfirstlane(g1 < g0 ? nd.c1 : nd.c0);
-        } else if (a0 || a1) {
-            node = a0 ? nd.c0 : nd.c1;
-        } else {
-            ok = false;
-        }
-    }
-    if (ok) v2v_rows(c, pb, bits + (size_t)qb * V, rows[2 * node], rows[2 * node + 1]);
+    bool have = false;
     if (hint) {
         // the partner found for this column by an earlier call (e.g. the previous iteration of a fit): still an
         // admissible row, so its current distance is a valid -- and usually almost final -- upper bound
         const int j = hint[(size_t)b * Vp + i0];
         if (j >= 0 && j < V && ((bits[(size_t)qb * V + j] >> lane) & 1)) {
             const float dx = c.px - pb[3 * j], dy = c.py - pb[3 * j + 1], dz = c.pz - pb[3 * j + 2];
-            const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-            if (d < c.best || (d == c.best && j < c.arg)) { c.best = d; c.arg = j; }
+            c.best = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            c.arg = j;
+            have = true;
         }
+    }
+    // Every column that has an allowed row at all already holds a bound: the descent to the nearest admissible leaf and
+    // its rows would add nothing the walk does not find (22 -> 8 us at the head of the search's chain in an iterative fit).
+    if ((mk[0] & ~__builtin_amdgcn_ballot_w64(have)) != 0) {
+        float lo[3] = {c.px, c.py, c.pz}, hi[3] = {c.px, c.py, c.pz};
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = fminf(lo[k], __shfl_xor(lo[k], m));
+                hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m));
+            }
+        const float* bb = bounds + (size_t)b * N * 8;
+        auto gap2 = [&](int node) {                 // squared distance between the block's box and the node's box
+            const float* box = bb + (size_t)node * 8;
+            float g = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float e = fmaxf(fmaxf(box[k] - hi[k], lo[k] - box[4 + k]), 0.0f);
+                g = fmaf(e, e, g);
+            }
+            return g;
+        };
+        int node = 0;
+        bool ok = mk[0] != 0;
+        while (ok) {
+            const TreeNode nd = nodes[node];
+            if (nd.c0 < 0) break;
+            const bool a0 = mk[nd.c0] != 0, a1 = mk[nd.c1] != 0;
+            if (a0 && a1) {
+                const float g0 = gap2(nd.c0), g1 = gap2(nd.c1);
+                node = __builtin_amdgcn_readfirstlane(g1 < g0 ? nd.c1 : nd.c0);
+            } else if (a0 || a1) {
+                node = a0 ? nd.c0 : nd.c1;
+            } else {
+                ok = false;
+            }
+        }
+        if (ok) v2v_rows(c, pb, bits + (size_t)qb * V, rows[2 * node], rows[2 * node + 1]);
     }
     keys[(size_t)b * Vp + i0] = v2v_key(c.best, c.arg);
 }
