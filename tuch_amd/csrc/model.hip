@@ -100,9 +100,9 @@ extern "C" int tuch_contact_model_create(
         // has too many clusters for the LDS-resident boxes) simply keeps the flat strip path
         tuch_cluster_tree t;
         const char* e = getenv("TUCH_TREE_LEAF_FACES");
-        // at most ~800 nodes: their slabs are staged in 64 KB of LDS by tree_inner_bounds_kernel
+        // at most ~740 nodes: their slabs (80 B) and child indices (8 B) are staged in 64 KB of LDS by tree_inner_bounds_kernel
         const int leaf_faces = e ? atoi(e) : (F / 400 > 64 ? F / 400 : 64);
-        if (tuch_cluster_tree_build_impl(V, F, faces, leaf_faces, t) && t.num_nodes <= 800) {
+        if (tuch_cluster_tree_build_impl(V, F, faces, leaf_faces, t) && t.num_nodes <= 740) {
             m->tree_nodes = t.num_nodes;
             m->tree_stream_len = t.stream_len;
             m->tree_exact_len = t.exact_len;

@@ -14,20 +14,27 @@ static __global__ __launch_bounds__(kBoundsBlock) void tree_inner_bounds_kernel(
     const int32_t* __restrict__ height_nodes, int num_heights, float* __restrict__ bounds,
     const int32_t* __restrict__ info = nullptr)      // [N][2] or nullptr: see below
 {
-    extern __shared__ float sb[];
+    extern __shared__ float sb[];                       // N * 2K floats of slabs, then N * 2 ints of child indices
     constexpr int S = 2 * K;
+    int* child = reinterpret_cast<int*>(sb + (size_t)N * S);
     float* out = bounds + (size_t)blockIdx.x * N * S;
+    // one round of loads: the leaf slabs and every node's children (the per-level loop below then runs out of LDS; with
+    // the child indices fetched from global memory inside it, every level was a dependent load latency)
     for (int i = height_off[0] + threadIdx.x; i < height_off[1]; i += kBoundsBlock) {
         const int node = height_nodes[i];
 #pragma unroll
         for (int k = 0; k < S; ++k) sb[node * S + k] = out[node * S + k];
     }
+    for (int node = threadIdx.x; node < N; node += kBoundsBlock) {
+        child[2 * node] = nodes[node].c0;
+        child[2 * node + 1] = nodes[node].c1;
+    }
     __syncthreads();
     for (int h = 1; h < num_heights; ++h) {
         for (int i = height_off[h] + threadIdx.x; i < height_off[h + 1]; i += kBoundsBlock) {
             const int node = height_nodes[i];
-            const float* a = sb + nodes[node].c0 * S;
-            const float* c = sb + nodes[node].c1 * S;
+            const float* a = sb + child[2 * node] * S;
+            const float* c = sb + child[2 * node + 1] * S;
             float o[S];
 #pragma unroll
             for (int k = 0; k < K; ++k) {

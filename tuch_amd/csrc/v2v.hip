@@ -372,7 +372,24 @@ __device__ __forceinline__ uint64_t v2v_key(float d, int j)
     return ((uint64_t)__float_as_uint(d) << 32) | (uint32_t)j;
 }
 
-// rows in tree order + box of every leaf's rows; one wave per (leaf, body)
+// minimum over the 16 lanes of a DPP row, left in every lane (quad swaps, then the two mirror controls: single VALU
+// instructions, no LDS crossbar)
+template <int kCtrl>
+__device__ __forceinline__ float dpp_move(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), kCtrl, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row_min(float v)
+{
+    v = fminf(v, dpp_move<0xB1>(v));        // quad_perm [1,0,3,2]
+    v = fminf(v, dpp_move<0x4E>(v));        // quad_perm [2,3,0,1]
+    v = fminf(v, dpp_move<0x141>(v));       // row_half_mirror
+    v = fminf(v, dpp_move<0x140>(v));       // row_mirror
+    return v;
+}
+
+// rows in tree order + box of every leaf's rows; 16 lanes per (leaf, body): a leaf is a few dozen rows, a whole wavefront
+// per leaf was mostly idle lanes behind its chain of dependent loads
 __global__ __launch_bounds__(kBoundsBlock) void v2v_rows_kernel(
     const float* __restrict__ verts, int V, int Vp, const int32_t* __restrict__ qperm,
     const int32_t* __restrict__ rows, const int32_t* __restrict__ height_off,
@@ -381,37 +398,32 @@ __global__ __launch_bounds__(kBoundsBlock) void v2v_rows_kernel(
     float* __restrict__ bounds)                  // [B,N,8]
 {
     const int b = blockIdx.y;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int i = height_off[0] + blockIdx.x * (kBoundsBlock / 64) + wave;
+    const int group = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    const int i = height_off[0] + blockIdx.x * (kBoundsBlock / 16) + group;
     const float* vb = verts + (size_t)b * V * 3;
     float* pb = prow + (size_t)b * Vp * 3;
-    if (blockIdx.x == 0 && wave == 0)            // padding columns repeat the last vertex
-        for (int j = V + lane; j < Vp; j += 64) {
+    if (blockIdx.x == 0 && threadIdx.x < 64)     // padding columns repeat the last vertex
+        for (int j = V + (int)threadIdx.x; j < Vp; j += 64) {
             const int v = qperm[j];
             pb[3 * j] = vb[3 * v]; pb[3 * j + 1] = vb[3 * v + 1]; pb[3 * j + 2] = vb[3 * v + 2];
         }
-    if (i >= height_off[1]) return;
-    const int node = height_nodes[i];
-    const int off = rows[2 * node], len = rows[2 * node + 1];
-    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-    for (int j = off + lane; j < off + len; j += 64) {
+    const bool real = i < height_off[1];         // all lanes stay: the DPP rows need them
+    const int node = height_nodes[real ? i : height_off[0]];
+    const int off = rows[2 * node], len = real ? rows[2 * node + 1] : 0;
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, nhi[3] = {3.0e38f, 3.0e38f, 3.0e38f};
+    for (int j = off + sub; j < off + len; j += 16) {
         const int v = qperm[j];
         const float x = vb[3 * v], y = vb[3 * v + 1], z = vb[3 * v + 2];
         pb[3 * j] = x; pb[3 * j + 1] = y; pb[3 * j + 2] = z;
         lo[0] = fminf(lo[0], x); lo[1] = fminf(lo[1], y); lo[2] = fminf(lo[2], z);
-        hi[0] = fmaxf(hi[0], x); hi[1] = fmaxf(hi[1], y); hi[2] = fmaxf(hi[2], z);
+        nhi[0] = fminf(nhi[0], -x); nhi[1] = fminf(nhi[1], -y); nhi[2] = fminf(nhi[2], -z);
     }
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            lo[k] = fminf(lo[k], __shfl_xor(lo[k], m));
-            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m));
-        }
-    if (lane == 0) {
+    for (int k = 0; k < 3; ++k) { lo[k] = row_min(lo[k]); nhi[k] = row_min(nhi[k]); }
+    if (real && sub == 0) {
         float* o = bounds + ((size_t)b * N + node) * 8;
         o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = 0.0f;
-        o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = 0.0f;
+        o[4] = -nhi[0]; o[5] = -nhi[1]; o[6] = -nhi[2]; o[7] = 0.0f;
     }
 }
 
@@ -759,10 +771,10 @@ extern "C" int tuch_v2v_min_model_shared(const tuch_contact_model* m, const floa
     hipStream_t s = (hipStream_t)stream;
     const int V = m->V, Vp = m->tree_qblocks * 2 * kTreeCols, N = m->tree_nodes;
     const TreeNode* nodes = (const TreeNode*)m->tree_node;
-    hipLaunchKernelGGL(v2v_rows_kernel, dim3(ceil_div(m->tree_leaves, kBoundsBlock / 64), B), dim3(kBoundsBlock), 0, s,
+    hipLaunchKernelGGL(v2v_rows_kernel, dim3(ceil_div(m->tree_leaves, kBoundsBlock / 16), B), dim3(kBoundsBlock), 0, s,
                        verts, V, Vp, (const int32_t*)m->tree_qperm, (const int32_t*)m->tree_rows,
                        (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, N, prow, bounds);
-    hipLaunchKernelGGL(tree_inner_bounds_kernel<4>, dim3(B), dim3(kBoundsBlock), (size_t)N * 8 * sizeof(float), s, nodes, N,
+    hipLaunchKernelGGL(tree_inner_bounds_kernel<4>, dim3(B), dim3(kBoundsBlock), (size_t)N * (8 * sizeof(float) + 2 * sizeof(int)), s, nodes, N,
                        (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, m->tree_heights, bounds,
                        (const int32_t*)m->tree_v2v_info);
     hipLaunchKernelGGL(v2v_seed_kernel, dim3(B, 2 * m->tree_qblocks), dim3(64), 0, s, (const float*)prow, V, Vp,
