@@ -56,16 +56,16 @@ PEAK_HBM_GBS = 8000.0
 # profiles/README.md); constants from those files, NOT measured in this run.
 PROFILE = {
     'v2v_tree_kernel': {
-        'traffic_bytes': int((31188.8 + 3492.9) * 1024),
+        'traffic_bytes': int((31371.8 + 3933.6) * 1024),
         'valu_busy': 0.66,
         'source': 'profiles/r02_n_pmc_fetch.txt + r02_n_pmc_write.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, '
-                  'KB x 1024) and r02_n_pmc_sq.txt (SQ_ACTIVE_INST_VALU x 4 / (1024 x GRBM_GUI_ACTIVE / 8) = 9.161e7 x 4 / '
-                  '(1024 x 4.334e6 / 8)), batch 64, inside the step, where the walk runs with its occupancy cap beside the '
+                  'KB x 1024) and r02_n_pmc_sq.txt (SQ_ACTIVE_INST_VALU x 4 / (1024 x GRBM_GUI_ACTIVE / 8) = 9.307e7 x 4 / '
+                  '(1024 x 4.407e6 / 8)), batch 64, inside the step, where the walk runs with its occupancy cap beside the '
                   'inside test; from profiles/, not measured in this run'},
     'ray_leaf_kernel': {
-        'traffic_bytes': int((25558.5 + 11717.1) * 1024),
+        'traffic_bytes': int((25568.8 + 11744.0) * 1024),
         'valu_busy': 0.89,
-        'source': 'profiles/r02_n_pmc_fetch.txt + r02_n_pmc_write.txt and r02_n_pmc_sq.txt (9.322e7 x 4 / (1024 x 3.272e6 / 8)), '
+        'source': 'profiles/r02_n_pmc_fetch.txt + r02_n_pmc_write.txt and r02_n_pmc_sq.txt (9.293e7 x 4 / (1024 x 3.286e6 / 8)), '
                   'batch 64; from profiles/, not measured in this run'},
 }
 _BODY = {}
