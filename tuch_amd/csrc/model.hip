@@ -100,9 +100,13 @@ extern "C" int tuch_contact_model_create(
         // has too many clusters for the LDS-resident boxes) simply keeps the flat strip path
         tuch_cluster_tree t;
         const char* e = getenv("TUCH_TREE_LEAF_FACES");
-        // at most ~740 nodes: their slabs (80 B) and child indices (8 B) are staged in 64 KB of LDS by tree_inner_bounds_kernel
-        const int leaf_faces = e ? atoi(e) : (F / 400 > 64 ? F / 400 : 64);
-        if (tuch_cluster_tree_build_impl(V, F, faces, leaf_faces, t) && t.num_nodes <= 740) {
+        // at most 1800 nodes: their slabs (80 B) and child indices (8 B) are staged in the CU's 160 KB of LDS by
+        // tree_inner_bounds_kernel
+        // 32 faces per leaf (SMPL: 430 leaves): measured best for the step at batch 64 -- 16: 104.5, 24: 109.2, 32: 110.3,
+        // 40: 109.4, 48: 108.4, 64: 104.7, 96: 98.6 k body iterations/s (tighter slabs and boxes against more leaves to
+        // test and emptier tiles); larger meshes get larger leaves so that the tree stays under the node limit below
+        const int leaf_faces = e ? atoi(e) : (F / 850 > 32 ? F / 850 : 32);
+        if (tuch_cluster_tree_build_impl(V, F, faces, leaf_faces, t) && t.num_nodes <= 1800) {
             m->tree_nodes = t.num_nodes;
             m->tree_stream_len = t.stream_len;
             m->tree_exact_len = t.exact_len;

@@ -57,3 +57,18 @@ static __global__ __launch_bounds__(kBoundsBlock) void tree_inner_bounds_kernel(
             out[node * S + 7] = __int_as_float(info[2 * node + 1]);
         }
 }
+
+// LDS the kernel above stages for N nodes; above the default 64 KB per-launch limit the attribute has to be raised first
+template <int K>
+static inline size_t tree_inner_bounds_lds(int N)
+{
+    const size_t bytes = (size_t)N * (2 * K * sizeof(float) + 2 * sizeof(int));
+    if (bytes > 64 * 1024) {
+        static size_t raised = 0;                       // per instantiation
+        if (bytes > raised &&
+            hipFuncSetAttribute((const void*)tree_inner_bounds_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)bytes) == hipSuccess)
+            raised = bytes;
+    }
+    return bytes;
+}

@@ -889,7 +889,7 @@ void launch_tree_boxes(const tuch_contact_model* m, const float* verts, int B, S
                        dim3(kBoundsBlock), 0, s, (const StreamElem*)st, T, (const TreeNode*)m->tree_node,
                        m->tree_nodes, (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, bounds);
     hipLaunchKernelGGL(tree_inner_bounds_kernel<kSlabStride>, dim3(B), dim3(kBoundsBlock),
-                       (size_t)m->tree_nodes * (2 * kSlabStride * sizeof(float) + 2 * sizeof(int)), s, (const TreeNode*)m->tree_node, m->tree_nodes,
+                       tree_inner_bounds_lds<kSlabStride>(m->tree_nodes), s, (const TreeNode*)m->tree_node, m->tree_nodes,
                        (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, m->tree_heights,
                        bounds);
 }
