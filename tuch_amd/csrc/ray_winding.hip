@@ -715,10 +715,11 @@ __global__ __launch_bounds__(kBlock) void segment_shear_entries_kernel(
 
 // Work items of the crossing kernel: (body, segment, block of 64 compacted queries), only those that exist -- a grid
 // over the worst case (every segment vertex interior) is ten times larger and costs more in dispatch than in work.
-// One workgroup; items[i] = (body * S + segment, first query), items_total[0] = how many.
+// One workgroup; items[i] = (body * S + segment, first query), items_total[0] = how many, items_total[1] = face splits.
 constexpr int kItemsBlock = 256;
 __global__ __launch_bounds__(kItemsBlock) void segment_items_kernel(
-    const int32_t* __restrict__ count, int BS, int2* __restrict__ items, int32_t* __restrict__ items_total)
+    const int32_t* __restrict__ count, int BS, int2* __restrict__ items, int32_t* __restrict__ items_total,
+    int max_split, int grid)
 {
     __shared__ int sc[kItemsBlock];
     __shared__ int base;
@@ -742,7 +743,13 @@ __global__ __launch_bounds__(kItemsBlock) void segment_items_kernel(
         if (t == kItemsBlock - 1) base += sc[t];
         __syncthreads();
     }
-    if (t == 0) items_total[0] = base;
+    if (t == 0) {
+        items_total[0] = base;
+        // as many face splits as keep (items x splits) within 7/8 of one round of the crossing kernel's grid: a second,
+        // mostly empty round cost more than the longer loops of fewer splits (16 splits: 110.3, 12: 112.1 k it/s at batch 64)
+        const int fit = base > 0 ? (grid - grid / 8) / base : max_split;
+        items_total[1] = fit < 1 ? 1 : (fit > max_split ? max_split : fit);
+    }
 }
 
 __global__ __launch_bounds__(64) void segment_ray_kernel(
@@ -756,10 +763,11 @@ __global__ __launch_bounds__(64) void segment_ray_kernel(
     const P3 u_dir = {kFanX, kFanY, kFanZ};
     const P3 us = {shear_x(kFanX, kFanZ), shear_y(kFanY, kFanZ), kFanZ};
     __shared__ float sT[kSegRayChunk * 9];
-    const int units = items_total[0] * nsplit;                          // (item, face split)
+    const int ns = items_total[1];                                      // face splits in use (<= nsplit, the array stride)
+    const int units = items_total[0] * ns;                              // (item, face split)
     for (int unit = blockIdx.x; unit < units; unit += gridDim.x) {
-        const int2 item = items[unit / nsplit];
-        const int split = unit % nsplit;
+        const int2 item = items[unit / ns];
+        const int split = unit % ns;
         const int b = item.x / S, s = item.x % S, k_start = item.y;
         const int n = count[item.x];
         const int q_beg = seg_q_off[s];
@@ -770,7 +778,7 @@ __global__ __launch_bounds__(64) void segment_ray_kernel(
         const float qz = vb[3 * v0 + 2];
         const float qx = shear_x(vb[3 * v0], qz), qy = shear_y(vb[3 * v0 + 1], qz);
         const int f_seg = ent_off[s], f_cnt = ent_off[s + 1] - f_seg;
-        const int per = (f_cnt + nsplit - 1) / nsplit;
+        const int per = (f_cnt + ns - 1) / ns;
         const int f_beg = f_seg + split * per, f_end = min(f_seg + f_cnt, f_beg + per);
         int crossings = 0;
         float half_sum = 0.0f;
@@ -841,11 +849,12 @@ __global__ __launch_bounds__(kBlock) void segment_ray_finalize_kernel(
     const int32_t* __restrict__ count, const int32_t* __restrict__ list,
     const int32_t* __restrict__ leaf_counts,      // [B][slots][2] crossings with the segments' body faces, or nullptr
     const int32_t* __restrict__ vpos, int slots, int V, int K,
-    int Qs_total, int S, int nsplit, float thresh, float* __restrict__ seg_w, uint8_t* __restrict__ seg_ext,
-    uint8_t* __restrict__ exterior)
+    int Qs_total, int S, int nsplit, const int32_t* __restrict__ items_total, float thresh, float* __restrict__ seg_w,
+    uint8_t* __restrict__ seg_ext, uint8_t* __restrict__ exterior)
 {
     const int b = blockIdx.y;
     const int q = blockIdx.x * kBlock + threadIdx.x;       // a list position
+    const int ns = items_total[1];                         // face splits the crossing kernel used (<= nsplit, the stride)
     // all lanes stay to the end: long link lists below are shared out over the wavefront
     bool active = q < Qs_total;
     const int s = active ? seg_of_q[q] : 0;
@@ -855,7 +864,7 @@ __global__ __launch_bounds__(kBlock) void segment_ray_finalize_kernel(
     float half_sum = 0.0f;
     int qq = 0, v = 0;
     if (active) {
-        for (int sp = 0; sp < nsplit; ++sp) {
+        for (int sp = 0; sp < ns; ++sp) {
             n += partial[((size_t)b * nsplit + sp) * Qs_total + q];
             half_sum += partial_half[((size_t)b * nsplit + sp) * Qs_total + q];
         }
@@ -1131,9 +1140,11 @@ int tuch_ray_segment_flags(const tuch_contact_model* m, const float* verts, cons
     // work items behind the two partial arrays (B * num_seg_blocks int2 + 1 counter; the caller sizes seg_partial for it)
     int2* items = (int2*)(partial_half + (size_t)B * nsplit * m->seg_q_total);
     int32_t* items_total = (int32_t*)(items + (size_t)B * m->num_seg_blocks);
-    hipLaunchKernelGGL(segment_items_kernel, dim3(1), dim3(kItemsBlock), 0, s, seg_count, B * m->num_segments, items, items_total);
     const long worst = (long)B * m->num_seg_blocks * nsplit;
-    hipLaunchKernelGGL(segment_ray_kernel, dim3((unsigned)(worst < 8192 ? worst : 8192)), dim3(64), 0, s, verts,
+    const int grid = (int)(worst < 8192 ? worst : 8192);
+    hipLaunchKernelGGL(segment_items_kernel, dim3(1), dim3(kItemsBlock), 0, s, seg_count, B * m->num_segments, items, items_total,
+                       nsplit, grid);
+    hipLaunchKernelGGL(segment_ray_kernel, dim3((unsigned)grid), dim3(64), 0, s, verts,
                        (const float*)seg_entries, (const int2*)items, (const int32_t*)items_total, (const int32_t*)m->seg_q_off,
                        (const int32_t*)m->seg_q_vidx, ent_off, seg_count, seg_list, m->V, E,
                        m->seg_q_total, m->num_segments, nsplit, seg_partial, partial_half);
@@ -1142,6 +1153,7 @@ int tuch_ray_segment_flags(const tuch_contact_model* m, const float* verts, cons
                        (const int32_t*)m->seg_q_off, (const int32_t*)m->seg_q_vidx, (const int32_t*)m->seg_link_off,
                        (const int32_t*)m->seg_link, seg_count, seg_list, assisted ? leaf_counts : nullptr,
                        (const int32_t*)m->seg_vpos, 2 * m->tree_qblocks * kRayQueries, m->V,
-                       m->num_caps, m->seg_q_total, m->num_segments, nsplit, thresh, seg_w, seg_ext, exterior);
+                       m->num_caps, m->seg_q_total, m->num_segments, nsplit, (const int32_t*)items_total, thresh, seg_w, seg_ext,
+                       exterior);
     return tuch_check_launch("tuch_ray_segment_flags");
 }
