@@ -56,16 +56,16 @@ PEAK_HBM_GBS = 8000.0
 # profiles/README.md); constants from those files, NOT measured in this run.
 PROFILE = {
     'v2v_tree_kernel': {
-        'traffic_bytes': int((31371.8 + 3933.6) * 1024),
-        'valu_busy': 0.66,
+        'traffic_bytes': int((30682.7 + 3745.0) * 1024),
+        'valu_busy': 0.59,
         'source': 'profiles/r02_n_pmc_fetch.txt + r02_n_pmc_write.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, '
-                  'KB x 1024) and r02_n_pmc_sq.txt (SQ_ACTIVE_INST_VALU x 4 / (1024 x GRBM_GUI_ACTIVE / 8) = 9.307e7 x 4 / '
-                  '(1024 x 4.407e6 / 8)), batch 64, inside the step, where the walk runs with its occupancy cap beside the '
+                  'KB x 1024) and r02_n_pmc_sq.txt (SQ_ACTIVE_INST_VALU x 4 / (1024 x GRBM_GUI_ACTIVE / 8) = 7.880e7 x 4 / '
+                  '(1024 x 4.195e6 / 8)), batch 64, inside the step, where the walk runs with its occupancy cap beside the '
                   'inside test; from profiles/, not measured in this run'},
     'ray_leaf_kernel': {
-        'traffic_bytes': int((25568.8 + 11744.0) * 1024),
-        'valu_busy': 0.89,
-        'source': 'profiles/r02_n_pmc_fetch.txt + r02_n_pmc_write.txt and r02_n_pmc_sq.txt (9.293e7 x 4 / (1024 x 3.286e6 / 8)), '
+        'traffic_bytes': int((27294.7 + 14110.7) * 1024),
+        'valu_busy': 0.80,
+        'source': 'profiles/r02_n_pmc_fetch.txt + r02_n_pmc_write.txt and r02_n_pmc_sq.txt (6.132e7 x 4 / (1024 x 2.386e6 / 8)), '
                   'batch 64; from profiles/, not measured in this run'},
 }
 _BODY = {}
@@ -375,8 +375,8 @@ def rooflines(p, batch):
             'note': 'achieved = 8 FLOP x V^2 x B / launch time (SURVEY 8d); most (column, row) pairs are never evaluated -- pruned '
                     'by box distance, by the lanes the mask leaves a row for below a node, and in groups of four rows no '
                     'reachable lane may use; the mask is bit-packed and L2-resident: the equivalent-bandwidth figures are NOT '
-                    'physical bandwidth.  Per launch 9.2e7 VALU and 9.0e7 scalar instructions (one scalar instruction per cycle '
-                    'per CU = 0.15 ms of the 0.23): vector units 0.66 busy under the occupancy cap it runs with in the step'}
+                    'physical bandwidth.  Per launch 7.9e7 VALU and 8.9e7 scalar instructions (one scalar instruction per cycle '
+                    'per CU = 0.15 ms of the 0.20): vector units 0.59 busy under the occupancy cap it runs with in the step'}
     # ---- the inside test: sheared strips + leaf slabs + near-leaf lists + tiles + ray_leaf_kernel + fan finalize
     t_w = time_kernel(lambda: model.exterior_flags(verts, apply_segments=False), 10)
     work = model.ray_work(verts)
