@@ -321,14 +321,14 @@ __global__ __launch_bounds__(64) void ray_near_kernel(
     const float* bb = bounds + (size_t)b * N * (2 * kSlabStride);
     RayEntry* list = lists + ((size_t)b * qblocks + qb) * num_leaves;
     int cnt = 0;
+    __shared__ float slab[64][16];              // the 13 slab values of the chunk's leaves, one row per lane
     for (int base = 0; base < num_leaves; base += 64) {
         const int leaf = base + lane;
         const int node = leaf_nodes[leaf < num_leaves ? leaf : num_leaves - 1];
         const float* lo = bb + (size_t)node * (2 * kSlabStride);
         const float* hi = lo + kSlabStride;
-        // the 13 slab values the tests use, one leaf per lane; the per-ray test below takes a passing leaf's values from
-        // its lane (v_readlane) instead of fetching them again through the scalar cache: the loop over the passing
-        // leaves was a chain of scalar-memory latencies
+        // the 13 slab values the tests use, one leaf per lane (fetching a passing leaf's values again through the scalar
+        // cache made the loop over the passing leaves a chain of scalar-memory latencies)
         const float lo0 = lo[0], lo1 = lo[1], lo3 = lo[3], lo4 = lo[4], lo6 = lo[6], lo8 = lo[8];
         const float hi0 = hi[0], hi1 = hi[1], hi2 = hi[2], hi3 = hi[3], hi4 = hi[4], hi5 = hi[5], hi7 = hi[7];
         bool pass = leaf < num_leaves;
@@ -336,20 +336,33 @@ __global__ __launch_bounds__(64) void ray_near_kernel(
         pass = pass && b40 <= hi3 && b41 >= lo3 && b50 <= hi4 && b51 >= lo4;
         pass = pass && bz0 <= hi2 && b60 <= hi5 && b71 >= lo6 && b80 <= hi7 && b91 >= lo8;
         unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
-        auto from = [](float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
+        // the per-ray test below takes a passing leaf's 13 values from LDS (four 16-byte reads of one address: broadcast)
+        // -- 13 v_readlane per leaf, each feeding a VALU instruction through a scalar register, cost more than the rest
+        // of the loop
+        __syncthreads();                            // (one wavefront per workgroup) the previous chunk's reads are done
+        {
+            float4* mine = reinterpret_cast<float4*>(slab[lane]);
+            mine[0] = make_float4(lo0, lo1, lo3, lo4);
+            mine[1] = make_float4(lo6, lo8, hi0, hi1);
+            mine[2] = make_float4(hi2, hi3, hi4, hi5);
+            mine[3] = make_float4(hi7, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
         while (mask) {
             const int j = __builtin_ctzll(mask);
             mask &= mask - 1;
             const int nd = __builtin_amdgcn_readlane(node, j);
-            float out = __builtin_fmaxf(from(lo0, j) - qx, qx - from(hi0, j));
-            out = __builtin_fmaxf(out, __builtin_fmaxf(from(lo1, j) - qy, qy - from(hi1, j)));
-            out = __builtin_fmaxf(out, __builtin_fmaxf(from(lo3, j) - q4, q4 - from(hi3, j)));
-            out = __builtin_fmaxf(out, __builtin_fmaxf(from(lo4, j) - q5, q5 - from(hi4, j)));
-            out = __builtin_fmaxf(out, qz - from(hi2, j));
-            out = __builtin_fmaxf(out, q6 - from(hi5, j));
-            out = __builtin_fmaxf(out, from(lo6, j) - q7);
-            out = __builtin_fmaxf(out, q8 - from(hi7, j));
-            out = __builtin_fmaxf(out, from(lo8, j) - q9);
+            const float4* sj = reinterpret_cast<const float4*>(slab[j]);
+            const float4 s0 = sj[0], s1 = sj[1], s2 = sj[2], s3 = sj[3];
+            float out = __builtin_fmaxf(s0.x - qx, qx - s1.z);
+            out = __builtin_fmaxf(out, __builtin_fmaxf(s0.y - qy, qy - s1.w));
+            out = __builtin_fmaxf(out, __builtin_fmaxf(s0.z - q4, q4 - s2.y));
+            out = __builtin_fmaxf(out, __builtin_fmaxf(s0.w - q5, q5 - s2.z));
+            out = __builtin_fmaxf(out, qz - s2.x);
+            out = __builtin_fmaxf(out, q6 - s2.w);
+            out = __builtin_fmaxf(out, s1.x - q7);
+            out = __builtin_fmaxf(out, q8 - s3.x);
+            out = __builtin_fmaxf(out, s1.y - q9);
             const unsigned long long hit = __builtin_amdgcn_ballot_w64(real && !(out > 0.0f));
             if (hit) {
                 if (lane == 0) {
