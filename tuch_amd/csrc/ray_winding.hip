@@ -44,6 +44,7 @@ constexpr float kShearX = 0.3217f, kShearY = 0.4331f;
 constexpr float kFanX = 0.8191f, kFanY = 0.3467f, kFanZ = 0.4571f;
 constexpr int kSlabs = 9;
 constexpr int kSlabStride = 10;               // as winding.hip: node = [lo[10], hi[10]]
+constexpr int kNearSlabs = 13;                // of the 18 slab values of a leaf, those the near test uses
 
 struct RayElem { float x, y, z, sign; };      // sheared position of a strip vertex, orientation of the triangle it closes
 
@@ -119,16 +120,24 @@ __global__ __launch_bounds__(kBoundsBlock) void ray_leaf_bounds_kernel(
 #pragma unroll
     for (int k = 0; k < kSlabs; ++k) { lo[k] = row_min(lo[k]); nhi[k] = row_min(nhi[k]); }
     if (real && sub == 0) {
-        float* o = bounds + ((size_t)b * N + node) * (2 * kSlabStride);
+        // the 13 values ray_near_kernel tests, one array per value over the leaves ([B][13][leaves]): its lanes take one
+        // leaf each, so a value's load is 64 consecutive floats, addressed by the leaf's index alone (as [node][20] it
+        // was a gather over 40 cache lines behind a load of the node id)
+        const int L = height_off[1] - height_off[0], leaf = i - height_off[0];
+        float* o = bounds + (size_t)b * kNearSlabs * L + leaf;
+        float lo_p[kSlabs], hi_p[kSlabs];
 #pragma unroll
         for (int k = 0; k < kSlabs; ++k) {
             const float hi = -nhi[k];
             const float pad = 4e-7f * fmaxf(fabsf(lo[k]), fabsf(hi)) + 1e-9f;
-            o[k] = lo[k] - pad;
-            o[kSlabStride + k] = hi + pad;
+            lo_p[k] = lo[k] - pad;
+            hi_p[k] = hi + pad;
         }
-        o[kSlabs] = 0.0f;
-        o[kSlabStride + kSlabs] = 0.0f;
+        // order: lo0 lo1 lo3 lo4 lo6 lo8 | hi0 hi1 hi2 hi3 hi4 hi5 hi7
+        o[0 * (size_t)L] = lo_p[0]; o[1 * (size_t)L] = lo_p[1]; o[2 * (size_t)L] = lo_p[3]; o[3 * (size_t)L] = lo_p[4];
+        o[4 * (size_t)L] = lo_p[6]; o[5 * (size_t)L] = lo_p[8];
+        o[6 * (size_t)L] = hi_p[0]; o[7 * (size_t)L] = hi_p[1]; o[8 * (size_t)L] = hi_p[2]; o[9 * (size_t)L] = hi_p[3];
+        o[10 * (size_t)L] = hi_p[4]; o[11 * (size_t)L] = hi_p[5]; o[12 * (size_t)L] = hi_p[7];
     }
 }
 
@@ -318,19 +327,20 @@ __global__ __launch_bounds__(64) void ray_near_kernel(
     const float bx0 = wave_min(qx), bx1 = wave_max(qx), by0 = wave_min(qy), by1 = wave_max(qy);
     const float b40 = wave_min(q4), b41 = wave_max(q4), b50 = wave_min(q5), b51 = wave_max(q5);
     const float bz0 = wave_min(qz), b60 = wave_min(q6), b71 = wave_max(q7), b80 = wave_min(q8), b91 = wave_max(q9);
-    const float* bb = bounds + (size_t)b * N * (2 * kSlabStride);
+    const float* bb = bounds + (size_t)b * kNearSlabs * num_leaves;       // [13][leaves], see ray_leaf_bounds_kernel
     RayEntry* list = lists + ((size_t)b * qblocks + qb) * num_leaves;
     int cnt = 0;
     __shared__ float slab[64][16];              // the 13 slab values of the chunk's leaves, one row per lane
     for (int base = 0; base < num_leaves; base += 64) {
         const int leaf = base + lane;
         const int node = leaf_nodes[leaf < num_leaves ? leaf : num_leaves - 1];
-        const float* lo = bb + (size_t)node * (2 * kSlabStride);
-        const float* hi = lo + kSlabStride;
-        // the 13 slab values the tests use, one leaf per lane (fetching a passing leaf's values again through the scalar
-        // cache made the loop over the passing leaves a chain of scalar-memory latencies)
-        const float lo0 = lo[0], lo1 = lo[1], lo3 = lo[3], lo4 = lo[4], lo6 = lo[6], lo8 = lo[8];
-        const float hi0 = hi[0], hi1 = hi[1], hi2 = hi[2], hi3 = hi[3], hi4 = hi[4], hi5 = hi[5], hi7 = hi[7];
+        // the 13 slab values the tests use, one leaf per lane, coalesced (fetching a passing leaf's values again through the
+        // scalar cache made the loop over the passing leaves a chain of scalar-memory latencies)
+        const float* sv = bb + (leaf < num_leaves ? leaf : num_leaves - 1);
+        const size_t L = (size_t)num_leaves;
+        const float lo0 = sv[0], lo1 = sv[L], lo3 = sv[2 * L], lo4 = sv[3 * L], lo6 = sv[4 * L], lo8 = sv[5 * L];
+        const float hi0 = sv[6 * L], hi1 = sv[7 * L], hi2 = sv[8 * L], hi3 = sv[9 * L], hi4 = sv[10 * L], hi5 = sv[11 * L],
+                    hi7 = sv[12 * L];
         bool pass = leaf < num_leaves;
         pass = pass && bx0 <= hi0 && bx1 >= lo0 && by0 <= hi1 && by1 >= lo1;
         pass = pass && b40 <= hi3 && b41 >= lo3 && b50 <= hi4 && b51 >= lo4;
