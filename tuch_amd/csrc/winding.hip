@@ -610,10 +610,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 // cap vertex of band c = mean of the band's boundary-loop vertices (segmentation.py:74-76)
 __global__ __launch_bounds__(64) void cap_centroid_kernel(
     const float* __restrict__ verts, const int32_t* __restrict__ cap_off,
-    const int32_t* __restrict__ cap_vidx, int V, int K, float* __restrict__ caps)   // [B,K,3]
+    const int32_t* __restrict__ cap_vidx, int V, int K, float* __restrict__ caps,   // [B,K,3]
+    int32_t* __restrict__ seg_count_clear, int S)         // [B,S] or nullptr: cleared here (no memset node of its own)
 {
     // one wave per (cap, body): lanes stride over the loop, shuffle-reduce
     const int c = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    if (seg_count_clear && c == 0)
+        for (int i = lane; i < S; i += 64) seg_count_clear[(size_t)b * S + i] = 0;
     const float* vb = verts + (size_t)b * V * 3;
     float sx = 0.f, sy = 0.f, sz = 0.f;
     const int beg = cap_off[c], end = cap_off[c + 1];
@@ -1000,10 +1003,11 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
     const bool segments_by_rays = segments && m->seg_link_off && (ray == 2 || (ray == 1 && !seg_w));
     if (segments) {
         // what the segment pass needs of the vertices alone goes first, off the critical chain behind the body test
-        hipLaunchKernelGGL(cap_centroid_kernel, dim3(m->num_caps, B), dim3(64), 0, s,
-                           verts, (const int32_t*)m->cap_off, (const int32_t*)m->cap_vidx, m->V,
-                           m->num_caps, (float*)(ws + l.caps));
-        if (hipMemsetAsync(ws + l.seg_count, 0, (size_t)B * m->num_segments * sizeof(int32_t), s) != hipSuccess) {
+        if (m->num_caps > 0) {
+            hipLaunchKernelGGL(cap_centroid_kernel, dim3(m->num_caps, B), dim3(64), 0, s,
+                               verts, (const int32_t*)m->cap_off, (const int32_t*)m->cap_vidx, m->V,
+                               m->num_caps, (float*)(ws + l.caps), (int32_t*)(ws + l.seg_count), m->num_segments);
+        } else if (hipMemsetAsync(ws + l.seg_count, 0, (size_t)B * m->num_segments * sizeof(int32_t), s) != hipSuccess) {
             tuch_set_error("tuch_exterior_flags: hipMemsetAsync failed");
             return TUCH_ERR_HIP;
         }
