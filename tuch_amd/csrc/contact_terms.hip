@@ -177,14 +177,34 @@ __global__ __launch_bounds__(kBlock) void stage2_finish_kernel(
     float in_sum = 0.0f, ex_sum = 0.0f, r_sum = 0.0f;
     if (!body_valid || body_valid[b]) {
         const float* pb = pts + (size_t)b * N * 3;
-        for (int i = threadIdx.x; i < N; i += kBlock) {
-            const int p = partner[(size_t)b * N + i];
-            const float dx = pb[3 * i] - pb[3 * p], dy = pb[3 * i + 1] - pb[3 * p + 1],
-                        dz = pb[3 * i + 2] - pb[3 * p + 2];
-            const float d = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
-            const bool ext = exterior[(size_t)b * N + i] != 0;
-            const Term t = contact_term(d, ext, mode, euclthres);
-            if (ext) ex_sum += t.value; else in_sum += t.value;
+        // eight points per thread and pass (one pass at SMPL size): their partners first, then both endpoints of all of
+        // them -- two rounds of loads per pass instead of two per point (the sums are added in point order all the same)
+        constexpr int kPer = 8;
+        for (int i0 = threadIdx.x; i0 < N; i0 += kBlock * kPer) {
+            int pr[kPer];
+            uint8_t ex[kPer];
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                const int i = min(i0 + u * kBlock, N - 1);
+                pr[u] = partner[(size_t)b * N + i];
+                ex[u] = exterior[(size_t)b * N + i];
+            }
+            float xi[kPer][3], xp[kPer][3];
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                const int i = min(i0 + u * kBlock, N - 1);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { xi[u][c] = pb[3 * i + c]; xp[u][c] = pb[3 * pr[u] + c]; }
+            }
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                if (i0 + u * kBlock >= N) break;
+                const float dx = xi[u][0] - xp[u][0], dy = xi[u][1] - xp[u][1], dz = xi[u][2] - xp[u][2];
+                const float d = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
+                const bool ext = ex[u] != 0;
+                const Term t = contact_term(d, ext, mode, euclthres);
+                if (ext) ex_sum += t.value; else in_sum += t.value;
+            }
         }
     }
     if (r2r)
@@ -245,11 +265,14 @@ __global__ __launch_bounds__(256) void stage2_bwd_kernel(
     }
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
-    const float gs = (!body_valid || body_valid[b]) ? contact_scale * g : 0.0f;
-    if (gs == 0.0f) return;
+    // the point's own data is requested before the upstream gradient and the body's flag are looked at (one round of
+    // loads less on a kernel that is nothing but its load latencies)
     const bool ext = exterior[(size_t)b * N + i] != 0;
     const int p = partner[(size_t)b * N + i];
-    const float dx = pb[3 * i] - pb[3 * p], dy = pb[3 * i + 1] - pb[3 * p + 1], dz = pb[3 * i + 2] - pb[3 * p + 2];
+    const float xi = pb[3 * i], yi = pb[3 * i + 1], zi = pb[3 * i + 2];
+    const float gs = (!body_valid || body_valid[b]) ? contact_scale * g : 0.0f;
+    if (gs == 0.0f) return;
+    const float dx = xi - pb[3 * p], dy = yi - pb[3 * p + 1], dz = zi - pb[3 * p + 2];
     const float d = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
     if (!(d > 0.0f)) return;
     const Term t = contact_term(d, ext, mode, euclthres);
