@@ -156,6 +156,14 @@ int tuch_contact_model_create(tuch_contact_model** out, int V, int F, const int3
                               int num_regions, const int32_t* region_off, const int32_t* region_vidx,
                               int num_pairs, const int32_t* pairs);
 void tuch_contact_model_destroy(tuch_contact_model* model);
+/* Switches of the hot calls (A/B measurements, tests): winding_ray (0 never / 1 when only flags are wanted / 2 also for
+ * w), winding_tree, winding_strips, tree_waves, ray_pair_cap, ray_waves, v2v_tree, v2v_waves, v2v_lds, seg_splits,
+ * seg_assist (fixed at create), canary, deterministic.  The environment variables TUCH_<NAME> are read ONCE, by
+ * tuch_contact_model_create; afterwards only set_option changes a model's switches -- no hot call looks at the
+ * environment, so a captured hipGraph cannot depend on it.  (The workspace sizes depend on ray_pair_cap and canary:
+ * query *_workspace_bytes again after changing them.) */
+int tuch_contact_model_set_option(tuch_contact_model* model, const char* name, int value);
+int tuch_contact_model_get_option(const tuch_contact_model* model, const char* name, int* value);
 const uint64_t* tuch_contact_model_mask_bits(const tuch_contact_model* model);
 const int32_t* tuch_contact_model_faces(const tuch_contact_model* model);
 /* eight device ints, zero between calls: arrival counters for tuch_smplify_stage2_finish (one per stream in flight) */

@@ -39,7 +39,7 @@ import torch
 
 import golden_io as gio
 from oracle import lbs as olbs
-from tuch_amd.synthetic import dense_hd_regressor, make_body, random_poses
+from tuch_amd.synthetic import dense_hd_regressor, make_body, random_poses, through_pose
 
 torch.cuda.LongTensor = torch.LongTensor  # F7 shim
 torch.manual_seed(0)
@@ -113,9 +113,9 @@ def _common_inputs(body, out):
     out['hd_face'] = body.hd_face_id
 
 
-def contact_case(tag, rings, segs, batch, seed, store_dense):
+def contact_case(tag, body_kw, batch, seed, store_dense):
     """K1-K6 + a6/a7/a8 of SURVEY.md §8a on one synthetic model."""
-    body = make_body(rings, segs)
+    body = make_body(**body_kw)
     _use_body(body)
     verts_np, joints_np, bp, go, be = _posed_verts(body, batch, seed)
     out = {}
@@ -279,66 +279,89 @@ def contact_case(tag, rings, segs, batch, seed, store_dense):
     print('wrote', path, '%.1f KB' % (os.path.getsize(path) / 1024))
 
 
-def fullsize_case():
-    """One SMPL-sized body (V=6890, F=13776): winding numbers, masked v2v and the SMPLify
-    contact term with segments, straight from the reference (peak RSS ~8 GB)."""
-    body = make_body(84, 82)
-    _use_body(body)
+def _fullsize_poses(tag, body):
+    """(verts [B,V,3], ignore_idxs [B]) of a full-size fixture."""
+    if tag == 'full2':
+        # body 0: the left forearm pushed THROUGH the trunk / hip (157 of its 306 vertices inside, 230 interior
+        # vertices in all), body 1: an ordinary pose that the caller marks ignore_idxs (losses.py:74)
+        m = olbs.model_tensors(body)
+        bp, go, be = through_pose(2, 2003)
+        v, _ = olbs.smpl_forward(m, torch.tensor(be), torch.tensor(bp), torch.tensor(go))
+        return v.numpy().astype(np.float32), np.array([False, True])
     verts_np, _, _, _, _ = _posed_verts(body, 1, 2002)
+    return verts_np, np.array([False])
+
+
+def fullsize_case(tag='full', body_kw=None):
+    """SMPL-sized bodies (V=6890, F=13776; 'ico_full': the irregular mesh, V=6762): winding numbers, masked v2v and
+    the SMPLify contact term with segments, straight from the reference (peak RSS ~8 GB per body)."""
+    body = make_body(**(body_kw or FULL_BODIES[tag]))
+    _use_body(body)
+    verts_np, ignore = _fullsize_poses(tag, body)
+    batch = verts_np.shape[0]
     out = {}
     _common_inputs(body, out)
     out['verts'] = verts_np
+    out['ignore_idxs'] = ignore
     face_tensor = torch.tensor(body.faces, dtype=torch.long)[None]
     geomask = torch.tensor(body.geodesics) > ref_config.geothres
     verts = torch.tensor(verts_np)
-    tris = verts[0][face_tensor[0]]
-    out['winding'] = ref_contact.winding_numbers(verts[[0]], tris[None]).numpy()
-    P = ref_contact.batch_pairwise_dist(verts[[0]], verts[[0]], squared=True)
-    P[:, ~geomask] = float('inf')
-    mn, arg = torch.min(P, dim=1)
-    out['v2v_min'] = mn.numpy()
-    out['v2v_argmin'] = arg.numpy()
-    del P
     names = list(body.segments.keys())
     segments = ref_segmentation.BatchBodySegment(names, face_tensor[0])
-    exts = segments.batch_has_self_isec(verts[[0]])
-    out['segment_exterior'] = np.concatenate([e.numpy().astype(np.uint8) for e in exts])[None]
+    ws, mins, args, seg_ext = [], [], [], []
+    for b in range(batch):
+        tris = verts[b][face_tensor[0]]
+        ws.append(ref_contact.winding_numbers(verts[[b]], tris[None])[0].numpy())
+        P = ref_contact.batch_pairwise_dist(verts[[b]], verts[[b]], squared=True)
+        P[:, ~geomask] = float('inf')
+        mn, arg = torch.min(P, dim=1)
+        mins.append(mn[0].numpy())
+        args.append(arg[0].numpy())
+        del P
+        exts = segments.batch_has_self_isec(verts[[b]])
+        seg_ext.append(np.concatenate([e.numpy().astype(np.uint8) for e in exts]))
+    out['winding'] = np.stack(ws)
+    out['v2v_min'] = np.stack(mins)
+    out['v2v_argmin'] = np.stack(args)
+    out['segment_exterior'] = np.stack(seg_ext)
     zero_prior = lambda pose, betas: torch.zeros(pose.shape[0])
     cdict = {'classes': [list(p) for p in body.region_pairs], 'csig': dict(body.regions)}
-    gt = np.zeros((1, len(body.region_pairs)), np.float32)
-    gt[0, :3] = 1.0
+    gt = np.zeros((batch, len(body.region_pairs)), np.float32)
+    gt[:, :3] = 1.0
     out['gt_contact'] = gt
     for eu_tag, eucl in (('e0', 0.0), ('e2', ref_config.euclthres)):
         v = torch.tensor(verts_np, requires_grad=True)
         loss = ref_losses.contact_fitting_loss(
-            torch.zeros(1, 69), torch.zeros(1, 3), None, None, torch.zeros(1, 10), torch.zeros(1, 49, 3) + 1.0,
-            geomask, eucl, torch.tensor([[0., 0., 20.]]), torch.zeros(1, 2), torch.zeros(1, 49, 2),
-            torch.zeros(1, 49), zero_prior, cdict, [torch.tensor(gt), None], torch.zeros(1, dtype=torch.bool),
-            torch.ones(1, dtype=torch.bool), v, face_tensor=face_tensor, device='cpu',
-            contact_loss_weight=2000.0, segments=segments)
+            torch.zeros(batch, 69), torch.zeros(batch, 3), None, None, torch.zeros(batch, 10),
+            torch.zeros(batch, 49, 3) + 1.0, geomask, eucl, torch.tensor([[0., 0., 20.]]).repeat(batch, 1),
+            torch.zeros(batch, 2), torch.zeros(batch, 49, 2), torch.zeros(batch, 49), zero_prior, cdict,
+            [torch.tensor(gt), None], torch.tensor(ignore), torch.ones(batch, dtype=torch.bool), v,
+            face_tensor=face_tensor, device='cpu', contact_loss_weight=2000.0, segments=segments)
         loss.backward()
         out['smplify_%s_seg_contact_loss' % eu_tag] = np.float64(loss.item())
         out['smplify_%s_seg_contact_grad_verts' % eu_tag] = v.grad.numpy()
+        print(tag, eu_tag, loss.item(), flush=True)
     out['contact_loss_weight'] = np.float32(2000.0)
     out['euclthres'] = np.float32(ref_config.euclthres)
-    path = os.path.join(HERE, 'contact_full.npz')
+    path = os.path.join(HERE, 'contact_%s.npz' % tag)
     np.savez_compressed(path, **out)
     print('wrote', path, '%.1f KB' % (os.path.getsize(path) / 1024))
 
 
-def fullsize_train_case():
-    """The SMPL-sized body of ``fullsize_case`` (same vertices) through the reference's
+def fullsize_train_case(tag='full'):
+    """The SMPL-sized bodies of ``fullsize_case(tag)`` (same vertices) through the reference's
     RegressorLoss.contact_loss, plain and HD branch with all N_hd = 3 F = 41 328 HD points
     (tuch/train/loss.py:240-317), and through EFTLoss.contact_loss (tuch/eft/loss.py:129-181).
     Inputs live in contact_full.npz; this file holds the expected outputs only."""
-    body = make_body(84, 82)
+    body = make_body(**FULL_BODIES[tag])
     _use_body(body)
-    verts_np, _, _, _, _ = _posed_verts(body, 1, 2002)
-    assert np.array_equal(verts_np, gio.load('contact_full.npz')['verts'])
+    verts_np, _ = _fullsize_poses(tag, body)
+    assert np.array_equal(verts_np, gio.load('contact_%s.npz' % tag)['verts'])
+    batch = verts_np.shape[0]
     out = {}
     face_tensor = torch.tensor(body.faces, dtype=torch.long)[None]
     geomask = torch.tensor(body.geodesics) > ref_config.geothres
-    valid = torch.ones(1, dtype=torch.bool)
+    valid = torch.ones(batch, dtype=torch.bool)
     with tempfile.TemporaryDirectory() as tmp:
         ref_config.HD_MODEL_DIR = tmp
         np.save(os.path.join(tmp, 'smpl_neutral_hd_vert_regressor.npy'), dense_hd_regressor(body))
@@ -362,29 +385,47 @@ def fullsize_train_case():
     names = list(body.segments.keys())
     segments = ref_segmentation.BatchBodySegment(names, face_tensor[0])
     cdict = {'classes': [list(p) for p in body.region_pairs], 'csig': dict(body.regions)}
-    gt = gio.load('contact_full.npz')['gt_contact']
+    gt = gio.load('contact_%s.npz' % tag)['gt_contact']
     eft = ref_eft.EFTLoss.__new__(ref_eft.EFTLoss)
     torch.nn.Module.__init__(eft)
     eft.device, eft.options = 'cpu', types.SimpleNamespace(batch_size=1)
     eft.face_tensor, eft.geomask, eft.cdict, eft.segments = face_tensor, geomask, cdict, segments
-    v = torch.tensor(verts_np, requires_grad=True)
-    l = eft.contact_loss(torch.tensor(gt), v)
-    l.backward()
-    out['eft_loss'] = np.asarray([l.item()], np.float64)
-    out['eft_grad_verts'] = v.grad.numpy()
-    print('eft', l.item(), flush=True)
-    path = os.path.join(HERE, 'contact_full_train.npz')
+    eft_loss, eft_grad = [], []
+    for b in range(batch):              # the reference tests the segments with the whole batch (:150): one call per body
+        v = torch.tensor(verts_np[b:b + 1], requires_grad=True)
+        l = eft.contact_loss(torch.tensor(gt[b:b + 1]), v)
+        l.backward()
+        eft_loss.append(l.item())
+        eft_grad.append(v.grad.numpy()[0])
+        print('eft', l.item(), flush=True)
+    out['eft_loss'] = np.asarray(eft_loss, np.float64)
+    out['eft_grad_verts'] = np.stack(eft_grad)
+    path = os.path.join(HERE, 'contact_%s_train.npz' % tag)
     np.savez_compressed(path, **out)
     print('wrote', path, '%.1f KB' % (os.path.getsize(path) / 1024))
 
 
+BODIES = {
+    'small': (dict(rings=10, segs=12), 2, 1001, True),
+    'medium': (dict(rings=40, segs=40), 3, 1002, False),
+    # irregular topology: geodesic icosahedron + random edge flips (valence 4-9, V not a multiple of 64), painted
+    # segments with ragged boundaries and stray vertices
+    'ico_small': (dict(topology='ico', freq=4), 2, 1003, True),
+    'ico_medium': (dict(topology='ico', freq=13), 3, 1004, False),
+}
+FULL_BODIES = {
+    'full': dict(rings=84, segs=82),
+    'full2': dict(rings=84, segs=82),
+    'ico_full': dict(topology='ico', freq=26),
+}
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['small', 'medium', 'full', 'full_train']
-    if 'small' in which:
-        contact_case('small', 10, 12, batch=2, seed=1001, store_dense=True)
-    if 'medium' in which:
-        contact_case('medium', 40, 40, batch=3, seed=1002, store_dense=False)
-    if 'full' in which:
-        fullsize_case()
-    if 'full_train' in which:
-        fullsize_train_case()
+    which = sys.argv[1:] or (list(BODIES) + [t + s for t in FULL_BODIES for s in ('', '_train')])
+    for tag, (kw, batch, seed, dense) in BODIES.items():
+        if tag in which:
+            contact_case(tag, kw, batch=batch, seed=seed, store_dense=dense)
+    for tag in FULL_BODIES:
+        if tag in which:
+            fullsize_case(tag)
+        if tag + '_train' in which:
+            fullsize_train_case(tag)

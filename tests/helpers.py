@@ -67,3 +67,40 @@ def touches_surface(verts_b, faces, vid, tol=2e-6):
     for s, e in ((a, b), (b, c), (c, a)):
         inside &= (np.cross(e - s, q - s) * n).sum(1) >= -tol * np.linalg.norm(e - s, axis=1)
     return bool(inside.any())
+
+
+def _log(line: str) -> None:
+    import os
+    print(line)
+    try:
+        out = os.path.join(gio.GOLDEN_DIR, '..', '..', 'gpurun_out')
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, 'parity_counts.txt'), 'a') as f:
+            f.write(line + '\n')
+    except OSError:
+        pass
+
+
+def report(what, count, total):
+    """Observed index/flag mismatches against the reference (allowed only between candidates tied within the
+    reference's own float32 noise): printed (-s) and appended to gpurun_out/parity_counts.txt."""
+    _log('%-72s %6d / %d' % (what, count, total))
+
+
+# Relative tolerance of gradients against the reference's autograd (north_star: 1e-4), on top of an absolute floor that
+# is a fraction of the largest entry (cancellation in float32 sums).  Observed maxima are logged by grad_close.
+GRAD_RTOL = 1e-4
+# see tests/test_oracle_golden.py: the quantised derivative of a saturated tanh^2 term in float32 autograd
+TANH_QUANTUM = 12 * 2.4e-7
+
+
+def grad_close(actual, expected, floor, what, rtol=GRAD_RTOL, quantum=False):
+    """|actual - expected| <= rtol |expected| + floor * max|expected| (+ TANH_QUANTUM for the HD term); logs the
+    observed maximum of the error relative to the largest entry and relative to that bound."""
+    actual, expected = np.asarray(actual, np.float64), np.asarray(expected, np.float64)
+    scale = np.abs(expected).max()
+    atol = floor * scale + (TANH_QUANTUM if quantum else 0.0)
+    err = np.abs(actual - expected)
+    _log('grad %-60s max|err|/max|ref| %.2e   max err/bound %.3f' % (what, err.max() / max(scale, 1e-30),
+                                                                     (err / (atol + rtol * np.abs(expected))).max()))
+    assert_close(actual, expected, rtol, atol, what)

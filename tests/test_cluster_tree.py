@@ -69,7 +69,7 @@ def walk(tree, verts, start=0, stop=None, stats=None):
     return out
 
 
-@pytest.mark.parametrize('tag', ['small', 'medium'])
+@pytest.mark.parametrize('tag', ['small', 'medium', 'ico_small', 'ico_medium'])
 def test_tree_structure(tag):
     g = golden(tag)
     faces, v = g['faces'], g['verts'].shape[1]
@@ -112,7 +112,7 @@ def test_tree_structure(tag):
         assert sorted(order.tolist()) == sorted((s << 16) | q for s in range(len(fr)) for q in range(qblocks))
 
 
-@pytest.mark.parametrize('tag', ['small', 'medium'])
+@pytest.mark.parametrize('tag', ['small', 'medium', 'ico_small', 'ico_medium'])
 def test_cap_of_every_node_equals_its_faces_for_outside_queries(tag):
     """The identity the method rests on, node by node: for queries outside the node's box, the cap
     triangulation subtends the same solid angle as the node's faces."""
@@ -137,7 +137,8 @@ def test_cap_of_every_node_equals_its_faces_for_outside_queries(tag):
     assert checked >= (len(nodes) - 1) // 2
 
 
-@pytest.mark.parametrize('tag,leaf', [('small', 16), ('small', 64), ('medium', 24), ('medium', 64)])
+@pytest.mark.parametrize('tag,leaf', [('small', 16), ('small', 64), ('medium', 24), ('medium', 64), ('ico_small', 16),
+                                      ('ico_medium', 24), ('ico_medium', 32), ('ico_medium', 64)])
 def test_tree_walk_equals_flat_sum(tag, leaf):
     g = golden(tag)
     faces = g['faces']

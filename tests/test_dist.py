@@ -87,20 +87,12 @@ def _hip_worker(rank, world, port, out):
                          torch.tensor(np.where(gm, 1.0, 0.0).astype(np.float32), device=d), geothres=0.3,
                          euclthres=float(g['euclthres']), face_tensor=face_tensor, use_hd=(rank >= 0),
                          segments=BatchBodySegment(list(segs.keys()), face_tensor[0], segs),
-                         hd_regressor=(g['hd_idx'], g['hd_w']), hd_faces=g['hd_face'])
+                         hd_regressor=(g['hd_idx'], g['hd_w']), hd_faces=g['hd_face'], global_mean=True)
     verts = torch.tensor(g['verts'][lo:hi], device=d, requires_grad=True)
-    # all_reduce of the valid count inside contact_loss: gloo needs host tensors, the product passes the device
-    # tensor (RCCL on a real multi-GPU node) -> route this test's reduction through the host
-    real = dist.all_reduce
-
-    def via_host(t, op=dist.ReduceOp.SUM):
-        h = t.cpu()
-        real(h, op=op)
-        t.copy_(h)
-    dist.all_reduce = via_host
+    # global_mean=True: the all-reduce of the valid count inside contact_loss goes through dist.all_reduce_sum (gloo
+    # takes host tensors only: a host copy; RCCL takes the device tensor)
     share = crit.contact_loss(verts, torch.tensor(g['valid_fit'][lo:hi], device=d))
     share.backward()
-    dist.all_reduce = real
     total = share.detach().cpu().reshape(1)
     dist.all_reduce(total)
     grads = [None] * world

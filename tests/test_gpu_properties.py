@@ -132,3 +132,103 @@ def test_model_without_optional_tables():
         model.region_pair_min(verts)
     with pytest.raises(_C.TuchError):
         model.exterior_flags(verts.cpu())
+
+
+# ---- the shape bench.py times: batch 64, V=6890, bench.build_problem's own vertices ---------------------------------
+@pytest.fixture(scope='module')
+def headline():
+    import bench
+    dev = torch.device(DEV)
+    p = bench.build_problem(64, dev, seed=1002)            # rank 0's problem of the default bench run
+    with torch.no_grad():
+        verts = p['smpl'](global_orient=p['global_orient'], body_pose=p['body_pose'], betas=p['betas']).vertices.contiguous()
+    return p, verts
+
+
+def _oracle_bodies(p, verts_np, which):
+    body = p['body']
+    gm = body.geodesics > 0.3
+    osegs = [oc.Segment(n, body.faces, s['vidx'], list(s['bands'].values())) for n, s in body.segments.items()]
+    return {b: oc.smplify_contact_body(verts_np[b], body.faces, gm, 0.02, osegs, None) for b in which}, gm, osegs
+
+
+def test_headline_batch64_flags_partners_and_contact_value_for_every_body(headline):
+    """What the timed step computes behind the body model -- exterior flags by ray crossings WITH the segment filter,
+    masked partners, the contact value of losses.py:96-105 -- at the bench's own launch shape (64 bodies: eight per XCD
+    column, choose_v2v_frontier(64), one grid pass of the crossing kernel) against the oracle for ALL 64 bodies."""
+    from helpers import report
+    from tuch_amd.ops import MODE_SMPLIFY, contact_terms
+    from tuch_amd.smplify.losses import contact_model_for
+    p, verts = headline
+    model = contact_model_for(p['geomask'], p['face_tensor'], p['segments'], p['cdict'])
+    assert model.get_option('winding_ray') == 1
+    v = verts.clone().requires_grad_(True)
+    ext, mn, partner, _ = model.exterior_and_partner(v.detach(), apply_segments=True)     # as _Stage2Tail calls it
+    per_body, _ = contact_terms(v, partner, ext, None, MODE_SMPLIFY, 0.02)
+    per_body.sum().backward()
+    torch.cuda.synchronize()
+    verts_np = verts.cpu().numpy()
+    ref, gm, _ = _oracle_bodies(p, verts_np, range(64))
+    ext_np, part_np, mn_np = ext.cpu().numpy().astype(bool), partner.cpu().numpy().astype(np.int64), mn.cpu().numpy()
+    flag_mismatch = part_mismatch = interior = 0
+    worst_val = worst_grad = 0.0
+    for b in range(64):
+        r = ref[b]
+        # the SMPLify form applies the segment filter only when the body has an interior vertex (losses.py:85); the
+        # device applies it always -- identical, since the filter can only turn interior vertices exterior
+        clear = np.abs(r['winding'] - 0.99) > 1e-4
+        bad = (ext_np[b] != r['exterior']) & clear
+        flag_mismatch += int(bad.sum())
+        interior += int((~r['exterior']).sum())
+        assert_close(mn_np[b], r['min_d2'], 0, 1e-6, 'min d2 body %d' % b)
+        diff = part_np[b] != r['argmin']
+        part_mismatch += int(diff.sum())
+        vb = verts_np[b].astype(np.float64)
+        d_ours = ((vb - vb[part_np[b]]) ** 2).sum(1)
+        d_ref = ((vb - vb[r['argmin']]) ** 2).sum(1)
+        assert np.all(np.abs(d_ours - d_ref)[diff] < 2e-6)             # different partner only between tied rows
+        assert gm[part_np[b], np.arange(gm.shape[0])].all()
+        if not (ext_np[b] != r['exterior']).any() and not diff.any():
+            got = per_body[b].item()
+            worst_val = max(worst_val, abs(got - r['contact']) / max(abs(r['contact']), 1e-6))
+            assert_close(got, r['contact'], 1e-4, 1e-6, 'contact value body %d' % b)
+            gerr = np.abs(v.grad[b].cpu().numpy() - r['grad_contact'])
+            scale = np.abs(r['grad_contact']).max()
+            worst_grad = max(worst_grad, gerr.max() / max(scale, 1e-12))
+            assert_close(v.grad[b].cpu().numpy(), r['grad_contact'], 1e-4, 2e-6 * scale, 'contact grad body %d' % b)
+    report('headline B=64: exterior flags (ray + segments) != oracle where |w-0.99|>1e-4', flag_mismatch, 64 * verts.shape[1])
+    report('headline B=64: partners != oracle (tied rows only)', part_mismatch, 64 * verts.shape[1])
+    report('headline B=64: interior vertices in the batch', interior, 64 * verts.shape[1])
+    report('headline B=64: worst contact value rel err x1e9', int(worst_val * 1e9), 64)
+    report('headline B=64: worst contact grad err / max|grad| x1e9', int(worst_grad * 1e9), 64)
+    assert flag_mismatch == 0 and part_mismatch <= 64 and interior > 2000
+
+
+def test_headline_batch64_hd_contact_loss_against_the_oracle(headline):
+    """RegressorLoss.contact_loss(use_hd=True) on the bench's vertices at batch 64; eight of the bodies (every eighth:
+    one per XCD column) are checked against the oracle's HD branch (loss.py:274-315), all N_hd = 41 328 points."""
+    import bench
+    from helpers import grad_close
+    p, verts = headline
+    body = p['body']
+    crit = bench.regressor_loss(p, True)
+    which = list(range(0, 64, 8))
+    v = verts.clone().requires_grad_(True)
+    valid = torch.zeros(64, dtype=torch.bool, device=v.device)
+    valid[which] = True
+    loss = crit.contact_loss(v, valid)          # mean over the 8 valid bodies, the other 56 ride along in the batch
+    loss.backward()
+    verts_np = verts.cpu().numpy()
+    gm = body.geodesics > 0.3
+    osegs = [oc.Segment(n, body.faces, s['vidx'], list(s['bands'].values())) for n, s in body.segments.items()]
+    want, grads = [], {}
+    for b in which:
+        r = oc.train_contact_body(verts_np[b], body.faces, gm, 0.02, osegs, True, hd_idx=body.hd_bary_idx,
+                                  hd_w=body.hd_bary_w, hd_face=body.hd_face_id)
+        want.append(r['loss'])
+        grads[b] = r['grad'] / len(which)
+    assert_close(loss.item(), float(np.mean(want)), 1e-4, 0, 'HD contact loss, 8 of 64 bodies')
+    g = v.grad.cpu().numpy()
+    assert np.all(g[[b for b in range(64) if b not in which]] == 0)
+    for b in which:
+        grad_close(g[b], grads[b], 5e-6, 'headline HD grad body %d' % b, quantum=True)

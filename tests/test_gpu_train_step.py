@@ -64,6 +64,37 @@ def test_fits_dict_gather_and_scatter_match_the_reference(tmp_path):
     assert np.allclose(np.load(tmp_path / (names[0] + '_fits.npy')), fd.fits_dict[names[0]].cpu().numpy())
 
 
+def test_fits_dict_duplicate_rows_follow_the_reference_order(tmp_path):
+    """A sample index that occurs twice in one batch (MixedDataset wraps small datasets): the reference writes sample by
+    sample, only where ``update`` is set (fits_dict.py:75-85) -- the last updating occurrence wins, a non-updating one
+    never overwrites.  All four orders of (update, no update) on duplicated rows, on two datasets."""
+    from tuch_amd.train.fits_dict import FitsDict
+    rng = np.random.default_rng(8)
+    sizes = {'dsA': 7, 'dsB': 5}
+    for n, k in sizes.items():
+        np.save(tmp_path / (n + '_fits.npy'), rng.standard_normal((k, 82)).astype(np.float32))
+    ds = types.SimpleNamespace(dataset_dict={n: i for i, n in enumerate(sizes)}, datasets=[list(range(k)) for k in sizes.values()])
+    fd = FitsDict(types.SimpleNamespace(checkpoint_dir=str(tmp_path)), ds, device=DEV)
+    before = {n: t.cpu().numpy().copy() for n, t in fd.fits_dict.items()}
+    names = ['dsA', 'dsB', 'dsA', 'dsA', 'dsB', 'dsA', 'dsB', 'dsA', 'dsA', 'dsB', 'dsA', 'dsA']
+    index = [3, 1, 3, 0, 1, 0, 4, 5, 5, 2, 6, 6]
+    update = [1, 0, 0, 0, 1, 1, 1, 1, 1, 0, 0, 0]      # A3: (1,0)  B1: (0,1)  A0: (0,1)  A5: (1,1)  A6: (0,0)
+    pose = (0.4 * rng.standard_normal((12, 72))).astype(np.float32)     # |global orient| < pi: axis-angle round trip is the identity
+    betas = rng.standard_normal((12, 10)).astype(np.float32)
+    z = torch.zeros(12, device=DEV)
+    for _ in range(2):                                  # twice: the scratch column must be clean again after a call
+        fd[(names, torch.tensor(index, device=DEV), z, z, torch.tensor(update, device=DEV))] = \
+            (torch.tensor(pose, device=DEV), torch.tensor(betas, device=DEV))
+    want = {n: t.copy() for n, t in before.items()}
+    for n, (name, i, u) in enumerate(zip(names, index, update)):
+        if u:
+            want[name][i] = np.concatenate([pose[n], betas[n]])
+    for n in sizes:
+        got = fd.fits_dict[n].cpu().numpy()
+        assert_close(got, want[n], 1e-5, 1e-6, 'table ' + n)       # rot = 0: the round trip through rotation matrices
+        assert np.array_equal(got[[1, 2]] if n == 'dsA' else got[[0, 3]], before[n][[1, 2]] if n == 'dsA' else before[n][[0, 3]])
+
+
 def test_forward_train_step_matches_the_reference(tmp_path):
     """run_smplify + use_contact_in_the_loop: regressor -> SMPL (pose2rot=False) -> rotation matrices to axis-angle ->
     SMPLify-DC (5 + 5 iterations) -> better-fit bookkeeping + dictionary update -> RegressorLoss with the HD contact

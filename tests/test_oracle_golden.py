@@ -12,7 +12,12 @@ import golden_io as gio
 from helpers import assert_close, golden, golden_mask, oracle_segments, region_pair_lists
 from oracle import contact as oc
 
-TAGS = ['small', 'medium']
+TAGS = ['small', 'medium', 'ico_small', 'ico_medium']   # ico_*: irregular topology (valence 4-9, ragged painted segments)
+# float32 autograd evaluates d tanh^2 as 2 t (1 - t*t): for a saturated term (exterior point a few cm from its partner,
+# d / 0.005 > 6) 1 - t*t is a multiple of 2^-23, so one ulp of difference in tanh moves a point's derivative by 2.4e-7
+# whatever its size; a vertex collects ~12 such HD-point terms (weights 1/3 ... 2/3, own and partner side)
+TANH_QUANTUM = 12 * 2.4e-7
+FULL = ['full', 'full2', 'ico_full']                      # SMPL-sized; full2: forearm through the trunk + an ignored body
 
 
 def test_pairwise_dense():
@@ -22,7 +27,7 @@ def test_pairwise_dense():
     assert np.all(np.diag(p) == 0)
 
 
-@pytest.mark.parametrize('tag', TAGS + ['full'])
+@pytest.mark.parametrize('tag', TAGS + FULL)
 def test_v2v_min_masked(tag):
     g, gm = golden(tag), golden_mask(tag)
     for b in range(g['verts'].shape[0]):
@@ -43,7 +48,7 @@ def test_solid_angles_dense():
     assert_close(sa, g['solid_angles_b0'], 1e-5, 1e-5, 'solid angles')
 
 
-@pytest.mark.parametrize('tag', TAGS + ['full'])
+@pytest.mark.parametrize('tag', TAGS + FULL)
 def test_winding(tag):
     g = golden(tag)
     for b in range(g['verts'].shape[0]):
@@ -57,7 +62,7 @@ def test_winding(tag):
         assert np.array_equal((w <= 0.99)[clear], (g['winding'][b] <= 0.99)[clear])
 
 
-@pytest.mark.parametrize('tag', TAGS + ['full'])
+@pytest.mark.parametrize('tag', TAGS + FULL)
 def test_segments(tag):
     g = golden(tag)
     segs = oracle_segments(g)
@@ -74,8 +79,11 @@ def _smplify_total(g, gm, segs, eucl):
     b_count, v_count = g['verts'].shape[:2]
     clw = float(g['contact_loss_weight'])
     has_dc = g['has_discrete_contact'] if 'has_discrete_contact' in g else np.ones(b_count, bool)
+    ignore = g['ignore_idxs'] if 'ignore_idxs' in g else np.zeros(b_count, bool)
     total, grad = 0.0, np.zeros((b_count, v_count, 3))
     for b in range(b_count):
+        if ignore[b]:                      # losses.py:74: bodies in ignore_idxs get no contact terms
+            continue
         rp = region_pair_lists(g, b) if has_dc[b] else None
         r = oc.smplify_contact_body(g['verts'][b], g['faces'], gm, eucl, segs, rp)
         total += 10 * r['contact'] + clw * r['r2r']            # losses.py:120
@@ -96,9 +104,10 @@ def test_smplify_contact_loss(tag, eu, sg):
     assert_close(grad, g[key + '_grad_verts'], 1e-4, 1e-6 * scale, key + ' grad')
 
 
+@pytest.mark.parametrize('tag', FULL)
 @pytest.mark.parametrize('eu', ['e0', 'e2'])
-def test_smplify_contact_loss_fullsize(eu):
-    g, gm = golden('full'), golden_mask('full')
+def test_smplify_contact_loss_fullsize(eu, tag):
+    g, gm = golden(tag), golden_mask(tag)
     eucl = 0.0 if eu == 'e0' else float(g['euclthres'])
     total, grad = _smplify_total(g, gm, oracle_segments(g), eucl)
     key = 'smplify_%s_seg_contact' % eu
@@ -117,7 +126,7 @@ def test_train_contact_loss(tag, use_hd):
     key = 'train_hd' if use_hd else 'train_plain'
     assert_close(loss, g[key + '_loss'], 1e-5, 0, key)
     scale = np.abs(g[key + '_grad_verts']).max()
-    assert_close(grad, g[key + '_grad_verts'], 1e-4, 2e-6 * scale, key + ' grad')
+    assert_close(grad, g[key + '_grad_verts'], 1e-4, 2e-6 * scale + TANH_QUANTUM, key + ' grad')
 
 
 @pytest.mark.parametrize('tag', TAGS)
@@ -174,17 +183,18 @@ def test_eft_contact_loss(tag):
         assert_close(grad, g['eft_grad_verts'][b], 1e-4, 2e-6 * scale, 'eft grad')
 
 
-def _full_train():
-    data = gio.load('contact_full_train.npz')
+def _full_train(tag='full'):
+    data = gio.load('contact_%s_train.npz' % tag)
     return {k: data[k] for k in data.files}
 
 
+@pytest.mark.parametrize('tag', FULL)
 @pytest.mark.parametrize('use_hd', [False, True])
-def test_train_contact_loss_fullsize(use_hd):
+def test_train_contact_loss_fullsize(use_hd, tag):
     """a7 at SMPL size (V=6890, N_hd=41328), plain and HD branch (loss.py:240-317)."""
-    g, gm, gt = golden('full'), golden_mask('full'), _full_train()
+    g, gm, gt = golden(tag), golden_mask(tag), _full_train(tag)
     loss, grad, _ = oc.train_contact_loss(
-        g['verts'], np.ones(1, bool), g['faces'], gm, float(g['euclthres']), oracle_segments(g),
+        g['verts'], np.ones(g['verts'].shape[0], bool), g['faces'], gm, float(g['euclthres']), oracle_segments(g),
         use_hd, hd_idx=g['hd_idx'], hd_w=g['hd_w'], hd_face=g['hd_face'])
     key = 'train_hd' if use_hd else 'train_plain'
     assert_close(loss, gt[key + '_loss'], 1e-5, 0, key)
@@ -192,13 +202,15 @@ def test_train_contact_loss_fullsize(use_hd):
     assert_close(grad, gt[key + '_grad_verts'], 1e-4, 2e-6 * scale, key + ' grad')
 
 
-def test_eft_contact_loss_fullsize():
-    g, gm, gt = golden('full'), golden_mask('full'), _full_train()
-    r = oc.eft_contact_body(g['verts'][0], g['faces'], gm, oracle_segments(g), region_pair_lists(g, 0))
-    assert_close(100 * (r['contact'] + 0.5 * r['r2r']), gt['eft_loss'][0], 1e-5, 1e-6, 'eft loss')
-    grad = 100 * (r['grad_contact'] + 0.5 * r['grad_r2r'])
-    scale = np.abs(gt['eft_grad_verts'][0]).max()
-    assert_close(grad, gt['eft_grad_verts'][0], 1e-4, 2e-6 * scale, 'eft grad')
+@pytest.mark.parametrize('tag', FULL)
+def test_eft_contact_loss_fullsize(tag):
+    g, gm, gt = golden(tag), golden_mask(tag), _full_train(tag)
+    for b in range(g['verts'].shape[0]):
+        r = oc.eft_contact_body(g['verts'][b], g['faces'], gm, oracle_segments(g), region_pair_lists(g, b))
+        assert_close(100 * (r['contact'] + 0.5 * r['r2r']), gt['eft_loss'][b], 1e-5, 1e-6, 'eft loss')
+        grad = 100 * (r['grad_contact'] + 0.5 * r['grad_r2r'])
+        scale = np.abs(gt['eft_grad_verts'][b]).max()
+        assert_close(grad, gt['eft_grad_verts'][b], 1e-4, 2e-6 * scale, 'eft grad')
 
 
 @pytest.mark.parametrize('tag', TAGS)

@@ -13,13 +13,13 @@ for leaf in [int(x) for x in os.environ.get('LEAVES', '32,48,64,96,128').split('
     os.environ['TUCH_TREE_LEAF_FACES'] = str(leaf)
     model = ops.ContactModel(faces, device=dev)
     for waves in [int(x) for x in os.environ.get('WAVES', '8192,32768,131072').split(',')]:
-        os.environ['TUCH_TREE_WAVES'] = str(waves)
+        model.set_option('tree_waves', waves)
         for B in (64, 8, 1):
             v = verts[:B].contiguous()
             t = bench.time_kernel(lambda: model.exterior_flags(v, apply_segments=False), 10)
             print('leaf %3d waves %6d B %2d: %.3f ms' % (leaf, waves, B, t * 1e3), flush=True)
     ext, det = model.exterior_flags(verts, apply_segments=False, return_details=True)[:2] if False else (None, None)
-os.environ['TUCH_WINDING_TREE'] = '0'
+model.set_option('winding_tree', 0)
 for B in (64, 8, 1):
     v = verts[:B].contiguous()
     t = bench.time_kernel(lambda: model.exterior_flags(v, apply_segments=False), 10)

@@ -10,7 +10,7 @@ with torch.no_grad():
 faces = torch.as_tensor(body.faces.astype(np.int64))
 model = ops.ContactModel(faces, device=dev)
 for waves in (4096, 16384, 32768, 65536, 131072):
-    os.environ['TUCH_TREE_WAVES'] = str(waves)
+    model.set_option('tree_waves', waves)
     w = model.winding_tree_work(verts)
     t = bench.time_kernel(lambda: model.exterior_flags(verts, apply_segments=False), 10)
     print(waves, w, 'per block: leaf %.0f cap %.0f' % (w['leaf_elements'] / w['query_blocks'], w['cap_elements'] / w['query_blocks']), '%.3f ms' % (t * 1e3))

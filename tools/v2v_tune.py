@@ -7,14 +7,14 @@ from tuch_amd.smplify.losses import contact_model_for
 model = contact_model_for(p['geomask'], p['face_tensor'], p['segments'], p['cdict'])
 with torch.no_grad():
     verts = p['smpl'](global_orient=p['global_orient'], body_pose=p['body_pose'], betas=p['betas']).vertices
-os.environ['TUCH_V2V_TREE'] = '0'
+model.set_option('v2v_tree', 0)
 mn0, a0 = model.v2v_min(verts)
 for B in (64, 8, 1):
     v = verts[:B].contiguous()
     print('flat B %2d: %.3f ms' % (B, bench.time_kernel(lambda: model.v2v_min(v), 10) * 1e3))
-os.environ['TUCH_V2V_TREE'] = '1'
+model.set_option('v2v_tree', 1)
 for waves in [int(x) for x in os.environ.get('WAVES', '4096,8192,16384,32768,65536').split(',')]:
-    os.environ['TUCH_V2V_WAVES'] = str(waves)
+    model.set_option('v2v_waves', waves)
     mn1, a1 = model.v2v_min(verts)
     torch.cuda.synchronize()
     same = (a0 == a1).float().mean().item()

@@ -49,6 +49,8 @@ _SIGNATURES = {
                                           c_int, c_void_p, c_void_p,
                                           c_int, c_void_p, c_void_p, c_int, c_void_p]),
     'tuch_contact_model_destroy': (None, [c_void_p]),
+    'tuch_contact_model_set_option': (c_int, [c_void_p, c_char_p, c_int]),
+    'tuch_contact_model_get_option': (c_int, [c_void_p, c_char_p, POINTER(c_int)]),
     'tuch_contact_model_mask_bits': (c_void_p, [c_void_p]),
     'tuch_contact_model_faces': (c_void_p, [c_void_p]),
     'tuch_contact_model_tickets': (c_void_p, [c_void_p]),

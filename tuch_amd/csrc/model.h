@@ -30,6 +30,26 @@ void tuch_build_strips(const int32_t* faces, int F, std::vector<int32_t>& vidx, 
 
 struct tuch_contact_model;
 
+// Switches of the hot calls (A/B measurements, tests).  The environment variables of the same names (TUCH_ + upper
+// case) are read ONCE, when the model is created; afterwards only tuch_contact_model_set_option changes them.  A hot
+// call never looks at the environment: what a captured graph does cannot depend on it silently.
+struct tuch_options {
+    int winding_ray = 1;        // 0: never by ray crossings, 1: when only the flags are wanted, 2: also for w (crossings - fan)
+    int winding_tree = 1;       // 0: flat strip walk instead of the cluster tree
+    int winding_strips = 1;     // 0: per-triangle kernel
+    int tree_waves = 32768;     // frontier choice of the solid-angle walk (128-query blocks)
+    int ray_pair_cap = 16;      // (ray, leaf) pairs per query the pair list has room for
+    int ray_waves = 32768;      // wavefronts of the crossing kernel
+    int v2v_tree = 1;           // 0: flat nearest-vertex search
+    int v2v_waves = 65536;      // frontier choice of the search
+    int v2v_lds = 6400;         // LDS bytes a workgroup of the search holds back when something runs beside it
+    int seg_splits = 16;        // face splits of the solid-angle segment kernel
+    int seg_assist = 1;         // 0: the segment pass counts its body-face crossings itself (read at create only)
+    int canary = 0;             // 1: guard words between the regions of every workspace, see tuch_workspace_canaries
+    int deterministic = 0;      // 1: gradient scatters as gathers over inverse partner lists (bit-reproducible fits)
+};
+void tuch_options_from_env(tuch_options* o);
+
 // Inside test by signed ray crossings (ray_winding.hip): exterior flags of the model's own vertices / of arbitrary
 // points, identical to thresholding the winding-number sum wherever that sum is well separated from the threshold.
 bool tuch_ray_available(const tuch_contact_model* m);
@@ -60,6 +80,7 @@ extern "C" int tuch_winding_points(const tuch_contact_model* m, const float* ver
 
 struct tuch_contact_model {
     int device;
+    tuch_options opt;
     int V, F;
     int32_t* faces;            // [F,3]
     int32_t* tickets;          // [8] arrival counters of "the last block adds up" kernels, zero between calls

@@ -78,6 +78,8 @@ extern "C" int tuch_contact_model_create(
     tuch_contact_model* m = (tuch_contact_model*)calloc(1, sizeof(tuch_contact_model));
     m->V = V;
     m->F = F;
+    m->opt = tuch_options();
+    tuch_options_from_env(&m->opt);          // the only place the hot calls' switches are read from the environment
     (void)hipGetDevice(&m->device);
     int rc = upload(&m->faces, faces, (size_t)F * 3);
     if (rc == TUCH_OK) {
@@ -297,8 +299,8 @@ extern "C" int tuch_contact_model_create(
             if (rc == TUCH_OK) rc = upload(&m->seg_ray_off, eoff.data(), eoff.size());
             if (rc == TUCH_OK) rc = upload(&m->seg_ray_ent, ent.data(), ent.size());
             // leaf-assisted form (model.h)
-            const char* ea = getenv("TUCH_SEG_ASSIST");              // 0: keep the segment pass self-contained (A/B, tests)
-            bool assist = rc == TUCH_OK && m->tree_nodes > 0 && tree_exact_host > 0 && num_segments <= 8 && !(ea && atoi(ea) == 0);
+            // option seg_assist = 0: keep the segment pass self-contained (A/B, tests)
+            bool assist = rc == TUCH_OK && m->tree_nodes > 0 && tree_exact_host > 0 && num_segments <= 8 && m->opt.seg_assist != 0;
             if (assist) {
                 auto key3 = [](int a, int b, int c) {          // rotation with the smallest id first: orientation kept
                     if (b < a && b < c) { const int t2 = a; a = b; b = c; c = t2; }
@@ -392,6 +394,56 @@ extern "C" int tuch_contact_model_create(
     }
     *out = m;
     return TUCH_OK;
+}
+
+namespace {
+struct OptionName { const char* name; int tuch_options::*field; };
+const OptionName kOptions[] = {
+    {"winding_ray", &tuch_options::winding_ray}, {"winding_tree", &tuch_options::winding_tree},
+    {"winding_strips", &tuch_options::winding_strips}, {"tree_waves", &tuch_options::tree_waves},
+    {"ray_pair_cap", &tuch_options::ray_pair_cap}, {"ray_waves", &tuch_options::ray_waves},
+    {"v2v_tree", &tuch_options::v2v_tree}, {"v2v_waves", &tuch_options::v2v_waves}, {"v2v_lds", &tuch_options::v2v_lds},
+    {"seg_splits", &tuch_options::seg_splits}, {"seg_assist", &tuch_options::seg_assist},
+    {"canary", &tuch_options::canary}, {"deterministic", &tuch_options::deterministic},
+};
+}  // namespace
+
+void tuch_options_from_env(tuch_options* o)
+{
+    for (const OptionName& k : kOptions) {
+        char env[64] = "TUCH_";
+        size_t n = strlen(env);
+        for (const char* c = k.name; *c && n + 1 < sizeof(env); ++c) env[n++] = (char)toupper((unsigned char)*c);
+        env[n] = 0;
+        const char* e = getenv(env);
+        if (e && *e) o->*(k.field) = atoi(e);
+    }
+}
+
+extern "C" int tuch_contact_model_set_option(tuch_contact_model* m, const char* name, int value)
+{
+    TUCH_REQUIRE(m && name, "tuch_contact_model_set_option: null argument");
+    for (const OptionName& k : kOptions)
+        if (!strcmp(k.name, name)) {
+            TUCH_REQUIRE(strcmp(name, "seg_assist") != 0, "tuch_contact_model_set_option: seg_assist is fixed when the model "
+                         "is created (TUCH_SEG_ASSIST)");
+            m->opt.*(k.field) = value;
+            return TUCH_OK;
+        }
+    tuch_set_error("tuch_contact_model_set_option: unknown option '%s'", name);
+    return TUCH_ERR_ARG;
+}
+
+extern "C" int tuch_contact_model_get_option(const tuch_contact_model* m, const char* name, int* value)
+{
+    TUCH_REQUIRE(m && name && value, "tuch_contact_model_get_option: null argument");
+    for (const OptionName& k : kOptions)
+        if (!strcmp(k.name, name)) {
+            *value = m->opt.*(k.field);
+            return TUCH_OK;
+        }
+    tuch_set_error("tuch_contact_model_get_option: unknown option '%s'", name);
+    return TUCH_ERR_ARG;
 }
 
 extern "C" const uint64_t* tuch_contact_model_mask_bits(const tuch_contact_model* m)

@@ -974,17 +974,11 @@ struct RayLayout {
 bool tuch_ray_available(const tuch_contact_model* m)
 {
     if (!m || m->tree_nodes <= 0 || !m->ring_off || m->tree_exact_len <= 0) return false;
-    const char* e = getenv("TUCH_WINDING_RAY");
-    return !e || atoi(e) != 0;
+    return m->opt.winding_ray != 0;
 }
 
-// room in the pair list, in (ray, leaf) pairs per query (a ray passes the slabs of ~4-5 leaves; TUCH_RAY_PAIR_CAP)
-static int ray_pair_cap()
-{
-    const char* e = getenv("TUCH_RAY_PAIR_CAP");
-    const int c = e ? atoi(e) : 16;
-    return c < 1 ? 1 : c;
-}
+// room in the pair list, in (ray, leaf) pairs per query (a ray passes the slabs of ~4-5 leaves; option ray_pair_cap)
+static int ray_pair_cap(const tuch_contact_model* m) { return m->opt.ray_pair_cap < 1 ? 1 : m->opt.ray_pair_cap; }
 
 static RayLayout full_layout(const tuch_contact_model* m, int B, int Q, bool verts)
 {
@@ -993,7 +987,7 @@ static RayLayout full_layout(const tuch_contact_model* m, int B, int Q, bool ver
     // leaf strips are the first part of the tree stream; the caps behind them are never read
     l.T = ceil_div(m->tree_exact_len, 3) * 3 + 6;
     const int L = m->tree_leaves;
-    const long cap = (long)ray_pair_cap() * Q;
+    const long cap = (long)ray_pair_cap(m) * Q;
     l.cap = (int)(cap < 0x3fffffffL ? cap : 0x3fffffffL);
     // tiles of a body: its pairs in 64s + one ragged tile per leaf; never fewer than the block-major fallback needs
     l.max_tiles = l.cap / 64 + L;
@@ -1001,8 +995,7 @@ static RayLayout full_layout(const tuch_contact_model* m, int B, int Q, bool ver
     // one column of wavefronts per XCD; four times what the chip holds at once (256 CUs x 4 SIMDs x 8), so that a
     // wavefront's share is about one tile and the hardware balances the rest (TUCH_RAY_WAVES)
     l.columns = B < 8 ? B : 8;
-    const char* e = getenv("TUCH_RAY_WAVES");
-    const int waves = e && atoi(e) > 0 ? atoi(e) : 32768;
+    const int waves = m->opt.ray_waves > 0 ? m->opt.ray_waves : 32768;
     l.workers = waves / l.columns > 0 ? waves / l.columns : 1;
     size_t o = 0;
     l.stream = o;    o += align256((size_t)B * l.T * sizeof(RayElem));

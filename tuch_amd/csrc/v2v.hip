@@ -654,14 +654,12 @@ TreeV2VLayout tree_v2v_layout(const tuch_contact_model* m, int B)
 bool use_v2v_tree(const tuch_contact_model* m)
 {
     if (m->tree_nodes <= 0 || !m->tree_mask_bits || !m->tree_v2v_info) return false;
-    const char* e = getenv("TUCH_V2V_TREE");
-    return !e || atoi(e) != 0;
+    return m->opt.v2v_tree != 0;
 }
 
 int choose_v2v_frontier(const tuch_contact_model* m, int B)
 {
-    const char* e = getenv("TUCH_V2V_WAVES");
-    const long target = e ? atol(e) : 65536L;
+    const long target = m->opt.v2v_waves;
     int f = 0;
     while (f + 1 < m->tree_num_frontiers &&
            (long)B * m->tree_qblocks * (m->tree_frontier_off_host[f + 1] - m->tree_frontier_off_host[f]) < target) ++f;
@@ -787,8 +785,7 @@ extern "C" int tuch_v2v_min_model_shared(const tuch_contact_model* m, const floa
     // kernels -- every slot is taken and those (and a 16 MB memset) queue behind the walk's workgroups: the chain only
     // got going when the walk was done (tools/graph_timeline.py: the memset took 236 us).  -2.5 % step time; alone the
     // walk is 10 % slower with the cap (0.28 -> 0.31 ms), hence a flag (TUCH_V2V_LDS: bytes, to compare).
-    static const int lds_env = [] { const char* e = getenv("TUCH_V2V_LDS"); return e ? atoi(e) : 6400; }();
-    const int lds_pad = leave_room ? lds_env : 0;
+    const int lds_pad = leave_room ? m->opt.v2v_lds : 0;
     hipLaunchKernelGGL(v2v_tree_kernel, dim3(B, 2 * nsub * m->tree_qblocks), dim3(64), (size_t)lds_pad, s, (const float*)prow, V, Vp,
                        (const uint64_t*)m->tree_mask_bits, nodes, (const int32_t*)m->tree_rows, (const float*)bounds,
                        (const uint64_t*)m->tree_masked, N, (const int32_t*)m->tree_frontier_nodes + f0,

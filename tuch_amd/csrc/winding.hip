@@ -659,10 +659,10 @@ __global__ __launch_bounds__(kBlock) void gather_segment_triangles_kernel(
 constexpr int kSegBlock = 64;     // one wave = 64 compacted queries per workgroup
 constexpr int kSegChunk = 128;    // triangles staged in LDS per pass
 constexpr int kSegSplits = 16;   // maximum; few (compacted) queries per segment: parallelism comes from the faces
-int seg_splits()
+int seg_splits(const tuch_contact_model* m)
 {
-    static const int v = [] { const char* e = getenv("TUCH_SEG_SPLITS"); int x = e ? atoi(e) : 16; return x < 1 ? 1 : (x > kSegSplits ? kSegSplits : x); }();
-    return v;
+    const int x = m->opt.seg_splits;
+    return x < 1 ? 1 : (x > kSegSplits ? kSegSplits : x);
 }
 
 // list[b][seg_q_off[s] + k] = position (within the segment) of its k-th vertex that needs the test
@@ -773,12 +773,8 @@ __global__ __launch_bounds__(kBlock) void segment_finalize_kernel(
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// TUCH_WINDING_STRIPS=0 selects the plain per-triangle kernel (A/B measurements)
-bool use_strips()
-{
-    static const int v = [] { const char* e = getenv("TUCH_WINDING_STRIPS"); return e ? atoi(e) : 1; }();
-    return v != 0;
-}
+// option winding_strips = 0 selects the plain per-triangle kernel (A/B measurements)
+bool use_strips(const tuch_contact_model* m) { return m->opt.winding_strips != 0; }
 
 // Number of stream chunks for the strip kernel: fill the 256 CUs x 4 SIMDs x 8 resident waves an
 // integral number of times (tail effect), keep chunks long enough to amortise the priming triple.
@@ -804,29 +800,26 @@ struct ExteriorLayout {
     int tree_subs;
 };
 
-// Inside test by ray crossings (ray_winding.hip): TUCH_WINDING_RAY=0 never, 1 (default) when only the flags are
-// wanted, 2 also when the caller asks for w (reported as crossings - fan angles); read per call
+// Inside test by ray crossings (ray_winding.hip): option winding_ray = 0 never, 1 (default) when only the flags are
+// wanted, 2 also when the caller asks for w (reported as crossings - fan angles)
 int ray_mode(const tuch_contact_model* m)
 {
     if (!tuch_ray_available(m)) return 0;
-    const char* e = getenv("TUCH_WINDING_RAY");
-    return e ? atoi(e) : 1;
+    return m->opt.winding_ray;
 }
 
-// TUCH_WINDING_TREE=0 keeps the flat strip walk (A/B measurements); read per call
+// option winding_tree = 0 keeps the flat strip walk (A/B measurements)
 bool use_tree(const tuch_contact_model* m)
 {
     if (m->tree_nodes <= 0) return false;
-    const char* e = getenv("TUCH_WINDING_TREE");
-    return !e || atoi(e) != 0;
+    return m->opt.winding_tree != 0;
 }
 
 // smallest frontier (set of subtrees, one workgroup column each) that yields enough wavefronts to
 // balance the uneven subtree costs over 256 CUs
 int choose_frontier(const tuch_contact_model* m, int B)
 {
-    const char* e = getenv("TUCH_TREE_WAVES");
-    const long target = e ? atol(e) : 32768L;   // counted in 128-query blocks: two wavefronts each
+    const long target = m->opt.tree_waves;   // counted in 128-query blocks: two wavefronts each
     int f = 0;
     while (f + 1 < m->tree_num_frontiers &&
            (long)B * m->tree_qblocks * (m->tree_frontier_off_host[f + 1] - m->tree_frontier_off_host[f]) < target) ++f;
@@ -1018,12 +1011,12 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
     if (body_by_rays) {
         rc = tuch_ray_exterior_verts(m, verts, B, thresh, exterior, w, ws + l.ray, s, nullptr);
         if (rc != TUCH_OK) return rc;
-    } else if (use_strips() && use_tree(m)) {
+    } else if (use_strips(m) && use_tree(m)) {
         launch_tree_walk(m, l, verts, B, ws, nullptr, s);
         hipLaunchKernelGGL(winding_finalize_tree_kernel, dim3(ceil_div(m->V, kBlock), B), dim3(kBlock), 0, s,
                            (const float*)(ws + l.partial), (const int32_t*)m->tree_qperm, m->V,
                            2 * m->tree_qblocks * kTreeQueries, l.tree_subs, thresh, w, exterior);
-    } else if (use_strips() && m->strip_len > 0) {
+    } else if (use_strips(m) && m->strip_len > 0) {
         StreamElem* st = (StreamElem*)tris;
         hipLaunchKernelGGL(gather_stream_kernel, dim3(ceil_div(l.lpad, kBlock), B), dim3(kBlock), 0, s, verts,
                            (const int32_t*)m->strip_vidx, (const float*)m->strip_sign, m->V, m->strip_len,
@@ -1059,7 +1052,7 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
             // the body's inside test, when it ran by ray crossings just above, has left the crossings of every vertex
             // with the body faces of its segments
             rc = tuch_ray_segment_flags(m, verts, caps, seg_count, seg_list,
-                                        body_by_rays ? tuch_ray_segment_counts(m, B, ws + l.ray) : nullptr, B, seg_splits(),
+                                        body_by_rays ? tuch_ray_segment_counts(m, B, ws + l.ray) : nullptr, B, seg_splits(m),
                                         thresh, seg_tris, (int32_t*)seg_partial, seg_w, seg_exterior, exterior, s);
             if (rc != TUCH_OK) return rc;
             return tuch_check_launch("tuch_exterior_flags");
@@ -1067,7 +1060,7 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
         hipLaunchKernelGGL(gather_segment_triangles_kernel, dim3(ceil_div(m->seg_f_total * 3, kBlock), B),
                            dim3(kBlock), 0, s, verts, (const float*)caps, (const int32_t*)m->seg_faces,
                            m->V, m->num_caps, m->seg_f_total, seg_tris);
-        hipLaunchKernelGGL(segment_winding_kernel, dim3(B, seg_splits(), m->num_seg_blocks), dim3(kSegBlock),
+        hipLaunchKernelGGL(segment_winding_kernel, dim3(B, seg_splits(m), m->num_seg_blocks), dim3(kSegBlock),
                            0, s, verts, (const float*)seg_tris, (const int32_t*)m->seg_blocks,
                            (const int32_t*)m->seg_q_off, (const int32_t*)m->seg_q_vidx,
                            (const int32_t*)m->seg_f_off, (const int32_t*)seg_count, (const int32_t*)seg_list,
@@ -1075,7 +1068,7 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
         hipLaunchKernelGGL(segment_finalize_kernel, dim3(ceil_div(m->seg_q_total, kBlock), B), dim3(kBlock), 0, s,
                            (const float*)seg_partial, (const int32_t*)m->seg_of_q, (const int32_t*)m->seg_q_off,
                            (const int32_t*)m->seg_q_vidx, (const int32_t*)seg_count, (const int32_t*)seg_list,
-                           m->V, m->seg_q_total, m->num_segments, seg_splits(), thresh, seg_w, seg_exterior, exterior);
+                           m->V, m->seg_q_total, m->num_segments, seg_splits(m), thresh, seg_w, seg_exterior, exterior);
     }
     return tuch_check_launch("tuch_exterior_flags");
 }
@@ -1178,7 +1171,7 @@ extern "C" int tuch_winding_points(const tuch_contact_model* m, const float* ver
     const int ray = ray_mode(m);
     if (ray == 2 || (ray == 1 && !w))     // off-surface points: the winding number is the integer crossing count
         return tuch_ray_exterior_points(m, verts, points, counts, B, Q, thresh, exterior, w, workspace, s);
-    if (use_strips() && use_tree(m)) {
+    if (use_strips(m) && use_tree(m)) {
         // hierarchical walk (cluster tree + boundary caps) with the caller's points as queries
         const PointsLayout l = points_layout(m, B, Q);
         char* ws = (char*)workspace;

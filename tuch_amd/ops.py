@@ -346,8 +346,11 @@ class _Stage2Tail(torch.autograd.Function):
                 _C.ptr(precisions), _C.ptr(logw), b, nj, means.shape[0], float(const['focal']), float(const['sigma']),
                 float(const['prior_scale']), _C.ptr(small), _C.ptr(gj), _C.ptr(gc), _C.ptr(gp), _C.stream()))
             # the cleared vertex gradient the backward pass accumulates into: filled here, beside the walk, instead of
-            # between two kernels of the backward chain
-            return (r2r, ij, small, gj, gc, gp, torch.zeros_like(v))
+            # between two kernels of the backward chain.  One more zero word behind it is the arrival counter of
+            # stage2_finish ("the last block adds up"): it belongs to THIS call -- no counter shared between streams,
+            # none left non-zero by an aborted launch
+            zeros = torch.zeros(v.numel() + 1, dtype=torch.float32, device=v.device)
+            return (r2r, ij, small, gj, gc, gp, zeros[:v.numel()].view(v.shape), zeros[v.numel():].view(torch.int32))
         exterior, _, partner, _extra = model.exterior_and_partner(v, apply_segments=const['apply_segments'],
                                                                   also=beside_the_walk)
         out = torch.empty(1, dtype=torch.float32, device=v.device)
@@ -355,7 +358,7 @@ class _Stage2Tail(torch.autograd.Function):
         _C.check(L.tuch_smplify_stage2_finish(_C.ptr(v), _C.ptr(partner), _C.ptr(exterior), _C.ptr(valid), b, v.shape[1],
                                               MODE_SMPLIFY, float(const['euclthres']), _C.ptr(small), _C.ptr(r2r), p,
                                               float(const['contact_scale']), float(const['r2r_scale']), _C.ptr(share),
-                                              model.ticket(), None, _C.ptr(out), _C.stream()))
+                                              _C.ptr(_extra[7]), None, _C.ptr(out), _C.stream()))
         ctx.save_for_backward(v, partner, exterior, valid, ij, gj, gc, gp)
         ctx.model, ctx.const, ctx.dims = model, const, (b, nj, p)
         ctx.in_dtypes = (verts.dtype, joints.dtype, camera_t.dtype, body_pose.dtype)
@@ -531,6 +534,11 @@ class ContactModel:
         self._host = (keep, gm, len(cap_off) - 1, len(regions))
         self._h = None
         self._faces_i32 = None
+        # host-side switches, read from the environment once (like the library's own, tuch_contact_model_set_option):
+        # overlap = search on a second stream beside the inside test, v2v_hint = partner hints kept between calls
+        self._py_options = {'overlap': int(os.environ.get('TUCH_OVERLAP', '1') != '0'),
+                            'v2v_hint': int(os.environ.get('TUCH_V2V_HINT', '1') != '0')}
+        self._pending_options = {}
 
     @property
     def _handle(self):
@@ -549,7 +557,28 @@ class ContactModel:
                     num_regions, p(keep['reg_off']), p(keep['reg_v']), self.num_pairs, p(keep['pairs'])))
             self._h = handle
             self._host = None          # the 47 MB byte mask is not needed again
+            for name, value in self._pending_options.items():
+                _C.check(_C.lib().tuch_contact_model_set_option(handle, name.encode(), int(value)))
+            self._pending_options = {}
         return self._h
+
+    def set_option(self, name: str, value: int) -> None:
+        """Change one of the model's switches (include/tuch_amd.h: tuch_contact_model_set_option; plus the host-side
+        'overlap' and 'v2v_hint').  The environment is read once, when the model is created; hot calls never read it.
+        Captured hipGraphs keep the behaviour they were captured with."""
+        if name in self._py_options:
+            self._py_options[name] = int(value)
+        elif self._h is None:
+            self._pending_options[name] = int(value)
+        else:
+            _C.check(_C.lib().tuch_contact_model_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        if name in self._py_options:
+            return self._py_options[name]
+        out = ctypes.c_int(0)
+        _C.check(_C.lib().tuch_contact_model_get_option(self._handle, name.encode(), ctypes.byref(out)))
+        return out.value
 
     @property
     def faces_i32(self):
@@ -577,23 +606,12 @@ class ContactModel:
                                              sign.ctypes.data_as(ctypes.c_void_p)))
         return vidx, sign, k.value
 
-    def ticket(self) -> ctypes.c_void_p:
-        """Arrival counter (device int, zero between calls) of the "last block adds up" kernels for the CURRENT stream:
-        the model owns eight, dealt out round-robin to the streams that ask, so that up to eight calls in flight on
-        different streams do not share one (a counter is busy only while its kernel runs)."""
-        key = torch.cuda.current_stream().cuda_stream
-        slots = self.__dict__.setdefault('_ticket_slots', {})
-        if key not in slots:
-            slots[key] = len(slots) % 8
-        base = _C.lib().tuch_contact_model_tickets(self._handle)
-        return ctypes.c_void_p(base + 4 * slots[key])
-
     def exterior_and_partner(self, verts: torch.Tensor, apply_segments: bool = True, also=None):
         """exterior_flags + v2v_min of the same vertices -> (exterior, min_d2, partner[, also()]).
         The two only share their input: the nearest-vertex search (and the optional callable ``also``,
         e.g. the region pairs) runs on a second stream so that its tail fills the gaps of the long winding
-        walk (TUCH_OVERLAP=0 keeps everything on the current stream)."""
-        if not (verts.is_cuda and os.environ.get('TUCH_OVERLAP', '1') != '0'):
+        walk (option overlap = 0 keeps everything on the current stream)."""
+        if not (verts.is_cuda and self._py_options['overlap']):
             exterior = self.exterior_flags(verts, apply_segments=apply_segments)
             mn, partner = self.v2v_min(verts)
             return exterior, mn, partner, (also() if also is not None else None)
@@ -674,9 +692,9 @@ class ContactModel:
 
     def _v2v_hint(self, batch: int) -> Optional[torch.Tensor]:
         """Persistent per-batch-size buffer in which the search leaves its partners for the next call (an iterative
-        fit re-finds almost the same partners): seeds only, the results never depend on it (TUCH_V2V_HINT=0: off).
+        fit re-finds almost the same partners): seeds only, the results never depend on it (option v2v_hint = 0: off).
         Buffers are kept for the life of the model (a captured hipGraph may hold their addresses)."""
-        if os.environ.get('TUCH_V2V_HINT', '1') == '0':
+        if not self._py_options['v2v_hint']:
             return None
         buf = self._hints.get(batch)
         if buf is None:
@@ -731,9 +749,11 @@ class ContactModel:
         return mn, arg
 
     def tree_positions(self) -> Optional[np.ndarray]:
-        """position of every vertex in the cluster tree's vertex order (inverse of qperm), or None without tree."""
+        """position of every vertex in the cluster tree's vertex order (inverse of the MODEL'S OWN qperm, whatever leaf
+        size it was built with: tuch_contact_model_tree_order), or None without tree."""
+        qperm = np.zeros(self.num_verts, np.int32)
         try:
-            qperm = cluster_tree(self.faces_np, self.num_verts)['qperm'][:self.num_verts]
+            _C.check(_C.lib().tuch_contact_model_tree_order(self._handle, qperm.ctypes.data_as(ctypes.c_void_p), None))
         except _C.TuchError:
             return None
         pos = np.empty(self.num_verts, np.int32)

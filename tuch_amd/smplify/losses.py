@@ -15,6 +15,10 @@ import torch
 from .. import ops
 from ..utils.geometry import perspective_projection
 
+# one autograd node for everything behind the body model (ops._Stage2Tail) instead of separate nodes; read from the
+# environment once, at import (TUCH_FUSED_TAIL=0: A/B measurements; the tests flip the attribute)
+FUSED_TAIL = os.environ.get('TUCH_FUSED_TAIL', '1') != '0'
+
 _MODEL_CACHE: Dict[tuple, tuple] = {}
 _ANGLE_SIGNS: Dict[tuple, tuple] = {}
 
@@ -106,7 +110,7 @@ def stage2_objective(model, valid, select, body_pose, betas, model_joints, euclt
              and pose_prior.means.dtype == torch.float32 and pose_prior.means.is_cuda
              and model_joints.dtype == torch.float32 and body_pose.dtype == torch.float32)
 
-    if fused and camera_t.shape == (body_pose.shape[0], 3) and os.environ.get('TUCH_FUSED_TAIL', '1') != '0':
+    if fused and camera_t.shape == (body_pose.shape[0], 3) and FUSED_TAIL:
         # one autograd node for everything behind the body model (ops._Stage2Tail): the same kernels, less glue
         return ops.smplify_stage2_tail(
             verts, model_joints, camera_t, body_pose, model, valid,

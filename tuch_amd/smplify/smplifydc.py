@@ -77,6 +77,10 @@ class SMPLifyDC():
         # measurement / test aid (not in the reference): with record_history the objective and the parameters
         # *before* every update are kept per stage in self.history = {'stage1': [...], 'stage2': [...]}
         self.record_history = record_history
+        # read once: TUCH_GRAPH_STRICT=1 turns a failed capture into an error (the tests set it), TUCH_SMPLIFY_SESSIONS=0
+        # makes every call capture its loops afresh
+        self.graph_strict = os.environ.get('TUCH_GRAPH_STRICT', '0') == '1'
+        self.keep_sessions = os.environ.get('TUCH_SMPLIFY_SESSIONS', '1') != '0'
         self.history = None
         self.graph_replayed = {}
         # captured loops are kept between calls (keyed by batch size and the constant arguments): a training step
@@ -124,7 +128,7 @@ class SMPLifyDC():
             except Exception as exc:
                 # a loop that cannot be captured still runs (eagerly), but never silently: TUCH_GRAPH_STRICT=1
                 # (set by the tests) turns this into an error
-                if os.environ.get('TUCH_GRAPH_STRICT', '0') == '1':
+                if self.graph_strict:
                     raise
                 log.warning('SMPLifyDC: hipGraph capture of the %s loop failed (%r); finishing with eager launches',
                             stage, exc)
@@ -187,7 +191,11 @@ class SMPLifyDC():
             self.owner.graph_replayed[self.name] = num_iters - done
 
     def _session(self, batch, use_contact, contactlist, segments, contact_loss_weight, with_pairs, like):
-        key = (batch, bool(use_contact), id(contactlist), id(segments), float(contact_loss_weight), bool(with_pairs))
+        # everything a captured loop bakes in: the tables (the session keeps them alive, so their ids cannot be reused by
+        # other objects) and the fitter's own settings -- changing one of those after a call starts a new session
+        key = (batch, bool(use_contact), id(contactlist), id(segments), float(contact_loss_weight), bool(with_pairs),
+               float(self.step_size), float(self.euclthres), float(self.focal_length), tuple(self.ign_joints),
+               id(self.pose_prior), int(self.num_iters))
         sess = self._sessions.get(key)
         if sess is not None:
             return sess
@@ -223,7 +231,7 @@ class SMPLifyDC():
 
         def flags(bp, go, be, ct):
             body_pose.requires_grad, global_orient.requires_grad, betas.requires_grad, cam.requires_grad = bp, go, be, ct
-        sess = dict(t=t, flags=flags, use_contact=use_contact)
+        sess = dict(t=t, flags=flags, use_contact=use_contact, keys_alive=(contactlist, segments, self.pose_prior))
         # stage 1 optimises [betas, cam] with contact, [global_orient, cam] without (smplifydc.py:104-117)
         flags(False, not use_contact, bool(use_contact), True)
         sess['stage1'] = self._Stage(self, 'stage1', [betas, cam] if use_contact else [global_orient, cam], camera_iteration,
@@ -297,14 +305,14 @@ class SMPLifyDC():
     def _fit(self, init_pose, init_betas, init_cam_t, camera_center, keypoints_2d, use_contact, contactlist, gt_contact,
              ignore_idxs, has_discrete_contact, has_gt_keypoints, contact_loss_weight, contact_loss_return, segments):
         if (self.use_graph and init_pose.is_cuda and self.num_iters > 4 and not self.record_history
-                and os.environ.get('TUCH_SMPLIFY_SESSIONS', '1') != '0'
+                and self.keep_sessions
                 and (not use_contact or (ignore_idxs is not None and isinstance(contactlist, (dict, list))))):
             try:
                 return self._call_cached(init_pose, init_betas, init_cam_t, camera_center, keypoints_2d, use_contact,
                                          contactlist, gt_contact, ignore_idxs, has_discrete_contact, has_gt_keypoints,
                                          contact_loss_weight, segments)
             except Exception as exc:
-                if os.environ.get('TUCH_GRAPH_STRICT', '0') == '1':
+                if self.graph_strict:
                     raise
                 log.warning('SMPLifyDC: the cached hipGraph loops failed (%r); running this call without them', exc)
                 self._sessions.clear()

@@ -120,6 +120,93 @@ def _uv_sphere_topology(rings: int, segs: int) -> Tuple[np.ndarray, np.ndarray]:
     return dirs, faces
 
 
+def _ico_topology(freq: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Geodesic icosahedron of frequency ``freq``: V = 10 freq^2 + 2 (never a multiple of 64), F = 20 freq^2,
+    valence 6 except at the twelve corners (5).  Unit directions and faces."""
+    t = (1.0 + np.sqrt(5.0)) / 2.0
+    corners = np.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
+                        [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], np.float64)
+    corners /= np.linalg.norm(corners, axis=1, keepdims=True)
+    base = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6),
+            (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10),
+            (8, 6, 7), (9, 8, 1)]
+    index: Dict[tuple, int] = {}
+    pts: List[np.ndarray] = []
+
+    def vid(p: np.ndarray) -> int:
+        key = tuple(np.round(p * 1e6).astype(np.int64).tolist())
+        if key not in index:
+            index[key] = len(pts)
+            pts.append(p)
+        return index[key]
+    faces = []
+    for a, b, c in base:
+        A, B, C = corners[a], corners[b], corners[c]
+        grid = {}
+        for i in range(freq + 1):
+            for j in range(freq + 1 - i):
+                p = (A * (freq - i - j) + B * i + C * j) / freq
+                grid[(i, j)] = vid(p / np.linalg.norm(p))
+        for i in range(freq):
+            for j in range(freq - i):
+                faces.append((grid[(i, j)], grid[(i + 1, j)], grid[(i, j + 1)]))
+                if i + j < freq - 1:
+                    faces.append((grid[(i + 1, j)], grid[(i + 1, j + 1)], grid[(i, j + 1)]))
+    return np.asarray(pts), np.asarray(faces, dtype=np.int64)
+
+
+def _random_edge_flips(dirs: np.ndarray, faces: np.ndarray, flips: int, rng, min_valence: int = 4,
+                       max_valence: int = 9) -> np.ndarray:
+    """``flips`` random edge flips on a closed triangulation of the sphere: the result is still a closed, consistently
+    oriented manifold (a flip is taken only if the new diagonal does not exist yet and the quad is convex on the
+    sphere) with valences in [min_valence, max_valence] -- the spread of the SMPL mesh (3 ... 10,
+    tuch/models/smpl.py:37-42 loads it as it is) instead of a regular grid."""
+    faces = faces.copy()
+    # orient consistently outward first (the flip's convexity test assumes it)
+    vol = np.einsum('ij,ij->i', dirs[faces[:, 0]], np.cross(dirs[faces[:, 1]], dirs[faces[:, 2]]))
+    faces[vol < 0] = faces[vol < 0][:, [0, 2, 1]]
+    edge: Dict[tuple, list] = {}
+    for f, (a, b, c) in enumerate(faces.tolist()):
+        for x, y in ((a, b), (b, c), (c, a)):
+            edge.setdefault((min(x, y), max(x, y)), []).append(f)
+    valence = np.bincount(faces.ravel(), minlength=len(dirs))
+    det = lambda x, y, z: float(dirs[x] @ np.cross(dirs[y], dirs[z]))
+    done = tries = 0
+    keys = sorted(edge)
+    while done < flips and tries < 200 * max(flips, 1):
+        tries += 1
+        a, b = keys[int(rng.integers(len(keys)))]
+        if (a, b) not in edge:
+            continue
+        f1, f2 = edge[(a, b)]
+        t1 = faces[f1].tolist()
+        k = t1.index(a)
+        if t1[(k + 1) % 3] != b:            # make f1 the face that holds the directed edge a -> b
+            f1, f2 = f2, f1
+            t1 = faces[f1].tolist()
+            k = t1.index(a)
+        c = t1[(k + 2) % 3]
+        t2 = faces[f2].tolist()
+        d = t2[(t2.index(b) + 2) % 3]
+        if (min(c, d), max(c, d)) in edge or valence[a] <= min_valence or valence[b] <= min_valence \
+                or valence[c] >= max_valence or valence[d] >= max_valence:
+            continue
+        if det(a, d, c) <= 1e-9 or det(d, b, c) <= 1e-9:
+            continue
+        faces[f1] = (a, d, c)
+        faces[f2] = (d, b, c)
+        del edge[(a, b)]
+        edge[(min(c, d), max(c, d))] = [f1, f2]
+        e = edge[(min(a, d), max(a, d))]
+        e[e.index(f2)] = f1
+        e = edge[(min(b, c), max(b, c))]
+        e[e.index(f1)] = f2
+        valence[[a, b]] -= 1
+        valence[[c, d]] += 1
+        done += 1
+    return faces
+
+
 def _limb_axes() -> List[Tuple[np.ndarray, float, float]]:
     out = []
     for d, length, rad in _LIMBS:
@@ -347,12 +434,105 @@ def _make_segments(verts, faces, limb, axial, rings: int, segs: int) -> Dict[str
     return out
 
 
+def _painted_segment(paint: np.ndarray, faces: np.ndarray, num_verts: int, max_loops: int,
+                     strays: int, rng) -> Optional[dict]:
+    """A segment as the reference defines one (tuch/utils/segmentation.py:40-55): a painted VERTEX set; its faces are the
+    body faces with all three corners painted, its bands the ordered boundary loops.  ``paint`` is made consistent
+    (pinch vertices unpainted, everything outside the largest face component unpainted) so that the boundary is a set
+    of simple cycles -- however many: where two limbs merge a "band" is an open patch with ONE loop --; then ``strays`` painted vertices that belong to no segment face are added (a painted .ply may
+    hold such vertices; the reference tests them against the segment mesh like any other)."""
+    paint = paint.copy()
+    for _ in range(30):
+        fsel = paint[faces].all(1)
+        if fsel.sum() < 8:
+            return None
+        big = _largest_component(fsel, faces, num_verts)
+        keep = np.zeros(num_verts, bool)
+        keep[np.unique(faces[big])] = True
+        f = faces[keep[faces].all(1)]
+        e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], 0)
+        directed = set(map(tuple, e.tolist()))
+        out_deg: Dict[int, int] = {}
+        for a, b in directed:
+            if (b, a) not in directed:
+                out_deg[a] = out_deg.get(a, 0) + 1
+        pinch = [v for v, c in out_deg.items() if c > 1]
+        if not pinch and np.array_equal(keep, paint):
+            break
+        keep[pinch] = False
+        paint = keep
+    else:
+        return None
+    fsel = paint[faces].all(1)
+    loops = _boundary_loops(faces[fsel])
+    if loops is None or not 1 <= len(loops) <= max_loops:
+        return None
+    # stray painted vertices: not next to any painted vertex, so they complete no face
+    adj = _adjacency(num_verts, faces)
+    near = (adj @ (adj @ paint.astype(np.float64))) > 0
+    ring2 = (adj @ near.astype(np.float64)) > 0
+    cand = np.where(ring2 & ~near & ~paint)[0]
+    vidx = np.where(paint)[0]
+    if strays and len(cand):
+        pick = []
+        for v in rng.permutation(cand).tolist():
+            if all(abs(v - q) > 0 and adj[v, q] == 0 for q in pick):
+                pick.append(v)
+            if len(pick) == strays:
+                break
+        vidx = np.sort(np.concatenate([vidx, np.asarray(pick, np.int64)]))
+    bands = {'band%d' % bi: np.asarray(loop + [loop[0]], dtype=np.int64) for bi, loop in enumerate(loops)}
+    return {'vidx': vidx.astype(np.int64), 'bands': bands}
+
+
+def _make_painted_segments(verts, faces, rng) -> Dict[str, dict]:
+    """Segments of the irregular-topology body: vertices painted by a noisy geometric rule (ragged boundaries that
+    follow no edge loop of the mesh), eight of them like the UV body's."""
+    specs = {
+        'head': (0, 0.78, 9.0, 1), 'neckband': (0, 0.55, 0.74, 2),
+        'left_upperarm': (1, 0.25, 0.55, 2), 'right_upperarm': (2, 0.25, 0.55, 2),
+        'left_forearm': (1, 0.58, 0.90, 2), 'right_forearm': (2, 0.58, 0.90, 2),
+        'left_thigh': (3, 0.30, 0.64, 2), 'right_thigh': (4, 0.30, 0.64, 2),
+    }
+    axes = _limb_axes()
+    num_verts = len(verts)
+    v_limb = np.stack([_point_segment_distance(verts, np.zeros(3), dd * ll) - rr for dd, ll, rr in axes], 1).argmin(1)
+    e = np.concatenate([faces[:, [0, 1]], faces[:, [1, 2]], faces[:, [2, 0]]], 0)
+    elen = np.linalg.norm(verts[e[:, 0]] - verts[e[:, 1]], axis=1)
+    edge_len = np.bincount(e[:, 0], elen, num_verts) / np.maximum(np.bincount(e[:, 0], minlength=num_verts), 1)
+    out: Dict[str, dict] = {}
+    for si, (name, (k, f0, f1, loops)) in enumerate(specs.items()):
+        d, length, _ = axes[k]
+        ax = verts @ d + 0.2 * edge_len * rng.standard_normal(num_verts)    # ragged: per-vertex jitter of the cut
+        paint = (v_limb == k) & (ax >= f0 * length) & (ax <= f1 * length)
+        seg = _painted_segment(paint, faces, num_verts, 4, strays=2 if si % 2 == 0 else 0, rng=rng)
+        if seg is not None:
+            out[name] = seg
+    return out
+
+
 # -------------------------------------------------------------------------- main
 def make_body(rings: int = 84, segs: int = 82, seed: int = 1234, with_geodesics: bool = True,
               relax_iters: int = 200, num_regions: int = 24, hd_samples_per_face: int = 3,
-              geothres_for_pairs: float = 0.3) -> SyntheticBody:
+              geothres_for_pairs: float = 0.3, topology: str = 'uv', freq: int = 26,
+              flips: Optional[int] = None) -> SyntheticBody:
+    """topology 'uv': lat-long sphere of ``rings`` x ``segs`` (valence 6 + two poles, V = 6890 at (84, 82)).
+    topology 'ico': geodesic icosahedron of frequency ``freq`` (V = 10 freq^2 + 2: 6762 at 26) with ``flips`` random
+    edge flips (default V / 10) -> valences 4 ... 9, painted segments with ragged boundaries and stray vertices; what
+    the kernels meet on a mesh that is not a regular grid (the reference loads the SMPL mesh as it is,
+    tuch/models/smpl.py:37-42, tuch/utils/segmentation.py:40-66)."""
     rng = np.random.Generator(np.random.PCG64(seed))
-    dirs, faces = _uv_sphere_topology(rings, segs)
+    if topology == 'ico':
+        topo_rng = np.random.Generator(np.random.PCG64(seed + 77))
+        dirs, faces = _ico_topology(freq)
+        # a random rotation: no vertex on a symmetry plane of the limbs
+        q, _ = np.linalg.qr(topo_rng.standard_normal((3, 3)))
+        dirs = dirs @ (q * np.sign(np.linalg.det(q))).T
+        faces = _random_edge_flips(dirs, faces, len(dirs) // 10 if flips is None else flips, topo_rng)
+    elif topology == 'uv':
+        dirs, faces = _uv_sphere_topology(rings, segs)
+    else:
+        raise ValueError('topology must be uv or ico, got %r' % (topology,))
     num_verts = dirs.shape[0]
     adj = _adjacency(num_verts, faces)
     dirs = _relax(dirs, faces, relax_iters)
@@ -430,7 +610,10 @@ def make_body(rings: int = 84, segs: int = 82, seed: int = 1234, with_geodesics:
             if far:
                 pairs.append((names[i], names[k]))
 
-    segments = _make_segments(verts, faces, limb, axial, rings, segs)
+    if topology == 'ico':
+        segments = _make_painted_segments(verts, faces, topo_rng)
+    else:
+        segments = _make_segments(verts, faces, limb, axial, rings, segs)
 
     # HD regressor: fixed barycentric samples on every face
     bary = np.array([[0.6, 0.2, 0.2], [0.2, 0.6, 0.2], [0.2, 0.2, 0.6], [1 / 3, 1 / 3, 1 / 3]])
@@ -488,6 +671,41 @@ def random_poses(batch: int, seed: int, penetrating_fraction: float = 0.5):
         body_pose[b, 3 * 0 + 2] += 0.35 * amt      # L hip about z: legs together
         body_pose[b, 3 * 1 + 2] -= 0.35 * amt
     return (body_pose.astype(np.float32), global_orient.astype(np.float32), betas.astype(np.float32))
+
+
+def through_pose(batch: int, seed: int):
+    """Poses for parity cases where a limb goes THROUGH the body instead of resting against it: body 0 has the left
+    upper arm down along the trunk and the elbow bent inward so that the forearm passes through the trunk / hip
+    (about half of the forearm's vertices end up inside); further bodies are ordinary ``random_poses``."""
+    body_pose, global_orient, betas = random_poses(batch, seed, penetrating_fraction=0.0)
+    body_pose[0] = 0.0
+    body_pose[0, 3 * 15 + 2] = -1.2      # L shoulder about z
+    body_pose[0, 3 * 17 + 2] = -1.5      # L elbow about z: forearm across the body
+    global_orient[0] = 0.0
+    betas[0] = 0.0
+    return body_pose, global_orient, betas
+
+
+def folded_poses(batch: int, seed: int):
+    """Heavily self-penetrating poses (measurement of the worst case, not anatomy): on top of ``random_poses`` with
+    every body penetrating, a third of the bodies get a forearm through the trunk, a third the legs crossed through
+    each other, a third the trunk folded forward over the thighs."""
+    rng = np.random.Generator(np.random.PCG64(seed + 5))
+    body_pose, global_orient, betas = random_poses(batch, seed, penetrating_fraction=1.0)
+    for b in range(batch):
+        amt = 0.8 + 0.4 * rng.random()
+        if b % 3 == 0:
+            body_pose[b, 3 * 15 + 2] = -1.2 * amt
+            body_pose[b, 3 * 17 + 2] = -1.5 * amt
+        elif b % 3 == 1:
+            body_pose[b, 3 * 0 + 2] += 0.9 * amt       # hips about z: legs cross
+            body_pose[b, 3 * 1 + 2] -= 0.9 * amt
+        else:
+            body_pose[b, 3 * 2 + 0] += 0.9 * amt       # spine joints about x: fold forward
+            body_pose[b, 3 * 5 + 0] += 0.9 * amt
+            body_pose[b, 3 * 0 + 0] -= 0.8 * amt       # thighs up
+            body_pose[b, 3 * 1 + 0] -= 0.8 * amt
+    return body_pose.astype(np.float32), global_orient, betas
 
 
 # ------------------------------------------------------------------ asset files in the reference's formats

@@ -43,6 +43,7 @@ class FitsDict():
         self.flipped_parts = torch.tensor(_flip_perm(), dtype=torch.int64, device=self.device)
         self._ds_index = {}
         self._group_cache = {}
+        self._winner = {}             # per dataset: scratch column of __setitem__ (all -1 between calls)
         for ds_name, ds in train_dataset.dataset_dict.items():             # fits_dict.py:38-52
             dict_file = os.path.join(options.checkpoint_dir, ds_name + '_fits.npy')
             if not os.path.isfile(dict_file):
@@ -94,7 +95,19 @@ class FitsDict():
         params = torch.cat((pose, betas), dim=-1)
         for ds, pos, rows in self._groups(dataset_name, ind):
             table = self.fits_dict[ds]
-            table[rows] = torch.where(update[pos][:, None], params[pos], table[rows])     # no host sync on `update`
+            # The reference writes sample by sample, in batch order, only where ``update`` is set: if a row occurs twice
+            # in the batch (MixedDataset wraps small datasets) the LAST updating sample wins and a non-updating one
+            # never writes.  Same result without a host sync and without a write race: per table row the largest batch
+            # position that updates it (scatter-max into a persistent scratch column, -1 = nobody), then EVERY
+            # occurrence of the row writes that winner's value (or the old value) -- duplicates write identical data.
+            winner = self._winner.get(ds)
+            if winner is None:
+                winner = self._winner[ds] = torch.full((table.shape[0],), -1, dtype=torch.int64, device=self.device)
+            local = torch.arange(pos.shape[0], dtype=torch.int64, device=self.device)
+            winner.scatter_reduce_(0, rows, torch.where(update[pos], local, torch.full_like(local, -1)), 'amax')
+            w = winner[rows]
+            table[rows] = torch.where((w >= 0)[:, None], params[pos][w.clamp(min=0)], table[rows])
+            winner[rows] = -1
 
     def flip_pose(self, pose, is_flipped):
         """Flip SMPL pose parameters: swap left / right joints, negate the 2nd and 3rd axis-angle entries (:87-95)."""

@@ -33,9 +33,16 @@ def batch_face_normals(triangles):
 class RegressorLoss(nn.Module):
     def __init__(self, options, device, num_verts, faces, geodistssmpl, geothres=0.2, euclthres=0.02,
                  face_tensor=None, use_hd=True, segments=None, hd_regressor=None, hd_faces=None,
-                 hd_model_dir=None):
+                 hd_model_dir=None, global_mean=False):
         super().__init__()
         self.device = device
+        # contact_loss is a mean over the valid bodies (loss.py:317).  Default: over THIS process's bodies, like every
+        # other term of forward() -- under DistributedDataParallel (gradients averaged over ranks) all terms then share
+        # one normalisation.  global_mean=True divides the local sum by the all-reduced count of valid bodies instead
+        # (one float over RCCL on the calling stream): the ranks' values then SUM to the single-process mean and every
+        # body's gradient is the single-process gradient, which is what a trainer that SUMS gradients wants (and what
+        # makes ranks with few valid bodies weigh less); loss_dict['loss_contact'] is then the rank's share.
+        self.global_mean = bool(global_mean)
         self.options = options
         self.criterion_shape = nn.L1Loss().to(self.device)
         self.criterion_keypoints = nn.MSELoss(reduction='none').to(self.device)
@@ -79,9 +86,8 @@ class RegressorLoss(nn.Module):
         valid = valid_fit.bool()
         valid_u8 = valid.to(torch.uint8).contiguous()
         exterior, min_d2, partner, _ = model.exterior_and_partner(pred_vertices, apply_segments=True)   # :264-266
-        # loss.py:317 is a mean over ALL valid bodies: with the batch sharded over ranks the count is all-reduced
-        # (one float, no host sync), so that every body's gradient is the single-process one
-        n_valid = tdist.global_count(valid.sum())
+        # loss.py:317: mean over the valid bodies -- of this process, or (global_mean) of all ranks
+        n_valid = tdist.global_count(valid.sum()) if self.global_mean else valid.sum().to(torch.float32)
         if not self.use_hd:
             per_body, _ = ops.contact_terms(pred_vertices, partner, exterior, valid_u8, ops.MODE_TRAIN,
                                             self.euclthres)
