@@ -10,16 +10,23 @@ push/pull terms with winding-number inside test and segment filter + region-to-r
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 The batch dimension shards across ranks (weak scaling: 64 bodies per GPU; --global-batch G: strong
-scaling, G/N bodies per GPU); the only collective is a 2-float all-reduce of [sum of losses, body
-count] per step (RCCL).  Rank 0 prints ONE JSON line (contract in the task description) including
-  roofline     -- dominant kernel of the step (the masked vertex-distance search, v2v_tree_kernel: 260 of ~1150 us of
-                  kernel time), achieved FLOP/s in SURVEY 8(d)'s unit measured here with HIP events
+scaling, G/N bodies per GPU).  The fits of different bodies never exchange data, so there is no collective inside
+the loop: the two floats [sum of losses, body count] are all-reduced (RCCL) once per timed block of K steps.
+Rank 0 prints ONE JSON line (contract in the task description) including
+  roofline     -- dominant kernel of the step (the masked vertex-distance search, v2v_tree_kernel), achieved FLOP/s in
+                  SURVEY 8(d)'s unit measured here with HIP events; valu_busy / traffic parsed from the PMC summaries
+                  committed under profiles/ (the newest round's files)
   roofline_inside_test -- the second kernel group (inside test by ray crossings): executed operations per launch
   cpu_baseline -- the CPU oracle (test infrastructure) timed on this box's host cores, rank 0, N=1
+  selfcheck    -- after the timed blocks: the objective the replayed graph reports against an eager evaluation at the
+                  same parameters, and two sampled bodies of that state against the CPU oracle
+  rccl_smoke   -- N=1 only, in a child process: init_process_group('nccl', world_size=1), a device all-reduce, a
+                  contact loss with the all-reduced valid count captured in a hipGraph and replayed, destroy
+  kernels_per_step -- launches in one captured step (the graph's kernel nodes)
   repeat_ms_per_step -- the same K-step block timed --repeats times (median / min / max)
   shard_sweep  -- the step at 8/16/32/64 bodies on one GPU (the per-GPU shards of a global batch of 64)
   workloads    -- the per-rank workloads of BASELINE configs 3, 4 and 5
-  worst_case   -- every body self-penetrating
+  worst_case   -- every body self-penetrating; folded: limbs pushed THROUGH the body
 --config {2,3,4-shard,5-shard} makes one of those workloads the timed step instead (its own metric name).
 """
 import argparse
@@ -52,22 +59,60 @@ PEAK_FP32_VECTOR_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs x 16 
 # (one wave64 VALU instruction occupies its SIMD for 4 cycles: 4.1-4.5 measured, tools/ubench/valu_rate.hip -fno-slp-vectorize)
 PEAK_PLAIN_ISSUE_TLANEOPS = 39.3
 PEAK_HBM_GBS = 8000.0
-# HBM-side bytes per launch at batch 64 and VALU-busy fractions: PMC passes committed under profiles/ (see
-# profiles/README.md); constants from those files, NOT measured in this run.
-PROFILE = {
-    'v2v_tree_kernel': {
-        'traffic_bytes': int((30682.7 + 3745.0) * 1024),
-        'valu_busy': 0.59,
-        'source': 'profiles/r02_n_pmc_fetch.txt + r02_n_pmc_write.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, '
-                  'KB x 1024) and r02_n_pmc_sq.txt (SQ_ACTIVE_INST_VALU x 4 / (1024 x GRBM_GUI_ACTIVE / 8) = 7.880e7 x 4 / '
-                  '(1024 x 4.195e6 / 8)), batch 64, inside the step, where the walk runs with its occupancy cap beside the '
-                  'inside test; from profiles/, not measured in this run'},
-    'ray_leaf_kernel': {
-        'traffic_bytes': int((27294.7 + 14110.7) * 1024),
-        'valu_busy': 0.80,
-        'source': 'profiles/r02_n_pmc_fetch.txt + r02_n_pmc_write.txt and r02_n_pmc_sq.txt (6.132e7 x 4 / (1024 x 2.386e6 / 8)), '
-                  'batch 64; from profiles/, not measured in this run'},
-}
+
+
+def _pmc_rows(path):
+    """{first 60 characters of the kernel name: {counter: average per launch}} of a scripts/rocprof_pmc_summary.py file."""
+    rows = {}
+    with open(path) as f:
+        for line in f:
+            if line.startswith('#') or '=' not in line:
+                continue
+            counters = {}
+            for field in line.split():
+                name, eq, value = field.partition('=')
+                if eq and name.isupper():
+                    try:
+                        counters[name] = float(value)
+                    except ValueError:
+                        pass
+            rows[line[:60].strip()] = counters
+    return rows
+
+
+def profile_constants():
+    """HBM-side bytes per launch and VALU-busy fraction of the two big kernels at batch 64, parsed at start-up from the
+    newest committed PMC summaries (profiles/rNN_x_pmc_{fetch,write,sq}.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE /
+    SQ_* in separate passes, KB x 1024; VALU busy = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)).
+    From profiles/, NOT measured in this run."""
+    import glob
+    import re
+    out = {}
+    tags = sorted({re.match(r'(r\d+_[a-z]+)_pmc_sq\.txt', os.path.basename(f)).group(1)
+                   for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_sq.txt'))
+                   if re.match(r'(r\d+_[a-z]+)_pmc_sq\.txt', os.path.basename(f))})
+    for tag in reversed(tags):
+        files = {k: os.path.join(ROOT, 'profiles', '%s_pmc_%s.txt' % (tag, k)) for k in ('fetch', 'write', 'sq')}
+        if not all(os.path.exists(f) for f in files.values()):
+            continue
+        rows = {k: _pmc_rows(f) for k, f in files.items()}
+        for name in ('v2v_tree_kernel', 'ray_leaf_kernel'):
+            pick = lambda table: next((c for k, c in table.items() if name in k), None)
+            fe, wr, sq = pick(rows['fetch']), pick(rows['write']), pick(rows['sq'])
+            if fe and wr and sq and sq.get('GRBM_GUI_ACTIVE'):
+                out[name] = {'traffic_bytes': int((fe['FETCH_SIZE'] + wr['WRITE_SIZE']) * 1024),
+                             'valu_busy': round(sq['SQ_ACTIVE_INST_VALU'] * 4 / (1024 * sq['GRBM_GUI_ACTIVE'] / 8), 3),
+                             'valu_instr': sq.get('SQ_INSTS_VALU'), 'salu_instr': sq.get('SQ_INSTS_SALU'),
+                             'source': 'profiles/%s_pmc_{fetch,write,sq}.txt (batch 64, inside the step); from profiles/, '
+                                       'not measured in this run' % tag}
+        if len(out) == 2:
+            break
+    for name in ('v2v_tree_kernel', 'ray_leaf_kernel'):
+        out.setdefault(name, {'traffic_bytes': None, 'valu_busy': None, 'valu_instr': None, 'salu_instr': None,
+                              'source': 'no PMC summary under profiles/'})
+    return out
+
+
 _BODY = {}
 
 
@@ -88,6 +133,8 @@ def parse(argv=None):
     ap.add_argument('--no-torch-chain', action='store_true',
                     help='skip the torch-CPU op-chain baseline (one body, ~8 GB of host memory, ~30 s)')
     ap.add_argument('--no-extras', action='store_true', help='skip shard sweep, workloads, worst case, contact-loss eval')
+    ap.add_argument('--rccl-smoke', action='store_true', help='(internal) run the one-rank RCCL smoke and exit')
+    ap.add_argument('--no-rccl-smoke', action='store_true')
     return ap.parse_args(argv)
 
 
@@ -119,10 +166,10 @@ def synthetic_body():
     return _BODY['body']
 
 
-def build_problem(batch, device, seed, penetrating_fraction=0.5):
+def build_problem(batch, device, seed, penetrating_fraction=0.5, folded=False):
     from tuch_amd.models.smpl import SMPL
     from tuch_amd.smplify.prior import MaxMixturePrior
-    from tuch_amd.synthetic import random_poses
+    from tuch_amd.synthetic import folded_poses, random_poses
     from tuch_amd.utils.geometry import perspective_projection
     from tuch_amd.utils.segmentation import BatchBodySegment
     body = synthetic_body()
@@ -138,7 +185,7 @@ def build_problem(batch, device, seed, penetrating_fraction=0.5):
     smpl, prior, face_row, geomask, segments, cdict = _BODY[key]
     face_tensor = face_row[None].expand(batch, -1, -1)
     rng = np.random.Generator(np.random.PCG64(seed))
-    bp, go, be = random_poses(batch, seed, penetrating_fraction)
+    bp, go, be = folded_poses(batch, seed) if folded else random_poses(batch, seed, penetrating_fraction)
     t = lambda a: torch.tensor(a, device=device)
     body_pose, global_orient, betas = t(bp), t(go), t(be)
     cam_t = torch.tensor([[0.0, 0.0, 20.0]], device=device).repeat(batch, 1)
@@ -186,6 +233,20 @@ def make_step(p):
         opt.step()
         stats[0].copy_(loss.detach())
         return stats
+
+    def objective():
+        """The stage-2 objective at the CURRENT parameters, eager launches, no update; also the posed vertices."""
+        with torch.no_grad():
+            out = p['smpl'](global_orient=global_orient, body_pose=body_pose, betas=p['betas'])
+            loss = contact_fitting_loss(body_pose, global_orient, None, None, p['betas'], out.joints,
+                                        p['geomask'], 0.02, p['cam_t'], p['cam_c'], p['j2d'], p['conf'],
+                                        p['prior'], cdict=p['cdict'], gt_contact=[p['gt'], None],
+                                        ignore_idxs=p['ignore'], has_discrete_contact=p['has_dc'],
+                                        verts=out.vertices, face_tensor=p['face_tensor'],
+                                        focal_length=5000., contact_loss_weight=2000.0,
+                                        segments=p['segments'])
+        return float(loss), out.vertices.detach(), out.joints.detach(), body_pose.detach().clone()
+    step.objective = objective
     return step
 
 
@@ -313,6 +374,8 @@ def capture(step, warmup):
     def replay():
         graph.replay()
         return out
+    replay.objective = getattr(step, 'objective', None)
+    replay.graph = graph
     # the graph holds raw addresses of everything `step` owns (parameters, Adam state, ...): they must live as
     # long as the graph does.  (Round 1 dropped `step` here; its tensors were then recycled by the next regular
     # allocation -- the all-reduce's clone for N > 1 -- which is what "faulted next to a process group".)
@@ -360,7 +423,8 @@ def rooflines(p, batch):
     ach_v = alg_flop / t_v / 1e12
     ref_layout_bytes = batch * (12 * v + v * v + 8 * v)           # SURVEY.md 8(d) layout (i)
     compact_bytes = batch * (12 * v + 8 * v) + v * v // 8         # layout (ii): bit-packed mask read once
-    prof_v = PROFILE['v2v_tree_kernel']
+    prof = profile_constants()
+    prof_v = prof['v2v_tree_kernel']
     roof = {'kernel': 'v2v_tree_kernel (+ v2v_rows, tree_inner_bounds, v2v_seed, v2v_tree_finalize)', 'bound': 'valu',
             'achieved': round(ach_v, 2), 'peak': PEAK_FP32_VECTOR_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(ach_v / PEAK_FP32_VECTOR_TFLOPS, 4),
@@ -372,11 +436,12 @@ def rooflines(p, batch):
             'compact_layout_GBs': round(compact_bytes / t_v / 1e9, 1),
             'reference_layout_equivalent_GBs': round(ref_layout_bytes / t_v / 1e9, 1),
             'reference_layout_equivalent_frac_of_hbm': round(ref_layout_bytes / t_v / 1e9 / PEAK_HBM_GBS, 3),
-            'note': 'achieved = 8 FLOP x V^2 x B / launch time (SURVEY 8d); most (column, row) pairs are never evaluated -- pruned '
-                    'by box distance, by the lanes the mask leaves a row for below a node, and in groups of four rows no '
-                    'reachable lane may use; the mask is bit-packed and L2-resident: the equivalent-bandwidth figures are NOT '
-                    'physical bandwidth.  Per launch 7.9e7 VALU and 8.9e7 scalar instructions (one scalar instruction per cycle '
-                    'per CU = 0.15 ms of the 0.20): vector units 0.59 busy under the occupancy cap it runs with in the step'}
+            'valu_instr_per_launch': prof_v['valu_instr'], 'scalar_instr_per_launch': prof_v['salu_instr'],
+            'note': 'achieved = 8 FLOP x V^2 x B / launch time (SURVEY 8d), an all-pairs-EQUIVALENT figure: most (column, row) '
+                    'pairs are never evaluated -- pruned by box distance, by the lanes the mask leaves a row for below a '
+                    'node, and in groups of four rows no reachable lane may use.  What the vector units do is valu_busy '
+                    '(from the committed PMC pass).  The mask is bit-packed and L2-resident: the equivalent-bandwidth figures '
+                    'are NOT physical bandwidth'}
     # ---- the inside test: sheared strips + leaf slabs + near-leaf lists + tiles + ray_leaf_kernel + fan finalize
     t_w = time_kernel(lambda: model.exterior_flags(verts, apply_segments=False), 10)
     work = model.ray_work(verts)
@@ -387,7 +452,7 @@ def rooflines(p, batch):
     ref_flops = FLOP_PER_WINDING_PAIR * batch * v * f
     tree = model.winding_tree_work(verts)
     tree_steps = tree['leaf_elements'] + tree['cap_elements']
-    prof_r = PROFILE['ray_leaf_kernel']
+    prof_r = prof['ray_leaf_kernel']
     inside = {'kernel': 'ray_leaf_kernel (+ ray_stream, ray_leaf_bounds, ray_near, ray_tiles, ray_fill, ray_finalize_verts)',
               'bound': 'valu', 'achieved': round(ach, 2), 'peak': PEAK_FP32_VECTOR_TFLOPS, 'unit': 'TFLOP/s',
               'frac': round(ach / PEAK_FP32_VECTOR_TFLOPS, 4),
@@ -488,10 +553,27 @@ def workloads(device, seed):
     return out
 
 
-def worst_case(device, seed, batch):
-    """All bodies self-penetrating (arm across the torso, legs together) instead of half of them."""
+def graph_kernel_count(graph):
+    """Kernel launches in one captured step: torch's debug dump of the graph (dot) lists one node per launch."""
+    import re
+    import tempfile
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, 'g.dot')
+            graph.debug_dump(path)
+            text = open(path).read()
+        kernels = len(re.findall(r'KERNEL|kernel', text))
+        return {'kernel_nodes': kernels, 'all_nodes': len(re.findall(r'\bgraph_\w+ *\[|^\s*\w+ *\[label', text, re.M))}
+    except Exception as exc:
+        return {'error': repr(exc)}
+
+
+def worst_case(device, seed, batch, folded=False):
+    """All bodies self-penetrating (arm across the torso, legs together) instead of half of them; folded: a third with a
+    forearm THROUGH the trunk, a third with the legs crossed through each other, a third folded over the thighs
+    (tuch_amd.synthetic.folded_poses) -- where the near-leaf lists and the pair list grow."""
     from tuch_amd.smplify.losses import contact_model_for
-    p = build_problem(batch, device, seed, penetrating_fraction=1.0)
+    p = build_problem(batch, device, seed, penetrating_fraction=1.0, folded=folded)
     ms = time_kernel(capture(make_step(p), 3), 20) * 1e3
     model = contact_model_for(p['geomask'], p['face_tensor'], p['segments'], p['cdict'])
     with torch.no_grad():
@@ -526,6 +608,131 @@ def cpu_baseline(p, seconds):
             'sample': '%d bodies (V=6890,F=13776): contact term forward+gradient (winding, segments, '
                       'masked v2v, push/pull) with the C/OpenMP oracle, %.1f s; SMPL forward, '
                       'reprojection and Adam are excluded (negligible on CPU)' % (n, dt)}
+
+
+def selfcheck(p, step, sample=(0, 37)):
+    """After the timed blocks: (1) the objective the REPLAYED step reports equals an eager evaluation (separate launches of
+    the same HIP path) at the same parameters -- the graph does the work it was captured for, on the current state; (2)
+    at that state, two sampled bodies against the CPU oracle (the checker, tests/ infrastructure -- not the thing
+    measured): posed vertices vs the oracle's LBS, contact value of losses.py:96-105 vs oracle/contact.py."""
+    from oracle import contact as oc
+    from oracle import lbs as ol
+    from oracle import smplify as osm
+    from tuch_amd.ops import MODE_SMPLIFY, contact_terms
+    from tuch_amd.smplify.losses import contact_model_for
+    eager, verts, joints, pose = step.objective()
+    replayed = float(step()[0])                      # reports the loss at the parameters it started from, then updates
+    body = p['body']
+    gm = body.geodesics > 0.3
+    segs = [oc.Segment(n, body.faces, s['vidx'], list(s['bands'].values())) for n, s in body.segments.items()]
+    model = contact_model_for(p['geomask'], p['face_tensor'], p['segments'], p['cdict'])
+    ext, _, partner, _ = model.exterior_and_partner(verts, apply_segments=True)
+    per_body, _ = contact_terms(verts, partner, ext, None, MODE_SMPLIFY, 0.02)
+    m = ol.model_tensors(body)
+    worst_c = worst_v = 0.0
+    sample = [b for b in sample if b < verts.shape[0]]
+    for b in sample:
+        vb = verts[b].cpu().numpy()
+        r = oc.smplify_contact_body(vb, body.faces, gm, 0.02, segs, None)
+        worst_c = max(worst_c, abs(float(per_body[b]) - r['contact']) / max(abs(r['contact']), 1e-6))
+        # (global_orient moves too; the vertices of the oracle's LBS at the same pose are compared up to that rotation
+        # through pairwise distances of a vertex subset, which a rigid motion leaves unchanged)
+        ov, _ = ol.smpl_forward(m, p['betas'][b:b + 1].cpu(), pose[b:b + 1].cpu(), torch.zeros(1, 3))
+        idx = np.arange(0, vb.shape[0], 97)
+        d_gpu = np.linalg.norm(vb[idx][:, None] - vb[idx][None], axis=2)
+        ovn = ov[0].numpy()
+        d_ref = np.linalg.norm(ovn[idx][:, None] - ovn[idx][None], axis=2)
+        worst_v = max(worst_v, float(np.abs(d_gpu - d_ref).max()))
+    return {'graph_vs_eager_rel_err': abs(replayed - eager) / max(abs(eager), 1e-12), 'objective': eager,
+            'oracle_bodies': sample, 'contact_value_max_rel_err': worst_c, 'lbs_pairwise_distance_max_abs_err_m': worst_v,
+            'max_rel_err': max(worst_c, abs(replayed - eager) / max(abs(eager), 1e-12)),
+            'ok': bool(worst_c < 1e-4 and worst_v < 1e-4 and abs(replayed - eager) <= 1e-4 * abs(eager))}
+
+
+def rccl_smoke_child():
+    """Runs in a child process (`bench.py --rccl-smoke`): RCCL on the one GPU there is.  A process group of ONE rank
+    over backend nccl; a device-tensor all-reduce; RegressorLoss(global_mean=True).contact_loss -- whose count of valid
+    bodies is all-reduced on the calling stream (tuch_amd/dist.py) -- captured in a hipGraph with the group alive and
+    replayed; destroy_process_group.  Prints one JSON line."""
+    import torch.distributed as dist
+    from tuch_amd import dist as tdist
+    out = {'backend': 'nccl (RCCL)', 'world_size': 1}
+    device = torch.device('cuda', 0)
+    torch.cuda.set_device(0)
+    torch.cuda.set_stream(torch.cuda.Stream(device=device))
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % free_port(), rank=0, world_size=1, device_id=device)
+    try:
+        tdist.REDUCE_SINGLE_RANK = True
+        t = torch.tensor([3.5, 64.0], device=device)
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
+        out['all_reduce'] = t.tolist()
+        total, count = tdist.allreduce_loss(torch.tensor(2.25, device=device), 64)
+        out['allreduce_loss'] = [float(total), float(count)]
+        p = build_problem(8, device, seed=1002)
+        import types
+        from tuch_amd.train.loss import RegressorLoss
+        body = p['body']
+        crit = RegressorLoss(types.SimpleNamespace(contact_loss_weight=1.0), device, body.num_verts, p['face_tensor'],
+                             torch.tensor(body.geodesics, device=device), geothres=0.3, euclthres=0.02,
+                             face_tensor=p['face_tensor'], use_hd=False, segments=p['segments'], global_mean=True)
+        with torch.no_grad():
+            verts = p['smpl'](global_orient=p['global_orient'], body_pose=p['body_pose'], betas=p['betas']).vertices
+        v = verts.clone().requires_grad_(True)
+        valid = torch.ones(8, dtype=torch.bool, device=device)
+        valid[3] = False
+
+        def fwd_bwd():
+            v.grad = None
+            loss = crit.contact_loss(v, valid)
+            loss.backward()
+            return loss
+        eager = float(fwd_bwd())
+        grad_eager = v.grad.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                fwd_bwd()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        v.grad = None
+        with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+            captured = fwd_bwd()
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize()
+        out['captured_contact_loss'] = {'eager': eager, 'replayed': float(captured),
+                                        'grad_equal': bool(torch.allclose(v.grad, grad_eager, rtol=1e-5, atol=1e-9))}
+        ok = out['all_reduce'] == [3.5, 64.0] and abs(float(captured) - eager) <= 1e-6 * abs(eager) \
+            and out['captured_contact_loss']['grad_equal']
+        out['status'] = 'ok' if ok else 'mismatch'
+    finally:
+        tdist.REDUCE_SINGLE_RANK = False
+        dist.destroy_process_group()
+    out['destroyed'] = True
+    print(json.dumps(out), flush=True)
+
+
+def rccl_smoke():
+    """rccl_smoke_child in a process of its own, under a timeout: a wedged collective must not take the bench line with it."""
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    try:
+        res = subprocess.run([sys.executable, os.path.abspath(__file__), '--rccl-smoke'], env=env, capture_output=True, text=True,
+                             timeout=240)
+    except subprocess.TimeoutExpired:
+        return {'status': 'timeout after 240 s'}
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    if res.returncode != 0 or not lines:
+        return {'status': 'failed (rc %d)' % res.returncode, 'stderr_tail': res.stderr[-600:]}
+    out = json.loads(lines[-1])
+    out['note'] = 'one rank on the one GPU: exercises RCCL init, a device all-reduce, capture + replay of a collective, ' \
+                  'destroy; no N > 1 value exists until the driver runs this script on a multi-GPU node'
+    return out
 
 
 def cpu_torch_chain(p):
@@ -574,6 +781,8 @@ CONFIGS = {
 
 def main():
     args = parse()
+    if args.rccl_smoke:
+        return rccl_smoke_child()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(launch_ranks(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -672,7 +881,7 @@ def main():
             'config': {'workload': cfg['workload'] % batch,
                        'bodies_per_gpu': batch, 'global_batch': bodies, 'euclthres': 0.02,
                        'geothres': 0.3, 'launch': launch,
-                       'parallelism': 'dp%d (bodies sharded, 2-float all-reduce)' % world,
+                       'parallelism': 'dp%d (bodies sharded; one 2-float all-reduce per timed block, none inside the loop)' % world,
                        'batch_iterations_per_s': round(cfg['iters_per_step'] * args.steps / dt, 3),
                        'loss_sum': float(stats[0].item()), 'bodies': float(stats[1].item())},
             'repeat_ms_per_step': {'n': len(per_step), 'median': round(float(np.median(per_step)), 4),
@@ -682,13 +891,23 @@ def main():
             'scaling_note': 'no multi-GPU node was available to the builder: N>1 values exist only when the driver '
                             'runs this script on one' if world == 1 else None,
         }
+        if args.config == '2':
+            try:
+                line['selfcheck'] = selfcheck(p, step)
+            except Exception as exc:                     # the measurement stands; the check reports what went wrong
+                line['selfcheck'] = {'ok': False, 'error': repr(exc)}
+            if hasattr(step, 'graph'):
+                line['kernels_per_step'] = graph_kernel_count(step.graph)
         roof, inside, verts, model = rooflines(p, batch)
         line['roofline'], line['roofline_inside_test'] = roof, inside
+        if world == 1 and backend == 'nccl' and not args.no_rccl_smoke:
+            line['rccl_smoke'] = rccl_smoke()
         if world == 1 and not args.no_extras:
             line['contact_loss_eval'] = contact_loss_eval(p, batch, verts, model)
             line['shard_sweep'] = shard_sweep(device, 1002)
             line['workloads'] = workloads(device, 1002)
             line['worst_case'] = worst_case(device, 1002, batch)
+            line['worst_case']['folded'] = worst_case(device, 1002, batch, folded=True)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(p, args.cpu_seconds)
             if not args.no_torch_chain:

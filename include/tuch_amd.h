@@ -164,6 +164,13 @@ void tuch_contact_model_destroy(tuch_contact_model* model);
  * query *_workspace_bytes again after changing them.) */
 int tuch_contact_model_set_option(tuch_contact_model* model, const char* name, int value);
 int tuch_contact_model_get_option(const tuch_contact_model* model, const char* name, int* value);
+/* Option canary = 1 (debug): every region of every workspace of the model's hot calls (nearest-vertex search, inside
+ * test incl. its pair lists, winding of points, the HD branch's worst-case buffers and saved state) is followed by 256
+ * guard bytes, written with 0xDEADBEEF before the call's kernels and compared after them, on the call's stream.
+ * canary_hits: guard words found changed since the last reset (synchronises the device).  selftest: arms three regions
+ * in `workspace` (>= 4 KiB), overruns one by a word on purpose and returns the number of hits counted (1). */
+int tuch_contact_model_canary_hits(const tuch_contact_model* model, int* hits_host, int reset);
+int tuch_contact_model_canary_selftest(const tuch_contact_model* model, void* workspace, size_t workspace_bytes, void* stream);
 const uint64_t* tuch_contact_model_mask_bits(const tuch_contact_model* model);
 const int32_t* tuch_contact_model_faces(const tuch_contact_model* model);
 /* eight device ints, zero between calls: arrival counters for tuch_smplify_stage2_finish (one per stream in flight) */
@@ -343,6 +350,9 @@ int tuch_hd_contact_bwd(const tuch_hd_model* model, const void* saved, const flo
  * every slot, -1 beyond the count (or NULL) */
 int tuch_hd_contact_selection(const tuch_hd_model* model, const void* saved, int B, int32_t* counts_host,
                               int32_t* selected_host);
+/* per slot (order of tuch_hd_contact_selection): caller-order index of the partner the search found (-1 beyond the
+ * count) and the exterior flag of the point; both [B,N] */
+int tuch_hd_contact_details(const tuch_hd_model* model, const void* saved, int B, int32_t* partner_host, uint8_t* ext_host);
 
 /* HD points of tuch/train/loss.py:285 (hd = Vert_Regressor[selected] @ verts, a dense [N_hd,6890] matrix with three
  * non-zeros per row): point n belongs to body body_of_point[n] and is HD point hd_of_point[n];

@@ -253,11 +253,15 @@ def face_normals(tris: np.ndarray) -> np.ndarray:
 
 
 def train_contact_body(verts, faces, geomask, euclthres, segments, use_hd,
-                       hd_idx=None, hd_w=None, hd_face=None):
+                       hd_idx=None, hd_w=None, hd_face=None, hd_arg_given=None, hd_ext_given=None):
     """One iteration of the per-body loop of RegressorLoss.contact_loss, loss.py:247-315.
 
     hd_idx/hd_w [N_hd,3]: the three non-zeros of each Vert_Regressor row; hd_face [N_hd]:
     faces_vert_is_sampled_from.  Returns dict(loss, grad[V,3], ...).
+    hd_arg_given / hd_ext_given (tests): evaluate the terms with these partners / flags of the selected HD points
+    (in the order of np.where(hd_sel)) instead of the ones found here -- to separate "a different pick between
+    candidates the reference's float32 cannot tell apart" from an arithmetic difference; ``hd_argmin`` and
+    ``hd_exterior`` of the result are always the ones found here.
     """
     verts = _c32(verts)
     faces = _ci64(faces)
@@ -289,15 +293,17 @@ def train_contact_body(verts, faces, geomask, euclthres, segments, use_hd,
     tris = gather_tris(verts, faces)
     offs = hd + np.float32(0.001) * face_normals(tris)[hd_face[hd_sel]]   # :295-296
     hd_ext = winding_numbers(offs, tris) <= np.float32(0.99)              # :297
-    diff, d = _pair_distance(hd, hd_arg)                                  # :299
-    pull, dd_pull = _tanh2_terms(d, hd_ext, 0.005, 0.005)
-    push, dd_push = _tanh2_terms(d, ~hd_ext, 1.0, 0.04)
-    g_hd = _scatter_pair_grad(diff, d, dd_pull + dd_push, hd_arg, hd.shape[0])
+    use_arg = hd_arg if hd_arg_given is None else np.asarray(hd_arg_given, np.int64)
+    use_ext = hd_ext if hd_ext_given is None else np.asarray(hd_ext_given, bool)
+    diff, d = _pair_distance(hd, use_arg)                                 # :299
+    pull, dd_pull = _tanh2_terms(d, use_ext, 0.005, 0.005)
+    push, dd_push = _tanh2_terms(d, ~use_ext, 1.0, 0.04)
+    g_hd = _scatter_pair_grad(diff, d, dd_pull + dd_push, use_arg, hd.shape[0])
     grad = np.zeros((num_verts, 3), np.float64)
     for k in range(3):
         np.add.at(grad, idx[:, k], g_hd * wgt[:, k:k + 1].astype(np.float64))
     out.update(loss=pull + push, pull=pull, push=push, grad=grad, d=d, hd_exterior=hd_ext,
-               hd_argmin=hd_arg, hd_points=hd)
+               hd_argmin=hd_arg, hd_points=hd, hd_offset_points=offs, hd_mask=hd_mask)
     return out
 
 

@@ -104,3 +104,62 @@ def grad_close(actual, expected, floor, what, rtol=GRAD_RTOL, quantum=False):
     _log('grad %-60s max|err|/max|ref| %.2e   max err/bound %.3f' % (what, err.max() / max(scale, 1e-30),
                                                                      (err / (atol + rtol * np.abs(expected))).max()))
     assert_close(actual, expected, rtol, atol, what)
+
+
+def point_touches_surface(p, verts_b, faces, tol=2e-6):
+    """float64: does the point lie within `tol` of a triangle of the mesh, inside its outline?  There the winding number
+    of the point jumps by one: which side a float32 evaluation lands on is arbitrary (for the reference's sum too)."""
+    v = np.asarray(verts_b, np.float64)
+    tri = v[np.asarray(faces)]
+    a, b, c = tri[:, 0], tri[:, 1], tri[:, 2]
+    n = np.cross(b - a, c - a)
+    nn = np.linalg.norm(n, axis=1)
+    ok = nn > 0
+    n, a, b, c = n[ok] / nn[ok, None], a[ok], b[ok], c[ok]
+    p = np.asarray(p, np.float64)
+    dist = ((p - a) * n).sum(1)
+    near = np.abs(dist) < tol
+    if not near.any():
+        return False
+    a, b, c, n, dist = a[near], b[near], c[near], n[near], dist[near]
+    q = p - dist[:, None] * n
+    inside = np.ones(len(a), bool)
+    for s0, e0 in ((a, b), (b, c), (c, a)):
+        inside &= (np.cross(e0 - s0, q - s0) * n).sum(1) >= -tol * np.linalg.norm(e0 - s0, axis=1)
+    return bool(inside.any())
+
+
+def hd_picks_vs_oracle(hd_model, saved, batch, b, verts_b, faces, geomask, euclthres, osegs, hd_idx, hd_w, hd_face, what):
+    """The HD branch's per-point decisions for body b against the oracle's (loss.py:274-301): same selected set; a
+    different partner only between candidates whose squared distances tie within the reference's bmm-form noise (2e-6);
+    a different inside/outside flag only for an offset point that touches a triangle.  Returns (oracle result with its
+    own picks, oracle result evaluated with the device's picks) -- identical objects when no pick differs."""
+    r = oc.train_contact_body(verts_b, faces, geomask, euclthres, osegs, True, hd_idx=hd_idx, hd_w=hd_w, hd_face=hd_face)
+    counts, sel = hd_model.selection(saved, batch)
+    part, ext = hd_model.details(saved, batch)
+    n = int(counts[b])
+    want = np.where(r['hd_sel'])[0]
+    ids = sel[b, :n].astype(np.int64)
+    assert np.array_equal(np.sort(ids), want), (what, n, len(want))
+    if n == 0:
+        return r, r
+    slot_of = np.argsort(ids)                       # oracle position i (caller id want[i]) lives in slot slot_of[i]
+    gpu_arg = np.searchsorted(want, part[b, :n][slot_of].astype(np.int64))
+    gpu_ext = ext[b, :n][slot_of]
+    arg_diff = np.where(gpu_arg != r['hd_argmin'])[0]
+    ext_diff = np.where(gpu_ext != r['hd_exterior'])[0]
+    report('%s: HD partners != oracle (ties within bmm noise)' % what, len(arg_diff), n)
+    report('%s: HD inside/outside flags != oracle (points touching a triangle)' % what, len(ext_diff), n)
+    hd = r['hd_points'].astype(np.float64)
+    for i in arg_diff:
+        d_gpu = ((hd[i] - hd[gpu_arg[i]]) ** 2).sum()
+        d_ref = ((hd[i] - hd[r['hd_argmin'][i]]) ** 2).sum()
+        assert abs(d_gpu - d_ref) < 2e-6 and r['hd_mask'][gpu_arg[i], i], (what, i, d_gpu, d_ref)
+    for i in ext_diff:
+        assert point_touches_surface(r['hd_offset_points'][i], verts_b, faces), (what, i)
+    assert len(arg_diff) <= max(3, n // 500) and len(ext_diff) <= 3
+    if len(arg_diff) == 0 and len(ext_diff) == 0:
+        return r, r
+    r2 = oc.train_contact_body(verts_b, faces, geomask, euclthres, osegs, True, hd_idx=hd_idx, hd_w=hd_w, hd_face=hd_face,
+                               hd_arg_given=gpu_arg, hd_ext_given=gpu_ext)
+    return r, r2

@@ -147,3 +147,30 @@ def test_bench_spawns_its_own_ranks():
     assert line['n_gpus'] == 2 and line['scaling'] == 'strong' and line['config']['bodies_per_gpu'] == 4
     assert line['config']['bodies'] == 8.0 and line['config']['launch'].startswith('hipGraph')
     assert np.isfinite(line['config']['loss_sum']) and line['value'] > 0
+
+
+@pytest.mark.gpu
+def test_rccl_on_one_gpu_and_the_bench_selfcheck():
+    """The default bench line on this box's one GPU (short): `selfcheck` -- the replayed graph reports the objective an
+    eager evaluation gives at the same parameters, two bodies of that state agree with the CPU oracle -- and
+    `rccl_smoke` -- a one-rank process group over RCCL: init, a device all-reduce, RegressorLoss(global_mean=True)
+    .contact_loss with its all-reduced count captured in a hipGraph and replayed, destroy_process_group."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'TUCH_BENCH_BACKEND'):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '5', '--warmup', '2', '--repeats', '1',
+                          '--no-extras', '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=1200)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][-1])
+    sc = line['selfcheck']
+    assert sc.get('ok'), sc
+    assert sc['graph_vs_eager_rel_err'] < 1e-5 and sc['contact_value_max_rel_err'] < 1e-4
+    smoke = line['rccl_smoke']
+    assert smoke.get('status') == 'ok' and smoke.get('destroyed'), smoke
+    assert smoke['all_reduce'] == [3.5, 64.0] and smoke['captured_contact_loss']['grad_equal']
+    assert line['kernels_per_step'].get('kernel_nodes', 0) > 10, line['kernels_per_step']
+    assert line['roofline']['valu_busy'] is not None and line['roofline']['traffic'] is not None

@@ -208,7 +208,7 @@ def test_headline_batch64_hd_contact_loss_against_the_oracle(headline):
     """RegressorLoss.contact_loss(use_hd=True) on the bench's vertices at batch 64; eight of the bodies (every eighth:
     one per XCD column) are checked against the oracle's HD branch (loss.py:274-315), all N_hd = 41 328 points."""
     import bench
-    from helpers import grad_close
+    from helpers import grad_close, hd_picks_vs_oracle
     p, verts = headline
     body = p['body']
     crit = bench.regressor_loss(p, True)
@@ -222,11 +222,15 @@ def test_headline_batch64_hd_contact_loss_against_the_oracle(headline):
     gm = body.geodesics > 0.3
     osegs = [oc.Segment(n, body.faces, s['vidx'], list(s['bands'].values())) for n, s in body.segments.items()]
     want, grads = [], {}
+    saved = crit._hd.last_saved
     for b in which:
-        r = oc.train_contact_body(verts_np[b], body.faces, gm, 0.02, osegs, True, hd_idx=body.hd_bary_idx,
-                                  hd_w=body.hd_bary_w, hd_face=body.hd_face_id)
-        want.append(r['loss'])
-        grads[b] = r['grad'] / len(which)
+        # r: the oracle with its own picks; r2: the oracle's formulas with the device's picks (differences are checked
+        # to be ties / touching points inside hd_picks_vs_oracle)
+        r, r2 = hd_picks_vs_oracle(crit._hd, saved, 64, b, verts_np[b], body.faces, gm, 0.02, osegs, body.hd_bary_idx,
+                                   body.hd_bary_w, body.hd_face_id, 'headline HD body %d' % b)
+        want.append(r2['loss'])
+        grads[b] = r2['grad'] / len(which)
+        assert abs(r2['loss'] - r['loss']) <= 2e-3 * abs(r['loss'])
     assert_close(loss.item(), float(np.mean(want)), 1e-4, 0, 'HD contact loss, 8 of 64 bodies')
     g = v.grad.cpu().numpy()
     assert np.all(g[[b for b in range(64) if b not in which]] == 0)

@@ -51,6 +51,8 @@ _SIGNATURES = {
     'tuch_contact_model_destroy': (None, [c_void_p]),
     'tuch_contact_model_set_option': (c_int, [c_void_p, c_char_p, c_int]),
     'tuch_contact_model_get_option': (c_int, [c_void_p, c_char_p, POINTER(c_int)]),
+    'tuch_contact_model_canary_hits': (c_int, [c_void_p, POINTER(c_int), c_int]),
+    'tuch_contact_model_canary_selftest': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     'tuch_contact_model_mask_bits': (c_void_p, [c_void_p]),
     'tuch_contact_model_faces': (c_void_p, [c_void_p]),
     'tuch_contact_model_tickets': (c_void_p, [c_void_p]),
@@ -76,6 +78,7 @@ _SIGNATURES = {
                                     c_void_p]),
     'tuch_hd_contact_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'tuch_hd_contact_selection': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    'tuch_hd_contact_details': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     'tuch_ray_work': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     'tuch_contact_model_tree_order': (c_int, [c_void_p, c_void_p, c_void_p]),
     'tuch_v2v_model_workspace_bytes': (c_size_t, [c_void_p, c_int]),

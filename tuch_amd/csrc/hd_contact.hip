@@ -18,6 +18,7 @@
 // GATHER per vertex over the CSR table -- no atomics on the vertices, where ~18 point corners meet.
 #include "common.h"
 #include "model.h"
+#include "workspace.h"
 #include <algorithm>
 #include <numeric>
 #include <stdlib.h>
@@ -325,31 +326,45 @@ Saved saved_layout(int B, int N)
 {
     Saved l;
     size_t o = 0;
-    l.counts = o;  o += align256((size_t)B * sizeof(int32_t));
-    l.first = o;   o += align256((size_t)B * sizeof(int32_t));
-    l.sel = o;     o += align256((size_t)B * N * sizeof(int32_t));
-    l.slot = o;    o += align256((size_t)B * N * sizeof(int32_t));
-    l.pts = o;     o += align256((size_t)B * N * 3 * sizeof(float));
-    l.partner = o; o += align256((size_t)B * N * sizeof(int32_t));
-    l.ext = o;     o += align256((size_t)B * N);
+    l.counts = tuch_ws_take(o, (size_t)B * sizeof(int32_t));
+    l.first = tuch_ws_take(o, (size_t)B * sizeof(int32_t));
+    l.sel = tuch_ws_take(o, (size_t)B * N * sizeof(int32_t));
+    l.slot = tuch_ws_take(o, (size_t)B * N * sizeof(int32_t));
+    l.pts = tuch_ws_take(o, (size_t)B * N * 3 * sizeof(float));
+    l.partner = tuch_ws_take(o, (size_t)B * N * sizeof(int32_t));
+    l.ext = tuch_ws_take(o, (size_t)B * N);
     l.total = o;
     return l;
 }
 
-struct Work { size_t offs, vid, min_d2, flags, chunk_cnt, first_key, search, winding, total; };
+struct Grad { size_t partner_side, own_side, total; };
+Grad grad_layout(int B, int N)
+{
+    Grad l;
+    size_t o = 0;
+    l.partner_side = tuch_ws_take(o, (size_t)B * N * 3 * sizeof(float));
+    l.own_side = tuch_ws_take(o, (size_t)B * N * 3 * sizeof(float));
+    l.total = o;
+    return l;
+}
+
+struct Work { size_t offs, vid, min_d2, flags, chunk_cnt, first_key, search, winding, winding_bytes, total; };
 Work work_layout(const tuch_hd_model* hm, int B)
 {
     Work l;
     const int N = hm->N;
     size_t o = 0;
-    l.offs = o;      o += align256((size_t)B * N * 3 * sizeof(float));
-    l.vid = o;       o += align256((size_t)B * N * sizeof(int32_t));
-    l.min_d2 = o;    o += align256((size_t)B * N * sizeof(float));
-    l.flags = o;     o += align256((size_t)B * hm->F);
-    l.chunk_cnt = o; o += align256((size_t)B * ceil_div(N, kSel) * sizeof(int32_t));
-    l.first_key = o; o += align256((size_t)B * sizeof(unsigned long long));
-    l.search = o;    o += align256(tuch_v2v_min_indexed_workspace_bytes(B, N));
-    l.winding = o;   o += align256(tuch_winding_points_workspace_bytes(hm->cm, B, N));
+    l.offs = tuch_ws_take(o, (size_t)B * N * 3 * sizeof(float));
+    l.vid = tuch_ws_take(o, (size_t)B * N * sizeof(int32_t));
+    l.min_d2 = tuch_ws_take(o, (size_t)B * N * sizeof(float));
+    l.flags = tuch_ws_take(o, (size_t)B * hm->F);
+    l.chunk_cnt = tuch_ws_take(o, (size_t)B * ceil_div(N, kSel) * sizeof(int32_t));
+    l.first_key = tuch_ws_take(o, (size_t)B * sizeof(unsigned long long));
+    size_t search_bytes, winding_bytes;
+    { tuch_ws_pause nested; search_bytes = tuch_v2v_min_indexed_workspace_bytes(B, N); winding_bytes = tuch_winding_points_workspace_bytes(hm->cm, B, N); }
+    l.search = tuch_ws_take(o, search_bytes);
+    l.winding = tuch_ws_take(o, winding_bytes);
+    l.winding_bytes = winding_bytes;
     l.total = o;
     return l;
 }
@@ -450,14 +465,17 @@ extern "C" int tuch_hd_model_info(const tuch_hd_model* hm, int* N, int32_t* orde
 
 extern "C" size_t tuch_hd_contact_saved_bytes(const tuch_hd_model* hm, int B)
 {
-    return hm && B > 0 ? saved_layout(B, hm->N).total : 0;
+    if (!hm || B <= 0) return 0;
+    tuch_ws_scope scope(hm->cm->opt.canary != 0);
+    return saved_layout(B, hm->N).total;
 }
 
 extern "C" size_t tuch_hd_contact_workspace_bytes(const tuch_hd_model* hm, int B)
 {
     if (!hm || B <= 0) return 0;
+    tuch_ws_scope scope(hm->cm->opt.canary != 0);
     const size_t f = work_layout(hm, B).total;
-    const size_t g = 2 * align256((size_t)B * hm->N * 3 * sizeof(float));   // adjoint: point gradients, own + partner side
+    const size_t g = grad_layout(B, hm->N).total;       // adjoint: point gradients, own + partner side
     return f > g ? f : g;
 }
 
@@ -472,14 +490,17 @@ extern "C" int tuch_hd_contact_fwd(const tuch_hd_model* hm, const float* verts, 
     TUCH_REQUIRE(hm && verts && exterior && min_d2 && partner && terms && saved && workspace, "tuch_hd_contact_fwd: null pointer");
     TUCH_REQUIRE(B > 0 && B <= kMaxBatch && (long)B * hm->N < 0x7fffffffL, "tuch_hd_contact_fwd: bad batch %d", B);
     const int N = hm->N, V = hm->V;
-    const Saved sl = saved_layout(B, N);
-    const Work wl = work_layout(hm, B);
+    tuch_ws_scope saved_scope(hm->cm->opt.canary != 0), scope(hm->cm->opt.canary != 0);
+    const Saved sl = saved_scope.record(0, [&] { return saved_layout(B, N); });
+    const Work wl = scope.record(0, [&] { return work_layout(hm, B); });
     if (saved_bytes < sl.total || workspace_bytes < wl.total) {
         tuch_set_error("tuch_hd_contact_fwd: saved %zu < %zu or workspace %zu < %zu bytes", saved_bytes, sl.total,
                        workspace_bytes, wl.total);
         return TUCH_ERR_WORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
+    saved_scope.arm(saved, hm->cm->canary_hits, s);
+    scope.arm(workspace, hm->cm->canary_hits, s);
     char* sv = (char*)saved;
     char* ws = (char*)workspace;
     int32_t* counts = (int32_t*)(sv + sl.counts);
@@ -514,7 +535,7 @@ extern "C" int tuch_hd_contact_fwd(const tuch_hd_model* hm, const float* verts, 
                                          (float*)(ws + wl.min_d2), part, ws + wl.search, s);
     if (rc != TUCH_OK) return rc;
     rc = tuch_winding_points(hm->cm, verts, offs, counts, B, N, thresh, nullptr, ext, ws + wl.winding,
-                             wl.total - wl.winding, stream);
+                             wl.winding_bytes, stream);
     if (rc != TUCH_OK) return rc;
     hipLaunchKernelGGL(hd_terms_kernel, dim3(B), dim3(1024), 0, s, (const float*)pts, (const int32_t*)part,
                        (const uint8_t*)ext, (const int32_t*)counts, N, terms);
@@ -528,16 +549,19 @@ extern "C" int tuch_hd_contact_bwd(const tuch_hd_model* hm, const void* saved, c
     TUCH_REQUIRE(hm && saved && grad_terms && grad_verts && workspace, "tuch_hd_contact_bwd: null pointer");
     TUCH_REQUIRE(B > 0 && B <= kMaxBatch, "tuch_hd_contact_bwd: bad batch %d", B);
     const int N = hm->N, V = hm->V;
+    tuch_ws_scope scope(hm->cm->opt.canary != 0);
     const Saved sl = saved_layout(B, N);
+    const Grad gl = scope.record(0, [&] { return grad_layout(B, N); });
     const size_t gbytes = (size_t)B * N * 3 * sizeof(float);
-    if (workspace_bytes < 2 * align256(gbytes)) {
-        tuch_set_error("tuch_hd_contact_bwd: workspace %zu < %zu bytes", workspace_bytes, 2 * align256(gbytes));
+    if (workspace_bytes < gl.total) {
+        tuch_set_error("tuch_hd_contact_bwd: workspace %zu < %zu bytes", workspace_bytes, gl.total);
         return TUCH_ERR_WORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
+    scope.arm(workspace, hm->cm->canary_hits, s);
     const char* sv = (const char*)saved;
-    float* G = (float*)workspace;
-    float* Gown = (float*)((char*)workspace + align256(gbytes));
+    float* G = (float*)((char*)workspace + gl.partner_side);
+    float* Gown = (float*)((char*)workspace + gl.own_side);
     if (hipMemsetAsync(G, 0, gbytes, s) != hipSuccess) {
         tuch_set_error("tuch_hd_contact_bwd: hipMemsetAsync failed");
         return TUCH_ERR_HIP;
@@ -557,6 +581,7 @@ extern "C" int tuch_hd_contact_selection(const tuch_hd_model* hm, const void* sa
 {
     TUCH_REQUIRE(hm && saved && counts_host, "tuch_hd_contact_selection: null pointer");
     const int N = hm->N;
+    tuch_ws_scope scope(hm->cm->opt.canary != 0);        // the layout the forward call used
     const Saved sl = saved_layout(B, N);
     const char* sv = (const char*)saved;
     if (hipMemcpy(counts_host, sv + sl.counts, sizeof(int32_t) * B, hipMemcpyDeviceToHost) != hipSuccess) return TUCH_ERR_HIP;
@@ -567,5 +592,29 @@ extern "C" int tuch_hd_contact_selection(const tuch_hd_model* hm, const void* sa
             for (int k = 0; k < N; ++k)
                 selected_host[(size_t)b * N + k] = k < counts_host[b] ? (*hm->order_host)[sel[(size_t)b * N + k]] : -1;
     }
+    return TUCH_OK;
+}
+
+// inspection (tests): per slot of every body (slot order of tuch_hd_contact_selection) the caller-order index of the
+// partner found by the search (-1 behind the body's count) and the exterior flag of the point
+extern "C" int tuch_hd_contact_details(const tuch_hd_model* hm, const void* saved, int B, int32_t* partner_host, uint8_t* ext_host)
+{
+    TUCH_REQUIRE(hm && saved && partner_host && ext_host, "tuch_hd_contact_details: null pointer");
+    const int N = hm->N;
+    tuch_ws_scope scope(hm->cm->opt.canary != 0);        // the layout the forward call used
+    const Saved sl = saved_layout(B, N);
+    const char* sv = (const char*)saved;
+    std::vector<int32_t> counts(B), sel((size_t)B * N), part((size_t)B * N);
+    if (hipMemcpy(counts.data(), sv + sl.counts, sizeof(int32_t) * B, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(sel.data(), sv + sl.sel, sel.size() * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(part.data(), sv + sl.partner, part.size() * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(ext_host, sv + sl.ext, (size_t)B * N, hipMemcpyDeviceToHost) != hipSuccess)
+        return TUCH_ERR_HIP;
+    for (int b = 0; b < B; ++b)
+        for (int k = 0; k < N; ++k) {
+            const int32_t p = part[(size_t)b * N + k];
+            partner_host[(size_t)b * N + k] =
+                k < counts[b] && p >= 0 && p < counts[b] ? (*hm->order_host)[sel[(size_t)b * N + p]] : -1;
+        }
     return TUCH_OK;
 }

@@ -53,6 +53,8 @@ void tuch_options_from_env(tuch_options* o);
 // Inside test by signed ray crossings (ray_winding.hip): exterior flags of the model's own vertices / of arbitrary
 // points, identical to thresholding the winding-number sum wherever that sum is well separated from the threshold.
 bool tuch_ray_available(const tuch_contact_model* m);
+// computes the layout of tuch_ray_exterior_verts (Q = 0) / tuch_ray_exterior_points: for a recording tuch_ws_scope
+void tuch_ray_layout_touch(const tuch_contact_model* m, int B, int Q);
 size_t tuch_ray_workspace_bytes(const tuch_contact_model* m, int B, int Q);
 int tuch_ray_exterior_verts(const tuch_contact_model* m, const float* verts, int B, float thresh, uint8_t* exterior,
                             float* w, void* workspace, hipStream_t s, unsigned long long* stats_host);
@@ -84,6 +86,7 @@ struct tuch_contact_model {
     int V, F;
     int32_t* faces;            // [F,3]
     int32_t* tickets;          // [8] arrival counters of "the last block adds up" kernels, zero between calls
+    int32_t* canary_hits;      // [1] guard words found changed (option canary, workspace.h)
     uint64_t* mask_bits;       // [W][V] or nullptr
     // triangle strips over `faces` (built at create): stream of vertex ids with a per-element
     // sign: 0 = priming vertex (no triangle), +1/-1 = emit triangle (p-2, p-1, p) with that

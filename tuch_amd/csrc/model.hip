@@ -43,7 +43,7 @@ extern "C" void tuch_contact_model_destroy(tuch_contact_model* m)
     if (!m) return;
     void* dev[] = {m->ring_off, m->ring_vidx, m->faces, m->mask_bits, m->strip_vidx, m->strip_sign, m->tree_node, m->tree_vidx, m->tree_sign, m->tree_qperm,
                    m->tree_height_off, m->tree_height_nodes, m->tree_frontier_nodes, m->tree_launch_order, m->tree_ancestors, m->tree_rows, m->tree_v2v_info, m->tree_mask_bits, m->tree_masked, m->seg_blocks, m->seg_of_q, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces, m->seg_link_off, m->seg_link, m->seg_ray_off, m->seg_ray_ent, m->seg_elem_mask, m->seg_vmask, m->seg_vpos, m->seg_cap_off, m->seg_cap_ent,
-                   m->cap_off, m->cap_vidx, m->region_off, m->region_vidx, m->pairs, m->pair_mask, m->pair_mask_off, m->tickets};
+                   m->cap_off, m->cap_vidx, m->region_off, m->region_vidx, m->pairs, m->pair_mask, m->pair_mask_off, m->tickets, m->canary_hits};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     free(m->tree_frontier_off_host);
@@ -85,6 +85,7 @@ extern "C" int tuch_contact_model_create(
     if (rc == TUCH_OK) {
         const int32_t zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         rc = upload(&m->tickets, zeros, 8);
+        if (rc == TUCH_OK) rc = upload(&m->canary_hits, zeros, 1);
     }
     if (rc == TUCH_OK) {
         std::vector<int32_t> sv;
@@ -432,6 +433,18 @@ extern "C" int tuch_contact_model_set_option(tuch_contact_model* m, const char* 
         }
     tuch_set_error("tuch_contact_model_set_option: unknown option '%s'", name);
     return TUCH_ERR_ARG;
+}
+
+extern "C" int tuch_contact_model_canary_hits(const tuch_contact_model* m, int* hits_host, int reset)
+{
+    TUCH_REQUIRE(m && hits_host, "tuch_contact_model_canary_hits: null argument");
+    if (hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(hits_host, m->canary_hits, sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess ||
+        (reset && hipMemset(m->canary_hits, 0, sizeof(int32_t)) != hipSuccess)) {
+        tuch_set_error("tuch_contact_model_canary_hits: %s", hipGetErrorString(hipGetLastError()));
+        return TUCH_ERR_HIP;
+    }
+    return TUCH_OK;
 }
 
 extern "C" int tuch_contact_model_get_option(const tuch_contact_model* m, const char* name, int* value)

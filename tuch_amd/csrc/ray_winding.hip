@@ -29,6 +29,7 @@
 // noise (~1e-5) of the threshold; tests/test_gpu_contact.py compares the two on every fixture.
 #include "common.h"
 #include "model.h"
+#include "workspace.h"
 #include "tree_device.h"
 #include <stdlib.h>
 
@@ -998,24 +999,31 @@ static RayLayout full_layout(const tuch_contact_model* m, int B, int Q, bool ver
     const int waves = m->opt.ray_waves > 0 ? m->opt.ray_waves : 32768;
     l.workers = waves / l.columns > 0 ? waves / l.columns : 1;
     size_t o = 0;
-    l.stream = o;    o += align256((size_t)B * l.T * sizeof(RayElem));
-    l.bounds = o;    o += align256((size_t)B * m->tree_nodes * 2 * kSlabStride * sizeof(float));
-    l.lists = o;     o += align256((size_t)B * l.qblocks * L * sizeof(RayEntry));
-    l.list_len = o;  o += align256((size_t)B * l.qblocks * sizeof(int32_t));
+    l.stream = tuch_ws_take(o, (size_t)B * l.T * sizeof(RayElem));
+    l.bounds = tuch_ws_take(o, (size_t)B * m->tree_nodes * 2 * kSlabStride * sizeof(float));
+    l.lists = tuch_ws_take(o, (size_t)B * l.qblocks * L * sizeof(RayEntry));
+    l.list_len = tuch_ws_take(o, (size_t)B * l.qblocks * sizeof(int32_t));
     l.zeroed = o;                                                  // one memset: rays per leaf, fill cursors, crossing counts
-    l.leaf_cnt = o;  o += align256((size_t)B * L * sizeof(int32_t));
-    l.leaf_fill = o; o += align256((size_t)B * L * sizeof(int32_t));
-    l.count = o;     o += align256((size_t)B * l.qblocks * kRayQueries * sizeof(int32_t));
+    // (the span ray_stream_kernel clears in one go stays contiguous: no guards inside it, one behind it)
+    l.leaf_cnt = tuch_ws_take(o, (size_t)B * L * sizeof(int32_t), false);
+    l.leaf_fill = tuch_ws_take(o, (size_t)B * L * sizeof(int32_t), false);
+    l.count = tuch_ws_take(o, (size_t)B * l.qblocks * kRayQueries * sizeof(int32_t), false);
     l.seg_count = o;
     if (verts && m->seg_elem_mask) o += align256(2 * (size_t)B * l.qblocks * kRayQueries * sizeof(int32_t));
     l.zeroed_bytes = o - l.zeroed;
-    l.leaf_off = o;  o += align256((size_t)B * L * sizeof(int32_t));
-    l.tiles = o;     o += align256((size_t)B * l.max_tiles * sizeof(RayTile));
-    l.body = o;      o += align256((size_t)B * sizeof(RayBody));
-    l.pairs = o;     o += align256((size_t)B * l.cap * sizeof(int32_t));
-    l.stats = o;     o += 256;
+    (void)tuch_ws_take(o, 0);
+    l.leaf_off = tuch_ws_take(o, (size_t)B * L * sizeof(int32_t));
+    l.tiles = tuch_ws_take(o, (size_t)B * l.max_tiles * sizeof(RayTile));
+    l.body = tuch_ws_take(o, (size_t)B * sizeof(RayBody));
+    l.pairs = tuch_ws_take(o, (size_t)B * l.cap * sizeof(int32_t));
+    l.stats = tuch_ws_take(o, 256);
     l.total = o;
     return l;
+}
+
+void tuch_ray_layout_touch(const tuch_contact_model* m, int B, int Q)
+{
+    (void)full_layout(m, B, Q > 0 ? Q : m->V, Q <= 0);
 }
 
 size_t tuch_ray_workspace_bytes(const tuch_contact_model* m, int B, int Q)

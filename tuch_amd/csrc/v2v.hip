@@ -19,6 +19,7 @@
 //     torch.argmin, all-masked column -> (inf, 0).
 #include "common.h"
 #include "model.h"
+#include "workspace.h"
 #include "tree_device.h"
 #include <stdlib.h>
 
@@ -644,9 +645,9 @@ TreeV2VLayout tree_v2v_layout(const tuch_contact_model* m, int B)
     TreeV2VLayout l;
     size_t o = 0;
     const int Vp = m->tree_qblocks * 2 * kTreeCols;
-    l.prow = o;   o += align256((size_t)B * Vp * 3 * sizeof(float) + 64);
-    l.bounds = o; o += align256((size_t)B * m->tree_nodes * 8 * sizeof(float));
-    l.keys = o;   o += align256((size_t)B * Vp * sizeof(uint64_t));
+    l.prow = tuch_ws_take(o, (size_t)B * Vp * 3 * sizeof(float) + 64);
+    l.bounds = tuch_ws_take(o, (size_t)B * m->tree_nodes * 8 * sizeof(float));
+    l.keys = tuch_ws_take(o, (size_t)B * Vp * sizeof(uint64_t));
     l.total = o;
     return l;
 }
@@ -728,6 +729,7 @@ extern "C" size_t tuch_v2v_model_workspace_bytes(const tuch_contact_model* m, in
     if (!m || B <= 0) return 0;
     const size_t flat = tuch_v2v_workspace_bytes(B, m->V);
     if (m->tree_nodes <= 0 || !m->tree_mask_bits) return flat;
+    tuch_ws_scope scope(m->opt.canary != 0);
     const size_t tree = tree_v2v_layout(m, B).total;
     return tree > flat ? tree : flat;
 }
@@ -757,11 +759,13 @@ extern "C" int tuch_v2v_min_model_shared(const tuch_contact_model* m, const floa
     TUCH_REQUIRE(B > 0 && B <= 65535, "tuch_v2v_min_model: bad batch %d", B);
     if (!use_v2v_tree(m))
         return tuch_v2v_min_masked(verts, m->mask_bits, B, m->V, min_d2, argmin, workspace, workspace_bytes, stream);
-    const TreeV2VLayout l = tree_v2v_layout(m, B);
+    tuch_ws_scope scope(m->opt.canary != 0);
+    const TreeV2VLayout l = scope.record(0, [&] { return tree_v2v_layout(m, B); });
     if (!workspace || workspace_bytes < l.total) {
         tuch_set_error("tuch_v2v_min_model: workspace %zu < %zu bytes", workspace_bytes, l.total);
         return TUCH_ERR_WORKSPACE;
     }
+    scope.arm(workspace, m->canary_hits, (hipStream_t)stream);
     char* ws = (char*)workspace;
     float* prow = (float*)(ws + l.prow);
     float* bounds = (float*)(ws + l.bounds);

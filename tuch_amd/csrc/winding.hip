@@ -17,6 +17,7 @@
 //     kernel => bit-reproducible results, no float atomics.
 #include "common.h"
 #include "model.h"
+#include "workspace.h"
 #include "tree_device.h"
 #include <stdlib.h>
 
@@ -794,7 +795,7 @@ int choose_strip_splits(int B, int Q, int L)
 }
 
 struct ExteriorLayout {
-    size_t tris, partial, bounds, stats, caps, seg_tris, seg_partial, seg_count, seg_list, ray, total;
+    size_t tris, partial, bounds, stats, caps, seg_tris, seg_partial, seg_count, seg_list, ray, ray_bytes, total;
     int lpad;
     int tree_frontier;         // frontier used by the hierarchical path (-1: flat path)
     int tree_subs;
@@ -849,19 +850,20 @@ ExteriorLayout exterior_layout(const tuch_contact_model* m, int B)
         if (tree_bytes > strip_bytes) strip_bytes = tree_bytes;
         if (l.tree_subs > max_splits) max_splits = l.tree_subs;
     }
-    l.tris = o;     o += align256(tri_bytes > strip_bytes ? tri_bytes : strip_bytes);
-    l.partial = o;  o += align256((size_t)B * max_splits * (m->V + 128) * sizeof(float));
-    l.bounds = o;   o += align256((size_t)B * (m->tree_nodes > 0 ? m->tree_nodes : 1) * 2 * kSlabStride * sizeof(float));
-    l.stats = o;    o += 256;
-    l.caps = o;     o += align256((size_t)B * (m->num_caps > 0 ? m->num_caps : 1) * 3 * sizeof(float));
+    l.tris = tuch_ws_take(o, tri_bytes > strip_bytes ? tri_bytes : strip_bytes);
+    l.partial = tuch_ws_take(o, (size_t)B * max_splits * (m->V + 128) * sizeof(float));
+    l.bounds = tuch_ws_take(o, (size_t)B * (m->tree_nodes > 0 ? m->tree_nodes : 1) * 2 * kSlabStride * sizeof(float));
+    l.stats = tuch_ws_take(o, 256);
+    l.caps = tuch_ws_take(o, (size_t)B * (m->num_caps > 0 ? m->num_caps : 1) * 3 * sizeof(float));
     // triangles of the closed segments, or (ray form) faces + boundary entries; partial sums, two arrays in the ray form
     const int seg_entries = m->seg_ray_total > m->seg_f_total ? m->seg_ray_total : m->seg_f_total;
-    l.seg_tris = o; o += align256(((size_t)B * (seg_entries > 0 ? seg_entries : 1) + 1) * 9 * sizeof(float));
+    l.seg_tris = tuch_ws_take(o, ((size_t)B * (seg_entries > 0 ? seg_entries : 1) + 1) * 9 * sizeof(float));
     l.seg_partial = o; o += align256(2 * (size_t)B * kSegSplits * (m->seg_q_total > 0 ? m->seg_q_total : 1) * sizeof(float) +
                                       ((size_t)B * (m->num_seg_blocks > 0 ? m->num_seg_blocks : 1) * 2 + 4) * sizeof(int32_t));
-    l.seg_count = o; o += align256((size_t)B * (m->num_segments > 0 ? m->num_segments : 1) * sizeof(int32_t));
-    l.seg_list = o; o += align256((size_t)B * (m->seg_q_total > 0 ? m->seg_q_total : 1) * sizeof(int32_t));
-    l.ray = o;      o += align256(tuch_ray_workspace_bytes(m, B, 0));
+    l.seg_count = tuch_ws_take(o, (size_t)B * (m->num_segments > 0 ? m->num_segments : 1) * sizeof(int32_t));
+    l.seg_list = tuch_ws_take(o, (size_t)B * (m->seg_q_total > 0 ? m->seg_q_total : 1) * sizeof(int32_t));
+    { tuch_ws_pause nested; l.ray_bytes = tuch_ray_workspace_bytes(m, B, 0); }
+    l.ray = tuch_ws_take(o, l.ray_bytes);
     l.total = o;
     return l;
 }
@@ -968,6 +970,7 @@ extern "C" int tuch_gather_triangles(const float* verts, const int32_t* faces, i
 extern "C" size_t tuch_exterior_workspace_bytes(const tuch_contact_model* m, int B)
 {
     if (!m || B <= 0) return 0;
+    tuch_ws_scope scope(m->opt.canary != 0);
     return exterior_layout(m, B).total;
 }
 
@@ -981,11 +984,14 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
 {
     TUCH_REQUIRE(m && verts && exterior, "tuch_exterior_flags: null pointer");
     TUCH_REQUIRE(B > 0 && B <= 65535, "tuch_exterior_flags: bad batch %d", B);
-    const ExteriorLayout l = exterior_layout(m, B);
+    tuch_ws_scope scope(m->opt.canary != 0);
+    const ExteriorLayout l = scope.record(0, [&] { return exterior_layout(m, B); });
     if (!workspace || workspace_bytes < l.total) {
         tuch_set_error("tuch_exterior_flags: workspace %zu < %zu bytes", workspace_bytes, l.total);
         return TUCH_ERR_WORKSPACE;
     }
+    if (tuch_ray_available(m)) scope.record(l.ray, [&] { tuch_ray_layout_touch(m, B, 0); return 0; });
+    scope.arm(workspace, m->canary_hits, (hipStream_t)stream);
     char* ws = (char*)workspace;
     float* tris = (float*)(ws + l.tris);
     hipStream_t s = (hipStream_t)stream;
@@ -1136,9 +1142,9 @@ static PointsLayout points_layout(const tuch_contact_model* m, int B, int Q)
     l.frontier = f;
     l.nsub = m->tree_frontier_off_host[f + 1] - m->tree_frontier_off_host[f];
     size_t o = 0;
-    l.stream = o;  o += align256((size_t)B * (m->tree_stream_len + 3) * sizeof(StreamElem));
-    l.bounds = o;  o += align256((size_t)B * m->tree_nodes * 2 * kSlabStride * sizeof(float));
-    l.partial = o; o += align256((size_t)B * l.nsub * l.qblocks * kTreeQueries * sizeof(float));
+    l.stream = tuch_ws_take(o, (size_t)B * (m->tree_stream_len + 3) * sizeof(StreamElem));
+    l.bounds = tuch_ws_take(o, (size_t)B * m->tree_nodes * 2 * kSlabStride * sizeof(float));
+    l.partial = tuch_ws_take(o, (size_t)B * l.nsub * l.qblocks * kTreeQueries * sizeof(float));
     l.total = o;
     return l;
 }
@@ -1146,6 +1152,7 @@ static PointsLayout points_layout(const tuch_contact_model* m, int B, int Q)
 extern "C" size_t tuch_winding_points_workspace_bytes(const tuch_contact_model* m, int B, int Q)
 {
     if (!m || B <= 0 || Q <= 0) return 0;
+    tuch_ws_scope scope(m->opt.canary != 0);
     const int lpad = strip_lpad(m->strip_len);
     const size_t flat = align256((size_t)B * lpad * sizeof(StreamElem)) +
                         align256((size_t)B * choose_strip_splits(B, Q, lpad) * Q * sizeof(float));
@@ -1169,11 +1176,16 @@ extern "C" int tuch_winding_points(const tuch_contact_model* m, const float* ver
     }
     hipStream_t s = (hipStream_t)stream;
     const int ray = ray_mode(m);
-    if (ray == 2 || (ray == 1 && !w))     // off-surface points: the winding number is the integer crossing count
+    tuch_ws_scope scope(m->opt.canary != 0);
+    if (ray == 2 || (ray == 1 && !w)) {   // off-surface points: the winding number is the integer crossing count
+        scope.record(0, [&] { tuch_ray_layout_touch(m, B, Q); return 0; });
+        scope.arm(workspace, m->canary_hits, s);
         return tuch_ray_exterior_points(m, verts, points, counts, B, Q, thresh, exterior, w, workspace, s);
+    }
     if (use_strips(m) && use_tree(m)) {
         // hierarchical walk (cluster tree + boundary caps) with the caller's points as queries
-        const PointsLayout l = points_layout(m, B, Q);
+        const PointsLayout l = scope.record(0, [&] { return points_layout(m, B, Q); });
+        scope.arm(workspace, m->canary_hits, s);
         char* ws = (char*)workspace;
         StreamElem* st = (StreamElem*)(ws + l.stream);
         float* bounds = (float*)(ws + l.bounds);

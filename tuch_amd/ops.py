@@ -580,6 +580,21 @@ class ContactModel:
         _C.check(_C.lib().tuch_contact_model_get_option(self._handle, name.encode(), ctypes.byref(out)))
         return out.value
 
+    def canary_hits(self, reset: bool = True) -> int:
+        """Guard words between workspace regions found changed since the last reset (option canary = 1: debug mode,
+        include/tuch_amd.h).  Synchronises the device."""
+        out = ctypes.c_int(0)
+        _C.check(_C.lib().tuch_contact_model_canary_hits(self._handle, ctypes.byref(out), int(reset)))
+        return out.value
+
+    def canary_selftest(self) -> int:
+        """Overruns a guarded region on purpose: returns the hits counted (1 if the mechanism works)."""
+        ws = _workspace(8192, self.device)
+        rc = _C.lib().tuch_contact_model_canary_selftest(self._handle, _C.ptr(ws), ws.numel(), _C.stream())
+        if rc < 0:
+            _C.check(rc)
+        return rc
+
     @property
     def faces_i32(self):
         if self._faces_i32 is None:
@@ -809,6 +824,15 @@ class HDModel:
         _C.check(_C.lib().tuch_hd_contact_selection(self._handle, _C.ptr(saved), batch, counts.ctypes.data_as(ctypes.c_void_p),
                                                     sel.ctypes.data_as(ctypes.c_void_p)))
         return counts, sel
+
+
+    def details(self, saved, batch):
+        """(partner [B,N] caller-order id of every slot's partner or -1, exterior [B,N] bool) of a forward call (tests)."""
+        part = np.zeros((batch, self.num_points), np.int32)
+        ext = np.zeros((batch, self.num_points), np.uint8)
+        _C.check(_C.lib().tuch_hd_contact_details(self._handle, _C.ptr(saved), batch, part.ctypes.data_as(ctypes.c_void_p),
+                                                  ext.ctypes.data_as(ctypes.c_void_p)))
+        return part, ext.astype(bool)
 
 
 class _HDContact(torch.autograd.Function):
