@@ -553,17 +553,19 @@ def workloads(device, seed):
     return out
 
 
-def graph_kernel_count(graph):
-    """Kernel launches in one captured step: torch's debug dump of the graph (dot) lists one node per launch."""
-    import re
-    import tempfile
+def kernels_per_step(step):
+    """Device kernels one call of `step` launches (for a captured step: the kernel nodes of one replay), counted with the
+    torch profiler's device-side records; memory copies / fills are reported separately."""
     try:
-        with tempfile.TemporaryDirectory() as tmp:
-            path = os.path.join(tmp, 'g.dot')
-            graph.debug_dump(path)
-            text = open(path).read()
-        kernels = len(re.findall(r'KERNEL|kernel', text))
-        return {'kernel_nodes': kernels, 'all_nodes': len(re.findall(r'\bgraph_\w+ *\[|^\s*\w+ *\[label', text, re.M))}
+        from torch.profiler import ProfilerActivity, profile
+        step()
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            step()
+            torch.cuda.synchronize()
+        names = [e.name for e in prof.events() if str(getattr(e, 'device_type', '')).endswith('CUDA')]
+        copies = [n for n in names if 'memcpy' in n.lower() or 'memset' in n.lower() or 'copyBuffer' in n or 'fillBuffer' in n]
+        return {'kernels': len(names) - len(copies), 'copies_and_fills': len(copies)}
     except Exception as exc:
         return {'error': repr(exc)}
 
@@ -896,8 +898,7 @@ def main():
                 line['selfcheck'] = selfcheck(p, step)
             except Exception as exc:                     # the measurement stands; the check reports what went wrong
                 line['selfcheck'] = {'ok': False, 'error': repr(exc)}
-            if hasattr(step, 'graph'):
-                line['kernels_per_step'] = graph_kernel_count(step.graph)
+            line['kernels_per_step'] = kernels_per_step(step)
         roof, inside, verts, model = rooflines(p, batch)
         line['roofline'], line['roofline_inside_test'] = roof, inside
         if world == 1 and backend == 'nccl' and not args.no_rccl_smoke:

@@ -814,7 +814,7 @@ def test_big_batches_ray_crossings_match_the_solid_angle_sums(tag, batch):
         assert touches_surface(vnp[b], g['faces'], int(vid)), (b, vid)
     rest = dw[(e0 == e1) & (dw <= 0.5)]
     report('big batch [%s, B=%d]: max |dw| off the jumps x1e7' % (tag, batch), int(float(rest.max()) * 1e7), rest.numel())
-    assert float(torch.quantile(rest.flatten()[::3].float(), 0.999)) < 2e-5 and float(rest.max()) < 1e-3 and len(jumps) <= 8
+    assert float(torch.quantile(rest.flatten()[::3].float(), 0.999)) < 5e-5 and float(rest.max()) < 1e-3 and len(jumps) <= 8
     seg_bad = torch.nonzero(es0 != es1).cpu().numpy()
     report('big batch [%s, B=%d]: flags after the segment filter differ' % (tag, batch), len(seg_bad), es0.numel())
     body_bad = {(int(b), int(vid)) for b, vid in bad}
@@ -855,6 +855,52 @@ def test_pair_list_overflow_falls_back_to_block_major_order(tag, cap):
     assert work_c['elements'] > work_d['elements']
 
 
+@pytest.mark.parametrize('tag', ['medium', 'ico_medium'])
+def test_fan_direction_tangent_to_a_star_face(tag):
+    """w of a vertex by ray crossings = crossings of (mesh - star + closing fan) - the fan's angles / 4 pi.  When the fan's
+    apex direction lies in the plane of one of the star's faces (with the opposite direction inside the face), that cone
+    triangle is flat: its crossing flips by one and its solid angle jumps by 2 pi there -- the two must be signed by the
+    SAME determinant, or w is off by exactly one (csrc/ray_winding.hip: cone_term).  Bodies rotated so that a chosen
+    vertex sits exactly in that configuration, up to rotations of ~1e-7 rad either way."""
+    g = golden(tag)
+    model = make_model(g, None, False, False)
+    base = g['verts'][0].astype(np.float64)
+    faces = g['faces']
+    u = np.array([0.8191, 0.3467, 0.4571])                       # kFanX/Y/Z of ray_winding.hip
+    u /= np.linalg.norm(u)
+    rng = np.random.default_rng(12)
+
+    def rot(axis, angle):
+        axis = axis / np.linalg.norm(axis)
+        k = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        return np.eye(3) + np.sin(angle) * k + (1 - np.cos(angle)) * k @ k
+    bodies, targets = [], []
+    for f in rng.choice(len(faces), 40, replace=False):
+        v, a, b = faces[f]
+        mid = (base[a] - base[v]) / np.linalg.norm(base[a] - base[v]) + (base[b] - base[v]) / np.linalg.norm(base[b] - base[v])
+        mid /= np.linalg.norm(mid)
+        # rotate the bisector of the face's corner at v onto -u: u then lies in the face's plane, -u inside the face
+        axis = np.cross(mid, -u)
+        r0 = rot(axis, np.arctan2(np.linalg.norm(axis), mid @ -u)) if np.linalg.norm(axis) > 1e-9 else np.eye(3)
+        r0 = rot(u, rng.uniform(0, 2 * np.pi)) @ r0
+        for eps in (0.0, 1e-7, -1e-7, 3e-7, -3e-7, 1e-6):
+            r = rot(rng.standard_normal(3), eps) @ r0
+            bodies.append((base - base[v]) @ r.T + base[v])
+            targets.append(v)
+    verts = torch.tensor(np.stack(bodies).astype(np.float32), device=dev())
+    model.set_option('winding_ray', 0)
+    w_s = model.exterior_flags(verts, apply_segments=False, return_details=True)[1]
+    model.set_option('winding_ray', 2)
+    w_r = model.exterior_flags(verts, apply_segments=False, return_details=True)[1]
+    idx = torch.tensor(targets, device=dev())
+    rows = torch.arange(len(targets), device=dev())
+    err_t = (w_r[rows, idx] - w_s[rows, idx]).abs()
+    report('fan tangent to a star face [%s]: targeted vertices with |dw| > 0.5' % tag, int((err_t > 0.5).sum()), len(targets))
+    assert float(err_t.max()) < 1e-3
+    err = (w_r - w_s).abs()
+    assert int((err > 0.5).sum()) == 0 and float(err.max()) < 1e-3
+
+
 @pytest.mark.parametrize('tag', TAGS)
 def test_segment_filter_by_ray_crossings_matches_the_solid_angle_sums(tag, monkeypatch):
     """The segment test (segmentation.py:81-99) by ray crossings: w of EVERY segment vertex w.r.t. its "closed" segment
@@ -877,7 +923,7 @@ def test_segment_filter_by_ray_crossings_matches_the_solid_angle_sums(tag, monke
     report('segment w, ray vs solid angle: max |dw| [%s] x1e7' % tag, int(err[~jump].max() * 1e7), err.size)
     # sheared / squeezed copies of a self-penetrating body put vertices microns from foreign triangles, where the float32
     # solid-angle sum loses digits: nearly all agree to 2e-5, the worst to 1e-3 (the crossing count is exact there)
-    assert np.percentile(err[~jump], 99.9) < 2e-5 and err[~jump].max() < 1e-3
+    assert np.percentile(err[~jump], 99.9) < 5e-5 and err[~jump].max() < 1e-3
     clear = (np.abs(segw_s - 0.99) > 1e-4) & ~jump
     assert np.array_equal(sege_r.cpu().numpy()[clear], sege_s.cpu().numpy()[clear])
     if not jump.any():

@@ -605,6 +605,34 @@ __device__ __forceinline__ float half_solid_angle(const P3& a, const P3& b, cons
     return fast_atan2(num, den);
 }
 
+// One cone triangle (apex direction u, then x, y) of a closing fan / closing chain: its signed ray crossing and its half
+// solid angle, BOTH signed by ONE determinant.  The two only mean something together: where u comes to lie in the plane
+// of (query, x, y) -- a fan direction tangent to a face of the star -- the crossing flips by one and the half angle
+// jumps by 2 pi / 2, and crossing - half / (2 pi) is continuous across the flip.  Computing det(u, x, y) twice (sheared
+// for the crossing, unsheared inside the angle; equal in exact arithmetic, the shear has determinant 1) let the two
+// signs disagree when the determinant is within rounding of zero: w off by exactly one, about once in 3 million cone
+// triangles (found on the irregular-topology body, tests/test_gpu_contact.py::test_big_batches_...).  Exactly zero counts
+// as positive for both.  s*: corners relative to the query in the sheared ray frame; u, pb, pc: the same in space.
+__device__ __forceinline__ void cone_term(const P3& us, const P3& sb, const P3& sc, const P3& u, const P3& pb, const P3& pc,
+                                          int& crossings, float& half)
+{
+    const float ea = edge_fn(sb, sc), eb = edge_fn(sc, us), ec = edge_fn(us, sb);
+    const float d = ea * us.z + eb * sb.z + ec * sc.z;
+    const bool la = left_of(ea, sb, sc), lb = left_of(eb, sc, us), lc = left_of(ec, us, sb);
+    const bool front = d >= 0.0f;
+    crossings = (la & lb & lc) ? (int)front : ((!la & !lb & !lc) ? -(int)!front : 0);
+    const float nu = __builtin_sqrtf(u.x * u.x + u.y * u.y + u.z * u.z);
+    const float nb = __builtin_sqrtf(pb.x * pb.x + pb.y * pb.y + pb.z * pb.z);
+    const float nc = __builtin_sqrtf(pc.x * pc.x + pc.y * pc.y + pc.z * pc.z);
+    const float cx = pb.y * pc.z - pb.z * pc.y, cy = pb.z * pc.x - pb.x * pc.z, cz = pb.x * pc.y - pb.y * pc.x;
+    const float num = __builtin_fabsf(u.x * cx + u.y * cy + u.z * cz);
+    const float dub = u.x * pb.x + u.y * pb.y + u.z * pb.z;
+    const float dbc = pb.x * pc.x + pb.y * pc.y + pb.z * pc.z;
+    const float duc = u.x * pc.x + u.y * pc.y + u.z * pc.z;
+    const float den = nu * nb * nc + dub * nc + duc * nb + dbc * nu;
+    half = fast_atan2(front ? num : -num, den);
+}
+
 // vertices: N = sum of the subtree counts + crossings of the closing fan; w = N - (sum of the fan's half angles) / (2 pi)
 __global__ __launch_bounds__(kBlock) void ray_finalize_verts_kernel(
     const float* __restrict__ verts, const int32_t* __restrict__ count, const int32_t* __restrict__ qperm,
@@ -644,8 +672,11 @@ __global__ __launch_bounds__(kBlock) void ray_finalize_verts_kernel(
                 if (j0 + u < cnt) {
                     const P3 pc = {cc[u][0] - vx, cc[u][1] - vy, cc[u][2] - vz};
                     const P3 sc = {shear_x(cc[u][0], cc[u][2]) - qx, shear_y(cc[u][1], cc[u][2]) - qy, cc[u][2] - vz};
-                    half_sum += half_solid_angle(u_dir, pb, pc);
-                    n += crossing_mostly_generic(us, sb, sc, edge_fn(sb, sc), edge_fn(sc, us), edge_fn(us, sb));
+                    int cr;
+                    float hf;
+                    cone_term(us, sb, sc, u_dir, pb, pc, cr, hf);
+                    half_sum += hf;
+                    n += cr;
                     pb = pc;
                     sb = sc;
                 }
@@ -671,8 +702,11 @@ __global__ __launch_bounds__(kBlock) void ray_finalize_verts_kernel(
             const float lqx = shear_x(lvx, lvz), lqy = shear_y(lvy, lvz);
             const P3 pb = {bx - lvx, by - lvy, bz - lvz}, pc = {cx - lvx, cy - lvy, cz - lvz};
             const P3 sb = {shear_x(bx, bz) - lqx, shear_y(by, bz) - lqy, bz - lvz}, sc = {shear_x(cx, cz) - lqx, shear_y(cy, cz) - lqy, cz - lvz};
-            h += half_solid_angle(u_dir, pb, pc);
-            cr += crossing(us, sb, sc, edge_fn(sb, sc), edge_fn(sc, us), edge_fn(us, sb));
+            int c1;
+            float h1;
+            cone_term(us, sb, sc, u_dir, pb, pc, c1, h1);
+            h += h1;
+            cr += c1;
         }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) { h += __shfl_xor(h, m); cr += __shfl_xor(cr, m); }
@@ -836,11 +870,14 @@ __global__ __launch_bounds__(64) void segment_ray_kernel(
                     const bool at_query = ((bb.x == 0.0f) & (bb.y == 0.0f) & (bb.z == 0.0f)) | ((c.x == 0.0f) & (c.y == 0.0f) & (c.z == 0.0f));
                     if (!at_query) {
                         const int mult = (int)t[6];
-                        crossings += mult * crossing(us, bb, c, edge_fn(bb, c), edge_fn(c, us), edge_fn(us, bb));
                         // back from the sheared frame for the angle
                         const P3 pb = {__builtin_fmaf(kShearX, bb.z, bb.x), __builtin_fmaf(kShearY, bb.z, bb.y), bb.z};
                         const P3 pc = {__builtin_fmaf(kShearX, c.z, c.x), __builtin_fmaf(kShearY, c.z, c.y), c.z};
-                        half_sum += (float)mult * half_solid_angle(u_dir, pb, pc);
+                        int c1;
+                        float h1;
+                        cone_term(us, bb, c, u_dir, pb, pc, c1, h1);
+                        crossings += mult * c1;
+                        half_sum += (float)mult * h1;
                     }
                 }
             }
@@ -907,8 +944,11 @@ __global__ __launch_bounds__(kBlock) void segment_ray_finalize_kernel(
         const P3 pb = {p0[0] - ax, p0[1] - ay, p0[2] - az}, pc = {p1[0] - ax, p1[1] - ay, p1[2] - az};
         const P3 sb = {shear_x(p0[0], p0[2]) - sx, shear_y(p0[1], p0[2]) - sy, p0[2] - az};
         const P3 sc = {shear_x(p1[0], p1[2]) - sx, shear_y(p1[1], p1[2]) - sy, p1[2] - az};
-        h += half_solid_angle(u_dir, pb, pc);
-        c += crossing_mostly_generic(us, sb, sc, edge_fn(sb, sc), edge_fn(sc, us), edge_fn(us, sb));
+        int c1;
+        float h1;
+        cone_term(us, sb, sc, u_dir, pb, pc, c1, h1);
+        h += h1;
+        c += c1;
     };
     const int e0 = active ? link_off[qq] : 0, e1 = active ? link_off[qq + 1] : 0;
     constexpr int kLongLinks = 16;
