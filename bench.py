@@ -212,12 +212,10 @@ def make_step(p):
     from tuch_amd.smplify.losses import contact_fitting_loss
     body_pose = p['body_pose'].clone().requires_grad_(True)
     global_orient = p['global_orient'].clone().requires_grad_(True)
-    try:      # one multi-tensor kernel for the update; same arithmetic as the reference's torch.optim.Adam
-        opt = torch.optim.Adam([body_pose, global_orient], lr=1e-2, capturable=True, fused=True)
-    except (RuntimeError, TypeError):
-        opt = torch.optim.Adam([body_pose, global_orient], lr=1e-2, capturable=True)
-    stats = torch.zeros(2, device=body_pose.device)
-    stats[1] = float(body_pose.shape[0])          # set once: a host scalar write is not graph-capturable
+    from tuch_amd.optim import make_adam
+    # the reference's torch.optim.Adam update as one launch (tuch_amd/optim.py, what SMPLifyDC's own loops use)
+    opt = make_adam([body_pose, global_orient], 1e-2)
+    count = torch.full((), float(body_pose.shape[0]), device=body_pose.device)
 
     def step():
         out = p['smpl'](global_orient=global_orient, body_pose=body_pose, betas=p['betas'])
@@ -231,8 +229,7 @@ def make_step(p):
         opt.zero_grad(set_to_none=True)
         ops.backward_scalar(loss)                 # as SMPLifyDC._Stage._one does
         opt.step()
-        stats[0].copy_(loss.detach())
-        return stats
+        return loss.detach(), count               # [loss sum, bodies]: stacked by the caller, once per timed block
 
     def objective():
         """The stage-2 objective at the CURRENT parameters, eager launches, no update; also the posed vertices."""
@@ -624,6 +621,7 @@ def selfcheck(p, step, sample=(0, 37)):
     from tuch_amd.smplify.losses import contact_model_for
     eager, verts, joints, pose = step.objective()
     replayed = float(step()[0])                      # reports the loss at the parameters it started from, then updates
+    torch.cuda.synchronize()
     body = p['body']
     gm = body.geodesics > 0.3
     segs = [oc.Segment(n, body.faces, s['vidx'], list(s['bands'].values())) for n, s in body.segments.items()]
@@ -831,6 +829,8 @@ def main():
             torch.distributed.init_process_group(backend)
 
     def reduce(local_stats):
+        if isinstance(local_stats, tuple):               # (loss sum, bodies) as two 0-d tensors
+            local_stats = torch.stack([t.to(torch.float32).reshape(()) for t in local_stats])
         if os.environ.get('TUCH_BENCH_DEBUG'):
             print('rank', rank, 'local stats', local_stats.tolist(), flush=True)
         if world > 1:

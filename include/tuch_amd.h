@@ -113,6 +113,14 @@ int tuch_smplify_small_terms(const float* joints, const float* camera_t, const f
                              float prior_scale, float* out, float* grad_joints, float* grad_camera_t,
                              float* grad_body_pose, void* stream);
 
+/* Adam update (torch.optim.Adam without weight decay / amsgrad: tuch/smplify/smplifydc.py:117,150 optimises body pose,
+ * global orientation, betas, camera translation with it) of up to 8 small tensors in ONE launch, the step counter on the
+ * device (capturable).  params / grads / exp_avg / exp_avg_sq: `count` device pointers each (host arrays), sizes[k]
+ * floats; betas [count][2]; step: one device float = updates so far, incremented by the call. */
+int tuch_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg,
+                   float* const* exp_avg_sq, const int* sizes, const float* betas, float* step, float lr, float eps,
+                   void* stream);
+
 /* Objective assembly of losses.py:120-123 as one deterministic reduction:
  * out[0] = sum(small_terms [B,2]) + contact_scale * sum(contact_terms [B,2]) + r2r_scale * sum(r2r [B,P]). */
 int tuch_smplify_objective(const float* small_terms, const float* contact_terms, const float* r2r, int B, int P,
@@ -131,6 +139,16 @@ int tuch_smplify_tail_bwd(const float* grad_out, const uint8_t* valid, const flo
  * body and the objective's total (the block that finishes last adds the bodies up); backward: upstream scalar -> vertex
  * gradient (contact terms and region minima, grad_points pre-zeroed) and the scaled unit gradients of the small terms.
  * share: [B] floats of scratch; ticket: one int, zero before the first call, left zero by every call. */
+/* tuch_smplify_stage2_finish and -- when grad_points is given -- tuch_smplify_stage2_bwd for a UNIT upstream gradient in
+ * one launch: the objective is the root of the fit's autograd graph, so its vertex gradient can be written while the sums
+ * are formed.  share: tuch_smplify_stage2_fused_scratch_floats(B) floats; ticket: one int, zero before the call;
+ * grad_points [B,N,3] pre-zeroed or NULL; ij [B,P,2] from tuch_region_pair_min or NULL. */
+size_t tuch_smplify_stage2_fused_scratch_floats(int B);
+int tuch_smplify_stage2_fused(const float* points, const int32_t* partner, const uint8_t* exterior,
+                              const uint8_t* body_valid, int B, int N, int mode, float euclthres,
+                              const float* small_terms, const float* r2r, const int32_t* ij, int P, float contact_scale,
+                              float r2r_scale, float* share, int* ticket, float* terms, float* out, float* grad_points,
+                              void* stream);
 int tuch_smplify_stage2_finish(const float* points, const int32_t* partner, const uint8_t* exterior,
                                const uint8_t* body_valid, int B, int N, int mode, float euclthres,
                                const float* small_terms, const float* r2r, int P, float contact_scale, float r2r_scale,

@@ -855,6 +855,27 @@ def test_pair_list_overflow_falls_back_to_block_major_order(tag, cap):
     assert work_c['elements'] > work_d['elements']
 
 
+@pytest.mark.parametrize('tag', TAGS)
+def test_fused_segment_filter_matches_the_six_launch_pass(tag):
+    """The segment filter as one launch per call (csrc/ray_winding.hip: segment_fused_kernel -- compaction, cap centroids,
+    crossings and cones in LDS, one workgroup per (segment, body)) against the same filter as six launches (option
+    seg_fused = 0): identical flags, on the fixtures and on sheared / squeezed copies with many interior vertices."""
+    batch = 6 if tag in FULL else 11
+    g, verts = _posed_batch(tag, batch, 31, scale=1.3)
+    model = make_model(g, None, True, False)
+    assert model.get_option('seg_fused') == 1
+    plain = model.exterior_flags(verts, apply_segments=False)
+    fused = model.exterior_flags(verts, apply_segments=True)
+    model.set_option('seg_fused', 0)
+    six = model.exterior_flags(verts, apply_segments=True)
+    model.set_option('seg_fused', 1)
+    again = model.exterior_flags(verts, apply_segments=True)
+    assert torch.equal(fused, six) and torch.equal(again, fused)
+    changed = int((fused != plain).sum())
+    report('fused segment filter [%s]: vertices re-marked exterior by the filter' % tag, changed, plain.numel())
+    assert int((plain == 0).sum()) > 0
+
+
 @pytest.mark.parametrize('tag', ['medium', 'ico_medium'])
 def test_fan_direction_tangent_to_a_star_face(tag):
     """w of a vertex by ray crossings = crossings of (mesh - star + closing fan) - the fan's angles / 4 pi.  When the fan's

@@ -40,6 +40,8 @@ _SIGNATURES = {
     'tuch_contact_terms_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                        c_void_p, c_void_p]),
     'tuch_smplify_small_terms': (c_int, [c_void_p] * 9 + [c_int, c_int, c_int, c_float, c_float, c_float] + [c_void_p] * 5),
+    'tuch_adam_step': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
+                                c_void_p]),
     'tuch_smplify_objective': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p]),
     'tuch_smplify_objective_bwd': (c_int, [c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p,
                                            c_void_p]),
@@ -106,6 +108,10 @@ _SIGNATURES = {
                                   c_size_t, c_void_p]),
     'tuch_smpl_backward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_size_t, c_void_p]),
+    'tuch_smplify_stage2_fused_scratch_floats': (c_size_t, [c_int]),
+    'tuch_smplify_stage2_fused': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
+                                           c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p]),
     'tuch_smplify_stage2_finish': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
                                            c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p]),

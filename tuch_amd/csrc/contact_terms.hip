@@ -284,7 +284,158 @@ __global__ __launch_bounds__(256) void stage2_bwd_kernel(
     atomicAdd(gq + 0, -c * dx); atomicAdd(gq + 1, -c * dy); atomicAdd(gq + 2, -c * dz);
 }
 
+// Forward AND the unit-seed backward of the tail in ONE launch (stage2_finish + stage2_bwd with g = 1): the objective is
+// the root of the fit's autograd graph, its upstream gradient is the constant 1 (loss.backward()), so the vertex
+// gradient can be written while the sums are formed -- one kernel and one dependent launch less in the serial tail of
+// every iteration.  A caller whose upstream gradient is not 1 scales the outputs (ops._Stage2Tail.backward).
+// grid (kFusedSplits, B) x 256 threads: a body's points are shared out over kFusedSplits blocks (the scatter's atomics
+// want more than B workgroups); partial sums per (body, split), added up in a fixed order by the block that arrives last.
+constexpr int kFusedSplits = 8;
+constexpr int kFusedBlock = 256;
+
+__device__ __forceinline__ float block_sum_256(float v, float* smem)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) smem[wave] = v;
+    __syncthreads();
+    const float r = smem[0] + smem[1] + smem[2] + smem[3];
+    __syncthreads();
+    return r;   // same value in every thread
+}
+
+__global__ __launch_bounds__(kFusedBlock) void stage2_fused_kernel(
+    const float* __restrict__ pts, const int32_t* __restrict__ partner, const uint8_t* __restrict__ exterior,
+    const uint8_t* __restrict__ body_valid, int N, int mode, float euclthres, const float* __restrict__ small,
+    const float* __restrict__ r2r, const int32_t* __restrict__ ij, int P, float contact_scale, float r2r_scale,
+    float* __restrict__ share,        // [B][kFusedSplits][3] scratch
+    int* __restrict__ ticket, float* __restrict__ terms, float* __restrict__ out,
+    float* __restrict__ grad)         // [B,N,3] pre-zeroed, or nullptr (value only)
+{
+    __shared__ float smem[kFusedBlock / 64];
+    __shared__ bool last;
+    const int s = blockIdx.x, b = blockIdx.y;
+    const bool valid = !body_valid || body_valid[b];
+    const float* pb = pts + (size_t)b * N * 3;
+    float* gb = grad ? grad + (size_t)b * N * 3 : nullptr;
+    float in_sum = 0.0f, ex_sum = 0.0f, r_sum = 0.0f;
+    const int per = (N + kFusedSplits - 1) / kFusedSplits;
+    const int beg = s * per, end = min(beg + per, N);
+    if (valid) {
+        constexpr int kPer = 4;       // partners first, then both endpoints of all four: two rounds of loads per pass
+        for (int i0 = beg + threadIdx.x; i0 < end; i0 += kFusedBlock * kPer) {
+            int pr[kPer];
+            uint8_t ex[kPer];
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                const int i = min(i0 + u * kFusedBlock, end - 1);
+                pr[u] = partner[(size_t)b * N + i];
+                ex[u] = exterior[(size_t)b * N + i];
+            }
+            float xi[kPer][3], xp[kPer][3];
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                const int i = min(i0 + u * kFusedBlock, end - 1);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { xi[u][c] = pb[3 * i + c]; xp[u][c] = pb[3 * pr[u] + c]; }
+            }
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                const int i = i0 + u * kFusedBlock;
+                if (i >= end) break;
+                const float dx = xi[u][0] - xp[u][0], dy = xi[u][1] - xp[u][1], dz = xi[u][2] - xp[u][2];
+                const float d = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
+                const bool ext = ex[u] != 0;
+                const Term t = contact_term(d, ext, mode, euclthres);
+                if (ext) ex_sum += t.value; else in_sum += t.value;
+                if (gb && d > 0.0f && t.dd != 0.0f) {
+                    const float c = contact_scale * t.dd / d;
+                    float* gi = gb + 3 * (size_t)i;
+                    float* gq = gb + 3 * (size_t)pr[u];
+                    atomicAdd(gi + 0, c * dx); atomicAdd(gi + 1, c * dy); atomicAdd(gi + 2, c * dz);
+                    atomicAdd(gq + 0, -c * dx); atomicAdd(gq + 1, -c * dy); atomicAdd(gq + 2, -c * dz);
+                }
+            }
+        }
+    }
+    if (s == 0 && r2r) {
+        for (int p = threadIdx.x; p < P; p += kFusedBlock) {
+            const size_t o = (size_t)b * P + p;
+            r_sum += r2r[o];
+            if (gb && ij && r2r_scale != 0.0f) {
+                const int i = ij[2 * o], j = ij[2 * o + 1];
+                if (i >= 0 && j >= 0)
+                    for (int c = 0; c < 3; ++c) {
+                        const float d = 2.0f * r2r_scale * (pb[3 * i + c] - pb[3 * j + c]);
+                        atomicAdd(gb + 3 * i + c, d);
+                        atomicAdd(gb + 3 * j + c, -d);
+                    }
+            }
+        }
+    }
+    const float a = block_sum_256(in_sum, smem);
+    const float c = block_sum_256(ex_sum, smem);
+    const float r = block_sum_256(r_sum, smem);
+    if (threadIdx.x == 0) {
+        float* mine = share + ((size_t)b * kFusedSplits + s) * 3;
+        __hip_atomic_store(mine + 0, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 1, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 2, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)(gridDim.x * gridDim.y) - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    // bodies in order, a body's splits in order: the total does not depend on which block came last
+    float acc = 0.0f;
+    const int B = gridDim.y;
+    for (int bb = threadIdx.x; bb < B; bb += kFusedBlock) {
+        float ia = 0.0f, ea = 0.0f, ra = 0.0f;
+        for (int k = 0; k < kFusedSplits; ++k) {
+            const float* q = share + ((size_t)bb * kFusedSplits + k) * 3;
+            ia += __hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ea += __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ra += __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (terms) { terms[2 * bb] = ia; terms[2 * bb + 1] = ea; }
+        acc += (small[2 * bb] + small[2 * bb + 1]) + contact_scale * (ia + ea) + r2r_scale * ra;
+    }
+    // fixed-order sum over the block (B <= 256: one body per thread; more: a thread's bodies in order first)
+    __shared__ float part[kFusedBlock];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float total = 0.0f;
+        const int n = B < kFusedBlock ? B : kFusedBlock;
+        for (int k = 0; k < n; ++k) total += part[k];
+        out[0] = total;
+        __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 }  // namespace
+
+extern "C" size_t tuch_smplify_stage2_fused_scratch_floats(int B) { return (size_t)(B > 0 ? B : 0) * kFusedSplits * 3; }
+
+// tuch_smplify_stage2_finish and, when grad_points is given, tuch_smplify_stage2_bwd for a unit upstream gradient, in one
+// launch.  share: tuch_smplify_stage2_fused_scratch_floats(B) floats; ticket: one int, zero before the call (left zero);
+// grad_points [B,N,3] pre-zeroed or NULL; ij [B,P,2] from tuch_region_pair_min (needed for the gradient of the region
+// term) or NULL.  The unit gradients of the small terms are tuch_smplify_small_terms' own outputs.
+extern "C" int tuch_smplify_stage2_fused(const float* points, const int32_t* partner, const uint8_t* exterior,
+                                         const uint8_t* body_valid, int B, int N, int mode, float euclthres,
+                                         const float* small_terms, const float* r2r, const int32_t* ij, int P,
+                                         float contact_scale, float r2r_scale, float* share, int* ticket, float* terms,
+                                         float* out, float* grad_points, void* stream)
+{
+    TUCH_REQUIRE(points && partner && exterior && small_terms && share && ticket && out,
+                 "tuch_smplify_stage2_fused: null pointer");
+    TUCH_REQUIRE(B > 0 && B <= 65535 && N > 0 && P >= 0 && (mode == 0 || mode == 1), "tuch_smplify_stage2_fused: bad arguments");
+    hipLaunchKernelGGL(stage2_fused_kernel, dim3(kFusedSplits, B), dim3(kFusedBlock), 0, (hipStream_t)stream, points, partner,
+                       exterior, body_valid, N, mode, euclthres, small_terms, (P > 0 ? r2r : (const float*)nullptr),
+                       (P > 0 ? ij : (const int32_t*)nullptr), P, contact_scale, r2r_scale, share, ticket, terms, out,
+                       grad_points);
+    return tuch_check_launch("tuch_smplify_stage2_fused");
+}
 
 extern "C" int tuch_contact_terms_fwd(const float* points, const int32_t* partner,
                                       const uint8_t* exterior, const uint8_t* body_valid, int B, int N,

@@ -45,6 +45,7 @@ struct tuch_options {
     int v2v_lds = 6400;         // LDS bytes a workgroup of the search holds back when something runs beside it
     int seg_splits = 16;        // face splits of the solid-angle segment kernel
     int seg_assist = 1;         // 0: the segment pass counts its body-face crossings itself (read at create only)
+    int seg_fused = 1;          // 0: the segment filter as six launches instead of one (A/B, tests)
     int canary = 0;             // 1: guard words between the regions of every workspace, see tuch_workspace_canaries
     int deterministic = 0;      // 1: gradient scatters as gathers over inverse partner lists (bit-reproducible fits)
 };
@@ -63,6 +64,9 @@ int tuch_ray_exterior_verts(const tuch_contact_model* m, const float* verts, int
 const int32_t* tuch_ray_segment_counts(const tuch_contact_model* m, int B, const void* workspace);
 void tuch_ray_segment_prepare(const tuch_contact_model* m, const float* verts, const float* caps, int assisted, int B,
                               float* seg_entries, hipStream_t s);
+bool tuch_ray_segment_fused_available(const tuch_contact_model* m);
+int tuch_ray_segment_flags_fused(const tuch_contact_model* m, const float* verts, const int32_t* leaf_counts, int B,
+                                 float thresh, uint8_t* exterior, hipStream_t s);
 int tuch_ray_segment_flags(const tuch_contact_model* m, const float* verts, const float* caps, const int32_t* seg_count,
                            const int32_t* seg_list, const int32_t* leaf_counts, int B, int nsplit, float thresh, float* seg_tris,
                            int32_t* seg_partial, float* seg_w, uint8_t* seg_ext, uint8_t* exterior, hipStream_t s);
@@ -147,6 +151,7 @@ struct tuch_contact_model {
     int32_t* seg_vmask;        // [tree_qblocks*128] by tree position: bit s = the vertex is a vertex of segment s
     int32_t* seg_vpos;         // [V] tree position of every vertex
     int32_t* seg_cap_off;      // [S+1] into seg_cap_ent: as seg_ray_* without the body faces
+    int32_t* seg_cap_range;    // [S+1] the caps of segment s are cap_range[s] .. cap_range[s+1] (fused segment pass), or nullptr
     int32_t* seg_cap_ent;
     int seg_cap_total;
     int num_seg_blocks;        // 64-query blocks over all segments

@@ -42,7 +42,7 @@ extern "C" void tuch_contact_model_destroy(tuch_contact_model* m)
 {
     if (!m) return;
     void* dev[] = {m->ring_off, m->ring_vidx, m->faces, m->mask_bits, m->strip_vidx, m->strip_sign, m->tree_node, m->tree_vidx, m->tree_sign, m->tree_qperm,
-                   m->tree_height_off, m->tree_height_nodes, m->tree_frontier_nodes, m->tree_launch_order, m->tree_ancestors, m->tree_rows, m->tree_v2v_info, m->tree_mask_bits, m->tree_masked, m->seg_blocks, m->seg_of_q, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces, m->seg_link_off, m->seg_link, m->seg_ray_off, m->seg_ray_ent, m->seg_elem_mask, m->seg_vmask, m->seg_vpos, m->seg_cap_off, m->seg_cap_ent,
+                   m->tree_height_off, m->tree_height_nodes, m->tree_frontier_nodes, m->tree_launch_order, m->tree_ancestors, m->tree_rows, m->tree_v2v_info, m->tree_mask_bits, m->tree_masked, m->seg_blocks, m->seg_of_q, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces, m->seg_link_off, m->seg_link, m->seg_ray_off, m->seg_ray_ent, m->seg_elem_mask, m->seg_vmask, m->seg_vpos, m->seg_cap_off, m->seg_cap_ent, m->seg_cap_range,
                    m->cap_off, m->cap_vidx, m->region_off, m->region_vidx, m->pairs, m->pair_mask, m->pair_mask_off, m->tickets, m->canary_hits};
     for (void* p : dev)
         if (p) (void)hipFree(p);
@@ -349,6 +349,22 @@ extern "C" int tuch_contact_model_create(
                         if (rc == TUCH_OK) rc = upload(&m->seg_vpos, vpos.data(), vpos.size());
                         if (rc == TUCH_OK) rc = upload(&m->seg_cap_off, coff.data(), coff.size());
                         if (rc == TUCH_OK) rc = upload(&m->seg_cap_ent, cent.data(), cent.size());
+                        // the caps a segment's entries and links refer to: consecutive cap ids (the fused segment pass
+                        // keeps a segment's centroids in LDS), segments in order; anything else keeps the six-launch pass
+                        std::vector<int32_t> crange(1, 0);
+                        bool consecutive = true;
+                        for (int sg = 0; sg < num_segments && consecutive; ++sg) {
+                            int lo = num_caps, hi = -1;
+                            auto see = [&](int id) { if (id >= V) { lo = std::min(lo, id - V); hi = std::max(hi, id - V); } };
+                            for (int e = coff[sg]; e < coff[sg + 1]; ++e)
+                                for (int k = 0; k < 3; ++k) see(cent[3 * (size_t)e + k]);
+                            for (int q = seg_q_off[sg]; q < seg_q_off[sg + 1]; ++q)
+                                for (int e = loff[q]; e < loff[q + 1]; ++e) { see(links[2 * (size_t)e]); see(links[2 * (size_t)e + 1]); }
+                            if (hi < 0) { crange.push_back(crange.back()); continue; }
+                            consecutive = lo == crange.back() && hi - lo + 1 <= 8;
+                            crange.push_back(hi + 1);
+                        }
+                        if (rc == TUCH_OK && consecutive) rc = upload(&m->seg_cap_range, crange.data(), crange.size());
                     }
                 }
             }
@@ -404,7 +420,7 @@ const OptionName kOptions[] = {
     {"winding_strips", &tuch_options::winding_strips}, {"tree_waves", &tuch_options::tree_waves},
     {"ray_pair_cap", &tuch_options::ray_pair_cap}, {"ray_waves", &tuch_options::ray_waves},
     {"v2v_tree", &tuch_options::v2v_tree}, {"v2v_waves", &tuch_options::v2v_waves}, {"v2v_lds", &tuch_options::v2v_lds},
-    {"seg_splits", &tuch_options::seg_splits}, {"seg_assist", &tuch_options::seg_assist},
+    {"seg_splits", &tuch_options::seg_splits}, {"seg_assist", &tuch_options::seg_assist}, {"seg_fused", &tuch_options::seg_fused},
     {"canary", &tuch_options::canary}, {"deterministic", &tuch_options::deterministic},
 };
 }  // namespace

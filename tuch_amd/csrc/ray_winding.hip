@@ -1010,7 +1010,233 @@ struct RayLayout {
     size_t seg_count;        // per-segment crossing counts of the vertices (models with seg_elem_mask), zeroed with `count`
 };
 
+// ---- the whole segment filter as ONE launch (flags only, leaf-assisted models) ---------------------------------------
+// cap centroids -> sheared entries -> compaction of the interior vertices -> work items -> crossings -> cones + flags were
+// six launches (two ahead of the body test, four behind it: ~55 us of the step's serial tail at batch 64, ~25 us at batch
+// 8, for a few hundred interior vertices per body).  One workgroup per (segment, body) does all of it in LDS:
+//   A. the segment's interior vertices, compacted in list order (a scan: no atomics, the order is always the same);
+//      nothing interior -> done (most (segment, body) pairs);
+//   B. the segment's cap centroids (segmentation.py:74-76);
+//   C. the segment's cap faces and boundary edges, posed and sheared, staged in chunks; lane = vertex, entries by LDS
+//      broadcast; with <= 128 interior vertices the four wavefronts split every chunk between them;
+//   D. per vertex: + the crossings with the segment's body faces the body's own inside test has counted
+//      (seg_leaf_count), + the cones of the vertex's links; w = N - angles / 2 pi; not exterior to its own segment ->
+//      exterior in the body flags (losses.py:87-89, loss.py:265-266).
+constexpr int kSegFusedBlock = 256;
+constexpr int kSegFusedMaxQ = 1024;      // segment vertices (SMPL's largest painted segment: a few hundred)
+constexpr int kSegFusedMaxCaps = 8;
+constexpr int kSegFusedChunk = 256;      // entries staged per pass
+__global__ __launch_bounds__(kSegFusedBlock) void segment_fused_kernel(
+    const float* __restrict__ verts, uint8_t* __restrict__ exterior,
+    const int32_t* __restrict__ seg_q_off, const int32_t* __restrict__ seg_q_vidx,
+    const int32_t* __restrict__ cap_range,              // [S+1]: caps of segment s = cap_range[s] .. cap_range[s+1]
+    const int32_t* __restrict__ cap_off, const int32_t* __restrict__ cap_vidx,
+    const int32_t* __restrict__ ent_off, const int32_t* __restrict__ ent,       // cap faces + boundary edges (seg_cap_*)
+    const int32_t* __restrict__ link_off, const int32_t* __restrict__ link,
+    const int32_t* __restrict__ leaf_counts, const int32_t* __restrict__ vpos, int slots, int V, float thresh)
+{
+    __shared__ int32_t s_list[kSegFusedMaxQ];
+    __shared__ int32_t s_cross[4 * kSegFusedMaxQ];
+    __shared__ float s_half[4 * kSegFusedMaxQ];
+    __shared__ float sT[kSegFusedChunk * 9];
+    __shared__ float s_caps[kSegFusedMaxCaps * 3];
+    __shared__ int32_t s_wave[4];
+    __shared__ int32_t s_n;
+    const int sg = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float* vb = verts + (size_t)b * V * 3;
+    uint8_t* eb = exterior + (size_t)b * V;
+    const int q_beg = seg_q_off[sg], nq = seg_q_off[sg + 1] - q_beg;
+    // ---- A: compaction in list order
+    if (t == 0) s_n = 0;
+    __syncthreads();
+    for (int q0 = 0; q0 < nq; q0 += kSegFusedBlock) {
+        const int q = q0 + t;
+        const bool mine = q < nq && eb[seg_q_vidx[q_beg + q]] == 0;
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(mine);
+        if (lane == 0) s_wave[wave] = __builtin_popcountll(bal);
+        __syncthreads();
+        int base = s_n;
+        for (int w2 = 0; w2 < wave; ++w2) base += s_wave[w2];
+        if (mine) s_list[base + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = q;
+        __syncthreads();
+        if (t == 0) s_n += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    const int n = s_n;
+    if (n == 0) return;
+    // ---- B: cap centroids of this segment
+    const int c_lo = cap_range[sg], c_hi = cap_range[sg + 1];
+    for (int c = c_lo + wave; c < c_hi; c += 4) {
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        const int beg = cap_off[c], end = cap_off[c + 1];
+        for (int k = beg + lane; k < end; k += 64) {
+            const float* p = vb + 3 * cap_vidx[k];
+            sx += p[0]; sy += p[1]; sz += p[2];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { sx += __shfl_down(sx, o, 64); sy += __shfl_down(sy, o, 64); sz += __shfl_down(sz, o, 64); }
+        if (lane == 0) {
+            const float inv = 1.0f / (float)(end - beg);
+            s_caps[3 * (c - c_lo)] = sx * inv; s_caps[3 * (c - c_lo) + 1] = sy * inv; s_caps[3 * (c - c_lo) + 2] = sz * inv;
+        }
+    }
+    for (int i = t; i < 4 * n; i += kSegFusedBlock) { s_cross[i] = 0; s_half[i] = 0.0f; }
+    __syncthreads();
+    // a vertex id of the segment tables (>= V: cap vertex) -> position
+    auto pos = [&](int id, float (&o)[3]) {
+        if (id < V) { o[0] = vb[3 * (size_t)id]; o[1] = vb[3 * (size_t)id + 1]; o[2] = vb[3 * (size_t)id + 2]; }
+        else { const float* c = s_caps + 3 * (id - V - c_lo); o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; }
+    };
+    const P3 u_dir = {kFanX, kFanY, kFanZ};
+    const P3 us = {shear_x(kFanX, kFanZ), shear_y(kFanY, kFanZ), kFanZ};
+    // ---- C: crossings with cap faces, cones of the boundary edges
+    const int groups = (n + 63) >> 6;
+    const int splits = groups >= 4 ? 1 : (groups >= 2 ? 2 : 4);        // ways a chunk is shared between the wavefronts
+    const int e_beg = ent_off[sg], e_end = ent_off[sg + 1];
+    for (int chunk = e_beg; chunk < e_end; chunk += kSegFusedChunk) {
+        const int cn = min(kSegFusedChunk, e_end - chunk);
+        __syncthreads();
+        for (int i = t; i < cn; i += kSegFusedBlock) {
+            const int id[3] = {ent[3 * (size_t)(chunk + i)], ent[3 * (size_t)(chunk + i) + 1], ent[3 * (size_t)(chunk + i) + 2]};
+            float* dst = sT + i * 9;
+            const int corners = id[2] < 0 ? 2 : 3;
+            for (int k = 0; k < corners; ++k) {
+                float p[3];
+                pos(id[k], p);
+                dst[3 * k] = shear_x(p[0], p[2]); dst[3 * k + 1] = shear_y(p[1], p[2]); dst[3 * k + 2] = p[2];
+            }
+            if (corners == 2) { dst[6] = (float)id[2]; dst[7] = kConeMarker; dst[8] = 0.0f; }
+        }
+        __syncthreads();
+        for (int unit = wave; unit < groups * splits; unit += 4) {
+            const int g = unit / splits, sp = unit % splits;
+            const int k = g * 64 + lane;
+            const int v0 = seg_q_vidx[q_beg + s_list[min(k, n - 1)]];
+            const float qz = vb[3 * (size_t)v0 + 2];
+            const float qx = shear_x(vb[3 * (size_t)v0], qz), qy = shear_y(vb[3 * (size_t)v0 + 1], qz);
+            const int per = (cn + splits - 1) / splits;
+            const int f0 = sp * per, f1 = min(cn, f0 + per);
+            int crossings = 0;
+            float half_sum = 0.0f;
+            for (int f = f0; f < f1; ++f) {
+                const float* e = sT + f * 9;
+                if (e[7] != kConeMarker) {                              // a cap face (wave-uniform: LDS broadcast)
+                    const P3 a = {e[0] - qx, e[1] - qy, e[2] - qz}, bb = {e[3] - qx, e[4] - qy, e[5] - qz}, c = {e[6] - qx, e[7] - qy, e[8] - qz};
+                    const float ea = edge_fn(bb, c), eb2 = edge_fn(c, a), ec = edge_fn(a, bb);
+                    const float numz = ea * a.z + eb2 * bb.z + ec * c.z;
+                    const float mn = __builtin_fminf(__builtin_fminf(ea, eb2), ec), mx = __builtin_fmaxf(__builtin_fmaxf(ea, eb2), ec);
+                    int n1 = (int)(__builtin_fminf(mn, numz) > 0.0f) - (int)(__builtin_fmaxf(mx, numz) < 0.0f);
+                    const bool edge_zero = mn * mx == 0.0f;
+                    if (__builtin_amdgcn_ballot_w64(edge_zero)) {
+                        const bool tie = edge_zero & (numz != 0.0f);
+                        if (__builtin_amdgcn_ballot_w64(tie)) {
+                            if (tie) n1 = crossing_with_ties<true>(a, bb, c, ea, eb2, ec);
+                        }
+                    }
+                    crossings += n1;
+                } else {                                                // a boundary edge x -> y: the cone (u, x, y)
+                    const P3 bb = {e[0] - qx, e[1] - qy, e[2] - qz}, c = {e[3] - qx, e[4] - qy, e[5] - qz};
+                    const bool at_query = ((bb.x == 0.0f) & (bb.y == 0.0f) & (bb.z == 0.0f)) | ((c.x == 0.0f) & (c.y == 0.0f) & (c.z == 0.0f));
+                    if (!at_query) {
+                        const int mult = (int)e[6];
+                        const P3 pb = {__builtin_fmaf(kShearX, bb.z, bb.x), __builtin_fmaf(kShearY, bb.z, bb.y), bb.z};
+                        const P3 pc = {__builtin_fmaf(kShearX, c.z, c.x), __builtin_fmaf(kShearY, c.z, c.y), c.z};
+                        int c1;
+                        float h1;
+                        cone_term(us, bb, c, u_dir, pb, pc, c1, h1);
+                        crossings += mult * c1;
+                        half_sum += (float)mult * h1;
+                    }
+                }
+            }
+            if (k < n) { s_cross[sp * n + k] += crossings; s_half[sp * n + k] += half_sum; }       // (sp, k) has one owner
+        }
+    }
+    __syncthreads();
+    // ---- D: per vertex: body-face crossings from the body test, cones of the links, flag
+    for (int k0 = 0; k0 < n; k0 += kSegFusedBlock) {
+        const int k = k0 + t;
+        const bool active = k < n;                         // all lanes stay: long link lists are shared over the wavefront
+        const int qq = q_beg + s_list[active ? k : 0];
+        const int v = seg_q_vidx[qq];
+        int cnt = 0;
+        float half_sum = 0.0f;
+        if (active) {
+            for (int sp = 0; sp < splits; ++sp) { cnt += s_cross[sp * n + k]; half_sum += s_half[sp * n + k]; }
+            cnt += seg_leaf_count(leaf_counts + 2 * ((size_t)b * slots + vpos[v]), sg);
+        }
+        const float vx = vb[3 * (size_t)v], vy = vb[3 * (size_t)v + 1], vz = vb[3 * (size_t)v + 2];
+        const float qx = shear_x(vx, vz), qy = shear_y(vy, vz);
+        auto cone = [&](const float (&p0)[3], const float (&p1)[3], float ax, float ay, float az, float sx, float sy, float& h, int& c) {
+            const P3 pb = {p0[0] - ax, p0[1] - ay, p0[2] - az}, pc = {p1[0] - ax, p1[1] - ay, p1[2] - az};
+            const P3 sb = {shear_x(p0[0], p0[2]) - sx, shear_y(p0[1], p0[2]) - sy, p0[2] - az};
+            const P3 sc = {shear_x(p1[0], p1[2]) - sx, shear_y(p1[1], p1[2]) - sy, p1[2] - az};
+            int c1;
+            float h1;
+            cone_term(us, sb, sc, u_dir, pb, pc, c1, h1);
+            h += h1;
+            c += c1;
+        };
+        const int e0 = active ? link_off[qq] : 0, e1 = active ? link_off[qq + 1] : 0;
+        constexpr int kLongLinks = 16;
+        if (e1 - e0 <= kLongLinks) {
+            for (int e = e0; e < e1; e += 2) {             // two links at a time: their four corners are fetched together
+                int id[4];
+                float pp[4][3];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) id[u] = link[2 * min(e + (u >> 1), e1 - 1) + (u & 1)];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) pos(id[u], pp[u]);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    if (e + h < e1) cone(pp[2 * h], pp[2 * h + 1], vx, vy, vz, qx, qy, half_sum, cnt);
+            }
+        }
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(e1 - e0 > kLongLinks);
+        while (todo) {
+            const int src = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int le0 = __builtin_amdgcn_readlane(e0, src), le1 = __builtin_amdgcn_readlane(e1, src);
+            const float lvx = __shfl(vx, src), lvy = __shfl(vy, src), lvz = __shfl(vz, src);
+            const float lqx = __shfl(qx, src), lqy = __shfl(qy, src);
+            float h = 0.0f;
+            int cr = 0;
+            for (int e = le0 + lane; e < le1; e += 64) {
+                float a0[3], a1[3];
+                pos(link[2 * e], a0);
+                pos(link[2 * e + 1], a1);
+                cone(a0, a1, lvx, lvy, lvz, lqx, lqy, h, cr);
+            }
+#pragma unroll
+            for (int m2 = 32; m2 >= 1; m2 >>= 1) { h += __shfl_xor(h, m2); cr += __shfl_xor(cr, m2); }
+            if (lane == src) { half_sum += h; cnt += cr; }
+        }
+        if (active) {
+            const float w = (float)cnt - half_sum * (0.5f / kPi);
+            if (!(w <= thresh)) eb[v] = 1;
+        }
+    }
+}
+
 }  // namespace
+
+// can the segment filter run as the one fused launch?  (flags only; the caller checks that)
+bool tuch_ray_segment_fused_available(const tuch_contact_model* m)
+{
+    return m && m->seg_cap_off && m->seg_cap_range && m->seg_elem_mask && m->seg_q_max <= kSegFusedMaxQ && m->opt.seg_fused != 0;
+}
+
+// exterior [B,V] in/out; leaf_counts = tuch_ray_segment_counts of the SAME vertices
+int tuch_ray_segment_flags_fused(const tuch_contact_model* m, const float* verts, const int32_t* leaf_counts, int B,
+                                 float thresh, uint8_t* exterior, hipStream_t s)
+{
+    hipLaunchKernelGGL(segment_fused_kernel, dim3(m->num_segments, B), dim3(kSegFusedBlock), 0, s, verts, exterior,
+                       (const int32_t*)m->seg_q_off, (const int32_t*)m->seg_q_vidx, (const int32_t*)m->seg_cap_range,
+                       (const int32_t*)m->cap_off, (const int32_t*)m->cap_vidx, (const int32_t*)m->seg_cap_off,
+                       (const int32_t*)m->seg_cap_ent, (const int32_t*)m->seg_link_off, (const int32_t*)m->seg_link,
+                       leaf_counts, (const int32_t*)m->seg_vpos, 2 * m->tree_qblocks * kRayQueries, m->V, thresh);
+    return tuch_check_launch("tuch_ray_segment_flags_fused");
+}
 
 bool tuch_ray_available(const tuch_contact_model* m)
 {

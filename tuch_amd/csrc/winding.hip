@@ -1000,7 +1000,10 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
     const bool segments = apply_segments && m->num_segments > 0;
     const bool body_by_rays = ray == 2 || (ray == 1 && !w);
     const bool segments_by_rays = segments && m->seg_link_off && (ray == 2 || (ray == 1 && !seg_w));
-    if (segments) {
+    // flags only, by rays, leaf-assisted: the whole segment filter is one launch behind the body test (ray_winding.hip)
+    const bool segments_fused = segments && segments_by_rays && body_by_rays && !seg_w && !seg_exterior &&
+                                tuch_ray_segment_fused_available(m);
+    if (segments && !segments_fused) {
         // what the segment pass needs of the vertices alone goes first, off the critical chain behind the body test
         if (m->num_caps > 0) {
             hipLaunchKernelGGL(cap_centroid_kernel, dim3(m->num_caps, B), dim3(64), 0, s,
@@ -1041,7 +1044,10 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
                                   l.bounds - l.partial, stream);
         if (rc != TUCH_OK) return rc;
     }
-    if (segments) {
+    if (segments_fused) {
+        rc = tuch_ray_segment_flags_fused(m, verts, tuch_ray_segment_counts(m, B, ws + l.ray), B, thresh, exterior, s);
+        if (rc != TUCH_OK) return rc;
+    } else if (segments) {
         float* caps = (float*)(ws + l.caps);
         float* seg_tris = (float*)(ws + l.seg_tris);
         float* seg_partial = (float*)(ws + l.seg_partial);

@@ -354,34 +354,30 @@ class _Stage2Tail(torch.autograd.Function):
         exterior, _, partner, _extra = model.exterior_and_partner(v, apply_segments=const['apply_segments'],
                                                                   also=beside_the_walk)
         out = torch.empty(1, dtype=torch.float32, device=v.device)
-        share = torch.empty(b, dtype=torch.float32, device=v.device)
-        _C.check(L.tuch_smplify_stage2_finish(_C.ptr(v), _C.ptr(partner), _C.ptr(exterior), _C.ptr(valid), b, v.shape[1],
-                                              MODE_SMPLIFY, float(const['euclthres']), _C.ptr(small), _C.ptr(r2r), p,
-                                              float(const['contact_scale']), float(const['r2r_scale']), _C.ptr(share),
-                                              _C.ptr(_extra[7]), None, _C.ptr(out), _C.stream()))
-        ctx.save_for_backward(v, partner, exterior, valid, ij, gj, gc, gp)
-        ctx.model, ctx.const, ctx.dims = model, const, (b, nj, p)
+        share = torch.empty(L.tuch_smplify_stage2_fused_scratch_floats(b), dtype=torch.float32, device=v.device)
+        # the objective is the root of the fit's graph: its vertex gradient for a unit upstream gradient is written by the
+        # same launch that forms the sums (csrc/contact_terms.hip: stage2_fused_kernel); backward() only hands it over
+        want_grad = any(ctx.needs_input_grad[:4])
+        gv = _extra[6] if want_grad else None
+        _C.check(L.tuch_smplify_stage2_fused(_C.ptr(v), _C.ptr(partner), _C.ptr(exterior), _C.ptr(valid), b, v.shape[1],
+                                             MODE_SMPLIFY, float(const['euclthres']), _C.ptr(small), _C.ptr(r2r), _C.ptr(ij), p,
+                                             float(const['contact_scale']), float(const['r2r_scale']), _C.ptr(share),
+                                             _C.ptr(_extra[7]), None, _C.ptr(out), _C.ptr(gv), _C.stream()))
+        if want_grad:
+            ctx.save_for_backward(gv, gj, gc, gp)
         ctx.in_dtypes = (verts.dtype, joints.dtype, camera_t.dtype, body_pose.dtype)
-        ctx.gv_cleared = _extra[6]
         return out[0]
 
     @staticmethod
     def backward(ctx, g):
-        v, partner, exterior, valid, ij, gj, gc, gp = ctx.saved_tensors
-        b, nj, p = ctx.dims
-        const, L = ctx.const, _C.lib()
-        g = g.reshape(1).to(torch.float32).contiguous()
-        gj_o, gc_o, gp_o = torch.empty_like(gj), torch.empty_like(gc), torch.empty_like(gp)
-        gv, ctx.gv_cleared = ctx.gv_cleared, None
-        if gv is None:                           # a second backward pass through the same node
-            gv = torch.zeros_like(v)
-        _C.check(L.tuch_smplify_stage2_bwd(_C.ptr(g), _C.ptr(valid), _C.ptr(v), _C.ptr(partner), _C.ptr(exterior), b,
-                                           v.shape[1], MODE_SMPLIFY, float(const['euclthres']),
-                                           float(const['contact_scale']), _C.ptr(ij), p, float(const['r2r_scale']),
-                                           _C.ptr(gj), _C.ptr(gc), _C.ptr(gp), nj, _C.ptr(gv), _C.ptr(gj_o), _C.ptr(gc_o),
-                                           _C.ptr(gp_o), _C.stream()))
+        gv, gj, gc, gp = ctx.saved_tensors
         dv, dj, dc, dp = ctx.in_dtypes
-        return gv.to(dv), gj_o.to(dj), gc_o.to(dc), gp_o.to(dp), None, None, None, None
+        # loss.backward() through ops.backward_scalar seeds the graph with a cached tensor of ones: recognised by its
+        # address (no device round trip).  Any other upstream gradient scales the unit gradients.
+        if not any(g.data_ptr() == seed.data_ptr() for seed in _ONES.values()):
+            g = g.reshape(()).to(torch.float32)
+            gv, gj, gc, gp = gv * g, gj * g, gc * g, gp * g
+        return gv.to(dv), gj.to(dj), gc.to(dc), gp.to(dp), None, None, None, None
 
 
 def smplify_stage2_tail(verts, joints, camera_t, body_pose, model, valid_u8, select_u8, **const):

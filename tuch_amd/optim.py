@@ -1,0 +1,75 @@
+"""Adam for the handful of small tensors an SMPLify-DC loop optimises, as ONE kernel launch (csrc/adam.hip).
+
+The reference uses ``torch.optim.Adam`` (tuch/smplify/smplifydc.py:117,150); its capturable implementations take two to
+three launches per step, at the very end of every iteration's serial chain.  Same update rule (no weight decay, no
+amsgrad), step counter on the device, so a step is capturable in a hipGraph.  Parameters must be float32 HIP tensors of
+at most 65536 elements in total, at most 8 of them -- anything else: use torch.optim.Adam.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _C
+
+
+class Adam:
+    """Drop-in for the subset of torch.optim.Adam the fitting loops use: ``Adam(params, lr, betas)``, ``step()``,
+    ``zero_grad(set_to_none)``, ``state`` (per parameter: ``exp_avg``, ``exp_avg_sq``; plus the shared device ``step``)."""
+
+    MAX_TENSORS, MAX_ELEMENTS = 8, 65536
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, **unused):
+        self.params = list(params)
+        if not 0 < len(self.params) <= self.MAX_TENSORS or sum(p.numel() for p in self.params) > self.MAX_ELEMENTS:
+            raise ValueError('tuch_amd.optim.Adam is for a few small tensors; use torch.optim.Adam')
+        for p in self.params:
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                raise ValueError('tuch_amd.optim.Adam needs contiguous float32 HIP tensors')
+        self.lr, self.eps = float(lr), float(eps)
+        dev = self.params[0].device
+        self.step_count = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.state = {p: {'exp_avg': torch.zeros_like(p), 'exp_avg_sq': torch.zeros_like(p), 'step': self.step_count}
+                      for p in self.params}
+        n = len(self.params)
+        self._betas = (ctypes.c_float * (2 * n))(*[float(b) for _ in range(n) for b in betas])
+        self._sizes = (ctypes.c_int * n)(*[p.numel() for p in self.params])
+        ptrs = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+        self._p = ptrs(self.params)
+        self._m = ptrs([self.state[p]['exp_avg'] for p in self.params])
+        self._v = ptrs([self.state[p]['exp_avg_sq'] for p in self.params])
+        self.param_groups = [{'params': self.params, 'lr': self.lr, 'betas': tuple(betas), 'eps': self.eps}]
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        for p in self.params:
+            if p.grad is not None:
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.zero_()
+
+    def reset(self) -> None:
+        """A fresh optimiser (the reference creates one per stage and call): moments and step counter zeroed in place."""
+        torch._foreach_zero_([self.step_count] + [s[k] for s in self.state.values() for k in ('exp_avg', 'exp_avg_sq')])
+
+    def step(self) -> None:
+        grads = []
+        for p in self.params:
+            if p.grad is None:
+                raise RuntimeError('tuch_amd.optim.Adam.step: a parameter has no gradient')
+            grads.append(p.grad if p.grad.is_contiguous() else p.grad.contiguous())
+        n = len(self.params)
+        g = (ctypes.c_void_p * n)(*[t.data_ptr() for t in grads])
+        _C.check(_C.lib().tuch_adam_step(n, self._p, g, self._m, self._v, self._sizes, self._betas,
+                                         _C.ptr(self.step_count), self.lr, self.eps, _C.stream()))
+
+
+def make_adam(params, lr, capturable=True, **adam_kwargs):
+    """tuch_amd.optim.Adam where it applies (HIP float32 parameters, few and small), else torch.optim.Adam."""
+    params = list(params)
+    try:
+        return Adam(params, lr=lr, **adam_kwargs)
+    except ValueError:
+        return torch.optim.Adam(params, lr=lr, capturable=capturable and params[0].is_cuda, **adam_kwargs)

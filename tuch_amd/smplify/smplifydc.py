@@ -20,6 +20,7 @@ from .losses import (body_fitting_loss, camera_fitting_loss, contact_fitting_los
                      stage2_objective)
 from .prior import MaxMixturePrior
 from .. import ops
+from ..optim import make_adam
 
 log = logging.getLogger(__name__)
 
@@ -90,7 +91,8 @@ class SMPLifyDC():
     def _optimise(self, params, iteration, num_iters, adam_kwargs, collect=None, stage=''):
         """Run ``num_iters`` Adam iterations of ``iteration()`` (which returns (loss, vertices))."""
         graph_ok = self.use_graph and params[0].is_cuda and num_iters > 4
-        optimizer = torch.optim.Adam(params, lr=self.step_size, capturable=graph_ok, **adam_kwargs)
+        # torch.optim.Adam's update as one launch where it applies (tuch_amd/optim.py), else torch's own
+        optimizer = make_adam(params, self.step_size, capturable=graph_ok, **adam_kwargs)
         static = {}
         history = self.history[stage] if self.record_history else None
 
@@ -154,7 +156,7 @@ class SMPLifyDC():
 
         def __init__(self, owner, name, params, iteration, adam_kwargs):
             self.owner, self.name, self.params, self.iteration = owner, name, params, iteration
-            self.optimizer = torch.optim.Adam(params, lr=owner.step_size, capturable=True, **adam_kwargs)
+            self.optimizer = make_adam(params, owner.step_size, capturable=True, **adam_kwargs)
             self.graph, self.verts, self.loss = None, None, None
 
         def _one(self):
