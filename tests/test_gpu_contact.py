@@ -863,7 +863,7 @@ def test_fused_segment_filter_matches_the_six_launch_pass(tag):
     batch = 6 if tag in FULL else 11
     g, verts = _posed_batch(tag, batch, 31, scale=1.3)
     model = make_model(g, None, True, False)
-    assert model.get_option('seg_fused') == 1
+    assert model.get_option('seg_fused') == 1 and model.get_option('seg_fused_active') == 1
     plain = model.exterior_flags(verts, apply_segments=False)
     fused = model.exterior_flags(verts, apply_segments=True)
     model.set_option('seg_fused', 0)

@@ -58,15 +58,17 @@ bool tuch_ray_available(const tuch_contact_model* m);
 void tuch_ray_layout_touch(const tuch_contact_model* m, int B, int Q);
 size_t tuch_ray_workspace_bytes(const tuch_contact_model* m, int B, int Q);
 int tuch_ray_exterior_verts(const tuch_contact_model* m, const float* verts, int B, float thresh, uint8_t* exterior,
-                            float* w, void* workspace, hipStream_t s, unsigned long long* stats_host);
+                            float* w, void* workspace, hipStream_t s, unsigned long long* stats_host,
+                            uint8_t* exterior_copy = nullptr);
 // crossings of every vertex with the body faces of each of its segments, [B][tree_qblocks*128][8], left in the
 // workspace of tuch_ray_exterior_verts by a model with seg_elem_mask
 const int32_t* tuch_ray_segment_counts(const tuch_contact_model* m, int B, const void* workspace);
 void tuch_ray_segment_prepare(const tuch_contact_model* m, const float* verts, const float* caps, int assisted, int B,
                               float* seg_entries, hipStream_t s);
 bool tuch_ray_segment_fused_available(const tuch_contact_model* m);
-int tuch_ray_segment_flags_fused(const tuch_contact_model* m, const float* verts, const int32_t* leaf_counts, int B,
-                                 float thresh, uint8_t* exterior, hipStream_t s);
+int tuch_ray_segment_flags_fused(const tuch_contact_model* m, const float* verts, const uint8_t* body_flags,
+                                 const int32_t* leaf_counts, int B, float thresh, int32_t* seg_partial, uint8_t* exterior,
+                                 hipStream_t s);
 int tuch_ray_segment_flags(const tuch_contact_model* m, const float* verts, const float* caps, const int32_t* seg_count,
                            const int32_t* seg_list, const int32_t* leaf_counts, int B, int nsplit, float thresh, float* seg_tris,
                            int32_t* seg_partial, float* seg_w, uint8_t* seg_ext, uint8_t* exterior, hipStream_t s);

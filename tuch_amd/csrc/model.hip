@@ -466,6 +466,10 @@ extern "C" int tuch_contact_model_canary_hits(const tuch_contact_model* m, int* 
 extern "C" int tuch_contact_model_get_option(const tuch_contact_model* m, const char* name, int* value)
 {
     TUCH_REQUIRE(m && name && value, "tuch_contact_model_get_option: null argument");
+    if (!strcmp(name, "seg_fused_active")) {        // read-only: does the segment filter run as the one fused launch?
+        *value = tuch_ray_segment_fused_available(m) ? 1 : 0;
+        return TUCH_OK;
+    }
     for (const OptionName& k : kOptions)
         if (!strcmp(k.name, name)) {
             *value = m->opt.*(k.field);

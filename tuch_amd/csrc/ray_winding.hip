@@ -637,8 +637,9 @@ __device__ __forceinline__ void cone_term(const P3& us, const P3& sb, const P3& 
 __global__ __launch_bounds__(kBlock) void ray_finalize_verts_kernel(
     const float* __restrict__ verts, const int32_t* __restrict__ count, const int32_t* __restrict__ qperm,
     const int32_t* __restrict__ ring_off, const int32_t* __restrict__ ring_vidx,
-    int V, int stride, float thresh, float* __restrict__ w_out, uint8_t* __restrict__ exterior)
-{
+    int V, int stride, float thresh, float* __restrict__ w_out, uint8_t* __restrict__ exterior,
+    uint8_t* __restrict__ exterior_copy)                 // or nullptr: the same flags once more (the segment filter reads
+{                                                        // them while it re-marks `exterior`)
     const int b = blockIdx.y;
     const int i = blockIdx.x * kBlock + threadIdx.x;     // position in tree order
     const bool real = i < V;                             // all lanes stay: long rings below need the whole wavefront
@@ -712,11 +713,13 @@ __global__ __launch_bounds__(kBlock) void ray_finalize_verts_kernel(
         for (int m = 32; m >= 1; m >>= 1) { h += __shfl_xor(h, m); cr += __shfl_xor(cr, m); }
         if (lane == src) { half_sum = h; n += cr; }
     }
-    if (!real) return;
     const float w = (float)n - half_sum * (0.5f / kPi);
     const size_t o = (size_t)b * V + v;
-    if (w_out) w_out[o] = w;
-    if (exterior) exterior[o] = w <= thresh;
+    if (real) {
+        if (w_out) w_out[o] = w;
+        if (exterior) exterior[o] = w <= thresh;
+        if (exterior_copy) exterior_copy[o] = w <= thresh;
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void ray_finalize_points_kernel(
@@ -1010,63 +1013,65 @@ struct RayLayout {
     size_t seg_count;        // per-segment crossing counts of the vertices (models with seg_elem_mask), zeroed with `count`
 };
 
-// ---- the whole segment filter as ONE launch (flags only, leaf-assisted models) ---------------------------------------
+// ---- the segment filter in TWO launches behind the body test (flags only, leaf-assisted models) ---------------------
 // cap centroids -> sheared entries -> compaction of the interior vertices -> work items -> crossings -> cones + flags were
-// six launches (two ahead of the body test, four behind it: ~55 us of the step's serial tail at batch 64, ~25 us at batch
-// 8, for a few hundred interior vertices per body).  One workgroup per (segment, body) does all of it in LDS:
-//   A. the segment's interior vertices, compacted in list order (a scan: no atomics, the order is always the same);
-//      nothing interior -> done (most (segment, body) pairs);
-//   B. the segment's cap centroids (segmentation.py:74-76);
-//   C. the segment's cap faces and boundary edges, posed and sheared, staged in chunks; lane = vertex, entries by LDS
-//      broadcast; with <= 128 interior vertices the four wavefronts split every chunk between them;
-//   D. per vertex: + the crossings with the segment's body faces the body's own inside test has counted
-//      (seg_leaf_count), + the cones of the vertex's links; w = N - angles / 2 pi; not exterior to its own segment ->
-//      exterior in the body flags (losses.py:87-89, loss.py:265-266).
+// six launches (two ahead of the body test, four behind it: ~60 us of the step's serial chain at batch 64 for a few
+// hundred interior vertices per body).  Now:
+//   segment_cross_kernel, one workgroup per (segment, body, slice of the segment's cap faces / boundary edges):
+//     A. the segment's interior vertices (by the BODY test's flags, which nobody writes meanwhile), compacted in list
+//        order by a scan -- no atomics, the same list in every workgroup of the (segment, body); none -> done;
+//     B. the segment's cap centroids (segmentation.py:74-76) in LDS;
+//     C. its slice of the entries, posed and sheared, in LDS; lane = vertex, entries by LDS broadcast; crossings and the
+//        boundary cones' half angles per (slice, vertex) to the workspace.
+//   segment_flags_kernel, one workgroup per (segment, body): A and B again (cheaper than passing them on), then per
+//     interior vertex: the slices' sums + the crossings with the segment's body faces the body's own inside test has
+//     counted (seg_leaf_count) + the cones of the vertex's links; w = N - angles / 2 pi; not exterior to its own segment
+//     -> exterior in the body flags (losses.py:87-89, loss.py:265-266).
+// (One launch with everything in one workgroup per (segment, body) was tried first: 81 us -- a body whose arm lies in its
+// trunk puts ~300 interior vertices x ~400 entries on one workgroup while 400 of the 512 have nothing to do.)
 constexpr int kSegFusedBlock = 256;
-constexpr int kSegFusedMaxQ = 1024;      // segment vertices (SMPL's largest painted segment: a few hundred)
+constexpr int kSegFusedWaves = kSegFusedBlock / 64;
+constexpr int kSegFusedMaxQ = 4096;      // vertices of one segment (the synthetic head: ~1150)
 constexpr int kSegFusedMaxCaps = 8;
-constexpr int kSegFusedChunk = 256;      // entries staged per pass
-__global__ __launch_bounds__(kSegFusedBlock) void segment_fused_kernel(
-    const float* __restrict__ verts, uint8_t* __restrict__ exterior,
-    const int32_t* __restrict__ seg_q_off, const int32_t* __restrict__ seg_q_vidx,
-    const int32_t* __restrict__ cap_range,              // [S+1]: caps of segment s = cap_range[s] .. cap_range[s+1]
-    const int32_t* __restrict__ cap_off, const int32_t* __restrict__ cap_vidx,
-    const int32_t* __restrict__ ent_off, const int32_t* __restrict__ ent,       // cap faces + boundary edges (seg_cap_*)
-    const int32_t* __restrict__ link_off, const int32_t* __restrict__ link,
-    const int32_t* __restrict__ leaf_counts, const int32_t* __restrict__ vpos, int slots, int V, float thresh)
+constexpr int kSegFusedSlices = 16;      // = kSegSplits of winding.hip: the partial arrays have room for 16
+constexpr int kSegFusedChunk = 128;      // entries staged per pass (a slice is usually shorter)
+
+// A: interior vertices of segment sg (positions in its vertex list) -> s_list, count returned (uniform).  All of a
+// thread's flags are requested before the first is looked at (the rounds of the scan then only touch LDS).
+__device__ __forceinline__ int seg_fused_compact(const uint8_t* __restrict__ flags_b, const int32_t* __restrict__ seg_q_vidx,
+                                                 int q_beg, int nq, int32_t* s_list, int32_t* s_wave, int32_t* s_n)
 {
-    __shared__ int32_t s_list[kSegFusedMaxQ];
-    __shared__ int32_t s_cross[4 * kSegFusedMaxQ];
-    __shared__ float s_half[4 * kSegFusedMaxQ];
-    __shared__ float sT[kSegFusedChunk * 9];
-    __shared__ float s_caps[kSegFusedMaxCaps * 3];
-    __shared__ int32_t s_wave[4];
-    __shared__ int32_t s_n;
-    const int sg = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const float* vb = verts + (size_t)b * V * 3;
-    uint8_t* eb = exterior + (size_t)b * V;
-    const int q_beg = seg_q_off[sg], nq = seg_q_off[sg + 1] - q_beg;
-    // ---- A: compaction in list order
-    if (t == 0) s_n = 0;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    constexpr int kRounds = kSegFusedMaxQ / kSegFusedBlock;
+    uint32_t interior = 0;                                  // bit r: vertex r * block + t is interior
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+        const int q = r * kSegFusedBlock + t;
+        if (q < nq && flags_b[seg_q_vidx[q_beg + q]] == 0) interior |= 1u << r;
+    }
+    if (t == 0) *s_n = 0;
     __syncthreads();
-    for (int q0 = 0; q0 < nq; q0 += kSegFusedBlock) {
-        const int q = q0 + t;
-        const bool mine = q < nq && eb[seg_q_vidx[q_beg + q]] == 0;
+    for (int r = 0; r * kSegFusedBlock < nq; ++r) {
+        const bool mine = (interior >> r) & 1u;
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(mine);
         if (lane == 0) s_wave[wave] = __builtin_popcountll(bal);
         __syncthreads();
-        int base = s_n;
+        int base = *s_n;
         for (int w2 = 0; w2 < wave; ++w2) base += s_wave[w2];
-        if (mine) s_list[base + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = q;
+        if (mine) s_list[base + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = r * kSegFusedBlock + t;
         __syncthreads();
-        if (t == 0) s_n += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        if (t == 0) { int add = 0; for (int w2 = 0; w2 < kSegFusedWaves; ++w2) add += s_wave[w2]; *s_n += add; }
         __syncthreads();
     }
-    const int n = s_n;
-    if (n == 0) return;
-    // ---- B: cap centroids of this segment
-    const int c_lo = cap_range[sg], c_hi = cap_range[sg + 1];
-    for (int c = c_lo + wave; c < c_hi; c += 4) {
+    return *s_n;
+}
+
+// B: cap centroids of the caps c_lo .. c_hi -> s_caps
+__device__ __forceinline__ void seg_fused_caps(const float* __restrict__ vb, const int32_t* __restrict__ cap_off,
+                                               const int32_t* __restrict__ cap_vidx, int c_lo, int c_hi, float* s_caps)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = c_lo + wave; c < c_hi; c += kSegFusedWaves) {
         float sx = 0.f, sy = 0.f, sz = 0.f;
         const int beg = cap_off[c], end = cap_off[c + 1];
         for (int k = beg + lane; k < end; k += 64) {
@@ -1080,45 +1085,62 @@ __global__ __launch_bounds__(kSegFusedBlock) void segment_fused_kernel(
             s_caps[3 * (c - c_lo)] = sx * inv; s_caps[3 * (c - c_lo) + 1] = sy * inv; s_caps[3 * (c - c_lo) + 2] = sz * inv;
         }
     }
-    for (int i = t; i < 4 * n; i += kSegFusedBlock) { s_cross[i] = 0; s_half[i] = 0.0f; }
-    __syncthreads();
-    // a vertex id of the segment tables (>= V: cap vertex) -> position
-    auto pos = [&](int id, float (&o)[3]) {
-        if (id < V) { o[0] = vb[3 * (size_t)id]; o[1] = vb[3 * (size_t)id + 1]; o[2] = vb[3 * (size_t)id + 2]; }
-        else { const float* c = s_caps + 3 * (id - V - c_lo); o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; }
-    };
+}
+
+__global__ __launch_bounds__(kSegFusedBlock) void segment_cross_kernel(
+    const float* __restrict__ verts, const uint8_t* __restrict__ body_flags,
+    const int32_t* __restrict__ seg_q_off, const int32_t* __restrict__ seg_q_vidx,
+    const int32_t* __restrict__ cap_range, const int32_t* __restrict__ cap_off, const int32_t* __restrict__ cap_vidx,
+    const int32_t* __restrict__ ent_off, const int32_t* __restrict__ ent,       // cap faces + boundary edges (seg_cap_*)
+    int V, int Qs_total, int32_t* __restrict__ partial, float* __restrict__ partial_half)      // [B][slices][Qs_total]
+{
+    __shared__ int32_t s_list[kSegFusedMaxQ];
+    __shared__ float sT[kSegFusedChunk * 9];
+    __shared__ float s_caps[kSegFusedMaxCaps * 3];
+    __shared__ int32_t s_wave[kSegFusedWaves];
+    __shared__ int32_t s_n;
+    const int sg = blockIdx.x, b = blockIdx.y, z = blockIdx.z, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float* vb = verts + (size_t)b * V * 3;
+    const int q_beg = seg_q_off[sg], nq = seg_q_off[sg + 1] - q_beg;
+    const int e_seg = ent_off[sg], e_cnt = ent_off[sg + 1] - e_seg;
+    const int per = (e_cnt + kSegFusedSlices - 1) / kSegFusedSlices;
+    const int e_beg = e_seg + z * per, e_end = min(e_seg + e_cnt, e_beg + per);
+    const int n = seg_fused_compact(body_flags + (size_t)b * V, seg_q_vidx, q_beg, nq, s_list, s_wave, &s_n);
+    if (n == 0) return;
+    const size_t out = ((size_t)b * kSegFusedSlices + z) * Qs_total + q_beg;
+    if (e_beg >= e_end) {                                  // an empty slice still owns its row of the partial arrays
+        for (int k = t; k < n; k += kSegFusedBlock) { partial[out + k] = 0; partial_half[out + k] = 0.0f; }
+        return;
+    }
+    const int c_lo = cap_range[sg];
+    seg_fused_caps(vb, cap_off, cap_vidx, c_lo, cap_range[sg + 1], s_caps);
     const P3 u_dir = {kFanX, kFanY, kFanZ};
     const P3 us = {shear_x(kFanX, kFanZ), shear_y(kFanY, kFanZ), kFanZ};
-    // ---- C: crossings with cap faces, cones of the boundary edges
     const int groups = (n + 63) >> 6;
-    const int splits = groups >= 4 ? 1 : (groups >= 2 ? 2 : 4);        // ways a chunk is shared between the wavefronts
-    const int e_beg = ent_off[sg], e_end = ent_off[sg + 1];
-    for (int chunk = e_beg; chunk < e_end; chunk += kSegFusedChunk) {
-        const int cn = min(kSegFusedChunk, e_end - chunk);
-        __syncthreads();
-        for (int i = t; i < cn; i += kSegFusedBlock) {
-            const int id[3] = {ent[3 * (size_t)(chunk + i)], ent[3 * (size_t)(chunk + i) + 1], ent[3 * (size_t)(chunk + i) + 2]};
-            float* dst = sT + i * 9;
-            const int corners = id[2] < 0 ? 2 : 3;
-            for (int k = 0; k < corners; ++k) {
-                float p[3];
-                pos(id[k], p);
-                dst[3 * k] = shear_x(p[0], p[2]); dst[3 * k + 1] = shear_y(p[1], p[2]); dst[3 * k + 2] = p[2];
+    for (int g0 = 0; g0 < groups; g0 += kSegFusedWaves) {  // (usually one round: <= 256 interior vertices)
+        const int k = (g0 + wave) * 64 + lane;
+        const bool have = g0 + wave < groups;
+        const int v0 = seg_q_vidx[q_beg + s_list[min(k, n - 1)]];
+        const float qz = vb[3 * (size_t)v0 + 2];
+        const float qx = shear_x(vb[3 * (size_t)v0], qz), qy = shear_y(vb[3 * (size_t)v0 + 1], qz);
+        int crossings = 0;
+        float half_sum = 0.0f;
+        for (int chunk = e_beg; chunk < e_end; chunk += kSegFusedChunk) {
+            const int cn = min(kSegFusedChunk, e_end - chunk);
+            __syncthreads();
+            for (int i = t; i < cn; i += kSegFusedBlock) {
+                const int id[3] = {ent[3 * (size_t)(chunk + i)], ent[3 * (size_t)(chunk + i) + 1], ent[3 * (size_t)(chunk + i) + 2]};
+                float* dst = sT + i * 9;
+                const int corners = id[2] < 0 ? 2 : 3;
+                for (int c = 0; c < corners; ++c) {
+                    const float* p = id[c] < V ? vb + 3 * (size_t)id[c] : s_caps + 3 * (id[c] - V - c_lo);
+                    dst[3 * c] = shear_x(p[0], p[2]); dst[3 * c + 1] = shear_y(p[1], p[2]); dst[3 * c + 2] = p[2];
+                }
+                if (corners == 2) { dst[6] = (float)id[2]; dst[7] = kConeMarker; dst[8] = 0.0f; }
             }
-            if (corners == 2) { dst[6] = (float)id[2]; dst[7] = kConeMarker; dst[8] = 0.0f; }
-        }
-        __syncthreads();
-        for (int unit = wave; unit < groups * splits; unit += 4) {
-            const int g = unit / splits, sp = unit % splits;
-            const int k = g * 64 + lane;
-            const int v0 = seg_q_vidx[q_beg + s_list[min(k, n - 1)]];
-            const float qz = vb[3 * (size_t)v0 + 2];
-            const float qx = shear_x(vb[3 * (size_t)v0], qz), qy = shear_y(vb[3 * (size_t)v0 + 1], qz);
-            const int per = (cn + splits - 1) / splits;
-            const int f0 = sp * per, f1 = min(cn, f0 + per);
-            int crossings = 0;
-            float half_sum = 0.0f;
-            for (int f = f0; f < f1; ++f) {
+            __syncthreads();
+            if (!have) continue;
+            for (int f = 0; f < cn; ++f) {
                 const float* e = sT + f * 9;
                 if (e[7] != kConeMarker) {                              // a cap face (wave-uniform: LDS broadcast)
                     const P3 a = {e[0] - qx, e[1] - qy, e[2] - qz}, bb = {e[3] - qx, e[4] - qy, e[5] - qz}, c = {e[6] - qx, e[7] - qy, e[8] - qz};
@@ -1149,11 +1171,38 @@ __global__ __launch_bounds__(kSegFusedBlock) void segment_fused_kernel(
                     }
                 }
             }
-            if (k < n) { s_cross[sp * n + k] += crossings; s_half[sp * n + k] += half_sum; }       // (sp, k) has one owner
         }
+        if (have && k < n) { partial[out + k] = crossings; partial_half[out + k] = half_sum; }
     }
+}
+
+__global__ __launch_bounds__(kSegFusedBlock) void segment_flags_kernel(
+    const float* __restrict__ verts, const uint8_t* __restrict__ body_flags, uint8_t* __restrict__ exterior,
+    const int32_t* __restrict__ seg_q_off, const int32_t* __restrict__ seg_q_vidx,
+    const int32_t* __restrict__ cap_range, const int32_t* __restrict__ cap_off, const int32_t* __restrict__ cap_vidx,
+    const int32_t* __restrict__ link_off, const int32_t* __restrict__ link,
+    const int32_t* __restrict__ partial, const float* __restrict__ partial_half,
+    const int32_t* __restrict__ leaf_counts, const int32_t* __restrict__ vpos, int slots, int V, int Qs_total, float thresh)
+{
+    __shared__ int32_t s_list[kSegFusedMaxQ];
+    __shared__ float s_caps[kSegFusedMaxCaps * 3];
+    __shared__ int32_t s_wave[kSegFusedWaves];
+    __shared__ int32_t s_n;
+    const int sg = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63;
+    const float* vb = verts + (size_t)b * V * 3;
+    uint8_t* eb = exterior + (size_t)b * V;
+    const int q_beg = seg_q_off[sg], nq = seg_q_off[sg + 1] - q_beg;
+    const int n = seg_fused_compact(body_flags + (size_t)b * V, seg_q_vidx, q_beg, nq, s_list, s_wave, &s_n);
+    if (n == 0) return;
+    const int c_lo = cap_range[sg];
+    seg_fused_caps(vb, cap_off, cap_vidx, c_lo, cap_range[sg + 1], s_caps);
     __syncthreads();
-    // ---- D: per vertex: body-face crossings from the body test, cones of the links, flag
+    auto pos = [&](int id, float (&o)[3]) {                // a vertex id of the segment tables (>= V: cap vertex)
+        const float* p = id < V ? vb + 3 * (size_t)id : s_caps + 3 * (id - V - c_lo);
+        o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+    };
+    const P3 u_dir = {kFanX, kFanY, kFanZ};
+    const P3 us = {shear_x(kFanX, kFanZ), shear_y(kFanY, kFanZ), kFanZ};
     for (int k0 = 0; k0 < n; k0 += kSegFusedBlock) {
         const int k = k0 + t;
         const bool active = k < n;                         // all lanes stay: long link lists are shared over the wavefront
@@ -1162,7 +1211,11 @@ __global__ __launch_bounds__(kSegFusedBlock) void segment_fused_kernel(
         int cnt = 0;
         float half_sum = 0.0f;
         if (active) {
-            for (int sp = 0; sp < splits; ++sp) { cnt += s_cross[sp * n + k]; half_sum += s_half[sp * n + k]; }
+            for (int z = 0; z < kSegFusedSlices; ++z) {
+                const size_t o = ((size_t)b * kSegFusedSlices + z) * Qs_total + q_beg + k;
+                cnt += partial[o];
+                half_sum += partial_half[o];
+            }
             cnt += seg_leaf_count(leaf_counts + 2 * ((size_t)b * slots + vpos[v]), sg);
         }
         const float vx = vb[3 * (size_t)v], vy = vb[3 * (size_t)v + 1], vz = vb[3 * (size_t)v + 2];
@@ -1220,21 +1273,30 @@ __global__ __launch_bounds__(kSegFusedBlock) void segment_fused_kernel(
 
 }  // namespace
 
-// can the segment filter run as the one fused launch?  (flags only; the caller checks that)
+// can the segment filter run as the two launches above?  (flags only; the caller checks that)
 bool tuch_ray_segment_fused_available(const tuch_contact_model* m)
 {
     return m && m->seg_cap_off && m->seg_cap_range && m->seg_elem_mask && m->seg_q_max <= kSegFusedMaxQ && m->opt.seg_fused != 0;
 }
 
-// exterior [B,V] in/out; leaf_counts = tuch_ray_segment_counts of the SAME vertices
-int tuch_ray_segment_flags_fused(const tuch_contact_model* m, const float* verts, const int32_t* leaf_counts, int B,
-                                 float thresh, uint8_t* exterior, hipStream_t s)
+// body_flags [B,V]: the body test's own flags (a copy nobody writes during the call); exterior [B,V] in/out;
+// leaf_counts = tuch_ray_segment_counts of the SAME vertices; seg_partial: room for 2 x B x 16 x seg_q_total words
+int tuch_ray_segment_flags_fused(const tuch_contact_model* m, const float* verts, const uint8_t* body_flags,
+                                 const int32_t* leaf_counts, int B, float thresh, int32_t* seg_partial, uint8_t* exterior,
+                                 hipStream_t s)
 {
-    hipLaunchKernelGGL(segment_fused_kernel, dim3(m->num_segments, B), dim3(kSegFusedBlock), 0, s, verts, exterior,
+
+    float* partial_half = (float*)(seg_partial + (size_t)B * kSegFusedSlices * m->seg_q_total);
+    hipLaunchKernelGGL(segment_cross_kernel, dim3(m->num_segments, B, kSegFusedSlices), dim3(kSegFusedBlock), 0, s, verts,
+                       body_flags, (const int32_t*)m->seg_q_off, (const int32_t*)m->seg_q_vidx,
+                       (const int32_t*)m->seg_cap_range, (const int32_t*)m->cap_off, (const int32_t*)m->cap_vidx,
+                       (const int32_t*)m->seg_cap_off, (const int32_t*)m->seg_cap_ent, m->V, m->seg_q_total, seg_partial,
+                       partial_half);
+    hipLaunchKernelGGL(segment_flags_kernel, dim3(m->num_segments, B), dim3(kSegFusedBlock), 0, s, verts, body_flags, exterior,
                        (const int32_t*)m->seg_q_off, (const int32_t*)m->seg_q_vidx, (const int32_t*)m->seg_cap_range,
-                       (const int32_t*)m->cap_off, (const int32_t*)m->cap_vidx, (const int32_t*)m->seg_cap_off,
-                       (const int32_t*)m->seg_cap_ent, (const int32_t*)m->seg_link_off, (const int32_t*)m->seg_link,
-                       leaf_counts, (const int32_t*)m->seg_vpos, 2 * m->tree_qblocks * kRayQueries, m->V, thresh);
+                       (const int32_t*)m->cap_off, (const int32_t*)m->cap_vidx, (const int32_t*)m->seg_link_off,
+                       (const int32_t*)m->seg_link, (const int32_t*)seg_partial, (const float*)partial_half, leaf_counts,
+                       (const int32_t*)m->seg_vpos, 2 * m->tree_qblocks * kRayQueries, m->V, m->seg_q_total, thresh);
     return tuch_check_launch("tuch_ray_segment_flags_fused");
 }
 
@@ -1358,7 +1420,7 @@ static int launch_ray_counts(const tuch_contact_model* m, const RayLayout& l, co
 }
 
 int tuch_ray_exterior_verts(const tuch_contact_model* m, const float* verts, int B, float thresh, uint8_t* exterior,
-                            float* w, void* workspace, hipStream_t s, unsigned long long* stats_host)
+                            float* w, void* workspace, hipStream_t s, unsigned long long* stats_host, uint8_t* exterior_copy)
 {
     const RayLayout l = full_layout(m, B, m->V, true);
     char* ws = (char*)workspace;
@@ -1369,7 +1431,7 @@ int tuch_ray_exterior_verts(const tuch_contact_model* m, const float* verts, int
     if (w || exterior)
         hipLaunchKernelGGL(ray_finalize_verts_kernel, dim3(ceil_div(m->V, kBlock), B), dim3(kBlock), 0, s, verts,
                            (const int32_t*)(ws + l.count), (const int32_t*)m->tree_qperm, (const int32_t*)m->ring_off,
-                           (const int32_t*)m->ring_vidx, m->V, l.qblocks * kRayQueries, thresh, w, exterior);
+                           (const int32_t*)m->ring_vidx, m->V, l.qblocks * kRayQueries, thresh, w, exterior, exterior_copy);
     if (stats_host) {
         RayBody bodies[8];
         const int nb = B < 8 ? B : 8;

@@ -795,7 +795,7 @@ int choose_strip_splits(int B, int Q, int L)
 }
 
 struct ExteriorLayout {
-    size_t tris, partial, bounds, stats, caps, seg_tris, seg_partial, seg_count, seg_list, ray, ray_bytes, total;
+    size_t tris, partial, bounds, stats, caps, seg_tris, seg_partial, seg_count, seg_list, body_flags, ray, ray_bytes, total;
     int lpad;
     int tree_frontier;         // frontier used by the hierarchical path (-1: flat path)
     int tree_subs;
@@ -862,6 +862,7 @@ ExteriorLayout exterior_layout(const tuch_contact_model* m, int B)
                                       ((size_t)B * (m->num_seg_blocks > 0 ? m->num_seg_blocks : 1) * 2 + 4) * sizeof(int32_t));
     l.seg_count = tuch_ws_take(o, (size_t)B * (m->num_segments > 0 ? m->num_segments : 1) * sizeof(int32_t));
     l.seg_list = tuch_ws_take(o, (size_t)B * (m->seg_q_total > 0 ? m->seg_q_total : 1) * sizeof(int32_t));
+    l.body_flags = tuch_ws_take(o, (size_t)B * m->V);        // the body test's flags, kept for the fused segment filter
     { tuch_ws_pause nested; l.ray_bytes = tuch_ray_workspace_bytes(m, B, 0); }
     l.ray = tuch_ws_take(o, l.ray_bytes);
     l.total = o;
@@ -1018,7 +1019,8 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
                                      (float*)(ws + l.seg_tris), s);
     }
     if (body_by_rays) {
-        rc = tuch_ray_exterior_verts(m, verts, B, thresh, exterior, w, ws + l.ray, s, nullptr);
+        rc = tuch_ray_exterior_verts(m, verts, B, thresh, exterior, w, ws + l.ray, s, nullptr,
+                                     segments_fused ? (uint8_t*)(ws + l.body_flags) : (uint8_t*)nullptr);
         if (rc != TUCH_OK) return rc;
     } else if (use_strips(m) && use_tree(m)) {
         launch_tree_walk(m, l, verts, B, ws, nullptr, s);
@@ -1045,7 +1047,8 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
         if (rc != TUCH_OK) return rc;
     }
     if (segments_fused) {
-        rc = tuch_ray_segment_flags_fused(m, verts, tuch_ray_segment_counts(m, B, ws + l.ray), B, thresh, exterior, s);
+        rc = tuch_ray_segment_flags_fused(m, verts, (const uint8_t*)(ws + l.body_flags), tuch_ray_segment_counts(m, B, ws + l.ray),
+                                          B, thresh, (int32_t*)(ws + l.seg_partial), exterior, s);
         if (rc != TUCH_OK) return rc;
     } else if (segments) {
         float* caps = (float*)(ws + l.caps);
