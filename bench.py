@@ -629,24 +629,46 @@ def selfcheck(p, step, sample=(0, 37)):
     ext, _, partner, _ = model.exterior_and_partner(verts, apply_segments=True)
     per_body, _ = contact_terms(verts, partner, ext, None, MODE_SMPLIFY, 0.02)
     m = ol.model_tensors(body)
-    worst_c = worst_v = 0.0
+    worst_c = worst_v = worst_d = 0.0
+    flag_diff_clear = flag_diff_near = partner_diff = 0
     sample = [b for b in sample if b < verts.shape[0]]
     for b in sample:
         vb = verts[b].cpu().numpy()
         r = oc.smplify_contact_body(vb, body.faces, gm, 0.02, segs, None)
-        worst_c = max(worst_c, abs(float(per_body[b]) - r['contact']) / max(abs(r['contact']), 1e-6))
+        ext_gpu = ext[b].cpu().numpy().astype(bool)
+        part_gpu = partner[b].cpu().numpy().astype(np.int64)
+        # flags: identical unless the winding number sits within 1e-4 of the threshold (or the vertex touches a triangle:
+        # not checked here, the tests do); partners: identical up to ties within the reference's own distance noise
+        differ = ext_gpu != r['exterior']
+        near = np.abs(r['winding'] - 0.99) < 1e-4
+        flag_diff_near += int((differ & near).sum())
+        flag_diff_clear += int((differ & ~near).sum())
+        v64 = vb.astype(np.float64)
+        d_gpu = ((v64 - v64[part_gpu]) ** 2).sum(1)
+        d_ref = ((v64 - v64[r['argmin']]) ** 2).sum(1)
+        partner_diff += int((part_gpu != r['argmin']).sum())
+        worst_d = max(worst_d, float(np.abs(d_gpu - d_ref).max()))
+        # the value, by the oracle's arithmetic on the device's own flags and partners (losses.py:96-105)
+        _, dist = oc._pair_distance(vb, part_gpu)
+        inside, _ = oc._tanh2_terms(dist, ~ext_gpu, 1.0, 0.04)
+        outside, _ = oc._tanh2_terms(dist, ext_gpu & (dist < np.float32(0.02)), 0.005, 0.005)
+        want = inside + outside
+        worst_c = max(worst_c, abs(float(per_body[b]) - want) / max(abs(want), 1e-6))
         # (global_orient moves too; the vertices of the oracle's LBS at the same pose are compared up to that rotation
         # through pairwise distances of a vertex subset, which a rigid motion leaves unchanged)
         ov, _ = ol.smpl_forward(m, p['betas'][b:b + 1].cpu(), pose[b:b + 1].cpu(), torch.zeros(1, 3))
         idx = np.arange(0, vb.shape[0], 97)
-        d_gpu = np.linalg.norm(vb[idx][:, None] - vb[idx][None], axis=2)
+        d_g = np.linalg.norm(vb[idx][:, None] - vb[idx][None], axis=2)
         ovn = ov[0].numpy()
-        d_ref = np.linalg.norm(ovn[idx][:, None] - ovn[idx][None], axis=2)
-        worst_v = max(worst_v, float(np.abs(d_gpu - d_ref).max()))
-    return {'graph_vs_eager_rel_err': abs(replayed - eager) / max(abs(eager), 1e-12), 'objective': eager,
-            'oracle_bodies': sample, 'contact_value_max_rel_err': worst_c, 'lbs_pairwise_distance_max_abs_err_m': worst_v,
-            'max_rel_err': max(worst_c, abs(replayed - eager) / max(abs(eager), 1e-12)),
-            'ok': bool(worst_c < 1e-4 and worst_v < 1e-4 and abs(replayed - eager) <= 1e-4 * abs(eager))}
+        d_r = np.linalg.norm(ovn[idx][:, None] - ovn[idx][None], axis=2)
+        worst_v = max(worst_v, float(np.abs(d_g - d_r).max()))
+    graph_err = abs(replayed - eager) / max(abs(eager), 1e-12)
+    return {'graph_vs_eager_rel_err': graph_err, 'objective': eager, 'oracle_bodies': sample,
+            'contact_value_max_rel_err': worst_c, 'lbs_pairwise_distance_max_abs_err_m': worst_v,
+            'exterior_flags_differ_clear': flag_diff_clear, 'exterior_flags_differ_within_1e-4_of_threshold': flag_diff_near,
+            'partners_differ': partner_diff, 'partner_d2_max_abs_diff': worst_d,
+            'max_rel_err': max(worst_c, graph_err),
+            'ok': bool(worst_c < 1e-4 and worst_v < 1e-4 and graph_err <= 1e-4 and flag_diff_clear == 0 and worst_d < 2e-6)}
 
 
 def rccl_smoke_child():

@@ -583,8 +583,11 @@ def test_v2v_tree_walk_matches_flat_search(tag, batch, monkeypatch):
     model.set_option('v2v_tree', 0)
     mn_f, arg_f = model.v2v_min(verts)
     model.set_option('v2v_tree', 1)
-    for waves in ('1', '4096', '1000000'):               # one subtree ... as many as the model has
-        model.set_option('v2v_waves', int(waves))
+    # leaf_form 2: lanes over the subtree's leaves first (v2v_scan_kernel, the default); 1: leaf boxes four at a time
+    # (v2v_leaves_kernel); 0: the stackless walk (v2v_tree_kernel)
+    for waves, leaf_form in (('1', 2), ('4096', 2), ('1000000', 2), ('1', 1), ('4096', 1), ('1', 0), ('4096', 0), ('1000000', 0)):
+        model.set_option('v2v_waves', int(waves))        # one subtree ... as many as the model has
+        model.set_option('v2v_flat', leaf_form)
         mn_t, arg_t = model.v2v_min(verts)
         assert torch.equal(mn_t, mn_f)
         diff = (arg_t != arg_f).nonzero()

@@ -41,7 +41,8 @@ struct tuch_options {
     int ray_pair_cap = 16;      // (ray, leaf) pairs per query the pair list has room for
     int ray_waves = 32768;      // wavefronts of the crossing kernel
     int v2v_tree = 1;           // 0: flat nearest-vertex search
-    int v2v_waves = 65536;      // frontier choice of the search
+    int v2v_waves = 0;          // frontier choice of the search (wavefronts aimed at; 0: the form's own default)
+    int v2v_flat = 2;           // search: 2 lanes over a subtree's leaves first, 1 leaf boxes four at a time, 0 the stackless walk
     int v2v_lds = 6400;         // LDS bytes a workgroup of the search holds back when something runs beside it
     int seg_splits = 16;        // face splits of the solid-angle segment kernel
     int seg_assist = 1;         // 0: the segment pass counts its body-face crossings itself (read at create only)
@@ -118,6 +119,10 @@ struct tuch_contact_model {
     // (0: the mask rules the whole node out for the wavefront that owns these columns)
     uint64_t* tree_mask_bits;
     uint64_t* tree_masked;
+    // the same for the flat form of the search (v2v.hip: v2v_leaves_kernel): per frontier subtree its leaves as a range of
+    // the preorder leaf sequence, and the lane table of tree_masked by leaf index instead of node
+    int32_t* tree_sub_leaf;      // [frontier_total][2] = (first leaf index, number of leaves)
+    uint64_t* tree_masked_leaf;  // [2 * tree_qblocks][tree_leaves]
     int tree_num_frontiers;
     int* tree_frontier_off_host;   // [tree_num_frontiers+1]
     int32_t* tree_face_leaf_host;  // [F] leaf (preorder sequence number) of every face, host copy (or nullptr)

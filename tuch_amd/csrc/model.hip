@@ -42,7 +42,7 @@ extern "C" void tuch_contact_model_destroy(tuch_contact_model* m)
 {
     if (!m) return;
     void* dev[] = {m->ring_off, m->ring_vidx, m->faces, m->mask_bits, m->strip_vidx, m->strip_sign, m->tree_node, m->tree_vidx, m->tree_sign, m->tree_qperm,
-                   m->tree_height_off, m->tree_height_nodes, m->tree_frontier_nodes, m->tree_launch_order, m->tree_ancestors, m->tree_rows, m->tree_v2v_info, m->tree_mask_bits, m->tree_masked, m->seg_blocks, m->seg_of_q, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces, m->seg_link_off, m->seg_link, m->seg_ray_off, m->seg_ray_ent, m->seg_elem_mask, m->seg_vmask, m->seg_vpos, m->seg_cap_off, m->seg_cap_ent, m->seg_cap_range,
+                   m->tree_height_off, m->tree_height_nodes, m->tree_frontier_nodes, m->tree_launch_order, m->tree_ancestors, m->tree_rows, m->tree_v2v_info, m->tree_mask_bits, m->tree_masked, m->tree_sub_leaf, m->tree_masked_leaf, m->seg_blocks, m->seg_of_q, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces, m->seg_link_off, m->seg_link, m->seg_ray_off, m->seg_ray_ent, m->seg_elem_mask, m->seg_vmask, m->seg_vpos, m->seg_cap_off, m->seg_cap_ent, m->seg_cap_range,
                    m->cap_off, m->cap_vidx, m->region_off, m->region_vidx, m->pairs, m->pair_mask, m->pair_mask_off, m->tickets, m->canary_hits};
     for (void* p : dev)
         if (p) (void)hipFree(p);
@@ -171,6 +171,31 @@ extern "C" int tuch_contact_model_create(
                 }
                 rc = upload(&m->tree_mask_bits, bits.data(), bits.size());
                 if (rc == TUCH_OK) rc = upload(&m->tree_masked, lanes.data(), lanes.size());
+                // flat form: leaves by their preorder sequence (= their position among the height-0 nodes, which are
+                // listed in ascending node order); a subtree's leaves are a contiguous range of it
+                const int L = t.height_off[1];
+                std::vector<int32_t> leaf_index(N, -1);
+                bool ascending = true;
+                for (int i = 0; i < L; ++i) {
+                    leaf_index[t.height_nodes[i]] = i;
+                    ascending = ascending && (i == 0 || t.height_nodes[i] > t.height_nodes[i - 1]);
+                }
+                if (rc == TUCH_OK && ascending) {
+                    std::vector<int32_t> sub((size_t)t.frontier_nodes.size() * 2);
+                    for (size_t k = 0; k < t.frontier_nodes.size(); ++k) {
+                        const int lo = t.frontier_nodes[k], hi = t.nodes[(size_t)lo * 8 + 4];
+                        int first = -1, count = 0;
+                        for (int i = lo; i < hi; ++i)
+                            if (leaf_index[i] >= 0) { if (first < 0) first = leaf_index[i]; ++count; }
+                        sub[2 * k] = first < 0 ? 0 : first;
+                        sub[2 * k + 1] = count;
+                    }
+                    std::vector<uint64_t> by_leaf((size_t)Wp * L + 8, 0);        // + a batch of padding (v2v_leaves_kernel)
+                    for (int qb = 0; qb < Wp; ++qb)
+                        for (int i = 0; i < L; ++i) by_leaf[(size_t)qb * L + i] = lanes[(size_t)qb * N + t.height_nodes[i]];
+                    rc = upload(&m->tree_sub_leaf, sub.data(), sub.size());
+                    if (rc == TUCH_OK) rc = upload(&m->tree_masked_leaf, by_leaf.data(), by_leaf.size());
+                }
             }
         }
     }
@@ -419,7 +444,7 @@ const OptionName kOptions[] = {
     {"winding_ray", &tuch_options::winding_ray}, {"winding_tree", &tuch_options::winding_tree},
     {"winding_strips", &tuch_options::winding_strips}, {"tree_waves", &tuch_options::tree_waves},
     {"ray_pair_cap", &tuch_options::ray_pair_cap}, {"ray_waves", &tuch_options::ray_waves},
-    {"v2v_tree", &tuch_options::v2v_tree}, {"v2v_waves", &tuch_options::v2v_waves}, {"v2v_lds", &tuch_options::v2v_lds},
+    {"v2v_tree", &tuch_options::v2v_tree}, {"v2v_flat", &tuch_options::v2v_flat}, {"v2v_waves", &tuch_options::v2v_waves}, {"v2v_lds", &tuch_options::v2v_lds},
     {"seg_splits", &tuch_options::seg_splits}, {"seg_assist", &tuch_options::seg_assist}, {"seg_fused", &tuch_options::seg_fused},
     {"canary", &tuch_options::canary}, {"deterministic", &tuch_options::deterministic},
 };

@@ -396,8 +396,9 @@ __global__ __launch_bounds__(kBoundsBlock) void v2v_rows_kernel(
     const int32_t* __restrict__ rows, const int32_t* __restrict__ height_off,
     const int32_t* __restrict__ height_nodes, int N,
     float* __restrict__ prow,                    // [B,Vp,3]
-    float* __restrict__ bounds)                  // [B,N,8]
-{
+    float* __restrict__ bounds,                  // [B,N,8]
+    float* __restrict__ leafbox)                 // [B,L,8] or nullptr: the leaf boxes once more, by leaf index, with the
+{                                                // leaf's row range (first | count << 20) in the last padding word
     const int b = blockIdx.y;
     const int group = threadIdx.x >> 4, sub = threadIdx.x & 15;
     const int i = height_off[0] + blockIdx.x * (kBoundsBlock / 16) + group;
@@ -425,6 +426,12 @@ __global__ __launch_bounds__(kBoundsBlock) void v2v_rows_kernel(
         float* o = bounds + ((size_t)b * N + node) * 8;
         o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = 0.0f;
         o[4] = -nhi[0]; o[5] = -nhi[1]; o[6] = -nhi[2]; o[7] = 0.0f;
+        if (leafbox) {
+            const int L = height_off[1] - height_off[0];
+            float* q = leafbox + ((size_t)b * L + (i - height_off[0])) * 8;
+            q[0] = lo[0]; q[1] = lo[1]; q[2] = lo[2]; q[3] = 0.0f;
+            q[4] = -nhi[0]; q[5] = -nhi[1]; q[6] = -nhi[2]; q[7] = __int_as_float(off | (len << 20));
+        }
     }
 }
 
@@ -462,6 +469,27 @@ __device__ __forceinline__ void v2v_rows(Column& c, const float* __restrict__ pb
     // the row index costs it eight instructions per trip
     const uint64_t* mp = m0 + j0;
     const float* cp = pb + 3 * (size_t)j0;
+    // eight rows per trip while they last: the CU's one scalar unit is this loop's tightest resource (the loads, the test
+    // on the mask words, the pointer bumps and branches of a trip are scalar instructions: 0.8 busy against 0.7 for the
+    // vector units), and a trip of eight needs 18 of them where two trips of four need 28
+    for (; j + 8 <= j_end; j += 8, mp += 8, cp += 24) {
+        uint64_t k0[8];
+        float v[24];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) k0[u] = mp[u];
+#pragma unroll
+        for (int u = 0; u < 24; ++u) v[u] = cp[u];
+        asm volatile("" :: "s"(v[0]), "s"(v[8]), "s"(v[16]));
+        if (((k0[0] | k0[1] | k0[2] | k0[3] | k0[4] | k0[5] | k0[6] | k0[7]) & reach) == 0) continue;
+        float d[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) d[u] = dist(k0[u], v[3 * u], v[3 * u + 1], v[3 * u + 2]);
+        const float m = __builtin_fminf(min4_raw(d[0], d[1], d[2], d[3]), min4_raw(d[4], d[5], d[6], d[7]));
+        if (__builtin_amdgcn_ballot_w64(m <= c.best)) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) take(j + u, d[u]);                     // in row order: ties go to the smaller row
+        }
+    }
     for (; j + 4 <= j_end; j += 4, mp += 4, cp += 12) {
         uint64_t k0[4];
         float v[12];
@@ -505,7 +533,8 @@ __global__ __launch_bounds__(64) void v2v_seed_kernel(
     const TreeNode* __restrict__ nodes, const int32_t* __restrict__ rows, const float* __restrict__ bounds,
     const uint64_t* __restrict__ masked, int N,
     const int32_t* __restrict__ hint,            // [B,Vp] a row per column (tree order) from an earlier call, or nullptr
-    uint64_t* __restrict__ keys)                 // [B,Vp]
+    uint64_t* __restrict__ keys,                 // [B,Vp]
+    float* __restrict__ colbox)                  // [B][column blocks][8] or nullptr: the box of the block's 64 columns
 {
     const int b = blockIdx.x, qb = blockIdx.y, lane = threadIdx.x;
     const float* pb = prow + (size_t)b * Vp * 3;
@@ -514,6 +543,20 @@ __global__ __launch_bounds__(64) void v2v_seed_kernel(
     c.px = pb[3 * i0]; c.py = pb[3 * i0 + 1]; c.pz = pb[3 * i0 + 2];
     c.best = __builtin_inff();
     c.arg = 0;
+    if (colbox) {
+        float lo[3] = {c.px, c.py, c.pz}, hi[3] = {c.px, c.py, c.pz};
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = fminf(lo[k], __shfl_xor(lo[k], m));
+                hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m));
+            }
+        if (lane == 0) {
+            float* o = colbox + ((size_t)b * gridDim.y + qb) * 8;
+            o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = 0.0f; o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = 0.0f;
+        }
+    }
     const uint64_t* mk = masked + (size_t)qb * N;     // per node: the lanes with an allowed row below it
     bool have = false;
     if (hint) {
@@ -620,6 +663,142 @@ __global__ __launch_bounds__(64) void v2v_tree_kernel(
     if (k0 < init) atomicMin((unsigned long long*)(kb + i0), (unsigned long long)k0);
 }
 
+// The same search without the descent.  A wavefront's subtree is small (a frontier of 32 subtrees: ~13 leaves, ~27
+// nodes), and the stackless walk above visits most of its nodes one DEPENDENT round of scalar loads after the other:
+// ~20 rounds of ~230 cycles per wavefront for ~360 vector instructions -- a latency chain (VALU busy 0.59 with the SIMDs
+// full of such wavefronts).  Here: the subtree's root box first (most (column block, subtree) pairs end there), then the
+// boxes of its LEAVES, four at a time from one contiguous run (v2v_rows_kernel stores them by leaf index; a subtree's
+// leaves are a range of it), each re-tested against the bounds as they stand when its turn comes: the same rows are
+// evaluated as by the walk, in the same order -> the same keys.  ~5 rounds instead of ~20.
+constexpr int kLeafBatch = 4;
+__global__ __launch_bounds__(64) void v2v_leaves_kernel(
+    const float* __restrict__ prow, int V, int Vp, const uint64_t* __restrict__ bits,
+    const float* __restrict__ bounds, const float* __restrict__ leafbox, const uint64_t* __restrict__ masked,
+    const uint64_t* __restrict__ masked_leaf, int N, int L, const int32_t* __restrict__ frontier,
+    const int32_t* __restrict__ sub_leaf, const int32_t* __restrict__ order, uint64_t* __restrict__ keys)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int pair = __builtin_amdgcn_readfirstlane(order[blockIdx.y >> 1]);      // launch order over 128-blocks
+    const int sub = pair >> 16, qb = (pair & 0xffff) * 2 + (blockIdx.y & 1);
+    const float* pb = prow + (size_t)b * Vp * 3;
+    const int i0 = qb * kTreeCols + lane;
+    uint64_t* kb = keys + (size_t)b * Vp;
+    const uint64_t init = __hip_atomic_load(kb + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    Column c;
+    c.px = pb[3 * i0]; c.py = pb[3 * i0 + 1]; c.pz = pb[3 * i0 + 2];
+    c.best = __uint_as_float((uint32_t)(init >> 32));
+    c.arg = (int)(uint32_t)init;
+    const uint64_t* m0 = bits + (size_t)qb * V;
+    auto gap = [&](const float* box) {              // squared distance to a box through its nearest point, as box_dist2()
+        const float dx = c.px - __builtin_amdgcn_fmed3f(c.px, box[0], box[4]);
+        const float dy = c.py - __builtin_amdgcn_fmed3f(c.py, box[1], box[5]);
+        const float dz = c.pz - __builtin_amdgcn_fmed3f(c.pz, box[2], box[6]);
+        return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) * kPruneSlack;
+    };
+    const int root = __builtin_amdgcn_readfirstlane(frontier[sub]);
+    const int first = __builtin_amdgcn_readfirstlane(sub_leaf[2 * sub]), count = __builtin_amdgcn_readfirstlane(sub_leaf[2 * sub + 1]);
+    {
+        const float* box = bounds + ((size_t)b * N + root) * 8;
+        const float rb[8] = {box[0], box[1], box[2], 0.0f, box[4], box[5], box[6], 0.0f};
+        if ((__builtin_amdgcn_ballot_w64(gap(rb) <= c.best) & masked[(size_t)qb * N + root]) == 0) return;
+    }
+    const float* lb = leafbox + ((size_t)b * L + first) * 8;
+    const uint64_t* ml = masked_leaf + (size_t)qb * L + first;
+    for (int base = 0; base < count; base += kLeafBatch) {
+        float bx[kLeafBatch][8];
+        uint64_t lanes[kLeafBatch];
+#pragma unroll
+        for (int u = 0; u < kLeafBatch; ++u) {      // (reads past a subtree's last leaf stay inside the arrays' padding)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) bx[u][k] = lb[(size_t)(base + u) * 8 + k];
+            lanes[u] = ml[base + u];
+        }
+        float g[kLeafBatch];
+#pragma unroll
+        for (int u = 0; u < kLeafBatch; ++u) g[u] = gap(bx[u]);
+#pragma unroll
+        for (int u = 0; u < kLeafBatch; ++u) {
+            if (base + u >= count) break;
+            const uint64_t reach = __builtin_amdgcn_ballot_w64(g[u] <= c.best) & lanes[u];
+            if (reach) {
+                const int leaf = __float_as_int(bx[u][7]);
+                v2v_rows(c, pb, m0, leaf & 0xfffff, leaf >> 20, reach);
+            }
+        }
+    }
+    const uint64_t k0 = v2v_key(c.best, c.arg);
+    if (k0 < init) atomicMin((unsigned long long*)(kb + i0), (unsigned long long)k0);
+}
+
+// Third form: lanes over LEAVES first.  The walks above spend most of their vector instructions on box tests that fail
+// (~20 node tests of ~12 instructions per wavefront against ~80 instructions of row arithmetic; the kernel is ~70 % VALU
+// issue).  Here a wavefront tests all leaves of its subtree AT ONCE, one leaf per lane, against the box of its 64 columns
+// and the largest bound among them (conservative: box-to-box distance), and only the survivors get the per-column test
+// and their rows.  Same rows as the walks -> the same keys.  colbox: the box of every 64-column block, left by
+// v2v_seed_kernel ([B][column blocks][8]).
+__global__ __launch_bounds__(64) void v2v_scan_kernel(
+    const float* __restrict__ prow, int V, int Vp, const uint64_t* __restrict__ bits,
+    const float* __restrict__ leafbox, const float* __restrict__ colbox, const uint64_t* __restrict__ masked_leaf,
+    const uint64_t* __restrict__ masked, int N, int L, const int32_t* __restrict__ frontier,
+    const int32_t* __restrict__ sub_leaf, const int32_t* __restrict__ order, uint64_t* __restrict__ keys)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int pair = __builtin_amdgcn_readfirstlane(order[blockIdx.y >> 1]);      // launch order over 128-blocks
+    const int sub = pair >> 16, qb = (pair & 0xffff) * 2 + (blockIdx.y & 1);
+    const float* pb = prow + (size_t)b * Vp * 3;
+    const int i0 = qb * kTreeCols + lane;
+    uint64_t* kb = keys + (size_t)b * Vp;
+    const uint64_t init = __hip_atomic_load(kb + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    Column c;
+    c.px = pb[3 * i0]; c.py = pb[3 * i0 + 1]; c.pz = pb[3 * i0 + 2];
+    c.best = __uint_as_float((uint32_t)(init >> 32));
+    c.arg = (int)(uint32_t)init;
+    const uint64_t* m0 = bits + (size_t)qb * V;
+    const int first = __builtin_amdgcn_readfirstlane(sub_leaf[2 * sub]), count = __builtin_amdgcn_readfirstlane(sub_leaf[2 * sub + 1]);
+    // the largest bound among the columns that have an allowed row below this subtree at all
+    const uint64_t alive = masked[(size_t)qb * N + __builtin_amdgcn_readfirstlane(frontier[sub])];
+    if (alive == 0) return;
+    float reach2 = ((alive >> lane) & 1) ? c.best : 0.0f;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) reach2 = fmaxf(reach2, __shfl_xor(reach2, m));
+    const float* cbx = colbox + ((size_t)b * (Vp / kTreeCols) + qb) * 8;
+    const float clx = cbx[0], cly = cbx[1], clz = cbx[2], chx = cbx[4], chy = cbx[5], chz = cbx[6];
+    const float* lb = leafbox + ((size_t)b * L + first) * 8;
+    const uint64_t* ml = masked_leaf + (size_t)qb * L + first;
+    for (int base = 0; base < count; base += 64) {
+        // one leaf per lane: the gap between its box and the block's, against the largest bound
+        const int li = base + lane;
+        bool cand = false;
+        if (li < count) {
+            const float4 lo = *reinterpret_cast<const float4*>(lb + (size_t)li * 8);
+            const float4 hi = *reinterpret_cast<const float4*>(lb + (size_t)li * 8 + 4);
+            const float ex = fmaxf(fmaxf(lo.x - chx, clx - hi.x), 0.0f);
+            const float ey = fmaxf(fmaxf(lo.y - chy, cly - hi.y), 0.0f);
+            const float ez = fmaxf(fmaxf(lo.z - chz, clz - hi.z), 0.0f);
+            const float g = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) * kPruneSlack;
+            cand = g <= reach2 && (ml[li] & alive) != 0;
+        }
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(cand);
+        while (todo) {
+            const int u = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const float* box = lb + (size_t)(base + u) * 8;          // wave-uniform: scalar loads
+            const uint64_t lanes = ml[base + u];
+            const float dx = c.px - __builtin_amdgcn_fmed3f(c.px, box[0], box[4]);
+            const float dy = c.py - __builtin_amdgcn_fmed3f(c.py, box[1], box[5]);
+            const float dz = c.pz - __builtin_amdgcn_fmed3f(c.pz, box[2], box[6]);
+            const float g = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) * kPruneSlack;
+            const uint64_t reach = __builtin_amdgcn_ballot_w64(g <= c.best) & lanes;
+            if (reach) {
+                const int leaf = __float_as_int(box[7]);
+                v2v_rows(c, pb, m0, leaf & 0xfffff, leaf >> 20, reach);
+            }
+        }
+    }
+    const uint64_t k0 = v2v_key(c.best, c.arg);
+    if (k0 < init) atomicMin((unsigned long long*)(kb + i0), (unsigned long long)k0);
+}
+
 // keys -> (min, argmin) in the caller's vertex numbering; all-masked column -> (inf, 0)
 __global__ __launch_bounds__(kBlock) void v2v_tree_finalize_kernel(
     const uint64_t* __restrict__ keys, const int32_t* __restrict__ qperm, int V, int Vp,
@@ -638,7 +817,7 @@ __global__ __launch_bounds__(kBlock) void v2v_tree_finalize_kernel(
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-struct TreeV2VLayout { size_t prow, bounds, keys, total; };
+struct TreeV2VLayout { size_t prow, bounds, keys, leafbox, colbox, total; };
 
 TreeV2VLayout tree_v2v_layout(const tuch_contact_model* m, int B)
 {
@@ -648,6 +827,8 @@ TreeV2VLayout tree_v2v_layout(const tuch_contact_model* m, int B)
     l.prow = tuch_ws_take(o, (size_t)B * Vp * 3 * sizeof(float) + 64);
     l.bounds = tuch_ws_take(o, (size_t)B * m->tree_nodes * 8 * sizeof(float));
     l.keys = tuch_ws_take(o, (size_t)B * Vp * sizeof(uint64_t));
+    l.leafbox = tuch_ws_take(o, ((size_t)B * m->tree_leaves + kLeafBatch) * 8 * sizeof(float));     // + a batch of padding
+    l.colbox = tuch_ws_take(o, (size_t)B * 2 * m->tree_qblocks * 8 * sizeof(float));
     l.total = o;
     return l;
 }
@@ -658,9 +839,17 @@ bool use_v2v_tree(const tuch_contact_model* m)
     return m->opt.v2v_tree != 0;
 }
 
+static int flat_mode(const tuch_contact_model* m)
+{
+    return (m->tree_sub_leaf && m->tree_masked_leaf) ? m->opt.v2v_flat : 0;
+}
+
 int choose_v2v_frontier(const tuch_contact_model* m, int B)
 {
-    const long target = m->opt.v2v_waves;
+    // option v2v_waves = 0: the form's own default -- the walks want many short wavefronts (65536: 32 subtrees at batch
+    // 64), the leaf scan tests up to 64 leaves per wavefront at once and is best with a quarter as many (measured at
+    // batch 64, step time: 7000 / 14000 / 30000 / 65536 -> 0.56+ / 0.546 / 0.550 / 0.562 ms)
+    const long target = m->opt.v2v_waves > 0 ? m->opt.v2v_waves : (flat_mode(m) == 2 ? 14000L : 65536L);
     int f = 0;
     while (f + 1 < m->tree_num_frontiers &&
            (long)B * m->tree_qblocks * (m->tree_frontier_off_host[f + 1] - m->tree_frontier_off_host[f]) < target) ++f;
@@ -770,18 +959,23 @@ extern "C" int tuch_v2v_min_model_shared(const tuch_contact_model* m, const floa
     float* prow = (float*)(ws + l.prow);
     float* bounds = (float*)(ws + l.bounds);
     uint64_t* keys = (uint64_t*)(ws + l.keys);
+    float* leafbox = (float*)(ws + l.leafbox);
+    float* colbox = (float*)(ws + l.colbox);
+    const int scan = flat_mode(m);          // 2: lanes over leaves first, 1: leaf boxes four at a time, 0: the walk
+    const bool flat = flat_mode(m) != 0;
     hipStream_t s = (hipStream_t)stream;
     const int V = m->V, Vp = m->tree_qblocks * 2 * kTreeCols, N = m->tree_nodes;
     const TreeNode* nodes = (const TreeNode*)m->tree_node;
     hipLaunchKernelGGL(v2v_rows_kernel, dim3(ceil_div(m->tree_leaves, kBoundsBlock / 16), B), dim3(kBoundsBlock), 0, s,
                        verts, V, Vp, (const int32_t*)m->tree_qperm, (const int32_t*)m->tree_rows,
-                       (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, N, prow, bounds);
+                       (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, N, prow, bounds,
+                       flat ? leafbox : (float*)nullptr);
     hipLaunchKernelGGL(tree_inner_bounds_kernel<4>, dim3(B), dim3(kBoundsBlock), tree_inner_bounds_lds<4>(N), s, nodes, N,
                        (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, m->tree_heights, bounds,
                        (const int32_t*)m->tree_v2v_info);
     hipLaunchKernelGGL(v2v_seed_kernel, dim3(B, 2 * m->tree_qblocks), dim3(64), 0, s, (const float*)prow, V, Vp,
                        (const uint64_t*)m->tree_mask_bits, nodes, (const int32_t*)m->tree_rows, (const float*)bounds,
-                       (const uint64_t*)m->tree_masked, N, (const int32_t*)hint_inout, keys);
+                       (const uint64_t*)m->tree_masked, N, (const int32_t*)hint_inout, keys, scan == 2 ? colbox : (float*)nullptr);
     const int f = choose_v2v_frontier(m, B);
     const int f0 = m->tree_frontier_off_host[f], nsub = m->tree_frontier_off_host[f + 1] - f0;
     // leave_room: an unused LDS allocation caps the walk at 25 of a CU's 32 wave slots.  The walk is one grid of 220 k
@@ -790,6 +984,19 @@ extern "C" int tuch_v2v_min_model_shared(const tuch_contact_model* m, const floa
     // got going when the walk was done (tools/graph_timeline.py: the memset took 236 us).  -2.5 % step time; alone the
     // walk is 10 % slower with the cap (0.28 -> 0.31 ms), hence a flag (TUCH_V2V_LDS: bytes, to compare).
     const int lds_pad = leave_room ? m->opt.v2v_lds : 0;
+    if (scan == 2)
+        hipLaunchKernelGGL(v2v_scan_kernel, dim3(B, 2 * nsub * m->tree_qblocks), dim3(64), (size_t)lds_pad, s, (const float*)prow,
+                           V, Vp, (const uint64_t*)m->tree_mask_bits, (const float*)leafbox, (const float*)colbox,
+                           (const uint64_t*)m->tree_masked_leaf, (const uint64_t*)m->tree_masked, N, m->tree_leaves,
+                           (const int32_t*)m->tree_frontier_nodes + f0, (const int32_t*)m->tree_sub_leaf + 2 * (size_t)f0,
+                           (const int32_t*)m->tree_launch_order + (size_t)f0 * m->tree_qblocks, keys);
+    else if (flat)
+        hipLaunchKernelGGL(v2v_leaves_kernel, dim3(B, 2 * nsub * m->tree_qblocks), dim3(64), (size_t)lds_pad, s, (const float*)prow,
+                           V, Vp, (const uint64_t*)m->tree_mask_bits, (const float*)bounds, (const float*)leafbox,
+                           (const uint64_t*)m->tree_masked, (const uint64_t*)m->tree_masked_leaf, N, m->tree_leaves,
+                           (const int32_t*)m->tree_frontier_nodes + f0, (const int32_t*)m->tree_sub_leaf + 2 * (size_t)f0,
+                           (const int32_t*)m->tree_launch_order + (size_t)f0 * m->tree_qblocks, keys);
+    else
     hipLaunchKernelGGL(v2v_tree_kernel, dim3(B, 2 * nsub * m->tree_qblocks), dim3(64), (size_t)lds_pad, s, (const float*)prow, V, Vp,
                        (const uint64_t*)m->tree_mask_bits, nodes, (const int32_t*)m->tree_rows, (const float*)bounds,
                        (const uint64_t*)m->tree_masked, N, (const int32_t*)m->tree_frontier_nodes + f0,
