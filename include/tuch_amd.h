@@ -148,7 +148,12 @@ int tuch_smplify_stage2_fused(const float* points, const int32_t* partner, const
                               const uint8_t* body_valid, int B, int N, int mode, float euclthres,
                               const float* small_terms, const float* r2r, const int32_t* ij, int P, float contact_scale,
                               float r2r_scale, float* share, int* ticket, float* terms, float* out, float* grad_points,
-                              void* stream);
+                              const tuch_contact_model* model, const void* pair_keys, void* stream);
+/* The region-pair search of tuch_region_pair_min alone, for tuch_smplify_stage2_fused(model, pair_keys): keys [B,P]
+ * 64-bit words, ZERO on entry (the caller clears them with whatever else it clears); no clearing and no finalize
+ * launch.  pair_keys given: r2r / ij of tuch_smplify_stage2_fused are ignored. */
+int tuch_region_pair_keys(const tuch_contact_model* model, const float* verts, int B, const uint8_t* select,
+                          int use_geomask, void* keys_zeroed, void* stream);
 int tuch_smplify_stage2_finish(const float* points, const int32_t* partner, const uint8_t* exterior,
                                const uint8_t* body_valid, int B, int N, int mode, float euclthres,
                                const float* small_terms, const float* r2r, int P, float contact_scale, float r2r_scale,

@@ -14,6 +14,7 @@
 // the last ulp of a gradient, never in a loss value).  torch.norm's backward at
 // d == 0 is 0, reproduced explicitly.
 #include "common.h"
+#include "model.h"
 
 namespace {
 
@@ -311,7 +312,10 @@ __global__ __launch_bounds__(kFusedBlock) void stage2_fused_kernel(
     const float* __restrict__ r2r, const int32_t* __restrict__ ij, int P, float contact_scale, float r2r_scale,
     float* __restrict__ share,        // [B][kFusedSplits][3] scratch
     int* __restrict__ ticket, float* __restrict__ terms, float* __restrict__ out,
-    float* __restrict__ grad)         // [B,N,3] pre-zeroed, or nullptr (value only)
+    float* __restrict__ grad,         // [B,N,3] pre-zeroed, or nullptr (value only)
+    // instead of (r2r, ij): the raw keys of tuch_region_pair_keys and the model's region tables
+    const unsigned long long* __restrict__ pair_keys, const int32_t* __restrict__ region_off,
+    const int32_t* __restrict__ region_vidx, const int32_t* __restrict__ pairs)
 {
     __shared__ float smem[kFusedBlock / 64];
     __shared__ bool last;
@@ -359,12 +363,26 @@ __global__ __launch_bounds__(kFusedBlock) void stage2_fused_kernel(
             }
         }
     }
-    if (s == 0 && r2r) {
+    if (s == 0 && (r2r || pair_keys)) {
         for (int p = threadIdx.x; p < P; p += kFusedBlock) {
             const size_t o = (size_t)b * P + p;
-            r_sum += r2r[o];
-            if (gb && ij && r2r_scale != 0.0f) {
-                const int i = ij[2 * o], j = ij[2 * o + 1];
+            int i = -1, j = -1;
+            if (pair_keys) {
+                const unsigned long long inv = pair_keys[o];
+                if (inv != 0ull) {                       // (d2 bits << 32 | flat index), complemented
+                    const unsigned long long key = ~inv;
+                    const int r1 = pairs[2 * p], r2 = pairs[2 * p + 1];
+                    const int n2 = region_off[r2 + 1] - region_off[r2];
+                    const int idx = (int)(unsigned int)key;
+                    r_sum += __uint_as_float((unsigned int)(key >> 32));
+                    i = region_vidx[region_off[r1] + idx / n2];
+                    j = region_vidx[region_off[r2] + idx % n2];
+                }
+            } else {
+                r_sum += r2r[o];
+                if (ij) { i = ij[2 * o]; j = ij[2 * o + 1]; }
+            }
+            if (gb && r2r_scale != 0.0f) {
                 if (i >= 0 && j >= 0)
                     for (int c = 0; c < 3; ++c) {
                         const float d = 2.0f * r2r_scale * (pb[3 * i + c] - pb[3 * j + c]);
@@ -425,15 +443,20 @@ extern "C" int tuch_smplify_stage2_fused(const float* points, const int32_t* par
                                          const uint8_t* body_valid, int B, int N, int mode, float euclthres,
                                          const float* small_terms, const float* r2r, const int32_t* ij, int P,
                                          float contact_scale, float r2r_scale, float* share, int* ticket, float* terms,
-                                         float* out, float* grad_points, void* stream)
+                                         float* out, float* grad_points, const tuch_contact_model* model,
+                                         const void* pair_keys, void* stream)
 {
     TUCH_REQUIRE(points && partner && exterior && small_terms && share && ticket && out,
                  "tuch_smplify_stage2_fused: null pointer");
     TUCH_REQUIRE(B > 0 && B <= 65535 && N > 0 && P >= 0 && (mode == 0 || mode == 1), "tuch_smplify_stage2_fused: bad arguments");
+    TUCH_REQUIRE(!pair_keys || (model && model->num_pairs == P && P > 0),
+                 "tuch_smplify_stage2_fused: pair keys need the model they were computed with (P = its number of pairs)");
+    const bool raw = pair_keys != nullptr;
     hipLaunchKernelGGL(stage2_fused_kernel, dim3(kFusedSplits, B), dim3(kFusedBlock), 0, (hipStream_t)stream, points, partner,
-                       exterior, body_valid, N, mode, euclthres, small_terms, (P > 0 ? r2r : (const float*)nullptr),
-                       (P > 0 ? ij : (const int32_t*)nullptr), P, contact_scale, r2r_scale, share, ticket, terms, out,
-                       grad_points);
+                       exterior, body_valid, N, mode, euclthres, small_terms, (P > 0 && !raw ? r2r : (const float*)nullptr),
+                       (P > 0 && !raw ? ij : (const int32_t*)nullptr), P, contact_scale, r2r_scale, share, ticket, terms, out,
+                       grad_points, (const unsigned long long*)pair_keys, raw ? (const int32_t*)model->region_off : nullptr,
+                       raw ? (const int32_t*)model->region_vidx : nullptr, raw ? (const int32_t*)model->pairs : nullptr);
     return tuch_check_launch("tuch_smplify_stage2_fused");
 }
 

@@ -124,6 +124,7 @@ struct tuch_contact_model {
     int32_t* tree_sub_leaf;      // [frontier_total][2] = (first leaf index, number of leaves)
     uint64_t* tree_masked_leaf;  // [2 * tree_qblocks][tree_leaves]
     int tree_num_frontiers;
+    int tree_leaf_runs_tile;       // 1: the leaves' strip runs [ex_off, ex_off + ex_len) tile [0, tree_exact_len) without gaps
     int* tree_frontier_off_host;   // [tree_num_frontiers+1]
     int32_t* tree_face_leaf_host;  // [F] leaf (preorder sequence number) of every face, host copy (or nullptr)
     int32_t* tree_qperm_host;      // [tree_qblocks*128] host copy of tree_qperm (or nullptr)

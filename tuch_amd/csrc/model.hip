@@ -116,6 +116,18 @@ extern "C" int tuch_contact_model_create(
             m->tree_qblocks = t.num_qblocks;
             m->tree_heights = t.num_heights;
             m->tree_leaves = t.height_off[1];
+            {   // do the leaves' strip runs tile the exact part of the stream?  (ray_winding.hip poses the strip leaf by leaf)
+                std::vector<std::pair<int, int>> runs;
+                for (int i = 0; i < t.height_off[1]; ++i) {
+                    const int nd = t.height_nodes[i];
+                    runs.emplace_back(t.nodes[(size_t)nd * 8 + 2], t.nodes[(size_t)nd * 8 + 3]);
+                }
+                std::sort(runs.begin(), runs.end());
+                int at = 0;
+                bool tile = true;
+                for (const auto& r : runs) { tile = tile && r.first == at; at = r.first + r.second; }
+                m->tree_leaf_runs_tile = tile && at == t.exact_len ? 1 : 0;
+            }
             m->tree_num_frontiers = (int)t.frontier_off.size() - 1;
             m->tree_frontier_off_host = host_copy(t.frontier_off.data(), t.frontier_off.size());
             m->tree_face_leaf_host = host_copy(t.face_leaf.data(), t.face_leaf.size());

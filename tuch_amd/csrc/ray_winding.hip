@@ -97,9 +97,15 @@ __device__ __forceinline__ float row_min(float v)
 // slabs of every leaf in sheared coordinates, 16 lanes per (leaf, body): a leaf strip is a few dozen elements, so a
 // whole wavefront per leaf was mostly idle lanes behind four dependent rounds of loads; widened by a few ulps so that
 // a ray decided by the float edge functions to pass on the leaf's side of a shared edge can never test as missing it
+// kPose: the kernel also WRITES the sheared strip (each 16-lane group poses the run of its own leaf; the leaves' runs
+// tile the stream, checked at model creation) and clears the counters of the kernels that follow -- ray_stream_kernel's
+// work, without a launch of its own ahead of this one on the step's serial chain.
+template <bool kPose>
 __global__ __launch_bounds__(kBoundsBlock) void ray_leaf_bounds_kernel(
     const RayElem* __restrict__ stream, int T, const TreeNode* __restrict__ nodes, int N,
-    const int32_t* __restrict__ height_off, const int32_t* __restrict__ height_nodes, float* __restrict__ bounds)
+    const int32_t* __restrict__ height_off, const int32_t* __restrict__ height_nodes, float* __restrict__ bounds,
+    const float* __restrict__ verts, const int32_t* __restrict__ vidx, const float* __restrict__ sign, int V, int Lexact,
+    RayElem* __restrict__ stream_out, uint4* __restrict__ zeroed, size_t zeroed_n)
 {
     const int b = blockIdx.y;
     const RayElem* st = stream + (size_t)b * T;
@@ -108,11 +114,25 @@ __global__ __launch_bounds__(kBoundsBlock) void ray_leaf_bounds_kernel(
     const bool real = i < height_off[1];                // all lanes stay: the DPP rows need them
     const int node = height_nodes[real ? i : height_off[0]];
     const int off = nodes[node].ex_off, len = real ? nodes[node].ex_len : 0;
+    if (kPose) {
+        for (size_t g = ((size_t)b * gridDim.x + blockIdx.x) * kBoundsBlock + threadIdx.x; g < zeroed_n;
+             g += (size_t)gridDim.x * gridDim.y * kBoundsBlock)
+            zeroed[g] = make_uint4(0u, 0u, 0u, 0u);
+        if (blockIdx.x == 0)                            // the padding behind the last run (three readable elements past the end)
+            for (int p = Lexact + (int)threadIdx.x; p < T; p += kBoundsBlock) stream_out[(size_t)b * T + p] = RayElem{0.f, 0.f, 0.f, 0.f};
+    }
     float lo[kSlabs], nhi[kSlabs];                      // minima of the projections and of their negatives
 #pragma unroll
     for (int k = 0; k < kSlabs; ++k) { lo[k] = 3.0e38f; nhi[k] = 3.0e38f; }
     for (int p = sub; p < len; p += 16) {
-        const RayElem e = st[off + p];
+        RayElem e;
+        if (kPose) {
+            const float* c = verts + ((size_t)b * V + vidx[off + p]) * 3;
+            e.x = shear_x(c[0], c[2]); e.y = shear_y(c[1], c[2]); e.z = c[2]; e.sign = sign[off + p];
+            stream_out[(size_t)b * T + off + p] = e;
+        } else {
+            e = st[off + p];
+        }
         float pr[kSlabs];
         slab_project(e.x, e.y, e.z, pr);
 #pragma unroll
@@ -1367,12 +1387,22 @@ static void launch_ray_boxes(const tuch_contact_model* m, const RayLayout& l, co
 {
     RayElem* st = (RayElem*)(ws + l.stream);
     float* bounds = (float*)(ws + l.bounds);
+    if (m->tree_leaf_runs_tile) {                       // one launch: every leaf poses its own run of the strip
+        hipLaunchKernelGGL(ray_leaf_bounds_kernel<true>, dim3(ceil_div(m->tree_leaves, kBoundsBlock / 16), B), dim3(kBoundsBlock), 0,
+                           s, (const RayElem*)st, l.T, (const TreeNode*)m->tree_node, m->tree_nodes,
+                           (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, bounds, verts,
+                           (const int32_t*)m->tree_vidx, (const float*)m->tree_sign, m->V, m->tree_exact_len, st,
+                           (uint4*)(ws + l.zeroed), l.zeroed_bytes / sizeof(uint4));
+        return;
+    }
     hipLaunchKernelGGL(ray_stream_kernel, dim3(ceil_div(l.T, kBlock), B), dim3(kBlock), 0, s, verts,
                        (const int32_t*)m->tree_vidx, (const float*)m->tree_sign, m->V, m->tree_exact_len, l.T, st,
                        (uint4*)(ws + l.zeroed), l.zeroed_bytes / sizeof(uint4));
-    hipLaunchKernelGGL(ray_leaf_bounds_kernel, dim3(ceil_div(m->tree_leaves, kBoundsBlock / 16), B), dim3(kBoundsBlock), 0, s,
+    hipLaunchKernelGGL(ray_leaf_bounds_kernel<false>, dim3(ceil_div(m->tree_leaves, kBoundsBlock / 16), B), dim3(kBoundsBlock), 0, s,
                        (const RayElem*)st, l.T, (const TreeNode*)m->tree_node, m->tree_nodes,
-                       (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, bounds);
+                       (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, bounds,
+                       (const float*)nullptr, (const int32_t*)nullptr, (const float*)nullptr, 0, 0, (RayElem*)nullptr,
+                       (uint4*)nullptr, (size_t)0);
 }
 
 // near leaves -> rays per leaf -> tiles -> crossing counts (count[b][slot])

@@ -33,14 +33,15 @@ __device__ __forceinline__ Best better(Best x, Best y)
 // One wavefront per (body, pair, 64 rows of the first region): unselected pairs leave at once, the
 // selected ones spread over the whole chip (the SMPLify use selects ~10 of ~280 pairs per body;
 // contact_from_verts, train_module.py:69-91, takes all pairs, unmasked).
-template <bool kMasked>
+template <bool kMasked, bool kInverted>
 __global__ __launch_bounds__(64) void region_pair_min_kernel(
     const float* __restrict__ verts, const int32_t* __restrict__ region_off,
     const int32_t* __restrict__ region_vidx, const int32_t* __restrict__ pairs,
     const uint8_t* __restrict__ select,        // [B,P] or nullptr (= all)
     const uint32_t* __restrict__ pair_mask,    // per-pair geomask blocks (kMasked)
     const int64_t* __restrict__ pair_mask_off,
-    int V, int P, unsigned long long* __restrict__ keys)   // [B,P], preset to all ones
+    int V, int P, unsigned long long* __restrict__ keys)   // [B,P], preset to all ones (kInverted: to zero, the key stored
+                                                           // complemented and merged with atomicMax: 0 = no candidate)
 {
     __shared__ __attribute__((aligned(16))) float sx[kTile], sy[kTile], sz[kTile];
     const int b = blockIdx.x, p = blockIdx.y;
@@ -99,8 +100,10 @@ __global__ __launch_bounds__(64) void region_pair_min_kernel(
     }
     // d >= 0, so the float's bit pattern orders like the value: (d, flat index) packs into one
     // 64-bit key whose minimum is independent of the arrival order -> deterministic
-    if (threadIdx.x == 0 && r.idx != 0x7fffffff)
-        atomicMin(&keys[o], ((unsigned long long)__float_as_uint(r.d) << 32) | (unsigned int)r.idx);
+    if (threadIdx.x == 0 && r.idx != 0x7fffffff) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(r.d) << 32) | (unsigned int)r.idx;
+        if (kInverted) atomicMax(&keys[o], ~key); else atomicMin(&keys[o], key);
+    }
 }
 
 // keys -> (min d2, arg-min vertex ids); unselected / empty pairs give 0 and (-1, -1).  The keys
@@ -166,17 +169,41 @@ extern "C" int tuch_region_pair_min(const tuch_contact_model* m, const float* ve
     }
     const dim3 grid(B, m->num_pairs, ceil_div(m->region_max, 64));
     if (use_geomask)
-        hipLaunchKernelGGL(region_pair_min_kernel<true>, grid, dim3(64), 0, s, verts, (const int32_t*)m->region_off,
+        hipLaunchKernelGGL((region_pair_min_kernel<true, false>), grid, dim3(64), 0, s, verts, (const int32_t*)m->region_off,
                            (const int32_t*)m->region_vidx, (const int32_t*)m->pairs, select, (const uint32_t*)m->pair_mask,
                            (const int64_t*)m->pair_mask_off, m->V, m->num_pairs, (unsigned long long*)out_ij);
     else
-        hipLaunchKernelGGL(region_pair_min_kernel<false>, grid, dim3(64), 0, s, verts, (const int32_t*)m->region_off,
+        hipLaunchKernelGGL((region_pair_min_kernel<false, false>), grid, dim3(64), 0, s, verts, (const int32_t*)m->region_off,
                            (const int32_t*)m->region_vidx, (const int32_t*)m->pairs, select, (const uint32_t*)nullptr,
                            (const int64_t*)nullptr, m->V, m->num_pairs, (unsigned long long*)out_ij);
     hipLaunchKernelGGL(region_pair_finalize_kernel, dim3(ceil_div(m->num_pairs, kBlock), B), dim3(kBlock), 0, s,
                        (const int32_t*)m->region_off, (const int32_t*)m->region_vidx, (const int32_t*)m->pairs,
                        m->num_pairs, out_min, out_ij);
     return tuch_check_launch("tuch_region_pair_min");
+}
+
+// The search alone: keys [B,P] (64-bit) must be ZERO on entry; on return a pair's key is the complement of
+// (bits of min d2) << 32 | flat index (first-region row * n2 + second-region column), 0 for an unselected / empty pair.
+// No clearing launch, no finalize launch: the consumer (tuch_smplify_stage2_fused) decodes the keys itself, and the
+// caller clears them together with whatever else it has to clear.
+extern "C" int tuch_region_pair_keys(const tuch_contact_model* m, const float* verts, int B, const uint8_t* select,
+                                     int use_geomask, void* keys_zeroed, void* stream)
+{
+    TUCH_REQUIRE(m && verts && keys_zeroed, "tuch_region_pair_keys: null pointer");
+    TUCH_REQUIRE(B > 0 && B <= 65535, "tuch_region_pair_keys: bad batch %d", B);
+    TUCH_REQUIRE(m->num_pairs > 0, "tuch_region_pair_keys: model has no region pairs");
+    TUCH_REQUIRE(!use_geomask || m->pair_mask, "tuch_region_pair_keys: model has no geodesic mask");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(B, m->num_pairs, ceil_div(m->region_max, 64));
+    if (use_geomask)
+        hipLaunchKernelGGL((region_pair_min_kernel<true, true>), grid, dim3(64), 0, s, verts, (const int32_t*)m->region_off,
+                           (const int32_t*)m->region_vidx, (const int32_t*)m->pairs, select, (const uint32_t*)m->pair_mask,
+                           (const int64_t*)m->pair_mask_off, m->V, m->num_pairs, (unsigned long long*)keys_zeroed);
+    else
+        hipLaunchKernelGGL((region_pair_min_kernel<false, true>), grid, dim3(64), 0, s, verts, (const int32_t*)m->region_off,
+                           (const int32_t*)m->region_vidx, (const int32_t*)m->pairs, select, (const uint32_t*)nullptr,
+                           (const int64_t*)nullptr, m->V, m->num_pairs, (unsigned long long*)keys_zeroed);
+    return tuch_check_launch("tuch_region_pair_keys");
 }
 
 extern "C" int tuch_region_pair_min_bwd(const tuch_contact_model* m, const float* verts, int B,

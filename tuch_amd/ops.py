@@ -334,23 +334,22 @@ class _Stage2Tail(torch.autograd.Function):
         gc = torch.empty(b, 3, dtype=torch.float32, device=v.device)
         gp = torch.empty(b, 69, dtype=torch.float32, device=v.device)
         p = model.num_pairs if select is not None else 0
-        r2r = torch.empty(b, p, dtype=torch.float32, device=v.device) if p else None
-        ij = torch.empty(b, p, 2, dtype=torch.int32, device=v.device) if p else None
 
         def beside_the_walk():          # on the second stream (ContactModel.exterior_and_partner)
+            # ONE cleared buffer: the vertex gradient the unit backward accumulates into, the arrival counter of the
+            # tail kernel ("the last block adds up": it belongs to THIS call -- no counter shared between streams, none
+            # left non-zero by an aborted launch) and the region pairs' keys (tuch_region_pair_keys wants them zero)
+            n = v.numel()
+            k0 = n + 1 + ((n + 1) & 1)                  # the 64-bit keys start on an even word behind the counter
+            zeros = torch.zeros(k0 + 2 * b * p, dtype=torch.float32, device=v.device)
+            keys = zeros[k0:].view(torch.int64) if p else None
             if p:
-                _C.check(L.tuch_region_pair_min(model._handle, _C.ptr(v), b, _C.ptr(select), 1, _C.ptr(r2r), _C.ptr(ij),
-                                                _C.stream()))
+                _C.check(L.tuch_region_pair_keys(model._handle, _C.ptr(v), b, _C.ptr(select), 1, _C.ptr(keys), _C.stream()))
             _C.check(L.tuch_smplify_small_terms(
                 _C.ptr(j), _C.ptr(cam_t), _C.ptr(cam_c), _C.ptr(j2d), _C.ptr(conf), _C.ptr(pose), _C.ptr(means),
                 _C.ptr(precisions), _C.ptr(logw), b, nj, means.shape[0], float(const['focal']), float(const['sigma']),
                 float(const['prior_scale']), _C.ptr(small), _C.ptr(gj), _C.ptr(gc), _C.ptr(gp), _C.stream()))
-            # the cleared vertex gradient the backward pass accumulates into: filled here, beside the walk, instead of
-            # between two kernels of the backward chain.  One more zero word behind it is the arrival counter of
-            # stage2_finish ("the last block adds up"): it belongs to THIS call -- no counter shared between streams,
-            # none left non-zero by an aborted launch
-            zeros = torch.zeros(v.numel() + 1, dtype=torch.float32, device=v.device)
-            return (r2r, ij, small, gj, gc, gp, zeros[:v.numel()].view(v.shape), zeros[v.numel():].view(torch.int32))
+            return (keys, None, small, gj, gc, gp, zeros[:n].view(v.shape), zeros[n:n + 1].view(torch.int32))
         exterior, _, partner, _extra = model.exterior_and_partner(v, apply_segments=const['apply_segments'],
                                                                   also=beside_the_walk)
         out = torch.empty(1, dtype=torch.float32, device=v.device)
@@ -360,9 +359,10 @@ class _Stage2Tail(torch.autograd.Function):
         want_grad = any(ctx.needs_input_grad[:4])
         gv = _extra[6] if want_grad else None
         _C.check(L.tuch_smplify_stage2_fused(_C.ptr(v), _C.ptr(partner), _C.ptr(exterior), _C.ptr(valid), b, v.shape[1],
-                                             MODE_SMPLIFY, float(const['euclthres']), _C.ptr(small), _C.ptr(r2r), _C.ptr(ij), p,
+                                             MODE_SMPLIFY, float(const['euclthres']), _C.ptr(small), None, None, p,
                                              float(const['contact_scale']), float(const['r2r_scale']), _C.ptr(share),
-                                             _C.ptr(_extra[7]), None, _C.ptr(out), _C.ptr(gv), _C.stream()))
+                                             _C.ptr(_extra[7]), None, _C.ptr(out), _C.ptr(gv),
+                                             model._handle if p else None, _C.ptr(_extra[0]), _C.stream()))
         if want_grad:
             ctx.save_for_backward(gv, gj, gc, gp)
         ctx.in_dtypes = (verts.dtype, joints.dtype, camera_t.dtype, body_pose.dtype)
