@@ -148,7 +148,15 @@ int tuch_smplify_stage2_fused(const float* points, const int32_t* partner, const
                               const uint8_t* body_valid, int B, int N, int mode, float euclthres,
                               const float* small_terms, const float* r2r, const int32_t* ij, int P, float contact_scale,
                               float r2r_scale, float* share, int* ticket, float* terms, float* out, float* grad_points,
-                              const tuch_contact_model* model, const void* pair_keys, void* stream);
+                              const tuch_contact_model* model, const void* pair_keys, void* grad_fixed_zeroed, void* stream);
+/* Deterministic mode (also TUCH_DETERMINISTIC=1 in the environment when the library is loaded): the gradient scatters of
+ * tuch_smplify_stage2_fused (contact terms, region minima) and of tuch_smpl_backward (skinning adjoint) accumulate 64-bit
+ * fixed-point numbers (2^-36) with integer atomics instead of floats -- sums that do not depend on the order of arrival,
+ * so an SMPLify-DC fit reproduces bit for bit.  tuch_smplify_stage2_fused then wants grad_fixed_zeroed = B*N*3 zeroed
+ * 64-bit words (NULL: float atomics, whatever the mode) and converts to grad_points with a second launch. */
+void tuch_set_deterministic(int on);
+int tuch_get_deterministic(void);
+
 /* The region-pair search of tuch_region_pair_min alone, for tuch_smplify_stage2_fused(model, pair_keys): keys [B,P]
  * 64-bit words, ZERO on entry (the caller clears them with whatever else it clears); no clearing and no finalize
  * launch.  pair_keys given: r2r / ij of tuch_smplify_stage2_fused are ignored. */

@@ -330,3 +330,38 @@ def test_loops_kept_between_calls_reproduce_fresh_fits(monkeypatch):
         assert_close(a.cpu().numpy(), b.detach().cpu().numpy(), 2e-3, 2e-4, name)
     assert len(a2[6]) == len(b2[6]) == 8
     assert_close(a2[6][-1].cpu().numpy(), b2[6][-1].detach().cpu().numpy(), 2e-3, 2e-4, 'last optiverts')
+
+
+def test_deterministic_mode_reproduces_a_fit_bit_for_bit():
+    """ops.set_deterministic(True) (TUCH_DETERMINISTIC=1): the gradient scatters of the stage-2 tail and of the SMPL
+    adjoint accumulate 64-bit fixed-point numbers with integer atomics instead of float atomics -- the same fit twice,
+    from fresh fitters, gives identical BITS in every output (vertices, joints, pose, betas, camera, reprojection loss,
+    the per-iteration vertices); and the deterministic fit agrees with the float-atomic one to float tolerance."""
+    from tuch_amd import ops
+    from tuch_amd.smplify.smplifydc import SMPLifyDC
+    batch = 4
+    s = _setup(batch, 17)
+    body, t = s['body'], s['t']
+
+    def fit():
+        fitter = SMPLifyDC(step_size=1e-2, batch_size=batch, num_iters=12, focal_length=5000., geodistssmpl=t(body.geodesics),
+                           geothres=0.3, euclthres=0.02, device=torch.device(DEV), smpl=s['smpl'], pose_prior=s['prior'])
+        out = fitter(torch.cat([t(s['go']), t(s['bp'])], 1), t(s['be']), t(s['cam_t']), torch.zeros(batch, 2, device=DEV),
+                     t(s['kp']), use_contact=True, contactlist=s['cdict'], gt_contact=[t(s['gt']), None],
+                     ignore_idxs=torch.zeros(batch, dtype=torch.bool, device=DEV),
+                     has_discrete_contact=torch.ones(batch, dtype=torch.bool, device=DEV),
+                     contact_loss_weight=2000.0, segments=s['segments'])
+        torch.cuda.synchronize()
+        return [x.detach().clone() for x in out[:6]] + [v.detach().clone() for v in out[6]]
+    assert not ops.deterministic()
+    plain = fit()
+    ops.set_deterministic(True)
+    try:
+        first, second = fit(), fit()
+    finally:
+        ops.set_deterministic(False)
+    assert len(first) == len(second) > 6
+    for a, b in zip(first, second):
+        assert torch.equal(a, b)
+    for a, b in zip(first[:6], plain[:6]):
+        assert_close(a.cpu().numpy(), b.cpu().numpy(), 2e-3, 2e-4 * max(float(b.abs().max()), 1e-3), 'deterministic vs float atomics')

@@ -111,7 +111,9 @@ _SIGNATURES = {
     'tuch_smplify_stage2_fused_scratch_floats': (c_size_t, [c_int]),
     'tuch_smplify_stage2_fused': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
                                            c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                           c_void_p, c_void_p, c_void_p]),
+                                           c_void_p, c_void_p, c_void_p, c_void_p]),
+    'tuch_set_deterministic': (None, [c_int]),
+    'tuch_get_deterministic': (c_int, []),
     'tuch_region_pair_keys': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     'tuch_smplify_stage2_finish': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
                                            c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -25,3 +25,9 @@ int tuch_check_launch(const char* what)
 
 extern "C" const char* tuch_last_error(void) { return g_error; }
 extern "C" int tuch_abi_version(void) { return 1; }
+
+#include <stdlib.h>
+static int g_deterministic = [] { const char* e = getenv("TUCH_DETERMINISTIC"); return e && atoi(e) != 0 ? 1 : 0; }();
+int tuch_deterministic() { return g_deterministic; }
+extern "C" void tuch_set_deterministic(int on) { g_deterministic = on ? 1 : 0; }
+extern "C" int tuch_get_deterministic(void) { return g_deterministic; }

@@ -315,7 +315,8 @@ __global__ __launch_bounds__(kFusedBlock) void stage2_fused_kernel(
     float* __restrict__ grad,         // [B,N,3] pre-zeroed, or nullptr (value only)
     // instead of (r2r, ij): the raw keys of tuch_region_pair_keys and the model's region tables
     const unsigned long long* __restrict__ pair_keys, const int32_t* __restrict__ region_off,
-    const int32_t* __restrict__ region_vidx, const int32_t* __restrict__ pairs)
+    const int32_t* __restrict__ region_vidx, const int32_t* __restrict__ pairs,
+    long long* __restrict__ grad_fixed)     // deterministic mode: [B,N,3] 64-bit fixed-point accumulators (zeroed) instead of grad
 {
     __shared__ float smem[kFusedBlock / 64];
     __shared__ bool last;
@@ -323,6 +324,12 @@ __global__ __launch_bounds__(kFusedBlock) void stage2_fused_kernel(
     const bool valid = !body_valid || body_valid[b];
     const float* pb = pts + (size_t)b * N * 3;
     float* gb = grad ? grad + (size_t)b * N * 3 : nullptr;
+    long long* fb = grad_fixed ? grad_fixed + (size_t)b * N * 3 : nullptr;
+    const bool want = gb || fb;
+    auto add3 = [&](int at, float x, float y, float z) {
+        if (fb) { fixed_add(fb + 3 * (size_t)at, x); fixed_add(fb + 3 * (size_t)at + 1, y); fixed_add(fb + 3 * (size_t)at + 2, z); }
+        else { atomicAdd(gb + 3 * (size_t)at, x); atomicAdd(gb + 3 * (size_t)at + 1, y); atomicAdd(gb + 3 * (size_t)at + 2, z); }
+    };
     float in_sum = 0.0f, ex_sum = 0.0f, r_sum = 0.0f;
     const int per = (N + kFusedSplits - 1) / kFusedSplits;
     const int beg = s * per, end = min(beg + per, N);
@@ -353,12 +360,10 @@ __global__ __launch_bounds__(kFusedBlock) void stage2_fused_kernel(
                 const bool ext = ex[u] != 0;
                 const Term t = contact_term(d, ext, mode, euclthres);
                 if (ext) ex_sum += t.value; else in_sum += t.value;
-                if (gb && d > 0.0f && t.dd != 0.0f) {
+                if (want && d > 0.0f && t.dd != 0.0f) {
                     const float c = contact_scale * t.dd / d;
-                    float* gi = gb + 3 * (size_t)i;
-                    float* gq = gb + 3 * (size_t)pr[u];
-                    atomicAdd(gi + 0, c * dx); atomicAdd(gi + 1, c * dy); atomicAdd(gi + 2, c * dz);
-                    atomicAdd(gq + 0, -c * dx); atomicAdd(gq + 1, -c * dy); atomicAdd(gq + 2, -c * dz);
+                    add3(i, c * dx, c * dy, c * dz);
+                    add3(pr[u], -c * dx, -c * dy, -c * dz);
                 }
             }
         }
@@ -382,13 +387,14 @@ __global__ __launch_bounds__(kFusedBlock) void stage2_fused_kernel(
                 r_sum += r2r[o];
                 if (ij) { i = ij[2 * o]; j = ij[2 * o + 1]; }
             }
-            if (gb && r2r_scale != 0.0f) {
-                if (i >= 0 && j >= 0)
-                    for (int c = 0; c < 3; ++c) {
-                        const float d = 2.0f * r2r_scale * (pb[3 * i + c] - pb[3 * j + c]);
-                        atomicAdd(gb + 3 * i + c, d);
-                        atomicAdd(gb + 3 * j + c, -d);
-                    }
+            if (want && r2r_scale != 0.0f) {
+                if (i >= 0 && j >= 0) {
+                    const float k2 = 2.0f * r2r_scale;
+                    const float ex2 = k2 * (pb[3 * i] - pb[3 * j]), ey2 = k2 * (pb[3 * i + 1] - pb[3 * j + 1]),
+                                ez2 = k2 * (pb[3 * i + 2] - pb[3 * j + 2]);
+                    add3(i, ex2, ey2, ez2);
+                    add3(j, -ex2, -ey2, -ez2);
+                }
             }
         }
     }
@@ -431,6 +437,13 @@ __global__ __launch_bounds__(kFusedBlock) void stage2_fused_kernel(
     }
 }
 
+// deterministic mode: the fixed-point accumulators -> the float gradient
+__global__ __launch_bounds__(256) void fixed_to_float_kernel(const long long* __restrict__ acc, float* __restrict__ out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = fixed_value(acc[i]);
+}
+
 }  // namespace
 
 extern "C" size_t tuch_smplify_stage2_fused_scratch_floats(int B) { return (size_t)(B > 0 ? B : 0) * kFusedSplits * 3; }
@@ -444,7 +457,7 @@ extern "C" int tuch_smplify_stage2_fused(const float* points, const int32_t* par
                                          const float* small_terms, const float* r2r, const int32_t* ij, int P,
                                          float contact_scale, float r2r_scale, float* share, int* ticket, float* terms,
                                          float* out, float* grad_points, const tuch_contact_model* model,
-                                         const void* pair_keys, void* stream)
+                                         const void* pair_keys, void* grad_fixed_zeroed, void* stream)
 {
     TUCH_REQUIRE(points && partner && exterior && small_terms && share && ticket && out,
                  "tuch_smplify_stage2_fused: null pointer");
@@ -452,11 +465,20 @@ extern "C" int tuch_smplify_stage2_fused(const float* points, const int32_t* par
     TUCH_REQUIRE(!pair_keys || (model && model->num_pairs == P && P > 0),
                  "tuch_smplify_stage2_fused: pair keys need the model they were computed with (P = its number of pairs)");
     const bool raw = pair_keys != nullptr;
+    // deterministic mode (tuch_deterministic(): TUCH_DETERMINISTIC=1 / tuch_set_deterministic): the caller passes B*N*3
+    // zeroed 64-bit words; the scatter accumulates fixed-point integers there, a second launch converts to grad_points
+    const bool fixed = grad_points && grad_fixed_zeroed;
     hipLaunchKernelGGL(stage2_fused_kernel, dim3(kFusedSplits, B), dim3(kFusedBlock), 0, (hipStream_t)stream, points, partner,
                        exterior, body_valid, N, mode, euclthres, small_terms, (P > 0 && !raw ? r2r : (const float*)nullptr),
                        (P > 0 && !raw ? ij : (const int32_t*)nullptr), P, contact_scale, r2r_scale, share, ticket, terms, out,
-                       grad_points, (const unsigned long long*)pair_keys, raw ? (const int32_t*)model->region_off : nullptr,
-                       raw ? (const int32_t*)model->region_vidx : nullptr, raw ? (const int32_t*)model->pairs : nullptr);
+                       fixed ? (float*)nullptr : grad_points, (const unsigned long long*)pair_keys,
+                       raw ? (const int32_t*)model->region_off : nullptr, raw ? (const int32_t*)model->region_vidx : nullptr,
+                       raw ? (const int32_t*)model->pairs : nullptr, fixed ? (long long*)grad_fixed_zeroed : (long long*)nullptr);
+    if (fixed) {
+        const size_t n = (size_t)B * N * 3;
+        hipLaunchKernelGGL(fixed_to_float_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const long long*)grad_fixed_zeroed, grad_points, n);
+    }
     return tuch_check_launch("tuch_smplify_stage2_fused");
 }
 

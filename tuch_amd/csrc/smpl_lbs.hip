@@ -431,10 +431,16 @@ __global__ __launch_bounds__(256) void assemble_joints_kernel(
 // g_all[b][54][3] = scatter of g_joints through joint_map (deterministic gather form)
 __global__ __launch_bounds__(64) void joints_bwd_kernel(
     const float* __restrict__ g_joints, const int32_t* __restrict__ joint_map, float* __restrict__ g_all,
-    float* __restrict__ gA_clear)
+    float* __restrict__ gA_clear, int fixed)
 {
-    // also clears the body's [32][16] accumulator of the skinning adjoint, which runs next (no memset node in between)
-    for (int i = threadIdx.x; i < 32 * 16; i += 64) gA_clear[(size_t)blockIdx.x * 32 * 16 + i] = 0.f;
+    // also clears the body's [32][16] accumulator of the skinning adjoint, which runs next (no memset node in between);
+    // deterministic mode (`fixed`): the accumulators are 64-bit fixed-point words (common.h)
+    if (fixed) {
+        long long* z = reinterpret_cast<long long*>(gA_clear) + (size_t)blockIdx.x * 32 * 16;
+        for (int i = threadIdx.x; i < 32 * 16; i += 64) z[i] = 0;
+    } else {
+        for (int i = threadIdx.x; i < 32 * 16; i += 64) gA_clear[(size_t)blockIdx.x * 32 * 16 + i] = 0.f;
+    }
     // the map and the body's 49 x 3 gradients go to LDS in one round of loads; the 49-way match runs from there
     __shared__ int sMap[kOutJoints];
     __shared__ float sG[kOutJoints * 3];
@@ -458,7 +464,7 @@ __global__ __launch_bounds__(64) void joints_bwd_kernel(
 __global__ __launch_bounds__(kSkinBlock) void skin_bwd_kernel(
     const float* __restrict__ g_verts, const float* __restrict__ g_all, const float* __restrict__ Jrx,
     const int32_t* __restrict__ extra_ids, const float* __restrict__ v_posed, const float* __restrict__ A,
-    const float* __restrict__ weights, int V, float* __restrict__ g_vposed, float* __restrict__ gA_part)
+    const float* __restrict__ weights, int V, float* __restrict__ g_vposed, float* __restrict__ gA_part, int fixed)
 {
     __shared__ float sG[kSkinBlock][16];      // per vertex: g_v (x) [v_posed;1], 12 used
     __shared__ int sIds[kPicked];
@@ -533,6 +539,12 @@ __global__ __launch_bounds__(kSkinBlock) void skin_bwd_kernel(
     for (int i = 0; i < kSteps; ++i)
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(j < kJoints ? a[i] : 0.f, sG[k_beg + i * 4 + lq][lm], acc, 0, 0, 0);
     // [B][32][16], zeroed by the caller: the vertex blocks accumulate with float atomics
+    if (fixed) {                                        // deterministic mode: integer atomics on fixed-point words
+        long long* out = reinterpret_cast<long long*>(gA_part) + ((size_t)b * 32 + (wave & 1) * 16) * 16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fixed_add(&out[(lq * 4 + r) * 16 + lm], acc[r]);
+        return;
+    }
     float* out = gA_part + ((size_t)b * 32 + (wave & 1) * 16) * 16;
 #pragma unroll
     for (int r = 0; r < 4; ++r) atomicAdd(&out[(lq * 4 + r) * 16 + lm], acc[r]);
@@ -625,7 +637,7 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(
     int bpad, const float* __restrict__ g_all, const float* __restrict__ R, const float* __restrict__ J,
     const float* __restrict__ world, PoseRef pose, int pose2rot,
     const float* __restrict__ J_shapedirs, const int32_t* __restrict__ parents, int max_depth,
-    PoseGrad g_pose, float* __restrict__ g_betas)
+    PoseGrad g_pose, float* __restrict__ g_betas, int fixed)
 {
     __shared__ float sGA[kJoints][12];
     __shared__ float sGF[224];
@@ -645,8 +657,14 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(
     // (gA: one [32][16] accumulator per body, the skinning adjoint adds its blocks with atomics.)
     float ga0 = 0.f, ga1 = 0.f, w_v = 0.f, r_v = 0.f, j_v = 0.f, gall_v = 0.f, aa_v = 0.f, jsd[3] = {0.f, 0.f, 0.f};
     int par_v = -1, dep_v = -1;
-    ga0 = gA_part[((size_t)b * 32 + t / 12) * 16 + t % 12];
-    if (t + 256 < kJoints * 12) ga1 = gA_part[((size_t)b * 32 + (t + 256) / 12) * 16 + (t + 256) % 12];
+    if (fixed) {
+        const long long* gf = reinterpret_cast<const long long*>(gA_part);
+        ga0 = fixed_value(gf[((size_t)b * 32 + t / 12) * 16 + t % 12]);
+        if (t + 256 < kJoints * 12) ga1 = fixed_value(gf[((size_t)b * 32 + (t + 256) / 12) * 16 + (t + 256) % 12]);
+    } else {
+        ga0 = gA_part[((size_t)b * 32 + t / 12) * 16 + t % 12];
+        if (t + 256 < kJoints * 12) ga1 = gA_part[((size_t)b * 32 + (t + 256) / 12) * 16 + (t + 256) % 12];
+    }
     if (t < kJoints * 9) {
         w_v = world[((size_t)b * kJoints + t / 9) * 12 + t % 9];
         r_v = R[(size_t)b * kJoints * 9 + t];
@@ -831,7 +849,8 @@ BwdLayout bwd_layout(const tuch_smpl_model* m, int B)
     size_t o = 0;
     l.g_all = o;     o += align256((size_t)B * kAllJoints * 3 * 4);
     l.g_vposed = o;  o += align256((size_t)B * m->N3 * 4);
-    l.gA_part = o;   o += align256((size_t)B * 32 * 16 * 4);          // one accumulator per body (atomics over the blocks)
+    l.gA_part = o;   o += align256((size_t)B * 32 * 16 * 8);          // one accumulator per body (atomics over the blocks;
+                                                                       // 64-bit words in deterministic mode)
     l.feat_part = o; o += align256((size_t)l.feat_chunks * l.bpad * 224 * 4);
     l.total = o;
     return l;
@@ -1013,15 +1032,16 @@ extern "C" int tuch_smpl_backward_split(const tuch_smpl_model* m, const float* g
     float *g_all = (float*)(ws + l.g_all), *g_vposed = (float*)(ws + l.g_vposed), *gA_part = (float*)(ws + l.gA_part),
           *feat_part = (float*)(ws + l.feat_part);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(joints_bwd_kernel, dim3(B), dim3(64), 0, s, g_joints, (const int32_t*)m->joint_map, g_all, gA_part);
+    const int fixed = tuch_deterministic();
+    hipLaunchKernelGGL(joints_bwd_kernel, dim3(B), dim3(64), 0, s, g_joints, (const int32_t*)m->joint_map, g_all, gA_part, fixed);
     hipLaunchKernelGGL(skin_bwd_kernel, dim3(l.skin_blocks, B), dim3(kSkinBlock), 0, s, g_verts, (const float*)g_all,
                        (const float*)m->Jrx, (const int32_t*)m->extra_ids, v_posed, A, (const float*)m->weights, m->V,
-                       g_vposed, gA_part);
+                       g_vposed, gA_part, fixed);
     hipLaunchKernelGGL(blend_bwd_kernel, dim3(l.feat_chunks, ceil_div(l.bpad / 16, kBlendBwdGroups), 14 / kBlendBwdTiles),
                        dim3(64 * kBlendBwdWaves), 0, s, (const float*)g_vposed, (const float*)m->blend, B, m->N3, l.bpad, feat_part);
     hipLaunchKernelGGL(pose_bwd_kernel, dim3(B), dim3(256), 0, s, (const float*)gA_part,
                        (const float*)feat_part, l.feat_chunks, l.bpad, (const float*)g_all, R, J, world, pose, pose2rot,
-                       (const float*)m->J_shapedirs, (const int32_t*)m->parents, m->max_depth, g_pose, g_betas);
+                       (const float*)m->J_shapedirs, (const int32_t*)m->parents, m->max_depth, g_pose, g_betas, fixed);
     return tuch_check_launch("tuch_smpl_backward");
 }
 

@@ -63,6 +63,18 @@ def off_default_stream(device):
         cur.wait_stream(s)
 
 
+def deterministic() -> bool:
+    """Deterministic mode of the library (include/tuch_amd.h: tuch_set_deterministic; TUCH_DETERMINISTIC=1)."""
+    return bool(_C.lib().tuch_get_deterministic())
+
+
+def set_deterministic(on: bool) -> None:
+    """Gradient scatters through 64-bit fixed-point integer atomics instead of float atomics: an SMPLify-DC fit reproduces
+    bit for bit (stage-2 tail and SMPL adjoint; the training losses' HD / plain contact terms keep float atomics).
+    Graphs captured before the switch keep the mode they were captured in."""
+    _C.lib().tuch_set_deterministic(int(bool(on)))
+
+
 _ONES = {}
 def backward_scalar(loss: torch.Tensor) -> None:
     """``loss.backward()`` for a scalar loss with the seed gradient (ones) taken from a cache: autograd otherwise fills a
@@ -341,15 +353,17 @@ class _Stage2Tail(torch.autograd.Function):
             # left non-zero by an aborted launch) and the region pairs' keys (tuch_region_pair_keys wants them zero)
             n = v.numel()
             k0 = n + 1 + ((n + 1) & 1)                  # the 64-bit keys start on an even word behind the counter
-            zeros = torch.zeros(k0 + 2 * b * p, dtype=torch.float32, device=v.device)
-            keys = zeros[k0:].view(torch.int64) if p else None
+            det = 2 * n if deterministic() else 0       # deterministic mode: 64-bit fixed-point accumulators
+            zeros = torch.zeros(k0 + 2 * b * p + det, dtype=torch.float32, device=v.device)
+            keys = zeros[k0:k0 + 2 * b * p].view(torch.int64) if p else None
+            fixed = zeros[k0 + 2 * b * p:].view(torch.int64) if det else None
             if p:
                 _C.check(L.tuch_region_pair_keys(model._handle, _C.ptr(v), b, _C.ptr(select), 1, _C.ptr(keys), _C.stream()))
             _C.check(L.tuch_smplify_small_terms(
                 _C.ptr(j), _C.ptr(cam_t), _C.ptr(cam_c), _C.ptr(j2d), _C.ptr(conf), _C.ptr(pose), _C.ptr(means),
                 _C.ptr(precisions), _C.ptr(logw), b, nj, means.shape[0], float(const['focal']), float(const['sigma']),
                 float(const['prior_scale']), _C.ptr(small), _C.ptr(gj), _C.ptr(gc), _C.ptr(gp), _C.stream()))
-            return (keys, None, small, gj, gc, gp, zeros[:n].view(v.shape), zeros[n:n + 1].view(torch.int32))
+            return (keys, fixed, small, gj, gc, gp, zeros[:n].view(v.shape), zeros[n:n + 1].view(torch.int32))
         exterior, _, partner, _extra = model.exterior_and_partner(v, apply_segments=const['apply_segments'],
                                                                   also=beside_the_walk)
         out = torch.empty(1, dtype=torch.float32, device=v.device)
@@ -362,7 +376,8 @@ class _Stage2Tail(torch.autograd.Function):
                                              MODE_SMPLIFY, float(const['euclthres']), _C.ptr(small), None, None, p,
                                              float(const['contact_scale']), float(const['r2r_scale']), _C.ptr(share),
                                              _C.ptr(_extra[7]), None, _C.ptr(out), _C.ptr(gv),
-                                             model._handle if p else None, _C.ptr(_extra[0]), _C.stream()))
+                                             model._handle if p else None, _C.ptr(_extra[0]),
+                                             _C.ptr(_extra[1]) if want_grad else None, _C.stream()))
         if want_grad:
             ctx.save_for_backward(gv, gj, gc, gp)
         ctx.in_dtypes = (verts.dtype, joints.dtype, camera_t.dtype, body_pose.dtype)
