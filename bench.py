@@ -27,6 +27,8 @@ Rank 0 prints ONE JSON line (contract in the task description) including
   shard_sweep  -- the step at 8/16/32/64 bodies on one GPU (the per-GPU shards of a global batch of 64)
   workloads    -- the per-rank workloads of BASELINE configs 3, 4 and 5
   worst_case   -- every body self-penetrating; folded: limbs pushed THROUGH the body
+  deterministic_mode -- the step with bit-reproducible gradient scatters (TUCH_DETERMINISTIC=1)
+  irregular_topology -- the step and its pruning statistics on the irregular-topology body next to the lat-long one
 --config {2,3,4-shard,5-shard} makes one of those workloads the timed step instead (its own metric name).
 """
 import argparse
@@ -96,20 +98,21 @@ def profile_constants():
         if not all(os.path.exists(f) for f in files.values()):
             continue
         rows = {k: _pmc_rows(f) for k, f in files.items()}
-        for name in ('v2v_tree_kernel', 'ray_leaf_kernel'):
-            pick = lambda table: next((c for k, c in table.items() if name in k), None)
-            fe, wr, sq = pick(rows['fetch']), pick(rows['write']), pick(rows['sq'])
+        for key, names in (('search', ('v2v_scan_kernel', 'v2v_leaves_kernel', 'v2v_tree_kernel')), ('ray_leaf_kernel', ('ray_leaf_kernel',))):
+            pick = lambda table: next(((k, c) for n in names for k, c in table.items() if n in k), (None, None))
+            (kname, fe), (_, wr), (_, sq) = pick(rows['fetch']), pick(rows['write']), pick(rows['sq'])
             if fe and wr and sq and sq.get('GRBM_GUI_ACTIVE'):
-                out[name] = {'traffic_bytes': int((fe['FETCH_SIZE'] + wr['WRITE_SIZE']) * 1024),
-                             'valu_busy': round(sq['SQ_ACTIVE_INST_VALU'] * 4 / (1024 * sq['GRBM_GUI_ACTIVE'] / 8), 3),
-                             'valu_instr': sq.get('SQ_INSTS_VALU'), 'salu_instr': sq.get('SQ_INSTS_SALU'),
-                             'source': 'profiles/%s_pmc_{fetch,write,sq}.txt (batch 64, inside the step); from profiles/, '
-                                       'not measured in this run' % tag}
+                out[key] = {'kernel': (re.search(r'(\w+_kernel)', kname) or [None, kname])[1],
+                            'traffic_bytes': int((fe['FETCH_SIZE'] + wr['WRITE_SIZE']) * 1024),
+                            'valu_busy': round(sq['SQ_ACTIVE_INST_VALU'] * 4 / (1024 * sq['GRBM_GUI_ACTIVE'] / 8), 3),
+                            'valu_instr': sq.get('SQ_INSTS_VALU'), 'salu_instr': sq.get('SQ_INSTS_SALU'),
+                            'source': 'profiles/%s_pmc_{fetch,write,sq}.txt (batch 64, inside the step); from profiles/, '
+                                      'not measured in this run' % tag}
         if len(out) == 2:
             break
-    for name in ('v2v_tree_kernel', 'ray_leaf_kernel'):
-        out.setdefault(name, {'traffic_bytes': None, 'valu_busy': None, 'valu_instr': None, 'salu_instr': None,
-                              'source': 'no PMC summary under profiles/'})
+    for key in ('search', 'ray_leaf_kernel'):
+        out.setdefault(key, {'kernel': None, 'traffic_bytes': None, 'valu_busy': None, 'valu_instr': None, 'salu_instr': None,
+                             'source': 'no PMC summary under profiles/'})
     return out
 
 
@@ -159,21 +162,24 @@ def launch_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
-def synthetic_body():
+def synthetic_body(topology='uv'):
+    """'uv': the lat-long sphere warped into a humanoid (V=6890, F=13776: the headline); 'ico': the irregular one
+    (geodesic icosahedron + edge flips: V=6762, valence 4-9, painted ragged segments)."""
     from tuch_amd.synthetic import make_body
-    if 'body' not in _BODY:
-        _BODY['body'] = make_body(84, 82, seed=1234)
-    return _BODY['body']
+    key = 'body' if topology == 'uv' else 'body_' + topology
+    if key not in _BODY:
+        _BODY[key] = make_body(84, 82, seed=1234) if topology == 'uv' else make_body(topology='ico', freq=26, seed=1234)
+    return _BODY[key]
 
 
-def build_problem(batch, device, seed, penetrating_fraction=0.5, folded=False):
+def build_problem(batch, device, seed, penetrating_fraction=0.5, folded=False, topology='uv'):
     from tuch_amd.models.smpl import SMPL
     from tuch_amd.smplify.prior import MaxMixturePrior
     from tuch_amd.synthetic import folded_poses, random_poses
     from tuch_amd.utils.geometry import perspective_projection
     from tuch_amd.utils.segmentation import BatchBodySegment
-    body = synthetic_body()
-    key = ('shared', str(device))
+    body = synthetic_body(topology)
+    key = ('shared', str(device), topology)
     if key not in _BODY:       # model constants are shared by every problem built on this device
         smpl = SMPL(model_data=body, batch_size=batch).to(device)
         prior = MaxMixturePrior(num_gaussians=8, gmm=body.gmm).to(device)
@@ -421,8 +427,8 @@ def rooflines(p, batch):
     ref_layout_bytes = batch * (12 * v + v * v + 8 * v)           # SURVEY.md 8(d) layout (i)
     compact_bytes = batch * (12 * v + 8 * v) + v * v // 8         # layout (ii): bit-packed mask read once
     prof = profile_constants()
-    prof_v = prof['v2v_tree_kernel']
-    roof = {'kernel': 'v2v_tree_kernel (+ v2v_rows, tree_inner_bounds, v2v_seed, v2v_tree_finalize)', 'bound': 'valu',
+    prof_v = prof['search']
+    roof = {'kernel': 'v2v_scan_kernel (+ v2v_rows, tree_inner_bounds, v2v_seed, v2v_tree_finalize)', 'bound': 'valu',
             'achieved': round(ach_v, 2), 'peak': PEAK_FP32_VECTOR_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(ach_v / PEAK_FP32_VECTOR_TFLOPS, 4),
             'traffic': prof_v['traffic_bytes'] if batch == BATCH_PER_GPU else None,
@@ -584,6 +590,52 @@ def worst_case(device, seed, batch, folded=False):
             'solid_angle_tree_walk_steps': work['leaf_elements'] + work['cap_elements'],
             'mean_interior_vertices_per_body': round(interior, 1),
             'what': 'batch %d, penetrating_fraction=1.0 (default mix: 0.5)' % batch}
+
+
+def irregular_topology(device, seed, batch):
+    """The same step on the irregular-topology body (V=6762: geodesic icosahedron with random edge flips, valence 4-9,
+    painted segments with ragged boundaries) next to the lat-long sphere's numbers: what the pruning statistics look like
+    on a mesh that is not a regular grid."""
+    from tuch_amd.smplify.losses import contact_model_for
+    out = {}
+    for topo in ('uv', 'ico'):
+        p = build_problem(batch, device, seed, topology=topo)
+        ms = time_kernel(capture(make_step(p), 3), 20) * 1e3
+        model = contact_model_for(p['geomask'], p['face_tensor'], p['segments'], p['cdict'])
+        with torch.no_grad():
+            verts = p['smpl'](global_orient=p['global_orient'], body_pose=p['body_pose'], betas=p['betas']).vertices
+            interior = float((model.exterior_flags(verts, apply_segments=True) == 0).float().sum(1).mean())
+            t_search = time_kernel(lambda: model.v2v_min(verts), 10) * 1e3
+            t_inside = time_kernel(lambda: model.exterior_flags(verts, apply_segments=True), 10) * 1e3
+        body = p['body']
+        valence = np.bincount(np.bincount(body.faces.ravel()))
+        tree = ops_cluster_tree_info(model)
+        out[topo] = {'V': body.num_verts, 'F': body.num_faces, 'valence_min_max': [int(np.nonzero(valence)[0][0]), len(valence) - 1],
+                     'segments': len(body.segments), 'ms_per_step': round(ms, 4),
+                     'ray_element_steps': model.ray_work(verts)['elements'], 'search_ms': round(t_search, 4),
+                     'inside_test_with_segments_ms': round(t_inside, 4), 'mean_interior_vertices_per_body': round(interior, 1),
+                     'strip_stream_elements': tree['exact_len'], 'leaves': tree['leaves']}
+    return out
+
+
+def ops_cluster_tree_info(model):
+    """(leaf-strip stream length, number of leaves) of the model's cluster tree, through the host-side builder."""
+    from tuch_amd import ops
+    t = ops.cluster_tree(model.faces_np, model.num_verts, leaf_faces=max(model.num_faces // 850, 32))
+    return {'exact_len': int(t['exact_len']), 'leaves': int((t['nodes'][:, 3] > 0).sum())}
+
+
+def deterministic_cost(device, seed, batch):
+    """The step in deterministic mode (gradient scatters through 64-bit fixed-point integer atomics: bit-reproducible
+    fits), captured and replayed like the headline."""
+    from tuch_amd import ops
+    ops.set_deterministic(True)
+    try:
+        p = build_problem(batch, device, seed)
+        ms = time_kernel(capture(make_step(p), 3), 20) * 1e3
+    finally:
+        ops.set_deterministic(False)
+    return {'ms_per_step': round(ms, 4), 'body_iterations_per_s': round(batch / ms * 1e3, 1)}
 
 
 def cpu_baseline(p, seconds):
@@ -931,6 +983,8 @@ def main():
             line['workloads'] = workloads(device, 1002)
             line['worst_case'] = worst_case(device, 1002, batch)
             line['worst_case']['folded'] = worst_case(device, 1002, batch, folded=True)
+            line['deterministic_mode'] = deterministic_cost(device, 1002, batch)
+            line['irregular_topology'] = irregular_topology(device, 1002, batch)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(p, args.cpu_seconds)
             if not args.no_torch_chain:

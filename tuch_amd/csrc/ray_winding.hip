@@ -1383,11 +1383,14 @@ size_t tuch_ray_workspace_bytes(const tuch_contact_model* m, int B, int Q)
 }
 
 // sheared leaf strips and the slabs of every LEAF (inner nodes are not used by the flat near test)
-static void launch_ray_boxes(const tuch_contact_model* m, const RayLayout& l, const float* verts, int B, char* ws, hipStream_t s)
+static void launch_ray_boxes(const tuch_contact_model* m, const RayLayout& l, const float* verts, int B, char* ws, hipStream_t s,
+                             bool one_launch)
 {
     RayElem* st = (RayElem*)(ws + l.stream);
     float* bounds = (float*)(ws + l.bounds);
-    if (m->tree_leaf_runs_tile) {                       // one launch: every leaf poses its own run of the strip
+    // one launch: every leaf poses its own run of the strip.  (Not for the points form with its far larger span of
+    // counters to clear -- [B][Q] with Q = all HD points: the leaf grid has too few workgroups for that, 100 us)
+    if (one_launch && m->tree_leaf_runs_tile) {
         hipLaunchKernelGGL(ray_leaf_bounds_kernel<true>, dim3(ceil_div(m->tree_leaves, kBoundsBlock / 16), B), dim3(kBoundsBlock), 0,
                            s, (const RayElem*)st, l.T, (const TreeNode*)m->tree_node, m->tree_nodes,
                            (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, bounds, verts,
@@ -1410,7 +1413,7 @@ template <bool kVerts>
 static int launch_ray_counts(const tuch_contact_model* m, const RayLayout& l, const float* verts, const float* queries,
                              const int32_t* counts, int B, int Q, char* ws, hipStream_t s, unsigned long long* stats)
 {
-    launch_ray_boxes(m, l, verts, B, ws, s);          // clears the counters (l.zeroed) as well
+    launch_ray_boxes(m, l, verts, B, ws, s, kVerts);  // clears the counters (l.zeroed) as well
     const int L = m->tree_leaves;
     const TreeNode* nodes = (const TreeNode*)m->tree_node;
     // the leaves are the height-0 entries of the tree's height table (tree_height_off_host[0] == 0)

@@ -646,6 +646,8 @@ class ContactModel:
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             mn, partner = self.v2v_min(verts, leave_room=True)
+            # (the caller's extra work -- region pairs, reprojection + prior -- FIRST, beside the short head of the inside
+            # test's chain, was measured: 0.587 against 0.552 ms per step; it delays the search, which the chain waits for)
             extra = also() if also is not None else None
         exterior = self.exterior_flags(verts, apply_segments=apply_segments)
         cur.wait_stream(side)
