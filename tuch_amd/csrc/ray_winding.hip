@@ -100,6 +100,25 @@ __device__ __forceinline__ float row_min(float v)
 // kPose: the kernel also WRITES the sheared strip (each 16-lane group poses the run of its own leaf; the leaves' runs
 // tile the stream, checked at model creation) and clears the counters of the kernels that follow -- ray_stream_kernel's
 // work, without a launch of its own ahead of this one on the step's serial chain.
+// bits of the largest half-precision number <= x / the smallest >= x (|x| beyond the half range saturates outwards)
+__device__ __forceinline__ uint32_t half_below(float x)
+{
+    const _Float16 h = (_Float16)x;
+    uint32_t u = __builtin_bit_cast(uint16_t, h);
+    if ((float)h > x) u = (u & 0x8000u) ? u + 1 : (u == 0 ? 0x8001u : u - 1);
+    return u;
+}
+__device__ __forceinline__ uint32_t half_above(float x)
+{
+    const _Float16 h = (_Float16)x;
+    uint32_t u = __builtin_bit_cast(uint16_t, h);
+    if ((float)h < x) u = (u & 0x8000u) ? (u == 0x8000u ? 0x0001u : u - 1) : u + 1;
+    return u;
+}
+// where the tables of one call's `bounds` region start (floats): [B][13][L] | records [B][L][8 dwords] | centres [B][4]
+__device__ __host__ __forceinline__ size_t near_records_at(int B, int L) { return (size_t)B * kNearSlabs * L; }
+__device__ __host__ __forceinline__ size_t near_centres_at(int B, int L) { return near_records_at(B, L) + (size_t)B * L * 8; }
+
 template <bool kPose>
 __global__ __launch_bounds__(kBoundsBlock) void ray_leaf_bounds_kernel(
     const RayElem* __restrict__ stream, int T, const TreeNode* __restrict__ nodes, int N,
@@ -159,6 +178,30 @@ __global__ __launch_bounds__(kBoundsBlock) void ray_leaf_bounds_kernel(
         o[4 * (size_t)L] = lo_p[6]; o[5 * (size_t)L] = lo_p[8];
         o[6 * (size_t)L] = hi_p[0]; o[7 * (size_t)L] = hi_p[1]; o[8 * (size_t)L] = hi_p[2]; o[9 * (size_t)L] = hi_p[3];
         o[10 * (size_t)L] = hi_p[4]; o[11 * (size_t)L] = hi_p[5]; o[12 * (size_t)L] = hi_p[7];
+        // The same 13 values once more as the 32-byte RECORD the per-ray test reads: half precision, relative to a
+        // reference point of the body (the first element of its strip, so that the numbers stay small wherever the body
+        // stands), lower bounds rounded down and upper bounds up after a pad for the roundings of the subtraction.
+        float c[3];
+        if (kPose) {
+            const float* c0 = verts + ((size_t)b * V + vidx[0]) * 3;
+            c[0] = shear_x(c0[0], c0[2]); c[1] = shear_y(c0[1], c0[2]); c[2] = c0[2];
+        } else {
+            const RayElem e0 = st[0];
+            c[0] = e0.x; c[1] = e0.y; c[2] = e0.z;
+        }
+        float pc[kSlabs];
+        slab_project(c[0], c[1], c[2], pc);
+        uint32_t lo_h[kSlabs], hi_h[kSlabs];
+#pragma unroll
+        for (int k = 0; k < kSlabs; ++k) {
+            const float pad = 4e-6f * (fabsf(lo_p[k]) + fabsf(hi_p[k]) + fabsf(pc[k])) + 1e-7f;
+            lo_h[k] = half_below(lo_p[k] - pc[k] - pad);
+            hi_h[k] = half_above(hi_p[k] - pc[k] + pad);
+        }
+        uint4* r = reinterpret_cast<uint4*>(bounds + near_records_at(gridDim.y, L)) + ((size_t)b * L + leaf) * 2;
+        r[0] = make_uint4(lo_h[0] | lo_h[1] << 16, lo_h[3] | lo_h[4] << 16, lo_h[6] | lo_h[8] << 16, hi_h[0] | hi_h[1] << 16);
+        r[1] = make_uint4(hi_h[2] | hi_h[3] << 16, hi_h[4] | hi_h[5] << 16, hi_h[7] | (uint32_t)leaf << 16, (uint32_t)node);  // + who it is
+        if (leaf == 0) *reinterpret_cast<float4*>(bounds + near_centres_at(gridDim.y, L) + (size_t)b * 4) = make_float4(c[0], c[1], c[2], 0.f);
     }
 }
 
@@ -311,21 +354,68 @@ __device__ __forceinline__ float wave_max(float v)
 
 // One (query block, leaf) the block has to visit: which of its 64 rays pass the leaf's slabs.
 struct RayEntry { int32_t leaf, node; uint32_t mask_lo, mask_hi; };
+
+// (half in the low / high 16 bits of s) - q and q - (half of s) in single precision, one instruction each; the largest of three
+__device__ __forceinline__ float lo_minus(uint32_t s, float q)
+{
+    float d;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(s), "v"(q));
+    return d;
+}
+__device__ __forceinline__ float hi_minus(uint32_t s, float q)
+{
+    float d;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(s), "v"(q));
+    return d;
+}
+__device__ __forceinline__ float minus_lo(float q, uint32_t s)
+{
+    float d;
+    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(s), "v"(q));
+    return d;
+}
+__device__ __forceinline__ float minus_hi(float q, uint32_t s)
+{
+    float d;
+    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(s), "v"(q));
+    return d;
+}
+__device__ __forceinline__ float max3(float a, float b, float c)
+{
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 // One unit of work of ray_leaf_kernel: up to 64 rays (pairs[first .. first + n)) against one leaf's strip run.
 struct RayTile { int32_t ex_off, ex_len, first, n; };
 // per body: number of tiles, whether the pair list overflowed (the body is then walked block-major)
 struct RayBody { int32_t tiles, overflow; };
 
-template <bool kVerts>
-__global__ __launch_bounds__(64) void ray_near_kernel(
+// One workgroup of kWaves wavefronts per (block of 64 queries, body); every wavefront holds the block's 64 queries.
+//   ranges : the 13 block ranges (kWaves = 4: each reduced by one of the wavefronts, shared through LDS);
+//   rounds : the wavefronts take one chunk of 64 leaves each, lanes over LEAVES: block ranges against the slabs
+//            (stage 1); the records of the passing leaves go to a queue in LDS; the queue is then dealt out evenly,
+//            two entries per wavefront and trip: every ray against the record (stage 2).
+// A trip of stage 2 is a dependent chain (LDS read -> 19 VALU -> ballot -> branch, ~450 clocks measured with the cycle
+// counter) and the blocks through the trunk pass five times the average number of leaves: the time of the kernel is
+// that of its slowest workgroup plus the rounds of workgroups the chip needs.  With one wavefront testing a block's
+// leaves one at a time it was 59 us at batch 64 and 41 us at batch 8.  Four wavefronts and two chains per trip: 16 us
+// at batch 8.  At batch 64 the search runs beside this kernel on another stream and leaves 7 wave slots and < 4 KB of
+// LDS per CU (v2v.hip, leave_room): there the one-wavefront form (2 KB) is used -- workgroups of four with an 8 KB
+// queue waited for LDS until the search had drained (202 us, tools/graph_timeline.py).
+template <bool kVerts, int kWaves>
+__global__ __launch_bounds__(64 * kWaves) void ray_near_kernel(
     const float* __restrict__ pts, const TreeNode* __restrict__ nodes, const float* __restrict__ bounds, int N,
-    const int32_t* __restrict__ leaf_nodes, int num_leaves, const int32_t* __restrict__ qperm,
+    int num_leaves, const int32_t* __restrict__ qperm,
     const int32_t* __restrict__ counts, int Q, int qblocks, RayEntry* __restrict__ lists, int32_t* __restrict__ list_len,
     int32_t* __restrict__ leaf_cnt,             // [B][num_leaves], zeroed: rays per leaf
     unsigned long long* __restrict__ stats)     // measurement (or nullptr): [1] += (ray, element) pairs inside a listed
 {                                               // leaf's slabs, [2] += 64 x elements listed
-    const int qb = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
-    unsigned long long useful = 0, listed = 0;
+    const int qb = blockIdx.x, b = blockIdx.y, lane = threadIdx.x & 63;
+    const int wave = kWaves > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+    __shared__ uint4 queue[64 * kWaves][2];     // records of the round's leaves that passed stage 1
+    __shared__ float range[16];
+    __shared__ int queued[2], slots;            // queue entries (rounds in turn); list entries written (slots are taken from it)
     int i0;
     bool real;                                  // padding lanes repeat a query; they are left out of the masks
     if (kVerts) {
@@ -334,83 +424,123 @@ __global__ __launch_bounds__(64) void ray_near_kernel(
     } else {
         const int n = counts ? counts[b] : Q;
         if (qb * kRayQueries >= n) {
-            if (lane == 0) list_len[(size_t)b * qblocks + qb] = 0;
+            if (threadIdx.x == 0) list_len[(size_t)b * qblocks + qb] = 0;
             return;
         }
         i0 = min(qb * kRayQueries + lane, n - 1);
         real = qb * kRayQueries + lane < n;
     }
+    if (threadIdx.x == 0) { queued[0] = 0; queued[1] = 0; slots = 0; }
+    // every load that does not wait for the block's ranges is issued here: the body's reference point and the slab
+    // values / records of the wavefront's first chunk of leaves
+    const float4 ctr = *reinterpret_cast<const float4*>(bounds + near_centres_at(gridDim.y, num_leaves) + (size_t)b * 4);
+    const float* bb = bounds + (size_t)b * kNearSlabs * num_leaves;       // [13][leaves], see ray_leaf_bounds_kernel
+    const uint4* recs = reinterpret_cast<const uint4*>(bounds + near_records_at(gridDim.y, num_leaves)) + (size_t)b * num_leaves * 2;
+    struct Chunk { float v[kNearSlabs]; uint4 r0, r1; };
+    auto load_chunk = [&](int base) {
+        Chunk c;
+        const int lc = min(base + lane, num_leaves - 1);
+#pragma unroll
+        for (int k = 0; k < kNearSlabs; ++k) c.v[k] = bb[(size_t)k * num_leaves + lc];      // one leaf per lane, coalesced
+        c.r0 = recs[lc * 2];
+        c.r1 = recs[lc * 2 + 1];
+        return c;
+    };
+    Chunk nxt = load_chunk(wave * 64);
     const float* q3 = pts + ((size_t)b * Q + i0) * 3;
     const float qz = q3[2];
     const float qx = shear_x(q3[0], qz), qy = shear_y(q3[1], qz);
-    const float q4 = qx + qy, q5 = qx - qy, q6 = qx + qz, q7 = qx - qz, q8 = qy + qz, q9 = qy - qz;
-    // ranges of the block (wave-uniform after the reductions)
-    const float bx0 = wave_min(qx), bx1 = wave_max(qx), by0 = wave_min(qy), by1 = wave_max(qy);
-    const float b40 = wave_min(q4), b41 = wave_max(q4), b50 = wave_min(q5), b51 = wave_max(q5);
-    const float bz0 = wave_min(qz), b60 = wave_min(q6), b71 = wave_max(q7), b80 = wave_min(q8), b91 = wave_max(q9);
-    const float* bb = bounds + (size_t)b * kNearSlabs * num_leaves;       // [13][leaves], see ray_leaf_bounds_kernel
-    RayEntry* list = lists + ((size_t)b * qblocks + qb) * num_leaves;
-    int cnt = 0;
-    __shared__ float slab[64][16];              // the 13 slab values of the chunk's leaves, one row per lane
-    for (int base = 0; base < num_leaves; base += 64) {
-        const int leaf = base + lane;
-        const int node = leaf_nodes[leaf < num_leaves ? leaf : num_leaves - 1];
-        // the 13 slab values the tests use, one leaf per lane, coalesced (fetching a passing leaf's values again through the
-        // scalar cache made the loop over the passing leaves a chain of scalar-memory latencies)
-        const float* sv = bb + (leaf < num_leaves ? leaf : num_leaves - 1);
-        const size_t L = (size_t)num_leaves;
-        const float lo0 = sv[0], lo1 = sv[L], lo3 = sv[2 * L], lo4 = sv[3 * L], lo6 = sv[4 * L], lo8 = sv[5 * L];
-        const float hi0 = sv[6 * L], hi1 = sv[7 * L], hi2 = sv[8 * L], hi3 = sv[9 * L], hi4 = sv[10 * L], hi5 = sv[11 * L],
-                    hi7 = sv[12 * L];
-        bool pass = leaf < num_leaves;
-        pass = pass && bx0 <= hi0 && bx1 >= lo0 && by0 <= hi1 && by1 >= lo1;
-        pass = pass && b40 <= hi3 && b41 >= lo3 && b50 <= hi4 && b51 >= lo4;
-        pass = pass && bz0 <= hi2 && b60 <= hi5 && b71 >= lo6 && b80 <= hi7 && b91 >= lo8;
-        unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
-        // the per-ray test below takes a passing leaf's 13 values from LDS (four 16-byte reads of one address: broadcast)
-        // -- 13 v_readlane per leaf, each feeding a VALU instruction through a scalar register, cost more than the rest
-        // of the loop
-        __syncthreads();                            // (one wavefront per workgroup) the previous chunk's reads are done
-        {
-            float4* mine = reinterpret_cast<float4*>(slab[lane]);
-            mine[0] = make_float4(lo0, lo1, lo3, lo4);
-            mine[1] = make_float4(lo6, lo8, hi0, hi1);
-            mine[2] = make_float4(hi2, hi3, hi4, hi5);
-            mine[3] = make_float4(hi7, 0.f, 0.f, 0.f);
+    float bx0, bx1, by0, by1, b40, b41, b50, b51, bz0, b60, b71, b80, b91;
+    if (kWaves == 4) {
+        if (wave == 0) {
+            const float a = wave_min(qx), c = wave_max(qx), d = wave_min(qy), e = wave_max(qy);
+            if (lane == 0) { range[0] = a; range[1] = c; range[2] = d; range[3] = e; }
+        } else if (wave == 1) {
+            const float q4 = qx + qy, q5 = qx - qy;
+            const float a = wave_min(q4), c = wave_max(q4), d = wave_min(q5), e = wave_max(q5);
+            if (lane == 0) { range[4] = a; range[5] = c; range[6] = d; range[7] = e; }
+        } else if (wave == 2) {
+            const float a = wave_min(qz), c = wave_min(qx + qz), d = wave_max(qx - qz);
+            if (lane == 0) { range[8] = a; range[9] = c; range[10] = d; }
+        } else {
+            const float a = wave_min(qy + qz), c = wave_max(qy - qz);
+            if (lane == 0) { range[11] = a; range[12] = c; }
         }
         __syncthreads();
-        while (mask) {
-            const int j = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            const int nd = __builtin_amdgcn_readlane(node, j);
-            const float4* sj = reinterpret_cast<const float4*>(slab[j]);
-            const float4 s0 = sj[0], s1 = sj[1], s2 = sj[2], s3 = sj[3];
-            float out = __builtin_fmaxf(s0.x - qx, qx - s1.z);
-            out = __builtin_fmaxf(out, __builtin_fmaxf(s0.y - qy, qy - s1.w));
-            out = __builtin_fmaxf(out, __builtin_fmaxf(s0.z - q4, q4 - s2.y));
-            out = __builtin_fmaxf(out, __builtin_fmaxf(s0.w - q5, q5 - s2.z));
-            out = __builtin_fmaxf(out, qz - s2.x);
-            out = __builtin_fmaxf(out, q6 - s2.w);
-            out = __builtin_fmaxf(out, s1.x - q7);
-            out = __builtin_fmaxf(out, q8 - s3.x);
-            out = __builtin_fmaxf(out, s1.y - q9);
-            const unsigned long long hit = __builtin_amdgcn_ballot_w64(real && !(out > 0.0f));
-            if (hit) {
-                if (lane == 0) {
-                    list[cnt] = RayEntry{base + j, nd, (uint32_t)hit, (uint32_t)(hit >> 32)};
-                    atomicAdd(&leaf_cnt[(size_t)b * num_leaves + base + j], __builtin_popcountll(hit));
-                }
-                ++cnt;
-                if (stats) {
-                    const int len = nodes[nd].ex_len;
-                    useful += (unsigned long long)__builtin_popcountll(hit) * len;
-                    listed += 64ull * len;
-                }
-            }
-        }
+        bx0 = range[0]; bx1 = range[1]; by0 = range[2]; by1 = range[3]; b40 = range[4]; b41 = range[5]; b50 = range[6];
+        b51 = range[7]; bz0 = range[8]; b60 = range[9]; b71 = range[10]; b80 = range[11]; b91 = range[12];
+    } else {
+        const float q4 = qx + qy, q5 = qx - qy;
+        bx0 = wave_min(qx); bx1 = wave_max(qx); by0 = wave_min(qy); by1 = wave_max(qy);
+        b40 = wave_min(q4); b41 = wave_max(q4); b50 = wave_min(q5); b51 = wave_max(q5);
+        bz0 = wave_min(qz); b60 = wave_min(qx + qz); b71 = wave_max(qx - qz); b80 = wave_min(qy + qz); b91 = wave_max(qy - qz);
     }
-    if (lane == 0) list_len[(size_t)b * qblocks + qb] = cnt;
+    // the queries relative to the body's reference point, as the records are
+    const float rx = qx - ctr.x, ry = qy - ctr.y, rz = qz - ctr.z;
+    const float r4 = rx + ry, r5 = rx - ry, r6 = rx + rz, r7 = rx - rz, r8 = ry + rz, r9 = ry - rz;
+    RayEntry* list = lists + ((size_t)b * qblocks + qb) * num_leaves;
+    unsigned long long useful = 0, listed = 0;
+    // record: s0 = (lo0,lo1) (lo3,lo4) (lo6,lo8) (hi0,hi1)   s1 = (hi2,hi3) (hi4,hi5) (hi7,leaf) node
+    auto outside = [&](const uint4& s0, const uint4& s1) {
+        float out = max3(lo_minus(s0.x, rx), minus_lo(rx, s0.w), hi_minus(s0.x, ry));
+        out = max3(out, minus_hi(ry, s0.w), lo_minus(s0.y, r4));
+        out = max3(out, minus_hi(r4, s1.x), hi_minus(s0.y, r5));
+        out = max3(out, minus_lo(r5, s1.y), minus_lo(rz, s1.x));
+        out = max3(out, minus_hi(r6, s1.y), lo_minus(s0.z, r7));
+        return max3(out, minus_lo(r8, s1.z), hi_minus(s0.z, r9));
+    };
+    auto emit = [&](const uint4& s1, unsigned long long hit) {
+        if (!hit) return;
+        const int leaf = (int)(s1.z >> 16), nd = (int)s1.w;
+        if (lane == 0) {
+            const int slot = atomicAdd(&slots, 1);
+            list[slot] = RayEntry{leaf, nd, (uint32_t)hit, (uint32_t)(hit >> 32)};
+            atomicAdd(&leaf_cnt[(size_t)b * num_leaves + leaf], __builtin_popcountll(hit));
+        }
+        if (stats) {
+            const int len = nodes[nd].ex_len;
+            useful += (unsigned long long)__builtin_popcountll(hit) * len;
+            listed += 64ull * len;
+        }
+    };
+    // (one wavefront: its LDS accesses are served in order, nothing to wait for between the stages)
+    auto sync = [&] { if (kWaves > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier(); };
+    for (int round = 0; round * 64 * kWaves < num_leaves; ++round) {
+        const int base = (round * kWaves + wave) * 64;
+        const Chunk c = nxt;
+        if (base + 64 * kWaves < num_leaves) nxt = load_chunk(base + 64 * kWaves);
+        // order of v[]: lo0 lo1 lo3 lo4 lo6 lo8 | hi0 hi1 hi2 hi3 hi4 hi5 hi7
+        // (& not &&: no compare may gate a load -- with short-circuit tests the compiler fetched the 13 values in four
+        // dependent rounds)
+        const bool pass = (base + lane < num_leaves) & (bx0 <= c.v[6]) & (bx1 >= c.v[0]) & (by0 <= c.v[7]) & (by1 >= c.v[1]) &
+                          (b40 <= c.v[9]) & (b41 >= c.v[2]) & (b50 <= c.v[10]) & (b51 >= c.v[3]) & (bz0 <= c.v[8]) &
+                          (b60 <= c.v[11]) & (b71 >= c.v[4]) & (b80 <= c.v[12]) & (b91 >= c.v[5]);
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
+        if (mask) {
+            int at = 0;
+            if (kWaves > 1) {
+                if (lane == 0) at = atomicAdd(&queued[round & 1], __builtin_popcountll(mask));
+                at = __builtin_amdgcn_readfirstlane(at);
+            }
+            at += __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+            if (pass) { queue[at][0] = c.r0; queue[at][1] = c.r1; }
+        }
+        sync();
+        const int n = kWaves > 1 ? queued[round & 1] : __builtin_popcountll(mask);
+        if (kWaves > 1 && threadIdx.x == 0) queued[(round + 1) & 1] = 0;    // (last read before this round's first barrier)
+        for (int i = wave * 2; i < n; i += kWaves * 2) {
+            const int k = i + 1 < n ? i + 1 : i;
+            const uint4 a0 = queue[i][0], a1 = queue[i][1], c0 = queue[k][0], c1 = queue[k][1];
+            const float out_a = outside(a0, a1), out_c = outside(c0, c1);
+            const unsigned long long hit_a = __builtin_amdgcn_ballot_w64(real && !(out_a > 0.0f));
+            const unsigned long long hit_c = __builtin_amdgcn_ballot_w64(real && !(out_c > 0.0f) && k != i);
+            emit(a1, hit_a);
+            emit(c1, hit_c);
+        }
+        sync();
+    }
     if (stats && lane == 0) { atomicAdd(stats + 1, useful); atomicAdd(stats + 2, listed); }
+    if (threadIdx.x == 0) list_len[(size_t)b * qblocks + qb] = slots;
 }
 
 // Per body: where every leaf's rays start in the pair list (exclusive scan of the counts) and the table of tiles
@@ -1323,6 +1453,8 @@ int tuch_ray_segment_flags_fused(const tuch_contact_model* m, const float* verts
 bool tuch_ray_available(const tuch_contact_model* m)
 {
     if (!m || m->tree_nodes <= 0 || !m->ring_off || m->tree_exact_len <= 0) return false;
+    // ray_near_kernel's records hold the leaf in 16 bits (2 M faces; a mesh beyond that takes the solid-angle form)
+    if (m->tree_leaves > 65535) return false;
     return m->opt.winding_ray != 0;
 }
 
@@ -1426,9 +1558,15 @@ static int launch_ray_counts(const tuch_contact_model* m, const RayLayout& l, co
     RayTile* tiles = (RayTile*)(ws + l.tiles);
     RayBody* body = (RayBody*)(ws + l.body);
     int32_t* pairs = (int32_t*)(ws + l.pairs);
-    hipLaunchKernelGGL(ray_near_kernel<kVerts>, dim3(l.qblocks, B), dim3(64), 0, s, queries, nodes,
-                       (const float*)(ws + l.bounds), m->tree_nodes, leaf_nodes, L, qperm, counts, Q, l.qblocks, lists, list_len,
-                       leaf_cnt, stats);
+    // four wavefronts per query block while the blocks alone do not fill the chip (see the kernel)
+    if ((long)l.qblocks * B <= 2048)
+        hipLaunchKernelGGL((ray_near_kernel<kVerts, 4>), dim3(l.qblocks, B), dim3(256), 0, s, queries, nodes,
+                           (const float*)(ws + l.bounds), m->tree_nodes, L, qperm, counts, Q, l.qblocks, lists, list_len,
+                           leaf_cnt, stats);
+    else
+        hipLaunchKernelGGL((ray_near_kernel<kVerts, 1>), dim3(l.qblocks, B), dim3(64), 0, s, queries, nodes,
+                           (const float*)(ws + l.bounds), m->tree_nodes, L, qperm, counts, Q, l.qblocks, lists, list_len,
+                           leaf_cnt, stats);
     hipLaunchKernelGGL(ray_tiles_kernel, dim3(B), dim3(kTilesBlock), 0, s, (const int32_t*)leaf_cnt, nodes, leaf_nodes, L, l.cap,
                        l.max_tiles, l.qblocks * kFallbackChunks, leaf_off, tiles, body);
     hipLaunchKernelGGL(ray_fill_kernel, dim3(l.qblocks, B), dim3(64), 0, s, (const RayEntry*)lists, (const int32_t*)list_len,
