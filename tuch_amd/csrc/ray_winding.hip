@@ -617,6 +617,95 @@ __global__ __launch_bounds__(64) void ray_fill_kernel(
     }
 }
 
+// ray_tiles_kernel + ray_fill_kernel in one launch: kFillSplit workgroups of 256 threads per body.  Each scans the
+// body's counts for itself (430 numbers); the first one writes the tile table; the body's entries -- all its query
+// blocks' lists laid end to end through a prefix of their lengths -- are dealt out 64 at a time to the wavefronts of all
+// of them.  (As two launches with one wavefront per query block: 10 + 31 us at batch 64 and 7 + 14 us at batch 8, most
+// of it the launch rate of 6912 one-wavefront workgroups and three dependent global round trips in each; as ONE
+// workgroup per body, fill counters in LDS: 61 us -- the write loop below is ~25 instructions per entry and a
+// body's 4300 entries kept one CU busy that long.)
+constexpr int kTilesFillBlock = 256, kFillSplit = 16, kFillMaxBlocks = 2048;
+__global__ __launch_bounds__(kTilesFillBlock) void ray_tiles_fill_kernel(
+    const int32_t* __restrict__ leaf_cnt, const TreeNode* __restrict__ nodes, const int32_t* __restrict__ leaf_nodes,
+    int num_leaves, int cap, int max_tiles, int fallback_tiles, RayTile* __restrict__ tiles, RayBody* __restrict__ body,
+    const RayEntry* __restrict__ lists, const int32_t* __restrict__ list_len, int qblocks, int32_t* __restrict__ leaf_fill,
+    int32_t* __restrict__ pairs)
+{
+    extern __shared__ int32_t dyn[];                // off[num_leaves] | blk[qblocks + 1]
+    int32_t* off_s = dyn;
+    int32_t* blk = dyn + num_leaves;
+    __shared__ int sp[kTilesFillBlock], st[kTilesFillBlock], sq[kTilesFillBlock];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63;
+    const int per = (num_leaves + kTilesFillBlock - 1) / kTilesFillBlock;
+    const int l0 = min(t * per, num_leaves), l1 = min(l0 + per, num_leaves);
+    const int perq = (qblocks + kTilesFillBlock - 1) / kTilesFillBlock;
+    const int q0 = min(t * perq, qblocks), q1 = min(q0 + perq, qblocks);
+    const int32_t* cnt = leaf_cnt + (size_t)b * num_leaves;
+    const int32_t* len = list_len + (size_t)b * qblocks;
+    int npairs = 0, ntile = 0, nent = 0;
+    for (int l = l0; l < l1; ++l) { npairs += cnt[l]; ntile += (cnt[l] + 63) >> 6; }
+    for (int q = q0; q < q1; ++q) nent += len[q];
+    sp[t] = npairs;
+    st[t] = ntile;
+    sq[t] = nent;
+    __syncthreads();
+    for (int d = 1; d < kTilesFillBlock; d <<= 1) {          // inclusive scans
+        const int ap = t >= d ? sp[t - d] : 0, at = t >= d ? st[t - d] : 0, aq = t >= d ? sq[t - d] : 0;
+        __syncthreads();
+        sp[t] += ap;
+        st[t] += at;
+        sq[t] += aq;
+        __syncthreads();
+    }
+    const int total_pairs = sp[kTilesFillBlock - 1], total_tiles = st[kTilesFillBlock - 1], total = sq[kTilesFillBlock - 1];
+    const bool overflow = total_pairs > cap || total_tiles > max_tiles;
+    if (t == 0 && blockIdx.y == 0) body[b] = RayBody{overflow ? fallback_tiles : total_tiles, overflow ? 1 : 0};
+    if (overflow) return;
+    {
+        int off = sp[t] - npairs, tile = st[t] - ntile;
+        RayTile* out = tiles + (size_t)b * max_tiles;
+        for (int l = l0; l < l1; ++l) {
+            off_s[l] = off;
+            if (blockIdx.y == 0) {
+                const TreeNode nd = nodes[leaf_nodes[l]];
+                for (int k = 0; k < cnt[l]; k += 64) out[tile++] = RayTile{nd.ex_off, nd.ex_len, off + k, min(64, cnt[l] - k)};
+            }
+            off += cnt[l];
+        }
+        int ent = sq[t] - nent;
+        for (int q = q0; q < q1; ++q) { blk[q] = ent; ent += len[q]; }
+        if (t == 0) blk[qblocks] = total;
+    }
+    __syncthreads();
+    int32_t* fill = leaf_fill + (size_t)b * num_leaves;
+    int32_t* out = pairs + (size_t)b * cap;
+    for (int base = (blockIdx.y * (kTilesFillBlock / 64) + (t >> 6)) * 64; base < total; base += kFillSplit * kTilesFillBlock) {
+        // lanes over entries: reserve the entry's range in its leaf (64 atomics in flight)
+        const int g = base + lane;
+        RayEntry e = RayEntry{0, 0, 0u, 0u};
+        int dst = 0, qb = 0;
+        if (g < total) {
+            int lo = 0, hi = qblocks;                       // the block with blk[qb] <= g < blk[qb + 1]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (blk[mid] <= g) lo = mid; else hi = mid;
+            }
+            qb = lo;
+            e = lists[((size_t)b * qblocks + qb) * num_leaves + (g - blk[qb])];
+            dst = off_s[e.leaf] + atomicAdd(&fill[e.leaf], __builtin_popcount(e.mask_lo) + __builtin_popcount(e.mask_hi));
+        }
+        // lanes over rays: entry by entry, the set lanes write their slot
+        const int m = min(64, total - base);
+        for (int k = 0; k < m; ++k) {
+            const uint32_t lo = __builtin_amdgcn_readlane(e.mask_lo, k), hi = __builtin_amdgcn_readlane(e.mask_hi, k);
+            const int d = __builtin_amdgcn_readlane(dst, k), q = __builtin_amdgcn_readlane(qb, k);
+            const unsigned long long mask = ((unsigned long long)hi << 32) | lo;
+            if ((mask >> lane) & 1ull)
+                out[d + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = q * kRayQueries + lane;
+        }
+    }
+}
+
 // Crossing counts, leaf-major: a wavefront takes a tile -- one leaf and up to 64 of the rays that pass its slabs,
 // whichever query blocks they come from -- walks the leaf's strip run and adds each ray's crossings to its query's
 // count.  (Block-major, 64 neighbouring queries against every leaf any of them meets, only ~22 % of the lanes
@@ -1567,10 +1656,17 @@ static int launch_ray_counts(const tuch_contact_model* m, const RayLayout& l, co
         hipLaunchKernelGGL((ray_near_kernel<kVerts, 1>), dim3(l.qblocks, B), dim3(64), 0, s, queries, nodes,
                            (const float*)(ws + l.bounds), m->tree_nodes, L, qperm, counts, Q, l.qblocks, lists, list_len,
                            leaf_cnt, stats);
+    const size_t tf_lds = ((size_t)L + l.qblocks + 1) * sizeof(int32_t);
+    if (l.qblocks <= kFillMaxBlocks && tf_lds <= 48u * 1024)
+        hipLaunchKernelGGL(ray_tiles_fill_kernel, dim3(B, kFillSplit), dim3(kTilesFillBlock), tf_lds, s, (const int32_t*)leaf_cnt,
+                           nodes, leaf_nodes, L, l.cap, l.max_tiles, l.qblocks * kFallbackChunks, tiles, body,
+                           (const RayEntry*)lists, (const int32_t*)list_len, l.qblocks, (int32_t*)(ws + l.leaf_fill), pairs);
+    else {
     hipLaunchKernelGGL(ray_tiles_kernel, dim3(B), dim3(kTilesBlock), 0, s, (const int32_t*)leaf_cnt, nodes, leaf_nodes, L, l.cap,
                        l.max_tiles, l.qblocks * kFallbackChunks, leaf_off, tiles, body);
     hipLaunchKernelGGL(ray_fill_kernel, dim3(l.qblocks, B), dim3(64), 0, s, (const RayEntry*)lists, (const int32_t*)list_len,
                        (const RayBody*)body, (const int32_t*)leaf_off, L, l.qblocks, l.cap, (int32_t*)(ws + l.leaf_fill), pairs);
+    }
     const dim3 grid(l.columns, l.workers);
     const bool seg = kVerts && m->seg_elem_mask;
     const int32_t* emask = (const int32_t*)m->seg_elem_mask;
