@@ -778,7 +778,10 @@ def rccl_smoke_child():
             graph.replay()
         torch.cuda.synchronize()
         out['captured_contact_loss'] = {'eager': eager, 'replayed': float(captured),
-                                        'grad_equal': bool(torch.allclose(v.grad, grad_eager, rtol=1e-5, atol=1e-9))}
+                                        # (float atomics: the order of the additions differs from run to run)
+                                        'grad_equal': bool((v.grad - grad_eager).abs().max() <= 2e-6 * grad_eager.abs().max()),
+                                        'grad_max_abs_diff': float((v.grad - grad_eager).abs().max()),
+                                        'grad_max_abs': float(grad_eager.abs().max())}
         ok = out['all_reduce'] == [3.5, 64.0] and abs(float(captured) - eager) <= 1e-6 * abs(eager) \
             and out['captured_contact_loss']['grad_equal']
         out['status'] = 'ok' if ok else 'mismatch'

@@ -123,6 +123,12 @@ struct tuch_contact_model {
     // the preorder leaf sequence, and the lane table of tree_masked by leaf index instead of node
     int32_t* tree_sub_leaf;      // [frontier_total][2] = (first leaf index, number of leaves)
     uint64_t* tree_masked_leaf;  // [2 * tree_qblocks][tree_leaves]
+    // packed-row form of the search (v2v.hip: v2v_scan_kernel): every leaf's rows padded to groups of four; the first
+    // group of each leaf (prefix, [tree_leaves + 1]) and the mask words by padded row ([2 * tree_qblocks][4 * tree_groups],
+    // 0 for a padding row)
+    int32_t* tree_leaf_group;
+    uint64_t* tree_mask_bits_g;
+    int tree_groups;
     int tree_num_frontiers;
     int tree_leaf_runs_tile;       // 1: the leaves' strip runs [ex_off, ex_off + ex_len) tile [0, tree_exact_len) without gaps
     int* tree_frontier_off_host;   // [tree_num_frontiers+1]

@@ -42,7 +42,7 @@ extern "C" void tuch_contact_model_destroy(tuch_contact_model* m)
 {
     if (!m) return;
     void* dev[] = {m->ring_off, m->ring_vidx, m->faces, m->mask_bits, m->strip_vidx, m->strip_sign, m->tree_node, m->tree_vidx, m->tree_sign, m->tree_qperm,
-                   m->tree_height_off, m->tree_height_nodes, m->tree_frontier_nodes, m->tree_launch_order, m->tree_ancestors, m->tree_rows, m->tree_v2v_info, m->tree_mask_bits, m->tree_masked, m->tree_sub_leaf, m->tree_masked_leaf, m->seg_blocks, m->seg_of_q, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces, m->seg_link_off, m->seg_link, m->seg_ray_off, m->seg_ray_ent, m->seg_elem_mask, m->seg_vmask, m->seg_vpos, m->seg_cap_off, m->seg_cap_ent, m->seg_cap_range,
+                   m->tree_height_off, m->tree_height_nodes, m->tree_frontier_nodes, m->tree_launch_order, m->tree_ancestors, m->tree_rows, m->tree_v2v_info, m->tree_mask_bits, m->tree_masked, m->tree_sub_leaf, m->tree_masked_leaf, m->tree_leaf_group, m->tree_mask_bits_g, m->seg_blocks, m->seg_of_q, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces, m->seg_link_off, m->seg_link, m->seg_ray_off, m->seg_ray_ent, m->seg_elem_mask, m->seg_vmask, m->seg_vpos, m->seg_cap_off, m->seg_cap_ent, m->seg_cap_range,
                    m->cap_off, m->cap_vidx, m->region_off, m->region_vidx, m->pairs, m->pair_mask, m->pair_mask_off, m->tickets, m->canary_hits};
     for (void* p : dev)
         if (p) (void)hipFree(p);
@@ -207,6 +207,20 @@ extern "C" int tuch_contact_model_create(
                         for (int i = 0; i < L; ++i) by_leaf[(size_t)qb * L + i] = lanes[(size_t)qb * N + t.height_nodes[i]];
                     rc = upload(&m->tree_sub_leaf, sub.data(), sub.size());
                     if (rc == TUCH_OK) rc = upload(&m->tree_masked_leaf, by_leaf.data(), by_leaf.size());
+                    // packed-row form: the leaves' rows in groups of four
+                    std::vector<int32_t> group(L + 1, 0);
+                    for (int i = 0; i < L; ++i) group[i + 1] = group[i] + (t.rows[(size_t)t.height_nodes[i] * 2 + 1] + 3) / 4;
+                    const int G = group[L];
+                    std::vector<uint64_t> bits_g((size_t)Wp * G * 4 + 8, 0);
+                    for (int qb = 0; qb < Wp; ++qb)
+                        for (int i = 0; i < L; ++i) {
+                            const int lo = t.rows[(size_t)t.height_nodes[i] * 2], n = t.rows[(size_t)t.height_nodes[i] * 2 + 1];
+                            for (int k = 0; k < n; ++k)
+                                bits_g[(size_t)qb * G * 4 + (size_t)group[i] * 4 + k] = bits[(size_t)qb * V + lo + k];
+                        }
+                    m->tree_groups = G;
+                    if (rc == TUCH_OK) rc = upload(&m->tree_leaf_group, group.data(), group.size());
+                    if (rc == TUCH_OK) rc = upload(&m->tree_mask_bits_g, bits_g.data(), bits_g.size());
                 }
             }
         }

@@ -397,8 +397,11 @@ __global__ __launch_bounds__(kBoundsBlock) void v2v_rows_kernel(
     const int32_t* __restrict__ height_nodes, int N,
     float* __restrict__ prow,                    // [B,Vp,3]
     float* __restrict__ bounds,                  // [B,N,8]
-    float* __restrict__ leafbox)                 // [B,L,8] or nullptr: the leaf boxes once more, by leaf index, with the
-{                                                // leaf's row range (first | count << 20) in the last padding word
+    float* __restrict__ leafbox,                 // [B,L,8] or nullptr: the leaf boxes once more, by leaf index, with the
+                                                 // leaf's row range (first | count << 20) in the last padding word
+    const int32_t* __restrict__ leaf_group,      // with prow_g: first group of four rows of every leaf ([L + 1])
+    float* __restrict__ prow_g, int G)           // [B,G,12] or nullptr: the rows once more, every leaf's rows padded to
+{                                                // groups of four, a group = x[4] y[4] z[4]; box word [3] = first group
     const int b = blockIdx.y;
     const int group = threadIdx.x >> 4, sub = threadIdx.x & 15;
     const int i = height_off[0] + blockIdx.x * (kBoundsBlock / 16) + group;
@@ -413,10 +416,21 @@ __global__ __launch_bounds__(kBoundsBlock) void v2v_rows_kernel(
     const int node = height_nodes[real ? i : height_off[0]];
     const int off = rows[2 * node], len = real ? rows[2 * node + 1] : 0;
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, nhi[3] = {3.0e38f, 3.0e38f, 3.0e38f};
+    const int g0 = prow_g && real ? leaf_group[i - height_off[0]] : 0;
+    float* pg = prow_g ? prow_g + ((size_t)b * G + g0) * 12 : nullptr;
+    if (prow_g)                                  // the padding rows of the last group (their mask words are 0)
+        for (int k = len + sub; k < ((len + 3) & ~3); k += 16) {
+            float* o = pg + (k >> 2) * 12 + (k & 3);
+            o[0] = 0.0f; o[4] = 0.0f; o[8] = 0.0f;
+        }
     for (int j = off + sub; j < off + len; j += 16) {
         const int v = qperm[j];
         const float x = vb[3 * v], y = vb[3 * v + 1], z = vb[3 * v + 2];
         pb[3 * j] = x; pb[3 * j + 1] = y; pb[3 * j + 2] = z;
+        if (prow_g) {
+            float* o = pg + ((j - off) >> 2) * 12 + ((j - off) & 3);
+            o[0] = x; o[4] = y; o[8] = z;
+        }
         lo[0] = fminf(lo[0], x); lo[1] = fminf(lo[1], y); lo[2] = fminf(lo[2], z);
         nhi[0] = fminf(nhi[0], -x); nhi[1] = fminf(nhi[1], -y); nhi[2] = fminf(nhi[2], -z);
     }
@@ -429,7 +443,7 @@ __global__ __launch_bounds__(kBoundsBlock) void v2v_rows_kernel(
         if (leafbox) {
             const int L = height_off[1] - height_off[0];
             float* q = leafbox + ((size_t)b * L + (i - height_off[0])) * 8;
-            q[0] = lo[0]; q[1] = lo[1]; q[2] = lo[2]; q[3] = 0.0f;
+            q[0] = lo[0]; q[1] = lo[1]; q[2] = lo[2]; q[3] = __int_as_float(g0);
             q[4] = -nhi[0]; q[5] = -nhi[1]; q[6] = -nhi[2]; q[7] = __int_as_float(off | (len << 20));
         }
     }
@@ -515,6 +529,66 @@ __device__ __forceinline__ void v2v_rows(Column& c, const float* __restrict__ pb
         }
     }
     for (; j < j_end; ++j) row(j, m0[j], pb[3 * j], pb[3 * j + 1], pb[3 * j + 2]);
+}
+
+// The same over a leaf's rows stored in groups of four (x[4] y[4] z[4], padded; mg: the mask words by padded row): two
+// rows per packed FP32 instruction -- (x_j, x_j+1) sit in even-aligned scalar register pairs, and a leaf always starts
+// on a group, so there is no ragged head or tail to handle on the scalar unit (what sank the first attempt, see
+// above).  Same arithmetic per row (v_pk_mul / v_pk_fma round like their scalar forms): the same keys.
+__device__ __forceinline__ void v2v_rows_packed(Column& c, const float* __restrict__ pg, const uint64_t* __restrict__ mg,
+                                                int j0, int ngroups, uint64_t reach)
+{
+    const float inf = __builtin_inff();
+    const v2f px = splat2(c.px), py = splat2(c.py), pz = splat2(c.pz);
+    auto dist2 = [&](float xa, float xb, float ya, float yb, float za, float zb) {
+        const v2f dx = px - (v2f){xa, xb}, dy = py - (v2f){ya, yb}, dz = pz - (v2f){za, zb};
+        return fma2(dz, dz, fma2(dy, dy, dx * dx));
+    };
+    auto take = [&](int j, float d) {
+        if (d < c.best || (d == c.best && d < inf && j < c.arg)) { c.best = d; c.arg = j; }
+    };
+    int g = 0, j = j0;
+    for (; g + 2 <= ngroups; g += 2, j += 8, mg += 8, pg += 24) {
+        uint64_t k0[8];
+        float v[24];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) k0[u] = mg[u];
+#pragma unroll
+        for (int u = 0; u < 24; ++u) v[u] = pg[u];
+        asm volatile("" :: "s"(v[0]), "s"(v[8]), "s"(v[16]));
+        if (((k0[0] | k0[1] | k0[2] | k0[3] | k0[4] | k0[5] | k0[6] | k0[7]) & reach) == 0) continue;
+        const v2f d01 = dist2(v[0], v[1], v[4], v[5], v[8], v[9]), d23 = dist2(v[2], v[3], v[6], v[7], v[10], v[11]);
+        const v2f d45 = dist2(v[12], v[13], v[16], v[17], v[20], v[21]), d67 = dist2(v[14], v[15], v[18], v[19], v[22], v[23]);
+        float d[8];
+        d[0] = select_by_lane_mask(inf, d01.x, k0[0]); d[1] = select_by_lane_mask(inf, d01.y, k0[1]);
+        d[2] = select_by_lane_mask(inf, d23.x, k0[2]); d[3] = select_by_lane_mask(inf, d23.y, k0[3]);
+        d[4] = select_by_lane_mask(inf, d45.x, k0[4]); d[5] = select_by_lane_mask(inf, d45.y, k0[5]);
+        d[6] = select_by_lane_mask(inf, d67.x, k0[6]); d[7] = select_by_lane_mask(inf, d67.y, k0[7]);
+        const float m = __builtin_fminf(min4_raw(d[0], d[1], d[2], d[3]), min4_raw(d[4], d[5], d[6], d[7]));
+        if (__builtin_amdgcn_ballot_w64(m <= c.best)) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) take(j + u, d[u]);                     // in row order: ties go to the smaller row
+        }
+    }
+    if (g < ngroups) {
+        uint64_t k0[4];
+        float v[12];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) k0[u] = mg[u];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) v[u] = pg[u];
+        asm volatile("" :: "s"(v[0]), "s"(v[4]), "s"(v[8]));
+        if (((k0[0] | k0[1] | k0[2] | k0[3]) & reach) == 0) return;
+        const v2f d01 = dist2(v[0], v[1], v[4], v[5], v[8], v[9]), d23 = dist2(v[2], v[3], v[6], v[7], v[10], v[11]);
+        float d[4];
+        d[0] = select_by_lane_mask(inf, d01.x, k0[0]); d[1] = select_by_lane_mask(inf, d01.y, k0[1]);
+        d[2] = select_by_lane_mask(inf, d23.x, k0[2]); d[3] = select_by_lane_mask(inf, d23.y, k0[3]);
+        const float m = min4_raw(d[0], d[1], d[2], d[3]);
+        if (__builtin_amdgcn_ballot_w64(m <= c.best)) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) take(j + u, d[u]);
+        }
+    }
 }
 
 // squared distance from the lane's column to a box
@@ -740,7 +814,8 @@ __global__ __launch_bounds__(64) void v2v_scan_kernel(
     const float* __restrict__ prow, int V, int Vp, const uint64_t* __restrict__ bits,
     const float* __restrict__ leafbox, const float* __restrict__ colbox, const uint64_t* __restrict__ masked_leaf,
     const uint64_t* __restrict__ masked, int N, int L, const int32_t* __restrict__ frontier,
-    const int32_t* __restrict__ sub_leaf, const int32_t* __restrict__ order, uint64_t* __restrict__ keys)
+    const int32_t* __restrict__ sub_leaf, const int32_t* __restrict__ order, uint64_t* __restrict__ keys,
+    const float* __restrict__ prow_g, const uint64_t* __restrict__ bits_g, int G)   // rows / mask words in groups of four
 {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int pair = __builtin_amdgcn_readfirstlane(order[blockIdx.y >> 1]);      // launch order over 128-blocks
@@ -753,7 +828,8 @@ __global__ __launch_bounds__(64) void v2v_scan_kernel(
     c.px = pb[3 * i0]; c.py = pb[3 * i0 + 1]; c.pz = pb[3 * i0 + 2];
     c.best = __uint_as_float((uint32_t)(init >> 32));
     c.arg = (int)(uint32_t)init;
-    const uint64_t* m0 = bits + (size_t)qb * V;
+    const float* pg = prow_g + (size_t)b * G * 12;
+    const uint64_t* mg = bits_g + (size_t)qb * G * 4;
     const int first = __builtin_amdgcn_readfirstlane(sub_leaf[2 * sub]), count = __builtin_amdgcn_readfirstlane(sub_leaf[2 * sub + 1]);
     // the largest bound among the columns that have an allowed row below this subtree at all
     const uint64_t alive = masked[(size_t)qb * N + __builtin_amdgcn_readfirstlane(frontier[sub])];
@@ -769,29 +845,37 @@ __global__ __launch_bounds__(64) void v2v_scan_kernel(
         // one leaf per lane: the gap between its box and the block's, against the largest bound
         const int li = base + lane;
         bool cand = false;
+        float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;   // box; lo.w = first group, hi.w = row range of the leaf
+        uint64_t lanes_of = 0;
         if (li < count) {
-            const float4 lo = *reinterpret_cast<const float4*>(lb + (size_t)li * 8);
-            const float4 hi = *reinterpret_cast<const float4*>(lb + (size_t)li * 8 + 4);
+            lo = *reinterpret_cast<const float4*>(lb + (size_t)li * 8);
+            hi = *reinterpret_cast<const float4*>(lb + (size_t)li * 8 + 4);
+            lanes_of = ml[li];
             const float ex = fmaxf(fmaxf(lo.x - chx, clx - hi.x), 0.0f);
             const float ey = fmaxf(fmaxf(lo.y - chy, cly - hi.y), 0.0f);
             const float ez = fmaxf(fmaxf(lo.z - chz, clz - hi.z), 0.0f);
             const float g = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) * kPruneSlack;
-            cand = g <= reach2 && (ml[li] & alive) != 0;
+            cand = g <= reach2 && (lanes_of & alive) != 0;
         }
         unsigned long long todo = __builtin_amdgcn_ballot_w64(cand);
         while (todo) {
             const int u = __builtin_ctzll(todo);
             todo &= todo - 1;
-            const float* box = lb + (size_t)(base + u) * 8;          // wave-uniform: scalar loads
-            const uint64_t lanes = ml[base + u];
-            const float dx = c.px - __builtin_amdgcn_fmed3f(c.px, box[0], box[4]);
-            const float dy = c.py - __builtin_amdgcn_fmed3f(c.py, box[1], box[5]);
-            const float dz = c.pz - __builtin_amdgcn_fmed3f(c.pz, box[2], box[6]);
+            // the candidate's record from the lane that tested it: ten v_readlane instead of two scalar loads behind eight
+            // scalar instructions of address arithmetic -- the vector units have slack since the rows are packed, the
+            // scalar unit and the scalar-memory latencies on each wavefront's chain are what this kernel waits for
+            auto from = [&](float x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), u)); };
+            const float b0 = from(lo.x), b1 = from(lo.y), b2 = from(lo.z), b4 = from(hi.x), b5 = from(hi.y), b6 = from(hi.z);
+            const uint64_t lanes = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(lanes_of >> 32), u) << 32) |
+                                   (uint32_t)__builtin_amdgcn_readlane((int)lanes_of, u);
+            const float dx = c.px - __builtin_amdgcn_fmed3f(c.px, b0, b4);
+            const float dy = c.py - __builtin_amdgcn_fmed3f(c.py, b1, b5);
+            const float dz = c.pz - __builtin_amdgcn_fmed3f(c.pz, b2, b6);
             const float g = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) * kPruneSlack;
             const uint64_t reach = __builtin_amdgcn_ballot_w64(g <= c.best) & lanes;
             if (reach) {
-                const int leaf = __float_as_int(box[7]);
-                v2v_rows(c, pb, m0, leaf & 0xfffff, leaf >> 20, reach);
+                const int leaf = __float_as_int(from(hi.w)), g0 = __float_as_int(from(lo.w));
+                v2v_rows_packed(c, pg + (size_t)g0 * 12, mg + (size_t)g0 * 4, leaf & 0xfffff, ((leaf >> 20) + 3) >> 2, reach);
             }
         }
     }
@@ -817,7 +901,7 @@ __global__ __launch_bounds__(kBlock) void v2v_tree_finalize_kernel(
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-struct TreeV2VLayout { size_t prow, bounds, keys, leafbox, colbox, total; };
+struct TreeV2VLayout { size_t prow, bounds, keys, leafbox, colbox, prow_g, total; };
 
 TreeV2VLayout tree_v2v_layout(const tuch_contact_model* m, int B)
 {
@@ -829,6 +913,7 @@ TreeV2VLayout tree_v2v_layout(const tuch_contact_model* m, int B)
     l.keys = tuch_ws_take(o, (size_t)B * Vp * sizeof(uint64_t));
     l.leafbox = tuch_ws_take(o, ((size_t)B * m->tree_leaves + kLeafBatch) * 8 * sizeof(float));     // + a batch of padding
     l.colbox = tuch_ws_take(o, (size_t)B * 2 * m->tree_qblocks * 8 * sizeof(float));
+    l.prow_g = tuch_ws_take(o, ((size_t)B * m->tree_groups * 12 + 16) * sizeof(float));     // (+ a trip's read-ahead)
     l.total = o;
     return l;
 }
@@ -969,7 +1054,8 @@ extern "C" int tuch_v2v_min_model_shared(const tuch_contact_model* m, const floa
     hipLaunchKernelGGL(v2v_rows_kernel, dim3(ceil_div(m->tree_leaves, kBoundsBlock / 16), B), dim3(kBoundsBlock), 0, s,
                        verts, V, Vp, (const int32_t*)m->tree_qperm, (const int32_t*)m->tree_rows,
                        (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, N, prow, bounds,
-                       flat ? leafbox : (float*)nullptr);
+                       flat ? leafbox : (float*)nullptr, (const int32_t*)m->tree_leaf_group,
+                       scan == 2 ? (float*)(ws + l.prow_g) : (float*)nullptr, m->tree_groups);
     hipLaunchKernelGGL(tree_inner_bounds_kernel<4>, dim3(B), dim3(kBoundsBlock), tree_inner_bounds_lds<4>(N), s, nodes, N,
                        (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, m->tree_heights, bounds,
                        (const int32_t*)m->tree_v2v_info);
@@ -989,7 +1075,8 @@ extern "C" int tuch_v2v_min_model_shared(const tuch_contact_model* m, const floa
                            V, Vp, (const uint64_t*)m->tree_mask_bits, (const float*)leafbox, (const float*)colbox,
                            (const uint64_t*)m->tree_masked_leaf, (const uint64_t*)m->tree_masked, N, m->tree_leaves,
                            (const int32_t*)m->tree_frontier_nodes + f0, (const int32_t*)m->tree_sub_leaf + 2 * (size_t)f0,
-                           (const int32_t*)m->tree_launch_order + (size_t)f0 * m->tree_qblocks, keys);
+                           (const int32_t*)m->tree_launch_order + (size_t)f0 * m->tree_qblocks, keys,
+                           (const float*)(ws + l.prow_g), (const uint64_t*)m->tree_mask_bits_g, m->tree_groups);
     else if (flat)
         hipLaunchKernelGGL(v2v_leaves_kernel, dim3(B, 2 * nsub * m->tree_qblocks), dim3(64), (size_t)lds_pad, s, (const float*)prow,
                            V, Vp, (const uint64_t*)m->tree_mask_bits, (const float*)bounds, (const float*)leafbox,
