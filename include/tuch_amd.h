@@ -81,6 +81,16 @@ size_t tuch_v2v_min_indexed_workspace_bytes(int B, int max_points_per_body);
 int tuch_v2v_min_indexed(const float* points, const int32_t* vertex_ids, const int32_t* offsets,
                          const uint64_t* geomask_bits, int B, int V, int max_points_per_body, float* min_d2,
                          int32_t* argmin, void* workspace, size_t workspace_bytes, void* stream);
+/* The same search on the matrix cores (what the HD branch of tuch_hd_contact_fwd runs by default): distances of 32 rows x
+ * 64 columns from v_mfma_f32_32x32x2_f32 in coordinates relative to the column block, the mask as a bf16 penalty product.
+ * The winner of a column is the row with the smallest 20-bit key of that distance: it may differ from
+ * tuch_v2v_min_indexed's between rows whose squared distances tie within ~1e-6 relative + a few ulp of the block's
+ * squared radius (the reference's own |x|^2+|y|^2-2x.y form is noisier); min_d2 is the direct-difference distance of
+ * the winner.  Same arguments. */
+size_t tuch_v2v_min_indexed_mfma_workspace_bytes(int B, int max_points_per_body);
+int tuch_v2v_min_indexed_mfma(const float* points, const int32_t* vertex_ids, const int32_t* offsets,
+                              const uint64_t* geomask_bits, int B, int V, int max_points_per_body, float* min_d2,
+                              int32_t* argmin, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- pull/push terms: losses.py:96-105 (mode 0) / loss.py:303-315 (mode 1) ---------- */
 

@@ -701,6 +701,64 @@ def test_v2v_min_indexed_matches_brute_force(order):
         np.testing.assert_allclose(d64[rows[fin], a[fin]], want[fin], rtol=2e-6, atol=1e-9)
 
 
+@pytest.mark.parametrize('tag,order', [('medium', 'patch'), ('medium', 'shuffled'), ('full', 'patch')])
+def test_v2v_min_indexed_mfma_vs_exact(tag, order):
+    """The matrix-core form of the ragged search (hd_search.hip, what the HD branch runs) against the exact kernel:
+    every winner is admissible, its reported distance is its direct-difference distance, and that distance exceeds the
+    exact float32 minimum by no more than the key's rounding (1e-6 relative) + a few ulp of the column block's squared
+    radius -- 2e-8 for points sorted by surface patch (the HD branch keeps them so), 4e-6 for any order.  Columns
+    without an admissible row report (inf, 0).  Two runs agree bit for bit."""
+    g, gm = golden(tag), golden_mask(tag)
+    model = make_model(g, gm, False, False)
+    rng = np.random.default_rng(11)
+    v = g['verts'].shape[1]
+    pos = model.tree_positions()
+    counts = [2900, 0, 317, 64, 1, 33, 1000] if tag == 'medium' else [6100, 97, 4000]
+    pts, vids = [], []
+    for b, n in enumerate(counts):
+        base = rng.choice(v, n, replace=True)
+        if order == 'patch':
+            base = base[np.argsort(pos[base], kind='stable')]
+        pts.append(g['verts'][b % g['verts'].shape[0]][base] + 0.004 * rng.standard_normal((n, 3)))
+        vids.append(base)
+    pts = np.concatenate(pts).astype(np.float32)
+    vids = np.concatenate(vids).astype(np.int32)
+    offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    args = (torch.tensor(pts, device=dev()), torch.tensor(vids, device=dev()), torch.tensor(offsets, device=dev()), max(counts))
+    mn0, arg0 = model.v2v_min_indexed(*args)
+    mn1, arg1 = model.v2v_min_indexed(*args, mfma=True)
+    mn2, arg2 = model.v2v_min_indexed(*args, mfma=True)
+    assert torch.equal(mn1, mn2) and torch.equal(arg1, arg2)
+    mn0, arg0, mn1, arg1 = (t.cpu().numpy() for t in (mn0, arg0, mn1, arg1))
+    fin = np.isfinite(mn0)
+    assert np.array_equal(np.isfinite(mn1), fin)
+    assert (arg1[~fin] == 0).all()
+    worst, differ = 0.0, 0
+    for b, n in enumerate(counts):
+        lo = offsets[b]
+        if n == 0:
+            continue
+        f = fin[lo:lo + n]
+        a1 = arg1[lo:lo + n].astype(np.int64)
+        assert ((a1 >= 0) & (a1 < n)).all()
+        if not f.any():
+            continue
+        p, vid = pts[lo:lo + n], vids[lo:lo + n]
+        cols = np.arange(n)[f]
+        assert gm[vid[a1[f]], vid[cols]].all()                         # geomask[vid[row]][vid[column]]
+        d = p[cols] - p[a1[f]]
+        direct = (d[:, 2] * d[:, 2] + (d[:, 1] * d[:, 1] + d[:, 0] * d[:, 0])).astype(np.float32)
+        np.testing.assert_allclose(mn1[lo:lo + n][f], direct, rtol=3e-7, atol=0)
+        excess = mn1[lo:lo + n][f].astype(np.float64) - mn0[lo:lo + n][f]
+        assert (excess >= -1e-12).all()
+        tol = 2e-6 * mn0[lo:lo + n][f] + (2e-8 if order == 'patch' else 4e-6)
+        assert (excess <= tol).all(), (b, excess.max())
+        worst = max(worst, float(excess.max()))
+        differ += int((a1[f] != arg0[lo:lo + n][f]).sum())
+    report('v2v_min_indexed_mfma %s/%s: winners != exact kernel (ties within the key rounding), worst excess %.2e' %
+           (tag, order, worst), differ, int(fin.sum()))
+
+
 def test_winding_tree_work_counts():
     """The measurement aid behind bench.py's roofline: element steps walked by the tree, far below the flat walk."""
     g = golden('full')

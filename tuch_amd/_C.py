@@ -35,6 +35,9 @@ _SIGNATURES = {
     'tuch_v2v_min_indexed_workspace_bytes': (c_size_t, [c_int, c_int]),
     'tuch_v2v_min_indexed': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                      c_void_p, c_size_t, c_void_p]),
+    'tuch_v2v_min_indexed_mfma_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'tuch_v2v_min_indexed_mfma': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                          c_void_p, c_size_t, c_void_p]),
     'tuch_contact_terms_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                        c_void_p, c_void_p]),
     'tuch_contact_terms_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,

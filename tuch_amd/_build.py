@@ -18,6 +18,11 @@ LIB = os.path.join(HERE, 'libtuch_amd.so')
 ARCH = 'gfx950'
 
 
+# per-file flags.  hd_search.hip: matrix-core results in ordinary vector registers (its accumulators are read by the
+# vector unit at once: as AGPRs every value costs a v_accvgpr_read)
+EXTRA_FLAGS = {'hd_search.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
 
@@ -42,7 +47,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 os.path.getmtime(src), *[os.path.getmtime(os.path.join(CSRC, h))
                                          for h in os.listdir(CSRC) if h.endswith('.h')]):
             cmd = [hipcc, '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-I', CSRC,
-                   '-Wall', '-Wno-unused-function', '-c', src, '-o', obj]
+                   '-Wall', '-Wno-unused-function'] + EXTRA_FLAGS.get(os.path.basename(src), []) + ['-c', src, '-o', obj]
             if verbose:
                 print(' '.join(cmd))
             subprocess.run(cmd, check=True)

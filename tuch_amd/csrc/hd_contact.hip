@@ -361,7 +361,7 @@ Work work_layout(const tuch_hd_model* hm, int B)
     l.chunk_cnt = tuch_ws_take(o, (size_t)B * ceil_div(N, kSel) * sizeof(int32_t));
     l.first_key = tuch_ws_take(o, (size_t)B * sizeof(unsigned long long));
     size_t search_bytes, winding_bytes;
-    { tuch_ws_pause nested; search_bytes = tuch_v2v_min_indexed_workspace_bytes(B, N); winding_bytes = tuch_winding_points_workspace_bytes(hm->cm, B, N); }
+    { tuch_ws_pause nested; search_bytes = std::max(tuch_v2v_min_indexed_workspace_bytes(B, N), tuch_hd_search_workspace_bytes(B, N)); winding_bytes = tuch_winding_points_workspace_bytes(hm->cm, B, N); }
     l.search = tuch_ws_take(o, search_bytes);
     l.winding = tuch_ws_take(o, winding_bytes);
     l.winding_bytes = winding_bytes;
@@ -531,8 +531,11 @@ extern "C" int tuch_hd_contact_fwd(const tuch_hd_model* hm, const float* verts, 
     // (seeding the search from the vertex-level partners was tried: the seeds are excellent where they exist -- median
     // ratio to the final distance 1.00 -- but the nearest admissible HD point is ~10 cm away, so a column block still has
     // to visit ~40 % of the rows, and building the seeds cost more than the sampling pass they replace)
-    int rc = tuch_v2v_min_indexed_seeded(pts, vid, hm->offsets, counts, nullptr, nullptr, first, bits, B, V, N,
-                                         (float*)(ws + wl.min_d2), part, ws + wl.search, s);
+    int rc = hm->cm->opt.hd_search
+                 ? tuch_hd_search(pts, vid, hm->offsets, counts, first, bits, B, V, N, (float*)(ws + wl.min_d2), part,
+                                  ws + wl.search, s, hm->cm->opt.hd_search_waves)
+                 : tuch_v2v_min_indexed_seeded(pts, vid, hm->offsets, counts, nullptr, nullptr, first, bits, B, V, N,
+                                               (float*)(ws + wl.min_d2), part, ws + wl.search, s);
     if (rc != TUCH_OK) return rc;
     rc = tuch_winding_points(hm->cm, verts, offs, counts, B, N, thresh, nullptr, ext, ws + wl.winding,
                              wl.winding_bytes, stream);

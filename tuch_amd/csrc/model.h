@@ -49,6 +49,8 @@ struct tuch_options {
     int seg_fused = 1;          // 0: the segment filter as six launches instead of one (A/B, tests)
     int canary = 0;             // 1: guard words between the regions of every workspace, see tuch_workspace_canaries
     int deterministic = 0;      // 1: gradient scatters as gathers over inverse partner lists (bit-reproducible fits)
+    int hd_search = 1;          // HD branch: 1 nearest admissible point on the matrix cores (hd_search.hip), 0 v2v_indexed_kernel
+    int hd_search_waves = 4;    // wavefronts per block of 64 columns in that search (4, 2 or 1)
 };
 void tuch_options_from_env(tuch_options* o);
 
@@ -82,6 +84,11 @@ int tuch_v2v_min_indexed_seeded(const float* points, const int32_t* vertex_ids, 
                                 const int32_t* all_masked_arg, const uint64_t* geomask_bits, int B, int V,
                                 int max_points_per_body, float* min_d2, int32_t* argmin, void* workspace, hipStream_t s);
 extern "C" size_t tuch_v2v_min_indexed_workspace_bytes(int B, int max_points_per_body);
+// the same search on the matrix cores (hd_search.hip)
+size_t tuch_hd_search_workspace_bytes(int B, int max_points_per_body);
+int tuch_hd_search(const float* points, const int32_t* vertex_ids, const int32_t* offsets, const int32_t* counts,
+                   const int32_t* all_masked_arg, const uint64_t* geomask_bits, int B, int V, int max_points_per_body,
+                   float* min_d2, int32_t* argmin, void* workspace, hipStream_t s, int waves);
 extern "C" size_t tuch_winding_points_workspace_bytes(const tuch_contact_model* m, int B, int Q);
 extern "C" int tuch_winding_points(const tuch_contact_model* m, const float* verts, const float* points,
                                    const int32_t* counts, int B, int Q, float thresh, float* w,

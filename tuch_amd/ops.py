@@ -752,11 +752,13 @@ class ContactModel:
         return w, ext
 
     def v2v_min_indexed(self, points: torch.Tensor, vertex_ids: torch.Tensor, offsets: torch.Tensor,
-                        max_points: int, tree_order: bool = False):
+                        max_points: int, tree_order: bool = False, mfma: bool = False):
         """Ragged masked nearest neighbour (HD points, loss.py:288-291).  points [N,3], vertex_ids [N]
         int32, offsets [B+1] int32 -> (min_d2 [N], argmin [N] int32 relative to the body's first point).
         tree_order: vertex_ids are positions in the cluster tree's vertex order (``tree_positions``) and the
-        mask packed in that order is used -- the same answer, far fewer distinct mask words per wavefront."""
+        mask packed in that order is used -- the same answer, far fewer distinct mask words per wavefront.
+        mfma: the matrix-core form the HD branch runs (tuch_v2v_min_indexed_mfma: winners may differ between rows that tie
+        within ~1e-6 relative)."""
         if not self.has_mask:
             raise _C.TuchError('ContactModel was created without a geodesic mask')
         pts = _f32(points)
@@ -768,12 +770,14 @@ class ContactModel:
             L.tuch_contact_model_mask_bits(self._handle)
         if not bits:
             raise _C.TuchError('ContactModel has no mask in tree order (no cluster tree)')
-        nbytes = L.tuch_v2v_min_indexed_workspace_bytes(offsets.shape[0] - 1, int(max_points))
+        size_fn, fn = (L.tuch_v2v_min_indexed_mfma_workspace_bytes, L.tuch_v2v_min_indexed_mfma) if mfma else \
+            (L.tuch_v2v_min_indexed_workspace_bytes, L.tuch_v2v_min_indexed)
+        nbytes = size_fn(offsets.shape[0] - 1, int(max_points))
         ws = _workspace(nbytes, pts.device)
         vertex_ids, offsets = vertex_ids.contiguous(), offsets.contiguous()
-        _C.check(L.tuch_v2v_min_indexed(_C.ptr(pts), _C.ptr(vertex_ids), _C.ptr(offsets),
-                                        ctypes.c_void_p(bits), offsets.shape[0] - 1, self.num_verts, int(max_points),
-                                        _C.ptr(mn), _C.ptr(arg), _C.ptr(ws), nbytes, _C.stream()))
+        _C.check(fn(_C.ptr(pts), _C.ptr(vertex_ids), _C.ptr(offsets),
+                    ctypes.c_void_p(bits), offsets.shape[0] - 1, self.num_verts, int(max_points),
+                    _C.ptr(mn), _C.ptr(arg), _C.ptr(ws), nbytes, _C.stream()))
         return mn, arg
 
     def tree_positions(self) -> Optional[np.ndarray]:
