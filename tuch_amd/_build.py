@@ -20,7 +20,7 @@ ARCH = 'gfx950'
 
 # per-file flags.  hd_search.hip: matrix-core results in ordinary vector registers (its accumulators are read by the
 # vector unit at once: as AGPRs every value costs a v_accvgpr_read)
-EXTRA_FLAGS = {'hd_search.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
+EXTRA_FLAGS = {'hd_search.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'] + os.environ.get('TUCH_HDS_FLAGS', '').split()}
 
 
 def sources():

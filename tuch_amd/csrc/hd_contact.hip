@@ -404,10 +404,17 @@ extern "C" int tuch_hd_model_create(tuch_hd_model** out, const tuch_contact_mode
     // for the search).  The model's own tree decides (not a rebuilt one).
     std::vector<int32_t> order(N);
     std::iota(order.begin(), order.end(), 0);
+    // Within a patch: by the mask vertex (first vertex of the face, loss.py:88), then by face -- consecutive points that
+    // inherit the same mask row form the runs hd_search.hip fetches one mask word for.
     const bool tree = cm->tree_nodes > 0 && cm->tree_face_leaf_host;
     if (tree)
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-            return cm->tree_face_leaf_host[hd_face[a]] < cm->tree_face_leaf_host[hd_face[b]];
+            const int fa = hd_face[a], fb = hd_face[b];
+            const int la = cm->tree_face_leaf_host[fa], lb = cm->tree_face_leaf_host[fb];
+            if (la != lb) return la < lb;
+            const int va = faces[3 * (size_t)fa], vb = faces[3 * (size_t)fb];
+            if (va != vb) return va < vb;
+            return fa < fb;
         });
     std::vector<int32_t> pos(V);
     const bool tree_mask = tree && cm->tree_mask_bits && cm->tree_qperm_host;

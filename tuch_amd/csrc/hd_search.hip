@@ -16,8 +16,18 @@
 // rows whose squared distances tie within ~1e-6 relative + a few ulp of R^2 + |q'|^2 absolute (the reference's own
 // |x|^2+|y|^2-2x.y matrix is 20 times noisier); the distance reported for it is recomputed by direct
 // differences.  Deterministic: every reduction has a fixed order.
-// Pass 1 evaluates one representative row per tile (bounds for every column), pass 2 the tiles whose box some column
-// with an admissible row in it can still reach.
+// Pass 1 evaluates one representative row per tile (all 32 mask words of a group of representatives requested at once):
+// an upper bound for every column.  Pass 2, per wavefront and 64 of its tiles at a time with lane <-> tile: the tile's box
+// against the box of the column block and the largest bound in it, the survivors against every column's own bound (the
+// columns in reach kept as a 64-bit mask); what survives both gets a record in LDS (box, runs, the first eight mask
+// vertices, the reach mask).  The loop over the records requests the NEXT tile's mask words and rows before it works on
+// the current one (unconditionally: with the same number of loads in flight on every path the compiler waits for exactly
+// the older set); a tile none of whose reachable columns has an admissible run ends before the products.
+// Measured at batch 64 (5 600 column blocks of 192 tiles): 105 tiles per block pass the block filter, 65 the per-column
+// test, 40 reach the products; 215 us against 502 us for v2v_indexed_kernel, 7.0e7 instead of 2.0e8 vector instructions,
+// vector unit 0.58 busy.  (The mask words of the run slots as buffer loads with the column's part of the address in the
+// lane offset: no address arithmetic; -mllvm -amdgpu-mfma-vgpr-form keeps the accumulators out of the AGPRs, whose 32
+// v_accvgpr_read per tile were 12 % of the kernel.)
 #include "common.h"
 #include "model.h"
 #include "workspace.h"
@@ -29,6 +39,11 @@ constexpr float kBigNorm = 1e30f;         // "norm" of a row that does not exist
 constexpr float kNoKey = 1e29f;           // keys at or above: no admissible row
 constexpr uint32_t kPenalty = 0x7F00u;    // bf16 2^127
 constexpr float kSlack = 0.999999f;       // lower bounds are deflated by 1e-6
+constexpr uint32_t kPenaltyPair = kPenalty | (kPenalty << 16);
+constexpr int kRepStep = 1;               // pass 1: one representative row per this many tiles (2: same time, 4: slower)
+// runs of a tile whose mask words are requested one tile ahead (patch-sorted HD points: 7.6 runs per tile on average,
+// never more than 12; with 12 requested ahead the extra gathers cost more than the late groups of the few longer tiles)
+constexpr int kAhead = 8;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -37,7 +52,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct TileMeta {                         // 192 bytes per tile of 32 consecutive points of a body
     float lo[3]; int32_t runs;            // bounding box; number of runs (rows with the same mask vertex, consecutive)
     float hi[3]; int32_t rows;            // rows that exist (32 except in the body's last tile)
-    int32_t tv[32];                       // mask vertex of run k (0 behind the last run)
+    int32_t tv[32];                       // mask vertex of run k (behind the last run: the last run's again)
     uint8_t ridx[32];                     // run of row i (255: the row does not exist)
 };
 static_assert(sizeof(TileMeta) == 192, "TileMeta layout");
@@ -52,13 +67,12 @@ __global__ __launch_bounds__(256) void hd_tiles_kernel(
     const int tile = blockIdx.x * 8 + ((int)threadIdx.x >> 5), i = threadIdx.x & 31;
     const int beg = off[b], n = counts ? counts[b] : off[b + 1] - beg;
     const int tiles = (n + kTile - 1) / kTile;
-    if (tile >= tiles) {
-        // the representatives are read in groups of 32: pad the last group
-        if (tile < ((tiles + 31) & ~31) && tile < rep_stride && i == 0) {
-            rep_tv[(size_t)b * rep_stride + tile] = 0;
-            rep_xyz[(size_t)b * rep_stride + tile] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        return;
+    if (tile >= tiles) return;
+    const int reps = (tiles + kRepStep - 1) / kRepStep;
+    // the representatives are read in groups of 32: pad the last group
+    if (tile == 0 && i > 0 && reps + i - 1 < ((reps + 31) & ~31)) {
+        rep_tv[(size_t)b * rep_stride + reps + i - 1] = 0;
+        rep_xyz[(size_t)b * rep_stride + reps + i - 1] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const int r = tile * kTile + i;
     const bool valid = r < n;
@@ -79,14 +93,18 @@ __global__ __launch_bounds__(256) void hd_tiles_kernel(
     const int run = __builtin_popcount(sb & ((2u << i) - 1u)) - 1;
     const int runs = __builtin_popcount(sb);
     TileMeta* m = meta + (size_t)b * max_tiles + tile;
-    if (i >= runs) m->tv[i] = 0;
+    // unused run slots repeat the last run's vertex: the search may fetch their mask words, they change nothing
+    const int last_v = __shfl(v, min(kTile, n - tile * kTile) - 1, 32);
+    if (i >= runs) m->tv[i] = last_v;
     if (start) m->tv[run] = v;
     m->ridx[i] = valid ? (uint8_t)run : (uint8_t)255;
     if (i == 0) {
         m->lo[0] = lo[0]; m->lo[1] = lo[1]; m->lo[2] = lo[2]; m->runs = runs;
         m->hi[0] = hi[0]; m->hi[1] = hi[1]; m->hi[2] = hi[2]; m->rows = min(kTile, n - tile * kTile);
-        rep_tv[(size_t)b * rep_stride + tile] = v;
-        rep_xyz[(size_t)b * rep_stride + tile] = make_float4(x, y, z, 0.f);
+        if (tile % kRepStep == 0) {
+            rep_tv[(size_t)b * rep_stride + tile / kRepStep] = v;
+            rep_xyz[(size_t)b * rep_stride + tile / kRepStep] = make_float4(x, y, z, 0.f);
+        }
     }
 }
 
@@ -107,6 +125,51 @@ __device__ __forceinline__ void swap_halves(uint32_t& x, uint32_t& y)
     x = r[0]; y = r[1];
 }
 
+// mask words of N runs (mask vertices tvp[0..N), a scalar pointer) for the lane's column: all requested before any is
+// used.  Buffer loads: the run's part of the address is the scalar offset, the column's part the lane offset -- no
+// address arithmetic on the vector unit.
+template <int N>
+__device__ __forceinline__ void request_words(__amdgpu_buffer_rsrc_t rsrc, uint32_t lane_off, const int32_t* tvp, int (&w)[N])
+{
+    static_assert(N % 4 == 0, "whole groups");
+#pragma unroll
+    for (int g = 0; g < N / 4; ++g) {
+        const int4 tv = *reinterpret_cast<const int4*>(tvp + 4 * g);         // scalar load
+        w[4 * g + 0] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_off, tv.x * 8, 0);
+        w[4 * g + 1] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_off, tv.y * 8, 0);
+        w[4 * g + 2] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_off, tv.z * 8, 0);
+        w[4 * g + 3] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_off, tv.w * 8, 0);
+    }
+}
+// A[(K0 + u) >> 1], 16 bits per run K0 + u (runs counted from the array's first): all ones where the column may use it
+template <int N, int K0>
+__device__ __forceinline__ void digest_words(const int (&w)[N], uint32_t shift, uint32_t (&A)[8])
+{
+    static_assert(K0 + N <= 16, "eight registers hold sixteen runs");
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        const int k = K0 + u;
+        const uint32_t t = (uint32_t)__builtin_amdgcn_sbfe(w[u], shift, 1);
+        A[k >> 1] = (t & (0xFFFFu << (16 * (k & 1)))) | A[k >> 1];
+    }
+}
+// groups [G0, 8) of four runs each, as far as the tile has runs (K, wave-uniform; kBase = first run of the array)
+template <int G0, int kBase>
+__device__ __forceinline__ void late_groups(__amdgpu_buffer_rsrc_t rsrc, uint32_t lane_off, const int32_t* tvp, int K, uint32_t shift,
+                                            uint32_t (&A)[8])
+{
+    if constexpr (G0 < 4) {
+        if (kBase + 4 * G0 < K) {
+            int w[4];
+            request_words<4>(rsrc, lane_off, tvp + kBase + 4 * G0, w);
+            digest_words<4, 4 * G0>(w, shift, A);
+            late_groups<G0 + 1, kBase>(rsrc, lane_off, tvp, K, shift, A);
+        }
+    }
+}
+
+constexpr int kRecord = 8 + kAhead + 2;   // dwords of a candidate's record in LDS: lo, tile << 8 | runs, hi, rows, tv[kAhead], columns in reach
+
 // Lane layouts.  "Own column": lane l <-> column 64 cb + l (box tests, mask words).  Matrix layout of sub-tile s (columns
 // 32 s ... 32 s + 31): lane l <-> column 32 s + (l & 31); accumulator register a of lane l is row (a & 3) + 8 (a >> 2) +
 // 4 (l >> 5) of the tile; the A operand of lane l belongs to row l & 31, the k index of both operands is chosen by l >> 5.
@@ -121,6 +184,7 @@ __global__ __launch_bounds__(64 * kWaves) void hd_search_kernel(
     __shared__ float s_f[kWaves][2][64];
     __shared__ int s_i[kWaves][2][64];
     __shared__ float s_bound[64];
+    __shared__ int s_rec[kWaves][64][kRecord];
     const int b = blockIdx.y, cb = blockIdx.x;
     const int beg = __builtin_amdgcn_readfirstlane(off[b]);
     const int n = counts ? __builtin_amdgcn_readfirstlane(counts[b]) : __builtin_amdgcn_readfirstlane(off[b + 1]) - beg;
@@ -173,38 +237,10 @@ __global__ __launch_bounds__(64 * kWaves) void hd_search_kernel(
     }
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-    // penalties of runs [0, K) for the own column (R[k >> 1], 16 bits per run), and whether any run is admissible.  The
-    // mask word of (column's 32-vertex block, run's vertex) through a buffer load: the run's part of the address is the
-    // scalar offset, the column's part the lane offset -- no address arithmetic on the vector unit
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(bits), 0, 0x7ffffffc, 0x00020000);
     const uint32_t shift = va & 31;
-    constexpr uint32_t kPenaltyPair = kPenalty | (kPenalty << 16);
-    auto build = [&](const int32_t* tvp, int K, uint32_t (&R)[16], uint32_t& any) {
-        uint32_t A[16];                                                      // admissible runs: 0xFFFF per run
-#pragma unroll
-        for (int m = 0; m < 16; ++m) A[m] = 0u;
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            if (4 * g >= K) break;                                           // wave-uniform
-            const int4 tv = *reinterpret_cast<const int4*>(tvp + 4 * g);     // scalar load
-            int w[4];
-            w[0] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_off, tv.x * 8, 0);
-            w[1] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_off, tv.y * 8, 0);
-            w[2] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_off, tv.z * 8, 0);
-            w[3] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_off, tv.w * 8, 0);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = 4 * g + u;
-                const uint32_t t = (uint32_t)__builtin_amdgcn_sbfe(w[u], shift, 1);        // admissible: all ones
-                A[k >> 1] = (t & (0xFFFFu << (16 * (k & 1)))) | A[k >> 1];
-            }
-            any |= A[2 * g] | A[2 * g + 1];
-        }
-#pragma unroll
-        for (int m = 0; m < 16; ++m) R[m] = ~A[m] & kPenaltyPair;
-    };
-    // the tile: distances + penalties for both sub-tiles.  kMany: more than 16 runs (two penalty products)
-    auto product = [&](float qx, float qy, float qz, bool exists, int ridx, uint32_t (&R)[16], bool many, f32x16 (&acc)[2]) {
+    // the tile: distances + the penalties of runs 0..15 for both sub-tiles
+    auto product = [&](float qx, float qy, float qz, bool exists, int ridx, uint32_t (&R)[8], f32x16 (&acc)[2]) {
         const float ux = qx - cx, uy = qy - cy, uz = qz - cz;
         const float nrm = exists ? __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux)) + R2 : kBigNorm;
         const float A1 = h ? uy : ux, A2 = h ? nrm : uz;
@@ -221,30 +257,41 @@ __global__ __launch_bounds__(64 * kWaves) void hd_search_kernel(
         acc[1] = mfma_f32(A2, B2[1], acc[1]);
         acc[0] = mfma_bf16(oh0, P0, acc[0]);
         acc[1] = mfma_bf16(oh0, P1, acc[1]);
-        if (many) {
-            const unsigned e1 = (unsigned)(ridx - 16 - 8 * h);
-            const u32x4 oh1 = onehot[e1 < 8u ? e1 : 8u];
+    };
+    // the penalties of runs 16..31 on top
+    auto product_high = [&](int ridx, uint32_t (&R)[8], f32x16 (&acc)[2]) {
+        const unsigned e1 = (unsigned)(ridx - 16 - 8 * h);
+        const u32x4 oh1 = onehot[e1 < 8u ? e1 : 8u];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) swap_halves(R[8 + m], R[12 + m]);
-            const u32x4 Q0 = {R[8], R[9], R[10], R[11]}, Q1 = {R[12], R[13], R[14], R[15]};
-            acc[0] = mfma_bf16(oh1, Q0, acc[0]);
-            acc[1] = mfma_bf16(oh1, Q1, acc[1]);
-        }
+        for (int m = 0; m < 4; ++m) swap_halves(R[m], R[4 + m]);
+        const u32x4 Q0 = {R[0], R[1], R[2], R[3]}, Q1 = {R[4], R[5], R[6], R[7]};
+        acc[0] = mfma_bf16(oh1, Q0, acc[0]);
+        acc[1] = mfma_bf16(oh1, Q1, acc[1]);
     };
     __syncthreads();                                                          // onehot
 
     // ---- pass 1: one representative per tile -> an upper bound for every column ------------------------------------
     float bestf[2] = {kNoKey, kNoKey};
-    const int rep_tiles = (tiles + 31) >> 5;
+    const int reps = (tiles + kRepStep - 1) / kRepStep, rep_tiles = (reps + 31) >> 5;
     for (int u = wave; u < rep_tiles; u += kWaves) {
         const size_t rb = (size_t)b * rep_stride + 32 * u;
-        uint32_t R[16] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-        uint32_t any = 0u;
-        const int K = min(32, tiles - 32 * u);
-        build(rep_tv + rb, K, R, any);
+        const int K = min(32, reps - 32 * u);
+        int w[32];
+        request_words<32>(rsrc, lane_off, rep_tv + rb, w);
         const float4 q = rep_xyz[rb + j];
+        uint32_t R[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, Rh[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        {
+            int wl[16], wh[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { wl[k] = w[k]; wh[k] = w[16 + k]; }
+            digest_words<16, 0>(wl, shift, R);
+            digest_words<16, 0>(wh, shift, Rh);
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) { R[m] = ~R[m] & kPenaltyPair; Rh[m] = ~Rh[m] & kPenaltyPair; }
         f32x16 acc[2];
-        product(q.x, q.y, q.z, j < K, j, R, true, acc);
+        product(q.x, q.y, q.z, j < K, j, R, acc);
+        product_high(j, Rh, acc);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             float m = bestf[s];
@@ -274,47 +321,45 @@ __global__ __launch_bounds__(64 * kWaves) void hd_search_kernel(
     for (int s = 0; s < 2; ++s) bestkey[s] = __float_as_int(s_bound[32 * s + j]) | 15;
 
     // ---- pass 2 ------------------------------------------------------------------------------------------------------
-    // 64 tiles at a time, lane <-> tile: the tile's box against the box of the column block and the largest bound in
-    // it (a lower bound of what any single column could find); only the survivors get the test per column
-    for (int t0 = wave; t0 < tiles; t0 += 64 * kWaves) {
-    unsigned long long todo;
-    {
-        float bmax = bnd;
+    // Candidates, 64 tiles per wavefront at a time with lane <-> tile: the tile's box against the box of the column block
+    // and the largest bound in it (a lower bound of what any single column could find).  A survivor's record (box, runs,
+    // the first kAhead mask vertices) goes to LDS: the loop over the survivors then finds everything a tile needs one ds_read
+    // away and requests the NEXT tile's mask words and rows before it works on the current one.
+    auto request_tile = [&](int i, int (&w)[kAhead], float& qx, float& qy, float& qz, int& ridx) {
+        const int* rec = s_rec[wave][i];
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, m));
-        const int tl = t0 + kWaves * lane;
-        bool cand = false;
-        if (tl < tiles) {
-            const float4 l4 = *reinterpret_cast<const float4*>(mb[tl].lo), h4 = *reinterpret_cast<const float4*>(mb[tl].hi);
-            const float gx = fmaxf(fmaxf(l4.x - hi[0], lo[0] - h4.x), 0.0f);
-            const float gy = fmaxf(fmaxf(l4.y - hi[1], lo[1] - h4.y), 0.0f);
-            const float gz = fmaxf(fmaxf(l4.z - hi[2], lo[2] - h4.z), 0.0f);
-            cand = __builtin_fmaf(gz, gz, __builtin_fmaf(gy, gy, gx * gx)) * kSlack <= bmax;
+        for (int k = 0; k < kAhead; ++k)
+            w[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_off + 8u * (uint32_t)rec[8 + k], 0, 0);
+        const int t = __builtin_amdgcn_readfirstlane(rec[3]) >> 8;
+        const int rc = min(t * kTile + j, n - 1);
+        qx = bp[3 * rc]; qy = bp[3 * rc + 1]; qz = bp[3 * rc + 2];
+        ridx = mb[t].ridx[j];
+    };
+    auto tile_step = [&](int i, const int (&w)[kAhead], float qx, float qy, float qz, int ridx) {
+        const int* rec = s_rec[wave][i];
+        // (the columns in reach were found when the candidates were listed; testing again against the bounds as they are
+        // now prunes a few tiles more and costs more than it saves)
+        const bool near = (rec[(lane >> 5) + 8 + kAhead] >> (lane & 31)) & 1;
+        const int tk = __builtin_amdgcn_readfirstlane(rec[3]), t = tk >> 8, K = tk & 255;
+        const int rows = __builtin_amdgcn_readfirstlane(rec[7]);
+        uint32_t A[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, Ah[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        digest_words<kAhead, 0>(w, shift, A);
+        if (K > kAhead) {                                                    // wave-uniform, rare for patch-sorted points
+            late_groups<kAhead / 4, 0>(rsrc, lane_off, mb[t].tv, K, shift, A);
+            if (K > 16) late_groups<0, 16>(rsrc, lane_off, mb[t].tv, K, shift, Ah);
         }
-        todo = __builtin_amdgcn_ballot_w64(cand);
-    }
-    while (todo) {
-        const int t = t0 + kWaves * (int)__builtin_ctzll(todo);
-        todo &= todo - 1;
-        const TileMeta* mt = mb + t;
-        const float ex = fmaxf(fmaxf(mt->lo[0] - px, px - mt->hi[0]), 0.0f);
-        const float ey = fmaxf(fmaxf(mt->lo[1] - py, py - mt->hi[1]), 0.0f);
-        const float ez = fmaxf(fmaxf(mt->lo[2] - pz, pz - mt->hi[2]), 0.0f);
-        const float lb = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) * kSlack;
-        const bool near = lb <= bnd;
-        if (__builtin_amdgcn_ballot_w64(near) == 0) continue;
-        const int K = mt->runs, rows = mt->rows;
-        uint32_t R[16] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
         uint32_t any = 0u;
-        build(mt->tv, K, R, any);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) { any |= A[m]; A[m] = ~A[m] & kPenaltyPair; }
+        if (K > 16) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) { any |= Ah[m]; Ah[m] = ~Ah[m] & kPenaltyPair; }
+        }
         // a column that is near but has no admissible row here does not make the tile worth a product
-        if (__builtin_amdgcn_ballot_w64(near && any != 0u) == 0) continue;
-        const int slot = t * kTile + j;
-        const int rc = min(slot, n - 1);
-        const float qx = bp[3 * rc], qy = bp[3 * rc + 1], qz = bp[3 * rc + 2];
-        const int ridx = mt->ridx[j];
+        if (__builtin_amdgcn_ballot_w64(near && any != 0u) == 0) return;
         f32x16 acc[2];
-        product(qx, qy, qz, j < rows, ridx, R, K > 16, acc);
+        product(qx, qy, qz, j < rows, ridx, A, acc);
+        if (K > 16) product_high(ridx, Ah, acc);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             int key[16];
@@ -329,13 +374,71 @@ __global__ __launch_bounds__(64 * kWaves) void hd_search_kernel(
             btile[s] = better ? t : btile[s];
         }
         // the own columns' bounds: smaller of the two halves' keys
+        uint32_t k0 = (uint32_t)bestkey[0], k1 = (uint32_t)bestkey[1];
+        swap_halves(k0, k1);
+        const float f = __int_as_float(min((int)k0, (int)k1) & ~15);
+        bnd = fminf(bnd, (f - own_o) + 4e-6f * (f + R2));
+    };
+    for (int t0 = wave; t0 < tiles; t0 += 64 * kWaves) {
+        int nc;
         {
-            uint32_t k0 = (uint32_t)bestkey[0], k1 = (uint32_t)bestkey[1];
-            swap_halves(k0, k1);
-            const float f = __int_as_float(min((int)k0, (int)k1) & ~15);
-            bnd = fminf(bnd, (f - own_o) + 4e-6f * (f + R2));
+            float bmax = bnd;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, m));
+            const int tl = t0 + kWaves * lane;
+            bool cand = false;
+            float4 l4 = make_float4(0.f, 0.f, 0.f, 0.f), h4 = l4;
+            if (tl < tiles) {
+                l4 = *reinterpret_cast<const float4*>(mb[tl].lo);
+                h4 = *reinterpret_cast<const float4*>(mb[tl].hi);
+                const float gx = fmaxf(fmaxf(l4.x - hi[0], lo[0] - h4.x), 0.0f);
+                const float gy = fmaxf(fmaxf(l4.y - hi[1], lo[1] - h4.y), 0.0f);
+                const float gz = fmaxf(fmaxf(l4.z - hi[2], lo[2] - h4.z), 0.0f);
+                cand = __builtin_fmaf(gz, gz, __builtin_fmaf(gy, gy, gx * gx)) * kSlack <= bmax;
+            }
+            // the survivors against every column's own bound (tile boxes from the lanes that hold them): mask words and
+            // rows are requested only for tiles some column can reach
+            unsigned long long m = 0ull, my_reach = 0ull;
+            for (unsigned long long todo = __builtin_amdgcn_ballot_w64(cand); todo; todo &= todo - 1ull) {
+                const int pos = (int)__builtin_ctzll(todo);
+                auto pick = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), pos)); };
+                const float ex = fmaxf(fmaxf(pick(l4.x) - px, px - pick(h4.x)), 0.0f);
+                const float ey = fmaxf(fmaxf(pick(l4.y) - py, py - pick(h4.y)), 0.0f);
+                const float ez = fmaxf(fmaxf(pick(l4.z) - pz, pz - pick(h4.z)), 0.0f);
+                const unsigned long long reach =
+                    __builtin_amdgcn_ballot_w64(__builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) * kSlack <= bnd);
+                if (reach) m |= 1ull << pos;
+                if (lane == pos) my_reach = reach;
+            }
+            cand = (m >> lane) & 1ull;
+            nc = __builtin_popcountll(m);
+            if (cand) {
+                int* rec = s_rec[wave][__builtin_popcountll(m & ((1ull << lane) - 1ull))];
+                rec[0] = __float_as_int(l4.x); rec[1] = __float_as_int(l4.y); rec[2] = __float_as_int(l4.z);
+                rec[3] = (tl << 8) | __float_as_int(l4.w);
+                rec[4] = __float_as_int(h4.x); rec[5] = __float_as_int(h4.y); rec[6] = __float_as_int(h4.z);
+                rec[7] = __float_as_int(h4.w);
+                rec[8 + kAhead] = (int)(uint32_t)my_reach; rec[9 + kAhead] = (int)(uint32_t)(my_reach >> 32);
+#pragma unroll
+                for (int g = 0; g < kAhead / 4; ++g) {
+                    const int4 tv = *reinterpret_cast<const int4*>(mb[tl].tv + 4 * g);
+                    rec[8 + 4 * g] = tv.x; rec[9 + 4 * g] = tv.y; rec[10 + 4 * g] = tv.z; rec[11 + 4 * g] = tv.w;
+                }
+            }
         }
-    }
+        if (nc == 0) continue;
+        int wA[kAhead], wB[kAhead], rA = 0, rB = 0;
+        float qA[3] = {0.f, 0.f, 0.f}, qB[3] = {0.f, 0.f, 0.f};
+        request_tile(0, wA, qA[0], qA[1], qA[2], rA);
+        for (int i = 0; i < nc; i += 2) {
+            // tile i lives in A; tile i + 1 is requested into B before A is worked on, and the other way round.  The
+            // requests are unconditional (behind the last tile: the last tile again): with the same number of loads in
+            // flight on every path the compiler can wait for exactly the older set
+            request_tile(min(i + 1, nc - 1), wB, qB[0], qB[1], qB[2], rB);
+            tile_step(i, wA, qA[0], qA[1], qA[2], rA);
+            request_tile(min(i + 2, nc - 1), wA, qA[0], qA[1], qA[2], rA);
+            if (i + 1 < nc) tile_step(i + 1, wB, qB[0], qB[1], qB[2], rB);
+        }
     }
     // ---- the candidates' distances by direct differences, lexicographic (distance, row) minimum per column -----------
 #pragma unroll
