@@ -34,6 +34,7 @@ struct tuch_hd_model {
     int32_t* tv;         // [N] template vertex = first vertex of that face (loss.py:88 geovec_verts)
     int32_t* mask_id;    // [N] row / column of the geodesic mask the point inherits: tv, or its position in tree order
     int32_t* orig;       // [N] index of the point in the caller's order
+    int32_t* by_orig;    // [N] inverse: where the caller's point r sits in the sorted order
     int32_t* v_off;      // [V+1] CSR: vertex -> entries (point * 4 + corner)
     int32_t* v_ent;
     int32_t* offsets;    // [kMaxBatch+1] = b * N (device): where body b's slots start
@@ -63,16 +64,14 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // ---- selection (loss.py:278-281) -------------------------------------------------------------------------------
 // candidate vertices -> face flags; then the selected HD points of every body compacted in their order: chunks of
-// kSel points are counted, the chunk counts prefix-summed by every chunk for itself (at most ~40 of them), and the
-// points scattered to their slots
+// kSel points are counted, the chunk counts prefix-summed by every chunk for itself (one wavefront, a count per lane), and
+// the points scattered to their slots
 __global__ __launch_bounds__(256) void hd_face_flags_kernel(
     const uint8_t* __restrict__ exterior, const float* __restrict__ min_d2, const uint8_t* __restrict__ valid,
-    const int32_t* __restrict__ faces, int V, int F, float eucl2, uint8_t* __restrict__ face_flag,
-    unsigned long long* __restrict__ first_key)
+    const int32_t* __restrict__ faces, int V, int F, float eucl2, uint8_t* __restrict__ face_flag)
 {
     const int b = blockIdx.y;
     const int f = blockIdx.x * 256 + threadIdx.x;
-    if (f == 0) first_key[b] = ~0ull;
     if (f >= F) return;
     bool any = false;
     if (!valid || valid[b]) {
@@ -87,70 +86,70 @@ __global__ __launch_bounds__(256) void hd_face_flags_kernel(
     face_flag[(size_t)b * F + f] = any;
 }
 
+// per chunk of kSel points: how many are selected (points in the sorted order), and the first selected point of the
+// chunk in the CALLER's order (the same index range read as caller indices): what torch.min reports for an all-inf column
+// is the first selected point in the caller's order = the first hit of the first chunk that has one
 __global__ __launch_bounds__(kSel) void hd_count_kernel(
-    const uint8_t* __restrict__ face_flag, const int32_t* __restrict__ hd_face, int F, int N, int chunks,
-    int32_t* __restrict__ chunk_cnt)
+    const uint8_t* __restrict__ face_flag, const int32_t* __restrict__ hd_face, const int32_t* __restrict__ by_orig, int F, int N,
+    int chunks, int32_t* __restrict__ chunk_cnt, int32_t* __restrict__ chunk_first)
 {
-    __shared__ int wave_sum[kSel / 64];
+    __shared__ int wave_sum[kSel / 64], wave_first[kSel / 64];
     const int b = blockIdx.y, c = blockIdx.x, n = c * kSel + threadIdx.x;
-    const bool take = n < N && face_flag[(size_t)b * F + hd_face[n]];               // :281
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(take);
-    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = __builtin_popcountll(m);
+    const uint8_t* fb = face_flag + (size_t)b * F;
+    const bool take = n < N && fb[hd_face[n]];                                       // :281
+    const bool take_r = n < N && fb[hd_face[by_orig[n]]];
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(take), mr = __builtin_amdgcn_ballot_w64(take_r);
+    if ((threadIdx.x & 63) == 0) {
+        wave_sum[threadIdx.x >> 6] = __builtin_popcountll(m);
+        wave_first[threadIdx.x >> 6] = mr ? n + (int)__builtin_ctzll(mr) : 0x7fffffff;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int t = 0;
+        int t = 0, first = 0x7fffffff;
 #pragma unroll
-        for (int k = 0; k < kSel / 64; ++k) t += wave_sum[k];
+        for (int k = 0; k < kSel / 64; ++k) { t += wave_sum[k]; first = min(first, wave_first[k]); }
         chunk_cnt[(size_t)b * chunks + c] = t;
+        chunk_first[(size_t)b * chunks + c] = first;
     }
 }
 
 __global__ __launch_bounds__(kSel) void hd_scatter_kernel(
-    const uint8_t* __restrict__ face_flag, const int32_t* __restrict__ hd_face, const int32_t* __restrict__ hd_orig,
-    const int32_t* __restrict__ chunk_cnt, int F, int N, int chunks, int32_t* __restrict__ sel, int32_t* __restrict__ slot,
-    int32_t* __restrict__ counts, unsigned long long* __restrict__ first_key)
+    const uint8_t* __restrict__ face_flag, const int32_t* __restrict__ hd_face, const int32_t* __restrict__ chunk_cnt, int F, int N,
+    int chunks, int32_t* __restrict__ sel, int32_t* __restrict__ slot, int32_t* __restrict__ counts)
 {
     __shared__ int wave_sum[kSel / 64];
+    __shared__ int s_base, s_total;
     const int b = blockIdx.y, c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = c * kSel + tid;
-    int base = 0, total = 0;
-    for (int k = 0; k < chunks; ++k) {                 // wave-uniform, <= ~40 scalar loads
-        const int t = chunk_cnt[(size_t)b * chunks + k];
-        base += k < c ? t : 0;
-        total += t;
+    // the chunk counts before this chunk and in all: one wavefront, a count per lane (a loop of dependent scalar loads
+    // over the ~40 chunks, and one 64-bit atomic per chunk on ONE address per body for the first selected point, were
+    // what this kernel spent its 35 us on)
+    if (wave == 0) {
+        int before = 0, all = 0;
+        for (int k0 = 0; k0 < chunks; k0 += 64) {
+            const int k = k0 + lane;
+            const int t = k < chunks ? chunk_cnt[(size_t)b * chunks + k] : 0;
+            before += k < c ? t : 0;
+            all += t;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { before += __shfl_xor(before, o); all += __shfl_xor(all, o); }
+        if (lane == 0) { s_base = before; s_total = all; }
     }
     const bool take = n < N && face_flag[(size_t)b * F + hd_face[n]];
     const unsigned long long m = __builtin_amdgcn_ballot_w64(take);
     const int before = __builtin_popcountll(m & ((1ull << lane) - 1ull));
     if (lane == 0) wave_sum[wave] = __builtin_popcountll(m);
     __syncthreads();
-    int wbase = 0;
+    int wbase = s_base;
 #pragma unroll
     for (int k = 0; k < kSel / 64; ++k) wbase += k < wave ? wave_sum[k] : 0;
-    // the selected point that comes first in the CALLER's order: what torch.min reports for an all-inf column
-    unsigned long long key = ~0ull;
     if (n < N) {
-        const int s = take ? base + wbase + before : -1;
+        const int s = take ? wbase + before : -1;
         slot[(size_t)b * N + n] = s;
-        if (take) {
-            sel[(size_t)b * N + s] = n;
-            key = ((unsigned long long)(uint32_t)hd_orig[n] << 32) | (uint32_t)s;
-        }
+        if (take) sel[(size_t)b * N + s] = n;
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        const unsigned long long other = __shfl_xor(key, o);
-        key = other < key ? other : key;
-    }
-    __shared__ unsigned long long wave_key[kSel / 64];
-    if (lane == 0) wave_key[wave] = key;
-    __syncthreads();
-    if (tid == 0) {
-#pragma unroll
-        for (int k = 1; k < kSel / 64; ++k) key = wave_key[k] < key ? wave_key[k] : key;
-        if (key != ~0ull) atomicMin(first_key + b, key);          // one atomic per chunk
-        if (c == 0) counts[b] = total;
-    }
+    if (tid == 0 && c == 0) counts[b] = s_total;
 }
 
 // ---- positions (loss.py:285, :295-296) ---------------------------------------------------------------------------
@@ -158,12 +157,19 @@ __global__ __launch_bounds__(256) void hd_points_kernel(
     const float* __restrict__ verts, const int32_t* __restrict__ sel, const int32_t* __restrict__ counts,
     const int32_t* __restrict__ idx, const float* __restrict__ w, const int32_t* __restrict__ hd_face,
     const int32_t* __restrict__ faces, const int32_t* __restrict__ mask_id, int V, int N,
-    const unsigned long long* __restrict__ first_key, int32_t* __restrict__ first_slot,
-    float* __restrict__ pts, float* __restrict__ offs, int32_t* __restrict__ vid)
+    const int32_t* __restrict__ chunk_first, const int32_t* __restrict__ by_orig, const int32_t* __restrict__ slot, int chunks,
+    int32_t* __restrict__ first_slot, float* __restrict__ pts, float* __restrict__ offs, int32_t* __restrict__ vid)
 {
     const int b = blockIdx.y;
     const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k == 0) first_slot[b] = counts[b] > 0 ? (int32_t)(first_key[b] & 0xffffffffu) : 0;
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        // the selected point that comes first in the caller's order: smallest first hit over the chunks
+        int first = 0x7fffffff;
+        for (int c = threadIdx.x; c < chunks; c += 64) first = min(first, chunk_first[(size_t)b * chunks + c]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) first = min(first, __shfl_xor(first, o));
+        if (threadIdx.x == 0) first_slot[b] = first < N ? slot[(size_t)b * N + by_orig[first]] : 0;
+    }
     if (k >= counts[b]) return;
     const size_t o = (size_t)b * N + k;
     const int n = sel[o];
@@ -229,40 +235,75 @@ __global__ __launch_bounds__(1024) void hd_terms_kernel(
     }
 }
 
-// gradient on the points: the point's own side is a plain store (Gown), the partner's side is scattered with atomics
-// (G pre-zeroed); the vertex gather adds the two
-__global__ __launch_bounds__(256) void hd_grad_points_kernel(
+// gradient on the points, G[b][k] = own side + what the points that picked k as their partner send it.  A workgroup owns
+// kGradSpan consecutive points of one body and keeps their sums in LDS: it walks ALL the body's points (four per thread and
+// trip, their loads requested together), takes those whose partner lies in its span (the partner's side of the term: LDS
+// atomics) and those in the span themselves (own side).  Nothing is added up in global memory.  (Before: float atomics on
+// a zeroed [B,N,3] array -- device-scope atomics on this part are resolved behind the per-XCD L2s, 1 M of them took 82 us.)
+constexpr int kGradSpan = 1024;
+constexpr int kGradBlock = 1024;
+__global__ __launch_bounds__(kGradBlock) void hd_grad_points_kernel(
     const float* __restrict__ pts, const int32_t* __restrict__ partner, const uint8_t* __restrict__ ext,
-    const int32_t* __restrict__ counts, const float* __restrict__ gscale, int N, float* __restrict__ G,
-    float* __restrict__ Gown)
+    const int32_t* __restrict__ counts, const float* __restrict__ gscale, int N, float* __restrict__ G)
 {
-    const int b = blockIdx.y;
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= counts[b]) return;
-    const size_t o = (size_t)b * N + k;
-    const bool e = ext[o] != 0;
-    const float g = gscale[2 * b + (e ? 1 : 0)];
-    float ox = 0.0f, oy = 0.0f, oz = 0.0f;
-    if (g != 0.0f) {
-        const float* pb = pts + (size_t)b * N * 3;
-        const int p = partner[o];
-        const float dx = pb[3 * k] - pb[3 * p], dy = pb[3 * k + 1] - pb[3 * p + 1], dz = pb[3 * k + 2] - pb[3 * p + 2];
-        const float d = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
-        if (d > 0.0f) {                               // torch.norm's backward at 0 is 0
-            const Term t = contact_term(d, e);
-            const float c = g * t.dd / d;
-            ox = c * dx; oy = c * dy; oz = c * dz;
-            float* gp = G + 3 * ((size_t)b * N + p);
-            atomicAdd(gp, -ox); atomicAdd(gp + 1, -oy); atomicAdd(gp + 2, -oz);
+    __shared__ float acc[3 * kGradSpan];
+    const int b = blockIdx.y, n = counts[b];
+    const int lo = blockIdx.x * kGradSpan;
+    if (lo >= n) return;
+    const int hi = min(n, lo + kGradSpan);
+    for (int i = threadIdx.x; i < 3 * kGradSpan; i += kGradBlock) acc[i] = 0.0f;
+    __syncthreads();
+    const float* pb = pts + (size_t)b * N * 3;
+    const int32_t* qb = partner + (size_t)b * N;
+    const uint8_t* eb = ext + (size_t)b * N;
+    const float g_in = gscale[2 * b], g_ex = gscale[2 * b + 1];
+    constexpr int kU = 2;
+    for (int k0 = threadIdx.x; k0 < n; k0 += kU * kGradBlock) {
+        int k[kU], p[kU];
+        bool e[kU], use[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            k[u] = k0 + u * kGradBlock;
+            const bool in = k[u] < n;
+            p[u] = in ? qb[k[u]] : 0;
+            e[u] = in ? eb[k[u]] != 0 : false;
+            use[u] = in;
+        }
+        float a[kU][3], c[kU][3];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            use[u] = use[u] && ((k[u] >= lo && k[u] < hi) || (p[u] >= lo && p[u] < hi));
+            const int ku = use[u] ? k[u] : 0, pu = use[u] ? p[u] : 0;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { a[u][d] = pb[3 * ku + d]; c[u][d] = pb[3 * pu + d]; }
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const float g = e[u] ? g_ex : g_in;
+            const float dx = a[u][0] - c[u][0], dy = a[u][1] - c[u][1], dz = a[u][2] - c[u][2];
+            const float d = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
+            if (!use[u] || g == 0.0f || !(d > 0.0f)) continue;   // torch.norm's backward at 0 is 0
+            const Term t = contact_term(d, e[u]);
+            const float s = g * t.dd / d;
+            const float ox = s * dx, oy = s * dy, oz = s * dz;
+            if (k[u] >= lo && k[u] < hi) {
+                float* o = acc + 3 * (k[u] - lo);
+                atomicAdd(o, ox); atomicAdd(o + 1, oy); atomicAdd(o + 2, oz);
+            }
+            if (p[u] >= lo && p[u] < hi) {
+                float* o = acc + 3 * (p[u] - lo);
+                atomicAdd(o, -ox); atomicAdd(o + 1, -oy); atomicAdd(o + 2, -oz);
+            }
         }
     }
-    float* gk = Gown + 3 * o;
-    gk[0] = ox; gk[1] = oy; gk[2] = oz;
+    __syncthreads();
+    float* gb = G + 3 * ((size_t)b * N + lo);
+    for (int i = threadIdx.x; i < 3 * (hi - lo); i += kGradBlock) gb[i] = acc[i];
 }
 
 // adjoint of the regressor rows: a gather per vertex over the points it supports
 __global__ __launch_bounds__(256) void hd_grad_verts_kernel(
-    const float* __restrict__ G, const float* __restrict__ Gown, const int32_t* __restrict__ slot,
+    const float* __restrict__ G, const int32_t* __restrict__ slot,
     const int32_t* __restrict__ v_off, const int32_t* __restrict__ v_ent, const float* __restrict__ w, int V, int N,
     float* __restrict__ grad_verts)
 {
@@ -272,14 +313,12 @@ __global__ __launch_bounds__(256) void hd_grad_verts_kernel(
     const int e0 = real ? v_off[v] : 0, e1 = real ? v_off[v + 1] : 0;
     const int32_t* sb = slot + (size_t)b * N;
     const float* gb = G + 3 * (size_t)b * N;
-    const float* go = Gown + 3 * (size_t)b * N;
     float x = 0.f, y = 0.f, z = 0.f;
     auto add = [&](int ent, int s) {                 // entry = point * 4 + corner; s = the point's slot in this body
         if (s < 0) return;
         const float wc = w[3 * (size_t)(ent >> 2) + (ent & 3)];
         const float* g = gb + 3 * (size_t)s;
-        const float* o = go + 3 * (size_t)s;
-        x = __builtin_fmaf(wc, g[0] + o[0], x); y = __builtin_fmaf(wc, g[1] + o[1], y); z = __builtin_fmaf(wc, g[2] + o[2], z);
+        x = __builtin_fmaf(wc, g[0], x); y = __builtin_fmaf(wc, g[1], y); z = __builtin_fmaf(wc, g[2], z);
     };
     constexpr int kLong = 64;
     if (e1 - e0 <= kLong) {
@@ -309,8 +348,7 @@ __global__ __launch_bounds__(256) void hd_grad_verts_kernel(
             if (s < 0) continue;
             const float wc = w[3 * (size_t)(ent >> 2) + (ent & 3)];
             const float* g = gb + 3 * (size_t)s;
-            const float* o = go + 3 * (size_t)s;
-            px = __builtin_fmaf(wc, g[0] + o[0], px); py = __builtin_fmaf(wc, g[1] + o[1], py); pz = __builtin_fmaf(wc, g[2] + o[2], pz);
+            px = __builtin_fmaf(wc, g[0], px); py = __builtin_fmaf(wc, g[1], py); pz = __builtin_fmaf(wc, g[2], pz);
         }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) { px += __shfl_xor(px, m); py += __shfl_xor(py, m); pz += __shfl_xor(pz, m); }
@@ -337,18 +375,17 @@ Saved saved_layout(int B, int N)
     return l;
 }
 
-struct Grad { size_t partner_side, own_side, total; };
+struct Grad { size_t points, total; };
 Grad grad_layout(int B, int N)
 {
     Grad l;
     size_t o = 0;
-    l.partner_side = tuch_ws_take(o, (size_t)B * N * 3 * sizeof(float));
-    l.own_side = tuch_ws_take(o, (size_t)B * N * 3 * sizeof(float));
+    l.points = tuch_ws_take(o, (size_t)B * N * 3 * sizeof(float));
     l.total = o;
     return l;
 }
 
-struct Work { size_t offs, vid, min_d2, flags, chunk_cnt, first_key, search, winding, winding_bytes, total; };
+struct Work { size_t offs, vid, min_d2, flags, chunk_cnt, chunk_first, search, winding, winding_bytes, total; };
 Work work_layout(const tuch_hd_model* hm, int B)
 {
     Work l;
@@ -359,7 +396,7 @@ Work work_layout(const tuch_hd_model* hm, int B)
     l.min_d2 = tuch_ws_take(o, (size_t)B * N * sizeof(float));
     l.flags = tuch_ws_take(o, (size_t)B * hm->F);
     l.chunk_cnt = tuch_ws_take(o, (size_t)B * ceil_div(N, kSel) * sizeof(int32_t));
-    l.first_key = tuch_ws_take(o, (size_t)B * sizeof(unsigned long long));
+    l.chunk_first = tuch_ws_take(o, (size_t)B * ceil_div(N, kSel) * sizeof(int32_t));
     size_t search_bytes, winding_bytes;
     { tuch_ws_pause nested; search_bytes = std::max(tuch_v2v_min_indexed_workspace_bytes(B, N), tuch_hd_search_workspace_bytes(B, N)); winding_bytes = tuch_winding_points_workspace_bytes(hm->cm, B, N); }
     l.search = tuch_ws_take(o, search_bytes);
@@ -374,7 +411,7 @@ Work work_layout(const tuch_hd_model* hm, int B)
 extern "C" void tuch_hd_model_destroy(tuch_hd_model* hm)
 {
     if (!hm) return;
-    void* dev[] = {hm->idx, hm->w, hm->face, hm->tv, hm->mask_id, hm->orig, hm->v_off, hm->v_ent, hm->offsets};
+    void* dev[] = {hm->idx, hm->w, hm->face, hm->tv, hm->mask_id, hm->orig, hm->by_orig, hm->v_off, hm->v_ent, hm->offsets};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     delete hm->order_host;
@@ -450,6 +487,11 @@ extern "C" int tuch_hd_model_create(tuch_hd_model** out, const tuch_contact_mode
     if (rc == TUCH_OK) rc = upload(&hm->tv, tv.data(), tv.size());
     if (rc == TUCH_OK) rc = upload(&hm->mask_id, mask_id.data(), mask_id.size());
     if (rc == TUCH_OK) rc = upload(&hm->orig, order.data(), order.size());
+    if (rc == TUCH_OK) {
+        std::vector<int32_t> inverse(N);
+        for (int k = 0; k < N; ++k) inverse[order[k]] = k;
+        rc = upload(&hm->by_orig, inverse.data(), inverse.size());
+    }
     if (rc == TUCH_OK) rc = upload(&hm->v_off, v_off.data(), v_off.size());
     if (rc == TUCH_OK) rc = upload(&hm->v_ent, v_ent.data(), v_ent.size());
     if (rc == TUCH_OK) rc = upload(&hm->offsets, offsets.data(), offsets.size());
@@ -482,7 +524,7 @@ extern "C" size_t tuch_hd_contact_workspace_bytes(const tuch_hd_model* hm, int B
     if (!hm || B <= 0) return 0;
     tuch_ws_scope scope(hm->cm->opt.canary != 0);
     const size_t f = work_layout(hm, B).total;
-    const size_t g = grad_layout(B, hm->N).total;       // adjoint: point gradients, own + partner side
+    const size_t g = grad_layout(B, hm->N).total;       // adjoint: point gradients
     return f > g ? f : g;
 }
 
@@ -521,20 +563,20 @@ extern "C" int tuch_hd_contact_fwd(const tuch_hd_model* hm, const float* verts, 
     int32_t* vid = (int32_t*)(ws + wl.vid);
     uint8_t* flags = (uint8_t*)(ws + wl.flags);
     int32_t* chunk_cnt = (int32_t*)(ws + wl.chunk_cnt);
-    unsigned long long* first_key = (unsigned long long*)(ws + wl.first_key);
+    int32_t* chunk_first = (int32_t*)(ws + wl.chunk_first);
     const int chunks = ceil_div(N, kSel);
     const uint64_t* bits = hm->tree_order ? hm->cm->tree_mask_bits : hm->cm->mask_bits;
     hipLaunchKernelGGL(hd_face_flags_kernel, dim3(ceil_div(hm->F, 256), B), dim3(256), 0, s, exterior, min_d2, valid,
-                       (const int32_t*)hm->cm->faces, V, hm->F, euclthres * euclthres, flags, first_key);
+                       (const int32_t*)hm->cm->faces, V, hm->F, euclthres * euclthres, flags);
     hipLaunchKernelGGL(hd_count_kernel, dim3(chunks, B), dim3(kSel), 0, s, (const uint8_t*)flags, (const int32_t*)hm->face,
-                       hm->F, N, chunks, chunk_cnt);
+                       (const int32_t*)hm->by_orig, hm->F, N, chunks, chunk_cnt, chunk_first);
     hipLaunchKernelGGL(hd_scatter_kernel, dim3(chunks, B), dim3(kSel), 0, s, (const uint8_t*)flags, (const int32_t*)hm->face,
-                       (const int32_t*)hm->orig, (const int32_t*)chunk_cnt, hm->F, N, chunks, sel, slot, counts, first_key);
+                       (const int32_t*)chunk_cnt, hm->F, N, chunks, sel, slot, counts);
     const dim3 pgrid(ceil_div(N, 256), B);
     hipLaunchKernelGGL(hd_points_kernel, pgrid, dim3(256), 0, s, verts, (const int32_t*)sel, (const int32_t*)counts,
                        (const int32_t*)hm->idx, (const float*)hm->w, (const int32_t*)hm->face,
-                       (const int32_t*)hm->cm->faces, (const int32_t*)hm->mask_id, V, N,
-                       (const unsigned long long*)first_key, first, pts, offs, vid);
+                       (const int32_t*)hm->cm->faces, (const int32_t*)hm->mask_id, V, N, (const int32_t*)chunk_first,
+                       (const int32_t*)hm->by_orig, (const int32_t*)slot, chunks, first, pts, offs, vid);
     // (seeding the search from the vertex-level partners was tried: the seeds are excellent where they exist -- median
     // ratio to the final distance 1.00 -- but the nearest admissible HD point is ~10 cm away, so a column block still has
     // to visit ~40 % of the rows, and building the seeds cost more than the sampling pass they replace)
@@ -562,7 +604,6 @@ extern "C" int tuch_hd_contact_bwd(const tuch_hd_model* hm, const void* saved, c
     tuch_ws_scope scope(hm->cm->opt.canary != 0);
     const Saved sl = saved_layout(B, N);
     const Grad gl = scope.record(0, [&] { return grad_layout(B, N); });
-    const size_t gbytes = (size_t)B * N * 3 * sizeof(float);
     if (workspace_bytes < gl.total) {
         tuch_set_error("tuch_hd_contact_bwd: workspace %zu < %zu bytes", workspace_bytes, gl.total);
         return TUCH_ERR_WORKSPACE;
@@ -570,16 +611,11 @@ extern "C" int tuch_hd_contact_bwd(const tuch_hd_model* hm, const void* saved, c
     hipStream_t s = (hipStream_t)stream;
     scope.arm(workspace, hm->cm->canary_hits, s);
     const char* sv = (const char*)saved;
-    float* G = (float*)((char*)workspace + gl.partner_side);
-    float* Gown = (float*)((char*)workspace + gl.own_side);
-    if (hipMemsetAsync(G, 0, gbytes, s) != hipSuccess) {
-        tuch_set_error("tuch_hd_contact_bwd: hipMemsetAsync failed");
-        return TUCH_ERR_HIP;
-    }
-    hipLaunchKernelGGL(hd_grad_points_kernel, dim3(ceil_div(N, 256), B), dim3(256), 0, s, (const float*)(sv + sl.pts),
+    float* G = (float*)((char*)workspace + gl.points);
+    hipLaunchKernelGGL(hd_grad_points_kernel, dim3(ceil_div(N, kGradSpan), B), dim3(kGradBlock), 0, s, (const float*)(sv + sl.pts),
                        (const int32_t*)(sv + sl.partner), (const uint8_t*)(sv + sl.ext), (const int32_t*)(sv + sl.counts),
-                       grad_terms, N, G, Gown);
-    hipLaunchKernelGGL(hd_grad_verts_kernel, dim3(ceil_div(V, 256), B), dim3(256), 0, s, (const float*)G, (const float*)Gown,
+                       grad_terms, N, G);
+    hipLaunchKernelGGL(hd_grad_verts_kernel, dim3(ceil_div(V, 256), B), dim3(256), 0, s, (const float*)G,
                        (const int32_t*)(sv + sl.slot), (const int32_t*)hm->v_off, (const int32_t*)hm->v_ent,
                        (const float*)hm->w, V, N, grad_verts);
     return tuch_check_launch("tuch_hd_contact_bwd");
