@@ -347,6 +347,15 @@ int tuch_smpl_backward_split(const tuch_smpl_model* model, const float* global_o
                              const void* fwd_workspace, const float* g_verts, const float* g_joints, float* g_betas,
                              float* g_global_orient, int g_global_orient_stride, float* g_body_pose,
                              int g_body_pose_stride, void* workspace, size_t workspace_bytes, void* stream);
+/* The same with a gradient the caller already holds for body_pose (g_body_pose_add: same shape, row stride in floats; or
+ * NULL): g_body_pose = this call's gradient + that one.  In SMPLify-DC body_pose feeds the body model and the pose prior
+ * (tuch/smplify/losses.py:63): autograd would add the two gradients in a separate launch. */
+int tuch_smpl_backward_split_add(const tuch_smpl_model* model, const float* global_orient, int global_orient_stride,
+                                 const float* body_pose, int body_pose_stride, int pose2rot, int B,
+                                 const void* fwd_workspace, const float* g_verts, const float* g_joints, float* g_betas,
+                                 float* g_global_orient, int g_global_orient_stride, float* g_body_pose,
+                                 int g_body_pose_stride, const float* g_body_pose_add, int g_body_pose_add_stride,
+                                 void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- caller-side glue of the training step ----------------------------------------
  * tuch_estimate_translation: tuch/utils/geometry.py:114-205 (estimate_translation + estimate_translation_np):

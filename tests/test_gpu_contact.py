@@ -600,6 +600,29 @@ def test_v2v_tree_walk_matches_flat_search(tag, batch, monkeypatch):
     # repeatable despite the atomics
     mn_again, arg_again = model.v2v_min(verts)
     assert torch.equal(mn_again, mn_t) and torch.equal(arg_again, arg_t)
+    # leaf_form 3: a leaf's rows on the matrix cores (v2v_mfma_kernel).  Its rows are candidates found through a 20-bit
+    # key of the distance in coordinates relative to the column block; the reported distance is the candidate's
+    # direct-difference distance: never below the exact minimum, above it only between rows that tie within the key
+    for waves in (1, 4096, 1000000):
+        model.set_option('v2v_waves', waves)
+        model.set_option('v2v_flat', 3)
+        mn_m, arg_m = model.v2v_min(verts)
+        fin = torch.isfinite(mn_f)
+        assert torch.equal(torch.isfinite(mn_m), fin)
+        excess = (mn_m.double() - mn_f.double())[fin]
+        assert float(excess.min()) >= 0.0
+        assert bool((excess <= 2e-6 * mn_f.double()[fin] + 2e-8).all()), float(excess.max())
+        bb, ii = fin.nonzero(as_tuple=True)
+        assert gm[arg_m[bb, ii].cpu().numpy(), ii.cpu().numpy()].all()
+        v = verts.double()
+        d_m = ((v[bb, ii] - v[bb, arg_m[bb, ii].long()]) ** 2).sum(-1)
+        assert bool(((d_m - mn_m.double()[fin]).abs() <= 3e-7 * d_m + 1e-12).all())
+        report('v2v matrix-core form [%s, batch %d, waves %d]: partners != exact search (ties within the key), worst excess %.1e'
+               % (tag, batch, waves, float(excess.max())), int((arg_m != arg_f)[fin].sum()), int(fin.sum()))
+        mn_again, arg_again = model.v2v_min(verts)
+        assert torch.equal(mn_again, mn_m) and torch.equal(arg_again, arg_m)
+    model.set_option('v2v_flat', 2)
+    model.set_option('v2v_waves', 0)
 
 
 @pytest.mark.parametrize('tag', ['medium', 'ico_medium', 'full', 'ico_full'])

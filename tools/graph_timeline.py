@@ -1,4 +1,4 @@
-"""Timeline of ONE replayed stage-2 step: python tools/graph_timeline.py run [batch]  -> runs warm-up + a few graph replays;
+"""Timeline of ONE replayed stage-2 step: python tools/graph_timeline.py run [batch | hd]  -> runs warm-up + a few graph replays;
 python tools/graph_timeline.py show <results.db>  -> per-kernel start offset / duration of the last replay, the idle gaps
 and how much of the step has 1 / 2 kernels in flight.   (rocprofv3 --kernel-trace -d DIR -o kt -- python tools/graph_timeline.py run)"""
 import os, sys
@@ -9,6 +9,13 @@ def run():
     import torch, bench
     dev = torch.device('cuda:0')
     torch.cuda.set_stream(torch.cuda.Stream(dev))
+    if len(sys.argv) > 2 and sys.argv[2] == 'hd':            # the train.py-style HD contact step, eager launches
+        p = bench.build_problem(64, dev, 1002)
+        fn = bench.make_train_step(p, True)
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        return
     p = bench.build_problem(int(sys.argv[2]) if len(sys.argv) > 2 else 64, dev, 1002)
     fn = bench.capture(bench.make_step(p), 3)
     for _ in range(5):

@@ -129,6 +129,9 @@ _SIGNATURES = {
     'tuch_smpl_backward_split': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t,
                                          c_void_p]),
+    'tuch_smpl_backward_split_add': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                             c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                             c_size_t, c_void_p]),
     'tuch_region_pair_min_bwd': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 

@@ -18,9 +18,9 @@ LIB = os.path.join(HERE, 'libtuch_amd.so')
 ARCH = 'gfx950'
 
 
-# per-file flags.  hd_search.hip: matrix-core results in ordinary vector registers (its accumulators are read by the
-# vector unit at once: as AGPRs every value costs a v_accvgpr_read)
-EXTRA_FLAGS = {'hd_search.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'] + os.environ.get('TUCH_HDS_FLAGS', '').split()}
+# per-file flags.  hd_search.hip, v2v.hip: matrix-core results in ordinary vector registers (the accumulators are read by
+# the vector unit at once: as AGPRs every value costs a v_accvgpr_read)
+EXTRA_FLAGS = {'hd_search.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'], 'v2v.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
 
 
 def sources():

@@ -141,7 +141,8 @@ __device__ __forceinline__ void rodrigues_bwd(const float* aa, const M3& g, floa
 // tensors in the reference's API (models/smpl.py:44-47 concatenates them); joint t of body b is read from / its gradient
 // written to the right one directly.  w = 3 (axis-angle) or 9 (rotation matrix) floats per joint; strides in floats.
 struct PoseRef { const float* root; const float* body; int root_stride, body_stride; };
-struct PoseGrad { float* root; float* body; int root_stride, body_stride; };
+// body_add (or nullptr): a gradient the caller already holds for body_pose, added to what is written (no separate add launch)
+struct PoseGrad { float* root; float* body; int root_stride, body_stride; const float* body_add; int body_add_stride; };
 __device__ __forceinline__ const float* pose_joint(const PoseRef& p, int b, int t, int w)
 {
     return t == 0 ? p.root + (size_t)b * p.root_stride : p.body + (size_t)b * p.body_stride + (size_t)(t - 1) * w;
@@ -793,12 +794,14 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(
             float ga[3];
             rodrigues_bwd(sAA[t], g, ga);
             float* dst = pose_joint(g_pose, b, t, 3);
+            const float* add = t > 0 && g_pose.body_add ? g_pose.body_add + (size_t)b * g_pose.body_add_stride + (size_t)(t - 1) * 3 : nullptr;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) dst[c] = ga[c];
+            for (int c = 0; c < 3; ++c) dst[c] = ga[c] + (add ? add[c] : 0.0f);
         } else {
             float* dst = pose_joint(g_pose, b, t, 9);
+            const float* add = t > 0 && g_pose.body_add ? g_pose.body_add + (size_t)b * g_pose.body_add_stride + (size_t)(t - 1) * 9 : nullptr;
 #pragma unroll
-            for (int e = 0; e < 9; ++e) dst[e] = g.m[e];
+            for (int e = 0; e < 9; ++e) dst[e] = g.m[e] + (add ? add[e] : 0.0f);
         }
     }
     // shape gradient: 10 x 24 threads take one joint each, then ten add the joints up
@@ -1002,6 +1005,13 @@ extern "C" int tuch_smpl_forward(const tuch_smpl_model* m, const float* betas, c
                                    workspace, workspace_bytes, stream);
 }
 
+extern "C" int tuch_smpl_backward_split_add(const tuch_smpl_model* m, const float* global_orient, int global_orient_stride,
+                                            const float* body_pose, int body_pose_stride, int pose2rot, int B,
+                                            const void* fwd_workspace, const float* g_verts, const float* g_joints,
+                                            float* g_betas, float* g_global_orient, int g_global_orient_stride,
+                                            float* g_body_pose, int g_body_pose_stride, const float* g_body_pose_add,
+                                            int g_body_pose_add_stride, void* workspace, size_t workspace_bytes, void* stream);
+
 // g_verts [B,V,3] and/or g_joints [B,49,3] (either may be NULL) -> g_betas [B,10] and
 // the pose gradient, written as the two tensors of tuch_smpl_forward_split (same shapes, strides in floats).
 extern "C" int tuch_smpl_backward_split(const tuch_smpl_model* m, const float* global_orient, int global_orient_stride,
@@ -1011,6 +1021,21 @@ extern "C" int tuch_smpl_backward_split(const tuch_smpl_model* m, const float* g
                                         float* g_body_pose, int g_body_pose_stride, void* workspace,
                                         size_t workspace_bytes, void* stream)
 {
+    return tuch_smpl_backward_split_add(m, global_orient, global_orient_stride, body_pose, body_pose_stride, pose2rot, B,
+                                        fwd_workspace, g_verts, g_joints, g_betas, g_global_orient, g_global_orient_stride,
+                                        g_body_pose, g_body_pose_stride, nullptr, 0, workspace, workspace_bytes, stream);
+}
+
+// The same with a gradient the caller already holds for body_pose (g_body_pose_add, same shape, row stride in floats; or
+// NULL): g_body_pose = this call's gradient + that one -- what autograd would otherwise do in a separate add launch when
+// body_pose feeds the body model AND another term (SMPLify-DC: the pose prior, losses.py:63).
+extern "C" int tuch_smpl_backward_split_add(const tuch_smpl_model* m, const float* global_orient, int global_orient_stride,
+                                            const float* body_pose, int body_pose_stride, int pose2rot, int B,
+                                            const void* fwd_workspace, const float* g_verts, const float* g_joints,
+                                            float* g_betas, float* g_global_orient, int g_global_orient_stride,
+                                            float* g_body_pose, int g_body_pose_stride, const float* g_body_pose_add,
+                                            int g_body_pose_add_stride, void* workspace, size_t workspace_bytes, void* stream)
+{
     TUCH_REQUIRE(m && global_orient && body_pose && fwd_workspace && g_betas && g_global_orient && g_body_pose,
                  "tuch_smpl_backward: null pointer");
     TUCH_REQUIRE(B > 0 && B <= 65535, "tuch_smpl_backward: bad batch %d", B);
@@ -1018,7 +1043,9 @@ extern "C" int tuch_smpl_backward_split(const tuch_smpl_model* m, const float* g
     TUCH_REQUIRE(global_orient_stride >= w && body_pose_stride >= 23 * w && g_global_orient_stride >= w &&
                  g_body_pose_stride >= 23 * w, "tuch_smpl_backward: bad pose strides");
     const PoseRef pose{global_orient, body_pose, global_orient_stride, body_pose_stride};
-    const PoseGrad g_pose{g_global_orient, g_body_pose, g_global_orient_stride, g_body_pose_stride};
+    TUCH_REQUIRE(!g_body_pose_add || g_body_pose_add_stride >= 23 * w, "tuch_smpl_backward: bad stride of the added gradient");
+    const PoseGrad g_pose{g_global_orient, g_body_pose, g_global_orient_stride, g_body_pose_stride, g_body_pose_add,
+                          g_body_pose_add_stride};
     const FwdLayout f = fwd_layout(m, B);
     const BwdLayout l = bwd_layout(m, B);
     if (!workspace || workspace_bytes < l.total) {

@@ -810,13 +810,16 @@ __global__ __launch_bounds__(64) void v2v_leaves_kernel(
 // and the largest bound among them (conservative: box-to-box distance), and only the survivors get the per-column test
 // and their rows.  Same rows as the walks -> the same keys.  colbox: the box of every 64-column block, left by
 // v2v_seed_kernel ([B][column blocks][8]).
-__global__ __launch_bounds__(64) void v2v_scan_kernel(
+template <bool kShared>
+__device__ __forceinline__ void v2v_scan_body(
     const float* __restrict__ prow, int V, int Vp, const uint64_t* __restrict__ bits,
     const float* __restrict__ leafbox, const float* __restrict__ colbox, const uint64_t* __restrict__ masked_leaf,
     const uint64_t* __restrict__ masked, int N, int L, const int32_t* __restrict__ frontier,
     const int32_t* __restrict__ sub_leaf, const int32_t* __restrict__ order, uint64_t* __restrict__ keys,
     const float* __restrict__ prow_g, const uint64_t* __restrict__ bits_g, int G)   // rows / mask words in groups of four
 {
+    // (80 registers = 6 wavefronts per SIMD: touching v79 is what sets the kernel's register count)
+    if constexpr (kShared) asm volatile("v_mov_b32 v79, 0" ::: "v79");
     const int b = blockIdx.x, lane = threadIdx.x;
     const int pair = __builtin_amdgcn_readfirstlane(order[blockIdx.y >> 1]);      // launch order over 128-blocks
     const int sub = pair >> 16, qb = (pair & 0xffff) * 2 + (blockIdx.y & 1);
@@ -883,6 +886,169 @@ __global__ __launch_bounds__(64) void v2v_scan_kernel(
     if (k0 < init) atomicMin((unsigned long long*)(kb + i0), (unsigned long long)k0);
 }
 
+// Fourth form: the rows of a surviving leaf on the MATRIX CORES (the idea of hd_search.hip).  Everything up to the rows is
+// v2v_scan_kernel; 32 rows of a leaf x the wavefront's 64 columns are two 32 x 32 tiles of v_mfma_f32_32x32x2_f32,
+// |q'|^2 + R^2 - 2 p'.q' in coordinates relative to the centre of the column block (exact f32 fma chains).  The mask of a
+// tile comes as ready-made lane masks: tree_mask_tiles[column block][tile][sub-tile][accumulator register] holds the two
+// rows an accumulator register spans (row i for lanes 0-31, row i + 4 for lanes 32-63), so an inadmissible pair is one
+// v_cndmask away; what is left per value is the row's place in the low four mantissa bits (v_and_or) and half a v_min3_i32.
+// The rows found this way are CANDIDATES: their distances are recomputed by direct differences and merged into the same
+// 64-bit (distance, row) keys with atomicMin -- the result differs from the other forms only where two rows of one
+// (column block, subtree) tie within the 20-bit key (~1e-6 relative), which the reference's own bmm-form distances cannot
+// tell apart either.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ int select_key(int if_clear, int if_set, uint64_t lane_mask)
+{
+    int r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(lane_mask));
+    return r;
+}
+__global__ __launch_bounds__(64) void v2v_mfma_kernel(
+    const float* __restrict__ prow, int V, int Vp, const float* __restrict__ leafbox, const float* __restrict__ colbox,
+    const uint64_t* __restrict__ masked_leaf, const uint64_t* __restrict__ masked, const uint64_t* __restrict__ mask_tiles,
+    const int32_t* __restrict__ leaf_tile, int T, int N, int L, const int32_t* __restrict__ frontier, const int32_t* __restrict__ sub_leaf, const int32_t* __restrict__ order,
+    uint64_t* __restrict__ keys)
+{
+    const int b = blockIdx.x, lane = threadIdx.x, h = lane >> 5, j = lane & 31;
+    const int pair = __builtin_amdgcn_readfirstlane(order[blockIdx.y >> 1]);      // launch order over 128-blocks
+    const int sub = pair >> 16, qb = (pair & 0xffff) * 2 + (blockIdx.y & 1);
+    const float* pb = prow + (size_t)b * Vp * 3;
+    const int i0 = qb * kTreeCols + lane;
+    uint64_t* kb = keys + (size_t)b * Vp;
+    const uint64_t init = __hip_atomic_load(kb + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    Column c;                                                                    // own column: lane <-> column i0
+    c.px = pb[3 * i0]; c.py = pb[3 * i0 + 1]; c.pz = pb[3 * i0 + 2];
+    c.best = __uint_as_float((uint32_t)(init >> 32));
+    c.arg = 0;
+    const int first = __builtin_amdgcn_readfirstlane(sub_leaf[2 * sub]), count = __builtin_amdgcn_readfirstlane(sub_leaf[2 * sub + 1]);
+    const uint64_t alive = masked[(size_t)qb * N + __builtin_amdgcn_readfirstlane(frontier[sub])];
+    if (alive == 0) return;
+    float reach2 = ((alive >> lane) & 1) ? c.best : 0.0f;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) reach2 = fmaxf(reach2, __shfl_xor(reach2, m));
+    const float* cbx = colbox + ((size_t)b * (Vp / kTreeCols) + qb) * 8;
+    const float clx = cbx[0], cly = cbx[1], clz = cbx[2], chx = cbx[4], chy = cbx[5], chz = cbx[6];
+    // centre and squared radius of the column block; key = squared distance + (R^2 - |p'|^2) >= 0
+    const float cx = 0.5f * (clx + chx), cy = 0.5f * (cly + chy), cz = 0.5f * (clz + chz);
+    const float rx = chx - cx, ry = chy - cy, rz = chz - cz;
+    const float R2 = (rx * rx + ry * ry + rz * rz) * 1.0001f + 1e-12f;
+    auto offset_of = [&](float x, float y, float z) {
+        const float ux = x - cx, uy = y - cy, uz = z - cz;
+        return R2 - __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
+    };
+    const float own_o = offset_of(c.px, c.py, c.pz);
+    float B1[2], B2[2];
+    int bestkey[2], brow[2] = {-1, -1};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int col = qb * kTreeCols + 32 * s + j;
+        const float x = pb[3 * col], y = pb[3 * col + 1], z = pb[3 * col + 2];
+        B1[s] = h ? -2.0f * (y - cy) : -2.0f * (x - cx);
+        B2[s] = h ? 1.0f : -2.0f * (z - cz);
+        // nothing at or above the key of the column's current bound can improve on it
+        const uint64_t k = __hip_atomic_load(kb + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float bound = __uint_as_float((uint32_t)(k >> 32));
+        const float kf = bound + offset_of(x, y, z);
+        bestkey[s] = bound < __builtin_inff() ? (__float_as_int(__builtin_fmaf(kf, 4e-6f, kf) + 4e-6f * R2 + 1e-12f) | 15) : 0x7f000000;
+    }
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* lb = leafbox + ((size_t)b * L + first) * 8;
+    const uint64_t* ml = masked_leaf + (size_t)qb * L + first;
+    for (int base = 0; base < count; base += 64) {
+        const int li = base + lane;
+        bool cand = false;
+        float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;   // box; hi.w = row range of the leaf
+        uint64_t lanes_of = 0;
+        int tile0 = 0;
+        if (li < count) {
+            lo = *reinterpret_cast<const float4*>(lb + (size_t)li * 8);
+            hi = *reinterpret_cast<const float4*>(lb + (size_t)li * 8 + 4);
+            lanes_of = ml[li];
+            tile0 = leaf_tile[first + li];
+            const float ex = fmaxf(fmaxf(lo.x - chx, clx - hi.x), 0.0f);
+            const float ey = fmaxf(fmaxf(lo.y - chy, cly - hi.y), 0.0f);
+            const float ez = fmaxf(fmaxf(lo.z - chz, clz - hi.z), 0.0f);
+            const float g = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) * kPruneSlack;
+            cand = g <= reach2 && (lanes_of & alive) != 0;
+        }
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(cand);
+        while (todo) {
+            const int u = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            auto from = [&](float x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), u)); };
+            const float b0 = from(lo.x), b1 = from(lo.y), b2 = from(lo.z), b4 = from(hi.x), b5 = from(hi.y), b6 = from(hi.z);
+            const uint64_t lanes = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(lanes_of >> 32), u) << 32) |
+                                   (uint32_t)__builtin_amdgcn_readlane((int)lanes_of, u);
+            const float dx = c.px - __builtin_amdgcn_fmed3f(c.px, b0, b4);
+            const float dy = c.py - __builtin_amdgcn_fmed3f(c.py, b1, b5);
+            const float dz = c.pz - __builtin_amdgcn_fmed3f(c.pz, b2, b6);
+            const float g = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) * kPruneSlack;
+            if ((__builtin_amdgcn_ballot_w64(g <= c.best) & lanes) == 0) continue;
+            const int leaf = __float_as_int(from(hi.w)), nrows = leaf >> 20;
+            const int t0 = __builtin_amdgcn_readlane(tile0, u);
+            for (int tt = 0; 32 * tt < nrows; ++tt) {                 // (one tile unless the leaf has more than 32 rows)
+                const int row0 = (leaf & 0xfffff) + 32 * tt, nr = min(32, nrows - 32 * tt);
+                // the tile's rows as the A operand (lane l <-> row l & 31; l >> 5 picks the k index)
+                const int r = row0 + min(j, nr - 1);
+                const float ux = pb[3 * r] - cx, uy = pb[3 * r + 1] - cy, uz = pb[3 * r + 2] - cz;
+                const float nrm = j < nr ? __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux)) + R2 : 1e30f;
+                const float A1 = h ? uy : ux, A2 = h ? nrm : uz;
+                f32x16 acc[2];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B1[0], zero, 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B1[1], zero, 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A2, B2[0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A2, B2[1], acc[1], 0, 0, 0);
+                const uint64_t* mt = mask_tiles + ((size_t)qb * T + (t0 + tt)) * 32;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    int key[16];
+#pragma unroll
+                    for (int a = 0; a < 16; ++a)
+                        key[a] = select_key(0x7f000000, (__float_as_int(acc[s][a]) & ~15) | a, mt[16 * s + a]);
+                    int m = min(min(key[0], key[1]), key[2]);
+#pragma unroll
+                    for (int a = 3; a < 15; a += 2) m = min(min(m, key[a]), key[a + 1]);
+                    m = min(m, key[15]);
+                    const bool better = m < bestkey[s];
+                    bestkey[s] = better ? m : bestkey[s];
+                    brow[s] = better ? row0 : brow[s];
+                }
+            }
+            // the own columns' bounds: smaller of the two halves' keys
+            const auto sw = __builtin_amdgcn_permlane32_swap((uint32_t)bestkey[0], (uint32_t)bestkey[1], false, false);
+            const float f = __int_as_float(min((int)sw[0], (int)sw[1]) & ~15);
+            c.best = fminf(c.best, (f - own_o) + 4e-6f * (f + R2));
+        }
+    }
+    // candidates -> exact keys
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        if (brow[s] < 0) continue;
+        const int a = bestkey[s] & 15, row = brow[s] + 4 * h + 8 * (a >> 2) + (a & 3);
+        const int col = qb * kTreeCols + 32 * s + j;
+        const float dx = pb[3 * col] - pb[3 * row], dy = pb[3 * col + 1] - pb[3 * row + 1], dz = pb[3 * col + 2] - pb[3 * row + 2];
+        const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        atomicMin((unsigned long long*)(kb + col), (unsigned long long)v2v_key(d, row));
+    }
+}
+
+#define TUCH_SCAN_PARAMS                                                                                                   \
+    const float* __restrict__ prow, int V, int Vp, const uint64_t* __restrict__ bits, const float* __restrict__ leafbox,    \
+    const float* __restrict__ colbox, const uint64_t* __restrict__ masked_leaf, const uint64_t* __restrict__ masked, int N, \
+    int L, const int32_t* __restrict__ frontier, const int32_t* __restrict__ sub_leaf, const int32_t* __restrict__ order,   \
+    uint64_t* __restrict__ keys, const float* __restrict__ prow_g, const uint64_t* __restrict__ bits_g, int G
+#define TUCH_SCAN_ARGS prow, V, Vp, bits, leafbox, colbox, masked_leaf, masked, N, L, frontier, sub_leaf, order, keys, prow_g, bits_g, G
+__global__ __launch_bounds__(64) void v2v_scan_kernel(TUCH_SCAN_PARAMS) { v2v_scan_body<false>(TUCH_SCAN_ARGS); }
+// The same beside the inside test's chain of small kernels (another stream): at most 6 of a SIMD's 8 wave slots, by
+// REGISTER count.  (Round 2 capped the walk with an unused LDS allocation -- 25 x 6400 B is ALL of a CU's LDS: the
+// chain's kernels that need LDS themselves, ray_near and ray_tiles_fill, then waited for the search to drain.)
+__global__ __launch_bounds__(64) void v2v_scan_shared_kernel(TUCH_SCAN_PARAMS)
+{
+    v2v_scan_body<true>(TUCH_SCAN_ARGS);
+}
+#undef TUCH_SCAN_PARAMS
+#undef TUCH_SCAN_ARGS
+
 // keys -> (min, argmin) in the caller's vertex numbering; all-masked column -> (inf, 0)
 __global__ __launch_bounds__(kBlock) void v2v_tree_finalize_kernel(
     const uint64_t* __restrict__ keys, const int32_t* __restrict__ qperm, int V, int Vp,
@@ -926,7 +1092,9 @@ bool use_v2v_tree(const tuch_contact_model* m)
 
 static int flat_mode(const tuch_contact_model* m)
 {
-    return (m->tree_sub_leaf && m->tree_masked_leaf) ? m->opt.v2v_flat : 0;
+    if (!(m->tree_sub_leaf && m->tree_masked_leaf)) return 0;
+    if (m->opt.v2v_flat == 3 && !m->tree_mask_tiles) return 2;
+    return m->opt.v2v_flat;
 }
 
 int choose_v2v_frontier(const tuch_contact_model* m, int B)
@@ -934,7 +1102,7 @@ int choose_v2v_frontier(const tuch_contact_model* m, int B)
     // option v2v_waves = 0: the form's own default -- the walks want many short wavefronts (65536: 32 subtrees at batch
     // 64), the leaf scan tests up to 64 leaves per wavefront at once and is best with a quarter as many (measured at
     // batch 64, step time: 7000 / 14000 / 30000 / 65536 -> 0.56+ / 0.546 / 0.550 / 0.562 ms)
-    const long target = m->opt.v2v_waves > 0 ? m->opt.v2v_waves : (flat_mode(m) == 2 ? 14000L : 65536L);
+    const long target = m->opt.v2v_waves > 0 ? m->opt.v2v_waves : (flat_mode(m) >= 2 ? 14000L : 65536L);
     int f = 0;
     while (f + 1 < m->tree_num_frontiers &&
            (long)B * m->tree_qblocks * (m->tree_frontier_off_host[f + 1] - m->tree_frontier_off_host[f]) < target) ++f;
@@ -1061,7 +1229,7 @@ extern "C" int tuch_v2v_min_model_shared(const tuch_contact_model* m, const floa
                        (const int32_t*)m->tree_v2v_info);
     hipLaunchKernelGGL(v2v_seed_kernel, dim3(B, 2 * m->tree_qblocks), dim3(64), 0, s, (const float*)prow, V, Vp,
                        (const uint64_t*)m->tree_mask_bits, nodes, (const int32_t*)m->tree_rows, (const float*)bounds,
-                       (const uint64_t*)m->tree_masked, N, (const int32_t*)hint_inout, keys, scan == 2 ? colbox : (float*)nullptr);
+                       (const uint64_t*)m->tree_masked, N, (const int32_t*)hint_inout, keys, scan >= 2 ? colbox : (float*)nullptr);
     const int f = choose_v2v_frontier(m, B);
     const int f0 = m->tree_frontier_off_host[f], nsub = m->tree_frontier_off_host[f + 1] - f0;
     // leave_room: an unused LDS allocation caps the walk at 25 of a CU's 32 wave slots.  The walk is one grid of 220 k
@@ -1069,8 +1237,22 @@ extern "C" int tuch_v2v_min_model_shared(const tuch_contact_model* m, const floa
     // kernels -- every slot is taken and those (and a 16 MB memset) queue behind the walk's workgroups: the chain only
     // got going when the walk was done (tools/graph_timeline.py: the memset took 236 us).  -2.5 % step time; alone the
     // walk is 10 % slower with the cap (0.28 -> 0.31 ms), hence a flag (TUCH_V2V_LDS: bytes, to compare).
-    const int lds_pad = leave_room ? m->opt.v2v_lds : 0;
-    if (scan == 2)
+    const int lds_pad = leave_room && m->opt.v2v_lds > 0 ? m->opt.v2v_lds : 0;
+    if (scan == 3)
+        hipLaunchKernelGGL(v2v_mfma_kernel, dim3(B, 2 * nsub * m->tree_qblocks), dim3(64), 0, s, (const float*)prow, V, Vp,
+                           (const float*)leafbox, (const float*)colbox, (const uint64_t*)m->tree_masked_leaf,
+                           (const uint64_t*)m->tree_masked, (const uint64_t*)m->tree_mask_tiles,
+                           (const int32_t*)m->tree_leaf_tile, m->tree_tiles, N, m->tree_leaves,
+                           (const int32_t*)m->tree_frontier_nodes + f0, (const int32_t*)m->tree_sub_leaf + 2 * (size_t)f0,
+                           (const int32_t*)m->tree_launch_order + (size_t)f0 * m->tree_qblocks, keys);
+    else if (scan == 2 && leave_room && m->opt.v2v_lds < 0)
+        hipLaunchKernelGGL(v2v_scan_shared_kernel, dim3(B, 2 * nsub * m->tree_qblocks), dim3(64), 0, s, (const float*)prow,
+                           V, Vp, (const uint64_t*)m->tree_mask_bits, (const float*)leafbox, (const float*)colbox,
+                           (const uint64_t*)m->tree_masked_leaf, (const uint64_t*)m->tree_masked, N, m->tree_leaves,
+                           (const int32_t*)m->tree_frontier_nodes + f0, (const int32_t*)m->tree_sub_leaf + 2 * (size_t)f0,
+                           (const int32_t*)m->tree_launch_order + (size_t)f0 * m->tree_qblocks, keys,
+                           (const float*)(ws + l.prow_g), (const uint64_t*)m->tree_mask_bits_g, m->tree_groups);
+    else if (scan == 2)
         hipLaunchKernelGGL(v2v_scan_kernel, dim3(B, 2 * nsub * m->tree_qblocks), dim3(64), (size_t)lds_pad, s, (const float*)prow,
                            V, Vp, (const uint64_t*)m->tree_mask_bits, (const float*)leafbox, (const float*)colbox,
                            (const uint64_t*)m->tree_masked_leaf, (const uint64_t*)m->tree_masked, N, m->tree_leaves,

@@ -68,6 +68,11 @@ class _SmplLBS(torch.autograd.Function):
                                            int(pose2rot), b, _C.ptr(verts), _C.ptr(joints), _C.ptr(ws), nbytes, _C.stream()))
         ctx.dm, ctx.pose2rot = dm, bool(pose2rot)
         ctx.shapes = (global_orient.shape, body_pose.shape)
+        # A later node that holds ANOTHER gradient for the same body_pose (ops._Stage2Tail: the pose prior) may leave it in
+        # pose_grad_extra instead of returning it: backward() then adds it inside its last kernel and autograd has nothing
+        # left to sum (one add launch less per step).  pose_key: how that node recognises the tensor.
+        ctx.pose_key = (body_pose.data_ptr(), tuple(body_pose.shape), body_pose.dtype) if ctx.needs_input_grad[2] else None
+        ctx.pose_grad_extra = None
         ctx.save_for_backward(go, bp, ws)
         return verts, joints
 
@@ -84,10 +89,13 @@ class _SmplLBS(torch.autograd.Function):
         g_bp = torch.empty(bp.shape, dtype=torch.float32, device=go.device)
         nbytes = L.tuch_smpl_backward_workspace_bytes(ctx.dm._handle, b)
         ws2 = torch.empty(nbytes, dtype=torch.uint8, device=go.device)
-        _C.check(L.tuch_smpl_backward_split(ctx.dm._handle, _C.row_ptr(go), go.stride(0), _C.row_ptr(bp), bp.stride(0),
-                                            int(ctx.pose2rot), b, _C.ptr(ws), _C.ptr(gv), _C.ptr(gj),
-                                            _C.ptr(g_betas), _C.ptr(g_go), w, _C.ptr(g_bp), 23 * w, _C.ptr(ws2),
-                                            nbytes, _C.stream()))
+        extra, ctx.pose_grad_extra = ctx.pose_grad_extra, None
+        if extra is not None:
+            extra = extra.to(torch.float32).reshape(b, 23 * w).contiguous()
+        _C.check(L.tuch_smpl_backward_split_add(ctx.dm._handle, _C.row_ptr(go), go.stride(0), _C.row_ptr(bp), bp.stride(0),
+                                                int(ctx.pose2rot), b, _C.ptr(ws), _C.ptr(gv), _C.ptr(gj),
+                                                _C.ptr(g_betas), _C.ptr(g_go), w, _C.ptr(g_bp), 23 * w,
+                                                _C.ptr(extra), 23 * w, _C.ptr(ws2), nbytes, _C.stream()))
         return g_betas, g_go.view(ctx.shapes[0]), g_bp.view(ctx.shapes[1]), None, None
 
 

@@ -381,6 +381,13 @@ class _Stage2Tail(torch.autograd.Function):
         if want_grad:
             ctx.save_for_backward(gv, gj, gc, gp)
         ctx.in_dtypes = (verts.dtype, joints.dtype, camera_t.dtype, body_pose.dtype)
+        # body_pose also feeds the body model that made `verts`: that node's backward runs after this one (it waits for the
+        # vertex gradient) and can add the prior's pose gradient inside its own last kernel (lbs._SmplLBS: pose_grad_extra)
+        # instead of autograd summing two gradients in a launch of its own
+        node = verts.grad_fn
+        key = (body_pose.data_ptr(), tuple(body_pose.shape), body_pose.dtype)
+        ctx.lbs_node = node if (want_grad and ctx.needs_input_grad[0] and ctx.needs_input_grad[3] and node is not None
+                                and getattr(node, 'pose_key', None) == key) else None
         return out[0]
 
     @staticmethod
@@ -392,6 +399,9 @@ class _Stage2Tail(torch.autograd.Function):
         if not any(g.data_ptr() == seed.data_ptr() for seed in _ONES.values()):
             g = g.reshape(()).to(torch.float32)
             gv, gj, gc, gp = gv * g, gj * g, gc * g, gp * g
+        if ctx.lbs_node is not None:
+            ctx.lbs_node.pose_grad_extra = gp
+            return gv.to(dv), gj.to(dj), gc.to(dc), None, None, None, None, None
         return gv.to(dv), gj.to(dj), gc.to(dc), gp.to(dp), None, None, None, None
 
 
