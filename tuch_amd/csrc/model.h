@@ -42,8 +42,8 @@ struct tuch_options {
     int ray_waves = 32768;      // wavefronts of the crossing kernel
     int v2v_tree = 1;           // 0: flat nearest-vertex search
     int v2v_waves = 0;          // frontier choice of the search (wavefronts aimed at; 0: the form's own default)
-    int v2v_flat = 2;           // search: 3 a leaf's rows on the matrix cores, 2 lanes over a subtree's leaves first, 1 leaf boxes four at a time, 0 the stackless walk
-    int v2v_lds = 6400;         // LDS bytes a workgroup of the search holds back when something runs beside it
+    int v2v_flat = 2;           // search: 3 aligned row tiles on the matrix cores, 2 lanes over a subtree's leaves first, 1 leaf boxes four at a time, 0 the stackless walk
+    int v2v_lds = -1;           // search beside the inside test: -1 capped at 6 wavefronts per SIMD by register count, > 0 by an LDS allocation of that many bytes per workgroup (6400: round 2), 0 uncapped
     int seg_splits = 16;        // face splits of the solid-angle segment kernel
     int seg_assist = 1;         // 0: the segment pass counts its body-face crossings itself (read at create only)
     int seg_fused = 1;          // 0: the segment filter as six launches instead of one (A/B, tests)
@@ -135,11 +135,12 @@ struct tuch_contact_model {
     // 0 for a padding row)
     int32_t* tree_leaf_group;
     uint64_t* tree_mask_bits_g;
-    // matrix-core form (v2v.hip: v2v_mfma_kernel): a leaf's rows in tiles of 32; per (column block, tile) 32 lane masks =
-    // [sub-tile][accumulator register] -> {row i of the tile for columns 32 s .. 32 s + 31 | row i + 4}
+    // matrix-core form (v2v.hip: v2v_mfma_kernel): the rows in tree order in aligned tiles of 32; per (column block, tile) 32
+    // lane masks = [sub-tile][accumulator register] -> {row i of the tile for columns 32 s .. 32 s + 31 | row i + 4}, and
+    // the columns with any admissible row in the tile
     uint64_t* tree_mask_tiles;   // [2 * tree_qblocks][tree_tiles][32]
-    int32_t* tree_leaf_tile;     // [tree_leaves + 1] first tile of every leaf
-    int tree_tiles;
+    uint64_t* tree_tile_lanes;   // [2 * tree_qblocks][tree_tiles]
+    int tree_tiles;              // 4 * tree_qblocks
     int tree_groups;
     int tree_num_frontiers;
     int tree_leaf_runs_tile;       // 1: the leaves' strip runs [ex_off, ex_off + ex_len) tile [0, tree_exact_len) without gaps

@@ -42,7 +42,7 @@ extern "C" void tuch_contact_model_destroy(tuch_contact_model* m)
 {
     if (!m) return;
     void* dev[] = {m->ring_off, m->ring_vidx, m->faces, m->mask_bits, m->strip_vidx, m->strip_sign, m->tree_node, m->tree_vidx, m->tree_sign, m->tree_qperm,
-                   m->tree_height_off, m->tree_height_nodes, m->tree_frontier_nodes, m->tree_launch_order, m->tree_ancestors, m->tree_rows, m->tree_v2v_info, m->tree_mask_bits, m->tree_masked, m->tree_sub_leaf, m->tree_masked_leaf, m->tree_leaf_group, m->tree_mask_bits_g, m->tree_mask_tiles, m->tree_leaf_tile, m->seg_blocks, m->seg_of_q, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces, m->seg_link_off, m->seg_link, m->seg_ray_off, m->seg_ray_ent, m->seg_elem_mask, m->seg_vmask, m->seg_vpos, m->seg_cap_off, m->seg_cap_ent, m->seg_cap_range,
+                   m->tree_height_off, m->tree_height_nodes, m->tree_frontier_nodes, m->tree_launch_order, m->tree_ancestors, m->tree_rows, m->tree_v2v_info, m->tree_mask_bits, m->tree_masked, m->tree_sub_leaf, m->tree_masked_leaf, m->tree_leaf_group, m->tree_mask_bits_g, m->tree_mask_tiles, m->tree_tile_lanes, m->seg_blocks, m->seg_of_q, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces, m->seg_link_off, m->seg_link, m->seg_ray_off, m->seg_ray_ent, m->seg_elem_mask, m->seg_vmask, m->seg_vpos, m->seg_cap_off, m->seg_cap_ent, m->seg_cap_range,
                    m->cap_off, m->cap_vidx, m->region_off, m->region_vidx, m->pairs, m->pair_mask, m->pair_mask_off, m->tickets, m->canary_hits};
     for (void* p : dev)
         if (p) (void)hipFree(p);
@@ -221,28 +221,29 @@ extern "C" int tuch_contact_model_create(
                     m->tree_groups = G;
                     if (rc == TUCH_OK) rc = upload(&m->tree_leaf_group, group.data(), group.size());
                     if (rc == TUCH_OK) rc = upload(&m->tree_mask_bits_g, bits_g.data(), bits_g.size());
-                    // matrix-core form: a leaf's rows in tiles of 32 (leaf_tile = first tile of every leaf); lane masks per
-                    // (column block, tile, sub-tile s, accumulator register a): low word = columns 32 s .. 32 s + 31 against row
-                    // i = (a & 3) + 8 (a >> 2) of the tile, high word = against row i + 4
+                    // matrix-core form: the rows in tree order in aligned tiles of 32; lane masks per (column block, tile,
+                    // sub-tile s, accumulator register a): low word = columns 32 s .. 32 s + 31 against row i = (a & 3) +
+                    // 8 (a >> 2) of the tile, high word = against row i + 4; and per (column block, tile) the columns with
+                    // any admissible row in the tile
                     if (rc == TUCH_OK) {
-                        std::vector<int32_t> leaf_tile(L + 1, 0);
-                        for (int i = 0; i < L; ++i) leaf_tile[i + 1] = leaf_tile[i] + (t.rows[(size_t)t.height_nodes[i] * 2 + 1] + 31) / 32;
-                        const int T = leaf_tile[L];
-                        std::vector<uint64_t> tiles((size_t)Wp * T * 32, 0);
-                        for (int qb = 0; qb < Wp; ++qb)
-                            for (int i = 0; i < L; ++i) {
-                                const int lo = t.rows[(size_t)t.height_nodes[i] * 2], n = t.rows[(size_t)t.height_nodes[i] * 2 + 1];
-                                auto word = [&](int k) { return k < n ? bits[(size_t)qb * V + lo + k] : (uint64_t)0; };
-                                for (int tt = leaf_tile[i]; tt < leaf_tile[i + 1]; ++tt)
-                                    for (int sx = 0; sx < 2; ++sx)
-                                        for (int a = 0; a < 16; ++a) {
-                                            const int r0 = 32 * (tt - leaf_tile[i]) + (a & 3) + 8 * (a >> 2);
-                                            const uint64_t w0 = (word(r0) >> (32 * sx)) & 0xffffffffull, w1 = (word(r0 + 4) >> (32 * sx)) & 0xffffffffull;
-                                            tiles[((size_t)qb * T + tt) * 32 + 16 * sx + a] = w0 | (w1 << 32);
-                                        }
+                        const int T = 4 * t.num_qblocks;
+                        std::vector<uint64_t> tiles((size_t)Wp * T * 32, 0), any((size_t)Wp * T, 0);
+                        for (int qb = 0; qb < Wp; ++qb) {
+                            auto word = [&](int k) { return k < V ? bits[(size_t)qb * V + k] : (uint64_t)0; };
+                            for (int tt = 0; tt < T; ++tt) {
+                                uint64_t all = 0;
+                                for (int k = 0; k < 32; ++k) all |= word(32 * tt + k);
+                                any[(size_t)qb * T + tt] = all;
+                                for (int sx = 0; sx < 2; ++sx)
+                                    for (int a = 0; a < 16; ++a) {
+                                        const int r0 = 32 * tt + (a & 3) + 8 * (a >> 2);
+                                        const uint64_t w0 = (word(r0) >> (32 * sx)) & 0xffffffffull, w1 = (word(r0 + 4) >> (32 * sx)) & 0xffffffffull;
+                                        tiles[((size_t)qb * T + tt) * 32 + 16 * sx + a] = w0 | (w1 << 32);
+                                    }
                             }
+                        }
                         m->tree_tiles = T;
-                        rc = upload(&m->tree_leaf_tile, leaf_tile.data(), leaf_tile.size());
+                        rc = upload(&m->tree_tile_lanes, any.data(), any.size());
                         if (rc == TUCH_OK) rc = upload(&m->tree_mask_tiles, tiles.data(), tiles.size());
                     }
                 }

@@ -608,7 +608,8 @@ __global__ __launch_bounds__(64) void v2v_seed_kernel(
     const uint64_t* __restrict__ masked, int N,
     const int32_t* __restrict__ hint,            // [B,Vp] a row per column (tree order) from an earlier call, or nullptr
     uint64_t* __restrict__ keys,                 // [B,Vp]
-    float* __restrict__ colbox)                  // [B][column blocks][8] or nullptr: the box of the block's 64 columns
+    float* __restrict__ colbox,                  // [B][column blocks][8] or nullptr: the box of the block's 64 columns
+    float* __restrict__ tilebox)                 // [B][2 * column blocks][8] or nullptr: the boxes of its two 32-row halves
 {
     const int b = blockIdx.x, qb = blockIdx.y, lane = threadIdx.x;
     const float* pb = prow + (size_t)b * Vp * 3;
@@ -619,13 +620,38 @@ __global__ __launch_bounds__(64) void v2v_seed_kernel(
     c.arg = 0;
     if (colbox) {
         float lo[3] = {c.px, c.py, c.pz}, hi[3] = {c.px, c.py, c.pz};
+        if (tilebox) {
+            // the matrix-core form walks the rows in aligned tiles of 32 (= half a column block): their boxes, rows behind
+            // the last vertex left out
+            const bool real = i0 < V;
+            const float inf = __builtin_inff();
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1)
+            for (int k = 0; k < 3; ++k) { lo[k] = real ? lo[k] : inf; hi[k] = real ? hi[k] : -inf; }
+#pragma unroll
+            for (int m = 16; m >= 1; m >>= 1)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    lo[k] = fminf(lo[k], __shfl_xor(lo[k], m));
+                    hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m));
+                }
+            if ((lane & 31) == 0) {
+                float* o = tilebox + ((size_t)b * gridDim.y * 2 + 2 * qb + (lane >> 5)) * 8;
+                o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = 0.0f; o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = 0.0f;
+            }
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                lo[k] = fminf(lo[k], __shfl_xor(lo[k], m));
-                hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m));
+                lo[k] = fminf(lo[k], __shfl_xor(lo[k], 32));
+                hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], 32));
             }
+        } else {
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    lo[k] = fminf(lo[k], __shfl_xor(lo[k], m));
+                    hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m));
+                }
+        }
         if (lane == 0) {
             float* o = colbox + ((size_t)b * gridDim.y + qb) * 8;
             o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = 0.0f; o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = 0.0f;
@@ -886,17 +912,23 @@ __device__ __forceinline__ void v2v_scan_body(
     if (k0 < init) atomicMin((unsigned long long*)(kb + i0), (unsigned long long)k0);
 }
 
-// Fourth form: the rows of a surviving leaf on the MATRIX CORES (the idea of hd_search.hip).  Everything up to the rows is
-// v2v_scan_kernel; 32 rows of a leaf x the wavefront's 64 columns are two 32 x 32 tiles of v_mfma_f32_32x32x2_f32,
-// |q'|^2 + R^2 - 2 p'.q' in coordinates relative to the centre of the column block (exact f32 fma chains).  The mask of a
-// tile comes as ready-made lane masks: tree_mask_tiles[column block][tile][sub-tile][accumulator register] holds the two
-// rows an accumulator register spans (row i for lanes 0-31, row i + 4 for lanes 32-63), so an inadmissible pair is one
-// v_cndmask away; what is left per value is the row's place in the low four mantissa bits (v_and_or) and half a v_min3_i32.
+// Fourth form: the rows on the MATRIX CORES (the idea of hd_search.hip), no tree.  The rows in tree order are cut into
+// aligned tiles of 32 (compact patches: half a column block each; boxes left by v2v_seed_kernel); a wavefront owns 64
+// columns and a quarter of the tiles: lane <-> tile for the tile's box against the block's box and the largest bound in
+// it (+ the static table of the columns with ANY admissible row in the tile), the survivors against every column's own
+// bound, and what is left as two 32 x 32 products of v_mfma_f32_32x32x2_f32 per tile: |q'|^2 + R^2 - 2 p'.q' in
+// coordinates relative to the centre of the column block (exact f32 fma chains).  Full tiles: the leaves of the cluster
+// tree hold ~16 rows and would half-fill them (measured: 197 us against 162 us for the leaf scan), aligned tiles prune a
+// little coarser and waste nothing.  The mask of a tile comes as ready-made lane masks:
+// tree_mask_tiles[column block][tile][sub-tile][accumulator register] holds the two rows an accumulator register spans
+// (row i for lanes 0-31, row i + 4 for lanes 32-63), so an inadmissible pair is one v_cndmask away; what is left per value
+// is the row's place in the low four mantissa bits (v_and_or) and half a v_min3_i32.
 // The rows found this way are CANDIDATES: their distances are recomputed by direct differences and merged into the same
 // 64-bit (distance, row) keys with atomicMin -- the result differs from the other forms only where two rows of one
-// (column block, subtree) tie within the 20-bit key (~1e-6 relative), which the reference's own bmm-form distances cannot
+// (column block, quarter) tie within the 20-bit key (~1e-6 relative), which the reference's own bmm-form distances cannot
 // tell apart either.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kTileWaves = 4;             // wavefronts per column block: they share out the row tiles
 __device__ __forceinline__ int select_key(int if_clear, int if_set, uint64_t lane_mask)
 {
     int r;
@@ -904,26 +936,21 @@ __device__ __forceinline__ int select_key(int if_clear, int if_set, uint64_t lan
     return r;
 }
 __global__ __launch_bounds__(64) void v2v_mfma_kernel(
-    const float* __restrict__ prow, int V, int Vp, const float* __restrict__ leafbox, const float* __restrict__ colbox,
-    const uint64_t* __restrict__ masked_leaf, const uint64_t* __restrict__ masked, const uint64_t* __restrict__ mask_tiles,
-    const int32_t* __restrict__ leaf_tile, int T, int N, int L, const int32_t* __restrict__ frontier, const int32_t* __restrict__ sub_leaf, const int32_t* __restrict__ order,
-    uint64_t* __restrict__ keys)
+    const float* __restrict__ prow, int V, int Vp, const float* __restrict__ tilebox, const float* __restrict__ colbox,
+    const uint64_t* __restrict__ tile_lanes, const uint64_t* __restrict__ mask_tiles, int T, uint64_t* __restrict__ keys)
 {
     const int b = blockIdx.x, lane = threadIdx.x, h = lane >> 5, j = lane & 31;
-    const int pair = __builtin_amdgcn_readfirstlane(order[blockIdx.y >> 1]);      // launch order over 128-blocks
-    const int sub = pair >> 16, qb = (pair & 0xffff) * 2 + (blockIdx.y & 1);
+    const int qb = blockIdx.y / kTileWaves, wave = blockIdx.y % kTileWaves;
+    if (qb * kTreeCols >= V) return;
     const float* pb = prow + (size_t)b * Vp * 3;
     const int i0 = qb * kTreeCols + lane;
     uint64_t* kb = keys + (size_t)b * Vp;
     const uint64_t init = __hip_atomic_load(kb + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     Column c;                                                                    // own column: lane <-> column i0
     c.px = pb[3 * i0]; c.py = pb[3 * i0 + 1]; c.pz = pb[3 * i0 + 2];
-    c.best = __uint_as_float((uint32_t)(init >> 32));
+    c.best = i0 < V ? __uint_as_float((uint32_t)(init >> 32)) : 0.0f;
     c.arg = 0;
-    const int first = __builtin_amdgcn_readfirstlane(sub_leaf[2 * sub]), count = __builtin_amdgcn_readfirstlane(sub_leaf[2 * sub + 1]);
-    const uint64_t alive = masked[(size_t)qb * N + __builtin_amdgcn_readfirstlane(frontier[sub])];
-    if (alive == 0) return;
-    float reach2 = ((alive >> lane) & 1) ? c.best : 0.0f;
+    float reach2 = c.best;
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) reach2 = fmaxf(reach2, __shfl_xor(reach2, m));
     const float* cbx = colbox + ((size_t)b * (Vp / kTreeCols) + qb) * 8;
@@ -949,27 +976,27 @@ __global__ __launch_bounds__(64) void v2v_mfma_kernel(
         const uint64_t k = __hip_atomic_load(kb + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const float bound = __uint_as_float((uint32_t)(k >> 32));
         const float kf = bound + offset_of(x, y, z);
-        bestkey[s] = bound < __builtin_inff() ? (__float_as_int(__builtin_fmaf(kf, 4e-6f, kf) + 4e-6f * R2 + 1e-12f) | 15) : 0x7f000000;
+        bestkey[s] = col < V && bound < __builtin_inff() ? (__float_as_int(__builtin_fmaf(kf, 4e-6f, kf) + 4e-6f * R2 + 1e-12f) | 15)
+                                                          : 0x7f000000;
     }
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const float* lb = leafbox + ((size_t)b * L + first) * 8;
-    const uint64_t* ml = masked_leaf + (size_t)qb * L + first;
-    for (int base = 0; base < count; base += 64) {
-        const int li = base + lane;
+    const float* tb = tilebox + (size_t)b * T * 8;
+    const uint64_t* tl = tile_lanes + (size_t)qb * T;
+    for (int base = wave; base < T; base += 64 * kTileWaves) {
+        // one tile per lane: the gap between its box and the block's, against the largest bound
+        const int t = base + kTileWaves * lane;
         bool cand = false;
-        float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;   // box; hi.w = row range of the leaf
+        float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
         uint64_t lanes_of = 0;
-        int tile0 = 0;
-        if (li < count) {
-            lo = *reinterpret_cast<const float4*>(lb + (size_t)li * 8);
-            hi = *reinterpret_cast<const float4*>(lb + (size_t)li * 8 + 4);
-            lanes_of = ml[li];
-            tile0 = leaf_tile[first + li];
+        if (t < T) {
+            lo = *reinterpret_cast<const float4*>(tb + (size_t)t * 8);
+            hi = *reinterpret_cast<const float4*>(tb + (size_t)t * 8 + 4);
+            lanes_of = tl[t];
             const float ex = fmaxf(fmaxf(lo.x - chx, clx - hi.x), 0.0f);
             const float ey = fmaxf(fmaxf(lo.y - chy, cly - hi.y), 0.0f);
             const float ez = fmaxf(fmaxf(lo.z - chz, clz - hi.z), 0.0f);
             const float g = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) * kPruneSlack;
-            cand = g <= reach2 && (lanes_of & alive) != 0;
+            cand = g <= reach2 && lanes_of != 0;
         }
         unsigned long long todo = __builtin_amdgcn_ballot_w64(cand);
         while (todo) {
@@ -984,35 +1011,31 @@ __global__ __launch_bounds__(64) void v2v_mfma_kernel(
             const float dz = c.pz - __builtin_amdgcn_fmed3f(c.pz, b2, b6);
             const float g = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) * kPruneSlack;
             if ((__builtin_amdgcn_ballot_w64(g <= c.best) & lanes) == 0) continue;
-            const int leaf = __float_as_int(from(hi.w)), nrows = leaf >> 20;
-            const int t0 = __builtin_amdgcn_readlane(tile0, u);
-            for (int tt = 0; 32 * tt < nrows; ++tt) {                 // (one tile unless the leaf has more than 32 rows)
-                const int row0 = (leaf & 0xfffff) + 32 * tt, nr = min(32, nrows - 32 * tt);
-                // the tile's rows as the A operand (lane l <-> row l & 31; l >> 5 picks the k index)
-                const int r = row0 + min(j, nr - 1);
-                const float ux = pb[3 * r] - cx, uy = pb[3 * r + 1] - cy, uz = pb[3 * r + 2] - cz;
-                const float nrm = j < nr ? __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux)) + R2 : 1e30f;
-                const float A1 = h ? uy : ux, A2 = h ? nrm : uz;
-                f32x16 acc[2];
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B1[0], zero, 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B1[1], zero, 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A2, B2[0], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A2, B2[1], acc[1], 0, 0, 0);
-                const uint64_t* mt = mask_tiles + ((size_t)qb * T + (t0 + tt)) * 32;
+            const int tile = base + kTileWaves * u, row0 = 32 * tile;
+            // the tile's rows as the A operand (lane l <-> row l & 31; l >> 5 picks the k index)
+            const int r = row0 + j;
+            const float ux = pb[3 * r] - cx, uy = pb[3 * r + 1] - cy, uz = pb[3 * r + 2] - cz;
+            const float nrm = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux)) + R2;
+            const float A1 = h ? uy : ux, A2 = h ? nrm : uz;
+            f32x16 acc[2];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B1[0], zero, 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B1[1], zero, 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A2, B2[0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A2, B2[1], acc[1], 0, 0, 0);
+            const uint64_t* mt = mask_tiles + ((size_t)qb * T + tile) * 32;
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    int key[16];
+            for (int s = 0; s < 2; ++s) {
+                int key[16];
 #pragma unroll
-                    for (int a = 0; a < 16; ++a)
-                        key[a] = select_key(0x7f000000, (__float_as_int(acc[s][a]) & ~15) | a, mt[16 * s + a]);
-                    int m = min(min(key[0], key[1]), key[2]);
+                for (int a = 0; a < 16; ++a)
+                    key[a] = select_key(0x7f000000, (__float_as_int(acc[s][a]) & ~15) | a, mt[16 * s + a]);
+                int m = min(min(key[0], key[1]), key[2]);
 #pragma unroll
-                    for (int a = 3; a < 15; a += 2) m = min(min(m, key[a]), key[a + 1]);
-                    m = min(m, key[15]);
-                    const bool better = m < bestkey[s];
-                    bestkey[s] = better ? m : bestkey[s];
-                    brow[s] = better ? row0 : brow[s];
-                }
+                for (int a = 3; a < 15; a += 2) m = min(min(m, key[a]), key[a + 1]);
+                m = min(m, key[15]);
+                const bool better = m < bestkey[s];
+                bestkey[s] = better ? m : bestkey[s];
+                brow[s] = better ? row0 : brow[s];
             }
             // the own columns' bounds: smaller of the two halves' keys
             const auto sw = __builtin_amdgcn_permlane32_swap((uint32_t)bestkey[0], (uint32_t)bestkey[1], false, false);
@@ -1067,7 +1090,7 @@ __global__ __launch_bounds__(kBlock) void v2v_tree_finalize_kernel(
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-struct TreeV2VLayout { size_t prow, bounds, keys, leafbox, colbox, prow_g, total; };
+struct TreeV2VLayout { size_t prow, bounds, keys, leafbox, colbox, prow_g, tilebox, total; };
 
 TreeV2VLayout tree_v2v_layout(const tuch_contact_model* m, int B)
 {
@@ -1080,6 +1103,7 @@ TreeV2VLayout tree_v2v_layout(const tuch_contact_model* m, int B)
     l.leafbox = tuch_ws_take(o, ((size_t)B * m->tree_leaves + kLeafBatch) * 8 * sizeof(float));     // + a batch of padding
     l.colbox = tuch_ws_take(o, (size_t)B * 2 * m->tree_qblocks * 8 * sizeof(float));
     l.prow_g = tuch_ws_take(o, ((size_t)B * m->tree_groups * 12 + 16) * sizeof(float));     // (+ a trip's read-ahead)
+    l.tilebox = tuch_ws_take(o, (size_t)B * 4 * m->tree_qblocks * 8 * sizeof(float));
     l.total = o;
     return l;
 }
@@ -1229,7 +1253,8 @@ extern "C" int tuch_v2v_min_model_shared(const tuch_contact_model* m, const floa
                        (const int32_t*)m->tree_v2v_info);
     hipLaunchKernelGGL(v2v_seed_kernel, dim3(B, 2 * m->tree_qblocks), dim3(64), 0, s, (const float*)prow, V, Vp,
                        (const uint64_t*)m->tree_mask_bits, nodes, (const int32_t*)m->tree_rows, (const float*)bounds,
-                       (const uint64_t*)m->tree_masked, N, (const int32_t*)hint_inout, keys, scan >= 2 ? colbox : (float*)nullptr);
+                       (const uint64_t*)m->tree_masked, N, (const int32_t*)hint_inout, keys, scan >= 2 ? colbox : (float*)nullptr,
+                       scan == 3 ? (float*)(ws + l.tilebox) : (float*)nullptr);
     const int f = choose_v2v_frontier(m, B);
     const int f0 = m->tree_frontier_off_host[f], nsub = m->tree_frontier_off_host[f + 1] - f0;
     // leave_room: an unused LDS allocation caps the walk at 25 of a CU's 32 wave slots.  The walk is one grid of 220 k
@@ -1239,12 +1264,9 @@ extern "C" int tuch_v2v_min_model_shared(const tuch_contact_model* m, const floa
     // walk is 10 % slower with the cap (0.28 -> 0.31 ms), hence a flag (TUCH_V2V_LDS: bytes, to compare).
     const int lds_pad = leave_room && m->opt.v2v_lds > 0 ? m->opt.v2v_lds : 0;
     if (scan == 3)
-        hipLaunchKernelGGL(v2v_mfma_kernel, dim3(B, 2 * nsub * m->tree_qblocks), dim3(64), 0, s, (const float*)prow, V, Vp,
-                           (const float*)leafbox, (const float*)colbox, (const uint64_t*)m->tree_masked_leaf,
-                           (const uint64_t*)m->tree_masked, (const uint64_t*)m->tree_mask_tiles,
-                           (const int32_t*)m->tree_leaf_tile, m->tree_tiles, N, m->tree_leaves,
-                           (const int32_t*)m->tree_frontier_nodes + f0, (const int32_t*)m->tree_sub_leaf + 2 * (size_t)f0,
-                           (const int32_t*)m->tree_launch_order + (size_t)f0 * m->tree_qblocks, keys);
+        hipLaunchKernelGGL(v2v_mfma_kernel, dim3(B, 2 * m->tree_qblocks * kTileWaves), dim3(64), 0, s, (const float*)prow, V, Vp,
+                           (const float*)(ws + l.tilebox), (const float*)colbox, (const uint64_t*)m->tree_tile_lanes,
+                           (const uint64_t*)m->tree_mask_tiles, m->tree_tiles, keys);
     else if (scan == 2 && leave_room && m->opt.v2v_lds < 0)
         hipLaunchKernelGGL(v2v_scan_shared_kernel, dim3(B, 2 * nsub * m->tree_qblocks), dim3(64), 0, s, (const float*)prow,
                            V, Vp, (const uint64_t*)m->tree_mask_bits, (const float*)leafbox, (const float*)colbox,
