@@ -98,7 +98,7 @@ def profile_constants():
         if not all(os.path.exists(f) for f in files.values()):
             continue
         rows = {k: _pmc_rows(f) for k, f in files.items()}
-        for key, names in (('search', ('v2v_scan_kernel', 'v2v_leaves_kernel', 'v2v_tree_kernel')), ('ray_leaf_kernel', ('ray_leaf_kernel',))):
+        for key, names in (('search', ('v2v_scan_shared_kernel', 'v2v_scan_kernel', 'v2v_mfma_kernel', 'v2v_leaves_kernel', 'v2v_tree_kernel')), ('ray_leaf_kernel', ('ray_leaf_kernel',))):
             pick = lambda table: next(((k, c) for n in names for k, c in table.items() if n in k), (None, None))
             (kname, fe), (_, wr), (_, sq) = pick(rows['fetch']), pick(rows['write']), pick(rows['sq'])
             if fe and wr and sq and sq.get('GRBM_GUI_ACTIVE'):
@@ -428,7 +428,8 @@ def rooflines(p, batch):
     compact_bytes = batch * (12 * v + 8 * v) + v * v // 8         # layout (ii): bit-packed mask read once
     prof = profile_constants()
     prof_v = prof['search']
-    roof = {'kernel': 'v2v_scan_kernel (+ v2v_rows, tree_inner_bounds, v2v_seed, v2v_tree_finalize)', 'bound': 'valu',
+    roof = {'kernel': 'v2v_scan_kernel (+ v2v_rows, tree_inner_bounds, v2v_seed, v2v_tree_finalize; beside the inside test: '
+                      'v2v_scan_shared_kernel, the same code capped at 6 wavefronts per SIMD)', 'bound': 'valu',
             'achieved': round(ach_v, 2), 'peak': PEAK_FP32_VECTOR_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(ach_v / PEAK_FP32_VECTOR_TFLOPS, 4),
             'traffic': prof_v['traffic_bytes'] if batch == BATCH_PER_GPU else None,

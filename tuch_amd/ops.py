@@ -556,9 +556,11 @@ class ContactModel:
         self._h = None
         self._faces_i32 = None
         # host-side switches, read from the environment once (like the library's own, tuch_contact_model_set_option):
-        # overlap = search on a second stream beside the inside test, v2v_hint = partner hints kept between calls
+        # overlap = search on a second stream beside the inside test, v2v_hint = partner hints kept between calls,
+        # inside_first = the inside test's chain is enqueued before the search
         self._py_options = {'overlap': int(os.environ.get('TUCH_OVERLAP', '1') != '0'),
-                            'v2v_hint': int(os.environ.get('TUCH_V2V_HINT', '1') != '0')}
+                            'v2v_hint': int(os.environ.get('TUCH_V2V_HINT', '1') != '0'),
+                            'inside_first': int(os.environ.get('TUCH_INSIDE_FIRST', '1') != '0')}
         self._pending_options = {}
 
     @property
@@ -654,12 +656,21 @@ class ContactModel:
         cur = torch.cuda.current_stream(verts.device)
         side = _side_stream(verts.device)
         side.wait_stream(cur)
+        # (while a graph is being captured the order of the two branches is the round-2 one: a replayed graph starts its
+        # branches together, and the step at batch 8 was 3 % slower with the chain captured first)
+        first = self._py_options.get('inside_first', 0) and not torch.cuda.is_current_stream_capturing()
+        if first:
+            # eager launches: the inside test's chain FIRST (the side stream waits only for what was enqueued before its
+            # wait above).  Launched behind the search, the chain's small head kernels find every wave slot taken by the
+            # search's 55 k one-wave workgroups and only get going when it is done (ray_leaf_bounds: 119 us instead of 14)
+            exterior = self.exterior_flags(verts, apply_segments=apply_segments)
         with torch.cuda.stream(side):
             mn, partner = self.v2v_min(verts, leave_room=True)
             # (the caller's extra work -- region pairs, reprojection + prior -- FIRST, beside the short head of the inside
             # test's chain, was measured: 0.587 against 0.552 ms per step; it delays the search, which the chain waits for)
             extra = also() if also is not None else None
-        exterior = self.exterior_flags(verts, apply_segments=apply_segments)
+        if not first:
+            exterior = self.exterior_flags(verts, apply_segments=apply_segments)
         cur.wait_stream(side)
         for t in (mn, partner) + (tuple(extra) if isinstance(extra, (tuple, list)) else (extra,)):
             if torch.is_tensor(t):
