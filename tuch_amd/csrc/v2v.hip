@@ -609,7 +609,9 @@ __global__ __launch_bounds__(64) void v2v_seed_kernel(
     const int32_t* __restrict__ hint,            // [B,Vp] a row per column (tree order) from an earlier call, or nullptr
     uint64_t* __restrict__ keys,                 // [B,Vp]
     float* __restrict__ colbox,                  // [B][column blocks][8] or nullptr: the box of the block's 64 columns
-    float* __restrict__ tilebox)                 // [B][2 * column blocks][8] or nullptr: the boxes of its two 32-row halves
+    float* __restrict__ tilebox,                 // [B][2 * column blocks][8] or nullptr: the boxes of its two 32-row halves
+    const float* __restrict__ leafbox,           // [B][L][8] + masked_leaf [column blocks][L]: the leaf to seed from is found
+    const uint64_t* __restrict__ masked_leaf, int L)   // among the leaves themselves (no inner boxes needed), or nullptr
 {
     const int b = blockIdx.x, qb = blockIdx.y, lane = threadIdx.x;
     const float* pb = prow + (size_t)b * Vp * 3;
@@ -681,6 +683,42 @@ __global__ __launch_bounds__(64) void v2v_seed_kernel(
                 lo[k] = fminf(lo[k], __shfl_xor(lo[k], m));
                 hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m));
             }
+        if (leafbox) {
+            // flat form: one leaf per lane, the nearest of those that hold an allowed row for a column still without a
+            // bound (any admissible rows make a valid seed; the leaf scans do not need the inner nodes' boxes at all, so
+            // tree_inner_bounds_kernel is no longer in their chain)
+            const uint64_t need = mk[0] & ~__builtin_amdgcn_ballot_w64(have);
+            const float inf = __builtin_inff();
+            float gbest = inf;
+            int lbest = 0x7fffffff;
+            for (int base = 0; base < L; base += 64) {
+                const int li = base + lane;
+                float g = inf;
+                if (li < L && (masked_leaf[(size_t)qb * L + li] & need) != 0) {
+                    const float* box = leafbox + ((size_t)b * L + li) * 8;
+                    g = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const float e = fmaxf(fmaxf(box[k] - hi[k], lo[k] - box[4 + k]), 0.0f);
+                        g = fmaf(e, e, g);
+                    }
+                }
+                if (g < gbest) { gbest = g; lbest = li; }
+            }
+            float gmin = gbest;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) gmin = fminf(gmin, __shfl_xor(gmin, m));
+            if (gmin < inf) {
+                int pick = gbest == gmin ? lbest : 0x7fffffff;          // the smallest leaf index among the nearest
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) pick = min(pick, __shfl_xor(pick, m));
+                pick = __builtin_amdgcn_readfirstlane(pick);
+                const int range = __builtin_amdgcn_readfirstlane(__float_as_int(leafbox[((size_t)b * L + pick) * 8 + 7]));
+                v2v_rows(c, pb, bits + (size_t)qb * V, range & 0xfffff, range >> 20);
+            }
+            keys[(size_t)b * Vp + i0] = v2v_key(c.best, c.arg);
+            return;
+        }
         const float* bb = bounds + (size_t)b * N * 8;
         auto gap2 = [&](int node) {                 // squared distance between the block's box and the node's box
             const float* box = bb + (size_t)node * 8;
@@ -1248,13 +1286,15 @@ extern "C" int tuch_v2v_min_model_shared(const tuch_contact_model* m, const floa
                        (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, N, prow, bounds,
                        flat ? leafbox : (float*)nullptr, (const int32_t*)m->tree_leaf_group,
                        scan == 2 ? (float*)(ws + l.prow_g) : (float*)nullptr, m->tree_groups);
-    hipLaunchKernelGGL(tree_inner_bounds_kernel<4>, dim3(B), dim3(kBoundsBlock), tree_inner_bounds_lds<4>(N), s, nodes, N,
-                       (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, m->tree_heights, bounds,
-                       (const int32_t*)m->tree_v2v_info);
+    if (scan < 2)      // (the leaf scans seed from the leaf boxes and never look at an inner node)
+        hipLaunchKernelGGL(tree_inner_bounds_kernel<4>, dim3(B), dim3(kBoundsBlock), tree_inner_bounds_lds<4>(N), s, nodes, N,
+                           (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, m->tree_heights, bounds,
+                           (const int32_t*)m->tree_v2v_info);
     hipLaunchKernelGGL(v2v_seed_kernel, dim3(B, 2 * m->tree_qblocks), dim3(64), 0, s, (const float*)prow, V, Vp,
                        (const uint64_t*)m->tree_mask_bits, nodes, (const int32_t*)m->tree_rows, (const float*)bounds,
                        (const uint64_t*)m->tree_masked, N, (const int32_t*)hint_inout, keys, scan >= 2 ? colbox : (float*)nullptr,
-                       scan == 3 ? (float*)(ws + l.tilebox) : (float*)nullptr);
+                       scan == 3 ? (float*)(ws + l.tilebox) : (float*)nullptr, scan >= 2 ? (const float*)leafbox : (const float*)nullptr,
+                       (const uint64_t*)m->tree_masked_leaf, m->tree_leaves);
     const int f = choose_v2v_frontier(m, B);
     const int f0 = m->tree_frontier_off_host[f], nsub = m->tree_frontier_off_host[f + 1] - f0;
     // leave_room: an unused LDS allocation caps the walk at 25 of a CU's 32 wave slots.  The walk is one grid of 220 k

@@ -656,13 +656,13 @@ class ContactModel:
         cur = torch.cuda.current_stream(verts.device)
         side = _side_stream(verts.device)
         side.wait_stream(cur)
-        # (while a graph is being captured the order of the two branches is the round-2 one: a replayed graph starts its
-        # branches together, and the step at batch 8 was 3 % slower with the chain captured first)
-        first = self._py_options.get('inside_first', 0) and not torch.cuda.is_current_stream_capturing()
+        first = self._py_options.get('inside_first', 0)
         if first:
-            # eager launches: the inside test's chain FIRST (the side stream waits only for what was enqueued before its
-            # wait above).  Launched behind the search, the chain's small head kernels find every wave slot taken by the
-            # search's 55 k one-wave workgroups and only get going when it is done (ray_leaf_bounds: 119 us instead of 14)
+            # the inside test's chain FIRST (the side stream waits only for what was enqueued before its wait above).
+            # Launched -- or captured -- behind the search, the chain's small head kernels find every wave slot taken by
+            # the search's 55 k one-wave workgroups and only get going when it is done (eager: ray_leaf_bounds 119 us
+            # instead of 14; replayed graph at batch 8: 0.240 against 0.213 ms once tree_inner_bounds_kernel no longer
+            # delays the search's start)
             exterior = self.exterior_flags(verts, apply_segments=apply_segments)
         with torch.cuda.stream(side):
             mn, partner = self.v2v_min(verts, leave_room=True)
