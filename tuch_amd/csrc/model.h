@@ -135,12 +135,12 @@ struct tuch_contact_model {
     // 0 for a padding row)
     int32_t* tree_leaf_group;
     uint64_t* tree_mask_bits_g;
-    // matrix-core form (v2v.hip: v2v_mfma_kernel): the rows in tree order in aligned tiles of 32; per (column block, tile) 32
-    // lane masks = [sub-tile][accumulator register] -> {row i of the tile for columns 32 s .. 32 s + 31 | row i + 4}, and
+    // matrix-core form (v2v.hip: v2v_mfma_kernel): the rows in tree order in aligned tiles of 16; per (column block, tile) 16
+    // lane masks = [group of 16 columns][accumulator register r] -> row r + 4 q of the tile for the lanes of quarter q, and
     // the columns with any admissible row in the tile
-    uint64_t* tree_mask_tiles;   // [2 * tree_qblocks][tree_tiles][32]
+    uint64_t* tree_mask_tiles;   // [2 * tree_qblocks][tree_tiles][16]
     uint64_t* tree_tile_lanes;   // [2 * tree_qblocks][tree_tiles]
-    int tree_tiles;              // 4 * tree_qblocks
+    int tree_tiles;              // 8 * tree_qblocks
     int tree_groups;
     int tree_num_frontiers;
     int tree_leaf_runs_tile;       // 1: the leaves' strip runs [ex_off, ex_off + ex_len) tile [0, tree_exact_len) without gaps

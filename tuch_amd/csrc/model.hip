@@ -221,24 +221,23 @@ extern "C" int tuch_contact_model_create(
                     m->tree_groups = G;
                     if (rc == TUCH_OK) rc = upload(&m->tree_leaf_group, group.data(), group.size());
                     if (rc == TUCH_OK) rc = upload(&m->tree_mask_bits_g, bits_g.data(), bits_g.size());
-                    // matrix-core form: the rows in tree order in aligned tiles of 32; lane masks per (column block, tile,
-                    // sub-tile s, accumulator register a): low word = columns 32 s .. 32 s + 31 against row i = (a & 3) +
-                    // 8 (a >> 2) of the tile, high word = against row i + 4; and per (column block, tile) the columns with
-                    // any admissible row in the tile
+                    // matrix-core form: the rows in tree order in aligned tiles of 16; lane masks per (column block, tile,
+                    // column group g of 16 columns, accumulator register r): the lanes of quarter q see row r + 4 q of the
+                    // tile against columns 16 g .. 16 g + 15; and per (column block, tile) the columns with any admissible row
                     if (rc == TUCH_OK) {
-                        const int T = 4 * t.num_qblocks;
-                        std::vector<uint64_t> tiles((size_t)Wp * T * 32, 0), any((size_t)Wp * T, 0);
+                        const int T = 8 * t.num_qblocks;
+                        std::vector<uint64_t> tiles((size_t)Wp * T * 16, 0), any((size_t)Wp * T, 0);
                         for (int qb = 0; qb < Wp; ++qb) {
                             auto word = [&](int k) { return k < V ? bits[(size_t)qb * V + k] : (uint64_t)0; };
                             for (int tt = 0; tt < T; ++tt) {
                                 uint64_t all = 0;
-                                for (int k = 0; k < 32; ++k) all |= word(32 * tt + k);
+                                for (int k = 0; k < 16; ++k) all |= word(16 * tt + k);
                                 any[(size_t)qb * T + tt] = all;
-                                for (int sx = 0; sx < 2; ++sx)
-                                    for (int a = 0; a < 16; ++a) {
-                                        const int r0 = 32 * tt + (a & 3) + 8 * (a >> 2);
-                                        const uint64_t w0 = (word(r0) >> (32 * sx)) & 0xffffffffull, w1 = (word(r0 + 4) >> (32 * sx)) & 0xffffffffull;
-                                        tiles[((size_t)qb * T + tt) * 32 + 16 * sx + a] = w0 | (w1 << 32);
+                                for (int g = 0; g < 4; ++g)
+                                    for (int r = 0; r < 4; ++r) {
+                                        uint64_t w = 0;
+                                        for (int q = 0; q < 4; ++q) w |= ((word(16 * tt + r + 4 * q) >> (16 * g)) & 0xffffull) << (16 * q);
+                                        tiles[((size_t)qb * T + tt) * 16 + 4 * g + r] = w;
                                     }
                             }
                         }

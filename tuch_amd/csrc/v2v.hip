@@ -623,28 +623,30 @@ __global__ __launch_bounds__(64) void v2v_seed_kernel(
     if (colbox) {
         float lo[3] = {c.px, c.py, c.pz}, hi[3] = {c.px, c.py, c.pz};
         if (tilebox) {
-            // the matrix-core form walks the rows in aligned tiles of 32 (= half a column block): their boxes, rows behind
-            // the last vertex left out
+            // the matrix-core form walks the rows in aligned tiles of 16 (= a quarter of a column block): their boxes, rows
+            // behind the last vertex left out
             const bool real = i0 < V;
             const float inf = __builtin_inff();
 #pragma unroll
             for (int k = 0; k < 3; ++k) { lo[k] = real ? lo[k] : inf; hi[k] = real ? hi[k] : -inf; }
 #pragma unroll
-            for (int m = 16; m >= 1; m >>= 1)
+            for (int m = 8; m >= 1; m >>= 1)
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     lo[k] = fminf(lo[k], __shfl_xor(lo[k], m));
                     hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m));
                 }
-            if ((lane & 31) == 0) {
-                float* o = tilebox + ((size_t)b * gridDim.y * 2 + 2 * qb + (lane >> 5)) * 8;
+            if ((lane & 15) == 0) {
+                float* o = tilebox + ((size_t)b * gridDim.y * 4 + 4 * qb + (lane >> 4)) * 8;
                 o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = 0.0f; o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = 0.0f;
             }
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                lo[k] = fminf(lo[k], __shfl_xor(lo[k], 32));
-                hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], 32));
-            }
+            for (int m = 32; m >= 16; m >>= 1)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    lo[k] = fminf(lo[k], __shfl_xor(lo[k], m));
+                    hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m));
+                }
         } else {
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1)
@@ -951,22 +953,29 @@ __device__ __forceinline__ void v2v_scan_body(
 }
 
 // Fourth form: the rows on the MATRIX CORES (the idea of hd_search.hip), no tree.  The rows in tree order are cut into
-// aligned tiles of 32 (compact patches: half a column block each; boxes left by v2v_seed_kernel); a wavefront owns 64
-// columns and a quarter of the tiles: lane <-> tile for the tile's box against the block's box and the largest bound in
-// it (+ the static table of the columns with ANY admissible row in the tile), the survivors against every column's own
-// bound, and what is left as two 32 x 32 products of v_mfma_f32_32x32x2_f32 per tile: |q'|^2 + R^2 - 2 p'.q' in
-// coordinates relative to the centre of the column block (exact f32 fma chains).  Full tiles: the leaves of the cluster
-// tree hold ~16 rows and would half-fill them (measured: 197 us against 162 us for the leaf scan), aligned tiles prune a
-// little coarser and waste nothing.  The mask of a tile comes as ready-made lane masks:
-// tree_mask_tiles[column block][tile][sub-tile][accumulator register] holds the two rows an accumulator register spans
-// (row i for lanes 0-31, row i + 4 for lanes 32-63), so an inadmissible pair is one v_cndmask away; what is left per value
-// is the row's place in the low four mantissa bits (v_and_or) and half a v_min3_i32.
+// aligned tiles of 16 (compact patches: a quarter of a column block each; boxes left by v2v_seed_kernel); a wavefront
+// owns 64 columns and a quarter of the tiles: lane <-> tile for the tile's box against the block's box and the largest
+// bound in it (+ the static table of the columns with ANY admissible row in the tile), the survivors against every
+// column's own bound, and what is left as four products of v_mfma_f32_16x16x4_f32 per tile (16 rows x 16 columns each, the
+// whole K = 4 in one instruction: no dependent chain): |q'|^2 + R^2 - 2 p'.q' in coordinates relative to the centre of the
+// column block (exact f32 fma chains).  Tiles of 16 rows because that is what the pruning wants: the leaves of the cluster
+// tree hold ~16 rows -- one 32 x 32 tile per leaf is half empty (measured: 197 us against 162 us for the leaf scan), and
+// aligned tiles of 32 prune coarser (31 % of all pairs instead of 16 %: 187 us).  MEASURED: identical partners on every
+// fixture, and 199 us -- 21 % of the pairs, 2.5 M MFMAs, but 8.9e7 vector instructions (the scan: 7.8e7): ~140 per
+// 16 x 64 tile, of which the four products' keys are 52 and everything around them (the candidate's box from its lane,
+// the per-column test, the rows' operand, tiles that fail the test) the rest.  The scan's row step -- mask word = lane
+// mask, 10.5 instructions per row of 64 columns -- leaves the matrix cores nothing to win here, unlike the HD search whose
+// mask and row bookkeeping dominated.  Opt-in (v2v_flat = 3), kept as the measured alternative.  The mask of a tile comes as ready-made
+// lane masks: tree_mask_tiles[column block][tile][column group][accumulator register] holds the four rows an accumulator
+// register spans (row r + 4 q for the lanes of quarter q), so an inadmissible pair is one v_cndmask away; what is left per
+// value is the row's place in the low two mantissa bits (v_and_or) and a share of a v_min3_i32.
 // The rows found this way are CANDIDATES: their distances are recomputed by direct differences and merged into the same
 // 64-bit (distance, row) keys with atomicMin -- the result differs from the other forms only where two rows of one
-// (column block, quarter) tie within the 20-bit key (~1e-6 relative), which the reference's own bmm-form distances cannot
-// tell apart either.
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+// (column block, quarter of the tiles) tie within the 22-bit key (~5e-7 relative), which the reference's own bmm-form
+// distances cannot tell apart either.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kTileWaves = 4;             // wavefronts per column block: they share out the row tiles
+constexpr int kTileRows = 16;
 __device__ __forceinline__ int select_key(int if_clear, int if_set, uint64_t lane_mask)
 {
     int r;
@@ -977,7 +986,7 @@ __global__ __launch_bounds__(64) void v2v_mfma_kernel(
     const float* __restrict__ prow, int V, int Vp, const float* __restrict__ tilebox, const float* __restrict__ colbox,
     const uint64_t* __restrict__ tile_lanes, const uint64_t* __restrict__ mask_tiles, int T, uint64_t* __restrict__ keys)
 {
-    const int b = blockIdx.x, lane = threadIdx.x, h = lane >> 5, j = lane & 31;
+    const int b = blockIdx.x, lane = threadIdx.x, q = lane >> 4, j = lane & 15;
     const int qb = blockIdx.y / kTileWaves, wave = blockIdx.y % kTileWaves;
     if (qb * kTreeCols >= V) return;
     const float* pb = prow + (size_t)b * Vp * 3;
@@ -1002,24 +1011,39 @@ __global__ __launch_bounds__(64) void v2v_mfma_kernel(
         return R2 - __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
     };
     const float own_o = offset_of(c.px, c.py, c.pz);
-    float B1[2], B2[2];
-    int bestkey[2], brow[2] = {-1, -1};
+    // matrix layout of column group g (columns 16 g ... 16 g + 15): lane l <-> column 16 g + (l & 15); the k index of both
+    // operands is l >> 4; accumulator register r of lane l is row r + 4 (l >> 4) of the tile
+    float Bop[4];
+    int bestkey[4], brow[4] = {-1, -1, -1, -1};
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const int col = qb * kTreeCols + 32 * s + j;
+    for (int g = 0; g < 4; ++g) {
+        const int col = qb * kTreeCols + 16 * g + j;
         const float x = pb[3 * col], y = pb[3 * col + 1], z = pb[3 * col + 2];
-        B1[s] = h ? -2.0f * (y - cy) : -2.0f * (x - cx);
-        B2[s] = h ? 1.0f : -2.0f * (z - cz);
+        Bop[g] = q == 0 ? -2.0f * (x - cx) : q == 1 ? -2.0f * (y - cy) : q == 2 ? -2.0f * (z - cz) : 1.0f;
         // nothing at or above the key of the column's current bound can improve on it
         const uint64_t k = __hip_atomic_load(kb + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const float bound = __uint_as_float((uint32_t)(k >> 32));
         const float kf = bound + offset_of(x, y, z);
-        bestkey[s] = col < V && bound < __builtin_inff() ? (__float_as_int(__builtin_fmaf(kf, 4e-6f, kf) + 4e-6f * R2 + 1e-12f) | 15)
+        bestkey[g] = col < V && bound < __builtin_inff() ? (__float_as_int(__builtin_fmaf(kf, 4e-6f, kf) + 4e-6f * R2 + 1e-12f) | 3)
                                                           : 0x7f000000;
     }
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     const float* tb = tilebox + (size_t)b * T * 8;
     const uint64_t* tl = tile_lanes + (size_t)qb * T;
+    int since = 0;
+    auto refresh = [&]() {
+        // the own columns' bounds: column l lives in group l >> 4, its candidates in the four quarters of that group
+        int m[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            m[g] = min(bestkey[g], __shfl_xor(bestkey[g], 16));
+            m[g] = min(m[g], __shfl_xor(m[g], 32));
+        }
+        const int mine = q == 0 ? m[0] : q == 1 ? m[1] : q == 2 ? m[2] : m[3];
+        const float f = __int_as_float(mine & ~3);
+        c.best = fminf(c.best, (f - own_o) + 4e-6f * (f + R2));
+        since = 0;
+    };
     for (int base = wave; base < T; base += 64 * kTileWaves) {
         // one tile per lane: the gap between its box and the block's, against the largest bound
         const int t = base + kTileWaves * lane;
@@ -1049,44 +1073,34 @@ __global__ __launch_bounds__(64) void v2v_mfma_kernel(
             const float dz = c.pz - __builtin_amdgcn_fmed3f(c.pz, b2, b6);
             const float g = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) * kPruneSlack;
             if ((__builtin_amdgcn_ballot_w64(g <= c.best) & lanes) == 0) continue;
-            const int tile = base + kTileWaves * u, row0 = 32 * tile;
-            // the tile's rows as the A operand (lane l <-> row l & 31; l >> 5 picks the k index)
+            const int tile = base + kTileWaves * u, row0 = kTileRows * tile;
+            // the tile's rows as the A operand: lane l <-> row l & 15, component l >> 4 of (x', y', z', |q'|^2 + R^2)
             const int r = row0 + j;
             const float ux = pb[3 * r] - cx, uy = pb[3 * r + 1] - cy, uz = pb[3 * r + 2] - cz;
             const float nrm = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux)) + R2;
-            const float A1 = h ? uy : ux, A2 = h ? nrm : uz;
-            f32x16 acc[2];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B1[0], zero, 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B1[1], zero, 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A2, B2[0], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A2, B2[1], acc[1], 0, 0, 0);
-            const uint64_t* mt = mask_tiles + ((size_t)qb * T + tile) * 32;
+            const float A = q == 0 ? ux : q == 1 ? uy : q == 2 ? uz : nrm;
+            const uint64_t* mt = mask_tiles + ((size_t)qb * T + tile) * 16;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                int key[16];
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A, Bop[g4], zero, 0, 0, 0);
+                int key[4];
 #pragma unroll
-                for (int a = 0; a < 16; ++a)
-                    key[a] = select_key(0x7f000000, (__float_as_int(acc[s][a]) & ~15) | a, mt[16 * s + a]);
-                int m = min(min(key[0], key[1]), key[2]);
-#pragma unroll
-                for (int a = 3; a < 15; a += 2) m = min(min(m, key[a]), key[a + 1]);
-                m = min(m, key[15]);
-                const bool better = m < bestkey[s];
-                bestkey[s] = better ? m : bestkey[s];
-                brow[s] = better ? row0 : brow[s];
+                for (int a = 0; a < 4; ++a) key[a] = select_key(0x7f000000, (__float_as_int(acc[a]) & ~3) | a, mt[4 * g4 + a]);
+                const int m = min(min(key[0], key[1]), min(key[2], key[3]));
+                const bool better = m < bestkey[g4];
+                bestkey[g4] = better ? m : bestkey[g4];
+                brow[g4] = better ? row0 : brow[g4];
             }
-            // the own columns' bounds: smaller of the two halves' keys
-            const auto sw = __builtin_amdgcn_permlane32_swap((uint32_t)bestkey[0], (uint32_t)bestkey[1], false, false);
-            const float f = __int_as_float(min((int)sw[0], (int)sw[1]) & ~15);
-            c.best = fminf(c.best, (f - own_o) + 4e-6f * (f + R2));
+            if (++since == 4) refresh();
         }
+        if (since) refresh();
     }
     // candidates -> exact keys
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        if (brow[s] < 0) continue;
-        const int a = bestkey[s] & 15, row = brow[s] + 4 * h + 8 * (a >> 2) + (a & 3);
-        const int col = qb * kTreeCols + 32 * s + j;
+    for (int g = 0; g < 4; ++g) {
+        if (brow[g] < 0) continue;
+        const int row = brow[g] + 4 * q + (bestkey[g] & 3);
+        const int col = qb * kTreeCols + 16 * g + j;
         const float dx = pb[3 * col] - pb[3 * row], dy = pb[3 * col + 1] - pb[3 * row + 1], dz = pb[3 * col + 2] - pb[3 * row + 2];
         const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
         atomicMin((unsigned long long*)(kb + col), (unsigned long long)v2v_key(d, row));
@@ -1141,7 +1155,7 @@ TreeV2VLayout tree_v2v_layout(const tuch_contact_model* m, int B)
     l.leafbox = tuch_ws_take(o, ((size_t)B * m->tree_leaves + kLeafBatch) * 8 * sizeof(float));     // + a batch of padding
     l.colbox = tuch_ws_take(o, (size_t)B * 2 * m->tree_qblocks * 8 * sizeof(float));
     l.prow_g = tuch_ws_take(o, ((size_t)B * m->tree_groups * 12 + 16) * sizeof(float));     // (+ a trip's read-ahead)
-    l.tilebox = tuch_ws_take(o, (size_t)B * 4 * m->tree_qblocks * 8 * sizeof(float));
+    l.tilebox = tuch_ws_take(o, (size_t)B * 8 * m->tree_qblocks * 8 * sizeof(float));
     l.total = o;
     return l;
 }
