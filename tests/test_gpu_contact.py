@@ -1097,6 +1097,43 @@ def test_ray_crossing_flags_of_points_match_the_solid_angle_sums(tag, monkeypatc
     assert len(np.unique(w_r)) >= 2                                                # inside and outside points both occur
 
 
+def test_hd_gradient_is_bit_reproducible_in_deterministic_mode():
+    """ops.set_deterministic(True): the HD branch's point gradients are summed as 64-bit fixed-point integers (LDS integer
+    atomics) and gathered per vertex in a fixed order -- the gradient of contact_loss(use_hd=True) is the same BITS every
+    time, and agrees with the float-atomic one to float tolerance."""
+    import types
+    from tuch_amd import ops
+    from tuch_amd.train.loss import RegressorLoss
+    from tuch_amd.utils.segmentation import BatchBodySegment
+    g, gm = golden('medium'), golden_mask('medium')
+    d = dev()
+    batch = g['verts'].shape[0]
+    face_tensor = torch.tensor(g['faces'], device=d)[None].repeat(batch, 1, 1)
+    segs = gio.unpack_segments(g)
+    crit = RegressorLoss(types.SimpleNamespace(contact_loss_weight=1.0), d, g['verts'].shape[1], face_tensor,
+                         torch.tensor(np.where(gm, 1.0, 0.0).astype(np.float32), device=d), geothres=0.3,
+                         euclthres=float(g['euclthres']), face_tensor=face_tensor, use_hd=True,
+                         segments=BatchBodySegment(list(segs.keys()), face_tensor[0], segs),
+                         hd_regressor=(g['hd_idx'], g['hd_w']), hd_faces=g['hd_face'])
+    valid = torch.tensor(g['valid_fit'], device=d)
+
+    def grad():
+        v = torch.tensor(g['verts'], device=d, requires_grad=True)
+        crit.contact_loss(v, valid).backward()
+        torch.cuda.synchronize()
+        return v.grad.clone()
+    plain = grad()
+    assert float(plain.abs().max()) > 0
+    ops.set_deterministic(True)
+    try:
+        runs = [grad() for _ in range(4)]
+    finally:
+        ops.set_deterministic(False)
+    for r in runs[1:]:
+        assert torch.equal(r, runs[0])
+    assert_close(runs[0].cpu().numpy(), plain.cpu().numpy(), 1e-4, 1e-6 * float(plain.abs().max()), 'deterministic vs LDS float atomics')
+
+
 @pytest.mark.parametrize('tag', SMALL)
 def test_hd_branch_selection_partners_and_graph_capture(tag):
     """The fused HD branch (csrc/hd_contact.hip): the selected HD points of every body are exactly those of the

@@ -20,6 +20,7 @@
 #include "model.h"
 #include "workspace.h"
 #include <algorithm>
+#include <type_traits>
 #include <numeric>
 #include <stdlib.h>
 #include <string.h>
@@ -242,17 +243,26 @@ __global__ __launch_bounds__(1024) void hd_terms_kernel(
 // a zeroed [B,N,3] array -- device-scope atomics on this part are resolved behind the per-XCD L2s, 1 M of them took 82 us.)
 constexpr int kGradSpan = 1024;
 constexpr int kGradBlock = 1024;
+// kFixed (deterministic mode, common.h): the sums are 64-bit fixed-point integers (LDS integer atomics: associative, so the
+// order of arrival does not matter) converted once at the end; the vertex gather behind this kernel has a fixed order
+// anyway, so the whole HD adjoint then reproduces bit for bit
+template <bool kFixed>
 __global__ __launch_bounds__(kGradBlock) void hd_grad_points_kernel(
     const float* __restrict__ pts, const int32_t* __restrict__ partner, const uint8_t* __restrict__ ext,
     const int32_t* __restrict__ counts, const float* __restrict__ gscale, int N, float* __restrict__ G)
 {
-    __shared__ float acc[3 * kGradSpan];
+    using Acc = typename std::conditional<kFixed, long long, float>::type;
+    __shared__ Acc acc[3 * kGradSpan];
     const int b = blockIdx.y, n = counts[b];
     const int lo = blockIdx.x * kGradSpan;
     if (lo >= n) return;
     const int hi = min(n, lo + kGradSpan);
-    for (int i = threadIdx.x; i < 3 * kGradSpan; i += kGradBlock) acc[i] = 0.0f;
+    for (int i = threadIdx.x; i < 3 * kGradSpan; i += kGradBlock) acc[i] = 0;
     __syncthreads();
+    auto add = [&](int i, float x) {
+        if constexpr (kFixed) atomicAdd((unsigned long long*)&acc[i], (unsigned long long)__double2ll_rn((double)x * kFixedScale));
+        else atomicAdd(&acc[i], x);
+    };
     const float* pb = pts + (size_t)b * N * 3;
     const int32_t* qb = partner + (size_t)b * N;
     const uint8_t* eb = ext + (size_t)b * N;
@@ -286,19 +296,16 @@ __global__ __launch_bounds__(kGradBlock) void hd_grad_points_kernel(
             const Term t = contact_term(d, e[u]);
             const float s = g * t.dd / d;
             const float ox = s * dx, oy = s * dy, oz = s * dz;
-            if (k[u] >= lo && k[u] < hi) {
-                float* o = acc + 3 * (k[u] - lo);
-                atomicAdd(o, ox); atomicAdd(o + 1, oy); atomicAdd(o + 2, oz);
-            }
-            if (p[u] >= lo && p[u] < hi) {
-                float* o = acc + 3 * (p[u] - lo);
-                atomicAdd(o, -ox); atomicAdd(o + 1, -oy); atomicAdd(o + 2, -oz);
-            }
+            if (k[u] >= lo && k[u] < hi) { add(3 * (k[u] - lo), ox); add(3 * (k[u] - lo) + 1, oy); add(3 * (k[u] - lo) + 2, oz); }
+            if (p[u] >= lo && p[u] < hi) { add(3 * (p[u] - lo), -ox); add(3 * (p[u] - lo) + 1, -oy); add(3 * (p[u] - lo) + 2, -oz); }
         }
     }
     __syncthreads();
     float* gb = G + 3 * ((size_t)b * N + lo);
-    for (int i = threadIdx.x; i < 3 * (hi - lo); i += kGradBlock) gb[i] = acc[i];
+    for (int i = threadIdx.x; i < 3 * (hi - lo); i += kGradBlock) {
+        if constexpr (kFixed) gb[i] = fixed_value(acc[i]);
+        else gb[i] = acc[i];
+    }
 }
 
 // adjoint of the regressor rows: a gather per vertex over the points it supports
@@ -612,9 +619,14 @@ extern "C" int tuch_hd_contact_bwd(const tuch_hd_model* hm, const void* saved, c
     scope.arm(workspace, hm->cm->canary_hits, s);
     const char* sv = (const char*)saved;
     float* G = (float*)((char*)workspace + gl.points);
-    hipLaunchKernelGGL(hd_grad_points_kernel, dim3(ceil_div(N, kGradSpan), B), dim3(kGradBlock), 0, s, (const float*)(sv + sl.pts),
-                       (const int32_t*)(sv + sl.partner), (const uint8_t*)(sv + sl.ext), (const int32_t*)(sv + sl.counts),
-                       grad_terms, N, G);
+    if (tuch_deterministic())
+        hipLaunchKernelGGL(hd_grad_points_kernel<true>, dim3(ceil_div(N, kGradSpan), B), dim3(kGradBlock), 0, s,
+                           (const float*)(sv + sl.pts), (const int32_t*)(sv + sl.partner), (const uint8_t*)(sv + sl.ext),
+                           (const int32_t*)(sv + sl.counts), grad_terms, N, G);
+    else
+        hipLaunchKernelGGL(hd_grad_points_kernel<false>, dim3(ceil_div(N, kGradSpan), B), dim3(kGradBlock), 0, s,
+                           (const float*)(sv + sl.pts), (const int32_t*)(sv + sl.partner), (const uint8_t*)(sv + sl.ext),
+                           (const int32_t*)(sv + sl.counts), grad_terms, N, G);
     hipLaunchKernelGGL(hd_grad_verts_kernel, dim3(ceil_div(V, 256), B), dim3(256), 0, s, (const float*)G,
                        (const int32_t*)(sv + sl.slot), (const int32_t*)hm->v_off, (const int32_t*)hm->v_ent,
                        (const float*)hm->w, V, N, grad_verts);
