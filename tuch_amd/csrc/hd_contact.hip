@@ -69,10 +69,14 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // the points scattered to their slots
 __global__ __launch_bounds__(256) void hd_face_flags_kernel(
     const uint8_t* __restrict__ exterior, const float* __restrict__ min_d2, const uint8_t* __restrict__ valid,
-    const int32_t* __restrict__ faces, int V, int F, float eucl2, uint8_t* __restrict__ face_flag)
+    const int32_t* __restrict__ faces, int V, int F, float eucl2, uint8_t* __restrict__ face_flag,
+    uint8_t* __restrict__ vert_flag)
 {
     const int b = blockIdx.y;
     const int f = blockIdx.x * 256 + threadIdx.x;
+    // (cleared here, set by hd_points_kernel for the vertices that support a selected point: the adjoint's gather per
+    // vertex skips the other ~85 %)
+    for (int v = f; v < V; v += gridDim.x * 256) vert_flag[(size_t)b * V + v] = 0;
     if (f >= F) return;
     bool any = false;
     if (!valid || valid[b]) {
@@ -159,7 +163,8 @@ __global__ __launch_bounds__(256) void hd_points_kernel(
     const int32_t* __restrict__ idx, const float* __restrict__ w, const int32_t* __restrict__ hd_face,
     const int32_t* __restrict__ faces, const int32_t* __restrict__ mask_id, int V, int N,
     const int32_t* __restrict__ chunk_first, const int32_t* __restrict__ by_orig, const int32_t* __restrict__ slot, int chunks,
-    int32_t* __restrict__ first_slot, float* __restrict__ pts, float* __restrict__ offs, int32_t* __restrict__ vid)
+    int32_t* __restrict__ first_slot, float* __restrict__ pts, float* __restrict__ offs, int32_t* __restrict__ vid,
+    uint8_t* __restrict__ vert_flag)
 {
     const int b = blockIdx.y;
     const int k = blockIdx.x * 256 + threadIdx.x;
@@ -179,7 +184,9 @@ __global__ __launch_bounds__(256) void hd_points_kernel(
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float wc = w[3 * (size_t)n + c];
-        const float* p = vb + 3 * (size_t)idx[3 * (size_t)n + c];
+        const int sv = idx[3 * (size_t)n + c];
+        vert_flag[(size_t)b * V + sv] = 1;
+        const float* p = vb + 3 * (size_t)sv;
         x = __builtin_fmaf(wc, p[0], x); y = __builtin_fmaf(wc, p[1], y); z = __builtin_fmaf(wc, p[2], z);
     }
     pts[3 * o] = x; pts[3 * o + 1] = y; pts[3 * o + 2] = z;
@@ -312,12 +319,13 @@ __global__ __launch_bounds__(kGradBlock) void hd_grad_points_kernel(
 __global__ __launch_bounds__(256) void hd_grad_verts_kernel(
     const float* __restrict__ G, const int32_t* __restrict__ slot,
     const int32_t* __restrict__ v_off, const int32_t* __restrict__ v_ent, const float* __restrict__ w, int V, int N,
-    float* __restrict__ grad_verts)
+    const uint8_t* __restrict__ vert_flag, float* __restrict__ grad_verts)
 {
     const int b = blockIdx.y;
     const int v = blockIdx.x * 256 + threadIdx.x;
     const bool real = v < V;                          // all lanes stay: the long lists below need the whole wavefront
-    const int e0 = real ? v_off[v] : 0, e1 = real ? v_off[v + 1] : 0;
+    const bool touched = real && vert_flag[(size_t)b * V + v] != 0;      // supports a selected point at all?
+    const int e0 = touched ? v_off[v] : 0, e1 = touched ? v_off[v + 1] : 0;
     const int32_t* sb = slot + (size_t)b * N;
     const float* gb = G + 3 * (size_t)b * N;
     float x = 0.f, y = 0.f, z = 0.f;
@@ -366,8 +374,8 @@ __global__ __launch_bounds__(256) void hd_grad_verts_kernel(
     o[0] = x; o[1] = y; o[2] = z;
 }
 
-struct Saved { size_t counts, first, sel, slot, pts, partner, ext, total; };
-Saved saved_layout(int B, int N)
+struct Saved { size_t counts, first, sel, slot, pts, partner, ext, vert_flag, total; };
+Saved saved_layout(int B, int N, int V)
 {
     Saved l;
     size_t o = 0;
@@ -378,6 +386,7 @@ Saved saved_layout(int B, int N)
     l.pts = tuch_ws_take(o, (size_t)B * N * 3 * sizeof(float));
     l.partner = tuch_ws_take(o, (size_t)B * N * sizeof(int32_t));
     l.ext = tuch_ws_take(o, (size_t)B * N);
+    l.vert_flag = tuch_ws_take(o, (size_t)B * V);
     l.total = o;
     return l;
 }
@@ -523,7 +532,7 @@ extern "C" size_t tuch_hd_contact_saved_bytes(const tuch_hd_model* hm, int B)
 {
     if (!hm || B <= 0) return 0;
     tuch_ws_scope scope(hm->cm->opt.canary != 0);
-    return saved_layout(B, hm->N).total;
+    return saved_layout(B, hm->N, hm->V).total;
 }
 
 extern "C" size_t tuch_hd_contact_workspace_bytes(const tuch_hd_model* hm, int B)
@@ -547,7 +556,7 @@ extern "C" int tuch_hd_contact_fwd(const tuch_hd_model* hm, const float* verts, 
     TUCH_REQUIRE(B > 0 && B <= kMaxBatch && (long)B * hm->N < 0x7fffffffL, "tuch_hd_contact_fwd: bad batch %d", B);
     const int N = hm->N, V = hm->V;
     tuch_ws_scope saved_scope(hm->cm->opt.canary != 0), scope(hm->cm->opt.canary != 0);
-    const Saved sl = saved_scope.record(0, [&] { return saved_layout(B, N); });
+    const Saved sl = saved_scope.record(0, [&] { return saved_layout(B, N, V); });
     const Work wl = scope.record(0, [&] { return work_layout(hm, B); });
     if (saved_bytes < sl.total || workspace_bytes < wl.total) {
         tuch_set_error("tuch_hd_contact_fwd: saved %zu < %zu or workspace %zu < %zu bytes", saved_bytes, sl.total,
@@ -574,7 +583,7 @@ extern "C" int tuch_hd_contact_fwd(const tuch_hd_model* hm, const float* verts, 
     const int chunks = ceil_div(N, kSel);
     const uint64_t* bits = hm->tree_order ? hm->cm->tree_mask_bits : hm->cm->mask_bits;
     hipLaunchKernelGGL(hd_face_flags_kernel, dim3(ceil_div(hm->F, 256), B), dim3(256), 0, s, exterior, min_d2, valid,
-                       (const int32_t*)hm->cm->faces, V, hm->F, euclthres * euclthres, flags);
+                       (const int32_t*)hm->cm->faces, V, hm->F, euclthres * euclthres, flags, (uint8_t*)(sv + sl.vert_flag));
     hipLaunchKernelGGL(hd_count_kernel, dim3(chunks, B), dim3(kSel), 0, s, (const uint8_t*)flags, (const int32_t*)hm->face,
                        (const int32_t*)hm->by_orig, hm->F, N, chunks, chunk_cnt, chunk_first);
     hipLaunchKernelGGL(hd_scatter_kernel, dim3(chunks, B), dim3(kSel), 0, s, (const uint8_t*)flags, (const int32_t*)hm->face,
@@ -583,7 +592,7 @@ extern "C" int tuch_hd_contact_fwd(const tuch_hd_model* hm, const float* verts, 
     hipLaunchKernelGGL(hd_points_kernel, pgrid, dim3(256), 0, s, verts, (const int32_t*)sel, (const int32_t*)counts,
                        (const int32_t*)hm->idx, (const float*)hm->w, (const int32_t*)hm->face,
                        (const int32_t*)hm->cm->faces, (const int32_t*)hm->mask_id, V, N, (const int32_t*)chunk_first,
-                       (const int32_t*)hm->by_orig, (const int32_t*)slot, chunks, first, pts, offs, vid);
+                       (const int32_t*)hm->by_orig, (const int32_t*)slot, chunks, first, pts, offs, vid, (uint8_t*)(sv + sl.vert_flag));
     // (seeding the search from the vertex-level partners was tried: the seeds are excellent where they exist -- median
     // ratio to the final distance 1.00 -- but the nearest admissible HD point is ~10 cm away, so a column block still has
     // to visit ~40 % of the rows, and building the seeds cost more than the sampling pass they replace)
@@ -609,7 +618,7 @@ extern "C" int tuch_hd_contact_bwd(const tuch_hd_model* hm, const void* saved, c
     TUCH_REQUIRE(B > 0 && B <= kMaxBatch, "tuch_hd_contact_bwd: bad batch %d", B);
     const int N = hm->N, V = hm->V;
     tuch_ws_scope scope(hm->cm->opt.canary != 0);
-    const Saved sl = saved_layout(B, N);
+    const Saved sl = saved_layout(B, N, hm->V);
     const Grad gl = scope.record(0, [&] { return grad_layout(B, N); });
     if (workspace_bytes < gl.total) {
         tuch_set_error("tuch_hd_contact_bwd: workspace %zu < %zu bytes", workspace_bytes, gl.total);
@@ -629,7 +638,7 @@ extern "C" int tuch_hd_contact_bwd(const tuch_hd_model* hm, const void* saved, c
                            (const int32_t*)(sv + sl.counts), grad_terms, N, G);
     hipLaunchKernelGGL(hd_grad_verts_kernel, dim3(ceil_div(V, 256), B), dim3(256), 0, s, (const float*)G,
                        (const int32_t*)(sv + sl.slot), (const int32_t*)hm->v_off, (const int32_t*)hm->v_ent,
-                       (const float*)hm->w, V, N, grad_verts);
+                       (const float*)hm->w, V, N, (const uint8_t*)(sv + sl.vert_flag), grad_verts);
     return tuch_check_launch("tuch_hd_contact_bwd");
 }
 
@@ -640,7 +649,7 @@ extern "C" int tuch_hd_contact_selection(const tuch_hd_model* hm, const void* sa
     TUCH_REQUIRE(hm && saved && counts_host, "tuch_hd_contact_selection: null pointer");
     const int N = hm->N;
     tuch_ws_scope scope(hm->cm->opt.canary != 0);        // the layout the forward call used
-    const Saved sl = saved_layout(B, N);
+    const Saved sl = saved_layout(B, N, hm->V);
     const char* sv = (const char*)saved;
     if (hipMemcpy(counts_host, sv + sl.counts, sizeof(int32_t) * B, hipMemcpyDeviceToHost) != hipSuccess) return TUCH_ERR_HIP;
     if (selected_host) {
@@ -660,7 +669,7 @@ extern "C" int tuch_hd_contact_details(const tuch_hd_model* hm, const void* save
     TUCH_REQUIRE(hm && saved && partner_host && ext_host, "tuch_hd_contact_details: null pointer");
     const int N = hm->N;
     tuch_ws_scope scope(hm->cm->opt.canary != 0);        // the layout the forward call used
-    const Saved sl = saved_layout(B, N);
+    const Saved sl = saved_layout(B, N, hm->V);
     const char* sv = (const char*)saved;
     std::vector<int32_t> counts(B), sel((size_t)B * N), part((size_t)B * N);
     if (hipMemcpy(counts.data(), sv + sl.counts, sizeof(int32_t) * B, hipMemcpyDeviceToHost) != hipSuccess ||
