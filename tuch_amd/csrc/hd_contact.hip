@@ -20,6 +20,7 @@
 #include "model.h"
 #include "workspace.h"
 #include <algorithm>
+#include <mutex>
 #include <type_traits>
 #include <numeric>
 #include <stdlib.h>
@@ -41,6 +42,11 @@ struct tuch_hd_model {
     int32_t* offsets;    // [kMaxBatch+1] = b * N (device): where body b's slots start
     int tree_order;      // mask ids are tree positions (the model's mask in tree order is used)
     std::vector<int32_t>* order_host;   // sorted -> original index
+    // the search of the selected points and their inside test only share their input: the inside test runs on a stream of
+    // the model's own beside the search (option hd_overlap; fork / join through events, capturable)
+    hipStream_t side;
+    hipEvent_t ev_fork, ev_join;
+    std::mutex* enqueue;                // one forward call at a time enqueues on `side`
 };
 
 namespace {
@@ -430,6 +436,10 @@ extern "C" void tuch_hd_model_destroy(tuch_hd_model* hm)
     void* dev[] = {hm->idx, hm->w, hm->face, hm->tv, hm->mask_id, hm->orig, hm->by_orig, hm->v_off, hm->v_ent, hm->offsets};
     for (void* p : dev)
         if (p) (void)hipFree(p);
+    if (hm->side) (void)hipStreamDestroy(hm->side);
+    if (hm->ev_fork) (void)hipEventDestroy(hm->ev_fork);
+    if (hm->ev_join) (void)hipEventDestroy(hm->ev_join);
+    delete hm->enqueue;
     delete hm->order_host;
     free(hm);
 }
@@ -497,6 +507,15 @@ extern "C" int tuch_hd_model_create(tuch_hd_model** out, const tuch_contact_mode
     tuch_hd_model* hm = (tuch_hd_model*)calloc(1, sizeof(tuch_hd_model));
     hm->cm = cm; hm->N = N; hm->V = V; hm->F = F; hm->tree_order = tree_mask ? 1 : 0;
     hm->order_host = new std::vector<int32_t>(order);
+    hm->enqueue = new std::mutex();
+    if (hipStreamCreateWithFlags(&hm->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&hm->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&hm->ev_join, hipEventDisableTiming) != hipSuccess) {
+        tuch_set_error("tuch_hd_model_create: cannot create the side stream / events");
+        tuch_hd_model_destroy(hm);
+        *out = nullptr;
+        return TUCH_ERR_HIP;
+    }
     int rc = upload(&hm->idx, idx.data(), idx.size());
     if (rc == TUCH_OK) rc = upload(&hm->w, w.data(), w.size());
     if (rc == TUCH_OK) rc = upload(&hm->face, face.data(), face.size());
@@ -596,14 +615,34 @@ extern "C" int tuch_hd_contact_fwd(const tuch_hd_model* hm, const float* verts, 
     // (seeding the search from the vertex-level partners was tried: the seeds are excellent where they exist -- median
     // ratio to the final distance 1.00 -- but the nearest admissible HD point is ~10 cm away, so a column block still has
     // to visit ~40 % of the rows, and building the seeds cost more than the sampling pass they replace)
-    int rc = hm->cm->opt.hd_search
+    // the inside test of the points beside their search: fork here, join in front of the terms
+    const bool overlap = hm->cm->opt.hd_overlap != 0;
+    std::unique_lock<std::mutex> lock(*hm->enqueue, std::defer_lock);
+    hipStream_t ws_stream = s;
+    if (overlap) {
+        lock.lock();
+        if (hipEventRecord(hm->ev_fork, s) != hipSuccess || hipStreamWaitEvent(hm->side, hm->ev_fork, 0) != hipSuccess) {
+            tuch_set_error("tuch_hd_contact_fwd: fork onto the side stream failed");
+            return TUCH_ERR_HIP;
+        }
+        ws_stream = hm->side;
+    }
+    int rc = tuch_winding_points(hm->cm, verts, offs, counts, B, N, thresh, nullptr, ext, ws + wl.winding,
+                                 wl.winding_bytes, (void*)ws_stream);
+    if (rc == TUCH_OK)
+        rc = hm->cm->opt.hd_search
                  ? tuch_hd_search(pts, vid, hm->offsets, counts, first, bits, B, V, N, (float*)(ws + wl.min_d2), part,
                                   ws + wl.search, s, hm->cm->opt.hd_search_waves)
                  : tuch_v2v_min_indexed_seeded(pts, vid, hm->offsets, counts, nullptr, nullptr, first, bits, B, V, N,
                                                (float*)(ws + wl.min_d2), part, ws + wl.search, s);
-    if (rc != TUCH_OK) return rc;
-    rc = tuch_winding_points(hm->cm, verts, offs, counts, B, N, thresh, nullptr, ext, ws + wl.winding,
-                             wl.winding_bytes, stream);
+    if (overlap) {
+        // (joined whatever happened above: a captured fork must not be left open)
+        if (hipEventRecord(hm->ev_join, hm->side) != hipSuccess || hipStreamWaitEvent(s, hm->ev_join, 0) != hipSuccess) {
+            tuch_set_error("tuch_hd_contact_fwd: join of the side stream failed");
+            return TUCH_ERR_HIP;
+        }
+        lock.unlock();
+    }
     if (rc != TUCH_OK) return rc;
     hipLaunchKernelGGL(hd_terms_kernel, dim3(B), dim3(1024), 0, s, (const float*)pts, (const int32_t*)part,
                        (const uint8_t*)ext, (const int32_t*)counts, N, terms);

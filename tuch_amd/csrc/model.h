@@ -51,6 +51,7 @@ struct tuch_options {
     int deterministic = 0;      // 1: gradient scatters as gathers over inverse partner lists (bit-reproducible fits)
     int hd_search = 1;          // HD branch: 1 nearest admissible point on the matrix cores (hd_search.hip), 0 v2v_indexed_kernel
     int hd_search_waves = 4;    // wavefronts per block of 64 columns in that search (4, 2 or 1)
+    int hd_overlap = 1;         // HD branch: the inside test of the selected points on a second stream beside their search
 };
 void tuch_options_from_env(tuch_options* o);
 

@@ -496,7 +496,7 @@ const OptionName kOptions[] = {
     {"ray_pair_cap", &tuch_options::ray_pair_cap}, {"ray_waves", &tuch_options::ray_waves},
     {"v2v_tree", &tuch_options::v2v_tree}, {"v2v_flat", &tuch_options::v2v_flat}, {"v2v_waves", &tuch_options::v2v_waves}, {"v2v_lds", &tuch_options::v2v_lds},
     {"seg_splits", &tuch_options::seg_splits}, {"seg_assist", &tuch_options::seg_assist}, {"seg_fused", &tuch_options::seg_fused},
-    {"canary", &tuch_options::canary}, {"deterministic", &tuch_options::deterministic}, {"hd_search", &tuch_options::hd_search}, {"hd_search_waves", &tuch_options::hd_search_waves},
+    {"canary", &tuch_options::canary}, {"deterministic", &tuch_options::deterministic}, {"hd_search", &tuch_options::hd_search}, {"hd_search_waves", &tuch_options::hd_search_waves}, {"hd_overlap", &tuch_options::hd_overlap},
 };
 }  // namespace
 
