@@ -510,6 +510,13 @@ def contact_loss_eval(p, batch, verts, model):
         out['regressor_%s_fwd_ms_per_body' % tag] = round(time_kernel(fwd, iters) * 1e3 / batch, 5)
         out['regressor_%s_fwd_bwd_ms_per_body' % tag] = round(time_kernel(fwd_bwd, iters) * 1e3 / batch, 5)
         out['train_style_%s_step_ms' % tag] = round(time_kernel(make_train_step(p, use_hd), iters) * 1e3, 4)
+        # the same step captured once and replayed as one hipGraph (what a training loop that captures its step pays:
+        # the eager figure above includes the host's launch rate, ~50 launches per step)
+        try:
+            replay = capture(make_train_step(p, use_hd), 3)
+            out['train_style_%s_step_graph_ms' % tag] = round(time_kernel(replay, 10) * 1e3, 4)
+        except Exception as e:                                   # noqa: BLE001 -- reported, not fatal for the bench line
+            out['train_style_%s_step_graph_ms' % tag] = 'capture failed: %s' % type(e).__name__
     return out
 
 
