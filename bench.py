@@ -116,6 +116,38 @@ def profile_constants():
     return out
 
 
+def timeline_constants():
+    """Head / middle / tail of ONE replayed step from the newest committed timelines (profiles/rNN_x_graph_timeline.txt,
+    _b8.txt: tools/graph_timeline.py under rocprofv3 --kernel-trace): head = up to the start of the nearest-vertex
+    search's big kernel, middle = until both big kernels (search, ray_leaf_kernel) are done, tail = the rest.  From
+    profiles/, NOT measured in this run (the profiler adds ~4 % to the step)."""
+    import glob
+    import re
+    out = {}
+    for key, suffix in (('batch64', '_graph_timeline.txt'), ('batch8', '_graph_timeline_b8.txt')):
+        files = sorted(f for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*' + suffix))
+                       if re.match(r'r\d+_[a-z]+' + re.escape(suffix) + '$', os.path.basename(f)))
+        if not files:
+            continue
+        rows, head = [], {}
+        with open(files[-1]) as f:
+            for line in f:
+                m = re.match(r'kernels in the step: (\d+), wall ([\d.]+) us, summed kernel time ([\d.]+) us', line)
+                if m:
+                    head = {'kernels': int(m.group(1)), 'wall_us': float(m.group(2)), 'summed_kernel_us': float(m.group(3))}
+                m = re.match(r'\s*([\d.]+)\s+([\d.]+)\s+(.*)', line)
+                if m and not line.startswith('kernels') and not line.startswith('time'):
+                    rows.append((float(m.group(1)), float(m.group(2)), m.group(3)))
+        big = [r for r in rows if re.search(r'v2v_(scan|mfma|leaves|tree)\w*_kernel\(', r[2]) and 'finalize' not in r[2]
+               or 'ray_leaf_kernel' in r[2]]
+        search = [r for r in big if 'v2v_' in r[2]]
+        if head and big and search:
+            mid_end = max(r[0] + r[1] for r in big)
+            out[key] = dict(head, head_us=round(search[0][0], 1), middle_us=round(mid_end - search[0][0], 1),
+                            tail_us=round(head['wall_us'] - mid_end, 1), source='profiles/' + os.path.basename(files[-1]))
+    return out
+
+
 _BODY = {}
 
 
@@ -984,6 +1016,7 @@ def main():
             except Exception as exc:                     # the measurement stands; the check reports what went wrong
                 line['selfcheck'] = {'ok': False, 'error': repr(exc)}
             line['kernels_per_step'] = kernels_per_step(step)
+            line['graph_timeline'] = timeline_constants()
         roof, inside, verts, model = rooflines(p, batch)
         line['roofline'], line['roofline_inside_test'] = roof, inside
         if world == 1 and backend == 'nccl' and not args.no_rccl_smoke:
