@@ -391,8 +391,8 @@ __device__ __forceinline__ float row_min(float v)
 
 // rows in tree order + box of every leaf's rows; 16 lanes per (leaf, body): a leaf is a few dozen rows, a whole wavefront
 // per leaf was mostly idle lanes behind its chain of dependent loads
-__global__ __launch_bounds__(kBoundsBlock) void v2v_rows_kernel(
-    const float* __restrict__ verts, int V, int Vp, const int32_t* __restrict__ qperm,
+__device__ __forceinline__ void v2v_rows_body(
+    int bx, const float* __restrict__ verts, int V, int Vp, const int32_t* __restrict__ qperm,
     const int32_t* __restrict__ rows, const int32_t* __restrict__ height_off,
     const int32_t* __restrict__ height_nodes, int N,
     float* __restrict__ prow,                    // [B,Vp,3]
@@ -404,10 +404,10 @@ __global__ __launch_bounds__(kBoundsBlock) void v2v_rows_kernel(
 {                                                // groups of four, a group = x[4] y[4] z[4]; box word [3] = first group
     const int b = blockIdx.y;
     const int group = threadIdx.x >> 4, sub = threadIdx.x & 15;
-    const int i = height_off[0] + blockIdx.x * (kBoundsBlock / 16) + group;
+    const int i = height_off[0] + bx * (kBoundsBlock / 16) + group;
     const float* vb = verts + (size_t)b * V * 3;
     float* pb = prow + (size_t)b * Vp * 3;
-    if (blockIdx.x == 0 && threadIdx.x < 64)     // padding columns repeat the last vertex
+    if (bx == 0 && threadIdx.x < 64)             // padding columns repeat the last vertex
         for (int j = V + (int)threadIdx.x; j < Vp; j += 64) {
             const int v = qperm[j];
             pb[3 * j] = vb[3 * v]; pb[3 * j + 1] = vb[3 * v + 1]; pb[3 * j + 2] = vb[3 * v + 2];
@@ -447,6 +447,15 @@ __global__ __launch_bounds__(kBoundsBlock) void v2v_rows_kernel(
             q[4] = -nhi[0]; q[5] = -nhi[1]; q[6] = -nhi[2]; q[7] = __int_as_float(off | (len << 20));
         }
     }
+}
+
+__global__ __launch_bounds__(kBoundsBlock) void v2v_rows_kernel(
+    const float* __restrict__ verts, int V, int Vp, const int32_t* __restrict__ qperm, const int32_t* __restrict__ rows,
+    const int32_t* __restrict__ height_off, const int32_t* __restrict__ height_nodes, int N, float* __restrict__ prow,
+    float* __restrict__ bounds, float* __restrict__ leafbox, const int32_t* __restrict__ leaf_group, float* __restrict__ prow_g,
+    int G)
+{
+    v2v_rows_body(blockIdx.x, verts, V, Vp, qperm, rows, height_off, height_nodes, N, prow, bounds, leafbox, leaf_group, prow_g, G);
 }
 
 // One column per lane (64 columns per wavefront): the union of the columns' search balls is smaller for 64
@@ -750,6 +759,70 @@ __global__ __launch_bounds__(64) void v2v_seed_kernel(
         if (ok) v2v_rows(c, pb, bits + (size_t)qb * V, rows[2 * node], rows[2 * node + 1]);
     }
     keys[(size_t)b * Vp + i0] = v2v_key(c.best, c.arg);
+}
+
+// v2v_rows_kernel and the seed of an iterative fit in ONE launch.  With partner hints from the previous call the seed is
+// one gather per column; it needs the posed vertices, not the rows kernel's output (a row in tree order is
+// verts[qperm[row]]), so the two have nothing to wait for in each other: workgroups [0, row_blocks) pose the rows and box
+// the leaves, the others seed four column blocks each (behind the rows kernel and beside ray_near the seed took 26 us of
+// the search's head).  No fall-back descent here: a column whose hint is not an admissible row starts without a bound
+// (slower, never wrong) -- calls without hints take the two launches.
+__global__ __launch_bounds__(kBoundsBlock) void v2v_rows_seed_kernel(
+    const float* __restrict__ verts, int V, int Vp, const int32_t* __restrict__ qperm, const int32_t* __restrict__ rows,
+    const int32_t* __restrict__ height_off, const int32_t* __restrict__ height_nodes, int N, float* __restrict__ prow,
+    float* __restrict__ bounds, float* __restrict__ leafbox, const int32_t* __restrict__ leaf_group, float* __restrict__ prow_g,
+    int G, int row_blocks, const uint64_t* __restrict__ bits, const int32_t* __restrict__ hint, uint64_t* __restrict__ keys,
+    float* __restrict__ colbox, float* __restrict__ tilebox)
+{
+    if ((int)blockIdx.x < row_blocks) {
+        v2v_rows_body(blockIdx.x, verts, V, Vp, qperm, rows, height_off, height_nodes, N, prow, bounds, leafbox, leaf_group,
+                      prow_g, G);
+        return;
+    }
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int blocks = Vp / kTreeCols;
+    const int qb = ((int)blockIdx.x - row_blocks) * (kBoundsBlock / 64) + ((int)threadIdx.x >> 6);
+    if (qb >= blocks) return;
+    const float* vb = verts + (size_t)b * V * 3;
+    const int i0 = qb * kTreeCols + lane;
+    const int v0 = qperm[i0];
+    const float px = vb[3 * v0], py = vb[3 * v0 + 1], pz = vb[3 * v0 + 2];
+    float best = __builtin_inff();
+    int arg = 0;
+    const int j = hint[(size_t)b * Vp + i0];
+    if (j >= 0 && j < V && ((bits[(size_t)qb * V + j] >> lane) & 1)) {
+        const int vj = qperm[j];
+        const float dx = px - vb[3 * vj], dy = py - vb[3 * vj + 1], dz = pz - vb[3 * vj + 2];
+        best = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        arg = j;
+    }
+    keys[(size_t)b * Vp + i0] = v2v_key(best, arg);
+    // boxes of the block's columns (and of its four 16-row tiles for the matrix-core form), rows behind the last vertex left out
+    const bool real = i0 < V;
+    const float inf = __builtin_inff();
+    float lo[3] = {real ? px : inf, real ? py : inf, real ? pz : inf}, hi[3] = {real ? px : -inf, real ? py : -inf, real ? pz : -inf};
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], m));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m));
+        }
+    if (tilebox && (lane & 15) == 0) {
+        float* o = tilebox + ((size_t)b * blocks * 4 + 4 * qb + (lane >> 4)) * 8;
+        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = 0.0f; o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = 0.0f;
+    }
+#pragma unroll
+    for (int m = 32; m >= 16; m >>= 1)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], m));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m));
+        }
+    if (lane == 0) {
+        float* o = colbox + ((size_t)b * blocks + qb) * 8;
+        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = 0.0f; o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = 0.0f;
+    }
 }
 
 __global__ __launch_bounds__(64) void v2v_tree_kernel(
@@ -1295,7 +1368,17 @@ extern "C" int tuch_v2v_min_model_shared(const tuch_contact_model* m, const floa
     hipStream_t s = (hipStream_t)stream;
     const int V = m->V, Vp = m->tree_qblocks * 2 * kTreeCols, N = m->tree_nodes;
     const TreeNode* nodes = (const TreeNode*)m->tree_node;
-    hipLaunchKernelGGL(v2v_rows_kernel, dim3(ceil_div(m->tree_leaves, kBoundsBlock / 16), B), dim3(kBoundsBlock), 0, s,
+    const int row_blocks = ceil_div(m->tree_leaves, kBoundsBlock / 16);
+    if (scan >= 2 && hint_inout) {
+        // rows + the seed from the previous call's partners in one launch (see v2v_rows_seed_kernel)
+        hipLaunchKernelGGL(v2v_rows_seed_kernel, dim3(row_blocks + ceil_div(2 * m->tree_qblocks, kBoundsBlock / 64), B),
+                           dim3(kBoundsBlock), 0, s, verts, V, Vp, (const int32_t*)m->tree_qperm, (const int32_t*)m->tree_rows,
+                           (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, N, prow, bounds, leafbox,
+                           (const int32_t*)m->tree_leaf_group, scan == 2 ? (float*)(ws + l.prow_g) : (float*)nullptr,
+                           m->tree_groups, row_blocks, (const uint64_t*)m->tree_mask_bits, (const int32_t*)hint_inout, keys,
+                           colbox, scan == 3 ? (float*)(ws + l.tilebox) : (float*)nullptr);
+    } else {
+    hipLaunchKernelGGL(v2v_rows_kernel, dim3(row_blocks, B), dim3(kBoundsBlock), 0, s,
                        verts, V, Vp, (const int32_t*)m->tree_qperm, (const int32_t*)m->tree_rows,
                        (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, N, prow, bounds,
                        flat ? leafbox : (float*)nullptr, (const int32_t*)m->tree_leaf_group,
@@ -1309,6 +1392,7 @@ extern "C" int tuch_v2v_min_model_shared(const tuch_contact_model* m, const floa
                        (const uint64_t*)m->tree_masked, N, (const int32_t*)hint_inout, keys, scan >= 2 ? colbox : (float*)nullptr,
                        scan == 3 ? (float*)(ws + l.tilebox) : (float*)nullptr, scan >= 2 ? (const float*)leafbox : (const float*)nullptr,
                        (const uint64_t*)m->tree_masked_leaf, m->tree_leaves);
+    }
     const int f = choose_v2v_frontier(m, B);
     const int f0 = m->tree_frontier_off_host[f], nsub = m->tree_frontier_off_host[f + 1] - f0;
     // leave_room: an unused LDS allocation caps the walk at 25 of a CU's 32 wave slots.  The walk is one grid of 220 k
