@@ -419,6 +419,7 @@ __global__ __launch_bounds__(64 * kWaves) void ray_near_kernel(
     int i0;
     bool real;                                  // padding lanes repeat a query; they are left out of the masks
     if (kVerts) {
+    __builtin_amdgcn_s_setprio(3);               // (see ray_tiles_fill_kernel)
         i0 = qperm[qb * kRayQueries + lane];
         real = qb * kRayQueries + lane < Q;
     } else {
@@ -631,6 +632,10 @@ __global__ __launch_bounds__(kTilesFillBlock) void ray_tiles_fill_kernel(
     const RayEntry* __restrict__ lists, const int32_t* __restrict__ list_len, int qblocks, int32_t* __restrict__ leaf_fill,
     int32_t* __restrict__ pairs)
 {
+    // a chain of short dependent steps on few wavefronts: beside the nearest-vertex search (six busy wavefronts per SIMD
+    // on the other stream) its wavefronts got a seventh of the issue slots and the kernel took 100 us instead of 24 --
+    // ask for them first
+    __builtin_amdgcn_s_setprio(3);
     extern __shared__ int32_t dyn[];                // off[num_leaves] | blk[qblocks + 1]
     int32_t* off_s = dyn;
     int32_t* blk = dyn + num_leaves;
