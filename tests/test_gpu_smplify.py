@@ -77,6 +77,53 @@ def test_stage2_gradient_matches_oracle_composition():
         assert_close(got.cpu().numpy(), want.numpy(), 2e-3, 2e-4 * scale, 'grad ' + name)
 
 
+def test_pose_prior_gradient_rides_with_the_body_model_within_one_backward_pass(monkeypatch):
+    """The fused stage-2 tail leaves the pose prior's gradient with the body model's autograd node (one add launch less
+    per step).  Same gradients as autograd's own sum; and a gradient left behind by a backward pass that never reached
+    the body model's node (only camera_t asked for) does not leak into a later pass through that node."""
+    from tuch_amd import ops
+    from tuch_amd.smplify.losses import contact_fitting_loss
+    batch = 3
+    s = _setup(batch, 11)
+    body, t = s['body'], s['t']
+    gm = t(body.geodesics > 0.3)
+    face_tensor = t(body.faces)[None].repeat(batch, 1, 1)
+
+    def build():
+        bp = t(s['bp']).requires_grad_(True)
+        go = t(s['go']).requires_grad_(True)
+        cam = t(s['cam_t']).requires_grad_(True)
+        out = s['smpl'](global_orient=go, body_pose=bp, betas=t(s['be']))
+        loss = contact_fitting_loss(bp, go, None, None, t(s['be']), out.joints, gm, 0.02, cam,
+                                    torch.zeros(batch, 2, device=DEV), t(s['kp'][:, :, :2]), t(s['kp'][:, :, 2]),
+                                    s['prior'], s['cdict'], [t(s['gt']), None],
+                                    torch.zeros(batch, dtype=torch.bool, device=DEV),
+                                    torch.ones(batch, dtype=torch.bool, device=DEV), out.vertices,
+                                    face_tensor=face_tensor, contact_loss_weight=2000.0, segments=s['segments'])
+        return bp, go, cam, out, loss
+    bp, go, cam, out, loss = build()
+    node = out.vertices.grad_fn
+    assert getattr(node, 'pose_key', None) is not None          # the body model's node, recognisable
+    g_new = torch.autograd.grad(loss, [bp, go, cam], retain_graph=True)
+    assert node.pose_grad_extra is None                         # consumed
+    # autograd's own sum: the side channel off
+    monkeypatch.setattr(ops, '_graph_task_id', lambda: -1)
+    bp2, go2, cam2, out2, loss2 = build()
+    g_ref = torch.autograd.grad(loss2, [bp2, go2, cam2])
+    monkeypatch.undo()
+    scale = float(g_ref[0].abs().max())
+    for a, b, name in zip(g_new, g_ref, ('body_pose', 'global_orient', 'camera_t')):
+        assert_close(a.cpu().numpy(), b.cpu().numpy(), 1e-5, 1e-6 * max(scale, float(b.abs().max())), 'grad ' + name)
+    # a pass that stops in front of the body model leaves the prior's gradient with its node ...
+    torch.autograd.grad(loss, [cam], retain_graph=True)
+    assert node.pose_grad_extra is not None
+    # ... and a later pass through the node alone must not pick it up
+    g_alone = torch.autograd.grad(out.vertices.sum(), [bp], retain_graph=True)[0]
+    bp3, go3, cam3, out3, loss3 = build()
+    g_want = torch.autograd.grad(out3.vertices.sum(), [bp3])[0]
+    assert torch.equal(g_alone, g_want)
+
+
 @pytest.mark.parametrize('use_contact', [True, False])
 def test_smplifydc_runs_and_reduces_the_objective(use_contact):
     from tuch_amd.smplify.smplifydc import SMPLifyDC

@@ -89,9 +89,12 @@ class _SmplLBS(torch.autograd.Function):
         g_bp = torch.empty(bp.shape, dtype=torch.float32, device=go.device)
         nbytes = L.tuch_smpl_backward_workspace_bytes(ctx.dm._handle, b)
         ws2 = torch.empty(nbytes, dtype=torch.uint8, device=go.device)
-        extra, ctx.pose_grad_extra = ctx.pose_grad_extra, None
-        if extra is not None:
-            extra = extra.to(torch.float32).reshape(b, 23 * w).contiguous()
+        tagged, ctx.pose_grad_extra = ctx.pose_grad_extra, None
+        extra = None
+        if tagged is not None:
+            f = getattr(torch._C, '_current_graph_task_id', None)
+            if f is not None and int(f()) == tagged[1]:          # left by a node of THIS backward pass
+                extra = tagged[0].to(torch.float32).reshape(b, 23 * w).contiguous()
         _C.check(L.tuch_smpl_backward_split_add(ctx.dm._handle, _C.row_ptr(go), go.stride(0), _C.row_ptr(bp), bp.stride(0),
                                                 int(ctx.pose2rot), b, _C.ptr(ws), _C.ptr(gv), _C.ptr(gj),
                                                 _C.ptr(g_betas), _C.ptr(g_go), w, _C.ptr(g_bp), 23 * w,

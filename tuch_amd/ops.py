@@ -324,6 +324,12 @@ def smplify_objective(small, terms, r2r, contact_scale, r2r_scale):
     return _Objective.apply(small, terms, r2r, contact_scale, r2r_scale)
 
 
+def _graph_task_id() -> int:
+    """id of the running autograd backward pass (-1 outside one, or where this torch build has no such query)"""
+    f = getattr(torch._C, '_current_graph_task_id', None)
+    return int(f()) if f is not None else -1
+
+
 class _Stage2Tail(torch.autograd.Function):
     """Everything of the stage-2 objective behind the body model as ONE autograd node (tuch/smplify/losses.py:56-123):
     inside test + nearest admissible vertex (no gradient), contact sums, region minima, reprojection + prior, the
@@ -399,8 +405,10 @@ class _Stage2Tail(torch.autograd.Function):
         if not any(g.data_ptr() == seed.data_ptr() for seed in _ONES.values()):
             g = g.reshape(()).to(torch.float32)
             gv, gj, gc, gp = gv * g, gj * g, gc * g, gp * g
-        if ctx.lbs_node is not None:
-            ctx.lbs_node.pose_grad_extra = gp
+        if ctx.lbs_node is not None and _graph_task_id() >= 0:
+            # tagged with THIS backward pass: the body model's node takes it only within the same pass (a gradient left by
+            # a pass that never reached that node must not leak into a later one)
+            ctx.lbs_node.pose_grad_extra = (gp, _graph_task_id())
             return gv.to(dv), gj.to(dj), gc.to(dc), None, None, None, None, None
         return gv.to(dv), gj.to(dj), gc.to(dc), gp.to(dp), None, None, None, None
 
