@@ -69,3 +69,28 @@ def test_segment_face_tables_match_reference(tag):
     for name, w in zip(segs.keys(), want):
         assert np.array_equal(bbs.segmentation[name].segment_faces.numpy().ravel(), w)
         assert bbs.segmentation[name].append_idx == gg['faces'].max()
+
+
+def test_bench_reads_its_constants_from_the_committed_profiles():
+    """bench.py's roofline.traffic / valu_busy and graph_timeline come from the newest summaries under profiles/ (not
+    literals): the files parse, name the kernels the step runs today, and are internally consistent."""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    bench = importlib.import_module('bench')
+    prof = bench.profile_constants()
+    for key in ('search', 'ray_leaf_kernel'):
+        c = prof[key]
+        assert c['kernel'] and c['source'].startswith('profiles/r'), c
+        assert 1e6 < c['traffic_bytes'] < 1e9 and 0.2 < c['valu_busy'] <= 1.0 and c['valu_instr'] > 1e6, c
+    assert prof['search']['kernel'].startswith('v2v_')
+    tl = bench.timeline_constants()
+    for key in ('batch64', 'batch8'):
+        t = tl[key]
+        assert t['kernels'] >= 10 and t['source'].startswith('profiles/r')
+        assert abs(t['head_us'] + t['middle_us'] + t['tail_us'] - t['wall_us']) < 0.5
+        assert 0 < t['wall_us'] < t['summed_kernel_us'] * 1.2
+    assert tl['batch8']['wall_us'] < tl['batch64']['wall_us']
