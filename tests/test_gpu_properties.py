@@ -236,3 +236,46 @@ def test_headline_batch64_hd_contact_loss_against_the_oracle(headline):
     assert np.all(g[[b for b in range(64) if b not in which]] == 0)
     for b in which:
         grad_close(g[b], grads[b], 5e-6, 'headline HD grad body %d' % b, quantum=True)
+
+
+def test_headline_batch64_hd_search_on_the_matrix_cores_against_the_exact_kernel(headline):
+    """The HD branch at the bench's batch 64 with ALL bodies valid, once with the matrix-core search (hd_search.hip, the
+    default) and once with the exact kernel (v2v_indexed_kernel): same selection, partners identical except between rows
+    that tie (verified per point: squared distances within 2e-6 relative + 2e-8), same inside / outside flags, same
+    loss to 1e-6 -- for every one of the ~390 000 selected points of the batch."""
+    import bench
+    from helpers import report
+    p, verts = headline
+    crit = bench.regressor_loss(p, True)
+    model = crit._model
+    valid = torch.ones(64, dtype=torch.bool, device=verts.device)
+    res = {}
+    for form in (1, 0):
+        model.set_option('hd_search', form)
+        with torch.no_grad():
+            loss = crit.contact_loss(verts, valid)
+        torch.cuda.synchronize()
+        counts, sel = crit._hd.selection(crit._hd.last_saved, 64)
+        part, ext = crit._hd.details(crit._hd.last_saved, 64)
+        res[form] = (float(loss), counts.copy(), sel.copy(), part.copy(), ext.copy())
+    model.set_option('hd_search', 1)
+    (l1, c1, s1, p1, e1), (l0, c0, s0, p0, e0) = res[1], res[0]
+    assert np.array_equal(c1, c0) and np.array_equal(s1, s0) and np.array_equal(e1, e0)
+    assert abs(l1 - l0) <= 1e-6 * abs(l0)
+    body = p['body']
+    idx, w = np.asarray(body.hd_bary_idx), np.asarray(body.hd_bary_w, np.float64)
+    verts_np = verts.cpu().numpy().astype(np.float64)
+    differ = total = 0
+    for b in range(64):
+        n = int(c1[b])
+        total += n
+        d = np.where(p1[b, :n] != p0[b, :n])[0]
+        differ += len(d)
+        if len(d) == 0:
+            continue
+        pt = lambda ids: (verts_np[b][idx[ids]] * w[ids][..., None]).sum(1)      # HD points by caller index
+        me, a, c = pt(s1[b, :n][d]), pt(p1[b, :n][d]), pt(p0[b, :n][d])
+        da, dc = ((me - a) ** 2).sum(1), ((me - c) ** 2).sum(1)
+        assert (np.abs(da - dc) <= 2e-6 * dc + 2e-8).all(), (b, float(np.abs(da - dc).max()))
+    report('headline HD: partners, matrix-core search != exact kernel (ties within the key)', differ, total)
+    assert differ <= max(8, total // 5000)
