@@ -411,6 +411,7 @@ __global__ __launch_bounds__(64 * kWaves) void ray_near_kernel(
     int32_t* __restrict__ leaf_cnt,             // [B][num_leaves], zeroed: rays per leaf
     unsigned long long* __restrict__ stats)     // measurement (or nullptr): [1] += (ray, element) pairs inside a listed
 {                                               // leaf's slabs, [2] += 64 x elements listed
+    __builtin_amdgcn_s_setprio(3);               // (see ray_tiles_fill_kernel)
     const int qb = blockIdx.x, b = blockIdx.y, lane = threadIdx.x & 63;
     const int wave = kWaves > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
     __shared__ uint4 queue[64 * kWaves][2];     // records of the round's leaves that passed stage 1
@@ -419,7 +420,6 @@ __global__ __launch_bounds__(64 * kWaves) void ray_near_kernel(
     int i0;
     bool real;                                  // padding lanes repeat a query; they are left out of the masks
     if (kVerts) {
-    __builtin_amdgcn_s_setprio(3);               // (see ray_tiles_fill_kernel)
         i0 = qperm[qb * kRayQueries + lane];
         real = qb * kRayQueries + lane < Q;
     } else {
