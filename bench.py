@@ -603,12 +603,17 @@ def kernels_per_step(step):
         from torch.profiler import ProfilerActivity, profile
         step()
         torch.cuda.synchronize()
-        with profile(activities=[ProfilerActivity.CUDA]) as prof:
-            step()
-            torch.cuda.synchronize()
-        names = [e.name for e in prof.events() if str(getattr(e, 'device_type', '')).endswith('CUDA')]
-        copies = [n for n in names if 'memcpy' in n.lower() or 'memset' in n.lower() or 'copyBuffer' in n or 'fillBuffer' in n]
-        return {'kernels': len(names) - len(copies), 'copies_and_fills': len(copies)}
+        best = None
+        for _ in range(3):          # the tracer now and then drops device records of a graph replay: it can only under-count
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                step()
+                torch.cuda.synchronize()
+            names = [e.name for e in prof.events() if str(getattr(e, 'device_type', '')).endswith('CUDA')]
+            copies = [n for n in names if 'memcpy' in n.lower() or 'memset' in n.lower() or 'copyBuffer' in n or 'fillBuffer' in n]
+            got = {'kernels': len(names) - len(copies), 'copies_and_fills': len(copies)}
+            if best is None or got['kernels'] + got['copies_and_fills'] > best['kernels'] + best['copies_and_fills']:
+                best = got
+        return best
     except Exception as exc:
         return {'error': repr(exc)}
 
