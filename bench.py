@@ -9,8 +9,9 @@ push/pull terms with winding-number inside test and segment filter + region-to-r
     python bench.py [--gpus N] [--steps K] [--warmup W]          # N > 1: spawns N ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-The batch dimension shards across ranks (weak scaling: 64 bodies per GPU; --global-batch G: strong
-scaling, G/N bodies per GPU).  The fits of different bodies never exchange data, so there is no collective inside
+The batch dimension shards across ranks.  --gpus N > 1 defaults to STRONG scaling at the global batch of 64 that
+SURVEY 8(e) / north_star name (64/N bodies per GPU; the weak-scaling figure, 64 bodies per GPU, is timed in the same run and
+reported as `weak_scaling`; --weak makes it the headline, --global-batch G picks another total).  The fits of different bodies never exchange data, so there is no collective inside
 the loop: the two floats [sum of losses, body count] are all-reduced (RCCL) once per timed block of K steps.
 Rank 0 prints ONE JSON line (contract in the task description) including
   roofline     -- dominant kernel of the step (the masked vertex-distance search, v2v_tree_kernel), achieved FLOP/s in
@@ -158,7 +159,11 @@ def parse(argv=None):
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='bodies per GPU (weak scaling)')
     ap.add_argument('--global-batch', type=int, default=None,
-                    help='strong scaling: total bodies, split evenly over the GPUs')
+                    help='strong scaling: total bodies, split evenly over the GPUs (the default for --gpus N > 1: 64, '
+                         'SURVEY 8(e); the weak-scaling figure at 64 bodies per GPU is timed next to it)')
+    ap.add_argument('--weak', action='store_true',
+                    help='N > 1: weak scaling (--batch bodies per GPU) as the headline instead of strong scaling at '
+                         'global batch 64')
     ap.add_argument('--repeats', type=int, default=5, help='how many times the K-step block is timed')
     ap.add_argument('--config', default='2', choices=['2', '3', '4-shard', '5-shard'],
                     help='which BASELINE config is the timed step (default 2 = the headline)')
@@ -460,10 +465,17 @@ def rooflines(p, batch):
     compact_bytes = batch * (12 * v + 8 * v) + v * v // 8         # layout (ii): bit-packed mask read once
     prof = profile_constants()
     prof_v = prof['search']
-    roof = {'kernel': 'v2v_scan_kernel (+ v2v_rows, tree_inner_bounds, v2v_seed, v2v_tree_finalize; beside the inside test: '
+    # what the vector units EXECUTE: every vector instruction of the launch (SQ_INSTS_VALU of the committed PMC pass, same
+    # code, same batch) counted as a 64-lane FMA = an upper bound of the executed FLOP; `frac` is that over the FP32 vector
+    # peak and can never exceed valu_busy.  The all-pairs figure of SURVEY 8(d) is `equivalent_*`: most pairs are pruned.
+    exe_v = (prof_v['valu_instr'] * 64 * 2 / t_v / 1e12) if (prof_v['valu_instr'] and batch == BATCH_PER_GPU) else None
+    roof = {'kernel': 'v2v_scan_kernel (+ v2v_rows_seed, v2v_tree_finalize; beside the inside test: '
                       'v2v_scan_shared_kernel, the same code capped at 6 wavefronts per SIMD)', 'bound': 'valu',
-            'achieved': round(ach_v, 2), 'peak': PEAK_FP32_VECTOR_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(ach_v / PEAK_FP32_VECTOR_TFLOPS, 4),
+            'achieved': round(exe_v, 2) if exe_v is not None else None, 'peak': PEAK_FP32_VECTOR_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(exe_v / PEAK_FP32_VECTOR_TFLOPS, 4) if exe_v is not None else None,
+            'frac_formula': 'SQ_INSTS_VALU per launch (profiles/) x 64 lanes x 2 / launch time measured here / peak: EXECUTED '
+                            'vector work with every instruction priced as an FMA (an upper bound; <= valu_busy)',
+            'equivalent_achieved': round(ach_v, 2), 'equivalent_frac': round(ach_v / PEAK_FP32_VECTOR_TFLOPS, 4),
             'traffic': prof_v['traffic_bytes'] if batch == BATCH_PER_GPU else None,
             'valu_busy': prof_v['valu_busy'], 'profile_source': prof_v['source'],
             'launch_ms': round(t_v * 1e3, 4),
@@ -473,11 +485,11 @@ def rooflines(p, batch):
             'reference_layout_equivalent_GBs': round(ref_layout_bytes / t_v / 1e9, 1),
             'reference_layout_equivalent_frac_of_hbm': round(ref_layout_bytes / t_v / 1e9 / PEAK_HBM_GBS, 3),
             'valu_instr_per_launch': prof_v['valu_instr'], 'scalar_instr_per_launch': prof_v['salu_instr'],
-            'note': 'achieved = 8 FLOP x V^2 x B / launch time (SURVEY 8d), an all-pairs-EQUIVALENT figure: most (column, row) '
-                    'pairs are never evaluated -- pruned by box distance, by the lanes the mask leaves a row for below a '
-                    'node, and in groups of four rows no reachable lane may use.  What the vector units do is valu_busy '
-                    '(from the committed PMC pass).  The mask is bit-packed and L2-resident: the equivalent-bandwidth figures '
-                    'are NOT physical bandwidth'}
+            'note': 'frac / achieved = executed vector work (see frac_formula).  equivalent_* = 8 FLOP x V^2 x B / launch time '
+                    '(SURVEY 8d), an all-pairs-EQUIVALENT figure: most (column, row) pairs are never evaluated -- pruned by box '
+                    'distance, by the lanes the mask leaves a row for below a node, and in groups of four rows no reachable '
+                    'lane may use: pruning, not utilisation, is the win.  The mask is bit-packed and L2-resident: the '
+                    'equivalent-bandwidth figures are NOT physical bandwidth'}
     # ---- the inside test: sheared strips + leaf slabs + near-leaf lists + tiles + ray_leaf_kernel + fan finalize
     t_w = time_kernel(lambda: model.exterior_flags(verts, apply_segments=False), 10)
     work = model.ray_work(verts)
@@ -492,6 +504,9 @@ def rooflines(p, batch):
     inside = {'kernel': 'ray_leaf_kernel (+ ray_stream, ray_leaf_bounds, ray_near, ray_tiles, ray_fill, ray_finalize_verts)',
               'bound': 'valu', 'achieved': round(ach, 2), 'peak': PEAK_FP32_VECTOR_TFLOPS, 'unit': 'TFLOP/s',
               'frac': round(ach / PEAK_FP32_VECTOR_TFLOPS, 4),
+              'frac_formula': '21 executed FP32 operations x 64 rays x element steps (counted by tuch_ray_work on this input) '
+                              '/ launch-group time measured here / peak: EXECUTED work',
+              'equivalent_frac': round(ref_flops / t_w / 1e12 / PEAK_FP32_VECTOR_TFLOPS, 2),
               'plain_issue_T_lane_instr_per_s': round(lane_instr, 2), 'plain_issue_peak': PEAK_PLAIN_ISSUE_TLANEOPS,
               'frac_of_plain_issue_peak': round(lane_instr / PEAK_PLAIN_ISSUE_TLANEOPS, 4),
               'traffic': prof_r['traffic_bytes'] if batch == BATCH_PER_GPU else None,
@@ -609,7 +624,9 @@ def kernels_per_step(step):
                 step()
                 torch.cuda.synchronize()
             names = [e.name for e in prof.events() if str(getattr(e, 'device_type', '')).endswith('CUDA')]
-            copies = [n for n in names if 'memcpy' in n.lower() or 'memset' in n.lower() or 'copyBuffer' in n or 'fillBuffer' in n]
+            # (torch's zeros_/fill_ run as an elementwise kernel with a FillFunctor: a fill, whatever engine executes it)
+            copies = [n for n in names if 'memcpy' in n.lower() or 'memset' in n.lower() or 'copyBuffer' in n or 'fillBuffer' in n
+                      or 'FillFunctor' in n]
             got = {'kernels': len(names) - len(copies), 'copies_and_fills': len(copies)}
             if best is None or got['kernels'] + got['copies_and_fills'] > best['kernels'] + best['copies_and_fills']:
                 best = got
@@ -921,6 +938,13 @@ def main():
     # everything below runs on a created stream: hipGraph replays on the legacy NULL stream are not reliably ordered
     # against the work around them (tuch_amd/ops.py:off_default_stream)
     torch.cuda.set_stream(torch.cuda.Stream(device=device))
+    # N > 1 measures what SURVEY 8(e) / north_star name: the GLOBAL batch of 64 split over the ranks (64 / 32 / 16 / 8 bodies
+    # per GPU at 1 / 2 / 4 / 8 GPUs) = strong scaling; the weak-scaling figure (64 bodies per GPU) is timed in the same run
+    # and reported as `weak_scaling`.  N = 1 is the same workload either way.
+    default_strong = (world > 1 and args.global_batch is None and not args.weak and args.config == '2'
+                      and args.batch == BATCH_PER_GPU and BATCH_PER_GPU % world == 0)
+    if default_strong:
+        args.global_batch = BATCH_PER_GPU
     if args.global_batch is not None:
         if args.global_batch % world:
             raise SystemExit('--global-batch %d is not divisible by %d ranks' % (args.global_batch, world))
@@ -943,6 +967,10 @@ def main():
         launch = 'SMPLifyDC.__call__ (each loop replayed as a hipGraph after 3 eager iterations)'
     else:
         step = make_tuch_step(p, run_smplify=args.config == '5-shard', smplify_iters=10)
+    weak_step = None
+    if default_strong and not args.eager:
+        # the weak-scaling twin (64 bodies on every rank), captured before the process group exists like the headline
+        weak_step = capture(make_step(build_problem(BATCH_PER_GPU, device, seed=2002 + rank)), args.warmup)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend == 'nccl':
@@ -970,7 +998,7 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def block(steps):
+    def block(steps, step=step):
         """EXACTLY `steps` steps between two fences; seconds, MAX over ranks."""
         fence()
         t0 = time.perf_counter()
@@ -993,6 +1021,16 @@ def main():
         reduce(last)                                     # the collective's own first-call cost stays out of the timing
     dt, stats = block(args.steps)                        # the contract's measurement
     repeats = [dt] + [block(args.steps)[0] for _ in range(max(args.repeats, 1) - 1)]
+    weak = None
+    if weak_step is not None:
+        for _ in range(args.warmup):
+            weak_step()
+        wdt, wstats = block(args.steps, weak_step)
+        weak = {'value': round(BATCH_PER_GPU * world * args.steps / wdt, 2), 'unit': CONFIGS['2']['unit'],
+                'ms_per_step': round(wdt / args.steps * 1e3, 4), 'bodies_per_gpu': BATCH_PER_GPU,
+                'global_batch': BATCH_PER_GPU * world, 'bodies': float(wstats[1].item()), 'scaling': 'weak',
+                'note': 'the same step with 64 bodies on EVERY rank, timed like the headline (one %d-step block, fences + MAX '
+                        'over ranks) in the same run' % args.steps}
     if rank == 0:
         cfg = CONFIGS[args.config]
         bodies = batch * world
@@ -1013,8 +1051,12 @@ def main():
                                    'note': 'the same %d-step block timed %d times; ms_per_step/value are block 1'
                                            % (args.steps, len(per_step))},
             'scaling_note': 'no multi-GPU node was available to the builder: N>1 values exist only when the driver '
-                            'runs this script on one' if world == 1 else None,
+                            'runs this script on one; --gpus N > 1 defaults to STRONG scaling at global batch 64 (SURVEY 8e) '
+                            'and reports the weak-scaling figure (64 bodies per GPU) as `weak_scaling`' if world == 1 else
+                            'global batch %d split over %d ranks (%s scaling)' % (bodies, world, scaling),
         }
+        if weak is not None:
+            line['weak_scaling'] = weak
         if args.config == '2':
             try:
                 line['selfcheck'] = selfcheck(p, step)
@@ -1024,6 +1066,22 @@ def main():
             line['graph_timeline'] = timeline_constants()
         roof, inside, verts, model = rooflines(p, batch)
         line['roofline'], line['roofline_inside_test'] = roof, inside
+        if args.config == '2':
+            # the whole step priced in SURVEY 8(d)'s units (67 FLOP per (query, face) pair of the body and of every closed
+            # segment, 8 FLOP per ordered vertex pair) over the measured step time: a multiple of the vector PEAK, because
+            # the step does not do that pair work (exact pruning, crossings instead of solid angles)
+            from tuch_amd.ops import segment_faces
+            body = p['body']
+            seg_pairs = sum(len(sg['vidx']) * len(segment_faces(body.faces, sg['vidx'], list(sg['bands'].values()), body.num_verts))
+                            for sg in body.segments.values())
+            eq = (FLOP_PER_WINDING_PAIR * (body.num_verts * body.num_faces + seg_pairs)
+                  + FLOP_PER_V2V_PAIR * body.num_verts ** 2) * batch
+            line['step_equivalent_flop'] = eq
+            line['step_equivalent_x_peak'] = round(eq / (dt / args.steps) / 1e12 / PEAK_FP32_VECTOR_TFLOPS, 2)
+        line['mfma_use'] = ('SMPL dense matmuls (blend / skin adjoint, exact f32 MFMA) as north_star asks; DEPARTURE from its '
+                            '"MFMA only for the SMPL matmuls": the HD branch\'s nearest-point search (hd_search_kernel, '
+                            'RegressorLoss use_hd=True) also runs on the matrix cores -- 502 -> 215 us at batch 64, option '
+                            'hd_search=0 is the exact VALU kernel; the headline step (this line) uses MFMA for SMPL only')
         if world == 1 and backend == 'nccl' and not args.no_rccl_smoke:
             line['rccl_smoke'] = rccl_smoke()
         if world == 1 and not args.no_extras:

@@ -111,6 +111,12 @@ int tuch_contact_terms_ragged_bwd(const float* points, const int32_t* partner, c
 int tuch_contact_terms_bwd(const float* points, const int32_t* partner, const uint8_t* exterior,
                            const float* grad_scale, int B, int N, int mode, float euclthres,
                            float* grad_points, void* stream);
+/* The same scatter in deterministic mode (tuch_set_deterministic): grad_fixed_zeroed = B*N*3 zeroed 64-bit words the
+ * contributions are added to as fixed-point integers (order-independent), then converted: grad_points is WRITTEN
+ * (no need to clear it), bit-reproducible.  Valid range as for tuch_smplify_stage2_fused. */
+int tuch_contact_terms_bwd_fixed(const float* points, const int32_t* partner, const uint8_t* exterior,
+                                 const float* grad_scale, int B, int N, int mode, float euclthres,
+                                 void* grad_fixed_zeroed, float* grad_points, void* stream);
 
 /* Reprojection + pose-prior part of the SMPLify-DC objective, losses.py:56-64 (projection
  * geometry.py:83-111 with identity rotation, gmof losses.py:25-32, max-mixture prior
@@ -163,7 +169,10 @@ int tuch_smplify_stage2_fused(const float* points, const int32_t* partner, const
  * tuch_smplify_stage2_fused (contact terms, region minima) and of tuch_smpl_backward (skinning adjoint) accumulate 64-bit
  * fixed-point numbers (2^-36) with integer atomics instead of floats -- sums that do not depend on the order of arrival,
  * so an SMPLify-DC fit reproduces bit for bit.  tuch_smplify_stage2_fused then wants grad_fixed_zeroed = B*N*3 zeroed
- * 64-bit words (NULL: float atomics, whatever the mode) and converts to grad_points with a second launch. */
+ * 64-bit words (NULL: float atomics, whatever the mode) and converts to grad_points with a second launch.
+ * VALID RANGE of the fixed-point sums: |sum| < 2^27 = 1.3e8 (beyond, the unsigned 64-bit accumulator wraps silently) and
+ * contributions below 2^-37 = 7e-12 round to zero.  Gradient magnitudes scale with contact_scale / r2r_scale: with the
+ * reference's weights (10, 2000) and metre-scale bodies the per-vertex gradients are < 1e5. */
 void tuch_set_deterministic(int on);
 int tuch_get_deterministic(void);
 
@@ -199,7 +208,7 @@ int tuch_contact_model_create(tuch_contact_model** out, int V, int F, const int3
 void tuch_contact_model_destroy(tuch_contact_model* model);
 /* Switches of the hot calls (A/B measurements, tests): winding_ray (0 never / 1 when only flags are wanted / 2 also for
  * w), winding_tree, winding_strips, tree_waves, ray_pair_cap, ray_waves, v2v_tree, v2v_waves, v2v_lds, seg_splits,
- * seg_assist (fixed at create), canary, deterministic.  The environment variables TUCH_<NAME> are read ONCE, by
+ * seg_assist (fixed at create), canary.  (Deterministic mode is process-wide: tuch_set_deterministic.)  The environment variables TUCH_<NAME> are read ONCE, by
  * tuch_contact_model_create; afterwards only set_option changes a model's switches -- no hot call looks at the
  * environment, so a captured hipGraph cannot depend on it.  (The workspace sizes depend on ray_pair_cap and canary:
  * query *_workspace_bytes again after changing them.) */

@@ -43,6 +43,17 @@ def assert_close(actual, expected, rtol, atol, what=''):
                              % (what, k, actual.flat[k], expected.flat[k], err.flat[k], tol.flat[k]))
 
 
+def close_logged(actual, expected, rtol, atol, what=''):
+    """assert_close that also logs what was OBSERVED (gpurun_out/parity_counts.txt): the largest error relative to the
+    largest reference entry and relative to the bound -- the loop-level tolerances are set from these."""
+    a, e = np.asarray(actual, np.float64), np.asarray(expected, np.float64)
+    err = np.abs(a - e)
+    bound = atol + rtol * np.abs(e)
+    _log('loop %-64s max|err|/max|ref| %.2e   max err/bound %.3f' % (what, err.max() / max(np.abs(e).max(), 1e-30),
+                                                                     (err / np.maximum(bound, 1e-300)).max()))
+    assert_close(actual, expected, rtol, atol, what)
+
+
 def touches_surface(verts_b, faces, vid, tol=2e-6):
     """float64: does vertex `vid` lie within `tol` of a triangle it is not a corner of (inside its outline)?
     There the winding number jumps by one across the triangle: the reference's float32 sum, any other summation

@@ -122,8 +122,11 @@ def test_two_ranks_on_the_hip_path_reproduce_the_reference_mean():
         assert p.exitcode == 0
     assert abs(total - float(g['train_hd_loss'])) <= 1e-4 * abs(float(g['train_hd_loss']))
     gv = g['train_hd_grad_verts']
+    from helpers import grad_close
     for lo, hi, grad in grads:
-        assert np.allclose(grad, gv[lo:hi], rtol=1e-3, atol=5e-6 * np.abs(gv).max())
+        # as every single-evaluation gradient test: 1e-4 relative + a floor of 5e-6 of the largest entry (+ the quantised
+        # derivative of a saturated tanh^2 term, helpers.TANH_QUANTUM); observed maxima are logged
+        grad_close(grad, gv[lo:hi], 5e-6, '2 gloo ranks on the HIP path, bodies %d:%d' % (lo, hi), quantum=True)
 
 
 @pytest.mark.gpu
@@ -137,16 +140,27 @@ def test_bench_spawns_its_own_ranks():
     env = dict(os.environ, TUCH_BENCH_BACKEND='gloo')
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
         env.pop(k, None)
-    res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
-                          '--global-batch', '8', '--repeats', '2', '--no-extras', '--no-cpu-baseline'],
-                         env=env, capture_output=True, text=True, timeout=900)
-    assert res.returncode == 0, res.stderr[-3000:]
-    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
-    assert len(lines) == 1, res.stdout[-2000:]
-    line = json.loads(lines[0])
+    def run(*extra):
+        res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                              '--repeats', '2', '--no-extras', '--no-cpu-baseline'] + list(extra),
+                             env=env, capture_output=True, text=True, timeout=900)
+        assert res.returncode == 0, res.stderr[-3000:]
+        lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+        assert len(lines) == 1, res.stdout[-2000:]
+        return json.loads(lines[0])
+    line = run('--global-batch', '8')
     assert line['n_gpus'] == 2 and line['scaling'] == 'strong' and line['config']['bodies_per_gpu'] == 4
     assert line['config']['bodies'] == 8.0 and line['config']['launch'].startswith('hipGraph')
-    assert np.isfinite(line['config']['loss_sum']) and line['value'] > 0
+    assert np.isfinite(line['config']['loss_sum']) and line['value'] > 0 and 'weak_scaling' not in line
+    # the DEFAULT for N > 1 is what SURVEY 8(e) specifies: the global batch of 64 split over the ranks (strong scaling);
+    # the weak-scaling figure (64 bodies per rank) rides along
+    line = run()
+    assert line['n_gpus'] == 2 and line['scaling'] == 'strong' and line['config']['bodies_per_gpu'] == 32
+    assert line['config']['global_batch'] == 64 and line['config']['bodies'] == 64.0
+    weak = line['weak_scaling']
+    assert weak['scaling'] == 'weak' and weak['bodies_per_gpu'] == 64 and weak['bodies'] == 128.0 and weak['value'] > 0
+    line = run('--weak')
+    assert line['scaling'] == 'weak' and line['config']['bodies_per_gpu'] == 64 and 'weak_scaling' not in line
 
 
 @pytest.mark.gpu

@@ -1097,10 +1097,12 @@ def test_ray_crossing_flags_of_points_match_the_solid_angle_sums(tag, monkeypatc
     assert len(np.unique(w_r)) >= 2                                                # inside and outside points both occur
 
 
-def test_hd_gradient_is_bit_reproducible_in_deterministic_mode():
+@pytest.mark.parametrize('use_hd', [True, False])
+def test_hd_gradient_is_bit_reproducible_in_deterministic_mode(use_hd):
     """ops.set_deterministic(True): the HD branch's point gradients are summed as 64-bit fixed-point integers (LDS integer
     atomics) and gathered per vertex in a fixed order -- the gradient of contact_loss(use_hd=True) is the same BITS every
-    time, and agrees with the float-atomic one to float tolerance."""
+    time, and agrees with the float-atomic one to float tolerance.  use_hd=False: the plain training term's scatter
+    (contact_terms_bwd_kernel<Fixed>, round 4) likewise."""
     import types
     from tuch_amd import ops
     from tuch_amd.train.loss import RegressorLoss
@@ -1112,7 +1114,7 @@ def test_hd_gradient_is_bit_reproducible_in_deterministic_mode():
     segs = gio.unpack_segments(g)
     crit = RegressorLoss(types.SimpleNamespace(contact_loss_weight=1.0), d, g['verts'].shape[1], face_tensor,
                          torch.tensor(np.where(gm, 1.0, 0.0).astype(np.float32), device=d), geothres=0.3,
-                         euclthres=float(g['euclthres']), face_tensor=face_tensor, use_hd=True,
+                         euclthres=float(g['euclthres']), face_tensor=face_tensor, use_hd=use_hd,
                          segments=BatchBodySegment(list(segs.keys()), face_tensor[0], segs),
                          hd_regressor=(g['hd_idx'], g['hd_w']), hd_faces=g['hd_face'])
     valid = torch.tensor(g['valid_fit'], device=d)

@@ -7,13 +7,15 @@ import pytest
 import torch
 
 import golden_io as gio
-from helpers import assert_close, golden, golden_mask, oracle_segments, region_pair_lists
+from helpers import assert_close, close_logged, golden, golden_mask, oracle_segments, region_pair_lists
 from oracle import contact as oc
 from oracle import lbs as ol
 from tuch_amd.synthetic import make_body, random_poses
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
+# loop-level tolerance (10 + 10 Adam iterations through float atomics): 3 x the observed maximum, see close_logged's log
+LOOP_RTOL = 1e-3
 
 
 def _setup(batch, seed):
@@ -229,11 +231,12 @@ def test_smplifydc_matches_the_reference_loop(use_contact, use_graph, monkeypatc
     names = ('vertices', 'joints', 'pose', 'betas', 'camera_translation', 'reprojection_loss')
     for name, got in zip(names, res[:6]):
         want = g['%s_%s' % (tag, name)]
-        assert_close(got.detach().cpu().numpy(), want, 1e-3, 1e-3 * np.abs(want).max(), '%s %s' % (tag, name))
+        close_logged(got.detach().cpu().numpy(), want, LOOP_RTOL, LOOP_RTOL * np.abs(want).max(),
+                     'SMPLifyDC loop %s %s graph=%d' % (tag, name, use_graph))
     optiverts = torch.stack([v.detach() for v in res[6]]).cpu().numpy()
     want = g['%s_optiverts' % tag]
     assert optiverts.shape == want.shape
-    assert_close(optiverts, want, 1e-3, 1e-3, tag + ' optiverts')
+    close_logged(optiverts, want, LOOP_RTOL, LOOP_RTOL, 'SMPLifyDC loop %s optiverts graph=%d' % (tag, use_graph))
     assert torch.equal(kp, t(g['keypoints_2d']))                 # __call__ does not write into its input
     # the fit actually moved: not a comparison of two untouched initial states
     assert np.abs(g['%s_pose' % tag] - g['init_pose']).max() > 0.05
@@ -303,7 +306,7 @@ def test_config3_fit_batch32_fullsize(monkeypatch):
         bp, go = h['params'][0].cpu(), h['params'][1].cpu()
         v_o, j_o = ol.smpl_forward(m, betas.cpu(), bp, go)
         v_gpu = optiverts[it].cpu().numpy()
-        assert_close(v_gpu, v_o.numpy(), 1e-4, 1e-5, 'vertices at iteration %d' % it)
+        close_logged(v_gpu, v_o.numpy(), 1e-4, 1e-5, 'config 3: vertices at iteration %d' % it)
         idx = np.asarray(sample)
         rp = [[(body.regions[a], body.regions[c]) for k, (a, c) in enumerate(body.region_pairs) if gt[b, k] == 1]
               for b in idx]
@@ -313,7 +316,7 @@ def test_config3_fit_batch32_fullsize(monkeypatch):
             None, contact_loss_weight=2000.0)
         if len(sample) == batch:
             n_sel = float(gt.sum())
-            assert_close(float(losses[it]), total, 1e-4, 2000 * 1e-6 * n_sel, 'objective at iteration %d' % it)
+            close_logged(float(losses[it]), total, 1e-4, 2000 * 1e-6 * n_sel, 'config 3: objective at iteration %d' % it)
         else:
             # the GPU reports the batch sum; compare the sampled bodies through a sub-batch evaluation on the GPU
             from tuch_amd.smplify.losses import contact_fitting_loss
@@ -327,7 +330,7 @@ def test_config3_fit_batch32_fullsize(monkeypatch):
                                            verts=out.vertices, face_tensor=fitter.face_tensor[:len(idx)],
                                            focal_length=5000., contact_loss_weight=2000.0, segments=p['segments'])
             n_sel = float(gt[idx].sum())
-            assert_close(sub.item(), total, 1e-4, 2000 * 1e-6 * n_sel, 'objective of the sample at iteration %d' % it)
+            close_logged(sub.item(), total, 1e-4, 2000 * 1e-6 * n_sel, 'config 3: objective of the sample at iteration %d' % it)
 
 
 def test_loops_kept_between_calls_reproduce_fresh_fits(monkeypatch):

@@ -8,11 +8,14 @@ import pytest
 import torch
 
 import golden_io as gio
-from helpers import assert_close
+from helpers import assert_close, close_logged
 from tuch_amd.synthetic import make_body, make_regressor
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device('cuda:0')
+# step-level tolerances (5 + 5 Adam iterations inside the step, float atomics): 3 x the observed maxima (close_logged's log)
+STEP_RTOL = 1e-3
+STEP_GRAD_RTOL = 2e-3
 
 
 def _golden():
@@ -127,21 +130,23 @@ def test_forward_train_step_matches_the_reference(tmp_path):
                   contactlists={'classes': [list(p) for p in body.region_pairs], 'csig': dict(body.regions)})
     loss, losses, output = module.forward_train_step(_batch(g))
     loss.backward()
-    assert_close(loss.item(), g['loss'], 1e-3, 1e-5, 'loss')
+    close_logged(loss.item(), g['loss'], STEP_RTOL, 1e-5, 'train step: loss')
     for k, v in losses.items():
-        assert_close(v.cpu().numpy(), g['losses_' + k], 1e-3, 1e-6, 'losses[%s]' % k)
+        close_logged(v.cpu().numpy(), g['losses_' + k], STEP_RTOL, 1e-6, 'train step: losses[%s]' % k)
     assert np.array_equal(output['valid_kpts_anno'].cpu().numpy(), g['output_valid_kpts_anno'])
     for k in ('pred_vertices', 'opt_vertices', 'pred_cam_t', 'opt_cam_t', 'spin_vertices', 'spin_cam_t', 'gt_keypoints'):
         want = g['output_' + k]
-        assert_close(output[k].cpu().numpy(), want, 1e-3, 1e-3 * max(np.abs(want).max(), 1e-3), 'output[%s]' % k)
-    assert_close(output['smplifyoptiverts'][-1].cpu().numpy(), g['output_smplifyoptiverts_last'], 1e-3, 1e-3, 'optiverts')
+        close_logged(output[k].cpu().numpy(), want, STEP_RTOL, STEP_RTOL * max(np.abs(want).max(), 1e-3), 'train step: output[%s]' % k)
+    close_logged(output['smplifyoptiverts'][-1].cpu().numpy(), g['output_smplifyoptiverts_last'], STEP_RTOL, STEP_RTOL,
+                 'train step: optiverts')
     for n in names:
         want = g['fits_after_step_' + n]
         got = module.fits_dict.fits_dict[n].cpu().numpy()
         assert np.array_equal((got != g['static_fits_' + n]).any(1), (want != g['static_fits_' + n]).any(1)), 'updated rows ' + n
-        assert_close(got, want, 1e-3, 2e-3, 'fits table ' + n)
+        close_logged(got, want, STEP_RTOL, 2 * STEP_RTOL, 'train step: fits table ' + n)
     gw = g['grad_fc_weight']
-    assert_close(module.model.fc.weight.grad.cpu().numpy(), gw, 2e-3, 2e-4 * np.abs(gw).max(), 'regressor gradient')
+    close_logged(module.model.fc.weight.grad.cpu().numpy(), gw, STEP_GRAD_RTOL, 0.1 * STEP_GRAD_RTOL * np.abs(gw).max(),
+                 'train step: regressor gradient')
 
 
 def test_forward_train_step_replays_as_a_hip_graph(tmp_path):

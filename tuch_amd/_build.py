@@ -59,5 +59,45 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+ASAN_LIB = os.path.join(HERE, 'libtuch_amd_asan.so')
+
+
+def sanitizer_runtime() -> str:
+    """clang's shared ASan runtime (it carries the UBSan handlers too): LD_PRELOAD it into the python that loads ASAN_LIB."""
+    import glob
+    hits = sorted(glob.glob('/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so'))
+    if not hits:
+        raise FileNotFoundError('libclang_rt.asan-x86_64.so not found under /opt/rocm/lib/llvm')
+    return hits[-1]
+
+
+def build_sanitized(force: bool = False) -> str:
+    """The same sources with AddressSanitizer + UndefinedBehaviorSanitizer on the HOST side (-fno-gpu-sanitize: device
+    code as in the product build) -> libtuch_amd_asan.so.  For the ~1 200 lines of host C++ that build tables (cluster
+    tree, strips, rings, segment / region / HD tables): tests/test_sanitized_host.py, tests/test_gpu_hardening.py."""
+    from concurrent.futures import ThreadPoolExecutor
+    deps = sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    if not force and os.path.exists(ASAN_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(ASAN_LIB) for d in deps):
+        return ASAN_LIB
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    out = os.path.join(HERE, 'build', 'asan')
+    os.makedirs(out, exist_ok=True)
+    san = ['-fsanitize=address,undefined', '-fno-gpu-sanitize', '-fno-sanitize-recover=undefined', '-fno-omit-frame-pointer']
+
+    def compile_one(src):
+        obj = os.path.join(out, os.path.basename(src)[:-4] + '.o')
+        subprocess.run([hipcc, '--offload-arch=' + ARCH, '-O1', '-g', '-std=c++17', '-fPIC', '-I', CSRC] + san
+                       + EXTRA_FLAGS.get(os.path.basename(src), []) + ['-c', src, '-o', obj], check=True)
+        return obj
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        objs = list(pool.map(compile_one, sources()))
+    subprocess.run([hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-fsanitize=address,undefined', '-shared-libsan',
+                    '-o', ASAN_LIB] + objs, check=True)
+    return ASAN_LIB
+
+
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv, verbose=True))
+    if '--sanitized' in sys.argv:
+        print(build_sanitized(force='--force' in sys.argv))
+    else:
+        print(build(force='--force' in sys.argv, verbose=True))

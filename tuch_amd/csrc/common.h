@@ -27,6 +27,12 @@ static __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __built
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Model constants: device memory, or host memory under TUCH_HOST_TABLES=1 (api.hip: sanitizer runs of the table builders)
+int tuch_host_tables();
+int tuch_table_upload(void** dst, const void* src, size_t bytes);
+int tuch_table_download(void* dst_host, const void* src, size_t bytes);
+void tuch_table_free(void* p);
+
 // Deterministic mode (TUCH_DETERMINISTIC=1, read once when the library is loaded, or tuch_set_deterministic): the gradient
 // scatters that are float atomics otherwise (order-dependent in the last ulp) accumulate 64-bit fixed-point numbers with
 // INTEGER atomics -- associative, so the sums do not depend on the order of arrival -- and are converted once at the end:

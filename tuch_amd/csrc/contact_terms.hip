@@ -109,10 +109,13 @@ __global__ __launch_bounds__(kBlock) void contact_terms_ragged_fwd_kernel(
 }
 
 // grad[b][i] += g_b * dd * (x_i - x_p)/d ; grad[b][p] -= the same.  grad pre-zeroed by the caller.
+// Fixed: deterministic mode -- the same scatter into zeroed 64-bit fixed-point accumulators (common.h: fixed_add; integer
+// atomics are associative, the sums do not depend on the order of arrival), converted by fixed_to_float_kernel.
+template <bool Fixed>
 __global__ __launch_bounds__(256) void contact_terms_bwd_kernel(
     const float* __restrict__ pts, const int32_t* __restrict__ partner,
     const uint8_t* __restrict__ exterior, const float* __restrict__ gscale,
-    int N, int mode, float euclthres, float* __restrict__ grad)
+    int N, int mode, float euclthres, float* __restrict__ grad, long long* __restrict__ grad_fixed)
 {
     const int b = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -129,10 +132,17 @@ __global__ __launch_bounds__(256) void contact_terms_bwd_kernel(
     const Term t = contact_term(d, ext, mode, euclthres);
     if (t.dd == 0.0f) return;
     const float c = g * t.dd / d;
-    float* gi = grad + ((size_t)b * N + i) * 3;
-    float* gp = grad + ((size_t)b * N + p) * 3;
-    atomicAdd(gi + 0, c * dx); atomicAdd(gi + 1, c * dy); atomicAdd(gi + 2, c * dz);
-    atomicAdd(gp + 0, -c * dx); atomicAdd(gp + 1, -c * dy); atomicAdd(gp + 2, -c * dz);
+    if (Fixed) {
+        long long* gi = grad_fixed + ((size_t)b * N + i) * 3;
+        long long* gp = grad_fixed + ((size_t)b * N + p) * 3;
+        fixed_add(gi + 0, c * dx); fixed_add(gi + 1, c * dy); fixed_add(gi + 2, c * dz);
+        fixed_add(gp + 0, -c * dx); fixed_add(gp + 1, -c * dy); fixed_add(gp + 2, -c * dz);
+    } else {
+        float* gi = grad + ((size_t)b * N + i) * 3;
+        float* gp = grad + ((size_t)b * N + p) * 3;
+        atomicAdd(gi + 0, c * dx); atomicAdd(gi + 1, c * dy); atomicAdd(gi + 2, c * dz);
+        atomicAdd(gp + 0, -c * dx); atomicAdd(gp + 1, -c * dy); atomicAdd(gp + 2, -c * dz);
+    }
 }
 
 // ragged backward: point i belongs to body body_of[i]; grad [N,3] pre-zeroed by the caller
@@ -500,10 +510,26 @@ extern "C" int tuch_contact_terms_bwd(const float* points, const int32_t* partne
     TUCH_REQUIRE(points && partner && exterior && grad_scale && grad_points,
                  "tuch_contact_terms_bwd: null pointer");
     TUCH_REQUIRE(B > 0 && N > 0 && (mode == 0 || mode == 1), "tuch_contact_terms_bwd: bad arguments");
-    hipLaunchKernelGGL(contact_terms_bwd_kernel, dim3(ceil_div(N, 256), B), dim3(256), 0,
+    hipLaunchKernelGGL(contact_terms_bwd_kernel<false>, dim3(ceil_div(N, 256), B), dim3(256), 0,
                        (hipStream_t)stream, points, partner, exterior, grad_scale, N, mode, euclthres,
-                       grad_points);
+                       grad_points, (long long*)nullptr);
     return tuch_check_launch("tuch_contact_terms_bwd");
+}
+
+extern "C" int tuch_contact_terms_bwd_fixed(const float* points, const int32_t* partner,
+                                            const uint8_t* exterior, const float* grad_scale, int B, int N,
+                                            int mode, float euclthres, void* grad_fixed_zeroed, float* grad_points, void* stream)
+{
+    TUCH_REQUIRE(points && partner && exterior && grad_scale && grad_points && grad_fixed_zeroed,
+                 "tuch_contact_terms_bwd_fixed: null pointer");
+    TUCH_REQUIRE(B > 0 && N > 0 && (mode == 0 || mode == 1), "tuch_contact_terms_bwd_fixed: bad arguments");
+    hipLaunchKernelGGL(contact_terms_bwd_kernel<true>, dim3(ceil_div(N, 256), B), dim3(256), 0,
+                       (hipStream_t)stream, points, partner, exterior, grad_scale, N, mode, euclthres,
+                       (float*)nullptr, (long long*)grad_fixed_zeroed);
+    const size_t n = (size_t)B * N * 3;
+    hipLaunchKernelGGL(fixed_to_float_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const long long*)grad_fixed_zeroed, grad_points, n);
+    return tuch_check_launch("tuch_contact_terms_bwd_fixed");
 }
 
 extern "C" int tuch_contact_terms_ragged_fwd(const float* points, const int32_t* partner,

@@ -57,14 +57,7 @@ constexpr int kSel = 1024;
 template <typename T>
 int upload(T** dst, const T* src, size_t count)
 {
-    *dst = nullptr;
-    if (count == 0) return TUCH_OK;
-    if (hipMalloc((void**)dst, count * sizeof(T)) != hipSuccess ||
-        hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) {
-        tuch_set_error("tuch_hd_model_create: device allocation / copy of %zu bytes failed", count * sizeof(T));
-        return TUCH_ERR_HIP;
-    }
-    return TUCH_OK;
+    return tuch_table_upload((void**)dst, src, count * sizeof(T));
 }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -434,8 +427,7 @@ extern "C" void tuch_hd_model_destroy(tuch_hd_model* hm)
 {
     if (!hm) return;
     void* dev[] = {hm->idx, hm->w, hm->face, hm->tv, hm->mask_id, hm->orig, hm->by_orig, hm->v_off, hm->v_ent, hm->offsets};
-    for (void* p : dev)
-        if (p) (void)hipFree(p);
+    for (void* p : dev) tuch_table_free(p);
     if (hm->side) (void)hipStreamDestroy(hm->side);
     if (hm->ev_fork) (void)hipEventDestroy(hm->ev_fork);
     if (hm->ev_join) (void)hipEventDestroy(hm->ev_join);
@@ -453,7 +445,7 @@ extern "C" int tuch_hd_model_create(tuch_hd_model** out, const tuch_contact_mode
     TUCH_REQUIRE(cm->mask_bits, "tuch_hd_model_create: the contact model has no geodesic mask");
     const int V = cm->V, F = cm->F;
     std::vector<int32_t> faces((size_t)F * 3);
-    if (hipMemcpy(faces.data(), cm->faces, faces.size() * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) {
+    if (tuch_table_download(faces.data(), cm->faces, faces.size() * sizeof(int32_t)) != TUCH_OK) {
         tuch_set_error("tuch_hd_model_create: cannot read the model's faces");
         return TUCH_ERR_HIP;
     }
@@ -508,9 +500,10 @@ extern "C" int tuch_hd_model_create(tuch_hd_model** out, const tuch_contact_mode
     hm->cm = cm; hm->N = N; hm->V = V; hm->F = F; hm->tree_order = tree_mask ? 1 : 0;
     hm->order_host = new std::vector<int32_t>(order);
     hm->enqueue = new std::mutex();
-    if (hipStreamCreateWithFlags(&hm->side, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&hm->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&hm->ev_join, hipEventDisableTiming) != hipSuccess) {
+    if (!tuch_host_tables() &&
+        (hipStreamCreateWithFlags(&hm->side, hipStreamNonBlocking) != hipSuccess ||
+         hipEventCreateWithFlags(&hm->ev_fork, hipEventDisableTiming) != hipSuccess ||
+         hipEventCreateWithFlags(&hm->ev_join, hipEventDisableTiming) != hipSuccess)) {
         tuch_set_error("tuch_hd_model_create: cannot create the side stream / events");
         tuch_hd_model_destroy(hm);
         *out = nullptr;

@@ -48,7 +48,6 @@ struct tuch_options {
     int seg_assist = 1;         // 0: the segment pass counts its body-face crossings itself (read at create only)
     int seg_fused = 1;          // 0: the segment filter as six launches instead of one (A/B, tests)
     int canary = 0;             // 1: guard words between the regions of every workspace, see tuch_workspace_canaries
-    int deterministic = 0;      // 1: gradient scatters as gathers over inverse partner lists (bit-reproducible fits)
     int hd_search = 1;          // HD branch: 1 nearest admissible point on the matrix cores (hd_search.hip), 0 v2v_indexed_kernel
     int hd_search_waves = 4;    // wavefronts per block of 64 columns in that search (4, 2 or 1)
     int hd_overlap = 1;         // HD branch: the inside test of the selected points on a second stream beside their search

@@ -16,17 +16,7 @@ namespace {
 template <typename T>
 int upload(T** dst, const T* src, size_t count)
 {
-    *dst = nullptr;
-    if (count == 0) return TUCH_OK;
-    if (hipMalloc((void**)dst, count * sizeof(T)) != hipSuccess) {
-        tuch_set_error("tuch_contact_model_create: hipMalloc(%zu) failed", count * sizeof(T));
-        return TUCH_ERR_HIP;
-    }
-    if (hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) {
-        tuch_set_error("tuch_contact_model_create: hipMemcpy failed");
-        return TUCH_ERR_HIP;
-    }
-    return TUCH_OK;
+    return tuch_table_upload((void**)dst, src, count * sizeof(T));
 }
 
 int* host_copy(const int32_t* src, size_t n)
@@ -44,8 +34,7 @@ extern "C" void tuch_contact_model_destroy(tuch_contact_model* m)
     void* dev[] = {m->ring_off, m->ring_vidx, m->faces, m->mask_bits, m->strip_vidx, m->strip_sign, m->tree_node, m->tree_vidx, m->tree_sign, m->tree_qperm,
                    m->tree_height_off, m->tree_height_nodes, m->tree_frontier_nodes, m->tree_launch_order, m->tree_ancestors, m->tree_rows, m->tree_v2v_info, m->tree_mask_bits, m->tree_masked, m->tree_sub_leaf, m->tree_masked_leaf, m->tree_leaf_group, m->tree_mask_bits_g, m->tree_mask_tiles, m->tree_tile_lanes, m->seg_blocks, m->seg_of_q, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces, m->seg_link_off, m->seg_link, m->seg_ray_off, m->seg_ray_ent, m->seg_elem_mask, m->seg_vmask, m->seg_vpos, m->seg_cap_off, m->seg_cap_ent, m->seg_cap_range,
                    m->cap_off, m->cap_vidx, m->region_off, m->region_vidx, m->pairs, m->pair_mask, m->pair_mask_off, m->tickets, m->canary_hits};
-    for (void* p : dev)
-        if (p) (void)hipFree(p);
+    for (void* p : dev) tuch_table_free(p);
     free(m->tree_frontier_off_host);
     free(m->tree_face_leaf_host);
     free(m->tree_qperm_host);
@@ -496,7 +485,7 @@ const OptionName kOptions[] = {
     {"ray_pair_cap", &tuch_options::ray_pair_cap}, {"ray_waves", &tuch_options::ray_waves},
     {"v2v_tree", &tuch_options::v2v_tree}, {"v2v_flat", &tuch_options::v2v_flat}, {"v2v_waves", &tuch_options::v2v_waves}, {"v2v_lds", &tuch_options::v2v_lds},
     {"seg_splits", &tuch_options::seg_splits}, {"seg_assist", &tuch_options::seg_assist}, {"seg_fused", &tuch_options::seg_fused},
-    {"canary", &tuch_options::canary}, {"deterministic", &tuch_options::deterministic}, {"hd_search", &tuch_options::hd_search}, {"hd_search_waves", &tuch_options::hd_search_waves}, {"hd_overlap", &tuch_options::hd_overlap},
+    {"canary", &tuch_options::canary}, {"hd_search", &tuch_options::hd_search}, {"hd_search_waves", &tuch_options::hd_search_waves}, {"hd_overlap", &tuch_options::hd_overlap},
 };
 }  // namespace
 
@@ -594,9 +583,9 @@ extern "C" int tuch_contact_model_strips(const tuch_contact_model* m, int* strea
     TUCH_REQUIRE(m, "tuch_contact_model_strips: null model");
     if (stream_len) *stream_len = m->strip_len;
     if (num_strips) *num_strips = m->num_strips;
-    if (vidx_host && hipMemcpy(vidx_host, m->strip_vidx, sizeof(int32_t) * m->strip_len, hipMemcpyDeviceToHost) != hipSuccess)
+    if (vidx_host && tuch_table_download(vidx_host, m->strip_vidx, sizeof(int32_t) * m->strip_len) != TUCH_OK)
         return TUCH_ERR_HIP;
-    if (sign_host && hipMemcpy(sign_host, m->strip_sign, sizeof(float) * m->strip_len, hipMemcpyDeviceToHost) != hipSuccess)
+    if (sign_host && tuch_table_download(sign_host, m->strip_sign, sizeof(float) * m->strip_len) != TUCH_OK)
         return TUCH_ERR_HIP;
     return TUCH_OK;
 }

@@ -429,33 +429,16 @@ __global__ __launch_bounds__(256) void assemble_joints_kernel(
 }
 
 // ----------------------------------------------------------------------------------- backward
-// g_all[b][54][3] = scatter of g_joints through joint_map (deterministic gather form)
-__global__ __launch_bounds__(64) void joints_bwd_kernel(
-    const float* __restrict__ g_joints, const int32_t* __restrict__ joint_map, float* __restrict__ g_all,
-    float* __restrict__ gA_clear, int fixed)
+// g_all[54][3] = scatter of g_joints [49][3] through joint_map (deterministic gather form), formed in LDS by every block
+// that needs it (the skinning adjoint: picked + regressed rows; the per-body tail: the 24 chain joints) from sMap / sG the
+// block loaded together with its other inputs.  As a launch of its own (joints_bwd_kernel, rounds 1-3) this was 6 us at the
+// head of the backward chain for 162 additions per body.
+__device__ __forceinline__ float g_all_entry(const int* sMap, const float* sG, int src, int c)
 {
-    // also clears the body's [32][16] accumulator of the skinning adjoint, which runs next (no memset node in between);
-    // deterministic mode (`fixed`): the accumulators are 64-bit fixed-point words (common.h)
-    if (fixed) {
-        long long* z = reinterpret_cast<long long*>(gA_clear) + (size_t)blockIdx.x * 32 * 16;
-        for (int i = threadIdx.x; i < 32 * 16; i += 64) z[i] = 0;
-    } else {
-        for (int i = threadIdx.x; i < 32 * 16; i += 64) gA_clear[(size_t)blockIdx.x * 32 * 16 + i] = 0.f;
-    }
-    // the map and the body's 49 x 3 gradients go to LDS in one round of loads; the 49-way match runs from there
-    __shared__ int sMap[kOutJoints];
-    __shared__ float sG[kOutJoints * 3];
-    const int b = blockIdx.x;
-    if (threadIdx.x < kOutJoints) sMap[threadIdx.x] = joint_map[threadIdx.x];
-    for (int i = threadIdx.x; i < kOutJoints * 3; i += 64)
-        sG[i] = g_joints ? g_joints[(size_t)b * kOutJoints * 3 + i] : 0.f;
-    __syncthreads();
-    for (int i = threadIdx.x; i < kAllJoints * 3; i += 64) {
-        const int src = i / 3, c = i % 3;
-        float acc = 0.f;
-        for (int o = 0; o < kOutJoints; ++o) acc += sMap[o] == src ? sG[o * 3 + c] : 0.f;
-        g_all[(size_t)b * kAllJoints * 3 + i] = acc;
-    }
+    float acc = 0.f;
+#pragma unroll 7
+    for (int o = 0; o < kOutJoints; ++o) acc += sMap[o] == src ? sG[o * 3 + c] : 0.f;
+    return acc;
 }
 
 // Skinning adjoint.  Per (body, 256-vertex block):
@@ -463,37 +446,31 @@ __global__ __launch_bounds__(64) void joints_bwd_kernel(
 //   g_vposed = T_R^T g_v
 //   gA_part[b][block][j][n] = sum_v W[v][j] * (g_v (x) [v_posed; 1])[n]      (MFMA, K = vertices)
 __global__ __launch_bounds__(kSkinBlock) void skin_bwd_kernel(
-    const float* __restrict__ g_verts, const float* __restrict__ g_all, const float* __restrict__ Jrx,
+    const float* __restrict__ g_verts, const float* __restrict__ g_joints, const int32_t* __restrict__ joint_map,
+    const float* __restrict__ Jrx,
     const int32_t* __restrict__ extra_ids, const float* __restrict__ v_posed, const float* __restrict__ A,
-    const float* __restrict__ weights, int V, float* __restrict__ g_vposed, float* __restrict__ gA_part, int fixed)
+    const float* __restrict__ weights, int V, float* __restrict__ g_vposed, float* __restrict__ gA_part)
 {
     __shared__ float sG[kSkinBlock][16];      // per vertex: g_v (x) [v_posed;1], 12 used
     __shared__ int sIds[kPicked];
-    if (threadIdx.x < kPicked) sIds[threadIdx.x] = extra_ids[threadIdx.x];
+    __shared__ int sMap[kOutJoints];
+    __shared__ float sGj[kOutJoints * 3];
+    __shared__ float sGall[(kPicked + kExtra) * 3];     // rows 24..53 of g_all: picked vertices | regressed joints
     const int b = blockIdx.y;
+    if (threadIdx.x < kPicked) sIds[threadIdx.x] = extra_ids[threadIdx.x];
+    if (threadIdx.x < kOutJoints) sMap[threadIdx.x] = joint_map[threadIdx.x];
+    if (threadIdx.x < kOutJoints * 3) sGj[threadIdx.x] = g_joints ? g_joints[(size_t)b * kOutJoints * 3 + threadIdx.x] : 0.f;
     const int v = blockIdx.x * kSkinBlock + threadIdx.x;
     const bool ok = v < V;
     const int vc = ok ? v : V - 1;
-    const float* ga = g_all + (size_t)b * kAllJoints * 3;
     float g[3] = {0.f, 0.f, 0.f};
     if (g_verts) {
         const float* gp = g_verts + ((size_t)b * V + vc) * 3;
         g[0] = gp[0]; g[1] = gp[1]; g[2] = gp[2];
     }
+    float jr[kExtra];
 #pragma unroll
-    for (int j = 0; j < kExtra; ++j) {
-        const float w = Jrx[(size_t)j * V + vc];
-        const float* gj = ga + (kJoints + kPicked + j) * 3;
-        g[0] = __builtin_fmaf(w, gj[0], g[0]); g[1] = __builtin_fmaf(w, gj[1], g[1]); g[2] = __builtin_fmaf(w, gj[2], g[2]);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < kPicked; ++e)
-        if (sIds[e] == vc) {
-            const float* gj = ga + (kJoints + e) * 3;
-            g[0] += gj[0]; g[1] += gj[1]; g[2] += gj[2];
-        }
-    if (!ok) { g[0] = 0.f; g[1] = 0.f; g[2] = 0.f; }
+    for (int j = 0; j < kExtra; ++j) jr[j] = Jrx[(size_t)j * V + vc];
     const float* Ab = A + (size_t)b * kJoints * 12;
     const float* w = weights + (size_t)vc * kJoints;
     float T[9];
@@ -507,6 +484,22 @@ __global__ __launch_bounds__(kSkinBlock) void skin_bwd_kernel(
     }
     const float* p = v_posed + ((size_t)b * V + vc) * 3;
     const float ph[4] = {p[0], p[1], p[2], 1.0f};
+    __syncthreads();
+    if (threadIdx.x < (kPicked + kExtra) * 3)
+        sGall[threadIdx.x] = g_all_entry(sMap, sGj, kJoints + threadIdx.x / 3, threadIdx.x % 3);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kExtra; ++j) {
+        const float* gj = sGall + (kPicked + j) * 3;
+        g[0] = __builtin_fmaf(jr[j], gj[0], g[0]); g[1] = __builtin_fmaf(jr[j], gj[1], g[1]); g[2] = __builtin_fmaf(jr[j], gj[2], g[2]);
+    }
+#pragma unroll
+    for (int e = 0; e < kPicked; ++e)
+        if (sIds[e] == vc) {
+            const float* gj = sGall + e * 3;
+            g[0] += gj[0]; g[1] += gj[1]; g[2] += gj[2];
+        }
+    if (!ok) { g[0] = 0.f; g[1] = 0.f; g[2] = 0.f; }
     if (ok) {
         float* o = g_vposed + ((size_t)b * V + v) * 3;
 #pragma unroll
@@ -539,16 +532,21 @@ __global__ __launch_bounds__(kSkinBlock) void skin_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < kSteps; ++i)
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(j < kJoints ? a[i] : 0.f, sG[k_beg + i * 4 + lq][lm], acc, 0, 0, 0);
-    // [B][32][16], zeroed by the caller: the vertex blocks accumulate with float atomics
-    if (fixed) {                                        // deterministic mode: integer atomics on fixed-point words
-        long long* out = reinterpret_cast<long long*>(gA_part) + ((size_t)b * 32 + (wave & 1) * 16) * 16;
+    // The block's OWN [32][16] slice, plain stores (rounds 1-3: one accumulator per body, float atomics over the blocks --
+    // it had to be cleared first and the sum depended on the order of arrival; pose_bwd_kernel now adds the ~27 slices in
+    // a fixed order, bit-reproducible without a fixed-point mode).  The second half's partial meets the first in LDS.
+    __syncthreads();                                    // every wavefront is done reading sG
+    float* xch = &sG[0][0];                             // [2][4][64] floats
+    if (wave >= 2) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) fixed_add(&out[(lq * 4 + r) * 16 + lm], acc[r]);
-        return;
+        for (int r = 0; r < 4; ++r) xch[((wave & 1) * 4 + r) * 64 + lane] = acc[r];
     }
-    float* out = gA_part + ((size_t)b * 32 + (wave & 1) * 16) * 16;
+    __syncthreads();
+    if (wave < 2) {
+        float* out = gA_part + (((size_t)b * gridDim.x + blockIdx.x) * 32 + wave * 16) * 16;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(&out[(lq * 4 + r) * 16 + lm], acc[r]);
+        for (int r = 0; r < 4; ++r) out[(lq * 4 + r) * 16 + lm] = acc[r] + xch[(wave * 4 + r) * 64 + lane];
+    }
 }
 
 // part[block][m][n] = sum_{k in the block's 256 columns} g_vposed[m][k] * blend[n][k];  n < 224.
@@ -633,12 +631,22 @@ __global__ __launch_bounds__(64 * kBlendBwdWaves) void blend_bwd_kernel(
 }
 
 // Per body: reduce the partials, chain adjoint, Rodrigues adjoint, shape gradient.
+// adam (optional, SMPLify-DC stage 2): torch.optim.Adam's update of THIS body's global_orient and body_pose rows applied
+// right here, by the block that has just formed their gradients (csrc/adam.hip's arithmetic; the launch of its own, one
+// workgroup at the very end of every iteration's chain, is gone).  step: the shared device counter -- every block reads it
+// before the block that arrives last (ticket) advances it.
+struct PoseAdam {
+    float* root; float* body; int root_stride, body_stride;      // the parameters (axis-angle rows), updated in place
+    float* m_root; float* v_root; float* m_body; float* v_body;  // exp_avg / exp_avg_sq, contiguous [B,3] / [B,69]
+    float* step; int* ticket; float lr, eps, beta1, beta2;
+};
 __global__ __launch_bounds__(256) void pose_bwd_kernel(
-    const float* __restrict__ gA_part, const float* __restrict__ feat_part, int feat_chunks,
-    int bpad, const float* __restrict__ g_all, const float* __restrict__ R, const float* __restrict__ J,
+    const float* __restrict__ gA_part, int skin_blocks, const float* __restrict__ feat_part, int feat_chunks,
+    int bpad, const float* __restrict__ g_joints, const int32_t* __restrict__ joint_map,
+    const float* __restrict__ R, const float* __restrict__ J,
     const float* __restrict__ world, PoseRef pose, int pose2rot,
     const float* __restrict__ J_shapedirs, const int32_t* __restrict__ parents, int max_depth,
-    PoseGrad g_pose, float* __restrict__ g_betas, int fixed)
+    PoseGrad g_pose, float* __restrict__ g_betas, PoseAdam adam)
 {
     __shared__ float sGA[kJoints][12];
     __shared__ float sGF[224];
@@ -656,15 +664,29 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(
     // Everything the block reads from global memory is requested here, in one go: the kernel is a handful of threads
     // of arithmetic behind its loads, and every separate round of loads costs a full memory latency.
     // (gA: one [32][16] accumulator per body, the skinning adjoint adds its blocks with atomics.)
-    float ga0 = 0.f, ga1 = 0.f, w_v = 0.f, r_v = 0.f, j_v = 0.f, gall_v = 0.f, aa_v = 0.f, jsd[3] = {0.f, 0.f, 0.f};
+    float ga0 = 0.f, ga1 = 0.f, w_v = 0.f, r_v = 0.f, j_v = 0.f, aa_v = 0.f, jsd[3] = {0.f, 0.f, 0.f};
     int par_v = -1, dep_v = -1;
-    if (fixed) {
-        const long long* gf = reinterpret_cast<const long long*>(gA_part);
-        ga0 = fixed_value(gf[((size_t)b * 32 + t / 12) * 16 + t % 12]);
-        if (t + 256 < kJoints * 12) ga1 = fixed_value(gf[((size_t)b * 32 + (t + 256) / 12) * 16 + (t + 256) % 12]);
-    } else {
-        ga0 = gA_part[((size_t)b * 32 + t / 12) * 16 + t % 12];
-        if (t + 256 < kJoints * 12) ga1 = gA_part[((size_t)b * 32 + (t + 256) / 12) * 16 + (t + 256) % 12];
+    __shared__ int sMap[kOutJoints];
+    __shared__ float sGj[kOutJoints * 3];
+    if (t < kOutJoints) sMap[t] = joint_map[t];
+    if (t < kOutJoints * 3) sGj[t] = g_joints ? g_joints[(size_t)b * kOutJoints * 3 + t] : 0.f;
+    const float adam_t = adam.step ? adam.step[0] + 1.0f : 0.f;       // read before any block can advance it (ticket below)
+    {
+        // the skinning adjoint's per-block slices [skin_blocks][32][16], added in block order (all loads in flight at once)
+        const float* gp = gA_part + ((size_t)b * skin_blocks * 32 + t / 12) * 16 + t % 12;
+        const float* gq = gA_part + ((size_t)b * skin_blocks * 32 + (t + 256) / 12) * 16 + (t + 256) % 12;
+        const bool second = t + 256 < kJoints * 12;
+        for (int s0 = 0; s0 < skin_blocks; s0 += 9) {
+            float u0[9], u1[9];
+#pragma unroll
+            for (int u = 0; u < 9; ++u) {
+                const bool in = s0 + u < skin_blocks;
+                u0[u] = in ? gp[(size_t)(s0 + u) * 512] : 0.f;
+                u1[u] = in && second ? gq[(size_t)(s0 + u) * 512] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 9; ++u) { ga0 += u0[u]; ga1 += u1[u]; }
+        }
     }
     if (t < kJoints * 9) {
         w_v = world[((size_t)b * kJoints + t / 9) * 12 + t % 9];
@@ -672,7 +694,6 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(
     }
     if (t < kJoints * 3) {
         j_v = J[(size_t)b * kJoints * 3 + t];
-        gall_v = g_all[(size_t)b * kAllJoints * 3 + t];
         if (pose2rot) aa_v = pose_joint(pose, b, t / 3, 3)[t % 3];
     }
     if (t < kJoints) { par_v = parents[t]; dep_v = parents[kJoints + t]; }
@@ -707,7 +728,7 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(
     sGA[t / 12][t % 12] = ga0;                                   // 256 < 288: always a valid slot
     if (t + 256 < kJoints * 12) sGA[(t + 256) / 12][(t + 256) % 12] = ga1;
     if (t < kJoints * 9) { sW[t / 9][t % 9] = w_v; sRl[t / 9][t % 9] = r_v; }
-    if (t < kJoints * 3) { sJb[t / 3][t % 3] = j_v; sGall[t / 3][t % 3] = gall_v; sAA[t / 3][t % 3] = aa_v; }
+    if (t < kJoints * 3) { sJb[t / 3][t % 3] = j_v; sAA[t / 3][t % 3] = aa_v; }
     if (t < kJoints) { sParent[t] = par_v; sDepth[t] = dep_v; }
     __syncthreads();
     if (t < 224) {
@@ -716,6 +737,9 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(
         for (int g = 0; g < kGroups; ++g) sum += sPart[g][t];
         sGF[t] = sum;
     }
+    // rows 0..23 of g_all (the chain joints' share of the joint gradient), formed here instead of by a launch of its own
+    if (t < kJoints * 3) sGall[t / 3][t % 3] = g_all_entry(sMap, sGj, t / 3, t % 3);
+    __syncthreads();
     // Chain adjoint.  Phase A (one thread per joint): contributions of A_k and of the posed joint.
     // Phase B: from the leaves to the root one tree level at a time, the state in LDS: the joints of a level turn their
     // finished gradients into what their parent receives, then every parent adds its children up in a fixed order.
@@ -796,7 +820,26 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(
             float* dst = pose_joint(g_pose, b, t, 3);
             const float* add = t > 0 && g_pose.body_add ? g_pose.body_add + (size_t)b * g_pose.body_add_stride + (size_t)(t - 1) * 3 : nullptr;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) dst[c] = ga[c] + (add ? add[c] : 0.0f);
+            for (int c = 0; c < 3; ++c) ga[c] += add ? add[c] : 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dst[c] = ga[c];
+            if (adam.step) {                    // torch.optim.Adam's update of this joint's three parameters (adam.hip)
+                float* p = t == 0 ? adam.root + (size_t)b * adam.root_stride : adam.body + (size_t)b * adam.body_stride + (size_t)(t - 1) * 3;
+                float* m = t == 0 ? adam.m_root + (size_t)b * 3 : adam.m_body + ((size_t)b * (kJoints - 1) + (t - 1)) * 3;
+                float* v = t == 0 ? adam.v_root + (size_t)b * 3 : adam.v_body + ((size_t)b * (kJoints - 1) + (t - 1)) * 3;
+                const float b1 = adam.beta1, b2 = adam.beta2;
+                const float bc1 = 1.0f - __builtin_powf(b1, adam_t), bc2 = 1.0f - __builtin_powf(b2, adam_t);
+                const float step_size = adam.lr / bc1, inv_sqrt_bc2 = 1.0f / __builtin_sqrtf(bc2);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float mo = m[c], vo = v[c];
+                    const float mn = mo + (ga[c] - mo) * (1.0f - b1);              // lerp, as torch
+                    const float vn = vo * b2 + (1.0f - b2) * ga[c] * ga[c];
+                    m[c] = mn;
+                    v[c] = vn;
+                    p[c] -= step_size * mn / (__builtin_sqrtf(vn) * inv_sqrt_bc2 + adam.eps);
+                }
+            }
         } else {
             float* dst = pose_joint(g_pose, b, t, 9);
             const float* add = t > 0 && g_pose.body_add ? g_pose.body_add + (size_t)b * g_pose.body_add_stride + (size_t)(t - 1) * 9 : nullptr;
@@ -818,6 +861,13 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(
         float acc = sGF[kPoseFeat + t];
         for (int q = 0; q < kJoints; ++q) acc += sShape[t][q];
         g_betas[(size_t)b * kBetas + t] = acc;
+    }
+    if (adam.step && t == 0) {                  // every block has read the counter by the time the last ticket is taken
+        __threadfence();
+        if (atomicAdd(adam.ticket, 1) == (int)gridDim.x - 1) {
+            adam.step[0] = adam_t;
+            *adam.ticket = 0;
+        }
     }
 }
 
@@ -841,7 +891,7 @@ FwdLayout fwd_layout(const tuch_smpl_model* m, int B)
     return l;
 }
 
-struct BwdLayout { size_t g_all, g_vposed, gA_part, feat_part, total; int skin_blocks, feat_chunks, bpad; };
+struct BwdLayout { size_t g_vposed, gA_part, feat_part, total; int skin_blocks, feat_chunks, bpad; };
 
 BwdLayout bwd_layout(const tuch_smpl_model* m, int B)
 {
@@ -850,10 +900,8 @@ BwdLayout bwd_layout(const tuch_smpl_model* m, int B)
     l.feat_chunks = ceil_div(m->N3, kBlendBwdChunk * kBlendBwdWaves);
     l.bpad = ceil_div(B, 16) * 16;
     size_t o = 0;
-    l.g_all = o;     o += align256((size_t)B * kAllJoints * 3 * 4);
     l.g_vposed = o;  o += align256((size_t)B * m->N3 * 4);
-    l.gA_part = o;   o += align256((size_t)B * 32 * 16 * 8);          // one accumulator per body (atomics over the blocks;
-                                                                       // 64-bit words in deterministic mode)
+    l.gA_part = o;   o += align256((size_t)B * l.skin_blocks * 32 * 16 * 4);   // one [32][16] slice per (body, vertex block)
     l.feat_part = o; o += align256((size_t)l.feat_chunks * l.bpad * 224 * 4);
     l.total = o;
     return l;
@@ -862,13 +910,7 @@ BwdLayout bwd_layout(const tuch_smpl_model* m, int B)
 template <typename T>
 int upload(T** dst, const T* src, size_t count)
 {
-    *dst = nullptr;
-    if (hipMalloc((void**)dst, count * sizeof(T)) != hipSuccess ||
-        hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) {
-        tuch_set_error("tuch_smpl_model_create: device upload of %zu bytes failed", count * sizeof(T));
-        return TUCH_ERR_HIP;
-    }
-    return TUCH_OK;
+    return tuch_table_upload((void**)dst, src, count * sizeof(T));
 }
 
 }  // namespace
@@ -877,8 +919,7 @@ extern "C" void tuch_smpl_model_destroy(tuch_smpl_model* m)
 {
     if (!m) return;
     void* dev[] = {m->blend, m->J_template, m->J_shapedirs, m->weights, m->Jrx, m->parents, m->extra_ids, m->joint_map};
-    for (void* p : dev)
-        if (p) (void)hipFree(p);
+    for (void* p : dev) tuch_table_free(p);
     free(m);
 }
 
@@ -1029,12 +1070,12 @@ extern "C" int tuch_smpl_backward_split(const tuch_smpl_model* m, const float* g
 // The same with a gradient the caller already holds for body_pose (g_body_pose_add, same shape, row stride in floats; or
 // NULL): g_body_pose = this call's gradient + that one -- what autograd would otherwise do in a separate add launch when
 // body_pose feeds the body model AND another term (SMPLify-DC: the pose prior, losses.py:63).
-extern "C" int tuch_smpl_backward_split_add(const tuch_smpl_model* m, const float* global_orient, int global_orient_stride,
-                                            const float* body_pose, int body_pose_stride, int pose2rot, int B,
-                                            const void* fwd_workspace, const float* g_verts, const float* g_joints,
-                                            float* g_betas, float* g_global_orient, int g_global_orient_stride,
-                                            float* g_body_pose, int g_body_pose_stride, const float* g_body_pose_add,
-                                            int g_body_pose_add_stride, void* workspace, size_t workspace_bytes, void* stream)
+static int backward_impl(const tuch_smpl_model* m, const float* global_orient, int global_orient_stride,
+                         const float* body_pose, int body_pose_stride, int pose2rot, int B,
+                         const void* fwd_workspace, const float* g_verts, const float* g_joints,
+                         float* g_betas, float* g_global_orient, int g_global_orient_stride,
+                         float* g_body_pose, int g_body_pose_stride, const float* g_body_pose_add,
+                         int g_body_pose_add_stride, const PoseAdam& adam, void* workspace, size_t workspace_bytes, void* stream)
 {
     TUCH_REQUIRE(m && global_orient && body_pose && fwd_workspace && g_betas && g_global_orient && g_body_pose,
                  "tuch_smpl_backward: null pointer");
@@ -1056,20 +1097,61 @@ extern "C" int tuch_smpl_backward_split_add(const tuch_smpl_model* m, const floa
     const float *R = (const float*)(fw + f.R), *J = (const float*)(fw + f.J), *world = (const float*)(fw + f.world),
                 *A = (const float*)(fw + f.A), *v_posed = (const float*)(fw + f.v_posed);
     char* ws = (char*)workspace;
-    float *g_all = (float*)(ws + l.g_all), *g_vposed = (float*)(ws + l.g_vposed), *gA_part = (float*)(ws + l.gA_part),
-          *feat_part = (float*)(ws + l.feat_part);
+    float *g_vposed = (float*)(ws + l.g_vposed), *gA_part = (float*)(ws + l.gA_part), *feat_part = (float*)(ws + l.feat_part);
     hipStream_t s = (hipStream_t)stream;
-    const int fixed = tuch_deterministic();
-    hipLaunchKernelGGL(joints_bwd_kernel, dim3(B), dim3(64), 0, s, g_joints, (const int32_t*)m->joint_map, g_all, gA_part, fixed);
-    hipLaunchKernelGGL(skin_bwd_kernel, dim3(l.skin_blocks, B), dim3(kSkinBlock), 0, s, g_verts, (const float*)g_all,
-                       (const float*)m->Jrx, (const int32_t*)m->extra_ids, v_posed, A, (const float*)m->weights, m->V,
-                       g_vposed, gA_part, fixed);
+    hipLaunchKernelGGL(skin_bwd_kernel, dim3(l.skin_blocks, B), dim3(kSkinBlock), 0, s, g_verts, g_joints,
+                       (const int32_t*)m->joint_map, (const float*)m->Jrx, (const int32_t*)m->extra_ids, v_posed, A,
+                       (const float*)m->weights, m->V, g_vposed, gA_part);
     hipLaunchKernelGGL(blend_bwd_kernel, dim3(l.feat_chunks, ceil_div(l.bpad / 16, kBlendBwdGroups), 14 / kBlendBwdTiles),
                        dim3(64 * kBlendBwdWaves), 0, s, (const float*)g_vposed, (const float*)m->blend, B, m->N3, l.bpad, feat_part);
-    hipLaunchKernelGGL(pose_bwd_kernel, dim3(B), dim3(256), 0, s, (const float*)gA_part,
-                       (const float*)feat_part, l.feat_chunks, l.bpad, (const float*)g_all, R, J, world, pose, pose2rot,
-                       (const float*)m->J_shapedirs, (const int32_t*)m->parents, m->max_depth, g_pose, g_betas, fixed);
+    hipLaunchKernelGGL(pose_bwd_kernel, dim3(B), dim3(256), 0, s, (const float*)gA_part, l.skin_blocks,
+                       (const float*)feat_part, l.feat_chunks, l.bpad, g_joints, (const int32_t*)m->joint_map, R, J, world, pose,
+                       pose2rot, (const float*)m->J_shapedirs, (const int32_t*)m->parents, m->max_depth, g_pose, g_betas, adam);
     return tuch_check_launch("tuch_smpl_backward");
+}
+
+extern "C" int tuch_smpl_backward_split_add(const tuch_smpl_model* m, const float* global_orient, int global_orient_stride,
+                                            const float* body_pose, int body_pose_stride, int pose2rot, int B,
+                                            const void* fwd_workspace, const float* g_verts, const float* g_joints,
+                                            float* g_betas, float* g_global_orient, int g_global_orient_stride,
+                                            float* g_body_pose, int g_body_pose_stride, const float* g_body_pose_add,
+                                            int g_body_pose_add_stride, void* workspace, size_t workspace_bytes, void* stream)
+{
+    PoseAdam none;
+    memset(&none, 0, sizeof(none));
+    return backward_impl(m, global_orient, global_orient_stride, body_pose, body_pose_stride, pose2rot, B, fwd_workspace,
+                         g_verts, g_joints, g_betas, g_global_orient, g_global_orient_stride, g_body_pose, g_body_pose_stride,
+                         g_body_pose_add, g_body_pose_add_stride, none, workspace, workspace_bytes, stream);
+}
+
+// tuch_smpl_backward_split_add + torch.optim.Adam's update (tuch_adam_step's arithmetic) of the two pose tensors THEMSELVES,
+// applied by the last backward kernel to the rows whose gradient it has just written (axis-angle poses only): for a fit
+// whose optimiser holds exactly [global_orient, body_pose] and whose whole gradient arrives through this call (SMPLify-DC
+// stage 2, smplifydc.py:149-183: the body model + the pose prior via g_body_pose_add).  param_*: the tensors the optimiser
+// updates (normally the very memory global_orient / body_pose point to), exp_avg / exp_avg_sq contiguous [B,3] / [B,69],
+// step: the optimiser's device counter (advanced by one), ticket: one zeroed int the call leaves zero.  The gradients are
+// still written to g_*.
+extern "C" int tuch_smpl_backward_split_adam(const tuch_smpl_model* m, const float* global_orient, int global_orient_stride,
+                                             const float* body_pose, int body_pose_stride, int B,
+                                             const void* fwd_workspace, const float* g_verts, const float* g_joints,
+                                             float* g_betas, float* g_global_orient, int g_global_orient_stride,
+                                             float* g_body_pose, int g_body_pose_stride, const float* g_body_pose_add,
+                                             int g_body_pose_add_stride,
+                                             float* param_global_orient, int param_global_orient_stride, float* param_body_pose,
+                                             int param_body_pose_stride, float* exp_avg_global_orient, float* exp_avg_sq_global_orient,
+                                             float* exp_avg_body_pose, float* exp_avg_sq_body_pose, float* step, int* ticket,
+                                             float lr, float beta1, float beta2, float eps,
+                                             void* workspace, size_t workspace_bytes, void* stream)
+{
+    TUCH_REQUIRE(param_global_orient && param_body_pose && exp_avg_global_orient && exp_avg_sq_global_orient && exp_avg_body_pose &&
+                 exp_avg_sq_body_pose && step && ticket, "tuch_smpl_backward_split_adam: null pointer");
+    TUCH_REQUIRE(param_global_orient_stride >= 3 && param_body_pose_stride >= 69, "tuch_smpl_backward_split_adam: bad parameter strides");
+    const PoseAdam adam{param_global_orient, param_body_pose, param_global_orient_stride, param_body_pose_stride,
+                        exp_avg_global_orient, exp_avg_sq_global_orient, exp_avg_body_pose, exp_avg_sq_body_pose, step, ticket,
+                        lr, eps, beta1, beta2};
+    return backward_impl(m, global_orient, global_orient_stride, body_pose, body_pose_stride, 1, B, fwd_workspace,
+                         g_verts, g_joints, g_betas, g_global_orient, g_global_orient_stride, g_body_pose, g_body_pose_stride,
+                         g_body_pose_add, g_body_pose_add_stride, adam, workspace, workspace_bytes, stream);
 }
 
 // pose / g_pose: [B,72] or [B,24,3,3], the concatenated form.

@@ -4,6 +4,7 @@ tuch/models/smpl.py:44-56.  No torch-op fallback."""
 from __future__ import annotations
 
 import ctypes
+import weakref
 
 import numpy as np
 import torch
@@ -26,7 +27,10 @@ class SmplDeviceModel:
         assert arrays[3].shape == (24, self.num_verts) and arrays[4].shape == (self.num_verts, 24)
         assert arrays[6].shape == (21,) and arrays[7].shape == (9, self.num_verts) and arrays[8].shape == (49,)
         handle = ctypes.c_void_p(0)
-        with torch.cuda.device(self.device):
+        import contextlib
+        import os
+        host_tables = os.environ.get('TUCH_HOST_TABLES', '0') not in ('', '0')     # sanitizer runs of the table builders
+        with (contextlib.nullcontext() if host_tables else torch.cuda.device(self.device)):
             _C.check(_C.lib().tuch_smpl_model_create(ctypes.byref(handle), self.num_verts,
                                                      *[a.ctypes.data_as(ctypes.c_void_p) for a in arrays]))
         self._handle = handle
@@ -70,8 +74,9 @@ class _SmplLBS(torch.autograd.Function):
         ctx.shapes = (global_orient.shape, body_pose.shape)
         # A later node that holds ANOTHER gradient for the same body_pose (ops._Stage2Tail: the pose prior) may leave it in
         # pose_grad_extra instead of returning it: backward() then adds it inside its last kernel and autograd has nothing
-        # left to sum (one add launch less per step).  pose_key: how that node recognises the tensor.
-        ctx.pose_key = (body_pose.data_ptr(), tuple(body_pose.shape), body_pose.dtype) if ctx.needs_input_grad[2] else None
+        # left to sum (one add launch less per step).  pose_ref: how that node recognises the tensor -- by IDENTITY (the very
+        # tensor object this node will return a gradient for; an alias with the same address and shape is another leaf).
+        ctx.pose_ref = weakref.ref(body_pose) if ctx.needs_input_grad[2] else None
         ctx.pose_grad_extra = None
         ctx.save_for_backward(go, bp, ws)
         return verts, joints

@@ -205,8 +205,11 @@ class SMPL(nn.Module):
         """Reference: tuch/models/smpl.py:44-56 over smplx SMPL.forward."""
         from .. import lbs
         w = 3 if pose2rot else 9
-        global_orient_rows = global_orient.reshape(-1, w)
-        body_pose_rows = body_pose.reshape(-1, 23 * w)
+        rows = lambda t, n: t if (t.dim() == 2 and t.shape[1] == n) else t.reshape(-1, n)
+        # (a tensor that already has the row shape is passed on AS THE SAME OBJECT: ops._Stage2Tail recognises the pose tensor
+        # it shares with this node by identity)
+        global_orient_rows = rows(global_orient, w)
+        body_pose_rows = rows(body_pose, 23 * w)
         if betas.shape[0] != body_pose_rows.shape[0]:
             betas = betas.expand(body_pose_rows.shape[0], -1)
         # the kernels read the two pose tensors where they are; the concatenation of models/smpl.py:44-47 only on request

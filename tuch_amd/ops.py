@@ -12,6 +12,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import _C
 
@@ -70,7 +71,7 @@ def deterministic() -> bool:
 
 def set_deterministic(on: bool) -> None:
     """Gradient scatters through 64-bit fixed-point integer atomics instead of float atomics: an SMPLify-DC fit reproduces
-    bit for bit (stage-2 tail and SMPL adjoint; the training losses' HD / plain contact terms keep float atomics).
+    bit for bit (stage-2 tail, SMPL adjoint, the training loss's plain term -- _ContactTerms -- and its HD term).
     Graphs captured before the switch keep the mode they were captured in."""
     _C.lib().tuch_set_deterministic(int(bool(on)))
 
@@ -179,11 +180,18 @@ class _ContactTerms(torch.autograd.Function):
     def backward(ctx, grad_terms):
         pts, partner, exterior, valid = ctx.saved_tensors
         b, n, _ = pts.shape
-        grad = torch.zeros_like(pts)
         g = grad_terms.to(torch.float32)
         if valid is not None:
             g = g * valid.to(g.dtype)[:, None]
         g = g.contiguous()   # [B,2]: upstream gradient of the interior and of the exterior sum
+        if deterministic():
+            # 64-bit fixed-point accumulators + integer atomics: the plain training term's gradient is bit-reproducible too
+            fixed = torch.zeros(b * n * 3, dtype=torch.int64, device=pts.device)
+            grad = torch.empty_like(pts)
+            _C.check(_C.lib().tuch_contact_terms_bwd_fixed(_C.ptr(pts), _C.ptr(partner), _C.ptr(exterior), _C.ptr(g), b, n,
+                                                           ctx.mode, ctx.euclthres, _C.ptr(fixed), _C.ptr(grad), _C.stream()))
+            return grad, None, None, None, None, None
+        grad = torch.zeros_like(pts)
         _C.check(_C.lib().tuch_contact_terms_bwd(_C.ptr(pts), _C.ptr(partner), _C.ptr(exterior), _C.ptr(g),
                                                  b, n, ctx.mode, ctx.euclthres, _C.ptr(grad), _C.stream()))
         return grad, None, None, None, None, None
@@ -391,12 +399,13 @@ class _Stage2Tail(torch.autograd.Function):
         # vertex gradient) and can add the prior's pose gradient inside its own last kernel (lbs._SmplLBS: pose_grad_extra)
         # instead of autograd summing two gradients in a launch of its own
         node = verts.grad_fn
-        key = (body_pose.data_ptr(), tuple(body_pose.shape), body_pose.dtype)
-        ctx.lbs_node = node if (want_grad and ctx.needs_input_grad[0] and ctx.needs_input_grad[3] and node is not None
-                                and getattr(node, 'pose_key', None) == key) else None
+        ref = getattr(node, 'pose_ref', None) if node is not None else None
+        ctx.lbs_node = node if (want_grad and ctx.needs_input_grad[0] and ctx.needs_input_grad[3] and ref is not None
+                                and ref() is body_pose) else None
         return out[0]
 
     @staticmethod
+    @once_differentiable          # the gradients were formed in forward(): constants of a second differentiation
     def backward(ctx, g):
         gv, gj, gc, gp = ctx.saved_tensors
         dv, dj, dc, dp = ctx.in_dtypes
@@ -575,11 +584,12 @@ class ContactModel:
     def _handle(self):
         if self._h is None:
             keep, gm, num_caps, num_regions = self._host
-            if self.device.type != 'cuda':
+            host_tables = os.environ.get('TUCH_HOST_TABLES', '0') not in ('', '0')    # sanitizer runs of the table builders
+            if self.device.type != 'cuda' and not host_tables:
                 raise _C.TuchError('tuch_amd kernels need a HIP device, the model was created for %s' % self.device)
             p = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a.size else ctypes.c_void_p(0)
             handle = ctypes.c_void_p(0)
-            with torch.cuda.device(self.device):
+            with (contextlib.nullcontext() if host_tables else torch.cuda.device(self.device)):
                 _C.check(_C.lib().tuch_contact_model_create(
                     ctypes.byref(handle), self.num_verts, self.num_faces, p(keep['faces']),
                     gm.ctypes.data_as(ctypes.c_void_p) if gm is not None else ctypes.c_void_p(0),
@@ -843,7 +853,8 @@ class HDModel:
             idx, w, face = self._host
             handle = ctypes.c_void_p(0)
             cm = self.contact_model._handle
-            with torch.cuda.device(self.contact_model.device):
+            host_tables = os.environ.get('TUCH_HOST_TABLES', '0') not in ('', '0')
+            with (contextlib.nullcontext() if host_tables else torch.cuda.device(self.contact_model.device)):
                 _C.check(_C.lib().tuch_hd_model_create(ctypes.byref(handle), cm, self.num_points,
                                                        idx.ctypes.data_as(ctypes.c_void_p), w.ctypes.data_as(ctypes.c_void_p),
                                                        face.ctypes.data_as(ctypes.c_void_p)))

@@ -21,7 +21,15 @@ class Adam:
 
     MAX_TENSORS, MAX_ELEMENTS = 8, 65536
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, **unused):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, **other):
+        # only torch.optim.Adam's plain update: anything that would change it (weight_decay, amsgrad, maximize, ...) is
+        # refused, so that make_adam falls back to torch.optim.Adam instead of silently ignoring the setting
+        changed = {k: v for k, v in other.items()
+                   if not (k in ('weight_decay', 'amsgrad', 'maximize') and not v or k in ('capturable', 'foreach', 'fused',
+                                                                                         'differentiable') and v in (None, False))}
+        if changed:
+            raise ValueError('tuch_amd.optim.Adam supports lr / betas / eps only (got %s); use torch.optim.Adam'
+                             % ', '.join(sorted(changed)))
         self.params = list(params)
         if not 0 < len(self.params) <= self.MAX_TENSORS or sum(p.numel() for p in self.params) > self.MAX_ELEMENTS:
             raise ValueError('tuch_amd.optim.Adam is for a few small tensors; use torch.optim.Adam')
@@ -62,8 +70,11 @@ class Adam:
             grads.append(p.grad if p.grad.is_contiguous() else p.grad.contiguous())
         n = len(self.params)
         g = (ctypes.c_void_p * n)(*[t.data_ptr() for t in grads])
+        # lr / eps as they are NOW in param_groups (a scheduler or the caller may have changed them; a captured hipGraph keeps
+        # the values it was captured with, like torch's own non-tensor lr)
+        group = self.param_groups[0]
         _C.check(_C.lib().tuch_adam_step(n, self._p, g, self._m, self._v, self._sizes, self._betas,
-                                         _C.ptr(self.step_count), self.lr, self.eps, _C.stream()))
+                                         _C.ptr(self.step_count), float(group['lr']), float(group['eps']), _C.stream()))
 
 
 def make_adam(params, lr, capturable=True, **adam_kwargs):
