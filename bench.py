@@ -257,7 +257,8 @@ def make_step(p):
     global_orient = p['global_orient'].clone().requires_grad_(True)
     from tuch_amd.optim import make_adam
     # the reference's torch.optim.Adam update as one launch (tuch_amd/optim.py, what SMPLifyDC's own loops use)
-    opt = make_adam([body_pose, global_orient], 1e-2)
+    # (fuse_backward: the body model's last backward kernel applies the update itself, as in SMPLifyDC's kept stage-2 loop)
+    opt = make_adam([body_pose, global_orient], 1e-2, fuse_backward=os.environ.get('TUCH_FUSED_ADAM', '1') != '0')
     count = torch.full((), float(body_pose.shape[0]), device=body_pose.device)
 
     def step():

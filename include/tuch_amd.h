@@ -271,6 +271,12 @@ int tuch_v2v_min_model(const tuch_contact_model* model, const float* verts, int 
 int tuch_v2v_min_model_shared(const tuch_contact_model* model, const float* verts, int B, float* min_d2,
                               int32_t* argmin, void* hint_inout, void* workspace, size_t workspace_bytes, int leave_room,
                               void* stream);
+/* The same; additionally `zero` (16-byte aligned, zero_bytes a multiple of 16; or NULL / 0) is cleared by the call's first
+ * kernel: on the stream, before anything the caller enqueues behind the call -- instead of a fill launch of its own
+ * (SMPLify-DC stage 2: the vertex gradient its tail scatters into, the tail's arrival counter, the region pairs' keys). */
+int tuch_v2v_min_model_shared_zero(const tuch_contact_model* model, const float* verts, int B, float* min_d2, int32_t* argmin,
+                                   void* hint_inout, void* workspace, size_t workspace_bytes, int leave_room, void* zero,
+                                   size_t zero_bytes, void* stream);
 
 /* Cluster tree over the faces of a closed mesh (host only, no device needed): the structure behind the
  * hierarchical evaluation of winding_numbers (tuch/utils/contact.py:112-147) inside tuch_exterior_flags.
@@ -365,6 +371,23 @@ int tuch_smpl_backward_split_add(const tuch_smpl_model* model, const float* glob
                                  float* g_global_orient, int g_global_orient_stride, float* g_body_pose,
                                  int g_body_pose_stride, const float* g_body_pose_add, int g_body_pose_add_stride,
                                  void* workspace, size_t workspace_bytes, void* stream);
+/* tuch_smpl_backward_split_add (axis-angle poses) + torch.optim.Adam's update (tuch_adam_step's arithmetic) of the two pose
+ * tensors themselves, applied by the last backward kernel to the rows whose gradient it has just written: for a fit whose
+ * optimiser holds exactly [global_orient, body_pose] and whose whole gradient arrives through this call (SMPLify-DC stage 2,
+ * tuch/smplify/smplifydc.py:149-183: the body model + the pose prior via g_body_pose_add) -- the optimiser's own launch at
+ * the end of every iteration is gone.  param_*: the tensors the optimiser updates (normally the memory global_orient /
+ * body_pose point to), exp_avg* contiguous [B,3] / [B,69], step: the optimiser's device counter (advanced by one),
+ * ticket: one zeroed int the call leaves zero.  The gradients are still written to g_*. */
+int tuch_smpl_backward_split_adam(const tuch_smpl_model* model, const float* global_orient, int global_orient_stride,
+                                  const float* body_pose, int body_pose_stride, int B, const void* fwd_workspace,
+                                  const float* g_verts, const float* g_joints, float* g_betas, float* g_global_orient,
+                                  int g_global_orient_stride, float* g_body_pose, int g_body_pose_stride,
+                                  const float* g_body_pose_add, int g_body_pose_add_stride,
+                                  float* param_global_orient, int param_global_orient_stride, float* param_body_pose,
+                                  int param_body_pose_stride, float* exp_avg_global_orient, float* exp_avg_sq_global_orient,
+                                  float* exp_avg_body_pose, float* exp_avg_sq_body_pose, float* step, int* ticket,
+                                  float lr, float beta1, float beta2, float eps,
+                                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- caller-side glue of the training step ----------------------------------------
  * tuch_estimate_translation: tuch/utils/geometry.py:114-205 (estimate_translation + estimate_translation_np):

@@ -203,8 +203,12 @@ def run(v):
     torch.cuda.synchronize()
     return ext.cpu().numpy(), mn.cpu().numpy(), partner.cpu().numpy(), per_body.detach().cpu().numpy(), v.grad.cpu().numpy()
 
+from tuch_amd import ops
+ops.set_deterministic(True)          # gradient scatters through integer atomics: bit-reproducible, so "identical" can be asked
 clean = run(verts)
-out = {}
+again = run(verts)
+out = {'repeat': {'others_bit_identical': all(np.array_equal(a, c) for a, c in zip(again, clean)), 'differs': []}}
+names = ('exterior', 'min_d2', 'partner', 'contact', 'grad')
 for kind, value, ids in (('nan_one_vertex', float('nan'), [1234]), ('inf_one_vertex', float('inf'), [77]),
                          ('nan_whole_body', float('nan'), None), ('nan_scattered', float('nan'), list(range(0, 6890, 13)))):
     v = verts.clone()
@@ -214,11 +218,12 @@ for kind, value, ids in (('nan_one_vertex', float('nan'), [1234]), ('inf_one_ver
         v[3, ids, 1] = value
     got = run(v)
     others = [b for b in range(8) if b != 3]
-    same = all(np.array_equal(a[others], c[others], equal_nan=False) for a, c in zip(got, clean))
+    differs = [n for n, a, c in zip(names, got, clean) if not np.array_equal(a[others], c[others])]
     V = verts.shape[1]
-    out[kind] = {'others_bit_identical': bool(same), 'bad_body_loss': float(got[3][3]),
+    out[kind] = {'others_bit_identical': not differs, 'differs': differs, 'bad_body_loss': float(got[3][3]),
                  'bad_body_loss_finite': bool(np.isfinite(got[3][3])),
                  'partners_in_range': bool(((got[2] >= 0) & (got[2] < V)).all())}
+ops.set_deterministic(False)
 # the whole stage-2 step (LBS + objective + backward + Adam) with a NaN pose: must terminate
 p['body_pose'][5, 7] = float('nan')
 step = bench.make_step(p)
@@ -247,7 +252,12 @@ def test_nonfinite_body_in_a_batch_of_eight():
         if kind == 'step_with_nan_pose':
             assert not r['loss_finite'], out
             continue
-        assert r['others_bit_identical'], (kind, out)
+        assert r['others_bit_identical'], (kind, r)
+        if kind == 'repeat':
+            continue
         assert r['partners_in_range'], (kind, out)
-        assert not r['bad_body_loss_finite'], (kind, out)
+        # NaN coordinates: the reference's d_i = |v_i - v_j*| of the bad vertex is NaN -> NaN loss (losses.py:98-105).  An INF
+        # coordinate gives the reference a finite (meaningless) value as well -- tanh(inf)^2 = 1 -- so only NaN is held to NaN
+        if kind.startswith('nan'):
+            assert not r['bad_body_loss_finite'], (kind, out)
         report('non-finite input [%s]: other bodies bit-identical, bad body loss %r' % (kind, r['bad_body_loss']), 0, 7)

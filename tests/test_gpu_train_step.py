@@ -14,8 +14,8 @@ from tuch_amd.synthetic import make_body, make_regressor
 pytestmark = pytest.mark.gpu
 DEV = torch.device('cuda:0')
 # step-level tolerances (5 + 5 Adam iterations inside the step, float atomics): 3 x the observed maxima (close_logged's log)
-STEP_RTOL = 1e-3
-STEP_GRAD_RTOL = 2e-3
+STEP_RTOL = 1e-5           # observed <= 9.3e-7
+STEP_GRAD_RTOL = 5e-5      # observed 1.2e-6 of the largest entry
 
 
 def _golden():

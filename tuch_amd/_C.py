@@ -42,6 +42,10 @@ _SIGNATURES = {
                                        c_void_p, c_void_p]),
     'tuch_contact_terms_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                        c_void_p, c_void_p]),
+    'tuch_smpl_backward_split_adam': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                                              c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_size_t, c_void_p]),
     'tuch_contact_terms_bwd_fixed': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                              c_void_p, c_void_p, c_void_p]),
     'tuch_smplify_small_terms': (c_int, [c_void_p] * 9 + [c_int, c_int, c_int, c_float, c_float, c_float] + [c_void_p] * 5),
@@ -93,6 +97,8 @@ _SIGNATURES = {
     'tuch_v2v_min_model': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'tuch_v2v_min_model_shared': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int,
                                           c_void_p]),
+    'tuch_v2v_min_model_shared_zero': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int,
+                                               c_void_p, c_size_t, c_void_p]),
     'tuch_exterior_workspace_bytes': (c_size_t, [c_void_p, c_int]),
     'tuch_exterior_flags': (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -25,16 +25,13 @@ __global__ __launch_bounds__(kAdamBlock) void adam_kernel(AdamTensors a, float* 
 {
     const float t = step[0] + 1.0f;
     for (int k = 0; k < a.count; ++k) {
-        const float b1 = a.beta1[k], b2 = a.beta2[k];
-        const float bc1 = 1.0f - __builtin_powf(b1, t), bc2 = 1.0f - __builtin_powf(b2, t);
-        const float step_size = lr / bc1, inv_sqrt_bc2 = 1.0f / __builtin_sqrtf(bc2);
+        const AdamScalars sc = adam_scalars(lr, a.beta1[k], a.beta2[k], eps, t);
         for (int i = threadIdx.x; i < a.n[k]; i += kAdamBlock) {
-            const float g = a.g[k][i];
-            const float m = a.m[k][i] + (g - a.m[k][i]) * (1.0f - b1);            // lerp, as torch
-            const float v = a.v[k][i] * b2 + (1.0f - b2) * g * g;
+            float p = a.p[k][i], m = a.m[k][i], v = a.v[k][i];
+            adam_update(p, m, v, a.g[k][i], sc);                                  // common.h: the same bits as the fused form
             a.m[k][i] = m;
             a.v[k][i] = v;
-            a.p[k][i] -= step_size * m / (__builtin_sqrtf(v) * inv_sqrt_bc2 + eps);
+            a.p[k][i] = p;
         }
     }
     __syncthreads();

@@ -44,3 +44,25 @@ static __device__ __forceinline__ void fixed_add(long long* acc, float x)
     atomicAdd((unsigned long long*)acc, (unsigned long long)__double2ll_rn((double)x * kFixedScale));
 }
 static __device__ __forceinline__ float fixed_value(long long acc) { return (float)((double)acc * (1.0 / kFixedScale)); }
+
+// torch.optim.Adam's update of one element (no weight decay / amsgrad), shared by adam_kernel (adam.hip) and the body
+// model's last backward kernel (smpl_lbs.hip: PoseAdam) so that the two give the same BITS: every operation is spelled
+// out (no contraction left to the compiler, which may group a * b + c * d either way in different kernels).
+//   m = lerp(m, g, 1 - b1);  v = b2 v + (1 - b2) g g;  p -= step_size m / (sqrt(v) inv_sqrt_bc2 + eps)
+struct AdamScalars { float b1, b2, step_size, inv_sqrt_bc2, eps; };
+static __device__ __forceinline__ AdamScalars adam_scalars(float lr, float beta1, float beta2, float eps, float t)
+{
+    const float bc1 = 1.0f - __builtin_powf(beta1, t), bc2 = 1.0f - __builtin_powf(beta2, t);
+    return AdamScalars{beta1, beta2, lr / bc1, 1.0f / __builtin_sqrtf(bc2), eps};
+}
+#pragma clang fp contract(off)
+static __device__ __forceinline__ void adam_update(float& p, float& m, float& v, float g, const AdamScalars& a)
+{
+    const float mn = __builtin_fmaf(g - m, 1.0f - a.b1, m);                       // lerp, as torch
+    const float vn = __builtin_fmaf((1.0f - a.b2) * g, g, v * a.b2);
+    const float denom = __builtin_fmaf(__builtin_sqrtf(vn), a.inv_sqrt_bc2, a.eps);
+    m = mn;
+    v = vn;
+    p = p - a.step_size * mn / denom;
+}
+#pragma clang fp contract(fast)

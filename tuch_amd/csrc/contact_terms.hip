@@ -30,7 +30,13 @@ __device__ __forceinline__ Term contact_term(float d, bool exterior, int mode, f
     Term t = {0.0f, 0.0f};
     float weight, scale;
     if (exterior) {
-        if (mode == 0 && !(d < euclthres)) return t;
+        if (mode == 0 && !(d < euclthres)) {
+            // a NaN distance (a non-finite vertex or partner) poisons the body's sum whatever the flag says: the reference's
+            // winding numbers are NaN for EVERY query of such a body (contact.py:79-109), `.le(0.99)` is false, the vertex
+            // counts as interior and its tanh^2(NaN) reaches the loss (losses.py:96-105)
+            if (d != d) t.value = d;
+            return t;
+        }
         weight = 0.005f; scale = 0.005f;
     } else {
         weight = 1.0f; scale = 0.04f;

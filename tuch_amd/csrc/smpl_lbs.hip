@@ -827,18 +827,9 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(
                 float* p = t == 0 ? adam.root + (size_t)b * adam.root_stride : adam.body + (size_t)b * adam.body_stride + (size_t)(t - 1) * 3;
                 float* m = t == 0 ? adam.m_root + (size_t)b * 3 : adam.m_body + ((size_t)b * (kJoints - 1) + (t - 1)) * 3;
                 float* v = t == 0 ? adam.v_root + (size_t)b * 3 : adam.v_body + ((size_t)b * (kJoints - 1) + (t - 1)) * 3;
-                const float b1 = adam.beta1, b2 = adam.beta2;
-                const float bc1 = 1.0f - __builtin_powf(b1, adam_t), bc2 = 1.0f - __builtin_powf(b2, adam_t);
-                const float step_size = adam.lr / bc1, inv_sqrt_bc2 = 1.0f / __builtin_sqrtf(bc2);
+                const AdamScalars sc = adam_scalars(adam.lr, adam.beta1, adam.beta2, adam.eps, adam_t);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float mo = m[c], vo = v[c];
-                    const float mn = mo + (ga[c] - mo) * (1.0f - b1);              // lerp, as torch
-                    const float vn = vo * b2 + (1.0f - b2) * ga[c] * ga[c];
-                    m[c] = mn;
-                    v[c] = vn;
-                    p[c] -= step_size * mn / (__builtin_sqrtf(vn) * inv_sqrt_bc2 + adam.eps);
-                }
+                for (int c = 0; c < 3; ++c) adam_update(p[c], m[c], v[c], ga[c], sc);
             }
         } else {
             float* dst = pose_joint(g_pose, b, t, 9);

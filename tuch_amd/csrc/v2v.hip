@@ -772,8 +772,16 @@ __global__ __launch_bounds__(kBoundsBlock) void v2v_rows_seed_kernel(
     const int32_t* __restrict__ height_off, const int32_t* __restrict__ height_nodes, int N, float* __restrict__ prow,
     float* __restrict__ bounds, float* __restrict__ leafbox, const int32_t* __restrict__ leaf_group, float* __restrict__ prow_g,
     int G, int row_blocks, const uint64_t* __restrict__ bits, const int32_t* __restrict__ hint, uint64_t* __restrict__ keys,
-    float* __restrict__ colbox, float* __restrict__ tilebox)
+    float* __restrict__ colbox, float* __restrict__ tilebox, uint4* __restrict__ zero, size_t zero_n16)
 {
+    // a buffer the CALLER wants cleared before the kernels it enqueues behind this call run (SMPLify-DC stage 2: the vertex
+    // gradient the tail scatters into, its arrival counter, the region pairs' keys -- a fill launch of 5 us in front of them
+    // otherwise): one 16-byte store per thread, every workgroup of this launch takes part
+    if (zero) {
+        const size_t stride = (size_t)gridDim.x * gridDim.y * kBoundsBlock;
+        for (size_t i = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kBoundsBlock + threadIdx.x; i < zero_n16; i += stride)
+            zero[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
     if ((int)blockIdx.x < row_blocks) {
         v2v_rows_body(blockIdx.x, verts, V, Vp, qperm, rows, height_off, height_nodes, N, prow, bounds, leafbox, leaf_group,
                       prow_g, G);
@@ -1331,9 +1339,16 @@ extern "C" size_t tuch_v2v_hint_bytes(const tuch_contact_model* m, int B)
     return (size_t)B * m->tree_qblocks * 2 * kTreeCols * sizeof(int32_t);
 }
 
+extern "C" int tuch_v2v_min_model_shared_zero(const tuch_contact_model* m, const float* verts, int B, float* min_d2,
+                                              int32_t* argmin, void* hint_inout, void* workspace, size_t workspace_bytes,
+                                              int leave_room, void* zero, size_t zero_bytes, void* stream);
 extern "C" int tuch_v2v_min_model_shared(const tuch_contact_model* m, const float* verts, int B, float* min_d2,
                                          int32_t* argmin, void* hint_inout, void* workspace, size_t workspace_bytes,
-                                         int leave_room, void* stream);
+                                         int leave_room, void* stream)
+{
+    return tuch_v2v_min_model_shared_zero(m, verts, B, min_d2, argmin, hint_inout, workspace, workspace_bytes, leave_room, nullptr, 0,
+                                          stream);
+}
 
 extern "C" int tuch_v2v_min_model(const tuch_contact_model* m, const float* verts, int B, float* min_d2,
                                   int32_t* argmin, void* hint_inout, void* workspace, size_t workspace_bytes, void* stream)
@@ -1341,13 +1356,20 @@ extern "C" int tuch_v2v_min_model(const tuch_contact_model* m, const float* vert
     return tuch_v2v_min_model_shared(m, verts, B, min_d2, argmin, hint_inout, workspace, workspace_bytes, 0, stream);
 }
 
-extern "C" int tuch_v2v_min_model_shared(const tuch_contact_model* m, const float* verts, int B, float* min_d2,
-                                         int32_t* argmin, void* hint_inout, void* workspace, size_t workspace_bytes,
-                                         int leave_room, void* stream)
+// zero / zero_bytes (multiple of 16, or NULL / 0): a caller buffer cleared by this call's FIRST kernel -- on the stream, before
+// anything enqueued behind the call (no fill launch of the caller's own).
+extern "C" int tuch_v2v_min_model_shared_zero(const tuch_contact_model* m, const float* verts, int B, float* min_d2,
+                                              int32_t* argmin, void* hint_inout, void* workspace, size_t workspace_bytes,
+                                              int leave_room, void* zero, size_t zero_bytes, void* stream)
 {
     TUCH_REQUIRE(m && verts && (min_d2 || argmin), "tuch_v2v_min_model: null pointer");
     TUCH_REQUIRE(m->mask_bits, "tuch_v2v_min_model: the model has no geodesic mask");
     TUCH_REQUIRE(B > 0 && B <= 65535, "tuch_v2v_min_model: bad batch %d", B);
+    TUCH_REQUIRE((zero_bytes & 15) == 0 && (((uintptr_t)zero) & 15) == 0 && (zero || zero_bytes == 0),
+                 "tuch_v2v_min_model: the buffer to clear must be 16-byte aligned and a multiple of 16 bytes");
+    const bool fused_zero = zero && zero_bytes && use_v2v_tree(m) && flat_mode(m) >= 2 && hint_inout;
+    if (zero && zero_bytes && !fused_zero && hipMemsetAsync(zero, 0, zero_bytes, (hipStream_t)stream) != hipSuccess)
+        return tuch_check_launch("tuch_v2v_min_model: clearing the caller's buffer");
     if (!use_v2v_tree(m))
         return tuch_v2v_min_masked(verts, m->mask_bits, B, m->V, min_d2, argmin, workspace, workspace_bytes, stream);
     tuch_ws_scope scope(m->opt.canary != 0);
@@ -1376,7 +1398,8 @@ extern "C" int tuch_v2v_min_model_shared(const tuch_contact_model* m, const floa
                            (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, N, prow, bounds, leafbox,
                            (const int32_t*)m->tree_leaf_group, scan == 2 ? (float*)(ws + l.prow_g) : (float*)nullptr,
                            m->tree_groups, row_blocks, (const uint64_t*)m->tree_mask_bits, (const int32_t*)hint_inout, keys,
-                           colbox, scan == 3 ? (float*)(ws + l.tilebox) : (float*)nullptr);
+                           colbox, scan == 3 ? (float*)(ws + l.tilebox) : (float*)nullptr, (uint4*)(fused_zero ? zero : nullptr),
+                           fused_zero ? zero_bytes / 16 : (size_t)0);
     } else {
     hipLaunchKernelGGL(v2v_rows_kernel, dim3(row_blocks, B), dim3(kBoundsBlock), 0, s,
                        verts, V, Vp, (const int32_t*)m->tree_qperm, (const int32_t*)m->tree_rows,

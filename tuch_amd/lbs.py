@@ -77,7 +77,9 @@ class _SmplLBS(torch.autograd.Function):
         # left to sum (one add launch less per step).  pose_ref: how that node recognises the tensor -- by IDENTITY (the very
         # tensor object this node will return a gradient for; an alias with the same address and shape is another leaf).
         ctx.pose_ref = weakref.ref(body_pose) if ctx.needs_input_grad[2] else None
+        ctx.orient_ref = weakref.ref(global_orient) if ctx.needs_input_grad[1] else None
         ctx.pose_grad_extra = None
+        ctx.root_pass = None          # set by ops._Stage2Tail.backward: the id of a backward pass whose ROOT is that node
         ctx.save_for_backward(go, bp, ws)
         return verts, joints
 
@@ -96,10 +98,36 @@ class _SmplLBS(torch.autograd.Function):
         ws2 = torch.empty(nbytes, dtype=torch.uint8, device=go.device)
         tagged, ctx.pose_grad_extra = ctx.pose_grad_extra, None
         extra = None
-        if tagged is not None:
-            f = getattr(torch._C, '_current_graph_task_id', None)
-            if f is not None and int(f()) == tagged[1]:          # left by a node of THIS backward pass
-                extra = tagged[0].to(torch.float32).reshape(b, 23 * w).contiguous()
+        f = getattr(torch._C, '_current_graph_task_id', None)
+        task = int(f()) if f is not None else -1
+        if tagged is not None and task >= 0 and task == tagged[1]:          # left by a node of THIS backward pass
+            extra = tagged[0].to(torch.float32).reshape(b, 23 * w).contiguous()
+        # Adam inside the last backward kernel (optim.Adam(fuse_backward=True)): only when this pass's root is the stage-2
+        # objective node, which has routed the prior's gradient here -- then what this call computes IS the whole gradient
+        # of the two pose tensors
+        adam = None
+        root_pass, ctx.root_pass = ctx.root_pass, None
+        if ctx.pose2rot and extra is not None and task >= 0 and root_pass == task and ctx.orient_ref is not None \
+                and not ctx.needs_input_grad[0]:
+            from . import optim
+            go_t, bp_t = ctx.orient_ref(), ctx.pose_ref() if ctx.pose_ref is not None else None
+            adam = optim.fusable_for(go_t, bp_t)
+            if adam is not None and not (go_t.is_contiguous() and bp_t.is_contiguous() and go_t.shape == (b, 3)
+                                         and bp_t.shape == (b, 69) and go_t.data_ptr() == go.data_ptr()
+                                         and bp_t.data_ptr() == bp.data_ptr()):
+                adam = None
+        if adam is not None:
+            group = adam.param_groups[0]
+            st_go, st_bp = adam.state[go_t], adam.state[bp_t]
+            _C.check(L.tuch_smpl_backward_split_adam(
+                ctx.dm._handle, _C.row_ptr(go), go.stride(0), _C.row_ptr(bp), bp.stride(0), b, _C.ptr(ws), _C.ptr(gv), _C.ptr(gj),
+                _C.ptr(g_betas), _C.ptr(g_go), w, _C.ptr(g_bp), 23 * w, _C.ptr(extra), 23 * w,
+                _C.ptr(go_t), go_t.stride(0), _C.ptr(bp_t), bp_t.stride(0), _C.ptr(st_go['exp_avg']), _C.ptr(st_go['exp_avg_sq']),
+                _C.ptr(st_bp['exp_avg']), _C.ptr(st_bp['exp_avg_sq']), _C.ptr(adam.step_count), _C.ptr(adam._ticket),
+                float(group['lr']), float(group['betas'][0]), float(group['betas'][1]), float(group['eps']),
+                _C.ptr(ws2), nbytes, _C.stream()))
+            adam._applied = True
+            return g_betas, g_go.view(ctx.shapes[0]), g_bp.view(ctx.shapes[1]), None, None
         _C.check(L.tuch_smpl_backward_split_add(ctx.dm._handle, _C.row_ptr(go), go.stride(0), _C.row_ptr(bp), bp.stride(0),
                                                 int(ctx.pose2rot), b, _C.ptr(ws), _C.ptr(gv), _C.ptr(gj),
                                                 _C.ptr(g_betas), _C.ptr(g_go), w, _C.ptr(g_bp), 23 * w,

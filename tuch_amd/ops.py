@@ -361,16 +361,17 @@ class _Stage2Tail(torch.autograd.Function):
         gp = torch.empty(b, 69, dtype=torch.float32, device=v.device)
         p = model.num_pairs if select is not None else 0
 
-        def beside_the_walk():          # on the second stream (ContactModel.exterior_and_partner)
-            # ONE cleared buffer: the vertex gradient the unit backward accumulates into, the arrival counter of the
-            # tail kernel ("the last block adds up": it belongs to THIS call -- no counter shared between streams, none
-            # left non-zero by an aborted launch) and the region pairs' keys (tuch_region_pair_keys wants them zero)
-            n = v.numel()
-            k0 = n + 1 + ((n + 1) & 1)                  # the 64-bit keys start on an even word behind the counter
-            det = 2 * n if deterministic() else 0       # deterministic mode: 64-bit fixed-point accumulators
-            zeros = torch.zeros(k0 + 2 * b * p + det, dtype=torch.float32, device=v.device)
+        # ONE cleared buffer: the vertex gradient the unit backward accumulates into, the arrival counter of the
+        # tail kernel ("the last block adds up": it belongs to THIS call -- no counter shared between streams, none
+        # left non-zero by an aborted launch) and the region pairs' keys (tuch_region_pair_keys wants them zero).  It is
+        # cleared by the FIRST kernel of the search (a fill launch of its own was 5 us of the second stream's chain).
+        n = v.numel()
+        k0 = n + 1 + ((n + 1) & 1)                  # the 64-bit keys start on an even word behind the counter
+        det = 2 * n if deterministic() else 0       # deterministic mode: 64-bit fixed-point accumulators
+
+        def beside_the_walk(zeros):          # on the second stream (ContactModel.exterior_and_partner), behind the search
             keys = zeros[k0:k0 + 2 * b * p].view(torch.int64) if p else None
-            fixed = zeros[k0 + 2 * b * p:].view(torch.int64) if det else None
+            fixed = zeros[k0 + 2 * b * p:k0 + 2 * b * p + det].view(torch.int64) if det else None
             if p:
                 _C.check(L.tuch_region_pair_keys(model._handle, _C.ptr(v), b, _C.ptr(select), 1, _C.ptr(keys), _C.stream()))
             _C.check(L.tuch_smplify_small_terms(
@@ -379,7 +380,7 @@ class _Stage2Tail(torch.autograd.Function):
                 float(const['prior_scale']), _C.ptr(small), _C.ptr(gj), _C.ptr(gc), _C.ptr(gp), _C.stream()))
             return (keys, fixed, small, gj, gc, gp, zeros[:n].view(v.shape), zeros[n:n + 1].view(torch.int32))
         exterior, _, partner, _extra = model.exterior_and_partner(v, apply_segments=const['apply_segments'],
-                                                                  also=beside_the_walk)
+                                                                  also=beside_the_walk, zero_floats=k0 + 2 * b * p + det)
         out = torch.empty(1, dtype=torch.float32, device=v.device)
         share = torch.empty(L.tuch_smplify_stage2_fused_scratch_floats(b), dtype=torch.float32, device=v.device)
         # the objective is the root of the fit's graph: its vertex gradient for a unit upstream gradient is written by the
@@ -411,13 +412,17 @@ class _Stage2Tail(torch.autograd.Function):
         dv, dj, dc, dp = ctx.in_dtypes
         # loss.backward() through ops.backward_scalar seeds the graph with a cached tensor of ones: recognised by its
         # address (no device round trip).  Any other upstream gradient scales the unit gradients.
-        if not any(g.data_ptr() == seed.data_ptr() for seed in _ONES.values()):
+        root = any(g.data_ptr() == seed.data_ptr() for seed in _ONES.values())
+        if not root:
             g = g.reshape(()).to(torch.float32)
             gv, gj, gc, gp = gv * g, gj * g, gc * g, gp * g
         if ctx.lbs_node is not None and _graph_task_id() >= 0:
             # tagged with THIS backward pass: the body model's node takes it only within the same pass (a gradient left by
             # a pass that never reached that node must not leak into a later one)
             ctx.lbs_node.pose_grad_extra = (gp, _graph_task_id())
+            # seeded by ops.backward_scalar: this node is the ROOT of the pass, every gradient of the fit's parameters flows
+            # through what it returns -- the body model's node may then apply the optimiser's update itself (lbs.py)
+            ctx.lbs_node.root_pass = _graph_task_id() if root else None
             return gv.to(dv), gj.to(dj), gc.to(dc), None, None, None, None, None
         return gv.to(dv), gj.to(dj), gc.to(dc), gp.to(dp), None, None, None, None
 
@@ -662,15 +667,23 @@ class ContactModel:
                                              sign.ctypes.data_as(ctypes.c_void_p)))
         return vidx, sign, k.value
 
-    def exterior_and_partner(self, verts: torch.Tensor, apply_segments: bool = True, also=None):
+    def exterior_and_partner(self, verts: torch.Tensor, apply_segments: bool = True, also=None, zero_floats: int = 0):
         """exterior_flags + v2v_min of the same vertices -> (exterior, min_d2, partner[, also()]).
         The two only share their input: the nearest-vertex search (and the optional callable ``also``,
         e.g. the region pairs) runs on a second stream so that its tail fills the gaps of the long winding
-        walk (option overlap = 0 keeps everything on the current stream)."""
+        walk (option overlap = 0 keeps everything on the current stream).
+        zero_floats > 0: a float32 buffer of (at least) that many ZEROS is handed to ``also(buffer)`` -- cleared by the
+        search's first kernel (tuch_v2v_min_model_shared_zero), not by a fill launch."""
+        zero = None
+        if zero_floats > 0:
+            zero = torch.empty((int(zero_floats) + 3) // 4 * 4, dtype=torch.float32, device=verts.device)
+            call_also = (lambda: also(zero)) if also is not None else None
+        else:
+            call_also = also
         if not (verts.is_cuda and self._py_options['overlap']):
             exterior = self.exterior_flags(verts, apply_segments=apply_segments)
-            mn, partner = self.v2v_min(verts)
-            return exterior, mn, partner, (also() if also is not None else None)
+            mn, partner = self.v2v_min(verts, zero=zero)
+            return exterior, mn, partner, (call_also() if call_also is not None else None)
         cur = torch.cuda.current_stream(verts.device)
         side = _side_stream(verts.device)
         side.wait_stream(cur)
@@ -683,10 +696,12 @@ class ContactModel:
             # delays the search's start)
             exterior = self.exterior_flags(verts, apply_segments=apply_segments)
         with torch.cuda.stream(side):
-            mn, partner = self.v2v_min(verts, leave_room=True)
+            if zero is not None:
+                zero.record_stream(side)
+            mn, partner = self.v2v_min(verts, leave_room=True, zero=zero)
             # (the caller's extra work -- region pairs, reprojection + prior -- FIRST, beside the short head of the inside
             # test's chain, was measured: 0.587 against 0.552 ms per step; it delays the search, which the chain waits for)
-            extra = also() if also is not None else None
+            extra = call_also() if call_also is not None else None
         if not first:
             exterior = self.exterior_flags(verts, apply_segments=apply_segments)
         cur.wait_stream(side)
@@ -741,8 +756,9 @@ class ContactModel:
         return (ext, w, seg_w, seg_e) if return_details else ext
 
     # K1
-    def v2v_min(self, verts: torch.Tensor, leave_room: bool = False):
-        """leave_room: other kernels run beside the search on another stream (tuch_v2v_min_model_shared)."""
+    def v2v_min(self, verts: torch.Tensor, leave_room: bool = False, zero: Optional[torch.Tensor] = None):
+        """leave_room: other kernels run beside the search on another stream (tuch_v2v_min_model_shared).
+        zero: a caller tensor (numel * itemsize a multiple of 16) cleared by the call's first kernel (..._shared_zero)."""
         if not self.has_mask:
             raise _C.TuchError('ContactModel was created without a geodesic mask')
         verts = _f32(verts)
@@ -753,8 +769,9 @@ class ContactModel:
         arg = torch.empty(b, self.num_verts, dtype=torch.int32, device=verts.device)
         nbytes = L.tuch_v2v_model_workspace_bytes(self._handle, b)
         ws = _workspace(nbytes, verts.device)
-        _C.check(L.tuch_v2v_min_model_shared(self._handle, _C.ptr(verts), b, _C.ptr(mn), _C.ptr(arg),
-                                             _C.ptr(self._v2v_hint(b)), _C.ptr(ws), nbytes, int(leave_room), _C.stream()))
+        _C.check(L.tuch_v2v_min_model_shared_zero(self._handle, _C.ptr(verts), b, _C.ptr(mn), _C.ptr(arg),
+                                                  _C.ptr(self._v2v_hint(b)), _C.ptr(ws), nbytes, int(leave_room), _C.ptr(zero),
+                                                  zero.numel() * zero.element_size() if zero is not None else 0, _C.stream()))
         return mn, arg
 
     def _v2v_hint(self, batch: int) -> Optional[torch.Tensor]:

@@ -8,11 +8,27 @@ at most 65536 elements in total, at most 8 of them -- anything else: use torch.o
 from __future__ import annotations
 
 import ctypes
+import weakref
 
 import numpy as np
 import torch
 
 from . import _C
+
+# optimisers created with fuse_backward=True, by the id of each of their parameters (lbs._SmplLBS.backward asks)
+_FUSABLE = weakref.WeakValueDictionary()
+
+
+def fusable_for(global_orient, body_pose):
+    """The Adam (created with fuse_backward=True) whose parameters are EXACTLY these two tensor objects, else None."""
+    if global_orient is None or body_pose is None:
+        return None
+    opt = _FUSABLE.get(id(global_orient))
+    if opt is None or opt is not _FUSABLE.get(id(body_pose)) or len(opt.params) != 2:
+        return None
+    if not any(p is global_orient for p in opt.params) or not any(p is body_pose for p in opt.params):
+        return None
+    return opt
 
 
 class Adam:
@@ -21,7 +37,7 @@ class Adam:
 
     MAX_TENSORS, MAX_ELEMENTS = 8, 65536
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, **other):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, fuse_backward=False, **other):
         # only torch.optim.Adam's plain update: anything that would change it (weight_decay, amsgrad, maximize, ...) is
         # refused, so that make_adam falls back to torch.optim.Adam instead of silently ignoring the setting
         changed = {k: v for k, v in other.items()
@@ -49,6 +65,17 @@ class Adam:
         self._m = ptrs([self.state[p]['exp_avg'] for p in self.params])
         self._v = ptrs([self.state[p]['exp_avg_sq'] for p in self.params])
         self.param_groups = [{'params': self.params, 'lr': self.lr, 'betas': tuple(betas), 'eps': self.eps}]
+        # fuse_backward (opt-in, SMPLify-DC stage 2): when the parameters are exactly the body model's two pose tensors and
+        # the WHOLE gradient of the objective reaches them through one _SmplLBS node (ops._Stage2Tail is the root of the graph
+        # and routes the pose prior's gradient through that node), the node's last backward kernel applies this update itself
+        # (tuch_smpl_backward_split_adam) and the following step() is a no-op: one launch less at the end of every iteration.
+        # NOTE the consequence: with fuse_backward the parameters move during loss.backward(), not during step().
+        self._applied = False
+        self._ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.fuse_backward = bool(fuse_backward)
+        if self.fuse_backward:
+            for p in self.params:
+                _FUSABLE[id(p)] = self
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         for p in self.params:
@@ -63,6 +90,9 @@ class Adam:
         torch._foreach_zero_([self.step_count] + [s[k] for s in self.state.values() for k in ('exp_avg', 'exp_avg_sq')])
 
     def step(self) -> None:
+        if self._applied:               # the backward pass has applied this update already (fuse_backward)
+            self._applied = False
+            return
         grads = []
         for p in self.params:
             if p.grad is None:
@@ -77,10 +107,10 @@ class Adam:
                                          _C.ptr(self.step_count), float(group['lr']), float(group['eps']), _C.stream()))
 
 
-def make_adam(params, lr, capturable=True, **adam_kwargs):
+def make_adam(params, lr, capturable=True, fuse_backward=False, **adam_kwargs):
     """tuch_amd.optim.Adam where it applies (HIP float32 parameters, few and small), else torch.optim.Adam."""
     params = list(params)
     try:
-        return Adam(params, lr=lr, **adam_kwargs)
+        return Adam(params, lr=lr, fuse_backward=fuse_backward, **adam_kwargs)
     except ValueError:
         return torch.optim.Adam(params, lr=lr, capturable=capturable and params[0].is_cuda, **adam_kwargs)

@@ -82,6 +82,7 @@ class SMPLifyDC():
         # makes every call capture its loops afresh
         self.graph_strict = os.environ.get('TUCH_GRAPH_STRICT', '0') == '1'
         self.keep_sessions = os.environ.get('TUCH_SMPLIFY_SESSIONS', '1') != '0'
+        self.fused_adam = os.environ.get('TUCH_FUSED_ADAM', '1') != '0'      # 0: Adam as a launch of its own (A/B, tests)
         self.history = None
         self.graph_replayed = {}
         # captured loops are kept between calls (keyed by batch size and the constant arguments): a training step
@@ -154,9 +155,11 @@ class SMPLifyDC():
     class _Stage:
         """One Adam loop on static tensors: three eager iterations + capture the first time, replays afterwards."""
 
-        def __init__(self, owner, name, params, iteration, adam_kwargs):
+        def __init__(self, owner, name, params, iteration, adam_kwargs, fuse_backward=False):
             self.owner, self.name, self.params, self.iteration = owner, name, params, iteration
-            self.optimizer = make_adam(params, owner.step_size, capturable=True, **adam_kwargs)
+            # fuse_backward (the contact stage 2: parameters = the body model's two pose tensors, objective = one root node):
+            # the body model's last backward kernel applies Adam's update itself, step() is then a no-op (optim.py)
+            self.optimizer = make_adam(params, owner.step_size, capturable=True, fuse_backward=fuse_backward, **adam_kwargs)
             self.graph, self.verts, self.loss = None, None, None
 
         def _one(self):
@@ -240,7 +243,8 @@ class SMPLifyDC():
                                      dict(betas=(0.9, 0.999)))
         if use_contact:
             sess['stage2'] = (lambda: flags(True, True, False, False),
-                              lambda: self._Stage(self, 'stage2', [body_pose, global_orient], contact_iteration, {}))
+                              lambda: self._Stage(self, 'stage2', [body_pose, global_orient], contact_iteration, {},
+                                                  fuse_backward=self.fused_adam))
         else:
             sess['stage2'] = (lambda: flags(True, True, True, False),
                               lambda: self._Stage(self, 'stage2', [body_pose, betas, global_orient], body_iteration,
