@@ -605,10 +605,18 @@ def workloads(device, seed):
                 'regressors; ms = eager (CPU-launch-bound: ~580 small launches), graph_ms = the same step captured once and '
                 'replayed; contact_only_* = SMPL fwd (pose2rot=False) + RegressorLoss.contact_loss + backward alone'}
     p64 = build_problem(64, device, seed + 2)
+    step5 = make_tuch_step(p64, run_smplify=True, smplify_iters=10)
+    ms5 = round(time_kernel(step5, 2) * 1e3, 4)
+    try:        # the whole step as ONE hipGraph: the SMPLify-DC iterations are unrolled into the enclosing capture
+        graph5 = round(time_kernel(capture(step5, 3), 5) * 1e3, 4)
+    except Exception as e:                                       # noqa: BLE001 -- reported, not fatal for the bench line
+        graph5 = 'capture failed: %s: %s' % (type(e).__name__, str(e).splitlines()[0][:200])
     out['config5_shard_b64_in_the_loop_step'] = {
-        'ms': round(time_kernel(make_tuch_step(p64, run_smplify=True, smplify_iters=10), 2) * 1e3, 4),
+        'ms': ms5, 'graph_ms': graph5,
         'what': 'TUCH.forward_train_step with --run_smplify (SMPLify-DC 10 + 10 iterations with contact in the loop) + '
-                'backward, 64 bodies per rank (512 / 8); the bf16 ResNet regressor is stock PyTorch and not part of the path'}
+                'backward, 64 bodies per rank (512 / 8); ms = eager step (its SMPLify loops replay their own kept graphs), '
+                'graph_ms = the whole step captured once and replayed as one hipGraph (the loops unrolled into it); the '
+                'bf16 ResNet regressor is stock PyTorch and not part of the path'}
     return out
 
 

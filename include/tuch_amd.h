@@ -129,6 +129,17 @@ int tuch_smplify_small_terms(const float* joints, const float* camera_t, const f
                              float prior_scale, float* out, float* grad_joints, float* grad_camera_t,
                              float* grad_body_pose, void* stream);
 
+/* The stage-1 objective of SMPLify-DC, camera_fitting_loss (tuch/smplify/losses.py:125-152), in one launch:
+ * out[0] = sum_b [ sum_j conf^2 gmof(proj - j2d, sigma) + depth_weight^2 (t_z - t_z^est)^2 + shape_weight^2 |betas_b|^2 ]
+ * and its gradients for a unit upstream gradient: grad_joints [B,J,3], grad_camera_t [B,3], grad_betas [B,num_betas]
+ * (betas / grad_betas may be NULL: no shape term).  share: B floats of scratch; ticket: one int, zero before the first
+ * call and left zero by every call (the block that arrives last adds the bodies up in body order: deterministic). */
+int tuch_smplify_stage1_terms(const float* joints, const float* camera_t, const float* camera_t_est,
+                              const float* camera_center, const float* joints_2d, const float* joints_conf,
+                              const float* betas, int B, int num_joints, int num_betas, float focal_length, float sigma,
+                              float depth_weight, float shape_weight, float* share, int* ticket, float* out,
+                              float* grad_joints, float* grad_camera_t, float* grad_betas, void* stream);
+
 /* Adam update (torch.optim.Adam without weight decay / amsgrad: tuch/smplify/smplifydc.py:117,150 optimises body pose,
  * global orientation, betas, camera translation with it) of up to 8 small tensors in ONE launch, the step counter on the
  * device (capturable).  params / grads / exp_avg / exp_avg_sq: `count` device pointers each (host arrays), sizes[k]

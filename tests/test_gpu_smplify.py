@@ -462,3 +462,40 @@ def test_adam_inside_the_backward_kernel_matches_the_separate_launch(monkeypatch
     # step() is called in the three eager iterations and the capture of each kept loop: stage 1 always launches its own
     # update, stage 2 only without the fusion
     assert sum(steps_plain) > sum(steps_fused) >= 1 and sum(steps_plain) - sum(steps_fused) >= 3, (steps_fused, steps_plain)
+
+
+@pytest.mark.parametrize('shape_w', [1.0, 0.0])
+def test_stage1_objective_in_one_launch_vs_reference_and_torch_ops(shape_w):
+    """camera_fitting_loss (losses.py:125-152) on a HIP device is ONE kernel (ops._Stage1Objective): the value against the
+    reference's own golden (shape_prior_weight = 1) and, value + gradients w.r.t. joints / camera translation / betas,
+    against the torch-op form of the same function (autograd), also under a non-unit upstream gradient."""
+    import types
+    from tuch_amd.smplify import losses
+    g = golden('medium')
+    t = lambda a: torch.tensor(a, device=DEV)
+
+    def run(fused, scale):
+        losses.STAGE1_FUSED = fused
+        try:
+            j = t(g['model_joints']).requires_grad_(True)
+            cam = t(g['camera_t']).requires_grad_(True)
+            be = t(g['betas']).requires_grad_(True)
+            out = types.SimpleNamespace(joints=j, betas=be)
+            val = losses.camera_fitting_loss(out, cam, t(g['camera_t_est']), t(g['camera_center']), t(g['joints_2d']),
+                                             t(g['joints_conf']), focal_length=5000., shape_prior_weight=shape_w)
+            (val * scale).backward()
+            return val.item(), j.grad.cpu().numpy(), cam.grad.cpu().numpy(), None if be.grad is None else be.grad.cpu().numpy()
+        finally:
+            losses.STAGE1_FUSED = True
+    for scale in (1.0, 0.37):
+        v1, gj1, gc1, gb1 = run(True, scale)
+        v0, gj0, gc0, gb0 = run(False, scale)
+        if shape_w == 1.0:
+            assert_close(v1, g['camera_fitting_loss'], 1e-5, 0, 'fused stage-1 objective vs the reference')
+        assert_close(v1, v0, 1e-5, 0, 'value')
+        for a, b_, name in ((gj1, gj0, 'joints'), (gc1, gc0, 'camera_t')):
+            assert_close(a, b_, 1e-4, 1e-6 * np.abs(b_).max(), 'grad ' + name)
+        if shape_w:
+            assert_close(gb1, gb0, 1e-5, 1e-7, 'grad betas')
+        else:
+            assert gb1 is None or not gb1.any()

@@ -49,6 +49,7 @@ _SIGNATURES = {
     'tuch_contact_terms_bwd_fixed': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                              c_void_p, c_void_p, c_void_p]),
     'tuch_smplify_small_terms': (c_int, [c_void_p] * 9 + [c_int, c_int, c_int, c_float, c_float, c_float] + [c_void_p] * 5),
+    'tuch_smplify_stage1_terms': (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_float, c_float, c_float, c_float] + [c_void_p] * 7),
     'tuch_adam_step': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                 c_void_p]),
     'tuch_smplify_objective': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p]),

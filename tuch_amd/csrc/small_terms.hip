@@ -132,6 +132,97 @@ extern "C" int tuch_smplify_small_terms(const float* joints, const float* camera
     return tuch_check_launch("tuch_smplify_small_terms");
 }
 
+// ---- the stage-1 objective of SMPLify-DC as ONE launch (tuch/smplify/losses.py:125-152: camera_fitting_loss) ----------------
+//   total = sum_b [ sum_j conf^2 gmof(proj - j2d) + dw^2 (t_z - t_z^est)^2 + sw^2 |beta|^2 ]
+// and its gradients w.r.t. joints, camera translation and betas for a unit upstream gradient.  One block per body; the
+// block that arrives last (ticket: one int the call finds zero and leaves zero) adds the bodies' shares up in body order.
+// As torch ops (projection, division, gmof, three reductions and their autograd) the loop body was ~50 launches of ~3 us
+// at the end of every stage-1 iteration: a quarter of a 100 + 100-iteration fit (BASELINE config 3).
+namespace {
+__global__ __launch_bounds__(kBlock) void stage1_terms_kernel(
+    const float* __restrict__ joints, const float* __restrict__ cam_t, const float* __restrict__ cam_t_est,
+    const float* __restrict__ cam_c, const float* __restrict__ j2d, const float* __restrict__ conf,
+    const float* __restrict__ betas, int J, int NB, float focal, float sigma, float depth_w2, float shape_w2,
+    float* __restrict__ share, int* __restrict__ ticket, float* __restrict__ out,
+    float* __restrict__ g_joints, float* __restrict__ g_cam, float* __restrict__ g_betas)
+{
+    __shared__ float red[kBlock];
+    __shared__ float sgc[3][kBlock];
+    __shared__ bool last;
+    const int b = blockIdx.x, t = threadIdx.x;
+    float loss = 0.f, gcx = 0.f, gcy = 0.f, gcz = 0.f;
+    const float s2 = sigma * sigma;
+    for (int j = t; j < J; j += kBlock) {                     // (the arithmetic of small_terms_kernel)
+        const float* X = joints + ((size_t)b * J + j) * 3;
+        const float x = X[0] + cam_t[3 * b], y = X[1] + cam_t[3 * b + 1], z = X[2] + cam_t[3 * b + 2];
+        const float iz = 1.0f / z;
+        const float rx = focal * (x * iz) + cam_c[2 * b] - j2d[((size_t)b * J + j) * 2];
+        const float ry = focal * (y * iz) + cam_c[2 * b + 1] - j2d[((size_t)b * J + j) * 2 + 1];
+        const float c2 = conf[(size_t)b * J + j] * conf[(size_t)b * J + j];
+        const float dx = s2 + rx * rx, dy = s2 + ry * ry;
+        loss += c2 * (s2 * rx * rx / dx + s2 * ry * ry / dy);
+        const float gx = c2 * 2.0f * s2 * s2 * rx / (dx * dx), gy = c2 * 2.0f * s2 * s2 * ry / (dy * dy);
+        const float a = gx * focal * iz, c = gy * focal * iz;
+        const float e = -(gx * focal * x + gy * focal * y) * iz * iz;
+        float* g = g_joints + ((size_t)b * J + j) * 3;
+        g[0] = a; g[1] = c; g[2] = e;
+        gcx += a; gcy += c; gcz += e;
+    }
+    float shape = 0.f;
+    if (betas && t < NB) {
+        const float be = betas[(size_t)b * NB + t];
+        shape = shape_w2 * be * be;
+        if (g_betas) g_betas[(size_t)b * NB + t] = 2.0f * shape_w2 * be;
+    }
+    red[t] = loss + shape; sgc[0][t] = gcx; sgc[1][t] = gcy; sgc[2][t] = gcz;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if (t < s) {
+            red[t] += red[t + s];
+            sgc[0][t] += sgc[0][t + s]; sgc[1][t] += sgc[1][t + s]; sgc[2][t] += sgc[2][t + s];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const float dz = cam_t[3 * b + 2] - cam_t_est[3 * b + 2];
+        share[b] = red[0] + depth_w2 * dz * dz;
+        g_cam[3 * b] = sgc[0][0]; g_cam[3 * b + 1] = sgc[1][0]; g_cam[3 * b + 2] = sgc[2][0] + 2.0f * depth_w2 * dz;
+        __threadfence();
+        last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    float acc = 0.f;
+    for (int i = t; i < (int)gridDim.x; i += kBlock) acc += __builtin_nontemporal_load(share + i);
+    red[t] = acc;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if (t < s) red[t] += red[t + s];
+        __syncthreads();
+    }
+    if (t == 0) { out[0] = red[0]; *ticket = 0; }
+}
+}  // namespace
+
+extern "C" int tuch_smplify_stage1_terms(const float* joints, const float* camera_t, const float* camera_t_est,
+                                         const float* camera_center, const float* joints_2d, const float* joints_conf,
+                                         const float* betas, int B, int num_joints, int num_betas, float focal_length,
+                                         float sigma, float depth_weight, float shape_weight, float* share, int* ticket,
+                                         float* out, float* grad_joints, float* grad_camera_t, float* grad_betas,
+                                         void* stream)
+{
+    TUCH_REQUIRE(joints && camera_t && camera_t_est && camera_center && joints_2d && joints_conf && share && ticket && out &&
+                     grad_joints && grad_camera_t, "tuch_smplify_stage1_terms: null pointer");
+    TUCH_REQUIRE(B > 0 && num_joints > 0 && num_betas >= 0 && num_betas <= kBlock && (!betas || grad_betas),
+                 "tuch_smplify_stage1_terms: bad sizes");
+    hipLaunchKernelGGL(stage1_terms_kernel, dim3(B), dim3(kBlock), 0, (hipStream_t)stream, joints, camera_t, camera_t_est,
+                       camera_center, joints_2d, joints_conf, betas, num_joints, num_betas, focal_length, sigma,
+                       depth_weight * depth_weight, shape_weight * shape_weight, share, ticket, out, grad_joints,
+                       grad_camera_t, grad_betas);
+    return tuch_check_launch("tuch_smplify_stage1_terms");
+}
+
 // ---- SMPLify-DC objective assembly, tuch/smplify/losses.py:120-123 ---------------------------
 //   total = sum_b [ reprojection_b + prior_b + 10 * (interior_b + exterior_b) + clw * sum_p r2r[b,p] ]
 // one block, fixed-order tree reduction (deterministic).

@@ -332,6 +332,62 @@ def smplify_objective(small, terms, r2r, contact_scale, r2r_scale):
     return _Objective.apply(small, terms, r2r, contact_scale, r2r_scale)
 
 
+_TICKETS = {}
+
+
+def _ticket(device) -> torch.Tensor:
+    """One zeroed int per (device, stream): the arrival counter of kernels whose last block finishes the job (they leave it
+    zero).  Calls on one stream are ordered, so they can share it; another stream gets its own."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    t = _TICKETS.get(key)
+    if t is None:
+        t = _TICKETS[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return t
+
+
+class _Stage1Objective(torch.autograd.Function):
+    """camera_fitting_loss (tuch/smplify/losses.py:125-152) as ONE launch: reprojection + depth term + shape prior, the
+    scalar total and the unit gradients w.r.t. joints / camera translation / betas (csrc/small_terms.hip:
+    stage1_terms_kernel).  backward() only hands the gradients over (scaled unless the upstream gradient is the cached
+    unit seed of ops.backward_scalar)."""
+
+    @staticmethod
+    def forward(ctx, joints, camera_t, betas, camera_t_est, camera_center, joints_2d, joints_conf, focal, sigma, depth_w,
+                shape_w):
+        j, ct = _f32(joints), _f32(camera_t)
+        b, nj, _ = j.shape
+        be = _f32(betas) if betas is not None and shape_w != 0.0 else None
+        est, cc, j2d, conf = _f32(camera_t_est), _f32(camera_center), _f32(joints_2d), _f32(joints_conf)
+        out = torch.empty(1, dtype=torch.float32, device=j.device)
+        share = torch.empty(b, dtype=torch.float32, device=j.device)
+        gj = torch.empty_like(j)
+        gc = torch.empty(b, 3, dtype=torch.float32, device=j.device)
+        gb = torch.empty_like(be) if be is not None else None
+        _C.check(_C.lib().tuch_smplify_stage1_terms(
+            _C.ptr(j), _C.ptr(ct), _C.ptr(est), _C.ptr(cc), _C.ptr(j2d), _C.ptr(conf), _C.ptr(be), b, nj,
+            be.shape[1] if be is not None else 0, float(focal), float(sigma), float(depth_w), float(shape_w), _C.ptr(share),
+            _C.ptr(_ticket(j.device)), _C.ptr(out), _C.ptr(gj), _C.ptr(gc), _C.ptr(gb), _C.stream()))
+        ctx.save_for_backward(gj, gc, gb)
+        ctx.in_dtypes = (joints.dtype, camera_t.dtype, betas.dtype if betas is not None else None)
+        return out[0]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        gj, gc, gb = ctx.saved_tensors
+        if not any(g.data_ptr() == seed.data_ptr() for seed in _ONES.values()):
+            g = g.reshape(()).to(torch.float32)
+            gj, gc, gb = gj * g, gc * g, (gb * g if gb is not None else None)
+        dj, dc, db = ctx.in_dtypes
+        return (gj.to(dj), gc.to(dc), gb.to(db) if gb is not None else None) + (None,) * 8
+
+
+def smplify_stage1_objective(joints, camera_t, betas, camera_t_est, camera_center, joints_2d, joints_conf, focal, sigma,
+                             depth_weight, shape_weight):
+    return _Stage1Objective.apply(joints, camera_t, betas, camera_t_est, camera_center, joints_2d, joints_conf, focal, sigma,
+                                  depth_weight, shape_weight)
+
+
 def _graph_task_id() -> int:
     """id of the running autograd backward pass (-1 outside one, or where this torch build has no such query)"""
     f = getattr(torch._C, '_current_graph_task_id', None)

@@ -18,6 +18,8 @@ from ..utils.geometry import perspective_projection
 # one autograd node for everything behind the body model (ops._Stage2Tail) instead of separate nodes; read from the
 # environment once, at import (TUCH_FUSED_TAIL=0: A/B measurements; the tests flip the attribute)
 FUSED_TAIL = os.environ.get('TUCH_FUSED_TAIL', '1') != '0'
+# camera_fitting_loss (the stage-1 objective) as one launch on HIP devices (ops._Stage1Objective); 0: the torch-op form
+STAGE1_FUSED = os.environ.get('TUCH_STAGE1_FUSED', '1') != '0'
 
 _MODEL_CACHE: Dict[tuple, tuple] = {}
 _ANGLE_SIGNS: Dict[tuple, tuple] = {}
@@ -145,7 +147,14 @@ def stage2_objective(model, valid, select, body_pose, betas, model_joints, euclt
 
 def camera_fitting_loss(smpl_output, camera_t, camera_t_est, camera_center, joints_2d, joints_conf,
                         focal_length=5000, depth_loss_weight=100, sigma=100, shape_prior_weight=0.0):
-    """Stage-1 objective for camera translation / betas (reference: losses.py:125-152)."""
+    """Stage-1 objective for camera translation / betas (reference: losses.py:125-152).  On a HIP device the whole
+    objective and its gradients are one kernel launch (ops.smplify_stage1_objective); the torch-op form below is the
+    same arithmetic for other devices / dtypes."""
+    joints = smpl_output.joints
+    if joints.is_cuda and joints.dtype == torch.float32 and STAGE1_FUSED:
+        return ops.smplify_stage1_objective(joints, camera_t, smpl_output.betas if shape_prior_weight != 0 else None,
+                                            camera_t_est, camera_center, joints_2d, joints_conf, focal_length, sigma,
+                                            depth_loss_weight, shape_prior_weight)
     reprojection_loss = _reprojection(smpl_output.joints, camera_t, camera_center, joints_2d, joints_conf,
                                       focal_length, sigma)
     depth_loss = (depth_loss_weight ** 2) * (camera_t[:, 2] - camera_t_est[:, 2]) ** 2

@@ -174,6 +174,15 @@ class SMPLifyDC():
                 for v in state.values():
                     if torch.is_tensor(v):
                         v.zero_()
+            if torch.cuda.is_current_stream_capturing():
+                # an ENCLOSING capture is recording (TUCH.forward_train_step --run_smplify captured as one hipGraph: BASELINE
+                # config 5): a child graph cannot be replayed into it -- the iterations are unrolled into the enclosing graph
+                for _ in range(num_iters):
+                    self._one()
+                    if collect is not None:
+                        collect.append(self.verts.detach().clone())
+                self.owner.graph_replayed[self.name] = 0
+                return
             done = 0
             if self.graph is None:
                 side = torch.cuda.Stream()

@@ -107,7 +107,7 @@ class FitsDict():
             winner.scatter_reduce_(0, rows, torch.where(update[pos], local, torch.full_like(local, -1)), 'amax')
             w = winner[rows]
             table[rows] = torch.where((w >= 0)[:, None], params[pos][w.clamp(min=0)], table[rows])
-            winner[rows] = -1
+            winner.index_fill_(0, rows, -1)          # (not `winner[rows] = -1`: that uploads a host scalar -- no hipGraph capture)
 
     def flip_pose(self, pose, is_flipped):
         """Flip SMPL pose parameters: swap left / right joints, negate the 2nd and 3rd axis-angle entries (:87-95)."""
