@@ -99,7 +99,7 @@ def profile_constants():
         if not all(os.path.exists(f) for f in files.values()):
             continue
         rows = {k: _pmc_rows(f) for k, f in files.items()}
-        for key, names in (('search', ('v2v_scan_shared_kernel', 'v2v_scan_kernel', 'v2v_mfma_kernel', 'v2v_leaves_kernel', 'v2v_tree_kernel')), ('ray_leaf_kernel', ('ray_leaf_kernel',))):
+        for key, names in (('search', ('v2v_scan_shared_kernel', 'v2v_scan_kernel', 'v2v_tree_kernel')), ('ray_leaf_kernel', ('ray_leaf_kernel',))):
             pick = lambda table: next(((k, c) for n in names for k, c in table.items() if n in k), (None, None))
             (kname, fe), (_, wr), (_, sq) = pick(rows['fetch']), pick(rows['write']), pick(rows['sq'])
             if fe and wr and sq and sq.get('GRBM_GUI_ACTIVE'):

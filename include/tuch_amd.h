@@ -423,6 +423,11 @@ int tuch_rotmat_to_angle_axis(const float* rotmat, int N, int row_stride, float*
 typedef struct tuch_hd_model tuch_hd_model;
 int tuch_hd_model_create(tuch_hd_model** out, const tuch_contact_model* contact_model, int N, const int32_t* hd_idx,
                          const float* hd_w, const int32_t* hd_face);
+/* The same for a regressor with up to K (1..8) non-zeros per row: hd_idx / hd_w [N,K], rows with fewer non-zeros padded
+ * with weight 0 (any valid vertex id).  The reference multiplies the DENSE matrix (loss.py:285): a regressor file that is
+ * not a plain barycentric sampling (<= 3 non-zeros) still loads. */
+int tuch_hd_model_create_k(tuch_hd_model** out, const tuch_contact_model* contact_model, int N, int K,
+                           const int32_t* hd_idx, const float* hd_w, const int32_t* hd_face);
 void tuch_hd_model_destroy(tuch_hd_model* model);
 int tuch_hd_model_info(const tuch_hd_model* model, int* N, int32_t* order_host);
 /* One call = loss.py:274-315 for the whole batch: exterior [B,V] u8, min_d2 [B,V], partner [B,V] int32 are the

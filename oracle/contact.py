@@ -256,7 +256,7 @@ def train_contact_body(verts, faces, geomask, euclthres, segments, use_hd,
                        hd_idx=None, hd_w=None, hd_face=None, hd_arg_given=None, hd_ext_given=None):
     """One iteration of the per-body loop of RegressorLoss.contact_loss, loss.py:247-315.
 
-    hd_idx/hd_w [N_hd,3]: the three non-zeros of each Vert_Regressor row; hd_face [N_hd]:
+    hd_idx/hd_w [N_hd,K]: the non-zeros of each Vert_Regressor row (K = 3 for barycentric samples); hd_face [N_hd]:
     faces_vert_is_sampled_from.  Returns dict(loss, grad[V,3], ...).
     hd_arg_given / hd_ext_given (tests): evaluate the terms with these partners / flags of the selected HD points
     (in the order of np.where(hd_sel)) instead of the ones found here -- to separate "a different pick between
@@ -300,7 +300,7 @@ def train_contact_body(verts, faces, geomask, euclthres, segments, use_hd,
     push, dd_push = _tanh2_terms(d, ~use_ext, 1.0, 0.04)
     g_hd = _scatter_pair_grad(diff, d, dd_pull + dd_push, use_arg, hd.shape[0])
     grad = np.zeros((num_verts, 3), np.float64)
-    for k in range(3):
+    for k in range(idx.shape[1]):                                         # the row's non-zeros (3 for barycentric samples)
         np.add.at(grad, idx[:, k], g_hd * wgt[:, k:k + 1].astype(np.float64))
     out.update(loss=pull + push, pull=pull, push=push, grad=grad, d=d, hd_exterior=hd_ext,
                hd_argmin=hd_arg, hd_points=hd, hd_offset_points=offs, hd_mask=hd_mask)

@@ -4,6 +4,8 @@ import pickle
 import struct
 
 import numpy as np
+import pytest
+import torch
 
 from tuch_amd import assets
 from tuch_amd.synthetic import dense_hd_regressor, make_body
@@ -57,3 +59,77 @@ def test_geodesics_regions_and_hd_regressor(tmp_path):
     dense = np.zeros((len(idx), body.num_verts), np.float32)
     np.add.at(dense, (np.repeat(np.arange(len(idx)), 3), idx.ravel()), w.ravel())
     assert np.allclose(dense, dense_hd_regressor(body), atol=1e-7)
+
+
+def test_hd_regressor_with_more_than_three_non_zeros_per_row(tmp_path):
+    """The reference multiplies the DENSE regressor (loss.py:285): a file whose rows are not plain barycentric samples
+    (here 1 ... 5 non-zeros per row) loads as [N,K] tables with K = the largest row, padded with weight 0; more than 8
+    non-zeros in a row are refused."""
+    body = make_body(10, 12)
+    rng = np.random.default_rng(5)
+    n, v = 300, body.num_verts
+    dense = np.zeros((n, v), np.float32)
+    for r in range(n):
+        k = 1 + r % 5
+        cols = rng.choice(v, k, replace=False)
+        dense[r, cols] = rng.dirichlet(np.ones(k)).astype(np.float32)
+    idx, w = assets.sparse_rows(dense)
+    assert idx.shape == w.shape == (n, 5)
+    back = np.zeros_like(dense)
+    np.add.at(back, (np.repeat(np.arange(n), 5), idx.ravel()), w.ravel())
+    assert np.array_equal(back, dense)
+    assert ((w != 0).sum(1) == 1 + np.arange(n) % 5).all() and (idx >= 0).all() and (idx < v).all()
+    dense[0, rng.choice(v, 9, replace=False)] = 0.1
+    with pytest.raises(ValueError):
+        assets.sparse_rows(dense)
+
+
+def test_smpl_pickle_with_chumpy_typed_arrays_and_sparse_joint_regressor(tmp_path):
+    """The official SMPL_*.pkl carries its arrays as ``chumpy.ch.Ch`` objects (state dict with the data under 'x') and
+    J_regressor as a scipy.sparse matrix, written by Python 2 (latin1).  Read here without chumpy installed: a stand-in
+    module named chumpy exists only while the file is WRITTEN; the loader (models/smpl.py: _read_pickle) must return the
+    same arrays as from a plain-numpy pickle, and a body model built from the file the same constants."""
+    import sys
+    import types
+    import scipy.sparse as sp
+    from tuch_amd.models import smpl as smpl_mod
+    assert 'chumpy' not in sys.modules
+    body = make_body(10, 12)
+    v = body.num_verts
+    ch = types.ModuleType('chumpy.ch')
+
+    class Ch(object):
+        def __init__(self, x):
+            self.x = np.asarray(x)
+            self._dirty_vars = set()           # what real chumpy objects drag along
+            self._itr = None
+
+        def __getstate__(self):
+            return dict(self.__dict__)
+    Ch.__module__ = 'chumpy.ch'
+    Ch.__qualname__ = 'Ch'
+    ch.Ch = Ch
+    pkg = types.ModuleType('chumpy')
+    pkg.ch = ch
+    kintree = np.stack([np.where(body.parents < 0, 2 ** 32 - 1, body.parents), np.arange(24)]).astype(np.int64)
+    model = {'v_template': Ch(body.v_template.astype(np.float64)), 'shapedirs': Ch(body.shapedirs.astype(np.float64)),
+             'posedirs': Ch(body.posedirs.reshape(207, v, 3).transpose(1, 2, 0).astype(np.float64)),
+             'J_regressor': sp.csc_matrix(body.J_regressor.astype(np.float64)), 'weights': Ch(body.lbs_weights.astype(np.float64)),
+             'kintree_table': kintree, 'f': body.faces.astype(np.uint32), 'extra_vertex_ids': body.extra_vertex_ids}
+    sys.modules['chumpy'], sys.modules['chumpy.ch'] = pkg, ch
+    try:
+        with open(os.path.join(tmp_path, 'SMPL_NEUTRAL.pkl'), 'wb') as f:
+            pickle.dump(model, f, protocol=2)
+    finally:
+        del sys.modules['chumpy'], sys.modules['chumpy.ch']
+    with pytest.raises(ModuleNotFoundError):
+        with open(os.path.join(tmp_path, 'SMPL_NEUTRAL.pkl'), 'rb') as f:
+            pickle.load(f, encoding='latin1')                      # plain pickle cannot read it here
+    d = smpl_mod._load_model_dir(str(tmp_path))
+    assert np.allclose(d['v_template'], body.v_template) and d['posedirs'].shape == (207, 3 * v)
+    assert np.allclose(d['posedirs'], body.posedirs.reshape(207, 3 * v), atol=1e-7)
+    assert np.allclose(d['J_regressor'], body.J_regressor, atol=1e-7) and np.allclose(d['lbs_weights'], body.lbs_weights)
+    assert np.array_equal(d['parents'][1:], body.parents[1:]) and d['parents'][0] == -1
+    m = smpl_mod.SMPL(str(tmp_path), batch_size=2, create_transl=False, J_regressor_extra=body.J_regressor_extra,
+                      joint_map=body.joint_map)
+    assert m.v_template.dtype == torch.float32 and tuple(m.shapedirs.shape) == (v, 3, 10) and m.get_num_verts() == v

@@ -82,6 +82,7 @@ _SIGNATURES = {
     'tuch_rotmat_to_angle_axis': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'tuch_winding_tree_work': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     'tuch_hd_model_create': (c_int, [POINTER(c_void_p), c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    'tuch_hd_model_create_k': (c_int, [POINTER(c_void_p), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'tuch_hd_model_destroy': (None, [c_void_p]),
     'tuch_hd_model_info': (c_int, [c_void_p, POINTER(c_int), c_void_p]),
     'tuch_hd_contact_saved_bytes': (c_size_t, [c_void_p, c_int]),

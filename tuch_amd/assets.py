@@ -68,21 +68,31 @@ def load_contact_regions(dsc_root: str = None) -> Dict[str, object]:
     return {'classes': classes, 'csig': csig}
 
 
+def sparse_rows(dense: np.ndarray, max_nnz: int = 8) -> Tuple[np.ndarray, np.ndarray]:
+    """Dense regressor [N,V] -> (ids [N,K], weights [N,K]) with K = the largest number of non-zeros in a row (at least 3:
+    barycentric samples; rows with fewer are padded with weight 0).  The reference multiplies the dense matrix
+    (loss.py:285); the device tables hold its non-zeros -- a row with more than ``max_nnz`` of them is refused."""
+    nnz = int((dense != 0).sum(1).max())
+    if nnz > max_nnz:
+        raise ValueError('HD regressor rows have up to %d non-zeros (at most %d are supported)' % (nnz, max_nnz))
+    k = max(nnz, 3)
+    idx = np.argsort(-np.abs(dense), axis=1, kind='stable')[:, :k]
+    wgt = np.take_along_axis(dense, idx, 1).astype(np.float32)
+    idx = np.where(wgt != 0, idx, idx[:, :1])               # padding: weight 0, a valid id
+    return idx.astype(np.int64), wgt
+
+
 def load_hd_regressor(hd_model_dir: str = None) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
-    """smpl_neutral_hd_vert_regressor.npy (dense [N,V], barycentric: <= 3 non-zeros per row) and
-    smpl_neutral_hd_sample_from_mesh_out.pkl -> (corner ids [N,3], weights [N,3], face ids [N])
-    (loss.py:81-88)."""
+    """smpl_neutral_hd_vert_regressor.npy (dense [N,V]; barycentric samples: <= 3 non-zeros per row, a general sparse
+    regressor with up to 8 also loads) and smpl_neutral_hd_sample_from_mesh_out.pkl -> (vertex ids [N,K], weights [N,K],
+    face ids [N]) (loss.py:81-88)."""
     if hd_model_dir is None:
         hd_model_dir = config_path('HD_MODEL_DIR')
     dense = np.load(os.path.join(hd_model_dir, 'smpl_neutral_hd_vert_regressor.npy'))
-    idx = np.argsort(-np.abs(dense), axis=1)[:, :3]
-    wgt = np.take_along_axis(dense, idx, 1).astype(np.float32)
-    rest = np.abs(dense).sum(1) - np.abs(wgt).sum(1)
-    if rest.max() > 1e-6:
-        raise ValueError('HD regressor rows have more than three non-zeros (max residual %g)' % rest.max())
+    idx, wgt = sparse_rows(dense)
     with open(os.path.join(hd_model_dir, 'smpl_neutral_hd_sample_from_mesh_out.pkl'), 'rb') as f:
         faces = np.asarray(pickle.load(f)['faces_vert_is_sampled_from'])
-    return idx.astype(np.int64), wgt, faces.astype(np.int64)
+    return idx, wgt, faces.astype(np.int64)
 
 
 _PLY_TYPES = {'char': 'b', 'int8': 'b', 'uchar': 'B', 'uint8': 'B', 'short': 'h', 'int16': 'h',

@@ -30,14 +30,15 @@
 struct tuch_hd_model {
     const tuch_contact_model* cm;
     int N, V, F;
-    int32_t* idx;        // [N,3] supporting vertices (sorted order)
-    float* w;            // [N,3] barycentric weights
+    int K;               // non-zeros per regressor row (3: barycentric samples; up to 8 for a general sparse regressor)
+    int32_t* idx;        // [N,K] supporting vertices (sorted order; rows with fewer non-zeros padded with weight 0)
+    float* w;            // [N,K] weights
     int32_t* face;       // [N] face the point was sampled from (loss.py:87 faces_vert_is_sampled_from)
     int32_t* tv;         // [N] template vertex = first vertex of that face (loss.py:88 geovec_verts)
     int32_t* mask_id;    // [N] row / column of the geodesic mask the point inherits: tv, or its position in tree order
     int32_t* orig;       // [N] index of the point in the caller's order
     int32_t* by_orig;    // [N] inverse: where the caller's point r sits in the sorted order
-    int32_t* v_off;      // [V+1] CSR: vertex -> entries (point * 4 + corner)
+    int32_t* v_off;      // [V+1] CSR: vertex -> entries (point * 8 + corner), non-zero weights only
     int32_t* v_ent;
     int32_t* offsets;    // [kMaxBatch+1] = b * N (device): where body b's slots start
     int tree_order;      // mask ids are tree positions (the model's mask in tree order is used)
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(kSel) void hd_scatter_kernel(
 // ---- positions (loss.py:285, :295-296) ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void hd_points_kernel(
     const float* __restrict__ verts, const int32_t* __restrict__ sel, const int32_t* __restrict__ counts,
-    const int32_t* __restrict__ idx, const float* __restrict__ w, const int32_t* __restrict__ hd_face,
+    const int32_t* __restrict__ idx, const float* __restrict__ w, int K, const int32_t* __restrict__ hd_face,
     const int32_t* __restrict__ faces, const int32_t* __restrict__ mask_id, int V, int N,
     const int32_t* __restrict__ chunk_first, const int32_t* __restrict__ by_orig, const int32_t* __restrict__ slot, int chunks,
     int32_t* __restrict__ first_slot, float* __restrict__ pts, float* __restrict__ offs, int32_t* __restrict__ vid,
@@ -180,10 +181,21 @@ __global__ __launch_bounds__(256) void hd_points_kernel(
     const int n = sel[o];
     const float* vb = verts + (size_t)b * V * 3;
     float x = 0.f, y = 0.f, z = 0.f;
+    // the K non-zeros of the regressor row (loss.py:285 multiplies the dense matrix; K = 3 for barycentric samples), all
+    // requested before the first is used
+    float wk[8];
+    int sk[8];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float wc = w[3 * (size_t)n + c];
-        const int sv = idx[3 * (size_t)n + c];
+    for (int c = 0; c < 8; ++c) {
+        const int cc = c < K ? c : K - 1;
+        wk[c] = c < K ? w[(size_t)K * n + cc] : 0.0f;
+        sk[c] = idx[(size_t)K * n + cc];
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        if (c >= K) break;
+        const float wc = wk[c];
+        const int sv = sk[c];
         vert_flag[(size_t)b * V + sv] = 1;
         const float* p = vb + 3 * (size_t)sv;
         x = __builtin_fmaf(wc, p[0], x); y = __builtin_fmaf(wc, p[1], y); z = __builtin_fmaf(wc, p[2], z);
@@ -317,7 +329,7 @@ __global__ __launch_bounds__(kGradBlock) void hd_grad_points_kernel(
 // adjoint of the regressor rows: a gather per vertex over the points it supports
 __global__ __launch_bounds__(256) void hd_grad_verts_kernel(
     const float* __restrict__ G, const int32_t* __restrict__ slot,
-    const int32_t* __restrict__ v_off, const int32_t* __restrict__ v_ent, const float* __restrict__ w, int V, int N,
+    const int32_t* __restrict__ v_off, const int32_t* __restrict__ v_ent, const float* __restrict__ w, int K, int V, int N,
     const uint8_t* __restrict__ vert_flag, float* __restrict__ grad_verts)
 {
     const int b = blockIdx.y;
@@ -328,9 +340,9 @@ __global__ __launch_bounds__(256) void hd_grad_verts_kernel(
     const int32_t* sb = slot + (size_t)b * N;
     const float* gb = G + 3 * (size_t)b * N;
     float x = 0.f, y = 0.f, z = 0.f;
-    auto add = [&](int ent, int s) {                 // entry = point * 4 + corner; s = the point's slot in this body
+    auto add = [&](int ent, int s) {                 // entry = point * 8 + corner; s = the point's slot in this body
         if (s < 0) return;
-        const float wc = w[3 * (size_t)(ent >> 2) + (ent & 3)];
+        const float wc = w[(size_t)K * (ent >> 3) + (ent & 7)];
         const float* g = gb + 3 * (size_t)s;
         x = __builtin_fmaf(wc, g[0], x); y = __builtin_fmaf(wc, g[1], y); z = __builtin_fmaf(wc, g[2], z);
     };
@@ -342,7 +354,7 @@ __global__ __launch_bounds__(256) void hd_grad_verts_kernel(
 #pragma unroll
             for (int u = 0; u < 4; ++u) ent[u] = v_ent[min(e + u, e1 - 1)];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) s[u] = e + u < e1 ? sb[ent[u] >> 2] : -1;
+            for (int u = 0; u < 4; ++u) s[u] = e + u < e1 ? sb[ent[u] >> 3] : -1;
 #pragma unroll
             for (int u = 0; u < 4; ++u) add(ent[u], s[u]);
         }
@@ -358,9 +370,9 @@ __global__ __launch_bounds__(256) void hd_grad_verts_kernel(
         const int le0 = __builtin_amdgcn_readlane(e0, src), le1 = __builtin_amdgcn_readlane(e1, src);
         float px = 0.f, py = 0.f, pz = 0.f;
         for (int e = le0 + lane; e < le1; e += 64) {
-            const int ent = v_ent[e], s = sb[ent >> 2];
+            const int ent = v_ent[e], s = sb[ent >> 3];
             if (s < 0) continue;
-            const float wc = w[3 * (size_t)(ent >> 2) + (ent & 3)];
+            const float wc = w[(size_t)K * (ent >> 3) + (ent & 7)];
             const float* g = gb + 3 * (size_t)s;
             px = __builtin_fmaf(wc, g[0], px); py = __builtin_fmaf(wc, g[1], py); pz = __builtin_fmaf(wc, g[2], pz);
         }
@@ -438,10 +450,20 @@ extern "C" void tuch_hd_model_destroy(tuch_hd_model* hm)
 
 // hd_idx / hd_w [N,3]: the three non-zeros of every row of the HD vertex regressor; hd_face [N]: the face each point
 // was sampled from.  The contact model must outlive the HD model.
+extern "C" int tuch_hd_model_create_k(tuch_hd_model** out, const tuch_contact_model* cm, int N, int K, const int32_t* hd_idx,
+                                      const float* hd_w, const int32_t* hd_face);
 extern "C" int tuch_hd_model_create(tuch_hd_model** out, const tuch_contact_model* cm, int N, const int32_t* hd_idx,
                                     const float* hd_w, const int32_t* hd_face)
 {
+    return tuch_hd_model_create_k(out, cm, N, 3, hd_idx, hd_w, hd_face);
+}
+
+// The same for a regressor with up to K <= 8 non-zeros per row (hd_idx / hd_w [N,K]; rows with fewer: weight 0, any valid id).
+extern "C" int tuch_hd_model_create_k(tuch_hd_model** out, const tuch_contact_model* cm, int N, int K, const int32_t* hd_idx,
+                                      const float* hd_w, const int32_t* hd_face)
+{
     TUCH_REQUIRE(out && cm && hd_idx && hd_w && hd_face && N > 0, "tuch_hd_model_create: bad arguments");
+    TUCH_REQUIRE(K >= 1 && K <= 8, "tuch_hd_model_create: %d non-zeros per row (1..8)", K);
     TUCH_REQUIRE(cm->mask_bits, "tuch_hd_model_create: the contact model has no geodesic mask");
     const int V = cm->V, F = cm->F;
     std::vector<int32_t> faces((size_t)F * 3);
@@ -451,8 +473,8 @@ extern "C" int tuch_hd_model_create(tuch_hd_model** out, const tuch_contact_mode
     }
     for (int n = 0; n < N; ++n) {
         TUCH_REQUIRE(hd_face[n] >= 0 && hd_face[n] < F, "tuch_hd_model_create: face id %d out of range", hd_face[n]);
-        for (int c = 0; c < 3; ++c)
-            TUCH_REQUIRE(hd_idx[3 * n + c] >= 0 && hd_idx[3 * n + c] < V, "tuch_hd_model_create: vertex id out of range");
+        for (int c = 0; c < K; ++c)
+            TUCH_REQUIRE(hd_idx[(size_t)K * n + c] >= 0 && hd_idx[(size_t)K * n + c] < V, "tuch_hd_model_create: vertex id out of range");
     }
     // The HD points are a set (the loss sums over them): keep them sorted by the surface patch of their face, so that
     // consecutive selected points are neighbours in space (coherent query blocks for the inside test, tight row boxes
@@ -475,11 +497,11 @@ extern "C" int tuch_hd_model_create(tuch_hd_model** out, const tuch_contact_mode
     const bool tree_mask = tree && cm->tree_mask_bits && cm->tree_qperm_host;
     if (tree_mask)
         for (int i = 0; i < V; ++i) pos[cm->tree_qperm_host[i]] = i;
-    std::vector<int32_t> idx((size_t)N * 3), face(N), tv(N), mask_id(N);
-    std::vector<float> w((size_t)N * 3);
+    std::vector<int32_t> idx((size_t)N * K), face(N), tv(N), mask_id(N);
+    std::vector<float> w((size_t)N * K);
     for (int k = 0; k < N; ++k) {
         const int n = order[k];
-        for (int c = 0; c < 3; ++c) { idx[3 * k + c] = hd_idx[3 * n + c]; w[3 * k + c] = hd_w[3 * n + c]; }
+        for (int c = 0; c < K; ++c) { idx[(size_t)K * k + c] = hd_idx[(size_t)K * n + c]; w[(size_t)K * k + c] = hd_w[(size_t)K * n + c]; }
         face[k] = hd_face[n];
         tv[k] = faces[3 * (size_t)hd_face[n]];                       // loss.py:88: first vertex of the face
         mask_id[k] = tree_mask ? pos[tv[k]] : tv[k];
@@ -487,17 +509,20 @@ extern "C" int tuch_hd_model_create(tuch_hd_model** out, const tuch_contact_mode
     // CSR tables
     std::vector<int32_t> v_off(V + 1, 0);
     for (int k = 0; k < N; ++k) {
-        for (int c = 0; c < 3; ++c) ++v_off[idx[3 * k + c] + 1];
+        for (int c = 0; c < K; ++c)
+            if (w[(size_t)K * k + c] != 0.0f) ++v_off[idx[(size_t)K * k + c] + 1];
     }
     for (int v = 0; v < V; ++v) v_off[v + 1] += v_off[v];
-    std::vector<int32_t> v_ent((size_t)N * 3), vf(v_off.begin(), v_off.end() - 1);
+    TUCH_REQUIRE((long)N * 8 < 0x7fffffffL, "tuch_hd_model_create: too many HD points");
+    std::vector<int32_t> v_ent((size_t)v_off[V] + 1), vf(v_off.begin(), v_off.end() - 1);
     for (int k = 0; k < N; ++k) {
-        for (int c = 0; c < 3; ++c) v_ent[vf[idx[3 * k + c]]++] = k * 4 + c;
+        for (int c = 0; c < K; ++c)
+            if (w[(size_t)K * k + c] != 0.0f) v_ent[vf[idx[(size_t)K * k + c]]++] = k * 8 + c;
     }
     std::vector<int32_t> offsets(kMaxBatch + 1);
     for (int b = 0; b <= kMaxBatch; ++b) offsets[b] = (int32_t)((long)b * N < 0x7fffffffL ? (long)b * N : 0x7fffffffL);
     tuch_hd_model* hm = (tuch_hd_model*)calloc(1, sizeof(tuch_hd_model));
-    hm->cm = cm; hm->N = N; hm->V = V; hm->F = F; hm->tree_order = tree_mask ? 1 : 0;
+    hm->cm = cm; hm->N = N; hm->V = V; hm->F = F; hm->K = K; hm->tree_order = tree_mask ? 1 : 0;
     hm->order_host = new std::vector<int32_t>(order);
     hm->enqueue = new std::mutex();
     if (!tuch_host_tables() &&
@@ -602,7 +627,7 @@ extern "C" int tuch_hd_contact_fwd(const tuch_hd_model* hm, const float* verts, 
                        (const int32_t*)chunk_cnt, hm->F, N, chunks, sel, slot, counts);
     const dim3 pgrid(ceil_div(N, 256), B);
     hipLaunchKernelGGL(hd_points_kernel, pgrid, dim3(256), 0, s, verts, (const int32_t*)sel, (const int32_t*)counts,
-                       (const int32_t*)hm->idx, (const float*)hm->w, (const int32_t*)hm->face,
+                       (const int32_t*)hm->idx, (const float*)hm->w, hm->K, (const int32_t*)hm->face,
                        (const int32_t*)hm->cm->faces, (const int32_t*)hm->mask_id, V, N, (const int32_t*)chunk_first,
                        (const int32_t*)hm->by_orig, (const int32_t*)slot, chunks, first, pts, offs, vid, (uint8_t*)(sv + sl.vert_flag));
     // (seeding the search from the vertex-level partners was tried: the seeds are excellent where they exist -- median
@@ -670,7 +695,7 @@ extern "C" int tuch_hd_contact_bwd(const tuch_hd_model* hm, const void* saved, c
                            (const int32_t*)(sv + sl.counts), grad_terms, N, G);
     hipLaunchKernelGGL(hd_grad_verts_kernel, dim3(ceil_div(V, 256), B), dim3(256), 0, s, (const float*)G,
                        (const int32_t*)(sv + sl.slot), (const int32_t*)hm->v_off, (const int32_t*)hm->v_ent,
-                       (const float*)hm->w, V, N, (const uint8_t*)(sv + sl.vert_flag), grad_verts);
+                       (const float*)hm->w, hm->K, V, N, (const uint8_t*)(sv + sl.vert_flag), grad_verts);
     return tuch_check_launch("tuch_hd_contact_bwd");
 }
 

@@ -42,7 +42,7 @@ struct tuch_options {
     int ray_waves = 32768;      // wavefronts of the crossing kernel
     int v2v_tree = 1;           // 0: flat nearest-vertex search
     int v2v_waves = 0;          // frontier choice of the search (wavefronts aimed at; 0: the form's own default)
-    int v2v_flat = 2;           // search: 3 aligned row tiles on the matrix cores, 2 lanes over a subtree's leaves first, 1 leaf boxes four at a time, 0 the stackless walk
+    int v2v_flat = 2;           // search: 2 lanes over a subtree's leaves first (v2v_scan_kernel), 0 the stackless walk (v2v_tree_kernel)
     int v2v_lds = -1;           // search beside the inside test: -1 capped at 6 wavefronts per SIMD by register count, > 0 by an LDS allocation of that many bytes per workgroup (6400: round 2), 0 uncapped
     int seg_splits = 16;        // face splits of the solid-angle segment kernel
     int seg_assist = 1;         // 0: the segment pass counts its body-face crossings itself (read at create only)
@@ -126,7 +126,7 @@ struct tuch_contact_model {
     // (0: the mask rules the whole node out for the wavefront that owns these columns)
     uint64_t* tree_mask_bits;
     uint64_t* tree_masked;
-    // the same for the flat form of the search (v2v.hip: v2v_leaves_kernel): per frontier subtree its leaves as a range of
+    // the same for the leaf scan of the search (v2v.hip: v2v_scan_kernel): per frontier subtree its leaves as a range of
     // the preorder leaf sequence, and the lane table of tree_masked by leaf index instead of node
     int32_t* tree_sub_leaf;      // [frontier_total][2] = (first leaf index, number of leaves)
     uint64_t* tree_masked_leaf;  // [2 * tree_qblocks][tree_leaves]
@@ -135,12 +135,6 @@ struct tuch_contact_model {
     // 0 for a padding row)
     int32_t* tree_leaf_group;
     uint64_t* tree_mask_bits_g;
-    // matrix-core form (v2v.hip: v2v_mfma_kernel): the rows in tree order in aligned tiles of 16; per (column block, tile) 16
-    // lane masks = [group of 16 columns][accumulator register r] -> row r + 4 q of the tile for the lanes of quarter q, and
-    // the columns with any admissible row in the tile
-    uint64_t* tree_mask_tiles;   // [2 * tree_qblocks][tree_tiles][16]
-    uint64_t* tree_tile_lanes;   // [2 * tree_qblocks][tree_tiles]
-    int tree_tiles;              // 8 * tree_qblocks
     int tree_groups;
     int tree_num_frontiers;
     int tree_leaf_runs_tile;       // 1: the leaves' strip runs [ex_off, ex_off + ex_len) tile [0, tree_exact_len) without gaps

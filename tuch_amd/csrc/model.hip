@@ -32,7 +32,7 @@ extern "C" void tuch_contact_model_destroy(tuch_contact_model* m)
 {
     if (!m) return;
     void* dev[] = {m->ring_off, m->ring_vidx, m->faces, m->mask_bits, m->strip_vidx, m->strip_sign, m->tree_node, m->tree_vidx, m->tree_sign, m->tree_qperm,
-                   m->tree_height_off, m->tree_height_nodes, m->tree_frontier_nodes, m->tree_launch_order, m->tree_ancestors, m->tree_rows, m->tree_v2v_info, m->tree_mask_bits, m->tree_masked, m->tree_sub_leaf, m->tree_masked_leaf, m->tree_leaf_group, m->tree_mask_bits_g, m->tree_mask_tiles, m->tree_tile_lanes, m->seg_blocks, m->seg_of_q, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces, m->seg_link_off, m->seg_link, m->seg_ray_off, m->seg_ray_ent, m->seg_elem_mask, m->seg_vmask, m->seg_vpos, m->seg_cap_off, m->seg_cap_ent, m->seg_cap_range,
+                   m->tree_height_off, m->tree_height_nodes, m->tree_frontier_nodes, m->tree_launch_order, m->tree_ancestors, m->tree_rows, m->tree_v2v_info, m->tree_mask_bits, m->tree_masked, m->tree_sub_leaf, m->tree_masked_leaf, m->tree_leaf_group, m->tree_mask_bits_g, m->seg_blocks, m->seg_of_q, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces, m->seg_link_off, m->seg_link, m->seg_ray_off, m->seg_ray_ent, m->seg_elem_mask, m->seg_vmask, m->seg_vpos, m->seg_cap_off, m->seg_cap_ent, m->seg_cap_range,
                    m->cap_off, m->cap_vidx, m->region_off, m->region_vidx, m->pairs, m->pair_mask, m->pair_mask_off, m->tickets, m->canary_hits};
     for (void* p : dev) tuch_table_free(p);
     free(m->tree_frontier_off_host);
@@ -191,7 +191,7 @@ extern "C" int tuch_contact_model_create(
                         sub[2 * k] = first < 0 ? 0 : first;
                         sub[2 * k + 1] = count;
                     }
-                    std::vector<uint64_t> by_leaf((size_t)Wp * L + 8, 0);        // + a batch of padding (v2v_leaves_kernel)
+                    std::vector<uint64_t> by_leaf((size_t)Wp * L + 8, 0);        // + padding
                     for (int qb = 0; qb < Wp; ++qb)
                         for (int i = 0; i < L; ++i) by_leaf[(size_t)qb * L + i] = lanes[(size_t)qb * N + t.height_nodes[i]];
                     rc = upload(&m->tree_sub_leaf, sub.data(), sub.size());
@@ -210,30 +210,6 @@ extern "C" int tuch_contact_model_create(
                     m->tree_groups = G;
                     if (rc == TUCH_OK) rc = upload(&m->tree_leaf_group, group.data(), group.size());
                     if (rc == TUCH_OK) rc = upload(&m->tree_mask_bits_g, bits_g.data(), bits_g.size());
-                    // matrix-core form: the rows in tree order in aligned tiles of 16; lane masks per (column block, tile,
-                    // column group g of 16 columns, accumulator register r): the lanes of quarter q see row r + 4 q of the
-                    // tile against columns 16 g .. 16 g + 15; and per (column block, tile) the columns with any admissible row
-                    if (rc == TUCH_OK) {
-                        const int T = 8 * t.num_qblocks;
-                        std::vector<uint64_t> tiles((size_t)Wp * T * 16, 0), any((size_t)Wp * T, 0);
-                        for (int qb = 0; qb < Wp; ++qb) {
-                            auto word = [&](int k) { return k < V ? bits[(size_t)qb * V + k] : (uint64_t)0; };
-                            for (int tt = 0; tt < T; ++tt) {
-                                uint64_t all = 0;
-                                for (int k = 0; k < 16; ++k) all |= word(16 * tt + k);
-                                any[(size_t)qb * T + tt] = all;
-                                for (int g = 0; g < 4; ++g)
-                                    for (int r = 0; r < 4; ++r) {
-                                        uint64_t w = 0;
-                                        for (int q = 0; q < 4; ++q) w |= ((word(16 * tt + r + 4 * q) >> (16 * g)) & 0xffffull) << (16 * q);
-                                        tiles[((size_t)qb * T + tt) * 16 + 4 * g + r] = w;
-                                    }
-                            }
-                        }
-                        m->tree_tiles = T;
-                        rc = upload(&m->tree_tile_lanes, any.data(), any.size());
-                        if (rc == TUCH_OK) rc = upload(&m->tree_mask_tiles, tiles.data(), tiles.size());
-                    }
                 }
             }
         }
@@ -530,10 +506,6 @@ extern "C" int tuch_contact_model_canary_hits(const tuch_contact_model* m, int* 
 extern "C" int tuch_contact_model_get_option(const tuch_contact_model* m, const char* name, int* value)
 {
     TUCH_REQUIRE(m && name && value, "tuch_contact_model_get_option: null argument");
-    if (!strcmp(name, "v2v_mfma_available")) {      // read-only: are the tables of the matrix-core search there?
-        *value = m->tree_mask_tiles ? 1 : 0;
-        return TUCH_OK;
-    }
     if (!strcmp(name, "seg_fused_active")) {        // read-only: does the segment filter run as the one fused launch?
         *value = tuch_ray_segment_fused_available(m) ? 1 : 0;
         return TUCH_OK;

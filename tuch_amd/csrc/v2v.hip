@@ -618,7 +618,6 @@ __global__ __launch_bounds__(64) void v2v_seed_kernel(
     const int32_t* __restrict__ hint,            // [B,Vp] a row per column (tree order) from an earlier call, or nullptr
     uint64_t* __restrict__ keys,                 // [B,Vp]
     float* __restrict__ colbox,                  // [B][column blocks][8] or nullptr: the box of the block's 64 columns
-    float* __restrict__ tilebox,                 // [B][2 * column blocks][8] or nullptr: the boxes of its two 32-row halves
     const float* __restrict__ leafbox,           // [B][L][8] + masked_leaf [column blocks][L]: the leaf to seed from is found
     const uint64_t* __restrict__ masked_leaf, int L)   // among the leaves themselves (no inner boxes needed), or nullptr
 {
@@ -631,40 +630,13 @@ __global__ __launch_bounds__(64) void v2v_seed_kernel(
     c.arg = 0;
     if (colbox) {
         float lo[3] = {c.px, c.py, c.pz}, hi[3] = {c.px, c.py, c.pz};
-        if (tilebox) {
-            // the matrix-core form walks the rows in aligned tiles of 16 (= a quarter of a column block): their boxes, rows
-            // behind the last vertex left out
-            const bool real = i0 < V;
-            const float inf = __builtin_inff();
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { lo[k] = real ? lo[k] : inf; hi[k] = real ? hi[k] : -inf; }
+        for (int m = 32; m >= 1; m >>= 1)
 #pragma unroll
-            for (int m = 8; m >= 1; m >>= 1)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    lo[k] = fminf(lo[k], __shfl_xor(lo[k], m));
-                    hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m));
-                }
-            if ((lane & 15) == 0) {
-                float* o = tilebox + ((size_t)b * gridDim.y * 4 + 4 * qb + (lane >> 4)) * 8;
-                o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = 0.0f; o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = 0.0f;
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = fminf(lo[k], __shfl_xor(lo[k], m));
+                hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m));
             }
-#pragma unroll
-            for (int m = 32; m >= 16; m >>= 1)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    lo[k] = fminf(lo[k], __shfl_xor(lo[k], m));
-                    hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m));
-                }
-        } else {
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    lo[k] = fminf(lo[k], __shfl_xor(lo[k], m));
-                    hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m));
-                }
-        }
         if (lane == 0) {
             float* o = colbox + ((size_t)b * gridDim.y + qb) * 8;
             o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = 0.0f; o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = 0.0f;
@@ -772,7 +744,7 @@ __global__ __launch_bounds__(kBoundsBlock) void v2v_rows_seed_kernel(
     const int32_t* __restrict__ height_off, const int32_t* __restrict__ height_nodes, int N, float* __restrict__ prow,
     float* __restrict__ bounds, float* __restrict__ leafbox, const int32_t* __restrict__ leaf_group, float* __restrict__ prow_g,
     int G, int row_blocks, const uint64_t* __restrict__ bits, const int32_t* __restrict__ hint, uint64_t* __restrict__ keys,
-    float* __restrict__ colbox, float* __restrict__ tilebox, uint4* __restrict__ zero, size_t zero_n16)
+    float* __restrict__ colbox, uint4* __restrict__ zero, size_t zero_n16)
 {
     // a buffer the CALLER wants cleared before the kernels it enqueues behind this call run (SMPLify-DC stage 2: the vertex
     // gradient the tail scatters into, its arrival counter, the region pairs' keys -- a fill launch of 5 us in front of them
@@ -816,10 +788,6 @@ __global__ __launch_bounds__(kBoundsBlock) void v2v_rows_seed_kernel(
             lo[k] = fminf(lo[k], __shfl_xor(lo[k], m));
             hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m));
         }
-    if (tilebox && (lane & 15) == 0) {
-        float* o = tilebox + ((size_t)b * blocks * 4 + 4 * qb + (lane >> 4)) * 8;
-        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = 0.0f; o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = 0.0f;
-    }
 #pragma unroll
     for (int m = 32; m >= 16; m >>= 1)
 #pragma unroll
@@ -884,74 +852,7 @@ __global__ __launch_bounds__(64) void v2v_tree_kernel(
     if (k0 < init) atomicMin((unsigned long long*)(kb + i0), (unsigned long long)k0);
 }
 
-// The same search without the descent.  A wavefront's subtree is small (a frontier of 32 subtrees: ~13 leaves, ~27
-// nodes), and the stackless walk above visits most of its nodes one DEPENDENT round of scalar loads after the other:
-// ~20 rounds of ~230 cycles per wavefront for ~360 vector instructions -- a latency chain (VALU busy 0.59 with the SIMDs
-// full of such wavefronts).  Here: the subtree's root box first (most (column block, subtree) pairs end there), then the
-// boxes of its LEAVES, four at a time from one contiguous run (v2v_rows_kernel stores them by leaf index; a subtree's
-// leaves are a range of it), each re-tested against the bounds as they stand when its turn comes: the same rows are
-// evaluated as by the walk, in the same order -> the same keys.  ~5 rounds instead of ~20.
-constexpr int kLeafBatch = 4;
-__global__ __launch_bounds__(64) void v2v_leaves_kernel(
-    const float* __restrict__ prow, int V, int Vp, const uint64_t* __restrict__ bits,
-    const float* __restrict__ bounds, const float* __restrict__ leafbox, const uint64_t* __restrict__ masked,
-    const uint64_t* __restrict__ masked_leaf, int N, int L, const int32_t* __restrict__ frontier,
-    const int32_t* __restrict__ sub_leaf, const int32_t* __restrict__ order, uint64_t* __restrict__ keys)
-{
-    const int b = blockIdx.x, lane = threadIdx.x;
-    const int pair = __builtin_amdgcn_readfirstlane(order[blockIdx.y >> 1]);      // launch order over 128-blocks
-    const int sub = pair >> 16, qb = (pair & 0xffff) * 2 + (blockIdx.y & 1);
-    const float* pb = prow + (size_t)b * Vp * 3;
-    const int i0 = qb * kTreeCols + lane;
-    uint64_t* kb = keys + (size_t)b * Vp;
-    const uint64_t init = __hip_atomic_load(kb + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    Column c;
-    c.px = pb[3 * i0]; c.py = pb[3 * i0 + 1]; c.pz = pb[3 * i0 + 2];
-    c.best = __uint_as_float((uint32_t)(init >> 32));
-    c.arg = (int)(uint32_t)init;
-    const uint64_t* m0 = bits + (size_t)qb * V;
-    auto gap = [&](const float* box) {              // squared distance to a box through its nearest point, as box_dist2()
-        const float dx = c.px - __builtin_amdgcn_fmed3f(c.px, box[0], box[4]);
-        const float dy = c.py - __builtin_amdgcn_fmed3f(c.py, box[1], box[5]);
-        const float dz = c.pz - __builtin_amdgcn_fmed3f(c.pz, box[2], box[6]);
-        return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) * kPruneSlack;
-    };
-    const int root = __builtin_amdgcn_readfirstlane(frontier[sub]);
-    const int first = __builtin_amdgcn_readfirstlane(sub_leaf[2 * sub]), count = __builtin_amdgcn_readfirstlane(sub_leaf[2 * sub + 1]);
-    {
-        const float* box = bounds + ((size_t)b * N + root) * 8;
-        const float rb[8] = {box[0], box[1], box[2], 0.0f, box[4], box[5], box[6], 0.0f};
-        if ((__builtin_amdgcn_ballot_w64(gap(rb) <= c.best) & masked[(size_t)qb * N + root]) == 0) return;
-    }
-    const float* lb = leafbox + ((size_t)b * L + first) * 8;
-    const uint64_t* ml = masked_leaf + (size_t)qb * L + first;
-    for (int base = 0; base < count; base += kLeafBatch) {
-        float bx[kLeafBatch][8];
-        uint64_t lanes[kLeafBatch];
-#pragma unroll
-        for (int u = 0; u < kLeafBatch; ++u) {      // (reads past a subtree's last leaf stay inside the arrays' padding)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) bx[u][k] = lb[(size_t)(base + u) * 8 + k];
-            lanes[u] = ml[base + u];
-        }
-        float g[kLeafBatch];
-#pragma unroll
-        for (int u = 0; u < kLeafBatch; ++u) g[u] = gap(bx[u]);
-#pragma unroll
-        for (int u = 0; u < kLeafBatch; ++u) {
-            if (base + u >= count) break;
-            const uint64_t reach = __builtin_amdgcn_ballot_w64(g[u] <= c.best) & lanes[u];
-            if (reach) {
-                const int leaf = __float_as_int(bx[u][7]);
-                v2v_rows(c, pb, m0, leaf & 0xfffff, leaf >> 20, reach);
-            }
-        }
-    }
-    const uint64_t k0 = v2v_key(c.best, c.arg);
-    if (k0 < init) atomicMin((unsigned long long*)(kb + i0), (unsigned long long)k0);
-}
-
-// Third form: lanes over LEAVES first.  The walks above spend most of their vector instructions on box tests that fail
+// Second form (the default): lanes over LEAVES first.  The walk above spends most of their vector instructions on box tests that fail
 // (~20 node tests of ~12 instructions per wavefront against ~80 instructions of row arithmetic; the kernel is ~70 % VALU
 // issue).  Here a wavefront tests all leaves of its subtree AT ONCE, one leaf per lane, against the box of its 64 columns
 // and the largest bound among them (conservative: box-to-box distance), and only the survivors get the per-column test
@@ -1033,161 +934,6 @@ __device__ __forceinline__ void v2v_scan_body(
     if (k0 < init) atomicMin((unsigned long long*)(kb + i0), (unsigned long long)k0);
 }
 
-// Fourth form: the rows on the MATRIX CORES (the idea of hd_search.hip), no tree.  The rows in tree order are cut into
-// aligned tiles of 16 (compact patches: a quarter of a column block each; boxes left by v2v_seed_kernel); a wavefront
-// owns 64 columns and a quarter of the tiles: lane <-> tile for the tile's box against the block's box and the largest
-// bound in it (+ the static table of the columns with ANY admissible row in the tile), the survivors against every
-// column's own bound, and what is left as four products of v_mfma_f32_16x16x4_f32 per tile (16 rows x 16 columns each, the
-// whole K = 4 in one instruction: no dependent chain): |q'|^2 + R^2 - 2 p'.q' in coordinates relative to the centre of the
-// column block (exact f32 fma chains).  Tiles of 16 rows because that is what the pruning wants: the leaves of the cluster
-// tree hold ~16 rows -- one 32 x 32 tile per leaf is half empty (measured: 197 us against 162 us for the leaf scan), and
-// aligned tiles of 32 prune coarser (31 % of all pairs instead of 16 %: 187 us).  MEASURED: identical partners on every
-// fixture, and 199 us -- 21 % of the pairs, 2.5 M MFMAs, but 8.9e7 vector instructions (the scan: 7.8e7): ~140 per
-// 16 x 64 tile, of which the four products' keys are 52 and everything around them (the candidate's box from its lane,
-// the per-column test, the rows' operand, tiles that fail the test) the rest.  The scan's row step -- mask word = lane
-// mask, 10.5 instructions per row of 64 columns -- leaves the matrix cores nothing to win here, unlike the HD search whose
-// mask and row bookkeeping dominated.  Opt-in (v2v_flat = 3), kept as the measured alternative.  The mask of a tile comes as ready-made
-// lane masks: tree_mask_tiles[column block][tile][column group][accumulator register] holds the four rows an accumulator
-// register spans (row r + 4 q for the lanes of quarter q), so an inadmissible pair is one v_cndmask away; what is left per
-// value is the row's place in the low two mantissa bits (v_and_or) and a share of a v_min3_i32.
-// The rows found this way are CANDIDATES: their distances are recomputed by direct differences and merged into the same
-// 64-bit (distance, row) keys with atomicMin -- the result differs from the other forms only where two rows of one
-// (column block, quarter of the tiles) tie within the 22-bit key (~5e-7 relative), which the reference's own bmm-form
-// distances cannot tell apart either.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kTileWaves = 4;             // wavefronts per column block: they share out the row tiles
-constexpr int kTileRows = 16;
-__device__ __forceinline__ int select_key(int if_clear, int if_set, uint64_t lane_mask)
-{
-    int r;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(lane_mask));
-    return r;
-}
-__global__ __launch_bounds__(64) void v2v_mfma_kernel(
-    const float* __restrict__ prow, int V, int Vp, const float* __restrict__ tilebox, const float* __restrict__ colbox,
-    const uint64_t* __restrict__ tile_lanes, const uint64_t* __restrict__ mask_tiles, int T, uint64_t* __restrict__ keys)
-{
-    const int b = blockIdx.x, lane = threadIdx.x, q = lane >> 4, j = lane & 15;
-    const int qb = blockIdx.y / kTileWaves, wave = blockIdx.y % kTileWaves;
-    if (qb * kTreeCols >= V) return;
-    const float* pb = prow + (size_t)b * Vp * 3;
-    const int i0 = qb * kTreeCols + lane;
-    uint64_t* kb = keys + (size_t)b * Vp;
-    const uint64_t init = __hip_atomic_load(kb + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    Column c;                                                                    // own column: lane <-> column i0
-    c.px = pb[3 * i0]; c.py = pb[3 * i0 + 1]; c.pz = pb[3 * i0 + 2];
-    c.best = i0 < V ? __uint_as_float((uint32_t)(init >> 32)) : 0.0f;
-    c.arg = 0;
-    float reach2 = c.best;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) reach2 = fmaxf(reach2, __shfl_xor(reach2, m));
-    const float* cbx = colbox + ((size_t)b * (Vp / kTreeCols) + qb) * 8;
-    const float clx = cbx[0], cly = cbx[1], clz = cbx[2], chx = cbx[4], chy = cbx[5], chz = cbx[6];
-    // centre and squared radius of the column block; key = squared distance + (R^2 - |p'|^2) >= 0
-    const float cx = 0.5f * (clx + chx), cy = 0.5f * (cly + chy), cz = 0.5f * (clz + chz);
-    const float rx = chx - cx, ry = chy - cy, rz = chz - cz;
-    const float R2 = (rx * rx + ry * ry + rz * rz) * 1.0001f + 1e-12f;
-    auto offset_of = [&](float x, float y, float z) {
-        const float ux = x - cx, uy = y - cy, uz = z - cz;
-        return R2 - __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
-    };
-    const float own_o = offset_of(c.px, c.py, c.pz);
-    // matrix layout of column group g (columns 16 g ... 16 g + 15): lane l <-> column 16 g + (l & 15); the k index of both
-    // operands is l >> 4; accumulator register r of lane l is row r + 4 (l >> 4) of the tile
-    float Bop[4];
-    int bestkey[4], brow[4] = {-1, -1, -1, -1};
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int col = qb * kTreeCols + 16 * g + j;
-        const float x = pb[3 * col], y = pb[3 * col + 1], z = pb[3 * col + 2];
-        Bop[g] = q == 0 ? -2.0f * (x - cx) : q == 1 ? -2.0f * (y - cy) : q == 2 ? -2.0f * (z - cz) : 1.0f;
-        // nothing at or above the key of the column's current bound can improve on it
-        const uint64_t k = __hip_atomic_load(kb + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float bound = __uint_as_float((uint32_t)(k >> 32));
-        const float kf = bound + offset_of(x, y, z);
-        bestkey[g] = col < V && bound < __builtin_inff() ? (__float_as_int(__builtin_fmaf(kf, 4e-6f, kf) + 4e-6f * R2 + 1e-12f) | 3)
-                                                          : 0x7f000000;
-    }
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    const float* tb = tilebox + (size_t)b * T * 8;
-    const uint64_t* tl = tile_lanes + (size_t)qb * T;
-    int since = 0;
-    auto refresh = [&]() {
-        // the own columns' bounds: column l lives in group l >> 4, its candidates in the four quarters of that group
-        int m[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            m[g] = min(bestkey[g], __shfl_xor(bestkey[g], 16));
-            m[g] = min(m[g], __shfl_xor(m[g], 32));
-        }
-        const int mine = q == 0 ? m[0] : q == 1 ? m[1] : q == 2 ? m[2] : m[3];
-        const float f = __int_as_float(mine & ~3);
-        c.best = fminf(c.best, (f - own_o) + 4e-6f * (f + R2));
-        since = 0;
-    };
-    for (int base = wave; base < T; base += 64 * kTileWaves) {
-        // one tile per lane: the gap between its box and the block's, against the largest bound
-        const int t = base + kTileWaves * lane;
-        bool cand = false;
-        float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
-        uint64_t lanes_of = 0;
-        if (t < T) {
-            lo = *reinterpret_cast<const float4*>(tb + (size_t)t * 8);
-            hi = *reinterpret_cast<const float4*>(tb + (size_t)t * 8 + 4);
-            lanes_of = tl[t];
-            const float ex = fmaxf(fmaxf(lo.x - chx, clx - hi.x), 0.0f);
-            const float ey = fmaxf(fmaxf(lo.y - chy, cly - hi.y), 0.0f);
-            const float ez = fmaxf(fmaxf(lo.z - chz, clz - hi.z), 0.0f);
-            const float g = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) * kPruneSlack;
-            cand = g <= reach2 && lanes_of != 0;
-        }
-        unsigned long long todo = __builtin_amdgcn_ballot_w64(cand);
-        while (todo) {
-            const int u = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            auto from = [&](float x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), u)); };
-            const float b0 = from(lo.x), b1 = from(lo.y), b2 = from(lo.z), b4 = from(hi.x), b5 = from(hi.y), b6 = from(hi.z);
-            const uint64_t lanes = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(lanes_of >> 32), u) << 32) |
-                                   (uint32_t)__builtin_amdgcn_readlane((int)lanes_of, u);
-            const float dx = c.px - __builtin_amdgcn_fmed3f(c.px, b0, b4);
-            const float dy = c.py - __builtin_amdgcn_fmed3f(c.py, b1, b5);
-            const float dz = c.pz - __builtin_amdgcn_fmed3f(c.pz, b2, b6);
-            const float g = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) * kPruneSlack;
-            if ((__builtin_amdgcn_ballot_w64(g <= c.best) & lanes) == 0) continue;
-            const int tile = base + kTileWaves * u, row0 = kTileRows * tile;
-            // the tile's rows as the A operand: lane l <-> row l & 15, component l >> 4 of (x', y', z', |q'|^2 + R^2)
-            const int r = row0 + j;
-            const float ux = pb[3 * r] - cx, uy = pb[3 * r + 1] - cy, uz = pb[3 * r + 2] - cz;
-            const float nrm = __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux)) + R2;
-            const float A = q == 0 ? ux : q == 1 ? uy : q == 2 ? uz : nrm;
-            const uint64_t* mt = mask_tiles + ((size_t)qb * T + tile) * 16;
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A, Bop[g4], zero, 0, 0, 0);
-                int key[4];
-#pragma unroll
-                for (int a = 0; a < 4; ++a) key[a] = select_key(0x7f000000, (__float_as_int(acc[a]) & ~3) | a, mt[4 * g4 + a]);
-                const int m = min(min(key[0], key[1]), min(key[2], key[3]));
-                const bool better = m < bestkey[g4];
-                bestkey[g4] = better ? m : bestkey[g4];
-                brow[g4] = better ? row0 : brow[g4];
-            }
-            if (++since == 4) refresh();
-        }
-        if (since) refresh();
-    }
-    // candidates -> exact keys
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        if (brow[g] < 0) continue;
-        const int row = brow[g] + 4 * q + (bestkey[g] & 3);
-        const int col = qb * kTreeCols + 16 * g + j;
-        const float dx = pb[3 * col] - pb[3 * row], dy = pb[3 * col + 1] - pb[3 * row + 1], dz = pb[3 * col + 2] - pb[3 * row + 2];
-        const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-        atomicMin((unsigned long long*)(kb + col), (unsigned long long)v2v_key(d, row));
-    }
-}
-
 #define TUCH_SCAN_PARAMS                                                                                                   \
     const float* __restrict__ prow, int V, int Vp, const uint64_t* __restrict__ bits, const float* __restrict__ leafbox,    \
     const float* __restrict__ colbox, const uint64_t* __restrict__ masked_leaf, const uint64_t* __restrict__ masked, int N, \
@@ -1223,7 +969,7 @@ __global__ __launch_bounds__(kBlock) void v2v_tree_finalize_kernel(
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-struct TreeV2VLayout { size_t prow, bounds, keys, leafbox, colbox, prow_g, tilebox, total; };
+struct TreeV2VLayout { size_t prow, bounds, keys, leafbox, colbox, prow_g, total; };
 
 TreeV2VLayout tree_v2v_layout(const tuch_contact_model* m, int B)
 {
@@ -1233,10 +979,9 @@ TreeV2VLayout tree_v2v_layout(const tuch_contact_model* m, int B)
     l.prow = tuch_ws_take(o, (size_t)B * Vp * 3 * sizeof(float) + 64);
     l.bounds = tuch_ws_take(o, (size_t)B * m->tree_nodes * 8 * sizeof(float));
     l.keys = tuch_ws_take(o, (size_t)B * Vp * sizeof(uint64_t));
-    l.leafbox = tuch_ws_take(o, ((size_t)B * m->tree_leaves + kLeafBatch) * 8 * sizeof(float));     // + a batch of padding
+    l.leafbox = tuch_ws_take(o, ((size_t)B * m->tree_leaves + 4) * 8 * sizeof(float));     // + padding
     l.colbox = tuch_ws_take(o, (size_t)B * 2 * m->tree_qblocks * 8 * sizeof(float));
     l.prow_g = tuch_ws_take(o, ((size_t)B * m->tree_groups * 12 + 16) * sizeof(float));     // (+ a trip's read-ahead)
-    l.tilebox = tuch_ws_take(o, (size_t)B * 8 * m->tree_qblocks * 8 * sizeof(float));
     l.total = o;
     return l;
 }
@@ -1249,9 +994,11 @@ bool use_v2v_tree(const tuch_contact_model* m)
 
 static int flat_mode(const tuch_contact_model* m)
 {
+    // 2: lanes over a subtree's leaves first (v2v_scan_kernel, the default); 0: the stackless walk (v2v_tree_kernel: models
+    // without the leaf tables, and the A/B reference).  (Rounds 2-3 also had "leaf boxes four at a time" and a matrix-core
+    // form: identical keys, both slower -- DESIGN.md section 3; removed in round 4.)
     if (!(m->tree_sub_leaf && m->tree_masked_leaf)) return 0;
-    if (m->opt.v2v_flat == 3 && !m->tree_mask_tiles) return 2;
-    return m->opt.v2v_flat;
+    return m->opt.v2v_flat >= 2 ? 2 : 0;
 }
 
 int choose_v2v_frontier(const tuch_contact_model* m, int B)
@@ -1385,8 +1132,7 @@ extern "C" int tuch_v2v_min_model_shared_zero(const tuch_contact_model* m, const
     uint64_t* keys = (uint64_t*)(ws + l.keys);
     float* leafbox = (float*)(ws + l.leafbox);
     float* colbox = (float*)(ws + l.colbox);
-    const int scan = flat_mode(m);          // 2: lanes over leaves first, 1: leaf boxes four at a time, 0: the walk
-    const bool flat = flat_mode(m) != 0;
+    const int scan = flat_mode(m);          // 2: lanes over leaves first, 0: the walk
     hipStream_t s = (hipStream_t)stream;
     const int V = m->V, Vp = m->tree_qblocks * 2 * kTreeCols, N = m->tree_nodes;
     const TreeNode* nodes = (const TreeNode*)m->tree_node;
@@ -1398,13 +1144,13 @@ extern "C" int tuch_v2v_min_model_shared_zero(const tuch_contact_model* m, const
                            (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, N, prow, bounds, leafbox,
                            (const int32_t*)m->tree_leaf_group, scan == 2 ? (float*)(ws + l.prow_g) : (float*)nullptr,
                            m->tree_groups, row_blocks, (const uint64_t*)m->tree_mask_bits, (const int32_t*)hint_inout, keys,
-                           colbox, scan == 3 ? (float*)(ws + l.tilebox) : (float*)nullptr, (uint4*)(fused_zero ? zero : nullptr),
+                           colbox, (uint4*)(fused_zero ? zero : nullptr),
                            fused_zero ? zero_bytes / 16 : (size_t)0);
     } else {
     hipLaunchKernelGGL(v2v_rows_kernel, dim3(row_blocks, B), dim3(kBoundsBlock), 0, s,
                        verts, V, Vp, (const int32_t*)m->tree_qperm, (const int32_t*)m->tree_rows,
                        (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, N, prow, bounds,
-                       flat ? leafbox : (float*)nullptr, (const int32_t*)m->tree_leaf_group,
+                       scan >= 2 ? leafbox : (float*)nullptr, (const int32_t*)m->tree_leaf_group,
                        scan == 2 ? (float*)(ws + l.prow_g) : (float*)nullptr, m->tree_groups);
     if (scan < 2)      // (the leaf scans seed from the leaf boxes and never look at an inner node)
         hipLaunchKernelGGL(tree_inner_bounds_kernel<4>, dim3(B), dim3(kBoundsBlock), tree_inner_bounds_lds<4>(N), s, nodes, N,
@@ -1413,7 +1159,7 @@ extern "C" int tuch_v2v_min_model_shared_zero(const tuch_contact_model* m, const
     hipLaunchKernelGGL(v2v_seed_kernel, dim3(B, 2 * m->tree_qblocks), dim3(64), 0, s, (const float*)prow, V, Vp,
                        (const uint64_t*)m->tree_mask_bits, nodes, (const int32_t*)m->tree_rows, (const float*)bounds,
                        (const uint64_t*)m->tree_masked, N, (const int32_t*)hint_inout, keys, scan >= 2 ? colbox : (float*)nullptr,
-                       scan == 3 ? (float*)(ws + l.tilebox) : (float*)nullptr, scan >= 2 ? (const float*)leafbox : (const float*)nullptr,
+                       scan >= 2 ? (const float*)leafbox : (const float*)nullptr,
                        (const uint64_t*)m->tree_masked_leaf, m->tree_leaves);
     }
     const int f = choose_v2v_frontier(m, B);
@@ -1424,11 +1170,7 @@ extern "C" int tuch_v2v_min_model_shared_zero(const tuch_contact_model* m, const
     // got going when the walk was done (tools/graph_timeline.py: the memset took 236 us).  -2.5 % step time; alone the
     // walk is 10 % slower with the cap (0.28 -> 0.31 ms), hence a flag (TUCH_V2V_LDS: bytes, to compare).
     const int lds_pad = leave_room && m->opt.v2v_lds > 0 ? m->opt.v2v_lds : 0;
-    if (scan == 3)
-        hipLaunchKernelGGL(v2v_mfma_kernel, dim3(B, 2 * m->tree_qblocks * kTileWaves), dim3(64), 0, s, (const float*)prow, V, Vp,
-                           (const float*)(ws + l.tilebox), (const float*)colbox, (const uint64_t*)m->tree_tile_lanes,
-                           (const uint64_t*)m->tree_mask_tiles, m->tree_tiles, keys);
-    else if (scan == 2 && leave_room && m->opt.v2v_lds < 0)
+    if (scan == 2 && leave_room && m->opt.v2v_lds < 0)
         hipLaunchKernelGGL(v2v_scan_shared_kernel, dim3(B, 2 * nsub * m->tree_qblocks), dim3(64), 0, s, (const float*)prow,
                            V, Vp, (const uint64_t*)m->tree_mask_bits, (const float*)leafbox, (const float*)colbox,
                            (const uint64_t*)m->tree_masked_leaf, (const uint64_t*)m->tree_masked, N, m->tree_leaves,
@@ -1442,12 +1184,6 @@ extern "C" int tuch_v2v_min_model_shared_zero(const tuch_contact_model* m, const
                            (const int32_t*)m->tree_frontier_nodes + f0, (const int32_t*)m->tree_sub_leaf + 2 * (size_t)f0,
                            (const int32_t*)m->tree_launch_order + (size_t)f0 * m->tree_qblocks, keys,
                            (const float*)(ws + l.prow_g), (const uint64_t*)m->tree_mask_bits_g, m->tree_groups);
-    else if (flat)
-        hipLaunchKernelGGL(v2v_leaves_kernel, dim3(B, 2 * nsub * m->tree_qblocks), dim3(64), (size_t)lds_pad, s, (const float*)prow,
-                           V, Vp, (const uint64_t*)m->tree_mask_bits, (const float*)bounds, (const float*)leafbox,
-                           (const uint64_t*)m->tree_masked, (const uint64_t*)m->tree_masked_leaf, N, m->tree_leaves,
-                           (const int32_t*)m->tree_frontier_nodes + f0, (const int32_t*)m->tree_sub_leaf + 2 * (size_t)f0,
-                           (const int32_t*)m->tree_launch_order + (size_t)f0 * m->tree_qblocks, keys);
     else
     hipLaunchKernelGGL(v2v_tree_kernel, dim3(B, 2 * nsub * m->tree_qblocks), dim3(64), (size_t)lds_pad, s, (const float*)prow, V, Vp,
                        (const uint64_t*)m->tree_mask_bits, nodes, (const int32_t*)m->tree_rows, (const float*)bounds,

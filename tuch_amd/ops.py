@@ -911,12 +911,19 @@ class ContactModel:
 
 class HDModel:
     """Device tables of the HD vertex regressor for the fused HD branch (wraps tuch_hd_model; csrc/hd_contact.hip).
-    hd_idx / hd_w [N,3]: the three non-zeros of every regressor row; hd_face [N]: faces_vert_is_sampled_from."""
+    hd_idx / hd_w [N,K]: the K <= 8 non-zeros of every regressor row (K = 3: barycentric samples); hd_face [N]:
+    faces_vert_is_sampled_from."""
 
     def __init__(self, contact_model: ContactModel, hd_idx, hd_w, hd_face):
         self.contact_model = contact_model
         self.num_points = int(np.asarray(hd_face).shape[0])
-        self._host = (_i32(np.asarray(hd_idx).reshape(-1, 3)), np.ascontiguousarray(np.asarray(hd_w).reshape(-1, 3), np.float32),
+        hd_idx, hd_w = np.asarray(hd_idx), np.asarray(hd_w)
+        # [N,K]: K non-zeros per regressor row (3 for barycentric samples; up to 8)
+        self.row_nnz = int(hd_idx.shape[-1]) if hd_idx.ndim == 2 else 3
+        if not 1 <= self.row_nnz <= 8 or hd_idx.size != self.num_points * self.row_nnz or hd_w.size != hd_idx.size:
+            raise ValueError('HDModel: hd_idx / hd_w must be [N,K] with 1 <= K <= 8 (got %s, %s for %d points)'
+                             % (hd_idx.shape, hd_w.shape, self.num_points))
+        self._host = (_i32(hd_idx.reshape(-1, self.row_nnz)), np.ascontiguousarray(hd_w.reshape(-1, self.row_nnz), np.float32),
                       _i32(hd_face))
         self._h = None
 
@@ -928,9 +935,9 @@ class HDModel:
             cm = self.contact_model._handle
             host_tables = os.environ.get('TUCH_HOST_TABLES', '0') not in ('', '0')
             with (contextlib.nullcontext() if host_tables else torch.cuda.device(self.contact_model.device)):
-                _C.check(_C.lib().tuch_hd_model_create(ctypes.byref(handle), cm, self.num_points,
-                                                       idx.ctypes.data_as(ctypes.c_void_p), w.ctypes.data_as(ctypes.c_void_p),
-                                                       face.ctypes.data_as(ctypes.c_void_p)))
+                _C.check(_C.lib().tuch_hd_model_create_k(ctypes.byref(handle), cm, self.num_points, self.row_nnz,
+                                                         idx.ctypes.data_as(ctypes.c_void_p), w.ctypes.data_as(ctypes.c_void_p),
+                                                         face.ctypes.data_as(ctypes.c_void_p)))
             self._h = handle
         return self._h
 
