@@ -921,21 +921,22 @@ def test_pair_list_overflow_falls_back_to_block_major_order(tag, cap):
 
 @pytest.mark.parametrize('tag', TAGS)
 def test_fused_segment_filter_matches_the_six_launch_pass(tag):
-    """The segment filter as one launch per call (csrc/ray_winding.hip: segment_fused_kernel -- compaction, cap centroids,
-    crossings and cones in LDS, one workgroup per (segment, body)) against the same filter as six launches (option
-    seg_fused = 0): identical flags, on the fixtures and on sheared / squeezed copies with many interior vertices."""
+    """The segment filter behind the body test as ONE launch (segment_one_kernel, option seg_fused = 1: eight workgroups
+    per (segment, body), each finishing a share of the interior vertices) against the general six-launch pass
+    (seg_fused = 0): identical flags, on the fixtures and on sheared / squeezed copies with many interior vertices, at a
+    batch that is not a multiple of anything."""
     batch = 6 if tag in FULL else 11
     g, verts = _posed_batch(tag, batch, 31, scale=1.3)
     model = make_model(g, None, True, False)
     assert model.get_option('seg_fused') == 1 and model.get_option('seg_fused_active') == 1
     plain = model.exterior_flags(verts, apply_segments=False)
-    fused = model.exterior_flags(verts, apply_segments=True)
+    one = model.exterior_flags(verts, apply_segments=True)
     model.set_option('seg_fused', 0)
     six = model.exterior_flags(verts, apply_segments=True)
     model.set_option('seg_fused', 1)
     again = model.exterior_flags(verts, apply_segments=True)
-    assert torch.equal(fused, six) and torch.equal(again, fused)
-    changed = int((fused != plain).sum())
+    assert torch.equal(one, six) and torch.equal(again, one)
+    changed = int((one != plain).sum())
     report('fused segment filter [%s]: vertices re-marked exterior by the filter' % tag, changed, plain.numel())
     assert int((plain == 0).sum()) > 0
 

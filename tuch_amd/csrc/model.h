@@ -46,7 +46,7 @@ struct tuch_options {
     int v2v_lds = -1;           // search beside the inside test: -1 capped at 6 wavefronts per SIMD by register count, > 0 by an LDS allocation of that many bytes per workgroup (6400: round 2), 0 uncapped
     int seg_splits = 16;        // face splits of the solid-angle segment kernel
     int seg_assist = 1;         // 0: the segment pass counts its body-face crossings itself (read at create only)
-    int seg_fused = 1;          // 0: the segment filter as six launches instead of one (A/B, tests)
+    int seg_fused = 1;          // the segment filter behind the body test: 1 one launch (segment_one_kernel, round 4), 0 the general six-launch pass (A/B, tests)
     int canary = 0;             // 1: guard words between the regions of every workspace, see tuch_workspace_canaries
     int hd_search = 1;          // HD branch: 1 nearest admissible point on the matrix cores (hd_search.hip), 0 v2v_indexed_kernel
     int hd_search_waves = 4;    // wavefronts per block of 64 columns in that search (4, 2 or 1)
@@ -69,9 +69,8 @@ const int32_t* tuch_ray_segment_counts(const tuch_contact_model* m, int B, const
 void tuch_ray_segment_prepare(const tuch_contact_model* m, const float* verts, const float* caps, int assisted, int B,
                               float* seg_entries, hipStream_t s);
 bool tuch_ray_segment_fused_available(const tuch_contact_model* m);
-int tuch_ray_segment_flags_fused(const tuch_contact_model* m, const float* verts, const uint8_t* body_flags,
-                                 const int32_t* leaf_counts, int B, float thresh, int32_t* seg_partial, uint8_t* exterior,
-                                 hipStream_t s);
+int tuch_ray_segment_flags_one(const tuch_contact_model* m, const float* verts, const uint8_t* body_flags,
+                               const int32_t* leaf_counts, int B, float thresh, uint8_t* exterior, hipStream_t s);
 int tuch_ray_segment_flags(const tuch_contact_model* m, const float* verts, const float* caps, const int32_t* seg_count,
                            const int32_t* seg_list, const int32_t* leaf_counts, int B, int nsplit, float thresh, float* seg_tris,
                            int32_t* seg_partial, float* seg_w, uint8_t* seg_ext, uint8_t* exterior, hipStream_t s);

@@ -877,19 +877,11 @@ __device__ __forceinline__ void cone_term(const P3& us, const P3& sb, const P3& 
     half = fast_atan2(front ? num : -num, den);
 }
 
-// vertices: N = sum of the subtree counts + crossings of the closing fan; w = N - (sum of the fan's half angles) / (2 pi)
-__global__ __launch_bounds__(kBlock) void ray_finalize_verts_kernel(
-    const float* __restrict__ verts, const int32_t* __restrict__ count, const int32_t* __restrict__ qperm,
-    const int32_t* __restrict__ ring_off, const int32_t* __restrict__ ring_vidx,
-    int V, int stride, float thresh, float* __restrict__ w_out, uint8_t* __restrict__ exterior,
-    uint8_t* __restrict__ exterior_copy)                 // or nullptr: the same flags once more (the segment filter reads
-{                                                        // them while it re-marks `exterior`)
-    const int b = blockIdx.y;
-    const int i = blockIdx.x * kBlock + threadIdx.x;     // position in tree order
-    const bool real = i < V;                             // all lanes stay: long rings below need the whole wavefront
-    const int v = qperm[real ? i : V - 1];
-    int n = count[(size_t)b * stride + (real ? i : V - 1)];
-    const float* vb = verts + (size_t)b * V * 3;
+// w of a VERTEX from its crossing count: N = count + crossings of the closing fan; w = N - (sum of the fan's half angles) / (2 pi).
+// One vertex per lane (`real` = false: a padding lane; all lanes of the wavefront must call -- long rings are shared out).
+__device__ __forceinline__ float fan_winding(const float* __restrict__ vb, int v, bool real, int n,
+                                             const int32_t* __restrict__ ring_off, const int32_t* __restrict__ ring_vidx)
+{
     const float vx = vb[3 * v], vy = vb[3 * v + 1], vz = vb[3 * v + 2];
     const float qx = shear_x(vx, vz), qy = shear_y(vy, vz);
     // the apex direction of the fan, in space and sheared (ray frame)
@@ -935,9 +927,8 @@ __global__ __launch_bounds__(kBlock) void ray_finalize_verts_kernel(
     while (todo) {
         const int src = __builtin_ctzll(todo);
         todo &= todo - 1;
-        const int lv = __builtin_amdgcn_readlane(v, src), llo = __builtin_amdgcn_readlane(lo, src), lcnt = __builtin_amdgcn_readlane(cnt, src);
+        const int llo = __builtin_amdgcn_readlane(lo, src), lcnt = __builtin_amdgcn_readlane(cnt, src);
         const float lvx = __shfl(vx, src), lvy = __shfl(vy, src), lvz = __shfl(vz, src);
-        (void)lv;
         float h = 0.0f;
         int cr = 0;
         for (int j = lane; j < lcnt; j += 64) {
@@ -957,7 +948,22 @@ __global__ __launch_bounds__(kBlock) void ray_finalize_verts_kernel(
         for (int m = 32; m >= 1; m >>= 1) { h += __shfl_xor(h, m); cr += __shfl_xor(cr, m); }
         if (lane == src) { half_sum = h; n += cr; }
     }
-    const float w = (float)n - half_sum * (0.5f / kPi);
+    return (float)n - half_sum * (0.5f / kPi);
+}
+
+// vertices: the body test's flags from the crossing counts
+__global__ __launch_bounds__(kBlock) void ray_finalize_verts_kernel(
+    const float* __restrict__ verts, const int32_t* __restrict__ count, const int32_t* __restrict__ qperm,
+    const int32_t* __restrict__ ring_off, const int32_t* __restrict__ ring_vidx,
+    int V, int stride, float thresh, float* __restrict__ w_out, uint8_t* __restrict__ exterior,
+    uint8_t* __restrict__ exterior_copy)                 // or nullptr: the same flags once more (the two-launch segment
+{                                                        // filter reads them while it re-marks `exterior`)
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * kBlock + threadIdx.x;     // position in tree order
+    const bool real = i < V;                             // all lanes stay: long rings need the whole wavefront
+    const int v = qperm[real ? i : V - 1];
+    const int n = count[(size_t)b * stride + (real ? i : V - 1)];
+    const float w = fan_winding(verts + (size_t)b * V * 3, v, real, n, ring_off, ring_vidx);
     const size_t o = (size_t)b * V + v;
     if (real) {
         if (w_out) w_out[o] = w;
@@ -1257,65 +1263,21 @@ struct RayLayout {
     size_t seg_count;        // per-segment crossing counts of the vertices (models with seg_elem_mask), zeroed with `count`
 };
 
-// ---- the segment filter in TWO launches behind the body test (flags only, leaf-assisted models) ---------------------
+// ---- the segment filter behind the body test (flags only, leaf-assisted models) ------------------------------------------
 // cap centroids -> sheared entries -> compaction of the interior vertices -> work items -> crossings -> cones + flags were
-// six launches (two ahead of the body test, four behind it: ~60 us of the step's serial chain at batch 64 for a few
-// hundred interior vertices per body).  Now:
-//   segment_cross_kernel, one workgroup per (segment, body, slice of the segment's cap faces / boundary edges):
-//     A. the segment's interior vertices (by the BODY test's flags, which nobody writes meanwhile), compacted in list
-//        order by a scan -- no atomics, the same list in every workgroup of the (segment, body); none -> done;
-//     B. the segment's cap centroids (segmentation.py:74-76) in LDS;
-//     C. its slice of the entries, posed and sheared, in LDS; lane = vertex, entries by LDS broadcast; crossings and the
-//        boundary cones' half angles per (slice, vertex) to the workspace.
-//   segment_flags_kernel, one workgroup per (segment, body): A and B again (cheaper than passing them on), then per
-//     interior vertex: the slices' sums + the crossings with the segment's body faces the body's own inside test has
-//     counted (seg_leaf_count) + the cones of the vertex's links; w = N - angles / 2 pi; not exterior to its own segment
-//     -> exterior in the body flags (losses.py:87-89, loss.py:265-266).
-// (One launch with everything in one workgroup per (segment, body) was tried first: 81 us -- a body whose arm lies in its
-// trunk puts ~300 interior vertices x ~400 entries on one workgroup while 400 of the 512 have nothing to do.)
-constexpr int kSegFusedBlock = 256;
-constexpr int kSegFusedWaves = kSegFusedBlock / 64;
+// six launches in round 2 (two ahead of the body test, four behind it: ~60 us of the step's serial chain at batch 64 for a
+// few hundred interior vertices per body), two in round 3 (segment_cross_kernel: one workgroup per (segment, body, 1/16 of
+// the entries), partial sums to global memory; segment_flags_kernel: sums + cones + flags: 48 + 18 us), one since round 4.
 constexpr int kSegFusedMaxQ = 4096;      // vertices of one segment (the synthetic head: ~1150)
 constexpr int kSegFusedMaxCaps = 8;
-constexpr int kSegFusedSlices = 16;      // = kSegSplits of winding.hip: the partial arrays have room for 16
-constexpr int kSegFusedChunk = 128;      // entries staged per pass (a slice is usually shorter)
 
-// A: interior vertices of segment sg (positions in its vertex list) -> s_list, count returned (uniform).  All of a
-// thread's flags are requested before the first is looked at (the rounds of the scan then only touch LDS).
-__device__ __forceinline__ int seg_fused_compact(const uint8_t* __restrict__ flags_b, const int32_t* __restrict__ seg_q_vidx,
-                                                 int q_beg, int nq, int32_t* s_list, int32_t* s_wave, int32_t* s_n)
-{
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    constexpr int kRounds = kSegFusedMaxQ / kSegFusedBlock;
-    uint32_t interior = 0;                                  // bit r: vertex r * block + t is interior
-#pragma unroll
-    for (int r = 0; r < kRounds; ++r) {
-        const int q = r * kSegFusedBlock + t;
-        if (q < nq && flags_b[seg_q_vidx[q_beg + q]] == 0) interior |= 1u << r;
-    }
-    if (t == 0) *s_n = 0;
-    __syncthreads();
-    for (int r = 0; r * kSegFusedBlock < nq; ++r) {
-        const bool mine = (interior >> r) & 1u;
-        const unsigned long long bal = __builtin_amdgcn_ballot_w64(mine);
-        if (lane == 0) s_wave[wave] = __builtin_popcountll(bal);
-        __syncthreads();
-        int base = *s_n;
-        for (int w2 = 0; w2 < wave; ++w2) base += s_wave[w2];
-        if (mine) s_list[base + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = r * kSegFusedBlock + t;
-        __syncthreads();
-        if (t == 0) { int add = 0; for (int w2 = 0; w2 < kSegFusedWaves; ++w2) add += s_wave[w2]; *s_n += add; }
-        __syncthreads();
-    }
-    return *s_n;
-}
-
-// B: cap centroids of the caps c_lo .. c_hi -> s_caps
+// cap centroids of the caps c_lo .. c_hi -> s_caps (segmentation.py:74-76), a wavefront per cap
+template <int kWaves>
 __device__ __forceinline__ void seg_fused_caps(const float* __restrict__ vb, const int32_t* __restrict__ cap_off,
                                                const int32_t* __restrict__ cap_vidx, int c_lo, int c_hi, float* s_caps)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int c = c_lo + wave; c < c_hi; c += kSegFusedWaves) {
+    for (int c = c_lo + wave; c < c_hi; c += kWaves) {
         float sx = 0.f, sy = 0.f, sz = 0.f;
         const int beg = cap_off[c], end = cap_off[c + 1];
         for (int k = beg + lane; k < end; k += 64) {
@@ -1331,48 +1293,97 @@ __device__ __forceinline__ void seg_fused_caps(const float* __restrict__ vb, con
     }
 }
 
-__global__ __launch_bounds__(kSegFusedBlock) void segment_cross_kernel(
-    const float* __restrict__ verts, const uint8_t* __restrict__ body_flags,
+// ---- ONE launch (round 4) ---------------------------------------------------------------------------------------------
+// In the two launches of round 3 every one of the 16 slice workgroups of a (segment, body) compacted the segment's interior
+// vertices again, and the slices' sums travelled through global memory to the second launch.  Here kSegOneZ workgroups of eight wavefronts share a (segment, body) by VERTICES, not by entries:
+//   A. the segment's interior vertices by the body test's flags (the copy nobody writes), compacted in list order -- the
+//      same list in every workgroup; workgroup z owns the groups of 64 of them with index = z (mod kSegOneZ); none -> done;
+//   B. the cap centroids;
+//   C. ALL entries of the segment (cap faces, boundary edges), posed and sheared 256 at a time in LDS; the wavefronts share
+//      out (own group) x (sub-slice of the entries): one group -> eight sub-slices, eight groups -> one each; lane = vertex,
+//      entries by LDS broadcast; the sub-slices' sums meet in LDS;
+//   D. per own interior vertex: those sums in sub-slice order + the crossings with the segment's body faces the body's own
+//      inside test has counted (seg_leaf_count) + the cones of its links -> w; not exterior to its own segment ->
+//      exterior[v] = 1 (losses.py:87-89, loss.py:265-266).
+// Nothing crosses workgroups: no partial sums in global memory, no arrival counter, no second launch.
+// (Measured on the way, solo at batch 64, against 63 us for the two launches: one workgroup per (segment, body) with four
+// wavefronts, round 3: 81 us; 128 vertices per workgroup with the body winding numbers recomputed from the crossing counts
+// so that nothing waits for the flags: 89 us -- interior vertices are scattered over a segment's list, every chunk that
+// holds one walks all entries with a handful of live lanes; one workgroup of SIXTEEN wavefronts: 44 us at every batch size --
+// a body whose arm lies in its trunk keeps one compute unit busy with ~80 k instructions; four workgroups sharing the
+// ENTRIES with the last arrival finishing (partial sums + fence + ticket per workgroup): 74 us.)
+constexpr int kSegOneBlock = 512, kSegOneWaves = kSegOneBlock / 64, kSegOneChunk = 256, kSegOneZ = 8;
+constexpr int kSegOneOwn = kSegFusedMaxQ / kSegOneZ;      // interior vertices a workgroup can own (groups of 64 dealt round-robin)
+__global__ __launch_bounds__(kSegOneBlock) void segment_one_kernel(
+    const float* __restrict__ verts, const uint8_t* __restrict__ body_flags, uint8_t* __restrict__ exterior,
     const int32_t* __restrict__ seg_q_off, const int32_t* __restrict__ seg_q_vidx,
     const int32_t* __restrict__ cap_range, const int32_t* __restrict__ cap_off, const int32_t* __restrict__ cap_vidx,
-    const int32_t* __restrict__ ent_off, const int32_t* __restrict__ ent,       // cap faces + boundary edges (seg_cap_*)
-    int V, int Qs_total, int32_t* __restrict__ partial, float* __restrict__ partial_half)      // [B][slices][Qs_total]
+    const int32_t* __restrict__ ent_off, const int32_t* __restrict__ ent,
+    const int32_t* __restrict__ link_off, const int32_t* __restrict__ link, const int32_t* __restrict__ leaf_counts,
+    const int32_t* __restrict__ vpos, int slots, int V, float thresh)
 {
     __shared__ int32_t s_list[kSegFusedMaxQ];
-    __shared__ float sT[kSegFusedChunk * 9];
+    __shared__ int32_t s_cnt[kSegOneOwn];
+    __shared__ float s_half[kSegOneOwn];
+    __shared__ float sT[kSegOneChunk * 9];
     __shared__ float s_caps[kSegFusedMaxCaps * 3];
-    __shared__ int32_t s_wave[kSegFusedWaves];
+    __shared__ int32_t s_wave[kSegOneWaves];
     __shared__ int32_t s_n;
     const int sg = blockIdx.x, b = blockIdx.y, z = blockIdx.z, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const float* vb = verts + (size_t)b * V * 3;
+    uint8_t* eb = exterior + (size_t)b * V;
     const int q_beg = seg_q_off[sg], nq = seg_q_off[sg + 1] - q_beg;
-    const int e_seg = ent_off[sg], e_cnt = ent_off[sg + 1] - e_seg;
-    const int per = (e_cnt + kSegFusedSlices - 1) / kSegFusedSlices;
-    const int e_beg = e_seg + z * per, e_end = min(e_seg + e_cnt, e_beg + per);
-    const int n = seg_fused_compact(body_flags + (size_t)b * V, seg_q_vidx, q_beg, nq, s_list, s_wave, &s_n);
-    if (n == 0) return;
-    const size_t out = ((size_t)b * kSegFusedSlices + z) * Qs_total + q_beg;
-    if (e_beg >= e_end) {                                  // an empty slice still owns its row of the partial arrays
-        for (int k = t; k < n; k += kSegFusedBlock) { partial[out + k] = 0; partial_half[out + k] = 0.0f; }
-        return;
+    // A.  All of a thread's flags are requested before the first is looked at (the rounds of the scan then only touch LDS).
+    {
+        const uint8_t* fb = body_flags + (size_t)b * V;
+        constexpr int kRounds = kSegFusedMaxQ / kSegOneBlock;
+        uint32_t interior = 0;                              // bit r: vertex r * block + t is interior
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) {
+            const int q = r * kSegOneBlock + t;
+            if (q < nq && fb[seg_q_vidx[q_beg + q]] == 0) interior |= 1u << r;
+        }
+        if (t == 0) s_n = 0;
+        __syncthreads();
+        for (int r = 0; r * kSegOneBlock < nq; ++r) {
+            const bool in = (interior >> r) & 1u;
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(in);
+            if (lane == 0) s_wave[wave] = __builtin_popcountll(bal);
+            __syncthreads();
+            int base = s_n;
+            for (int w2 = 0; w2 < wave; ++w2) base += s_wave[w2];
+            if (in) s_list[base + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = r * kSegOneBlock + t;
+            __syncthreads();
+            if (t == 0) { int add = 0; for (int w2 = 0; w2 < kSegOneWaves; ++w2) add += s_wave[w2]; s_n += add; }
+            __syncthreads();
+        }
     }
+    const int n = s_n;
+    const int groups = (n + 63) >> 6;
+    const int mine = groups > z ? (groups - z + kSegOneZ - 1) / kSegOneZ : 0;      // own groups: z, z + Z, ...
+    if (mine == 0) return;
+    // B.
     const int c_lo = cap_range[sg];
-    seg_fused_caps(vb, cap_off, cap_vidx, c_lo, cap_range[sg + 1], s_caps);
+    seg_fused_caps<kSegOneWaves>(vb, cap_off, cap_vidx, c_lo, cap_range[sg + 1], s_caps);
+    // C.
     const P3 u_dir = {kFanX, kFanY, kFanZ};
     const P3 us = {shear_x(kFanX, kFanZ), shear_y(kFanY, kFanZ), kFanZ};
-    const int groups = (n + 63) >> 6;
-    for (int g0 = 0; g0 < groups; g0 += kSegFusedWaves) {  // (usually one round: <= 256 interior vertices)
-        const int k = (g0 + wave) * 64 + lane;
-        const bool have = g0 + wave < groups;
+    const int e_beg = ent_off[sg], e_end = ent_off[sg + 1];
+    const int slices = mine >= kSegOneWaves ? 1 : kSegOneWaves / mine;          // wavefronts per own group
+    for (int j0 = 0; j0 < mine; j0 += kSegOneWaves) {                           // (one round unless n > 1024)
+        const int j = slices > 1 ? wave / slices : j0 + wave;                    // own group, sub-slice of the entries
+        const int sl = slices > 1 ? wave % slices : 0;
+        const bool have = j < mine && (slices == 1 || wave < mine * slices);
+        const int k = (z + (have ? j : 0) * kSegOneZ) * 64 + lane;               // position in the compacted list
         const int v0 = seg_q_vidx[q_beg + s_list[min(k, n - 1)]];
         const float qz = vb[3 * (size_t)v0 + 2];
         const float qx = shear_x(vb[3 * (size_t)v0], qz), qy = shear_y(vb[3 * (size_t)v0 + 1], qz);
         int crossings = 0;
         float half_sum = 0.0f;
-        for (int chunk = e_beg; chunk < e_end; chunk += kSegFusedChunk) {
-            const int cn = min(kSegFusedChunk, e_end - chunk);
+        for (int chunk = e_beg; chunk < e_end; chunk += kSegOneChunk) {
+            const int cn = min(kSegOneChunk, e_end - chunk);
             __syncthreads();
-            for (int i = t; i < cn; i += kSegFusedBlock) {
+            for (int i = t; i < cn; i += kSegOneBlock) {
                 const int id[3] = {ent[3 * (size_t)(chunk + i)], ent[3 * (size_t)(chunk + i) + 1], ent[3 * (size_t)(chunk + i) + 2]};
                 float* dst = sT + i * 9;
                 const int corners = id[2] < 0 ? 2 : 3;
@@ -1384,7 +1395,7 @@ __global__ __launch_bounds__(kSegFusedBlock) void segment_cross_kernel(
             }
             __syncthreads();
             if (!have) continue;
-            for (int f = 0; f < cn; ++f) {
+            for (int f = sl; f < cn; f += slices) {
                 const float* e = sT + f * 9;
                 if (e[7] != kConeMarker) {                              // a cap face (wave-uniform: LDS broadcast)
                     const P3 a = {e[0] - qx, e[1] - qy, e[2] - qz}, bb = {e[3] - qx, e[4] - qy, e[5] - qz}, c = {e[6] - qx, e[7] - qy, e[8] - qz};
@@ -1416,49 +1427,33 @@ __global__ __launch_bounds__(kSegFusedBlock) void segment_cross_kernel(
                 }
             }
         }
-        if (have && k < n) { partial[out + k] = crossings; partial_half[out + k] = half_sum; }
+        // sums: [sub-slice][own group][lane] with several sub-slices (mine x slices <= 8 wavefronts), else [own group][lane]
+        if (have) {
+            const int at = slices > 1 ? (sl * mine + j) * 64 + lane : j * 64 + lane;
+            s_cnt[at] = crossings;
+            s_half[at] = half_sum;
+        }
+        if (slices > 1) break;
     }
-}
-
-__global__ __launch_bounds__(kSegFusedBlock) void segment_flags_kernel(
-    const float* __restrict__ verts, const uint8_t* __restrict__ body_flags, uint8_t* __restrict__ exterior,
-    const int32_t* __restrict__ seg_q_off, const int32_t* __restrict__ seg_q_vidx,
-    const int32_t* __restrict__ cap_range, const int32_t* __restrict__ cap_off, const int32_t* __restrict__ cap_vidx,
-    const int32_t* __restrict__ link_off, const int32_t* __restrict__ link,
-    const int32_t* __restrict__ partial, const float* __restrict__ partial_half,
-    const int32_t* __restrict__ leaf_counts, const int32_t* __restrict__ vpos, int slots, int V, int Qs_total, float thresh)
-{
-    __shared__ int32_t s_list[kSegFusedMaxQ];
-    __shared__ float s_caps[kSegFusedMaxCaps * 3];
-    __shared__ int32_t s_wave[kSegFusedWaves];
-    __shared__ int32_t s_n;
-    const int sg = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63;
-    const float* vb = verts + (size_t)b * V * 3;
-    uint8_t* eb = exterior + (size_t)b * V;
-    const int q_beg = seg_q_off[sg], nq = seg_q_off[sg + 1] - q_beg;
-    const int n = seg_fused_compact(body_flags + (size_t)b * V, seg_q_vidx, q_beg, nq, s_list, s_wave, &s_n);
-    if (n == 0) return;
-    const int c_lo = cap_range[sg];
-    seg_fused_caps(vb, cap_off, cap_vidx, c_lo, cap_range[sg + 1], s_caps);
     __syncthreads();
+    // D. one thread per own interior vertex (all lanes of a wavefront stay: long link lists are shared out over it)
     auto pos = [&](int id, float (&o)[3]) {                // a vertex id of the segment tables (>= V: cap vertex)
         const float* p = id < V ? vb + 3 * (size_t)id : s_caps + 3 * (id - V - c_lo);
         o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
     };
-    const P3 u_dir = {kFanX, kFanY, kFanZ};
-    const P3 us = {shear_x(kFanX, kFanZ), shear_y(kFanY, kFanZ), kFanZ};
-    for (int k0 = 0; k0 < n; k0 += kSegFusedBlock) {
-        const int k = k0 + t;
-        const bool active = k < n;                         // all lanes stay: long link lists are shared over the wavefront
+    for (int j = wave; j < mine; j += kSegOneWaves) {       // (wave-uniform)
+        const int k = (z + j * kSegOneZ) * 64 + lane;
+        const bool active = k < n;
         const int qq = q_beg + s_list[active ? k : 0];
         const int v = seg_q_vidx[qq];
         int cnt = 0;
         float half_sum = 0.0f;
         if (active) {
-            for (int z = 0; z < kSegFusedSlices; ++z) {
-                const size_t o = ((size_t)b * kSegFusedSlices + z) * Qs_total + q_beg + k;
-                cnt += partial[o];
-                half_sum += partial_half[o];
+            if (slices > 1) {
+                for (int s2 = 0; s2 < slices; ++s2) { cnt += s_cnt[(s2 * mine + j) * 64 + lane]; half_sum += s_half[(s2 * mine + j) * 64 + lane]; }
+            } else {
+                cnt = s_cnt[j * 64 + lane];
+                half_sum = s_half[j * 64 + lane];
             }
             cnt += seg_leaf_count(leaf_counts + 2 * ((size_t)b * slots + vpos[v]), sg);
         }
@@ -1517,31 +1512,24 @@ __global__ __launch_bounds__(kSegFusedBlock) void segment_flags_kernel(
 
 }  // namespace
 
-// can the segment filter run as the two launches above?  (flags only; the caller checks that)
+// can the segment filter run as the one launch above?  (flags only; the caller checks that)
 bool tuch_ray_segment_fused_available(const tuch_contact_model* m)
 {
     return m && m->seg_cap_off && m->seg_cap_range && m->seg_elem_mask && m->seg_q_max <= kSegFusedMaxQ && m->opt.seg_fused != 0;
 }
 
-// body_flags [B,V]: the body test's own flags (a copy nobody writes during the call); exterior [B,V] in/out;
-// leaf_counts = tuch_ray_segment_counts of the SAME vertices; seg_partial: room for 2 x B x 16 x seg_q_total words
-int tuch_ray_segment_flags_fused(const tuch_contact_model* m, const float* verts, const uint8_t* body_flags,
-                                 const int32_t* leaf_counts, int B, float thresh, int32_t* seg_partial, uint8_t* exterior,
-                                 hipStream_t s)
+// The segment filter as ONE launch (segment_one_kernel): kSegOneZ workgroups per (segment, body) read body_flags (the body
+// test's own flags: a copy nobody writes during the call) and write ones into `exterior` [B,V]; leaf_counts =
+// tuch_ray_segment_counts of the SAME vertices.
+int tuch_ray_segment_flags_one(const tuch_contact_model* m, const float* verts, const uint8_t* body_flags,
+                               const int32_t* leaf_counts, int B, float thresh, uint8_t* exterior, hipStream_t s)
 {
-
-    float* partial_half = (float*)(seg_partial + (size_t)B * kSegFusedSlices * m->seg_q_total);
-    hipLaunchKernelGGL(segment_cross_kernel, dim3(m->num_segments, B, kSegFusedSlices), dim3(kSegFusedBlock), 0, s, verts,
-                       body_flags, (const int32_t*)m->seg_q_off, (const int32_t*)m->seg_q_vidx,
-                       (const int32_t*)m->seg_cap_range, (const int32_t*)m->cap_off, (const int32_t*)m->cap_vidx,
-                       (const int32_t*)m->seg_cap_off, (const int32_t*)m->seg_cap_ent, m->V, m->seg_q_total, seg_partial,
-                       partial_half);
-    hipLaunchKernelGGL(segment_flags_kernel, dim3(m->num_segments, B), dim3(kSegFusedBlock), 0, s, verts, body_flags, exterior,
+    hipLaunchKernelGGL(segment_one_kernel, dim3(m->num_segments, B, kSegOneZ), dim3(kSegOneBlock), 0, s, verts, body_flags, exterior,
                        (const int32_t*)m->seg_q_off, (const int32_t*)m->seg_q_vidx, (const int32_t*)m->seg_cap_range,
-                       (const int32_t*)m->cap_off, (const int32_t*)m->cap_vidx, (const int32_t*)m->seg_link_off,
-                       (const int32_t*)m->seg_link, (const int32_t*)seg_partial, (const float*)partial_half, leaf_counts,
-                       (const int32_t*)m->seg_vpos, 2 * m->tree_qblocks * kRayQueries, m->V, m->seg_q_total, thresh);
-    return tuch_check_launch("tuch_ray_segment_flags_fused");
+                       (const int32_t*)m->cap_off, (const int32_t*)m->cap_vidx, (const int32_t*)m->seg_cap_off,
+                       (const int32_t*)m->seg_cap_ent, (const int32_t*)m->seg_link_off, (const int32_t*)m->seg_link, leaf_counts,
+                       (const int32_t*)m->seg_vpos, 2 * m->tree_qblocks * kRayQueries, m->V, thresh);
+    return tuch_check_launch("tuch_ray_segment_flags_one");
 }
 
 bool tuch_ray_available(const tuch_contact_model* m)

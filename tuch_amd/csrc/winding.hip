@@ -1047,8 +1047,8 @@ extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* ver
         if (rc != TUCH_OK) return rc;
     }
     if (segments_fused) {
-        rc = tuch_ray_segment_flags_fused(m, verts, (const uint8_t*)(ws + l.body_flags), tuch_ray_segment_counts(m, B, ws + l.ray),
-                                          B, thresh, (int32_t*)(ws + l.seg_partial), exterior, s);
+        rc = tuch_ray_segment_flags_one(m, verts, (const uint8_t*)(ws + l.body_flags), tuch_ray_segment_counts(m, B, ws + l.ray), B, thresh,
+                                        exterior, s);
         if (rc != TUCH_OK) return rc;
     } else if (segments) {
         float* caps = (float*)(ws + l.caps);
