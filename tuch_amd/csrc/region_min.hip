@@ -6,11 +6,10 @@
 // per region pair in a Python loop over all P pairs ("Speed up this function will
 // speed up training loop!", :74).
 //
-// One wavefront per (body, pair, 64 rows of the first region).  The second region's vertices
-// are staged in LDS and read by all lanes at the same address (broadcast, conflict-free); every
-// lane owns one vertex of the first region; the minimum and its (i, j) are found with a wavefront
-// shuffle reduction on (d2, flat index) keys and merged across wavefronts with a 64-bit atomicMin,
-// so that ties resolve to the first flat index like torch.min / argmin.
+// One workgroup per (body, pair).  The second region's vertices are staged in LDS and read by all lanes at the
+// same address (broadcast, conflict-free); every lane owns one vertex of the first region (64-row blocks dealt to
+// the wavefronts); the minimum and its (i, j) are found with a wavefront shuffle reduction on (d2, flat index)
+// keys, so that ties resolve to the first flat index like torch.min / argmin.
 // Distances are direct differences (DESIGN.md "Parity").
 #include "common.h"
 #include "model.h"
@@ -30,11 +29,11 @@ __device__ __forceinline__ Best better(Best x, Best y)
     return (y.d < x.d || (y.d == x.d && y.idx < x.idx)) ? y : x;
 }
 
-// One wavefront per (body, pair, 64 rows of the first region): unselected pairs leave at once, the
-// selected ones spread over the whole chip (the SMPLify use selects ~10 of ~280 pairs per body;
-// contact_from_verts, train_module.py:69-91, takes all pairs, unmasked).
+// FEW pairs selected (the SMPLify use: ~5 of ~180 per body): one wavefront per (body, pair, 64 rows of the first region) --
+// unselected pairs leave at once, the selected ones spread over the whole chip (a pair of 500-vertex regions is ~50 k
+// wavefront instructions: as one workgroup of four wavefronts it takes 30 us, as nine one-wave workgroups 13).
 template <bool kMasked, bool kInverted>
-__global__ __launch_bounds__(64) void region_pair_min_kernel(
+__global__ __launch_bounds__(64) void region_pair_rows_kernel(
     const float* __restrict__ verts, const int32_t* __restrict__ region_off,
     const int32_t* __restrict__ region_vidx, const int32_t* __restrict__ pairs,
     const uint8_t* __restrict__ select,        // [B,P] or nullptr (= all)
@@ -106,6 +105,120 @@ __global__ __launch_bounds__(64) void region_pair_min_kernel(
     }
 }
 
+// ALL pairs (contact_from_verts, train_module.py:69-91: select == NULL): one workgroup of four wavefronts per (body, pair).  The second region is staged in
+// LDS ONCE per pair, the wavefronts take the 64-row blocks of the first region in turn, their minima meet in LDS: one
+// owner per key, no atomic (251 -> 188 us for the 182 x 64 pairs of the bench's batch: the row-block form stages the second
+// region once per 64 rows).
+constexpr int kPairWaves = 4;
+template <bool kMasked, bool kInverted>
+__global__ __launch_bounds__(64 * kPairWaves) void region_pair_min_kernel(
+    const float* __restrict__ verts, const int32_t* __restrict__ region_off,
+    const int32_t* __restrict__ region_vidx, const int32_t* __restrict__ pairs,
+    const uint8_t* __restrict__ select,        // [B,P] or nullptr (= all)
+    const uint32_t* __restrict__ pair_mask,    // per-pair geomask blocks (kMasked)
+    const int64_t* __restrict__ pair_mask_off,
+    int V, int P, unsigned long long* __restrict__ keys)   // [B,P], preset to all ones (kInverted: to zero, the key stored
+                                                           // complemented: 0 = no candidate)
+{
+    __shared__ __attribute__((aligned(16))) float sx[kTile], sy[kTile], sz[kTile];
+    __shared__ float s_best[kPairWaves];
+    __shared__ int s_idx[kPairWaves];
+    const int b = blockIdx.x, p = blockIdx.y;
+    const size_t o = (size_t)b * P + p;
+    if (select && !select[o]) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r1 = pairs[2 * p], r2 = pairs[2 * p + 1];
+    const int a_beg = region_off[r1], n1 = region_off[r1 + 1] - a_beg;
+    const int b_beg = region_off[r2], n2 = region_off[r2 + 1] - b_beg;
+    const float* vb = verts + (size_t)b * V * 3;
+    const int wpr = (n2 + 31) / 32;
+    const float inf = __builtin_inff();
+    Best r = {inf, 0x7fffffff};
+    // the rows of the first region: block z = wave, wave + 4, ... ; rows and columns ascend, so within a lane the first
+    // minimum (strict '<') is the one with the smallest flat index
+    const int zblocks = (n1 + 63) / 64;
+    for (int z0 = 0; z0 < zblocks; z0 += kPairWaves) {
+        const int z = z0 + wave;
+        const bool have = z < zblocks;
+        const int a = z * 64 + lane;                               // this lane's row of the first region
+        const int i = region_vidx[a_beg + min(have ? a : 0, n1 - 1)];
+        const float px = vb[3 * i], py = vb[3 * i + 1], pz = vb[3 * i + 2];
+        const uint32_t* mrow = kMasked ? pair_mask + pair_mask_off[p] + (size_t)min(have ? a : 0, n1 - 1) * wpr : nullptr;
+        // the row's mask words, all requested before the first column is looked at (one per 32 columns inside the loop was a
+        // dependent global load each time round: ~1 us x 9 per row block)
+        constexpr int kWords = 16;
+        uint32_t mw[kWords];
+        if (kMasked && wpr <= kWords) {
+#pragma unroll
+            for (int u = 0; u < kWords; ++u) mw[u] = u < wpr ? mrow[u] : 0u;
+        }
+        float best = inf;
+        int best_k = -1;                                            // column of the second region
+        auto column = [&](int k, float x, float y, float z2, bool allowed) {
+            const float dx = px - x, dy = py - y, dz = pz - z2;
+            float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            if (kMasked && !allowed) d = inf;
+            if (d < best) { best = d; best_k = k; }
+        };
+        for (int t0 = 0; t0 < n2; t0 += kTile) {
+            const int tn = min(kTile, n2 - t0);
+            if (z0 == 0 || n2 > kTile) {                            // (a region that fits one tile is staged once)
+                __syncthreads();
+                for (int k = threadIdx.x; k < tn; k += 64 * kPairWaves) {
+                    const int v = region_vidx[b_beg + t0 + k];
+                    sx[k] = vb[3 * v]; sy[k] = vb[3 * v + 1]; sz[k] = vb[3 * v + 2];
+                }
+                __syncthreads();
+            }
+            if (have && a < n1)
+                for (int g = 0; g < tn; g += 32) {
+                    uint32_t word = 0xffffffffu;
+                    if (kMasked) {
+                        if (wpr <= kWords) {
+                            const int wi = (t0 + g) >> 5;
+#pragma unroll
+                            for (int u = 0; u < kWords; ++u) word = u == wi ? mw[u] : word;      // (no dynamic register index)
+                        } else {
+                            word = mrow[(t0 + g) >> 5];
+                        }
+                    }
+                    const int gn = min(32, tn - g);
+                    int kk = 0;
+                    for (; kk + 4 <= gn; kk += 4) {               // four columns per LDS read (b128 broadcasts)
+                        const float4 x4 = *(const float4*)&sx[g + kk];
+                        const float4 y4 = *(const float4*)&sy[g + kk];
+                        const float4 z4 = *(const float4*)&sz[g + kk];
+                        column(t0 + g + kk + 0, x4.x, y4.x, z4.x, (word >> (kk + 0)) & 1);
+                        column(t0 + g + kk + 1, x4.y, y4.y, z4.y, (word >> (kk + 1)) & 1);
+                        column(t0 + g + kk + 2, x4.z, y4.z, z4.z, (word >> (kk + 2)) & 1);
+                        column(t0 + g + kk + 3, x4.w, y4.w, z4.w, (word >> (kk + 3)) & 1);
+                    }
+                    for (; kk < gn; ++kk) column(t0 + g + kk, sx[g + kk], sy[g + kk], sz[g + kk], (word >> kk) & 1);
+                }
+        }
+        const Best mine = {best, best_k >= 0 ? a * n2 + best_k : 0x7fffffff};
+        r = better(r, mine);
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        Best other = {__shfl_down(r.d, s, 64), __shfl_down(r.idx, s, 64)};
+        r = better(r, other);
+    }
+    if (lane == 0) { s_best[wave] = r.d; s_idx[wave] = r.idx; }
+    __syncthreads();
+    // d >= 0, so the float's bit pattern orders like the value: (d, flat index) packs into one 64-bit key; ties resolve
+    // to the first flat index like torch.min / argmin
+    if (threadIdx.x == 0) {
+        Best t = {s_best[0], s_idx[0]};
+#pragma unroll
+        for (int w = 1; w < kPairWaves; ++w) t = better(t, Best{s_best[w], s_idx[w]});
+        if (t.idx != 0x7fffffff) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(t.d) << 32) | (unsigned int)t.idx;
+            keys[o] = kInverted ? ~key : key;
+        }
+    }
+}
+
 // keys -> (min d2, arg-min vertex ids); unselected / empty pairs give 0 and (-1, -1).  The keys
 // live in the storage of out_ij and are overwritten in place.
 __global__ __launch_bounds__(kBlock) void region_pair_finalize_kernel(
@@ -167,15 +280,27 @@ extern "C" int tuch_region_pair_min(const tuch_contact_model* m, const float* ve
         tuch_set_error("tuch_region_pair_min: hipMemsetAsync failed");
         return TUCH_ERR_HIP;
     }
-    const dim3 grid(B, m->num_pairs, ceil_div(m->region_max, 64));
+    if (select) {       // few pairs: a wavefront per 64 rows
+        const dim3 rgrid(B, m->num_pairs, ceil_div(m->region_max, 64));
+        if (use_geomask)
+            hipLaunchKernelGGL((region_pair_rows_kernel<true, false>), rgrid, dim3(64), 0, s, verts, (const int32_t*)m->region_off,
+                               (const int32_t*)m->region_vidx, (const int32_t*)m->pairs, select, (const uint32_t*)m->pair_mask,
+                               (const int64_t*)m->pair_mask_off, m->V, m->num_pairs, (unsigned long long*)out_ij);
+        else
+            hipLaunchKernelGGL((region_pair_rows_kernel<false, false>), rgrid, dim3(64), 0, s, verts, (const int32_t*)m->region_off,
+                               (const int32_t*)m->region_vidx, (const int32_t*)m->pairs, select, (const uint32_t*)nullptr,
+                               (const int64_t*)nullptr, m->V, m->num_pairs, (unsigned long long*)out_ij);
+    } else {
+    const dim3 grid(B, m->num_pairs);
     if (use_geomask)
-        hipLaunchKernelGGL((region_pair_min_kernel<true, false>), grid, dim3(64), 0, s, verts, (const int32_t*)m->region_off,
+        hipLaunchKernelGGL((region_pair_min_kernel<true, false>), grid, dim3(64 * kPairWaves), 0, s, verts, (const int32_t*)m->region_off,
                            (const int32_t*)m->region_vidx, (const int32_t*)m->pairs, select, (const uint32_t*)m->pair_mask,
                            (const int64_t*)m->pair_mask_off, m->V, m->num_pairs, (unsigned long long*)out_ij);
     else
-        hipLaunchKernelGGL((region_pair_min_kernel<false, false>), grid, dim3(64), 0, s, verts, (const int32_t*)m->region_off,
+        hipLaunchKernelGGL((region_pair_min_kernel<false, false>), grid, dim3(64 * kPairWaves), 0, s, verts, (const int32_t*)m->region_off,
                            (const int32_t*)m->region_vidx, (const int32_t*)m->pairs, select, (const uint32_t*)nullptr,
                            (const int64_t*)nullptr, m->V, m->num_pairs, (unsigned long long*)out_ij);
+    }
     hipLaunchKernelGGL(region_pair_finalize_kernel, dim3(ceil_div(m->num_pairs, kBlock), B), dim3(kBlock), 0, s,
                        (const int32_t*)m->region_off, (const int32_t*)m->region_vidx, (const int32_t*)m->pairs,
                        m->num_pairs, out_min, out_ij);
@@ -194,13 +319,25 @@ extern "C" int tuch_region_pair_keys(const tuch_contact_model* m, const float* v
     TUCH_REQUIRE(m->num_pairs > 0, "tuch_region_pair_keys: model has no region pairs");
     TUCH_REQUIRE(!use_geomask || m->pair_mask, "tuch_region_pair_keys: model has no geodesic mask");
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid(B, m->num_pairs, ceil_div(m->region_max, 64));
+    if (select) {
+        const dim3 rgrid(B, m->num_pairs, ceil_div(m->region_max, 64));
+        if (use_geomask)
+            hipLaunchKernelGGL((region_pair_rows_kernel<true, true>), rgrid, dim3(64), 0, s, verts, (const int32_t*)m->region_off,
+                               (const int32_t*)m->region_vidx, (const int32_t*)m->pairs, select, (const uint32_t*)m->pair_mask,
+                               (const int64_t*)m->pair_mask_off, m->V, m->num_pairs, (unsigned long long*)keys_zeroed);
+        else
+            hipLaunchKernelGGL((region_pair_rows_kernel<false, true>), rgrid, dim3(64), 0, s, verts, (const int32_t*)m->region_off,
+                               (const int32_t*)m->region_vidx, (const int32_t*)m->pairs, select, (const uint32_t*)nullptr,
+                               (const int64_t*)nullptr, m->V, m->num_pairs, (unsigned long long*)keys_zeroed);
+        return tuch_check_launch("tuch_region_pair_keys");
+    }
+    const dim3 grid(B, m->num_pairs);
     if (use_geomask)
-        hipLaunchKernelGGL((region_pair_min_kernel<true, true>), grid, dim3(64), 0, s, verts, (const int32_t*)m->region_off,
+        hipLaunchKernelGGL((region_pair_min_kernel<true, true>), grid, dim3(64 * kPairWaves), 0, s, verts, (const int32_t*)m->region_off,
                            (const int32_t*)m->region_vidx, (const int32_t*)m->pairs, select, (const uint32_t*)m->pair_mask,
                            (const int64_t*)m->pair_mask_off, m->V, m->num_pairs, (unsigned long long*)keys_zeroed);
     else
-        hipLaunchKernelGGL((region_pair_min_kernel<false, true>), grid, dim3(64), 0, s, verts, (const int32_t*)m->region_off,
+        hipLaunchKernelGGL((region_pair_min_kernel<false, true>), grid, dim3(64 * kPairWaves), 0, s, verts, (const int32_t*)m->region_off,
                            (const int32_t*)m->region_vidx, (const int32_t*)m->pairs, select, (const uint32_t*)nullptr,
                            (const int64_t*)nullptr, m->V, m->num_pairs, (unsigned long long*)keys_zeroed);
     return tuch_check_launch("tuch_region_pair_keys");
