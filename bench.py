@@ -14,10 +14,14 @@ SURVEY 8(e) / north_star name (64/N bodies per GPU; the weak-scaling figure, 64 
 reported as `weak_scaling`; --weak makes it the headline, --global-batch G picks another total).  The fits of different bodies never exchange data, so there is no collective inside
 the loop: the two floats [sum of losses, body count] are all-reduced (RCCL) once per timed block of K steps.
 Rank 0 prints ONE JSON line (contract in the task description) including
-  roofline     -- dominant kernel of the step (the masked vertex-distance search, v2v_tree_kernel), achieved FLOP/s in
-                  SURVEY 8(d)'s unit measured here with HIP events; valu_busy / traffic parsed from the PMC summaries
-                  committed under profiles/ (the newest round's files)
+  roofline     -- dominant kernel of the step (the masked vertex-distance search, v2v_scan_kernel): `frac` = EXECUTED vector
+                  work (SQ_INSTS_VALU of the committed PMC pass x 64 lanes x 2 / launch time measured here with HIP events /
+                  FP32 vector peak); `equivalent_frac` = SURVEY 8(d)'s all-pairs figure (most pairs are pruned); valu_busy /
+                  traffic parsed from the PMC summaries committed under profiles/ (the newest round's files)
   roofline_inside_test -- the second kernel group (inside test by ray crossings): executed operations per launch
+  step_equivalent_x_peak -- the whole step priced in SURVEY 8(d)'s pair units over the FP32 vector peak (> 1: pruning)
+  weak_scaling -- N > 1 only: the same step with 64 bodies on every rank (the headline of N > 1 is strong scaling at
+                  global batch 64)
   cpu_baseline -- the CPU oracle (test infrastructure) timed on this box's host cores, rank 0, N=1
   selfcheck    -- after the timed blocks: the objective the replayed graph reports against an eager evaluation at the
                   same parameters, and two sampled bodies of that state against the CPU oracle
@@ -502,7 +506,7 @@ def rooflines(p, batch):
     tree = model.winding_tree_work(verts)
     tree_steps = tree['leaf_elements'] + tree['cap_elements']
     prof_r = prof['ray_leaf_kernel']
-    inside = {'kernel': 'ray_leaf_kernel (+ ray_stream, ray_leaf_bounds, ray_near, ray_tiles, ray_fill, ray_finalize_verts)',
+    inside = {'kernel': 'ray_leaf_kernel (+ ray_leaf_bounds, ray_near, ray_tiles_fill, ray_finalize_verts)',
               'bound': 'valu', 'achieved': round(ach, 2), 'peak': PEAK_FP32_VECTOR_TFLOPS, 'unit': 'TFLOP/s',
               'frac': round(ach / PEAK_FP32_VECTOR_TFLOPS, 4),
               'frac_formula': '21 executed FP32 operations x 64 rays x element steps (counted by tuch_ray_work on this input) '
