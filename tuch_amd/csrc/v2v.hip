@@ -46,6 +46,15 @@ __device__ __forceinline__ float min4_raw(float a, float b, float c, float d)
     return r;
 }
 
+// minimum of eight such distances: four instructions
+__device__ __forceinline__ float min8_raw(const float* d)
+{
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3\n\tv_min3_f32 %0, %0, %4, %5\n\tv_min3_f32 %0, %0, %6, %7\n\tv_min_f32_e32 %0, %0, %8"
+        : "=&v"(r) : "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4]), "v"(d[5]), "v"(d[6]), "v"(d[7]));
+    return r;
+}
+
 __device__ __forceinline__ uint64_t uniform64(uint64_t x)
 {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x);
@@ -368,6 +377,26 @@ __global__ __launch_bounds__(64 * kIndexedWaves) void v2v_indexed_kernel(
 constexpr int kTreeCols = 64;
 constexpr float kPruneSlack = 0.999999f;      // lower bounds are deflated by 1e-6: rounding of the two sums
 
+#ifdef TUCH_SCAN_COUNTS
+// diagnostic build only (tools/diag/scan_counts.py builds a second library with -DTUCH_SCAN_COUNTS): where the scan's
+// instructions go.  [0] wavefronts, [1] leaf-per-lane trips, [2] candidate leaves (box against box), [3] leaves that reach
+// their rows (per-column test), [4] trips of eight rows, [5] of them skipped by the mask words, [6] of them taking the
+// update branch, [7] trips of four, [8] skipped, [9] taking, [10] wavefronts that return at once (no admissible row)
+__device__ unsigned long long g_scan_counts[16];
+#define SCAN_COUNT(i) do { if (threadIdx.x == 0) atomicAdd(&g_scan_counts[i], 1ull); } while (0)
+extern "C" int tuch_debug_scan_counts(unsigned long long* out, int reset)
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scan_counts), sizeof(unsigned long long) * 16) != hipSuccess) return TUCH_ERR_HIP;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_scan_counts), z, sizeof(z)) != hipSuccess) return TUCH_ERR_HIP;
+    }
+    return TUCH_OK;
+}
+#else
+#define SCAN_COUNT(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ uint64_t v2v_key(float d, int j)
 {
     return ((uint64_t)__float_as_uint(d) << 32) | (uint32_t)j;
@@ -565,7 +594,8 @@ __device__ __forceinline__ void v2v_rows_packed(Column& c, const float* __restri
 #pragma unroll
         for (int u = 0; u < 24; ++u) v[u] = pg[u];
         asm volatile("" :: "s"(v[0]), "s"(v[8]), "s"(v[16]));
-        if (((k0[0] | k0[1] | k0[2] | k0[3] | k0[4] | k0[5] | k0[6] | k0[7]) & reach) == 0) continue;
+        SCAN_COUNT(4);
+        if (((k0[0] | k0[1] | k0[2] | k0[3] | k0[4] | k0[5] | k0[6] | k0[7]) & reach) == 0) { SCAN_COUNT(5); continue; }
         const v2f d01 = dist2(v[0], v[1], v[4], v[5], v[8], v[9]), d23 = dist2(v[2], v[3], v[6], v[7], v[10], v[11]);
         const v2f d45 = dist2(v[12], v[13], v[16], v[17], v[20], v[21]), d67 = dist2(v[14], v[15], v[18], v[19], v[22], v[23]);
         float d[8];
@@ -573,13 +603,18 @@ __device__ __forceinline__ void v2v_rows_packed(Column& c, const float* __restri
         d[2] = select_by_lane_mask(inf, d23.x, k0[2]); d[3] = select_by_lane_mask(inf, d23.y, k0[3]);
         d[4] = select_by_lane_mask(inf, d45.x, k0[4]); d[5] = select_by_lane_mask(inf, d45.y, k0[5]);
         d[6] = select_by_lane_mask(inf, d67.x, k0[6]); d[7] = select_by_lane_mask(inf, d67.y, k0[7]);
-        const float m = __builtin_fminf(min4_raw(d[0], d[1], d[2], d[3]), min4_raw(d[4], d[5], d[6], d[7]));
-        if (__builtin_amdgcn_ballot_w64(m <= c.best)) {
+        const float m = min8_raw(d);
+        if (__builtin_amdgcn_ballot_w64(m <= c.best)) {                       // rare once the bounds have settled
+            SCAN_COUNT(6);
+            // the eight updates in row order amount to ONE with (m, first row attaining m): ties go to the smaller row
+            int first = 7;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) take(j + u, d[u]);                     // in row order: ties go to the smaller row
+            for (int u = 6; u >= 0; --u) first = d[u] == m ? u : first;
+            take(j + first, m);
         }
     }
     if (g < ngroups) {
+        SCAN_COUNT(7);
         uint64_t k0[4];
         float v[12];
 #pragma unroll
@@ -587,15 +622,18 @@ __device__ __forceinline__ void v2v_rows_packed(Column& c, const float* __restri
 #pragma unroll
         for (int u = 0; u < 12; ++u) v[u] = pg[u];
         asm volatile("" :: "s"(v[0]), "s"(v[4]), "s"(v[8]));
-        if (((k0[0] | k0[1] | k0[2] | k0[3]) & reach) == 0) return;
+        if (((k0[0] | k0[1] | k0[2] | k0[3]) & reach) == 0) { SCAN_COUNT(8); return; }
         const v2f d01 = dist2(v[0], v[1], v[4], v[5], v[8], v[9]), d23 = dist2(v[2], v[3], v[6], v[7], v[10], v[11]);
         float d[4];
         d[0] = select_by_lane_mask(inf, d01.x, k0[0]); d[1] = select_by_lane_mask(inf, d01.y, k0[1]);
         d[2] = select_by_lane_mask(inf, d23.x, k0[2]); d[3] = select_by_lane_mask(inf, d23.y, k0[3]);
         const float m = min4_raw(d[0], d[1], d[2], d[3]);
         if (__builtin_amdgcn_ballot_w64(m <= c.best)) {
+            SCAN_COUNT(9);
+            int first = 3;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) take(j + u, d[u]);
+            for (int u = 2; u >= 0; --u) first = d[u] == m ? u : first;
+            take(j + first, m);
         }
     }
 }
@@ -884,10 +922,20 @@ __device__ __forceinline__ void v2v_scan_body(
     const int first = __builtin_amdgcn_readfirstlane(sub_leaf[2 * sub]), count = __builtin_amdgcn_readfirstlane(sub_leaf[2 * sub + 1]);
     // the largest bound among the columns that have an allowed row below this subtree at all
     const uint64_t alive = masked[(size_t)qb * N + __builtin_amdgcn_readfirstlane(frontier[sub])];
-    if (alive == 0) return;
+    SCAN_COUNT(0);
+    if (alive == 0) { SCAN_COUNT(10); return; }
+    // lower bounds are compared as g <= bound * (1 + 1e-6): the slack of kPruneSlack on the side that changes rarely
+    constexpr float kBoundSlack = 1.000001f;
     float reach2 = ((alive >> lane) & 1) ? c.best : 0.0f;
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) reach2 = fmaxf(reach2, __shfl_xor(reach2, m));
+    reach2 *= kBoundSlack;
+    float best_s = c.best * kBoundSlack;
+    // the boxes of a trip's 64 leaves, for the per-column test of the candidates among them: a candidate's box is one
+    // broadcast read of LDS (two 16-byte reads) instead of six v_readlane + three v_mov (one scalar operand per vector
+    // instruction) -- the per-column test is a third of this kernel's vector instructions (tools/diag/scan_counts.py: 21
+    // candidates per wavefront, 6 of them reach their rows)
+    __shared__ float4 leaf_lo[64], leaf_hi[64];
     const float* cbx = colbox + ((size_t)b * (Vp / kTreeCols) + qb) * 8;
     const float clx = cbx[0], cly = cbx[1], clz = cbx[2], chx = cbx[4], chy = cbx[5], chz = cbx[6];
     const float* lb = leafbox + ((size_t)b * L + first) * 8;
@@ -896,6 +944,7 @@ __device__ __forceinline__ void v2v_scan_body(
         // one leaf per lane: the gap between its box and the block's, against the largest bound
         const int li = base + lane;
         bool cand = false;
+        SCAN_COUNT(1);
         float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;   // box; lo.w = first group, hi.w = row range of the leaf
         uint64_t lanes_of = 0;
         if (li < count) {
@@ -905,28 +954,57 @@ __device__ __forceinline__ void v2v_scan_body(
             const float ex = fmaxf(fmaxf(lo.x - chx, clx - hi.x), 0.0f);
             const float ey = fmaxf(fmaxf(lo.y - chy, cly - hi.y), 0.0f);
             const float ez = fmaxf(fmaxf(lo.z - chz, clz - hi.z), 0.0f);
-            const float g = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) * kPruneSlack;
+            const float g = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
             cand = g <= reach2 && (lanes_of & alive) != 0;
+#ifdef TUCH_SCAN_COUNTS
+            // what a first-level test against sub-blocks of 16 / 8 columns (own box, own largest bound) would let through
+            if (cand) {
+                bool any16 = false, any8 = false;
+                for (int w = 8; w <= 16; w += 8)
+                    for (int s0 = 0; s0 < 64; s0 += w) {
+                        float bl[3] = {3e38f, 3e38f, 3e38f}, bh[3] = {-3e38f, -3e38f, -3e38f}, bb = 0.0f;
+                        bool live = false;
+                        for (int t = s0; t < s0 + w; ++t) {
+                            const float* q = pb + 3 * (size_t)(qb * kTreeCols + t);
+                            for (int k = 0; k < 3; ++k) { bl[k] = fminf(bl[k], q[k]); bh[k] = fmaxf(bh[k], q[k]); }
+                            if ((alive >> t) & (lanes_of >> t) & 1) {
+                                live = true;
+                                bb = fmaxf(bb, __uint_as_float((uint32_t)(__hip_atomic_load(kb + qb * kTreeCols + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32)));
+                            }
+                        }
+                        const float fx = fmaxf(fmaxf(lo.x - bh[0], bl[0] - hi.x), 0.0f);
+                        const float fy = fmaxf(fmaxf(lo.y - bh[1], bl[1] - hi.y), 0.0f);
+                        const float fz = fmaxf(fmaxf(lo.z - bh[2], bl[2] - hi.z), 0.0f);
+                        const bool pass = live && (fx * fx + fy * fy + fz * fz) * kPruneSlack <= bb;
+                        if (w == 16) any16 |= pass; else any8 |= pass;
+                    }
+                if (any16) atomicAdd(&g_scan_counts[11], 1ull);
+                if (any8) atomicAdd(&g_scan_counts[12], 1ull);
+            }
+#endif
         }
         unsigned long long todo = __builtin_amdgcn_ballot_w64(cand);
+        if (todo == 0) continue;
+        leaf_lo[lane] = lo;                      // one wavefront per workgroup: LDS operations of a wavefront stay in order
+        leaf_hi[lane] = hi;
         while (todo) {
             const int u = __builtin_ctzll(todo);
             todo &= todo - 1;
-            // the candidate's record from the lane that tested it: ten v_readlane instead of two scalar loads behind eight
-            // scalar instructions of address arithmetic -- the vector units have slack since the rows are packed, the
-            // scalar unit and the scalar-memory latencies on each wavefront's chain are what this kernel waits for
-            auto from = [&](float x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), u)); };
-            const float b0 = from(lo.x), b1 = from(lo.y), b2 = from(lo.z), b4 = from(hi.x), b5 = from(hi.y), b6 = from(hi.z);
+            SCAN_COUNT(2);
+            const float4 blo = leaf_lo[u], bhi = leaf_hi[u];
             const uint64_t lanes = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(lanes_of >> 32), u) << 32) |
                                    (uint32_t)__builtin_amdgcn_readlane((int)lanes_of, u);
-            const float dx = c.px - __builtin_amdgcn_fmed3f(c.px, b0, b4);
-            const float dy = c.py - __builtin_amdgcn_fmed3f(c.py, b1, b5);
-            const float dz = c.pz - __builtin_amdgcn_fmed3f(c.pz, b2, b6);
-            const float g = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) * kPruneSlack;
-            const uint64_t reach = __builtin_amdgcn_ballot_w64(g <= c.best) & lanes;
+            const float dx = c.px - __builtin_amdgcn_fmed3f(c.px, blo.x, bhi.x);
+            const float dy = c.py - __builtin_amdgcn_fmed3f(c.py, blo.y, bhi.y);
+            const float dz = c.pz - __builtin_amdgcn_fmed3f(c.pz, blo.z, bhi.z);
+            const float g = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            const uint64_t reach = __builtin_amdgcn_ballot_w64(g <= best_s) & lanes;
             if (reach) {
-                const int leaf = __float_as_int(from(hi.w)), g0 = __float_as_int(from(lo.w));
+                SCAN_COUNT(3);
+                const int leaf = __builtin_amdgcn_readfirstlane(__float_as_int(bhi.w));
+                const int g0 = __builtin_amdgcn_readfirstlane(__float_as_int(blo.w));
                 v2v_rows_packed(c, pg + (size_t)g0 * 12, mg + (size_t)g0 * 4, leaf & 0xfffff, ((leaf >> 20) + 3) >> 2, reach);
+                best_s = c.best * kBoundSlack;
             }
         }
     }
