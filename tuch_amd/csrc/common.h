@@ -25,6 +25,31 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 static __device__ __forceinline__ v2f splat2(float x) { return (v2f){x, x}; }
 static __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
+// Maximum / minimum over the 64 lanes of a wavefront, wave-uniform (a scalar register): six v_max/min_f32_dpp (quad swaps,
+// the two row mirrors, then row_bcast15 / row_bcast31 into the later rows) and one v_readlane of lane 63 -- no trip
+// through the LDS crossbar (a __shfl_xor butterfly is six dependent ds_bpermute round trips and ~45 instructions).  No
+// operand may be a NaN.  The s_nop are the two wait states a DPP read of a just-written register needs (inline assembly
+// is not seen by the hazard recogniser).
+#define TUCH_WAVE_REDUCE(op)                                                                           \
+    asm("s_nop 1\n\t"                                                                                 \
+        op " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                \
+        op " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                \
+        op " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                    \
+        op " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                         \
+        op " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"                       \
+        op " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"                            \
+        : "+v"(v))
+static __device__ __forceinline__ float wave_max_uniform(float v)
+{
+    TUCH_WAVE_REDUCE("v_max_f32_dpp");
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+static __device__ __forceinline__ float wave_min_uniform(float v)
+{
+    TUCH_WAVE_REDUCE("v_min_f32_dpp");
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // Model constants: device memory, or host memory under TUCH_HOST_TABLES=1 (api.hip: sanitizer runs of the table builders)

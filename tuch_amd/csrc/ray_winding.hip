@@ -339,18 +339,8 @@ __device__ __forceinline__ void ray_run(const RayElem* __restrict__ st, const in
 // descent: with ~215 leaves the flat test is four rounds of 64 lanes, and nothing in it waits on a parent's verdict.
 constexpr int kFallbackChunks = 8;            // wavefronts per query block when a body falls back to block-major order
 
-__device__ __forceinline__ float wave_min(float v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m));
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
-    return v;
-}
+__device__ __forceinline__ float wave_min(float v) { return wave_min_uniform(v); }      // common.h: DPP, no LDS trips
+__device__ __forceinline__ float wave_max(float v) { return wave_max_uniform(v); }
 
 // One (query block, leaf) the block has to visit: which of its 64 rays pass the leaf's slabs.
 struct RayEntry { int32_t leaf, node; uint32_t mask_lo, mask_hi; };

@@ -585,16 +585,26 @@ __device__ __forceinline__ void v2v_rows_packed(Column& c, const float* __restri
     auto take = [&](int j, float d) {
         if (d < c.best || (d == c.best && d < inf && j < c.arg)) { c.best = d; c.arg = j; }
     };
-    int g = 0, j = j0;
-    for (; g + 2 <= ngroups; g += 2, j += 8, mg += 8, pg += 24) {
+    // ONE induction variable (the byte offset into the mask words; the rows' is 3/2 of it): the scalar unit issues as many
+    // instructions in this loop as the vector units, and four running 64-bit quantities cost it eleven per trip
+    const char* mb = reinterpret_cast<const char*>(mg);
+    const char* pb = reinterpret_cast<const char*>(pg);
+    uint32_t om = 0;
+    const uint32_t om_end = (uint32_t)(ngroups >> 1) * 64u;
+    for (; om < om_end; om += 64u) {
+        asm("" : "+s"(om));                      // opaque: keeps the loop optimiser from splitting it into three again
+        const uint64_t* mgo = reinterpret_cast<const uint64_t*>(mb + om);
+        const float* pgo = reinterpret_cast<const float*>(pb + (om + (om >> 1)));
         uint64_t k0[8];
         float v[24];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) k0[u] = mg[u];
+        for (int u = 0; u < 8; ++u) k0[u] = mgo[u];
 #pragma unroll
-        for (int u = 0; u < 24; ++u) v[u] = pg[u];
+        for (int u = 0; u < 24; ++u) v[u] = pgo[u];
         asm volatile("" :: "s"(v[0]), "s"(v[8]), "s"(v[16]));
         SCAN_COUNT(4);
+        // (without this test -- nine scalar instructions per trip against 37 vector instructions for one trip in eight --
+        // the kernel takes the same time: 129.5 against 127.8 us)
         if (((k0[0] | k0[1] | k0[2] | k0[3] | k0[4] | k0[5] | k0[6] | k0[7]) & reach) == 0) { SCAN_COUNT(5); continue; }
         const v2f d01 = dist2(v[0], v[1], v[4], v[5], v[8], v[9]), d23 = dist2(v[2], v[3], v[6], v[7], v[10], v[11]);
         const v2f d45 = dist2(v[12], v[13], v[16], v[17], v[20], v[21]), d67 = dist2(v[14], v[15], v[18], v[19], v[22], v[23]);
@@ -610,17 +620,19 @@ __device__ __forceinline__ void v2v_rows_packed(Column& c, const float* __restri
             int first = 7;
 #pragma unroll
             for (int u = 6; u >= 0; --u) first = d[u] == m ? u : first;
-            take(j + first, m);
+            take(j0 + (int)(om >> 3) + first, m);
         }
     }
-    if (g < ngroups) {
+    if (ngroups & 1) {
         SCAN_COUNT(7);
+        const uint64_t* mgo = reinterpret_cast<const uint64_t*>(mb + om);
+        const float* pgo = reinterpret_cast<const float*>(pb + (om + (om >> 1)));
         uint64_t k0[4];
         float v[12];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) k0[u] = mg[u];
+        for (int u = 0; u < 4; ++u) k0[u] = mgo[u];
 #pragma unroll
-        for (int u = 0; u < 12; ++u) v[u] = pg[u];
+        for (int u = 0; u < 12; ++u) v[u] = pgo[u];
         asm volatile("" :: "s"(v[0]), "s"(v[4]), "s"(v[8]));
         if (((k0[0] | k0[1] | k0[2] | k0[3]) & reach) == 0) { SCAN_COUNT(8); return; }
         const v2f d01 = dist2(v[0], v[1], v[4], v[5], v[8], v[9]), d23 = dist2(v[2], v[3], v[6], v[7], v[10], v[11]);
@@ -633,7 +645,7 @@ __device__ __forceinline__ void v2v_rows_packed(Column& c, const float* __restri
             int first = 3;
 #pragma unroll
             for (int u = 2; u >= 0; --u) first = d[u] == m ? u : first;
-            take(j + first, m);
+            take(j0 + (int)(om >> 3) + first, m);
         }
     }
 }
@@ -815,24 +827,12 @@ __global__ __launch_bounds__(kBoundsBlock) void v2v_rows_seed_kernel(
         arg = j;
     }
     keys[(size_t)b * Vp + i0] = v2v_key(best, arg);
-    // boxes of the block's columns (and of its four 16-row tiles for the matrix-core form), rows behind the last vertex left out
+    // box of the block's columns, rows behind the last vertex left out
     const bool real = i0 < V;
     const float inf = __builtin_inff();
     float lo[3] = {real ? px : inf, real ? py : inf, real ? pz : inf}, hi[3] = {real ? px : -inf, real ? py : -inf, real ? pz : -inf};
 #pragma unroll
-    for (int m = 8; m >= 1; m >>= 1)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            lo[k] = fminf(lo[k], __shfl_xor(lo[k], m));
-            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m));
-        }
-#pragma unroll
-    for (int m = 32; m >= 16; m >>= 1)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            lo[k] = fminf(lo[k], __shfl_xor(lo[k], m));
-            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], m));
-        }
+    for (int k = 0; k < 3; ++k) { lo[k] = wave_min_uniform(lo[k]); hi[k] = wave_max_uniform(hi[k]); }
     if (lane == 0) {
         float* o = colbox + ((size_t)b * blocks + qb) * 8;
         o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = 0.0f; o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = 0.0f;
@@ -926,10 +926,7 @@ __device__ __forceinline__ void v2v_scan_body(
     if (alive == 0) { SCAN_COUNT(10); return; }
     // lower bounds are compared as g <= bound * (1 + 1e-6): the slack of kPruneSlack on the side that changes rarely
     constexpr float kBoundSlack = 1.000001f;
-    float reach2 = ((alive >> lane) & 1) ? c.best : 0.0f;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) reach2 = fmaxf(reach2, __shfl_xor(reach2, m));
-    reach2 *= kBoundSlack;
+    const float reach2 = wave_max_uniform(((alive >> lane) & 1) ? c.best : 0.0f) * kBoundSlack;
     float best_s = c.best * kBoundSlack;
     // the boxes of a trip's 64 leaves, for the per-column test of the candidates among them: a candidate's box is one
     // broadcast read of LDS (two 16-byte reads) instead of six v_readlane + three v_mov (one scalar operand per vector
@@ -989,7 +986,7 @@ __device__ __forceinline__ void v2v_scan_body(
         leaf_hi[lane] = hi;
         while (todo) {
             const int u = __builtin_ctzll(todo);
-            todo &= todo - 1;
+            asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(u));
             SCAN_COUNT(2);
             const float4 blo = leaf_lo[u], bhi = leaf_hi[u];
             const uint64_t lanes = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(lanes_of >> 32), u) << 32) |
