@@ -475,7 +475,7 @@ def rooflines(p, batch):
     # peak and can never exceed valu_busy.  The all-pairs figure of SURVEY 8(d) is `equivalent_*`: most pairs are pruned.
     exe_v = (prof_v['valu_instr'] * 64 * 2 / t_v / 1e12) if (prof_v['valu_instr'] and batch == BATCH_PER_GPU) else None
     roof = {'kernel': 'v2v_scan_kernel (+ v2v_rows_seed, v2v_tree_finalize; beside the inside test: '
-                      'v2v_scan_shared_kernel, the same code capped at 6 wavefronts per SIMD)', 'bound': 'valu',
+                      'v2v_scan_shared_kernel, the same code capped at 7 wavefronts per SIMD)', 'bound': 'valu',
             'achieved': round(exe_v, 2) if exe_v is not None else None, 'peak': PEAK_FP32_VECTOR_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(exe_v / PEAK_FP32_VECTOR_TFLOPS, 4) if exe_v is not None else None,
             'frac_formula': 'SQ_INSTS_VALU per launch (profiles/) x 64 lanes x 2 / launch time measured here / peak: EXECUTED '

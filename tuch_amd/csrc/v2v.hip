@@ -896,7 +896,7 @@ __global__ __launch_bounds__(64) void v2v_tree_kernel(
 // and the largest bound among them (conservative: box-to-box distance), and only the survivors get the per-column test
 // and their rows.  Same rows as the walks -> the same keys.  colbox: the box of every 64-column block, left by
 // v2v_seed_kernel ([B][column blocks][8]).
-template <bool kShared>
+template <int kShared>
 __device__ __forceinline__ void v2v_scan_body(
     const float* __restrict__ prow, int V, int Vp, const uint64_t* __restrict__ bits,
     const float* __restrict__ leafbox, const float* __restrict__ colbox, const uint64_t* __restrict__ masked_leaf,
@@ -904,8 +904,11 @@ __device__ __forceinline__ void v2v_scan_body(
     const int32_t* __restrict__ sub_leaf, const int32_t* __restrict__ order, uint64_t* __restrict__ keys,
     const float* __restrict__ prow_g, const uint64_t* __restrict__ bits_g, int G)   // rows / mask words in groups of four
 {
-    // (80 registers = 6 wavefronts per SIMD: touching v79 is what sets the kernel's register count)
-    if constexpr (kShared) asm volatile("v_mov_b32 v79, 0" ::: "v79");
+    // (72 registers = 7 wavefronts per SIMD, 80 = 6, ...: touching the last one is what sets the kernel's register count)
+    if constexpr (kShared == 7) asm volatile("v_mov_b32 v71, 0" ::: "v71");
+    if constexpr (kShared == 6) asm volatile("v_mov_b32 v79, 0" ::: "v79");
+    if constexpr (kShared == 5) asm volatile("v_mov_b32 v99, 0" ::: "v99");
+    if constexpr (kShared == 4) asm volatile("v_mov_b32 v127, 0" ::: "v127");
     const int b = blockIdx.x, lane = threadIdx.x;
     const int pair = __builtin_amdgcn_readfirstlane(order[blockIdx.y >> 1]);      // launch order over 128-blocks
     const int sub = pair >> 16, qb = (pair & 0xffff) * 2 + (blockIdx.y & 1);
@@ -1015,13 +1018,14 @@ __device__ __forceinline__ void v2v_scan_body(
     int L, const int32_t* __restrict__ frontier, const int32_t* __restrict__ sub_leaf, const int32_t* __restrict__ order,   \
     uint64_t* __restrict__ keys, const float* __restrict__ prow_g, const uint64_t* __restrict__ bits_g, int G
 #define TUCH_SCAN_ARGS prow, V, Vp, bits, leafbox, colbox, masked_leaf, masked, N, L, frontier, sub_leaf, order, keys, prow_g, bits_g, G
-__global__ __launch_bounds__(64) void v2v_scan_kernel(TUCH_SCAN_PARAMS) { v2v_scan_body<false>(TUCH_SCAN_ARGS); }
-// The same beside the inside test's chain of small kernels (another stream): at most 6 of a SIMD's 8 wave slots, by
+__global__ __launch_bounds__(64) void v2v_scan_kernel(TUCH_SCAN_PARAMS) { v2v_scan_body<0>(TUCH_SCAN_ARGS); }
+// The same beside the inside test's chain of small kernels (another stream): at most kSlots of a SIMD's 8 wave slots, by
 // REGISTER count.  (Round 2 capped the walk with an unused LDS allocation -- 25 x 6400 B is ALL of a CU's LDS: the
 // chain's kernels that need LDS themselves, ray_near and ray_tiles_fill, then waited for the search to drain.)
+template <int kSlots>
 __global__ __launch_bounds__(64) void v2v_scan_shared_kernel(TUCH_SCAN_PARAMS)
 {
-    v2v_scan_body<true>(TUCH_SCAN_ARGS);
+    v2v_scan_body<kSlots>(TUCH_SCAN_ARGS);
 }
 #undef TUCH_SCAN_PARAMS
 #undef TUCH_SCAN_ARGS
@@ -1245,13 +1249,16 @@ extern "C" int tuch_v2v_min_model_shared_zero(const tuch_contact_model* m, const
     // got going when the walk was done (tools/graph_timeline.py: the memset took 236 us).  -2.5 % step time; alone the
     // walk is 10 % slower with the cap (0.28 -> 0.31 ms), hence a flag (TUCH_V2V_LDS: bytes, to compare).
     const int lds_pad = leave_room && m->opt.v2v_lds > 0 ? m->opt.v2v_lds : 0;
-    if (scan == 2 && leave_room && m->opt.v2v_lds < 0)
-        hipLaunchKernelGGL(v2v_scan_shared_kernel, dim3(B, 2 * nsub * m->tree_qblocks), dim3(64), 0, s, (const float*)prow,
+    if (scan == 2 && leave_room && m->opt.v2v_lds < 0) {
+        auto* kernel = m->opt.v2v_lds == -4 ? v2v_scan_shared_kernel<4> : m->opt.v2v_lds == -5 ? v2v_scan_shared_kernel<5> : m->opt.v2v_lds == -6 ? v2v_scan_shared_kernel<6>
+                                                                                                  : v2v_scan_shared_kernel<7>;
+        hipLaunchKernelGGL(kernel, dim3(B, 2 * nsub * m->tree_qblocks), dim3(64), 0, s, (const float*)prow,
                            V, Vp, (const uint64_t*)m->tree_mask_bits, (const float*)leafbox, (const float*)colbox,
                            (const uint64_t*)m->tree_masked_leaf, (const uint64_t*)m->tree_masked, N, m->tree_leaves,
                            (const int32_t*)m->tree_frontier_nodes + f0, (const int32_t*)m->tree_sub_leaf + 2 * (size_t)f0,
                            (const int32_t*)m->tree_launch_order + (size_t)f0 * m->tree_qblocks, keys,
                            (const float*)(ws + l.prow_g), (const uint64_t*)m->tree_mask_bits_g, m->tree_groups);
+    }
     else if (scan == 2)
         hipLaunchKernelGGL(v2v_scan_kernel, dim3(B, 2 * nsub * m->tree_qblocks), dim3(64), (size_t)lds_pad, s, (const float*)prow,
                            V, Vp, (const uint64_t*)m->tree_mask_bits, (const float*)leafbox, (const float*)colbox,
