@@ -279,7 +279,11 @@ __device__ __forceinline__ void ray_step(const RayElem el, int em, P3 (&s)[3], f
     // e[A] = e(Bq -> Cq) is carried over from the previous triangle; the two edges at the new vertex:
     e[Bq] = edge_fn(s[Cq], s[A]);
     e[Cq] = edge_fn(s[A], s[Bq]);
-    if (el.sign != 0.0f) {                                        // wave-uniform: the two priming vertices of a strip
+    // the orientation as an integer on the SCALAR unit (gfx950 has no scalar float compare: `sign > 0` and `sign != 0`
+    // on the wave-uniform element cost a vector compare each): +1.0f = 0x3f800000, -1.0f = 0xbf800000, 0.0f = 0
+    const int sbits = __float_as_int(el.sign);
+    if (sbits != 0) {                                             // wave-uniform: the two priming vertices of a strip
+        const int isign = 1 + (sbits >> 30);                      // +1 / -1
         // triangle (Bq, Cq, A): det = sum of (edge function opposite a corner) x (that corner's depth)
         const float numz = __builtin_fmaf(e[A], s[A].z, __builtin_fmaf(e[Cq], s[Cq].z, e[Bq] * s[Bq].z));
         const float mn = __builtin_fminf(__builtin_fminf(e[0], e[1]), e[2]);
@@ -298,12 +302,18 @@ __device__ __forceinline__ void ray_step(const RayElem el, int em, P3 (&s)[3], f
                 if (tie) c = crossing_with_ties<kSkipIncident>(s[Bq], s[Cq], s[A], e[Bq], e[Cq], e[A]);
             }
         }
-        const int cs = el.sign > 0.0f ? c : -c;
-        count += cs;
-        if (kSeg && em != 0) {                                        // wave-uniform
+        // one full-rate instruction (left to the compiler, c * isign + count becomes a 64-bit multiply-add: quarter rate)
+        asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(count) : "v"(c), "s"(isign));
+        if (kSeg && em != 0) {                                    // wave-uniform
+            // few lanes belong to one of the element's segments AND cross it: the counters' arithmetic (32-bit integer
+            // multiplications: quarter rate) only when some lane has something to add
             const uint32_t t = (uint32_t)(em & qmask);
-            pa += (uint32_t)cs * (((t & 15u) * 0x00204081u) & 0x01010101u);
-            pb += (uint32_t)cs * (((t >> 4) * 0x00204081u) & 0x01010101u);
+            if (__builtin_amdgcn_ballot_w64((t != 0) & (c != 0))) {
+                uint32_t cs;
+                asm("v_mul_i32_i24 %0, %1, %2" : "=v"(cs) : "v"(c), "s"(isign));
+                pa += cs * (((t & 15u) * 0x00204081u) & 0x01010101u);
+                pb += cs * ((((t >> 4) & 15u) * 0x00204081u) & 0x01010101u);
+            }
         }
     }
 }
@@ -314,11 +324,13 @@ __device__ __forceinline__ void ray_run(const RayElem* __restrict__ st, const in
                                         int qmask, uint32_t& pa, uint32_t& pb)
 {
     const RayElem* p = st + off;
-    const RayElem* end = p + len;
     const int32_t* m = kSeg ? emask + off : nullptr;
     RayElem n0 = p[0], n1 = p[1], n2 = p[2];
     int m0 = kSeg ? m[0] : 0, m1 = kSeg ? m[1] : 0, m2 = kSeg ? m[2] : 0;
-    for (; p < end; p += 3) {
+    // (a 32-bit count, opaque to the loop optimiser: compared on the scalar unit; the pointer form `p < end` is a 64-bit
+    // VECTOR compare on gfx950)
+    for (int left = len; left > 0; left -= 3, p += 3) {
+        asm("" : "+s"(left));
         const RayElem e0 = n0, e1 = n1, e2 = n2;
         const int k0 = m0, k1 = m1, k2 = m2;
         n0 = p[3]; n1 = p[4]; n2 = p[5];
