@@ -268,13 +268,26 @@ __device__ __forceinline__ int crossing_with_ties(const P3 a, const P3 b, const 
 // every segment vertex, its crossings with the faces of its own segments only).  Eight counters as biased bytes of two
 // words: bits 0-3 of (em & qmask) are spread to the byte positions by one multiplication.
 constexpr uint32_t kSegBias = 0x80808080u;
+// a strip vertex relative to the query, (x, y) as a register pair: the two products of an edge function are ONE packed
+// multiplication with crossed halves (v_pk_mul_f32 rounds each product like v_mul_f32: the same bits, still exactly
+// antisymmetric), and the subtraction of the query is one packed add
+struct S3 { v2f xy; float z; };
+__device__ __forceinline__ float edge_fn(const S3& p, const S3& q)
+{
+    v2f r;                                                        // (p.x q.y, p.y q.x)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(p.xy), "v"(q.xy));
+    float d;                                                      // (in assembly: left to the vectoriser, the difference is
+    asm("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(r.x), "v"(r.y));    // paired with the z subtraction behind three v_mov)
+    return d;
+}
+__device__ __forceinline__ P3 p3(const S3& a) { return P3{a.xy.x, a.xy.y, a.z}; }
+
 template <int A, bool kSkipIncident, bool kSeg>
-__device__ __forceinline__ void ray_step(const RayElem el, int em, P3 (&s)[3], float (&e)[3], float qx, float qy, float qz, int& count,
+__device__ __forceinline__ void ray_step(const RayElem el, int em, S3 (&s)[3], float (&e)[3], v2f qxy, float qz, int& count,
                                          int qmask, uint32_t& pa, uint32_t& pb)
 {
     constexpr int Bq = (A + 1) % 3, Cq = (A + 2) % 3;            // slots of stream positions p-2 and p-1
-    s[A].x = el.x - qx;
-    s[A].y = el.y - qy;
+    s[A].xy = (v2f){el.x, el.y} - qxy;
     s[A].z = el.z - qz;
     // e[A] = e(Bq -> Cq) is carried over from the previous triangle; the two edges at the new vertex:
     e[Bq] = edge_fn(s[Cq], s[A]);
@@ -299,7 +312,7 @@ __device__ __forceinline__ void ray_step(const RayElem el, int em, P3 (&s)[3], f
         if (__builtin_amdgcn_ballot_w64(edge_zero)) {             // the wavefronts of a query's own leaf; else rare
             const bool tie = edge_zero & (numz != 0.0f);
             if (__builtin_amdgcn_ballot_w64(tie)) {
-                if (tie) c = crossing_with_ties<kSkipIncident>(s[Bq], s[Cq], s[A], e[Bq], e[Cq], e[A]);
+                if (tie) c = crossing_with_ties<kSkipIncident>(p3(s[Bq]), p3(s[Cq]), p3(s[A]), e[Bq], e[Cq], e[A]);
             }
         }
         // one full-rate instruction (left to the compiler, c * isign + count becomes a 64-bit multiply-add: quarter rate)
@@ -320,7 +333,7 @@ __device__ __forceinline__ void ray_step(const RayElem el, int em, P3 (&s)[3], f
 
 template <bool kSkipIncident, bool kSeg>
 __device__ __forceinline__ void ray_run(const RayElem* __restrict__ st, const int32_t* __restrict__ emask, int off, int len,
-                                        P3 (&s)[3], float (&e)[3], float qx, float qy, float qz, int& count,
+                                        S3 (&s)[3], float (&e)[3], v2f qxy, float qz, int& count,
                                         int qmask, uint32_t& pa, uint32_t& pb)
 {
     const RayElem* p = st + off;
@@ -335,9 +348,9 @@ __device__ __forceinline__ void ray_run(const RayElem* __restrict__ st, const in
         const int k0 = m0, k1 = m1, k2 = m2;
         n0 = p[3]; n1 = p[4]; n2 = p[5];
         if (kSeg) { m += 3; m0 = m[0]; m1 = m[1]; m2 = m[2]; }
-        ray_step<0, kSkipIncident, kSeg>(e0, k0, s, e, qx, qy, qz, count, qmask, pa, pb);
-        ray_step<1, kSkipIncident, kSeg>(e1, k1, s, e, qx, qy, qz, count, qmask, pa, pb);
-        ray_step<2, kSkipIncident, kSeg>(e2, k2, s, e, qx, qy, qz, count, qmask, pa, pb);
+        ray_step<0, kSkipIncident, kSeg>(e0, k0, s, e, qxy, qz, count, qmask, pa, pb);
+        ray_step<1, kSkipIncident, kSeg>(e1, k1, s, e, qxy, qz, count, qmask, pa, pb);
+        ray_step<2, kSkipIncident, kSeg>(e2, k2, s, e, qxy, qz, count, qmask, pa, pb);
     }
 }
 
@@ -782,15 +795,16 @@ __global__ __launch_bounds__(64) void ray_leaf_kernel(
     while (next.b >= 0) {
         const Work w = next;
         next = fetch();
-        P3 s[3];
+        S3 s[3];
         float e[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { s[k].x = s[k].y = s[k].z = 0.0f; e[k] = 0.0f; }
+        for (int k = 0; k < 3; ++k) { s[k].xy = (v2f){0.0f, 0.0f}; s[k].z = 0.0f; e[k] = 0.0f; }
+        const v2f qxy = {w.qx, w.qy};
         int crossings = 0;
         uint32_t pa = kSegBias, pb = kSegBias;
         const RayElem* st = stream + (size_t)w.b * T;
         if (w.len >= 0) {
-            ray_run<kVerts, kSeg>(st, elem_mask, w.off, w.len, s, e, w.qx, w.qy, w.qz, crossings, w.qmask, pa, pb);
+            ray_run<kVerts, kSeg>(st, elem_mask, w.off, w.len, s, e, qxy, w.qz, crossings, w.qmask, pa, pb);
             if (kCount) walked += w.len;
         } else {
             const int qb = w.off / kFallbackChunks, c = w.off % kFallbackChunks;
@@ -798,7 +812,7 @@ __global__ __launch_bounds__(64) void ray_leaf_kernel(
             const RayEntry* list = lists + ((size_t)w.b * qblocks + qb) * num_leaves;
             for (int j = c; j < cnt; j += kFallbackChunks) {
                 const TreeNode nd = nodes[__builtin_amdgcn_readfirstlane(list[j].node)];
-                ray_run<kVerts, kSeg>(st, elem_mask, nd.ex_off, nd.ex_len, s, e, w.qx, w.qy, w.qz, crossings, w.qmask, pa, pb);
+                ray_run<kVerts, kSeg>(st, elem_mask, nd.ex_off, nd.ex_len, s, e, qxy, w.qz, crossings, w.qmask, pa, pb);
                 if (kCount) walked += nd.ex_len;
             }
         }
