@@ -112,6 +112,7 @@ struct tuch_contact_model {
     int32_t* tree_node;        // [tree_nodes][8]
     int32_t* tree_vidx;        // [tree_stream_len]
     float* tree_sign;
+    int32_t* tree_sign_word;   // [like tree_sign] orientation as an integer in bits 0-23, seg_elem_mask in bits 24-31
     int32_t* tree_qperm;       // [tree_qblocks*128]
     int32_t* tree_height_off;  // [tree_heights+1]
     int32_t* tree_height_nodes;

@@ -31,7 +31,7 @@ int* host_copy(const int32_t* src, size_t n)
 extern "C" void tuch_contact_model_destroy(tuch_contact_model* m)
 {
     if (!m) return;
-    void* dev[] = {m->ring_off, m->ring_vidx, m->faces, m->mask_bits, m->strip_vidx, m->strip_sign, m->tree_node, m->tree_vidx, m->tree_sign, m->tree_qperm,
+    void* dev[] = {m->ring_off, m->ring_vidx, m->faces, m->mask_bits, m->strip_vidx, m->strip_sign, m->tree_node, m->tree_vidx, m->tree_sign, m->tree_sign_word, m->tree_qperm,
                    m->tree_height_off, m->tree_height_nodes, m->tree_frontier_nodes, m->tree_launch_order, m->tree_ancestors, m->tree_rows, m->tree_v2v_info, m->tree_mask_bits, m->tree_masked, m->tree_sub_leaf, m->tree_masked_leaf, m->tree_leaf_group, m->tree_mask_bits_g, m->seg_blocks, m->seg_of_q, m->seg_q_off, m->seg_q_vidx, m->seg_f_off, m->seg_faces, m->seg_link_off, m->seg_link, m->seg_ray_off, m->seg_ray_ent, m->seg_elem_mask, m->seg_vmask, m->seg_vpos, m->seg_cap_off, m->seg_cap_ent, m->seg_cap_range,
                    m->cap_off, m->cap_vidx, m->region_off, m->region_vidx, m->pairs, m->pair_mask, m->pair_mask_off, m->tickets, m->canary_hits};
     for (void* p : dev) tuch_table_free(p);
@@ -86,6 +86,7 @@ extern "C" int tuch_contact_model_create(
     }
     std::vector<int32_t> tree_vidx_host, tree_qperm_host;     // for the segment tables further down
     std::vector<float> tree_sign_host;
+    std::vector<int32_t> elem_mask_host;                       // per strip element: the segments that list its triangle
     int tree_exact_host = 0;
     if (rc == TUCH_OK) {
         // cluster tree for the hierarchical winding numbers; a mesh that is not a closed manifold (or
@@ -384,6 +385,7 @@ extern "C" int tuch_contact_model_create(
                     if (cent.empty()) cent.assign(3, 0);
                     if (assist) {
                         m->seg_cap_total = coff.back();
+                        elem_mask_host = emask;
                         rc = upload(&m->seg_elem_mask, emask.data(), emask.size());
                         if (rc == TUCH_OK) rc = upload(&m->seg_vmask, vmask.data(), vmask.size());
                         if (rc == TUCH_OK) rc = upload(&m->seg_vpos, vpos.data(), vpos.size());
@@ -443,6 +445,18 @@ extern "C" int tuch_contact_model_create(
             rc = upload(&m->pair_mask, words.data(), words.size());
             if (rc == TUCH_OK) rc = upload(&m->pair_mask_off, off.data(), off.size());
         }
+    }
+    if (rc == TUCH_OK && !tree_sign_host.empty()) {
+        // the fourth word of a posed strip element (ray_winding.hip: RayElem): the orientation as the INTEGER +1 / -1 / 0 in
+        // bits 0-23 and the element's segments (seg_elem_mask) in bits 24-31 -- both wave-uniform in the crossing kernel,
+        // read and tested on the scalar unit
+        std::vector<int32_t> word(tree_sign_host.size(), 0);
+        for (size_t p = 0; p < word.size(); ++p) {
+            const int32_t sg = tree_sign_host[p] > 0.0f ? 1 : tree_sign_host[p] < 0.0f ? -1 : 0;
+            const int32_t em = p < elem_mask_host.size() ? elem_mask_host[p] : 0;
+            word[p] = (int32_t)(((uint32_t)em << 24) | ((uint32_t)sg & 0xffffffu));
+        }
+        rc = upload(&m->tree_sign_word, word.data(), word.size());
     }
     if (rc != TUCH_OK) {
         tuch_contact_model_destroy(m);

@@ -47,7 +47,9 @@ constexpr int kSlabs = 9;
 constexpr int kSlabStride = 10;               // as winding.hip: node = [lo[10], hi[10]]
 constexpr int kNearSlabs = 13;                // of the 18 slab values of a leaf, those the near test uses
 
-struct RayElem { float x, y, z, sign; };      // sheared position of a strip vertex, orientation of the triangle it closes
+struct RayElem { float x, y, z, sign; };      // sheared position of a strip vertex; `sign` holds the model's word for the
+                                              // element (tree_sign_word): bits 0-23 the orientation of the triangle it
+                                              // closes as the INTEGER +1 / -1 / 0, bits 24-31 the segments that list it
 
 __device__ __forceinline__ float shear_x(float x, float z) { return __builtin_fmaf(-kShearX, z, x); }
 __device__ __forceinline__ float shear_y(float y, float z) { return __builtin_fmaf(-kShearY, z, y); }
@@ -283,7 +285,7 @@ __device__ __forceinline__ float edge_fn(const S3& p, const S3& q)
 __device__ __forceinline__ P3 p3(const S3& a) { return P3{a.xy.x, a.xy.y, a.z}; }
 
 template <int A, bool kSkipIncident, bool kSeg>
-__device__ __forceinline__ void ray_step(const RayElem el, int em, S3 (&s)[3], float (&e)[3], v2f qxy, float qz, int& count,
+__device__ __forceinline__ void ray_step(const RayElem el, S3 (&s)[3], float (&e)[3], v2f qxy, float qz, int& count,
                                          int qmask, uint32_t& pa, uint32_t& pb)
 {
     constexpr int Bq = (A + 1) % 3, Cq = (A + 2) % 3;            // slots of stream positions p-2 and p-1
@@ -292,11 +294,10 @@ __device__ __forceinline__ void ray_step(const RayElem el, int em, S3 (&s)[3], f
     // e[A] = e(Bq -> Cq) is carried over from the previous triangle; the two edges at the new vertex:
     e[Bq] = edge_fn(s[Cq], s[A]);
     e[Cq] = edge_fn(s[A], s[Bq]);
-    // the orientation as an integer on the SCALAR unit (gfx950 has no scalar float compare: `sign > 0` and `sign != 0`
-    // on the wave-uniform element cost a vector compare each): +1.0f = 0x3f800000, -1.0f = 0xbf800000, 0.0f = 0
-    const int sbits = __float_as_int(el.sign);
-    if (sbits != 0) {                                             // wave-uniform: the two priming vertices of a strip
-        const int isign = 1 + (sbits >> 30);                      // +1 / -1
+    // the element's fourth word: orientation (integer, bits 0-23) and segments (bits 24-31), see RayElem.  gfx950 has no
+    // scalar float compare -- `sign > 0` and `sign != 0` on the wave-uniform element cost a vector compare each
+    const int word = __float_as_int(el.sign);
+    if ((word & 0xffffff) != 0) {                                 // wave-uniform: the two priming vertices of a strip
         // triangle (Bq, Cq, A): det = sum of (edge function opposite a corner) x (that corner's depth)
         const float numz = __builtin_fmaf(e[A], s[A].z, __builtin_fmaf(e[Cq], s[Cq].z, e[Bq] * s[Bq].z));
         const float mn = __builtin_fminf(__builtin_fminf(e[0], e[1]), e[2]);
@@ -315,15 +316,16 @@ __device__ __forceinline__ void ray_step(const RayElem el, int em, S3 (&s)[3], f
                 if (tie) c = crossing_with_ties<kSkipIncident>(p3(s[Bq]), p3(s[Cq]), p3(s[A]), e[Bq], e[Cq], e[A]);
             }
         }
-        // one full-rate instruction (left to the compiler, c * isign + count becomes a 64-bit multiply-add: quarter rate)
-        asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(count) : "v"(c), "s"(isign));
-        if (kSeg && em != 0) {                                    // wave-uniform
+        // one full-rate instruction (left to the compiler, c * sign + count becomes a 64-bit multiply-add: quarter rate);
+        // the 24-bit multiply reads bits 0-23 of the word: the orientation
+        asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(count) : "v"(c), "s"(word));
+        if (kSeg && ((uint32_t)word >> 24) != 0) {                // wave-uniform
             // few lanes belong to one of the element's segments AND cross it: the counters' arithmetic (32-bit integer
             // multiplications: quarter rate) only when some lane has something to add
-            const uint32_t t = (uint32_t)(em & qmask);
+            const uint32_t t = ((uint32_t)word >> 24) & (uint32_t)qmask;
             if (__builtin_amdgcn_ballot_w64((t != 0) & (c != 0))) {
                 uint32_t cs;
-                asm("v_mul_i32_i24 %0, %1, %2" : "=v"(cs) : "v"(c), "s"(isign));
+                asm("v_mul_i32_i24 %0, %1, %2" : "=v"(cs) : "v"(c), "s"(word));
                 pa += cs * (((t & 15u) * 0x00204081u) & 0x01010101u);
                 pb += cs * ((((t >> 4) & 15u) * 0x00204081u) & 0x01010101u);
             }
@@ -332,25 +334,21 @@ __device__ __forceinline__ void ray_step(const RayElem el, int em, S3 (&s)[3], f
 }
 
 template <bool kSkipIncident, bool kSeg>
-__device__ __forceinline__ void ray_run(const RayElem* __restrict__ st, const int32_t* __restrict__ emask, int off, int len,
+__device__ __forceinline__ void ray_run(const RayElem* __restrict__ st, int off, int len,
                                         S3 (&s)[3], float (&e)[3], v2f qxy, float qz, int& count,
                                         int qmask, uint32_t& pa, uint32_t& pb)
 {
     const RayElem* p = st + off;
-    const int32_t* m = kSeg ? emask + off : nullptr;
     RayElem n0 = p[0], n1 = p[1], n2 = p[2];
-    int m0 = kSeg ? m[0] : 0, m1 = kSeg ? m[1] : 0, m2 = kSeg ? m[2] : 0;
     // (a 32-bit count, opaque to the loop optimiser: compared on the scalar unit; the pointer form `p < end` is a 64-bit
     // VECTOR compare on gfx950)
     for (int left = len; left > 0; left -= 3, p += 3) {
         asm("" : "+s"(left));
         const RayElem e0 = n0, e1 = n1, e2 = n2;
-        const int k0 = m0, k1 = m1, k2 = m2;
         n0 = p[3]; n1 = p[4]; n2 = p[5];
-        if (kSeg) { m += 3; m0 = m[0]; m1 = m[1]; m2 = m[2]; }
-        ray_step<0, kSkipIncident, kSeg>(e0, k0, s, e, qxy, qz, count, qmask, pa, pb);
-        ray_step<1, kSkipIncident, kSeg>(e1, k1, s, e, qxy, qz, count, qmask, pa, pb);
-        ray_step<2, kSkipIncident, kSeg>(e2, k2, s, e, qxy, qz, count, qmask, pa, pb);
+        ray_step<0, kSkipIncident, kSeg>(e0, s, e, qxy, qz, count, qmask, pa, pb);
+        ray_step<1, kSkipIncident, kSeg>(e1, s, e, qxy, qz, count, qmask, pa, pb);
+        ray_step<2, kSkipIncident, kSeg>(e2, s, e, qxy, qz, count, qmask, pa, pb);
     }
 }
 
@@ -639,7 +637,8 @@ __global__ __launch_bounds__(64) void ray_fill_kernel(
 // of them.  (As two launches with one wavefront per query block: 10 + 31 us at batch 64 and 7 + 14 us at batch 8, most
 // of it the launch rate of 6912 one-wavefront workgroups and three dependent global round trips in each; as ONE
 // workgroup per body, fill counters in LDS: 61 us -- the write loop below is ~25 instructions per entry and a
-// body's 4300 entries kept one CU busy that long.)
+// body's 4300 entries kept one CU busy that long.  Beside the search the kernel takes ~75 us whether a body has 2, 4,
+// 8, 16 or 32 workgroups: step 0.465 ... 0.472 ms, noise.)
 constexpr int kTilesFillBlock = 256, kFillSplit = 16, kFillMaxBlocks = 2048;
 __global__ __launch_bounds__(kTilesFillBlock) void ray_tiles_fill_kernel(
     const int32_t* __restrict__ leaf_cnt, const TreeNode* __restrict__ nodes, const int32_t* __restrict__ leaf_nodes,
@@ -699,7 +698,7 @@ __global__ __launch_bounds__(kTilesFillBlock) void ray_tiles_fill_kernel(
     __syncthreads();
     int32_t* fill = leaf_fill + (size_t)b * num_leaves;
     int32_t* out = pairs + (size_t)b * cap;
-    for (int base = (blockIdx.y * (kTilesFillBlock / 64) + (t >> 6)) * 64; base < total; base += kFillSplit * kTilesFillBlock) {
+    for (int base = (blockIdx.y * (kTilesFillBlock / 64) + (t >> 6)) * 64; base < total; base += (int)gridDim.y * kTilesFillBlock) {
         // lanes over entries: reserve the entry's range in its leaf (64 atomics in flight)
         const int g = base + lane;
         RayEntry e = RayEntry{0, 0, 0u, 0u};
@@ -804,7 +803,7 @@ __global__ __launch_bounds__(64) void ray_leaf_kernel(
         uint32_t pa = kSegBias, pb = kSegBias;
         const RayElem* st = stream + (size_t)w.b * T;
         if (w.len >= 0) {
-            ray_run<kVerts, kSeg>(st, elem_mask, w.off, w.len, s, e, qxy, w.qz, crossings, w.qmask, pa, pb);
+            ray_run<kVerts, kSeg>(st, w.off, w.len, s, e, qxy, w.qz, crossings, w.qmask, pa, pb);
             if (kCount) walked += w.len;
         } else {
             const int qb = w.off / kFallbackChunks, c = w.off % kFallbackChunks;
@@ -812,7 +811,7 @@ __global__ __launch_bounds__(64) void ray_leaf_kernel(
             const RayEntry* list = lists + ((size_t)w.b * qblocks + qb) * num_leaves;
             for (int j = c; j < cnt; j += kFallbackChunks) {
                 const TreeNode nd = nodes[__builtin_amdgcn_readfirstlane(list[j].node)];
-                ray_run<kVerts, kSeg>(st, elem_mask, nd.ex_off, nd.ex_len, s, e, qxy, w.qz, crossings, w.qmask, pa, pb);
+                ray_run<kVerts, kSeg>(st, nd.ex_off, nd.ex_len, s, e, qxy, w.qz, crossings, w.qmask, pa, pb);
                 if (kCount) walked += nd.ex_len;
             }
         }
@@ -1624,12 +1623,12 @@ static void launch_ray_boxes(const tuch_contact_model* m, const RayLayout& l, co
         hipLaunchKernelGGL(ray_leaf_bounds_kernel<true>, dim3(ceil_div(m->tree_leaves, kBoundsBlock / 16), B), dim3(kBoundsBlock), 0,
                            s, (const RayElem*)st, l.T, (const TreeNode*)m->tree_node, m->tree_nodes,
                            (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, bounds, verts,
-                           (const int32_t*)m->tree_vidx, (const float*)m->tree_sign, m->V, m->tree_exact_len, st,
+                           (const int32_t*)m->tree_vidx, (const float*)m->tree_sign_word, m->V, m->tree_exact_len, st,
                            (uint4*)(ws + l.zeroed), l.zeroed_bytes / sizeof(uint4));
         return;
     }
     hipLaunchKernelGGL(ray_stream_kernel, dim3(ceil_div(l.T, kBlock), B), dim3(kBlock), 0, s, verts,
-                       (const int32_t*)m->tree_vidx, (const float*)m->tree_sign, m->V, m->tree_exact_len, l.T, st,
+                       (const int32_t*)m->tree_vidx, (const float*)m->tree_sign_word, m->V, m->tree_exact_len, l.T, st,
                        (uint4*)(ws + l.zeroed), l.zeroed_bytes / sizeof(uint4));
     hipLaunchKernelGGL(ray_leaf_bounds_kernel<false>, dim3(ceil_div(m->tree_leaves, kBoundsBlock / 16), B), dim3(kBoundsBlock), 0, s,
                        (const RayElem*)st, l.T, (const TreeNode*)m->tree_node, m->tree_nodes,
