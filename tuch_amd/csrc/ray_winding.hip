@@ -738,7 +738,8 @@ __global__ __launch_bounds__(kTilesFillBlock) void ray_tiles_fill_kernel(
 // list from t % 8).
 // kCount: elements walked are added to stats[0] (measurement).
 // kSeg (vertex queries of a model with segments): the crossings with the faces of the lane's own segments are counted
-// as well (seg_count[b][slot][2], four signed byte counters per word; seg_elem_mask / seg_vmask of the model).
+// as well (seg_count[b][slot][2], four signed byte counters per word; the elements' segments ride in the stream's
+// fourth word -- tree_sign_word --, the vertices' in seg_vmask).
 template <bool kVerts, bool kCount, bool kSeg>
 __global__ __launch_bounds__(64) void ray_leaf_kernel(
     const float* __restrict__ pts, const RayElem* __restrict__ stream, const RayTile* __restrict__ tiles,
@@ -746,7 +747,7 @@ __global__ __launch_bounds__(64) void ray_leaf_kernel(
     const int32_t* __restrict__ list_len, const TreeNode* __restrict__ nodes, int num_leaves,
     const int32_t* __restrict__ qperm, const int32_t* __restrict__ counts, int Q, int T, int qblocks, int num_bodies,
     int cap, int max_tiles, int32_t* __restrict__ count, unsigned long long* __restrict__ stats,
-    const int32_t* __restrict__ elem_mask, const int32_t* __restrict__ vmask, int32_t* __restrict__ seg_count)
+    const int32_t* __restrict__ vmask, int32_t* __restrict__ seg_count)
 {
     const int lane = threadIdx.x;
     struct Work { int b, off, len, slot, qmask; bool active; float qx, qy, qz; };     // b < 0: nothing left; len < 0: block-major tile `off`
@@ -1677,14 +1678,13 @@ static int launch_ray_counts(const tuch_contact_model* m, const RayLayout& l, co
     }
     const dim3 grid(l.columns, l.workers);
     const bool seg = kVerts && m->seg_elem_mask;
-    const int32_t* emask = (const int32_t*)m->seg_elem_mask;
     const int32_t* vmask = (const int32_t*)m->seg_vmask;
     int32_t* seg_count = (int32_t*)(ws + l.seg_count);
 #define TUCH_LAUNCH_RAY_LEAF(COUNT, SEG)                                                                                      \
     hipLaunchKernelGGL((ray_leaf_kernel<kVerts, COUNT, SEG>), grid, dim3(64), 0, s, queries, (const RayElem*)(ws + l.stream),  \
                        (const RayTile*)tiles, (const RayBody*)body, (const int32_t*)pairs, (const RayEntry*)lists,            \
                        (const int32_t*)list_len, nodes, L, qperm, counts, Q, l.T, l.qblocks, B, l.cap, l.max_tiles,           \
-                       (int32_t*)(ws + l.count), stats, emask, vmask, seg_count)
+                       (int32_t*)(ws + l.count), stats, vmask, seg_count)
     if (stats) {
         if (seg) TUCH_LAUNCH_RAY_LEAF(true, kVerts); else TUCH_LAUNCH_RAY_LEAF(true, false);
     } else {
