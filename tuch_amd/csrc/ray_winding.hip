@@ -448,14 +448,15 @@ __global__ __launch_bounds__(64 * kWaves) void ray_near_kernel(
     // every load that does not wait for the block's ranges is issued here: the body's reference point and the slab
     // values / records of the wavefront's first chunk of leaves
     const float4 ctr = *reinterpret_cast<const float4*>(bounds + near_centres_at(gridDim.y, num_leaves) + (size_t)b * 4);
-    const float* bb = bounds + (size_t)b * kNearSlabs * num_leaves;       // [13][leaves], see ray_leaf_bounds_kernel
     const uint4* recs = reinterpret_cast<const uint4*>(bounds + near_records_at(gridDim.y, num_leaves)) + (size_t)b * num_leaves * 2;
-    struct Chunk { float v[kNearSlabs]; uint4 r0, r1; };
+    // stage 1 reads the leaves' 32-byte RECORDS only (half precision, relative to the body's reference point, bounds rounded
+    // outwards: what stage 2 tests every ray against) -- with the 13 single-precision slab values beside them every
+    // block fetched 84 bytes per leaf, 257 MB per launch at batch 64 out of the L2s: the kernel's time.  A leaf that some
+    // ray passes in stage 2 passes stage 1 (the block's range holds the ray's value, the record is the same).
+    struct Chunk { uint4 r0, r1; };
     auto load_chunk = [&](int base) {
         Chunk c;
         const int lc = min(base + lane, num_leaves - 1);
-#pragma unroll
-        for (int k = 0; k < kNearSlabs; ++k) c.v[k] = bb[(size_t)k * num_leaves + lc];      // one leaf per lane, coalesced
         c.r0 = recs[lc * 2];
         c.r1 = recs[lc * 2 + 1];
         return c;
@@ -464,50 +465,57 @@ __global__ __launch_bounds__(64 * kWaves) void ray_near_kernel(
     const float* q3 = pts + ((size_t)b * Q + i0) * 3;
     const float qz = q3[2];
     const float qx = shear_x(q3[0], qz), qy = shear_y(q3[1], qz);
+    // the queries relative to the body's reference point, as the records are
+    const float rx = qx - ctr.x, ry = qy - ctr.y, rz = qz - ctr.z;
+    const float r4 = rx + ry, r5 = rx - ry, r6 = rx + rz, r7 = rx - rz, r8 = ry + rz, r9 = ry - rz;
+    // the block's ranges of these nine values, the side each record bound is compared with
     float bx0, bx1, by0, by1, b40, b41, b50, b51, bz0, b60, b71, b80, b91;
     if (kWaves == 4) {
         if (wave == 0) {
-            const float a = wave_min(qx), c = wave_max(qx), d = wave_min(qy), e = wave_max(qy);
+            const float a = wave_min(rx), c = wave_max(rx), d = wave_min(ry), e = wave_max(ry);
             if (lane == 0) { range[0] = a; range[1] = c; range[2] = d; range[3] = e; }
         } else if (wave == 1) {
-            const float q4 = qx + qy, q5 = qx - qy;
-            const float a = wave_min(q4), c = wave_max(q4), d = wave_min(q5), e = wave_max(q5);
+            const float a = wave_min(r4), c = wave_max(r4), d = wave_min(r5), e = wave_max(r5);
             if (lane == 0) { range[4] = a; range[5] = c; range[6] = d; range[7] = e; }
         } else if (wave == 2) {
-            const float a = wave_min(qz), c = wave_min(qx + qz), d = wave_max(qx - qz);
+            const float a = wave_min(rz), c = wave_min(r6), d = wave_max(r7);
             if (lane == 0) { range[8] = a; range[9] = c; range[10] = d; }
         } else {
-            const float a = wave_min(qy + qz), c = wave_max(qy - qz);
+            const float a = wave_min(r8), c = wave_max(r9);
             if (lane == 0) { range[11] = a; range[12] = c; }
         }
         __syncthreads();
         bx0 = range[0]; bx1 = range[1]; by0 = range[2]; by1 = range[3]; b40 = range[4]; b41 = range[5]; b50 = range[6];
         b51 = range[7]; bz0 = range[8]; b60 = range[9]; b71 = range[10]; b80 = range[11]; b91 = range[12];
     } else {
-        const float q4 = qx + qy, q5 = qx - qy;
-        bx0 = wave_min(qx); bx1 = wave_max(qx); by0 = wave_min(qy); by1 = wave_max(qy);
-        b40 = wave_min(q4); b41 = wave_max(q4); b50 = wave_min(q5); b51 = wave_max(q5);
-        bz0 = wave_min(qz); b60 = wave_min(qx + qz); b71 = wave_max(qx - qz); b80 = wave_min(qy + qz); b91 = wave_max(qy - qz);
+        bx0 = wave_min(rx); bx1 = wave_max(rx); by0 = wave_min(ry); by1 = wave_max(ry);
+        b40 = wave_min(r4); b41 = wave_max(r4); b50 = wave_min(r5); b51 = wave_max(r5);
+        bz0 = wave_min(rz); b60 = wave_min(r6); b71 = wave_max(r7); b80 = wave_min(r8); b91 = wave_max(r9);
     }
-    // the queries relative to the body's reference point, as the records are
-    const float rx = qx - ctr.x, ry = qy - ctr.y, rz = qz - ctr.z;
-    const float r4 = rx + ry, r5 = rx - ry, r6 = rx + rz, r7 = rx - rz, r8 = ry + rz, r9 = ry - rz;
     RayEntry* list = lists + ((size_t)b * qblocks + qb) * num_leaves;
     unsigned long long useful = 0, listed = 0;
     // record: s0 = (lo0,lo1) (lo3,lo4) (lo6,lo8) (hi0,hi1)   s1 = (hi2,hi3) (hi4,hi5) (hi7,leaf) node
-    auto outside = [&](const uint4& s0, const uint4& s1) {
-        float out = max3(lo_minus(s0.x, rx), minus_lo(rx, s0.w), hi_minus(s0.x, ry));
-        out = max3(out, minus_hi(ry, s0.w), lo_minus(s0.y, r4));
-        out = max3(out, minus_hi(r4, s1.x), hi_minus(s0.y, r5));
-        out = max3(out, minus_lo(r5, s1.y), minus_lo(rz, s1.x));
-        out = max3(out, minus_hi(r6, s1.y), lo_minus(s0.z, r7));
-        return max3(out, minus_lo(r8, s1.z), hi_minus(s0.z, r9));
+    // > 0: outside some slab.  x1 .. : the value set against the slab's LOWER bound, x0 .. : against its UPPER bound (a
+    // ray's value twice; the block's largest and smallest)
+    auto outside13 = [&](const uint4& s0, const uint4& s1, float x1, float x0, float y1, float y0, float p1, float p0,
+                         float m1, float m0, float z0, float xz0, float xz1, float yz0, float yz1) {
+        float out = max3(lo_minus(s0.x, x1), minus_lo(x0, s0.w), hi_minus(s0.x, y1));
+        out = max3(out, minus_hi(y0, s0.w), lo_minus(s0.y, p1));
+        out = max3(out, minus_hi(p0, s1.x), hi_minus(s0.y, m1));
+        out = max3(out, minus_lo(m0, s1.y), minus_lo(z0, s1.x));
+        out = max3(out, minus_hi(xz0, s1.y), lo_minus(s0.z, xz1));
+        return max3(out, minus_lo(yz0, s1.z), hi_minus(s0.z, yz1));
     };
+    auto outside = [&](const uint4& s0, const uint4& s1) {
+        return outside13(s0, s1, rx, rx, ry, ry, r4, r4, r5, r5, rz, r6, r7, r8, r9);
+    };
+    int nslots = 0;                             // one wavefront: the list's length in a (scalar) register, no LDS atomic
     auto emit = [&](const uint4& s1, unsigned long long hit) {
         if (!hit) return;
         const int leaf = (int)(s1.z >> 16), nd = (int)s1.w;
+        if (kWaves == 1) ++nslots;
         if (lane == 0) {
-            const int slot = atomicAdd(&slots, 1);
+            const int slot = kWaves == 1 ? nslots - 1 : atomicAdd(&slots, 1);
             list[slot] = RayEntry{leaf, nd, (uint32_t)hit, (uint32_t)(hit >> 32)};
             atomicAdd(&leaf_cnt[(size_t)b * num_leaves + leaf], __builtin_popcountll(hit));
         }
@@ -523,12 +531,8 @@ __global__ __launch_bounds__(64 * kWaves) void ray_near_kernel(
         const int base = (round * kWaves + wave) * 64;
         const Chunk c = nxt;
         if (base + 64 * kWaves < num_leaves) nxt = load_chunk(base + 64 * kWaves);
-        // order of v[]: lo0 lo1 lo3 lo4 lo6 lo8 | hi0 hi1 hi2 hi3 hi4 hi5 hi7
-        // (& not &&: no compare may gate a load -- with short-circuit tests the compiler fetched the 13 values in four
-        // dependent rounds)
-        const bool pass = (base + lane < num_leaves) & (bx0 <= c.v[6]) & (bx1 >= c.v[0]) & (by0 <= c.v[7]) & (by1 >= c.v[1]) &
-                          (b40 <= c.v[9]) & (b41 >= c.v[2]) & (b50 <= c.v[10]) & (b51 >= c.v[3]) & (bz0 <= c.v[8]) &
-                          (b60 <= c.v[11]) & (b71 >= c.v[4]) & (b80 <= c.v[12]) & (b91 >= c.v[5]);
+        const bool pass = (base + lane < num_leaves) &
+                          !(outside13(c.r0, c.r1, bx1, bx0, by1, by0, b41, b40, b51, b50, bz0, b60, b71, b80, b91) > 0.0f);
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
         if (mask) {
             int at = 0;
@@ -542,6 +546,24 @@ __global__ __launch_bounds__(64 * kWaves) void ray_near_kernel(
         sync();
         const int n = kWaves > 1 ? queued[round & 1] : __builtin_popcountll(mask);
         if (kWaves > 1 && threadIdx.x == 0) queued[(round + 1) & 1] = 0;    // (last read before this round's first barrier)
+        if (kWaves == 1) {
+            // one wavefront per block (large batches): FOUR records per trip -- the trip is a dependent chain (LDS read ->
+            // 19 vector instructions -> ballot -> branch) and the blocks through the trunk have ~200 of them
+            for (int i = 0; i < n; i += 4) {
+                const int k1 = min(i + 1, n - 1), k2 = min(i + 2, n - 1), k3 = min(i + 3, n - 1);
+                const uint4 a0 = queue[i][0], a1 = queue[i][1], c0 = queue[k1][0], c1 = queue[k1][1];
+                const uint4 d0 = queue[k2][0], d1 = queue[k2][1], f0 = queue[k3][0], f1 = queue[k3][1];
+                const float out_a = outside(a0, a1), out_c = outside(c0, c1), out_d = outside(d0, d1), out_f = outside(f0, f1);
+                const unsigned long long hit_a = __builtin_amdgcn_ballot_w64(real && !(out_a > 0.0f));
+                const unsigned long long hit_c = __builtin_amdgcn_ballot_w64(real && !(out_c > 0.0f) && i + 1 < n);
+                const unsigned long long hit_d = __builtin_amdgcn_ballot_w64(real && !(out_d > 0.0f) && i + 2 < n);
+                const unsigned long long hit_f = __builtin_amdgcn_ballot_w64(real && !(out_f > 0.0f) && i + 3 < n);
+                emit(a1, hit_a);
+                emit(c1, hit_c);
+                emit(d1, hit_d);
+                emit(f1, hit_f);
+            }
+        } else
         for (int i = wave * 2; i < n; i += kWaves * 2) {
             const int k = i + 1 < n ? i + 1 : i;
             const uint4 a0 = queue[i][0], a1 = queue[i][1], c0 = queue[k][0], c1 = queue[k][1];
@@ -554,7 +576,7 @@ __global__ __launch_bounds__(64 * kWaves) void ray_near_kernel(
         sync();
     }
     if (stats && lane == 0) { atomicAdd(stats + 1, useful); atomicAdd(stats + 2, listed); }
-    if (threadIdx.x == 0) list_len[(size_t)b * qblocks + qb] = slots;
+    if (threadIdx.x == 0) list_len[(size_t)b * qblocks + qb] = kWaves == 1 ? nslots : slots;
 }
 
 // Per body: where every leaf's rays start in the pair list (exclusive scan of the counts) and the table of tiles
