@@ -653,74 +653,72 @@ __global__ __launch_bounds__(64) void ray_fill_kernel(
     }
 }
 
-// ray_tiles_kernel + ray_fill_kernel in one launch: kFillSplit workgroups of 256 threads per body.  Each scans the
-// body's counts for itself (430 numbers); the first one writes the tile table; the body's entries -- all its query
-// blocks' lists laid end to end through a prefix of their lengths -- are dealt out 64 at a time to the wavefronts of all
-// of them.  (As two launches with one wavefront per query block: 10 + 31 us at batch 64 and 7 + 14 us at batch 8, most
-// of it the launch rate of 6912 one-wavefront workgroups and three dependent global round trips in each; as ONE
-// workgroup per body, fill counters in LDS: 61 us -- the write loop below is ~25 instructions per entry and a
-// body's 4300 entries kept one CU busy that long.  Beside the search the kernel takes ~75 us whether a body has 2, 4,
-// 8, 16 or 32 workgroups: step 0.465 ... 0.472 ms, noise.)
-constexpr int kTilesFillBlock = 256, kFillSplit = 16, kFillMaxBlocks = 2048;
+// ray_tiles_kernel + ray_fill_kernel in one launch: kFillSplit one-wave workgroups per body.  Each scans the body's
+// counts for itself (430 numbers, seven per lane and a wavefront scan); the first one writes the tile table; the body's
+// entries -- all its query blocks' lists laid end to end through a prefix of their lengths -- are dealt out 64 at a time.
+// (As two launches with one wavefront per query block: 10 + 31 us at batch 64 and 7 + 14 us at batch 8, most of it the
+// launch rate of 6912 one-wavefront workgroups and three dependent global round trips in each; as ONE workgroup per body,
+// fill counters in LDS: 61 us -- the write loop below is ~25 instructions per entry and a body's 4300 entries kept one CU
+// busy that long.)
+// ONE-wavefront workgroups: beside the nearest-vertex search -- 55 k one-wave workgroups that take every wave slot as it
+// falls free -- a workgroup of four wavefronts waits until a CU has four free slots AT ONCE: the 256-thread form of
+// this kernel took 24 us alone and 77-95 us in the replayed step, on the chain in front of the crossing kernel.
+constexpr int kTilesFillBlock = 64, kFillSplit = 64, kFillMaxBlocks = 2048;
+__device__ __forceinline__ int wave_inclusive_scan(int v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(v, d, 64);
+        if (lane >= d) v += up;
+    }
+    return v;
+}
 __global__ __launch_bounds__(kTilesFillBlock) void ray_tiles_fill_kernel(
     const int32_t* __restrict__ leaf_cnt, const TreeNode* __restrict__ nodes, const int32_t* __restrict__ leaf_nodes,
     int num_leaves, int cap, int max_tiles, int fallback_tiles, RayTile* __restrict__ tiles, RayBody* __restrict__ body,
     const RayEntry* __restrict__ lists, const int32_t* __restrict__ list_len, int qblocks, int32_t* __restrict__ leaf_fill,
     int32_t* __restrict__ pairs)
 {
-    // a chain of short dependent steps on few wavefronts: beside the nearest-vertex search (six busy wavefronts per SIMD
-    // on the other stream) its wavefronts got a seventh of the issue slots and the kernel took 100 us instead of 24 --
-    // ask for them first
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(3);                  // a chain of short dependent steps: ask for the issue slots first
     extern __shared__ int32_t dyn[];                // off[num_leaves] | blk[qblocks + 1]
     int32_t* off_s = dyn;
     int32_t* blk = dyn + num_leaves;
-    __shared__ int sp[kTilesFillBlock], st[kTilesFillBlock], sq[kTilesFillBlock];
-    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63;
-    const int per = (num_leaves + kTilesFillBlock - 1) / kTilesFillBlock;
-    const int l0 = min(t * per, num_leaves), l1 = min(l0 + per, num_leaves);
-    const int perq = (qblocks + kTilesFillBlock - 1) / kTilesFillBlock;
-    const int q0 = min(t * perq, qblocks), q1 = min(q0 + perq, qblocks);
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int per = (num_leaves + 63) / 64;
+    const int l0 = min(lane * per, num_leaves), l1 = min(l0 + per, num_leaves);
+    const int perq = (qblocks + 63) / 64;
+    const int q0 = min(lane * perq, qblocks), q1 = min(q0 + perq, qblocks);
     const int32_t* cnt = leaf_cnt + (size_t)b * num_leaves;
     const int32_t* len = list_len + (size_t)b * qblocks;
     int npairs = 0, ntile = 0, nent = 0;
-    for (int l = l0; l < l1; ++l) { npairs += cnt[l]; ntile += (cnt[l] + 63) >> 6; }
+    for (int l = l0; l < l1; ++l) { const int c = cnt[l]; npairs += c; ntile += (c + 63) >> 6; }
     for (int q = q0; q < q1; ++q) nent += len[q];
-    sp[t] = npairs;
-    st[t] = ntile;
-    sq[t] = nent;
-    __syncthreads();
-    for (int d = 1; d < kTilesFillBlock; d <<= 1) {          // inclusive scans
-        const int ap = t >= d ? sp[t - d] : 0, at = t >= d ? st[t - d] : 0, aq = t >= d ? sq[t - d] : 0;
-        __syncthreads();
-        sp[t] += ap;
-        st[t] += at;
-        sq[t] += aq;
-        __syncthreads();
-    }
-    const int total_pairs = sp[kTilesFillBlock - 1], total_tiles = st[kTilesFillBlock - 1], total = sq[kTilesFillBlock - 1];
+    const int sp = wave_inclusive_scan(npairs, lane), st = wave_inclusive_scan(ntile, lane), sq = wave_inclusive_scan(nent, lane);
+    const int total_pairs = __builtin_amdgcn_readlane(sp, 63), total_tiles = __builtin_amdgcn_readlane(st, 63);
+    const int total = __builtin_amdgcn_readlane(sq, 63);
     const bool overflow = total_pairs > cap || total_tiles > max_tiles;
-    if (t == 0 && blockIdx.y == 0) body[b] = RayBody{overflow ? fallback_tiles : total_tiles, overflow ? 1 : 0};
+    if (lane == 0 && blockIdx.y == 0) body[b] = RayBody{overflow ? fallback_tiles : total_tiles, overflow ? 1 : 0};
     if (overflow) return;
     {
-        int off = sp[t] - npairs, tile = st[t] - ntile;
+        int off = sp - npairs, tile = st - ntile;
         RayTile* out = tiles + (size_t)b * max_tiles;
         for (int l = l0; l < l1; ++l) {
+            const int c = cnt[l];
             off_s[l] = off;
             if (blockIdx.y == 0) {
                 const TreeNode nd = nodes[leaf_nodes[l]];
-                for (int k = 0; k < cnt[l]; k += 64) out[tile++] = RayTile{nd.ex_off, nd.ex_len, off + k, min(64, cnt[l] - k)};
+                for (int k = 0; k < c; k += 64) out[tile++] = RayTile{nd.ex_off, nd.ex_len, off + k, min(64, c - k)};
             }
-            off += cnt[l];
+            off += c;
         }
-        int ent = sq[t] - nent;
+        int ent = sq - nent;
         for (int q = q0; q < q1; ++q) { blk[q] = ent; ent += len[q]; }
-        if (t == 0) blk[qblocks] = total;
+        if (lane == 0) blk[qblocks] = total;
     }
     __syncthreads();
     int32_t* fill = leaf_fill + (size_t)b * num_leaves;
     int32_t* out = pairs + (size_t)b * cap;
-    for (int base = (blockIdx.y * (kTilesFillBlock / 64) + (t >> 6)) * 64; base < total; base += (int)gridDim.y * kTilesFillBlock) {
+    for (int base = (int)blockIdx.y * 64; base < total; base += (int)gridDim.y * 64) {
         // lanes over entries: reserve the entry's range in its leaf (64 atomics in flight)
         const int g = base + lane;
         RayEntry e = RayEntry{0, 0, 0u, 0u};
