@@ -41,7 +41,7 @@ torch.cuda.synchronize()
 L.tuch_debug_scan_counts(out, 0)
 names = ['wavefronts', 'leaf-per-lane trips', 'candidate leaves (box-box)', 'leaves reaching rows', 'trips of 8 rows',
          '  skipped by mask', '  taking the update branch', 'trips of 4 rows', '  skipped by mask', '  taking the update branch',
-         'wavefronts returning at once', 'candidates passing 16-column sub-blocks', 'candidates passing 8-column sub-blocks']
+         'wavefronts returning at once', 'candidates passing 16-column sub-blocks', 'candidates passing 8-column sub-blocks', 'trips of 8 with all mask words = all ones', 'trips of 8 with all reach lanes allowed']
 c = list(out)
 for n, v in zip(names, c):
     print('%-32s %12d  per body %10.1f' % (n, v, v / B))

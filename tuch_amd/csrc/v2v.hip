@@ -603,6 +603,10 @@ __device__ __forceinline__ void v2v_rows_packed(Column& c, const float* __restri
         for (int u = 0; u < 24; ++u) v[u] = pgo[u];
         asm volatile("" :: "s"(v[0]), "s"(v[8]), "s"(v[16]));
         SCAN_COUNT(4);
+#ifdef TUCH_SCAN_COUNTS
+        if ((k0[0] & k0[1] & k0[2] & k0[3] & k0[4] & k0[5] & k0[6] & k0[7]) == ~0ull) SCAN_COUNT(13);       // no mask needed at all
+        if (((k0[0] & k0[1] & k0[2] & k0[3] & k0[4] & k0[5] & k0[6] & k0[7]) & reach) == reach) SCAN_COUNT(14);  // ... for the lanes in reach
+#endif
         // (without this test -- nine scalar instructions per trip against 37 vector instructions for one trip in eight --
         // the kernel takes the same time: 129.5 against 127.8 us)
         if (((k0[0] | k0[1] | k0[2] | k0[3] | k0[4] | k0[5] | k0[6] | k0[7]) & reach) == 0) { SCAN_COUNT(5); continue; }
