@@ -58,9 +58,10 @@ FLOP_PER_V2V_PAIR = 8
 FLOP_PER_STRIP_ELEMENT = 41
 # executed arithmetic of the ray-crossing walk per (ray, strip element): 3 sub, 2 edge functions (4 mul + 2 sub, never
 # contracted), depth determinant (1 mul + 2 fma = 5), min3 + max3 (2 + 2), min, max, 1 mul for the tie test = 21 FP32
-# operations in 26 VALU instructions (29 with the per-segment counters; SQ_INSTS_VALU / element, profiles/r02_m_pmc_sq.txt)
+# operations in 20 VALU instructions since round 4 (packed subtraction and packed edge-function products, the count as one
+# multiply-add; 21.0 = SQ_INSTS_VALU / element with the kernel's prologues, profiles/r04_z_pmc_sq.txt; round 2: 29)
 OPS_PER_RAY_ELEMENT = 21
-VALU_INSTR_PER_RAY_ELEMENT = 29
+VALU_INSTR_PER_RAY_ELEMENT = 21
 PEAK_FP32_VECTOR_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs x 16 lanes x 2 (FMA) x 2 (packed) x 2.4 GHz
 # what a stream of plain (non-packed) wave64 instructions can issue: 256 x 4 SIMDs x 16 lanes x 2.4 GHz lane-instructions/s
 # (one wave64 VALU instruction occupies its SIMD for 4 cycles: 4.1-4.5 measured, tools/ubench/valu_rate.hip -fno-slp-vectorize)
@@ -527,9 +528,9 @@ def rooflines(p, batch):
               'reference_formulation_flop_per_launch': ref_flops,
               'reference_formulation_equivalent_TFLOPs': round(ref_flops / t_w / 1e12, 1),
               'algorithmic_bytes_per_launch': batch * (v * 12 + v) + f * 12,
-              'note': 'the whole launch group is timed; ray_leaf_kernel alone is ~0.6 of it and runs at ~0.8 of the plain '
-                      'issue peak (profiles/r02_m_*): packed FP32 would double that peak but the edge functions do not '
-                      'pair up without register moves'}
+              'note': 'the whole launch group is timed; ray_leaf_kernel alone is ~0.5 of it (98 of ~200 us) and keeps the vector '
+                      'units ~0.75 busy (valu_busy): its two edge-function products are one packed multiplication, the '
+                      'rest is plain FP32 / integer work the packed forms do not cover (min3 / max3, compares)'}
     return roof, inside, verts, model
 
 
