@@ -676,16 +676,18 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(
         const float* gp = gA_part + ((size_t)b * skin_blocks * 32 + t / 12) * 16 + t % 12;
         const float* gq = gA_part + ((size_t)b * skin_blocks * 32 + (t + 256) / 12) * 16 + (t + 256) % 12;
         const bool second = t + 256 < kJoints * 12;
-        for (int s0 = 0; s0 < skin_blocks; s0 += 9) {
-            float u0[9], u1[9];
+        constexpr int kInFlight = 27;            // a round of loads is a full memory latency: 108 slices = 4 rounds
+        for (int s0 = 0; s0 < skin_blocks; s0 += kInFlight) {
+            float u0[kInFlight], u1[kInFlight];
 #pragma unroll
-            for (int u = 0; u < 9; ++u) {
+            for (int u = 0; u < kInFlight; ++u) {
                 const bool in = s0 + u < skin_blocks;
                 u0[u] = in ? gp[(size_t)(s0 + u) * 512] : 0.f;
                 u1[u] = in && second ? gq[(size_t)(s0 + u) * 512] : 0.f;
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < 9; ++u) { ga0 += u0[u]; ga1 += u1[u]; }
+            for (int u = 0; u < kInFlight; ++u) { ga0 += u0[u]; ga1 += u1[u]; }
         }
     }
     if (t < kJoints * 9) {
@@ -697,6 +699,24 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(
         if (pose2rot) aa_v = pose_joint(pose, b, t / 3, 3)[t % 3];
     }
     if (t < kJoints) { par_v = parents[t]; dep_v = parents[kJoints + t]; }
+    // what the last step needs of this joint's parameters -- the prior's share of the gradient, Adam's moments and the
+    // parameters themselves -- is requested here too (behind the chain each was one more memory latency)
+    float add_v[3] = {0.f, 0.f, 0.f}, p_v[3] = {0.f, 0.f, 0.f}, m_v[3] = {0.f, 0.f, 0.f}, v_v[3] = {0.f, 0.f, 0.f};
+    float *adam_p = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+    if (pose2rot && t < kJoints) {
+        if (t > 0 && g_pose.body_add) {
+            const float* add = g_pose.body_add + (size_t)b * g_pose.body_add_stride + (size_t)(t - 1) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) add_v[c] = add[c];
+        }
+        if (adam.step) {
+            adam_p = t == 0 ? adam.root + (size_t)b * adam.root_stride : adam.body + (size_t)b * adam.body_stride + (size_t)(t - 1) * 3;
+            adam_m = t == 0 ? adam.m_root + (size_t)b * 3 : adam.m_body + ((size_t)b * (kJoints - 1) + (t - 1)) * 3;
+            adam_v = t == 0 ? adam.v_root + (size_t)b * 3 : adam.v_body + ((size_t)b * (kJoints - 1) + (t - 1)) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { p_v[c] = adam_p[c]; m_v[c] = adam_m[c]; v_v[c] = adam_v[c]; }
+        }
+    }
     if (t < kBetas * kJoints) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) jsd[c] = J_shapedirs[((t % kJoints) * 3 + c) * kBetas + t / kJoints];
@@ -818,18 +838,17 @@ __global__ __launch_bounds__(256) void pose_bwd_kernel(
             float ga[3];
             rodrigues_bwd(sAA[t], g, ga);
             float* dst = pose_joint(g_pose, b, t, 3);
-            const float* add = t > 0 && g_pose.body_add ? g_pose.body_add + (size_t)b * g_pose.body_add_stride + (size_t)(t - 1) * 3 : nullptr;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) ga[c] += add ? add[c] : 0.0f;
+            for (int c = 0; c < 3; ++c) ga[c] += add_v[c];
 #pragma unroll
             for (int c = 0; c < 3; ++c) dst[c] = ga[c];
             if (adam.step) {                    // torch.optim.Adam's update of this joint's three parameters (adam.hip)
-                float* p = t == 0 ? adam.root + (size_t)b * adam.root_stride : adam.body + (size_t)b * adam.body_stride + (size_t)(t - 1) * 3;
-                float* m = t == 0 ? adam.m_root + (size_t)b * 3 : adam.m_body + ((size_t)b * (kJoints - 1) + (t - 1)) * 3;
-                float* v = t == 0 ? adam.v_root + (size_t)b * 3 : adam.v_body + ((size_t)b * (kJoints - 1) + (t - 1)) * 3;
                 const AdamScalars sc = adam_scalars(adam.lr, adam.beta1, adam.beta2, adam.eps, adam_t);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) adam_update(p[c], m[c], v[c], ga[c], sc);
+                for (int c = 0; c < 3; ++c) {
+                    adam_update(p_v[c], m_v[c], v_v[c], ga[c], sc);
+                    adam_p[c] = p_v[c]; adam_m[c] = m_v[c]; adam_v[c] = v_v[c];
+                }
             }
         } else {
             float* dst = pose_joint(g_pose, b, t, 9);
