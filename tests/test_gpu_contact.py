@@ -190,6 +190,39 @@ def test_region_pair_min(tag):
         assert_close(grad[b], r['grad_r2r'], 1e-4, 1e-6, 'r2r grad')
 
 
+@pytest.mark.parametrize('tag', ['medium', 'ico_medium'])
+@pytest.mark.parametrize('masked', [True, False])
+def test_region_pairs_selected_form_equals_the_all_pairs_form(tag, masked):
+    """The few-pairs kernel (wavefronts find their share of a body's selected pairs in its row of `select`; tasks of 64
+    rows x a quarter of the columns, merged with atomics) against the all-pairs kernel (one workgroup per pair): the
+    same minima and the same (first) index pairs, bit for bit -- with more than 256 pairs (the select row is read 256
+    bytes at a time), bodies with none, one, a few and ALL pairs selected."""
+    from tuch_amd.ops import ContactModel
+    g, gm = golden(tag), golden_mask(tag)
+    regions, pairs = gio.unpack_regions(g)
+    names = list(regions.keys())
+    base = np.asarray([[names.index(a), names.index(b)] for a, b in pairs], np.int64)
+    reps = -(-300 // len(base))
+    pair_idx = np.concatenate([base, base[:, ::-1]] * reps)[:300]           # 300 pairs, both orders of every pair
+    model = ContactModel(g['faces'], gm, None, [regions[n] for n in names], pair_idx, device=dev())
+    verts = torch.tensor(np.concatenate([g['verts']] * 3)[:5], device=dev())
+    B, P = verts.shape[0], len(pair_idx)
+    rng = np.random.default_rng(5)
+    sel = np.zeros((B, P), bool)
+    sel[1, 299] = True
+    sel[2, rng.choice(P, 7, replace=False)] = True
+    sel[3] = True
+    sel[4, rng.choice(P, 40, replace=False)] = True
+    sel_t = torch.tensor(sel, device=dev())
+    out_all, ij_all = model.region_pair_min(verts, masked=masked)
+    out_sel, ij_sel = model.region_pair_min(verts, select=sel_t, masked=masked)
+    out_all, ij_all, out_sel, ij_sel = (t.cpu().numpy() for t in (out_all, ij_all, out_sel, ij_sel))
+    assert np.array_equal(out_sel[sel], out_all[sel])
+    finite = sel & np.isfinite(out_all)
+    assert np.array_equal(ij_sel[finite], ij_all[finite])
+    assert np.all(out_sel[~sel] == 0) or np.all(~np.isfinite(out_sel[~sel]) | (out_sel[~sel] == 0))
+
+
 def _fitting_inputs(g, full):
     from tuch_amd.smplify.prior import MaxMixturePrior
     d = dev()
