@@ -680,9 +680,10 @@ __global__ __launch_bounds__(kTilesFillBlock) void ray_tiles_fill_kernel(
     int32_t* __restrict__ pairs)
 {
     __builtin_amdgcn_s_setprio(3);                  // a chain of short dependent steps: ask for the issue slots first
-    extern __shared__ int32_t dyn[];                // off[num_leaves] | blk[qblocks + 1]
+    extern __shared__ int32_t dyn[];                // off[num_leaves] | tile[num_leaves] | blk[qblocks + 1]
     int32_t* off_s = dyn;
-    int32_t* blk = dyn + num_leaves;
+    int32_t* tile_s = dyn + num_leaves;
+    int32_t* blk = dyn + 2 * num_leaves;
     const int b = blockIdx.x, lane = threadIdx.x;
     const int per = (num_leaves + 63) / 64;
     const int l0 = min(lane * per, num_leaves), l1 = min(l0 + per, num_leaves);
@@ -701,21 +702,27 @@ __global__ __launch_bounds__(kTilesFillBlock) void ray_tiles_fill_kernel(
     if (overflow) return;
     {
         int off = sp - npairs, tile = st - ntile;
-        RayTile* out = tiles + (size_t)b * max_tiles;
         for (int l = l0; l < l1; ++l) {
             const int c = cnt[l];
             off_s[l] = off;
-            if (blockIdx.y == 0) {
-                const TreeNode nd = nodes[leaf_nodes[l]];
-                for (int k = 0; k < c; k += 64) out[tile++] = RayTile{nd.ex_off, nd.ex_len, off + k, min(64, c - k)};
-            }
+            tile_s[l] = tile;
             off += c;
+            tile += (c + 63) >> 6;
         }
         int ent = sq - nent;
         for (int q = q0; q < q1; ++q) { blk[q] = ent; ent += len[q]; }
         if (lane == 0) blk[qblocks] = total;
     }
     __syncthreads();
+    // the tile table: every workgroup of the body writes the tiles of a few leaves (one leaf per lane: two dependent loads
+    // and a short loop) -- written by the body's first workgroup alone, seven leaves per lane one after the other, it was
+    // the longest chain in the launch
+    for (int l = (int)blockIdx.y + (int)gridDim.y * lane; l < num_leaves; l += (int)gridDim.y * 64) {
+        const TreeNode nd = nodes[leaf_nodes[l]];
+        const int c = cnt[l], off = off_s[l];
+        RayTile* out = tiles + (size_t)b * max_tiles + tile_s[l];
+        for (int k = 0; k < c; k += 64) *out++ = RayTile{nd.ex_off, nd.ex_len, off + k, min(64, c - k)};
+    }
     int32_t* fill = leaf_fill + (size_t)b * num_leaves;
     int32_t* out = pairs + (size_t)b * cap;
     for (int base = (int)blockIdx.y * 64; base < total; base += (int)gridDim.y * 64) {
@@ -1685,7 +1692,7 @@ static int launch_ray_counts(const tuch_contact_model* m, const RayLayout& l, co
         hipLaunchKernelGGL((ray_near_kernel<kVerts, 1>), dim3(l.qblocks, B), dim3(64), 0, s, queries, nodes,
                            (const float*)(ws + l.bounds), m->tree_nodes, L, qperm, counts, Q, l.qblocks, lists, list_len,
                            leaf_cnt, stats);
-    const size_t tf_lds = ((size_t)L + l.qblocks + 1) * sizeof(int32_t);
+    const size_t tf_lds = (2 * (size_t)L + l.qblocks + 1) * sizeof(int32_t);
     if (l.qblocks <= kFillMaxBlocks && tf_lds <= 48u * 1024)
         hipLaunchKernelGGL(ray_tiles_fill_kernel, dim3(B, kFillSplit), dim3(kTilesFillBlock), tf_lds, s, (const int32_t*)leaf_cnt,
                            nodes, leaf_nodes, L, l.cap, l.max_tiles, l.qblocks * kFallbackChunks, tiles, body,
