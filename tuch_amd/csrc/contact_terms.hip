@@ -301,6 +301,22 @@ __global__ __launch_bounds__(256) void stage2_bwd_kernel(
     atomicAdd(gq + 0, -c * dx); atomicAdd(gq + 1, -c * dy); atomicAdd(gq + 2, -c * dz);
 }
 
+#ifdef TUCH_STAGE2_CLOCKS
+// diagnostic build only (tools/diag/stage2_clocks.py): s_memrealtime stamps (100 MHz) of block (0, 0) and of the block that
+// arrives last: [0] start, [1] loads done, [2] atomics issued, [3] block sums, [4] ticket taken; last block: [5] start of the
+// final reduction, [6] end
+__device__ unsigned long long g_stage2_clocks[16];
+#define STAGE2_CLOCK(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_stage2_clocks[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define STAGE2_CLOCK_LAST(i) do { if (threadIdx.x == 0) g_stage2_clocks[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int tuch_debug_stage2_clocks(unsigned long long* out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stage2_clocks), sizeof(unsigned long long) * 16) == hipSuccess ? TUCH_OK : TUCH_ERR_HIP;
+}
+#else
+#define STAGE2_CLOCK(i) do { } while (0)
+#define STAGE2_CLOCK_LAST(i) do { } while (0)
+#endif
+
 // Forward AND the unit-seed backward of the tail in ONE launch (stage2_finish + stage2_bwd with g = 1): the objective is
 // the root of the fit's autograd graph, its upstream gradient is the constant 1 (loss.backward()), so the vertex
 // gradient can be written while the sums are formed -- one kernel and one dependent launch less in the serial tail of
@@ -334,7 +350,6 @@ __global__ __launch_bounds__(kFusedBlock) void stage2_fused_kernel(
     const int32_t* __restrict__ region_vidx, const int32_t* __restrict__ pairs,
     long long* __restrict__ grad_fixed)     // deterministic mode: [B,N,3] 64-bit fixed-point accumulators (zeroed) instead of grad
 {
-    __shared__ float smem[kFusedBlock / 64];
     __shared__ bool last;
     const int s = blockIdx.x, b = blockIdx.y;
     const bool valid = !body_valid || body_valid[b];
@@ -346,6 +361,30 @@ __global__ __launch_bounds__(kFusedBlock) void stage2_fused_kernel(
         if (fb) { fixed_add(fb + 3 * (size_t)at, x); fixed_add(fb + 3 * (size_t)at + 1, y); fixed_add(fb + 3 * (size_t)at + 2, z); }
         else { atomicAdd(gb + 3 * (size_t)at, x); atomicAdd(gb + 3 * (size_t)at + 1, y); atomicAdd(gb + 3 * (size_t)at + 2, z); }
     };
+    // What the PARTNERS receive meets in LDS first: a penetrating region's vertices share few partners (20 to 40 vertices
+    // of a body scatter into the same one: tools/diag/partner_degree.py), and atomics on one address queue behind each
+    // other in the L2 -- the block that arrived last was 19 us behind the first (tools/diag/stage2_clocks.py).  A
+    // direct-mapped table of kPartnerSlots partners per block; a partner whose slot is taken goes to memory as before.
+    constexpr int kPartnerSlots = 256;
+    __shared__ int p_tag[kPartnerSlots];
+    __shared__ float p_acc[kPartnerSlots][3];
+    const bool in_lds = gb && !fb;
+    if (in_lds) {
+        for (int k = threadIdx.x; k < kPartnerSlots; k += kFusedBlock) { p_tag[k] = -1; p_acc[k][0] = p_acc[k][1] = p_acc[k][2] = 0.0f; }
+        __syncthreads();
+    }
+    auto add3_partner = [&](int at, float x, float y, float z) {
+        if (in_lds) {
+            const int slot = at & (kPartnerSlots - 1);
+            const int old = atomicCAS(&p_tag[slot], -1, at);
+            if (old == -1 || old == at) {
+                atomicAdd(&p_acc[slot][0], x); atomicAdd(&p_acc[slot][1], y); atomicAdd(&p_acc[slot][2], z);
+                return;
+            }
+        }
+        add3(at, x, y, z);
+    };
+    STAGE2_CLOCK(0);
     float in_sum = 0.0f, ex_sum = 0.0f, r_sum = 0.0f;
     const int per = (N + kFusedSplits - 1) / kFusedSplits;
     const int beg = s * per, end = min(beg + per, N);
@@ -367,6 +406,10 @@ __global__ __launch_bounds__(kFusedBlock) void stage2_fused_kernel(
 #pragma unroll
                 for (int c = 0; c < 3; ++c) { xi[u][c] = pb[3 * i + c]; xp[u][c] = pb[3 * pr[u] + c]; }
             }
+#ifdef TUCH_STAGE2_CLOCKS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            STAGE2_CLOCK(1);
+#endif
 #pragma unroll
             for (int u = 0; u < kPer; ++u) {
                 const int i = i0 + u * kFusedBlock;
@@ -379,10 +422,16 @@ __global__ __launch_bounds__(kFusedBlock) void stage2_fused_kernel(
                 if (want && d > 0.0f && t.dd != 0.0f) {
                     const float c = contact_scale * t.dd / d;
                     add3(i, c * dx, c * dy, c * dz);
-                    add3(pr[u], -c * dx, -c * dy, -c * dz);
+                    add3_partner(pr[u], -c * dx, -c * dy, -c * dz);
                 }
             }
         }
+    }
+    STAGE2_CLOCK(2);
+    if (in_lds) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < kPartnerSlots; k += kFusedBlock)
+            if (p_tag[k] >= 0) add3(p_tag[k], p_acc[k][0], p_acc[k][1], p_acc[k][2]);
     }
     if (s == 0 && (r2r || pair_keys)) {
         for (int p = threadIdx.x; p < P; p += kFusedBlock) {
@@ -414,18 +463,33 @@ __global__ __launch_bounds__(kFusedBlock) void stage2_fused_kernel(
             }
         }
     }
-    const float a = block_sum_256(in_sum, smem);
-    const float c = block_sum_256(ex_sum, smem);
-    const float r = block_sum_256(r_sum, smem);
+    // the three sums together: one butterfly (the three values' steps interleave), one exchange through LDS -- one after
+    // the other they were three times six dependent shuffles and six barriers on the step's serial tail
+    STAGE2_CLOCK(7);
+    float a = in_sum, c = ex_sum, r = r_sum;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); c += __shfl_down(c, o, 64); r += __shfl_down(r, o, 64); }
+    __shared__ float sums3[kFusedBlock / 64][3];
+    if ((threadIdx.x & 63) == 0) { float* q = sums3[threadIdx.x >> 6]; q[0] = a; q[1] = c; q[2] = r; }
+    __syncthreads();
+    a = sums3[0][0] + sums3[1][0] + sums3[2][0] + sums3[3][0];
+    c = sums3[0][1] + sums3[1][1] + sums3[2][1] + sums3[3][1];
+    r = sums3[0][2] + sums3[1][2] + sums3[2][2] + sums3[3][2];
+    STAGE2_CLOCK(3);
     if (threadIdx.x == 0) {
         float* mine = share + ((size_t)b * kFusedSplits + s) * 3;
         __hip_atomic_store(mine + 0, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(mine + 1, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(mine + 2, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (two levels of tickets -- the last block of a body takes a ticket of the launch -- were slower, 20.3 against 17.1 us:
+        // it is not the 512 arrivals on one word that cost but the release in front of each, ~4.5 us per block on this
+        // multi-XCD part; the body's last block then pays it twice)
         last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)(gridDim.x * gridDim.y) - 1;
     }
     __syncthreads();
+    STAGE2_CLOCK(4);
     if (!last) return;
+    STAGE2_CLOCK_LAST(5);
     // bodies in order, a body's splits in order: the total does not depend on which block came last
     float acc = 0.0f;
     const int B = gridDim.y;
@@ -449,6 +513,7 @@ __global__ __launch_bounds__(kFusedBlock) void stage2_fused_kernel(
         const int n = B < kFusedBlock ? B : kFusedBlock;
         for (int k = 0; k < n; ++k) total += part[k];
         out[0] = total;
+        STAGE2_CLOCK_LAST(6);
         __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
