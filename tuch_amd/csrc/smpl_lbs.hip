@@ -32,6 +32,8 @@ struct tuch_smpl_model {
     float* J_template;         // [24*3]
     float* J_shapedirs;        // [24*3][10]
     float* weights;            // [V][24]
+    float* weights_t;          // [24][V]: the same by joint -- a wavefront's 64 vertices read one joint's weights from two
+                               // cache lines; by vertex (96 bytes apart) every load touched 64 lines
     float* Jrx;                // [9][V]  J_regressor_extra
     int32_t* parents;          // [48]: parent of joint k (-1 for the root) | depth of joint k in the tree
     int max_depth;
@@ -339,7 +341,7 @@ __device__ __forceinline__ void butterfly_level(float (&val)[32], int lane)
 // wavefronts through LDS: a fixed order); assemble_joints_kernel adds the blocks up.  As a kernel of its own (MFMA split-K over the finished vertices)
 // the regression was 21 us of pure latency in front of everything that waits for the joints.
 __global__ __launch_bounds__(kSkinBlock) void skin_kernel(
-    const float* __restrict__ v_posed, const float* __restrict__ A, const float* __restrict__ weights,
+    const float* __restrict__ v_posed, const float* __restrict__ A, const float* __restrict__ weights_t,
     const float* __restrict__ Jrx, int V, float* __restrict__ verts, float* __restrict__ xpart)
 {
     const int b = blockIdx.y;
@@ -347,13 +349,13 @@ __global__ __launch_bounds__(kSkinBlock) void skin_kernel(
     const bool real = v < V;
     const int vc = real ? v : V - 1;
     const float* Ab = A + (size_t)b * kJoints * 12;   // wave-uniform -> scalar loads
-    const float* w = weights + (size_t)vc * kJoints;
+    const float* w = weights_t + vc;                  // [24][V]: coalesced
     float T[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) T[e] = 0.f;
 #pragma unroll
     for (int j = 0; j < kJoints; ++j) {
-        const float wj = w[j];
+        const float wj = w[(size_t)j * V];
 #pragma unroll
         for (int e = 0; e < 12; ++e) T[e] = __builtin_fmaf(wj, Ab[j * 12 + e], T[e]);
     }
@@ -449,7 +451,8 @@ __global__ __launch_bounds__(kSkinBlock) void skin_bwd_kernel(
     const float* __restrict__ g_verts, const float* __restrict__ g_joints, const int32_t* __restrict__ joint_map,
     const float* __restrict__ Jrx,
     const int32_t* __restrict__ extra_ids, const float* __restrict__ v_posed, const float* __restrict__ A,
-    const float* __restrict__ weights, int V, float* __restrict__ g_vposed, float* __restrict__ gA_part)
+    const float* __restrict__ weights, const float* __restrict__ weights_t, int V, float* __restrict__ g_vposed,
+    float* __restrict__ gA_part)
 {
     __shared__ float sG[kSkinBlock][16];      // per vertex: g_v (x) [v_posed;1], 12 used
     __shared__ int sIds[kPicked];
@@ -472,13 +475,13 @@ __global__ __launch_bounds__(kSkinBlock) void skin_bwd_kernel(
 #pragma unroll
     for (int j = 0; j < kExtra; ++j) jr[j] = Jrx[(size_t)j * V + vc];
     const float* Ab = A + (size_t)b * kJoints * 12;
-    const float* w = weights + (size_t)vc * kJoints;
+    const float* w = weights_t + vc;                  // [24][V]: coalesced
     float T[9];
 #pragma unroll
     for (int e = 0; e < 9; ++e) T[e] = 0.f;
 #pragma unroll
     for (int j = 0; j < kJoints; ++j) {
-        const float wj = w[j];
+        const float wj = w[(size_t)j * V];
 #pragma unroll
         for (int e = 0; e < 9; ++e) T[e] = __builtin_fmaf(wj, Ab[j * 12 + e], T[e]);
     }
@@ -928,7 +931,7 @@ int upload(T** dst, const T* src, size_t count)
 extern "C" void tuch_smpl_model_destroy(tuch_smpl_model* m)
 {
     if (!m) return;
-    void* dev[] = {m->blend, m->J_template, m->J_shapedirs, m->weights, m->Jrx, m->parents, m->extra_ids, m->joint_map};
+    void* dev[] = {m->blend, m->J_template, m->J_shapedirs, m->weights, m->weights_t, m->Jrx, m->parents, m->extra_ids, m->joint_map};
     for (void* p : dev) tuch_table_free(p);
     free(m);
 }
@@ -987,6 +990,12 @@ extern "C" int tuch_smpl_model_create(tuch_smpl_model** out, int V, const float*
     if (rc == TUCH_OK) rc = upload(&m->J_template, jt.data(), jt.size());
     if (rc == TUCH_OK) rc = upload(&m->J_shapedirs, js.data(), js.size());
     if (rc == TUCH_OK) rc = upload(&m->weights, lbs_weights, (size_t)V * kJoints);
+    if (rc == TUCH_OK) {
+        std::vector<float> wt((size_t)kJoints * V);
+        for (int v = 0; v < V; ++v)
+            for (int j = 0; j < kJoints; ++j) wt[(size_t)j * V + v] = lbs_weights[(size_t)v * kJoints + j];
+        rc = upload(&m->weights_t, wt.data(), wt.size());
+    }
     if (rc == TUCH_OK) rc = upload(&m->Jrx, J_regressor_extra, (size_t)kExtra * V);
     if (rc == TUCH_OK) rc = upload(&m->parents, par, 2 * kJoints);
     if (rc == TUCH_OK) rc = upload(&m->extra_ids, extra_vertex_ids, kPicked);
@@ -1038,7 +1047,7 @@ extern "C" int tuch_smpl_forward_split(const tuch_smpl_model* m, const float* be
     hipLaunchKernelGGL(blend_kernel, dim3(ceil_div(m->N3, 16 * kBlendJ), l.fpad / 64), dim3(256), 0, s,
                        (const float*)feat, l.fpad, (const float*)m->blend, B, m->N3, v_posed);
     hipLaunchKernelGGL(skin_kernel, dim3(ceil_div(m->V, kSkinBlock), B), dim3(kSkinBlock), 0, s,
-                       (const float*)v_posed, (const float*)A, (const float*)m->weights, (const float*)m->Jrx, m->V, verts, partial);
+                       (const float*)v_posed, (const float*)A, (const float*)m->weights_t, (const float*)m->Jrx, m->V, verts, partial);
     hipLaunchKernelGGL(assemble_joints_kernel, dim3(B), dim3(256), 0, s, (const float*)world, (const float*)verts,
                        (const float*)partial, (const int32_t*)m->extra_ids, (const int32_t*)m->joint_map, m->V,
                        ceil_div(m->V, kSkinBlock), joints);
@@ -1111,7 +1120,7 @@ static int backward_impl(const tuch_smpl_model* m, const float* global_orient, i
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(skin_bwd_kernel, dim3(l.skin_blocks, B), dim3(kSkinBlock), 0, s, g_verts, g_joints,
                        (const int32_t*)m->joint_map, (const float*)m->Jrx, (const int32_t*)m->extra_ids, v_posed, A,
-                       (const float*)m->weights, m->V, g_vposed, gA_part);
+                       (const float*)m->weights, (const float*)m->weights_t, m->V, g_vposed, gA_part);
     hipLaunchKernelGGL(blend_bwd_kernel, dim3(l.feat_chunks, ceil_div(l.bpad / 16, kBlendBwdGroups), 14 / kBlendBwdTiles),
                        dim3(64 * kBlendBwdWaves), 0, s, (const float*)g_vposed, (const float*)m->blend, B, m->N3, l.bpad, feat_part);
     hipLaunchKernelGGL(pose_bwd_kernel, dim3(B), dim3(256), 0, s, (const float*)gA_part, l.skin_blocks,
