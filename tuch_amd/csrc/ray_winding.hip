@@ -1357,6 +1357,19 @@ __device__ __forceinline__ void seg_fused_caps(const float* __restrict__ vb, con
 // ENTRIES with the last arrival finishing (partial sums + fence + ticket per workgroup): 74 us.)
 constexpr int kSegOneBlock = 512, kSegOneWaves = kSegOneBlock / 64, kSegOneChunk = 256, kSegOneZ = 8;
 constexpr int kSegOneOwn = kSegFusedMaxQ / kSegOneZ;      // interior vertices a workgroup can own (groups of 64 dealt round-robin)
+#ifdef TUCH_SEG_CLOCKS
+// diagnostic build only (tools/diag/seg_clocks.py): s_memrealtime (100 MHz) of every block at the phase boundaries of
+// segment_one_kernel: [block][0] start, [1] interior vertices compacted, [2] caps, [3] entries walked, [4] end
+__device__ unsigned long long g_seg_clocks[8192][8];
+#define SEG_CLOCK(i) do { if (threadIdx.x == 0) { const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; if (blk < 8192) g_seg_clocks[blk][i] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+extern "C" int tuch_debug_seg_clocks(unsigned long long* out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_seg_clocks), sizeof(unsigned long long) * 8192 * 8) == hipSuccess ? TUCH_OK : TUCH_ERR_HIP;
+}
+#else
+#define SEG_CLOCK(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(kSegOneBlock) void segment_one_kernel(
     const float* __restrict__ verts, const uint8_t* __restrict__ body_flags, uint8_t* __restrict__ exterior,
     const int32_t* __restrict__ seg_q_off, const int32_t* __restrict__ seg_q_vidx,
@@ -1376,6 +1389,7 @@ __global__ __launch_bounds__(kSegOneBlock) void segment_one_kernel(
     const float* vb = verts + (size_t)b * V * 3;
     uint8_t* eb = exterior + (size_t)b * V;
     const int q_beg = seg_q_off[sg], nq = seg_q_off[sg + 1] - q_beg;
+    SEG_CLOCK(0);
     // A.  All of a thread's flags are requested before the first is looked at (the rounds of the scan then only touch LDS).
     {
         const uint8_t* fb = body_flags + (size_t)b * V;
@@ -1404,10 +1418,12 @@ __global__ __launch_bounds__(kSegOneBlock) void segment_one_kernel(
     const int n = s_n;
     const int groups = (n + 63) >> 6;
     const int mine = groups > z ? (groups - z + kSegOneZ - 1) / kSegOneZ : 0;      // own groups: z, z + Z, ...
+    SEG_CLOCK(1);
     if (mine == 0) return;
     // B.
     const int c_lo = cap_range[sg];
     seg_fused_caps<kSegOneWaves>(vb, cap_off, cap_vidx, c_lo, cap_range[sg + 1], s_caps);
+    SEG_CLOCK(2);
     // C.
     const P3 u_dir = {kFanX, kFanY, kFanZ};
     const P3 us = {shear_x(kFanX, kFanZ), shear_y(kFanY, kFanZ), kFanZ};
@@ -1479,6 +1495,7 @@ __global__ __launch_bounds__(kSegOneBlock) void segment_one_kernel(
         if (slices > 1) break;
     }
     __syncthreads();
+    SEG_CLOCK(3);
     // D. one thread per own interior vertex (all lanes of a wavefront stay: long link lists are shared out over it)
     auto pos = [&](int id, float (&o)[3]) {                // a vertex id of the segment tables (>= V: cap vertex)
         const float* p = id < V ? vb + 3 * (size_t)id : s_caps + 3 * (id - V - c_lo);
@@ -1551,6 +1568,7 @@ __global__ __launch_bounds__(kSegOneBlock) void segment_one_kernel(
             if (!(w <= thresh)) eb[v] = 1;
         }
     }
+    SEG_CLOCK(4);
 }
 
 }  // namespace
