@@ -933,7 +933,35 @@ __device__ __forceinline__ float fan_winding(const float* __restrict__ vb, int v
     const int lo = ring_off[v], cnt = real ? ring_off[v + 1] - lo : 0;
     float half_sum = 0.0f;
     constexpr int kLongRing = 16;
-    if (cnt > 0 && cnt <= kLongRing) {
+    constexpr int kShortRing = 8;
+    if (cnt > 0 && cnt <= kShortRing) {
+        // the usual case (SMPL: valence 6, a few 7 - 9): ALL ring vertices' ids in one round of loads, all their coordinates
+        // in the next -- with four at a time and the cycle's last vertex first this was six dependent rounds
+        int rr[kShortRing];
+        float cc[kShortRing][3];
+#pragma unroll
+        for (int u = 0; u < kShortRing; ++u) rr[u] = ring_vidx[lo + min(u, cnt - 1)];
+#pragma unroll
+        for (int u = 0; u < kShortRing; ++u) { cc[u][0] = vb[3 * rr[u]]; cc[u][1] = vb[3 * rr[u] + 1]; cc[u][2] = vb[3 * rr[u] + 2]; }
+        // slots behind the ring repeat its last vertex: slot kShortRing - 1 always holds the cycle's predecessor of vertex 0
+        P3 pb = {cc[kShortRing - 1][0] - vx, cc[kShortRing - 1][1] - vy, cc[kShortRing - 1][2] - vz};
+        P3 sb = {shear_x(cc[kShortRing - 1][0], cc[kShortRing - 1][2]) - qx, shear_y(cc[kShortRing - 1][1], cc[kShortRing - 1][2]) - qy,
+                 cc[kShortRing - 1][2] - vz};
+#pragma unroll
+        for (int u = 0; u < kShortRing; ++u) {
+            if (u < cnt) {
+                const P3 pc = {cc[u][0] - vx, cc[u][1] - vy, cc[u][2] - vz};
+                const P3 sc = {shear_x(cc[u][0], cc[u][2]) - qx, shear_y(cc[u][1], cc[u][2]) - qy, cc[u][2] - vz};
+                int cr;
+                float hf;
+                cone_term(us, sb, sc, u_dir, pb, pc, cr, hf);
+                half_sum += hf;
+                n += cr;
+                pb = pc;
+                sb = sc;
+            }
+        }
+    } else if (cnt > 0 && cnt <= kLongRing) {
         // previous ring vertex (j = cnt-1) to start the cycle
         int r = ring_vidx[lo + cnt - 1];
         P3 pb = {vb[3 * r] - vx, vb[3 * r + 1] - vy, vb[3 * r + 2] - vz};
