@@ -185,6 +185,7 @@ __global__ __launch_bounds__(64 * kWaves) void hd_search_kernel(
     __shared__ int s_i[kWaves][2][64];
     __shared__ float s_bound[64];
     __shared__ int s_rec[kWaves][64][kRecord];
+    __shared__ float4 s_box[kWaves][64][2];
     const int b = blockIdx.y, cb = blockIdx.x;
     const int beg = __builtin_amdgcn_readfirstlane(off[b]);
     const int n = counts ? __builtin_amdgcn_readfirstlane(counts[b]) : __builtin_amdgcn_readfirstlane(off[b + 1]) - beg;
@@ -382,9 +383,7 @@ __global__ __launch_bounds__(64 * kWaves) void hd_search_kernel(
     for (int t0 = wave; t0 < tiles; t0 += 64 * kWaves) {
         int nc;
         {
-            float bmax = bnd;
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, m));
+            const float bmax = wave_max_uniform(bnd);           // (bnd: a squared distance or +inf, never a NaN)
             const int tl = t0 + kWaves * lane;
             bool cand = false;
             float4 l4 = make_float4(0.f, 0.f, 0.f, 0.f), h4 = l4;
@@ -398,15 +397,24 @@ __global__ __launch_bounds__(64 * kWaves) void hd_search_kernel(
             }
             // the survivors against every column's own bound (tile boxes from the lanes that hold them): mask words and
             // rows are requested only for tiles some column can reach
+            // (the candidate's box as two broadcast reads of LDS instead of six v_readlane + the moves their scalar operands
+            // need -- as in v2v.hip's scan; s_box: this wavefront's 64 tile boxes of the trip)
             unsigned long long m = 0ull, my_reach = 0ull;
-            for (unsigned long long todo = __builtin_amdgcn_ballot_w64(cand); todo; todo &= todo - 1ull) {
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(cand);
+            if (todo) {
+                s_box[wave][lane][0] = l4;
+                s_box[wave][lane][1] = h4;
+            }
+            const float bnd_s = bnd * (1.0f / kSlack);
+            while (todo) {
                 const int pos = (int)__builtin_ctzll(todo);
-                auto pick = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), pos)); };
-                const float ex = fmaxf(fmaxf(pick(l4.x) - px, px - pick(h4.x)), 0.0f);
-                const float ey = fmaxf(fmaxf(pick(l4.y) - py, py - pick(h4.y)), 0.0f);
-                const float ez = fmaxf(fmaxf(pick(l4.z) - pz, pz - pick(h4.z)), 0.0f);
+                asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(pos));
+                const float4 bl = s_box[wave][pos][0], bh = s_box[wave][pos][1];
+                const float dx = px - __builtin_amdgcn_fmed3f(px, bl.x, bh.x);
+                const float dy = py - __builtin_amdgcn_fmed3f(py, bl.y, bh.y);
+                const float dz = pz - __builtin_amdgcn_fmed3f(pz, bl.z, bh.z);
                 const unsigned long long reach =
-                    __builtin_amdgcn_ballot_w64(__builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) * kSlack <= bnd);
+                    __builtin_amdgcn_ballot_w64(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) <= bnd_s);
                 if (reach) m |= 1ull << pos;
                 if (lane == pos) my_reach = reach;
             }
