@@ -162,11 +162,9 @@ __global__ __launch_bounds__(kBoundsBlock) void ray_leaf_bounds_kernel(
 #pragma unroll
     for (int k = 0; k < kSlabs; ++k) { lo[k] = row_min(lo[k]); nhi[k] = row_min(nhi[k]); }
     if (real && sub == 0) {
-        // the 13 values ray_near_kernel tests, one array per value over the leaves ([B][13][leaves]): its lanes take one
-        // leaf each, so a value's load is 64 consecutive floats, addressed by the leaf's index alone (as [node][20] it
-        // was a gather over 40 cache lines behind a load of the node id)
+        // the 13 slab values the near test uses, padded for the roundings of the projections (round 2-3: also stored in
+        // single precision, one array per value over the leaves; since round 4 ray_near_kernel reads the records alone)
         const int L = height_off[1] - height_off[0], leaf = i - height_off[0];
-        float* o = bounds + (size_t)b * kNearSlabs * L + leaf;
         float lo_p[kSlabs], hi_p[kSlabs];
 #pragma unroll
         for (int k = 0; k < kSlabs; ++k) {
@@ -175,12 +173,7 @@ __global__ __launch_bounds__(kBoundsBlock) void ray_leaf_bounds_kernel(
             lo_p[k] = lo[k] - pad;
             hi_p[k] = hi + pad;
         }
-        // order: lo0 lo1 lo3 lo4 lo6 lo8 | hi0 hi1 hi2 hi3 hi4 hi5 hi7
-        o[0 * (size_t)L] = lo_p[0]; o[1 * (size_t)L] = lo_p[1]; o[2 * (size_t)L] = lo_p[3]; o[3 * (size_t)L] = lo_p[4];
-        o[4 * (size_t)L] = lo_p[6]; o[5 * (size_t)L] = lo_p[8];
-        o[6 * (size_t)L] = hi_p[0]; o[7 * (size_t)L] = hi_p[1]; o[8 * (size_t)L] = hi_p[2]; o[9 * (size_t)L] = hi_p[3];
-        o[10 * (size_t)L] = hi_p[4]; o[11 * (size_t)L] = hi_p[5]; o[12 * (size_t)L] = hi_p[7];
-        // The same 13 values once more as the 32-byte RECORD the per-ray test reads: half precision, relative to a
+        // ... as the 32-byte RECORD both stages of the near test read: half precision, relative to a
         // reference point of the body (the first element of its strip, so that the numbers stay small wherever the body
         // stands), lower bounds rounded down and upper bounds up after a pad for the roundings of the subtraction.
         float c[3];
