@@ -619,7 +619,9 @@ def test_v2v_tree_walk_matches_flat_search(tag, batch, monkeypatch):
     # leaf_form 2: lanes over the subtree's leaves first (v2v_scan_kernel, the default); 0: the stackless walk
     # (v2v_tree_kernel).  (Two more forms -- leaf boxes four at a time, aligned row tiles on the matrix cores -- gave the
     # same keys and were slower; removed in round 4, DESIGN.md section 3 keeps their measurements.)
-    for waves, leaf_form in (('1', 2), ('4096', 2), ('1000000', 2), ('1', 0), ('4096', 0), ('1000000', 0)):
+    # 3: leaf-major (opt-in): the columns in reach of every leaf listed, regrouped by leaf, evaluated 64 columns at a time
+    for waves, leaf_form in (('1', 2), ('4096', 2), ('1000000', 2), ('1', 0), ('4096', 0), ('1000000', 0), ('1', 3), ('4096', 3),
+                             ('1000000', 3)):
         model.set_option('v2v_waves', int(waves))        # one subtree ... as many as the model has
         model.set_option('v2v_flat', leaf_form)
         mn_t, arg_t = model.v2v_min(verts)

@@ -46,6 +46,7 @@ c = list(out)
 for n, v in zip(names, c):
     print('%-32s %12d  per body %10.1f' % (n, v, v / B))
 w = c[0] - c[10]
+print('columns in reach of a leaf whose rows are evaluated: %.1f of 64 on average' % (c[15] / max(c[3], 1)))
 print('per live wavefront: trips %.2f candidates %.2f reaching %.2f rows8 %.2f (skipped %.2f, taking %.3f) rows4 %.2f (skipped %.2f)'
       % (c[1] / w, c[2] / w, c[3] / w, c[4] / w, c[5] / w, c[6] / w, c[7] / w, c[8] / w))
 # rough VALU estimate per event (read off the ISA: tools/diag/README)

@@ -57,6 +57,17 @@ void tuch_options_from_env(tuch_options* o);
 // Inside test by signed ray crossings (ray_winding.hip): exterior flags of the model's own vertices / of arbitrary
 // points, identical to thresholding the winding-number sum wherever that sum is well separated from the threshold.
 bool tuch_ray_available(const tuch_contact_model* m);
+// (query block, leaf) entries -> the rays of every leaf, in tiles of 64 (ray_winding.hip: ray_near_kernel's lists regrouped
+// by ray_tiles_fill_kernel; v2v.hip's leaf-major search regroups its (column block, leaf) entries with the same launch)
+struct RayEntry { int32_t leaf, node; uint32_t mask_lo, mask_hi; };   // which of the block's 64 lanes
+struct RayTile { int32_t ex_off, ex_len, first, n; };                 // n <= 64 slots pairs[first ..] of one leaf
+struct RayBody { int32_t tiles, overflow; };
+struct TreeNode;
+// nodes == NULL: a tile's ex_off is the leaf's index, ex_len 0.  list_stride: entries reserved per block in `lists`.
+int tuch_tiles_fill_launch(const int32_t* leaf_cnt, const TreeNode* nodes, const int32_t* leaf_nodes, int num_leaves, int cap,
+                           int max_tiles, int fallback_tiles, RayTile* tiles, RayBody* body, const RayEntry* lists,
+                           const int32_t* list_len, int blocks, int list_stride, int32_t* leaf_fill, int32_t* pairs, int B,
+                           hipStream_t s);
 // computes the layout of tuch_ray_exterior_verts (Q = 0) / tuch_ray_exterior_points: for a recording tuch_ws_scope
 void tuch_ray_layout_touch(const tuch_contact_model* m, int B, int Q);
 size_t tuch_ray_workspace_bytes(const tuch_contact_model* m, int B, int Q);
@@ -136,9 +147,12 @@ struct tuch_contact_model {
     int32_t* tree_leaf_group;
     uint64_t* tree_mask_bits_g;
     int tree_groups;
+    int tree_leaf_rows_max;    // most rows (vertices) in one leaf
+    int mask_symmetric;        // geomask[i][j] == geomask[j][i] for all i, j
     int tree_num_frontiers;
     int tree_leaf_runs_tile;       // 1: the leaves' strip runs [ex_off, ex_off + ex_len) tile [0, tree_exact_len) without gaps
     int* tree_frontier_off_host;   // [tree_num_frontiers+1]
+    int* tree_sub_leaf_host;       // host copy of tree_sub_leaf
     int32_t* tree_face_leaf_host;  // [F] leaf (preorder sequence number) of every face, host copy (or nullptr)
     int32_t* tree_qperm_host;      // [tree_qblocks*128] host copy of tree_qperm (or nullptr)
     // ordered one-ring of every vertex (closed manifold meshes only, else nullptr): ring_vidx[ring_off[v] + j] = r_j

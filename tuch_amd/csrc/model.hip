@@ -36,6 +36,7 @@ extern "C" void tuch_contact_model_destroy(tuch_contact_model* m)
                    m->cap_off, m->cap_vidx, m->region_off, m->region_vidx, m->pairs, m->pair_mask, m->pair_mask_off, m->tickets, m->canary_hits};
     for (void* p : dev) tuch_table_free(p);
     free(m->tree_frontier_off_host);
+    free(m->tree_sub_leaf_host);
     free(m->tree_face_leaf_host);
     free(m->tree_qperm_host);
     free(m->seg_q_off_host);
@@ -195,11 +196,20 @@ extern "C" int tuch_contact_model_create(
                     std::vector<uint64_t> by_leaf((size_t)Wp * L + 8, 0);        // + padding
                     for (int qb = 0; qb < Wp; ++qb)
                         for (int i = 0; i < L; ++i) by_leaf[(size_t)qb * L + i] = lanes[(size_t)qb * N + t.height_nodes[i]];
+                    m->tree_sub_leaf_host = host_copy(sub.data(), sub.size());
                     rc = upload(&m->tree_sub_leaf, sub.data(), sub.size());
                     if (rc == TUCH_OK) rc = upload(&m->tree_masked_leaf, by_leaf.data(), by_leaf.size());
                     // packed-row form: the leaves' rows in groups of four
                     std::vector<int32_t> group(L + 1, 0);
                     for (int i = 0; i < L; ++i) group[i + 1] = group[i] + (t.rows[(size_t)t.height_nodes[i] * 2 + 1] + 3) / 4;
+                    // for the leaf-major search (v2v.hip: v2v_tiles_kernel): a leaf's rows fit one 64-bit window of a column's
+                    // mask row, and that row stands for the column's own admissible rows only if the mask is symmetric
+                    m->tree_leaf_rows_max = 0;
+                    for (int i = 0; i < L; ++i) m->tree_leaf_rows_max = std::max(m->tree_leaf_rows_max, (int)t.rows[(size_t)t.height_nodes[i] * 2 + 1]);
+                    m->mask_symmetric = 1;
+                    for (int a = 0; a < V && m->mask_symmetric; ++a)
+                        for (int c2 = a + 1; c2 < V; ++c2)
+                            if ((geomask[(size_t)a * V + c2] != 0) != (geomask[(size_t)c2 * V + a] != 0)) { m->mask_symmetric = 0; break; }
                     const int G = group[L];
                     std::vector<uint64_t> bits_g((size_t)Wp * G * 4 + 8, 0);
                     for (int qb = 0; qb < Wp; ++qb)

@@ -359,7 +359,7 @@ __device__ __forceinline__ float wave_min(float v) { return wave_min_uniform(v);
 __device__ __forceinline__ float wave_max(float v) { return wave_max_uniform(v); }
 
 // One (query block, leaf) the block has to visit: which of its 64 rays pass the leaf's slabs.
-struct RayEntry { int32_t leaf, node; uint32_t mask_lo, mask_hi; };
+// (RayEntry, RayTile, RayBody: model.h)
 
 // (half in the low / high 16 bits of s) - q and q - (half of s) in single precision, one instruction each; the largest of three
 __device__ __forceinline__ float lo_minus(uint32_t s, float q)
@@ -393,9 +393,7 @@ __device__ __forceinline__ float max3(float a, float b, float c)
     return d;
 }
 // One unit of work of ray_leaf_kernel: up to 64 rays (pairs[first .. first + n)) against one leaf's strip run.
-struct RayTile { int32_t ex_off, ex_len, first, n; };
 // per body: number of tiles, whether the pair list overflowed (the body is then walked block-major)
-struct RayBody { int32_t tiles, overflow; };
 
 // One workgroup of kWaves wavefronts per (block of 64 queries, body); every wavefront holds the block's 64 queries.
 //   ranges : the 13 block ranges (kWaves = 4: each reduced by one of the wavefronts, shared through LDS);
@@ -670,7 +668,7 @@ __global__ __launch_bounds__(kTilesFillBlock) void ray_tiles_fill_kernel(
     const int32_t* __restrict__ leaf_cnt, const TreeNode* __restrict__ nodes, const int32_t* __restrict__ leaf_nodes,
     int num_leaves, int cap, int max_tiles, int fallback_tiles, RayTile* __restrict__ tiles, RayBody* __restrict__ body,
     const RayEntry* __restrict__ lists, const int32_t* __restrict__ list_len, int qblocks, int32_t* __restrict__ leaf_fill,
-    int32_t* __restrict__ pairs)
+    int32_t* __restrict__ pairs, int list_stride)
 {
     __builtin_amdgcn_s_setprio(3);                  // a chain of short dependent steps: ask for the issue slots first
     extern __shared__ int32_t dyn[];                // off[num_leaves] | tile[num_leaves] | blk[qblocks + 1]
@@ -711,10 +709,11 @@ __global__ __launch_bounds__(kTilesFillBlock) void ray_tiles_fill_kernel(
     // and a short loop) -- written by the body's first workgroup alone, seven leaves per lane one after the other, it was
     // the longest chain in the launch
     for (int l = (int)blockIdx.y + (int)gridDim.y * lane; l < num_leaves; l += (int)gridDim.y * 64) {
-        const TreeNode nd = nodes[leaf_nodes[l]];
+        int ex_off = l, ex_len = 0;                  // (nodes == NULL: the leaf's index itself, v2v.hip)
+        if (nodes) { const TreeNode nd = nodes[leaf_nodes[l]]; ex_off = nd.ex_off; ex_len = nd.ex_len; }
         const int c = cnt[l], off = off_s[l];
         RayTile* out = tiles + (size_t)b * max_tiles + tile_s[l];
-        for (int k = 0; k < c; k += 64) *out++ = RayTile{nd.ex_off, nd.ex_len, off + k, min(64, c - k)};
+        for (int k = 0; k < c; k += 64) *out++ = RayTile{ex_off, ex_len, off + k, min(64, c - k)};
     }
     int32_t* fill = leaf_fill + (size_t)b * num_leaves;
     int32_t* out = pairs + (size_t)b * cap;
@@ -730,7 +729,7 @@ __global__ __launch_bounds__(kTilesFillBlock) void ray_tiles_fill_kernel(
                 if (blk[mid] <= g) lo = mid; else hi = mid;
             }
             qb = lo;
-            e = lists[((size_t)b * qblocks + qb) * num_leaves + (g - blk[qb])];
+            e = lists[((size_t)b * qblocks + qb) * list_stride + (g - blk[qb])];
             dst = off_s[e.leaf] + atomicAdd(&fill[e.leaf], __builtin_popcount(e.mask_lo) + __builtin_popcount(e.mask_hi));
         }
         // lanes over rays: entry by entry, the set lanes write their slot
@@ -1614,6 +1613,22 @@ int tuch_ray_segment_flags_one(const tuch_contact_model* m, const float* verts, 
     return tuch_check_launch("tuch_ray_segment_flags_one");
 }
 
+int tuch_tiles_fill_launch(const int32_t* leaf_cnt, const TreeNode* nodes, const int32_t* leaf_nodes, int num_leaves, int cap,
+                           int max_tiles, int fallback_tiles, RayTile* tiles, RayBody* body, const RayEntry* lists,
+                           const int32_t* list_len, int blocks, int list_stride, int32_t* leaf_fill, int32_t* pairs, int B,
+                           hipStream_t s)
+{
+    const size_t lds = (2 * (size_t)num_leaves + blocks + 1) * sizeof(int32_t);
+    if (blocks > kFillMaxBlocks || lds > 48u * 1024) {
+        tuch_set_error("tuch_tiles_fill_launch: %d blocks / %d leaves do not fit the kernel's LDS tables", blocks, num_leaves);
+        return TUCH_ERR_ARG;
+    }
+    hipLaunchKernelGGL(ray_tiles_fill_kernel, dim3(B, kFillSplit), dim3(kTilesFillBlock), lds, s, leaf_cnt, nodes, leaf_nodes,
+                       num_leaves, cap, max_tiles, fallback_tiles, tiles, body, lists, list_len, blocks, leaf_fill, pairs,
+                       list_stride);
+    return tuch_check_launch("tuch_tiles_fill_launch");
+}
+
 bool tuch_ray_available(const tuch_contact_model* m)
 {
     if (!m || m->tree_nodes <= 0 || !m->ring_off || m->tree_exact_len <= 0) return false;
@@ -1735,7 +1750,7 @@ static int launch_ray_counts(const tuch_contact_model* m, const RayLayout& l, co
     if (l.qblocks <= kFillMaxBlocks && tf_lds <= 48u * 1024)
         hipLaunchKernelGGL(ray_tiles_fill_kernel, dim3(B, kFillSplit), dim3(kTilesFillBlock), tf_lds, s, (const int32_t*)leaf_cnt,
                            nodes, leaf_nodes, L, l.cap, l.max_tiles, l.qblocks * kFallbackChunks, tiles, body,
-                           (const RayEntry*)lists, (const int32_t*)list_len, l.qblocks, (int32_t*)(ws + l.leaf_fill), pairs);
+                           (const RayEntry*)lists, (const int32_t*)list_len, l.qblocks, (int32_t*)(ws + l.leaf_fill), pairs, L);
     else {
     hipLaunchKernelGGL(ray_tiles_kernel, dim3(B), dim3(kTilesBlock), 0, s, (const int32_t*)leaf_cnt, nodes, leaf_nodes, L, l.cap,
                        l.max_tiles, l.qblocks * kFallbackChunks, leaf_off, tiles, body);

@@ -900,13 +900,19 @@ __global__ __launch_bounds__(64) void v2v_tree_kernel(
 // and the largest bound among them (conservative: box-to-box distance), and only the survivors get the per-column test
 // and their rows.  Same rows as the walks -> the same keys.  colbox: the box of every 64-column block, left by
 // v2v_seed_kernel ([B][column blocks][8]).
-template <int kShared>
+// lists (leaf-major form, v2v_flat = 3): the wavefront does not evaluate a reaching leaf's rows itself -- on average 12 of
+// its 64 columns are in reach of one (tools/diag/scan_counts.py): the row arithmetic runs at a fifth of the lanes -- but
+// leaves an entry (leaf, the columns in reach) in its list; the entries are regrouped by leaf (tuch_tiles_fill_launch) and
+// v2v_tiles_kernel evaluates a leaf's rows for 64 columns that all want them, whichever blocks they come from.
+struct ScanLists { RayEntry* lists; int32_t* list_len; int32_t* leaf_cnt; int stride; };
+template <int kShared, bool kLists = false>
 __device__ __forceinline__ void v2v_scan_body(
     const float* __restrict__ prow, int V, int Vp, const uint64_t* __restrict__ bits,
     const float* __restrict__ leafbox, const float* __restrict__ colbox, const uint64_t* __restrict__ masked_leaf,
     const uint64_t* __restrict__ masked, int N, int L, const int32_t* __restrict__ frontier,
     const int32_t* __restrict__ sub_leaf, const int32_t* __restrict__ order, uint64_t* __restrict__ keys,
-    const float* __restrict__ prow_g, const uint64_t* __restrict__ bits_g, int G)   // rows / mask words in groups of four
+    const float* __restrict__ prow_g, const uint64_t* __restrict__ bits_g, int G,   // rows / mask words in groups of four
+    ScanLists out = ScanLists{nullptr, nullptr, nullptr, 0})
 {
     // (72 registers = 7 wavefronts per SIMD, 80 = 6, ...: touching the last one is what sets the kernel's register count)
     if constexpr (kShared == 7) asm volatile("v_mov_b32 v71, 0" ::: "v71");
@@ -930,7 +936,14 @@ __device__ __forceinline__ void v2v_scan_body(
     // the largest bound among the columns that have an allowed row below this subtree at all
     const uint64_t alive = masked[(size_t)qb * N + __builtin_amdgcn_readfirstlane(frontier[sub])];
     SCAN_COUNT(0);
-    if (alive == 0) { SCAN_COUNT(10); return; }
+    const size_t wave_id = (size_t)b * gridDim.y + blockIdx.y;
+    if (alive == 0) {
+        SCAN_COUNT(10);
+        if (kLists && lane == 0) out.list_len[wave_id] = 0;
+        return;
+    }
+    int nlist = 0;                               // (kLists) entries of this wavefront, wave-uniform
+    RayEntry* mylist = kLists ? out.lists + wave_id * out.stride : nullptr;
     // lower bounds are compared as g <= bound * (1 + 1e-6): the slack of kPruneSlack on the side that changes rarely
     constexpr float kBoundSlack = 1.000001f;
     const float reach2 = wave_max_uniform(((alive >> lane) & 1) ? c.best : 0.0f) * kBoundSlack;
@@ -1005,12 +1018,28 @@ __device__ __forceinline__ void v2v_scan_body(
             const uint64_t reach = __builtin_amdgcn_ballot_w64(g <= best_s) & lanes;
             if (reach) {
                 SCAN_COUNT(3);
-                const int leaf = __builtin_amdgcn_readfirstlane(__float_as_int(bhi.w));
-                const int g0 = __builtin_amdgcn_readfirstlane(__float_as_int(blo.w));
-                v2v_rows_packed(c, pg + (size_t)g0 * 12, mg + (size_t)g0 * 4, leaf & 0xfffff, ((leaf >> 20) + 3) >> 2, reach);
-                best_s = c.best * kBoundSlack;
+#ifdef TUCH_SCAN_COUNTS
+                if (threadIdx.x == 0) atomicAdd(&g_scan_counts[15], (unsigned long long)__builtin_popcountll(reach));   // columns in reach
+#endif
+                if constexpr (kLists) {
+                    if (lane == 0) {
+                        const int li = first + base + u;
+                        mylist[nlist] = RayEntry{li, 0, (uint32_t)reach, (uint32_t)(reach >> 32)};
+                        atomicAdd(&out.leaf_cnt[(size_t)b * L + li], __builtin_popcountll(reach));
+                    }
+                    ++nlist;
+                } else {
+                    const int leaf = __builtin_amdgcn_readfirstlane(__float_as_int(bhi.w));
+                    const int g0 = __builtin_amdgcn_readfirstlane(__float_as_int(blo.w));
+                    v2v_rows_packed(c, pg + (size_t)g0 * 12, mg + (size_t)g0 * 4, leaf & 0xfffff, ((leaf >> 20) + 3) >> 2, reach);
+                    best_s = c.best * kBoundSlack;
+                }
             }
         }
+    }
+    if constexpr (kLists) {
+        if (lane == 0) out.list_len[wave_id] = nlist;
+        return;
     }
     const uint64_t k0 = v2v_key(c.best, c.arg);
     if (k0 < init) atomicMin((unsigned long long*)(kb + i0), (unsigned long long)k0);
@@ -1031,8 +1060,91 @@ __global__ __launch_bounds__(64) void v2v_scan_shared_kernel(TUCH_SCAN_PARAMS)
 {
     v2v_scan_body<kSlots>(TUCH_SCAN_ARGS);
 }
+// the leaf-major form's first half: the columns in reach of every leaf, nothing evaluated
+template <int kSlots>
+__global__ __launch_bounds__(64) void v2v_reach_kernel(TUCH_SCAN_PARAMS, ScanLists out)
+{
+    v2v_scan_body<kSlots, true>(TUCH_SCAN_ARGS, out);
+}
 #undef TUCH_SCAN_PARAMS
 #undef TUCH_SCAN_ARGS
+
+// ... and its second half: a tile = one leaf and up to 64 columns in reach of it (pairs[first ..]: wavefront of the reach
+// kernel * 64 + lane).  The leaf's rows -- scalar operands, in groups of four as for v2v_rows_packed -- against the lanes'
+// own columns; a column's admissible rows of this leaf come from ITS row of the bit matrix (the geodesic mask is
+// symmetric: checked when the model is made), one or two 64-bit words per lane and tile; the running (distance, row) of
+// a column is merged into its key with atomicMin like every subtree's result.  Persistent wavefronts, bodies dealt to
+// the XCDs like ray_leaf_kernel's.
+__global__ __launch_bounds__(64) void v2v_tiles_kernel(
+    const float* __restrict__ prow, int Vp, const uint64_t* __restrict__ bits, int V, const float* __restrict__ leafbox, int L,
+    const int32_t* __restrict__ order, const RayTile* __restrict__ tiles, const RayBody* __restrict__ body,
+    const int32_t* __restrict__ pairs, int cap, int max_tiles, int num_bodies, uint64_t* __restrict__ keys,
+    const float* __restrict__ prow_g, int G)
+{
+    const int lane = threadIdx.x;
+    const float inf = __builtin_inff();
+    int b_cur = blockIdx.x, base = 0, g = blockIdx.y;
+    while (b_cur < num_bodies) {
+        const int b = b_cur;
+        const int nt = __builtin_amdgcn_readfirstlane(body[b].tiles);
+        if (g >= base + nt) { base += nt; b_cur += gridDim.x; continue; }
+        const int t = g - base;
+        g += gridDim.y;
+        const RayTile tile = tiles[(size_t)b * max_tiles + t];
+        const int leaf = __builtin_amdgcn_readfirstlane(tile.ex_off), first = __builtin_amdgcn_readfirstlane(tile.first);
+        const int n = __builtin_amdgcn_readfirstlane(tile.n);
+        const bool active = lane < n;
+        const int slot = pairs[(size_t)b * cap + first + (active ? lane : 0)];
+        const int pair = order[slot >> 7];                                 // (wavefront of the reach kernel) >> 1
+        const int qb = (pair & 0xffff) * 2 + ((slot >> 6) & 1);
+        const int i0 = qb * kTreeCols + (slot & 63);
+        const float* pb = prow + (size_t)b * Vp * 3;
+        uint64_t* kb = keys + (size_t)b * Vp;
+        const uint64_t init = __hip_atomic_load(kb + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        Column c;
+        c.px = pb[3 * i0]; c.py = pb[3 * i0 + 1]; c.pz = pb[3 * i0 + 2];
+        c.best = active ? __uint_as_float((uint32_t)(init >> 32)) : -1.0f;   // (idle lanes never improve)
+        c.arg = (int)(uint32_t)init;
+        const float* lbx = leafbox + ((size_t)b * L + leaf) * 8;
+        const int g0 = __builtin_amdgcn_readfirstlane(__float_as_int(lbx[3]));
+        const int range = __builtin_amdgcn_readfirstlane(__float_as_int(lbx[7]));
+        const int j0 = range & 0xfffff, nrows = range >> 20;
+        // the column's admissible rows among [j0, j0 + nrows): bit k of `am` = row j0 + k (nrows <= 64)
+        const uint64_t* brow = bits + (size_t)(j0 >> 6) * V + i0;           // bits[w][j]: word w of row j; symmetric mask
+        const uint64_t w0 = i0 < V ? brow[0] : 0ull;
+        const int sh = j0 & 63;
+        uint64_t am = w0 >> sh;
+        if (sh + nrows > 64) am |= (i0 < V ? brow[V] : 0ull) << (64 - sh);
+        if (nrows < 64) am &= (1ull << nrows) - 1ull;                        // rows behind the leaf's last are not its own
+        const v2f px = splat2(c.px), py = splat2(c.py), pz = splat2(c.pz);
+        const float* pg = prow_g + ((size_t)b * G + g0) * 12;
+        const int ngroups = (nrows + 3) >> 2;
+        uint32_t alo = (uint32_t)am, ahi = (uint32_t)(am >> 32);
+        for (int gg = 0; gg < ngroups; ++gg, pg += 12) {
+            if (gg == 8) alo = ahi;                                           // rows 32 .. 63
+            float v[12];
+#pragma unroll
+            for (int u = 0; u < 12; ++u) v[u] = pg[u];
+            const v2f dx0 = px - (v2f){v[0], v[1]}, dy0 = py - (v2f){v[4], v[5]}, dz0 = pz - (v2f){v[8], v[9]};
+            const v2f dx1 = px - (v2f){v[2], v[3]}, dy1 = py - (v2f){v[6], v[7]}, dz1 = pz - (v2f){v[10], v[11]};
+            const v2f d01 = fma2(dz0, dz0, fma2(dy0, dy0, dx0 * dx0)), d23 = fma2(dz1, dz1, fma2(dy1, dy1, dx1 * dx1));
+            float d[4] = {d01.x, d01.y, d23.x, d23.y};
+            const int kbit = (gg & 7) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) d[u] = ((alo >> (kbit + u)) & 1u) ? d[u] : inf;
+            const float m = min4_raw(d[0], d[1], d[2], d[3]);
+            if (__builtin_amdgcn_ballot_w64(m <= c.best)) {
+                int firstu = 3;
+#pragma unroll
+                for (int u = 2; u >= 0; --u) firstu = d[u] == m ? u : firstu;
+                const int j = j0 + gg * 4 + firstu;
+                if (m < c.best || (m == c.best && m < inf && j < c.arg)) { c.best = m; c.arg = j; }
+            }
+        }
+        const uint64_t k0 = v2v_key(c.best, c.arg);
+        if (active && k0 < init) atomicMin((unsigned long long*)(kb + i0), (unsigned long long)k0);
+    }
+}
 
 // keys -> (min, argmin) in the caller's vertex numbering; all-masked column -> (inf, 0)
 __global__ __launch_bounds__(kBlock) void v2v_tree_finalize_kernel(
@@ -1052,7 +1164,11 @@ __global__ __launch_bounds__(kBlock) void v2v_tree_finalize_kernel(
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-struct TreeV2VLayout { size_t prow, bounds, keys, leafbox, colbox, prow_g, total; };
+struct TreeV2VLayout { size_t prow, bounds, keys, leafbox, colbox, prow_g, lists, list_len, leaf_cnt, pairs, tiles, body, total;
+                       int waves, stride, cap, max_tiles; };
+
+static int flat_mode(const tuch_contact_model* m);
+int choose_v2v_frontier(const tuch_contact_model* m, int B);
 
 TreeV2VLayout tree_v2v_layout(const tuch_contact_model* m, int B)
 {
@@ -1065,6 +1181,25 @@ TreeV2VLayout tree_v2v_layout(const tuch_contact_model* m, int B)
     l.leafbox = tuch_ws_take(o, ((size_t)B * m->tree_leaves + 4) * 8 * sizeof(float));     // + padding
     l.colbox = tuch_ws_take(o, (size_t)B * 2 * m->tree_qblocks * 8 * sizeof(float));
     l.prow_g = tuch_ws_take(o, ((size_t)B * m->tree_groups * 12 + 16) * sizeof(float));     // (+ a trip's read-ahead)
+    l.lists = l.list_len = l.leaf_cnt = l.pairs = l.tiles = l.body = 0;
+    l.waves = l.stride = l.cap = l.max_tiles = 0;
+    if (flat_mode(m) == 3) {
+        // leaf-major form: the reach kernel's lists (one per wavefront, as long as its subtree has leaves), the columns of
+        // every leaf.  cap is the exact worst case -- every column in reach of every leaf -- so that the pair list cannot
+        // overflow (untouched memory costs nothing; 12 MB per body at SMPL size)
+        const int f = choose_v2v_frontier(m, B);
+        const int f0 = m->tree_frontier_off_host[f], nsub = m->tree_frontier_off_host[f + 1] - f0;
+        l.waves = 2 * nsub * m->tree_qblocks;
+        for (int k = 0; k < nsub; ++k) l.stride = std::max(l.stride, m->tree_sub_leaf_host[2 * (f0 + k) + 1]);
+        l.cap = Vp * m->tree_leaves;
+        l.max_tiles = l.cap / 64 + m->tree_leaves;
+        l.lists = tuch_ws_take(o, (size_t)B * l.waves * l.stride * sizeof(RayEntry));
+        l.list_len = tuch_ws_take(o, (size_t)B * l.waves * sizeof(int32_t));
+        l.leaf_cnt = tuch_ws_take(o, 2 * (size_t)B * m->tree_leaves * sizeof(int32_t));      // counts | fill cursors: cleared together
+        l.pairs = tuch_ws_take(o, (size_t)B * l.cap * sizeof(int32_t));
+        l.tiles = tuch_ws_take(o, (size_t)B * l.max_tiles * sizeof(RayTile));
+        l.body = tuch_ws_take(o, (size_t)B * sizeof(RayBody));
+    }
     l.total = o;
     return l;
 }
@@ -1081,6 +1216,9 @@ static int flat_mode(const tuch_contact_model* m)
     // without the leaf tables, and the A/B reference).  (Rounds 2-3 also had "leaf boxes four at a time" and a matrix-core
     // form: identical keys, both slower -- DESIGN.md section 3; removed in round 4.)
     if (!(m->tree_sub_leaf && m->tree_masked_leaf)) return 0;
+    // 3: leaf-major (v2v_reach_kernel -> tuch_tiles_fill_launch -> v2v_tiles_kernel): needs a symmetric mask and leaves of
+    // at most 64 rows
+    if (m->opt.v2v_flat >= 3 && m->mask_symmetric && m->tree_leaf_rows_max <= 64 && m->tree_sub_leaf_host) return 3;
     return m->opt.v2v_flat >= 2 ? 2 : 0;
 }
 
@@ -1092,7 +1230,11 @@ int choose_v2v_frontier(const tuch_contact_model* m, int B)
     const long target = m->opt.v2v_waves > 0 ? m->opt.v2v_waves : (flat_mode(m) >= 2 ? 14000L : 65536L);
     int f = 0;
     while (f + 1 < m->tree_num_frontiers &&
-           (long)B * m->tree_qblocks * (m->tree_frontier_off_host[f + 1] - m->tree_frontier_off_host[f]) < target) ++f;
+           (long)B * m->tree_qblocks * (m->tree_frontier_off_host[f + 1] - m->tree_frontier_off_host[f]) < target) {
+        // (leaf-major form: a body's wavefronts are the "blocks" of tuch_tiles_fill_launch, at most 2048)
+        if (flat_mode(m) == 3 && 2L * m->tree_qblocks * (m->tree_frontier_off_host[f + 2] - m->tree_frontier_off_host[f + 1]) > 2048) break;
+        ++f;
+    }
     return f;
 }
 
@@ -1225,7 +1367,7 @@ extern "C" int tuch_v2v_min_model_shared_zero(const tuch_contact_model* m, const
         hipLaunchKernelGGL(v2v_rows_seed_kernel, dim3(row_blocks + ceil_div(2 * m->tree_qblocks, kBoundsBlock / 64), B),
                            dim3(kBoundsBlock), 0, s, verts, V, Vp, (const int32_t*)m->tree_qperm, (const int32_t*)m->tree_rows,
                            (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, N, prow, bounds, leafbox,
-                           (const int32_t*)m->tree_leaf_group, scan == 2 ? (float*)(ws + l.prow_g) : (float*)nullptr,
+                           (const int32_t*)m->tree_leaf_group, scan >= 2 ? (float*)(ws + l.prow_g) : (float*)nullptr,
                            m->tree_groups, row_blocks, (const uint64_t*)m->tree_mask_bits, (const int32_t*)hint_inout, keys,
                            colbox, (uint4*)(fused_zero ? zero : nullptr),
                            fused_zero ? zero_bytes / 16 : (size_t)0);
@@ -1234,7 +1376,7 @@ extern "C" int tuch_v2v_min_model_shared_zero(const tuch_contact_model* m, const
                        verts, V, Vp, (const int32_t*)m->tree_qperm, (const int32_t*)m->tree_rows,
                        (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, N, prow, bounds,
                        scan >= 2 ? leafbox : (float*)nullptr, (const int32_t*)m->tree_leaf_group,
-                       scan == 2 ? (float*)(ws + l.prow_g) : (float*)nullptr, m->tree_groups);
+                       scan >= 2 ? (float*)(ws + l.prow_g) : (float*)nullptr, m->tree_groups);
     if (scan < 2)      // (the leaf scans seed from the leaf boxes and never look at an inner node)
         hipLaunchKernelGGL(tree_inner_bounds_kernel<4>, dim3(B), dim3(kBoundsBlock), tree_inner_bounds_lds<4>(N), s, nodes, N,
                            (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, m->tree_heights, bounds,
@@ -1253,7 +1395,32 @@ extern "C" int tuch_v2v_min_model_shared_zero(const tuch_contact_model* m, const
     // got going when the walk was done (tools/graph_timeline.py: the memset took 236 us).  -2.5 % step time; alone the
     // walk is 10 % slower with the cap (0.28 -> 0.31 ms), hence a flag (TUCH_V2V_LDS: bytes, to compare).
     const int lds_pad = leave_room && m->opt.v2v_lds > 0 ? m->opt.v2v_lds : 0;
-    if (scan == 2 && leave_room && m->opt.v2v_lds < 0) {
+    if (scan == 3) {
+        ScanLists out = {(RayEntry*)(ws + l.lists), (int32_t*)(ws + l.list_len), (int32_t*)(ws + l.leaf_cnt), l.stride};
+        int32_t* leaf_cnt = (int32_t*)(ws + l.leaf_cnt);
+        int32_t* leaf_fill = leaf_cnt + (size_t)B * m->tree_leaves;
+        if (hipMemsetAsync(leaf_cnt, 0, 2 * (size_t)B * m->tree_leaves * sizeof(int32_t), s) != hipSuccess)
+            return tuch_check_launch("tuch_v2v_min_model: clearing the leaf counters");
+        auto* reach = leave_room ? v2v_reach_kernel<7> : v2v_reach_kernel<0>;
+        hipLaunchKernelGGL(reach, dim3(B, 2 * nsub * m->tree_qblocks), dim3(64), 0, s, (const float*)prow,
+                           V, Vp, (const uint64_t*)m->tree_mask_bits, (const float*)leafbox, (const float*)colbox,
+                           (const uint64_t*)m->tree_masked_leaf, (const uint64_t*)m->tree_masked, N, m->tree_leaves,
+                           (const int32_t*)m->tree_frontier_nodes + f0, (const int32_t*)m->tree_sub_leaf + 2 * (size_t)f0,
+                           (const int32_t*)m->tree_launch_order + (size_t)f0 * m->tree_qblocks, keys,
+                           (const float*)(ws + l.prow_g), (const uint64_t*)m->tree_mask_bits_g, m->tree_groups, out);
+        const int rc = tuch_tiles_fill_launch(leaf_cnt, nullptr, nullptr, m->tree_leaves, l.cap, l.max_tiles, 0,
+                                              (RayTile*)(ws + l.tiles), (RayBody*)(ws + l.body), (const RayEntry*)(ws + l.lists),
+                                              (const int32_t*)(ws + l.list_len), l.waves, l.stride, leaf_fill,
+                                              (int32_t*)(ws + l.pairs), B, s);
+        if (rc != TUCH_OK) return rc;
+        const int columns = B < 8 ? B : 8;
+        hipLaunchKernelGGL(v2v_tiles_kernel, dim3(columns, 16384 / columns), dim3(64), 0, s, (const float*)prow, Vp,
+                           (const uint64_t*)m->tree_mask_bits, V, (const float*)leafbox, m->tree_leaves,
+                           (const int32_t*)m->tree_launch_order + (size_t)f0 * m->tree_qblocks, (const RayTile*)(ws + l.tiles),
+                           (const RayBody*)(ws + l.body), (const int32_t*)(ws + l.pairs), l.cap, l.max_tiles, B, keys,
+                           (const float*)(ws + l.prow_g), m->tree_groups);
+    }
+    else if (scan == 2 && leave_room && m->opt.v2v_lds < 0) {
         auto* kernel = m->opt.v2v_lds == -4 ? v2v_scan_shared_kernel<4> : m->opt.v2v_lds == -5 ? v2v_scan_shared_kernel<5> : m->opt.v2v_lds == -6 ? v2v_scan_shared_kernel<6>
                                                                                                   : v2v_scan_shared_kernel<7>;
         hipLaunchKernelGGL(kernel, dim3(B, 2 * nsub * m->tree_qblocks), dim3(64), 0, s, (const float*)prow,
