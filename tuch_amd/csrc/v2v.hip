@@ -798,7 +798,8 @@ __global__ __launch_bounds__(kBoundsBlock) void v2v_rows_seed_kernel(
     const int32_t* __restrict__ height_off, const int32_t* __restrict__ height_nodes, int N, float* __restrict__ prow,
     float* __restrict__ bounds, float* __restrict__ leafbox, const int32_t* __restrict__ leaf_group, float* __restrict__ prow_g,
     int G, int row_blocks, const uint64_t* __restrict__ bits, const int32_t* __restrict__ hint, uint64_t* __restrict__ keys,
-    float* __restrict__ colbox, uint4* __restrict__ zero, size_t zero_n16)
+    float* __restrict__ colbox, uint4* __restrict__ zero, size_t zero_n16,
+    uint4* __restrict__ zero2 = nullptr, size_t zero2_n16 = 0)       // the leaf-major form's counters (v2v_flat = 3)
 {
     // a buffer the CALLER wants cleared before the kernels it enqueues behind this call run (SMPLify-DC stage 2: the vertex
     // gradient the tail scatters into, its arrival counter, the region pairs' keys -- a fill launch of 5 us in front of them
@@ -807,6 +808,11 @@ __global__ __launch_bounds__(kBoundsBlock) void v2v_rows_seed_kernel(
         const size_t stride = (size_t)gridDim.x * gridDim.y * kBoundsBlock;
         for (size_t i = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kBoundsBlock + threadIdx.x; i < zero_n16; i += stride)
             zero[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (zero2) {
+        const size_t stride = (size_t)gridDim.x * gridDim.y * kBoundsBlock;
+        for (size_t i = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kBoundsBlock + threadIdx.x; i < zero2_n16; i += stride)
+            zero2[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     if ((int)blockIdx.x < row_blocks) {
         v2v_rows_body(blockIdx.x, verts, V, Vp, qperm, rows, height_off, height_nodes, N, prow, bounds, leafbox, leaf_group,
@@ -1083,66 +1089,107 @@ __global__ __launch_bounds__(64) void v2v_tiles_kernel(
 {
     const int lane = threadIdx.x;
     const float inf = __builtin_inff();
+    // a tile's inputs are a chain of dependent loads (tile -> slot -> column -> coordinates, key, mask words): the NEXT
+    // tile's are requested while this one's rows are walked
+    struct Work { int b, i0, g0, j0, nrows; bool active; float px, py, pz; uint64_t init, am; };
     int b_cur = blockIdx.x, base = 0, g = blockIdx.y;
-    while (b_cur < num_bodies) {
-        const int b = b_cur;
-        const int nt = __builtin_amdgcn_readfirstlane(body[b].tiles);
-        if (g >= base + nt) { base += nt; b_cur += gridDim.x; continue; }
-        const int t = g - base;
-        g += gridDim.y;
-        const RayTile tile = tiles[(size_t)b * max_tiles + t];
-        const int leaf = __builtin_amdgcn_readfirstlane(tile.ex_off), first = __builtin_amdgcn_readfirstlane(tile.first);
-        const int n = __builtin_amdgcn_readfirstlane(tile.n);
-        const bool active = lane < n;
-        const int slot = pairs[(size_t)b * cap + first + (active ? lane : 0)];
-        const int pair = order[slot >> 7];                                 // (wavefront of the reach kernel) >> 1
-        const int qb = (pair & 0xffff) * 2 + ((slot >> 6) & 1);
-        const int i0 = qb * kTreeCols + (slot & 63);
-        const float* pb = prow + (size_t)b * Vp * 3;
-        uint64_t* kb = keys + (size_t)b * Vp;
-        const uint64_t init = __hip_atomic_load(kb + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        Column c;
-        c.px = pb[3 * i0]; c.py = pb[3 * i0 + 1]; c.pz = pb[3 * i0 + 2];
-        c.best = active ? __uint_as_float((uint32_t)(init >> 32)) : -1.0f;   // (idle lanes never improve)
-        c.arg = (int)(uint32_t)init;
-        const float* lbx = leafbox + ((size_t)b * L + leaf) * 8;
-        const int g0 = __builtin_amdgcn_readfirstlane(__float_as_int(lbx[3]));
-        const int range = __builtin_amdgcn_readfirstlane(__float_as_int(lbx[7]));
-        const int j0 = range & 0xfffff, nrows = range >> 20;
-        // the column's admissible rows among [j0, j0 + nrows): bit k of `am` = row j0 + k (nrows <= 64)
-        const uint64_t* brow = bits + (size_t)(j0 >> 6) * V + i0;           // bits[w][j]: word w of row j; symmetric mask
-        const uint64_t w0 = i0 < V ? brow[0] : 0ull;
-        const int sh = j0 & 63;
-        uint64_t am = w0 >> sh;
-        if (sh + nrows > 64) am |= (i0 < V ? brow[V] : 0ull) << (64 - sh);
-        if (nrows < 64) am &= (1ull << nrows) - 1ull;                        // rows behind the leaf's last are not its own
-        const v2f px = splat2(c.px), py = splat2(c.py), pz = splat2(c.pz);
-        const float* pg = prow_g + ((size_t)b * G + g0) * 12;
-        const int ngroups = (nrows + 3) >> 2;
-        uint32_t alo = (uint32_t)am, ahi = (uint32_t)(am >> 32);
-        for (int gg = 0; gg < ngroups; ++gg, pg += 12) {
-            if (gg == 8) alo = ahi;                                           // rows 32 .. 63
+    auto fetch = [&]() {
+        Work w;
+        w.b = -1; w.i0 = w.g0 = w.j0 = w.nrows = 0; w.active = false; w.px = w.py = w.pz = 0.0f; w.init = 0ull; w.am = 0ull;
+        while (b_cur < num_bodies) {
+            const int b = b_cur;
+            const int nt = __builtin_amdgcn_readfirstlane(body[b].tiles);
+            if (g >= base + nt) { base += nt; b_cur += gridDim.x; continue; }
+            const int t = g - base;
+            g += gridDim.y;
+            const RayTile tile = tiles[(size_t)b * max_tiles + t];
+            const int leaf = __builtin_amdgcn_readfirstlane(tile.ex_off), first = __builtin_amdgcn_readfirstlane(tile.first);
+            const int n = __builtin_amdgcn_readfirstlane(tile.n);
+            w.b = b;
+            w.active = lane < n;
+            const int slot = pairs[(size_t)b * cap + first + (w.active ? lane : 0)];
+            const int pair = order[slot >> 7];                             // (wavefront of the reach kernel) >> 1
+            const int qb = (pair & 0xffff) * 2 + ((slot >> 6) & 1);
+            w.i0 = qb * kTreeCols + (slot & 63);
+            const float* pb = prow + (size_t)b * Vp * 3;
+            w.init = __hip_atomic_load(keys + (size_t)b * Vp + w.i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            w.px = pb[3 * w.i0]; w.py = pb[3 * w.i0 + 1]; w.pz = pb[3 * w.i0 + 2];
+            const float* lbx = leafbox + ((size_t)b * L + leaf) * 8;
+            w.g0 = __builtin_amdgcn_readfirstlane(__float_as_int(lbx[3]));
+            const int range = __builtin_amdgcn_readfirstlane(__float_as_int(lbx[7]));
+            w.j0 = range & 0xfffff;
+            w.nrows = range >> 20;
+            // the column's admissible rows among [j0, j0 + nrows): bit k of `am` = row j0 + k (nrows <= 64)
+            const uint64_t* brow = bits + (size_t)(w.j0 >> 6) * V + w.i0;   // bits[w][j]: word w of row j; symmetric mask
+            const int sh = w.j0 & 63;
+            uint64_t am = (w.i0 < V ? brow[0] : 0ull) >> sh;
+            if (sh + w.nrows > 64) am |= (w.i0 < V ? brow[V] : 0ull) << (64 - sh);
+            if (w.nrows < 64) am &= (1ull << w.nrows) - 1ull;               // rows behind the leaf's last are not its own
+            w.am = am;
+            break;
+        }
+        return w;
+    };
+    Work next = fetch();
+    while (next.b >= 0) {
+        const Work w = next;
+        next = fetch();
+        float best = w.active ? __uint_as_float((uint32_t)(w.init >> 32)) : -1.0f;      // (idle lanes never improve)
+        int arg = (int)(uint32_t)w.init;
+        const v2f px = splat2(w.px), py = splat2(w.py), pz = splat2(w.pz);
+        const float* pg = prow_g + ((size_t)w.b * G + w.g0) * 12;
+        const int ngroups = (w.nrows + 3) >> 2;
+        // NOT-admissible bits, eight rows of the trip in the low byte: a row's distance becomes a quiet NaN where its bit is
+        // set (two instructions: bit -> all ones, AND-OR), and v_min3 / v_min skip NaN operands
+        uint64_t nam = ~w.am;
+        auto dist2 = [&](float xa, float xb, float ya, float yb, float za, float zb) {
+            const v2f dx = px - (v2f){xa, xb}, dy = py - (v2f){ya, yb}, dz = pz - (v2f){za, zb};
+            return fma2(dz, dz, fma2(dy, dy, dx * dx));
+        };
+        auto masked = [&](float d, uint32_t word, int k) {
+            const int x = __builtin_amdgcn_sbfe(word, k, 1);                  // -1 where the row is not admissible
+            uint32_t r;
+            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(0x7FC00000u), "v"(__float_as_uint(d)));
+            return __uint_as_float(r);
+        };
+        auto take = [&](int j, float m) {
+            if (m < best || (m == best && m < inf && j < arg)) { best = m; arg = j; }
+        };
+        int gg = 0;
+        for (; gg + 2 <= ngroups; gg += 2, pg += 24, nam >>= 8) {
+            float v[24];
+#pragma unroll
+            for (int u = 0; u < 24; ++u) v[u] = pg[u];
+            const uint32_t word = (uint32_t)nam;
+            const v2f d01 = dist2(v[0], v[1], v[4], v[5], v[8], v[9]), d23 = dist2(v[2], v[3], v[6], v[7], v[10], v[11]);
+            const v2f d45 = dist2(v[12], v[13], v[16], v[17], v[20], v[21]), d67 = dist2(v[14], v[15], v[18], v[19], v[22], v[23]);
+            float d[8] = {masked(d01.x, word, 0), masked(d01.y, word, 1), masked(d23.x, word, 2), masked(d23.y, word, 3),
+                          masked(d45.x, word, 4), masked(d45.y, word, 5), masked(d67.x, word, 6), masked(d67.y, word, 7)};
+            const float m = min8_raw(d);
+            if (__builtin_amdgcn_ballot_w64(m <= best)) {
+                int firstu = 7;
+#pragma unroll
+                for (int u = 6; u >= 0; --u) firstu = d[u] == m ? u : firstu;
+                take(w.j0 + gg * 4 + firstu, m);
+            }
+        }
+        if (gg < ngroups) {
             float v[12];
 #pragma unroll
             for (int u = 0; u < 12; ++u) v[u] = pg[u];
-            const v2f dx0 = px - (v2f){v[0], v[1]}, dy0 = py - (v2f){v[4], v[5]}, dz0 = pz - (v2f){v[8], v[9]};
-            const v2f dx1 = px - (v2f){v[2], v[3]}, dy1 = py - (v2f){v[6], v[7]}, dz1 = pz - (v2f){v[10], v[11]};
-            const v2f d01 = fma2(dz0, dz0, fma2(dy0, dy0, dx0 * dx0)), d23 = fma2(dz1, dz1, fma2(dy1, dy1, dx1 * dx1));
-            float d[4] = {d01.x, d01.y, d23.x, d23.y};
-            const int kbit = (gg & 7) * 4;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) d[u] = ((alo >> (kbit + u)) & 1u) ? d[u] : inf;
+            const uint32_t word = (uint32_t)nam;
+            const v2f d01 = dist2(v[0], v[1], v[4], v[5], v[8], v[9]), d23 = dist2(v[2], v[3], v[6], v[7], v[10], v[11]);
+            float d[4] = {masked(d01.x, word, 0), masked(d01.y, word, 1), masked(d23.x, word, 2), masked(d23.y, word, 3)};
             const float m = min4_raw(d[0], d[1], d[2], d[3]);
-            if (__builtin_amdgcn_ballot_w64(m <= c.best)) {
+            if (__builtin_amdgcn_ballot_w64(m <= best)) {
                 int firstu = 3;
 #pragma unroll
                 for (int u = 2; u >= 0; --u) firstu = d[u] == m ? u : firstu;
-                const int j = j0 + gg * 4 + firstu;
-                if (m < c.best || (m == c.best && m < inf && j < c.arg)) { c.best = m; c.arg = j; }
+                take(w.j0 + gg * 4 + firstu, m);
             }
         }
-        const uint64_t k0 = v2v_key(c.best, c.arg);
-        if (active && k0 < init) atomicMin((unsigned long long*)(kb + i0), (unsigned long long)k0);
+        const uint64_t k0 = v2v_key(best, arg);
+        if (w.active && k0 < w.init) atomicMin((unsigned long long*)(keys + (size_t)w.b * Vp + w.i0), (unsigned long long)k0);
     }
 }
 
@@ -1165,7 +1212,7 @@ __global__ __launch_bounds__(kBlock) void v2v_tree_finalize_kernel(
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct TreeV2VLayout { size_t prow, bounds, keys, leafbox, colbox, prow_g, lists, list_len, leaf_cnt, pairs, tiles, body, total;
-                       int waves, stride, cap, max_tiles; };
+                       int waves, stride, cap, max_tiles; size_t leaf_cnt_bytes; };
 
 static int flat_mode(const tuch_contact_model* m);
 int choose_v2v_frontier(const tuch_contact_model* m, int B);
@@ -1183,6 +1230,7 @@ TreeV2VLayout tree_v2v_layout(const tuch_contact_model* m, int B)
     l.prow_g = tuch_ws_take(o, ((size_t)B * m->tree_groups * 12 + 16) * sizeof(float));     // (+ a trip's read-ahead)
     l.lists = l.list_len = l.leaf_cnt = l.pairs = l.tiles = l.body = 0;
     l.waves = l.stride = l.cap = l.max_tiles = 0;
+    l.leaf_cnt_bytes = 0;
     if (flat_mode(m) == 3) {
         // leaf-major form: the reach kernel's lists (one per wavefront, as long as its subtree has leaves), the columns of
         // every leaf.  cap is the exact worst case -- every column in reach of every leaf -- so that the pair list cannot
@@ -1195,7 +1243,8 @@ TreeV2VLayout tree_v2v_layout(const tuch_contact_model* m, int B)
         l.max_tiles = l.cap / 64 + m->tree_leaves;
         l.lists = tuch_ws_take(o, (size_t)B * l.waves * l.stride * sizeof(RayEntry));
         l.list_len = tuch_ws_take(o, (size_t)B * l.waves * sizeof(int32_t));
-        l.leaf_cnt = tuch_ws_take(o, 2 * (size_t)B * m->tree_leaves * sizeof(int32_t));      // counts | fill cursors: cleared together
+        l.leaf_cnt_bytes = (2 * (size_t)B * m->tree_leaves * sizeof(int32_t) + 15) & ~(size_t)15;
+        l.leaf_cnt = tuch_ws_take(o, l.leaf_cnt_bytes);      // counts | fill cursors: cleared together (by the search's first kernel)
         l.pairs = tuch_ws_take(o, (size_t)B * l.cap * sizeof(int32_t));
         l.tiles = tuch_ws_take(o, (size_t)B * l.max_tiles * sizeof(RayTile));
         l.body = tuch_ws_take(o, (size_t)B * sizeof(RayBody));
@@ -1370,7 +1419,8 @@ extern "C" int tuch_v2v_min_model_shared_zero(const tuch_contact_model* m, const
                            (const int32_t*)m->tree_leaf_group, scan >= 2 ? (float*)(ws + l.prow_g) : (float*)nullptr,
                            m->tree_groups, row_blocks, (const uint64_t*)m->tree_mask_bits, (const int32_t*)hint_inout, keys,
                            colbox, (uint4*)(fused_zero ? zero : nullptr),
-                           fused_zero ? zero_bytes / 16 : (size_t)0);
+                           fused_zero ? zero_bytes / 16 : (size_t)0, (uint4*)(scan == 3 ? ws + l.leaf_cnt : nullptr),
+                           scan == 3 ? l.leaf_cnt_bytes / 16 : (size_t)0);
     } else {
     hipLaunchKernelGGL(v2v_rows_kernel, dim3(row_blocks, B), dim3(kBoundsBlock), 0, s,
                        verts, V, Vp, (const int32_t*)m->tree_qperm, (const int32_t*)m->tree_rows,
@@ -1399,7 +1449,7 @@ extern "C" int tuch_v2v_min_model_shared_zero(const tuch_contact_model* m, const
         ScanLists out = {(RayEntry*)(ws + l.lists), (int32_t*)(ws + l.list_len), (int32_t*)(ws + l.leaf_cnt), l.stride};
         int32_t* leaf_cnt = (int32_t*)(ws + l.leaf_cnt);
         int32_t* leaf_fill = leaf_cnt + (size_t)B * m->tree_leaves;
-        if (hipMemsetAsync(leaf_cnt, 0, 2 * (size_t)B * m->tree_leaves * sizeof(int32_t), s) != hipSuccess)
+        if (!hint_inout && hipMemsetAsync(leaf_cnt, 0, l.leaf_cnt_bytes, s) != hipSuccess)      // (else: v2v_rows_seed_kernel)
             return tuch_check_launch("tuch_v2v_min_model: clearing the leaf counters");
         auto* reach = leave_room ? v2v_reach_kernel<7> : v2v_reach_kernel<0>;
         hipLaunchKernelGGL(reach, dim3(B, 2 * nsub * m->tree_qblocks), dim3(64), 0, s, (const float*)prow,
@@ -1414,7 +1464,7 @@ extern "C" int tuch_v2v_min_model_shared_zero(const tuch_contact_model* m, const
                                               (int32_t*)(ws + l.pairs), B, s);
         if (rc != TUCH_OK) return rc;
         const int columns = B < 8 ? B : 8;
-        hipLaunchKernelGGL(v2v_tiles_kernel, dim3(columns, 16384 / columns), dim3(64), 0, s, (const float*)prow, Vp,
+        hipLaunchKernelGGL(v2v_tiles_kernel, dim3(columns, 32768 / columns), dim3(64), 0, s, (const float*)prow, Vp,
                            (const uint64_t*)m->tree_mask_bits, V, (const float*)leafbox, m->tree_leaves,
                            (const int32_t*)m->tree_launch_order + (size_t)f0 * m->tree_qblocks, (const RayTile*)(ws + l.tiles),
                            (const RayBody*)(ws + l.body), (const int32_t*)(ws + l.pairs), l.cap, l.max_tiles, B, keys,
