@@ -88,6 +88,32 @@ def _pmc_rows(path):
     return rows
 
 
+def _source_hash(name):
+    import hashlib
+    try:
+        return hashlib.sha256(open(os.path.join(ROOT, 'tuch_amd', 'csrc', name), 'rb').read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def profile_staleness(sq_file, sources):
+    """(stale, reason): were the committed counters profiled on the kernel sources this run executes?  The PMC summaries
+    carry '# source sha256: file=hash ...' of the tree they were collected from (scripts/rocprof_pmc_summary.py); a
+    summary without that line (rounds 1-4) cannot be verified and counts as stale."""
+    recorded = {}
+    with open(sq_file) as f:
+        for line in f:
+            if line.startswith('# source sha256:'):
+                recorded = dict(item.split('=', 1) for item in line.split(':', 1)[1].split() if '=' in item)
+                break
+    if not recorded:
+        return True, 'no source hashes recorded in %s' % os.path.basename(sq_file)
+    changed = [s for s in sources if recorded.get(s) != _source_hash(s)]
+    if changed:
+        return True, '%s changed since %s was collected' % (', '.join(changed), os.path.basename(sq_file))
+    return False, None
+
+
 def profile_constants():
     """HBM-side bytes per launch and VALU-busy fraction of the two big kernels at batch 64, parsed at start-up from the
     newest committed PMC summaries (profiles/rNN_x_pmc_{fetch,write,sq}.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE /
@@ -108,7 +134,9 @@ def profile_constants():
             pick = lambda table: next(((k, c) for n in names for k, c in table.items() if n in k), (None, None))
             (kname, fe), (_, wr), (_, sq) = pick(rows['fetch']), pick(rows['write']), pick(rows['sq'])
             if fe and wr and sq and sq.get('GRBM_GUI_ACTIVE'):
-                out[key] = {'kernel': (re.search(r'(\w+_kernel)', kname) or [None, kname])[1],
+                stale, why = profile_staleness(files['sq'], ('v2v.hip', 'common.h', 'tree_device.h') if key == 'search' else
+                                               ('ray_winding.hip', 'common.h', 'tree_device.h'))
+                out[key] = {'kernel': (re.search(r'(\w+_kernel)', kname) or [None, kname])[1], 'stale': stale, 'stale_reason': why,
                             'traffic_bytes': int((fe['FETCH_SIZE'] + wr['WRITE_SIZE']) * 1024),
                             'valu_busy': round(sq['SQ_ACTIVE_INST_VALU'] * 4 / (1024 * sq['GRBM_GUI_ACTIVE'] / 8), 3),
                             'valu_instr': sq.get('SQ_INSTS_VALU'), 'salu_instr': sq.get('SQ_INSTS_SALU'),
@@ -118,6 +146,7 @@ def profile_constants():
             break
     for key in ('search', 'ray_leaf_kernel'):
         out.setdefault(key, {'kernel': None, 'traffic_bytes': None, 'valu_busy': None, 'valu_instr': None, 'salu_instr': None,
+                             'stale': True, 'stale_reason': 'no PMC summary under profiles/',
                              'source': 'no PMC summary under profiles/'})
     return out
 
@@ -334,17 +363,35 @@ def regressor_loss(p, use_hd):
     return _BODY[key]
 
 
-def make_train_step(p, use_hd, smplify_iters=0):
+FRESH_BATCHES = 4      # distinct pose batches rotated through the "fresh bodies" legs (a training loop never repeats a body)
+
+
+def fresh_problems(p, device, seed):
+    """p followed by FRESH_BATCHES - 1 more problems of the same batch size with other random poses / shapes."""
+    key = ('fresh', str(device), p['body_pose'].shape[0], seed)
+    if key not in _BODY:
+        _BODY[key] = [build_problem(p['body_pose'].shape[0], device, seed + 101 * k) for k in range(1, FRESH_BATCHES)]
+    return [p] + _BODY[key]
+
+
+def make_train_step(p, use_hd, smplify_iters=0, fresh=None):
     """The contact part of a train.py-style step in isolation (used for the HD / plain comparison): SMPL forward with
     pose2rot=False (train_module.py:202-204) -> RegressorLoss.contact_loss (mean over the valid bodies of ALL ranks)
-    -> backward to the rotation matrices and betas."""
+    -> backward to the rotation matrices and betas.
+    fresh: a list of problems; step.next_bodies() then writes the NEXT problem's rotation matrices and betas into the
+    step's input tensors in place (a copy on the stream, outside the captured step) -- what a training loop does to a
+    captured step between replays: every replay sees bodies it has never seen."""
     from tuch_amd.utils.geometry import batch_rodrigues
     batch = p['body_pose'].shape[0]
     dev = p['body_pose'].device
     crit = regressor_loss(p, use_hd)
-    full_pose = torch.cat([p['global_orient'], p['body_pose']], dim=1).detach()
-    rotmat = batch_rodrigues(full_pose.reshape(-1, 3)).view(batch, 24, 3, 3).detach().requires_grad_(True)
-    betas = p['betas'].detach().clone().requires_grad_(True)
+
+    def inputs(q):
+        full_pose = torch.cat([q['global_orient'], q['body_pose']], dim=1).detach()
+        return batch_rodrigues(full_pose.reshape(-1, 3)).view(batch, 24, 3, 3).detach().clone(), q['betas'].detach().clone()
+    rot0, bet0 = inputs(p)
+    rotmat = rot0.clone().requires_grad_(True)
+    betas = bet0.clone().requires_grad_(True)
     valid = torch.ones(batch, dtype=torch.bool, device=dev)
     stats = torch.zeros(2, device=dev)
     stats[1] = float(batch)
@@ -356,6 +403,16 @@ def make_train_step(p, use_hd, smplify_iters=0):
         loss.backward()
         stats[0] = loss.detach() * batch
         return stats
+    if fresh:
+        pool = [inputs(q) for q in fresh]
+        state = {'i': 0}
+
+        def next_bodies():
+            state['i'] = (state['i'] + 1) % len(pool)
+            with torch.no_grad():
+                rotmat.copy_(pool[state['i']][0])
+                betas.copy_(pool[state['i']][1])
+        step.next_bodies = next_bodies
     return step
 
 
@@ -401,6 +458,22 @@ def make_tuch_step(p, run_smplify, smplify_iters=10, seed=77):
         loss.backward()
         stats[0] = loss.detach() * batch
         return stats
+    # fresh bodies: the images (what the regressor stand-in turns into poses and shapes), keypoints and pseudo ground truth of
+    # FRESH_BATCHES different input batches, written into the step's input tensors in place between calls / replays (dataset
+    # names, sample indices and the has_* flags stay: they steer the fits dictionary, not the contact path)
+    swap = ('img', 'keypoints', 'pose_3d', 'pose', 'betas', 'contact_vec')
+    pool = [{k: input_batch[k].clone() for k in swap}]
+    for k in range(1, FRESH_BATCHES):
+        other = make_train_batch(body, batch, seed + 101 * k, datasets)
+        pool.append({name: torch.tensor(other[name], device=dev) for name in swap})
+    state = {'i': 0}
+
+    def next_bodies():
+        state['i'] = (state['i'] + 1) % len(pool)
+        with torch.no_grad():
+            for name in swap:
+                input_batch[name].copy_(pool[state['i']][name])
+    step.next_bodies = next_bodies
     return step
 
 
@@ -421,6 +494,7 @@ def capture(step, warmup):
         graph.replay()
         return out
     replay.objective = getattr(step, 'objective', None)
+    replay.next_bodies = getattr(step, 'next_bodies', None)
     replay.graph = graph
     # the graph holds raw addresses of everything `step` owns (parameters, Adam state, ...): they must live as
     # long as the graph does.  (Round 1 dropped `step` here; its tensors were then recycled by the next regular
@@ -429,22 +503,28 @@ def capture(step, warmup):
     return replay
 
 
-def time_kernel(fn, iters):
+def time_kernel(fn, iters, between=None):
     """Seconds per call (HIP events on the current stream); best of two passes after two warm-up calls, so that
-    a one-off allocator growth does not land in the figure."""
-    fn()
-    fn()
+    a one-off allocator growth does not land in the figure.
+    between: called before every timed call (the "fresh bodies" legs: new inputs written in place; its few small device
+    copies are part of the figure)."""
+    call = fn if between is None else (lambda: (between(), fn()))
+    for _ in range(2 if between is None else FRESH_BATCHES + 1):
+        call()
     torch.cuda.synchronize()
-    best = float('inf')
-    for _ in range(2):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        best = min(best, e0.elapsed_time(e1) / iters * 1e-3)
-    return best
+
+    def best_of_two(f):
+        best = float('inf')
+        for _ in range(2):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                f()
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / iters * 1e-3)
+        return best
+    return best_of_two(call)
 
 
 def rooflines(p, batch):
@@ -484,6 +564,9 @@ def rooflines(p, batch):
             'equivalent_achieved': round(ach_v, 2), 'equivalent_frac': round(ach_v / PEAK_FP32_VECTOR_TFLOPS, 4),
             'traffic': prof_v['traffic_bytes'] if batch == BATCH_PER_GPU else None,
             'valu_busy': prof_v['valu_busy'], 'profile_source': prof_v['source'],
+            # frac mixes an instruction count from profiles/ with a launch time measured here: stale = the kernel source has
+            # changed since that count was collected (then frac / valu_busy / traffic describe OLDER code)
+            'stale': prof_v['stale'], 'stale_reason': prof_v['stale_reason'],
             'launch_ms': round(t_v * 1e3, 4),
             'algorithmic_flop_per_launch': alg_flop, 'flop_per_pair': FLOP_PER_V2V_PAIR,
             'algorithmic_bytes_per_launch': compact_bytes,
@@ -517,6 +600,7 @@ def rooflines(p, batch):
               'frac_of_plain_issue_peak': round(lane_instr / PEAK_PLAIN_ISSUE_TLANEOPS, 4),
               'traffic': prof_r['traffic_bytes'] if batch == BATCH_PER_GPU else None,
               'valu_busy': prof_r['valu_busy'], 'profile_source': prof_r['source'],
+              'stale': prof_r['stale'], 'stale_reason': prof_r['stale_reason'],
               'launch_ms': round(t_w * 1e3, 4),
               'executed_op_per_launch': ops, 'op_per_ray_element': OPS_PER_RAY_ELEMENT,
               'element_steps_per_launch': steps, 'wavefront_tiles': work['wavefronts'],
@@ -548,9 +632,24 @@ def contact_loss_eval(p, batch, verts, model):
             out['contact_from_verts_ms'] = round(time_kernel(
                 lambda: model.region_pair_min(verts, select=None, masked=False), 5) * 1e3, 4)
         out['contact_from_verts_pairs'] = model.num_pairs
+    # FRESH bodies: a training loop calls the loss on bodies it has never seen (tuch/train/train_module.py:302-317), while
+    # timing one tensor over and over hands the nearest-vertex search its own previous answer as the seed.  *_fresh_*: K
+    # distinct pose batches in turn -- the seed of every call is ANOTHER batch's answer; the captured step gets its inputs
+    # rewritten in place between replays.  The figures without the suffix are the same-bodies (hinted) ones of rounds 1-4.
+    probs = fresh_problems(p, dev, 1002)
+    with torch.no_grad():
+        fresh_verts = [verts] + [q['smpl'](global_orient=q['global_orient'], body_pose=q['body_pose'],
+                                           betas=q['betas']).vertices for q in probs[1:]]
+    out['fresh_batches'] = len(fresh_verts)
     for tag, use_hd in (('plain', False), ('hd', True)):
         crit = regressor_loss(p, use_hd)
         v = verts.clone().requires_grad_(True)
+        turn = {'i': 0}
+
+        def next_verts():
+            turn['i'] = (turn['i'] + 1) % len(fresh_verts)
+            with torch.no_grad():
+                v.copy_(fresh_verts[turn['i']])
 
         def fwd():
             with torch.no_grad():
@@ -562,14 +661,23 @@ def contact_loss_eval(p, batch, verts, model):
         iters = 5 if not use_hd else 3
         out['regressor_%s_fwd_ms_per_body' % tag] = round(time_kernel(fwd, iters) * 1e3 / batch, 5)
         out['regressor_%s_fwd_bwd_ms_per_body' % tag] = round(time_kernel(fwd_bwd, iters) * 1e3 / batch, 5)
+        out['regressor_%s_fwd_fresh_ms_per_body' % tag] = round(time_kernel(fwd, 2 * iters, next_verts) * 1e3 / batch, 5)
+        out['regressor_%s_fwd_bwd_fresh_ms_per_body' % tag] = round(time_kernel(fwd_bwd, 2 * iters, next_verts) * 1e3 / batch, 5)
+        with torch.no_grad():
+            v.copy_(verts)
         out['train_style_%s_step_ms' % tag] = round(time_kernel(make_train_step(p, use_hd), iters) * 1e3, 4)
         # the same step captured once and replayed as one hipGraph (what a training loop that captures its step pays:
         # the eager figure above includes the host's launch rate, ~50 launches per step)
         try:
-            replay = capture(make_train_step(p, use_hd), 3)
+            replay = capture(make_train_step(p, use_hd, fresh=probs), 3)
             out['train_style_%s_step_graph_ms' % tag] = round(time_kernel(replay, 10) * 1e3, 4)
+            out['train_style_%s_step_graph_fresh_ms' % tag] = round(time_kernel(replay, 12, replay.next_bodies) * 1e3, 4)
         except Exception as e:                                   # noqa: BLE001 -- reported, not fatal for the bench line
             out['train_style_%s_step_graph_ms' % tag] = 'capture failed: %s' % type(e).__name__
+    out['fresh_note'] = ('*_fresh_*: %d distinct pose batches rotated through the same call / the same captured step (inputs '
+                         'written in place between replays, those small copies included): the nearest-vertex search is '
+                         'seeded by ANOTHER batch\'s partners, as in a training loop; without the suffix: identical bodies '
+                         'every call (the search is seeded by its own previous answer, as in an iterative fit)' % len(fresh_verts))
     return out
 
 
@@ -598,30 +706,43 @@ def workloads(device, seed):
                                             'graph_replayed': dict(fitter.graph_replayed)}
     tuch_step = make_tuch_step(p32, run_smplify=False)
     eager_ms = time_kernel(tuch_step, 5) * 1e3
+    graph_fresh_ms = None
     try:        # our part of the step has no host synchronisation: the whole step replays as one hipGraph
-        graph_ms = round(time_kernel(capture(tuch_step, 3), 10) * 1e3, 4)
+        replay4 = capture(tuch_step, 3)
+        graph_ms = round(time_kernel(replay4, 10) * 1e3, 4)
+        graph_fresh_ms = round(time_kernel(replay4, 12, replay4.next_bodies) * 1e3, 4)
     except RuntimeError as e:
         graph_ms = 'capture failed: %s' % str(e).splitlines()[0]
     out['config4_shard_b32_train_step'] = {
-        'ms': round(eager_ms, 4), 'graph_ms': graph_ms,
+        'ms': round(eager_ms, 4), 'graph_ms': graph_ms, 'graph_fresh_ms': graph_fresh_ms,
+        'fresh_ms': round(time_kernel(tuch_step, 8, tuch_step.next_bodies) * 1e3, 4),
         'contact_only_plain_ms': round(time_kernel(make_train_step(p32, False), 5) * 1e3, 4),
         'contact_only_hd_ms': round(time_kernel(make_train_step(p32, True), 3) * 1e3, 4),
         'what': 'TUCH.forward_train_step (no SMPLify in the loop) + backward, 32 bodies per rank (256 / 8), stand-in '
                 'regressors; ms = eager (CPU-launch-bound: ~580 small launches), graph_ms = the same step captured once and '
-                'replayed; contact_only_* = SMPL fwd (pose2rot=False) + RegressorLoss.contact_loss + backward alone'}
+                'replayed; contact_only_* = SMPL fwd (pose2rot=False) + RegressorLoss.contact_loss + backward alone; '
+                '*fresh_ms = %d different input batches in turn, written in place between calls / replays (the bodies are new '
+                'every step, as in training; ms / graph_ms repeat ONE batch, whose searches are seeded by their own previous '
+                'answer)' % FRESH_BATCHES}
     p64 = build_problem(64, device, seed + 2)
     step5 = make_tuch_step(p64, run_smplify=True, smplify_iters=10)
     ms5 = round(time_kernel(step5, 2) * 1e3, 4)
+    fresh5 = round(time_kernel(step5, 4, step5.next_bodies) * 1e3, 4)
+    graph_fresh5 = None
     try:        # the whole step as ONE hipGraph: the SMPLify-DC iterations are unrolled into the enclosing capture
-        graph5 = round(time_kernel(capture(step5, 3), 5) * 1e3, 4)
+        replay5 = capture(step5, 3)
+        graph5 = round(time_kernel(replay5, 5) * 1e3, 4)
+        graph_fresh5 = round(time_kernel(replay5, 8, replay5.next_bodies) * 1e3, 4)
     except Exception as e:                                       # noqa: BLE001 -- reported, not fatal for the bench line
         graph5 = 'capture failed: %s: %s' % (type(e).__name__, str(e).splitlines()[0][:200])
     out['config5_shard_b64_in_the_loop_step'] = {
-        'ms': ms5, 'graph_ms': graph5,
+        'ms': ms5, 'graph_ms': graph5, 'fresh_ms': fresh5, 'graph_fresh_ms': graph_fresh5,
         'what': 'TUCH.forward_train_step with --run_smplify (SMPLify-DC 10 + 10 iterations with contact in the loop) + '
                 'backward, 64 bodies per rank (512 / 8); ms = eager step (its SMPLify loops replay their own kept graphs), '
                 'graph_ms = the whole step captured once and replayed as one hipGraph (the loops unrolled into it); the '
-                'bf16 ResNet regressor is stock PyTorch and not part of the path'}
+                'bf16 ResNet regressor is stock PyTorch and not part of the path; *fresh_ms as for config 4 (the fits of the '
+                'SMPLify-DC loop inside are iterative: from their second iteration on the search is seeded by the previous '
+                'iteration whatever the bodies)'}
     return out
 
 
@@ -699,6 +820,21 @@ def ops_cluster_tree_info(model):
     from tuch_amd import ops
     t = ops.cluster_tree(model.faces_np, model.num_verts, leaf_faces=max(model.num_faces // 850, 32))
     return {'exact_len': int(t['exact_len']), 'leaves': int((t['nodes'][:, 3] > 0).sum())}
+
+
+def headline_without_hints(device, seed, batch):
+    """The headline step with the search's partner hints switched OFF (option v2v_hint = 0): every iteration's search starts
+    from the hint-free seed, as the first call on new bodies does.  (An iterative fit is what the hints are for -- Adam
+    moves a pose by 1e-2 per iteration --; this line says what they are worth.)"""
+    from tuch_amd.smplify.losses import contact_model_for
+    p = build_problem(batch, device, seed)
+    model = contact_model_for(p['geomask'], p['face_tensor'], p['segments'], p['cdict'])
+    model.set_option('v2v_hint', 0)
+    try:
+        ms = time_kernel(capture(make_step(p), 3), 20) * 1e3
+    finally:
+        model.set_option('v2v_hint', 1)
+    return {'ms_per_step': round(ms, 4), 'body_iterations_per_s': round(batch / ms * 1e3, 1)}
 
 
 def deterministic_cost(device, seed, batch):
@@ -980,7 +1116,10 @@ def main():
         step = make_fit(p, 100)[0]
         launch = 'SMPLifyDC.__call__ (each loop replayed as a hipGraph after 3 eager iterations)'
     else:
-        step = make_tuch_step(p, run_smplify=args.config == '5-shard', smplify_iters=10)
+        # a training loop: every step sees a NEW input batch (FRESH_BATCHES of them in turn, written in place)
+        one = make_tuch_step(p, run_smplify=args.config == '5-shard', smplify_iters=10)
+        step = lambda: (one.next_bodies(), one())[1]
+        launch = 'eager; %d different input batches in turn' % FRESH_BATCHES
     weak_step = None
     if default_strong and not args.eager:
         # the weak-scaling twin (64 bodies on every rank), captured before the process group exists like the headline
@@ -1105,6 +1244,7 @@ def main():
             line['worst_case'] = worst_case(device, 1002, batch)
             line['worst_case']['folded'] = worst_case(device, 1002, batch, folded=True)
             line['deterministic_mode'] = deterministic_cost(device, 1002, batch)
+            line['headline_without_hints'] = headline_without_hints(device, 1002, batch)
             line['irregular_topology'] = irregular_topology(device, 1002, batch)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(p, args.cpu_seconds)

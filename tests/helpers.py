@@ -92,6 +92,11 @@ def _log(line: str) -> None:
         pass
 
 
+def report_value(what, value):
+    """An observed maximum (printed with -s, appended to gpurun_out/parity_counts.txt): what the tolerances are set from."""
+    _log('%-72s %.3e' % (what, value))
+
+
 def report(what, count, total):
     """Observed index/flag mismatches against the reference (allowed only between candidates tied within the
     reference's own float32 noise): printed (-s) and appended to gpurun_out/parity_counts.txt."""

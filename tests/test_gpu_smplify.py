@@ -464,6 +464,76 @@ def test_adam_inside_the_backward_kernel_matches_the_separate_launch(monkeypatch
     assert sum(steps_plain) > sum(steps_fused) >= 1 and sum(steps_plain) - sum(steps_fused) >= 3, (steps_fused, steps_plain)
 
 
+def test_fused_adam_only_when_the_stage2_objective_is_the_root_of_the_pass():
+    """optim.Adam(fuse_backward=True) may apply its update inside the body model's backward kernel only when EVERY gradient
+    of the two pose tensors flows through the stage-2 objective node.  `tail + extra(body_pose)` sent through
+    ops.backward_scalar reaches that node with the same cached unit seed (AddBackward forwards it unchanged): the update must
+    then be left to step(), with the extra term's gradient in it.  Also: a fused update whose step() never came does not
+    swallow the next one (zero_grad clears the flag), and a second backward before step() does not move the parameters twice."""
+    from tuch_amd import ops, optim
+    from tuch_amd.smplify.losses import contact_fitting_loss
+    batch = 3
+    s = _setup(batch, 31)
+    body, t = s['body'], s['t']
+    gm = t(body.geodesics > 0.3)
+    face_tensor = t(body.faces)[None].repeat(batch, 1, 1)
+
+    def objective(bp, go):
+        out = s['smpl'](global_orient=go, body_pose=bp, betas=t(s['be']))
+        return contact_fitting_loss(bp, go, None, None, t(s['be']), out.joints, gm, 0.02, t(s['cam_t']),
+                                    torch.zeros(batch, 2, device=DEV), t(s['kp'][:, :, :2]), t(s['kp'][:, :, 2]),
+                                    s['prior'], s['cdict'], [t(s['gt']), None],
+                                    torch.zeros(batch, dtype=torch.bool, device=DEV),
+                                    torch.ones(batch, dtype=torch.bool, device=DEV), out.vertices,
+                                    face_tensor=face_tensor, contact_loss_weight=2000.0, segments=s['segments'])
+
+    def one_step(fused, with_extra):
+        bp = t(s['bp']).requires_grad_(True)
+        go = t(s['go']).requires_grad_(True)
+        opt = optim.make_adam([bp, go], 1e-2, fuse_backward=fused)
+        assert isinstance(opt, optim.Adam)
+        loss = objective(bp, go)
+        if with_extra:
+            loss = loss + 1e4 * (bp ** 2).sum()
+        opt.zero_grad(set_to_none=True)
+        ops.backward_scalar(loss)
+        applied = opt._applied
+        opt.step()
+        torch.cuda.synchronize()
+        return bp.detach().clone(), go.detach().clone(), applied
+    ops.set_deterministic(True)
+    try:
+        with ops.off_default_stream(DEV):
+            bp_f, go_f, applied_f = one_step(True, False)
+            bp_p, go_p, applied_p = one_step(False, False)
+            assert applied_f and not applied_p                       # the plain objective IS the root: fused
+            assert torch.equal(bp_f, bp_p) and torch.equal(go_f, go_p)
+            bp_fx, go_fx, applied_fx = one_step(True, True)
+            bp_px, go_px, _ = one_step(False, True)
+            assert not applied_fx                                    # not the root: the update waits for step()
+            assert torch.equal(bp_fx, bp_px) and torch.equal(go_fx, go_px)
+            assert float((bp_fx - bp_f).abs().max()) > 1e-3          # ... and the extra term's gradient is in it
+            # a fused update without its step(): the next zero_grad() / step() pair is a real step again
+            bp = t(s['bp']).requires_grad_(True)
+            go = t(s['go']).requires_grad_(True)
+            opt = optim.make_adam([bp, go], 1e-2, fuse_backward=True)
+            ops.backward_scalar(objective(bp, go))
+            assert opt._applied
+            moved = bp.detach().clone()
+            ops.backward_scalar(objective(bp, go))                   # second pass before step(): gradients only
+            torch.cuda.synchronize()
+            assert torch.equal(bp.detach(), moved)
+            opt.zero_grad(set_to_none=True)
+            assert not opt._applied
+            (bp ** 2).sum().backward()
+            go.grad = torch.zeros_like(go)
+            opt.step()
+            torch.cuda.synchronize()
+            assert not torch.equal(bp.detach(), moved)               # this step() was not skipped
+    finally:
+        ops.set_deterministic(False)
+
+
 @pytest.mark.parametrize('shape_w', [1.0, 0.0])
 def test_stage1_objective_in_one_launch_vs_reference_and_torch_ops(shape_w):
     """camera_fitting_loss (losses.py:125-152) on a HIP device is ONE kernel (ops._Stage1Objective): the value against the

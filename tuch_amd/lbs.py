@@ -116,6 +116,10 @@ class _SmplLBS(torch.autograd.Function):
                                          and bp_t.shape == (b, 69) and go_t.data_ptr() == go.data_ptr()
                                          and bp_t.data_ptr() == bp.data_ptr()):
                 adam = None
+        if adam is not None and adam._applied:
+            # a second backward pass before step() / zero_grad(): the first pass has already moved the parameters; applying
+            # another update here would be a second optimiser step nobody asked for -- this pass only returns gradients
+            adam = None
         if adam is not None:
             group = adam.param_groups[0]
             st_go, st_bp = adam.state[go_t], adam.state[bp_t]

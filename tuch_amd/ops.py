@@ -8,6 +8,7 @@ from __future__ import annotations
 import contextlib
 import ctypes
 import os
+import threading
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -77,14 +78,30 @@ def set_deterministic(on: bool) -> None:
 
 
 _ONES = {}
+_ROOT = threading.local()      # .node: the autograd node of the loss a running backward_scalar() was called on
+
+
 def backward_scalar(loss: torch.Tensor) -> None:
     """``loss.backward()`` for a scalar loss with the seed gradient (ones) taken from a cache: autograd otherwise fills a
-    fresh one per call, a launch of its own at the head of every backward chain."""
+    fresh one per call, a launch of its own at the head of every backward chain.  The loss's own autograd node is
+    remembered for the duration of the pass: a node that finds ITSELF there is the root of the pass -- every gradient of
+    the pass flows through what it returns (what ops._Stage2Tail needs to know before it lets the body model's backward
+    kernel apply the optimiser's update; the seed's address alone does not say so: AddBackward hands the same tensor on)."""
     key = (loss.device, loss.dtype, tuple(loss.shape))
     seed = _ONES.get(key)
     if seed is None:
         seed = _ONES[key] = torch.ones(loss.shape, dtype=loss.dtype, device=loss.device)
-    loss.backward(gradient=seed)
+    prev = getattr(_ROOT, 'node', None)
+    _ROOT.node = loss.grad_fn
+    try:
+        loss.backward(gradient=seed)
+    finally:
+        _ROOT.node = prev
+
+
+def is_root_of_backward_scalar(node) -> bool:
+    """True inside a backward pass started by backward_scalar() on the output of exactly this autograd node."""
+    return node is not None and getattr(_ROOT, 'node', None) is node
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
@@ -336,12 +353,29 @@ _TICKETS = {}
 
 
 def _ticket(device) -> torch.Tensor:
-    """One zeroed int per (device, stream): the arrival counter of kernels whose last block finishes the job (they leave it
-    zero).  Calls on one stream are ordered, so they can share it; another stream gets its own."""
+    """A zeroed int: the arrival counter of kernels whose last block finishes the job (they leave it zero).
+    Eager calls: one per (device, stream) -- calls on one stream are ordered, so they can share it; another stream gets its
+    own.  Under hipGraph capture: a counter of the call's own, allocated from the capturing graph's pool and cleared by a
+    memset node of that graph -- a captured graph may be replayed on ANY stream, beside other graphs that were captured on
+    the same (shared) capture stream, so a counter keyed by the capture stream would be shared by launches that are not
+    ordered against each other (and would live in the pool of whichever graph happened to be captured first)."""
+    if device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+        return torch.zeros(1, dtype=torch.int32, device=device)
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     t = _TICKETS.get(key)
     if t is None:
         t = _TICKETS[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return t
+
+
+def _rows_of(t, b, tail, name):
+    """float32, contiguous, [b, *tail]; a batch of one is broadcast like the torch-op form would (the kernels index raw
+    pointers by body: any other shape would be an out-of-bounds read)."""
+    t = _f32(t)
+    if t.dim() == len(tail) + 1 and t.shape[0] == 1 and b > 1:
+        t = t.expand(b, *t.shape[1:]).contiguous()
+    if tuple(t.shape) != (b,) + tuple(tail):
+        raise ValueError('stage-1 objective: %s has shape %s, expected %s' % (name, tuple(t.shape), (b,) + tuple(tail)))
     return t
 
 
@@ -354,10 +388,18 @@ class _Stage1Objective(torch.autograd.Function):
     @staticmethod
     def forward(ctx, joints, camera_t, betas, camera_t_est, camera_center, joints_2d, joints_conf, focal, sigma, depth_w,
                 shape_w):
-        j, ct = _f32(joints), _f32(camera_t)
+        j = _f32(joints)
+        if j.dim() != 3 or j.shape[2] != 3:
+            raise ValueError('stage-1 objective: joints must be [B,J,3], got %s' % (tuple(j.shape),))
         b, nj, _ = j.shape
-        be = _f32(betas) if betas is not None and shape_w != 0.0 else None
-        est, cc, j2d, conf = _f32(camera_t_est), _f32(camera_center), _f32(joints_2d), _f32(joints_conf)
+        ct = _rows_of(camera_t, b, (3,), 'camera_t')
+        be = None
+        if betas is not None and shape_w != 0.0:
+            if betas.dim() != 2:
+                raise ValueError('stage-1 objective: betas must be [B,n], got %s' % (tuple(betas.shape),))
+            be = _rows_of(betas, b, (betas.shape[1],), 'betas')
+        est, cc = _rows_of(camera_t_est, b, (3,), 'camera_t_est'), _rows_of(camera_center, b, (2,), 'camera_center')
+        j2d, conf = _rows_of(joints_2d, b, (nj, 2), 'joints_2d'), _rows_of(joints_conf, b, (nj,), 'joints_conf')
         out = torch.empty(1, dtype=torch.float32, device=j.device)
         share = torch.empty(b, dtype=torch.float32, device=j.device)
         gj = torch.empty_like(j)
@@ -369,6 +411,7 @@ class _Stage1Objective(torch.autograd.Function):
             _C.ptr(_ticket(j.device)), _C.ptr(out), _C.ptr(gj), _C.ptr(gc), _C.ptr(gb), _C.stream()))
         ctx.save_for_backward(gj, gc, gb)
         ctx.in_dtypes = (joints.dtype, camera_t.dtype, betas.dtype if betas is not None else None)
+        ctx.in_shapes = (tuple(camera_t.shape), tuple(betas.shape) if betas is not None else None)
         return out[0]
 
     @staticmethod
@@ -379,6 +422,11 @@ class _Stage1Objective(torch.autograd.Function):
             g = g.reshape(()).to(torch.float32)
             gj, gc, gb = gj * g, gc * g, (gb * g if gb is not None else None)
         dj, dc, db = ctx.in_dtypes
+        sc, sb = ctx.in_shapes
+        if tuple(gc.shape) != sc:                     # a broadcast batch of one: its gradient is the sum over the bodies
+            gc = gc.sum(0, keepdim=True)
+        if gb is not None and tuple(gb.shape) != sb:
+            gb = gb.sum(0, keepdim=True)
         return (gj.to(dj), gc.to(dc), gb.to(db) if gb is not None else None) + (None,) * 8
 
 
@@ -468,16 +516,20 @@ class _Stage2Tail(torch.autograd.Function):
         dv, dj, dc, dp = ctx.in_dtypes
         # loss.backward() through ops.backward_scalar seeds the graph with a cached tensor of ones: recognised by its
         # address (no device round trip).  Any other upstream gradient scales the unit gradients.
-        root = any(g.data_ptr() == seed.data_ptr() for seed in _ONES.values())
-        if not root:
+        unit = any(g.data_ptr() == seed.data_ptr() for seed in _ONES.values())
+        if not unit:
             g = g.reshape(()).to(torch.float32)
             gv, gj, gc, gp = gv * g, gj * g, gc * g, gp * g
+        # the ROOT of the pass: backward_scalar() was called on THIS node's output (a loss like `tail + other(body_pose)`
+        # reaches this node with the same unit seed -- AddBackward forwards it unchanged -- but then not every gradient of
+        # the parameters flows through here, and the optimiser's update must not be applied from this node's gradient alone)
+        root = unit and is_root_of_backward_scalar(ctx)
         if ctx.lbs_node is not None and _graph_task_id() >= 0:
             # tagged with THIS backward pass: the body model's node takes it only within the same pass (a gradient left by
             # a pass that never reached that node must not leak into a later one)
             ctx.lbs_node.pose_grad_extra = (gp, _graph_task_id())
-            # seeded by ops.backward_scalar: this node is the ROOT of the pass, every gradient of the fit's parameters flows
-            # through what it returns -- the body model's node may then apply the optimiser's update itself (lbs.py)
+            # this node is the ROOT of the pass (see above): every gradient of the fit's parameters flows through what it
+            # returns -- the body model's node may then apply the optimiser's update itself (lbs.py)
             ctx.lbs_node.root_pass = _graph_task_id() if root else None
             return gv.to(dv), gj.to(dj), gc.to(dc), None, None, None, None, None
         return gv.to(dv), gj.to(dj), gc.to(dc), gp.to(dp), None, None, None, None

@@ -78,6 +78,8 @@ class Adam:
                 _FUSABLE[id(p)] = self
 
     def zero_grad(self, set_to_none: bool = True) -> None:
+        # a fused update whose step() never came (an exception, a gradient-only evaluation) must not swallow the NEXT step()
+        self._applied = False
         for p in self.params:
             if p.grad is not None:
                 if set_to_none:
@@ -88,6 +90,7 @@ class Adam:
     def reset(self) -> None:
         """A fresh optimiser (the reference creates one per stage and call): moments and step counter zeroed in place."""
         torch._foreach_zero_([self.step_count] + [s[k] for s in self.state.values() for k in ('exp_avg', 'exp_avg_sq')])
+        self._applied = False
 
     def step(self) -> None:
         if self._applied:               # the backward pass has applied this update already (fuse_backward)
