@@ -114,3 +114,43 @@ def test_concatenated_pose_and_the_two_pose_tensors_agree(bodies, pose2rot):
     ((v1 * w).sum() + j1.sum()).backward()
     ((out.vertices * w).sum() + out.joints.sum()).backward()
     assert torch.equal(full.grad, torch.cat([go_.grad, bp_.grad], 1))
+
+
+@pytest.mark.parametrize('size,batch', [('tiny', 5), ('full', 33), ('ico_full', 64), ('full', 16)])
+def test_sparse_skinning_is_the_dense_sum_bit_for_bit_and_every_batch_form_agrees(bodies, size, batch, monkeypatch):
+    """(1) A model whose vertices have at most four non-zero skinning weights (SMPL's own) takes the sparse skinning kernels:
+    the same fma chain as the dense 24-joint loop minus its fma(0, A, T) = T terms -- vertices, joints and gradients are
+    the dense kernels' BITS (TUCH_SKIN_DENSE=1 at model creation keeps the dense form).  (2) A body with more than four
+    weights per vertex falls back to the dense kernels and still matches the oracle.  The batch sizes cover the three
+    forms of the blend kernel (one / two body tiles per wavefront, K split over the workgroup)."""
+    body = bodies[size]
+    assert int((body.lbs_weights != 0).sum(1).max()) <= 4
+    bp, go, be = random_poses(batch, 77)
+    t = lambda a: torch.tensor(a, device=DEV)
+    rng = np.random.default_rng(9)
+    gv, gj = t(rng.standard_normal((batch, body.num_verts, 3)).astype(np.float32)), t(rng.standard_normal((batch, 49, 3)).astype(np.float32))
+
+    def run(dense):
+        if dense:
+            monkeypatch.setenv('TUCH_SKIN_DENSE', '1')
+        else:
+            monkeypatch.delenv('TUCH_SKIN_DENSE', raising=False)
+        smpl = _smpl(body)
+        b_, p_, g_ = t(be).requires_grad_(True), t(bp).requires_grad_(True), t(go).requires_grad_(True)
+        out = smpl(betas=b_, body_pose=p_, global_orient=g_)
+        torch.autograd.backward([out.vertices, out.joints], [gv, gj])
+        return [x.detach().clone() for x in (out.vertices, out.joints, b_.grad, p_.grad, g_.grad)]
+    sparse, dense = run(False), run(True)
+    for a, b, name in zip(sparse, dense, ('verts', 'joints', 'g_betas', 'g_body_pose', 'g_global_orient')):
+        assert torch.equal(a, b), name
+    # more than four weights per vertex: the dense kernels, against the oracle
+    import copy
+    fat = copy.copy(body)
+    w = body.lbs_weights.astype(np.float64) + 0.02
+    fat.lbs_weights = (w / w.sum(1, keepdims=True)).astype(np.float32)
+    monkeypatch.delenv('TUCH_SKIN_DENSE', raising=False)
+    n = min(batch, 3)
+    out = _smpl(fat)(betas=t(be[:n]), body_pose=t(bp[:n]), global_orient=t(go[:n]))
+    t64 = lambda a: torch.tensor(a, dtype=torch.float64)
+    v64, _ = ol.smpl_forward(ol.model_tensors(fat, torch.float64), t64(be[:n]), t64(bp[:n]), t64(go[:n]))
+    assert_close(out.vertices.cpu().numpy(), v64.numpy(), 1e-4, 5e-6, 'dense-weight body vs fp64')

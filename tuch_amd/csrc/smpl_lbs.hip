@@ -28,12 +28,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct tuch_smpl_model {
     int V, N3;                 // vertices, 3V
-    float* blend;              // [kFeat][N3]: posedirs (207) | shapedirs^T (10) | v_template | 0 0
+    int N3p;                   // row stride of blend / v_posed / g_vposed: 3V rounded up to 64 floats (rows start on 256 bytes)
+    float* blend;              // [kFeatRows][N3p]: posedirs (207) | shapedirs^T (10) | v_template | zero rows; zero padding columns
     float* J_template;         // [24*3]
     float* J_shapedirs;        // [24*3][10]
     float* weights;            // [V][24]
     float* weights_t;          // [24][V]: the same by joint -- a wavefront's 64 vertices read one joint's weights from two
                                // cache lines; by vertex (96 bytes apart) every load touched 64 lines
+    int skin_nnz;              // largest number of non-zero skinning weights of a vertex; <= 4: the sparse tables below exist
+    int32_t* skin_joint;       // [4][V]: the vertex's joints with a non-zero weight in ascending order (padding: joint 0) ...
+    float* skin_weight;        // [4][V]: ... and their weights (padding: 0).  SMPL's own lbs_weights have at most 4 per vertex
     float* Jrx;                // [9][V]  J_regressor_extra
     int32_t* parents;          // [48]: parent of joint k (-1 for the root) | depth of joint k in the tree
     int max_depth;
@@ -48,6 +52,7 @@ constexpr int kJoints = 24;
 constexpr int kBetas = 10;
 constexpr int kPoseFeat = 207;
 constexpr int kFeat = 220;            // 207 + 10 + 1, padded to a multiple of 4
+constexpr int kFeatRows = 224;        // rows of the matrix in memory: the forward's four K quarters are 56 rows each
 constexpr int kPicked = 21;
 constexpr int kExtra = 9;
 constexpr int kAllJoints = kJoints + kPicked + kExtra;   // 54
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(64) void pose_kernel(
     float* __restrict__ J_out,      // [B,24,3]
     float* __restrict__ world_out,  // [B,24,12] world rotation | world translation (= posed joint)
     float* __restrict__ A_out,      // [B,24,12] rotation | translation relative to the rest pose
-    float* __restrict__ feat, int fpad)       // [220][fpad]: feature-major, bodies contiguous (blend_kernel)
+    float* __restrict__ feat, int fpad)       // [224][fpad]: feature-major, bodies contiguous (blend_kernel)
 {
     __shared__ float sR[kJoints][9];
     __shared__ float sJ[kJoints][3];
@@ -193,11 +198,7 @@ __global__ __launch_bounds__(64) void pose_kernel(
         J_out[(size_t)b * kJoints * 3 + i] = acc;
     }
     if (t < kBetas) feat[(size_t)(kPoseFeat + t) * fpad + b] = be[t];
-    if (t == 0) {
-        feat[(size_t)217 * fpad + b] = 1.0f;
-        feat[(size_t)218 * fpad + b] = 0.0f;
-        feat[(size_t)219 * fpad + b] = 0.0f;
-    }
+    if (t >= 32 && t < 32 + kFeatRows - 217) feat[(size_t)(217 + t - 32) * fpad + b] = t == 32 ? 1.0f : 0.0f;
     // Kinematic chain, one tree level at a time (SMPL: 9 levels), every joint of a level on its own lane, the world
     // transforms in LDS.  (One lane walking all 24 joints through global memory was 23 store -> load round trips.)
     __shared__ float sW[kJoints][12];
@@ -247,21 +248,66 @@ __global__ __launch_bounds__(64) void pose_kernel(
     }
 }
 
-// v_posed[b][n] = sum_k feat[k][b] * blend[k][n]   (features stored feature-major by pose_kernel).
-// One workgroup per (64 bodies, 32 columns); its four wavefronts take a quarter of K each (14 MFMA k-steps) and hold
-// all four 16-body tiles, so the matrix is read once per 64 bodies.  The MFMA rows / columns are dealt out so that a
-// lane's operands are contiguous in memory: A row i of body tile t is body 4 i + t, B column c of tile j is column
-// 2 c + j -- one 16-byte load brings a lane's A values of a k-step for all four tiles, one 8-byte load its B values
-// (blend rows start on 4-byte boundaries only: the loads are typed so).  All 28 loads of the quarter are issued before
-// the first MFMA waits: with one wavefront walking 55 k-steps of scalar gathers this kernel was a chain of load
-// latencies, 28 us for a 17 MB matrix.  The partial tiles meet in LDS: wavefront w finishes and stores body tile w
-// (fixed order of addition).
-constexpr int kBlendSteps = kFeat / 4;                  // MFMA k-steps (K = 4 each)
-constexpr int kBlendWaveSteps = (kBlendSteps + 3) / 4;  // per wavefront
-constexpr int kBlendJ = 2;                              // 16-column tiles per workgroup
-typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+// v_posed[b][n] = sum_k feat[k][b] * blend[k][n],  feat = [R[1:] - I (207) | beta (10) | 1 | 0 ...] (pose_kernel).
+// One WAVEFRONT per 16 bodies x 16 columns, the whole K = 224 in one chain of 56 v_mfma_f32_16x16x4_f32 (exact f32 FMA
+// chains, one fixed order): no split of K, so no partial tiles, no LDS, no barrier -- and every one of a wavefront's 112
+// operand loads (4 bytes per lane: 110 registers) is in flight before its first MFMA waits.
+// What bounds it: NOT the stream of the matrix -- 18.6 MB arrive in 2.5 - 4 us even from a cold cache (tools/ubench/
+// stream_read.hip; the four body tiles of a batch of 64 read it four times, out of the L2 / the Infinity Cache) -- but the
+// FP32 matrix cores: 4 x 1296 x 56 MFMAs of 32 cycles each over 1024 SIMDs are 3.8 us at batch 64 with every SIMD evenly
+// loaded (5184 wavefronts: 5 or 6 per SIMD); a batch of 8 is one body tile, a quarter of that (round 4: always four).
+// Measured on the way (batch 64): K split over the four wavefronts of a workgroup with 4 x 2 tiles each (round 4) 14.5 us,
+// with 4 x 4 tiles and 16-byte operand loads 20 us (half as many wavefronts, twice as long), with the features formed
+// in-kernel (no wait for pose_kernel, Rodrigues of the quarter's joints per wavefront) 17 us.
+constexpr int kBlendSteps = kFeatRows / 4;              // 56 MFMA k-steps (K = 4 each)
+constexpr int kBlendCols = 64;                          // columns per workgroup: four wavefronts, 16 each
+template <int kTiles>                                   // body tiles per wavefront (row i of tile t = body kTiles i + t)
 __global__ __launch_bounds__(256) void blend_kernel(
-    const float* __restrict__ feat, int fpad, const float* __restrict__ blend, int B, int N3,
+    const float* __restrict__ feat, int fpad, const float* __restrict__ blend, int B, int N3p, float* __restrict__ v_posed)
+{
+    typedef float avec __attribute__((ext_vector_type(kTiles)));
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lm = lane & 15, lq = lane >> 4;
+    const int m_base = blockIdx.y * (16 * kTiles);
+    const int col = blockIdx.x * kBlendCols + wave * 16 + lm;
+    const float* b_ptr = blend + (size_t)lq * N3p + col;
+    const float* a_ptr = feat + (size_t)lq * fpad + m_base + kTiles * lm;
+    float bv[kBlendSteps];
+    avec av[kBlendSteps];
+#pragma unroll
+    for (int i = 0; i < kBlendSteps; ++i) {
+        bv[i] = b_ptr[(size_t)(4 * i) * N3p];
+        av[i] = *(const avec*)(a_ptr + (size_t)(4 * i) * fpad);
+    }
+    __builtin_amdgcn_sched_barrier(0);          // everything is in flight before the first MFMA waits
+    f32x4 acc[kTiles];
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < kBlendSteps; ++i)
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][t], bv[i], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m_base + (lq * 4 + r) * kTiles + t;
+            if (m < B) v_posed[(size_t)m * N3p + col] = acc[t][r];             // (padding columns: zeros)
+        }
+}
+
+// The form for more than 32 bodies (round 4's kernel on the padded matrix): 64 bodies x 32 columns per workgroup, its four
+// wavefronts take a quarter of K each and hold all 4 x 2 tiles, the partial tiles meet in LDS.  At batch 64 every form is
+// bound by what its wavefronts ask the L1 for, not by the matrix cores or the 18.6 MB of the matrix (tools/ubench/
+// blend_phases.hip: clock stamps per wavefront): one tile per wavefront re-reads the features and the matrix four times
+// (148 MB through 64 B / clk / CU: operands arrive after a median 11 k cycles), four body tiles per wavefront 91 MB (4.9 k
+// cycles, then 2 x 7.7 k cycles of MFMAs on the SIMDs that hold two of the 1296 wavefronts), this one 54 MB (7.1 k cycles,
+// 3.9 k of MFMAs, 5.7 k for the exchange + stores): 12.3 us back to back against 14.2 - 15.0.
+constexpr int kBlendWaveSteps = kBlendSteps / 4;        // per wavefront (K split four ways)
+constexpr int kBlendJ = 2;                              // 16-column tiles per workgroup (K-split form)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void blend_ksplit_kernel(
+    const float* __restrict__ feat, int fpad, const float* __restrict__ blend, int B, int N3p,
     float* __restrict__ v_posed)
 {
     __shared__ float red[4][3][kBlendJ * 4][64];     // [body tile][sender slot][j * 4 + r][lane]
@@ -270,14 +316,14 @@ __global__ __launch_bounds__(256) void blend_kernel(
     const int m_base = blockIdx.y * 64;
     const int cbase = blockIdx.x * (16 * kBlendJ) + lm * kBlendJ;      // this lane's columns: cbase + j
     const float* a_ptr = feat + m_base + lm * 4;
-    const float* b_ptr = blend + (cbase < N3 ? cbase : 0);             // the matrix has 4 floats of slack behind it
+    const float* b_ptr = blend + cbase;                                // (rows start on 256 bytes: aligned 8-byte loads)
     f32x4 a[kBlendWaveSteps];
-    f32x2u bv[kBlendWaveSteps];
+    f32x2 bv[kBlendWaveSteps];
 #pragma unroll
     for (int i = 0; i < kBlendWaveSteps; ++i) {
-        const int k = min(wave * kBlendWaveSteps + i, kBlendSteps - 1) * 4 + lq;
+        const int k = (wave * kBlendWaveSteps + i) * 4 + lq;           // (rows 220 .. 223 of the matrix are zero)
         a[i] = *(const f32x4*)(a_ptr + (size_t)k * fpad);
-        bv[i] = *(const f32x2u*)(b_ptr + (size_t)k * N3);
+        bv[i] = *(const f32x2*)(b_ptr + (size_t)k * N3p);
     }
     __builtin_amdgcn_sched_barrier(0);          // the whole quarter is in flight before the first MFMA waits
     f32x4 acc[4][kBlendJ];
@@ -287,10 +333,9 @@ __global__ __launch_bounds__(256) void blend_kernel(
         for (int j = 0; j < kBlendJ; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < kBlendWaveSteps; ++i) {
-        const bool live = wave * kBlendWaveSteps + i < kBlendSteps;   // the last wavefront has one step less
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const float av = (i < kBlendSteps - 3 * kBlendWaveSteps || live) ? a[i][t] : 0.f;
+            const float av = a[i][t];
 #pragma unroll
             for (int j = 0; j < kBlendJ; ++j)
                 acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[i][j], acc[t][j], 0, 0, 0);
@@ -316,7 +361,7 @@ __global__ __launch_bounds__(256) void blend_kernel(
             for (int t = 0; t < 4; ++t) sum = (t == wave) ? acc[t][j][r] : sum;     // own partial, no dynamic index
 #pragma unroll
             for (int slot = 0; slot < 3; ++slot) sum += red[wave][slot][j * 4 + r][lane];
-            if (m < B && cbase + j < N3) v_posed[(size_t)m * N3 + cbase + j] = sum;
+            if (m < B) v_posed[(size_t)m * N3p + cbase + j] = sum;              // (padding columns: zeros)
         }
     }
 }
@@ -340,8 +385,20 @@ __device__ __forceinline__ void butterfly_level(float (&val)[32], int lane)
 // contribution of its 256 vertices, xpart[b][block][9][3] (a transposing butterfly over the wavefront, then the four
 // wavefronts through LDS: a fixed order); assemble_joints_kernel adds the blocks up.  As a kernel of its own (MFMA split-K over the finished vertices)
 // the regression was 21 us of pure latency in front of everything that waits for the joints.
+// kSparse: every vertex has at most four non-zero weights (SMPL's own have): T = sum over those joints in ascending order --
+// the same fma chain as the dense loop, whose other 20 terms are fma(0, A, T) = T, so the same BITS for finite transforms --
+// with the body's 24 transforms in LDS (per-lane joints: the dense form reads them through scalar loads): 48 fma + 12
+// 16-byte LDS reads per vertex instead of 288 fma + 24 weight loads.
+__device__ __forceinline__ void stage_transforms(float* sA, const float* __restrict__ Ab)
+{
+    for (int i = threadIdx.x; i < kJoints * 12 / 4; i += kSkinBlock)
+        reinterpret_cast<f32x4*>(sA)[i] = reinterpret_cast<const f32x4*>(Ab)[i];
+    __syncthreads();
+}
+template <bool kSparse>
 __global__ __launch_bounds__(kSkinBlock) void skin_kernel(
-    const float* __restrict__ v_posed, const float* __restrict__ A, const float* __restrict__ weights_t,
+    const float* __restrict__ v_posed, int N3p, const float* __restrict__ A, const float* __restrict__ weights_t,
+    const int32_t* __restrict__ skin_joint, const float* __restrict__ skin_weight,
     const float* __restrict__ Jrx, int V, float* __restrict__ verts, float* __restrict__ xpart)
 {
     const int b = blockIdx.y;
@@ -349,17 +406,34 @@ __global__ __launch_bounds__(kSkinBlock) void skin_kernel(
     const bool real = v < V;
     const int vc = real ? v : V - 1;
     const float* Ab = A + (size_t)b * kJoints * 12;   // wave-uniform -> scalar loads
-    const float* w = weights_t + vc;                  // [24][V]: coalesced
     float T[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) T[e] = 0.f;
+    if constexpr (kSparse) {
+        __shared__ __attribute__((aligned(16))) float sA[kJoints * 12];
+        int jn[4];
+        float wn[4];
 #pragma unroll
-    for (int j = 0; j < kJoints; ++j) {
-        const float wj = w[(size_t)j * V];
+        for (int n = 0; n < 4; ++n) { jn[n] = skin_joint[(size_t)n * V + vc]; wn[n] = skin_weight[(size_t)n * V + vc]; }
+        stage_transforms(sA, Ab);
 #pragma unroll
-        for (int e = 0; e < 12; ++e) T[e] = __builtin_fmaf(wj, Ab[j * 12 + e], T[e]);
+        for (int n = 0; n < 4; ++n) {
+            const f32x4* a = reinterpret_cast<const f32x4*>(sA + jn[n] * 12);
+            const f32x4 a0 = a[0], a1 = a[1], a2 = a[2];
+            const float aj[12] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3], a2[0], a2[1], a2[2], a2[3]};
+#pragma unroll
+            for (int e = 0; e < 12; ++e) T[e] = __builtin_fmaf(wn[n], aj[e], T[e]);
+        }
+    } else {
+        const float* w = weights_t + vc;                  // [24][V]: coalesced
+#pragma unroll
+        for (int j = 0; j < kJoints; ++j) {
+            const float wj = w[(size_t)j * V];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) T[e] = __builtin_fmaf(wj, Ab[j * 12 + e], T[e]);
+        }
     }
-    const float* p = v_posed + ((size_t)b * V + vc) * 3;
+    const float* p = v_posed + (size_t)b * N3p + (size_t)vc * 3;
     float o[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) o[i] = T[3 * i] * p[0] + T[3 * i + 1] * p[1] + T[3 * i + 2] * p[2] + T[9 + i];
@@ -447,12 +521,13 @@ __device__ __forceinline__ float g_all_entry(const int* sMap, const float* sG, i
 //   g_v      = g_verts + Jrx^T g_extra + picked-vertex gradients
 //   g_vposed = T_R^T g_v
 //   gA_part[b][block][j][n] = sum_v W[v][j] * (g_v (x) [v_posed; 1])[n]      (MFMA, K = vertices)
+template <bool kSparse>
 __global__ __launch_bounds__(kSkinBlock) void skin_bwd_kernel(
     const float* __restrict__ g_verts, const float* __restrict__ g_joints, const int32_t* __restrict__ joint_map,
     const float* __restrict__ Jrx,
-    const int32_t* __restrict__ extra_ids, const float* __restrict__ v_posed, const float* __restrict__ A,
-    const float* __restrict__ weights, const float* __restrict__ weights_t, int V, float* __restrict__ g_vposed,
-    float* __restrict__ gA_part)
+    const int32_t* __restrict__ extra_ids, const float* __restrict__ v_posed, int N3p, const float* __restrict__ A,
+    const float* __restrict__ weights, const float* __restrict__ weights_t, const int32_t* __restrict__ skin_joint,
+    const float* __restrict__ skin_weight, int V, float* __restrict__ g_vposed, float* __restrict__ gA_part)
 {
     __shared__ float sG[kSkinBlock][16];      // per vertex: g_v (x) [v_posed;1], 12 used
     __shared__ int sIds[kPicked];
@@ -475,19 +550,36 @@ __global__ __launch_bounds__(kSkinBlock) void skin_bwd_kernel(
 #pragma unroll
     for (int j = 0; j < kExtra; ++j) jr[j] = Jrx[(size_t)j * V + vc];
     const float* Ab = A + (size_t)b * kJoints * 12;
-    const float* w = weights_t + vc;                  // [24][V]: coalesced
     float T[9];
 #pragma unroll
     for (int e = 0; e < 9; ++e) T[e] = 0.f;
-#pragma unroll
-    for (int j = 0; j < kJoints; ++j) {
-        const float wj = w[(size_t)j * V];
-#pragma unroll
-        for (int e = 0; e < 9; ++e) T[e] = __builtin_fmaf(wj, Ab[j * 12 + e], T[e]);
-    }
-    const float* p = v_posed + ((size_t)b * V + vc) * 3;
+    const float* p = v_posed + (size_t)b * N3p + (size_t)vc * 3;
     const float ph[4] = {p[0], p[1], p[2], 1.0f};
-    __syncthreads();
+    if constexpr (kSparse) {                         // (see skin_kernel: the same bits as the dense loop)
+        __shared__ __attribute__((aligned(16))) float sA[kJoints * 12];
+        int jn[4];
+        float wn[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) { jn[n] = skin_joint[(size_t)n * V + vc]; wn[n] = skin_weight[(size_t)n * V + vc]; }
+        stage_transforms(sA, Ab);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const f32x4* a = reinterpret_cast<const f32x4*>(sA + jn[n] * 12);
+            const f32x4 a0 = a[0], a1 = a[1], a2 = a[2];
+            const float aj[9] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3], a2[0]};
+#pragma unroll
+            for (int e = 0; e < 9; ++e) T[e] = __builtin_fmaf(wn[n], aj[e], T[e]);
+        }
+    } else {
+        const float* w = weights_t + vc;                  // [24][V]: coalesced
+#pragma unroll
+        for (int j = 0; j < kJoints; ++j) {
+            const float wj = w[(size_t)j * V];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) T[e] = __builtin_fmaf(wj, Ab[j * 12 + e], T[e]);
+        }
+        __syncthreads();
+    }
     if (threadIdx.x < (kPicked + kExtra) * 3)
         sGall[threadIdx.x] = g_all_entry(sMap, sGj, kJoints + threadIdx.x / 3, threadIdx.x % 3);
     __syncthreads();
@@ -504,7 +596,7 @@ __global__ __launch_bounds__(kSkinBlock) void skin_bwd_kernel(
         }
     if (!ok) { g[0] = 0.f; g[1] = 0.f; g[2] = 0.f; }
     if (ok) {
-        float* o = g_vposed + ((size_t)b * V + v) * 3;
+        float* o = g_vposed + (size_t)b * N3p + (size_t)v * 3;
 #pragma unroll
         for (int i = 0; i < 3; ++i) o[i] = T[i] * g[0] + T[3 + i] * g[1] + T[6 + i] * g[2];
     }
@@ -566,7 +658,7 @@ constexpr int kBlendBwdWaves = 4;           // 3 workgroups fit a CU: all 81 x 7
 constexpr int kBlendBwdAccs = kBlendBwdTiles * kBlendBwdGroups;
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 __global__ __launch_bounds__(64 * kBlendBwdWaves) void blend_bwd_kernel(
-    const float* __restrict__ g_vposed, const float* __restrict__ blend, int B, int N3, int bpad,
+    const float* __restrict__ g_vposed, const float* __restrict__ blend, int B, int N3, int N3p, int bpad,
     float* __restrict__ part)
 {
     __shared__ float red[kBlendBwdWaves][kBlendBwdAccs * 4][64];
@@ -582,10 +674,10 @@ __global__ __launch_bounds__(64 * kBlendBwdWaves) void blend_bwd_kernel(
         const int kc = kk < N3 ? kk : 0;
 #pragma unroll
         for (int g = 0; g < kBlendBwdGroups; ++g)
-            a4[it][g] = *(const f32x4u*)(g_vposed + (size_t)min((g0 + g) * 16 + lm, B - 1) * N3 + kc);
+            a4[it][g] = *(const f32x4*)(g_vposed + (size_t)min((g0 + g) * 16 + lm, B - 1) * N3p + kc);
 #pragma unroll
         for (int j = 0; j < kBlendBwdTiles; ++j)
-            b4[it][j] = *(const f32x4u*)(blend + (size_t)min((j0 + j) * 16 + lm, kFeat - 1) * N3 + kc);
+            b4[it][j] = *(const f32x4*)(blend + (size_t)min((j0 + j) * 16 + lm, kFeat - 1) * N3p + kc);
     }
     __builtin_amdgcn_sched_barrier(0);          // every load of the wavefront is in flight before the first MFMA waits
     f32x4 acc[kBlendBwdGroups][kBlendBwdTiles];
@@ -897,8 +989,8 @@ FwdLayout fwd_layout(const tuch_smpl_model* m, int B)
     l.world = o;   o += align256((size_t)B * kJoints * 12 * 4);
     l.A = o;       o += align256((size_t)B * kJoints * 12 * 4);
     l.fpad = ceil_div(B, 64) * 64;
-    l.feat = o;    o += align256((size_t)l.fpad * kFeat * 4);
-    l.v_posed = o; o += align256((size_t)B * m->N3 * 4);
+    l.feat = o;    o += align256((size_t)l.fpad * kFeatRows * 4);
+    l.v_posed = o; o += align256((size_t)B * m->N3p * 4);
     l.partial = o; o += align256((size_t)B * ceil_div(m->V, kSkinBlock) * kExtra * 3 * 4);   // xpart of skin_kernel
     l.total = o;
     return l;
@@ -913,7 +1005,7 @@ BwdLayout bwd_layout(const tuch_smpl_model* m, int B)
     l.feat_chunks = ceil_div(m->N3, kBlendBwdChunk * kBlendBwdWaves);
     l.bpad = ceil_div(B, 16) * 16;
     size_t o = 0;
-    l.g_vposed = o;  o += align256((size_t)B * m->N3 * 4);
+    l.g_vposed = o;  o += align256((size_t)B * m->N3p * 4);
     l.gA_part = o;   o += align256((size_t)B * l.skin_blocks * 32 * 16 * 4);   // one [32][16] slice per (body, vertex block)
     l.feat_part = o; o += align256((size_t)l.feat_chunks * l.bpad * 224 * 4);
     l.total = o;
@@ -931,7 +1023,8 @@ int upload(T** dst, const T* src, size_t count)
 extern "C" void tuch_smpl_model_destroy(tuch_smpl_model* m)
 {
     if (!m) return;
-    void* dev[] = {m->blend, m->J_template, m->J_shapedirs, m->weights, m->weights_t, m->Jrx, m->parents, m->extra_ids, m->joint_map};
+    void* dev[] = {m->blend, m->J_template, m->J_shapedirs, m->weights, m->weights_t, m->Jrx, m->parents, m->extra_ids, m->joint_map,
+                   m->skin_joint, m->skin_weight};
     for (void* p : dev) tuch_table_free(p);
     free(m);
 }
@@ -956,12 +1049,13 @@ extern "C" int tuch_smpl_model_create(tuch_smpl_model** out, int V, const float*
     tuch_smpl_model* m = (tuch_smpl_model*)calloc(1, sizeof(tuch_smpl_model));
     m->V = V;
     m->N3 = 3 * V;
-    const size_t n3 = (size_t)m->N3;
-    std::vector<float> blend((size_t)kFeat * n3 + 4, 0.f);      // + 4: the adjoint reads whole 4-float groups of a row
-    memcpy(blend.data(), posedirs, sizeof(float) * kPoseFeat * n3);
+    m->N3p = ceil_div(m->N3, 64) * 64;
+    const size_t n3 = (size_t)m->N3, n3p = (size_t)m->N3p;
+    std::vector<float> blend((size_t)kFeatRows * n3p, 0.f);      // zero rows 218 .. 223, zero padding columns
+    for (int k = 0; k < kPoseFeat; ++k) memcpy(blend.data() + (size_t)k * n3p, posedirs + (size_t)k * n3, sizeof(float) * n3);
     for (size_t n = 0; n < n3; ++n) {
-        for (int l = 0; l < kBetas; ++l) blend[(size_t)(kPoseFeat + l) * n3 + n] = shapedirs[n * kBetas + l];
-        blend[(size_t)217 * n3 + n] = v_template[n];
+        for (int l = 0; l < kBetas; ++l) blend[(size_t)(kPoseFeat + l) * n3p + n] = shapedirs[n * kBetas + l];
+        blend[(size_t)217 * n3p + n] = v_template[n];
     }
     // joint regressor folded through the shape basis (double accumulation, rounded once)
     std::vector<float> jt(kJoints * 3), js((size_t)kJoints * 3 * kBetas);
@@ -995,6 +1089,31 @@ extern "C" int tuch_smpl_model_create(tuch_smpl_model** out, int V, const float*
         for (int v = 0; v < V; ++v)
             for (int j = 0; j < kJoints; ++j) wt[(size_t)j * V + v] = lbs_weights[(size_t)v * kJoints + j];
         rc = upload(&m->weights_t, wt.data(), wt.size());
+    }
+    if (rc == TUCH_OK) {
+        // sparse skinning tables: the non-zero weights of every vertex in ascending joint order
+        m->skin_nnz = 0;
+        for (int v = 0; v < V; ++v) {
+            int n = 0;
+            for (int j = 0; j < kJoints; ++j) n += lbs_weights[(size_t)v * kJoints + j] != 0.0f;
+            m->skin_nnz = std::max(m->skin_nnz, n);
+        }
+        const bool off = getenv("TUCH_SKIN_DENSE") && atoi(getenv("TUCH_SKIN_DENSE")) != 0;     // A/B, tests (read per model)
+        if (m->skin_nnz <= 4 && !off) {
+            std::vector<int32_t> sj((size_t)4 * V, 0);
+            std::vector<float> sw((size_t)4 * V, 0.f);
+            for (int v = 0; v < V; ++v) {
+                int n = 0;
+                for (int j = 0; j < kJoints; ++j)
+                    if (lbs_weights[(size_t)v * kJoints + j] != 0.0f) {
+                        sj[(size_t)n * V + v] = j;
+                        sw[(size_t)n * V + v] = lbs_weights[(size_t)v * kJoints + j];
+                        ++n;
+                    }
+            }
+            rc = upload(&m->skin_joint, sj.data(), sj.size());
+            if (rc == TUCH_OK) rc = upload(&m->skin_weight, sw.data(), sw.size());
+        }
     }
     if (rc == TUCH_OK) rc = upload(&m->Jrx, J_regressor_extra, (size_t)kExtra * V);
     if (rc == TUCH_OK) rc = upload(&m->parents, par, 2 * kJoints);
@@ -1044,10 +1163,21 @@ extern "C" int tuch_smpl_forward_split(const tuch_smpl_model* m, const float* be
     const PoseRef pose{global_orient, body_pose, global_orient_stride, body_pose_stride};
     hipLaunchKernelGGL(pose_kernel, dim3(B), dim3(64), 0, s, betas, pose, pose2rot, (const float*)m->J_template,
                        (const float*)m->J_shapedirs, (const int32_t*)m->parents, m->max_depth, R, J, world, A, feat, l.fpad);
-    hipLaunchKernelGGL(blend_kernel, dim3(ceil_div(m->N3, 16 * kBlendJ), l.fpad / 64), dim3(256), 0, s,
-                       (const float*)feat, l.fpad, (const float*)m->blend, B, m->N3, v_posed);
-    hipLaunchKernelGGL(skin_kernel, dim3(ceil_div(m->V, kSkinBlock), B), dim3(kSkinBlock), 0, s,
-                       (const float*)v_posed, (const float*)A, (const float*)m->weights_t, (const float*)m->Jrx, m->V, verts, partial);
+    {
+        static const int force = getenv("TUCH_BLEND_TILES") ? atoi(getenv("TUCH_BLEND_TILES")) : 0;
+        const int tiles = force ? force : (B <= 16 ? 1 : B <= 32 ? 2 : 0);
+        if (tiles == 0)
+            hipLaunchKernelGGL(blend_ksplit_kernel, dim3(m->N3p / (16 * kBlendJ), l.fpad / 64), dim3(256), 0, s, (const float*)feat,
+                               l.fpad, (const float*)m->blend, B, m->N3p, v_posed);
+        else {
+            auto* kernel = tiles == 1 ? blend_kernel<1> : tiles == 2 ? blend_kernel<2> : blend_kernel<4>;
+            hipLaunchKernelGGL(kernel, dim3(m->N3p / kBlendCols, ceil_div(B, 16 * tiles)), dim3(256), 0, s, (const float*)feat,
+                               l.fpad, (const float*)m->blend, B, m->N3p, v_posed);
+        }
+    }
+    hipLaunchKernelGGL(m->skin_joint ? skin_kernel<true> : skin_kernel<false>, dim3(ceil_div(m->V, kSkinBlock), B), dim3(kSkinBlock), 0, s,
+                       (const float*)v_posed, m->N3p, (const float*)A, (const float*)m->weights_t, (const int32_t*)m->skin_joint,
+                       (const float*)m->skin_weight, (const float*)m->Jrx, m->V, verts, partial);
     hipLaunchKernelGGL(assemble_joints_kernel, dim3(B), dim3(256), 0, s, (const float*)world, (const float*)verts,
                        (const float*)partial, (const int32_t*)m->extra_ids, (const int32_t*)m->joint_map, m->V,
                        ceil_div(m->V, kSkinBlock), joints);
@@ -1118,11 +1248,12 @@ static int backward_impl(const tuch_smpl_model* m, const float* global_orient, i
     char* ws = (char*)workspace;
     float *g_vposed = (float*)(ws + l.g_vposed), *gA_part = (float*)(ws + l.gA_part), *feat_part = (float*)(ws + l.feat_part);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(skin_bwd_kernel, dim3(l.skin_blocks, B), dim3(kSkinBlock), 0, s, g_verts, g_joints,
-                       (const int32_t*)m->joint_map, (const float*)m->Jrx, (const int32_t*)m->extra_ids, v_posed, A,
-                       (const float*)m->weights, (const float*)m->weights_t, m->V, g_vposed, gA_part);
+    hipLaunchKernelGGL(m->skin_joint ? skin_bwd_kernel<true> : skin_bwd_kernel<false>, dim3(l.skin_blocks, B), dim3(kSkinBlock), 0, s,
+                       g_verts, g_joints, (const int32_t*)m->joint_map, (const float*)m->Jrx, (const int32_t*)m->extra_ids, v_posed,
+                       m->N3p, A, (const float*)m->weights, (const float*)m->weights_t, (const int32_t*)m->skin_joint,
+                       (const float*)m->skin_weight, m->V, g_vposed, gA_part);
     hipLaunchKernelGGL(blend_bwd_kernel, dim3(l.feat_chunks, ceil_div(l.bpad / 16, kBlendBwdGroups), 14 / kBlendBwdTiles),
-                       dim3(64 * kBlendBwdWaves), 0, s, (const float*)g_vposed, (const float*)m->blend, B, m->N3, l.bpad, feat_part);
+                       dim3(64 * kBlendBwdWaves), 0, s, (const float*)g_vposed, (const float*)m->blend, B, m->N3, m->N3p, l.bpad, feat_part);
     hipLaunchKernelGGL(pose_bwd_kernel, dim3(B), dim3(256), 0, s, (const float*)gA_part, l.skin_blocks,
                        (const float*)feat_part, l.feat_chunks, l.bpad, g_joints, (const int32_t*)m->joint_map, R, J, world, pose,
                        pose2rot, (const float*)m->J_shapedirs, (const int32_t*)m->parents, m->max_depth, g_pose, g_betas, adam);

@@ -8,7 +8,6 @@ from __future__ import annotations
 import contextlib
 import ctypes
 import os
-import threading
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -78,7 +77,8 @@ def set_deterministic(on: bool) -> None:
 
 
 _ONES = {}
-_ROOT = threading.local()      # .node: the autograd node of the loss a running backward_scalar() was called on
+_ROOT_NODES = {}     # id(node) -> node: the autograd nodes of the losses of the RUNNING backward_scalar() calls (a plain dict:
+                     # the engine runs a device's nodes on its own worker thread, a thread-local would be invisible there)
 
 
 def backward_scalar(loss: torch.Tensor) -> None:
@@ -91,17 +91,19 @@ def backward_scalar(loss: torch.Tensor) -> None:
     seed = _ONES.get(key)
     if seed is None:
         seed = _ONES[key] = torch.ones(loss.shape, dtype=loss.dtype, device=loss.device)
-    prev = getattr(_ROOT, 'node', None)
-    _ROOT.node = loss.grad_fn
+    node = loss.grad_fn
+    if node is not None:
+        _ROOT_NODES[id(node)] = node
     try:
         loss.backward(gradient=seed)
     finally:
-        _ROOT.node = prev
+        if node is not None:
+            _ROOT_NODES.pop(id(node), None)
 
 
 def is_root_of_backward_scalar(node) -> bool:
     """True inside a backward pass started by backward_scalar() on the output of exactly this autograd node."""
-    return node is not None and getattr(_ROOT, 'node', None) is node
+    return node is not None and _ROOT_NODES.get(id(node)) is node
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
