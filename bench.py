@@ -474,7 +474,73 @@ def make_tuch_step(p, run_smplify, smplify_iters=10, seed=77):
             for name in swap:
                 input_batch[name].copy_(pool[state['i']][name])
     step.next_bodies = next_bodies
+    step.module, step.inputs = module, input_batch
     return step
+
+
+def check_tuch_step(p, step, run_smplify, sample=(0, 17)):
+    """The per-rank config-4 / config-5 step at FULL size against the CPU oracle (the checker -- tests/ infrastructure, not
+    the thing measured): one eager ``forward_train_step`` with a spy on ``RegressorLoss.contact_loss`` (and on the
+    SMPLify-DC call in the loop); for two sampled bodies the HD contact loss of the regressor's vertices against
+    ``oracle.contact.train_contact_body`` and, with SMPLify-DC in the loop, the stage-2 contact value of the FITTED
+    vertices against ``oracle.contact.smplify_contact_body``."""
+    from oracle import contact as oc
+    from tuch_amd.ops import MODE_SMPLIFY, contact_terms
+    from tuch_amd.smplify.losses import contact_model_for
+    module = step.module
+    crit = module.criterion_cospin
+    body = p['body']
+    seen = {}
+    real = crit.contact_loss
+
+    def spy(verts, valid):
+        seen['verts'], seen['valid'] = verts.detach(), valid.detach().clone()
+        return real(verts, valid)
+
+    class Spy:                                   # the SMPLify-DC object in the loop: its call's vertices are kept
+        def __init__(self, inner):
+            self.inner = inner
+
+        def __call__(self, *a, **k):
+            out = self.inner(*a, **k)
+            seen['fit_verts'] = out[0].detach()
+            return out
+
+        def __getattr__(self, name):
+            return getattr(self.inner, name)
+    crit.contact_loss = spy
+    inner = module.smplify
+    module.smplify = Spy(inner)
+    try:
+        loss, losses, _ = module.forward_train_step(step.inputs)
+        torch.cuda.synchronize()
+    finally:
+        crit.contact_loss = real
+        module.smplify = inner
+    gm = body.geodesics > 0.3
+    segs = [oc.Segment(n, body.faces, sg['vidx'], list(sg['bands'].values())) for n, sg in body.segments.items()]
+    one = torch.ones(1, dtype=torch.bool, device=seen['verts'].device)
+    sample = [b for b in sample if b < seen['verts'].shape[0]]
+    worst_train = worst_fit = 0.0
+    for b in sample:
+        with torch.no_grad():
+            got = float(real(seen['verts'][b:b + 1], one))
+        want = float(oc.train_contact_body(seen['verts'][b].cpu().numpy(), body.faces, gm, 0.02, segs, True, hd_idx=body.hd_bary_idx,
+                                           hd_w=body.hd_bary_w, hd_face=body.hd_face_id)['loss'])
+        worst_train = max(worst_train, abs(got - want) / max(abs(want), 1e-9))
+        if run_smplify and 'fit_verts' in seen:
+            model = contact_model_for(p['geomask'], p['face_tensor'], p['segments'], p['cdict'])
+            v = seen['fit_verts'][b:b + 1].contiguous()
+            ext, _, partner, _ = model.exterior_and_partner(v, apply_segments=True)
+            per_body, _ = contact_terms(v, partner, ext, None, MODE_SMPLIFY, 0.02)
+            r = oc.smplify_contact_body(v[0].cpu().numpy(), body.faces, gm, 0.02, segs, None)
+            worst_fit = max(worst_fit, abs(float(per_body[0]) - r['contact']) / max(abs(r['contact']), 1e-9))
+    out = {'oracle_bodies': sample, 'loss': float(loss), 'loss_contact': float(losses['loss_contact']),
+           'hd_contact_loss_max_rel_err_vs_oracle': worst_train, 'valid_bodies': int(seen['valid'].sum())}
+    if run_smplify:
+        out['fitted_vertices_contact_value_max_rel_err_vs_oracle'] = worst_fit
+    out['ok'] = bool(np.isfinite(out['loss']) and worst_train < 1e-4 and worst_fit < 1e-4)
+    return out
 
 
 def capture(step, warmup):
@@ -695,6 +761,13 @@ def shard_sweep(device, seed):
     return out
 
 
+def _checked(fn):
+    try:
+        return fn()
+    except Exception as exc:                     # noqa: BLE001 -- the measurement stands; the check reports what went wrong
+        return {'ok': False, 'error': repr(exc)}
+
+
 def workloads(device, seed):
     """Per-rank workloads of BASELINE configs 3, 4, 5 on this GPU (synthetic rotation matrices stand in for the
     frozen regressor's output)."""
@@ -716,6 +789,7 @@ def workloads(device, seed):
     out['config4_shard_b32_train_step'] = {
         'ms': round(eager_ms, 4), 'graph_ms': graph_ms, 'graph_fresh_ms': graph_fresh_ms,
         'fresh_ms': round(time_kernel(tuch_step, 8, tuch_step.next_bodies) * 1e3, 4),
+        'selfcheck': _checked(lambda: check_tuch_step(p32, tuch_step, False)),
         'contact_only_plain_ms': round(time_kernel(make_train_step(p32, False), 5) * 1e3, 4),
         'contact_only_hd_ms': round(time_kernel(make_train_step(p32, True), 3) * 1e3, 4),
         'what': 'TUCH.forward_train_step (no SMPLify in the loop) + backward, 32 bodies per rank (256 / 8), stand-in '
@@ -737,6 +811,7 @@ def workloads(device, seed):
         graph5 = 'capture failed: %s: %s' % (type(e).__name__, str(e).splitlines()[0][:200])
     out['config5_shard_b64_in_the_loop_step'] = {
         'ms': ms5, 'graph_ms': graph5, 'fresh_ms': fresh5, 'graph_fresh_ms': graph_fresh5,
+        'selfcheck': _checked(lambda: check_tuch_step(p64, step5, True)),
         'what': 'TUCH.forward_train_step with --run_smplify (SMPLify-DC 10 + 10 iterations with contact in the loop) + '
                 'backward, 64 bodies per rank (512 / 8); ms = eager step (its SMPLify loops replay their own kept graphs), '
                 'graph_ms = the whole step captured once and replayed as one hipGraph (the loops unrolled into it); the '

@@ -69,6 +69,53 @@ def test_two_rank_allreduce_matches_single_process():
     assert abs(mean - float(per_body[valid > 0].mean())) <= 1e-6 * abs(mean)
 
 
+def _mean_worker(rank, world, port, per_body, valid, spans, out):
+    """global_mean_loss on this rank's (uneven) span of the batch; also its gradient w.r.t. the rank's per-body losses."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    lo, hi = spans[rank]
+    pb = torch.tensor(per_body[lo:hi], requires_grad=True)
+    va = torch.tensor(valid[lo:hi])
+    share = tdist.global_mean_loss(pb, va)
+    share.backward()
+    total = share.detach().reshape(1).clone()
+    dist.all_reduce(total)
+    parts = [None] * world
+    dist.all_gather_object(parts, (lo, hi, pb.grad.numpy()))
+    if rank == 0:
+        out.put((float(total), parts))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_ranks_with_unequal_valid_counts_sum_to_the_reference_mean():
+    """``RegressorLoss(global_mean=True)`` on 4 ranks whose shards hold 3 / 0 / 5 / 1 valid bodies of 4 / 2 / 5 / 3 (one
+    rank without a single valid body): the SUM over the ranks of `local sum / global valid count` is
+    ``contact_loss[valid_fit].mean()`` over the whole batch (tuch/train/loss.py:317), and every rank's gradient with
+    respect to its own bodies is the single-process gradient (1 / global count where valid, 0 elsewhere)."""
+    rng = np.random.default_rng(12)
+    per_body = rng.random(14).astype(np.float32) + 0.1
+    valid = np.array([1, 1, 0, 1,   0, 0,   1, 1, 1, 1, 1,   0, 1, 0], np.float32)
+    spans = [(0, 4), (4, 6), (6, 11), (11, 14)]
+    assert [int(valid[a:b].sum()) for a, b in spans] == [3, 0, 5, 1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mean_worker, args=(r, 4, port, per_body, valid, spans, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    total, parts = q.get(timeout=180)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ref = torch.tensor(per_body, requires_grad=True)
+    want = ref[torch.tensor(valid) > 0].mean()
+    want.backward()
+    assert abs(total - float(want)) <= 1e-6 * abs(float(want))
+    for lo, hi, grad in parts:
+        assert np.allclose(grad, ref.grad.numpy()[lo:hi], rtol=1e-6, atol=0)
+
+
 def _hip_worker(rank, world, port, out):
     """Rank r evaluates RegressorLoss.contact_loss (HIP path) on its shard of the medium golden batch."""
     import types

@@ -223,3 +223,88 @@ def _replay_body(tmp_path):
     torch.cuda.synchronize()
     assert replay_loss != eager_loss
     assert_close(replay_loss, out.item(), 1e-5, 1e-7, 'replay with new inputs')
+
+
+def test_fp32_contact_path_behind_a_bf16_regressor(tmp_path):
+    """BASELINE config 5's precision boundary ("bf16 regressor + fp32 contact"): the whole ``forward_train_step`` (SMPLify-DC
+    in the loop) under ``torch.autocast('cuda', dtype=torch.bfloat16)`` -- the regressor's linear layer runs in bf16 and hands
+    bf16 / bf16-rounded tensors to the body model, whose kernels upcast them (tuch_amd/lbs.py).  Checked: (1) vertices,
+    contact term and total are float32 and finite; (2) the contact term equals, to 1e-4, the contact loss of a plain
+    float32 run on the SAME upcast regressor outputs; (3) the gradient that reaches the regressor's outputs through the
+    body model (cast back to their dtypes by autograd) equals that float32 run's gradient up to bf16 rounding; (4) the
+    regressor's (float32) parameters receive finite gradients."""
+    from tuch_amd.models.smpl import SMPL
+    from tuch_amd.smplify.prior import MaxMixturePrior
+    from tuch_amd.smplify.smplifydc import SMPLifyDC
+    from tuch_amd.train.loss import RegressorLoss
+    from tuch_amd.train.train_module import TUCH
+    from tuch_amd.utils.segmentation import BatchBodySegment
+    g = _golden()
+    batch = int(g['batch'])
+    body = make_body(int(g['rings']), int(g['segs']), relax_iters=int(g['relax_iters']))
+    train_ds, names = _datasets(g)
+    for n in names:
+        np.save(tmp_path / (n + '_fits.npy'), g['static_fits_' + n])
+    options = _options(g, tmp_path)
+    smpl = SMPL(model_data=body, batch_size=batch).to(DEV)
+    face_tensor = torch.tensor(body.faces.astype(np.int64), device=DEV)[None].repeat(batch, 1, 1)
+    geod = torch.tensor(body.geodesics, device=DEV)
+    smplify = SMPLifyDC(step_size=1e-2, batch_size=batch, num_iters=int(options.num_smplify_iters), focal_length=5000.,
+                        geodistssmpl=geod, geothres=0.3, euclthres=0.02, device=DEV, smpl=smpl,
+                        pose_prior=MaxMixturePrior(num_gaussians=8, gmm=body.gmm).to(DEV))
+    criterion = RegressorLoss(options=options, device=DEV, num_verts=body.num_verts, faces=face_tensor, geodistssmpl=geod,
+                              geothres=0.3, face_tensor=face_tensor,
+                              segments=BatchBodySegment(list(body.segments.keys()), face_tensor[0], body.segments),
+                              hd_regressor=(body.hd_bary_idx, body.hd_bary_w), hd_faces=body.hd_face_id)
+    module = TUCH(options=options, device=DEV, datasets=(train_ds, None), bodymodel=smpl, spin_model=make_regressor(11).to(DEV),
+                  regressor=make_regressor(12).to(DEV), optimization=smplify, criterion=criterion, geodistssmpl=geod,
+                  contactlists={'classes': [list(p) for p in body.region_pairs], 'csig': dict(body.regions)})
+    seen = {}
+
+    def keep(_module, _inputs, out):
+        for t in out:
+            t.retain_grad()
+        seen['out'] = out
+    handle = module.model.register_forward_hook(keep)
+    # the contact term alone, so that (3) compares exactly the path through the body model and the contact kernels
+    valid_seen = {}
+    real_contact = criterion.contact_loss
+
+    def spy(verts, valid):
+        valid_seen['valid'], valid_seen['verts'] = valid.clone(), verts
+        return real_contact(verts, valid)
+    criterion.contact_loss = spy
+    try:
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            loss, losses, output = module.forward_train_step(_batch(g))
+        contact = losses['loss_contact']
+        assert loss.dtype == torch.float32 and contact.dtype == torch.float32 and output['pred_vertices'].dtype == torch.float32
+        assert valid_seen['verts'].dtype == torch.float32
+        assert torch.isfinite(loss) and torch.isfinite(contact)
+        rot, betas, cam = seen['out']
+        assert torch.bfloat16 in (rot.dtype, betas.dtype), 'the regressor did not run under autocast'
+        # the contact term's own gradient at the regressor's outputs (bf16 where the outputs are)
+        g_rot, g_betas = torch.autograd.grad(contact_of := real_contact(valid_seen['verts'], valid_seen['valid']), [rot, betas],
+                                             retain_graph=True)
+        assert g_rot.dtype == rot.dtype and g_betas.dtype == betas.dtype
+        loss.backward()
+        for q in module.model.parameters():
+            assert q.grad is not None and q.grad.dtype == torch.float32 and bool(torch.isfinite(q.grad).all())
+    finally:
+        handle.remove()
+        criterion.contact_loss = real_contact
+    # the float32 run on the SAME upcast inputs
+    rot32 = rot.detach().float().requires_grad_(True)
+    betas32 = betas.detach().float().requires_grad_(True)
+    out32 = smpl(betas=betas32, body_pose=rot32[:, 1:], global_orient=rot32[:, 0].unsqueeze(1), pose2rot=False)
+    assert torch.equal(out32.vertices.detach(), output['pred_vertices'])          # identical upcast inputs -> identical vertices
+    contact32 = real_contact(out32.vertices, valid_seen['valid'])
+    close_logged(contact.item(), contact32.item(), 1e-4, 1e-9, 'bf16 regressor: contact term vs the float32 run on the same inputs')
+    close_logged(contact_of.item(), contact32.item(), 1e-4, 1e-9, 'bf16 regressor: contact term re-evaluated')
+    w_rot, w_betas = torch.autograd.grad(contact32, [rot32, betas32])
+    for got, want, name in ((g_rot, w_rot, 'rotmat'), (g_betas, w_betas, 'betas')):
+        # autograd casts the body model's float32 gradient to the dtype of the tensor it belongs to: one bf16 rounding (2^-8)
+        tol = 2.0 ** -7 if got.dtype == torch.bfloat16 else 1e-4
+        scale = float(want.abs().max())
+        err = float((got.float() - want).abs().max())
+        assert err <= tol * scale + 1e-12, (name, err, scale)

@@ -652,15 +652,15 @@ __global__ __launch_bounds__(kSkinBlock) void skin_bwd_kernel(
 // waits.  The four partial results meet in LDS, wavefront w adds up and stores accumulators w and w + 4: plain stores
 // into the block's own [Bpad][224] slice (no atomics, nothing to clear); pose_bwd_kernel adds the ~81 slices up.
 constexpr int kBlendBwdTiles = 2;
-constexpr int kBlendBwdGroups = 4;
 constexpr int kBlendBwdChunk = 64;          // K per wavefront
 constexpr int kBlendBwdWaves = 4;           // 3 workgroups fit a CU: all 81 x 7 of them run at once at batch 64
-constexpr int kBlendBwdAccs = kBlendBwdTiles * kBlendBwdGroups;
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+template <int kBlendBwdGroups>                  // 16-body groups per workgroup: 1 / 2 / 4 for batches up to 16 / 32 / more
 __global__ __launch_bounds__(64 * kBlendBwdWaves) void blend_bwd_kernel(
     const float* __restrict__ g_vposed, const float* __restrict__ blend, int B, int N3, int N3p, int bpad,
     float* __restrict__ part)
 {
+    constexpr int kBlendBwdAccs = kBlendBwdTiles * kBlendBwdGroups;
     __shared__ float red[kBlendBwdWaves][kBlendBwdAccs * 4][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lm = lane & 15, lq = lane >> 4;
     const int g0 = blockIdx.y * kBlendBwdGroups, j0 = blockIdx.z * kBlendBwdTiles;
@@ -1252,8 +1252,12 @@ static int backward_impl(const tuch_smpl_model* m, const float* global_orient, i
                        g_verts, g_joints, (const int32_t*)m->joint_map, (const float*)m->Jrx, (const int32_t*)m->extra_ids, v_posed,
                        m->N3p, A, (const float*)m->weights, (const float*)m->weights_t, (const int32_t*)m->skin_joint,
                        (const float*)m->skin_weight, m->V, g_vposed, gA_part);
-    hipLaunchKernelGGL(blend_bwd_kernel, dim3(l.feat_chunks, ceil_div(l.bpad / 16, kBlendBwdGroups), 14 / kBlendBwdTiles),
-                       dim3(64 * kBlendBwdWaves), 0, s, (const float*)g_vposed, (const float*)m->blend, B, m->N3, m->N3p, l.bpad, feat_part);
+    {
+        const int groups = B <= 16 ? 1 : B <= 32 ? 2 : 4;       // (the matrix cores work on whole 16-body groups: a batch of 8 = one)
+        auto* kernel = groups == 1 ? blend_bwd_kernel<1> : groups == 2 ? blend_bwd_kernel<2> : blend_bwd_kernel<4>;
+        hipLaunchKernelGGL(kernel, dim3(l.feat_chunks, ceil_div(l.bpad / 16, groups), 14 / kBlendBwdTiles),
+                           dim3(64 * kBlendBwdWaves), 0, s, (const float*)g_vposed, (const float*)m->blend, B, m->N3, m->N3p, l.bpad, feat_part);
+    }
     hipLaunchKernelGGL(pose_bwd_kernel, dim3(B), dim3(256), 0, s, (const float*)gA_part, l.skin_blocks,
                        (const float*)feat_part, l.feat_chunks, l.bpad, g_joints, (const int32_t*)m->joint_map, R, J, world, pose,
                        pose2rot, (const float*)m->J_shapedirs, (const int32_t*)m->parents, m->max_depth, g_pose, g_betas, adam);
