@@ -34,7 +34,7 @@ for _ in range(6):
 torch.cuda.synchronize()
 L = _C.lib()
 L.tuch_debug_scan_counts.argtypes = [ctypes.c_void_p, ctypes.c_int]
-out = (ctypes.c_ulonglong * 16)()
+out = (ctypes.c_ulonglong * 32)()
 L.tuch_debug_scan_counts(None, 1)
 fn()
 torch.cuda.synchronize()
@@ -45,8 +45,17 @@ names = ['wavefronts', 'leaf-per-lane trips', 'candidate leaves (box-box)', 'lea
 c = list(out)
 for n, v in zip(names, c):
     print('%-32s %12d  per body %10.1f' % (n, v, v / B))
-w = c[0] - c[10]
+w = max(c[0] - c[10], 1)
 print('columns in reach of a leaf whose rows are evaluated: %.1f of 64 on average' % (c[15] / max(c[3], 1)))
 print('per live wavefront: trips %.2f candidates %.2f reaching %.2f rows8 %.2f (skipped %.2f, taking %.3f) rows4 %.2f (skipped %.2f)'
       % (c[1] / w, c[2] / w, c[3] / w, c[4] / w, c[5] / w, c[6] / w, c[7] / w, c[8] / w))
 # rough VALU estimate per event (read off the ISA: tools/diag/README)
+
+if c[22]:
+    w = c[22]
+    print('regrouped form: wavefronts %d; per wavefront: leaves evaluated on the spot %.2f (%.1f columns in reach each), deferred entries %.2f (%.1f columns each)'
+          % (w, c[18] / w, c[19] / max(c[18], 1), c[20] / w, c[21] / max(c[20], 1)))
+    print('   tiles per wavefront %.2f, columns per tile %.1f, of them still in reach when the tile is evaluated %.1f (of 64 lanes)' % (c[16] / w, c[23] / max(c[16], 1), c[17] / max(c[16], 1)))
+    tot = sum(c[24:29])
+    for name, i in (('filter + direct rows', 24), ('offsets + barriers', 25), ('scatter', 26), ('tiles', 27), ('write-out + barrier', 28)):
+        print('   %-22s %8.0f ticks per wavefront (%4.1f %%)' % (name, c[i] / w, 100.0 * c[i] / max(tot, 1)))

@@ -44,6 +44,11 @@ static __device__ __forceinline__ float wave_max_uniform(float v)
     TUCH_WAVE_REDUCE("v_max_f32_dpp");
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+static __device__ __forceinline__ int wave_max_uniform_i32(int v)
+{
+    TUCH_WAVE_REDUCE("v_max_i32_dpp");
+    return __builtin_amdgcn_readlane(v, 63);
+}
 static __device__ __forceinline__ float wave_min_uniform(float v)
 {
     TUCH_WAVE_REDUCE("v_min_f32_dpp");

@@ -43,6 +43,7 @@ struct tuch_options {
     int v2v_tree = 1;           // 0: flat nearest-vertex search
     int v2v_waves = 0;          // frontier choice of the search (wavefronts aimed at; 0: the form's own default)
     int v2v_flat = 2;           // search: 2 lanes over a subtree's leaves first (v2v_scan_kernel), 0 the stackless walk (v2v_tree_kernel)
+    int v2v_pairs = 24;         // scan: a leaf in reach of FEWER columns of the wavefront than this is not walked row by row for all 64 lanes; its (leaf, column) pairs are queued and evaluated one per lane (round 5); 0: every leaf row by row (round 4)
     int v2v_lds = -1;           // search beside the inside test: -1 capped at 7 wavefronts per SIMD by register count (-4 / -5 / -6: at that many; round 4, lighter scan: 7 0.487, 6 0.494, 5 0.512, 4 0.530 ms per step), > 0 by an LDS allocation of that many bytes per workgroup (6400: round 2), 0 uncapped
     int seg_splits = 16;        // face splits of the solid-angle segment kernel
     int seg_assist = 1;         // 0: the segment pass counts its body-face crossings itself (read at create only)

@@ -382,13 +382,13 @@ constexpr float kPruneSlack = 0.999999f;      // lower bounds are deflated by 1e
 // instructions go.  [0] wavefronts, [1] leaf-per-lane trips, [2] candidate leaves (box against box), [3] leaves that reach
 // their rows (per-column test), [4] trips of eight rows, [5] of them skipped by the mask words, [6] of them taking the
 // update branch, [7] trips of four, [8] skipped, [9] taking, [10] wavefronts that return at once (no admissible row)
-__device__ unsigned long long g_scan_counts[16];
+__device__ unsigned long long g_scan_counts[32];
 #define SCAN_COUNT(i) do { if (threadIdx.x == 0) atomicAdd(&g_scan_counts[i], 1ull); } while (0)
 extern "C" int tuch_debug_scan_counts(unsigned long long* out, int reset)
 {
-    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scan_counts), sizeof(unsigned long long) * 16) != hipSuccess) return TUCH_ERR_HIP;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scan_counts), sizeof(unsigned long long) * 32) != hipSuccess) return TUCH_ERR_HIP;
     if (reset) {
-        unsigned long long z[16] = {};
+        unsigned long long z[32] = {};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_scan_counts), z, sizeof(z)) != hipSuccess) return TUCH_ERR_HIP;
     }
     return TUCH_OK;
@@ -798,8 +798,7 @@ __global__ __launch_bounds__(kBoundsBlock) void v2v_rows_seed_kernel(
     const int32_t* __restrict__ height_off, const int32_t* __restrict__ height_nodes, int N, float* __restrict__ prow,
     float* __restrict__ bounds, float* __restrict__ leafbox, const int32_t* __restrict__ leaf_group, float* __restrict__ prow_g,
     int G, int row_blocks, const uint64_t* __restrict__ bits, const int32_t* __restrict__ hint, uint64_t* __restrict__ keys,
-    float* __restrict__ colbox, uint4* __restrict__ zero, size_t zero_n16,
-    uint4* __restrict__ zero2 = nullptr, size_t zero2_n16 = 0)       // the leaf-major form's counters (v2v_flat = 3)
+    float* __restrict__ colbox, uint4* __restrict__ zero, size_t zero_n16)
 {
     // a buffer the CALLER wants cleared before the kernels it enqueues behind this call run (SMPLify-DC stage 2: the vertex
     // gradient the tail scatters into, its arrival counter, the region pairs' keys -- a fill launch of 5 us in front of them
@@ -808,11 +807,6 @@ __global__ __launch_bounds__(kBoundsBlock) void v2v_rows_seed_kernel(
         const size_t stride = (size_t)gridDim.x * gridDim.y * kBoundsBlock;
         for (size_t i = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kBoundsBlock + threadIdx.x; i < zero_n16; i += stride)
             zero[i] = make_uint4(0u, 0u, 0u, 0u);
-    }
-    if (zero2) {
-        const size_t stride = (size_t)gridDim.x * gridDim.y * kBoundsBlock;
-        for (size_t i = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kBoundsBlock + threadIdx.x; i < zero2_n16; i += stride)
-            zero2[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     if ((int)blockIdx.x < row_blocks) {
         v2v_rows_body(blockIdx.x, verts, V, Vp, qperm, rows, height_off, height_nodes, N, prow, bounds, leafbox, leaf_group,
@@ -906,19 +900,78 @@ __global__ __launch_bounds__(64) void v2v_tree_kernel(
 // and the largest bound among them (conservative: box-to-box distance), and only the survivors get the per-column test
 // and their rows.  Same rows as the walks -> the same keys.  colbox: the box of every 64-column block, left by
 // v2v_seed_kernel ([B][column blocks][8]).
-// lists (leaf-major form, v2v_flat = 3): the wavefront does not evaluate a reaching leaf's rows itself -- on average 12 of
-// its 64 columns are in reach of one (tools/diag/scan_counts.py): the row arithmetic runs at a fifth of the lanes -- but
-// leaves an entry (leaf, the columns in reach) in its list; the entries are regrouped by leaf (tuch_tiles_fill_launch) and
-// v2v_tiles_kernel evaluates a leaf's rows for 64 columns that all want them, whichever blocks they come from.
-struct ScanLists { RayEntry* lists; int32_t* list_len; int32_t* leaf_cnt; int stride; };
-template <int kShared, bool kLists = false>
+// Round 5: the (leaf, column) pairs of the SPARSE leaves, one per lane.  Of the ~6 leaves of a subtree whose rows a
+// wavefront evaluates, five are in reach of only ~8 of its 64 columns (tools/diag/scan_counts.py): walking their rows for all
+// 64 lanes costs ~90 instructions per leaf = 11 per useful (leaf, column) pair, where a leaf in reach of 40 columns costs 2.
+// Such leaves are no longer walked; their pairs go to a queue in LDS and are evaluated 64 at a time, every LANE its own
+// pair: the leaf's rows in groups of four through per-lane 16-byte loads (the same padded groups v2v_rows_packed reads
+// through scalar loads), the column from LDS, its admissible rows of the leaf one 64-bit window of ITS row of the bit matrix
+// (symmetric mask, leaves of at most 64 rows), the same distance arithmetic, the result merged into the column's key in LDS
+// with a 64-bit atomic minimum (several lanes may hold the same column with different leaves).  The same rows are
+// evaluated as before -> the same keys.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kPairQueue = 128;
+__device__ __forceinline__ void v2v_flush_pairs(int count, const uint2* s_q, const float4* s_col,
+                                                unsigned long long* s_key, const float* __restrict__ pg,
+                                                const uint64_t* __restrict__ bits, int V, int gi_base, int lane)
+{
+    const float inf = __builtin_inff();
+    const bool active = lane < count;
+    const uint2 e = s_q[active ? lane : 0];
+    const int range = (int)e.x, col = (int)(e.y >> 24), g0 = (int)(e.y & 0xffffffu);
+    const int j0 = range & 0xfffff, nrows = range >> 20;
+    const float4 p = s_col[col];
+    const unsigned long long key0 = s_key[col];
+    const int gi = gi_base + col;
+    const uint64_t* brow = bits + (size_t)(j0 >> 6) * V + gi;              // bits[w][j]: word w of row j; symmetric mask
+    const int sh = j0 & 63;
+    uint64_t am = (gi < V ? brow[0] : 0ull) >> sh;
+    if (sh + nrows > 64) am |= (gi < V ? brow[V] : 0ull) << (64 - sh);
+    if (nrows < 64) am &= (1ull << nrows) - 1ull;
+    float best = active ? __uint_as_float((uint32_t)(key0 >> 32)) : -1.0f;      // (idle lanes never improve)
+    int arg = (int)(uint32_t)key0;
+    const int ngroups = active ? (nrows + 3) >> 2 : 0;
+    const int gmax = wave_max_uniform_i32(ngroups);
+    const v2f px = splat2(p.x), py = splat2(p.y), pz = splat2(p.z);
+    const float* pl = pg + (size_t)g0 * 12;
+    uint32_t nam = ~(uint32_t)am, nam_hi = ~(uint32_t)(am >> 32);              // NOT-admissible bits, four rows per trip
+    for (int g = 0; g < gmax; ++g) {
+        if (g == 8) nam = nam_hi;
+        f32x4 x = {0.f, 0.f, 0.f, 0.f}, y = x, z = x;
+        const bool on = g < ngroups;
+        if (on) {
+            x = *reinterpret_cast<const f32x4*>(pl);
+            y = *reinterpret_cast<const f32x4*>(pl + 4);
+            z = *reinterpret_cast<const f32x4*>(pl + 8);
+            pl += 12;
+        }
+        const v2f dx0 = px - (v2f){x[0], x[1]}, dy0 = py - (v2f){y[0], y[1]}, dz0 = pz - (v2f){z[0], z[1]};
+        const v2f dx1 = px - (v2f){x[2], x[3]}, dy1 = py - (v2f){y[2], y[3]}, dz1 = pz - (v2f){z[2], z[3]};
+        const v2f d01 = fma2(dz0, dz0, fma2(dy0, dy0, dx0 * dx0)), d23 = fma2(dz1, dz1, fma2(dy1, dy1, dx1 * dx1));
+        const uint32_t word = on ? nam : 0xfu;
+        float d[4] = {(word & 1u) ? inf : d01.x, (word & 2u) ? inf : d01.y, (word & 4u) ? inf : d23.x, (word & 8u) ? inf : d23.y};
+        const float m = fminf(fminf(d[0], d[1]), fminf(d[2], d[3]));
+        if (__builtin_amdgcn_ballot_w64(m <= best)) {
+            int firstu = 3;
+#pragma unroll
+            for (int u = 2; u >= 0; --u) firstu = d[u] == m ? u : firstu;
+            const int j = j0 + g * 4 + firstu;
+            if (m < best || (m == best && m < inf && j < arg)) { best = m; arg = j; }
+        }
+        nam >>= 4;
+    }
+    const unsigned long long k1 = v2v_key(best, arg);
+    if (active && k1 < key0) atomicMin(&s_key[col], k1);
+}
+
+template <int kShared, bool kPairs>
 __device__ __forceinline__ void v2v_scan_body(
     const float* __restrict__ prow, int V, int Vp, const uint64_t* __restrict__ bits,
     const float* __restrict__ leafbox, const float* __restrict__ colbox, const uint64_t* __restrict__ masked_leaf,
     const uint64_t* __restrict__ masked, int N, int L, const int32_t* __restrict__ frontier,
     const int32_t* __restrict__ sub_leaf, const int32_t* __restrict__ order, uint64_t* __restrict__ keys,
     const float* __restrict__ prow_g, const uint64_t* __restrict__ bits_g, int G,   // rows / mask words in groups of four
-    ScanLists out = ScanLists{nullptr, nullptr, nullptr, 0})
+    int dense)                                   // kPairs: a leaf in reach of fewer columns than this is queued, not walked
 {
     // (72 registers = 7 wavefronts per SIMD, 80 = 6, ...: touching the last one is what sets the kernel's register count)
     if constexpr (kShared == 7) asm volatile("v_mov_b32 v71, 0" ::: "v71");
@@ -942,14 +995,10 @@ __device__ __forceinline__ void v2v_scan_body(
     // the largest bound among the columns that have an allowed row below this subtree at all
     const uint64_t alive = masked[(size_t)qb * N + __builtin_amdgcn_readfirstlane(frontier[sub])];
     SCAN_COUNT(0);
-    const size_t wave_id = (size_t)b * gridDim.y + blockIdx.y;
     if (alive == 0) {
         SCAN_COUNT(10);
-        if (kLists && lane == 0) out.list_len[wave_id] = 0;
         return;
     }
-    int nlist = 0;                               // (kLists) entries of this wavefront, wave-uniform
-    RayEntry* mylist = kLists ? out.lists + wave_id * out.stride : nullptr;
     // lower bounds are compared as g <= bound * (1 + 1e-6): the slack of kPruneSlack on the side that changes rarely
     constexpr float kBoundSlack = 1.000001f;
     const float reach2 = wave_max_uniform(((alive >> lane) & 1) ? c.best : 0.0f) * kBoundSlack;
@@ -959,6 +1008,26 @@ __device__ __forceinline__ void v2v_scan_body(
     // instruction) -- the per-column test is a third of this kernel's vector instructions (tools/diag/scan_counts.py: 21
     // candidates per wavefront, 6 of them reach their rows)
     __shared__ float4 leaf_lo[64], leaf_hi[64];
+    // kPairs: the wavefront's columns and their keys for the lanes that evaluate queued (leaf, column) pairs
+    __shared__ float4 s_col[kPairs ? 64 : 1];
+    __shared__ unsigned long long s_key[kPairs ? 64 : 1];
+    __shared__ uint2 s_q[kPairs ? kPairQueue : 1];        // (row range of the leaf, its first group | column << 24)
+    int queued = 0;                                       // wave-uniform
+    if constexpr (kPairs) {
+        s_col[lane] = make_float4(c.px, c.py, c.pz, 0.0f);
+        s_key[lane] = init;
+    }
+    auto flush = [&](int n) {
+        s_key[lane] = v2v_key(c.best, c.arg);             // (what the rows walked on the spot have found since)
+        // (a one-wavefront workgroup: no s_barrier is emitted, but the fences are needed -- without them lanes read the
+        // queue / the keys before the other lanes' writes: 157 of 4806 minima wrong on the 1602-vertex fixture)
+        __syncthreads();
+        v2v_flush_pairs(n, s_q, s_col, s_key, pg, bits, V, qb * kTreeCols, lane);
+        __syncthreads();
+        const unsigned long long k = s_key[lane];
+        c.best = __uint_as_float((uint32_t)(k >> 32));
+        c.arg = (int)(uint32_t)k;
+    };
     const float* cbx = colbox + ((size_t)b * (Vp / kTreeCols) + qb) * 8;
     const float clx = cbx[0], cly = cbx[1], clz = cbx[2], chx = cbx[4], chy = cbx[5], chz = cbx[6];
     const float* lb = leafbox + ((size_t)b * L + first) * 8;
@@ -1027,13 +1096,22 @@ __device__ __forceinline__ void v2v_scan_body(
 #ifdef TUCH_SCAN_COUNTS
                 if (threadIdx.x == 0) atomicAdd(&g_scan_counts[15], (unsigned long long)__builtin_popcountll(reach));   // columns in reach
 #endif
-                if constexpr (kLists) {
-                    if (lane == 0) {
-                        const int li = first + base + u;
-                        mylist[nlist] = RayEntry{li, 0, (uint32_t)reach, (uint32_t)(reach >> 32)};
-                        atomicAdd(&out.leaf_cnt[(size_t)b * L + li], __builtin_popcountll(reach));
+                const int nreach = __builtin_popcountll(reach);
+                if (kPairs && nreach < dense) {
+                    if ((reach >> lane) & 1) {
+                        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(reach >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)reach, 0));
+                        s_q[queued + rank] = make_uint2(__float_as_uint(bhi.w), __float_as_uint(blo.w) | ((uint32_t)lane << 24));
                     }
-                    ++nlist;
+                    queued += nreach;
+                    if (queued >= 64) {                   // a full wavefront of pairs: evaluate, keep the rest
+                        flush(64);
+                        best_s = c.best * kBoundSlack;
+                        queued -= 64;
+                        const uint2 rest = s_q[64 + (lane < queued ? lane : 0)];
+                        __syncthreads();
+                        if (lane < queued) s_q[lane] = rest;
+                        __syncthreads();
+                    }
                 } else {
                     const int leaf = __builtin_amdgcn_readfirstlane(__float_as_int(bhi.w));
                     const int g0 = __builtin_amdgcn_readfirstlane(__float_as_int(blo.w));
@@ -1043,9 +1121,8 @@ __device__ __forceinline__ void v2v_scan_body(
             }
         }
     }
-    if constexpr (kLists) {
-        if (lane == 0) out.list_len[wave_id] = nlist;
-        return;
+    if constexpr (kPairs) {
+        if (queued > 0) flush(queued);
     }
     const uint64_t k0 = v2v_key(c.best, c.arg);
     if (k0 < init) atomicMin((unsigned long long*)(kb + i0), (unsigned long long)k0);
@@ -1055,143 +1132,20 @@ __device__ __forceinline__ void v2v_scan_body(
     const float* __restrict__ prow, int V, int Vp, const uint64_t* __restrict__ bits, const float* __restrict__ leafbox,    \
     const float* __restrict__ colbox, const uint64_t* __restrict__ masked_leaf, const uint64_t* __restrict__ masked, int N, \
     int L, const int32_t* __restrict__ frontier, const int32_t* __restrict__ sub_leaf, const int32_t* __restrict__ order,   \
-    uint64_t* __restrict__ keys, const float* __restrict__ prow_g, const uint64_t* __restrict__ bits_g, int G
-#define TUCH_SCAN_ARGS prow, V, Vp, bits, leafbox, colbox, masked_leaf, masked, N, L, frontier, sub_leaf, order, keys, prow_g, bits_g, G
-__global__ __launch_bounds__(64) void v2v_scan_kernel(TUCH_SCAN_PARAMS) { v2v_scan_body<0>(TUCH_SCAN_ARGS); }
+    uint64_t* __restrict__ keys, const float* __restrict__ prow_g, const uint64_t* __restrict__ bits_g, int G, int dense
+#define TUCH_SCAN_ARGS prow, V, Vp, bits, leafbox, colbox, masked_leaf, masked, N, L, frontier, sub_leaf, order, keys, prow_g, bits_g, G, dense
+template <bool kPairs>
+__global__ __launch_bounds__(64) void v2v_scan_kernel(TUCH_SCAN_PARAMS) { v2v_scan_body<0, kPairs>(TUCH_SCAN_ARGS); }
 // The same beside the inside test's chain of small kernels (another stream): at most kSlots of a SIMD's 8 wave slots, by
 // REGISTER count.  (Round 2 capped the walk with an unused LDS allocation -- 25 x 6400 B is ALL of a CU's LDS: the
 // chain's kernels that need LDS themselves, ray_near and ray_tiles_fill, then waited for the search to drain.)
-template <int kSlots>
+template <int kSlots, bool kPairs>
 __global__ __launch_bounds__(64) void v2v_scan_shared_kernel(TUCH_SCAN_PARAMS)
 {
-    v2v_scan_body<kSlots>(TUCH_SCAN_ARGS);
-}
-// the leaf-major form's first half: the columns in reach of every leaf, nothing evaluated
-template <int kSlots>
-__global__ __launch_bounds__(64) void v2v_reach_kernel(TUCH_SCAN_PARAMS, ScanLists out)
-{
-    v2v_scan_body<kSlots, true>(TUCH_SCAN_ARGS, out);
+    v2v_scan_body<kSlots, kPairs>(TUCH_SCAN_ARGS);
 }
 #undef TUCH_SCAN_PARAMS
 #undef TUCH_SCAN_ARGS
-
-// ... and its second half: a tile = one leaf and up to 64 columns in reach of it (pairs[first ..]: wavefront of the reach
-// kernel * 64 + lane).  The leaf's rows -- scalar operands, in groups of four as for v2v_rows_packed -- against the lanes'
-// own columns; a column's admissible rows of this leaf come from ITS row of the bit matrix (the geodesic mask is
-// symmetric: checked when the model is made), one or two 64-bit words per lane and tile; the running (distance, row) of
-// a column is merged into its key with atomicMin like every subtree's result.  Persistent wavefronts, bodies dealt to
-// the XCDs like ray_leaf_kernel's.
-__global__ __launch_bounds__(64) void v2v_tiles_kernel(
-    const float* __restrict__ prow, int Vp, const uint64_t* __restrict__ bits, int V, const float* __restrict__ leafbox, int L,
-    const int32_t* __restrict__ order, const RayTile* __restrict__ tiles, const RayBody* __restrict__ body,
-    const int32_t* __restrict__ pairs, int cap, int max_tiles, int num_bodies, uint64_t* __restrict__ keys,
-    const float* __restrict__ prow_g, int G)
-{
-    const int lane = threadIdx.x;
-    const float inf = __builtin_inff();
-    // a tile's inputs are a chain of dependent loads (tile -> slot -> column -> coordinates, key, mask words): the NEXT
-    // tile's are requested while this one's rows are walked
-    struct Work { int b, i0, g0, j0, nrows; bool active; float px, py, pz; uint64_t init, am; };
-    int b_cur = blockIdx.x, base = 0, g = blockIdx.y;
-    auto fetch = [&]() {
-        Work w;
-        w.b = -1; w.i0 = w.g0 = w.j0 = w.nrows = 0; w.active = false; w.px = w.py = w.pz = 0.0f; w.init = 0ull; w.am = 0ull;
-        while (b_cur < num_bodies) {
-            const int b = b_cur;
-            const int nt = __builtin_amdgcn_readfirstlane(body[b].tiles);
-            if (g >= base + nt) { base += nt; b_cur += gridDim.x; continue; }
-            const int t = g - base;
-            g += gridDim.y;
-            const RayTile tile = tiles[(size_t)b * max_tiles + t];
-            const int leaf = __builtin_amdgcn_readfirstlane(tile.ex_off), first = __builtin_amdgcn_readfirstlane(tile.first);
-            const int n = __builtin_amdgcn_readfirstlane(tile.n);
-            w.b = b;
-            w.active = lane < n;
-            const int slot = pairs[(size_t)b * cap + first + (w.active ? lane : 0)];
-            const int pair = order[slot >> 7];                             // (wavefront of the reach kernel) >> 1
-            const int qb = (pair & 0xffff) * 2 + ((slot >> 6) & 1);
-            w.i0 = qb * kTreeCols + (slot & 63);
-            const float* pb = prow + (size_t)b * Vp * 3;
-            w.init = __hip_atomic_load(keys + (size_t)b * Vp + w.i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            w.px = pb[3 * w.i0]; w.py = pb[3 * w.i0 + 1]; w.pz = pb[3 * w.i0 + 2];
-            const float* lbx = leafbox + ((size_t)b * L + leaf) * 8;
-            w.g0 = __builtin_amdgcn_readfirstlane(__float_as_int(lbx[3]));
-            const int range = __builtin_amdgcn_readfirstlane(__float_as_int(lbx[7]));
-            w.j0 = range & 0xfffff;
-            w.nrows = range >> 20;
-            // the column's admissible rows among [j0, j0 + nrows): bit k of `am` = row j0 + k (nrows <= 64)
-            const uint64_t* brow = bits + (size_t)(w.j0 >> 6) * V + w.i0;   // bits[w][j]: word w of row j; symmetric mask
-            const int sh = w.j0 & 63;
-            uint64_t am = (w.i0 < V ? brow[0] : 0ull) >> sh;
-            if (sh + w.nrows > 64) am |= (w.i0 < V ? brow[V] : 0ull) << (64 - sh);
-            if (w.nrows < 64) am &= (1ull << w.nrows) - 1ull;               // rows behind the leaf's last are not its own
-            w.am = am;
-            break;
-        }
-        return w;
-    };
-    Work next = fetch();
-    while (next.b >= 0) {
-        const Work w = next;
-        next = fetch();
-        float best = w.active ? __uint_as_float((uint32_t)(w.init >> 32)) : -1.0f;      // (idle lanes never improve)
-        int arg = (int)(uint32_t)w.init;
-        const v2f px = splat2(w.px), py = splat2(w.py), pz = splat2(w.pz);
-        const float* pg = prow_g + ((size_t)w.b * G + w.g0) * 12;
-        const int ngroups = (w.nrows + 3) >> 2;
-        // NOT-admissible bits, eight rows of the trip in the low byte: a row's distance becomes a quiet NaN where its bit is
-        // set (two instructions: bit -> all ones, AND-OR), and v_min3 / v_min skip NaN operands
-        uint64_t nam = ~w.am;
-        auto dist2 = [&](float xa, float xb, float ya, float yb, float za, float zb) {
-            const v2f dx = px - (v2f){xa, xb}, dy = py - (v2f){ya, yb}, dz = pz - (v2f){za, zb};
-            return fma2(dz, dz, fma2(dy, dy, dx * dx));
-        };
-        auto masked = [&](float d, uint32_t word, int k) {
-            const int x = __builtin_amdgcn_sbfe(word, k, 1);                  // -1 where the row is not admissible
-            uint32_t r;
-            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(0x7FC00000u), "v"(__float_as_uint(d)));
-            return __uint_as_float(r);
-        };
-        auto take = [&](int j, float m) {
-            if (m < best || (m == best && m < inf && j < arg)) { best = m; arg = j; }
-        };
-        int gg = 0;
-        for (; gg + 2 <= ngroups; gg += 2, pg += 24, nam >>= 8) {
-            float v[24];
-#pragma unroll
-            for (int u = 0; u < 24; ++u) v[u] = pg[u];
-            const uint32_t word = (uint32_t)nam;
-            const v2f d01 = dist2(v[0], v[1], v[4], v[5], v[8], v[9]), d23 = dist2(v[2], v[3], v[6], v[7], v[10], v[11]);
-            const v2f d45 = dist2(v[12], v[13], v[16], v[17], v[20], v[21]), d67 = dist2(v[14], v[15], v[18], v[19], v[22], v[23]);
-            float d[8] = {masked(d01.x, word, 0), masked(d01.y, word, 1), masked(d23.x, word, 2), masked(d23.y, word, 3),
-                          masked(d45.x, word, 4), masked(d45.y, word, 5), masked(d67.x, word, 6), masked(d67.y, word, 7)};
-            const float m = min8_raw(d);
-            if (__builtin_amdgcn_ballot_w64(m <= best)) {
-                int firstu = 7;
-#pragma unroll
-                for (int u = 6; u >= 0; --u) firstu = d[u] == m ? u : firstu;
-                take(w.j0 + gg * 4 + firstu, m);
-            }
-        }
-        if (gg < ngroups) {
-            float v[12];
-#pragma unroll
-            for (int u = 0; u < 12; ++u) v[u] = pg[u];
-            const uint32_t word = (uint32_t)nam;
-            const v2f d01 = dist2(v[0], v[1], v[4], v[5], v[8], v[9]), d23 = dist2(v[2], v[3], v[6], v[7], v[10], v[11]);
-            float d[4] = {masked(d01.x, word, 0), masked(d01.y, word, 1), masked(d23.x, word, 2), masked(d23.y, word, 3)};
-            const float m = min4_raw(d[0], d[1], d[2], d[3]);
-            if (__builtin_amdgcn_ballot_w64(m <= best)) {
-                int firstu = 3;
-#pragma unroll
-                for (int u = 2; u >= 0; --u) firstu = d[u] == m ? u : firstu;
-                take(w.j0 + gg * 4 + firstu, m);
-            }
-        }
-        const uint64_t k0 = v2v_key(best, arg);
-        if (w.active && k0 < w.init) atomicMin((unsigned long long*)(keys + (size_t)w.b * Vp + w.i0), (unsigned long long)k0);
-    }
-}
 
 // keys -> (min, argmin) in the caller's vertex numbering; all-masked column -> (inf, 0)
 __global__ __launch_bounds__(kBlock) void v2v_tree_finalize_kernel(
@@ -1211,8 +1165,7 @@ __global__ __launch_bounds__(kBlock) void v2v_tree_finalize_kernel(
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-struct TreeV2VLayout { size_t prow, bounds, keys, leafbox, colbox, prow_g, lists, list_len, leaf_cnt, pairs, tiles, body, total;
-                       int waves, stride, cap, max_tiles; size_t leaf_cnt_bytes; };
+struct TreeV2VLayout { size_t prow, bounds, keys, leafbox, colbox, prow_g, total; };
 
 static int flat_mode(const tuch_contact_model* m);
 int choose_v2v_frontier(const tuch_contact_model* m, int B);
@@ -1228,27 +1181,6 @@ TreeV2VLayout tree_v2v_layout(const tuch_contact_model* m, int B)
     l.leafbox = tuch_ws_take(o, ((size_t)B * m->tree_leaves + 4) * 8 * sizeof(float));     // + padding
     l.colbox = tuch_ws_take(o, (size_t)B * 2 * m->tree_qblocks * 8 * sizeof(float));
     l.prow_g = tuch_ws_take(o, ((size_t)B * m->tree_groups * 12 + 16) * sizeof(float));     // (+ a trip's read-ahead)
-    l.lists = l.list_len = l.leaf_cnt = l.pairs = l.tiles = l.body = 0;
-    l.waves = l.stride = l.cap = l.max_tiles = 0;
-    l.leaf_cnt_bytes = 0;
-    if (flat_mode(m) == 3) {
-        // leaf-major form: the reach kernel's lists (one per wavefront, as long as its subtree has leaves), the columns of
-        // every leaf.  cap is the exact worst case -- every column in reach of every leaf -- so that the pair list cannot
-        // overflow (untouched memory costs nothing; 12 MB per body at SMPL size)
-        const int f = choose_v2v_frontier(m, B);
-        const int f0 = m->tree_frontier_off_host[f], nsub = m->tree_frontier_off_host[f + 1] - f0;
-        l.waves = 2 * nsub * m->tree_qblocks;
-        for (int k = 0; k < nsub; ++k) l.stride = std::max(l.stride, m->tree_sub_leaf_host[2 * (f0 + k) + 1]);
-        l.cap = Vp * m->tree_leaves;
-        l.max_tiles = l.cap / 64 + m->tree_leaves;
-        l.lists = tuch_ws_take(o, (size_t)B * l.waves * l.stride * sizeof(RayEntry));
-        l.list_len = tuch_ws_take(o, (size_t)B * l.waves * sizeof(int32_t));
-        l.leaf_cnt_bytes = (2 * (size_t)B * m->tree_leaves * sizeof(int32_t) + 15) & ~(size_t)15;
-        l.leaf_cnt = tuch_ws_take(o, l.leaf_cnt_bytes);      // counts | fill cursors: cleared together (by the search's first kernel)
-        l.pairs = tuch_ws_take(o, (size_t)B * l.cap * sizeof(int32_t));
-        l.tiles = tuch_ws_take(o, (size_t)B * l.max_tiles * sizeof(RayTile));
-        l.body = tuch_ws_take(o, (size_t)B * sizeof(RayBody));
-    }
     l.total = o;
     return l;
 }
@@ -1265,9 +1197,6 @@ static int flat_mode(const tuch_contact_model* m)
     // without the leaf tables, and the A/B reference).  (Rounds 2-3 also had "leaf boxes four at a time" and a matrix-core
     // form: identical keys, both slower -- DESIGN.md section 3; removed in round 4.)
     if (!(m->tree_sub_leaf && m->tree_masked_leaf)) return 0;
-    // 3: leaf-major (v2v_reach_kernel -> tuch_tiles_fill_launch -> v2v_tiles_kernel): needs a symmetric mask and leaves of
-    // at most 64 rows
-    if (m->opt.v2v_flat >= 3 && m->mask_symmetric && m->tree_leaf_rows_max <= 64 && m->tree_sub_leaf_host) return 3;
     return m->opt.v2v_flat >= 2 ? 2 : 0;
 }
 
@@ -1279,11 +1208,8 @@ int choose_v2v_frontier(const tuch_contact_model* m, int B)
     const long target = m->opt.v2v_waves > 0 ? m->opt.v2v_waves : (flat_mode(m) >= 2 ? 14000L : 65536L);
     int f = 0;
     while (f + 1 < m->tree_num_frontiers &&
-           (long)B * m->tree_qblocks * (m->tree_frontier_off_host[f + 1] - m->tree_frontier_off_host[f]) < target) {
-        // (leaf-major form: a body's wavefronts are the "blocks" of tuch_tiles_fill_launch, at most 2048)
-        if (flat_mode(m) == 3 && 2L * m->tree_qblocks * (m->tree_frontier_off_host[f + 2] - m->tree_frontier_off_host[f + 1]) > 2048) break;
+           (long)B * m->tree_qblocks * (m->tree_frontier_off_host[f + 1] - m->tree_frontier_off_host[f]) < target)
         ++f;
-    }
     return f;
 }
 
@@ -1419,8 +1345,7 @@ extern "C" int tuch_v2v_min_model_shared_zero(const tuch_contact_model* m, const
                            (const int32_t*)m->tree_leaf_group, scan >= 2 ? (float*)(ws + l.prow_g) : (float*)nullptr,
                            m->tree_groups, row_blocks, (const uint64_t*)m->tree_mask_bits, (const int32_t*)hint_inout, keys,
                            colbox, (uint4*)(fused_zero ? zero : nullptr),
-                           fused_zero ? zero_bytes / 16 : (size_t)0, (uint4*)(scan == 3 ? ws + l.leaf_cnt : nullptr),
-                           scan == 3 ? l.leaf_cnt_bytes / 16 : (size_t)0);
+                           fused_zero ? zero_bytes / 16 : (size_t)0);
     } else {
     hipLaunchKernelGGL(v2v_rows_kernel, dim3(row_blocks, B), dim3(kBoundsBlock), 0, s,
                        verts, V, Vp, (const int32_t*)m->tree_qperm, (const int32_t*)m->tree_rows,
@@ -1445,48 +1370,25 @@ extern "C" int tuch_v2v_min_model_shared_zero(const tuch_contact_model* m, const
     // got going when the walk was done (tools/graph_timeline.py: the memset took 236 us).  -2.5 % step time; alone the
     // walk is 10 % slower with the cap (0.28 -> 0.31 ms), hence a flag (TUCH_V2V_LDS: bytes, to compare).
     const int lds_pad = leave_room && m->opt.v2v_lds > 0 ? m->opt.v2v_lds : 0;
-    if (scan == 3) {
-        ScanLists out = {(RayEntry*)(ws + l.lists), (int32_t*)(ws + l.list_len), (int32_t*)(ws + l.leaf_cnt), l.stride};
-        int32_t* leaf_cnt = (int32_t*)(ws + l.leaf_cnt);
-        int32_t* leaf_fill = leaf_cnt + (size_t)B * m->tree_leaves;
-        if (!hint_inout && hipMemsetAsync(leaf_cnt, 0, l.leaf_cnt_bytes, s) != hipSuccess)      // (else: v2v_rows_seed_kernel)
-            return tuch_check_launch("tuch_v2v_min_model: clearing the leaf counters");
-        auto* reach = leave_room ? v2v_reach_kernel<7> : v2v_reach_kernel<0>;
-        hipLaunchKernelGGL(reach, dim3(B, 2 * nsub * m->tree_qblocks), dim3(64), 0, s, (const float*)prow,
+    if (scan == 2) {
+        // pairs: the sparse leaves' (leaf, column) pairs one per lane (needs a symmetric mask and leaves of at most 64 rows:
+        // a column's admissible rows of a leaf are one window of ITS row of the bit matrix)
+        const bool pairs = m->opt.v2v_pairs > 0 && m->mask_symmetric && m->tree_leaf_rows_max <= 64 && m->tree_groups < (1 << 24);
+        const int capped = leave_room && m->opt.v2v_lds < 0 ? -m->opt.v2v_lds : 0;       // wave slots by register count
+        void (*kernel)(const float*, int, int, const uint64_t*, const float*, const float*, const uint64_t*, const uint64_t*, int, int,
+                       const int32_t*, const int32_t*, const int32_t*, uint64_t*, const float*, const uint64_t*, int, int);
+        if (pairs) kernel = capped == 4 ? v2v_scan_shared_kernel<4, true> : capped == 5 ? v2v_scan_shared_kernel<5, true> : capped == 6 ? v2v_scan_shared_kernel<6, true>
+                            : capped ? v2v_scan_shared_kernel<7, true> : v2v_scan_kernel<true>;
+        else kernel = capped == 4 ? v2v_scan_shared_kernel<4, false> : capped == 5 ? v2v_scan_shared_kernel<5, false> : capped == 6 ? v2v_scan_shared_kernel<6, false>
+                      : capped ? v2v_scan_shared_kernel<7, false> : v2v_scan_kernel<false>;
+        hipLaunchKernelGGL(kernel, dim3(B, 2 * nsub * m->tree_qblocks), dim3(64), capped ? (size_t)0 : (size_t)lds_pad, s, (const float*)prow,
                            V, Vp, (const uint64_t*)m->tree_mask_bits, (const float*)leafbox, (const float*)colbox,
                            (const uint64_t*)m->tree_masked_leaf, (const uint64_t*)m->tree_masked, N, m->tree_leaves,
                            (const int32_t*)m->tree_frontier_nodes + f0, (const int32_t*)m->tree_sub_leaf + 2 * (size_t)f0,
                            (const int32_t*)m->tree_launch_order + (size_t)f0 * m->tree_qblocks, keys,
-                           (const float*)(ws + l.prow_g), (const uint64_t*)m->tree_mask_bits_g, m->tree_groups, out);
-        const int rc = tuch_tiles_fill_launch(leaf_cnt, nullptr, nullptr, m->tree_leaves, l.cap, l.max_tiles, 0,
-                                              (RayTile*)(ws + l.tiles), (RayBody*)(ws + l.body), (const RayEntry*)(ws + l.lists),
-                                              (const int32_t*)(ws + l.list_len), l.waves, l.stride, leaf_fill,
-                                              (int32_t*)(ws + l.pairs), B, s);
-        if (rc != TUCH_OK) return rc;
-        const int columns = B < 8 ? B : 8;
-        hipLaunchKernelGGL(v2v_tiles_kernel, dim3(columns, 32768 / columns), dim3(64), 0, s, (const float*)prow, Vp,
-                           (const uint64_t*)m->tree_mask_bits, V, (const float*)leafbox, m->tree_leaves,
-                           (const int32_t*)m->tree_launch_order + (size_t)f0 * m->tree_qblocks, (const RayTile*)(ws + l.tiles),
-                           (const RayBody*)(ws + l.body), (const int32_t*)(ws + l.pairs), l.cap, l.max_tiles, B, keys,
-                           (const float*)(ws + l.prow_g), m->tree_groups);
+                           (const float*)(ws + l.prow_g), (const uint64_t*)m->tree_mask_bits_g, m->tree_groups,
+                           std::min(m->opt.v2v_pairs, 33));       // (the queue holds 63 + 32 pairs)
     }
-    else if (scan == 2 && leave_room && m->opt.v2v_lds < 0) {
-        auto* kernel = m->opt.v2v_lds == -4 ? v2v_scan_shared_kernel<4> : m->opt.v2v_lds == -5 ? v2v_scan_shared_kernel<5> : m->opt.v2v_lds == -6 ? v2v_scan_shared_kernel<6>
-                                                                                                  : v2v_scan_shared_kernel<7>;
-        hipLaunchKernelGGL(kernel, dim3(B, 2 * nsub * m->tree_qblocks), dim3(64), 0, s, (const float*)prow,
-                           V, Vp, (const uint64_t*)m->tree_mask_bits, (const float*)leafbox, (const float*)colbox,
-                           (const uint64_t*)m->tree_masked_leaf, (const uint64_t*)m->tree_masked, N, m->tree_leaves,
-                           (const int32_t*)m->tree_frontier_nodes + f0, (const int32_t*)m->tree_sub_leaf + 2 * (size_t)f0,
-                           (const int32_t*)m->tree_launch_order + (size_t)f0 * m->tree_qblocks, keys,
-                           (const float*)(ws + l.prow_g), (const uint64_t*)m->tree_mask_bits_g, m->tree_groups);
-    }
-    else if (scan == 2)
-        hipLaunchKernelGGL(v2v_scan_kernel, dim3(B, 2 * nsub * m->tree_qblocks), dim3(64), (size_t)lds_pad, s, (const float*)prow,
-                           V, Vp, (const uint64_t*)m->tree_mask_bits, (const float*)leafbox, (const float*)colbox,
-                           (const uint64_t*)m->tree_masked_leaf, (const uint64_t*)m->tree_masked, N, m->tree_leaves,
-                           (const int32_t*)m->tree_frontier_nodes + f0, (const int32_t*)m->tree_sub_leaf + 2 * (size_t)f0,
-                           (const int32_t*)m->tree_launch_order + (size_t)f0 * m->tree_qblocks, keys,
-                           (const float*)(ws + l.prow_g), (const uint64_t*)m->tree_mask_bits_g, m->tree_groups);
     else
     hipLaunchKernelGGL(v2v_tree_kernel, dim3(B, 2 * nsub * m->tree_qblocks), dim3(64), (size_t)lds_pad, s, (const float*)prow, V, Vp,
                        (const uint64_t*)m->tree_mask_bits, nodes, (const int32_t*)m->tree_rows, (const float*)bounds,
