@@ -40,6 +40,7 @@ struct tuch_options {
     int tree_waves = 32768;     // frontier choice of the solid-angle walk (128-query blocks)
     int ray_pair_cap = 16;      // (ray, leaf) pairs per query the pair list has room for
     int ray_waves = 32768;      // wavefronts of the crossing kernel
+    int ray_fans = 0;           // the vertices' closing fans (they need the vertices only): 0 inside ray_finalize_verts_kernel, 1 by extra workgroups of the inside test's FIRST launch (ray_leaf_bounds_kernel), 2 of ray_near_kernel's launch.  Round 5, batch 64: 0.427 / 0.444 / 0.424 ms per step -- the finalize kernel drops from 28 to 6 - 13 us, but the launch that carries the fans grows by more (1: the search then starts ahead of ray_near, which crawls beside it: 117 us)
     int v2v_tree = 1;           // 0: flat nearest-vertex search
     int v2v_waves = 0;          // frontier choice of the search (wavefronts aimed at; 0: the form's own default)
     int v2v_flat = 2;           // search: 2 lanes over a subtree's leaves first (v2v_scan_kernel), 0 the stackless walk (v2v_tree_kernel)

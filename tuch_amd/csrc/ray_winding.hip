@@ -121,13 +121,34 @@ __device__ __forceinline__ uint32_t half_above(float x)
 __device__ __host__ __forceinline__ size_t near_records_at(int B, int L) { return (size_t)B * kNearSlabs * L; }
 __device__ __host__ __forceinline__ size_t near_centres_at(int B, int L) { return near_records_at(B, L) + (size_t)B * L * 8; }
 
+__device__ __forceinline__ float fan_terms(const float* __restrict__ vb, int v, bool real, int& n,
+                                           const int32_t* __restrict__ ring_off, const int32_t* __restrict__ ring_vidx);
+// kPose, leaf_blocks > 0: the workgroups behind the first leaf_blocks compute the closing fans of 256 vertices each
+// (fan_terms: they need the vertices only).  This launch is the first of the inside test's chain, with a handful of
+// workgroups per body on an otherwise idle chip; inside ray_finalize_verts_kernel, behind the crossing kernel, the fans
+// were 15 us of the step's critical chain, as workgroups of ray_near_kernel's launch they stretched that launch from 53
+// to 80 us (its own workgroups run beside the search, whose wavefronts hold the vector units).
 template <bool kPose>
 __global__ __launch_bounds__(kBoundsBlock) void ray_leaf_bounds_kernel(
     const RayElem* __restrict__ stream, int T, const TreeNode* __restrict__ nodes, int N,
     const int32_t* __restrict__ height_off, const int32_t* __restrict__ height_nodes, float* __restrict__ bounds,
     const float* __restrict__ verts, const int32_t* __restrict__ vidx, const float* __restrict__ sign, int V, int Lexact,
-    RayElem* __restrict__ stream_out, uint4* __restrict__ zeroed, size_t zeroed_n)
+    RayElem* __restrict__ stream_out, uint4* __restrict__ zeroed, size_t zeroed_n,
+    int leaf_blocks = 0, const int32_t* __restrict__ qperm = nullptr, const int32_t* __restrict__ ring_off = nullptr,
+    const int32_t* __restrict__ ring_vidx = nullptr, float2* __restrict__ fans = nullptr, int fan_stride = 0)
 {
+    if (kPose && leaf_blocks > 0 && (int)blockIdx.x >= leaf_blocks) {
+        for (size_t g = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kBoundsBlock + threadIdx.x; g < zeroed_n;
+             g += (size_t)gridDim.x * gridDim.y * kBoundsBlock)
+            zeroed[g] = make_uint4(0u, 0u, 0u, 0u);
+        const int i = ((int)blockIdx.x - leaf_blocks) * kBoundsBlock + (int)threadIdx.x;        // position in tree order
+        const bool real = i < V;
+        const int v = qperm[real ? i : V - 1];
+        int cr = 0;
+        const float half = fan_terms(verts + (size_t)blockIdx.y * V * 3, v, real, cr, ring_off, ring_vidx);
+        if (i < fan_stride) fans[(size_t)blockIdx.y * fan_stride + i] = make_float2(__int_as_float(cr), half);
+        return;
+    }
     const int b = blockIdx.y;
     const RayElem* st = stream + (size_t)b * T;
     const int group = threadIdx.x >> 4, sub = threadIdx.x & 15;
@@ -413,8 +434,23 @@ __global__ __launch_bounds__(64 * kWaves) void ray_near_kernel(
     int num_leaves, const int32_t* __restrict__ qperm,
     const int32_t* __restrict__ counts, int Q, int qblocks, RayEntry* __restrict__ lists, int32_t* __restrict__ list_len,
     int32_t* __restrict__ leaf_cnt,             // [B][num_leaves], zeroed: rays per leaf
-    unsigned long long* __restrict__ stats)     // measurement (or nullptr): [1] += (ray, element) pairs inside a listed
-{                                               // leaf's slabs, [2] += 64 x elements listed
+    unsigned long long* __restrict__ stats,     // measurement (or nullptr): [1] += (ray, element) pairs inside a listed
+                                                // leaf's slabs, [2] += 64 x elements listed
+    const int32_t* __restrict__ ring_off = nullptr, const int32_t* __restrict__ ring_vidx = nullptr,
+    float2* __restrict__ fans = nullptr)        // kVerts: workgroups behind the query blocks compute the vertices' closing fans
+{
+    if (kVerts && (int)blockIdx.x >= qblocks) {
+        // the closing fans of 64 kWaves vertices (fan_terms): vector work that needs the vertices only, beside this launch's
+        // own workgroups, which mostly wait (as a kernel of its own, or inside ray_finalize_verts_kernel behind the
+        // crossing kernel, it was 18 - 28 us on the step's critical chain)
+        const int i = ((int)blockIdx.x - qblocks) * (64 * kWaves) + (int)threadIdx.x;        // position in tree order
+        const bool real = i < Q;
+        const int v = qperm[real ? i : Q - 1];
+        int cr = 0;
+        const float half = fan_terms(pts + (size_t)blockIdx.y * Q * 3, v, real, cr, ring_off, ring_vidx);
+        if (i < qblocks * kRayQueries) fans[(size_t)blockIdx.y * qblocks * kRayQueries + i] = make_float2(__int_as_float(cr), half);
+        return;
+    }
     __builtin_amdgcn_s_setprio(3);               // (see ray_tiles_fill_kernel)
     const int qb = blockIdx.x, b = blockIdx.y, lane = threadIdx.x & 63;
     const int wave = kWaves > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
@@ -912,10 +948,13 @@ __device__ __forceinline__ void cone_term(const P3& us, const P3& sb, const P3& 
     half = fast_atan2(front ? num : -num, den);
 }
 
-// w of a VERTEX from its crossing count: N = count + crossings of the closing fan; w = N - (sum of the fan's half angles) / (2 pi).
+// The closing fan of a VERTEX: n += its signed crossings, returns the sum of its half angles.  w = N - half_sum / (2 pi),
+// N = count + crossings of the fan (fan_winding below).  The fan needs the vertices only -- not the crossing counts --: in
+// the loss path it is computed by extra workgroups of ray_near_kernel's launch (whose own workgroups are chains of dependent
+// steps that leave the vector units idle) and ray_finalize_verts_kernel only reads two words per vertex.
 // One vertex per lane (`real` = false: a padding lane; all lanes of the wavefront must call -- long rings are shared out).
-__device__ __forceinline__ float fan_winding(const float* __restrict__ vb, int v, bool real, int n,
-                                             const int32_t* __restrict__ ring_off, const int32_t* __restrict__ ring_vidx)
+__device__ __forceinline__ float fan_terms(const float* __restrict__ vb, int v, bool real, int& n,
+                                           const int32_t* __restrict__ ring_off, const int32_t* __restrict__ ring_vidx)
 {
     const float vx = vb[3 * v], vy = vb[3 * v + 1], vz = vb[3 * v + 2];
     const float qx = shear_x(vx, vz), qy = shear_y(vy, vz);
@@ -1011,6 +1050,12 @@ __device__ __forceinline__ float fan_winding(const float* __restrict__ vb, int v
         for (int m = 32; m >= 1; m >>= 1) { h += __shfl_xor(h, m); cr += __shfl_xor(cr, m); }
         if (lane == src) { half_sum = h; n += cr; }
     }
+    return half_sum;
+}
+__device__ __forceinline__ float fan_winding(const float* __restrict__ vb, int v, bool real, int n,
+                                             const int32_t* __restrict__ ring_off, const int32_t* __restrict__ ring_vidx)
+{
+    const float half_sum = fan_terms(vb, v, real, n, ring_off, ring_vidx);
     return (float)n - half_sum * (0.5f / kPi);
 }
 
@@ -1019,14 +1064,21 @@ __global__ __launch_bounds__(kBlock) void ray_finalize_verts_kernel(
     const float* __restrict__ verts, const int32_t* __restrict__ count, const int32_t* __restrict__ qperm,
     const int32_t* __restrict__ ring_off, const int32_t* __restrict__ ring_vidx,
     int V, int stride, float thresh, float* __restrict__ w_out, uint8_t* __restrict__ exterior,
-    uint8_t* __restrict__ exterior_copy)                 // or nullptr: the same flags once more (the two-launch segment
-{                                                        // filter reads them while it re-marks `exterior`)
+    uint8_t* __restrict__ exterior_copy,                 // or nullptr: the same flags once more (the two-launch segment
+                                                         // filter reads them while it re-marks `exterior`)
+    const float2* __restrict__ fans)                     // or nullptr: [B][stride] (fan crossings as int bits, half-angle sum)
+{                                                        // left by ray_near_kernel's fan workgroups
     const int b = blockIdx.y;
     const int i = blockIdx.x * kBlock + threadIdx.x;     // position in tree order
     const bool real = i < V;                             // all lanes stay: long rings need the whole wavefront
     const int v = qperm[real ? i : V - 1];
     const int n = count[(size_t)b * stride + (real ? i : V - 1)];
-    const float w = fan_winding(verts + (size_t)b * V * 3, v, real, n, ring_off, ring_vidx);
+    float w;
+    if (fans) {
+        const float2 f = fans[(size_t)b * stride + (real ? i : V - 1)];
+        w = (float)(n + __float_as_int(f.x)) - f.y * (0.5f / kPi);           // fan_winding's arithmetic
+    } else
+        w = fan_winding(verts + (size_t)b * V * 3, v, real, n, ring_off, ring_vidx);
     const size_t o = (size_t)b * V + v;
     if (real) {
         if (w_out) w_out[o] = w;
@@ -1321,7 +1373,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct RayLayout {
     size_t stream, bounds, lists, list_len, zeroed, zeroed_bytes, leaf_cnt, leaf_fill, count, leaf_off, tiles, body, pairs,
-        stats, total;
+        stats, fans, total;
     int T, qblocks, cap, max_tiles, workers, columns;
     size_t seg_count;        // per-segment crossing counts of the vertices (models with seg_elem_mask), zeroed with `count`
 };
@@ -1676,6 +1728,7 @@ static RayLayout full_layout(const tuch_contact_model* m, int B, int Q, bool ver
     l.body = tuch_ws_take(o, (size_t)B * sizeof(RayBody));
     l.pairs = tuch_ws_take(o, (size_t)B * l.cap * sizeof(int32_t));
     l.stats = tuch_ws_take(o, 256);
+    l.fans = verts ? tuch_ws_take(o, (size_t)B * l.qblocks * kRayQueries * sizeof(float2)) : 0;
     l.total = o;
     return l;
 }
@@ -1693,6 +1746,11 @@ size_t tuch_ray_workspace_bytes(const tuch_contact_model* m, int B, int Q)
     return a > b ? a : b;
 }
 
+// where the vertices' closing fans are computed (option ray_fans): 1 by workgroups of the chain's first launch, 2 of
+// ray_near_kernel's, 0 (and meshes without rings, or whose leaf runs do not tile the stream) inside the finalize kernel
+static bool fans_in_bounds_launch(const tuch_contact_model* m) { return m->ring_off && m->opt.ray_fans == 1 && m->tree_leaf_runs_tile; }
+static bool fans_in_near_launch(const tuch_contact_model* m) { return m->ring_off && m->opt.ray_fans == 2; }
+
 // sheared leaf strips and the slabs of every LEAF (inner nodes are not used by the flat near test)
 static void launch_ray_boxes(const tuch_contact_model* m, const RayLayout& l, const float* verts, int B, char* ws, hipStream_t s,
                              bool one_launch)
@@ -1702,11 +1760,15 @@ static void launch_ray_boxes(const tuch_contact_model* m, const RayLayout& l, co
     // one launch: every leaf poses its own run of the strip.  (Not for the points form with its far larger span of
     // counters to clear -- [B][Q] with Q = all HD points: the leaf grid has too few workgroups for that, 100 us)
     if (one_launch && m->tree_leaf_runs_tile) {
-        hipLaunchKernelGGL(ray_leaf_bounds_kernel<true>, dim3(ceil_div(m->tree_leaves, kBoundsBlock / 16), B), dim3(kBoundsBlock), 0,
+        const int leaf_blocks = ceil_div(m->tree_leaves, kBoundsBlock / 16);
+        const bool fans = fans_in_bounds_launch(m);
+        hipLaunchKernelGGL(ray_leaf_bounds_kernel<true>, dim3(leaf_blocks + (fans ? ceil_div(m->V, kBoundsBlock) : 0), B), dim3(kBoundsBlock), 0,
                            s, (const RayElem*)st, l.T, (const TreeNode*)m->tree_node, m->tree_nodes,
                            (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, bounds, verts,
                            (const int32_t*)m->tree_vidx, (const float*)m->tree_sign_word, m->V, m->tree_exact_len, st,
-                           (uint4*)(ws + l.zeroed), l.zeroed_bytes / sizeof(uint4));
+                           (uint4*)(ws + l.zeroed), l.zeroed_bytes / sizeof(uint4), fans ? leaf_blocks : 0,
+                           (const int32_t*)m->tree_qperm, (const int32_t*)m->ring_off, (const int32_t*)m->ring_vidx,
+                           (float2*)(ws + l.fans), l.qblocks * kRayQueries);
         return;
     }
     hipLaunchKernelGGL(ray_stream_kernel, dim3(ceil_div(l.T, kBlock), B), dim3(kBlock), 0, s, verts,
@@ -1738,14 +1800,17 @@ static int launch_ray_counts(const tuch_contact_model* m, const RayLayout& l, co
     RayBody* body = (RayBody*)(ws + l.body);
     int32_t* pairs = (int32_t*)(ws + l.pairs);
     // four wavefronts per query block while the blocks alone do not fill the chip (see the kernel)
+    // vertices of a closed manifold (rings): their closing fans ride in this launch, as workgroups behind the query blocks
+    const bool fans = kVerts && fans_in_near_launch(m);
+    float2* fan_out = fans ? (float2*)(ws + l.fans) : nullptr;
     if ((long)l.qblocks * B <= 2048)
-        hipLaunchKernelGGL((ray_near_kernel<kVerts, 4>), dim3(l.qblocks, B), dim3(256), 0, s, queries, nodes,
+        hipLaunchKernelGGL((ray_near_kernel<kVerts, 4>), dim3(l.qblocks + (fans ? ceil_div(Q, 256) : 0), B), dim3(256), 0, s, queries, nodes,
                            (const float*)(ws + l.bounds), m->tree_nodes, L, qperm, counts, Q, l.qblocks, lists, list_len,
-                           leaf_cnt, stats);
+                           leaf_cnt, stats, (const int32_t*)m->ring_off, (const int32_t*)m->ring_vidx, fan_out);
     else
-        hipLaunchKernelGGL((ray_near_kernel<kVerts, 1>), dim3(l.qblocks, B), dim3(64), 0, s, queries, nodes,
+        hipLaunchKernelGGL((ray_near_kernel<kVerts, 1>), dim3(l.qblocks + (fans ? ceil_div(Q, 64) : 0), B), dim3(64), 0, s, queries, nodes,
                            (const float*)(ws + l.bounds), m->tree_nodes, L, qperm, counts, Q, l.qblocks, lists, list_len,
-                           leaf_cnt, stats);
+                           leaf_cnt, stats, (const int32_t*)m->ring_off, (const int32_t*)m->ring_vidx, fan_out);
     const size_t tf_lds = (2 * (size_t)L + l.qblocks + 1) * sizeof(int32_t);
     if (l.qblocks <= kFillMaxBlocks && tf_lds <= 48u * 1024)
         hipLaunchKernelGGL(ray_tiles_fill_kernel, dim3(B, kFillSplit), dim3(kTilesFillBlock), tf_lds, s, (const int32_t*)leaf_cnt,
@@ -1787,7 +1852,8 @@ int tuch_ray_exterior_verts(const tuch_contact_model* m, const float* verts, int
     if (w || exterior)
         hipLaunchKernelGGL(ray_finalize_verts_kernel, dim3(ceil_div(m->V, kBlock), B), dim3(kBlock), 0, s, verts,
                            (const int32_t*)(ws + l.count), (const int32_t*)m->tree_qperm, (const int32_t*)m->ring_off,
-                           (const int32_t*)m->ring_vidx, m->V, l.qblocks * kRayQueries, thresh, w, exterior, exterior_copy);
+                           (const int32_t*)m->ring_vidx, m->V, l.qblocks * kRayQueries, thresh, w, exterior, exterior_copy,
+                           (const float2*)(fans_in_bounds_launch(m) || fans_in_near_launch(m) ? ws + l.fans : nullptr));
     if (stats_host) {
         RayBody bodies[8];
         const int nb = B < 8 ? B : 8;
