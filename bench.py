@@ -173,7 +173,7 @@ def timeline_constants():
                 m = re.match(r'\s*([\d.]+)\s+([\d.]+)\s+(.*)', line)
                 if m and not line.startswith('kernels') and not line.startswith('time'):
                     rows.append((float(m.group(1)), float(m.group(2)), m.group(3)))
-        big = [r for r in rows if re.search(r'v2v_(scan|mfma|leaves|tree)\w*_kernel(<\d+>)?\(', r[2]) and 'finalize' not in r[2]
+        big = [r for r in rows if re.search(r'v2v_(scan|mfma|leaves|tree)\w*_kernel(<[^>]*>)?\(', r[2]) and 'finalize' not in r[2]
                or 'ray_leaf_kernel' in r[2]]
         search = [r for r in big if 'v2v_' in r[2]]
         if head and big and search:
