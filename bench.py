@@ -114,6 +114,19 @@ def profile_staleness(sq_file, sources):
     return False, None
 
 
+def live_lane_fraction():
+    """(fraction, source) of the search's row arithmetic: lanes with a (leaf, column) pair in reach / lanes issued, from the
+    newest committed counting run (tools/diag/scan_counts.py: a second library built with -DTUCH_SCAN_COUNTS); from
+    profiles/, NOT measured in this run."""
+    import glob
+    import re
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_scan_counts.txt')), reverse=True):
+        m = re.search(r'^live_lane_fraction ([\d.]+)', open(f).read(), re.M)
+        if m:
+            return float(m.group(1)), 'profiles/' + os.path.basename(f)
+    return None, None
+
+
 def profile_constants():
     """HBM-side bytes per launch and VALU-busy fraction of the two big kernels at batch 64, parsed at start-up from the
     newest committed PMC summaries (profiles/rNN_x_pmc_{fetch,write,sq}.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE /
@@ -630,6 +643,7 @@ def rooflines(p, batch):
             'equivalent_achieved': round(ach_v, 2), 'equivalent_frac': round(ach_v / PEAK_FP32_VECTOR_TFLOPS, 4),
             'traffic': prof_v['traffic_bytes'] if batch == BATCH_PER_GPU else None,
             'valu_busy': prof_v['valu_busy'], 'profile_source': prof_v['source'],
+            'live_lane_fraction': live_lane_fraction()[0], 'live_lane_fraction_source': live_lane_fraction()[1],
             # frac mixes an instruction count from profiles/ with a launch time measured here: stale = the kernel source has
             # changed since that count was collected (then frac / valu_busy / traffic describe OLDER code)
             'stale': prof_v['stale'], 'stale_reason': prof_v['stale_reason'],

@@ -51,11 +51,8 @@ print('per live wavefront: trips %.2f candidates %.2f reaching %.2f rows8 %.2f (
       % (c[1] / w, c[2] / w, c[3] / w, c[4] / w, c[5] / w, c[6] / w, c[7] / w, c[8] / w))
 # rough VALU estimate per event (read off the ISA: tools/diag/README)
 
-if c[22]:
-    w = c[22]
-    print('regrouped form: wavefronts %d; per wavefront: leaves evaluated on the spot %.2f (%.1f columns in reach each), deferred entries %.2f (%.1f columns each)'
-          % (w, c[18] / w, c[19] / max(c[18], 1), c[20] / w, c[21] / max(c[20], 1)))
-    print('   tiles per wavefront %.2f, columns per tile %.1f, of them still in reach when the tile is evaluated %.1f (of 64 lanes)' % (c[16] / w, c[23] / max(c[16], 1), c[17] / max(c[16], 1)))
-    tot = sum(c[24:29])
-    for name, i in (('filter + direct rows', 24), ('offsets + barriers', 25), ('scatter', 26), ('tiles', 27), ('write-out + barrier', 28)):
-        print('   %-22s %8.0f ticks per wavefront (%4.1f %%)' % (name, c[i] / w, 100.0 * c[i] / max(tot, 1)))
+if c[16] or c[18]:
+    live = (c[19] + c[17]) / max(64.0 * (c[18] + c[16]), 1.0)
+    print('lane pairs: leaves walked row by row for the wavefront %.2f per wavefront (%.1f of 64 columns in reach), flushes of queued '
+          'pairs %.2f per wavefront (%.1f of 64 lanes)' % (c[18] / w, c[19] / max(c[18], 1), c[16] / w, c[17] / max(c[16], 1)))
+    print('live_lane_fraction %.3f   # row arithmetic: lanes with a (leaf, column) pair in reach / lanes issued (round 4: 12.2 / 64 = 0.19)' % live)

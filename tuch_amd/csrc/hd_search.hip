@@ -34,6 +34,18 @@
 
 namespace {
 
+#ifdef TUCH_SCAN_COUNTS
+__device__ unsigned long long g_hd_counts[16];
+extern "C" int tuch_debug_hd_counts(unsigned long long* out, int reset)
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hd_counts), sizeof(unsigned long long) * 16) != hipSuccess) return TUCH_ERR_HIP;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_hd_counts), z, sizeof(z)) != hipSuccess) return TUCH_ERR_HIP;
+    }
+    return TUCH_OK;
+}
+#endif
 constexpr int kTile = 32;                 // rows per tile
 constexpr float kBigNorm = 1e30f;         // "norm" of a row that does not exist
 constexpr float kNoKey = 1e29f;           // keys at or above: no admissible row
@@ -358,6 +370,17 @@ __global__ __launch_bounds__(64 * kWaves) void hd_search_kernel(
         }
         // a column that is near but has no admissible row here does not make the tile worth a product
         if (__builtin_amdgcn_ballot_w64(near && any != 0u) == 0) return;
+#ifdef TUCH_SCAN_COUNTS
+        {   // diagnostic build (tools/diag/hd_counts.py): tiles that reach the products, their columns in reach with an admissible run
+            const unsigned long long live_ = __builtin_amdgcn_ballot_w64(near && any != 0u), near_ = __builtin_amdgcn_ballot_w64(near);
+            if (lane == 0) {
+                atomicAdd(&g_hd_counts[0], 1ull);
+                atomicAdd(&g_hd_counts[1], (unsigned long long)__builtin_popcountll(live_));
+                atomicAdd(&g_hd_counts[2], (unsigned long long)__builtin_popcountll(near_));
+                atomicAdd(&g_hd_counts[3 + min(__builtin_popcountll(live_) / 8, 8)], 1ull);
+            }
+        }
+#endif
         f32x16 acc[2];
         product(qx, qy, qz, j < rows, ridx, A, acc);
         if (K > 16) product_high(ridx, Ah, acc);

@@ -1026,6 +1026,9 @@ __device__ __forceinline__ void v2v_scan_body(
         s_key[lane] = init;
     }
     auto flush = [&](int n) {
+#ifdef TUCH_SCAN_COUNTS
+        if (lane == 0) { atomicAdd(&g_scan_counts[16], 1ull); atomicAdd(&g_scan_counts[17], (unsigned long long)n); }
+#endif
         s_key[lane] = v2v_key(c.best, c.arg);             // (what the rows walked on the spot have found since)
         // (a one-wavefront workgroup: no s_barrier is emitted, but the fences are needed -- without them lanes read the
         // queue / the keys before the other lanes' writes: 157 of 4806 minima wrong on the 1602-vertex fixture)
@@ -1121,6 +1124,9 @@ __device__ __forceinline__ void v2v_scan_body(
                         __syncthreads();
                     }
                 } else {
+#ifdef TUCH_SCAN_COUNTS
+                    if (lane == 0) { atomicAdd(&g_scan_counts[18], 1ull); atomicAdd(&g_scan_counts[19], (unsigned long long)nreach); }
+#endif
                     const int leaf = __builtin_amdgcn_readfirstlane(__float_as_int(bhi.w));
                     const int g0 = __builtin_amdgcn_readfirstlane(__float_as_int(blo.w));
                     v2v_rows_packed(c, pg + (size_t)g0 * 12, mg + (size_t)g0 * 4, leaf & 0xfffff, ((leaf >> 20) + 3) >> 2, reach);
