@@ -218,8 +218,8 @@ int tuch_contact_model_create(tuch_contact_model** out, int V, int F, const int3
                               int num_pairs, const int32_t* pairs);
 void tuch_contact_model_destroy(tuch_contact_model* model);
 /* Switches of the hot calls (A/B measurements, tests): winding_ray (0 never / 1 when only flags are wanted / 2 also for
- * w), winding_tree, winding_strips, tree_waves, ray_pair_cap, ray_waves, v2v_tree, v2v_waves, v2v_lds, seg_splits,
- * seg_assist (fixed at create), canary.  (Deterministic mode is process-wide: tuch_set_deterministic.)  The environment variables TUCH_<NAME> are read ONCE, by
+ * w), winding_tree, winding_strips, tree_waves, ray_pair_cap, ray_waves, ray_fans, v2v_tree, v2v_flat, v2v_pairs, v2v_waves, v2v_lds,
+ * seg_splits, seg_fused, seg_assist (fixed at create), hd_search, hd_search_waves, hd_overlap, canary.  (Deterministic mode is process-wide: tuch_set_deterministic.)  The environment variables TUCH_<NAME> are read ONCE, by
  * tuch_contact_model_create; afterwards only set_option changes a model's switches -- no hot call looks at the
  * environment, so a captured hipGraph cannot depend on it.  (The workspace sizes depend on ray_pair_cap and canary:
  * query *_workspace_bytes again after changing them.) */
