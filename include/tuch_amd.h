@@ -277,8 +277,9 @@ size_t tuch_v2v_hint_bytes(const tuch_contact_model* model, int B);
 int tuch_v2v_min_model(const tuch_contact_model* model, const float* verts, int B, float* min_d2,
                        int32_t* argmin, void* hint_inout, void* workspace, size_t workspace_bytes, void* stream);
 /* The same search for callers that run other kernels beside it on another stream (as ops.ContactModel.exterior_and_partner
- * does with the inside test): leave_room != 0 caps the walk's occupancy so that the neighbours' small kernels are not
- * starved of wave slots.  Same results. */
+ * does with the inside test): leave_room & 1 caps the walk's occupancy so that the neighbours' small kernels are not
+ * starved of wave slots; leave_room & 2: the caller expects hint_inout to hold near-final partners (an iterative fit calling
+ * again after a small parameter update) -- the search then uses fewer, longer wavefronts.  Same results either way. */
 int tuch_v2v_min_model_shared(const tuch_contact_model* model, const float* verts, int B, float* min_d2,
                               int32_t* argmin, void* hint_inout, void* workspace, size_t workspace_bytes, int leave_room,
                               void* stream);

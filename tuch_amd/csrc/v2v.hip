@@ -1009,7 +1009,7 @@ __device__ __forceinline__ void v2v_scan_body(
     }
     // lower bounds are compared as g <= bound * (1 + 1e-6): the slack of kPruneSlack on the side that changes rarely
     constexpr float kBoundSlack = 1.000001f;
-    const float reach2 = wave_max_uniform(((alive >> lane) & 1) ? c.best : 0.0f) * kBoundSlack;
+    float reach2 = wave_max_uniform(((alive >> lane) & 1) ? c.best : 0.0f) * kBoundSlack;
     float best_s = c.best * kBoundSlack;
     // the boxes of a trip's 64 leaves, for the per-column test of the candidates among them: a candidate's box is one
     // broadcast read of LDS (two 16-byte reads) instead of six v_readlane + three v_mov (one scalar operand per vector
@@ -1044,7 +1044,9 @@ __device__ __forceinline__ void v2v_scan_body(
     const float* lb = leafbox + ((size_t)b * L + first) * 8;
     const uint64_t* ml = masked_leaf + (size_t)qb * L + first;
     for (int base = 0; base < count; base += 64) {
-        // one leaf per lane: the gap between its box and the block's, against the largest bound
+        // one leaf per lane: the gap between its box and the block's, against the largest bound -- as it is NOW: a search
+        // that started from poor bounds (new bodies) has tightened them in the trips before
+        if (base > 0) reach2 = wave_max_uniform(((alive >> lane) & 1) ? c.best : 0.0f) * kBoundSlack;
         const int li = base + lane;
         bool cand = false;
         SCAN_COUNT(1);
@@ -1182,7 +1184,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct TreeV2VLayout { size_t prow, bounds, keys, leafbox, colbox, prow_g, total; };
 
 static int flat_mode(const tuch_contact_model* m);
-int choose_v2v_frontier(const tuch_contact_model* m, int B);
+int choose_v2v_frontier(const tuch_contact_model* m, int B, bool iterative = false);
 
 TreeV2VLayout tree_v2v_layout(const tuch_contact_model* m, int B)
 {
@@ -1214,12 +1216,16 @@ static int flat_mode(const tuch_contact_model* m)
     return m->opt.v2v_flat >= 2 ? 2 : 0;
 }
 
-int choose_v2v_frontier(const tuch_contact_model* m, int B)
+int choose_v2v_frontier(const tuch_contact_model* m, int B, bool iterative)
 {
     // option v2v_waves = 0: the form's own default -- the walks want many short wavefronts (65536: 32 subtrees at batch
     // 64), the leaf scan tests up to 64 leaves per wavefront at once and is best with a quarter as many (measured at
-    // batch 64, step time: 7000 / 14000 / 30000 / 65536 -> 0.56+ / 0.546 / 0.550 / 0.562 ms)
-    const long target = m->opt.v2v_waves > 0 ? m->opt.v2v_waves : (flat_mode(m) >= 2 ? 14000L : 65536L);
+    // batch 64, step time: 7000 / 14000 / 30000 / 65536 -> 0.56+ / 0.546 / 0.550 / 0.562 ms, round 3).  Round 5, with the
+    // sparse pairs one per lane: a caller that says its bounds are near-final (an iterative fit: the hints are the previous
+    // iteration's partners) gets a quarter of that again -- fewer prologues, fuller flushes: 0.412 against 0.426 ms per
+    // step at batch 64 --; on NEW bodies the search is slower that way (183 against 163 us: two subtrees per block tighten
+    // poor bounds later than eight do), so that stays the default
+    const long target = m->opt.v2v_waves > 0 ? m->opt.v2v_waves : (flat_mode(m) >= 2 ? (iterative ? 3500L : 14000L) : 65536L);
     int f = 0;
     while (f + 1 < m->tree_num_frontiers &&
            (long)B * m->tree_qblocks * (m->tree_frontier_off_host[f + 1] - m->tree_frontier_off_host[f]) < target)
@@ -1325,6 +1331,8 @@ extern "C" int tuch_v2v_min_model_shared_zero(const tuch_contact_model* m, const
 {
     TUCH_REQUIRE(m && verts && (min_d2 || argmin), "tuch_v2v_min_model: null pointer");
     TUCH_REQUIRE(m->mask_bits, "tuch_v2v_min_model: the model has no geodesic mask");
+    const bool iterative = (leave_room & 2) != 0;      // flags: 1 leave room for kernels on another stream, 2 bounds are near-final
+    leave_room &= 1;
     TUCH_REQUIRE(B > 0 && B <= 65535, "tuch_v2v_min_model: bad batch %d", B);
     TUCH_REQUIRE((zero_bytes & 15) == 0 && (((uintptr_t)zero) & 15) == 0 && (zero || zero_bytes == 0),
                  "tuch_v2v_min_model: the buffer to clear must be 16-byte aligned and a multiple of 16 bytes");
@@ -1376,7 +1384,7 @@ extern "C" int tuch_v2v_min_model_shared_zero(const tuch_contact_model* m, const
                        scan >= 2 ? (const float*)leafbox : (const float*)nullptr,
                        (const uint64_t*)m->tree_masked_leaf, m->tree_leaves);
     }
-    const int f = choose_v2v_frontier(m, B);
+    const int f = choose_v2v_frontier(m, B, iterative);
     const int f0 = m->tree_frontier_off_host[f], nsub = m->tree_frontier_off_host[f + 1] - f0;
     // leave_room: an unused LDS allocation caps the walk at 25 of a CU's 32 wave slots.  The walk is one grid of 220 k
     // short one-wave workgroups; when the inside test runs beside it on another stream -- a chain of mostly small

@@ -486,7 +486,8 @@ class _Stage2Tail(torch.autograd.Function):
                 float(const['prior_scale']), _C.ptr(small), _C.ptr(gj), _C.ptr(gc), _C.ptr(gp), _C.stream()))
             return (keys, fixed, small, gj, gc, gp, zeros[:n].view(v.shape), zeros[n:n + 1].view(torch.int32))
         exterior, _, partner, _extra = model.exterior_and_partner(v, apply_segments=const['apply_segments'],
-                                                                  also=beside_the_walk, zero_floats=k0 + 2 * b * p + det)
+                                                                  also=beside_the_walk, zero_floats=k0 + 2 * b * p + det,
+                                                                  iterative=True)       # SMPLify-DC's stage-2 loop
         out = torch.empty(1, dtype=torch.float32, device=v.device)
         share = torch.empty(L.tuch_smplify_stage2_fused_scratch_floats(b), dtype=torch.float32, device=v.device)
         # the objective is the root of the fit's graph: its vertex gradient for a unit upstream gradient is written by the
@@ -777,13 +778,16 @@ class ContactModel:
                                              sign.ctypes.data_as(ctypes.c_void_p)))
         return vidx, sign, k.value
 
-    def exterior_and_partner(self, verts: torch.Tensor, apply_segments: bool = True, also=None, zero_floats: int = 0):
+    def exterior_and_partner(self, verts: torch.Tensor, apply_segments: bool = True, also=None, zero_floats: int = 0,
+                             iterative: bool = False):
         """exterior_flags + v2v_min of the same vertices -> (exterior, min_d2, partner[, also()]).
         The two only share their input: the nearest-vertex search (and the optional callable ``also``,
         e.g. the region pairs) runs on a second stream so that its tail fills the gaps of the long winding
         walk (option overlap = 0 keeps everything on the current stream).
         zero_floats > 0: a float32 buffer of (at least) that many ZEROS is handed to ``also(buffer)`` -- cleared by the
-        search's first kernel (tuch_v2v_min_model_shared_zero), not by a fill launch."""
+        search's first kernel (tuch_v2v_min_model_shared_zero), not by a fill launch.
+        iterative: the caller is an iterative fit (the previous call's partners, kept as hints, are almost this call's):
+        the search then uses fewer, longer wavefronts (see v2v_min).  Results never depend on it."""
         zero = None
         if zero_floats > 0:
             zero = torch.empty((int(zero_floats) + 3) // 4 * 4, dtype=torch.float32, device=verts.device)
@@ -792,7 +796,7 @@ class ContactModel:
             call_also = also
         if not (verts.is_cuda and self._py_options['overlap']):
             exterior = self.exterior_flags(verts, apply_segments=apply_segments)
-            mn, partner = self.v2v_min(verts, zero=zero)
+            mn, partner = self.v2v_min(verts, zero=zero, iterative=iterative)
             return exterior, mn, partner, (call_also() if call_also is not None else None)
         cur = torch.cuda.current_stream(verts.device)
         side = _side_stream(verts.device)
@@ -808,7 +812,7 @@ class ContactModel:
         with torch.cuda.stream(side):
             if zero is not None:
                 zero.record_stream(side)
-            mn, partner = self.v2v_min(verts, leave_room=True, zero=zero)
+            mn, partner = self.v2v_min(verts, leave_room=True, zero=zero, iterative=iterative)
             # (the caller's extra work -- region pairs, reprojection + prior -- FIRST, beside the short head of the inside
             # test's chain, was measured: 0.587 against 0.552 ms per step; it delays the search, which the chain waits for)
             extra = call_also() if call_also is not None else None
@@ -866,8 +870,10 @@ class ContactModel:
         return (ext, w, seg_w, seg_e) if return_details else ext
 
     # K1
-    def v2v_min(self, verts: torch.Tensor, leave_room: bool = False, zero: Optional[torch.Tensor] = None):
+    def v2v_min(self, verts: torch.Tensor, leave_room: bool = False, zero: Optional[torch.Tensor] = None, iterative: bool = False):
         """leave_room: other kernels run beside the search on another stream (tuch_v2v_min_model_shared).
+        iterative: the hints are expected to be near-final (SMPLify-DC's loops): a quarter of the wavefronts, each over more
+        leaves -- faster with good bounds (0.412 against 0.426 ms per stage-2 step at batch 64), slower on new bodies.
         zero: a caller tensor (numel * itemsize a multiple of 16) cleared by the call's first kernel (..._shared_zero)."""
         if not self.has_mask:
             raise _C.TuchError('ContactModel was created without a geodesic mask')
@@ -880,7 +886,7 @@ class ContactModel:
         nbytes = L.tuch_v2v_model_workspace_bytes(self._handle, b)
         ws = _workspace(nbytes, verts.device)
         _C.check(L.tuch_v2v_min_model_shared_zero(self._handle, _C.ptr(verts), b, _C.ptr(mn), _C.ptr(arg),
-                                                  _C.ptr(self._v2v_hint(b)), _C.ptr(ws), nbytes, int(leave_room), _C.ptr(zero),
+                                                  _C.ptr(self._v2v_hint(b)), _C.ptr(ws), nbytes, int(bool(leave_room)) | (2 if iterative else 0), _C.ptr(zero),
                                                   zero.numel() * zero.element_size() if zero is not None else 0, _C.stream()))
         return mn, arg
 

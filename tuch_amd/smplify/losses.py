@@ -132,7 +132,7 @@ def stage2_objective(model, valid, select, body_pose, betas, model_joints, euclt
         return r, sm
     # losses.py:79-89 (inside test) and losses.py:76-78,92-93 (nearest geodesically-far vertex)
     exterior, _, partner, (r2r, small) = model.exterior_and_partner(verts, apply_segments=apply_segments,
-                                                                    also=beside_the_walk)
+                                                                    also=beside_the_walk, iterative=True)
     contact_loss, contact_terms = ops.contact_terms(verts, partner, exterior, valid, ops.MODE_SMPLIFY, euclthres)
     if fused:      # objective assembled in one deterministic reduction
         return ops.smplify_objective(small, contact_terms, r2r, 10.0, contact_loss_weight)   # losses.py:120-123
