@@ -649,6 +649,35 @@ def test_v2v_tree_walk_matches_flat_search(tag, batch, monkeypatch):
     model.set_option('v2v_pairs', 24)
 
 
+@pytest.mark.parametrize('tag', ['medium', 'ico_medium'])
+def test_v2v_asymmetric_mask_takes_the_scan_without_lane_pairs(tag):
+    """The lane pairs read a column's admissible rows of a leaf from THAT column's row of the bit matrix: valid for a
+    symmetric mask only (a geodesic mask is).  A mask with pairs dropped one way only must fall back to the round-4 scan
+    (checked when the model is made) and still give the flat all-rows search's minima and partners; masking by the
+    reference's rule is P[:, ~mask] = inf with mask[row j, column i]."""
+    g, gm = golden(tag), golden_mask(tag).copy()
+    rng = np.random.default_rng(3)
+    drop = rng.random(gm.shape) < 0.3
+    gm[np.triu(drop, 1)] = False                      # rows j < columns i lose pairs; the mirrored entries stay
+    assert not np.array_equal(gm, gm.T)
+    model = make_model(g, gm, False, False)
+    verts = torch.tensor(g['verts'], device=dev())
+    model.set_option('v2v_tree', 0)
+    mn_f, arg_f = model.v2v_min(verts)
+    model.set_option('v2v_tree', 1)
+    for pairs in (24, 0):
+        model.set_option('v2v_pairs', pairs)
+        mn_t, arg_t = model.v2v_min(verts)
+        assert torch.equal(mn_t, mn_f)
+        assert int((arg_t != arg_f).sum()) <= 2
+    v = g['verts'][0].astype(np.float64)
+    d = ((v[:, None, :] - v[None, :, :]) ** 2).sum(2)
+    d[~gm] = np.inf
+    fin = np.isfinite(d.min(0))
+    got = mn_f[0].cpu().numpy()
+    assert np.array_equal(np.isfinite(got), fin) and np.allclose(got[fin], d.min(0)[fin], rtol=2e-6, atol=1e-9)
+
+
 @pytest.mark.parametrize('tag', ['medium', 'ico_medium', 'full', 'ico_full'])
 def test_winding_points_tree_matches_flat(tag, monkeypatch):
     """tuch_winding_points through the cluster tree (queries in the caller's order) against the flat strips."""
