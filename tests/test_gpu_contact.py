@@ -896,8 +896,9 @@ def test_v2v_fresh_bodies_foreign_hints_and_no_hints_agree_bit_for_bit_fullsize(
     buf = model._v2v_hint(batch)
     assert buf is not None
     order = [0, 1, 2, 1, 1, 0, 2, 0]             # foreign, foreign, foreign, foreign, OWN answer, foreign, ...
-    for i in order:
-        mn, arg = model.v2v_min(batches[i])
+    for n, i in enumerate(order):
+        # (iterative: the caller's word that its hints are near-final -- fewer, longer wavefronts; a wrong word costs time only)
+        mn, arg = model.v2v_min(batches[i], iterative=bool(n & 1), leave_room=bool(n & 2))
         assert torch.equal(mn, want[i][0]) and torch.equal(arg, want[i][1]), 'hinted call differs (batch %d)' % i
     for fill in ('zero', 'junk', 'minus one'):
         if fill == 'zero':
