@@ -1813,7 +1813,10 @@ static int launch_ray_counts(const tuch_contact_model* m, const RayLayout& l, co
                            leaf_cnt, stats, (const int32_t*)m->ring_off, (const int32_t*)m->ring_vidx, fan_out);
     const size_t tf_lds = (2 * (size_t)L + l.qblocks + 1) * sizeof(int32_t);
     if (l.qblocks <= kFillMaxBlocks && tf_lds <= 48u * 1024)
-        hipLaunchKernelGGL(ray_tiles_fill_kernel, dim3(B, kFillSplit), dim3(kTilesFillBlock), tf_lds, s, (const int32_t*)leaf_cnt,
+        // (one-wave workgroups per body: 64, more for small batches -- the kernel is a chain of dependent steps per workgroup, and a
+        // body's ~5000 list entries over 256 workgroups are one pass each: batch 8 0.180 -> 0.173 ms per step, batch 16 0.203 -> 0.199,
+        // batch 32 / 64 unchanged / slower with more)
+        hipLaunchKernelGGL(ray_tiles_fill_kernel, dim3(B, std::min(256, std::max(kFillSplit, 2048 / B))), dim3(kTilesFillBlock), tf_lds, s, (const int32_t*)leaf_cnt,
                            nodes, leaf_nodes, L, l.cap, l.max_tiles, l.qblocks * kFallbackChunks, tiles, body,
                            (const RayEntry*)lists, (const int32_t*)list_len, l.qblocks, (int32_t*)(ws + l.leaf_fill), pairs, L);
     else {
