@@ -397,6 +397,17 @@ extern "C" int tuch_debug_scan_counts(unsigned long long* out, int reset)
 #define SCAN_COUNT(i) do { } while (0)
 #endif
 
+#ifdef TUCH_SCAN_CLOCKS
+// diagnostic build only (tools/diag/scan_clocks.py): per wavefront of the scan its start and end (s_memrealtime, 100 MHz),
+// its place on the chip (HW_ID) and the trips / candidates it went through
+constexpr int kScanClockSlots = 1 << 17;
+__device__ unsigned long long g_scan_clocks[kScanClockSlots][4];
+extern "C" int tuch_debug_scan_clocks(unsigned long long* out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scan_clocks), sizeof(unsigned long long) * 4 * kScanClockSlots) == hipSuccess ? TUCH_OK : TUCH_ERR_HIP;
+}
+#endif
+
 __device__ __forceinline__ uint64_t v2v_key(float d, int j)
 {
     return ((uint64_t)__float_as_uint(d) << 32) | (uint32_t)j;
@@ -987,6 +998,11 @@ __device__ __forceinline__ void v2v_scan_body(
     if constexpr (kShared == 5) asm volatile("v_mov_b32 v99, 0" ::: "v99");
     if constexpr (kShared == 4) asm volatile("v_mov_b32 v127, 0" ::: "v127");
     const int b = blockIdx.x, lane = threadIdx.x;
+#ifdef TUCH_SCAN_CLOCKS
+    const unsigned long long clk0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long clk_cands = 0;
+    const int clk_slot = (blockIdx.y * gridDim.x + blockIdx.x) & (kScanClockSlots - 1);
+#endif
     const int pair = __builtin_amdgcn_readfirstlane(order[blockIdx.y >> 1]);      // launch order over 128-blocks
     const int sub = pair >> 16, qb = (pair & 0xffff) * 2 + (blockIdx.y & 1);
     const float* pb = prow + (size_t)b * Vp * 3;
@@ -1089,6 +1105,9 @@ __device__ __forceinline__ void v2v_scan_body(
 #endif
         }
         unsigned long long todo = __builtin_amdgcn_ballot_w64(cand);
+#ifdef TUCH_SCAN_CLOCKS
+        clk_cands += __builtin_popcountll(todo);
+#endif
         if (todo == 0) continue;
         leaf_lo[lane] = lo;                      // one wavefront per workgroup: LDS operations of a wavefront stay in order
         leaf_hi[lane] = hi;
@@ -1142,6 +1161,18 @@ __device__ __forceinline__ void v2v_scan_body(
     }
     const uint64_t k0 = v2v_key(c.best, c.arg);
     if (k0 < init) atomicMin((unsigned long long*)(kb + i0), (unsigned long long)k0);
+#ifdef TUCH_SCAN_CLOCKS
+    if (lane == 0) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_scan_clocks[clk_slot][0] = clk0;
+        g_scan_clocks[clk_slot][1] = __builtin_amdgcn_s_memrealtime();
+        g_scan_clocks[clk_slot][2] = ((unsigned long long)xcc << 32) | hw;
+        g_scan_clocks[clk_slot][3] = ((unsigned long long)blockIdx.y << 32) | (clk_cands << 8) | (unsigned)((count + 63) / 64);
+    }
+#endif
 }
 
 #define TUCH_SCAN_PARAMS                                                                                                   \
