@@ -126,3 +126,44 @@ for name, keyv in (('as launched', -np.arange(nj)), ('by mean lifetime', mean_li
     rank = np.empty(nj, np.int64); rank[jorder] = np.arange(nj)
     o2 = np.argsort(rank[job] * 4 + (by & 1), kind='stable')
     print('list scheduling, jobs %-20s: %.1f us' % (name, makespan(dur[o2], slots)))
+# static proxies of a job's weight from the mask alone (no geometry at model creation): leaves of the subtree the block's
+# columns may pair with at all / only partly (the rim of the 30 cm geodesic neighbourhood: near in space too)
+from tuch_amd.ops import cluster_tree
+faces_np = model.faces_np.reshape(-1, 3)
+V = int(faces_np.max()) + 1
+F = faces_np.shape[0]
+tr = cluster_tree(faces_np, V, max(32, F // 850))
+nsub = nj // tr['frontier_off'][-1] if False else None
+fo = tr['frontier_off']
+fi = [k for k in range(len(fo) - 1) if (fo[k + 1] - fo[k]) * (len(tr['qperm']) // 128) == nj]
+if fi:
+    f0 = fo[fi[0]]
+    qb_n = len(tr['qperm']) // 128
+    order_tab = tr['launch_order'][f0 * qb_n: f0 * qb_n + nj]
+    gm = p['geomask'].cpu().numpy().astype(bool)
+    qp = tr['qperm'][:]
+    nodes = tr['nodes']; rows = tr['rows']
+    leaves = [i for i in range(len(nodes)) if nodes[i, 5] < 0]
+    rim = np.zeros(nj); allowed = np.zeros(nj); pairs_allowed = np.zeros(nj); nleaves = np.zeros(nj)
+    for j in range(nj):
+        sub, qb = int(order_tab[j]) >> 16, int(order_tab[j]) & 0xffff
+        node = tr['frontier_nodes'][f0 + sub]; skip = nodes[node, 4]
+        cols = qp[qb * 128: qb * 128 + 128]
+        cols = cols[:max(0, min(128, V - qb * 128))] if qb * 128 + 128 > V else cols
+        for lf in leaves:
+            if lf < node or lf >= skip: continue
+            r0, rn = rows[lf]
+            if rn == 0: continue
+            sub_m = gm[np.ix_(cols, qp[r0:r0 + rn])]
+            cnt = int(sub_m.sum())
+            nleaves[j] += 1
+            if cnt > 0:
+                allowed[j] += 1; pairs_allowed[j] += cnt
+                if cnt < sub_m.size: rim[j] += 1
+    for name, x in (('leaves', nleaves), ('allowed leaves', allowed), ('rim leaves', rim), ('allowed pairs', pairs_allowed)):
+        print('static proxy %-15s: corr with the mean lifetime of the job %.2f, with its mean candidates %.2f' % (name, np.corrcoef(x, mean_life)[0, 1], np.corrcoef(x, mean_cand)[0, 1]))
+    for name, keyv in (('by rim leaves', rim), ('by rim, then allowed', rim * 1000 + allowed)):
+        jorder = np.argsort(-keyv, kind='stable')
+        rank = np.empty(nj, np.int64); rank[jorder] = np.arange(nj)
+        o2 = np.argsort(rank[job] * 4 + (by & 1), kind='stable')
+        print('list scheduling, jobs %-22s: %.1f us' % (name, makespan(dur[o2], slots)))
