@@ -60,16 +60,11 @@ void tuch_options_from_env(tuch_options* o);
 // points, identical to thresholding the winding-number sum wherever that sum is well separated from the threshold.
 bool tuch_ray_available(const tuch_contact_model* m);
 // (query block, leaf) entries -> the rays of every leaf, in tiles of 64 (ray_winding.hip: ray_near_kernel's lists regrouped
-// by ray_tiles_fill_kernel; v2v.hip's leaf-major search regroups its (column block, leaf) entries with the same launch)
+// by ray_tiles_fill_kernel)
 struct RayEntry { int32_t leaf, node; uint32_t mask_lo, mask_hi; };   // which of the block's 64 lanes
 struct RayTile { int32_t ex_off, ex_len, first, n; };                 // n <= 64 slots pairs[first ..] of one leaf
 struct RayBody { int32_t tiles, overflow; };
 struct TreeNode;
-// nodes == NULL: a tile's ex_off is the leaf's index, ex_len 0.  list_stride: entries reserved per block in `lists`.
-int tuch_tiles_fill_launch(const int32_t* leaf_cnt, const TreeNode* nodes, const int32_t* leaf_nodes, int num_leaves, int cap,
-                           int max_tiles, int fallback_tiles, RayTile* tiles, RayBody* body, const RayEntry* lists,
-                           const int32_t* list_len, int blocks, int list_stride, int32_t* leaf_fill, int32_t* pairs, int B,
-                           hipStream_t s);
 // computes the layout of tuch_ray_exterior_verts (Q = 0) / tuch_ray_exterior_points: for a recording tuch_ws_scope
 void tuch_ray_layout_touch(const tuch_contact_model* m, int B, int Q);
 size_t tuch_ray_workspace_bytes(const tuch_contact_model* m, int B, int Q);

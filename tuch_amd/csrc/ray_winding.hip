@@ -745,8 +745,8 @@ __global__ __launch_bounds__(kTilesFillBlock) void ray_tiles_fill_kernel(
     // and a short loop) -- written by the body's first workgroup alone, seven leaves per lane one after the other, it was
     // the longest chain in the launch
     for (int l = (int)blockIdx.y + (int)gridDim.y * lane; l < num_leaves; l += (int)gridDim.y * 64) {
-        int ex_off = l, ex_len = 0;                  // (nodes == NULL: the leaf's index itself, v2v.hip)
-        if (nodes) { const TreeNode nd = nodes[leaf_nodes[l]]; ex_off = nd.ex_off; ex_len = nd.ex_len; }
+        const TreeNode nd = nodes[leaf_nodes[l]];
+        const int ex_off = nd.ex_off, ex_len = nd.ex_len;
         const int c = cnt[l], off = off_s[l];
         RayTile* out = tiles + (size_t)b * max_tiles + tile_s[l];
         for (int k = 0; k < c; k += 64) *out++ = RayTile{ex_off, ex_len, off + k, min(64, c - k)};
@@ -1663,22 +1663,6 @@ int tuch_ray_segment_flags_one(const tuch_contact_model* m, const float* verts, 
                        (const int32_t*)m->seg_cap_ent, (const int32_t*)m->seg_link_off, (const int32_t*)m->seg_link, leaf_counts,
                        (const int32_t*)m->seg_vpos, 2 * m->tree_qblocks * kRayQueries, m->V, thresh);
     return tuch_check_launch("tuch_ray_segment_flags_one");
-}
-
-int tuch_tiles_fill_launch(const int32_t* leaf_cnt, const TreeNode* nodes, const int32_t* leaf_nodes, int num_leaves, int cap,
-                           int max_tiles, int fallback_tiles, RayTile* tiles, RayBody* body, const RayEntry* lists,
-                           const int32_t* list_len, int blocks, int list_stride, int32_t* leaf_fill, int32_t* pairs, int B,
-                           hipStream_t s)
-{
-    const size_t lds = (2 * (size_t)num_leaves + blocks + 1) * sizeof(int32_t);
-    if (blocks > kFillMaxBlocks || lds > 48u * 1024) {
-        tuch_set_error("tuch_tiles_fill_launch: %d blocks / %d leaves do not fit the kernel's LDS tables", blocks, num_leaves);
-        return TUCH_ERR_ARG;
-    }
-    hipLaunchKernelGGL(ray_tiles_fill_kernel, dim3(B, kFillSplit), dim3(kTilesFillBlock), lds, s, leaf_cnt, nodes, leaf_nodes,
-                       num_leaves, cap, max_tiles, fallback_tiles, tiles, body, lists, list_len, blocks, leaf_fill, pairs,
-                       list_stride);
-    return tuch_check_launch("tuch_tiles_fill_launch");
 }
 
 bool tuch_ray_available(const tuch_contact_model* m)
