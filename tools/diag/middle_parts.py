@@ -41,3 +41,27 @@ for name, fn in cases.items():
 model.set_option('overlap', 0)
 res['one after the other'] = timed(bench.capture(lambda: model.exterior_and_partner(verts, iterative=True), 3))
 print('%-62s %7.1f us' % ('one after the other', res['one after the other']))
+
+# what each side costs beside the other: the pair with one side on fewer bodies
+model.set_option('overlap', 1)
+from tuch_amd.ops import _side_stream
+
+
+def pair(bi, bs):
+    vi, vs = verts[:bi].contiguous(), verts[:bs].contiguous()
+
+    def fn():
+        cur = torch.cuda.current_stream(dev)
+        side = _side_stream(dev)
+        side.wait_stream(cur)
+        ext = model.exterior_flags(vi) if bi else None
+        with torch.cuda.stream(side):
+            out = model.v2v_min(vs, leave_room=True, iterative=True) if bs else None
+        cur.wait_stream(side)
+        return ext, out
+    return timed(bench.capture(fn, 3))
+
+
+print('side by side, bodies (inside test, search):')
+for bi, bs in ((B, B), (B, B // 2), (B, 0), (B // 2, B), (0, B), (B // 2, B // 2)):
+    print('   (%3d, %3d) %7.1f us' % (bi, bs, pair(bi, bs)), flush=True)
