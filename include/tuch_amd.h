@@ -118,6 +118,14 @@ int tuch_contact_terms_bwd_fixed(const float* points, const int32_t* partner, co
                                  const float* grad_scale, int B, int N, int mode, float euclthres,
                                  void* grad_fixed_zeroed, float* grad_points, void* stream);
 
+/* RegressorLoss.contact_loss's last line, loss.py:317 (`loss_contact.sum() / valid_fit.sum()` over the per-body terms of
+ * :272 / :315): terms [B,K] summed over the bodies with valid[b] != 0 and divided by their number, in one launch.
+ * out [2] = (mean, 1 / number of valid bodies); no valid body: 0 / 0 = NaN, as the reference's division.
+ * Backward: grad_terms [B,K] = upstream[0] * (valid[b] ? out[1] : 0) -- what tuch_contact_terms_bwd takes as grad_scale. */
+int tuch_valid_mean_fwd(const float* terms, const uint8_t* valid, int B, int K, float* out, void* stream);
+int tuch_valid_mean_bwd(const float* upstream, const float* fwd_out, const uint8_t* valid, int B, int K,
+                        float* grad_terms, void* stream);
+
 /* Reprojection + pose-prior part of the SMPLify-DC objective, losses.py:56-64 (projection
  * geometry.py:83-111 with identity rotation, gmof losses.py:25-32, max-mixture prior
  * prior.py:117-132).  out [B,2] = (sum_j conf^2 gmof, prior_scale * prior); gradients for a unit

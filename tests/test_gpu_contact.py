@@ -1355,3 +1355,30 @@ def test_hd_branch_with_a_general_sparse_regressor():
     got = v.grad.cpu().numpy()
     for b in range(batch):
         grad_close(got[b], grads[b], 2e-5, 'general sparse HD regressor, body %d' % b, quantum=True)
+
+
+def test_valid_mean_is_the_reference_division_in_one_launch():
+    """loss.py:317: ``loss_contact.sum() / valid_fit.sum()`` over the per-body terms (ops.valid_mean: one launch forward, one
+    backward): value within float32 summation order of torch's, gradient valid / n exactly, no valid body -> NaN."""
+    from tuch_amd import ops
+    DEV = dev()
+    g = torch.Generator(device='cpu').manual_seed(4)
+    for b, k in ((1, 1), (7, 2), (64, 2), (300, 1), (1000, 2)):
+        terms = torch.rand(b, k, generator=g).to(DEV).requires_grad_(True)
+        valid = (torch.rand(b, generator=g) < 0.7).to(DEV)
+        valid[0] = True
+        garbage = terms.detach().clone()
+        garbage[~valid] = float('nan')                       # the other bodies' terms are never read into the sum
+        garbage.requires_grad_(True)
+        got = ops.valid_mean(garbage, ops.as_u8(valid))
+        want = torch.where(valid[:, None], terms, torch.zeros_like(terms)).sum() / valid.sum()
+        assert abs(float(got.detach()) - float(want.detach())) <= 1e-6 * abs(float(want.detach()))
+        (3.0 * got).backward()
+        n = int(valid.sum())
+        expect = (valid[:, None].float() * (3.0 / n)).expand(b, k)
+        assert torch.allclose(garbage.grad, expect, rtol=1e-6, atol=0)
+        assert float(garbage.grad[~valid].abs().sum()) == 0.0
+    none = ops.valid_mean(torch.ones(5, 2, device=DEV), ops.as_u8(torch.zeros(5, dtype=torch.bool, device=DEV)))
+    assert torch.isnan(none)
+    m = torch.tensor([True, False, True], device=DEV)
+    assert ops.as_u8(m).data_ptr() == m.data_ptr() and ops.as_u8(m).dtype == torch.uint8

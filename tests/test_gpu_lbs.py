@@ -154,3 +154,50 @@ def test_sparse_skinning_is_the_dense_sum_bit_for_bit_and_every_batch_form_agree
     t64 = lambda a: torch.tensor(a, dtype=torch.float64)
     v64, _ = ol.smpl_forward(ol.model_tensors(fat, torch.float64), t64(be[:n]), t64(bp[:n]), t64(go[:n]))
     assert_close(out.vertices.cpu().numpy(), v64.numpy(), 1e-4, 5e-6, 'dense-weight body vs fp64')
+
+
+def test_train_style_slices_of_one_rotation_tensor_take_one_gradient(bodies):
+    """train_module.py:202-204 passes pred_rotmat[:, 1:] and pred_rotmat[:, 0].unsqueeze(1): two views of ONE [B,24,3,3]
+    tensor.  The module hands the kernels that tensor's rows and returns ONE gradient for it (autograd would zero-fill and
+    copy two slice gradients and add them): same bits as two separate tensors, and anything that is not exactly
+    (orientation first, pose behind it, nothing else) in one contiguous base keeps the two-tensor path."""
+    from tuch_amd import lbs
+    body = bodies['tiny']
+    smpl = _smpl(body)
+    bp, go, be = [torch.tensor(a, device=DEV) for a in random_poses(6, 23)]
+    rot = ol.rodrigues(torch.cat([go, bp], 1).reshape(-1, 3).cpu()).reshape(6, 24, 3, 3).to(DEV)
+    w = torch.linspace(0.5, 1.5, 6 * body.num_verts * 3, device=DEV).reshape(6, body.num_verts, 3)
+
+    def run(make):
+        leaf = rot.clone().requires_grad_(True)
+        g, p = make(leaf)
+        out = smpl(betas=be, body_pose=p, global_orient=g, pose2rot=False)
+        ((out.vertices * w).sum() + out.joints.sum()).backward()
+        return out.vertices.detach(), out.joints.detach(), leaf.grad
+    ref = run(lambda t: (t[:, :1].clone(), t[:, 1:].clone()))                       # two tensors of their own
+    shared = lambda t: lbs._shared_rows(*t, 9) is not None
+    leaf = rot.clone().requires_grad_(True)
+    forms = {'select + unsqueeze (the reference)': lambda t: (t[:, 0].unsqueeze(1), t[:, 1:]),
+             'two slices': lambda t: (t[:, :1], t[:, 1:]),
+             'rows of the flat tensor': lambda t: (t.view(6, 216)[:, :9], t.view(6, 216)[:, 9:])}
+    for name, make in forms.items():
+        assert shared(make(leaf)), name
+        got = run(make)
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b), name
+    # not the whole base / the wrong order / different bases / a copy: the two-tensor path, same numbers
+    wide = torch.cat([rot.reshape(6, 216), torch.zeros(6, 9, device=DEV)], 1).requires_grad_(True)
+    assert not shared((wide[:, :9], wide[:, 9:216]))
+    assert not shared((leaf[:, 1:2], leaf[:, 1:]))
+    assert not shared((rot.clone()[:, :1], leaf[:, 1:]))
+    assert not shared((leaf[:, :1].clone(), leaf[:, 1:]))
+    other = rot.clone().requires_grad_(True)
+    out = smpl(betas=be, body_pose=other[:, 1:], global_orient=leaf[:, :1], pose2rot=False)
+    ((out.vertices * w).sum() + out.joints.sum()).backward()
+    assert torch.equal(out.vertices.detach(), ref[0])
+    assert torch.equal(leaf.grad[:, :1], ref[2][:, :1]) and torch.equal(other.grad[:, 1:], ref[2][:, 1:])
+    assert float(leaf.grad[:, 1:].abs().max()) == 0.0 and float(other.grad[:, :1].abs().max()) == 0.0
+    # no gradient wanted: nothing changes
+    with torch.no_grad():
+        o2 = smpl(betas=be, body_pose=rot[:, 1:], global_orient=rot[:, :1], pose2rot=False)
+    assert torch.equal(o2.vertices, ref[0])

@@ -42,6 +42,8 @@ _SIGNATURES = {
                                        c_void_p, c_void_p]),
     'tuch_contact_terms_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                        c_void_p, c_void_p]),
+    'tuch_valid_mean_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'tuch_valid_mean_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'tuch_smpl_backward_split_adam': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
                                               c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

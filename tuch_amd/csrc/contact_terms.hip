@@ -563,6 +563,64 @@ extern "C" int tuch_smplify_stage2_fused(const float* points, const int32_t* par
     return tuch_check_launch("tuch_smplify_stage2_fused");
 }
 
+// loss.py:317 (and :272): the per-body terms summed over the VALID bodies and divided by their number, as one launch
+// (torch: a count, two sums, a division and their conversions -- seven small kernels forward, five backward in a chain
+// where every launch is 3 - 5 us).  out[0] = sum / n (0 / 0 = NaN like the reference's), out[1] = 1 / n.  One workgroup.
+__global__ __launch_bounds__(256) void valid_mean_fwd_kernel(const float* __restrict__ terms, const uint8_t* __restrict__ valid,
+                                                            int B, int K, float* __restrict__ out)
+{
+    __shared__ float s_sum[256];
+    __shared__ int s_cnt[256];
+    float sum = 0.0f;
+    int cnt = 0;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        if (valid[b]) {
+            ++cnt;
+            for (int k = 0; k < K; ++k) sum += terms[(size_t)b * K + k];
+        }
+    }
+    s_sum[threadIdx.x] = sum;
+    s_cnt[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {              // fixed order: reproducible
+        if ((int)threadIdx.x < d) { s_sum[threadIdx.x] += s_sum[threadIdx.x + d]; s_cnt[threadIdx.x] += s_cnt[threadIdx.x + d]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float n = (float)s_cnt[0];
+        out[0] = s_sum[0] / n;
+        out[1] = 1.0f / n;
+    }
+}
+
+// grad_terms[b][k] = upstream * (valid[b] ? 1 / n : 0)
+__global__ __launch_bounds__(256) void valid_mean_bwd_kernel(const float* __restrict__ upstream, const float* __restrict__ fwd_out,
+                                                            const uint8_t* __restrict__ valid, int B, int K,
+                                                            float* __restrict__ grad_terms)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * K) return;
+    grad_terms[i] = valid[i / K] ? upstream[0] * fwd_out[1] : 0.0f;
+}
+
+extern "C" int tuch_valid_mean_fwd(const float* terms, const uint8_t* valid, int B, int K, float* out, void* stream)
+{
+    TUCH_REQUIRE(terms && valid && out, "tuch_valid_mean_fwd: null pointer");
+    TUCH_REQUIRE(B > 0 && K > 0, "tuch_valid_mean_fwd: bad sizes");
+    hipLaunchKernelGGL(valid_mean_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, terms, valid, B, K, out);
+    return tuch_check_launch("tuch_valid_mean_fwd");
+}
+
+extern "C" int tuch_valid_mean_bwd(const float* upstream, const float* fwd_out, const uint8_t* valid, int B, int K,
+                                   float* grad_terms, void* stream)
+{
+    TUCH_REQUIRE(upstream && fwd_out && valid && grad_terms, "tuch_valid_mean_bwd: null pointer");
+    TUCH_REQUIRE(B > 0 && K > 0, "tuch_valid_mean_bwd: bad sizes");
+    hipLaunchKernelGGL(valid_mean_bwd_kernel, dim3(ceil_div(B * K, 256)), dim3(256), 0, (hipStream_t)stream, upstream, fwd_out,
+                       valid, B, K, grad_terms);
+    return tuch_check_launch("tuch_valid_mean_bwd");
+}
+
 extern "C" int tuch_contact_terms_fwd(const float* points, const int32_t* partner,
                                       const uint8_t* exterior, const uint8_t* body_valid, int B, int N,
                                       int mode, float euclthres, float* terms, void* stream)

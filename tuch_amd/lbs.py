@@ -56,10 +56,15 @@ class _SmplLBS(torch.autograd.Function):
     tensors go to the kernels as they are (no concatenated copy, and the gradient comes back as two tensors)."""
 
     @staticmethod
-    def forward(ctx, betas, global_orient, body_pose, dm: SmplDeviceModel, pose2rot: bool):
+    def forward(ctx, betas, global_orient, body_pose, dm: SmplDeviceModel, pose2rot: bool, full=None):
         L = _C.lib()
         w = 3 if pose2rot else 9
         be = betas.detach().to(torch.float32).contiguous()
+        # full: ONE float32 tensor [B, 24 w] that global_orient and body_pose are the row views [:, :w] and [:, w:] of
+        # (smpl_forward_split found them to be): the gradient then goes back to it as one tensor -- autograd does not
+        # have to zero-fill and copy two slice gradients and add them (five launches per step of a train.py-style loop,
+        # which passes pred_rotmat[:, 1:] and pred_rotmat[:, 0].unsqueeze(1), train_module.py:202-204)
+        ctx.full = full is not None
         go, bp = _pose_rows(global_orient, w), _pose_rows(body_pose, 23 * w)
         b = go.shape[0]
         if bp.shape[0] != b or be.shape[0] != b:
@@ -92,10 +97,19 @@ class _SmplLBS(torch.autograd.Function):
         gv = g_verts.to(torch.float32).contiguous() if g_verts is not None else None
         gj = g_joints.to(torch.float32).contiguous() if g_joints is not None else None
         g_betas = torch.empty(b, 10, dtype=torch.float32, device=go.device)
-        g_go = torch.empty(go.shape, dtype=torch.float32, device=go.device)
-        g_bp = torch.empty(bp.shape, dtype=torch.float32, device=go.device)
         nbytes = L.tuch_smpl_backward_workspace_bytes(ctx.dm._handle, b)
         ws2 = torch.empty(nbytes, dtype=torch.uint8, device=go.device)
+        if ctx.full:
+            # the kernel writes the two gradients with a row stride: one [B, 24 w] tensor takes both
+            g_full = torch.empty(b, 24 * w, dtype=torch.float32, device=go.device)
+            _C.check(L.tuch_smpl_backward_split_add(ctx.dm._handle, _C.row_ptr(go), go.stride(0), _C.row_ptr(bp), bp.stride(0),
+                                                    int(ctx.pose2rot), b, _C.ptr(ws), _C.ptr(gv), _C.ptr(gj),
+                                                    _C.ptr(g_betas), _C.row_ptr(g_full[:, :w]), 24 * w,
+                                                    _C.row_ptr(g_full[:, w:]), 24 * w, None, 23 * w,
+                                                    _C.ptr(ws2), nbytes, _C.stream()))
+            return g_betas, None, None, None, None, g_full
+        g_go = torch.empty(go.shape, dtype=torch.float32, device=go.device)
+        g_bp = torch.empty(bp.shape, dtype=torch.float32, device=go.device)
         tagged, ctx.pose_grad_extra = ctx.pose_grad_extra, None
         extra = None
         f = getattr(torch._C, '_current_graph_task_id', None)
@@ -131,12 +145,12 @@ class _SmplLBS(torch.autograd.Function):
                 float(group['lr']), float(group['betas'][0]), float(group['betas'][1]), float(group['eps']),
                 _C.ptr(ws2), nbytes, _C.stream()))
             adam._applied = True
-            return g_betas, g_go.view(ctx.shapes[0]), g_bp.view(ctx.shapes[1]), None, None
+            return g_betas, g_go.view(ctx.shapes[0]), g_bp.view(ctx.shapes[1]), None, None, None
         _C.check(L.tuch_smpl_backward_split_add(ctx.dm._handle, _C.row_ptr(go), go.stride(0), _C.row_ptr(bp), bp.stride(0),
                                                 int(ctx.pose2rot), b, _C.ptr(ws), _C.ptr(gv), _C.ptr(gj),
                                                 _C.ptr(g_betas), _C.ptr(g_go), w, _C.ptr(g_bp), 23 * w,
                                                 _C.ptr(extra), 23 * w, _C.ptr(ws2), nbytes, _C.stream()))
-        return g_betas, g_go.view(ctx.shapes[0]), g_bp.view(ctx.shapes[1]), None, None
+        return g_betas, g_go.view(ctx.shapes[0]), g_bp.view(ctx.shapes[1]), None, None, None
 
 
 def _device_model(smpl_module, device):
@@ -147,9 +161,38 @@ def _device_model(smpl_module, device):
     return dm
 
 
+def _shared_rows(global_orient, body_pose, w):
+    """The [B, 24 w] float32 tensor the two pose tensors are the row views [:, :w] / [:, w:] of, or None: both views of ONE
+    contiguous base holding exactly the B x 24 w values, the orientation first."""
+    base = getattr(global_orient, '_base', None)
+    if base is None or getattr(body_pose, '_base', None) is not base or base.dtype != torch.float32:
+        return None
+    if not base.is_contiguous() or base.dim() < 2 or global_orient.dim() < 2 or body_pose.dim() < 2:
+        return None
+    b = base.shape[0]
+    if base.numel() != b * 24 * w or global_orient.shape[0] != b or body_pose.shape[0] != b:
+        return None
+    if global_orient.numel() != b * w or body_pose.numel() != b * 23 * w:
+        return None
+    try:
+        go, bp = global_orient.view(b, w), body_pose.view(b, 23 * w)       # (raises if not expressible as row views)
+    except RuntimeError:
+        return None
+    if go.stride() != (24 * w, 1) or bp.stride() != (24 * w, 1):
+        return None
+    if go.storage_offset() != base.storage_offset() or bp.storage_offset() != base.storage_offset() + w:
+        return None
+    return base.view(b, 24 * w)
+
+
 def smpl_forward_split(smpl_module, betas, global_orient, body_pose, pose2rot=True):
     """(vertices [B,V,3], joints [B,49,3]) from the two pose tensors of SMPL.forward (tuch/models/smpl.py:44-47)."""
-    return _SmplLBS.apply(betas, global_orient, body_pose, _device_model(smpl_module, betas.device), pose2rot)
+    dm = _device_model(smpl_module, betas.device)
+    if torch.is_grad_enabled() and (global_orient.requires_grad or body_pose.requires_grad):
+        full = _shared_rows(global_orient, body_pose, 3 if pose2rot else 9)
+        if full is not None:
+            return _SmplLBS.apply(betas, global_orient.detach(), body_pose.detach(), dm, pose2rot, full)
+    return _SmplLBS.apply(betas, global_orient, body_pose, dm, pose2rot)
 
 
 def smpl_forward(smpl_module, betas, full_pose, pose2rot=True):

@@ -185,7 +185,7 @@ class _ContactTerms(torch.autograd.Function):
     """terms[b] = (interior sum, exterior sum); gradient flows to the points only."""
 
     @staticmethod
-    def forward(ctx, points, partner, exterior, valid, mode, euclthres):
+    def forward(ctx, points, partner, exterior, valid, mode, euclthres, grad_masked=False):
         pts = _f32(points)
         b, n, _ = pts.shape
         terms = torch.empty(b, 2, dtype=torch.float32, device=pts.device)
@@ -193,6 +193,7 @@ class _ContactTerms(torch.autograd.Function):
                                                  b, n, int(mode), float(euclthres), _C.ptr(terms), _C.stream()))
         ctx.save_for_backward(pts, partner, exterior, valid)
         ctx.mode, ctx.euclthres = int(mode), float(euclthres)
+        ctx.grad_masked = bool(grad_masked)     # the caller reduces the terms with valid_mean: its gradient is 0 for the others
         return terms
 
     @staticmethod
@@ -200,7 +201,7 @@ class _ContactTerms(torch.autograd.Function):
         pts, partner, exterior, valid = ctx.saved_tensors
         b, n, _ = pts.shape
         g = grad_terms.to(torch.float32)
-        if valid is not None:
+        if valid is not None and not ctx.grad_masked:
             g = g * valid.to(g.dtype)[:, None]
         g = g.contiguous()   # [B,2]: upstream gradient of the interior and of the exterior sum
         if deterministic():
@@ -209,11 +210,11 @@ class _ContactTerms(torch.autograd.Function):
             grad = torch.empty_like(pts)
             _C.check(_C.lib().tuch_contact_terms_bwd_fixed(_C.ptr(pts), _C.ptr(partner), _C.ptr(exterior), _C.ptr(g), b, n,
                                                            ctx.mode, ctx.euclthres, _C.ptr(fixed), _C.ptr(grad), _C.stream()))
-            return grad, None, None, None, None, None
+            return grad, None, None, None, None, None, None
         grad = torch.zeros_like(pts)
         _C.check(_C.lib().tuch_contact_terms_bwd(_C.ptr(pts), _C.ptr(partner), _C.ptr(exterior), _C.ptr(g),
                                                  b, n, ctx.mode, ctx.euclthres, _C.ptr(grad), _C.stream()))
-        return grad, None, None, None, None, None
+        return grad, None, None, None, None, None, None
 
 
 class _HDPoints(torch.autograd.Function):
@@ -281,6 +282,51 @@ def contact_terms(points, partner_i32, exterior_u8, valid_u8, mode, euclthres):
     """Sum of pull/push terms per body: [B] = interior + exterior (differentiable wrt points)."""
     terms = _ContactTerms.apply(points, partner_i32, exterior_u8, valid_u8, mode, euclthres)
     return terms.sum(dim=1), terms
+
+
+class _ValidMean(torch.autograd.Function):
+    """sum of terms [B,K] over the valid bodies / their number (loss.py:317), one launch each way."""
+
+    @staticmethod
+    def forward(ctx, terms, valid_u8):
+        t = _f32(terms)
+        b = t.shape[0]
+        k = t.numel() // b
+        out = torch.empty(2, dtype=torch.float32, device=t.device)
+        _C.check(_C.lib().tuch_valid_mean_fwd(_C.ptr(t), _C.ptr(valid_u8), b, k, _C.ptr(out), _C.stream()))
+        ctx.save_for_backward(out, valid_u8)
+        ctx.shape = tuple(terms.shape)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        out, valid_u8 = ctx.saved_tensors
+        b = ctx.shape[0]
+        k = int(torch.Size(ctx.shape).numel()) // b
+        grad = torch.empty(ctx.shape, dtype=torch.float32, device=out.device)
+        up = g.to(torch.float32).reshape(1).contiguous()
+        _C.check(_C.lib().tuch_valid_mean_bwd(_C.ptr(up), _C.ptr(out), _C.ptr(valid_u8), b, k, _C.ptr(grad), _C.stream()))
+        return grad, None
+
+
+def as_u8(mask):
+    """A [B] boolean / byte mask as uint8 without a copy where the bytes are already there."""
+    if mask.dtype == torch.bool and mask.is_contiguous():
+        return mask.view(torch.uint8)
+    return mask.to(torch.uint8).contiguous()
+
+
+def valid_mean(terms, valid_u8):
+    """Scalar: terms [B,...] summed over the bodies with valid != 0, divided by their number (NaN when there is none, like
+    the reference's ``loss.sum() / valid_fit.sum()``, loss.py:317).  The gradient of the other bodies' terms is 0."""
+    return _ValidMean.apply(terms, valid_u8)
+
+
+def contact_terms_mean(points, partner_i32, exterior_u8, valid_u8, mode, euclthres):
+    """``contact_terms(...)[0].sum() / valid.sum()`` of RegressorLoss.contact_loss (loss.py:259-272, 317) in two launches
+    forward and two backward."""
+    terms = _ContactTerms.apply(points, partner_i32, exterior_u8, valid_u8, mode, euclthres, True)
+    return valid_mean(terms, valid_u8)
 
 
 class _SmallTerms(torch.autograd.Function):

@@ -84,16 +84,23 @@ class RegressorLoss(nn.Module):
         (use_hd=False) or on the HD points resampled around contact / interior (use_hd=True)."""
         model = self._model
         valid = valid_fit.bool()
-        valid_u8 = valid.to(torch.uint8).contiguous()
+        valid_u8 = ops.as_u8(valid)
         exterior, min_d2, partner, _ = model.exterior_and_partner(pred_vertices, apply_segments=True)   # :264-266
-        # loss.py:317: mean over the valid bodies -- of this process, or (global_mean) of all ranks
-        n_valid = tdist.global_count(valid.sum()) if self.global_mean else valid.sum().to(torch.float32)
+        # loss.py:317: mean over the valid bodies -- of this process (one launch: ops.valid_mean), or (global_mean) of all
+        # ranks (the count is summed over the process group: torch)
+        fused = not self.global_mean and pred_vertices.is_cuda
+        if not fused:
+            n_valid = tdist.global_count(valid.sum()) if self.global_mean else valid.sum().to(torch.float32)
         if not self.use_hd:
+            if fused:
+                return ops.contact_terms_mean(pred_vertices, partner, exterior, valid_u8, ops.MODE_TRAIN, self.euclthres)
             per_body, _ = ops.contact_terms(pred_vertices, partner, exterior, valid_u8, ops.MODE_TRAIN,
                                             self.euclthres)
             return per_body.sum() / n_valid
         # HD branch, loss.py:274-315: one fixed sequence of kernels, no host synchronisation (hipGraph-capturable)
         terms = self._hd.contact_terms(pred_vertices, exterior, min_d2, partner, valid_u8, self.euclthres)
+        if fused:
+            return ops.valid_mean(terms, valid_u8)
         return terms.sum() / n_valid
 
     # ---------------------------------------------------------------------------- SPIN terms
