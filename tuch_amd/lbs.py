@@ -65,6 +65,7 @@ class _SmplLBS(torch.autograd.Function):
         # have to zero-fill and copy two slice gradients and add them (five launches per step of a train.py-style loop,
         # which passes pred_rotmat[:, 1:] and pred_rotmat[:, 0].unsqueeze(1), train_module.py:202-204)
         ctx.full = full is not None
+        ctx.set_materialize_grads(False)        # an output nobody differentiates arrives as None, not as a zero-filled tensor
         go, bp = _pose_rows(global_orient, w), _pose_rows(body_pose, 23 * w)
         b = go.shape[0]
         if bp.shape[0] != b or be.shape[0] != b:
@@ -94,6 +95,8 @@ class _SmplLBS(torch.autograd.Function):
         go, bp, ws = ctx.saved_tensors
         b = go.shape[0]
         w = go.shape[1]
+        if g_verts is None and g_joints is None:
+            return None, None, None, None, None, None
         gv = g_verts.to(torch.float32).contiguous() if g_verts is not None else None
         gj = g_joints.to(torch.float32).contiguous() if g_joints is not None else None
         g_betas = torch.empty(b, 10, dtype=torch.float32, device=go.device)
