@@ -43,7 +43,7 @@ torch.cuda.synchronize()
 print('search alone: %.1f us per call' % (e0.elapsed_time(e1) / 20 * 1e3))
 L = _C.lib()
 L.tuch_debug_scan_clocks.argtypes = [ctypes.c_void_p]
-out = np.zeros((1 << 17, 4), np.uint64)
+out = np.zeros((1 << 17, 8), np.uint64)
 L.tuch_debug_scan_clocks(out.ctypes.data_as(ctypes.c_void_p))
 c = out[out[:, 1] > 0]
 # the last launch only: stamps within 1 ms of the latest end
@@ -60,6 +60,12 @@ simd = (h >> 4) & 3; cu = (h >> 8) & 15; sh = (h >> 12) & 1; se = (h >> 13) & 7
 by = (c[:, 3] >> np.uint64(32)).astype(np.int64)
 cands = ((c[:, 3] >> np.uint64(8)) & np.uint64(0xffffff)).astype(np.int64)
 trips = (c[:, 3] & np.uint64(0xff)).astype(np.int64)
+ph = c[:, 4:8].astype(np.float64)
+tot = ph[:, 0].sum()
+print('a wavefront\'s life (s_memtime ticks): flushes of queued pairs %.1f %%, rows walked on the spot %.1f %%, leaf-per-lane tests '
+      'with their loads %.1f %%, the rest (prologue, per-column tests of the candidates, queueing) %.1f %%'
+      % (100 * ph[:, 1].sum() / tot, 100 * ph[:, 2].sum() / tot, 100 * ph[:, 3].sum() / tot,
+         100 * (tot - ph[:, 1:].sum()) / tot))
 print('%d wavefronts; kernel span %.1f us (first start -> last end); starts up to %.1f us' % (len(c), e.max(), s.max()))
 print('wavefront lifetime: mean %.1f median %.1f p90 %.1f max %.1f us; sum %.0f us = %.2f wavefronts resident on average per SIMD (1024 SIMDs)'
       % (dur.mean(), np.median(dur), np.percentile(dur, 90), dur.max(), dur.sum(), dur.sum() / e.max() / 1024))

@@ -401,10 +401,12 @@ extern "C" int tuch_debug_scan_counts(unsigned long long* out, int reset)
 // diagnostic build only (tools/diag/scan_clocks.py): per wavefront of the scan its start and end (s_memrealtime, 100 MHz),
 // its place on the chip (HW_ID) and the trips / candidates it went through
 constexpr int kScanClockSlots = 1 << 17;
-__device__ unsigned long long g_scan_clocks[kScanClockSlots][4];
+// [4..7]: s_memtime ticks of the whole wavefront, in flushes, in rows walked on the spot, in the leaf-per-lane tests (with their loads)
+__device__ unsigned long long g_scan_clocks[kScanClockSlots][8];
+#define SCAN_TICK() __builtin_amdgcn_s_memtime()
 extern "C" int tuch_debug_scan_clocks(unsigned long long* out)
 {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scan_clocks), sizeof(unsigned long long) * 4 * kScanClockSlots) == hipSuccess ? TUCH_OK : TUCH_ERR_HIP;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scan_clocks), sizeof(unsigned long long) * 8 * kScanClockSlots) == hipSuccess ? TUCH_OK : TUCH_ERR_HIP;
 }
 #endif
 
@@ -1001,6 +1003,8 @@ __device__ __forceinline__ void v2v_scan_body(
 #ifdef TUCH_SCAN_CLOCKS
     const unsigned long long clk0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long clk_cands = 0;
+    const unsigned long long tick0 = SCAN_TICK();
+    unsigned long long t_flush = 0, t_rows = 0, t_first = 0;
     const int clk_slot = (blockIdx.y * gridDim.x + blockIdx.x) & (kScanClockSlots - 1);
 #endif
     const int pair = __builtin_amdgcn_readfirstlane(order[blockIdx.y >> 1]);      // launch order over 128-blocks
@@ -1045,6 +1049,9 @@ __device__ __forceinline__ void v2v_scan_body(
 #ifdef TUCH_SCAN_COUNTS
         if (lane == 0) { atomicAdd(&g_scan_counts[16], 1ull); atomicAdd(&g_scan_counts[17], (unsigned long long)n); }
 #endif
+#ifdef TUCH_SCAN_CLOCKS
+        const unsigned long long tf0 = SCAN_TICK();
+#endif
         s_key[lane] = v2v_key(c.best, c.arg);             // (what the rows walked on the spot have found since)
         // (a one-wavefront workgroup: no s_barrier is emitted, but the fences are needed -- without them lanes read the
         // queue / the keys before the other lanes' writes: 157 of 4806 minima wrong on the 1602-vertex fixture)
@@ -1054,6 +1061,10 @@ __device__ __forceinline__ void v2v_scan_body(
         const unsigned long long k = s_key[lane];
         c.best = __uint_as_float((uint32_t)(k >> 32));
         c.arg = (int)(uint32_t)k;
+#ifdef TUCH_SCAN_CLOCKS
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
+        t_flush += SCAN_TICK() - tf0;
+#endif
     };
     const float* cbx = colbox + ((size_t)b * (Vp / kTreeCols) + qb) * 8;
     const float clx = cbx[0], cly = cbx[1], clz = cbx[2], chx = cbx[4], chy = cbx[5], chz = cbx[6];
@@ -1066,6 +1077,9 @@ __device__ __forceinline__ void v2v_scan_body(
         const int li = base + lane;
         bool cand = false;
         SCAN_COUNT(1);
+#ifdef TUCH_SCAN_CLOCKS
+        const unsigned long long tl0 = SCAN_TICK();
+#endif
         float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;   // box; lo.w = first group, hi.w = row range of the leaf
         uint64_t lanes_of = 0;
         if (li < count) {
@@ -1107,6 +1121,7 @@ __device__ __forceinline__ void v2v_scan_body(
         unsigned long long todo = __builtin_amdgcn_ballot_w64(cand);
 #ifdef TUCH_SCAN_CLOCKS
         clk_cands += __builtin_popcountll(todo);
+        t_first += SCAN_TICK() - tl0;
 #endif
         if (todo == 0) continue;
         leaf_lo[lane] = lo;                      // one wavefront per workgroup: LDS operations of a wavefront stay in order
@@ -1150,8 +1165,14 @@ __device__ __forceinline__ void v2v_scan_body(
 #endif
                     const int leaf = __builtin_amdgcn_readfirstlane(__float_as_int(bhi.w));
                     const int g0 = __builtin_amdgcn_readfirstlane(__float_as_int(blo.w));
+#ifdef TUCH_SCAN_CLOCKS
+                    const unsigned long long tr0 = SCAN_TICK();
+#endif
                     v2v_rows_packed(c, pg + (size_t)g0 * 12, mg + (size_t)g0 * 4, leaf & 0xfffff, ((leaf >> 20) + 3) >> 2, reach);
                     best_s = c.best * kBoundSlack;
+#ifdef TUCH_SCAN_CLOCKS
+                    t_rows += SCAN_TICK() - tr0;
+#endif
                 }
             }
         }
@@ -1171,6 +1192,10 @@ __device__ __forceinline__ void v2v_scan_body(
         g_scan_clocks[clk_slot][1] = __builtin_amdgcn_s_memrealtime();
         g_scan_clocks[clk_slot][2] = ((unsigned long long)xcc << 32) | hw;
         g_scan_clocks[clk_slot][3] = ((unsigned long long)blockIdx.y << 32) | (clk_cands << 8) | (unsigned)((count + 63) / 64);
+        g_scan_clocks[clk_slot][4] = SCAN_TICK() - tick0;
+        g_scan_clocks[clk_slot][5] = t_flush;
+        g_scan_clocks[clk_slot][6] = t_rows;
+        g_scan_clocks[clk_slot][7] = t_first;
     }
 #endif
 }
