@@ -949,8 +949,10 @@ __device__ __forceinline__ void v2v_flush_pairs(int count, const uint2* s_q, con
     const float* pl = pg + (size_t)g0 * 12;
     // NOT-admissible bits, four rows per trip: a row's distance becomes a quiet NaN where its bit is set (two instructions:
     // bit -> all ones, AND-OR), and v_min3 / v_min skip NaN operands.  Lanes whose leaf has no group left repeat their last
-    // one with every row masked (no branch around the loads); the NEXT trip's rows are requested before this trip's
-    // arithmetic (the loop was a chain of gmax dependent memory latencies).
+    // one with every row masked (no branch around the loads).  The next trip's rows are NOT requested ahead (they were,
+    // for a while): the twelve registers that took put the kernel at 74 -- six wavefronts per SIMD; at 62 there are eight,
+    // and the search's time is its wavefronts' chains of dependent steps, not its instruction count (search alone at batch
+    // 64: 122 -> 112 us)
     uint32_t nam = ~(uint32_t)am, nam_hi = ~(uint32_t)(am >> 32);
     auto maskd = [&](float d, uint32_t word, int k) {
         const int x = __builtin_amdgcn_sbfe(word, k, 1);                  // -1 where the row is not admissible
@@ -958,13 +960,12 @@ __device__ __forceinline__ void v2v_flush_pairs(int count, const uint2* s_q, con
         asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(0x7FC00000u), "v"(__float_as_uint(d)));
         return __uint_as_float(r);
     };
-    f32x4 x = *reinterpret_cast<const f32x4*>(pl), y = *reinterpret_cast<const f32x4*>(pl + 4), z = *reinterpret_cast<const f32x4*>(pl + 8);
     for (int g = 0; g < gmax; ++g) {
         if (g == 8) nam = nam_hi;
         const bool on = g < ngroups;
+        const f32x4 x = *reinterpret_cast<const f32x4*>(pl), y = *reinterpret_cast<const f32x4*>(pl + 4),
+                    z = *reinterpret_cast<const f32x4*>(pl + 8);
         if (g + 1 < ngroups) pl += 12;
-        const f32x4 nx = *reinterpret_cast<const f32x4*>(pl), ny = *reinterpret_cast<const f32x4*>(pl + 4),
-                    nz = *reinterpret_cast<const f32x4*>(pl + 8);
         const v2f dx0 = px - (v2f){x[0], x[1]}, dy0 = py - (v2f){y[0], y[1]}, dz0 = pz - (v2f){z[0], z[1]};
         const v2f dx1 = px - (v2f){x[2], x[3]}, dy1 = py - (v2f){y[2], y[3]}, dz1 = pz - (v2f){z[2], z[3]};
         const v2f d01 = fma2(dz0, dz0, fma2(dy0, dy0, dx0 * dx0)), d23 = fma2(dz1, dz1, fma2(dy1, dy1, dx1 * dx1));
@@ -979,7 +980,6 @@ __device__ __forceinline__ void v2v_flush_pairs(int count, const uint2* s_q, con
             if (m < best || (m == best && m < inf && j < arg)) { best = m; arg = j; }
         }
         nam >>= 4;
-        x = nx; y = ny; z = nz;
     }
     const unsigned long long k1 = v2v_key(best, arg);
     if (active && k1 < key0) atomicMin(&s_key[col], k1);
