@@ -43,3 +43,14 @@ if worked.any():
         print('%-16s median %.2f, latest %.2f us after the first start; phase itself median %.2f, longest %.2f us' %
               (name, np.median(w[:, i] - t0) / 100.0, (w[:, i].max() - t0) / 100.0,
                np.median(w[:, i] - w[:, i - 1]) / 100.0, (w[:, i] - w[:, i - 1]).max() / 100.0))
+# the blocks that end last: when they started, their phases, their z
+order = np.argsort(-c[:nb, 4])[:12]
+print('blocks that end last: (index, segment, body, z) start | compaction | caps | entries | end  [us after the first start; phase lengths]')
+for i in order:
+    r = c[i]
+    if r[4] == 0:
+        continue
+    sgn = 6
+    print('  %5d (seg %d, body %2d, z %d)  start %.1f | %.1f | %.1f | %.1f | %.1f   end %.1f' % (
+        i, i % sgn, (i // sgn) % B, i // (sgn * B), (r[0] - t0) / 100.0, (r[1] - r[0]) / 100.0, (r[2] - r[1]) / 100.0,
+        (r[3] - r[2]) / 100.0, (r[4] - r[3]) / 100.0, (r[4] - t0) / 100.0))
