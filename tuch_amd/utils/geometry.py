@@ -62,6 +62,24 @@ def estimate_translation(S, joints_2d, focal_length=5000., img_size=224., has_2d
     return out
 
 
+def estimate_translation_np(S, joints_2d, joints_conf, focal_length=5000, img_size=224):
+    """One sample on the host, numpy in / numpy out (reference: geometry.py:114-154; only its own
+    estimate_translation calls it, kept for scripts that import the name).  Normal equations of
+    sqrt(conf) * (f X + (c - u) t_z ... ) in closed form: rows (f, 0, c-u | (u-c) Z - f X) and the same for v."""
+    import numpy as np
+    S = np.asarray(S, dtype=np.float64)
+    uv = np.asarray(joints_2d, dtype=np.float64)[:, :2] - img_size / 2.
+    w = np.sqrt(np.asarray(joints_conf, dtype=np.float64))
+    n = S.shape[0]
+    Q = np.zeros((n, 2, 3))
+    Q[:, 0, 0] = Q[:, 1, 1] = focal_length
+    Q[:, :, 2] = -uv
+    c = uv * S[:, 2:3] - focal_length * S[:, :2]
+    Q = (Q * w[:, None, None]).reshape(2 * n, 3)
+    c = (c * w[:, None]).reshape(2 * n)
+    return np.linalg.solve(Q.T @ Q, Q.T @ c)
+
+
 def rotation_matrix_to_angle_axis(rotation_matrix):
     """Rotation matrices [N,3,4] (homogeneous column appended, as the reference's callers do,
     train_module.py:208-211) or [N,3,3] -> angle-axis [N,3]; the torchgeometry 0.1.2 function the
