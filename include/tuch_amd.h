@@ -38,6 +38,14 @@ int tuch_abi_version(void);
 int tuch_batch_pairwise_dist(const float* x, const float* y, int B, int Nx, int Ny, int squared,
                              float* P, void* stream);
 
+/* Adjoint of batch_pairwise_dist for callers that differentiate through the matrix (the reference does:
+ * tuch/smplify/losses.py:76-78 -> 115-116, tuch/eft/loss.py:142; torch autograd through the three bmm of
+ * contact.py:27-29).  grad_P [B,Nx,Ny] -> grad_x [B,Nx,3] and/or grad_y [B,Ny,3] (either may be NULL):
+ * grad_x_i = 2 sum_j g_ij (x_i - y_j), grad_y_j = 2 sum_i g_ij (y_j - x_i); !squared: g / (2 sqrt(P)) first.
+ * Fixed summation order (no atomics). */
+int tuch_batch_pairwise_dist_bwd(const float* x, const float* y, const float* grad_P, int B, int Nx, int Ny,
+                                 int squared, float* grad_x, float* grad_y, void* stream);
+
 /* solid_angles(points, triangles, thresh), contact.py:49-109.
  * points [B,Q,3], triangles [B,F,3,3] -> out [B,Q,F] = 2*atan2(num, den). */
 int tuch_solid_angles(const float* points, const float* triangles, int B, int Q, int F, float* out,

@@ -78,6 +78,18 @@ def pairwise_sq(x: np.ndarray, y: np.ndarray) -> np.ndarray:
     return out
 
 
+def pairwise_adjoint(x: np.ndarray, y: np.ndarray, g: np.ndarray, squared: bool = True):
+    """What torch autograd returns through tuch/utils/contact.py:23-47 for one batch element: P = rx + ry - 2 x y^T with
+    rx, ry the diagonals of x x^T and y y^T (:27-43), so dL/dx_i = 2 sum_j g_ij (x_i - y_j), dL/dy_j = 2 sum_i g_ij
+    (y_j - x_i); sqrt (:45) contributes g / (2 sqrt(P)).  float64 accumulation, float32 result."""
+    x64, y64, g64 = np.asarray(x, np.float64), np.asarray(y, np.float64), np.asarray(g, np.float64)
+    if not squared:
+        g64 = g64 / (2.0 * np.sqrt(pairwise_sq(x, y).astype(np.float64)))
+    gx = 2.0 * (x64 * g64.sum(1)[:, None] - g64 @ y64)
+    gy = 2.0 * (y64 * g64.sum(0)[:, None] - g64.T @ x64)
+    return gx.astype(np.float32), gy.astype(np.float32)
+
+
 def v2v_min_masked(verts: np.ndarray, geomask: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
     """tuch/smplify/losses.py:92-93, tuch/train/loss.py:269-270 -> (min_d2[V], argmin[V])."""
     verts = _c32(verts)

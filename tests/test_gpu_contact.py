@@ -79,6 +79,66 @@ def test_solid_angles_and_pairwise_dense():
     assert_close(p, g['pairwise_b0'], 0, 1e-6, 'pairwise')
 
 
+def test_batch_pairwise_dist_gradient_vs_reference_autograd():
+    """The reference differentiates through the materialised matrix (tuch/smplify/losses.py:76-78 -> 115-116,
+    tuch/eft/loss.py:142).  Goldens: torch autograd through the reference's own function on the CPU
+    (tests/golden/make_golden_pairwise_grad.py).  Tolerance: float32 sums of up to 130 terms of size <= 40, 2e-5 abs."""
+    from tuch_amd.utils.contact import batch_pairwise_dist
+    g = gio.load('pairwise_grad.npz')
+    G = torch.tensor(g['G'], device=dev())
+    for tag, squared in (('sq', True), ('root', False)):
+        x = torch.tensor(g['x'], device=dev(), requires_grad=True)
+        y = torch.tensor(g['y'], device=dev(), requires_grad=True)
+        P = batch_pairwise_dist(x, y, squared=squared)
+        assert P.requires_grad
+        assert_close(P.detach().cpu().numpy(), g['P_' + tag], 1e-6, 2e-6, 'P ' + tag)
+        (P * G).sum().backward()
+        assert_close(x.grad.cpu().numpy(), g['gx_' + tag], 1e-5, 2e-5, 'grad x ' + tag)
+        assert_close(y.grad.cpu().numpy(), g['gy_' + tag], 1e-5, 2e-5, 'grad y ' + tag)
+        # only one side differentiated; bit-reproducible (fixed summation order)
+        x2 = torch.tensor(g['x'], device=dev(), requires_grad=True)
+        P2 = batch_pairwise_dist(x2, y.detach(), squared=squared)
+        (P2 * G).sum().backward()
+        assert torch.equal(x2.grad, x.grad)
+    # one tensor as both arguments + block minima: the region-to-region term as the reference spells it (losses.py:112-116)
+    v = torch.tensor(g['v'], device=dev(), requires_grad=True)
+    P = batch_pairwise_dist(v[[0]], v[[0]], squared=True)
+    loss = 0
+    for r1, r2 in zip(g['blocks_a'], g['blocks_b']):
+        r1, r2 = torch.as_tensor(r1, device=dev()), torch.as_tensor(r2, device=dev())
+        loss = loss + torch.min(P[:, r1, :][:, :, r2])
+    loss.backward()
+    assert_close(loss.item(), g['r2r_loss'], 1e-5, 1e-6, 'r2r loss')
+    assert_close(v.grad.cpu().numpy(), g['r2r_grad'], 1e-5, 2e-6, 'r2r grad')
+    # many bodies, one region pair (train_module.py:83-88)
+    xa = torch.tensor(g['xa'], device=dev(), requires_grad=True)
+    ya = torch.tensor(g['ya'], device=dev(), requires_grad=True)
+    d = batch_pairwise_dist(xa, ya)
+    d.reshape(d.shape[0], -1).min(1)[0].sum().backward()
+    assert_close(xa.grad.cpu().numpy(), g['gxa'], 1e-5, 2e-6, 'wide grad x')
+    assert_close(ya.grad.cpu().numpy(), g['gya'], 1e-5, 2e-6, 'wide grad y')
+
+
+def test_forward_only_ops_raise_in_backward_instead_of_returning_zero():
+    """solid_angles / winding_numbers have no gradient kernel: under torch.no_grad() or on detached inputs (every call
+    site of the reference) nothing changes; when a graph is recorded, the value is the same and backward raises."""
+    from tuch_amd import ops
+    from tuch_amd.utils.contact import solid_angles, winding_numbers
+    g = golden('small')
+    verts = torch.tensor(g['verts'][:1], device=dev(), requires_grad=True)
+    tris = ops.gather_triangles(verts, torch.tensor(g['faces'].astype(np.int32), device=dev()))
+    with torch.no_grad():
+        w0 = winding_numbers(verts, tris)
+        s0 = solid_angles(verts, tris)
+    assert not w0.requires_grad and not s0.requires_grad
+    assert not winding_numbers(verts.detach(), tris).requires_grad
+    for fn, ref in ((winding_numbers, w0), (solid_angles, s0)):
+        out = fn(verts, tris)
+        assert out.requires_grad and torch.equal(out.detach(), ref)
+        with pytest.raises(NotImplementedError, match='no gradient kernel'):
+            out.sum().backward()
+
+
 @pytest.mark.parametrize('tag', TAGS)
 def test_v2v_min_masked_vs_reference(tag):
     g, gm = golden(tag), golden_mask(tag)
@@ -138,6 +198,25 @@ def test_exterior_flags_and_segments(tag):
         assert np.array_equal(ext[b], expect)
         ext_ref, _ = oc.exterior_flags(g['verts'][b], g['faces'], segs, always_filter=True)
         assert (ext[b] != ext_ref).sum() == 0
+
+
+@pytest.mark.parametrize('tag', TAGS)
+def test_exterior_flags_same_bits_wherever_the_closing_fans_are_computed(tag):
+    """Option ray_fans (csrc/ray_winding.hip: fans_in_bounds_launch / fans_in_near_launch): the vertices' closing fans
+    computed by the finalize kernel (0), by extra workgroups of the chain's first launch (1, only when the leaves' strip
+    runs tile the stream) or of the near-list launch (2).  Flags, segment flags and winding sums are the same bits."""
+    g, gm = golden(tag), golden_mask(tag)
+    model = make_model(g, gm, True, False)
+    verts = torch.tensor(g['verts'], device=dev())
+    got = {}
+    for fans in (0, 1, 2):
+        model.set_option('ray_fans', fans)
+        ext, w, _, seg_e = model.exterior_flags(verts, apply_segments=True, return_details=True)
+        plain = model.exterior_flags(verts, apply_segments=False)
+        got[fans] = (ext.clone(), w.clone(), seg_e.clone(), plain.clone())
+    for fans in (1, 2):
+        for a, b, what in zip(got[fans], got[0], ('exterior', 'w', 'segment flags', 'exterior without segments')):
+            assert torch.equal(a, b), (tag, fans, what)
 
 
 @pytest.mark.parametrize('tag', SMALL)

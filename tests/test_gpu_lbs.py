@@ -156,6 +156,41 @@ def test_sparse_skinning_is_the_dense_sum_bit_for_bit_and_every_batch_form_agree
     assert_close(out.vertices.cpu().numpy(), v64.numpy(), 1e-4, 5e-6, 'dense-weight body vs fp64')
 
 
+def test_leaf_views_of_a_plain_base_and_watched_views_keep_their_own_gradients(bodies):
+    """A fitting setup: pose = zeros(B,72) WITHOUT grad, the two parameters are its row views made leaves with
+    requires_grad_().  They look like the shared rows of one base but autograd owes each view its own .grad; likewise a
+    view somebody put a hook / retain_grad() on.  Same numbers as two independent tensors."""
+    body = bodies['tiny']
+    smpl = _smpl(body)
+    bp, go, be = [torch.tensor(a, device=DEV) for a in random_poses(5, 31)]
+    w = torch.linspace(0.5, 1.5, 5 * body.num_verts * 3, device=DEV).reshape(5, body.num_verts, 3)
+
+    def objective(g, p):
+        out = smpl(betas=be, body_pose=p, global_orient=g)
+        return (out.vertices * w).sum() + out.joints.sum()
+    g0, p0 = go.clone().requires_grad_(True), bp.clone().requires_grad_(True)
+    objective(g0, p0).backward()
+    # leaf views of a base without grad
+    pose = torch.cat([go, bp], 1).contiguous()
+    gl, pl = pose[:, :3].requires_grad_(), pose[:, 3:].requires_grad_()
+    assert gl.is_leaf and pl.is_leaf and not pose.requires_grad
+    objective(gl, pl).backward()
+    assert torch.equal(gl.grad, g0.grad) and torch.equal(pl.grad, p0.grad)
+    # non-leaf views of a differentiable base with a hook and a retained gradient on them
+    base = torch.cat([go, bp], 1).contiguous().requires_grad_(True)
+    gv, pv = base[:, :3], base[:, 3:]
+    seen = []
+    gv.register_hook(lambda grad: seen.append(grad.clone()))
+    pv.retain_grad()
+    objective(gv, pv).backward()
+    assert len(seen) == 1 and torch.equal(seen[0], g0.grad) and torch.equal(pv.grad, p0.grad)
+    assert torch.equal(base.grad[:, :3], g0.grad) and torch.equal(base.grad[:, 3:], p0.grad)
+    # unwatched views of a differentiable base: the one-gradient path, same bits
+    base2 = torch.cat([go, bp], 1).contiguous().requires_grad_(True)
+    objective(base2[:, :3], base2[:, 3:]).backward()
+    assert torch.equal(base2.grad, base.grad)
+
+
 def test_train_style_slices_of_one_rotation_tensor_take_one_gradient(bodies):
     """train_module.py:202-204 passes pred_rotmat[:, 1:] and pred_rotmat[:, 0].unsqueeze(1): two views of ONE [B,24,3,3]
     tensor.  The module hands the kernels that tensor's rows and returns ONE gradient for it (autograd would zero-fill and

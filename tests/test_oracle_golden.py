@@ -27,6 +27,16 @@ def test_pairwise_dense():
     assert np.all(np.diag(p) == 0)
 
 
+def test_pairwise_adjoint_vs_reference_autograd():
+    """tests/golden/make_golden_pairwise_grad.py: torch autograd through the reference's contact.py:23-47."""
+    g = gio.load('pairwise_grad.npz')
+    for tag, squared in (('sq', True), ('root', False)):
+        for b in range(g['x'].shape[0]):
+            gx, gy = oc.pairwise_adjoint(g['x'][b], g['y'][b], g['G'][b], squared)
+            assert_close(gx, g['gx_' + tag][b], 1e-5, 2e-5, 'grad x ' + tag)
+            assert_close(gy, g['gy_' + tag][b], 1e-5, 2e-5, 'grad y ' + tag)
+
+
 @pytest.mark.parametrize('tag', TAGS + FULL)
 def test_v2v_min_masked(tag):
     g, gm = golden(tag), golden_mask(tag)

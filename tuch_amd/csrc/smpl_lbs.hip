@@ -1164,7 +1164,12 @@ extern "C" int tuch_smpl_forward_split(const tuch_smpl_model* m, const float* be
     hipLaunchKernelGGL(pose_kernel, dim3(B), dim3(64), 0, s, betas, pose, pose2rot, (const float*)m->J_template,
                        (const float*)m->J_shapedirs, (const int32_t*)m->parents, m->max_depth, R, J, world, A, feat, l.fpad);
     {
-        static const int force = getenv("TUCH_BLEND_TILES") ? atoi(getenv("TUCH_BLEND_TILES")) : 0;
+        // measurement switch, read once per process; anything but 1, 2 or 4 body tiles means "choose by batch size"
+        static const int force = [] {
+            const char* e = getenv("TUCH_BLEND_TILES");
+            const int v = e ? atoi(e) : 0;
+            return v == 1 || v == 2 || v == 4 ? v : 0;
+        }();
         const int tiles = force ? force : (B <= 16 ? 1 : B <= 32 ? 2 : 0);
         if (tiles == 0)
             hipLaunchKernelGGL(blend_ksplit_kernel, dim3(m->N3p / (16 * kBlendJ), l.fpad / 64), dim3(256), 0, s, (const float*)feat,

@@ -175,6 +175,83 @@ __global__ __launch_bounds__(kBlock) void pairwise_kernel(
     out[((size_t)b * nx + i) * ny + j] = p;
 }
 
+// Adjoint of pairwise_kernel for callers that differentiate through the materialised matrix
+// (tuch/smplify/losses.py:76-78 -> :115-116, tuch/eft/loss.py:142): with g = dL/dP,
+//   dL/dx_i = 2 (x_i sum_j g_ij - sum_j g_ij y_j),   dL/dy_j = 2 (y_j sum_i g_ij - sum_i g_ij x_i);
+// for !squared g is first divided by 2 sqrt(p), p recomputed by the forward's formula (torch's sqrt adjoint:
+// the same inf/NaN where p <= 0).  Both reductions run in a fixed order: no atomics, bit-reproducible.
+__device__ __forceinline__ float pairwise_adjoint_weight(const float* xi, const float* yj, float g, int squared)
+{
+    if (squared) return g;
+    const float xx = xi[0] * xi[0] + xi[1] * xi[1] + xi[2] * xi[2];
+    const float yy = yj[0] * yj[0] + yj[1] * yj[1] + yj[2] * yj[2];
+    const float zz = xi[0] * yj[0] + xi[1] * yj[1] + xi[2] * yj[2];
+    return g / (2.0f * __builtin_sqrtf(xx + yy - 2.0f * zz));
+}
+
+// one workgroup per row i: the row of g is read coalesced, (sum g, sum g y) reduced over the wavefronts
+__global__ __launch_bounds__(kBlock) void pairwise_bwd_x_kernel(
+    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ g, int nx, int ny, int squared,
+    float* __restrict__ gx)
+{
+    const int b = blockIdx.y, i = blockIdx.x;
+    const float* xi = x + ((size_t)b * nx + i) * 3;
+    const float xv[3] = {xi[0], xi[1], xi[2]};
+    const float* grow = g + ((size_t)b * nx + i) * ny;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = threadIdx.x; j < ny; j += kBlock) {
+        const float* yj = y + ((size_t)b * ny + j) * 3;
+        const float yv[3] = {yj[0], yj[1], yj[2]};
+        const float w = pairwise_adjoint_weight(xv, yv, grow[j], squared);
+        acc[0] += w; acc[1] += w * yv[0]; acc[2] += w * yv[1]; acc[3] += w * yv[2];
+    }
+    __shared__ float part[kBlock / 64][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) acc[k] += __shfl_xor(acc[k], m);
+    }
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 4; ++k) part[threadIdx.x >> 6][k] = acc[k];
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float s0 = 0.f, sk = 0.f;
+        for (int w = 0; w < kBlock / 64; ++w) { s0 += part[w][0]; sk += part[w][1 + threadIdx.x]; }
+        gx[((size_t)b * nx + i) * 3 + threadIdx.x] = 2.0f * (xv[threadIdx.x] * s0 - sk);
+    }
+}
+
+// one workgroup per 64 columns: lane = column j, the wavefronts interleave the rows (x_i is wavefront-uniform),
+// 256-byte row segments of g per wavefront load
+__global__ __launch_bounds__(kBlock) void pairwise_bwd_y_kernel(
+    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ g, int nx, int ny, int squared,
+    float* __restrict__ gy)
+{
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    const bool live = j < ny;
+    const float* yj = y + ((size_t)b * ny + (live ? j : ny - 1)) * 3;
+    const float yv[3] = {yj[0], yj[1], yj[2]};
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = wave; i < nx; i += kBlock / 64) {
+        const float* xi = x + ((size_t)b * nx + i) * 3;
+        const float xv[3] = {xi[0], xi[1], xi[2]};
+        const float gij = live ? g[((size_t)b * nx + i) * ny + j] : 0.f;
+        const float w = pairwise_adjoint_weight(xv, yv, gij, squared);
+        acc[0] += w; acc[1] += w * xv[0]; acc[2] += w * xv[1]; acc[3] += w * xv[2];
+    }
+    __shared__ float part[kBlock / 64][4][64];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) part[wave][k][lane] = acc[k];
+    __syncthreads();
+    if (wave == 0 && live) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int w = 0; w < kBlock / 64; ++w)
+            for (int k = 0; k < 4; ++k) t[k] += part[w][k][lane];
+        for (int k = 0; k < 3; ++k) gy[((size_t)b * ny + j) * 3 + k] = 2.0f * (yv[k] * t[0] - t[1 + k]);
+    }
+}
+
 // Ragged variant for resampled (HD) point sets, tuch/train/loss.py:288-291: body b owns points
 // off[b]..off[b+1]; point a carries the template vertex vid[a] whose geodesic-mask row/column
 // it inherits (geovec_verts, loss.py:88).  Column a: min over the body's rows r with
@@ -1486,6 +1563,20 @@ extern "C" int tuch_batch_pairwise_dist(const float* x, const float* y, int B, i
     hipLaunchKernelGGL(pairwise_kernel, dim3(ceil_div(Ny, kBlock), Nx, B), dim3(kBlock), 0,
                        (hipStream_t)stream, x, y, Nx, Ny, squared, P);
     return tuch_check_launch("tuch_batch_pairwise_dist");
+}
+
+extern "C" int tuch_batch_pairwise_dist_bwd(const float* x, const float* y, const float* grad_P, int B, int Nx, int Ny,
+                                            int squared, float* grad_x, float* grad_y, void* stream)
+{
+    TUCH_REQUIRE(x && y && grad_P && (grad_x || grad_y), "tuch_batch_pairwise_dist_bwd: null pointer");
+    TUCH_REQUIRE(B > 0 && Nx > 0 && Ny > 0 && B <= 65535, "tuch_batch_pairwise_dist_bwd: bad sizes");
+    if (grad_x)
+        hipLaunchKernelGGL(pairwise_bwd_x_kernel, dim3(Nx, B), dim3(kBlock), 0, (hipStream_t)stream, x, y, grad_P, Nx, Ny,
+                           squared, grad_x);
+    if (grad_y)
+        hipLaunchKernelGGL(pairwise_bwd_y_kernel, dim3(ceil_div(Ny, 64), B), dim3(kBlock), 0, (hipStream_t)stream, x, y,
+                           grad_P, Nx, Ny, squared, grad_y);
+    return tuch_check_launch("tuch_batch_pairwise_dist_bwd");
 }
 
 extern "C" size_t tuch_v2v_min_indexed_workspace_bytes(int B, int max_points_per_body)

@@ -188,11 +188,20 @@ def _shared_rows(global_orient, body_pose, w):
     return base.view(b, 24 * w)
 
 
+def _plain_view(t) -> bool:
+    return t.grad_fn is not None and not t.retains_grad and not getattr(t, '_backward_hooks', None)
+
+
 def smpl_forward_split(smpl_module, betas, global_orient, body_pose, pose2rot=True):
     """(vertices [B,V,3], joints [B,49,3]) from the two pose tensors of SMPL.forward (tuch/models/smpl.py:44-47)."""
     dm = _device_model(smpl_module, betas.device)
     if torch.is_grad_enabled() and (global_orient.requires_grad or body_pose.requires_grad):
         full = _shared_rows(global_orient, body_pose, 3 if pose2rot else 9)
+        # one gradient to the shared base only when that is where autograd would send the two gradients anyway: the base
+        # is differentiable and both views hang off it (a leaf view of a non-differentiable base made a parameter with
+        # requires_grad_() keeps its own .grad), and nobody watches the views themselves (hooks, retain_grad)
+        if full is not None and not (full.requires_grad and _plain_view(global_orient) and _plain_view(body_pose)):
+            full = None
         if full is not None:
             return _SmplLBS.apply(betas, global_orient.detach(), body_pose.detach(), dm, pose2rot, full)
     return _SmplLBS.apply(betas, global_orient, body_pose, dm, pose2rot)

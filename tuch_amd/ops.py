@@ -111,17 +111,43 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------- raw functions
+class _PairwiseDist(torch.autograd.Function):
+    """tuch/utils/contact.py:23-47 with its gradient (the reference differentiates through the matrix:
+    smplify/losses.py:76-78 -> 115-116, eft/loss.py:142).  One kernel forward, one per differentiated input backward."""
+
+    @staticmethod
+    def forward(ctx, x, y, squared):
+        xf, yf = _f32(x), _f32(y)
+        b, nx, _ = xf.shape
+        ny = yf.shape[1]
+        out = torch.empty(b, nx, ny, dtype=torch.float32, device=xf.device)
+        _C.check(_C.lib().tuch_batch_pairwise_dist(_C.ptr(xf), _C.ptr(yf), b, nx, ny, int(squared), _C.ptr(out),
+                                                   _C.stream()))
+        ctx.save_for_backward(xf, yf)
+        ctx.squared = bool(squared)
+        ctx.dtypes = (x.dtype, y.dtype)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        xf, yf = ctx.saved_tensors
+        b, nx, _ = xf.shape
+        ny = yf.shape[1]
+        g = grad_out.to(torch.float32).contiguous()
+        gx = torch.empty_like(xf) if ctx.needs_input_grad[0] else None
+        gy = torch.empty_like(yf) if ctx.needs_input_grad[1] else None
+        if gx is not None or gy is not None:
+            _C.check(_C.lib().tuch_batch_pairwise_dist_bwd(_C.ptr(xf), _C.ptr(yf), _C.ptr(g), b, nx, ny, int(ctx.squared),
+                                                           _C.ptr(gx), _C.ptr(gy), _C.stream()))
+        return (None if gx is None else gx.to(ctx.dtypes[0]), None if gy is None else gy.to(ctx.dtypes[1]), None)
+
+
 def batch_pairwise_dist(x: torch.Tensor, y: torch.Tensor, squared: bool = True) -> torch.Tensor:
-    x, y = _f32(x), _f32(y)
-    b, nx, _ = x.shape
-    ny = y.shape[1]
-    out = torch.empty(b, nx, ny, dtype=torch.float32, device=x.device)
-    _C.check(_C.lib().tuch_batch_pairwise_dist(_C.ptr(x), _C.ptr(y), b, nx, ny, int(squared), _C.ptr(out),
-                                               _C.stream()))
-    return out
+    return _PairwiseDist.apply(x, y, squared)
 
 
-def solid_angles(points: torch.Tensor, triangles: torch.Tensor) -> torch.Tensor:
+def _solid_angles_raw(points: torch.Tensor, triangles: torch.Tensor) -> torch.Tensor:
     points, triangles = _f32(points), _f32(triangles)
     b, q, _ = points.shape
     f = triangles.shape[1]
@@ -130,8 +156,7 @@ def solid_angles(points: torch.Tensor, triangles: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def winding_numbers(points: torch.Tensor, triangles: torch.Tensor, thresh: Optional[float] = None):
-    """[B,Q,3], [B,F,3,3] -> w [B,Q] (and exterior = w <= thresh if thresh is given)."""
+def _winding_numbers_raw(points: torch.Tensor, triangles: torch.Tensor, thresh: Optional[float] = None):
     points, triangles = _f32(points), _f32(triangles)
     b, q, _ = points.shape
     f = triangles.shape[1]
@@ -144,6 +169,41 @@ def winding_numbers(points: torch.Tensor, triangles: torch.Tensor, thresh: Optio
                                     float(thresh if thresh is not None else 0.0), _C.ptr(ws), nbytes,
                                     _C.stream()))
     return (w, ext.bool()) if thresh is not None else w
+
+
+class _NoGradient(torch.autograd.Function):
+    """Forward-only kernels behind autograd: the value is returned attached to the graph, and a backward pass that
+    reaches it raises instead of handing back a silent zero.  Every call site of the reference runs these two under
+    torch.no_grad() or on detached inputs (smplify/losses.py:79-82, train/loss.py:251-261,287-297, eft/loss.py:145-148,
+    utils/segmentation.py:97 inside them), where this node is never built."""
+
+    @staticmethod
+    def forward(ctx, what, fn, points, triangles):
+        ctx.what = what
+        return fn(points, triangles)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        raise NotImplementedError(
+            'tuch_amd: %s has no gradient kernel (the reference only calls it under torch.no_grad(), '
+            'tuch/smplify/losses.py:79-82); detach the inputs or wrap the call in torch.no_grad()' % ctx.what)
+
+
+def _tracked(*tensors) -> bool:
+    return torch.is_grad_enabled() and any(t.requires_grad for t in tensors)
+
+
+def solid_angles(points: torch.Tensor, triangles: torch.Tensor) -> torch.Tensor:
+    if _tracked(points, triangles):
+        return _NoGradient.apply('solid_angles', _solid_angles_raw, points, triangles)
+    return _solid_angles_raw(points, triangles)
+
+
+def winding_numbers(points: torch.Tensor, triangles: torch.Tensor, thresh: Optional[float] = None):
+    """[B,Q,3], [B,F,3,3] -> w [B,Q] (and exterior = w <= thresh if thresh is given)."""
+    if thresh is None and _tracked(points, triangles):
+        return _NoGradient.apply('winding_numbers', _winding_numbers_raw, points, triangles)
+    return _winding_numbers_raw(points, triangles, thresh)
 
 
 def gather_triangles(verts: torch.Tensor, faces_i32: torch.Tensor) -> torch.Tensor:
