@@ -32,7 +32,7 @@ Rank 0 prints ONE JSON line (contract in the task description) including
   shard_sweep  -- the step at 8/16/32/64 bodies on one GPU (the per-GPU shards of a global batch of 64)
   workloads    -- the per-rank workloads of BASELINE configs 3, 4 and 5
   worst_case   -- every body self-penetrating; folded: limbs pushed THROUGH the body
-  deterministic_mode -- the step with bit-reproducible gradient scatters (TUCH_DETERMINISTIC=1)
+  float_atomics_mode -- the step with TUCH_DETERMINISTIC=0 (the headline runs deterministic: bit-reproducible gradient scatters)
   irregular_topology -- the step and its pruning statistics on the irregular-topology body next to the lat-long one
 --config {2,3,4-shard,5-shard} makes one of those workloads the timed step instead (its own metric name).
 """
@@ -222,6 +222,9 @@ def parse(argv=None):
     ap.add_argument('--no-extras', action='store_true', help='skip shard sweep, workloads, worst case, contact-loss eval')
     ap.add_argument('--rccl-smoke', action='store_true', help='(internal) run the one-rank RCCL smoke and exit')
     ap.add_argument('--no-rccl-smoke', action='store_true')
+    ap.add_argument('--allreduce-per-block', action='store_true',
+                    help='N > 1: reduce the two floats of statistics once per timed block instead of once per step (the default '
+                         'for N > 1 is one all-reduce per step, SURVEY 8e; the other form is timed as well and reported beside it)')
     return ap.parse_args(argv)
 
 
@@ -755,6 +758,20 @@ def contact_loss_eval(p, batch, verts, model):
             out['train_style_%s_step_graph_fresh_ms' % tag] = round(time_kernel(replay, 12, replay.next_bodies) * 1e3, 4)
         except Exception as e:                                   # noqa: BLE001 -- reported, not fatal for the bench line
             out['train_style_%s_step_graph_ms' % tag] = 'capture failed: %s' % type(e).__name__
+        if use_hd:
+            # the cost of bit-exact index work in the HD branch: option hd_search=0 is the exact VALU search (v2v_indexed_kernel:
+            # partners identical to a float32 brute force, first index on ties); the default search on the matrix cores is exact
+            # up to ties within 2e-6 relative of the squared distance (3 of 354 048 picks at batch 64, each verified per point in
+            # tests/test_gpu_properties.py) -- the reference's own picks are decided by ~4e-6 of bmm rounding there
+            crit._model.set_option('hd_search', 0)
+            try:
+                out['hd_exact_mode_fwd_bwd_ms_per_body'] = round(time_kernel(fwd_bwd, iters) * 1e3 / batch, 5)
+                replay = capture(make_train_step(p, use_hd, fresh=probs), 3)
+                out['hd_exact_mode_step_graph_ms'] = round(time_kernel(replay, 10) * 1e3, 4)
+            except Exception as e:                               # noqa: BLE001
+                out['hd_exact_mode_step_graph_ms'] = 'failed: %s' % type(e).__name__
+            finally:
+                crit._model.set_option('hd_search', 1)
     out['fresh_note'] = ('*_fresh_*: %d distinct pose batches rotated through the same call / the same captured step (inputs '
                          'written in place between replays, those small copies included): the nearest-vertex search is '
                          'seeded by ANOTHER batch\'s partners, as in a training loop; without the suffix: identical bodies '
@@ -927,16 +944,14 @@ def headline_without_hints(device, seed, batch):
     return {'ms_per_step': round(ms, 4), 'body_iterations_per_s': round(batch / ms * 1e3, 1)}
 
 
-def deterministic_cost(device, seed, batch):
-    """The step in deterministic mode (gradient scatters through 64-bit fixed-point integer atomics: bit-reproducible
-    fits), captured and replayed like the headline."""
+def float_atomics_cost(device, seed, batch):
+    """The step with TUCH_DETERMINISTIC=0 (gradient scatters through float atomics: last-ulp run-to-run noise) -- the
+    headline runs in the default, deterministic mode (64-bit fixed-point integer atomics: bit-reproducible fits);
+    captured and replayed like the headline."""
     from tuch_amd import ops
-    ops.set_deterministic(True)
-    try:
+    with ops.deterministic_mode(False):
         p = build_problem(batch, device, seed)
         ms = time_kernel(capture(make_step(p), 3), 20) * 1e3
-    finally:
-        ops.set_deterministic(False)
     return {'ms_per_step': round(ms, 4), 'body_iterations_per_s': round(batch / ms * 1e3, 1)}
 
 
@@ -1241,15 +1256,22 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def block(steps, step=step):
+    per_step = world > 1 and not args.allreduce_per_block
+
+    def block(steps, step=step, per_step=per_step):
         """EXACTLY `steps` steps between two fences; seconds, MAX over ranks."""
         fence()
         t0 = time.perf_counter()
-        # the fits of different bodies never exchange data (SMPLify-DC optimises every body on its own): the ranks run
-        # their shards without a collective in the loop; the two floats of statistics are reduced once per block
+        # the fits of different bodies never exchange data (SMPLify-DC optimises every body on its own): no gradient or
+        # parameter crosses ranks.  What SURVEY 8(e) / north_star specify is ONE all-reduce of the two floats of statistics
+        # (loss sum, bodies) PER STEP -- the reported scalar of every iteration; it is enqueued behind the step on the
+        # device (RCCL: no host synchronisation), inside the timed loop.  --allreduce-per-block reduces once per block.
         for _ in range(steps):
             stats = step()
-        stats = reduce(stats)
+            if per_step:
+                stats = reduce(stats)
+        if not per_step:
+            stats = reduce(stats)
         fence()
         dt = time.perf_counter() - t0
         tmax = torch.tensor([dt], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
@@ -1264,6 +1286,11 @@ def main():
         reduce(last)                                     # the collective's own first-call cost stays out of the timing
     dt, stats = block(args.steps)                        # the contract's measurement
     repeats = [dt] + [block(args.steps)[0] for _ in range(max(args.repeats, 1) - 1)]
+    other_form = None
+    if world > 1:
+        odt, _ = block(args.steps, per_step=not per_step)
+        other_form = {'allreduce': 'per block' if per_step else 'per step', 'ms_per_step': round(odt / args.steps * 1e3, 4),
+                      'value': round(batch * world * CONFIGS[args.config]['iters_per_step'] * args.steps / odt, 2)}
     weak = None
     if weak_step is not None:
         for _ in range(args.warmup):
@@ -1277,7 +1304,7 @@ def main():
     if rank == 0:
         cfg = CONFIGS[args.config]
         bodies = batch * world
-        per_step = [r / args.steps * 1e3 for r in repeats]
+        per_step_ms = [r / args.steps * 1e3 for r in repeats]
         line = {
             'metric': cfg['metric'], 'value': round(bodies * cfg['iters_per_step'] * args.steps / dt, 2),
             'unit': cfg['unit'], 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -1286,13 +1313,14 @@ def main():
             'config': {'workload': cfg['workload'] % batch,
                        'bodies_per_gpu': batch, 'global_batch': bodies, 'euclthres': 0.02,
                        'geothres': 0.3, 'launch': launch,
-                       'parallelism': 'dp%d (bodies sharded; one 2-float all-reduce per timed block, none inside the loop)' % world,
+                       'parallelism': 'dp%d (bodies sharded; one 2-float all-reduce per %s; no gradient or parameter exchange)'
+                                      % (world, 'step, inside the timed loop' if per_step else 'timed block'),
                        'batch_iterations_per_s': round(cfg['iters_per_step'] * args.steps / dt, 3),
                        'loss_sum': float(stats[0].item()), 'bodies': float(stats[1].item())},
-            'repeat_ms_per_step': {'n': len(per_step), 'median': round(float(np.median(per_step)), 4),
-                                   'min': round(min(per_step), 4), 'max': round(max(per_step), 4),
+            'repeat_ms_per_step': {'n': len(per_step_ms), 'median': round(float(np.median(per_step_ms)), 4),
+                                   'min': round(min(per_step_ms), 4), 'max': round(max(per_step_ms), 4),
                                    'note': 'the same %d-step block timed %d times; ms_per_step/value are block 1'
-                                           % (args.steps, len(per_step))},
+                                           % (args.steps, len(per_step_ms))},
             'scaling_note': 'no multi-GPU node was available to the builder: N>1 values exist only when the driver '
                             'runs this script on one; --gpus N > 1 defaults to STRONG scaling at global batch 64 (SURVEY 8e) '
                             'and reports the weak-scaling figure (64 bodies per GPU) as `weak_scaling`' if world == 1 else
@@ -1300,6 +1328,8 @@ def main():
         }
         if weak is not None:
             line['weak_scaling'] = weak
+        if other_form is not None:
+            line['other_allreduce_form'] = other_form
         if args.config == '2':
             try:
                 line['selfcheck'] = selfcheck(p, step)
@@ -1333,7 +1363,9 @@ def main():
             line['workloads'] = workloads(device, 1002)
             line['worst_case'] = worst_case(device, 1002, batch)
             line['worst_case']['folded'] = worst_case(device, 1002, batch, folded=True)
-            line['deterministic_mode'] = deterministic_cost(device, 1002, batch)
+            from tuch_amd import ops as ops_mod
+            line['deterministic'] = bool(ops_mod.deterministic())
+            line['float_atomics_mode'] = float_atomics_cost(device, 1002, batch)
             line['headline_without_hints'] = headline_without_hints(device, 1002, batch)
             line['irregular_topology'] = irregular_topology(device, 1002, batch)
         if world == 1 and not args.no_cpu_baseline:

@@ -192,7 +192,8 @@ int tuch_smplify_stage2_fused(const float* points, const int32_t* partner, const
                               const float* small_terms, const float* r2r, const int32_t* ij, int P, float contact_scale,
                               float r2r_scale, float* share, int* ticket, float* terms, float* out, float* grad_points,
                               const tuch_contact_model* model, const void* pair_keys, void* grad_fixed_zeroed, void* stream);
-/* Deterministic mode (also TUCH_DETERMINISTIC=1 in the environment when the library is loaded): the gradient scatters of
+/* Deterministic mode -- ON by default (TUCH_DETERMINISTIC=0 in the environment when the library is loaded, or
+ * tuch_set_deterministic(0), selects float atomics: last-ulp run-to-run noise in the gradients): the gradient scatters of
  * tuch_smplify_stage2_fused (contact terms, region minima) and of tuch_smpl_backward (skinning adjoint) accumulate 64-bit
  * fixed-point numbers (2^-36) with integer atomics instead of floats -- sums that do not depend on the order of arrival,
  * so an SMPLify-DC fit reproduces bit for bit.  tuch_smplify_stage2_fused then wants grad_fixed_zeroed = B*N*3 zeroed

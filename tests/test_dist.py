@@ -197,6 +197,13 @@ def test_bench_spawns_its_own_ranks():
         return json.loads(lines[0])
     line = run('--global-batch', '8')
     assert line['n_gpus'] == 2 and line['scaling'] == 'strong' and line['config']['bodies_per_gpu'] == 4
+    # one all-reduce of the two floats per STEP inside the timed loop is the default for N > 1; the per-block
+    # form is timed beside it
+    assert 'all-reduce per step' in line['config']['parallelism']
+    assert line['other_allreduce_form']['allreduce'] == 'per block' and line['other_allreduce_form']['value'] > 0
+    line_b = run('--global-batch', '8', '--allreduce-per-block')
+    assert 'per timed block' in line_b['config']['parallelism'] and line_b['other_allreduce_form']['allreduce'] == 'per step'
+    assert line_b['config']['bodies'] == 8.0
     assert line['config']['bodies'] == 8.0 and line['config']['launch'].startswith('hipGraph')
     assert np.isfinite(line['config']['loss_sum']) and line['value'] > 0 and 'weak_scaling' not in line
     # the DEFAULT for N > 1 is what SURVEY 8(e) specifies: the global batch of 64 split over the ranks (strong scaling);

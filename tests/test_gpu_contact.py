@@ -201,22 +201,26 @@ def test_exterior_flags_and_segments(tag):
 
 
 @pytest.mark.parametrize('tag', TAGS)
-def test_exterior_flags_same_bits_wherever_the_closing_fans_are_computed(tag):
-    """Option ray_fans (csrc/ray_winding.hip: fans_in_bounds_launch / fans_in_near_launch): the vertices' closing fans
-    computed by the finalize kernel (0), by extra workgroups of the chain's first launch (1, only when the leaves' strip
-    runs tile the stream) or of the near-list launch (2).  Flags, segment flags and winding sums are the same bits."""
+def test_exterior_flags_same_bits_in_every_form_of_the_ray_test(tag):
+    """Option ray_cross (csrc/ray_winding.hip): near lists, regrouping and crossings in one launch (1, ray_cross_kernel) or the
+    three launches of rounds 2 - 5 (0).  Option ray_fans: the vertices' closing fans computed by the finalize kernel (0), by
+    extra workgroups of the chain's first launch (1, only when the leaves' strip runs tile the stream) or of the near-list
+    launch (2, three-launch form only).  Flags, segment flags and winding sums are the same bits in every combination."""
     g, gm = golden(tag), golden_mask(tag)
     model = make_model(g, gm, True, False)
     verts = torch.tensor(g['verts'], device=dev())
     got = {}
-    for fans in (0, 1, 2):
-        model.set_option('ray_fans', fans)
-        ext, w, _, seg_e = model.exterior_flags(verts, apply_segments=True, return_details=True)
-        plain = model.exterior_flags(verts, apply_segments=False)
-        got[fans] = (ext.clone(), w.clone(), seg_e.clone(), plain.clone())
-    for fans in (1, 2):
-        for a, b, what in zip(got[fans], got[0], ('exterior', 'w', 'segment flags', 'exterior without segments')):
-            assert torch.equal(a, b), (tag, fans, what)
+    for cross in (0, 1):
+        for fans in (0, 1, 2):
+            model.set_option('ray_cross', cross)
+            model.set_option('ray_fans', fans)
+            ext, w, _, seg_e = model.exterior_flags(verts, apply_segments=True, return_details=True)
+            plain = model.exterior_flags(verts, apply_segments=False)
+            filtered = model.exterior_flags(verts, apply_segments=True)
+            got[cross, fans] = (ext.clone(), w.clone(), seg_e.clone(), plain.clone(), filtered.clone())
+    for key, vals in got.items():
+        for a, b, what in zip(vals, got[0, 0], ('exterior', 'w', 'segment flags', 'exterior without segments', 'flags only')):
+            assert torch.equal(a, b), (tag, key, what)
 
 
 @pytest.mark.parametrize('tag', SMALL)
@@ -1280,7 +1284,7 @@ def test_ray_crossing_flags_of_points_match_the_solid_angle_sums(tag, monkeypatc
 
 @pytest.mark.parametrize('use_hd', [True, False])
 def test_hd_gradient_is_bit_reproducible_in_deterministic_mode(use_hd):
-    """ops.set_deterministic(True): the HD branch's point gradients are summed as 64-bit fixed-point integers (LDS integer
+    """Deterministic mode (the default; ops.set_deterministic): the HD branch's point gradients are summed as 64-bit fixed-point integers (LDS integer
     atomics) and gathered per vertex in a fixed order -- the gradient of contact_loss(use_hd=True) is the same BITS every
     time, and agrees with the float-atomic one to float tolerance.  use_hd=False: the plain training term's scatter
     (contact_terms_bwd_kernel<Fixed>, round 4) likewise."""
@@ -1305,13 +1309,11 @@ def test_hd_gradient_is_bit_reproducible_in_deterministic_mode(use_hd):
         crit.contact_loss(v, valid).backward()
         torch.cuda.synchronize()
         return v.grad.clone()
-    plain = grad()
+    assert ops.deterministic()                         # the default
+    with ops.deterministic_mode(False):
+        plain = grad()
     assert float(plain.abs().max()) > 0
-    ops.set_deterministic(True)
-    try:
-        runs = [grad() for _ in range(4)]
-    finally:
-        ops.set_deterministic(False)
+    runs = [grad() for _ in range(4)]
     for r in runs[1:]:
         assert torch.equal(r, runs[0])
     assert_close(runs[0].cpu().numpy(), plain.cpu().numpy(), 1e-4, 1e-6 * float(plain.abs().max()), 'deterministic vs LDS float atomics')

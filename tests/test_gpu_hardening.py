@@ -204,7 +204,7 @@ def run(v):
     return ext.cpu().numpy(), mn.cpu().numpy(), partner.cpu().numpy(), per_body.detach().cpu().numpy(), v.grad.cpu().numpy()
 
 from tuch_amd import ops
-ops.set_deterministic(True)          # gradient scatters through integer atomics: bit-reproducible, so "identical" can be asked
+assert ops.deterministic()           # the default: gradient scatters through integer atomics, bit-reproducible, so "identical" can be asked
 clean = run(verts)
 again = run(verts)
 out = {'repeat': {'others_bit_identical': all(np.array_equal(a, c) for a, c in zip(again, clean)), 'differs': []}}
@@ -223,7 +223,6 @@ for kind, value, ids in (('nan_one_vertex', float('nan'), [1234]), ('inf_one_ver
     out[kind] = {'others_bit_identical': not differs, 'differs': differs, 'bad_body_loss': float(got[3][3]),
                  'bad_body_loss_finite': bool(np.isfinite(got[3][3])),
                  'partners_in_range': bool(((got[2] >= 0) & (got[2] < V)).all())}
-ops.set_deterministic(False)
 # the whole stage-2 step (LBS + objective + backward + Adam) with a NaN pose: must terminate
 p['body_pose'][5, 7] = float('nan')
 step = bench.make_step(p)

@@ -279,3 +279,26 @@ def test_headline_batch64_hd_search_on_the_matrix_cores_against_the_exact_kernel
         assert (np.abs(da - dc) <= 2e-6 * dc + 2e-8).all(), (b, float(np.abs(da - dc).max()))
     report('headline HD: partners, matrix-core search != exact kernel (ties within the key)', differ, total)
     assert differ <= max(8, total // 5000)
+
+
+def test_headline_batch64_step_reproduces_bit_for_bit_by_default(headline):
+    """SURVEY 8(b) asks for a deterministic path: since round 6 it is the default (TUCH_DETERMINISTIC=0 opts out).  The
+    bench's own step -- SMPL forward, stage-2 objective, backward, Adam -- captured and replayed eight times from the same
+    start, twice over: identical bits in the parameters and in the reported loss."""
+    import bench
+    from tuch_amd import ops
+    p, _ = headline
+    assert ops.deterministic()
+
+    def run():
+        with ops.off_default_stream(DEV):
+            step = bench.capture(bench.make_step(p), 3)
+            for _ in range(8):
+                loss, _ = step()
+            torch.cuda.synchronize()
+            value, verts, joints, pose = step.objective()
+        return loss.clone(), pose, verts.clone()
+    a, b = run(), run()
+    for x, y, what in zip(a, b, ('loss of the last step', 'body pose after the steps', 'posed vertices')):
+        assert torch.equal(x, y), what
+    assert float((a[1] - p['body_pose']).abs().max()) > 1e-3          # the steps did move the parameters

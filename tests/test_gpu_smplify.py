@@ -383,7 +383,7 @@ def test_loops_kept_between_calls_reproduce_fresh_fits(monkeypatch):
 
 
 def test_deterministic_mode_reproduces_a_fit_bit_for_bit():
-    """ops.set_deterministic(True) (TUCH_DETERMINISTIC=1): the gradient scatters of the stage-2 tail and of the SMPL
+    """Deterministic mode (the default; TUCH_DETERMINISTIC=0 / ops.set_deterministic(False) opt out): the gradient scatters of the stage-2 tail and of the SMPL
     adjoint accumulate 64-bit fixed-point numbers with integer atomics instead of float atomics -- the same fit twice,
     from fresh fitters, gives identical BITS in every output (vertices, joints, pose, betas, camera, reprojection loss,
     the per-iteration vertices); and the deterministic fit agrees with the float-atomic one to float tolerance."""
@@ -403,13 +403,10 @@ def test_deterministic_mode_reproduces_a_fit_bit_for_bit():
                      contact_loss_weight=2000.0, segments=s['segments'])
         torch.cuda.synchronize()
         return [x.detach().clone() for x in out[:6]] + [v.detach().clone() for v in out[6]]
-    assert not ops.deterministic()
-    plain = fit()
-    ops.set_deterministic(True)
-    try:
-        first, second = fit(), fit()
-    finally:
-        ops.set_deterministic(False)
+    assert ops.deterministic()                         # the default since round 6
+    with ops.deterministic_mode(False):
+        plain = fit()
+    first, second = fit(), fit()
     assert len(first) == len(second) > 6
     for a, b in zip(first, second):
         assert torch.equal(a, b)
@@ -449,13 +446,9 @@ def test_adam_inside_the_backward_kernel_matches_the_separate_launch(monkeypatch
                      contact_loss_weight=2000.0, segments=s['segments'])
         torch.cuda.synchronize()
         return [x.detach().clone() for x in out[:6]] + [v.detach().clone() for v in out[6]], list(launches)
-    ops.set_deterministic(True)
-    try:
-        with ops.off_default_stream(DEV):
-            fused, steps_fused = fit(True)
-            plain, steps_plain = fit(False)
-    finally:
-        ops.set_deterministic(False)
+    with ops.deterministic_mode(True), ops.off_default_stream(DEV):
+        fused, steps_fused = fit(True)
+        plain, steps_plain = fit(False)
     for a, b in zip(fused, plain):
         assert torch.equal(a, b)
     assert float((fused[2] - torch.cat([t(s['go']), t(s['bp'])], 1)).abs().max()) > 0.02        # the fit moved
@@ -501,6 +494,7 @@ def test_fused_adam_only_when_the_stage2_objective_is_the_root_of_the_pass():
         opt.step()
         torch.cuda.synchronize()
         return bp.detach().clone(), go.detach().clone(), applied
+    before = ops.deterministic()
     ops.set_deterministic(True)
     try:
         with ops.off_default_stream(DEV):
@@ -531,7 +525,7 @@ def test_fused_adam_only_when_the_stage2_objective_is_the_root_of_the_pass():
             torch.cuda.synchronize()
             assert not torch.equal(bp.detach(), moved)               # this step() was not skipped
     finally:
-        ops.set_deterministic(False)
+        ops.set_deterministic(before)
 
 
 @pytest.mark.parametrize('shape_w', [1.0, 0.0])

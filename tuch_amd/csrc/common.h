@@ -63,7 +63,8 @@ int tuch_table_upload(void** dst, const void* src, size_t bytes);
 int tuch_table_download(void* dst_host, const void* src, size_t bytes);
 void tuch_table_free(void* p);
 
-// Deterministic mode (TUCH_DETERMINISTIC=1, read once when the library is loaded, or tuch_set_deterministic): the gradient
+// Deterministic mode (the default; TUCH_DETERMINISTIC=0, read once when the library is loaded, or tuch_set_deterministic(0),
+// selects float atomics): the gradient
 // scatters that are float atomics otherwise (order-dependent in the last ulp) accumulate 64-bit fixed-point numbers with
 // INTEGER atomics -- associative, so the sums do not depend on the order of arrival -- and are converted once at the end:
 // an optimisation then reproduces bit for bit.  kFixedScale: 2^36 (range +-1.3e8, step 1.5e-11).

@@ -121,6 +121,43 @@ __device__ __forceinline__ uint32_t half_above(float x)
 __device__ __host__ __forceinline__ size_t near_records_at(int B, int L) { return (size_t)B * kNearSlabs * L; }
 __device__ __host__ __forceinline__ size_t near_centres_at(int B, int L) { return near_records_at(B, L) + (size_t)B * L * 8; }
 
+// ---- the query side of the one-launch crossing kernel (round 6, ray_cross_kernel below) -------------------------------
+// QRec: a vertex as a ray origin, in tree order (slot = position): its sheared coordinates -- the SAME bits as the strip
+// element of that vertex, shear_x / shear_y of the same three floats: the faces around a query are recognised by exact
+// zeros -- and tag = slot | (segments of the vertex) << 24; slot field 0xffffff: a padding lane of the last block.
+// ranges: per block of 64 slots the 13 extreme values the leaves' records are tested against (ray_near_kernel's block
+// ranges), relative to the body's reference point like the records.
+struct QRec { float x, y, z; int32_t tag; };
+constexpr int kNoSlot = 0xffffff;
+struct RayPre { int blocks, qblocks; QRec* qrec; float4* ranges; const int32_t* vmask; };
+
+__device__ __forceinline__ void ray_block_prepass(const float* __restrict__ vb, int first_vertex,
+                                                  const int32_t* __restrict__ qperm, const int32_t* __restrict__ vmask,
+                                                  int Q, int qb, int lane, QRec* __restrict__ qrec, float4* __restrict__ ranges)
+{
+    const int slot = qb * kRayQueries + lane;
+    const float* q3 = vb + 3 * (size_t)qperm[slot];          // (the table is padded: lanes behind Q repeat a vertex)
+    const float* c0 = vb + 3 * (size_t)first_vertex;         // the body's reference point: the first element of its strip
+    const float qz = q3[2], qx = shear_x(q3[0], qz), qy = shear_y(q3[1], qz);
+    const float cz = c0[2], cx = shear_x(c0[0], cz), cy = shear_y(c0[1], cz);
+    QRec r;
+    r.x = qx; r.y = qy; r.z = qz;
+    r.tag = slot < Q ? (slot | (vmask ? vmask[slot] << 24 : 0)) : kNoSlot;
+    qrec[slot] = r;
+    const float rx = qx - cx, ry = qy - cy, rz = qz - cz;
+    const float r4 = rx + ry, r5 = rx - ry, r6 = rx + rz, r7 = rx - rz, r8 = ry + rz, r9 = ry - rz;
+    const float bx0 = wave_min_uniform(rx), bx1 = wave_max_uniform(rx), by0 = wave_min_uniform(ry), by1 = wave_max_uniform(ry);
+    const float b40 = wave_min_uniform(r4), b41 = wave_max_uniform(r4), b50 = wave_min_uniform(r5), b51 = wave_max_uniform(r5);
+    const float bz0 = wave_min_uniform(rz), b60 = wave_min_uniform(r6), b71 = wave_max_uniform(r7);
+    const float b80 = wave_min_uniform(r8), b91 = wave_max_uniform(r9);
+    if (lane == 0) {
+        ranges[0] = make_float4(bx0, bx1, by0, by1);
+        ranges[1] = make_float4(b40, b41, b50, b51);
+        ranges[2] = make_float4(bz0, b60, b71, b80);
+        ranges[3] = make_float4(b91, 0.f, 0.f, 0.f);
+    }
+}
+
 __device__ __forceinline__ float fan_terms(const float* __restrict__ vb, int v, bool real, int& n,
                                            const int32_t* __restrict__ ring_off, const int32_t* __restrict__ ring_vidx);
 // kPose, leaf_blocks > 0: the workgroups behind the first leaf_blocks compute the closing fans of 256 vertices each
@@ -135,8 +172,21 @@ __global__ __launch_bounds__(kBoundsBlock) void ray_leaf_bounds_kernel(
     const float* __restrict__ verts, const int32_t* __restrict__ vidx, const float* __restrict__ sign, int V, int Lexact,
     RayElem* __restrict__ stream_out, uint4* __restrict__ zeroed, size_t zeroed_n,
     int leaf_blocks = 0, const int32_t* __restrict__ qperm = nullptr, const int32_t* __restrict__ ring_off = nullptr,
-    const int32_t* __restrict__ ring_vidx = nullptr, float2* __restrict__ fans = nullptr, int fan_stride = 0)
+    const int32_t* __restrict__ ring_vidx = nullptr, float2* __restrict__ fans = nullptr, int fan_stride = 0,
+    RayPre pre = RayPre{0, 0, nullptr, nullptr, nullptr})
 {
+    if (kPose && pre.blocks > 0 && (int)blockIdx.x >= (int)gridDim.x - pre.blocks) {
+        // the query side of the one-launch crossing kernel (ray_cross_kernel): four query blocks per workgroup
+        for (size_t g = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kBoundsBlock + threadIdx.x; g < zeroed_n;
+             g += (size_t)gridDim.x * gridDim.y * kBoundsBlock)
+            zeroed[g] = make_uint4(0u, 0u, 0u, 0u);
+        const int qb = ((int)blockIdx.x - ((int)gridDim.x - pre.blocks)) * (kBoundsBlock / 64) + (int)(threadIdx.x >> 6);
+        if (qb < pre.qblocks)
+            ray_block_prepass(verts + (size_t)blockIdx.y * V * 3, vidx[0], qperm, pre.vmask, V, qb, threadIdx.x & 63,
+                              pre.qrec + (size_t)blockIdx.y * pre.qblocks * kRayQueries,
+                              pre.ranges + ((size_t)blockIdx.y * pre.qblocks + qb) * 4);
+        return;
+    }
     if (kPose && leaf_blocks > 0 && (int)blockIdx.x >= leaf_blocks) {
         for (size_t g = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kBoundsBlock + threadIdx.x; g < zeroed_n;
              g += (size_t)gridDim.x * gridDim.y * kBoundsBlock)
@@ -219,6 +269,17 @@ __global__ __launch_bounds__(kBoundsBlock) void ray_leaf_bounds_kernel(
         r[1] = make_uint4(hi_h[2] | hi_h[3] << 16, hi_h[4] | hi_h[5] << 16, hi_h[7] | (uint32_t)leaf << 16, (uint32_t)node);  // + who it is
         if (leaf == 0) *reinterpret_cast<float4*>(bounds + near_centres_at(gridDim.y, L) + (size_t)b * 4) = make_float4(c[0], c[1], c[2], 0.f);
     }
+}
+
+// the query side alone (meshes whose leaf runs do not tile the strip: the boxes are then two launches of their own)
+__global__ __launch_bounds__(kBoundsBlock) void ray_prepass_kernel(
+    const float* __restrict__ verts, const int32_t* __restrict__ vidx, const int32_t* __restrict__ qperm, int V, RayPre pre)
+{
+    const int qb = (int)blockIdx.x * (kBoundsBlock / 64) + (int)(threadIdx.x >> 6);
+    if (qb < pre.qblocks)
+        ray_block_prepass(verts + (size_t)blockIdx.y * V * 3, vidx[0], qperm, pre.vmask, V, qb, threadIdx.x & 63,
+                          pre.qrec + (size_t)blockIdx.y * pre.qblocks * kRayQueries,
+                          pre.ranges + ((size_t)blockIdx.y * pre.qblocks + qb) * 4);
 }
 
 // ---- crossing test --------------------------------------------------------------------------------------------
@@ -883,6 +944,130 @@ __global__ __launch_bounds__(64) void ray_leaf_kernel(
     if (kCount && lane == 0) atomicAdd(stats, (unsigned long long)walked);
 }
 
+// ---- the middle of the inside test as ONE launch (round 6) ---------------------------------------------------------------
+// ray_near_kernel -> ray_tiles_fill_kernel -> ray_leaf_kernel are a chain of three launches on the step's critical path
+// (57 + 41 + 121 us in the replayed step at batch 64), the first two of them bookkeeping: which leaves the rays of a query
+// block can meet (lists in global memory), the lists regrouped by leaf into tiles of 64 rays (counters, an exclusive scan,
+// a fill pass).  Turned round, nothing has to leave the wavefront: ONE wavefront per (leaf, body)
+//   1. lanes over QUERY BLOCKS: the block's ranges (ray_block_prepass, beside the leaf bounds in the chain's first launch)
+//      against the leaf's record -- the same 13 comparisons as ray_near_kernel's stage 1, the same superset;
+//   2. lanes over QUERIES, the passing blocks three at a time (independent loads and tests in flight): every ray against
+//      the record -- ray_near_kernel's stage 2 --, the rays that pass are appended to a ring in LDS (coordinates + tag);
+//   3. whenever the ring holds 64 rays, and at the end for the rest: the leaf's strip run is walked for them (ray_run) and
+//      the crossings are added to the queries' counts.
+// The (ray, leaf) pairs walked are exactly those of the three-launch form, so are the counts (integer sums).  No lists, no
+// pair table, no overflow fallback; the leaf's record, strip range and the strip itself stay in scalar registers / the
+// scalar cache for all of the leaf's tiles.
+// Grid (G = min(B, 8), rows): workgroup (x, y) = body x + G (y / L), leaf y % L -- column x sits on one XCD (workgroups go
+// round-robin to the XCDs), which works through bodies x, x + G, ... in turn: a body's stream and query records stay in
+// that XCD's L2.
+constexpr int kCrossRing = 256, kCrossTrip = 3;
+template <bool kSeg>
+__global__ __launch_bounds__(64) void ray_cross_kernel(
+    const RayElem* __restrict__ stream, const TreeNode* __restrict__ nodes, const float* __restrict__ bounds, int num_leaves,
+    const int32_t* __restrict__ leaf_order,       // or nullptr: leaves in this order (heaviest first)
+    const QRec* __restrict__ qrec, const float4* __restrict__ ranges, int T, int qblocks, int num_bodies,
+    int32_t* __restrict__ count, int32_t* __restrict__ seg_count)
+{
+    __shared__ QRec ring[kCrossRing];
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x + gridDim.x * (blockIdx.y / num_leaves);
+    if (b >= num_bodies) return;
+    const int li = blockIdx.y % num_leaves;
+    const int leaf = leaf_order ? leaf_order[li] : li;
+    const uint4* recs = reinterpret_cast<const uint4*>(bounds + near_records_at(num_bodies, num_leaves)) + ((size_t)b * num_leaves + leaf) * 2;
+    const uint4 s0 = recs[0], s1 = recs[1];
+    const float4 ctr = *reinterpret_cast<const float4*>(bounds + near_centres_at(num_bodies, num_leaves) + (size_t)b * 4);
+    const TreeNode nd = nodes[(int)s1.w];
+    const int ex_off = __builtin_amdgcn_readfirstlane(nd.ex_off), ex_len = __builtin_amdgcn_readfirstlane(nd.ex_len);
+    const RayElem* st = stream + (size_t)b * T;
+    const QRec* qb_base = qrec + (size_t)b * qblocks * kRayQueries;
+    const float4* rg = ranges + (size_t)b * qblocks * 4;
+    // > 0: outside some slab (ray_near_kernel's test, word for word)
+    auto outside13 = [&](float x1, float x0, float y1, float y0, float p1, float p0, float m1, float m0, float z0, float xz0,
+                         float xz1, float yz0, float yz1) {
+        float out = max3(lo_minus(s0.x, x1), minus_lo(x0, s0.w), hi_minus(s0.x, y1));
+        out = max3(out, minus_hi(y0, s0.w), lo_minus(s0.y, p1));
+        out = max3(out, minus_hi(p0, s1.x), hi_minus(s0.y, m1));
+        out = max3(out, minus_lo(m0, s1.y), minus_lo(z0, s1.x));
+        out = max3(out, minus_hi(xz0, s1.y), lo_minus(s0.z, xz1));
+        return max3(out, minus_lo(yz0, s1.z), hi_minus(s0.z, yz1));
+    };
+    auto ray_outside = [&](const QRec& q) {
+        const float rx = q.x - ctr.x, ry = q.y - ctr.y, rz = q.z - ctr.z;
+        return outside13(rx, rx, ry, ry, rx + ry, rx + ry, rx - ry, rx - ry, rz, rx + rz, rx - rz, ry + rz, ry - rz);
+    };
+    int head = 0, tail = 0;                       // ring positions (wave-uniform)
+    int base = -64;
+    unsigned long long todo = 0;                  // blocks of the current 64 that passed stage 1 and are not yet tested
+    bool more = true;
+    for (;;) {
+        if (more && tail - head < 64) {
+            if (!todo) {
+                base += 64;
+                if (base >= qblocks) { more = false; continue; }
+                const int blk = base + lane;
+                const float4* g = rg + (size_t)min(blk, qblocks - 1) * 4;
+                const float4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
+                // (bx0, bx1, by0, by1) (b40, b41, b50, b51) (bz0, b60, b71, b80) (b91): the lower bounds of the record
+                // against the block's largest value, the upper ones against its smallest
+                const bool pass = (blk < qblocks) &
+                                  !(outside13(g0.y, g0.x, g0.w, g0.z, g1.y, g1.x, g1.w, g1.z, g2.x, g2.y, g2.z, g2.w, g3.x) > 0.0f);
+                todo = __builtin_amdgcn_ballot_w64(pass);
+                continue;
+            }
+            int k[kCrossTrip];
+            bool have[kCrossTrip];
+#pragma unroll
+            for (int j = 0; j < kCrossTrip; ++j) {
+                have[j] = todo != 0;
+                k[j] = have[j] ? base + (int)__builtin_ctzll(todo) : (j ? k[j - 1] : 0);
+                if (have[j]) todo &= todo - 1;
+            }
+            QRec q[kCrossTrip];
+#pragma unroll
+            for (int j = 0; j < kCrossTrip; ++j) {
+                const float4 v = *reinterpret_cast<const float4*>(qb_base + (size_t)k[j] * kRayQueries + lane);
+                q[j].x = v.x; q[j].y = v.y; q[j].z = v.z; q[j].tag = __float_as_int(v.w);
+            }
+            unsigned long long hit[kCrossTrip];
+#pragma unroll
+            for (int j = 0; j < kCrossTrip; ++j)
+                hit[j] = __builtin_amdgcn_ballot_w64(have[j] && (q[j].tag & kNoSlot) != kNoSlot && !(ray_outside(q[j]) > 0.0f));
+#pragma unroll
+            for (int j = 0; j < kCrossTrip; ++j) {
+                if (hit[j]) {
+                    const int pos = tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(hit[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hit[j], 0));
+                    if ((hit[j] >> lane) & 1ull) ring[pos & (kCrossRing - 1)] = q[j];
+                    tail += __builtin_popcountll(hit[j]);
+                }
+            }
+            continue;
+        }
+        const int n = min(64, tail - head);
+        if (n <= 0) break;
+        __builtin_amdgcn_wave_barrier();
+        const bool active = lane < n;
+        const QRec q = ring[(head + (active ? lane : 0)) & (kCrossRing - 1)];
+        __builtin_amdgcn_wave_barrier();
+        head += n;
+        const int slot = q.tag & kNoSlot;
+        S3 s[3];
+        float e[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) { s[u].xy = (v2f){0.0f, 0.0f}; s[u].z = 0.0f; e[u] = 0.0f; }
+        int crossings = 0;
+        uint32_t pa = kSegBias, pb = kSegBias;
+        ray_run<true, kSeg>(st, ex_off, ex_len, s, e, (v2f){q.x, q.y}, q.z, crossings, (int)((uint32_t)q.tag >> 24), pa, pb);
+        if (active && crossings != 0) atomicAdd(&count[((size_t)b * qblocks) * kRayQueries + slot], crossings);
+        if (kSeg && active && (pa != kSegBias || pb != kSegBias)) {             // few lanes (see ray_leaf_kernel)
+            int32_t* sc = seg_count + 2 * (((size_t)b * qblocks) * kRayQueries + slot);
+            if (pa != kSegBias) atomicAdd(sc, (int32_t)(pa - kSegBias));
+            if (pb != kSegBias) atomicAdd(sc + 1, (int32_t)(pb - kSegBias));
+        }
+    }
+}
+
 // atan2 with a degree-8 minimax atan on [0,1] (max abs error 1e-7), octant fix-up; atan2(0,0) = 0
 __device__ __forceinline__ float fast_atan2(float y, float x)
 {
@@ -1373,7 +1558,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct RayLayout {
     size_t stream, bounds, lists, list_len, zeroed, zeroed_bytes, leaf_cnt, leaf_fill, count, leaf_off, tiles, body, pairs,
-        stats, fans, total;
+        stats, fans, qrec, ranges, total;
     int T, qblocks, cap, max_tiles, workers, columns;
     size_t seg_count;        // per-segment crossing counts of the vertices (models with seg_elem_mask), zeroed with `count`
 };
@@ -1713,6 +1898,8 @@ static RayLayout full_layout(const tuch_contact_model* m, int B, int Q, bool ver
     l.pairs = tuch_ws_take(o, (size_t)B * l.cap * sizeof(int32_t));
     l.stats = tuch_ws_take(o, 256);
     l.fans = verts ? tuch_ws_take(o, (size_t)B * l.qblocks * kRayQueries * sizeof(float2)) : 0;
+    l.qrec = verts ? tuch_ws_take(o, (size_t)B * l.qblocks * kRayQueries * sizeof(QRec)) : 0;
+    l.ranges = verts ? tuch_ws_take(o, (size_t)B * l.qblocks * 4 * sizeof(float4)) : 0;
     l.total = o;
     return l;
 }
@@ -1733,28 +1920,42 @@ size_t tuch_ray_workspace_bytes(const tuch_contact_model* m, int B, int Q)
 // where the vertices' closing fans are computed (option ray_fans): 1 by workgroups of the chain's first launch, 2 of
 // ray_near_kernel's, 0 (and meshes without rings, or whose leaf runs do not tile the stream) inside the finalize kernel
 static bool fans_in_bounds_launch(const tuch_contact_model* m) { return m->ring_off && m->opt.ray_fans == 1 && m->tree_leaf_runs_tile; }
-static bool fans_in_near_launch(const tuch_contact_model* m) { return m->ring_off && m->opt.ray_fans == 2; }
+static bool cross_in_one_launch(const tuch_contact_model* m);
+static bool fans_in_near_launch(const tuch_contact_model* m) { return m->ring_off && m->opt.ray_fans == 2 && !cross_in_one_launch(m); }
+
+// the vertices' inside test with its middle as one launch (ray_cross_kernel; option ray_cross, default on): slots must fit
+// the 24-bit field of QRec::tag
+static bool cross_in_one_launch(const tuch_contact_model* m)
+{
+    return m->opt.ray_cross != 0 && 2L * m->tree_qblocks * kRayQueries < kNoSlot;
+}
 
 // sheared leaf strips and the slabs of every LEAF (inner nodes are not used by the flat near test)
 static void launch_ray_boxes(const tuch_contact_model* m, const RayLayout& l, const float* verts, int B, char* ws, hipStream_t s,
-                             bool one_launch)
+                             bool one_launch, bool query_side = false)
 {
     RayElem* st = (RayElem*)(ws + l.stream);
     float* bounds = (float*)(ws + l.bounds);
+    const RayPre pre{query_side ? ceil_div(l.qblocks, kBoundsBlock / 64) : 0, l.qblocks, (QRec*)(ws + l.qrec), (float4*)(ws + l.ranges),
+                     (const int32_t*)m->seg_vmask};
     // one launch: every leaf poses its own run of the strip.  (Not for the points form with its far larger span of
     // counters to clear -- [B][Q] with Q = all HD points: the leaf grid has too few workgroups for that, 100 us)
     if (one_launch && m->tree_leaf_runs_tile) {
         const int leaf_blocks = ceil_div(m->tree_leaves, kBoundsBlock / 16);
         const bool fans = fans_in_bounds_launch(m);
-        hipLaunchKernelGGL(ray_leaf_bounds_kernel<true>, dim3(leaf_blocks + (fans ? ceil_div(m->V, kBoundsBlock) : 0), B), dim3(kBoundsBlock), 0,
+        hipLaunchKernelGGL(ray_leaf_bounds_kernel<true>, dim3(leaf_blocks + (fans ? ceil_div(m->V, kBoundsBlock) : 0) + pre.blocks, B),
+                           dim3(kBoundsBlock), 0,
                            s, (const RayElem*)st, l.T, (const TreeNode*)m->tree_node, m->tree_nodes,
                            (const int32_t*)m->tree_height_off, (const int32_t*)m->tree_height_nodes, bounds, verts,
                            (const int32_t*)m->tree_vidx, (const float*)m->tree_sign_word, m->V, m->tree_exact_len, st,
                            (uint4*)(ws + l.zeroed), l.zeroed_bytes / sizeof(uint4), fans ? leaf_blocks : 0,
                            (const int32_t*)m->tree_qperm, (const int32_t*)m->ring_off, (const int32_t*)m->ring_vidx,
-                           (float2*)(ws + l.fans), l.qblocks * kRayQueries);
+                           (float2*)(ws + l.fans), l.qblocks * kRayQueries, pre);
         return;
     }
+    if (query_side)
+        hipLaunchKernelGGL(ray_prepass_kernel, dim3(pre.blocks, B), dim3(kBoundsBlock), 0, s, verts, (const int32_t*)m->tree_vidx,
+                           (const int32_t*)m->tree_qperm, m->V, pre);
     hipLaunchKernelGGL(ray_stream_kernel, dim3(ceil_div(l.T, kBlock), B), dim3(kBlock), 0, s, verts,
                        (const int32_t*)m->tree_vidx, (const float*)m->tree_sign_word, m->V, m->tree_exact_len, l.T, st,
                        (uint4*)(ws + l.zeroed), l.zeroed_bytes / sizeof(uint4));
@@ -1770,9 +1971,24 @@ template <bool kVerts>
 static int launch_ray_counts(const tuch_contact_model* m, const RayLayout& l, const float* verts, const float* queries,
                              const int32_t* counts, int B, int Q, char* ws, hipStream_t s, unsigned long long* stats)
 {
-    launch_ray_boxes(m, l, verts, B, ws, s, kVerts);  // clears the counters (l.zeroed) as well
+    const bool one = kVerts && !stats && cross_in_one_launch(m);
+    launch_ray_boxes(m, l, verts, B, ws, s, kVerts, one);  // clears the counters (l.zeroed) as well
     const int L = m->tree_leaves;
     const TreeNode* nodes = (const TreeNode*)m->tree_node;
+    if (one) {
+        const int columns = B < 8 ? B : 8;
+        const dim3 grid(columns, ceil_div(B, columns) * L);
+        int32_t* seg_cnt = (int32_t*)(ws + l.seg_count);
+        if (m->seg_elem_mask)
+            hipLaunchKernelGGL(ray_cross_kernel<true>, grid, dim3(64), 0, s, (const RayElem*)(ws + l.stream), nodes, (const float*)(ws + l.bounds), L,
+                               (const int32_t*)nullptr, (const QRec*)(ws + l.qrec), (const float4*)(ws + l.ranges), l.T, l.qblocks, B,
+                               (int32_t*)(ws + l.count), seg_cnt);
+        else
+            hipLaunchKernelGGL(ray_cross_kernel<false>, grid, dim3(64), 0, s, (const RayElem*)(ws + l.stream), nodes, (const float*)(ws + l.bounds), L,
+                               (const int32_t*)nullptr, (const QRec*)(ws + l.qrec), (const float4*)(ws + l.ranges), l.T, l.qblocks, B,
+                               (int32_t*)(ws + l.count), seg_cnt);
+        return TUCH_OK;
+    }
     // the leaves are the height-0 entries of the tree's height table (tree_height_off_host[0] == 0)
     const int32_t* leaf_nodes = (const int32_t*)m->tree_height_nodes;
     const int32_t* qperm = kVerts ? (const int32_t*)m->tree_qperm : nullptr;

@@ -65,12 +65,23 @@ def off_default_stream(device):
 
 
 def deterministic() -> bool:
-    """Deterministic mode of the library (include/tuch_amd.h: tuch_set_deterministic; TUCH_DETERMINISTIC=1)."""
+    """Deterministic mode of the library (include/tuch_amd.h: tuch_set_deterministic): on unless TUCH_DETERMINISTIC=0."""
     return bool(_C.lib().tuch_get_deterministic())
 
 
+@contextlib.contextmanager
+def deterministic_mode(on: bool):
+    """``with ops.deterministic_mode(False): ...`` -- the mode for the calls inside, the previous one restored after."""
+    before = deterministic()
+    set_deterministic(on)
+    try:
+        yield
+    finally:
+        set_deterministic(before)
+
+
 def set_deterministic(on: bool) -> None:
-    """Gradient scatters through 64-bit fixed-point integer atomics instead of float atomics: an SMPLify-DC fit reproduces
+    """True (the default): gradient scatters through 64-bit fixed-point integer atomics instead of float atomics: an SMPLify-DC fit reproduces
     bit for bit (stage-2 tail, SMPL adjoint, the training loss's plain term -- _ContactTerms -- and its HD term).
     Graphs captured before the switch keep the mode they were captured in."""
     _C.lib().tuch_set_deterministic(int(bool(on)))
