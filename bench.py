@@ -252,7 +252,7 @@ def launch_ranks(args):
 def synthetic_body(topology='uv'):
     """'uv': the lat-long sphere warped into a humanoid (V=6890, F=13776: the headline); 'ico': the irregular one
     (geodesic icosahedron + edge flips: V=6762, valence 4-9, painted ragged segments)."""
-    from tuch_amd.synthetic import make_body
+    from synthetic import make_body
     key = 'body' if topology == 'uv' else 'body_' + topology
     if key not in _BODY:
         _BODY[key] = make_body(84, 82, seed=1234) if topology == 'uv' else make_body(topology='ico', freq=26, seed=1234)
@@ -262,7 +262,7 @@ def synthetic_body(topology='uv'):
 def build_problem(batch, device, seed, penetrating_fraction=0.5, folded=False, topology='uv'):
     from tuch_amd.models.smpl import SMPL
     from tuch_amd.smplify.prior import MaxMixturePrior
-    from tuch_amd.synthetic import folded_poses, random_poses
+    from synthetic import folded_poses, random_poses
     from tuch_amd.utils.geometry import perspective_projection
     from tuch_amd.utils.segmentation import BatchBodySegment
     body = synthetic_body(topology)
@@ -435,14 +435,14 @@ def make_train_step(p, use_hd, smplify_iters=0, fresh=None):
 def make_tuch_step(p, run_smplify, smplify_iters=10, seed=77):
     """BASELINE configs[3] / [4] per-rank step: the whole TUCH.forward_train_step (tuch/train/train_module.py:105-335,
     restated in tuch_amd/train/train_module.py and pinned to the reference's own output by tests/test_gpu_train_step.py)
-    + backward.  The HMR / SPIN regressors are small deterministic stand-ins (tuch_amd.synthetic.make_regressor): the
+    + backward.  The HMR / SPIN regressors are small deterministic stand-ins (synthetic.make_regressor): the
     ResNet-50 is stock PyTorch and not part of the path; everything downstream of its output is the real step --
     SMPL with rotation matrices, rotation matrix -> axis-angle, estimate_translation, the dictionary of best fits,
     contact_from_verts, [SMPLify-DC in the loop with contact], RegressorLoss with the HD contact term."""
     import tempfile
     import types
     from tuch_amd.smplify.smplifydc import SMPLifyDC
-    from tuch_amd.synthetic import make_regressor, make_train_batch
+    from synthetic import make_regressor, make_train_batch
     from tuch_amd.train.train_module import TUCH
     batch = p['body_pose'].shape[0]
     dev = p['body_pose'].device
@@ -880,7 +880,7 @@ def kernels_per_step(step):
 def worst_case(device, seed, batch, folded=False):
     """All bodies self-penetrating (arm across the torso, legs together) instead of half of them; folded: a third with a
     forearm THROUGH the trunk, a third with the legs crossed through each other, a third folded over the thighs
-    (tuch_amd.synthetic.folded_poses) -- where the near-leaf lists and the pair list grow."""
+    (synthetic.folded_poses) -- where the near-leaf lists and the pair list grow."""
     from tuch_amd.smplify.losses import contact_model_for
     p = build_problem(batch, device, seed, penetrating_fraction=1.0, folded=folded)
     ms = time_kernel(capture(make_step(p), 3), 20) * 1e3

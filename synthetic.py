@@ -737,7 +737,7 @@ def write_reference_assets(body: SyntheticBody, root: str, with_extra_vertex_ids
     Returns the written paths by config name."""
     import os
     import pickle
-    from .models.smpl import SPIN_JOINT_NAMES
+    from tuch_amd.models.smpl import SPIN_JOINT_NAMES
     if with_extra_vertex_ids is None:
         with_extra_vertex_ids = body.num_verts != 6890
     j = lambda *p: os.path.join(root, *p)

@@ -39,7 +39,7 @@ import torch
 
 import golden_io as gio
 from oracle import lbs as olbs
-from tuch_amd.synthetic import dense_hd_regressor, make_body, random_poses, through_pose
+from synthetic import dense_hd_regressor, make_body, random_poses, through_pose
 
 torch.cuda.LongTensor = torch.LongTensor  # F7 shim
 torch.manual_seed(0)

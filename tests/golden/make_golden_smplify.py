@@ -48,7 +48,7 @@ import torch.nn as nn
 import golden_io as gio
 from oracle import lbs as olbs
 from tuch_amd.models.smpl import SPIN_JOINT_NAMES
-from tuch_amd.synthetic import make_body, random_poses
+from synthetic import make_body, random_poses
 
 torch.cuda.LongTensor = torch.LongTensor
 _STATE = {'body': None}

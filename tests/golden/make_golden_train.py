@@ -14,7 +14,7 @@ Stubs (the packages are absent here and not vendored):
     torch, runs on CPU);
   * ``cv2``: only ``cv2.Rodrigues(R)`` is used (fits_dict.py:115-117): stood in by scipy's
     ``Rotation.from_matrix(R).as_rotvec()``, an independent implementation of the same function;
-  * the two regressors (HMR, SPIN) are tuch_amd.synthetic.make_regressor stand-ins, the datasets object only carries
+  * the two regressors (HMR, SPIN) are synthetic.make_regressor stand-ins, the datasets object only carries
     ``dataset_dict`` / ``datasets`` (all that FitsDict reads);
   * F7 shims: torch.cuda.LongTensor, contact_fitting_loss(device='cpu'), SMPLifyDC(device='cpu').
 """
@@ -42,7 +42,7 @@ from scipy.spatial.transform import Rotation
 from oracle import geometry as ogeo
 from oracle import lbs as olbs
 from tuch_amd.models.smpl import SPIN_JOINT_NAMES
-from tuch_amd.synthetic import dense_hd_regressor, make_body, make_regressor, make_train_batch
+from synthetic import dense_hd_regressor, make_body, make_regressor, make_train_batch
 from tuch_amd.train.fits_dict import SMPL_JOINTS_FLIP_PERM, SMPL_POSE_FLIP_PERM
 from tuch_amd.utils import geometry as our_geometry
 

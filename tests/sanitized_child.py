@@ -49,7 +49,7 @@ def tables_part():
     from tuch_amd import lbs
     from tuch_amd.models.smpl import SMPL
     from tuch_amd.ops import ContactModel, HDModel
-    from tuch_amd.synthetic import make_body
+    from synthetic import make_body
     assert os.environ.get('TUCH_HOST_TABLES') == '1'
     dev = torch.device('cpu')
     for tag in ('small', 'ico_small', 'medium', 'ico_medium', 'full', 'ico_full'):

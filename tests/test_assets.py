@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from tuch_amd import assets
-from tuch_amd.synthetic import dense_hd_regressor, make_body
+from synthetic import dense_hd_regressor, make_body
 
 
 def _write_ply(path, verts, red, binary):

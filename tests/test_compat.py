@@ -188,7 +188,7 @@ def test_reference_script_import_blocks_run_after_install(tmp_path, script, firs
     that are absent here and for nothing else; data/ is the synthetic tree in the reference's formats."""
     import importlib
     import tuch_amd.compat as compat
-    from tuch_amd.synthetic import make_body, write_reference_assets
+    from synthetic import make_body, write_reference_assets
     write_reference_assets(make_body(10, 12), str(tmp_path))
     saved = _purge(('tuch', 'configs', 'data', 'torchgeometry') + tuple(t.split('.')[0] for t in _THIRD_PARTY
                                                                          if t.split('.')[0] != 'torch'))

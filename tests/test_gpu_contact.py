@@ -1234,7 +1234,7 @@ def test_segment_filter_by_ray_crossings_matches_the_solid_angle_sums(tag, monke
 def test_ray_crossing_flags_at_rest_pose_and_axis_aligned():
     """Degenerate input: the symmetric template itself, unposed and axis aligned (many exactly equal coordinates,
     rays through edges and vertices: the tie rules decide) and a mirrored copy (orientation reversed: w = -...)."""
-    from tuch_amd.synthetic import make_body
+    from synthetic import make_body
     body = make_body(40, 40)
     from tuch_amd.ops import ContactModel
     model = ContactModel(body.faces, None, None, None, None, device=dev())

@@ -7,7 +7,7 @@ import torch
 from helpers import assert_close
 from oracle import contact as oc
 from oracle import lbs as ol
-from tuch_amd.synthetic import make_body, random_poses
+from synthetic import make_body, random_poses
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'

@@ -10,7 +10,7 @@ import golden_io as gio
 from helpers import assert_close, close_logged, golden, golden_mask, oracle_segments, region_pair_lists
 from oracle import contact as oc
 from oracle import lbs as ol
-from tuch_amd.synthetic import make_body, random_poses
+from synthetic import make_body, random_poses
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'

@@ -9,7 +9,7 @@ import torch
 
 import golden_io as gio
 from helpers import assert_close, close_logged
-from tuch_amd.synthetic import make_body, make_regressor
+from synthetic import make_body, make_regressor
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device('cuda:0')

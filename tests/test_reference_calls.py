@@ -9,7 +9,7 @@ demo_smplify_dc.py:54-87, fit_eft.py:48-73):
     segments = BatchBodySegment([x for x in exn.segments.keys()], face_tensor[0])
 
 i.e. with nothing but paths from configs.config; every asset is loaded inside the constructors.  These tests
-write a synthetic data/ tree in the reference's file formats (tuch_amd.synthetic.write_reference_assets), make
+write a synthetic data/ tree in the reference's file formats (synthetic.write_reference_assets), make
 it the working directory, map the package onto the reference's module paths (compat.install) and run those
 calls as the scripts spell them.  CPU: construction + the loaded tables (no GPU needed: the device copy is made on
 first use; SMPLifyDC gets device= because its default is 'cuda').  GPU: the same calls verbatim and then the
@@ -24,7 +24,7 @@ import numpy as np
 import pytest
 import torch
 
-from tuch_amd.synthetic import make_body, write_reference_assets
+from synthetic import make_body, write_reference_assets
 
 
 class _Tree:
@@ -144,7 +144,7 @@ def test_reference_calls_verbatim_on_the_gpu(tmp_path):
     loaded from files) equals the one built from injected arrays, and a short SMPLifyDC fit runs."""
     from tuch_amd.train.loss import RegressorLoss as Injected
     from tuch_amd.utils.segmentation import BatchBodySegment as InjectedSegments
-    from tuch_amd.synthetic import random_poses
+    from synthetic import random_poses
     body = make_body(14, 16, relax_iters=40)
     dev = torch.device('cuda:0')
     batch = 3

@@ -6,7 +6,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
-from tuch_amd.synthetic import make_body, random_poses
+from synthetic import make_body, random_poses
 from tuch_amd import ops
 from oracle import lbs as olbs
 

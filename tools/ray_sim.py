@@ -2,7 +2,7 @@
 (vs the solid-angle tree walk's leaf + cap elements)?  Uses the model's cluster tree and oracle-posed bodies."""
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from tuch_amd.synthetic import make_body, random_poses
+from synthetic import make_body, random_poses
 from tuch_amd import ops
 from oracle import lbs as ol
 body = make_body(84, 82)

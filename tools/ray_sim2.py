@@ -2,7 +2,7 @@
 frame (the one closest to the block's mean outward normal); 9-slab ray/volume tests."""
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from tuch_amd.synthetic import make_body, random_poses
+from synthetic import make_body, random_poses
 from tuch_amd import ops
 from oracle import lbs as ol
 body = make_body(84, 82)

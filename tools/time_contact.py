@@ -1,6 +1,6 @@
 import sys, time; sys.path.insert(0,'tests'); sys.path.insert(0,'.')
 import numpy as np, torch
-from tuch_amd.synthetic import make_body, random_poses
+from synthetic import make_body, random_poses
 from tuch_amd import ops
 from oracle import lbs as ol
 dev=torch.device('cuda:0')

@@ -1,6 +1,6 @@
 import sys, numpy as np, torch
 sys.path.insert(0, '.')
-from tuch_amd.synthetic import make_body, random_poses
+from synthetic import make_body, random_poses
 from tuch_amd import ops
 from oracle import lbs as ol, contact as oc
 body = make_body()

@@ -10,7 +10,7 @@ and then does what the reference + smplx do between them: SMPL_{GENDER}.pkl from
 directory, ``J_regressor_extra`` from ``config.JOINT_REGRESSOR_TRAIN_EXTRA`` and the joint map
 from ``constants.JOINT_MAP / JOINT_NAMES`` (tuch/models/smpl.py:37-42), the 21 picked vertices
 from smplx's vertex-id table.  ``model_data=`` takes already loaded arrays instead (e.g.
-tuch_amd.synthetic.SyntheticBody).  Returns the same ``ModelOutput``.
+synthetic.SyntheticBody).  Returns the same ``ModelOutput``.
 """
 from __future__ import annotations
 
