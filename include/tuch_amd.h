@@ -197,10 +197,13 @@ int tuch_smplify_stage2_fused(const float* points, const int32_t* partner, const
  * tuch_smplify_stage2_fused (contact terms, region minima) and of tuch_smpl_backward (skinning adjoint) accumulate 64-bit
  * fixed-point numbers (2^-36) with integer atomics instead of floats -- sums that do not depend on the order of arrival,
  * so an SMPLify-DC fit reproduces bit for bit.  tuch_smplify_stage2_fused then wants grad_fixed_zeroed = B*N*3 zeroed
- * 64-bit words (NULL: float atomics, whatever the mode) and converts to grad_points with a second launch.
+ * 64-bit words (NULL: float atomics, whatever the mode) and converts to grad_points with a second launch; with
+ * grad_points = NULL the accumulators are the result (see g_verts_fixed of tuch_smpl_backward_split_add).
  * VALID RANGE of the fixed-point sums: |sum| < 2^27 = 1.3e8 (beyond, the unsigned 64-bit accumulator wraps silently) and
  * contributions below 2^-37 = 7e-12 round to zero.  Gradient magnitudes scale with contact_scale / r2r_scale: with the
  * reference's weights (10, 2000) and metre-scale bodies the per-vertex gradients are < 1e5. */
+/* n fixed-point sums -> floats (what tuch_smplify_stage2_fused does itself when grad_points is given) */
+int tuch_fixed_to_float(const void* fixed, size_t n, float* out, void* stream);
 void tuch_set_deterministic(int on);
 int tuch_get_deterministic(void);
 
@@ -399,7 +402,10 @@ int tuch_smpl_backward_split_add(const tuch_smpl_model* model, const float* glob
                                  const void* fwd_workspace, const float* g_verts, const float* g_joints, float* g_betas,
                                  float* g_global_orient, int g_global_orient_stride, float* g_body_pose,
                                  int g_body_pose_stride, const float* g_body_pose_add, int g_body_pose_add_stride,
-                                 void* workspace, size_t workspace_bytes, void* stream);
+                                 void* workspace, size_t workspace_bytes, void* stream, const void* g_verts_fixed);
+/* g_verts_fixed (here and in tuch_smpl_backward_split_adam; or NULL): [B,V,3] 64-bit fixed-point sums (2^-36, the accumulators
+ * tuch_smplify_stage2_fused leaves when it is called with grad_points = NULL in deterministic mode) ADDED to g_verts where the
+ * skinning adjoint reads it -- the stage-2 tail's vertex gradient without a conversion launch on the step's serial tail. */
 /* tuch_smpl_backward_split_add (axis-angle poses) + torch.optim.Adam's update (tuch_adam_step's arithmetic) of the two pose
  * tensors themselves, applied by the last backward kernel to the rows whose gradient it has just written: for a fit whose
  * optimiser holds exactly [global_orient, body_pose] and whose whole gradient arrives through this call (SMPLify-DC stage 2,
@@ -416,7 +422,7 @@ int tuch_smpl_backward_split_adam(const tuch_smpl_model* model, const float* glo
                                   int param_body_pose_stride, float* exp_avg_global_orient, float* exp_avg_sq_global_orient,
                                   float* exp_avg_body_pose, float* exp_avg_sq_body_pose, float* step, int* ticket,
                                   float lr, float beta1, float beta2, float eps,
-                                  void* workspace, size_t workspace_bytes, void* stream);
+                                  void* workspace, size_t workspace_bytes, void* stream, const void* g_verts_fixed);
 
 /* ---- caller-side glue of the training step ----------------------------------------
  * tuch_estimate_translation: tuch/utils/geometry.py:114-205 (estimate_translation + estimate_translation_np):

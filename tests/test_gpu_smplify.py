@@ -563,3 +563,65 @@ def test_stage1_objective_in_one_launch_vs_reference_and_torch_ops(shape_w):
             assert_close(gb1, gb0, 1e-5, 1e-7, 'grad betas')
         else:
             assert gb1 is None or not gb1.any()
+
+
+def test_fixed_point_vertex_gradient_reaches_every_kind_of_backward_pass():
+    """Deterministic mode (the default): the stage-2 node leaves its vertex gradient in 64-bit fixed-point accumulators and
+    the body model's skinning adjoint reads them there -- no conversion launch in a fit's `objective.backward()`.  Every
+    other way of asking gets the same numbers: loss.backward() (not through ops.backward_scalar), a scaled loss, the
+    gradient of the vertices themselves (torch.autograd.grad / retain_grad), a loss with a further term."""
+    from tuch_amd import ops
+    from tuch_amd.smplify.losses import contact_fitting_loss
+    batch = 3
+    s = _setup(batch, 41)
+    body, t = s['body'], s['t']
+    gm = t(body.geodesics > 0.3)
+    face_tensor = t(body.faces)[None].repeat(batch, 1, 1)
+    assert ops.deterministic()
+
+    def graph(retain=False):
+        bp = t(s['bp']).requires_grad_(True)
+        go = t(s['go']).requires_grad_(True)
+        out = s['smpl'](global_orient=go, body_pose=bp, betas=t(s['be']))
+        if retain:
+            out.vertices.retain_grad()
+        loss = contact_fitting_loss(bp, go, None, None, t(s['be']), out.joints, gm, 0.02, t(s['cam_t']),
+                                    torch.zeros(batch, 2, device=DEV), t(s['kp'][:, :, :2]), t(s['kp'][:, :, 2]),
+                                    s['prior'], s['cdict'], [t(s['gt']), None],
+                                    torch.zeros(batch, dtype=torch.bool, device=DEV),
+                                    torch.ones(batch, dtype=torch.bool, device=DEV), out.vertices,
+                                    face_tensor=face_tensor, contact_loss_weight=2000.0, segments=s['segments'])
+        return bp, go, out, loss
+    with ops.off_default_stream(DEV):
+        bp, go, _, loss = graph()
+        ops.backward_scalar(loss)                                   # the fit's pass: accumulators handed to the body model
+        want_bp, want_go = bp.grad.clone(), go.grad.clone()
+        assert float(want_bp.abs().max()) > 0
+        bp, go, _, loss = graph()
+        loss.backward()                                             # a plain backward: converted, the same bits
+        assert torch.equal(bp.grad, want_bp) and torch.equal(go.grad, want_go)
+        bp, go, _, loss = graph()
+        ops.backward_scalar(loss)                                   # ... and twice the same (bit-reproducible)
+        assert torch.equal(bp.grad, want_bp) and torch.equal(go.grad, want_go)
+        bp, go, _, loss = graph()
+        (3.0 * loss).backward()                                     # a scaled upstream gradient
+        assert_close(bp.grad.cpu().numpy(), 3.0 * want_bp.cpu().numpy(), 1e-5, 1e-6 * float(want_bp.abs().max()), 'scaled')
+        # the vertices' own gradient: real numbers, not the carrier of zeros -- and they give the same pose gradient
+        bp, go, out, loss = graph()
+        gv, = torch.autograd.grad(loss, out.vertices, retain_graph=True)
+        assert float(gv.abs().max()) > 0
+        bp2, go2, out2, loss2 = graph(retain=True)
+        ops.backward_scalar(loss2)
+        assert torch.equal(out2.vertices.grad, gv)
+        assert torch.equal(bp2.grad, want_bp) and torch.equal(go2.grad, want_go)
+        with ops.deterministic_mode(False):
+            bp3, go3, out3, loss3 = graph(retain=True)
+            ops.backward_scalar(loss3)
+        assert_close(out3.vertices.grad.cpu().numpy(), gv.cpu().numpy(), 1e-4, 1e-6 * float(gv.abs().max()), 'fixed vs float atomics')
+        # a further term on the vertices: autograd adds its gradient to the carrier, the adjoint adds the accumulators
+        bp, go, out, loss = graph()
+        extra = (out.vertices ** 2).sum()
+        ops.backward_scalar(loss + extra)
+        bp4, go4, out4, _ = graph()
+        (out4.vertices ** 2).sum().backward()
+        assert_close(bp.grad.cpu().numpy(), (want_bp + bp4.grad).cpu().numpy(), 1e-5, 1e-6 * float(want_bp.abs().max()), 'with a further term')

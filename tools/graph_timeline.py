@@ -16,6 +16,13 @@ def run():
             fn()
         torch.cuda.synchronize()
         return
+    if len(sys.argv) > 2 and sys.argv[2] in ('hdg', 'plaing'):  # the train.py-style contact step captured and replayed
+        p = bench.build_problem(64, dev, 1002)
+        fn = bench.capture(bench.make_train_step(p, sys.argv[2] == 'hdg'), 3)
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        return
     p = bench.build_problem(int(sys.argv[2]) if len(sys.argv) > 2 else 64, dev, 1002)
     fn = bench.capture(bench.make_step(p), 3)
     for _ in range(5):

@@ -49,7 +49,7 @@ _SIGNATURES = {
     'tuch_smpl_backward_split_adam': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
                                               c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                              c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_size_t, c_void_p]),
+                                              c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_size_t, c_void_p, c_void_p]),
     'tuch_contact_terms_bwd_fixed': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                              c_void_p, c_void_p, c_void_p]),
     'tuch_smplify_small_terms': (c_int, [c_void_p] * 9 + [c_int, c_int, c_int, c_float, c_float, c_float] + [c_void_p] * 5),
@@ -145,7 +145,8 @@ _SIGNATURES = {
                                          c_void_p]),
     'tuch_smpl_backward_split_add': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
-                                             c_size_t, c_void_p]),
+                                             c_size_t, c_void_p, c_void_p]),
+    'tuch_fixed_to_float': (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
     'tuch_region_pair_min_bwd': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 

@@ -366,11 +366,13 @@ __global__ __launch_bounds__(kFusedBlock) void stage2_fused_kernel(
     // other in the L2 -- the block that arrived last was 19 us behind the first (tools/diag/stage2_clocks.py).  A
     // direct-mapped table of kPartnerSlots partners per block; a partner whose slot is taken goes to memory as before.
     constexpr int kPartnerSlots = 256;
+    // (deterministic mode: the same table with 64-bit fixed-point cells -- integer sums, so which contributions meet in LDS
+    // and which go to memory does not change the result; without it the mode paid the queueing again, +10 us per step)
     __shared__ int p_tag[kPartnerSlots];
-    __shared__ float p_acc[kPartnerSlots][3];
-    const bool in_lds = gb && !fb;
+    __shared__ long long p_acc[kPartnerSlots][3];       // float mode: the low words hold the float sums
+    const bool in_lds = want;
     if (in_lds) {
-        for (int k = threadIdx.x; k < kPartnerSlots; k += kFusedBlock) { p_tag[k] = -1; p_acc[k][0] = p_acc[k][1] = p_acc[k][2] = 0.0f; }
+        for (int k = threadIdx.x; k < kPartnerSlots; k += kFusedBlock) { p_tag[k] = -1; p_acc[k][0] = p_acc[k][1] = p_acc[k][2] = 0; }
         __syncthreads();
     }
     auto add3_partner = [&](int at, float x, float y, float z) {
@@ -378,7 +380,11 @@ __global__ __launch_bounds__(kFusedBlock) void stage2_fused_kernel(
             const int slot = at & (kPartnerSlots - 1);
             const int old = atomicCAS(&p_tag[slot], -1, at);
             if (old == -1 || old == at) {
-                atomicAdd(&p_acc[slot][0], x); atomicAdd(&p_acc[slot][1], y); atomicAdd(&p_acc[slot][2], z);
+                if (fb) { fixed_add(&p_acc[slot][0], x); fixed_add(&p_acc[slot][1], y); fixed_add(&p_acc[slot][2], z); }
+                else {
+                    atomicAdd(reinterpret_cast<float*>(&p_acc[slot][0]), x); atomicAdd(reinterpret_cast<float*>(&p_acc[slot][1]), y);
+                    atomicAdd(reinterpret_cast<float*>(&p_acc[slot][2]), z);
+                }
                 return;
             }
         }
@@ -430,8 +436,15 @@ __global__ __launch_bounds__(kFusedBlock) void stage2_fused_kernel(
     STAGE2_CLOCK(2);
     if (in_lds) {
         __syncthreads();
-        for (int k = threadIdx.x; k < kPartnerSlots; k += kFusedBlock)
-            if (p_tag[k] >= 0) add3(p_tag[k], p_acc[k][0], p_acc[k][1], p_acc[k][2]);
+        for (int k = threadIdx.x; k < kPartnerSlots; k += kFusedBlock) {
+            if (p_tag[k] < 0) continue;
+            if (fb) {
+                long long* dst = fb + 3 * (size_t)p_tag[k];
+                for (int c = 0; c < 3; ++c) atomicAdd((unsigned long long*)(dst + c), (unsigned long long)p_acc[k][c]);
+            } else
+                add3(p_tag[k], *reinterpret_cast<float*>(&p_acc[k][0]), *reinterpret_cast<float*>(&p_acc[k][1]),
+                     *reinterpret_cast<float*>(&p_acc[k][2]));
+        }
     }
     if (s == 0 && (r2r || pair_keys)) {
         for (int p = threadIdx.x; p < P; p += kFusedBlock) {
@@ -548,19 +561,30 @@ extern "C" int tuch_smplify_stage2_fused(const float* points, const int32_t* par
     const bool raw = pair_keys != nullptr;
     // deterministic mode (tuch_deterministic(): TUCH_DETERMINISTIC=1 / tuch_set_deterministic): the caller passes B*N*3
     // zeroed 64-bit words; the scatter accumulates fixed-point integers there, a second launch converts to grad_points
-    const bool fixed = grad_points && grad_fixed_zeroed;
+    // grad_points NULL with grad_fixed_zeroed given: the accumulators are the result (no conversion launch -- the consumer
+    // reads them: tuch_smpl_backward_split_add's g_verts_fixed; tuch_fixed_to_float converts on demand)
+    const bool fixed = grad_fixed_zeroed != nullptr;
     hipLaunchKernelGGL(stage2_fused_kernel, dim3(kFusedSplits, B), dim3(kFusedBlock), 0, (hipStream_t)stream, points, partner,
                        exterior, body_valid, N, mode, euclthres, small_terms, (P > 0 && !raw ? r2r : (const float*)nullptr),
                        (P > 0 && !raw ? ij : (const int32_t*)nullptr), P, contact_scale, r2r_scale, share, ticket, terms, out,
                        fixed ? (float*)nullptr : grad_points, (const unsigned long long*)pair_keys,
                        raw ? (const int32_t*)model->region_off : nullptr, raw ? (const int32_t*)model->region_vidx : nullptr,
                        raw ? (const int32_t*)model->pairs : nullptr, fixed ? (long long*)grad_fixed_zeroed : (long long*)nullptr);
-    if (fixed) {
+    if (fixed && grad_points) {
         const size_t n = (size_t)B * N * 3;
         hipLaunchKernelGGL(fixed_to_float_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                            (const long long*)grad_fixed_zeroed, grad_points, n);
     }
     return tuch_check_launch("tuch_smplify_stage2_fused");
+}
+
+extern "C" int tuch_fixed_to_float(const void* fixed, size_t n, float* out, void* stream)
+{
+    TUCH_REQUIRE(fixed && out, "tuch_fixed_to_float: null pointer");
+    if (n == 0) return TUCH_OK;
+    hipLaunchKernelGGL(fixed_to_float_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const long long*)fixed, out, n);
+    return tuch_check_launch("tuch_fixed_to_float");
 }
 
 // loss.py:317 (and :272): the per-body terms summed over the VALID bodies and divided by their number, as one launch

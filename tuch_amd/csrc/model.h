@@ -42,6 +42,7 @@ struct tuch_options {
     int ray_waves = 32768;      // wavefronts of the crossing kernel
     int ray_fans = 0;           // the vertices' closing fans (they need the vertices only): 0 inside ray_finalize_verts_kernel, 1 by extra workgroups of the inside test's FIRST launch (ray_leaf_bounds_kernel), 2 of ray_near_kernel's launch.  Round 5, batch 64: 0.427 / 0.444 / 0.424 ms per step -- the finalize kernel drops from 28 to 6 - 13 us, but the launch that carries the fans grows by more (1: the search then starts ahead of ray_near, which crawls beside it: 117 us)
     int ray_cross = 0;          // the vertices' inside test: 0 the three launches of rounds 2 - 5 (ray_near -> ray_tiles_fill -> ray_leaf; also what arbitrary points take), 1 near lists, regrouping and crossings in ONE launch (ray_cross_kernel, round 6: one wavefront per (leaf, body), rays gathered in an LDS ring -- no lists, no pair table; 150 us alone against 51 + 24 + 100 and 6.1e7 against 6.5e7 vector instructions at batch 64, but the replayed step is 0.412 against 0.410 ms there -- the step's middle is bound by the SUM of the vector work of this test and of the search beside it, not by the chain -- and 0.214 against 0.176 ms at batch 8, where 3440 long one-wave chains are fewer than the chip's wave slots)
+    int ray_cross_split = 0;    // ray_cross_kernel: wavefronts that share a leaf's query blocks (0: 4 up to batch 8, 2 up to 32, else 1)
     int v2v_tree = 1;           // 0: flat nearest-vertex search
     int v2v_waves = 0;          // frontier choice of the search (wavefronts aimed at; 0: the form's own default)
     int v2v_flat = 2;           // search: 2 lanes over a subtree's leaves first (v2v_scan_kernel), 0 the stackless walk (v2v_tree_kernel)

@@ -965,16 +965,16 @@ constexpr int kCrossRing = 256, kCrossTrip = 3;
 template <bool kSeg>
 __global__ __launch_bounds__(64) void ray_cross_kernel(
     const RayElem* __restrict__ stream, const TreeNode* __restrict__ nodes, const float* __restrict__ bounds, int num_leaves,
-    const int32_t* __restrict__ leaf_order,       // or nullptr: leaves in this order (heaviest first)
+    int nsplit,                                   // wavefronts that share a leaf: wavefront z takes the query blocks z, z + nsplit, ...
     const QRec* __restrict__ qrec, const float4* __restrict__ ranges, int T, int qblocks, int num_bodies,
     int32_t* __restrict__ count, int32_t* __restrict__ seg_count)
 {
     __shared__ QRec ring[kCrossRing];
     const int lane = threadIdx.x;
-    const int b = blockIdx.x + gridDim.x * (blockIdx.y / num_leaves);
+    const int unit = blockIdx.y / nsplit, z = blockIdx.y % nsplit;
+    const int b = blockIdx.x + gridDim.x * (unit / num_leaves);
     if (b >= num_bodies) return;
-    const int li = blockIdx.y % num_leaves;
-    const int leaf = leaf_order ? leaf_order[li] : li;
+    const int leaf = unit % num_leaves;
     const uint4* recs = reinterpret_cast<const uint4*>(bounds + near_records_at(num_bodies, num_leaves)) + ((size_t)b * num_leaves + leaf) * 2;
     const uint4 s0 = recs[0], s1 = recs[1];
     const float4 ctr = *reinterpret_cast<const float4*>(bounds + near_centres_at(num_bodies, num_leaves) + (size_t)b * 4);
@@ -983,6 +983,7 @@ __global__ __launch_bounds__(64) void ray_cross_kernel(
     const RayElem* st = stream + (size_t)b * T;
     const QRec* qb_base = qrec + (size_t)b * qblocks * kRayQueries;
     const float4* rg = ranges + (size_t)b * qblocks * 4;
+    const int mine = qblocks > z ? (qblocks - z + nsplit - 1) / nsplit : 0;      // own query blocks: z + nsplit j, j < mine
     // > 0: outside some slab (ray_near_kernel's test, word for word)
     auto outside13 = [&](float x1, float x0, float y1, float y0, float p1, float p0, float m1, float m0, float z0, float xz0,
                          float xz1, float yz0, float yz1) {
@@ -998,67 +999,83 @@ __global__ __launch_bounds__(64) void ray_cross_kernel(
         return outside13(rx, rx, ry, ry, rx + ry, rx + ry, rx - ry, rx - ry, rz, rx + rz, rx - rz, ry + rz, ry - rz);
     };
     int head = 0, tail = 0;                       // ring positions (wave-uniform)
-    int base = -64;
-    unsigned long long todo = 0;                  // blocks of the current 64 that passed stage 1 and are not yet tested
-    bool more = true;
+    int base = -64;                               // first of the 64 own blocks `todo` is about
+    unsigned long long todo = 0;                  // own blocks that passed stage 1 and are not yet fetched
+    bool more = true, loaded = false;
+    QRec q[kCrossTrip];                           // the trip in flight: its loads were issued one trip ahead
+    bool have[kCrossTrip];
+#pragma unroll
+    for (int j = 0; j < kCrossTrip; ++j) { q[j] = QRec{0.f, 0.f, 0.f, kNoSlot}; have[j] = false; }
+    auto fetch = [&]() {                          // the next (up to) three passing blocks: one 16-byte load per lane each
+        int k[kCrossTrip];
+#pragma unroll
+        for (int j = 0; j < kCrossTrip; ++j) {
+            have[j] = todo != 0;
+            k[j] = have[j] ? z + nsplit * (base + (int)__builtin_ctzll(todo)) : (j ? k[j - 1] : z);
+            if (have[j]) todo &= todo - 1;
+        }
+#pragma unroll
+        for (int j = 0; j < kCrossTrip; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(qb_base + (size_t)k[j] * kRayQueries + lane);
+            q[j].x = v.x; q[j].y = v.y; q[j].z = v.z; q[j].tag = __float_as_int(v.w);
+        }
+        loaded = true;
+    };
     for (;;) {
-        if (more && tail - head < 64) {
+        if (tail - head < 64 && (more || loaded)) {
+            if (loaded) {
+                // this trip's records are here (or on their way); the NEXT trip's loads go out before they are tested
+                QRec qc[kCrossTrip];
+                bool hc[kCrossTrip];
+#pragma unroll
+                for (int j = 0; j < kCrossTrip; ++j) { qc[j] = q[j]; hc[j] = have[j]; }
+                loaded = false;
+                if (todo) fetch();
+                unsigned long long hit[kCrossTrip];
+#pragma unroll
+                for (int j = 0; j < kCrossTrip; ++j)
+                    hit[j] = __builtin_amdgcn_ballot_w64(hc[j] && (qc[j].tag & kNoSlot) != kNoSlot && !(ray_outside(qc[j]) > 0.0f));
+#pragma unroll
+                for (int j = 0; j < kCrossTrip; ++j) {
+                    if (hit[j]) {
+                        const int pos = tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(hit[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hit[j], 0));
+                        if ((hit[j] >> lane) & 1ull) ring[pos & (kCrossRing - 1)] = qc[j];
+                        tail += __builtin_popcountll(hit[j]);
+                    }
+                }
+                continue;
+            }
             if (!todo) {
                 base += 64;
-                if (base >= qblocks) { more = false; continue; }
-                const int blk = base + lane;
-                const float4* g = rg + (size_t)min(blk, qblocks - 1) * 4;
+                if (base >= mine) { more = false; continue; }
+                const int j = base + lane;
+                const float4* g = rg + (size_t)(z + nsplit * min(j, mine - 1)) * 4;
                 const float4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
                 // (bx0, bx1, by0, by1) (b40, b41, b50, b51) (bz0, b60, b71, b80) (b91): the lower bounds of the record
                 // against the block's largest value, the upper ones against its smallest
-                const bool pass = (blk < qblocks) &
+                const bool pass = (j < mine) &
                                   !(outside13(g0.y, g0.x, g0.w, g0.z, g1.y, g1.x, g1.w, g1.z, g2.x, g2.y, g2.z, g2.w, g3.x) > 0.0f);
                 todo = __builtin_amdgcn_ballot_w64(pass);
                 continue;
             }
-            int k[kCrossTrip];
-            bool have[kCrossTrip];
-#pragma unroll
-            for (int j = 0; j < kCrossTrip; ++j) {
-                have[j] = todo != 0;
-                k[j] = have[j] ? base + (int)__builtin_ctzll(todo) : (j ? k[j - 1] : 0);
-                if (have[j]) todo &= todo - 1;
-            }
-            QRec q[kCrossTrip];
-#pragma unroll
-            for (int j = 0; j < kCrossTrip; ++j) {
-                const float4 v = *reinterpret_cast<const float4*>(qb_base + (size_t)k[j] * kRayQueries + lane);
-                q[j].x = v.x; q[j].y = v.y; q[j].z = v.z; q[j].tag = __float_as_int(v.w);
-            }
-            unsigned long long hit[kCrossTrip];
-#pragma unroll
-            for (int j = 0; j < kCrossTrip; ++j)
-                hit[j] = __builtin_amdgcn_ballot_w64(have[j] && (q[j].tag & kNoSlot) != kNoSlot && !(ray_outside(q[j]) > 0.0f));
-#pragma unroll
-            for (int j = 0; j < kCrossTrip; ++j) {
-                if (hit[j]) {
-                    const int pos = tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(hit[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hit[j], 0));
-                    if ((hit[j] >> lane) & 1ull) ring[pos & (kCrossRing - 1)] = q[j];
-                    tail += __builtin_popcountll(hit[j]);
-                }
-            }
+            fetch();
             continue;
         }
         const int n = min(64, tail - head);
         if (n <= 0) break;
         __builtin_amdgcn_wave_barrier();
         const bool active = lane < n;
-        const QRec q = ring[(head + (active ? lane : 0)) & (kCrossRing - 1)];
+        const QRec w = ring[(head + (active ? lane : 0)) & (kCrossRing - 1)];
         __builtin_amdgcn_wave_barrier();
         head += n;
-        const int slot = q.tag & kNoSlot;
+        const int slot = w.tag & kNoSlot;
         S3 s[3];
         float e[3];
 #pragma unroll
         for (int u = 0; u < 3; ++u) { s[u].xy = (v2f){0.0f, 0.0f}; s[u].z = 0.0f; e[u] = 0.0f; }
         int crossings = 0;
         uint32_t pa = kSegBias, pb = kSegBias;
-        ray_run<true, kSeg>(st, ex_off, ex_len, s, e, (v2f){q.x, q.y}, q.z, crossings, (int)((uint32_t)q.tag >> 24), pa, pb);
+        ray_run<true, kSeg>(st, ex_off, ex_len, s, e, (v2f){w.x, w.y}, w.z, crossings, (int)((uint32_t)w.tag >> 24), pa, pb);
         if (active && crossings != 0) atomicAdd(&count[((size_t)b * qblocks) * kRayQueries + slot], crossings);
         if (kSeg && active && (pa != kSegBias || pb != kSegBias)) {             // few lanes (see ray_leaf_kernel)
             int32_t* sc = seg_count + 2 * (((size_t)b * qblocks) * kRayQueries + slot);
@@ -1977,15 +1994,19 @@ static int launch_ray_counts(const tuch_contact_model* m, const RayLayout& l, co
     const TreeNode* nodes = (const TreeNode*)m->tree_node;
     if (one) {
         const int columns = B < 8 ? B : 8;
-        const dim3 grid(columns, ceil_div(B, columns) * L);
+        // wavefronts per leaf: a leaf through the trunk meets five times the average number of rays -- one wavefront's chain
+        // of ~20 trips and 6 walks is what a small batch waits for (option ray_cross_split, 0: by batch size)
+        int nsplit = m->opt.ray_cross_split > 0 ? m->opt.ray_cross_split : (B <= 8 ? 4 : B <= 32 ? 2 : 1);
+        if (nsplit > l.qblocks) nsplit = l.qblocks;
+        const dim3 grid(columns, ceil_div(B, columns) * L * nsplit);
         int32_t* seg_cnt = (int32_t*)(ws + l.seg_count);
         if (m->seg_elem_mask)
             hipLaunchKernelGGL(ray_cross_kernel<true>, grid, dim3(64), 0, s, (const RayElem*)(ws + l.stream), nodes, (const float*)(ws + l.bounds), L,
-                               (const int32_t*)nullptr, (const QRec*)(ws + l.qrec), (const float4*)(ws + l.ranges), l.T, l.qblocks, B,
+                               nsplit, (const QRec*)(ws + l.qrec), (const float4*)(ws + l.ranges), l.T, l.qblocks, B,
                                (int32_t*)(ws + l.count), seg_cnt);
         else
             hipLaunchKernelGGL(ray_cross_kernel<false>, grid, dim3(64), 0, s, (const RayElem*)(ws + l.stream), nodes, (const float*)(ws + l.bounds), L,
-                               (const int32_t*)nullptr, (const QRec*)(ws + l.qrec), (const float4*)(ws + l.ranges), l.T, l.qblocks, B,
+                               nsplit, (const QRec*)(ws + l.qrec), (const float4*)(ws + l.ranges), l.T, l.qblocks, B,
                                (int32_t*)(ws + l.count), seg_cnt);
         return TUCH_OK;
     }

@@ -527,7 +527,8 @@ __global__ __launch_bounds__(kSkinBlock) void skin_bwd_kernel(
     const float* __restrict__ Jrx,
     const int32_t* __restrict__ extra_ids, const float* __restrict__ v_posed, int N3p, const float* __restrict__ A,
     const float* __restrict__ weights, const float* __restrict__ weights_t, const int32_t* __restrict__ skin_joint,
-    const float* __restrict__ skin_weight, int V, float* __restrict__ g_vposed, float* __restrict__ gA_part)
+    const float* __restrict__ skin_weight, int V, float* __restrict__ g_vposed, float* __restrict__ gA_part,
+    const long long* __restrict__ g_fixed)    // or nullptr: [B,V,3] 64-bit fixed-point sums (common.h) added to g_verts
 {
     __shared__ float sG[kSkinBlock][16];      // per vertex: g_v (x) [v_posed;1], 12 used
     __shared__ int sIds[kPicked];
@@ -545,6 +546,12 @@ __global__ __launch_bounds__(kSkinBlock) void skin_bwd_kernel(
     if (g_verts) {
         const float* gp = g_verts + ((size_t)b * V + vc) * 3;
         g[0] = gp[0]; g[1] = gp[1]; g[2] = gp[2];
+    }
+    if (g_fixed) {
+        // the stage-2 tail's vertex gradient in deterministic mode, read where it is used (a conversion launch of its own was
+        // 5 - 8 us of the step's serial tail); 0 + x = x: with g_verts zero this is fixed_to_float_kernel's value, bit for bit
+        const long long* fp = g_fixed + ((size_t)b * V + vc) * 3;
+        g[0] += fixed_value(fp[0]); g[1] += fixed_value(fp[1]); g[2] += fixed_value(fp[2]);
     }
     float jr[kExtra];
 #pragma unroll
@@ -1205,7 +1212,8 @@ extern "C" int tuch_smpl_backward_split_add(const tuch_smpl_model* m, const floa
                                             const void* fwd_workspace, const float* g_verts, const float* g_joints,
                                             float* g_betas, float* g_global_orient, int g_global_orient_stride,
                                             float* g_body_pose, int g_body_pose_stride, const float* g_body_pose_add,
-                                            int g_body_pose_add_stride, void* workspace, size_t workspace_bytes, void* stream);
+                                            int g_body_pose_add_stride, void* workspace, size_t workspace_bytes, void* stream,
+                                            const void* g_verts_fixed);
 
 // g_verts [B,V,3] and/or g_joints [B,49,3] (either may be NULL) -> g_betas [B,10] and
 // the pose gradient, written as the two tensors of tuch_smpl_forward_split (same shapes, strides in floats).
@@ -1218,7 +1226,7 @@ extern "C" int tuch_smpl_backward_split(const tuch_smpl_model* m, const float* g
 {
     return tuch_smpl_backward_split_add(m, global_orient, global_orient_stride, body_pose, body_pose_stride, pose2rot, B,
                                         fwd_workspace, g_verts, g_joints, g_betas, g_global_orient, g_global_orient_stride,
-                                        g_body_pose, g_body_pose_stride, nullptr, 0, workspace, workspace_bytes, stream);
+                                        g_body_pose, g_body_pose_stride, nullptr, 0, workspace, workspace_bytes, stream, nullptr);
 }
 
 // The same with a gradient the caller already holds for body_pose (g_body_pose_add, same shape, row stride in floats; or
@@ -1229,7 +1237,8 @@ static int backward_impl(const tuch_smpl_model* m, const float* global_orient, i
                          const void* fwd_workspace, const float* g_verts, const float* g_joints,
                          float* g_betas, float* g_global_orient, int g_global_orient_stride,
                          float* g_body_pose, int g_body_pose_stride, const float* g_body_pose_add,
-                         int g_body_pose_add_stride, const PoseAdam& adam, void* workspace, size_t workspace_bytes, void* stream)
+                         int g_body_pose_add_stride, const PoseAdam& adam, void* workspace, size_t workspace_bytes, void* stream,
+                         const void* g_verts_fixed)
 {
     TUCH_REQUIRE(m && global_orient && body_pose && fwd_workspace && g_betas && g_global_orient && g_body_pose,
                  "tuch_smpl_backward: null pointer");
@@ -1256,7 +1265,7 @@ static int backward_impl(const tuch_smpl_model* m, const float* global_orient, i
     hipLaunchKernelGGL(m->skin_joint ? skin_bwd_kernel<true> : skin_bwd_kernel<false>, dim3(l.skin_blocks, B), dim3(kSkinBlock), 0, s,
                        g_verts, g_joints, (const int32_t*)m->joint_map, (const float*)m->Jrx, (const int32_t*)m->extra_ids, v_posed,
                        m->N3p, A, (const float*)m->weights, (const float*)m->weights_t, (const int32_t*)m->skin_joint,
-                       (const float*)m->skin_weight, m->V, g_vposed, gA_part);
+                       (const float*)m->skin_weight, m->V, g_vposed, gA_part, (const long long*)g_verts_fixed);
     {
         const int groups = B <= 16 ? 1 : B <= 32 ? 2 : 4;       // (the matrix cores work on whole 16-body groups: a batch of 8 = one)
         auto* kernel = groups == 1 ? blend_bwd_kernel<1> : groups == 2 ? blend_bwd_kernel<2> : blend_bwd_kernel<4>;
@@ -1274,13 +1283,14 @@ extern "C" int tuch_smpl_backward_split_add(const tuch_smpl_model* m, const floa
                                             const void* fwd_workspace, const float* g_verts, const float* g_joints,
                                             float* g_betas, float* g_global_orient, int g_global_orient_stride,
                                             float* g_body_pose, int g_body_pose_stride, const float* g_body_pose_add,
-                                            int g_body_pose_add_stride, void* workspace, size_t workspace_bytes, void* stream)
+                                            int g_body_pose_add_stride, void* workspace, size_t workspace_bytes, void* stream,
+                                            const void* g_verts_fixed)
 {
     PoseAdam none;
     memset(&none, 0, sizeof(none));
     return backward_impl(m, global_orient, global_orient_stride, body_pose, body_pose_stride, pose2rot, B, fwd_workspace,
                          g_verts, g_joints, g_betas, g_global_orient, g_global_orient_stride, g_body_pose, g_body_pose_stride,
-                         g_body_pose_add, g_body_pose_add_stride, none, workspace, workspace_bytes, stream);
+                         g_body_pose_add, g_body_pose_add_stride, none, workspace, workspace_bytes, stream, g_verts_fixed);
 }
 
 // tuch_smpl_backward_split_add + torch.optim.Adam's update (tuch_adam_step's arithmetic) of the two pose tensors THEMSELVES,
@@ -1300,7 +1310,7 @@ extern "C" int tuch_smpl_backward_split_adam(const tuch_smpl_model* m, const flo
                                              int param_body_pose_stride, float* exp_avg_global_orient, float* exp_avg_sq_global_orient,
                                              float* exp_avg_body_pose, float* exp_avg_sq_body_pose, float* step, int* ticket,
                                              float lr, float beta1, float beta2, float eps,
-                                             void* workspace, size_t workspace_bytes, void* stream)
+                                             void* workspace, size_t workspace_bytes, void* stream, const void* g_verts_fixed)
 {
     TUCH_REQUIRE(param_global_orient && param_body_pose && exp_avg_global_orient && exp_avg_sq_global_orient && exp_avg_body_pose &&
                  exp_avg_sq_body_pose && step && ticket, "tuch_smpl_backward_split_adam: null pointer");
@@ -1310,7 +1320,7 @@ extern "C" int tuch_smpl_backward_split_adam(const tuch_smpl_model* m, const flo
                         lr, eps, beta1, beta2};
     return backward_impl(m, global_orient, global_orient_stride, body_pose, body_pose_stride, 1, B, fwd_workspace,
                          g_verts, g_joints, g_betas, g_global_orient, g_global_orient_stride, g_body_pose, g_body_pose_stride,
-                         g_body_pose_add, g_body_pose_add_stride, adam, workspace, workspace_bytes, stream);
+                         g_body_pose_add, g_body_pose_add_stride, adam, workspace, workspace_bytes, stream, g_verts_fixed);
 }
 
 // pose / g_pose: [B,72] or [B,24,3,3], the concatenated form.

@@ -85,6 +85,7 @@ class _SmplLBS(torch.autograd.Function):
         ctx.pose_ref = weakref.ref(body_pose) if ctx.needs_input_grad[2] else None
         ctx.orient_ref = weakref.ref(global_orient) if ctx.needs_input_grad[1] else None
         ctx.pose_grad_extra = None
+        ctx.verts_grad_fixed = None   # set by ops._Stage2Tail.backward (deterministic mode): (fixed-point vertex gradient, pass id)
         ctx.root_pass = None          # set by ops._Stage2Tail.backward: the id of a backward pass whose ROOT is that node
         ctx.save_for_backward(go, bp, ws)
         return verts, joints
@@ -109,7 +110,7 @@ class _SmplLBS(torch.autograd.Function):
                                                     int(ctx.pose2rot), b, _C.ptr(ws), _C.ptr(gv), _C.ptr(gj),
                                                     _C.ptr(g_betas), _C.row_ptr(g_full[:, :w]), 24 * w,
                                                     _C.row_ptr(g_full[:, w:]), 24 * w, None, 23 * w,
-                                                    _C.ptr(ws2), nbytes, _C.stream()))
+                                                    _C.ptr(ws2), nbytes, _C.stream(), None))
             return g_betas, None, None, None, None, g_full
         g_go = torch.empty(go.shape, dtype=torch.float32, device=go.device)
         g_bp = torch.empty(bp.shape, dtype=torch.float32, device=go.device)
@@ -119,6 +120,10 @@ class _SmplLBS(torch.autograd.Function):
         task = int(f()) if f is not None else -1
         if tagged is not None and task >= 0 and task == tagged[1]:          # left by a node of THIS backward pass
             extra = tagged[0].to(torch.float32).reshape(b, 23 * w).contiguous()
+        # the stage-2 tail's vertex gradient as 64-bit fixed-point sums (deterministic mode, ops._Stage2Tail): read by the
+        # skinning adjoint itself, added to g_verts (zeros from that node, plus whatever else flows into the vertices)
+        tagged_fixed, ctx.verts_grad_fixed = ctx.verts_grad_fixed, None
+        fixed = tagged_fixed[0] if tagged_fixed is not None and task >= 0 and task == tagged_fixed[1] else None
         # Adam inside the last backward kernel (optim.Adam(fuse_backward=True)): only when this pass's root is the stage-2
         # objective node, which has routed the prior's gradient here -- then what this call computes IS the whole gradient
         # of the two pose tensors
@@ -146,13 +151,13 @@ class _SmplLBS(torch.autograd.Function):
                 _C.ptr(go_t), go_t.stride(0), _C.ptr(bp_t), bp_t.stride(0), _C.ptr(st_go['exp_avg']), _C.ptr(st_go['exp_avg_sq']),
                 _C.ptr(st_bp['exp_avg']), _C.ptr(st_bp['exp_avg_sq']), _C.ptr(adam.step_count), _C.ptr(adam._ticket),
                 float(group['lr']), float(group['betas'][0]), float(group['betas'][1]), float(group['eps']),
-                _C.ptr(ws2), nbytes, _C.stream()))
+                _C.ptr(ws2), nbytes, _C.stream(), _C.ptr(fixed)))
             adam._applied = True
             return g_betas, g_go.view(ctx.shapes[0]), g_bp.view(ctx.shapes[1]), None, None, None
         _C.check(L.tuch_smpl_backward_split_add(ctx.dm._handle, _C.row_ptr(go), go.stride(0), _C.row_ptr(bp), bp.stride(0),
                                                 int(ctx.pose2rot), b, _C.ptr(ws), _C.ptr(gv), _C.ptr(gj),
                                                 _C.ptr(g_betas), _C.ptr(g_go), w, _C.ptr(g_bp), 23 * w,
-                                                _C.ptr(extra), 23 * w, _C.ptr(ws2), nbytes, _C.stream()))
+                                                _C.ptr(extra), 23 * w, _C.ptr(ws2), nbytes, _C.stream(), _C.ptr(fixed)))
         return g_betas, g_go.view(ctx.shapes[0]), g_bp.view(ctx.shapes[1]), None, None, None
 
 

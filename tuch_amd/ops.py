@@ -611,12 +611,17 @@ class _Stage2Tail(torch.autograd.Function):
         # same launch that forms the sums (csrc/contact_terms.hip: stage2_fused_kernel); backward() only hands it over
         want_grad = any(ctx.needs_input_grad[:4])
         gv = _extra[6] if want_grad else None
+        # deterministic mode: the vertex gradient stays in its 64-bit fixed-point accumulators (no conversion launch here);
+        # backward() hands them to the body model's node, whose skinning adjoint reads them -- or converts them if the pass
+        # is not the plain `objective.backward()` of a fit.  gv (zeros nobody writes in this mode) is what autograd carries.
+        fixed = _extra[1] if want_grad else None
         _C.check(L.tuch_smplify_stage2_fused(_C.ptr(v), _C.ptr(partner), _C.ptr(exterior), _C.ptr(valid), b, v.shape[1],
                                              MODE_SMPLIFY, float(const['euclthres']), _C.ptr(small), None, None, p,
                                              float(const['contact_scale']), float(const['r2r_scale']), _C.ptr(share),
-                                             _C.ptr(_extra[7]), None, _C.ptr(out), _C.ptr(gv),
+                                             _C.ptr(_extra[7]), None, _C.ptr(out), _C.ptr(gv) if fixed is None else None,
                                              model._handle if p else None, _C.ptr(_extra[0]),
-                                             _C.ptr(_extra[1]) if want_grad else None, _C.stream()))
+                                             _C.ptr(fixed), _C.stream()))
+        ctx.fixed = fixed
         if want_grad:
             ctx.save_for_backward(gv, gj, gc, gp)
         ctx.in_dtypes = (verts.dtype, joints.dtype, camera_t.dtype, body_pose.dtype)
@@ -624,6 +629,8 @@ class _Stage2Tail(torch.autograd.Function):
         # vertex gradient) and can add the prior's pose gradient inside its own last kernel (lbs._SmplLBS: pose_grad_extra)
         # instead of autograd summing two gradients in a launch of its own
         node = verts.grad_fn
+        # (somebody who retains / hooks the vertices' own gradient must see the real numbers, not the carrier of zeros)
+        ctx.verts_unwatched = not verts.retains_grad and not getattr(verts, '_backward_hooks', None)
         ref = getattr(node, 'pose_ref', None) if node is not None else None
         ctx.lbs_node = node if (want_grad and ctx.needs_input_grad[0] and ctx.needs_input_grad[3] and ref is not None
                                 and ref() is body_pose) else None
@@ -637,6 +644,14 @@ class _Stage2Tail(torch.autograd.Function):
         # loss.backward() through ops.backward_scalar seeds the graph with a cached tensor of ones: recognised by its
         # address (no device round trip).  Any other upstream gradient scales the unit gradients.
         unit = any(g.data_ptr() == seed.data_ptr() for seed in _ONES.values())
+        fixed, ctx.fixed = ctx.fixed, None
+        hand_over = (fixed is not None and unit and ctx.lbs_node is not None and _graph_task_id() >= 0
+                     and is_root_of_backward_scalar(ctx) and ctx.verts_unwatched)
+        if fixed is not None and not hand_over:
+            # anything but the plain backward of a fit (a scaled upstream gradient, a gradient asked for the vertices
+            # themselves, a loss with further terms): the float gradient, by a conversion launch
+            gv = torch.empty_like(gv)
+            _C.check(_C.lib().tuch_fixed_to_float(_C.ptr(fixed), fixed.numel(), _C.ptr(gv), _C.stream()))
         if not unit:
             g = g.reshape(()).to(torch.float32)
             gv, gj, gc, gp = gv * g, gj * g, gc * g, gp * g
@@ -648,6 +663,8 @@ class _Stage2Tail(torch.autograd.Function):
             # tagged with THIS backward pass: the body model's node takes it only within the same pass (a gradient left by
             # a pass that never reached that node must not leak into a later one)
             ctx.lbs_node.pose_grad_extra = (gp, _graph_task_id())
+            if hand_over:
+                ctx.lbs_node.verts_grad_fixed = (fixed, _graph_task_id())
             # this node is the ROOT of the pass (see above): every gradient of the fit's parameters flows through what it
             # returns -- the body model's node may then apply the optimiser's update itself (lbs.py)
             ctx.lbs_node.root_pass = _graph_task_id() if root else None
