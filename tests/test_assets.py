@@ -79,15 +79,23 @@ def test_hd_regressor_with_more_than_three_non_zeros_per_row(tmp_path):
     np.add.at(back, (np.repeat(np.arange(n), 5), idx.ravel()), w.ravel())
     assert np.array_equal(back, dense)
     assert ((w != 0).sum(1) == 1 + np.arange(n) % 5).all() and (idx >= 0).all() and (idx < v).all()
-    # negligible leftovers (below 1e-7 of the row's largest weight: a float32 row sum cannot see them) neither widen K for
-    # every row nor make the file fail to load; what was dropped is reported
+    # EXACT as long as the rows fit: tiny leftovers are non-zeros like any other (the reference multiplies the dense matrix)
     noisy = dense.copy()
-    free = np.flatnonzero(noisy[7] == 0)[:12]
+    free = np.flatnonzero(noisy[7] == 0)[:4]
+    noisy[7, free] = 1e-12
+    idx2, w2, dropped = assets.sparse_rows(noisy, return_dropped=True)
+    assert dropped == 0.0 and idx2.shape[1] == 7                    # row 7: 3 weights + 4 leftovers
+    back = np.zeros_like(noisy)
+    np.add.at(back, (np.repeat(np.arange(n), 7), idx2.ravel()), w2.ravel())
+    assert np.array_equal(back, noisy)
+    # only a row that does NOT fit is thinned (entries below 1e-7 of the row's largest weight: a float32 row sum cannot see
+    # them), with a warning, and what was dropped is returned
+    free = np.flatnonzero(noisy[7] == 0)[:8]
     noisy[7, free] = 1e-12
     with pytest.warns(UserWarning):
-        idx2, w2 = assets.sparse_rows(noisy)
-    assert np.array_equal(idx2, idx) and np.array_equal(w2, w)
-    assert 0 < assets.sparse_rows.last_dropped <= 12.1e-12
+        idx3, w3, dropped = assets.sparse_rows(noisy, return_dropped=True)
+    assert np.array_equal(idx3, idx) and np.array_equal(w3, w)
+    assert 0 < dropped <= 12.1e-12
     dense[0, rng.choice(v, 9, replace=False)] = 0.1
     with pytest.raises(ValueError):
         assets.sparse_rows(dense)

@@ -68,32 +68,33 @@ def load_contact_regions(dsc_root: str = None) -> Dict[str, object]:
     return {'classes': classes, 'csig': csig}
 
 
-def sparse_rows(dense: np.ndarray, max_nnz: int = 8, negligible: float = 1e-7) -> Tuple[np.ndarray, np.ndarray]:
+def sparse_rows(dense: np.ndarray, max_nnz: int = 8, negligible: float = 1e-7, return_dropped: bool = False):
     """Dense regressor [N,V] -> (ids [N,K], weights [N,K]) with K = the largest number of non-zeros in a row (at least 3:
     barycentric samples; rows with fewer are padded with weight 0).  The reference multiplies the dense matrix
-    (loss.py:285); the device tables hold its non-zeros -- a row with more than ``max_nnz`` of them is refused.
-    Entries below ``negligible`` x the row's largest magnitude do not count (a float32 sum of the row cannot see them: one
-    row with a handful of 1e-12 leftovers would otherwise widen K for ALL rows, or make the file fail to load); what they
-    add up to is kept in ``sparse_rows.last_dropped`` (largest absolute row sum of dropped entries) and warned about."""
+    (loss.py:285); the device tables hold its non-zeros -- EVERY non-zero, whatever its size, as long as no row has more
+    than ``max_nnz`` of them.  Only a matrix that does not fit is thinned: entries below ``negligible`` x their row's largest
+    magnitude are then dropped (a float32 sum of the row cannot see them), with a warning; a row that still has more than
+    ``max_nnz`` is refused.  return_dropped: also the largest absolute row sum of dropped entries (0.0: exact)."""
     mag = np.abs(dense)
-    keep = mag > negligible * mag.max(1, keepdims=True)
+    keep = mag > 0
     nnz = int(keep.sum(1).max()) if dense.size else 0
+    dropped = 0.0
     if nnz > max_nnz:
-        raise ValueError('HD regressor rows have up to %d non-zeros (at most %d are supported)' % (nnz, max_nnz))
-    dropped = float(np.where(keep, 0, mag).sum(1).max()) if dense.size else 0.0
-    sparse_rows.last_dropped = dropped
-    if dropped > 0:
+        keep = mag > negligible * mag.max(1, keepdims=True)
+        nnz = int(keep.sum(1).max())
+        if nnz > max_nnz:
+            raise ValueError('HD regressor rows have up to %d non-zeros (at most %d are supported)' % (nnz, max_nnz))
+        dropped = float(np.where(keep, 0, mag).sum(1).max())
         import warnings
-        warnings.warn('HD regressor: entries below %g of their row maximum dropped (largest row sum of them: %.3g)'
-                      % (negligible, dropped))
+        warnings.warn('HD regressor: rows with more than %d non-zeros -- entries below %g of their row maximum dropped '
+                      '(largest row sum of them: %.3g)' % (max_nnz, negligible, dropped))
     k = max(nnz, 3)
     idx = np.argsort(-np.where(keep, mag, 0), axis=1, kind='stable')[:, :k]
     wgt = np.where(np.take_along_axis(keep, idx, 1), np.take_along_axis(dense, idx, 1), 0).astype(np.float32)
     idx = np.where(wgt != 0, idx, idx[:, :1])               # padding: weight 0, a valid id
+    if return_dropped:
+        return idx.astype(np.int64), wgt, dropped
     return idx.astype(np.int64), wgt
-
-
-sparse_rows.last_dropped = 0.0
 
 
 def load_hd_regressor(hd_model_dir: str = None) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:

@@ -140,7 +140,13 @@ class _SmplLBS(torch.autograd.Function):
                 adam = None
         if adam is not None and adam._applied:
             # a second backward pass before step() / zero_grad(): the first pass has already moved the parameters; applying
-            # another update here would be a second optimiser step nobody asked for -- this pass only returns gradients
+            # another update here would be a second optimiser step nobody asked for -- this pass only returns gradients.
+            # (Gradient ACCUMULATION over several backward passes is not what fuse_backward can do: the first pass has stepped
+            # with its own gradient alone; torch.optim.Adam would step once with the sum.)
+            import warnings
+            warnings.warn('tuch_amd.optim.Adam(fuse_backward=True): a second backward pass before step() -- the parameters '
+                          'were already updated with the first pass\'s gradient; use fuse_backward=False to accumulate '
+                          'gradients over several passes', RuntimeWarning, stacklevel=2)
             adam = None
         if adam is not None:
             group = adam.param_groups[0]
