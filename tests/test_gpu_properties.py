@@ -302,3 +302,79 @@ def test_headline_batch64_step_reproduces_bit_for_bit_by_default(headline):
     for x, y, what in zip(a, b, ('loss of the last step', 'body pose after the steps', 'posed vertices')):
         assert torch.equal(x, y), what
     assert float((a[1] - p['body_pose']).abs().max()) > 1e-3          # the steps did move the parameters
+
+
+def test_headline_batch64_capped_search_gives_the_same_fit_and_the_same_partners_where_they_count(headline):
+    """Round 6: in SMPLify-DC's stage 2 the nearest-vertex search of the vertices the previous iteration found OUTSIDE the body
+    starts at the loss's cap (euclthres: an exterior vertex contributes only within it, tuch/smplify/losses.py:99-104) and the
+    vertices this iteration's inside test finds inside after all are searched again exhaustively (ops.ContactModel.
+    exterior_and_partner(cap=...), option v2v_cap).  (1) Ten iterations of the bench's own step with and without it: the
+    same loss and the same parameters, BIT FOR BIT (deterministic gradient sums).  (2) On moving bodies, call after call:
+    flags identical, and for every vertex that is inside or has a partner within the cap the capped call returns the plain
+    call's (min_d2, partner); for the others min_d2 = cap^2 and the partner is an admissible vertex farther than the cap."""
+    import bench
+    from helpers import report
+    from tuch_amd import ops
+    from tuch_amd.smplify.losses import contact_model_for
+    p, verts = headline
+    model = contact_model_for(p['geomask'], p['face_tensor'], p['segments'], p['cdict'])
+    model.set_option('v2v_cap', 1)                   # (off by default: measured, exact, not faster -- csrc/model.h)
+    assert model.v2v_can_cap(64)
+
+    def fit(cap):
+        model.set_option('v2v_cap', cap)
+        with ops.off_default_stream(DEV):
+            step = bench.make_step(p)
+            losses = []
+            for _ in range(10):
+                losses.append(step()[0].clone())
+            torch.cuda.synchronize()
+            return torch.stack(losses), step.objective()[3]
+    try:
+        la, pa = fit(1)
+        lb, pb = fit(0)
+    finally:
+        model.set_option('v2v_cap', 1)
+    assert torch.equal(la, lb) and torch.equal(pa, pb)
+    try:
+        _capped_outputs(model, p, verts, report)
+    finally:
+        model.set_option('v2v_cap', 0)
+
+
+def _capped_outputs(model, p, verts, report):
+    from tuch_amd import ops
+    # (2) the raw outputs on bodies that move between calls (what the hints and the predicted flags are for)
+    cap = 1.001 * 0.02 + 1e-6
+    gm = p['body'].geodesics > 0.3
+    rng = np.random.default_rng(3)
+    drift = torch.tensor(rng.standard_normal((64, 1, 3)).astype(np.float32) * 0.0, device=verts.device)
+    wobble = torch.tensor(rng.standard_normal(tuple(verts.shape)).astype(np.float32), device=verts.device)
+    capped_cols = fixed_cols = 0
+    for it in range(4):
+        v = (verts + 0.002 * it * wobble + drift).contiguous()
+        with ops.off_default_stream(DEV):
+            ext_c, mn_c, arg_c, _ = model.exterior_and_partner(v, apply_segments=True, iterative=True, cap=cap)
+            ext_p, mn_p, arg_p, _ = model.exterior_and_partner(v, apply_segments=True, iterative=True)
+        torch.cuda.synchronize()
+        assert torch.equal(ext_c, ext_p)
+        body_inside = model.exterior_flags(v, apply_segments=False) == 0
+        # what the loss looks at: the vertices that are inside (final flags) or have a partner within the cap
+        counts = ((ext_c == 0) | (mn_p < cap * cap))
+        assert torch.equal(mn_c[counts], mn_p[counts]) and torch.equal(arg_c[counts], arg_p[counts])
+        rest = ~counts
+        # the others: either searched without a cap (predicted inside; every vertex in the first call) -> the plain result,
+        cut = rest & (mn_c == np.float32(cap) * np.float32(cap))
+        plain = rest & ~cut
+        assert torch.equal(mn_c[plain], mn_p[plain]) and torch.equal(arg_c[plain], arg_p[plain])
+        # or cut off at the cap: the partner is a real admissible vertex farther than the cap
+        d2 = ((v - torch.gather(v, 1, arg_c.long()[..., None].expand(-1, -1, 3))) ** 2).sum(-1)
+        assert bool((d2[cut] >= np.float32(cap) ** 2 * (1 - 1e-5)).all())
+        gm_t = torch.tensor(gm, device=v.device)
+        idx = torch.arange(v.shape[1], device=v.device)[None].expand(64, -1)
+        assert bool(gm_t[idx[cut], arg_c.long()[cut]].all())
+        capped_cols += int(cut.sum())
+        fixed_cols += int((body_inside & ~(mn_p < cap * cap)).sum())
+    report('capped search: vertices cut off at the cap (4 calls x 64 bodies)', capped_cols, 4 * 64 * verts.shape[1])
+    report('capped search: inside vertices beyond the cap (searched without one / again)', fixed_cols, 4 * 64 * verts.shape[1])
+    assert capped_cols > 0.5 * 3 * 64 * verts.shape[1]

@@ -482,7 +482,7 @@ struct OptionName { const char* name; int tuch_options::*field; };
 const OptionName kOptions[] = {
     {"winding_ray", &tuch_options::winding_ray}, {"winding_tree", &tuch_options::winding_tree},
     {"winding_strips", &tuch_options::winding_strips}, {"tree_waves", &tuch_options::tree_waves},
-    {"ray_pair_cap", &tuch_options::ray_pair_cap}, {"ray_waves", &tuch_options::ray_waves}, {"ray_fans", &tuch_options::ray_fans}, {"ray_cross", &tuch_options::ray_cross}, {"ray_cross_split", &tuch_options::ray_cross_split},
+    {"ray_pair_cap", &tuch_options::ray_pair_cap}, {"ray_waves", &tuch_options::ray_waves}, {"ray_fans", &tuch_options::ray_fans}, {"ray_cross", &tuch_options::ray_cross}, {"v2v_cap", &tuch_options::v2v_cap}, {"ray_cross_split", &tuch_options::ray_cross_split},
     {"v2v_tree", &tuch_options::v2v_tree}, {"v2v_flat", &tuch_options::v2v_flat}, {"v2v_pairs", &tuch_options::v2v_pairs}, {"v2v_waves", &tuch_options::v2v_waves}, {"v2v_lds", &tuch_options::v2v_lds},
     {"seg_splits", &tuch_options::seg_splits}, {"seg_assist", &tuch_options::seg_assist}, {"seg_fused", &tuch_options::seg_fused},
     {"canary", &tuch_options::canary}, {"hd_search", &tuch_options::hd_search}, {"hd_search_waves", &tuch_options::hd_search_waves}, {"hd_overlap", &tuch_options::hd_overlap},

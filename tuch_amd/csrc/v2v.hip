@@ -888,7 +888,8 @@ __global__ __launch_bounds__(kBoundsBlock) void v2v_rows_seed_kernel(
     const int32_t* __restrict__ height_off, const int32_t* __restrict__ height_nodes, int N, float* __restrict__ prow,
     float* __restrict__ bounds, float* __restrict__ leafbox, const int32_t* __restrict__ leaf_group, float* __restrict__ prow_g,
     int G, int row_blocks, const uint64_t* __restrict__ bits, const int32_t* __restrict__ hint, uint64_t* __restrict__ keys,
-    float* __restrict__ colbox, uint4* __restrict__ zero, size_t zero_n16)
+    float* __restrict__ colbox, uint4* __restrict__ zero, size_t zero_n16,
+    const uint8_t* __restrict__ prev_exterior, float cap2)      // capped search (tuch_v2v_min_model_capped), or nullptr
 {
     // a buffer the CALLER wants cleared before the kernels it enqueues behind this call run (SMPLify-DC stage 2: the vertex
     // gradient the tail scatters into, its arrival counter, the region pairs' keys -- a fill launch of 5 us in front of them
@@ -919,6 +920,10 @@ __global__ __launch_bounds__(kBoundsBlock) void v2v_rows_seed_kernel(
         const float dx = px - vb[3 * vj], dy = py - vb[3 * vj + 1], dz = pz - vb[3 * vj + 2];
         best = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
         arg = j;
+        // a column the previous call found OUTSIDE the body only matters to the caller if its partner is within the cap:
+        // its bound starts at the cap (key = (cap^2, the hint): "nothing closer found" is recognisable, and the hint stays a
+        // real admissible row).  Columns without an admissible hint, and those predicted inside, search without a cap.
+        if (prev_exterior && i0 < V && prev_exterior[(size_t)b * V + v0] != 0) best = fminf(best, cap2);
     }
     keys[(size_t)b * Vp + i0] = v2v_key(best, arg);
     // box of the block's columns, rows behind the last vertex left out
@@ -1312,6 +1317,92 @@ __global__ __launch_bounds__(kBlock) void v2v_tree_finalize_kernel(
     if (out_arg) out_arg[(size_t)b * V + v] = d < __builtin_inff() ? qperm[(uint32_t)k] : 0;
 }
 
+// The second half of the capped search: columns whose key still is (cap^2, hint) -- nothing within the cap -- and that the
+// inside test has meanwhile found INSIDE the body need their exact partner after all (their term has no cap).  One wavefront per
+// block of 64 columns; such a column is searched by all 64 lanes over ALL rows (the same d^2 expression and the same (d^2, row)
+// order as the scan: the exact result, whatever the scan would have pruned).  Few columns per call in an iterative fit (the
+// vertices that crossed the surface since the previous iteration); any number is handled, only slower.  Also records this
+// call's flags as the next call's prediction.
+constexpr int kFixWaves = 4;
+__global__ __launch_bounds__(64 * kFixWaves) void v2v_fix_kernel(
+    const float* __restrict__ prow, int V, int Vp, const uint64_t* __restrict__ bits, const int32_t* __restrict__ qperm,
+    const uint8_t* __restrict__ exterior, uint8_t* __restrict__ prev_exterior, float cap2, uint64_t* __restrict__ keys,
+    float* __restrict__ out_min, int32_t* __restrict__ out_arg, int32_t* __restrict__ hint)
+{
+    // every wavefront of the workgroup holds the block's 64 columns; a column to search is shared by ROWS: wavefront w takes
+    // the w-th quarter, four rows per lane and trip (eight independent loads in flight), the quarters' minima meet in LDS
+    __shared__ uint64_t part[kFixWaves][64];
+    __shared__ unsigned long long s_todo;
+    const int qb = blockIdx.x, b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = qb * kTreeCols + lane;
+    const bool real = i0 < V;
+    // ONE wavefront reads the flags and decides which columns are searched: the segment filter may be re-marking `exterior`
+    // while this kernel runs (either value is fine -- a vertex it re-marks needs no partner beyond the cap), and wavefronts
+    // that read different values must not disagree about the columns they share
+    int v = 0;
+    bool need = false;
+    if (wave == 0) {
+        v = qperm[real ? i0 : V - 1];
+        const uint8_t ext = real ? exterior[(size_t)b * V + v] : (uint8_t)1;
+        const uint64_t k0 = keys[(size_t)b * Vp + i0];
+        need = real && ext == 0 && (uint32_t)(k0 >> 32) == __float_as_uint(cap2);
+        const unsigned long long any = __builtin_amdgcn_ballot_w64(need);
+        if (lane == 0) s_todo = any;
+        if (real) prev_exterior[(size_t)b * V + v] = ext;
+    }
+    __syncthreads();
+    unsigned long long todo = s_todo;
+    if (!todo) return;
+    const float* pb = prow + (size_t)b * Vp * 3;
+    const uint64_t* mrow = bits + (size_t)qb * V;
+    const int per = (V + kFixWaves - 1) / kFixWaves, beg = wave * per, end = min(beg + per, V);
+    uint64_t mine = ~0ull;
+    while (todo) {
+        const int c = (int)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        const float* pc = pb + 3 * (size_t)(qb * kTreeCols + c);
+        const float px = pc[0], py = pc[1], pz = pc[2];
+        uint64_t best = ~0ull;
+        for (int j0 = beg + lane; j0 < end; j0 += 256) {
+            uint64_t mw[4];
+            float r[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = min(j0 + 64 * u, end - 1);
+                mw[u] = mrow[j];
+                r[u][0] = pb[3 * j]; r[u][1] = pb[3 * j + 1]; r[u][2] = pb[3 * j + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + 64 * u;
+                const float dx = px - r[u][0], dy = py - r[u][1], dz = pz - r[u][2];
+                const uint64_t key = v2v_key(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)), j);
+                const bool ok = j < end && ((mw[u] >> c) & 1ull);
+                best = ok && key < best ? key : best;
+            }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const uint64_t o = ((uint64_t)(uint32_t)__shfl_xor((int)(best >> 32), m) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)best, m);
+            best = o < best ? o : best;
+        }
+        if (lane == c) mine = best;
+    }
+    part[wave][lane] = mine;
+    __syncthreads();
+    if (wave == 0 && need) {
+        uint64_t k = part[0][lane];
+#pragma unroll
+        for (int w = 1; w < kFixWaves; ++w) k = part[w][lane] < k ? part[w][lane] : k;
+        const bool found = k != ~0ull;
+        const float d = found ? __uint_as_float((uint32_t)(k >> 32)) : __builtin_inff();
+        keys[(size_t)b * Vp + i0] = found ? k : v2v_key(__builtin_inff(), 0);
+        if (hint) hint[(size_t)b * Vp + i0] = found ? (int)(uint32_t)k : -1;
+        if (out_min) out_min[(size_t)b * V + v] = d;
+        if (out_arg) out_arg[(size_t)b * V + v] = found ? qperm[(uint32_t)k] : 0;
+    }
+}
+
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct TreeV2VLayout { size_t prow, bounds, keys, leafbox, colbox, prow_g, total; };
@@ -1458,9 +1549,54 @@ extern "C" int tuch_v2v_min_model(const tuch_contact_model* m, const float* vert
 
 // zero / zero_bytes (multiple of 16, or NULL / 0): a caller buffer cleared by this call's FIRST kernel -- on the stream, before
 // anything enqueued behind the call (no fill launch of the caller's own).
+static int v2v_min_model_impl(const tuch_contact_model* m, const float* verts, int B, float* min_d2,
+                              int32_t* argmin, void* hint_inout, void* workspace, size_t workspace_bytes,
+                              int leave_room, void* zero, size_t zero_bytes, void* stream, const uint8_t* prev_exterior, float cap);
+
 extern "C" int tuch_v2v_min_model_shared_zero(const tuch_contact_model* m, const float* verts, int B, float* min_d2,
                                               int32_t* argmin, void* hint_inout, void* workspace, size_t workspace_bytes,
                                               int leave_room, void* zero, size_t zero_bytes, void* stream)
+{
+    return v2v_min_model_impl(m, verts, B, min_d2, argmin, hint_inout, workspace, workspace_bytes, leave_room, zero, zero_bytes,
+                              stream, nullptr, 0.0f);
+}
+
+// can this model's search run capped?  (the leaf scan seeded from hints: what the cap rides on)
+extern "C" int tuch_v2v_min_model_can_cap(const tuch_contact_model* m)
+{
+    return m && m->mask_bits && use_v2v_tree(m) && flat_mode(m) >= 2 && m->opt.v2v_cap != 0 ? 1 : 0;
+}
+
+extern "C" int tuch_v2v_min_model_capped(const tuch_contact_model* m, const float* verts, int B, float* min_d2,
+                                         int32_t* argmin, void* hint_inout, void* workspace, size_t workspace_bytes,
+                                         int leave_room, void* zero, size_t zero_bytes, const uint8_t* prev_exterior, float cap,
+                                         void* stream)
+{
+    TUCH_REQUIRE(prev_exterior && hint_inout && cap >= 0.0f, "tuch_v2v_min_model_capped: needs hints, the previous flags and a cap >= 0");
+    TUCH_REQUIRE(tuch_v2v_min_model_can_cap(m), "tuch_v2v_min_model_capped: this model's search cannot be capped");
+    return v2v_min_model_impl(m, verts, B, min_d2, argmin, hint_inout, workspace, workspace_bytes, leave_room, zero, zero_bytes,
+                              stream, prev_exterior, cap);
+}
+
+extern "C" int tuch_v2v_min_model_fix(const tuch_contact_model* m, int B, const uint8_t* exterior, uint8_t* prev_exterior,
+                                      float cap, float* min_d2, int32_t* argmin, void* hint_inout, void* workspace,
+                                      size_t workspace_bytes, void* stream)
+{
+    TUCH_REQUIRE(m && exterior && prev_exterior && workspace, "tuch_v2v_min_model_fix: null pointer");
+    TUCH_REQUIRE(tuch_v2v_min_model_can_cap(m) && B > 0 && B <= 65535, "tuch_v2v_min_model_fix: bad arguments");
+    const TreeV2VLayout l = tree_v2v_layout(m, B);
+    TUCH_REQUIRE(workspace_bytes >= l.total, "tuch_v2v_min_model_fix: not the workspace of the capped call");
+    char* ws = (char*)workspace;
+    const int Vp = m->tree_qblocks * 2 * kTreeCols;
+    hipLaunchKernelGGL(v2v_fix_kernel, dim3(2 * m->tree_qblocks, B), dim3(64 * kFixWaves), 0, (hipStream_t)stream, (const float*)(ws + l.prow), m->V, Vp,
+                       (const uint64_t*)m->tree_mask_bits, (const int32_t*)m->tree_qperm, exterior, prev_exterior, cap * cap,
+                       (uint64_t*)(ws + l.keys), min_d2, argmin, (int32_t*)hint_inout);
+    return tuch_check_launch("tuch_v2v_min_model_fix");
+}
+
+static int v2v_min_model_impl(const tuch_contact_model* m, const float* verts, int B, float* min_d2,
+                              int32_t* argmin, void* hint_inout, void* workspace, size_t workspace_bytes,
+                              int leave_room, void* zero, size_t zero_bytes, void* stream, const uint8_t* prev_exterior, float cap)
 {
     TUCH_REQUIRE(m && verts && (min_d2 || argmin), "tuch_v2v_min_model: null pointer");
     TUCH_REQUIRE(m->mask_bits, "tuch_v2v_min_model: the model has no geodesic mask");
@@ -1500,7 +1636,7 @@ extern "C" int tuch_v2v_min_model_shared_zero(const tuch_contact_model* m, const
                            (const int32_t*)m->tree_leaf_group, scan >= 2 ? (float*)(ws + l.prow_g) : (float*)nullptr,
                            m->tree_groups, row_blocks, (const uint64_t*)m->tree_mask_bits, (const int32_t*)hint_inout, keys,
                            colbox, (uint4*)(fused_zero ? zero : nullptr),
-                           fused_zero ? zero_bytes / 16 : (size_t)0);
+                           fused_zero ? zero_bytes / 16 : (size_t)0, prev_exterior, cap * cap);
     } else {
     hipLaunchKernelGGL(v2v_rows_kernel, dim3(row_blocks, B), dim3(kBoundsBlock), 0, s,
                        verts, V, Vp, (const int32_t*)m->tree_qperm, (const int32_t*)m->tree_rows,

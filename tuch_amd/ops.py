@@ -602,9 +602,12 @@ class _Stage2Tail(torch.autograd.Function):
                 _C.ptr(precisions), _C.ptr(logw), b, nj, means.shape[0], float(const['focal']), float(const['sigma']),
                 float(const['prior_scale']), _C.ptr(small), _C.ptr(gj), _C.ptr(gc), _C.ptr(gp), _C.stream()))
             return (keys, fixed, small, gj, gc, gp, zeros[:n].view(v.shape), zeros[n:n + 1].view(torch.int32))
+        # (cap: the contact term of losses.py:96-105 looks at the partner of an exterior vertex only within euclthres; 0.1 % more,
+        # because the term recomputes the distance with its own rounding)
         exterior, _, partner, _extra = model.exterior_and_partner(v, apply_segments=const['apply_segments'],
                                                                   also=beside_the_walk, zero_floats=k0 + 2 * b * p + det,
-                                                                  iterative=True)       # SMPLify-DC's stage-2 loop
+                                                                  iterative=True,       # SMPLify-DC's stage-2 loop
+                                                                  cap=1.001 * max(float(const['euclthres']), 0.0) + 1e-6)
         out = torch.empty(1, dtype=torch.float32, device=v.device)
         share = torch.empty(L.tuch_smplify_stage2_fused_scratch_floats(b), dtype=torch.float32, device=v.device)
         # the objective is the root of the fit's graph: its vertex gradient for a unit upstream gradient is written by the
@@ -781,6 +784,7 @@ class ContactModel:
         faces = np.asarray(faces.detach().cpu() if isinstance(faces, torch.Tensor) else faces)
         self.faces_np = faces.astype(np.int64)
         self._hints = {}
+        self._prev_flags = {}
         self.num_verts = int(faces.max()) + 1
         self.num_faces = int(faces.shape[0])
         gm = None
@@ -912,8 +916,12 @@ class ContactModel:
                                              sign.ctypes.data_as(ctypes.c_void_p)))
         return vidx, sign, k.value
 
+    def _exterior_flags_stage(self, verts, ext, ws, nbytes, apply_segments, thresh, stage):
+        _C.check(_C.lib().tuch_exterior_flags_stage(self._handle, _C.ptr(verts), verts.shape[0], int(apply_segments), float(thresh),
+                                                    _C.ptr(ext), _C.ptr(ws), nbytes, int(stage), _C.stream()))
+
     def exterior_and_partner(self, verts: torch.Tensor, apply_segments: bool = True, also=None, zero_floats: int = 0,
-                             iterative: bool = False):
+                             iterative: bool = False, cap: Optional[float] = None):
         """exterior_flags + v2v_min of the same vertices -> (exterior, min_d2, partner[, also()]).
         The two only share their input: the nearest-vertex search (and the optional callable ``also``,
         e.g. the region pairs) runs on a second stream so that its tail fills the gaps of the long winding
@@ -921,20 +929,55 @@ class ContactModel:
         zero_floats > 0: a float32 buffer of (at least) that many ZEROS is handed to ``also(buffer)`` -- cleared by the
         search's first kernel (tuch_v2v_min_model_shared_zero), not by a fill launch.
         iterative: the caller is an iterative fit (the previous call's partners, kept as hints, are almost this call's):
-        the search then uses fewer, longer wavefronts (see v2v_min).  Results never depend on it."""
+        the search then uses fewer, longer wavefronts (see v2v_min).  Results never depend on it.
+        cap: the caller only needs the partners of vertices that are INSIDE the body or have one within ``cap`` (the SMPLify-DC
+        contact term, tuch/smplify/losses.py:96-105, with cap >= euclthres): the search of the vertices the previous call found
+        outside starts at the cap (a third of the work at the bench's batch), and the few that this call's inside test finds
+        inside after all are searched again, exhaustively, beside the segment filter (v2v_fix).  For every other vertex min_d2
+        is cap^2 and the partner some admissible vertex farther than cap.  Exact for what the caller uses; see
+        include/tuch_amd.h: tuch_v2v_min_model_capped."""
         zero = None
         if zero_floats > 0:
             zero = torch.empty((int(zero_floats) + 3) // 4 * 4, dtype=torch.float32, device=verts.device)
             call_also = (lambda: also(zero)) if also is not None else None
         else:
             call_also = also
+        capped = cap is not None and verts.is_cuda and self.v2v_can_cap(verts.shape[0])
         if not (verts.is_cuda and self._py_options['overlap']):
             exterior = self.exterior_flags(verts, apply_segments=apply_segments)
-            mn, partner = self.v2v_min(verts, zero=zero, iterative=iterative)
+            if capped:
+                mn, partner, state = self.v2v_min(verts, zero=zero, iterative=iterative, cap=cap)
+                self.v2v_fix(exterior, mn, partner, state)
+            else:
+                mn, partner = self.v2v_min(verts, zero=zero, iterative=iterative)
             return exterior, mn, partner, (call_also() if call_also is not None else None)
         cur = torch.cuda.current_stream(verts.device)
         side = _side_stream(verts.device)
         side.wait_stream(cur)
+        if capped:
+            v = _f32(verts)
+            with torch.cuda.stream(side):
+                if zero is not None:
+                    zero.record_stream(side)
+                mn, partner, state = self.v2v_min(v, leave_room=True, zero=zero, iterative=iterative, cap=cap)
+                extra = call_also() if call_also is not None else None
+            L = _C.lib()
+            exterior = torch.empty(v.shape[0], self.num_verts, dtype=torch.uint8, device=v.device)
+            nbytes = L.tuch_exterior_workspace_bytes(self._handle, v.shape[0])
+            ws = _workspace(nbytes, v.device)
+            self._exterior_flags_stage(v, exterior, ws, nbytes, apply_segments, 0.99, 1)      # the body's inside test
+            body_done = torch.cuda.Event()
+            body_done.record(cur)
+            with torch.cuda.stream(side):
+                side.wait_event(body_done)
+                exterior.record_stream(side)
+                self.v2v_fix(exterior, mn, partner, state)                                    # beside the segment filter
+            self._exterior_flags_stage(v, exterior, ws, nbytes, apply_segments, 0.99, 2)
+            cur.wait_stream(side)
+            for t in (mn, partner, state[0]) + (tuple(extra) if isinstance(extra, (tuple, list)) else (extra,)):
+                if torch.is_tensor(t):
+                    t.record_stream(cur)
+            return exterior, mn, partner, extra
         first = self._py_options.get('inside_first', 0)
         if first:
             # the inside test's chain FIRST (the side stream waits only for what was enqueued before its wait above).
@@ -1004,7 +1047,8 @@ class ContactModel:
         return (ext, w, seg_w, seg_e) if return_details else ext
 
     # K1
-    def v2v_min(self, verts: torch.Tensor, leave_room: bool = False, zero: Optional[torch.Tensor] = None, iterative: bool = False):
+    def v2v_min(self, verts: torch.Tensor, leave_room: bool = False, zero: Optional[torch.Tensor] = None, iterative: bool = False,
+                cap: Optional[float] = None):
         """leave_room: other kernels run beside the search on another stream (tuch_v2v_min_model_shared).
         iterative: the hints are expected to be near-final (SMPLify-DC's loops): a quarter of the wavefronts, each over more
         leaves -- faster with good bounds (0.412 against 0.426 ms per stage-2 step at batch 64), slower on new bodies.
@@ -1019,10 +1063,38 @@ class ContactModel:
         arg = torch.empty(b, self.num_verts, dtype=torch.int32, device=verts.device)
         nbytes = L.tuch_v2v_model_workspace_bytes(self._handle, b)
         ws = _workspace(nbytes, verts.device)
+        flags = int(bool(leave_room)) | (2 if iterative else 0)
+        zbytes = zero.numel() * zero.element_size() if zero is not None else 0
+        if cap is not None:
+            # the capped form (see v2v_capped): the caller finishes it with v2v_fix(...) on the returned state
+            prev = self._v2v_prev(b)
+            _C.check(L.tuch_v2v_min_model_capped(self._handle, _C.ptr(verts), b, _C.ptr(mn), _C.ptr(arg), _C.ptr(self._v2v_hint(b)),
+                                                 _C.ptr(ws), nbytes, flags, _C.ptr(zero), zbytes, _C.ptr(prev), float(cap), _C.stream()))
+            return mn, arg, (ws, nbytes, prev, float(cap))
         _C.check(L.tuch_v2v_min_model_shared_zero(self._handle, _C.ptr(verts), b, _C.ptr(mn), _C.ptr(arg),
-                                                  _C.ptr(self._v2v_hint(b)), _C.ptr(ws), nbytes, int(bool(leave_room)) | (2 if iterative else 0), _C.ptr(zero),
-                                                  zero.numel() * zero.element_size() if zero is not None else 0, _C.stream()))
+                                                  _C.ptr(self._v2v_hint(b)), _C.ptr(ws), nbytes, flags, _C.ptr(zero), zbytes, _C.stream()))
         return mn, arg
+
+    def v2v_can_cap(self, batch: int) -> bool:
+        """Can the search of this model run capped (tuch_v2v_min_model_capped: the leaf scan with hints, option v2v_cap)?"""
+        return bool(self.has_mask and _C.lib().tuch_v2v_min_model_can_cap(self._handle)) and self._v2v_hint(batch) is not None
+
+    def v2v_fix(self, exterior: torch.Tensor, mn: torch.Tensor, arg: torch.Tensor, state) -> None:
+        """Second half of a capped search: the vertices that were cut off at the cap and that ``exterior`` [B,V] u8 (this
+        call's inside test; the segment filter may still be re-marking it) shows inside are searched exhaustively; mn / arg
+        are corrected in place, the flags become the next call's prediction."""
+        ws, nbytes, prev, cap = state
+        b = exterior.shape[0]
+        _C.check(_C.lib().tuch_v2v_min_model_fix(self._handle, b, _C.ptr(exterior), _C.ptr(prev), cap, _C.ptr(mn), _C.ptr(arg),
+                                                 _C.ptr(self._v2v_hint(b)), _C.ptr(ws), nbytes, _C.stream()))
+
+    def _v2v_prev(self, batch: int) -> torch.Tensor:
+        """Persistent per-batch-size flags of the previous capped call ([B,V] u8, 1 = outside the body; zeros at first:
+        nothing is capped).  A prediction only -- results never depend on it."""
+        buf = self._prev_flags.get(batch)
+        if buf is None:
+            buf = self._prev_flags[batch] = torch.zeros(batch, self.num_verts, dtype=torch.uint8, device=self.device)
+        return buf
 
     def _v2v_hint(self, batch: int) -> Optional[torch.Tensor]:
         """Persistent per-batch-size buffer in which the search leaves its partners for the next call (an iterative
