@@ -1237,7 +1237,8 @@ def main():
             torch.distributed.init_process_group(backend)
 
     def reduce(local_stats):
-        if isinstance(local_stats, tuple):               # (loss sum, bodies) as two 0-d tensors
+        fresh = isinstance(local_stats, tuple)
+        if fresh:                                        # (loss sum, bodies) as two 0-d tensors -> one new [2] tensor
             local_stats = torch.stack([t.to(torch.float32).reshape(()) for t in local_stats])
         if os.environ.get('TUCH_BENCH_DEBUG'):
             print('rank', rank, 'local stats', local_stats.tolist(), flush=True)
@@ -1246,7 +1247,8 @@ def main():
                 host = local_stats.cpu()
                 torch.distributed.all_reduce(host)
                 return host.to(local_stats.device)
-            local_stats = local_stats.clone()
+            if not fresh:                                # (never the step's own output buffer: a replayed graph rewrites it)
+                local_stats = local_stats.clone()
             torch.distributed.all_reduce(local_stats)    # 2 floats over RCCL / xGMI
         return local_stats
 
