@@ -316,7 +316,7 @@ int tuch_v2v_min_model_shared_zero(const tuch_contact_model* model, const float*
  * keeps them current; zeros at first: nothing capped).  A vertex with prev_exterior != 0 and an admissible hint starts its
  * search at cap^2: found closer -> exact; else min_d2 = cap^2 and argmin = its hint (a real admissible vertex, farther than
  * cap).  tuch_v2v_min_model_fix -- called with the SAME workspace once the inside test's flags `exterior` of THIS iteration
- * exist (the segment filter may still be re-marking vertices exterior: either value is fine) -- searches the columns again
+ * exist -- searches the columns again
  * that were cut off at the cap and are inside now (exhaustively: the exact result), and stores the flags as the next
  * prediction.  Together: exact (min_d2, argmin) for every vertex that is inside or has a partner within cap; cap must be
  * >= the loss's threshold (callers add 0.1 %: the loss recomputes the distance with its own rounding).
@@ -360,11 +360,6 @@ size_t tuch_exterior_workspace_bytes(const tuch_contact_model* model, int B);
 int tuch_exterior_flags(const tuch_contact_model* model, const float* verts, int B, int apply_segments,
                         float thresh, float* w, uint8_t* exterior, float* seg_w, uint8_t* seg_exterior,
                         void* workspace, size_t workspace_bytes, void* stream);
-/* The flags-only form in two stages (same arguments and workspace in both), for a caller that puts work of another stream
- * between them: stage 1 = the body's inside test (`exterior` = w <= thresh for every vertex), stage 2 = the segment filter
- * re-marking the vertices that are inside their own segment only (tuch/smplify/losses.py:85-89). */
-int tuch_exterior_flags_stage(const tuch_contact_model* model, const float* verts, int B, int apply_segments, float thresh,
-                              uint8_t* exterior, void* workspace, size_t workspace_bytes, int stage, void* stream);
 
 /* Winding numbers of arbitrary points against the model's mesh posed by `verts`, loss.py:295-297
  * (HD points offset along the face normals).  points [B,Q,3] (padded); counts [B] device ints or

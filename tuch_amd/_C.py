@@ -106,7 +106,6 @@ _SIGNATURES = {
     'tuch_v2v_min_model_shared_zero': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int,
                                                c_void_p, c_size_t, c_void_p]),
     'tuch_exterior_workspace_bytes': (c_size_t, [c_void_p, c_int]),
-    'tuch_exterior_flags_stage': (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     'tuch_v2v_min_model_can_cap': (c_int, [c_void_p]),
     'tuch_v2v_min_model_capped': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int,
                                           c_void_p, c_size_t, c_void_p, c_float, c_void_p]),

@@ -45,7 +45,7 @@ struct tuch_options {
     int ray_cross_split = 0;    // ray_cross_kernel: wavefronts that share a leaf's query blocks (0: 4 up to batch 8, 2 up to 32, else 1)
     int v2v_tree = 1;           // 0: flat nearest-vertex search
     int v2v_waves = 0;          // frontier choice of the search (wavefronts aimed at; 0: the form's own default)
-    int v2v_cap = 0;            // SMPLify-DC stage 2: 1 the search of vertices the previous iteration found outside the body starts at the loss's cap (euclthres) and the few that turn out inside are searched again beside the segment filter (tuch_v2v_min_model_capped / _fix, round 6).  Exact (bit-identical fits, tests/test_gpu_properties.py) and the search itself drops from 171 to 81 us inside the step at batch 64 -- but the step does not: 0.428 against 0.410 ms (batch 8: 0.205 against 0.176).  The inside test's chain is the critical path either way (its crossing kernel gains 16 us), the second half costs a cross-stream hand-over in the middle of that chain (2 x 10 us of dependency latency) and a kernel of 27 - 47 us beside the segment filter.  Off.
+    int v2v_cap = 0;            // SMPLify-DC stage 2: 1 the search of vertices the previous iteration found outside the body starts at the loss's cap (euclthres) and the few that turn out inside are searched again behind the inside test (tuch_v2v_min_model_capped / _fix, round 6).  Exact (bit-identical fits, tests/test_gpu_properties.py); the search itself drops from 171 to 81 us inside the step at batch 64, the step does not move (0.405 against 0.415 ms, within the blocks' spread; batch 8: 0.183 against 0.177): the inside test's chain is the critical path either way, and the second pass is one more dependent launch on it.  Off.
     int v2v_flat = 2;           // search: 2 lanes over a subtree's leaves first (v2v_scan_kernel), 0 the stackless walk (v2v_tree_kernel)
     int v2v_pairs = 24;         // scan: a leaf in reach of FEWER columns of the wavefront than this is not walked row by row for all 64 lanes; its (leaf, column) pairs are queued and evaluated one per lane (round 5); 0: every leaf row by row (round 4)
     int v2v_lds = -1;           // search beside the inside test: -1 capped at 7 wavefronts per SIMD by register count (-4 / -5 / -6: at that many; round 4, lighter scan: 7 0.487, 6 0.494, 5 0.512, 4 0.530 ms per step), > 0 by an LDS allocation of that many bytes per workgroup (6400: round 2), 0 uncapped

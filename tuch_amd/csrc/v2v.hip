@@ -1336,9 +1336,9 @@ __global__ __launch_bounds__(64 * kFixWaves) void v2v_fix_kernel(
     const int qb = blockIdx.x, b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i0 = qb * kTreeCols + lane;
     const bool real = i0 < V;
-    // ONE wavefront reads the flags and decides which columns are searched: the segment filter may be re-marking `exterior`
-    // while this kernel runs (either value is fine -- a vertex it re-marks needs no partner beyond the cap), and wavefronts
-    // that read different values must not disagree about the columns they share
+    // ONE wavefront reads the flags and decides which columns are searched (a caller may run this kernel beside the segment
+    // filter, which re-marks `exterior` -- either value is fine: a vertex it re-marks needs no partner beyond the cap --, and
+    // wavefronts that read different values must not disagree about the columns they share)
     int v = 0;
     bool need = false;
     if (wave == 0) {

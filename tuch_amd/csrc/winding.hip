@@ -978,35 +978,10 @@ extern "C" size_t tuch_exterior_workspace_bytes(const tuch_contact_model* m, int
 // exterior flags of tuch/smplify/losses.py:81-89 and tuch/train/loss.py:260-266:
 //   exterior = winding_numbers(verts, verts[faces]).le(thresh), then every vertex that is
 //   interior to its own closed body segment is re-marked exterior.
-static int exterior_flags_impl(const tuch_contact_model* m, const float* verts, int B, int apply_segments, float thresh, float* w,
-                               uint8_t* exterior, float* seg_w, uint8_t* seg_exterior, void* workspace, size_t workspace_bytes,
-                               void* stream, int stage);
-
 extern "C" int tuch_exterior_flags(const tuch_contact_model* m, const float* verts, int B,
                                    int apply_segments, float thresh, float* w, uint8_t* exterior,
                                    float* seg_w, uint8_t* seg_exterior,
                                    void* workspace, size_t workspace_bytes, void* stream)
-{
-    return exterior_flags_impl(m, verts, B, apply_segments, thresh, w, exterior, seg_w, seg_exterior, workspace, workspace_bytes,
-                               stream, 0);
-}
-
-// The flags-only call in two stages, for a caller that enqueues something on ANOTHER stream between them (ops.ContactModel.
-// exterior_and_partner: the second half of the capped search waits for stage 1 and runs beside stage 2).  stage 1: the body's
-// inside test -- `exterior` holds w <= thresh for every vertex when it is done; stage 2 (same arguments, same workspace): the
-// segment filter re-marks the vertices that are inside their own segment only.  Models whose segment filter is not the single
-// launch behind the body test do everything in stage 1; stage 2 is then empty.
-extern "C" int tuch_exterior_flags_stage(const tuch_contact_model* m, const float* verts, int B, int apply_segments, float thresh,
-                                         uint8_t* exterior, void* workspace, size_t workspace_bytes, int stage, void* stream)
-{
-    TUCH_REQUIRE(stage == 1 || stage == 2, "tuch_exterior_flags_stage: stage must be 1 or 2");
-    return exterior_flags_impl(m, verts, B, apply_segments, thresh, nullptr, exterior, nullptr, nullptr, workspace, workspace_bytes,
-                               stream, stage);
-}
-
-static int exterior_flags_impl(const tuch_contact_model* m, const float* verts, int B, int apply_segments, float thresh, float* w,
-                               uint8_t* exterior, float* seg_w, uint8_t* seg_exterior, void* workspace, size_t workspace_bytes,
-                               void* stream, int stage)
 {
     TUCH_REQUIRE(m && verts && exterior, "tuch_exterior_flags: null pointer");
     TUCH_REQUIRE(B > 0 && B <= 65535, "tuch_exterior_flags: bad batch %d", B);
@@ -1029,11 +1004,6 @@ static int exterior_flags_impl(const tuch_contact_model* m, const float* verts, 
     // flags only, by rays, leaf-assisted: the whole segment filter is one launch behind the body test (ray_winding.hip)
     const bool segments_fused = segments && segments_by_rays && body_by_rays && !seg_w && !seg_exterior &&
                                 tuch_ray_segment_fused_available(m);
-    if (stage == 2) {
-        if (!segments_fused) return TUCH_OK;            // (stage 1 has done everything)
-        return tuch_ray_segment_flags_one(m, verts, (const uint8_t*)(ws + l.body_flags), tuch_ray_segment_counts(m, B, ws + l.ray), B,
-                                          thresh, exterior, s);
-    }
     if (segments && !segments_fused) {
         // what the segment pass needs of the vertices alone goes first, off the critical chain behind the body test
         if (m->num_caps > 0) {
@@ -1076,7 +1046,6 @@ static int exterior_flags_impl(const tuch_contact_model* m, const float* verts, 
                                   l.bounds - l.partial, stream);
         if (rc != TUCH_OK) return rc;
     }
-    if (segments_fused && stage == 1) return tuch_check_launch("tuch_exterior_flags");
     if (segments_fused) {
         rc = tuch_ray_segment_flags_one(m, verts, (const uint8_t*)(ws + l.body_flags), tuch_ray_segment_counts(m, B, ws + l.ray), B, thresh,
                                         exterior, s);

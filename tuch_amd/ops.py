@@ -916,10 +916,6 @@ class ContactModel:
                                              sign.ctypes.data_as(ctypes.c_void_p)))
         return vidx, sign, k.value
 
-    def _exterior_flags_stage(self, verts, ext, ws, nbytes, apply_segments, thresh, stage):
-        _C.check(_C.lib().tuch_exterior_flags_stage(self._handle, _C.ptr(verts), verts.shape[0], int(apply_segments), float(thresh),
-                                                    _C.ptr(ext), _C.ptr(ws), nbytes, int(stage), _C.stream()))
-
     def exterior_and_partner(self, verts: torch.Tensor, apply_segments: bool = True, also=None, zero_floats: int = 0,
                              iterative: bool = False, cap: Optional[float] = None):
         """exterior_flags + v2v_min of the same vertices -> (exterior, min_d2, partner[, also()]).
@@ -956,27 +952,17 @@ class ContactModel:
         side.wait_stream(cur)
         if capped:
             v = _f32(verts)
+            exterior = self.exterior_flags(v, apply_segments=apply_segments)     # (the inside test's chain first, as below)
             with torch.cuda.stream(side):
                 if zero is not None:
                     zero.record_stream(side)
                 mn, partner, state = self.v2v_min(v, leave_room=True, zero=zero, iterative=iterative, cap=cap)
                 extra = call_also() if call_also is not None else None
-            L = _C.lib()
-            exterior = torch.empty(v.shape[0], self.num_verts, dtype=torch.uint8, device=v.device)
-            nbytes = L.tuch_exterior_workspace_bytes(self._handle, v.shape[0])
-            ws = _workspace(nbytes, v.device)
-            self._exterior_flags_stage(v, exterior, ws, nbytes, apply_segments, 0.99, 1)      # the body's inside test
-            body_done = torch.cuda.Event()
-            body_done.record(cur)
-            with torch.cuda.stream(side):
-                side.wait_event(body_done)
-                exterior.record_stream(side)
-                self.v2v_fix(exterior, mn, partner, state)                                    # beside the segment filter
-            self._exterior_flags_stage(v, exterior, ws, nbytes, apply_segments, 0.99, 2)
             cur.wait_stream(side)
             for t in (mn, partner, state[0]) + (tuple(extra) if isinstance(extra, (tuple, list)) else (extra,)):
                 if torch.is_tensor(t):
                     t.record_stream(cur)
+            self.v2v_fix(exterior, mn, partner, state)       # behind both: the final flags, the capped search's keys
             return exterior, mn, partner, extra
         first = self._py_options.get('inside_first', 0)
         if first:
