@@ -205,5 +205,13 @@ def row_ptr(t) -> c_void_p:
     return c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_cur_device = getattr(torch._C, '_cuda_getDevice', None)
+
+
 def stream() -> c_void_p:
+    """The current stream of the current device as a hipStream_t.  (torch.cuda.current_stream() builds a Python Stream
+    object through several device-index helpers: ~9 us a call, nine calls per eager step.)"""
+    if _raw_stream is not None and _cur_device is not None:
+        return c_void_p(_raw_stream(_cur_device()))
     return c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -27,13 +27,31 @@ def _f32(t: torch.Tensor) -> torch.Tensor:
 _SIDE_STREAMS = {}
 
 
+_STREAM_OBJECTS = {}
+
+
+def _current_stream(device) -> 'torch.cuda.Stream':
+    """torch.cuda.current_stream(device) without building a new Stream object through torch's device-index helpers on
+    every call (~9 us, several times per eager step): one object per (device, raw stream handle) is kept."""
+    raw, cur = _C._raw_stream, _C._cur_device
+    if raw is None or cur is None:
+        return torch.cuda.current_stream(device)
+    index = device.index if device.index is not None else cur()
+    key = (index, raw(index))
+    s = _STREAM_OBJECTS.get(key)
+    if s is None:
+        s = _STREAM_OBJECTS[key] = torch.cuda.current_stream(device)
+    return s
+
+
 def _side_stream(device) -> 'torch.cuda.Stream':
     """The companion stream of the CURRENT stream (one per stream: callers that run several fits on streams of
     their own must not be coupled through a shared side stream)."""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
-    return _SIDE_STREAMS[key]
+    key = (device.type, device.index, _current_stream(device).cuda_stream)
+    s = _SIDE_STREAMS.get(key)
+    if s is None:
+        s = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return s
 
 
 _GRAPH_STREAMS = {}
@@ -480,7 +498,7 @@ def _ticket(device) -> torch.Tensor:
     ordered against each other (and would live in the pool of whichever graph happened to be captured first)."""
     if device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
         return torch.zeros(1, dtype=torch.int32, device=device)
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, _current_stream(device).cuda_stream)
     t = _TICKETS.get(key)
     if t is None:
         t = _TICKETS[key] = torch.zeros(1, dtype=torch.int32, device=device)
@@ -947,7 +965,7 @@ class ContactModel:
             else:
                 mn, partner = self.v2v_min(verts, zero=zero, iterative=iterative)
             return exterior, mn, partner, (call_also() if call_also is not None else None)
-        cur = torch.cuda.current_stream(verts.device)
+        cur = _current_stream(verts.device)
         side = _side_stream(verts.device)
         side.wait_stream(cur)
         if capped:
