@@ -46,6 +46,14 @@ int tuch_batch_pairwise_dist(const float* x, const float* y, int B, int Nx, int 
 int tuch_batch_pairwise_dist_bwd(const float* x, const float* y, const float* grad_P, int B, int Nx, int Ny,
                                  int squared, float* grad_x, float* grad_y, void* stream);
 
+/* Adjoint of solid_angles / winding_numbers for callers that differentiate through them (plain torch ops in the reference,
+ * contact.py:79-109,147; the reference itself only calls them under torch.no_grad()).  grad_out [B,Q,F] (adjoint of
+ * tuch_solid_angles) or grad_w [B,Q] (of tuch_winding_numbers), exactly one; grad_points [B,Q,3] and / or grad_triangles
+ * [B,F,3,3] (either may be NULL).  torch's conventions at the singular points: d|a|/da = 0 at a = 0, NaN where the query sits
+ * on a corner (atan2 at (0,0)).  Fixed summation order. */
+int tuch_solid_angles_bwd(const float* points, const float* triangles, const float* grad_out, const float* grad_w,
+                          int B, int Q, int F, float* grad_points, float* grad_triangles, void* stream);
+
 /* solid_angles(points, triangles, thresh), contact.py:49-109.
  * points [B,Q,3], triangles [B,F,3,3] -> out [B,Q,F] = 2*atan2(num, den). */
 int tuch_solid_angles(const float* points, const float* triangles, int B, int Q, int F, float* out,

@@ -90,6 +90,32 @@ def pairwise_adjoint(x: np.ndarray, y: np.ndarray, g: np.ndarray, squared: bool 
     return gx.astype(np.float32), gy.astype(np.float32)
 
 
+def solid_angle_adjoint(points: np.ndarray, tris: np.ndarray, g: np.ndarray):
+    """What torch autograd returns through tuch/utils/contact.py:79-109 for one batch element: points [Q,3], tris [F,3,3],
+    g [Q,F] = dL/dOmega -> (dL/dpoints [Q,3], dL/dtris [F,3,3]).  Omega = 2 atan2(num, den), num = a.(b x c),
+    den = |a||b||c| + (a.b)|c| + (a.c)|b| + (b.c)|a| with a, b, c = corners - point (:80-100).  float64."""
+    p = np.asarray(points, np.float64)[:, None, None, :]
+    t = np.asarray(tris, np.float64)[None]
+    c = t - p                                            # [Q,F,3,3]
+    a, b, cc = c[:, :, 0], c[:, :, 1], c[:, :, 2]
+    la, lb, lc = (np.linalg.norm(x, axis=-1) for x in (a, b, cc))
+    bc, ca, ab = np.cross(b, cc), np.cross(cc, a), np.cross(a, b)
+    num = (a * bc).sum(-1)
+    dab, dac, dbc = (a * b).sum(-1), (a * cc).sum(-1), (b * cc).sum(-1)
+    den = la * lb * lc + dab * lc + dac * lb + dbc * la
+    k = 2.0 * np.asarray(g, np.float64) / (num * num + den * den)
+    unit = lambda x, l: x / np.where(l > 0, l, 1.0)[..., None] * (l > 0)[..., None]
+    da = unit(a, la) * (lb * lc + dbc)[..., None] + b * lc[..., None] + cc * lb[..., None]
+    db = unit(b, lb) * (la * lc + dac)[..., None] + a * lc[..., None] + cc * la[..., None]
+    dc = unit(cc, lc) * (la * lb + dab)[..., None] + a * lb[..., None] + b * la[..., None]
+    ga = k[..., None] * (den[..., None] * bc - num[..., None] * da)
+    gb = k[..., None] * (den[..., None] * ca - num[..., None] * db)
+    gc = k[..., None] * (den[..., None] * ab - num[..., None] * dc)
+    gt = np.stack([ga.sum(0), gb.sum(0), gc.sum(0)], 1)
+    gp = -(ga + gb + gc).sum(1)
+    return gp.astype(np.float32), gt.astype(np.float32)
+
+
 def v2v_min_masked(verts: np.ndarray, geomask: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
     """tuch/smplify/losses.py:92-93, tuch/train/loss.py:269-270 -> (min_d2[V], argmin[V])."""
     verts = _c32(verts)

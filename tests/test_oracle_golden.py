@@ -37,6 +37,19 @@ def test_pairwise_adjoint_vs_reference_autograd():
             assert_close(gy, g['gy_' + tag][b], 1e-5, 2e-5, 'grad y ' + tag)
 
 
+def test_solid_angle_adjoint_vs_reference_autograd():
+    """tests/golden/make_golden_solid_angle_grad.py: torch autograd through the reference's contact.py:49-147."""
+    g = gio.load('solid_angle_grad.npz')
+    for b in range(g['points'].shape[0]):
+        gp, gt = oc.solid_angle_adjoint(g['points'][b], g['triangles'][b], g['G'][b])
+        assert_close(gp, g['sa_grad_points'][b], 1e-4, 2e-4 * np.abs(g['sa_grad_points']).max(), 'd solid angles / d points')
+        assert_close(gt, g['sa_grad_triangles'][b], 1e-4, 2e-4 * np.abs(g['sa_grad_triangles']).max(), 'd solid angles / d triangles')
+        gw = np.repeat(g['gw'][b][:, None], g['triangles'].shape[1], 1) / (4 * np.pi)
+        gp, gt = oc.solid_angle_adjoint(g['points'][b], g['triangles'][b], gw)
+        assert_close(gp, g['w_grad_points'][b], 1e-4, 2e-4 * np.abs(g['w_grad_points']).max(), 'd winding / d points')
+        assert_close(gt, g['w_grad_triangles'][b], 1e-4, 2e-4 * np.abs(g['w_grad_triangles']).max(), 'd winding / d triangles')
+
+
 @pytest.mark.parametrize('tag', TAGS + FULL)
 def test_v2v_min_masked(tag):
     g, gm = golden(tag), golden_mask(tag)

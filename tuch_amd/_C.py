@@ -23,6 +23,7 @@ _SIGNATURES = {
     'tuch_batch_pairwise_dist': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'tuch_batch_pairwise_dist_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                              c_void_p]),
+    'tuch_solid_angles_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'tuch_solid_angles': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'tuch_gather_triangles': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'tuch_winding_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),

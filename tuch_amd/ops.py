@@ -200,22 +200,32 @@ def _winding_numbers_raw(points: torch.Tensor, triangles: torch.Tensor, thresh: 
     return (w, ext.bool()) if thresh is not None else w
 
 
-class _NoGradient(torch.autograd.Function):
-    """Forward-only kernels behind autograd: the value is returned attached to the graph, and a backward pass that
-    reaches it raises instead of handing back a silent zero.  Every call site of the reference runs these two under
-    torch.no_grad() or on detached inputs (smplify/losses.py:79-82, train/loss.py:251-261,287-297, eft/loss.py:145-148,
-    utils/segmentation.py:97 inside them), where this node is never built."""
+class _SolidAngles(torch.autograd.Function):
+    """solid_angles / winding_numbers (tuch/utils/contact.py:49-147) with their gradient: plain differentiable torch ops in the
+    reference (which itself only calls them under torch.no_grad()), two adjoint kernels here (csrc/solid_angle_bwd.hip)."""
 
     @staticmethod
-    def forward(ctx, what, fn, points, triangles):
-        ctx.what = what
-        return fn(points, triangles)
+    def forward(ctx, points, triangles, winding):
+        pf, tf = _f32(points), _f32(triangles)
+        ctx.save_for_backward(pf, tf)
+        ctx.winding = bool(winding)
+        ctx.dtypes = (points.dtype, triangles.dtype)
+        return _winding_numbers_raw(pf, tf) if winding else _solid_angles_raw(pf, tf)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad_out):
-        raise NotImplementedError(
-            'tuch_amd: %s has no gradient kernel (the reference only calls it under torch.no_grad(), '
-            'tuch/smplify/losses.py:79-82); detach the inputs or wrap the call in torch.no_grad()' % ctx.what)
+        pf, tf = ctx.saved_tensors
+        b, q, _ = pf.shape
+        f = tf.shape[1]
+        g = grad_out.to(torch.float32).contiguous()
+        gp = torch.empty_like(pf) if ctx.needs_input_grad[0] else None
+        gt = torch.empty_like(tf) if ctx.needs_input_grad[1] else None
+        if gp is not None or gt is not None:
+            _C.check(_C.lib().tuch_solid_angles_bwd(_C.ptr(pf), _C.ptr(tf), None if ctx.winding else _C.ptr(g),
+                                                    _C.ptr(g) if ctx.winding else None, b, q, f, _C.ptr(gp), _C.ptr(gt),
+                                                    _C.stream()))
+        return (None if gp is None else gp.to(ctx.dtypes[0]), None if gt is None else gt.to(ctx.dtypes[1]), None)
 
 
 def _tracked(*tensors) -> bool:
@@ -224,14 +234,14 @@ def _tracked(*tensors) -> bool:
 
 def solid_angles(points: torch.Tensor, triangles: torch.Tensor) -> torch.Tensor:
     if _tracked(points, triangles):
-        return _NoGradient.apply('solid_angles', _solid_angles_raw, points, triangles)
+        return _SolidAngles.apply(points, triangles, False)
     return _solid_angles_raw(points, triangles)
 
 
 def winding_numbers(points: torch.Tensor, triangles: torch.Tensor, thresh: Optional[float] = None):
     """[B,Q,3], [B,F,3,3] -> w [B,Q] (and exterior = w <= thresh if thresh is given)."""
     if thresh is None and _tracked(points, triangles):
-        return _NoGradient.apply('winding_numbers', _winding_numbers_raw, points, triangles)
+        return _SolidAngles.apply(points, triangles, True)
     return _winding_numbers_raw(points, triangles, thresh)
 
 
