@@ -958,8 +958,8 @@ class ContactModel:
         the search then uses fewer, longer wavefronts (see v2v_min).  Results never depend on it.
         cap: the caller only needs the partners of vertices that are INSIDE the body or have one within ``cap`` (the SMPLify-DC
         contact term, tuch/smplify/losses.py:96-105, with cap >= euclthres): the search of the vertices the previous call found
-        outside starts at the cap (a third of the work at the bench's batch), and the few that this call's inside test finds
-        inside after all are searched again, exhaustively, beside the segment filter (v2v_fix).  For every other vertex min_d2
+        outside starts at the cap (half the search's time at the bench's batch; the step does not follow: option v2v_cap, off), and the few that this call's inside test finds
+        inside after all are searched again, exhaustively, behind the inside test (v2v_fix).  For every other vertex min_d2
         is cap^2 and the partner some admissible vertex farther than cap.  Exact for what the caller uses; see
         include/tuch_amd.h: tuch_v2v_min_model_capped."""
         zero = None
@@ -1097,7 +1097,7 @@ class ContactModel:
 
     def v2v_fix(self, exterior: torch.Tensor, mn: torch.Tensor, arg: torch.Tensor, state) -> None:
         """Second half of a capped search: the vertices that were cut off at the cap and that ``exterior`` [B,V] u8 (this
-        call's inside test; the segment filter may still be re-marking it) shows inside are searched exhaustively; mn / arg
+        call's inside test) shows inside are searched exhaustively; mn / arg
         are corrected in place, the flags become the next call's prediction."""
         ws, nbytes, prev, cap = state
         b = exterior.shape[0]
